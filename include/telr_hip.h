@@ -1,0 +1,188 @@
+/*
+ * telr_hip.h — C ABI of libtelrhip.so, the MI355X (gfx950) alignment engine that
+ * replaces the seven aligner subprocess call sites of bergmanlab/TELR.
+ *
+ * The reference has no FFI: its boundary is `subprocess` argv + a SAM/PAF text
+ * file.  Each entry point below cites the reference call site(s) it stands in
+ * for (paths relative to the reference checkout):
+ *
+ *   S1  ngmlr -r R -q Q -x {ont,pacbio} ...            src/telr/TELR_alignment.py:31-51
+ *   S2  minimap2 --cs --MD -Y -L -ax P R Q             src/telr/TELR_alignment.py:69-82
+ *   S3  minimap2 -t N -ax P -r2k CNS READS             src/telr/TELR_assembly.py:199-212
+ *   S4  minimap2 -cx P --secondary=no -v 0 SUBJ QRY    src/telr/TELR_te.py:68-78
+ *   S5  minimap2 -cx P CONTIG LIB -v 0 -t T            src/telr/TELR_te.py:119-132
+ *   S6  minimap2 -a -x P -v 0 SUBJ QRY                 src/telr/TELR_te.py:504-506
+ *   S7  minimap2 -cx asm10 -v 0 -N 10 REF FLANK        src/telr/TELR_liftover.py:253-266
+ *   D   samtools depth -aa -r chr:S-E  -> median       src/telr/TELR_te.py:870-884
+ *
+ * Conventions: every function returns 0 on success and a negative TELR_E_* code
+ * on failure (telr_strerror() gives the text).  An empty result is NOT an
+ * error (the reference treats an empty PAF as "locus not passed",
+ * TELR_te.py:79-81).  The caller owns every input buffer (host pointers, may be
+ * freed after the call returns); the library owns outputs until the matching
+ * telr_*_free().  Device buffers never escape.  No torch types, no C++ types.
+ */
+#ifndef TELR_HIP_H
+#define TELR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TELR_OK            0
+#define TELR_E_NODEVICE   -1   /* no HIP device / HIP runtime error at init  */
+#define TELR_E_HIP        -2   /* HIP runtime error (see telr_last_error)    */
+#define TELR_E_ARG        -3   /* invalid argument                           */
+#define TELR_E_RANGE      -4   /* input exceeds the engine's coordinate bits */
+#define TELR_E_NOMEM      -5
+
+/* ---- alignment record flags -------------------------------------------- */
+#define TELR_F_PRIMARY     0x1   /* parent == self                                  */
+#define TELR_F_SECONDARY   0x2   /* overlaps a better chain on the query (SAM 0x100) */
+#define TELR_F_SUPPL       0x4   /* primary chain that is not the best (SAM 0x800)   */
+#define TELR_F_REV         0x8   /* query aligned on the reverse strand              */
+
+/* ---- index options (minimap2 -k/-w/-H) ---------------------------------- */
+typedef struct telr_idx_opt {
+    int32_t k;            /* k-mer length, 4..28                                  */
+    int32_t w;            /* minimizer window, 1..255                             */
+    int32_t is_hpc;       /* homopolymer-compressed k-mers (map-pb)               */
+    int32_t bucket_bits;  /* 0 = choose from the number of distinct minimizers    */
+} telr_idx_opt;
+
+/* ---- mapping options (one struct for all seven call sites) --------------- */
+typedef struct telr_map_opt {
+    /* seeding */
+    float   mid_occ_frac;     /* -f   : fraction of most frequent minimizers ignored  */
+    int32_t min_mid_occ;      /* -U lo                                                 */
+    int32_t max_mid_occ;      /* -U hi                                                 */
+    /* chaining */
+    int32_t max_gap;          /* -g   : max reference/query distance between anchors   */
+    int32_t bw;               /* -r   : max diagonal difference between anchors        */
+    int32_t chain_lookback;   /* predecessors examined per anchor (multiple of 64)     */
+    int32_t min_cnt;          /* -n   : min anchors per chain                          */
+    int32_t min_chain_score;  /* -m                                                    */
+    int32_t chain_gap_q8;     /* gap penalty per diagonal-difference base, Q8 fixed    */
+    int32_t chain_skip_q8;    /* penalty per skipped base, Q8 fixed                    */
+    /* chain selection */
+    float   mask_level;       /* -M                                                    */
+    float   pri_ratio;        /* -p                                                    */
+    int32_t best_n;           /* -N                                                    */
+    int32_t secondary;        /* --secondary=yes|no                                    */
+    /* base-level alignment */
+    int32_t a, b;             /* -A -B                                                 */
+    int32_t q, e, q2, e2;     /* -O q,q2  -E e,e2                                      */
+    int32_t sc_ambi;          /* penalty against an ambiguous base                     */
+    int32_t zdrop;            /* -z                                                    */
+    int32_t min_dp_max;       /* -s                                                    */
+    int32_t min_ksw_len;      /* min gap-fill segment length                           */
+    int32_t ext_max;          /* max bases an end extension may consume on the query   */
+    int32_t ext_band;         /* half band width of end extensions                     */
+    int32_t flags;            /* TELR_MF_*                                             */
+} telr_map_opt;
+
+#define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */
+#define TELR_MF_PER_TARGET 0x2   /* select/rank chains separately for every target:
+                                    one call answers "QRY vs each of N subjects"
+                                    (S5: the TE library against every contig)        */
+
+/* ---- one alignment (PAF line / SAM record worth of numbers), 88 bytes ---- */
+typedef struct telr_aln {
+    int32_t  qid;        /* query index in the query set                          */
+    int32_t  tid;        /* target index in the index                             */
+    int32_t  qlen;
+    int32_t  qs, qe;     /* query interval on the FORWARD query strand, [qs,qe)   */
+    int32_t  tlen;
+    int32_t  ts, te;     /* target interval, [ts,te)                              */
+    int32_t  mlen;       /* matching bases (PAF col 10)                           */
+    int32_t  blen;       /* alignment block length (PAF col 11)                   */
+    int32_t  score;      /* chaining score   (s1)                                 */
+    int32_t  subsc;      /* best secondary chaining score (s2)                    */
+    int32_t  dp_score;   /* DP alignment score (AS)                               */
+    int32_t  cnt;        /* anchors on the chain (cm)                             */
+    int32_t  n_sub;      /* number of suboptimal chains                           */
+    int32_t  parent;     /* index (within this query's records) of the parent     */
+    int32_t  n_cigar;    /* number of CIGAR ops                                   */
+    int32_t  flags;      /* TELR_F_*                                              */
+    int64_t  cigar_off;  /* offset of the first op in the result's cigar array    */
+    int32_t  mapq;
+    int32_t  n_ambi;     /* reserved (0): ambiguous columns count as mismatches   */
+} telr_aln;
+
+/* CIGAR op encoding: len<<4 | op, op 0=M 1=I 2=D (BAM numbering) */
+
+typedef struct telr_ctx    telr_ctx;     /* one per process per device            */
+typedef struct telr_seqset telr_seqset;  /* 2-bit packed sequences resident in HBM */
+typedef struct telr_index  telr_index;   /* minimizer index resident in HBM        */
+typedef struct telr_result telr_result;  /* host-side alignment records + CIGARs   */
+
+/* ---- context ------------------------------------------------------------- */
+int  telr_init(int device, telr_ctx **out);
+void telr_destroy(telr_ctx *ctx);
+const char *telr_strerror(int code);
+const char *telr_last_error(const telr_ctx *ctx);   /* text of the last HIP error   */
+int  telr_device_name(const telr_ctx *ctx, char *buf, int buflen);
+
+/* ---- presets: the -x values the reference passes -------------------------- */
+/* name in {"map-ont","map-pb","asm10","ngmlr-ont","ngmlr-pacbio"}; returns TELR_E_ARG otherwise */
+int  telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo);
+
+/* ---- sequence sets --------------------------------------------------------- */
+/* n sequences given as one concatenated ASCII buffer; seq i = ascii[off[i] .. off[i]+len[i]).
+ * Packs to 2 bits/base + an ambiguity bitmask and uploads to HBM. */
+int  telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii,
+                        const int64_t *off, const int32_t *len, telr_seqset **out);
+void telr_seqset_free(telr_seqset *s);
+int64_t telr_seqset_bases(const telr_seqset *s);
+int32_t telr_seqset_count(const telr_seqset *s);
+
+/* ---- index (replaces "minimap2 ... REF" re-indexing REF on every call) ----- */
+int  telr_index_build(telr_ctx *ctx, const telr_seqset *targets, const telr_idx_opt *io,
+                      telr_index **out);
+void telr_index_free(telr_index *idx);
+/* number of minimizers / distinct minimizers, for reports */
+int  telr_index_stats(const telr_index *idx, int64_t *n_minimizers, int64_t *n_distinct);
+
+/* ---- mapping (S1,S2,S7: all queries vs all targets; S3,S4,S6: query i vs the
+ *      single target qtarget[i]; S5: TELR_MF_PER_TARGET) ------------------------
+ * qtarget may be NULL (every query sees every target) or hold one target id
+ * per query (-1 = all).  Blocking; internally stream-asynchronous. */
+int  telr_map(telr_ctx *ctx, const telr_index *idx, const telr_seqset *queries,
+              const int32_t *qtarget, const telr_map_opt *mo, telr_result **out);
+
+int64_t         telr_result_count(const telr_result *r);
+const telr_aln *telr_result_alns(const telr_result *r);     /* sorted by (qid, rank) */
+int64_t         telr_result_cigar_count(const telr_result *r);
+const uint32_t *telr_result_cigars(const telr_result *r);
+void            telr_result_free(telr_result *r);
+
+/* ---- fused "samtools depth -aa -r | median" (D) --------------------------------
+ * For n_iv intervals (target id, 0-based start, 0-based INCLUSIVE end — the
+ * reference feeds 0-based numbers into samtools' 1-based inclusive region
+ * string, TELR_te.py:870-884, so E-S+1 positions are read starting one base
+ * to the left; callers pass the positions they want counted) compute the
+ * per-base depth of the result's primary+supplementary records (secondary
+ * skipped, deletions not counted) and return the median as samtools+python
+ * `statistics.median` would (mean of the two middle values for even counts). */
+int  telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n_targets,
+                        const int32_t *target_len, int32_t n_iv, const int32_t *iv_tid,
+                        const int32_t *iv_start, const int32_t *iv_end, double *median_out);
+
+/* ---- timing of the last telr_map / telr_index_build call (HIP events on the
+ *      engine's own stream).  Stage names: telr_stage_name(i). ---------------- */
+#define TELR_N_STAGES 12
+int  telr_stage_ms(const telr_ctx *ctx, float *ms_out /* [TELR_N_STAGES] */);
+const char *telr_stage_name(int i);
+/* algorithmic work counters of the last telr_map call (SURVEY §8d terms) */
+typedef struct telr_counters {
+    int64_t query_bases, minimizers, probes, anchors, chains, dp_problems, dp_cells,
+            window_bases, cigar_ops, records;
+} telr_counters;
+int  telr_last_counters(const telr_ctx *ctx, telr_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TELR_HIP_H */

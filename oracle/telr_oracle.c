@@ -1,0 +1,865 @@
+/*
+ * telr_oracle.c — CPU restatement of the TELR alignment hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in telr_amd/ may import, link or call this
+ * file; it is used by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg as the checker for the HIP engine (telr_amd/csrc).
+ *
+ * PARITY STATUS: "parity unpinned" against the upstream binaries.  The
+ * arithmetic of this path lives in third-party tools that are absent from
+ * /root/reference and from this image: minimap2 2.22 (envs/telr.yml:45; call
+ * sites src/telr/TELR_alignment.py:69-82, TELR_assembly.py:199-212,
+ * TELR_te.py:68-78,119-132,504-506, TELR_liftover.py:253-266) and ngmlr 0.2.7
+ * (envs/telr.yml:48; TELR_alignment.py:31-51).  The reference ships no tests
+ * or golden vectors for them.  This file restates the PUBLISHED algorithm
+ * (Li 2018, Bioinformatics 34:3094, sections 2.1-2.3: (w,k)-minimizers with an
+ * invertible hash, seed collection with an occurrence filter, anchor chaining
+ * f(i)=max{max_j f(j)+alpha(j,i)-beta(j,i), w_i}, two-piece affine gap DP
+ * between anchors with z-drop end extension, mapQ=40(1-f2/f1)min{1,m/10}log f1;
+ * Li 2021, Bioinformatics 37:4572 for the long-read presets) with every
+ * tie-break and heuristic fixed explicitly (see DESIGN.md "Engine spec") so a
+ * GPU implementation can be bit-exact against it.  It is pinned by (i) the
+ * reference's own bundled fixture (test/ FASTA files -> one jockey insertion near
+ * ref offset 33017, minus strand; tests/test_fixture_known_answer.py) and
+ * (ii) simulated-truth recovery.  The Python glue (liftover, AF) is pinned
+ * separately against golden vectors captured from the reference's own code
+ * (tests/golden/, tools/capture_goldens.py).
+ *
+ * Build: make -C oracle   ->  oracle/libtelroracle.so
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include "../include/telr_hip.h"
+
+#define NEG        (-(1 << 28))
+#define TPAD       16384          /* padding between targets in global coordinates */
+#define KEY_REV    (1ULL << 63)
+#define DP_DMAX    4096           /* widest band (diagonals) the DP accepts; wider -> diagonal fallback */
+#define DEPTH_CAP  8000           /* samtools depth default -d */
+
+/* ------------------------------------------------------------------------- */
+/* growable arrays                                                            */
+#define VEC(T) struct { T *a; int64_t n, m; }
+#define vpush(T, v, x) do { if ((v).n == (v).m) { (v).m = (v).m ? (v).m * 2 : 64; \
+        (v).a = (T*)realloc((v).a, sizeof(T) * (v).m); } (v).a[(v).n++] = (x); } while (0)
+
+static const uint8_t NT4[256] = {
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4,4,4,4,4,3,3,4,4,4,4,4,4,4,4,4,4,
+    4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4,4,4,4,4,3,3,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+    4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,
+};
+
+uint8_t tor_nt4(uint8_t c) { return NT4[c]; }
+
+/* invertible integer hash (Thomas Wang), Li 2018 section 2.1 */
+static inline uint64_t hash64(uint64_t key, uint64_t mask)
+{
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 1. minimizer sketch                                                        */
+/* A minimizer is (x, y): x = hash<<8 | span, y = (base + pos)<<1 | strand,   */
+/* pos = last base of the k-mer.  Set definition (Li 2018 Alg. 1 without the  */
+/* streaming quirks): slot u is selected iff it is valid and x_u <= x_v for   */
+/* every v of SOME window of min(w, nslots) consecutive slots containing u.   */
+typedef struct { uint64_t x; uint32_t y; } mz_t;
+typedef VEC(mz_t) mzv_t;
+
+static void sketch(const uint8_t *s /* nt4 codes */, int len, int k, int w, int hpc,
+                   uint32_t base, mzv_t *out)
+{
+    if (len < k) return;
+    int nu = 0;
+    uint8_t *hb; int32_t *hs, *he;
+    hb = (uint8_t*)malloc(len); hs = (int32_t*)malloc(4 * (size_t)len); he = (int32_t*)malloc(4 * (size_t)len);
+    if (hpc) {
+        for (int i = 0; i < len; ) {
+            int j = i + 1;
+            while (j < len && s[j] == s[i]) ++j;
+            hb[nu] = s[i]; hs[nu] = i; he[nu] = j - 1; ++nu; i = j;
+        }
+    } else {
+        for (int i = 0; i < len; ++i) { hb[i] = s[i]; hs[i] = he[i] = i; }
+        nu = len;
+    }
+    int ns = nu - k + 1;
+    if (ns >= 1) {
+        uint64_t mask = (1ULL << 2 * k) - 1, shift1 = 2 * (k - 1);
+        uint64_t *x = (uint64_t*)malloc(8 * (size_t)ns);
+        uint32_t *y = (uint32_t*)malloc(4 * (size_t)ns);
+        uint64_t fw = 0, rv = 0; int l = 0;
+        for (int i = 0; i < nu; ++i) {
+            int c = hb[i];
+            if (c < 4) { fw = (fw << 2 | c) & mask; rv = (rv >> 2) | (3ULL ^ c) << shift1; ++l; }
+            else l = 0, fw = rv = 0;
+            if (i >= k - 1) {
+                int u = i - k + 1;
+                int span = he[i] - hs[u] + 1;
+                if (l >= k && fw != rv && span < 256) {
+                    int z = fw < rv ? 0 : 1;
+                    x[u] = hash64(z ? rv : fw, mask) << 8 | (uint64_t)span;
+                    y[u] = (base + (uint32_t)he[i]) << 1 | (uint32_t)z;
+                } else x[u] = UINT64_MAX, y[u] = 0;
+            }
+        }
+        int need = w < ns ? w : ns;
+        for (int u = 0; u < ns; ++u) {
+            if (x[u] == UINT64_MAX) continue;
+            int L = 0, R = 0;
+            while (L < w - 1 && u - L - 1 >= 0 && x[u - L - 1] >= x[u]) ++L;
+            while (R < w - 1 && u + R + 1 < ns && x[u + R + 1] >= x[u]) ++R;
+            if (L + R + 1 >= need) { mz_t m = { x[u], y[u] }; vpush(mz_t, *out, m); }
+        }
+        free(x); free(y);
+    }
+    free(hb); free(hs); free(he);
+}
+
+/* debug entry: sketch one ASCII sequence */
+int64_t tor_sketch(const char *ascii, int32_t len, int k, int w, int hpc, uint32_t base,
+                   uint64_t *x_out, uint32_t *y_out, int64_t cap)
+{
+    uint8_t *s = (uint8_t*)malloc(len > 0 ? len : 1);
+    for (int i = 0; i < len; ++i) s[i] = NT4[(uint8_t)ascii[i]];
+    mzv_t v = {0, 0, 0};
+    sketch(s, len, k, w, hpc, base, &v);
+    int64_t n = v.n;
+    for (int64_t i = 0; i < n && i < cap; ++i) { x_out[i] = v.a[i].x; y_out[i] = v.a[i].y; }
+    free(v.a); free(s);
+    return n;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 2. index                                                                   */
+typedef struct tor_index {
+    int32_t k, w, hpc;
+    int32_t n_seq;
+    uint8_t **seq;        /* nt4 codes per target */
+    int32_t *len;
+    uint32_t *goff;       /* global coordinate of base 0 of each target */
+    int64_t n_mz;
+    uint64_t *hash;       /* [n_mz] sorted by (hash, y) */
+    uint32_t *ys;         /* [n_mz] */
+    int64_t n_ent;
+    uint64_t *ent_hash;   /* [n_ent] distinct hashes ascending */
+    uint32_t *ent_off;    /* [n_ent+1] */
+} tor_index;
+
+typedef struct { uint64_t h; uint32_t y; } hy_t;
+static int cmp_hy(const void *a, const void *b)
+{
+    const hy_t *p = (const hy_t*)a, *q = (const hy_t*)b;
+    if (p->h != q->h) return p->h < q->h ? -1 : 1;
+    return p->y < q->y ? -1 : p->y > q->y;
+}
+
+tor_index *tor_index_build(int32_t n, const char *ascii, const int64_t *off, const int32_t *len,
+                           const telr_idx_opt *io)
+{
+    tor_index *ix = (tor_index*)calloc(1, sizeof(*ix));
+    ix->k = io->k; ix->w = io->w; ix->hpc = io->is_hpc; ix->n_seq = n;
+    ix->seq = (uint8_t**)calloc(n, sizeof(uint8_t*));
+    ix->len = (int32_t*)calloc(n, 4); ix->goff = (uint32_t*)calloc(n + 1, 4);
+    mzv_t v = {0, 0, 0};
+    uint64_t g = 0;
+    for (int i = 0; i < n; ++i) {
+        ix->len[i] = len[i]; ix->goff[i] = (uint32_t)g;
+        ix->seq[i] = (uint8_t*)malloc(len[i] > 0 ? len[i] : 1);
+        for (int j = 0; j < len[i]; ++j) ix->seq[i][j] = NT4[(uint8_t)ascii[off[i] + j]];
+        sketch(ix->seq[i], len[i], io->k, io->w, io->is_hpc, (uint32_t)g, &v);
+        g = (g + (uint64_t)len[i] + TPAD + 63) & ~63ULL;
+    }
+    ix->goff[n] = (uint32_t)g;
+    hy_t *t = (hy_t*)malloc(sizeof(hy_t) * (v.n ? v.n : 1));
+    for (int64_t i = 0; i < v.n; ++i) { t[i].h = v.a[i].x >> 8; t[i].y = v.a[i].y; }
+    /* NOTE the span byte is not part of the index order: grouping is by hash only */
+    qsort(t, v.n, sizeof(hy_t), cmp_hy);
+    ix->n_mz = v.n;
+    ix->hash = (uint64_t*)malloc(8 * (size_t)(v.n ? v.n : 1)); ix->ys = (uint32_t*)malloc(4 * (size_t)(v.n ? v.n : 1));
+    int64_t ne = 0;
+    for (int64_t i = 0; i < v.n; ++i) { ix->hash[i] = t[i].h; ix->ys[i] = t[i].y; if (i == 0 || t[i].h != t[i-1].h) ++ne; }
+    ix->n_ent = ne;
+    ix->ent_hash = (uint64_t*)malloc(8 * (ne ? ne : 1)); ix->ent_off = (uint32_t*)malloc(4 * (ne + 1));
+    ne = 0;
+    for (int64_t i = 0; i < v.n; ++i) if (i == 0 || t[i].h != t[i-1].h) { ix->ent_hash[ne] = t[i].h; ix->ent_off[ne++] = (uint32_t)i; }
+    ix->ent_off[ne] = (uint32_t)v.n;
+    free(t); free(v.a);
+    return ix;
+}
+
+void tor_index_free(tor_index *ix)
+{
+    if (!ix) return;
+    for (int i = 0; i < ix->n_seq; ++i) free(ix->seq[i]);
+    free(ix->seq); free(ix->len); free(ix->goff); free(ix->hash); free(ix->ys); free(ix->ent_hash); free(ix->ent_off); free(ix);
+}
+
+int64_t tor_index_n_mz(const tor_index *ix) { return ix->n_mz; }
+int64_t tor_index_n_ent(const tor_index *ix) { return ix->n_ent; }
+void tor_index_dump(const tor_index *ix, uint64_t *hash, uint32_t *ys)
+{
+    memcpy(hash, ix->hash, 8 * ix->n_mz); memcpy(ys, ix->ys, 4 * ix->n_mz);
+}
+
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
+
+/* occurrence cut-off: the (1-f) quantile of the distinct-minimizer counts, +1, clamped */
+int32_t tor_mid_occ(const tor_index *ix, float frac, int32_t lo, int32_t hi)
+{
+    int64_t n = ix->n_ent;
+    int32_t occ;
+    if (n == 0) occ = lo;
+    else {
+        uint32_t *c = (uint32_t*)malloc(4 * n);
+        for (int64_t i = 0; i < n; ++i) c[i] = ix->ent_off[i + 1] - ix->ent_off[i];
+        qsort(c, n, 4, cmp_u32);
+        int64_t idx = (int64_t)((1.0 - (double)frac) * (double)n);
+        if (idx >= n) idx = n - 1;
+        occ = (int32_t)c[idx] + 1;
+        free(c);
+    }
+    if (occ < lo) occ = lo;
+    if (hi > lo && occ > hi) occ = hi;
+    return occ;
+}
+
+static inline int64_t index_lookup(const tor_index *ix, uint64_t h)
+{
+    int64_t lo = 0, hi = ix->n_ent - 1;
+    while (lo <= hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (ix->ent_hash[mid] == h) return mid;
+        if (ix->ent_hash[mid] < h) lo = mid + 1; else hi = mid - 1;
+    }
+    return -1;
+}
+
+static inline int32_t tid_of_gpos(const tor_index *ix, uint32_t g)
+{
+    int32_t lo = 0, hi = ix->n_seq - 1;
+    while (lo < hi) { int32_t mid = (lo + hi + 1) >> 1; if (ix->goff[mid] <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+/* ------------------------------------------------------------------------- */
+/* 3. seeding: anchors as sortable 64-bit keys                                */
+/*   bit 63     : query strand differs from target strand                     */
+/*   bits 62-32 : global target coordinate of the k-mer's last base           */
+/*   bits 31-8  : query coordinate (on the strand-adjusted query) of the last base */
+/*   bits 7-0   : query span                                                  */
+typedef VEC(uint64_t) u64v_t;
+static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : x > y; }
+
+#define A_REV(k)  ((int)((k) >> 63))
+#define A_G(k)    ((int32_t)(((k) >> 32) & 0x7fffffff))
+#define A_Q(k)    ((int32_t)(((k) >> 8) & 0xffffff))
+#define A_SPAN(k) ((int32_t)((k) & 0xff))
+
+static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int32_t tfilter, int32_t mid_occ,
+                            u64v_t *out, int64_t *n_mz, int64_t *n_probe)
+{
+    mzv_t mv = {0, 0, 0};
+    sketch(q, qlen, ix->k, ix->w, ix->hpc, 0, &mv);
+    *n_mz += mv.n;
+    uint32_t g0 = 0, g1 = 0xffffffffu;
+    if (tfilter >= 0) { g0 = ix->goff[tfilter]; g1 = g0 + (uint32_t)ix->len[tfilter]; }
+    for (int64_t i = 0; i < mv.n; ++i) {
+        int64_t e = index_lookup(ix, mv.a[i].x >> 8);
+        ++*n_probe;
+        if (e < 0) continue;
+        uint32_t o0 = ix->ent_off[e], o1 = ix->ent_off[e + 1];
+        int32_t cnt = 0;
+        if (tfilter >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t g = ix->ys[o] >> 1; if (g >= g0 && g < g1) ++cnt; } }
+        else cnt = (int32_t)(o1 - o0);
+        if (cnt == 0 || cnt > mid_occ) continue;
+        int32_t span = (int32_t)(mv.a[i].x & 0xff), qpos = (int32_t)(mv.a[i].y >> 1), qz = (int32_t)(mv.a[i].y & 1);
+        for (uint32_t o = o0; o < o1; ++o) {
+            uint32_t g = ix->ys[o] >> 1;
+            if (tfilter >= 0 && (g < g0 || g >= g1)) continue;
+            int tz = ix->ys[o] & 1;
+            uint64_t key;
+            if (tz == qz) key = (uint64_t)g << 32 | (uint64_t)qpos << 8 | (uint64_t)span;
+            else key = KEY_REV | (uint64_t)g << 32 | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
+            vpush(uint64_t, *out, key);
+        }
+    }
+    free(mv.a);
+    qsort(out->a, out->n, 8, cmp_u64);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 4. chaining                                                                */
+/* integer log2 in Q8 (piecewise-linear mantissa); v >= 1                     */
+static inline int32_t ilog2_q8(uint32_t v)
+{
+    int e = 31 - __builtin_clz(v);
+    uint32_t frac = e <= 8 ? (v << (8 - e)) - 256u : (v >> (e - 8)) - 256u;
+    return e * 256 + (int32_t)frac;
+}
+
+/* score of appending anchor i after anchor j; INT32_MIN if not allowed */
+static inline int32_t chain_sc(uint64_t ai, uint64_t aj, const telr_map_opt *mo)
+{
+    if ((ai >> 63) != (aj >> 63)) return INT32_MIN;
+    int32_t dr = A_G(ai) - A_G(aj), dq = A_Q(ai) - A_Q(aj);
+    if (dq <= 0 || dq > mo->max_gap) return INT32_MIN;
+    if (dr <= 0 || dr > mo->max_gap) return INT32_MIN;
+    int32_t dd = dr > dq ? dr - dq : dq - dr;
+    if (dd > mo->bw) return INT32_MIN;
+    int32_t dg = dr < dq ? dr : dq;
+    int32_t span = A_SPAN(ai);
+    int32_t sc = span < dg ? span : dg;
+    if (dd || dg > span) {
+        int32_t pen = mo->chain_gap_q8 * dd + mo->chain_skip_q8 * dg + (dd >= 1 ? ilog2_q8((uint32_t)dd + 1) >> 1 : 0);
+        sc -= pen >> 8;
+    }
+    return sc;
+}
+
+static void chain_dp(const uint64_t *a, int64_t n, const telr_map_opt *mo, int32_t *f, int32_t *p)
+{
+    int H = mo->chain_lookback;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t best = A_SPAN(a[i]), bp = -1;
+        int64_t st = i - H; if (st < 0) st = 0;
+        for (int64_t j = i - 1; j >= st; --j) {
+            int32_t sc = chain_sc(a[i], a[j], mo);
+            if (sc == INT32_MIN) continue;
+            int32_t v = f[j] + sc;
+            if (v > best) best = v, bp = (int32_t)j;
+        }
+        f[i] = best; p[i] = bp;
+    }
+}
+
+typedef struct {
+    int32_t score, cnt;
+    int64_t a_off;          /* into the per-query chain-anchor array */
+    int32_t rev, tid;
+    int32_t rs, re, qs, qe; /* target-local / strand-adjusted query coordinates */
+    int32_t disc;           /* discovery order */
+} chain_t;
+typedef VEC(chain_t) chainv_t;
+
+typedef struct { int32_t f, i; } peak_t;
+static int cmp_peak(const void *a, const void *b)
+{
+    const peak_t *x = (const peak_t*)a, *y = (const peak_t*)b;
+    if (x->f != y->f) return x->f > y->f ? -1 : 1;
+    return x->i < y->i ? -1 : x->i > y->i;
+}
+
+/* back-tracking: start from peaks (no successor with a larger f) in (f desc, index asc) order */
+static void chain_backtrack(const tor_index *ix, const uint64_t *a, int64_t n, const int32_t *f, const int32_t *p,
+                            const telr_map_opt *mo, chainv_t *chains, u64v_t *canch)
+{
+    uint8_t *nonpeak = (uint8_t*)calloc(n ? n : 1, 1), *vis = (uint8_t*)calloc(n ? n : 1, 1);
+    for (int64_t i = 0; i < n; ++i) if (p[i] >= 0 && f[i] > f[p[i]]) nonpeak[p[i]] = 1;
+    VEC(peak_t) pk = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) if (!nonpeak[i] && f[i] >= mo->min_chain_score) { peak_t t = { f[i], (int32_t)i }; vpush(peak_t, pk, t); }
+    qsort(pk.a, pk.n, sizeof(peak_t), cmp_peak);
+    for (int64_t t = 0; t < pk.n; ++t) {
+        int32_t i = pk.a[t].i;
+        if (vis[i]) continue;
+        int32_t cnt = 0, j = i, stop_f = 0;
+        while (j >= 0 && !vis[j]) { vis[j] = 1; ++cnt; j = p[j]; }
+        if (j >= 0) stop_f = f[j];
+        int32_t sc = f[i] - stop_f;
+        if (sc < mo->min_chain_score || cnt < mo->min_cnt) continue;
+        chain_t c; memset(&c, 0, sizeof(c));
+        c.score = sc; c.cnt = cnt; c.a_off = canch->n; c.disc = (int32_t)chains->n;
+        for (int32_t z = 0; z < cnt; ++z) vpush(uint64_t, *canch, 0);
+        j = i;
+        for (int32_t z = cnt - 1; z >= 0; --z) { canch->a[c.a_off + z] = a[j]; j = p[j]; }
+        uint64_t a0 = canch->a[c.a_off], a1 = canch->a[c.a_off + cnt - 1];
+        c.rev = A_REV(a0); c.tid = tid_of_gpos(ix, (uint32_t)A_G(a0));
+        int32_t go = (int32_t)ix->goff[c.tid];
+        c.rs = A_G(a0) - go - A_SPAN(a0) + 1; c.re = A_G(a1) - go + 1;
+        c.qs = A_Q(a0) - A_SPAN(a0) + 1;      c.qe = A_Q(a1) + 1;
+        vpush(chain_t, *chains, c);
+    }
+    free(nonpeak); free(vis); free(pk.a);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 5. chain selection (primary / secondary / supplementary)                   */
+typedef struct {
+    int32_t ci;            /* chain index */
+    int32_t key;           /* sort key: chain score (pass 1) or dp score (pass 2) */
+    int32_t ord;           /* tie-break: previous order */
+    int32_t fs, fe;        /* query interval on the forward strand */
+    int32_t tid;
+    int32_t parent, subsc, n_sub, keep;
+} sel_t;
+
+static int cmp_sel(const void *a, const void *b)
+{
+    const sel_t *x = (const sel_t*)a, *y = (const sel_t*)b;
+    if (x->key != y->key) return x->key > y->key ? -1 : 1;
+    return x->ord < y->ord ? -1 : x->ord > y->ord;
+}
+
+/* s[] sorted; sets parent/subsc/n_sub/keep */
+static void select_chains(sel_t *s, int n, const telr_map_opt *mo, const int32_t *sub_score /* by ci */)
+{
+    int per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
+    for (int i = 0; i < n; ++i) {
+        s[i].parent = i; s[i].subsc = 0; s[i].n_sub = 0;
+        for (int j = 0; j < i; ++j) {
+            if (s[j].parent != j) continue;
+            if (per_t && s[j].tid != s[i].tid) continue;
+            int32_t lo = s[i].fs > s[j].fs ? s[i].fs : s[j].fs, hi = s[i].fe < s[j].fe ? s[i].fe : s[j].fe;
+            int32_t ol = hi > lo ? hi - lo : 0;
+            int32_t li = s[i].fe - s[i].fs, lj = s[j].fe - s[j].fs, mn = li < lj ? li : lj;
+            if ((float)ol > mo->mask_level * (float)mn) {
+                s[i].parent = j;
+                if (sub_score[s[i].ci] > s[j].subsc) s[j].subsc = sub_score[s[i].ci];
+                ++s[j].n_sub;
+                break;
+            }
+        }
+    }
+    /* keep secondaries scoring >= pri_ratio * parent, at most best_n (per query, or per target) */
+    for (int i = 0; i < n; ++i) {
+        if (s[i].parent == i) { s[i].keep = 1; continue; }
+        s[i].keep = 0;
+        if (!mo->secondary) continue;
+        if ((float)s[i].key < (float)s[s[i].parent].key * mo->pri_ratio) continue;
+        int n2 = 0;
+        for (int j = 0; j < i; ++j) if (s[j].keep && s[j].parent != j && (!per_t || s[j].tid == s[i].tid)) ++n2;
+        if (n2 < mo->best_n) s[i].keep = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* 6. banded two-piece-affine DP over anti-diagonals                           */
+/* Cell (i,j): i query bases, j target bases consumed; a=i+j, d=j-i.           */
+/* Band dlo<=d<=dhi.  tb byte: bits0-2 source of H (0 diag,1 E1,2 F1,3 E2,4 F2) */
+/* bit3 E1 extended, bit4 F1 extended, bit5 E2 extended, bit6 F2 extended.      */
+typedef struct {
+    const uint8_t *q, *t;   /* sequence accessors: base x is q[qi0 + qstep*x]            */
+    int64_t qi0, ti0; int qstep, tstep; int qcomp; /* qcomp: complement the query base     */
+    int m, n;
+} dp_seq_t;
+
+static inline int qbase(const dp_seq_t *s, int i) { int c = s->q[s->qi0 + (int64_t)s->qstep * i]; return (s->qcomp && c < 4) ? 3 - c : c; }
+static inline int tbase(const dp_seq_t *s, int j) { return s->t[s->ti0 + (int64_t)s->tstep * j]; }
+
+typedef VEC(uint32_t) u32v_t;
+static inline void cig_push(u32v_t *c, int op, int len)
+{
+    if (len <= 0) return;
+    if (c->n && (int)(c->a[c->n - 1] & 0xf) == op) c->a[c->n - 1] += (uint32_t)len << 4;
+    else vpush(uint32_t, *c, (uint32_t)len << 4 | (uint32_t)op);
+}
+
+typedef struct { int score, bi, bj; int64_t cells; } dp_res_t;
+
+/* ext=0: global alignment of (m,n), returns H(m,n), traceback from (m,n).
+ * ext=1: extension from (0,0): best cell with z-drop, traceback from it.
+ * The CIGAR is appended to rev_cig in REVERSE order of ops (end -> start). */
+static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr_map_opt *mo, u32v_t *rev_cig)
+{
+    const int m = s->m, n = s->n, D = dhi - dlo + 1, stride = (D + 2) / 2;
+    const int q1 = mo->q, e1 = mo->e, q2 = mo->q2, e2 = mo->e2;
+    dp_res_t res = { 0, 0, 0, 0 };
+    int32_t *H = (int32_t*)malloc(4 * (size_t)(D + 2) * 5), *E1 = H + (D + 2), *F1 = E1 + (D + 2), *E2 = F1 + (D + 2), *F2 = E2 + (D + 2);
+    for (int x = 0; x < (D + 2) * 5; ++x) H[x] = NEG;
+    uint8_t *tb = (uint8_t*)calloc((size_t)(m + n + 1) * stride, 1);
+#define IX(d) ((d) - dlo + 1)
+    int best = 0, bi = 0, bj = 0, prev_cur = NEG, last_a = m + n;
+    if (0 >= dlo && 0 <= dhi) H[IX(0)] = 0;
+    for (int a = 1; a <= m + n; ++a) {
+        int d0 = -a > dlo ? -a : dlo; if (a - 2 * m > d0) d0 = a - 2 * m;
+        int d1 = a < dhi ? a : dhi;   if (2 * n - a < d1) d1 = 2 * n - a;
+        if (((d0 - a) & 1) != 0) ++d0;
+        int cur = NEG, cur_d = 0;
+        for (int d = d0; d <= d1; d += 2) {
+            int i = (a - d) >> 1, j = (a + d) >> 1, x = IX(d);
+            int32_t h, ve1, vf1, ve2, vf2; uint8_t t = 0;
+            if (i == 0) {          /* first row: a deletion of length j */
+                ve1 = -(q1 + j * e1); ve2 = -(q2 + j * e2); vf1 = vf2 = NEG;
+                h = ve1 > ve2 ? ve1 : ve2;
+            } else if (j == 0) {   /* first column: an insertion of length i */
+                vf1 = -(q1 + i * e1); vf2 = -(q2 + i * e2); ve1 = ve2 = NEG;
+                h = vf1 > vf2 ? vf1 : vf2;
+            } else {
+                int32_t hl = H[x - 1], hu = H[x + 1], hd = H[x];
+                int32_t o, g;
+                o = hl - q1 - e1; g = E1[x - 1] - e1; if (g > o) ve1 = g, t |= 8;  else ve1 = o;
+                o = hu - q1 - e1; g = F1[x + 1] - e1; if (g > o) vf1 = g, t |= 16; else vf1 = o;
+                o = hl - q2 - e2; g = E2[x - 1] - e2; if (g > o) ve2 = g, t |= 32; else ve2 = o;
+                o = hu - q2 - e2; g = F2[x + 1] - e2; if (g > o) vf2 = g, t |= 64; else vf2 = o;
+                int qb = qbase(s, i - 1), tbv = tbase(s, j - 1);
+                int sc = (qb > 3 || tbv > 3) ? -mo->sc_ambi : (qb == tbv ? mo->a : -mo->b);
+                h = hd + sc; int src = 0;
+                if (ve1 > h) h = ve1, src = 1;
+                if (vf1 > h) h = vf1, src = 2;
+                if (ve2 > h) h = ve2, src = 3;
+                if (vf2 > h) h = vf2, src = 4;
+                t |= (uint8_t)src;
+                tb[(size_t)a * stride + ((d - dlo) >> 1)] = t;
+                ++res.cells;
+            }
+            /* clamp so that unreachable cells stay near NEG without drifting */
+            if (h < NEG) h = NEG;
+            if (ve1 < NEG) ve1 = NEG;
+            if (vf1 < NEG) vf1 = NEG;
+            if (ve2 < NEG) ve2 = NEG;
+            if (vf2 < NEG) vf2 = NEG;
+            H[x] = h; E1[x] = ve1; F1[x] = vf1; E2[x] = ve2; F2[x] = vf2;
+            if (h > cur) cur = h, cur_d = d;
+        }
+        if (ext) {
+            if (cur > best) best = cur, bi = (a - cur_d) >> 1, bj = (a + cur_d) >> 1;
+            int c2 = cur > prev_cur ? cur : prev_cur;
+            if (best - c2 > mo->zdrop) { last_a = a; break; }
+            prev_cur = cur;
+        }
+    }
+    (void)last_a;
+    int i, j;
+    if (ext) { res.score = best; i = bi; j = bj; }
+    else { res.score = H[IX(n - m)]; i = m; j = n; }
+    res.bi = i; res.bj = j;
+    /* traceback */
+    int state = 0;
+    while (i > 0 && j > 0) {
+        uint8_t t = tb[(size_t)(i + j) * stride + ((j - i - dlo) >> 1)];
+        if (state == 0) state = t & 7;
+        if (state == 0) { cig_push(rev_cig, 0, 1); --i; --j; }
+        else if (state == 1) { cig_push(rev_cig, 2, 1); if (!(t & 8))  state = 0; --j; }
+        else if (state == 2) { cig_push(rev_cig, 1, 1); if (!(t & 16)) state = 0; --i; }
+        else if (state == 3) { cig_push(rev_cig, 2, 1); if (!(t & 32)) state = 0; --j; }
+        else                 { cig_push(rev_cig, 1, 1); if (!(t & 64)) state = 0; --i; }
+    }
+    if (i > 0) cig_push(rev_cig, 1, i);
+    if (j > 0) cig_push(rev_cig, 2, j);
+#undef IX
+    free(H); free(tb);
+    return res;
+}
+
+/* band wider than DP_DMAX: align min(m,n) bases on the main diagonal and close with one gap */
+static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v_t *rev_cig, int *mlen)
+{
+    dp_res_t r = { 0, s->m, s->n, 0 };
+    int mn = s->m < s->n ? s->m : s->n, g = s->m > s->n ? s->m - s->n : s->n - s->m;
+    *mlen = 0;
+    for (int x = 0; x < mn; ++x) {
+        int qb = qbase(s, x), tbv = tbase(s, x);
+        if (qb > 3 || tbv > 3) r.score -= mo->sc_ambi; else if (qb == tbv) { r.score += mo->a; ++*mlen; } else r.score -= mo->b;
+    }
+    if (g) { int c1 = mo->q + g * mo->e, c2 = mo->q2 + g * mo->e2; r.score -= c1 < c2 ? c1 : c2; cig_push(rev_cig, s->m > s->n ? 1 : 2, g); }
+    cig_push(rev_cig, 0, mn);
+    return r;
+}
+
+static inline int fill_band(int m, int n, const telr_map_opt *mo)
+{
+    int mn = m < n ? m : n;
+    int W = 16 + (mn >> 4);
+    return W < mo->bw ? W : mo->bw;
+}
+
+/* debug entry: one global banded alignment of two ASCII strings */
+int32_t tor_nw(const char *q, int m, const char *t, int n, const telr_map_opt *mo, uint32_t *cig, int32_t *n_cig, int32_t cap)
+{
+    uint8_t *qq = (uint8_t*)malloc(m + 1), *tt = (uint8_t*)malloc(n + 1);
+    for (int i = 0; i < m; ++i) qq[i] = NT4[(uint8_t)q[i]];
+    for (int i = 0; i < n; ++i) tt[i] = NT4[(uint8_t)t[i]];
+    dp_seq_t s = { qq, tt, 0, 0, 1, 1, 0, m, n };
+    int W = fill_band(m, n, mo), dl = n - m;
+    u32v_t rc = {0, 0, 0};
+    dp_res_t r = band_dp(&s, (dl < 0 ? dl : 0) - W, (dl > 0 ? dl : 0) + W, 0, mo, &rc);
+    *n_cig = (int32_t)rc.n;
+    for (int64_t i = 0; i < rc.n && i < cap; ++i) cig[i] = rc.a[rc.n - 1 - i];
+    free(rc.a); free(qq); free(tt);
+    return r.score;
+}
+
+/* debug entry: one z-drop extension */
+int32_t tor_ext(const char *q, int m, const char *t, int n, const telr_map_opt *mo, uint32_t *cig, int32_t *n_cig, int32_t cap,
+                int32_t *qend, int32_t *tend)
+{
+    uint8_t *qq = (uint8_t*)malloc(m + 1), *tt = (uint8_t*)malloc(n + 1);
+    for (int i = 0; i < m; ++i) qq[i] = NT4[(uint8_t)q[i]];
+    for (int i = 0; i < n; ++i) tt[i] = NT4[(uint8_t)t[i]];
+    int mq = m < mo->ext_max ? m : mo->ext_max, mt = n < mq + mo->ext_band ? n : mq + mo->ext_band;
+    dp_seq_t s = { qq, tt, 0, 0, 1, 1, 0, mq, mt };
+    u32v_t rc = {0, 0, 0};
+    dp_res_t r = band_dp(&s, -mo->ext_band, mo->ext_band, 1, mo, &rc);
+    *n_cig = (int32_t)rc.n; *qend = r.bi; *tend = r.bj;
+    for (int64_t i = 0; i < rc.n && i < cap; ++i) cig[i] = rc.a[rc.n - 1 - i];
+    free(rc.a); free(qq); free(tt);
+    return r.score;
+}
+
+/* align one chain; fills the alignment fields of `al` and appends the CIGAR */
+static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const chain_t *c, const uint64_t *ca,
+                        const telr_map_opt *mo, telr_aln *al, u32v_t *cigars, telr_counters *ctr)
+{
+    const uint8_t *t = ix->seq[c->tid];
+    const int tlen = ix->len[c->tid], go = (int32_t)ix->goff[c->tid];
+    /* query accessor on the chain's strand */
+    dp_seq_t s; s.q = q; s.t = t; s.qcomp = c->rev;
+    /* breakpoints */
+    VEC(int32_t) bp = {0, 0, 0};
+    int32_t r0 = c->rs, q0 = c->qs;
+    vpush(int32_t, bp, r0); vpush(int32_t, bp, q0);
+    int32_t lr = r0, lq = q0;
+    for (int32_t i = 0; i < c->cnt; ++i) {
+        int32_t cr = A_G(ca[i]) - go + 1, cq = A_Q(ca[i]) + 1;
+        if (i == c->cnt - 1 || (cq - lq >= mo->min_ksw_len && cr - lr >= mo->min_ksw_len)) {
+            vpush(int32_t, bp, cr); vpush(int32_t, bp, cq); lr = cr; lq = cq;
+        }
+    }
+    int nseg = (int)(bp.n / 2) - 1;
+    u32v_t cig = {0, 0, 0}, rc = {0, 0, 0};
+    int32_t dp = 0;
+    /* left extension: reversed sequences starting at (q0-1, r0-1) going down */
+    int32_t qs = q0, rs = r0;
+    if (q0 > 0 && r0 > 0) {
+        int mq = q0 < mo->ext_max ? q0 : mo->ext_max, mt = r0 < mq + mo->ext_band ? r0 : mq + mo->ext_band;
+        s.m = mq; s.n = mt; s.tstep = -1; s.ti0 = r0 - 1;
+        if (c->rev) { s.qstep = 1; s.qi0 = qlen - q0; } else { s.qstep = -1; s.qi0 = q0 - 1; }
+        rc.n = 0;
+        dp_res_t r = band_dp(&s, -mo->ext_band, mo->ext_band, 1, mo, &rc);
+        ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
+        dp += r.score; qs = q0 - r.bi; rs = r0 - r.bj;
+        /* rev_cig is end->start of the reversed problem == left-to-right on the forward sequences */
+        for (int64_t z = 0; z < rc.n; ++z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
+    }
+    for (int g = 0; g < nseg; ++g) {
+        int32_t sr = bp.a[2 * g], sq = bp.a[2 * g + 1], er = bp.a[2 * g + 2], eq = bp.a[2 * g + 3];
+        s.m = eq - sq; s.n = er - sr; s.tstep = 1; s.ti0 = sr;
+        if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - sq; } else { s.qstep = 1; s.qi0 = sq; }
+        int W = fill_band(s.m, s.n, mo), dl = s.n - s.m;
+        rc.n = 0;
+        int lo = (dl < 0 ? dl : 0) - W, hi = (dl > 0 ? dl : 0) + W, fb_mlen;
+        dp_res_t r = hi - lo + 1 > DP_DMAX ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
+        ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
+        dp += r.score;
+        for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
+    }
+    int32_t qe = c->qe, re = c->re;
+    if (qe < qlen && re < tlen) {
+        int rq = qlen - qe, rt = tlen - re;
+        int mq = rq < mo->ext_max ? rq : mo->ext_max, mt = rt < mq + mo->ext_band ? rt : mq + mo->ext_band;
+        s.m = mq; s.n = mt; s.tstep = 1; s.ti0 = re;
+        if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - qe; } else { s.qstep = 1; s.qi0 = qe; }
+        rc.n = 0;
+        dp_res_t r = band_dp(&s, -mo->ext_band, mo->ext_band, 1, mo, &rc);
+        ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
+        dp += r.score; qe += r.bi; re += r.bj;
+        for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
+    }
+    /* statistics from the final CIGAR */
+    int32_t mlen = 0, blen = 0, nambi = 0, qi = qs, ti = rs;
+    for (int64_t z = 0; z < cig.n; ++z) {
+        int op = cig.a[z] & 0xf, len = cig.a[z] >> 4;
+        blen += len;
+        if (op == 0) {
+            for (int x = 0; x < len; ++x) {
+                int qb = c->rev ? q[qlen - 1 - (qi + x)] : q[qi + x];
+                if (c->rev && qb < 4) qb = 3 - qb;
+                int tbv = t[ti + x];
+                if (qb < 4 && qb == tbv) ++mlen;
+            }
+            qi += len; ti += len;
+        } else if (op == 1) qi += len; else ti += len;
+    }
+    al->ts = rs; al->te = re;
+    if (c->rev) { al->qs = qlen - qe; al->qe = qlen - qs; } else { al->qs = qs; al->qe = qe; }
+    al->mlen = mlen; al->blen = blen; al->n_ambi = 0; al->dp_score = dp; (void)nambi;
+    al->n_cigar = (int32_t)cig.n; al->cigar_off = cigars->n;
+    for (int64_t z = 0; z < cig.n; ++z) vpush(uint32_t, *cigars, cig.a[z]);
+    ctr->cigar_ops += cig.n;
+    free(cig.a); free(rc.a); free(bp.a);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 7. the mapping driver                                                      */
+typedef struct tor_result {
+    VEC(telr_aln) alns;
+    u32v_t cigars;
+    telr_counters ctr;
+    /* debug captures (concatenated over queries) */
+    int debug;
+    u64v_t d_anchor; VEC(int64_t) d_anchor_off; VEC(int32_t) d_f, d_p;
+    VEC(int32_t) d_chain;  /* per chain: qid, score, cnt, rev, tid, rs, re, qs, qe */
+} tor_result;
+
+static int32_t mapq_of(const telr_aln *r, const telr_map_opt *mo)
+{
+    if (!(r->flags & TELR_F_PRIMARY) && !(r->flags & TELR_F_SUPPL)) return 0;
+    float f1 = (float)r->score, f2 = (float)(r->subsc > mo->min_chain_score ? r->subsc : mo->min_chain_score);
+    float pen_cm = r->cnt > 10 ? 1.0f : 0.1f * (float)r->cnt;
+    float x = f2 / f1; if (x > 1.0f) x = 1.0f;
+    int32_t mq = (int32_t)(40.0f * (1.0f - x) * pen_cm * logf(f1));
+    if (mq > 60) mq = 60;
+    if (mq < 0) mq = 0;
+    return mq;
+}
+
+tor_result *tor_map(const tor_index *ix, int32_t nq, const char *ascii, const int64_t *off, const int32_t *len,
+                    const int32_t *qtarget, const telr_map_opt *mo, int debug)
+{
+    tor_result *R = (tor_result*)calloc(1, sizeof(*R));
+    R->debug = debug;
+    int32_t mid_occ = tor_mid_occ(ix, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ);
+    for (int32_t qi = 0; qi < nq; ++qi) {
+        int qlen = len[qi];
+        uint8_t *q = (uint8_t*)malloc(qlen > 0 ? qlen : 1);
+        for (int i = 0; i < qlen; ++i) q[i] = NT4[(uint8_t)ascii[off[qi] + i]];
+        R->ctr.query_bases += qlen;
+        u64v_t an = {0, 0, 0};
+        collect_anchors(ix, q, qlen, qtarget ? qtarget[qi] : -1, mid_occ, &an, &R->ctr.minimizers, &R->ctr.probes);
+        R->ctr.anchors += an.n;
+        int32_t *f = (int32_t*)malloc(4 * (an.n ? an.n : 1)), *p = (int32_t*)malloc(4 * (an.n ? an.n : 1));
+        chain_dp(an.a, an.n, mo, f, p);
+        chainv_t ch = {0, 0, 0}; u64v_t ca = {0, 0, 0};
+        chain_backtrack(ix, an.a, an.n, f, p, mo, &ch, &ca);
+        R->ctr.chains += ch.n;
+        if (debug) {
+            vpush(int64_t, R->d_anchor_off, R->d_anchor.n);
+            for (int64_t i = 0; i < an.n; ++i) { vpush(uint64_t, R->d_anchor, an.a[i]); vpush(int32_t, R->d_f, f[i]); vpush(int32_t, R->d_p, p[i]); }
+            for (int64_t i = 0; i < ch.n; ++i) {
+                chain_t *c = &ch.a[i];
+                int32_t v[9] = { qi, c->score, c->cnt, c->rev, c->tid, c->rs, c->re, c->qs, c->qe };
+                for (int z = 0; z < 9; ++z) vpush(int32_t, R->d_chain, v[z]);
+            }
+        }
+        /* pass 1: selection on chain scores */
+        int n = (int)ch.n;
+        sel_t *s = (sel_t*)malloc(sizeof(sel_t) * (n ? n : 1));
+        int32_t *cscore = (int32_t*)malloc(4 * (n ? n : 1));
+        for (int i = 0; i < n; ++i) {
+            chain_t *c = &ch.a[i];
+            s[i].ci = i; s[i].key = c->score; s[i].ord = c->disc; s[i].tid = c->tid;
+            if (c->rev) { s[i].fs = qlen - c->qe; s[i].fe = qlen - c->qs; } else { s[i].fs = c->qs; s[i].fe = c->qe; }
+            cscore[i] = c->score;
+        }
+        qsort(s, n, sizeof(sel_t), cmp_sel);
+        select_chains(s, n, mo, cscore);
+        /* base-level alignment of the kept chains */
+        telr_aln *al = (telr_aln*)calloc(n ? n : 1, sizeof(telr_aln));
+        sel_t *s2 = (sel_t*)malloc(sizeof(sel_t) * (n ? n : 1));
+        int n2 = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!s[i].keep) continue;
+            chain_t *c = &ch.a[s[i].ci];
+            telr_aln *r = &al[s[i].ci];
+            r->qid = qi; r->tid = c->tid; r->qlen = qlen; r->tlen = ix->len[c->tid];
+            r->score = c->score; r->cnt = c->cnt; r->flags = c->rev ? TELR_F_REV : 0;
+            if (mo->flags & TELR_MF_CIGAR) {
+                align_chain(ix, q, qlen, c, ca.a + c->a_off, mo, r, &R->cigars, &R->ctr);
+                if (r->dp_score < mo->min_dp_max) continue;
+            } else {
+                r->ts = c->rs; r->te = c->re;
+                if (c->rev) { r->qs = qlen - c->qe; r->qe = qlen - c->qs; } else { r->qs = c->qs; r->qe = c->qe; }
+                r->mlen = c->score < (c->qe - c->qs) ? c->score : (c->qe - c->qs);
+                r->blen = (c->qe - c->qs) > (c->re - c->rs) ? (c->qe - c->qs) : (c->re - c->rs);
+                r->dp_score = c->score;
+            }
+            s2[n2].ci = s[i].ci; s2[n2].key = r->dp_score; s2[n2].ord = n2; s2[n2].tid = c->tid;
+            s2[n2].fs = r->qs; s2[n2].fe = r->qe;
+            ++n2;
+        }
+        /* pass 2: selection on DP scores, then flags and mapq */
+        qsort(s2, n2, sizeof(sel_t), cmp_sel);
+        select_chains(s2, n2, mo, cscore);
+        int64_t base = R->alns.n;
+        int32_t *newidx = (int32_t*)malloc(4 * (n2 ? n2 : 1));
+        int nk = 0;
+        for (int i = 0; i < n2; ++i) newidx[i] = s2[i].keep ? nk++ : -1;
+        int per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
+        for (int i = 0; i < n2; ++i) {
+            if (!s2[i].keep) continue;
+            telr_aln r = al[s2[i].ci];
+            r.parent = newidx[s2[i].parent]; r.subsc = s2[i].subsc; r.n_sub = s2[i].n_sub;
+            if (s2[i].parent == i) {
+                int first = 1;
+                for (int j = 0; j < i; ++j) if (s2[j].keep && s2[j].parent == j && (!per_t || s2[j].tid == s2[i].tid)) { first = 0; break; }
+                r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
+            } else r.flags |= TELR_F_SECONDARY;
+            r.mapq = mapq_of(&r, mo);
+            vpush(telr_aln, R->alns, r);
+        }
+        (void)base;
+        R->ctr.records += nk;
+        free(newidx); free(s2); free(al); free(cscore); free(s); free(ch.a); free(ca.a); free(f); free(p); free(an.a); free(q);
+    }
+    if (debug) vpush(int64_t, R->d_anchor_off, R->d_anchor.n);
+    return R;
+}
+
+int64_t tor_result_count(const tor_result *r) { return r->alns.n; }
+const telr_aln *tor_result_alns(const tor_result *r) { return r->alns.a; }
+int64_t tor_result_cigar_count(const tor_result *r) { return r->cigars.n; }
+const uint32_t *tor_result_cigars(const tor_result *r) { return r->cigars.a; }
+void tor_result_counters(const tor_result *r, telr_counters *c) { *c = r->ctr; }
+int64_t tor_debug_n_anchor(const tor_result *r) { return r->d_anchor.n; }
+const uint64_t *tor_debug_anchors(const tor_result *r) { return r->d_anchor.a; }
+const int64_t *tor_debug_anchor_off(const tor_result *r) { return r->d_anchor_off.a; }
+const int32_t *tor_debug_f(const tor_result *r) { return r->d_f.a; }
+const int32_t *tor_debug_p(const tor_result *r) { return r->d_p.a; }
+int64_t tor_debug_n_chain(const tor_result *r) { return r->d_chain.n / 9; }
+const int32_t *tor_debug_chains(const tor_result *r) { return r->d_chain.a; }
+void tor_result_free(tor_result *r)
+{
+    if (!r) return;
+    free(r->alns.a); free(r->cigars.a); free(r->d_anchor.a); free(r->d_anchor_off.a); free(r->d_f.a); free(r->d_p.a); free(r->d_chain.a); free(r);
+}
+
+/* ------------------------------------------------------------------------- */
+/* 8. depth medians (samtools depth -aa -r | statistics.median restated;       */
+/*    call site src/telr/TELR_te.py:870-884).  Counts M columns of records    */
+/*    that are not secondary; deletions and insertions do not count.           */
+void tor_depth_medians(const telr_aln *alns, int64_t n_aln, const uint32_t *cigars, int32_t n_targets, const int32_t *tlen,
+                       int32_t n_iv, const int32_t *iv_tid, const int32_t *iv_s, const int32_t *iv_e, double *out)
+{
+    int32_t **depth = (int32_t**)calloc(n_targets, sizeof(int32_t*));
+    for (int64_t i = 0; i < n_aln; ++i) {
+        const telr_aln *r = &alns[i];
+        if (r->flags & TELR_F_SECONDARY) continue;
+        if (!depth[r->tid]) depth[r->tid] = (int32_t*)calloc(tlen[r->tid] + 1, 4);
+        int32_t t = r->ts;
+        for (int32_t z = 0; z < r->n_cigar; ++z) {
+            uint32_t c = cigars[r->cigar_off + z]; int op = c & 0xf, l = c >> 4;
+            if (op == 0) { for (int x = 0; x < l; ++x) ++depth[r->tid][t + x]; t += l; }
+            else if (op == 2) t += l;
+        }
+    }
+    for (int32_t v = 0; v < n_iv; ++v) {
+        int32_t s = iv_s[v], e = iv_e[v], tid = iv_tid[v], L = tlen[tid];
+        /* -aa prints every position of the region that exists on the target */
+        if (s < 0) s = 0;
+        if (e > L - 1) e = L - 1;
+        int32_t n = e - s + 1;
+        if (n <= 0) { out[v] = NAN; continue; }
+        int32_t *a = (int32_t*)malloc(4 * n);
+        for (int32_t x = 0; x < n; ++x) { a[x] = depth[tid] ? depth[tid][s + x] : 0; if (a[x] > DEPTH_CAP) a[x] = DEPTH_CAP; }
+        qsort(a, n, 4, cmp_u32);
+        out[v] = (n & 1) ? (double)a[n / 2] : ((double)a[n / 2 - 1] + (double)a[n / 2]) / 2.0;
+        free(a);
+    }
+    for (int32_t i = 0; i < n_targets; ++i) free(depth[i]);
+    free(depth);
+}

@@ -1,0 +1,65 @@
+"""ctypes binding of libtelrhip.so (include/telr_hip.h).  There is no CPU fallback:
+if the HIP library is missing or no device is usable, calls raise."""
+import ctypes as C
+import os
+from ._abi import IdxOpt, MapOpt, Aln, Counters, N_STAGES
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtelrhip.so")
+
+EXPORTS = [
+    "telr_init", "telr_destroy", "telr_strerror", "telr_last_error", "telr_device_name", "telr_preset",
+    "telr_seqset_create", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
+    "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
+    "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_free",
+    "telr_depth_medians", "telr_stage_ms", "telr_stage_name", "telr_last_counters",
+]
+
+_lib = None
+
+
+class TelrError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise TelrError("libtelrhip.so is not built (run `python -m telr_amd.build`); there is no CPU fallback")
+    L = C.CDLL(SO_PATH)
+    vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
+    L.telr_init.restype = C.c_int; L.telr_init.argtypes = [C.c_int, C.POINTER(vp)]
+    L.telr_destroy.restype = None; L.telr_destroy.argtypes = [vp]
+    L.telr_strerror.restype = cp; L.telr_strerror.argtypes = [C.c_int]
+    L.telr_last_error.restype = cp; L.telr_last_error.argtypes = [vp]
+    L.telr_device_name.restype = C.c_int; L.telr_device_name.argtypes = [vp, cp, C.c_int]
+    L.telr_preset.restype = C.c_int; L.telr_preset.argtypes = [cp, C.POINTER(IdxOpt), C.POINTER(MapOpt)]
+    L.telr_seqset_create.restype = C.c_int; L.telr_seqset_create.argtypes = [vp, i32, vp, vp, vp, C.POINTER(vp)]
+    L.telr_seqset_free.restype = None; L.telr_seqset_free.argtypes = [vp]
+    L.telr_seqset_bases.restype = i64; L.telr_seqset_bases.argtypes = [vp]
+    L.telr_seqset_count.restype = i32; L.telr_seqset_count.argtypes = [vp]
+    L.telr_index_build.restype = C.c_int; L.telr_index_build.argtypes = [vp, vp, C.POINTER(IdxOpt), C.POINTER(vp)]
+    L.telr_index_free.restype = None; L.telr_index_free.argtypes = [vp]
+    L.telr_index_stats.restype = C.c_int; L.telr_index_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.telr_map.restype = C.c_int; L.telr_map.argtypes = [vp, vp, vp, vp, C.POINTER(MapOpt), C.POINTER(vp)]
+    L.telr_result_count.restype = i64; L.telr_result_count.argtypes = [vp]
+    L.telr_result_alns.restype = vp; L.telr_result_alns.argtypes = [vp]
+    L.telr_result_cigar_count.restype = i64; L.telr_result_cigar_count.argtypes = [vp]
+    L.telr_result_cigars.restype = vp; L.telr_result_cigars.argtypes = [vp]
+    L.telr_result_free.restype = None; L.telr_result_free.argtypes = [vp]
+    L.telr_depth_medians.restype = C.c_int
+    L.telr_depth_medians.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    L.telr_stage_ms.restype = C.c_int; L.telr_stage_ms.argtypes = [vp, vp]
+    L.telr_stage_name.restype = cp; L.telr_stage_name.argtypes = [C.c_int]
+    L.telr_last_counters.restype = C.c_int; L.telr_last_counters.argtypes = [vp, C.POINTER(Counters)]
+    # debug taps (not part of the public header; used by the stage-level parity tests)
+    L.telr_debug_n_anchor.restype = i64; L.telr_debug_n_anchor.argtypes = [vp]
+    L.telr_debug_fetch.restype = C.c_int; L.telr_debug_fetch.argtypes = [vp, cp, vp, i64]
+    L.telr_debug_n_chain.restype = i64; L.telr_debug_n_chain.argtypes = [vp]
+    L.telr_debug_chains.restype = vp; L.telr_debug_chains.argtypes = [vp]
+    L.telr_debug_index.restype = C.c_int; L.telr_debug_index.argtypes = [vp, vp, vp, vp, vp]
+    L.telr_debug_mid_occ.restype = i32; L.telr_debug_mid_occ.argtypes = [vp, C.POINTER(MapOpt)]
+    _lib = L
+    return L

@@ -1,0 +1,196 @@
+"""Object layer over the C ABI: Engine (context), SeqSet, Index, MapResult.
+
+This is the in-process replacement of the reference's `subprocess.call(["minimap2", ...])`
+boundary (TELR_alignment.py:69-82 and the five other sites listed in include/telr_hip.h).
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._abi import IdxOpt, MapOpt, Counters, ALN_DTYPE, N_STAGES
+from .fasta import concat
+
+
+def _np_from(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    dt = np.dtype(dtype)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+
+class Engine:
+    """One per process per device."""
+
+    def __init__(self, device=0):
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.telr_init(device, C.byref(h))
+        if rc != 0:
+            raise _lib.TelrError("telr_init(%d): %s" % (device, self.L.telr_strerror(rc).decode()))
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise _lib.TelrError("%s: %s [%s]" % (what, self.L.telr_strerror(rc).decode(),
+                                                  self.L.telr_last_error(self.h).decode()))
+
+    def device_name(self):
+        b = C.create_string_buffer(256)
+        self.L.telr_device_name(self.h, b, 256)
+        return b.value.decode()
+
+    def seqset(self, seqs):
+        return SeqSet(self, seqs)
+
+    def index(self, targets, io):
+        return Index(self, targets, io)
+
+    def stage_ms(self):
+        a = np.zeros(N_STAGES, np.float32)
+        self.L.telr_stage_ms(self.h, a.ctypes.data)
+        return {self.L.telr_stage_name(i).decode(): float(a[i]) for i in range(N_STAGES)}
+
+    def counters(self):
+        c = Counters()
+        self.L.telr_last_counters(self.h, C.byref(c))
+        return {k: getattr(c, k) for k, _ in Counters._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.telr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SeqSet:
+    def __init__(self, eng, seqs):
+        self.eng = eng
+        if isinstance(seqs, tuple) and len(seqs) == 3:
+            buf, off, ln = seqs
+        else:
+            buf, off, ln = concat(seqs)
+        self.len = np.ascontiguousarray(ln, dtype=np.int32)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        h = C.c_void_p()
+        eng._chk(eng.L.telr_seqset_create(eng.h, len(self.len), buf.ctypes.data, off.ctypes.data, self.len.ctypes.data,
+                                          C.byref(h)), "telr_seqset_create")
+        self.h = h
+        self.n = len(self.len)
+
+    def bases(self):
+        return int(self.eng.L.telr_seqset_bases(self.h))
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.eng.L.telr_seqset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MapResult:
+    def __init__(self, alns, cigars):
+        self.alns = alns
+        self.cigars = cigars
+
+    def cigar(self, i):
+        a = self.alns[i]
+        return self.cigars[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]]
+
+    def cigar_string(self, i):
+        return "".join("%d%s" % (c >> 4, "MID"[c & 0xf]) for c in self.cigar(i))
+
+
+class Index:
+    def __init__(self, eng, targets, io):
+        self.eng = eng
+        self.targets = targets if isinstance(targets, SeqSet) else SeqSet(eng, targets)
+        self.io = io
+        h = C.c_void_p()
+        eng._chk(eng.L.telr_index_build(eng.h, self.targets.h, C.byref(io), C.byref(h)), "telr_index_build")
+        self.h = h
+
+    def stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.eng.L.telr_index_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def map_raw(self, queries, mo, qtarget=None):
+        """-> opaque result handle (caller frees with free_raw)."""
+        q = queries if isinstance(queries, SeqSet) else SeqSet(self.eng, queries)
+        qt = None if qtarget is None else np.ascontiguousarray(qtarget, dtype=np.int32)
+        r = C.c_void_p()
+        self.eng._chk(self.eng.L.telr_map(self.eng.h, self.h, q.h, None if qt is None else qt.ctypes.data,
+                                          C.byref(mo), C.byref(r)), "telr_map")
+        return r
+
+    def free_raw(self, r):
+        self.eng.L.telr_result_free(r)
+
+    def result_arrays(self, r):
+        L = self.eng.L
+        alns = _np_from(L.telr_result_alns(r), L.telr_result_count(r), ALN_DTYPE)
+        cig = _np_from(L.telr_result_cigars(r), L.telr_result_cigar_count(r), np.uint32)
+        return MapResult(alns, cig)
+
+    def map(self, queries, mo, qtarget=None):
+        r = self.map_raw(queries, mo, qtarget)
+        try:
+            return self.result_arrays(r)
+        finally:
+            self.free_raw(r)
+
+    def depth_medians(self, r, iv_tid, iv_s, iv_e):
+        """Medians over 0-based inclusive intervals, from a raw result handle."""
+        tl = self.targets.len
+        a, b, c = (np.ascontiguousarray(x, dtype=np.int32) for x in (iv_tid, iv_s, iv_e))
+        out = np.zeros(len(a), np.float64)
+        self.eng._chk(self.eng.L.telr_depth_medians(self.eng.h, r, len(tl), tl.ctypes.data, len(a), a.ctypes.data,
+                                                    b.ctypes.data, c.ctypes.data, out.ctypes.data), "telr_depth_medians")
+        return out
+
+    # ---- debug taps for the stage-level parity tests ----------------------------------
+    def debug_dump(self):
+        L = self.eng.L
+        n_mz, n_ent = self.stats()
+        eh = np.zeros(n_ent, np.uint64); eo = np.zeros(n_ent + 1, np.uint32); pos = np.zeros(n_mz, np.uint32)
+        self.eng._chk(L.telr_debug_index(self.eng.h, self.h, eh.ctypes.data, eo.ctypes.data, pos.ctypes.data), "debug_index")
+        return eh, eo, pos
+
+    def debug_mid_occ(self, mo):
+        return int(self.eng.L.telr_debug_mid_occ(self.h, C.byref(mo)))
+
+    def debug_last_batch(self, nq):
+        L = self.eng.L
+        na = int(L.telr_debug_n_anchor(self.eng.h))
+        out = {}
+        for name, dt, n in (("skeys", np.uint64, na), ("chain_f", np.int32, na), ("chain_p", np.int32, na), ("q_aoff", np.int32, nq + 1)):
+            a = np.zeros(n, dt)
+            if n:
+                self.eng._chk(L.telr_debug_fetch(self.eng.h, name.encode(), a.ctypes.data, a.nbytes), "debug_fetch " + name)
+            out[name] = a
+        nc = int(L.telr_debug_n_chain(self.eng.h))
+        out["chains"] = _np_from(L.telr_debug_chains(self.eng.h), nc * 9, np.int32).reshape(-1, 9)
+        return out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.eng.L.telr_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

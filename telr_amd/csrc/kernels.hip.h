@@ -1,0 +1,721 @@
+// kernels.hip.h — gfx950 device code of the TELR alignment engine.
+//
+// Everything here is integer / byte work bounded by HBM and LDS traffic (no MFMA by
+// design: scoring is integer DP, not a dense contraction).  Data layout:
+//   * sequences: 2 bits/base in uint32 words (16 bases per word, base p at bits 2*(p&15)),
+//     plus an ambiguity bitmask (1 bit/base, 32 per word); every sequence starts at a
+//     64-base (16-byte) boundary so tiles are read with aligned, coalesced loads;
+//   * minimizers: SoA  x (u64 hash<<8|span)  /  y (u32 pos<<1|strand);
+//   * index: distinct hashes (u64, ascending) + u32 offsets into a u32 position array,
+//     addressed through a direct bucket table on the top hash bits;
+//   * anchors: ONE sortable u64 per anchor (strand | global target pos | query pos | span),
+//     half the footprint of the classic 16-byte anchor, so seeding, sorting and chaining
+//     each move 8 B per anchor;
+//   * DP: anti-diagonal sweep, one wave per problem, DP state in LDS, one trace-back byte
+//     per cell streamed to an HBM scratch row [a][slot] (coalesced 32-64 B per step).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TELR_NEG      (-(1 << 28))
+#define TELR_TPAD     16384
+#define SK_TILE       1024          // minimizer slots per sketch tile
+#define SK_THREADS    256
+#define DP_DMAX       4096          // widest band (diagonals) the DP kernel accepts
+
+struct ChainOpt {            // subset of telr_map_opt the device needs
+    int32_t max_gap, bw, min_cnt, min_chain_score, chain_gap_q8, chain_skip_q8;
+};
+struct DpOpt {
+    int32_t a, b, q, e, q2, e2, sc_ambi, zdrop;
+};
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+__device__ __forceinline__ uint64_t d_hash64(uint64_t key, uint64_t mask)
+{
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+
+// nb (<=28) bases starting at base index b, first base in the LOW bits
+__device__ __forceinline__ uint64_t d_get_bases(const uint32_t *__restrict__ seq2, int64_t b, int nb)
+{
+    int64_t w = b >> 4; int sh = (int)(b & 15) * 2;
+    uint64_t lo = (uint64_t)seq2[w] | (uint64_t)seq2[w + 1] << 32;
+    uint64_t hi = seq2[w + 2];
+    uint64_t v = lo >> sh;
+    if (sh) v |= hi << (64 - sh);
+    return v & ((1ULL << 2 * nb) - 1);
+}
+__device__ __forceinline__ uint32_t d_get_nbits(const uint32_t *__restrict__ nm, int64_t b, int nb)
+{
+    int64_t w = b >> 5; int sh = (int)(b & 31);
+    uint64_t v = ((uint64_t)nm[w] | (uint64_t)nm[w + 1] << 32) >> sh;
+    return (uint32_t)(v & ((1ULL << nb) - 1));
+}
+__device__ __forceinline__ int d_base(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nm, int64_t b)
+{
+    int c = (seq2[b >> 4] >> ((int)(b & 15) * 2)) & 3;
+    return ((nm[b >> 5] >> (int)(b & 31)) & 1) ? 4 : c;
+}
+// reverse the order of the 2-bit groups of the low 2k bits
+__device__ __forceinline__ uint64_t d_rev2(uint64_t v, int k)
+{
+    uint64_t r = __brevll(v) >> (64 - 2 * k);
+    return ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
+}
+
+// ---------------------------------------------------------------------------------------
+// 1. minimizer sketch (non-HPC): one block per tile of SK_TILE slots.
+//    mode 0: count selected slots per tile; mode 1: write (x,y) at tile_off[t].
+//    Selection rule (oracle sketch()): slot u selected iff valid and the run of slots
+//    around u whose x >= x_u is at least min(w, nslots) long.
+struct SketchArgs {
+    const uint32_t *seq2, *nmask;
+    const int64_t *boff;       // base offset of each sequence in the packed arrays
+    const int32_t *len;
+    const uint32_t *goff;      // global coordinate offsets (index build) or nullptr (queries: 0)
+    const int32_t *tile_seq, *tile_u0;
+    int32_t k, w;
+    int32_t *tile_cnt;         // mode 0 out
+    const int32_t *tile_off;   // mode 1 in (exclusive scan of tile_cnt)
+    uint64_t *out_x; uint32_t *out_y;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int halo = A.w - 1, nslot = SK_TILE + 2 * halo;
+    uint64_t *xs = (uint64_t*)smem;
+    uint8_t *zs = (uint8_t*)(xs + nslot);
+    __shared__ int32_t wsum[SK_THREADS / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int sid = A.tile_seq[t], u0 = A.tile_u0[t];
+    const int L = A.len[sid], ns = L - A.k + 1, k = A.k;
+    const int64_t base = A.boff[sid];
+    const uint64_t mask = (1ULL << 2 * k) - 1;
+    for (int s = tid; s < nslot; s += SK_THREADS) {
+        int u = u0 - halo + s;
+        uint64_t x = UINT64_MAX; uint8_t z = 0;
+        if (u >= 0 && u < ns) {
+            uint32_t nb = d_get_nbits(A.nmask, base + u, k);
+            if (nb == 0) {
+                uint64_t v = d_get_bases(A.seq2, base + u, k);
+                uint64_t fw = d_rev2(v, k), rv = (~v) & mask;
+                if (fw != rv) {
+                    z = fw < rv ? 0 : 1;
+                    x = d_hash64(z ? rv : fw, mask) << 8 | (uint64_t)k;
+                }
+            }
+        }
+        xs[s] = x; zs[s] = z;
+    }
+    __syncthreads();
+    const int need = A.w < ns ? A.w : ns;
+    uint32_t sel = 0;
+#pragma unroll
+    for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
+        int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
+        uint64_t x = xs[s];
+        if (u < ns && x != UINT64_MAX) {
+            int Lc = 0, Rc = 0;
+            while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
+            while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
+            if (Lc + Rc + 1 >= need) sel |= 1u << c;
+        }
+    }
+    int cnt = __popc(sel);
+    // block exclusive scan of cnt (wave scan + cross-wave in LDS)
+    int lane = tid & 63, wv = tid >> 6, inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SK_THREADS / 64; ++i) { if (i < wv) wbase += wsum[i]; total += wsum[i]; }
+    if (MODE == 0) {
+        if (tid == 0) A.tile_cnt[t] = total;
+    } else {
+        int o = A.tile_off[t] + wbase + inc - cnt;
+        uint32_t g0 = A.goff ? A.goff[sid] : 0u;
+#pragma unroll
+        for (int c = 0; c < SK_TILE / SK_THREADS; ++c) if (sel >> c & 1) {
+            int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
+            A.out_x[o] = xs[s];
+            A.out_y[o] = (g0 + (uint32_t)(u + k - 1)) << 1 | zs[s];
+            ++o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 2. index build helpers
+__global__ void k_head_flags(const uint64_t *__restrict__ h, int64_t n, int32_t *__restrict__ flag)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || h[i] != h[i - 1]) ? 1 : 0;
+}
+__global__ void k_write_entries(const uint64_t *__restrict__ h, const int32_t *__restrict__ flag, const int32_t *__restrict__ rank,
+                                int64_t n, uint64_t *__restrict__ ent_hash, uint32_t *__restrict__ ent_off, int32_t n_ent)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) { ent_hash[rank[i]] = h[i]; ent_off[rank[i]] = (uint32_t)i; }
+    if (i == 0) ent_off[n_ent] = (uint32_t)n;
+}
+__global__ void k_ent_counts(const uint32_t *__restrict__ ent_off, int32_t n_ent, uint32_t *__restrict__ cnt)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ent) cnt[i] = ent_off[i + 1] - ent_off[i];
+}
+// bstart[b] = first entry whose bucket >= b, for b in [0, nb]
+__global__ void k_bucket_table(const uint64_t *__restrict__ ent_hash, int32_t n_ent, int shift, uint32_t nb, uint32_t *__restrict__ bstart)
+{
+    int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e > n_ent) return;
+    uint32_t lo = e == 0 ? 0u : (uint32_t)(ent_hash[e - 1] >> shift) + 1u;
+    uint32_t hi = e == n_ent ? nb : (uint32_t)(ent_hash[e] >> shift);
+    for (uint32_t b = lo; b <= hi; ++b) bstart[b] = (uint32_t)e;
+}
+
+struct IndexView {
+    const uint64_t *ent_hash; const uint32_t *ent_off; const uint32_t *pos; const uint32_t *bstart;
+    const uint32_t *goff; const int32_t *tlen;
+    int32_t n_ent; int32_t shift; int32_t k, w;
+};
+
+__device__ __forceinline__ int32_t d_lookup(const IndexView &I, uint64_t h)
+{
+    uint32_t b = (uint32_t)(h >> I.shift);
+    uint32_t lo = I.bstart[b], hi = I.bstart[b + 1];
+    for (uint32_t e = lo; e < hi; ++e) if (I.ent_hash[e] == h) return (int32_t)e;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------------------
+// 3. seeding: one block per query.  MODE 0 counts anchors per minimizer, MODE 1 writes keys.
+struct SeedArgs {
+    IndexView I;
+    const uint64_t *mz_x; const uint32_t *mz_y;
+    const int32_t *q_mzoff;      // [nq+1]
+    const int32_t *qlen;
+    const int32_t *qtarget;      // nullable
+    int32_t mid_occ;
+    int32_t *mz_cnt;             // MODE 0 out
+    const int32_t *mz_aoff;      // MODE 1 in
+    uint64_t *keys;              // MODE 1 out
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_seed(SeedArgs A)
+{
+    const int q = blockIdx.x;
+    const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
+    const int tf = A.qtarget ? A.qtarget[q] : -1;
+    uint32_t g0 = 0, g1 = 0xffffffffu;
+    if (tf >= 0) { g0 = A.I.goff[tf]; g1 = g0 + (uint32_t)A.I.tlen[tf]; }
+    const int qlen = A.qlen[q];
+    for (int g = m0 + threadIdx.x; g < m1; g += blockDim.x) {
+        uint64_t x = A.mz_x[g];
+        int32_t e = d_lookup(A.I, x >> 8);
+        int32_t cnt = 0; uint32_t o0 = 0, o1 = 0;
+        if (e >= 0) {
+            o0 = A.I.ent_off[e]; o1 = A.I.ent_off[e + 1];
+            if (tf >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t gp = A.I.pos[o] >> 1; cnt += (gp >= g0 && gp < g1) ? 1 : 0; } }
+            else cnt = (int32_t)(o1 - o0);
+            if (cnt > A.mid_occ) cnt = 0;
+        }
+        if (MODE == 0) A.mz_cnt[g] = cnt;
+        else if (cnt > 0) {
+            uint32_t y = A.mz_y[g];
+            int32_t span = (int32_t)(x & 0xff), qpos = (int32_t)(y >> 1), qz = (int32_t)(y & 1);
+            uint64_t kf = (uint64_t)qpos << 8 | (uint64_t)span;
+            uint64_t kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
+            int32_t w = A.mz_aoff[g];
+            for (uint32_t o = o0; o < o1; ++o) {
+                uint32_t py = A.I.pos[o], gp = py >> 1;
+                if (tf >= 0 && (gp < g0 || gp >= g1)) continue;
+                A.keys[w++] = ((int)(py & 1) == qz ? kf : kr) | (uint64_t)gp << 32;
+            }
+        }
+    }
+}
+
+__global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t n, int32_t tail, int32_t *__restrict__ dst)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+    if (i == n) dst[n] = tail;
+}
+
+// ---------------------------------------------------------------------------------------
+// 4. chaining.  f(i) = max(span_i, max_{i-H<=j<i} f(j) + sc(j,i)), largest j among ties.
+//    One wave per query, "forward push": lane l owns the anchors i == l (mod 64) of the
+//    next R*64 indices in registers; at step j the owner lane publishes (key_j, f_j) by a
+//    lane read and every lane scores its own anchors against j.  No LDS, no reduction.
+#define A_G(k)    ((int32_t)(((k) >> 32) & 0x7fffffff))
+#define A_Q(k)    ((int32_t)(((k) >> 8) & 0xffffff))
+#define A_SPAN(k) ((int32_t)((k) & 0xff))
+
+__device__ __forceinline__ int32_t d_ilog2_q8(uint32_t v)
+{
+    int e = 31 - __clz((int)v);
+    uint32_t frac = e <= 8 ? (v << (8 - e)) - 256u : (v >> (e - 8)) - 256u;
+    return e * 256 + (int32_t)frac;
+}
+__device__ __forceinline__ int32_t d_chain_sc(uint64_t ai, uint64_t aj, const ChainOpt &o)
+{
+    if ((ai >> 63) != (aj >> 63)) return INT32_MIN;
+    int32_t dr = A_G(ai) - A_G(aj), dq = A_Q(ai) - A_Q(aj);
+    if (dq <= 0 || dq > o.max_gap) return INT32_MIN;
+    if (dr <= 0 || dr > o.max_gap) return INT32_MIN;
+    int32_t dd = dr > dq ? dr - dq : dq - dr;
+    if (dd > o.bw) return INT32_MIN;
+    int32_t dg = dr < dq ? dr : dq;
+    int32_t span = A_SPAN(ai);
+    int32_t sc = span < dg ? span : dg;
+    if (dd || dg > span) {
+        int32_t pen = o.chain_gap_q8 * dd + o.chain_skip_q8 * dg + (dd >= 1 ? d_ilog2_q8((uint32_t)dd + 1) >> 1 : 0);
+        sc -= pen >> 8;
+    }
+    return sc;
+}
+__device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int lane)
+{
+    uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (uint64_t)hi << 32 | lo;
+}
+
+template <int R>
+__global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
+                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p)
+{
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int lane = threadIdx.x;
+    const int64_t base = q_aoff[q];
+    const int n = q_aoff[q + 1] - q_aoff[q];
+    const uint64_t *a = keys + base;
+    uint64_t key[R]; int32_t best[R], bp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int i = r * 64 + lane;
+        key[r] = i < n ? a[i] : 0; best[r] = A_SPAN(key[r]); bp[r] = -1;
+    }
+    for (int jb = 0; jb < n; jb += 64 * R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int j0 = jb + r * 64;
+            if (j0 >= n) break;
+            // prefetch the key that replaces this slot once its anchor is final
+            const int inext = j0 + 64 * R + lane;
+            const uint64_t knext = inext < n ? a[inext] : 0;
+            int32_t myf = 0, myp = -1;
+            const int jn = n - j0 < 64 ? n - j0 : 64;
+            for (int jj = 0; jj < jn; ++jj) {
+                const int j = j0 + jj;
+                const uint64_t kj = d_readlane64(key[r], jj);
+                const int32_t fj = __builtin_amdgcn_readlane(best[r], jj);
+                if (lane == jj) { myf = best[r]; myp = bp[r]; key[r] = knext; best[r] = A_SPAN(knext); bp[r] = -1; }
+#pragma unroll
+                for (int s = 0; s < R; ++s) {
+                    // anchors currently owned: index > j and <= j + 64R by construction
+                    int32_t sc = d_chain_sc(key[s], kj, o);
+                    if (sc != INT32_MIN && key[s] != 0) {
+                        int32_t v = fj + sc;
+                        if (v > best[s] || (v == best[s] && bp[s] >= 0)) { best[s] = v; bp[s] = j; }
+                    }
+                }
+            }
+            if (lane < jn) { f[base + j0 + lane] = myf; p[base + j0 + lane] = myp; }
+        }
+    }
+}
+
+// peaks: anchors with no successor of larger f
+__global__ void k_nonpeak(const int32_t *__restrict__ q_aoff, const int32_t *__restrict__ f, const int32_t *__restrict__ p, uint8_t *__restrict__ nonpeak)
+{
+    const int q = blockIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int pj = p[base + i];
+        if (pj >= 0 && f[base + i] > f[base + pj]) nonpeak[base + pj] = 1;
+    }
+}
+__global__ void k_peaks(const int32_t *__restrict__ q_aoff, const int32_t *__restrict__ f, const uint8_t *__restrict__ nonpeak,
+                        int32_t min_sc, uint64_t *__restrict__ pk, int32_t *__restrict__ n_peaks, int32_t *__restrict__ pk_end)
+{
+    __shared__ int32_t cnt;
+    const int q = blockIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (!nonpeak[base + i] && f[base + i] >= min_sc) {
+            int s = atomicAdd(&cnt, 1);
+            pk[base + s] = (uint64_t)(uint32_t)(0x7fffffff - f[base + i]) << 32 | (uint32_t)i;   // ascending == (f desc, i asc)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { n_peaks[q] = cnt; pk_end[q] = (int32_t)base + cnt; }
+}
+
+struct ChainRec { int32_t score, cnt, a_off, pad; uint64_t a0, a1; };   // 32 B
+
+// back-tracking: one thread per query walks its sorted peaks (pointer chase; the steps stay
+// within the look-back window so the touched lines are L1/L2 resident)
+__global__ void k_backtrack(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
+                            const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
+                            const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
+                            uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t base = q_aoff[q];
+    const int np = n_peaks[q];
+    int nch = 0, wr = 0;
+    ChainRec *out = rec + ch_off[q];
+    for (int t = 0; t < np; ++t) {
+        int i = (int)(uint32_t)(pk[base + t] & 0xffffffffu);
+        if (vis[base + i]) continue;
+        int cnt = 0, j = i;
+        while (j >= 0 && !vis[base + j]) { vis[base + j] = 1; ++cnt; j = p[base + j]; }
+        int sc = f[base + i] - (j >= 0 ? f[base + j] : 0);
+        if (sc < min_sc || cnt < min_cnt) continue;
+        j = i;
+        for (int z = cnt - 1; z >= 0; --z) { canch[base + wr + z] = keys[base + j]; j = p[base + j]; }
+        ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr; r.pad = 0;
+        r.a0 = canch[base + wr]; r.a1 = canch[base + wr + cnt - 1];
+        out[nch++] = r; wr += cnt;
+    }
+    n_chains[q] = nch;
+}
+
+// ---------------------------------------------------------------------------------------
+// 5. DP problems
+struct KeptChain {          // uploaded by the host after chain selection
+    int32_t qid, tid, rev, cnt;
+    int64_t a_glob;         // offset of the chain's anchors in canch
+    int32_t rs, qs, re, qe; // chain box: target-local / strand-adjusted query
+    int32_t qlen, tlen;
+    int64_t qbase, tbase;   // packed base offsets of query / target
+    uint32_t goff; int32_t pad;
+};
+struct DpProb {             // 64 B
+    int64_t qi0, ti0;       // absolute packed base index of DP base 0
+    int64_t tb_off;         // byte offset into the trace-back scratch
+    int64_t cig_off;        // op offset into the raw cigar scratch
+    int32_t m, n, dlo, dhi;
+    int8_t qstep, tstep, qcomp, kind;   // kind 0 fill, 1 left ext, 2 right ext, 3 diagonal fallback
+    int32_t chain;          // kept-chain index
+    int32_t pad[2];
+};
+struct DpRes { int32_t score, bi, bj, nops, mlen, pad[3]; };   // 32 B
+
+__device__ __forceinline__ int d_fill_band(int m, int n, int bw)
+{
+    int mn = m < n ? m : n, W = 16 + (mn >> 4);
+    return W < bw ? W : bw;
+}
+
+// PASS 0: count problems per kept chain.  PASS 1: write descriptors.
+template <int PASS>
+__global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const uint64_t *__restrict__ canch,
+                           int32_t min_ksw_len, int32_t bw, int32_t ext_max, int32_t ext_band,
+                           int32_t *__restrict__ nprob, const int32_t *__restrict__ prob_off, DpProb *__restrict__ probs)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nk) return;
+    const KeptChain K = kc[c];
+    const uint64_t *ca = canch + K.a_glob;
+    int np = 0;
+    DpProb *out = PASS ? probs + prob_off[c] : nullptr;
+    const int go = (int)K.goff;
+    // left extension
+    if (K.qs > 0 && K.rs > 0) {
+        if (PASS) {
+            int mq = K.qs < ext_max ? K.qs : ext_max, mt = K.rs < mq + ext_band ? K.rs : mq + ext_band;
+            DpProb P; P.m = mq; P.n = mt; P.dlo = -ext_band; P.dhi = ext_band; P.kind = 1; P.chain = c;
+            P.tstep = -1; P.ti0 = K.tbase + K.rs - 1; P.qcomp = (int8_t)K.rev;
+            if (K.rev) { P.qstep = 1; P.qi0 = K.qbase + K.qlen - K.qs; } else { P.qstep = -1; P.qi0 = K.qbase + K.qs - 1; }
+            P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
+            out[np] = P;
+        }
+        ++np;
+    }
+    int lr = K.rs, lq = K.qs;
+    for (int i = 0; i < K.cnt; ++i) {
+        uint64_t a = ca[i];
+        int cr = A_G(a) - go + 1, cq = A_Q(a) + 1;
+        if (i == K.cnt - 1 || (cq - lq >= min_ksw_len && cr - lr >= min_ksw_len)) {
+            if (PASS) {
+                DpProb P; P.m = cq - lq; P.n = cr - lr; P.chain = c; P.kind = 0;
+                int W = d_fill_band(P.m, P.n, bw), dl = P.n - P.m;
+                P.dlo = (dl < 0 ? dl : 0) - W; P.dhi = (dl > 0 ? dl : 0) + W;
+                if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
+                P.tstep = 1; P.ti0 = K.tbase + lr; P.qcomp = (int8_t)K.rev;
+                if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - lq; } else { P.qstep = 1; P.qi0 = K.qbase + lq; }
+                P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
+                out[np] = P;
+            }
+            ++np; lr = cr; lq = cq;
+        }
+    }
+    if (K.qe < K.qlen && K.re < K.tlen) {
+        if (PASS) {
+            int rq = K.qlen - K.qe, rt = K.tlen - K.re;
+            int mq = rq < ext_max ? rq : ext_max, mt = rt < mq + ext_band ? rt : mq + ext_band;
+            DpProb P; P.m = mq; P.n = mt; P.dlo = -ext_band; P.dhi = ext_band; P.kind = 2; P.chain = c;
+            P.tstep = 1; P.ti0 = K.tbase + K.re; P.qcomp = (int8_t)K.rev;
+            if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - K.qe; } else { P.qstep = 1; P.qi0 = K.qbase + K.qe; }
+            P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
+            out[np] = P;
+        }
+        ++np;
+    }
+    if (!PASS) nprob[c] = np;
+}
+
+// per-problem scratch sizes (bytes of trace-back, ops of raw cigar) and DP class
+__device__ __forceinline__ int d_dp_class(int D) { return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4; }
+__global__ void k_prob_sizes(const DpProb *__restrict__ probs, int32_t np, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const DpProb P = probs[i];
+    int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
+    int64_t tb = P.kind == 3 ? 0 : ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
+    tb_bytes[i] = tb;
+    cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
+}
+__global__ void k_prob_assign(DpProb *__restrict__ probs, int32_t np, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ cig_off,
+                              int32_t *__restrict__ cls_cnt, int32_t *__restrict__ cls_list /* [5][np] */)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    probs[i].tb_off = tb_off[i]; probs[i].cig_off = cig_off[i];
+    int D = probs[i].dhi - probs[i].dlo + 1;
+    int c = probs[i].kind == 3 ? 0 : d_dp_class(D);
+    int s = atomicAdd(&cls_cnt[c], 1);
+    cls_list[(int64_t)c * np + s] = i;
+}
+
+// The DP kernel.  One wave per problem; DP state (H,E1,F1,E2,F2 per diagonal) in LDS,
+// updated in place anti-diagonal by anti-diagonal (cells of one anti-diagonal touch only
+// the other parity's diagonals, so the in-place update is race-free inside the wave).
+struct DpArgs {
+    const uint32_t *qseq2, *qnmask, *tseq2, *tnmask;
+    const DpProb *probs; const int32_t *list; int32_t nlist;
+    DpOpt o;
+    uint8_t *tb; uint32_t *cig; DpRes *res;
+    int32_t dcap;            // diagonals of LDS state per wave
+};
+
+__device__ __forceinline__ int64_t d_wave_max64(int64_t v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        int64_t w = (int64_t)((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)v, o) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)v >> 32), o) << 32);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64) k_dp(DpArgs A)
+{
+    extern __shared__ __align__(16) int32_t lds[];
+    const int pi = blockIdx.x;
+    if (pi >= A.nlist) return;
+    const int prob = A.list[pi];
+    const DpProb P = A.probs[prob];
+    const int lane = threadIdx.x;
+    const int m = P.m, n = P.n, dlo = P.dlo, dhi = P.dhi, D = dhi - dlo + 1, stride = (D + 2) / 2;
+    const DpOpt o = A.o;
+    const bool ext = P.kind == 1 || P.kind == 2;
+    DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.pad[0] = R.pad[1] = R.pad[2] = 0;
+
+    if (P.kind == 3) {
+        // band wider than the engine accepts: diagonal + one closing gap (oracle band_dp_fallback)
+        int mn = m < n ? m : n, sc = 0, ml = 0;
+        for (int x = lane; x < mn; x += 64) {
+            int qb = d_base(A.qseq2, A.qnmask, P.qi0 + (int64_t)P.qstep * x), tbv = d_base(A.tseq2, A.tnmask, P.ti0 + (int64_t)P.tstep * x);
+            if (P.qcomp && qb < 4) qb = 3 - qb;
+            if (qb > 3 || tbv > 3) sc -= o.sc_ambi; else if (qb == tbv) { sc += o.a; ++ml; } else sc -= o.b;
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) { sc += __shfl_xor(sc, s); ml += __shfl_xor(ml, s); }
+        int g = m > n ? m - n : n - m;
+        if (g) { int c1 = o.q + g * o.e, c2 = o.q2 + g * o.e2; sc -= c1 < c2 ? c1 : c2; }
+        if (lane == 0) {
+            int no = 0;
+            // emitted end -> start like the DP trace-back
+            if (g) A.cig[P.cig_off + no++] = (uint32_t)g << 4 | (m > n ? 1u : 2u);
+            if (mn) A.cig[P.cig_off + no++] = (uint32_t)mn << 4;
+            R.score = sc; R.bi = m; R.bj = n; R.nops = no; R.mlen = ml;
+            A.res[prob] = R;
+        }
+        return;
+    }
+
+    int32_t *H = lds, *E1 = H + (A.dcap + 2), *F1 = E1 + (A.dcap + 2), *E2 = F1 + (A.dcap + 2), *F2 = E2 + (A.dcap + 2);
+    for (int x = lane; x < D + 2; x += 64) { H[x] = TELR_NEG; E1[x] = TELR_NEG; F1[x] = TELR_NEG; E2[x] = TELR_NEG; F2[x] = TELR_NEG; }
+    __syncthreads();
+    if (lane == 0 && 0 >= dlo && 0 <= dhi) H[0 - dlo + 1] = 0;
+    __syncthreads();
+    uint8_t *tb = A.tb + P.tb_off;
+    int best = 0, bi = 0, bj = 0, prev_cur = TELR_NEG;
+    for (int a = 1; a <= m + n; ++a) {
+        int d0 = -a > dlo ? -a : dlo; if (a - 2 * m > d0) d0 = a - 2 * m;
+        int d1 = a < dhi ? a : dhi;   if (2 * n - a < d1) d1 = 2 * n - a;
+        if (((d0 - a) & 1) != 0) ++d0;
+        int64_t curk = INT64_MIN;
+        for (int d = d0 + 2 * lane; d <= d1; d += 128) {
+            const int i = (a - d) >> 1, j = (a + d) >> 1, x = d - dlo + 1;
+            int32_t h, ve1, vf1, ve2, vf2;
+            if (i == 0) {
+                ve1 = -(o.q + j * o.e); ve2 = -(o.q2 + j * o.e2); vf1 = vf2 = TELR_NEG;
+                h = ve1 > ve2 ? ve1 : ve2;
+            } else if (j == 0) {
+                vf1 = -(o.q + i * o.e); vf2 = -(o.q2 + i * o.e2); ve1 = ve2 = TELR_NEG;
+                h = vf1 > vf2 ? vf1 : vf2;
+            } else {
+                const int32_t hl = H[x - 1], hu = H[x + 1], hd = H[x];
+                uint32_t t = 0; int32_t op, g;
+                op = hl - o.q - o.e;   g = E1[x - 1] - o.e;  if (g > op) { ve1 = g; t |= 8; }  else ve1 = op;
+                op = hu - o.q - o.e;   g = F1[x + 1] - o.e;  if (g > op) { vf1 = g; t |= 16; } else vf1 = op;
+                op = hl - o.q2 - o.e2; g = E2[x - 1] - o.e2; if (g > op) { ve2 = g; t |= 32; } else ve2 = op;
+                op = hu - o.q2 - o.e2; g = F2[x + 1] - o.e2; if (g > op) { vf2 = g; t |= 64; } else vf2 = op;
+                int qb = d_base(A.qseq2, A.qnmask, P.qi0 + (int64_t)P.qstep * (i - 1));
+                int tbv = d_base(A.tseq2, A.tnmask, P.ti0 + (int64_t)P.tstep * (j - 1));
+                if (P.qcomp && qb < 4) qb = 3 - qb;
+                int sc;
+                if (qb > 3 || tbv > 3) sc = -o.sc_ambi; else if (qb == tbv) { sc = o.a; t |= 128; } else sc = -o.b;
+                h = hd + sc; uint32_t src = 0;
+                if (ve1 > h) { h = ve1; src = 1; }
+                if (vf1 > h) { h = vf1; src = 2; }
+                if (ve2 > h) { h = ve2; src = 3; }
+                if (vf2 > h) { h = vf2; src = 4; }
+                tb[(int64_t)a * stride + ((d - dlo) >> 1)] = (uint8_t)(t | src);
+            }
+            if (h < TELR_NEG) h = TELR_NEG;
+            if (ve1 < TELR_NEG) ve1 = TELR_NEG;
+            if (vf1 < TELR_NEG) vf1 = TELR_NEG;
+            if (ve2 < TELR_NEG) ve2 = TELR_NEG;
+            if (vf2 < TELR_NEG) vf2 = TELR_NEG;
+            H[x] = h; E1[x] = ve1; F1[x] = vf1; E2[x] = ve2; F2[x] = vf2;
+            // max h, smallest d among ties
+            int64_t kk = (int64_t)h * 4294967296LL + (int64_t)(0x7fffffff - (d - dlo));
+            curk = kk > curk ? kk : curk;
+        }
+        __syncthreads();   // single wave: orders the LDS writes of this step before the next step's reads
+        if (ext) {
+            curk = d_wave_max64(curk);
+            int cur = TELR_NEG, cur_d = 0;
+            if (curk != INT64_MIN) { cur = (int)(curk >> 32); cur_d = 0x7fffffff - (int)(curk & 0xffffffffLL) + dlo; }
+            if (cur > best) { best = cur; bi = (a - cur_d) >> 1; bj = (a + cur_d) >> 1; }
+            int c2 = cur > prev_cur ? cur : prev_cur;
+            if (best - c2 > o.zdrop) break;
+            prev_cur = cur;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int i, j;
+        if (ext) { R.score = best; i = bi; j = bj; }
+        else { R.score = H[(n - m) - dlo + 1]; i = m; j = n; }
+        R.bi = i; R.bj = j;
+        uint32_t *cg = A.cig + P.cig_off;
+        int no = 0, ml = 0, state = 0, cur_op = -1, cur_len = 0;
+        while (i > 0 && j > 0) {
+            // sc1 load: served from L2, never from a stale L1 line
+            uint32_t t = __hip_atomic_load(tb + (int64_t)(i + j) * stride + ((j - i - dlo) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (state == 0) state = t & 7;
+            int op;
+            if (state == 0) { op = 0; ml += (t >> 7) & 1; --i; --j; }
+            else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
+            else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
+            else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
+            else                 { op = 1; if (!(t & 64)) state = 0; --i; }
+            if (op == cur_op) ++cur_len;
+            else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
+        }
+        if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
+        if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
+        if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+        R.nops = no; R.mlen = ml;
+        A.res[prob] = R;
+    }
+}
+
+// compact the raw per-problem cigars (emission order preserved) into one dense array
+__global__ void k_cigar_gather(const DpProb *__restrict__ probs, const DpRes *__restrict__ res, const int64_t *__restrict__ dense_off,
+                               int32_t np, const uint32_t *__restrict__ raw, uint32_t *__restrict__ dense)
+{
+    const int pi = blockIdx.x;
+    if (pi >= np) return;
+    const int64_t so = probs[pi].cig_off, dofs = dense_off[pi];
+    const int no = res[pi].nops;
+    for (int x = threadIdx.x; x < no; x += blockDim.x) dense[dofs + x] = raw[so + x];
+}
+__global__ void k_res_nops(const DpRes *__restrict__ res, int32_t np, int64_t *__restrict__ nops)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) nops[i] = res[i].nops;
+}
+
+// ---------------------------------------------------------------------------------------
+// 6. depth medians (samtools depth -aa -r | statistics.median)
+struct DepthRec { int32_t tid, ts, n_cigar, pad; int64_t cigar_off; };
+__global__ void k_depth_diff(const DepthRec *__restrict__ recs, int32_t nrec, const uint32_t *__restrict__ cig,
+                             const int64_t *__restrict__ toff, int32_t *__restrict__ diff)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrec) return;
+    const DepthRec R = recs[r];
+    int32_t *d = diff + toff[R.tid];
+    int t = R.ts;
+    for (int z = 0; z < R.n_cigar; ++z) {
+        uint32_t c = cig[R.cigar_off + z]; int op = c & 0xf, l = c >> 4;
+        if (op == 0) { atomicAdd(&d[t], 1); atomicAdd(&d[t + l], -1); t += l; }
+        else if (op == 2) t += l;
+    }
+}
+#define DEPTH_CAP 8000
+__global__ void __launch_bounds__(256) k_depth_median(const int32_t *__restrict__ depth, const int64_t *__restrict__ toff, const int32_t *__restrict__ tlen,
+                                                      int32_t n_iv, const int32_t *__restrict__ iv_tid, const int32_t *__restrict__ iv_s,
+                                                      const int32_t *__restrict__ iv_e, double *__restrict__ out)
+{
+    __shared__ int32_t hist[DEPTH_CAP + 1];
+    const int v = blockIdx.x;
+    if (v >= n_iv) return;
+    const int tid = iv_tid[v], L = tlen[tid];
+    int s = iv_s[v], e = iv_e[v];
+    if (s < 0) s = 0;
+    if (e > L - 1) e = L - 1;
+    const int n = e - s + 1;
+    for (int x = threadIdx.x; x <= DEPTH_CAP; x += blockDim.x) hist[x] = 0;
+    __syncthreads();
+    const int32_t *d = depth + toff[tid];
+    for (int x = threadIdx.x; x < n; x += blockDim.x) { int c = d[s + x]; c = c > DEPTH_CAP ? DEPTH_CAP : c; atomicAdd(&hist[c], 1); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (n <= 0) { out[v] = __longlong_as_double(0x7ff8000000000000LL); return; }
+        // order statistics k1=(n-1)/2, k2=n/2 (0-based) from the histogram
+        int k1 = (n - 1) / 2, k2 = n / 2, acc = 0, v1 = -1, v2 = -1;
+        for (int x = 0; x <= DEPTH_CAP; ++x) {
+            acc += hist[x];
+            if (v1 < 0 && acc > k1) v1 = x;
+            if (v2 < 0 && acc > k2) { v2 = x; break; }
+        }
+        out[v] = ((double)v1 + (double)v2) / 2.0;
+    }
+}

@@ -1,0 +1,943 @@
+// telr_engine.hip — host runtime and C ABI (include/telr_hip.h) of the MI355X alignment
+// engine.  Pipeline of one telr_map() batch, all on one HIP stream:
+//   sketch -> seed (count/scan/fill) -> per-query radix sort -> chain DP -> peaks ->
+//   back-track -> [D2H chain boxes, host chain selection] -> DP problem list ->
+//   banded DP + trace-back -> cigar gather -> [D2H, host assembly + mapq].
+// Host steps carry the -N / -p / -M / --secondary semantics and never
+// touch bases; every base-level operation runs on the device.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/telr_hip.h"
+#include "kernels.hip.h"
+
+// ---------------------------------------------------------------------------------------
+static const char *STAGE_NAMES[TELR_N_STAGES] = {
+    "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "cigar_gather", "d2h", "assemble_host", "index_build"
+};
+enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX };
+
+struct DBuf { void *p = nullptr; size_t bytes = 0; };
+
+struct telr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
+    float stage_ms[TELR_N_STAGES] = {0};
+    telr_counters ctr = {};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char devname[256] = {0};
+    // debug captures of the last batch (device pointers stay valid until the next call)
+    int64_t dbg_na = 0; int32_t dbg_nq = 0;
+    std::vector<int32_t> dbg_chain;       // 9 ints per chain
+};
+
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
+    return _e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; } } while (0)
+#define TRY(expr) do { int _r = (expr); if (_r != TELR_OK) return _r; } while (0)
+
+static int ctx_buf(telr_ctx *ctx, const char *name, size_t bytes, void **out)
+{
+    DBuf &b = ctx->bufs[name];
+    if (b.bytes < bytes || !b.p) {
+        if (b.p) HIPCHK(hipFree(b.p));
+        b.p = nullptr; b.bytes = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return TELR_OK;
+}
+template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size_t n, T **out)
+{
+    void *p; TRY(ctx_buf(ctx, name, (n ? n : 1) * sizeof(T), &p)); *out = (T*)p; return TELR_OK;
+}
+
+struct StageTimer {
+    telr_ctx *ctx; int stage; bool gpu; std::chrono::steady_clock::time_point t0;
+    StageTimer(telr_ctx *c, int s, bool g) : ctx(c), stage(s), gpu(g) {
+        if (gpu) (void)hipEventRecord(ctx->ev0, ctx->stream); else t0 = std::chrono::steady_clock::now();
+    }
+    void stop() {
+        if (gpu) { (void)hipEventRecord(ctx->ev1, ctx->stream); (void)hipEventSynchronize(ctx->ev1); float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); ctx->stage_ms[stage] += ms; }
+        else ctx->stage_ms[stage] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+extern "C" const char *telr_strerror(int code)
+{
+    switch (code) {
+    case TELR_OK: return "ok";
+    case TELR_E_NODEVICE: return "no usable HIP device";
+    case TELR_E_HIP: return "HIP runtime error";
+    case TELR_E_ARG: return "invalid argument";
+    case TELR_E_RANGE: return "input exceeds the engine's coordinate range (targets < 2^31 bases, queries < 2^24 bases)";
+    case TELR_E_NOMEM: return "out of device memory";
+    default: return "unknown error";
+    }
+}
+extern "C" const char *telr_last_error(const telr_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+extern "C" const char *telr_stage_name(int i) { return i >= 0 && i < TELR_N_STAGES ? STAGE_NAMES[i] : ""; }
+extern "C" int telr_stage_ms(const telr_ctx *ctx, float *ms) { if (!ctx || !ms) return TELR_E_ARG; memcpy(ms, ctx->stage_ms, sizeof(ctx->stage_ms)); return TELR_OK; }
+extern "C" int telr_last_counters(const telr_ctx *ctx, telr_counters *out) { if (!ctx || !out) return TELR_E_ARG; *out = ctx->ctr; return TELR_OK; }
+
+extern "C" int telr_init(int device, telr_ctx **out)
+{
+    if (!out) return TELR_E_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TELR_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TELR_E_NODEVICE;
+    telr_ctx *ctx = new telr_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    *out = ctx;
+    return TELR_OK;
+}
+extern "C" void telr_destroy(telr_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+extern "C" int telr_device_name(const telr_ctx *ctx, char *buf, int buflen)
+{
+    if (!ctx || !buf || buflen <= 0) return TELR_E_ARG;
+    snprintf(buf, buflen, "%s", ctx->devname);
+    return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// presets (mirrors telr_amd/presets.py; tests/test_presets.py keeps them equal)
+extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
+{
+    if (!name || !io || !mo) return TELR_E_ARG;
+    std::string s(name);
+    io->k = 15; io->w = 10; io->is_hpc = 0; io->bucket_bits = 0;
+    memset(mo, 0, sizeof(*mo));
+    mo->mid_occ_frac = 2e-4f; mo->min_mid_occ = 10; mo->max_mid_occ = 1000000;
+    mo->max_gap = 5000; mo->bw = 500; mo->chain_lookback = 128; mo->min_cnt = 3; mo->min_chain_score = 40;
+    mo->mask_level = 0.5f; mo->pri_ratio = 0.8f; mo->best_n = 5; mo->secondary = 1;
+    mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
+    mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR;
+    if (s == "map-ont" || s == "ngmlr-ont") { }
+    else if (s == "map-pb" || s == "ngmlr-pacbio") { io->k = 19; io->is_hpc = 1; }
+    else if (s == "asm10") {
+        io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;
+        mo->a = 1; mo->b = 9; mo->q = 16; mo->e = 2; mo->q2 = 41; mo->e2 = 1; mo->min_dp_max = 200; mo->zdrop = 200; mo->best_n = 50;
+    } else return TELR_E_ARG;
+    mo->chain_gap_q8 = (int32_t)(0.01 * 0.8 * io->k * 256 + 0.5);
+    mo->chain_skip_q8 = 0;
+    return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// sequence sets
+struct telr_seqset {
+    telr_ctx *ctx;
+    int32_t n = 0;
+    int64_t total_bases = 0, padded_bases = 0;
+    std::vector<int64_t> boff;    // [n+1]
+    std::vector<int32_t> len;     // [n]
+    uint32_t *d_seq2 = nullptr, *d_nmask = nullptr;
+    int64_t *d_boff = nullptr; int32_t *d_len = nullptr;
+    int32_t max_len = 0;
+};
+
+static inline uint8_t nt4_of(unsigned char c)
+{
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                 case 'T': case 't': case 'U': case 'u': return 3; default: return 4; }
+}
+
+extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, const int64_t *off, const int32_t *len, telr_seqset **out)
+{
+    if (!ctx || n < 0 || !out || (n > 0 && (!ascii || !off || !len))) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    telr_seqset *s = new telr_seqset();
+    s->ctx = ctx; s->n = n; s->boff.resize(n + 1); s->len.assign(len, len + n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (len[i] < 0) { delete s; return TELR_E_ARG; }
+        s->boff[i] = tot; tot += ((int64_t)len[i] + 63) & ~63LL; s->total_bases += len[i];
+        if (len[i] > s->max_len) s->max_len = len[i];
+    }
+    s->boff[n] = tot; s->padded_bases = tot;
+    size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
+    std::vector<uint32_t> h2(w2, 0), hn(wn, 0);
+    int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (s->total_bases < (1 << 20)) nth = 1;
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
+        for (int i = t; i < n; i += nth) {
+            const unsigned char *p = (const unsigned char*)ascii + off[i];
+            int64_t b = s->boff[i];
+            for (int j = 0; j < len[i]; ++j) {
+                uint8_t c = nt4_of(p[j]); int64_t x = b + j;
+                if (c > 3) hn[x >> 5] |= 1u << (x & 31); else h2[x >> 4] |= (uint32_t)c << ((x & 15) * 2);
+            }
+        }
+    });
+    for (auto &t : th) t.join();
+    auto fail = [&](hipError_t e) { ctx->err = std::string("seqset upload: ") + hipGetErrorString(e); delete s; return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
+    hipError_t e;
+    if ((e = hipMalloc(&s->d_seq2, w2 * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(s->d_seq2, h2.data(), w2 * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(s->d_nmask, hn.data(), wn * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if (n && (e = hipMemcpy(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    *out = s;
+    return TELR_OK;
+}
+extern "C" void telr_seqset_free(telr_seqset *s)
+{
+    if (!s) return;
+    (void)hipFree(s->d_seq2); (void)hipFree(s->d_nmask); (void)hipFree(s->d_boff); (void)hipFree(s->d_len);
+    delete s;
+}
+extern "C" int64_t telr_seqset_bases(const telr_seqset *s) { return s ? s->total_bases : 0; }
+extern "C" int32_t telr_seqset_count(const telr_seqset *s) { return s ? s->n : 0; }
+
+// ---------------------------------------------------------------------------------------
+// rocPRIM plumbing (scans and sorts are library calls; the hot kernels are in kernels.hip.h)
+template <typename Tin, typename Tout>
+static int dev_exclusive_scan(telr_ctx *ctx, const Tin *in, Tout *out, size_t n)
+{
+    if (n == 0) return TELR_OK;
+    size_t tb = 0;
+    auto it = rocprim::make_transform_iterator(in, [] __device__(Tin v) { return (Tout)v; });
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, it, out, (Tout)0, n, rocprim::plus<Tout>(), ctx->stream));
+    void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+    HIPCHK(rocprim::exclusive_scan(tmp, tb, it, out, (Tout)0, n, rocprim::plus<Tout>(), ctx->stream));
+    return TELR_OK;
+}
+static int dev_inclusive_scan_i32(telr_ctx *ctx, int32_t *io, size_t n)
+{
+    if (n == 0) return TELR_OK;
+    size_t tb = 0;
+    HIPCHK(rocprim::inclusive_scan(nullptr, tb, io, io, n, rocprim::plus<int32_t>(), ctx->stream));
+    void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+    HIPCHK(rocprim::inclusive_scan(tmp, tb, io, io, n, rocprim::plus<int32_t>(), ctx->stream));
+    return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// tiles for the sketch kernel
+struct TileList { std::vector<int32_t> seq, u0, first; int32_t n = 0; };
+static void make_tiles(const telr_seqset *s, int32_t q0, int32_t q1, int k, TileList &T)
+{
+    T.seq.clear(); T.u0.clear(); T.first.assign(q1 - q0, 0);
+    for (int32_t q = q0; q < q1; ++q) {
+        T.first[q - q0] = (int32_t)T.seq.size();
+        int ns = s->len[q] - k + 1;
+        for (int u = 0; u < ns; u += SK_TILE) { T.seq.push_back(q); T.u0.push_back(u); }
+    }
+    T.n = (int32_t)T.seq.size();
+}
+
+// run the two-pass sketch over tiles; returns device arrays x,y (in ctx buffers named by prefix) and tile offsets
+static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, int k, int w, const uint32_t *d_goff, const char *prefix,
+                      uint64_t **d_x, uint32_t **d_y, int32_t **d_tile_off, int32_t *n_mz)
+{
+    std::string P(prefix);
+    int32_t *d_tseq, *d_tu0, *d_tcnt, *d_toff;
+    TRY(ctx_buf_t(ctx, (P + "tile_seq").c_str(), T.n + 1, &d_tseq));
+    TRY(ctx_buf_t(ctx, (P + "tile_u0").c_str(), T.n + 1, &d_tu0));
+    TRY(ctx_buf_t(ctx, (P + "tile_cnt").c_str(), T.n + 1, &d_tcnt));
+    TRY(ctx_buf_t(ctx, (P + "tile_off").c_str(), T.n + 1, &d_toff));
+    *n_mz = 0; *d_tile_off = d_toff;
+    if (T.n == 0) { TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), 1, d_x)); TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), 1, d_y)); return TELR_OK; }
+    HIPCHK(hipMemcpyAsync(d_tseq, T.seq.data(), T.n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_tu0, T.u0.data(), T.n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SketchArgs A;
+    A.seq2 = s->d_seq2; A.nmask = s->d_nmask; A.boff = s->d_boff; A.len = s->d_len; A.goff = d_goff;
+    A.tile_seq = d_tseq; A.tile_u0 = d_tu0; A.k = k; A.w = w; A.tile_cnt = d_tcnt; A.tile_off = nullptr; A.out_x = nullptr; A.out_y = nullptr;
+    size_t lds = (size_t)(SK_TILE + 2 * (w - 1)) * 9 + 16;
+    hipLaunchKernelGGL(k_sketch<0>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+    HIPCHK(hipGetLastError());
+    // exclusive scan over T.n+1 entries so that tile_off[T.n] = total
+    HIPCHK(hipMemsetAsync(d_tcnt + T.n, 0, 4, ctx->stream));
+    TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_tcnt, d_toff, (size_t)T.n + 1)));
+    HIPCHK(hipMemcpyAsync(n_mz, d_toff + T.n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), (size_t)*n_mz, d_x));
+    TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), (size_t)*n_mz, d_y));
+    A.tile_off = d_toff; A.out_x = *d_x; A.out_y = *d_y;
+    hipLaunchKernelGGL(k_sketch<1>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+    HIPCHK(hipGetLastError());
+    return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// index
+struct telr_index {
+    telr_ctx *ctx;
+    const telr_seqset *targets;
+    telr_idx_opt io;
+    std::vector<uint32_t> goff;          // [n+1]
+    int64_t n_mz = 0; int32_t n_ent = 0;
+    int32_t bucket_bits = 0, shift = 0;
+    uint64_t *d_ent_hash = nullptr; uint32_t *d_ent_off = nullptr, *d_pos = nullptr, *d_bstart = nullptr, *d_goff = nullptr;
+    std::vector<uint32_t> sorted_counts; // ascending, for the mid_occ quantile
+};
+
+extern "C" void telr_index_free(telr_index *ix)
+{
+    if (!ix) return;
+    (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff);
+    delete ix;
+}
+extern "C" int telr_index_stats(const telr_index *ix, int64_t *n_mz, int64_t *n_distinct)
+{
+    if (!ix) return TELR_E_ARG;
+    if (n_mz) *n_mz = ix->n_mz;
+    if (n_distinct) *n_distinct = ix->n_ent;
+    return TELR_OK;
+}
+
+static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx_opt *io, telr_index *ix)
+{
+    const int n = tg->n, k = io->k, w = io->w;
+    ix->ctx = ctx; ix->targets = tg; ix->io = *io;
+    ix->goff.resize(n + 1);
+    uint64_t g = 0;
+    for (int i = 0; i < n; ++i) { ix->goff[i] = (uint32_t)g; g = (g + (uint64_t)tg->len[i] + TELR_TPAD + 63) & ~63ULL; if (g >= (1ULL << 31)) return TELR_E_RANGE; }
+    ix->goff[n] = (uint32_t)g;
+    HIPCHK(hipMalloc(&ix->d_goff, (n + 1) * 4));
+    HIPCHK(hipMemcpy(ix->d_goff, ix->goff.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    TileList T; make_tiles(tg, 0, n, k, T);
+    uint64_t *d_x; uint32_t *d_y; int32_t *d_toff; int32_t nmz = 0;
+    TRY(run_sketch(ctx, tg, T, k, w, ix->d_goff, "ix_", &d_x, &d_y, &d_toff, &nmz));
+    ix->n_mz = nmz;
+    // hash = x >> 8 (in place), then stable radix sort by hash carrying y
+    uint64_t *d_h2; uint32_t *d_y2;
+    TRY(ctx_buf_t(ctx, "ix_h2", (size_t)nmz, &d_h2));
+    HIPCHK(hipMalloc(&ix->d_pos, ((size_t)nmz + 1) * 4));
+    d_y2 = ix->d_pos;
+    if (nmz > 0) {
+        auto hin = rocprim::make_transform_iterator(d_x, [] __device__(uint64_t v) { return v >> 8; });
+        size_t tb = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, hin, d_h2, d_y, d_y2, (size_t)nmz, 0, 2 * k, ctx->stream));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::radix_sort_pairs(tmp, tb, hin, d_h2, d_y, d_y2, (size_t)nmz, 0, 2 * k, ctx->stream));
+    }
+    // distinct entries
+    int32_t *d_flag, *d_rank;
+    TRY(ctx_buf_t(ctx, "ix_flag", (size_t)nmz + 1, &d_flag));
+    TRY(ctx_buf_t(ctx, "ix_rank", (size_t)nmz + 1, &d_rank));
+    int32_t n_ent = 0;
+    if (nmz > 0) {
+        hipLaunchKernelGGL(k_head_flags, dim3((nmz + 255) / 256), dim3(256), 0, ctx->stream, d_h2, (int64_t)nmz, d_flag);
+        HIPCHK(hipMemsetAsync(d_flag + nmz, 0, 4, ctx->stream));
+        TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_flag, d_rank, (size_t)nmz + 1)));
+        HIPCHK(hipMemcpyAsync(&n_ent, d_rank + nmz, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ix->n_ent = n_ent;
+    HIPCHK(hipMalloc(&ix->d_ent_hash, ((size_t)n_ent + 1) * 8));
+    HIPCHK(hipMalloc(&ix->d_ent_off, ((size_t)n_ent + 2) * 4));
+    if (nmz > 0) {
+        hipLaunchKernelGGL(k_write_entries, dim3((nmz + 255) / 256), dim3(256), 0, ctx->stream, d_h2, d_flag, d_rank, (int64_t)nmz, ix->d_ent_hash, ix->d_ent_off, n_ent);
+        HIPCHK(hipGetLastError());
+    } else HIPCHK(hipMemsetAsync(ix->d_ent_off, 0, 8, ctx->stream));
+    // bucket table on the top hash bits
+    int bb = io->bucket_bits;
+    if (bb <= 0) { bb = 10; while ((1LL << bb) < n_ent && bb < 28) ++bb; }
+    if (bb > 2 * k) bb = 2 * k;
+    ix->bucket_bits = bb; ix->shift = 2 * k - bb;
+    uint32_t nb = 1u << bb;
+    HIPCHK(hipMalloc(&ix->d_bstart, ((size_t)nb + 2) * 4));
+    hipLaunchKernelGGL(k_bucket_table, dim3((n_ent + 1 + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, n_ent, ix->shift, nb, ix->d_bstart);
+    HIPCHK(hipGetLastError());
+    // occurrence counts, sorted, to the host for the -f quantile
+    ix->sorted_counts.resize(n_ent);
+    if (n_ent > 0) {
+        uint32_t *d_c, *d_c2;
+        TRY(ctx_buf_t(ctx, "ix_cnt", (size_t)n_ent, &d_c));
+        TRY(ctx_buf_t(ctx, "ix_cnt2", (size_t)n_ent, &d_c2));
+        hipLaunchKernelGGL(k_ent_counts, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_off, n_ent, d_c);
+        size_t tb = 0;
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tb, d_c, d_c2, (size_t)n_ent, 0, 32, ctx->stream));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::radix_sort_keys(tmp, tb, d_c, d_c2, (size_t)n_ent, 0, 32, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ix->sorted_counts.data(), d_c2, (size_t)n_ent * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return TELR_OK;
+}
+
+extern "C" int telr_index_build(telr_ctx *ctx, const telr_seqset *targets, const telr_idx_opt *io, telr_index **out)
+{
+    if (!ctx || !targets || !io || !out) return TELR_E_ARG;
+    if (io->k < 4 || io->k > 28 || io->w < 1 || io->w > 255) return TELR_E_ARG;
+    if (io->is_hpc) { ctx->err = "homopolymer-compressed sketch is not implemented on the device yet"; return TELR_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
+    telr_index *ix = new telr_index();
+    StageTimer st(ctx, ST_INDEX, false);
+    int r = index_build_impl(ctx, targets, io, ix);
+    st.stop();
+    if (r != TELR_OK) { telr_index_free(ix); return r; }
+    *out = ix;
+    return TELR_OK;
+}
+
+static int32_t index_mid_occ(const telr_index *ix, const telr_map_opt *mo)
+{
+    int64_t n = ix->n_ent; int32_t occ;
+    if (n == 0) occ = mo->min_mid_occ;
+    else {
+        int64_t idx = (int64_t)((1.0 - (double)mo->mid_occ_frac) * (double)n);
+        if (idx >= n) idx = n - 1;
+        occ = (int32_t)ix->sorted_counts[idx] + 1;
+    }
+    if (occ < mo->min_mid_occ) occ = mo->min_mid_occ;
+    if (mo->max_mid_occ > mo->min_mid_occ && occ > mo->max_mid_occ) occ = mo->max_mid_occ;
+    return occ;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side chain selection (the oracle's select_chains(), restated for the product)
+struct Sel { int32_t ci, key, ord, fs, fe, tid, parent, subsc, n_sub, keep; };
+
+static void select_chains(std::vector<Sel> &s, const telr_map_opt *mo, const std::vector<int32_t> &sub_score)
+{
+    const bool per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
+    const int n = (int)s.size();
+    for (int i = 0; i < n; ++i) {
+        s[i].parent = i; s[i].subsc = 0; s[i].n_sub = 0;
+        for (int j = 0; j < i; ++j) {
+            if (s[j].parent != j) continue;
+            if (per_t && s[j].tid != s[i].tid) continue;
+            int32_t lo = std::max(s[i].fs, s[j].fs), hi = std::min(s[i].fe, s[j].fe);
+            int32_t ol = hi > lo ? hi - lo : 0;
+            int32_t mn = std::min(s[i].fe - s[i].fs, s[j].fe - s[j].fs);
+            if ((float)ol > mo->mask_level * (float)mn) {
+                s[i].parent = j;
+                if (sub_score[s[i].ci] > s[j].subsc) s[j].subsc = sub_score[s[i].ci];
+                ++s[j].n_sub;
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (s[i].parent == i) { s[i].keep = 1; continue; }
+        s[i].keep = 0;
+        if (!mo->secondary) continue;
+        if ((float)s[i].key < (float)s[s[i].parent].key * mo->pri_ratio) continue;
+        int n2 = 0;
+        for (int j = 0; j < i; ++j) if (s[j].keep && s[j].parent != j && (!per_t || s[j].tid == s[i].tid)) ++n2;
+        if (n2 < mo->best_n) s[i].keep = 1;
+    }
+}
+static bool sel_less(const Sel &x, const Sel &y) { return x.key != y.key ? x.key > y.key : x.ord < y.ord; }
+
+static int32_t mapq_of(const telr_aln &r, const telr_map_opt *mo)
+{
+    if (!(r.flags & TELR_F_PRIMARY) && !(r.flags & TELR_F_SUPPL)) return 0;
+    float f1 = (float)r.score, f2 = (float)(r.subsc > mo->min_chain_score ? r.subsc : mo->min_chain_score);
+    float pen_cm = r.cnt > 10 ? 1.0f : 0.1f * (float)r.cnt;
+    float x = f2 / f1; if (x > 1.0f) x = 1.0f;
+    int32_t mq = (int32_t)(40.0f * (1.0f - x) * pen_cm * logf(f1));
+    if (mq > 60) mq = 60;
+    if (mq < 0) mq = 0;
+    return mq;
+}
+
+struct telr_result {
+    std::vector<telr_aln> alns;
+    std::vector<uint32_t> cigars;
+};
+extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
+extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
+extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->cigars.size() : 0; }
+extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { return r ? r->cigars.data() : nullptr; }
+extern "C" void telr_result_free(telr_result *r) { delete r; }
+
+static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
+{
+    if (!len) return;
+    if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
+}
+
+struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int64_t a_glob; };
+
+// ---------------------------------------------------------------------------------------
+// one batch of queries [q0, q1)
+static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs, const int32_t *d_qtarget, int32_t q0, int32_t q1,
+                     const telr_map_opt *mo, int32_t mid_occ, telr_result *R)
+{
+    const int nq = q1 - q0, k = ix->io.k, w = ix->io.w;
+    const telr_seqset *tg = ix->targets;
+    hipStream_t st = ctx->stream;
+
+    // ---- sketch -------------------------------------------------------------------------
+    StageTimer t_sk(ctx, ST_SKETCH, true);
+    TileList T; make_tiles(qs, q0, q1, k, T);
+    uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
+    TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz));
+    // per-query minimizer offsets = tile_off[first tile of the query]
+    int32_t *d_first, *d_qmz;
+    TRY(ctx_buf_t(ctx, "q_first", (size_t)nq + 1, &d_first));
+    TRY(ctx_buf_t(ctx, "q_mzoff", (size_t)nq + 1, &d_qmz));
+    HIPCHK(hipMemcpyAsync(d_first, T.first.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_toff, d_first, nq, nmz, d_qmz);
+    HIPCHK(hipGetLastError());
+    t_sk.stop();
+    ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
+
+    // ---- seeding --------------------------------------------------------------------------
+    StageTimer t_sd(ctx, ST_SEED, true);
+    IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = ix->d_bstart; I.goff = ix->d_goff;
+    I.tlen = tg->d_len; I.n_ent = ix->n_ent; I.shift = ix->shift; I.k = k; I.w = w;
+    int32_t *d_mcnt, *d_maoff, *d_qaoff;
+    TRY(ctx_buf_t(ctx, "mz_cnt", (size_t)nmz + 1, &d_mcnt));
+    TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
+    TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
+    SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
+    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_aoff = nullptr; S.keys = nullptr;
+    hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));
+    // 64-bit total check first: anchors of a batch must stay below 2^31
+    TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_mcnt, d_maoff, (size_t)nmz + 1)));
+    int32_t na = 0;
+    HIPCHK(hipMemcpyAsync(&na, d_maoff + nmz, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (na < 0) return TELR_E_RANGE;
+    uint64_t *d_keys, *d_skeys;
+    TRY(ctx_buf_t(ctx, "keys", (size_t)na, &d_keys));
+    TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
+    S.mz_aoff = d_maoff; S.keys = d_keys;
+    hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, na, d_qaoff);
+    HIPCHK(hipGetLastError());
+    t_sd.stop();
+    ctx->ctr.anchors += na;
+
+    // ---- per-query sort of the anchor keys --------------------------------------------------
+    StageTimer t_so(ctx, ST_SORT, true);
+    if (na > 0) {
+        size_t tb = 0;
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 8, 64, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 8, 64, st));
+    }
+    t_so.stop();
+
+    // ---- chaining ---------------------------------------------------------------------------
+    StageTimer t_ch(ctx, ST_CHAIN, true);
+    int32_t *d_f, *d_p;
+    TRY(ctx_buf_t(ctx, "chain_f", (size_t)na, &d_f));
+    TRY(ctx_buf_t(ctx, "chain_p", (size_t)na, &d_p));
+    ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
+    co.chain_gap_q8 = mo->chain_gap_q8; co.chain_skip_q8 = mo->chain_skip_q8;
+    const int Rr = mo->chain_lookback / 64;
+    if (Rr == 1) hipLaunchKernelGGL(k_chain<1>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p);
+    else if (Rr == 2) hipLaunchKernelGGL(k_chain<2>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p);
+    else hipLaunchKernelGGL(k_chain<4>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p);
+    HIPCHK(hipGetLastError());
+    t_ch.stop();
+
+    // ---- peaks + back-tracking ----------------------------------------------------------------
+    StageTimer t_bt(ctx, ST_BACKTRACK, true);
+    uint8_t *d_flags; uint64_t *d_pk, *d_pk2, *d_canch; int32_t *d_npk, *d_pkend, *d_choff, *d_nch;
+    TRY(ctx_buf_t(ctx, "flags", (size_t)na * 2 + 16, &d_flags));   // nonpeak | vis
+    uint8_t *d_nonpeak = d_flags, *d_vis = d_flags + na;
+    TRY(ctx_buf_t(ctx, "pk", (size_t)na, &d_pk));
+    TRY(ctx_buf_t(ctx, "pk2", (size_t)na, &d_pk2));
+    TRY(ctx_buf_t(ctx, "canch", (size_t)na, &d_canch));
+    TRY(ctx_buf_t(ctx, "n_peaks", (size_t)nq + 1, &d_npk));
+    TRY(ctx_buf_t(ctx, "pk_end", (size_t)nq + 1, &d_pkend));
+    TRY(ctx_buf_t(ctx, "ch_off", (size_t)nq + 1, &d_choff));
+    TRY(ctx_buf_t(ctx, "n_chains", (size_t)nq + 1, &d_nch));
+    HIPCHK(hipMemsetAsync(d_flags, 0, (size_t)na * 2 + 16, st));
+    hipLaunchKernelGGL(k_nonpeak, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_p, d_nonpeak);
+    hipLaunchKernelGGL(k_peaks, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_nonpeak, mo->min_chain_score, d_pk, d_npk, d_pkend);
+    HIPCHK(hipGetLastError());
+    if (na > 0) {
+        size_t tb = 0;
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_pk, d_pk2, (unsigned)na, (unsigned)nq, d_qaoff, d_pkend, 0, 64, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_pk, d_pk2, (unsigned)na, (unsigned)nq, d_qaoff, d_pkend, 0, 64, st));
+    }
+    HIPCHK(hipMemsetAsync(d_npk + nq, 0, 4, st));
+    TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_npk, d_choff, (size_t)nq + 1)));
+    int32_t npk_tot = 0;
+    HIPCHK(hipMemcpyAsync(&npk_tot, d_choff + nq, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ChainRec *d_rec;
+    TRY(ctx_buf_t(ctx, "chain_rec", (size_t)npk_tot, &d_rec));
+    hipLaunchKernelGGL(k_backtrack, dim3((nq + 63) / 64), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                       mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> h_nch(nq), h_choff(nq + 1), h_qaoff(nq + 1);
+    std::vector<ChainRec> h_rec((size_t)npk_tot);
+    HIPCHK(hipMemcpyAsync(h_nch.data(), d_nch, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_choff.data(), d_choff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_qaoff.data(), d_qaoff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (npk_tot) HIPCHK(hipMemcpyAsync(h_rec.data(), d_rec, (size_t)npk_tot * sizeof(ChainRec), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    t_bt.stop();
+    ctx->dbg_na = na; ctx->dbg_nq = nq;
+
+    // ---- host: chain boxes + selection pass 1 ---------------------------------------------------
+    StageTimer t_sel(ctx, ST_SELECT, false);
+    std::vector<HostChain> chains;                 // all chains of the batch, query-major
+    std::vector<int32_t> q_ch0(nq + 1, 0);
+    for (int q = 0; q < nq; ++q) {
+        q_ch0[q] = (int32_t)chains.size();
+        const int qlen = qs->len[q0 + q]; (void)qlen;
+        for (int c = 0; c < h_nch[q]; ++c) {
+            const ChainRec &r = h_rec[h_choff[q] + c];
+            HostChain hc; hc.qid = q0 + q; hc.score = r.score; hc.cnt = r.cnt; hc.rev = (int)(r.a0 >> 63); hc.disc = c;
+            uint32_t g0 = (uint32_t)A_G(r.a0);
+            int tid = (int)(std::upper_bound(ix->goff.begin(), ix->goff.begin() + tg->n, g0) - ix->goff.begin()) - 1;
+            hc.tid = tid;
+            int go = (int)ix->goff[tid];
+            hc.rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; hc.re = A_G(r.a1) - go + 1;
+            hc.qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      hc.qe = A_Q(r.a1) + 1;
+            hc.a_glob = (int64_t)h_qaoff[q] + r.a_off;
+            chains.push_back(hc);
+        }
+    }
+    q_ch0[nq] = (int32_t)chains.size();
+    ctx->ctr.chains += (int64_t)chains.size();
+    ctx->dbg_chain.clear();
+    for (const HostChain &c : chains) { int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
+
+    std::vector<int32_t> kept;                     // indices into chains, query-major, pass-1 rank order
+    std::vector<int32_t> q_k0(nq + 1, 0);
+    {
+        std::vector<Sel> s; std::vector<int32_t> cscore;
+        for (int q = 0; q < nq; ++q) {
+            q_k0[q] = (int32_t)kept.size();
+            const int c0 = q_ch0[q], n = q_ch0[q + 1] - c0, qlen = qs->len[q0 + q];
+            s.resize(n); cscore.resize(n);
+            for (int i = 0; i < n; ++i) {
+                const HostChain &c = chains[c0 + i];
+                s[i].ci = i; s[i].key = c.score; s[i].ord = c.disc; s[i].tid = c.tid;
+                if (c.rev) { s[i].fs = qlen - c.qe; s[i].fe = qlen - c.qs; } else { s[i].fs = c.qs; s[i].fe = c.qe; }
+                cscore[i] = c.score;
+            }
+            std::sort(s.begin(), s.end(), sel_less);
+            select_chains(s, mo, cscore);
+            for (int i = 0; i < n; ++i) if (s[i].keep) kept.push_back(c0 + s[i].ci);
+        }
+        q_k0[nq] = (int32_t)kept.size();
+    }
+    const int nk = (int)kept.size();
+    t_sel.stop();
+
+    // results per kept chain
+    std::vector<telr_aln> kal(nk);
+    std::vector<std::vector<uint32_t>> kcig(nk);
+    for (int x = 0; x < nk; ++x) {
+        const HostChain &c = chains[kept[x]];
+        telr_aln &r = kal[x]; memset(&r, 0, sizeof(r));
+        const int qlen = qs->len[c.qid];
+        r.qid = c.qid; r.tid = c.tid; r.qlen = qlen; r.tlen = tg->len[c.tid]; r.score = c.score; r.cnt = c.cnt; r.flags = c.rev ? TELR_F_REV : 0;
+        r.ts = c.rs; r.te = c.re;
+        if (c.rev) { r.qs = qlen - c.qe; r.qe = qlen - c.qs; } else { r.qs = c.qs; r.qe = c.qe; }
+        r.mlen = std::min(c.score, c.qe - c.qs); r.blen = std::max(c.qe - c.qs, c.re - c.rs); r.dp_score = c.score;
+    }
+
+    if ((mo->flags & TELR_MF_CIGAR) && nk > 0) {
+        // ---- DP problem list ----------------------------------------------------------------
+        StageTimer t_sg(ctx, ST_SEGMENTS, true);
+        std::vector<KeptChain> hk(nk);
+        for (int x = 0; x < nk; ++x) {
+            const HostChain &c = chains[kept[x]]; KeptChain &K = hk[x];
+            K.qid = c.qid; K.tid = c.tid; K.rev = c.rev; K.cnt = c.cnt; K.a_glob = c.a_glob; K.rs = c.rs; K.qs = c.qs; K.re = c.re; K.qe = c.qe;
+            K.qlen = qs->len[c.qid]; K.tlen = tg->len[c.tid]; K.qbase = qs->boff[c.qid]; K.tbase = tg->boff[c.tid]; K.goff = ix->goff[c.tid]; K.pad = 0;
+        }
+        KeptChain *d_kc; int32_t *d_nprob, *d_poff;
+        TRY(ctx_buf_t(ctx, "kept", (size_t)nk, &d_kc));
+        TRY(ctx_buf_t(ctx, "nprob", (size_t)nk + 1, &d_nprob));
+        TRY(ctx_buf_t(ctx, "prob_off", (size_t)nk + 1, &d_poff));
+        HIPCHK(hipMemcpyAsync(d_kc, hk.data(), (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_segments<0>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(d_nprob + nk, 0, 4, st));
+        TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_nprob, d_poff, (size_t)nk + 1)));
+        std::vector<int32_t> h_poff(nk + 1);
+        HIPCHK(hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(nk + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const int np = h_poff[nk];
+        DpProb *d_probs; int64_t *d_tbb, *d_cgo, *d_tboff, *d_cgoff; int32_t *d_clscnt, *d_clslist;
+        TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
+        TRY(ctx_buf_t(ctx, "tb_bytes", (size_t)np + 1, &d_tbb));
+        TRY(ctx_buf_t(ctx, "cig_ops", (size_t)np + 1, &d_cgo));
+        TRY(ctx_buf_t(ctx, "tb_off", (size_t)np + 1, &d_tboff));
+        TRY(ctx_buf_t(ctx, "cig_off", (size_t)np + 1, &d_cgoff));
+        TRY(ctx_buf_t(ctx, "cls_cnt", 8, &d_clscnt));
+        TRY(ctx_buf_t(ctx, "cls_list", (size_t)np * 5, &d_clslist));
+        hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
+        hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tbb, d_cgo);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
+        HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
+        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbb, d_tboff, (size_t)np + 1)));
+        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_cgo, d_cgoff, (size_t)np + 1)));
+        HIPCHK(hipMemsetAsync(d_clscnt, 0, 32, st));
+        hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, d_cgoff, d_clscnt, d_clslist);
+        HIPCHK(hipGetLastError());
+        int64_t tb_total = 0, cg_total = 0; int32_t h_cls[8];
+        HIPCHK(hipMemcpyAsync(&tb_total, d_tboff + np, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&cg_total, d_cgoff + np, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        t_sg.stop();
+        ctx->ctr.dp_problems += np;
+
+        // ---- banded DP ------------------------------------------------------------------------
+        StageTimer t_dp(ctx, ST_DP, true);
+        uint8_t *d_tb; uint32_t *d_rawcig; DpRes *d_res;
+        TRY(ctx_buf_t(ctx, "tb", (size_t)tb_total + 256, &d_tb));
+        TRY(ctx_buf_t(ctx, "rawcig", (size_t)cg_total + 16, &d_rawcig));
+        TRY(ctx_buf_t(ctx, "dp_res", (size_t)np, &d_res));
+        DpArgs D; D.qseq2 = qs->d_seq2; D.qnmask = qs->d_nmask; D.tseq2 = tg->d_seq2; D.tnmask = tg->d_nmask; D.probs = d_probs;
+        D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
+        D.tb = d_tb; D.cig = d_rawcig; D.res = d_res;
+        static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
+        for (int c = 0; c < 5; ++c) {
+            if (h_cls[c] == 0) continue;
+            D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c]; D.dcap = CAP[c];
+            size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
+            if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, st, D);
+            HIPCHK(hipGetLastError());
+        }
+        t_dp.stop();
+
+        // ---- compact cigars and bring results home -------------------------------------------------
+        StageTimer t_g(ctx, ST_GATHER, true);
+        int64_t *d_nops, *d_doff; uint32_t *d_dense;
+        TRY(ctx_buf_t(ctx, "nops", (size_t)np + 1, &d_nops));
+        TRY(ctx_buf_t(ctx, "dense_off", (size_t)np + 1, &d_doff));
+        hipLaunchKernelGGL(k_res_nops, dim3((np + 255) / 256), dim3(256), 0, st, d_res, np, d_nops);
+        HIPCHK(hipMemsetAsync(d_nops + np, 0, 8, st));
+        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nops, d_doff, (size_t)np + 1)));
+        int64_t nops_total = 0;
+        HIPCHK(hipMemcpyAsync(&nops_total, d_doff + np, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        TRY(ctx_buf_t(ctx, "dense_cig", (size_t)nops_total, &d_dense));
+        hipLaunchKernelGGL(k_cigar_gather, dim3(np), dim3(64), 0, st, d_probs, d_res, d_doff, np, d_rawcig, d_dense);
+        HIPCHK(hipGetLastError());
+        t_g.stop();
+        StageTimer t_d(ctx, ST_D2H, true);
+        std::vector<DpRes> h_res(np); std::vector<int64_t> h_doff(np + 1); std::vector<uint32_t> h_cig((size_t)nops_total);
+        HIPCHK(hipMemcpyAsync(h_res.data(), d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_doff.data(), d_doff, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (nops_total) HIPCHK(hipMemcpyAsync(h_cig.data(), d_dense, (size_t)nops_total * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        t_d.stop();
+
+        // ---- host: stitch extension + fill cigars per chain ------------------------------------------
+        StageTimer t_as(ctx, ST_ASSEMBLE, false);
+        int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+        if (nk < 256) nth = 1;
+        std::vector<std::thread> th;
+        std::vector<int64_t> cells(nth, 0), wbases(nth, 0);
+        for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
+            for (int x = t; x < nk; x += nth) {
+                const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x]; std::vector<uint32_t> &cg = kcig[x];
+                const int qlen = r.qlen, tlen = r.tlen;
+                int p = h_poff[x]; const int pend = h_poff[x + 1];
+                int32_t dp = 0, mlen = 0, qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
+                const bool has_left = c.qs > 0 && c.rs > 0, has_right = c.qe < qlen && c.re < tlen;
+                if (has_left) {
+                    const DpRes &d = h_res[p]; dp += d.score; mlen += d.mlen; qs_ = c.qs - d.bi; rs_ = c.rs - d.bj;
+                    for (int64_t z = h_doff[p]; z < h_doff[p] + d.nops; ++z) cig_push(cg, h_cig[z] & 0xf, h_cig[z] >> 4);
+                    ++p;
+                }
+                const int fill_end = has_right ? pend - 1 : pend;
+                for (; p < fill_end; ++p) {
+                    const DpRes &d = h_res[p]; dp += d.score; mlen += d.mlen;
+                    for (int64_t z = h_doff[p] + d.nops - 1; z >= h_doff[p]; --z) cig_push(cg, h_cig[z] & 0xf, h_cig[z] >> 4);
+                }
+                if (has_right) {
+                    const DpRes &d = h_res[p]; dp += d.score; mlen += d.mlen; qe_ = c.qe + d.bi; re_ = c.re + d.bj;
+                    for (int64_t z = h_doff[p] + d.nops - 1; z >= h_doff[p]; --z) cig_push(cg, h_cig[z] & 0xf, h_cig[z] >> 4);
+                }
+                int32_t blen = 0;
+                for (uint32_t op : cg) blen += (int32_t)(op >> 4);
+                r.ts = rs_; r.te = re_;
+                if (c.rev) { r.qs = qlen - qe_; r.qe = qlen - qs_; } else { r.qs = qs_; r.qe = qe_; }
+                r.mlen = mlen; r.blen = blen; r.dp_score = dp; r.n_cigar = (int32_t)cg.size();
+            }
+        });
+        for (auto &t : th) t.join();
+        t_as.stop();
+    }
+
+    // ---- host: pass-2 selection, flags, mapq, emit ---------------------------------------------------
+    StageTimer t_as2(ctx, ST_ASSEMBLE, false);
+    const bool per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
+    std::vector<Sel> s2; std::vector<int32_t> cscore; std::vector<int32_t> newidx;
+    for (int q = 0; q < nq; ++q) {
+        const int k0 = q_k0[q], n1 = q_k0[q + 1] - k0;
+        s2.clear(); cscore.assign(n1, 0);
+        for (int i = 0; i < n1; ++i) {
+            const telr_aln &r = kal[k0 + i];
+            cscore[i] = r.score;
+            if ((mo->flags & TELR_MF_CIGAR) && r.dp_score < mo->min_dp_max) continue;
+            Sel s; s.ci = i; s.key = r.dp_score; s.ord = (int32_t)s2.size(); s.tid = r.tid; s.fs = r.qs; s.fe = r.qe;
+            s.parent = 0; s.subsc = 0; s.n_sub = 0; s.keep = 0;
+            s2.push_back(s);
+        }
+        std::sort(s2.begin(), s2.end(), sel_less);
+        select_chains(s2, mo, cscore);
+        const int n2 = (int)s2.size();
+        newidx.assign(n2, -1);
+        int nkp = 0;
+        for (int i = 0; i < n2; ++i) if (s2[i].keep) newidx[i] = nkp++;
+        for (int i = 0; i < n2; ++i) {
+            if (!s2[i].keep) continue;
+            telr_aln r = kal[k0 + s2[i].ci];
+            r.parent = newidx[s2[i].parent]; r.subsc = s2[i].subsc; r.n_sub = s2[i].n_sub;
+            if (s2[i].parent == i) {
+                bool first = true;
+                for (int j = 0; j < i; ++j) if (s2[j].keep && s2[j].parent == j && (!per_t || s2[j].tid == s2[i].tid)) { first = false; break; }
+                r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
+            } else r.flags |= TELR_F_SECONDARY;
+            r.mapq = mapq_of(r, mo);
+            const std::vector<uint32_t> &cg = kcig[k0 + s2[i].ci];
+            r.cigar_off = (int64_t)R->cigars.size(); r.n_cigar = (int32_t)cg.size();
+            R->cigars.insert(R->cigars.end(), cg.begin(), cg.end());
+            R->alns.push_back(r);
+            ctx->ctr.cigar_ops += (int64_t)cg.size(); ++ctx->ctr.records;
+        }
+    }
+    t_as2.stop();
+    return TELR_OK;
+}
+
+extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const telr_map_opt *mo, telr_result **out)
+{
+    if (!ctx || !ix || !queries || !mo || !out) return TELR_E_ARG;
+    if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
+    if (mo->max_gap >= TELR_TPAD || mo->ext_band * 2 + 1 > DP_DMAX || mo->ext_band < 1 || mo->ext_max < 1) return TELR_E_ARG;
+    if (queries->max_len >= (1 << 24)) return TELR_E_RANGE;
+    HIPCHK(hipSetDevice(ctx->device));
+    memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
+    memset(&ctx->ctr, 0, sizeof(ctx->ctr));
+    const int nq = queries->n;
+    if (qtarget) for (int i = 0; i < nq; ++i) if (qtarget[i] >= ix->targets->n) return TELR_E_ARG;
+    int32_t *d_qt = nullptr;
+    if (qtarget && nq > 0) {
+        TRY(ctx_buf_t(ctx, "qtarget", (size_t)nq, &d_qt));
+        HIPCHK(hipMemcpy(d_qt, qtarget, (size_t)nq * 4, hipMemcpyHostToDevice));
+    }
+    const int32_t mid_occ = index_mid_occ(ix, mo);
+    telr_result *R = new telr_result();
+    // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
+    int64_t batch_bases = 96LL << 20;
+    if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
+    int32_t q0 = 0;
+    while (q0 < nq) {
+        int32_t q1 = q0; int64_t b = 0;
+        while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= batch_bases)) { b += queries->len[q1]; ++q1; }
+        ctx->ctr.query_bases += b;
+        int r = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
+        if (r != TELR_OK) { delete R; return r; }
+        q0 = q1;
+    }
+    *out = R;
+    return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// debug taps for the stage-level parity tests (last batch of the last telr_map call)
+extern "C" int64_t telr_debug_n_anchor(const telr_ctx *ctx) { return ctx ? ctx->dbg_na : 0; }
+extern "C" int telr_debug_fetch(telr_ctx *ctx, const char *what, void *dst, int64_t bytes)
+{
+    if (!ctx || !what || !dst) return TELR_E_ARG;
+    auto it = ctx->bufs.find(what);
+    if (it == ctx->bufs.end() || !it->second.p || (size_t)bytes > it->second.bytes) return TELR_E_ARG;
+    HIPCHK(hipMemcpy(dst, it->second.p, (size_t)bytes, hipMemcpyDeviceToHost));
+    return TELR_OK;
+}
+extern "C" int64_t telr_debug_n_chain(const telr_ctx *ctx) { return ctx ? (int64_t)ctx->dbg_chain.size() / 9 : 0; }
+extern "C" const int32_t *telr_debug_chains(const telr_ctx *ctx) { return ctx ? ctx->dbg_chain.data() : nullptr; }
+extern "C" int telr_debug_index(telr_ctx *ctx, const telr_index *ix, uint64_t *ent_hash, uint32_t *ent_off, uint32_t *pos)
+{
+    if (!ctx || !ix) return TELR_E_ARG;
+    if (ent_hash) HIPCHK(hipMemcpy(ent_hash, ix->d_ent_hash, (size_t)ix->n_ent * 8, hipMemcpyDeviceToHost));
+    if (ent_off) HIPCHK(hipMemcpy(ent_off, ix->d_ent_off, ((size_t)ix->n_ent + 1) * 4, hipMemcpyDeviceToHost));
+    if (pos) HIPCHK(hipMemcpy(pos, ix->d_pos, (size_t)ix->n_mz * 4, hipMemcpyDeviceToHost));
+    return TELR_OK;
+}
+extern "C" int32_t telr_debug_mid_occ(const telr_index *ix, const telr_map_opt *mo) { return ix && mo ? index_mid_occ(ix, mo) : -1; }
+
+// ---------------------------------------------------------------------------------------
+// depth medians
+extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n_targets, const int32_t *target_len, int32_t n_iv,
+                                  const int32_t *iv_tid, const int32_t *iv_start, const int32_t *iv_end, double *median_out)
+{
+    if (!ctx || !r || n_targets <= 0 || !target_len || n_iv < 0 || (n_iv && (!iv_tid || !iv_start || !iv_end || !median_out))) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<int64_t> toff(n_targets + 1, 0);
+    for (int i = 0; i < n_targets; ++i) toff[i + 1] = toff[i] + target_len[i] + 1;
+    for (int i = 0; i < n_iv; ++i) if (iv_tid[i] < 0 || iv_tid[i] >= n_targets) return TELR_E_ARG;
+    std::vector<DepthRec> recs;
+    for (const telr_aln &a : r->alns) {
+        if (a.flags & TELR_F_SECONDARY) continue;
+        if (a.tid < 0 || a.tid >= n_targets) return TELR_E_ARG;
+        DepthRec d; d.tid = a.tid; d.ts = a.ts; d.n_cigar = a.n_cigar; d.pad = 0; d.cigar_off = a.cigar_off; recs.push_back(d);
+    }
+    int32_t *d_diff, *d_tlen, *d_ivt, *d_ivs, *d_ive; int64_t *d_toff; DepthRec *d_recs; uint32_t *d_cig; double *d_out;
+    TRY(ctx_buf_t(ctx, "dm_diff", (size_t)toff[n_targets] + 1, &d_diff));
+    TRY(ctx_buf_t(ctx, "dm_toff", (size_t)n_targets + 1, &d_toff));
+    TRY(ctx_buf_t(ctx, "dm_tlen", (size_t)n_targets, &d_tlen));
+    TRY(ctx_buf_t(ctx, "dm_recs", recs.size(), &d_recs));
+    TRY(ctx_buf_t(ctx, "dm_cig", r->cigars.size(), &d_cig));
+    TRY(ctx_buf_t(ctx, "dm_ivt", (size_t)n_iv, &d_ivt));
+    TRY(ctx_buf_t(ctx, "dm_ivs", (size_t)n_iv, &d_ivs));
+    TRY(ctx_buf_t(ctx, "dm_ive", (size_t)n_iv, &d_ive));
+    TRY(ctx_buf_t(ctx, "dm_out", (size_t)n_iv, &d_out));
+    HIPCHK(hipMemsetAsync(d_diff, 0, ((size_t)toff[n_targets] + 1) * 4, st));
+    HIPCHK(hipMemcpyAsync(d_toff, toff.data(), (size_t)(n_targets + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_tlen, target_len, (size_t)n_targets * 4, hipMemcpyHostToDevice, st));
+    if (!recs.empty()) HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(DepthRec), hipMemcpyHostToDevice, st));
+    if (!r->cigars.empty()) HIPCHK(hipMemcpyAsync(d_cig, r->cigars.data(), r->cigars.size() * 4, hipMemcpyHostToDevice, st));
+    if (n_iv) {
+        HIPCHK(hipMemcpyAsync(d_ivt, iv_tid, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_ivs, iv_start, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_ive, iv_end, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));
+    }
+    if (!recs.empty()) hipLaunchKernelGGL(k_depth_diff, dim3(((int)recs.size() + 63) / 64), dim3(64), 0, st, d_recs, (int32_t)recs.size(), d_cig, d_toff, d_diff);
+    TRY(dev_inclusive_scan_i32(ctx, d_diff, (size_t)toff[n_targets]));
+    if (n_iv) {
+        hipLaunchKernelGGL(k_depth_median, dim3(n_iv), dim3(256), 0, st, d_diff, d_toff, d_tlen, n_iv, d_ivt, d_ivs, d_ive, d_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(median_out, d_out, (size_t)n_iv * 8, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return TELR_OK;
+}

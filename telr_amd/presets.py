@@ -1,0 +1,39 @@
+"""Option presets for the seven aligner call sites of the reference.
+
+`-x map-ont` / `map-pb` are what TELR_alignment.py:57-60, TELR_assembly.py:193-197 and
+TELR_te.py:595-598 derive from `--presets {ont,pacbio}`; `asm10` is hard-wired in
+TELR_te.py:899 -> TELR_liftover.py:254-264.  Parameter values follow the minimap2 2.22
+manual as recorded in SURVEY.md 8(a) [recall]; `telr_preset()` in the C library returns
+the same numbers (tests/test_presets.py keeps them in lock-step).
+"""
+from ._abi import IdxOpt, MapOpt, MF_CIGAR
+
+
+def _gap_q8(k, scale=0.8):
+    # chain gap cost 0.01 * scale * k per base of diagonal drift, as Q8 fixed point
+    return int(0.01 * scale * k * 256 + 0.5)
+
+
+def preset(name):
+    io = IdxOpt(k=15, w=10, is_hpc=0, bucket_bits=0)
+    mo = MapOpt(
+        mid_occ_frac=2e-4, min_mid_occ=10, max_mid_occ=1000000,
+        max_gap=5000, bw=500, chain_lookback=128, min_cnt=3, min_chain_score=40,
+        chain_gap_q8=0, chain_skip_q8=0,
+        mask_level=0.5, pri_ratio=0.8, best_n=5, secondary=1,
+        a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, min_dp_max=80, min_ksw_len=200,
+        ext_max=2048, ext_band=31, flags=MF_CIGAR)
+    if name in ("map-ont", "ngmlr-ont"):
+        pass
+    elif name in ("map-pb", "ngmlr-pacbio"):
+        io.k, io.is_hpc = 19, 1
+    elif name == "asm10":
+        io.k, io.w = 19, 19
+        mo.min_mid_occ, mo.max_mid_occ = 50, 500
+        mo.bw, mo.max_gap = 10000, 10000
+        mo.a, mo.b, mo.q, mo.e, mo.q2, mo.e2 = 1, 9, 16, 2, 41, 1
+        mo.min_dp_max, mo.zdrop, mo.best_n = 200, 200, 50
+    else:
+        raise ValueError("unknown preset %r" % (name,))
+    mo.chain_gap_q8 = _gap_q8(io.k)
+    return io, mo

@@ -1,0 +1,145 @@
+"""HIP engine vs the CPU oracle, stage by stage and end to end (bit-exact: integer work)."""
+import numpy as np
+import pytest
+
+from telr_amd.presets import preset
+from telr_amd.fasta import read_fasta
+from telr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ALN_FIELDS = ["qid", "tid", "qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "score", "subsc", "dp_score", "cnt",
+              "n_sub", "parent", "n_cigar", "flags", "mapq"]
+
+
+def _as_str(a):
+    return bytes(a).decode() if not isinstance(a, str) else a
+
+
+def compare_all(engine, targets, queries, io, mo, qtarget=None, stages=True):
+    from oracle import binding as ob
+    targets = [_as_str(t) for t in targets]
+    queries = [_as_str(q) for q in queries]
+    oix = ob.OracleIndex(targets, io)
+    gix = engine.index(targets, io)
+    # --- index
+    oh, oy = oix.dump()
+    eh, eo, pos = gix.debug_dump()
+    assert len(pos) == len(oy), "minimizer count: gpu %d oracle %d" % (len(pos), len(oy))
+    np.testing.assert_array_equal(pos, oy)
+    np.testing.assert_array_equal(np.repeat(eh, np.diff(eo.astype(np.int64))), oh)
+    assert gix.debug_mid_occ(mo) == oix.mid_occ(mo)
+    # --- map
+    oref = oix.map(queries, mo, qtarget=qtarget, debug=True)
+    res = gix.map(queries, mo, qtarget=qtarget)
+    if stages:
+        dbg = gix.debug_last_batch(len(queries))
+        np.testing.assert_array_equal(dbg["q_aoff"].astype(np.int64), oref["anchor_off"])
+        np.testing.assert_array_equal(dbg["skeys"], oref["anchors"])
+        np.testing.assert_array_equal(dbg["chain_f"], oref["f"])
+        np.testing.assert_array_equal(dbg["chain_p"], oref["p"])
+        np.testing.assert_array_equal(dbg["chains"], oref["chains"])
+    assert len(res.alns) == len(oref["alns"])
+    for f in ALN_FIELDS:
+        np.testing.assert_array_equal(res.alns[f], oref["alns"][f], err_msg="field " + f)
+    for i in range(len(res.alns)):
+        a, b = res.alns[i], oref["alns"][i]
+        np.testing.assert_array_equal(res.cigars[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]],
+                                      oref["cigars"][b["cigar_off"]:b["cigar_off"] + b["n_cigar"]], err_msg="cigar of record %d" % i)
+    ctr = engine.counters()
+    for k in ("query_bases", "minimizers", "anchors", "chains", "dp_problems", "records", "cigar_ops"):
+        assert ctr[k] == oref["counters"][k], (k, ctr[k], oref["counters"][k])
+    return res, oref
+
+
+def test_fixture_map_ont(engine, data_dir):
+    _, ts = read_fasta(data_dir + "/ref_38kb.fasta")
+    _, qs = read_fasta(data_dir + "/reads.fasta")
+    io, mo = preset("map-ont")
+    res, _ = compare_all(engine, ts, qs, io, mo)
+    assert len(res.alns) >= 18
+
+
+def test_fixture_library_to_reads_asm10(engine, data_dir):
+    """TE library (jockey) against the bundled reads as targets: many targets, asm10 scoring."""
+    _, lib = read_fasta(data_dir + "/library.fasta")
+    _, qs = read_fasta(data_dir + "/reads.fasta")
+    io, mo = preset("asm10")
+    mo.best_n = 10
+    compare_all(engine, qs, lib, io, mo)
+
+
+@pytest.mark.parametrize("seed,lookback", [(1, 64), (2, 128), (3, 256)])
+def test_synthetic_reads(engine, seed, lookback):
+    rng = np.random.default_rng(20261002 + seed)
+    genome = [synth.random_seq(rng, 200000), synth.random_seq(rng, 60000)]
+    # a repeat family so that the occurrence filter and secondary chains are exercised
+    te = synth.random_seq(rng, 3000)
+    for g in genome:
+        for _ in range(6):
+            p = int(rng.integers(0, len(g) - 3000))
+            g[p:p + 3000] = synth.mutate(rng, te, 0.03, 0.0, 0.0)[:3000]
+    reads, truth = synth.simulate_reads(rng, genome, 60, 6000)
+    # one read with ambiguous bases, one shorter than k, one empty
+    reads[3][100:130] = ord("N")
+    reads.append(np.frombuffer(b"ACGTACG", dtype=np.uint8))
+    reads.append(np.zeros(0, np.uint8))
+    io, mo = preset("map-ont")
+    mo.chain_lookback = lookback
+    res, _ = compare_all(engine, genome, reads, io, mo)
+    # truth recovery: primary alignments land on the simulated origin
+    prim = res.alns[(res.alns["flags"] & 1) != 0]
+    ok = 0
+    for a in prim:
+        if a["qid"] >= len(truth):
+            continue
+        g, s, e, st = truth[a["qid"]]
+        if a["tid"] == g and a["ts"] < e and a["te"] > s and ((a["flags"] >> 3) & 1) == st:
+            ok += 1
+    assert ok >= 0.9 * len(truth)
+
+
+def test_target_filter_and_per_target(engine):
+    """S3/S4/S6 shape: query i sees only target qtarget[i]; S5 shape: per-target selection."""
+    rng = np.random.default_rng(7)
+    contigs = [synth.random_seq(rng, 20000) for _ in range(5)]
+    te = synth.random_seq(rng, 2500)
+    for c in contigs:
+        c[9000:11500] = synth.mutate(rng, te, 0.02, 0.0, 0.0)[:2500]
+    reads, qt = [], []
+    for ci, c in enumerate(contigs):
+        for _ in range(6):
+            s = int(rng.integers(0, 12000)); L = int(rng.integers(3000, 8000))
+            r = c[s:s + L]
+            if rng.integers(0, 2):
+                r = synth.revcomp_arr(r)
+            reads.append(synth.mutate(rng, r)); qt.append(ci)
+    io, mo = preset("map-ont")
+    res, _ = compare_all(engine, contigs, reads, io, mo, qtarget=np.array(qt, np.int32))
+    assert (res.alns["tid"] == np.array(qt)[res.alns["qid"]]).all()
+    mo2 = mo.copy(); mo2.flags |= 2
+    res2, _ = compare_all(engine, contigs, [te], io, mo2)
+    assert set(res2.alns["tid"].tolist()) == set(range(5))
+
+
+def test_depth_medians(engine):
+    from oracle import binding as ob
+    rng = np.random.default_rng(11)
+    contig = synth.random_seq(rng, 15000)
+    reads = []
+    for _ in range(40):
+        s = int(rng.integers(0, 9000)); L = int(rng.integers(2000, 6000))
+        reads.append(synth.mutate(rng, contig[s:s + L]))
+    io, mo = preset("map-ont")
+    gix = engine.index([bytes(contig).decode()], io)
+    r = gix.map_raw([bytes(x).decode() for x in reads], mo)
+    try:
+        res = gix.result_arrays(r)
+        iv_s = np.array([0, 5000, 7000, 14950, 100], np.int32); iv_e = np.array([50, 5100, 7050, 15100, 14000], np.int32)
+        iv_t = np.zeros(5, np.int32)
+        got = gix.depth_medians(r, iv_t, iv_s, iv_e)
+        want = ob.depth_medians(res.alns, res.cigars, [15000], iv_t, iv_s, iv_e)
+        np.testing.assert_array_equal(got, want)
+        assert got[1] > 3
+    finally:
+        gix.free_raw(r)

@@ -543,9 +543,9 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     StageTimer t_so(ctx, ST_SORT, true);
     if (na > 0) {
         size_t tb = 0;
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 8, 64, st));
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 8, 64, st));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
     }
     t_so.stop();
 

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — stage-1 long-read alignment throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (sketch -> seed -> sort -> chain -> back-track ->
+banded DP + trace-back -> records/CIGARs on the host) over the whole synthetic read set
+of BASELINE.json configs[1] (chr2L-sized genome, 10k ONT-like reads ~20x, 200 spiked TE
+insertions).  The reference index and the packed reads are resident in HBM before the
+timed region.  One process per GPU; reads are sharded per rank (each rank maps its own
+read set against a replicated index, weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-len", type=int, default=23513712)
+    ap.add_argument("--reads", type=int, default=10000)
+    ap.add_argument("--read-bases", type=int, default=470_000_000)
+    ap.add_argument("--insertions", type=int, default=200)
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-25 s of CPU work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preset", default="map-ont")
+    return ap.parse_args()
+
+
+def cpu_baseline(ref_str, reads, io, mo, n_sample, gbp_of):
+    """The CPU oracle ("port") timed on a bounded sample of the same read set."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as ob
+    cores = os.cpu_count() or 1
+    buf, off, ln = reads
+    t0 = time.time()
+    oix = ob.OracleIndex([ref_str], io)
+    t_index = time.time() - t0
+    n_sample = min(n_sample, len(ln))
+    seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in range(n_sample)]
+    shards = [seqs[i::cores] for i in range(cores)]
+    shards = [s for s in shards if s]
+
+    def work(s):
+        r = oix.map(s, mo)
+        prim = r["alns"][(r["alns"]["flags"] & 1) != 0]
+        return int(prim["qlen"].sum())
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=len(shards)) as ex:
+        aligned = sum(ex.map(work, shards))
+    dt = time.time() - t0
+    return {"value": aligned / dt / 1e9, "unit": "Gbp/s", "cores": len(shards), "kind": "port",
+            "sample": "first %d reads (%d bases) of the same read set, oracle/telr_oracle.c, %d threads, %.1f s; index build %.1f s excluded"
+                      % (n_sample, sum(len(s) for s in seqs), len(shards), dt, t_index)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from telr_amd.aligner import Engine
+    from telr_amd.presets import preset
+    from telr_amd import synth
+
+    io, mo = preset(a.preset)
+    t0 = time.time()
+    # every rank: same genome/insertions (seed), its own reads (seed + rank)
+    d = synth.make_stage1_dataset(seed=20261002, genome_len=a.genome_len, n_reads=a.reads, total_bases=a.read_bases,
+                                  n_ins=a.insertions, read_seed=20261002 + 1000 * (rank + 1))
+    t_gen = time.time() - t0
+    ref_str = bytes(d["ref"]).decode()
+    eng = Engine(local)
+    t0 = time.time()
+    ix = eng.index([ref_str], io)
+    t_index = time.time() - t0
+    qs = eng.seqset(d["reads"])
+    n_bases = qs.bases()
+
+    def step():
+        r = ix.map_raw(qs, mo)
+        L = eng.L
+        n = L.telr_result_count(r)
+        from telr_amd.aligner import _np_from
+        from telr_amd._abi import ALN_DTYPE
+        al = _np_from(L.telr_result_alns(r), n, ALN_DTYPE)
+        ix.free_raw(r)
+        prim = al[(al["flags"] & 1) != 0]
+        return int(prim["qlen"].sum()), al
+
+    def sync():
+        torch.cuda.synchronize(local)
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    stage_tot = {}
+    sync()
+    t0 = time.time()
+    aligned = 0
+    for _ in range(a.steps):
+        b, al = step()
+        aligned += b
+        for k, v in eng.stage_ms().items():
+            stage_tot[k] = stage_tot.get(k, 0.0) + v
+    sync()
+    dt = time.time() - t0
+    ctr = eng.counters()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        s = torch.tensor([aligned], dtype=torch.float64, device="cuda"); dist.all_reduce(s, op=dist.ReduceOp.SUM); aligned = float(s.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    value = aligned / dt / 1e9
+    # truth check on the last step: primary alignment overlaps the simulated origin (haplotype coordinates differ from
+    # reference coordinates by at most the inserted TE bases upstream, so compare loosely)
+    prim = al[(al["flags"] & 1) != 0]
+    frac_mapped = len(np.unique(prim["qid"])) / max(1, len(d["reads"][2]))
+    # roofline of the dominant kernel: the banded DP.  Algorithmic bytes per launch set (DESIGN.md "k_dp"):
+    # 2-bit query + target window bases read once, one 4-byte op per CIGAR run and one 32-byte result per problem.
+    dp_ms = stage_tot.get("dp", 0.0) / a.steps
+    dp_bytes = (ctr["query_bases"] + ctr.get("window_bases", 0)) / 4.0 + 4.0 * ctr["cigar_ops"] + 32.0 * ctr["dp_problems"]
+    achieved = dp_bytes / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0
+    # whole-path algorithmic bytes (SURVEY 8d formula) for reference
+    path_bytes = (ctr["query_bases"] / 4.0 + 32.0 * ctr["minimizers"] + 16.0 * ctr["probes"] + 48.0 * ctr["anchors"]
+                  + ctr["query_bases"] / 4.0 + 4.0 * ctr["cigar_ops"] + 64.0 * ctr["records"])
+    gpu_ms = sum(v for k, v in stage_tot.items() if k not in ("select_host", "assemble_host", "index_build")) / a.steps
+    out = {
+        "metric": "gbp_aligned_per_s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: synthetic chr2L-size genome (%d bp) + %d ONT-like reads (%.0f Mbp per GPU, 10%% error) + %d spiked TE insertions, preset %s, stage-1 reads->reference"
+                               % (a.genome_len, a.reads, n_bases / 1e6, a.insertions, a.preset),
+                   "reads_per_gpu": a.reads, "read_bases_per_gpu": n_bases, "parallelism": "reads sharded x%d, index replicated" % world},
+        "roofline": {"bound": "hbm", "kernel": "k_dp", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                     "traffic": None, "launch_ms": dp_ms, "algorithmic_bytes_per_step": dp_bytes,
+                     "gcups": ctr.get("dp_cells", 0) / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 and ctr.get("dp_cells", 0) else None},
+        "stage_ms_per_step": {k: v / a.steps for k, v in stage_tot.items()},
+        "path_algorithmic_GBps": path_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
+        "frac_reads_mapped": frac_mapped, "index_build_s": t_index, "datagen_s": t_gen, "device": eng.device_name(),
+        "counters": ctr,
+    }
+    if not a.no_cpu_baseline:
+        ns = a.cpu_sample_reads or max(8, int(8e6 * (os.cpu_count() or 1) / 8 / max(1.0, n_bases / len(d["reads"][2]))))
+        out["cpu_baseline"] = cpu_baseline(ref_str, d["reads"], io, mo, ns, None)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

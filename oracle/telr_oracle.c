@@ -574,9 +574,11 @@ static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v
 static inline int fill_band(int m, int n, const telr_map_opt *mo)
 {
     int mn = m < n ? m : n;
-    int W = 16 + (mn >> 4);
+    int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6);
     return W < mo->bw ? W : mo->bw;
 }
+/* the lower band edge is rounded down to an even diagonal (the GPU pairs diagonals per lane) */
+static inline int even_lo(int lo) { return lo - (lo & 1); }
 
 /* debug entry: one global banded alignment of two ASCII strings */
 int32_t tor_nw(const char *q, int m, const char *t, int n, const telr_map_opt *mo, uint32_t *cig, int32_t *n_cig, int32_t cap)
@@ -587,7 +589,7 @@ int32_t tor_nw(const char *q, int m, const char *t, int n, const telr_map_opt *m
     dp_seq_t s = { qq, tt, 0, 0, 1, 1, 0, m, n };
     int W = fill_band(m, n, mo), dl = n - m;
     u32v_t rc = {0, 0, 0};
-    dp_res_t r = band_dp(&s, (dl < 0 ? dl : 0) - W, (dl > 0 ? dl : 0) + W, 0, mo, &rc);
+    dp_res_t r = band_dp(&s, even_lo((dl < 0 ? dl : 0) - W), (dl > 0 ? dl : 0) + W, 0, mo, &rc);
     *n_cig = (int32_t)rc.n;
     for (int64_t i = 0; i < rc.n && i < cap; ++i) cig[i] = rc.a[rc.n - 1 - i];
     free(rc.a); free(qq); free(tt);
@@ -604,7 +606,7 @@ int32_t tor_ext(const char *q, int m, const char *t, int n, const telr_map_opt *
     int mq = m < mo->ext_max ? m : mo->ext_max, mt = n < mq + mo->ext_band ? n : mq + mo->ext_band;
     dp_seq_t s = { qq, tt, 0, 0, 1, 1, 0, mq, mt };
     u32v_t rc = {0, 0, 0};
-    dp_res_t r = band_dp(&s, -mo->ext_band, mo->ext_band, 1, mo, &rc);
+    dp_res_t r = band_dp(&s, even_lo(-mo->ext_band), mo->ext_band, 1, mo, &rc);
     *n_cig = (int32_t)rc.n; *qend = r.bi; *tend = r.bj;
     for (int64_t i = 0; i < rc.n && i < cap; ++i) cig[i] = rc.a[rc.n - 1 - i];
     free(rc.a); free(qq); free(tt);
@@ -640,7 +642,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         s.m = mq; s.n = mt; s.tstep = -1; s.ti0 = r0 - 1;
         if (c->rev) { s.qstep = 1; s.qi0 = qlen - q0; } else { s.qstep = -1; s.qi0 = q0 - 1; }
         rc.n = 0;
-        dp_res_t r = band_dp(&s, -mo->ext_band, mo->ext_band, 1, mo, &rc);
+        dp_res_t r = band_dp(&s, even_lo(-mo->ext_band), mo->ext_band, 1, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
         dp += r.score; qs = q0 - r.bi; rs = r0 - r.bj;
         /* rev_cig is end->start of the reversed problem == left-to-right on the forward sequences */
@@ -652,7 +654,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - sq; } else { s.qstep = 1; s.qi0 = sq; }
         int W = fill_band(s.m, s.n, mo), dl = s.n - s.m;
         rc.n = 0;
-        int lo = (dl < 0 ? dl : 0) - W, hi = (dl > 0 ? dl : 0) + W, fb_mlen;
+        int lo = even_lo((dl < 0 ? dl : 0) - W), hi = (dl > 0 ? dl : 0) + W, fb_mlen;
         dp_res_t r = hi - lo + 1 > DP_DMAX ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
         dp += r.score;
@@ -665,7 +667,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         s.m = mq; s.n = mt; s.tstep = 1; s.ti0 = re;
         if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - qe; } else { s.qstep = 1; s.qi0 = qe; }
         rc.n = 0;
-        dp_res_t r = band_dp(&s, -mo->ext_band, mo->ext_band, 1, mo, &rc);
+        dp_res_t r = band_dp(&s, even_lo(-mo->ext_band), mo->ext_band, 1, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
         dp += r.score; qe += r.bi; re += r.bj;
         for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
@@ -690,7 +692,6 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     al->mlen = mlen; al->blen = blen; al->n_ambi = 0; al->dp_score = dp; (void)nambi;
     al->n_cigar = (int32_t)cig.n; al->cigar_off = cigars->n;
     for (int64_t z = 0; z < cig.n; ++z) vpush(uint32_t, *cigars, cig.a[z]);
-    ctr->cigar_ops += cig.n;
     free(cig.a); free(rc.a); free(bp.a);
 }
 
@@ -800,6 +801,7 @@ tor_result *tor_map(const tor_index *ix, int32_t nq, const char *ascii, const in
                 r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
             } else r.flags |= TELR_F_SECONDARY;
             r.mapq = mapq_of(&r, mo);
+            R->ctr.cigar_ops += r.n_cigar;
             vpush(telr_aln, R->alns, r);
         }
         (void)base;

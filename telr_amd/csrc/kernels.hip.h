@@ -419,13 +419,15 @@ struct DpProb {             // 64 B
     int32_t chain;          // kept-chain index
     int32_t pad[2];
 };
-struct DpRes { int32_t score, bi, bj, nops, mlen, pad[3]; };   // 32 B
+struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, pad; };   // 32 B
 
 __device__ __forceinline__ int d_fill_band(int m, int n, int bw)
 {
-    int mn = m < n ? m : n, W = 16 + (mn >> 4);
+    int mn = m < n ? m : n;
+    int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6);
     return W < bw ? W : bw;
 }
+__device__ __forceinline__ int d_even_lo(int lo) { return lo - (lo & 1); }
 
 // PASS 0: count problems per kept chain.  PASS 1: write descriptors.
 template <int PASS>
@@ -444,7 +446,7 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
     if (K.qs > 0 && K.rs > 0) {
         if (PASS) {
             int mq = K.qs < ext_max ? K.qs : ext_max, mt = K.rs < mq + ext_band ? K.rs : mq + ext_band;
-            DpProb P; P.m = mq; P.n = mt; P.dlo = -ext_band; P.dhi = ext_band; P.kind = 1; P.chain = c;
+            DpProb P; P.m = mq; P.n = mt; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; P.kind = 1; P.chain = c;
             P.tstep = -1; P.ti0 = K.tbase + K.rs - 1; P.qcomp = (int8_t)K.rev;
             if (K.rev) { P.qstep = 1; P.qi0 = K.qbase + K.qlen - K.qs; } else { P.qstep = -1; P.qi0 = K.qbase + K.qs - 1; }
             P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
@@ -460,7 +462,7 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
             if (PASS) {
                 DpProb P; P.m = cq - lq; P.n = cr - lr; P.chain = c; P.kind = 0;
                 int W = d_fill_band(P.m, P.n, bw), dl = P.n - P.m;
-                P.dlo = (dl < 0 ? dl : 0) - W; P.dhi = (dl > 0 ? dl : 0) + W;
+                P.dlo = d_even_lo((dl < 0 ? dl : 0) - W); P.dhi = (dl > 0 ? dl : 0) + W;
                 if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
                 P.tstep = 1; P.ti0 = K.tbase + lr; P.qcomp = (int8_t)K.rev;
                 if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - lq; } else { P.qstep = 1; P.qi0 = K.qbase + lq; }
@@ -474,7 +476,7 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
         if (PASS) {
             int rq = K.qlen - K.qe, rt = K.tlen - K.re;
             int mq = rq < ext_max ? rq : ext_max, mt = rt < mq + ext_band ? rt : mq + ext_band;
-            DpProb P; P.m = mq; P.n = mt; P.dlo = -ext_band; P.dhi = ext_band; P.kind = 2; P.chain = c;
+            DpProb P; P.m = mq; P.n = mt; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; P.kind = 2; P.chain = c;
             P.tstep = 1; P.ti0 = K.tbase + K.re; P.qcomp = (int8_t)K.rev;
             if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - K.qe; } else { P.qstep = 1; P.qi0 = K.qbase + K.qe; }
             P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
@@ -485,39 +487,63 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
     if (!PASS) nprob[c] = np;
 }
 
-// per-problem scratch sizes (bytes of trace-back, ops of raw cigar) and DP class
-__device__ __forceinline__ int d_dp_class(int D) { return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4; }
-__global__ void k_prob_sizes(const DpProb *__restrict__ probs, int32_t np, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
+// DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
+// 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
+// (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
+#define DP_NCLS 10
+__device__ __forceinline__ int d_dp_class(int kind, int D)
+{
+    if (kind == 0) {
+        if (D <= 64) return 5;
+        if (D <= 128) return 6;
+        if (D <= 256) return 7;
+        if (D <= 512) return 8;
+        if (D <= 1024) return 9;
+    }
+    return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
+}
+__device__ __forceinline__ int d_cls_slots(int cls) { return cls == 5 ? 32 : 64 << (cls - 6); }   // dwords per packed trace-back row
+__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
-    int64_t tb = P.kind == 3 ? 0 : ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
+    int cls = d_dp_class(P.kind, D);
+    int64_t tb;
+    if (P.kind == 3) tb = 0;
+    else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
+    else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
+    probs[i].pad[0] = cls;
     tb_bytes[i] = tb;
     cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
-__global__ void k_prob_assign(DpProb *__restrict__ probs, int32_t np, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ cig_off,
-                              int32_t *__restrict__ cls_cnt, int32_t *__restrict__ cls_list /* [5][np] */)
+__global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs, int32_t np, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ cig_off,
+                                                     int32_t *__restrict__ cls_cnt, int32_t *__restrict__ cls_list /* [DP_NCLS][np] */)
 {
+    __shared__ int32_t lcnt[DP_NCLS], lbase[DP_NCLS];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= np) return;
-    probs[i].tb_off = tb_off[i]; probs[i].cig_off = cig_off[i];
-    int D = probs[i].dhi - probs[i].dlo + 1;
-    int c = probs[i].kind == 3 ? 0 : d_dp_class(D);
-    int s = atomicAdd(&cls_cnt[c], 1);
-    cls_list[(int64_t)c * np + s] = i;
+    if (threadIdx.x < DP_NCLS) lcnt[threadIdx.x] = 0;
+    __syncthreads();
+    int c = -1, s = 0;
+    if (i < np) {
+        probs[i].tb_off = tb_off[i]; probs[i].cig_off = cig_off[i];
+        c = probs[i].kind == 3 ? 0 : probs[i].pad[0];
+        s = atomicAdd(&lcnt[c], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < DP_NCLS) lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cls_cnt[threadIdx.x], lcnt[threadIdx.x]) : 0;
+    __syncthreads();
+    if (c >= 0) cls_list[(int64_t)c * np + lbase[c] + s] = i;
 }
 
-// The DP kernel.  One wave per problem; DP state (H,E1,F1,E2,F2 per diagonal) in LDS,
-// updated in place anti-diagonal by anti-diagonal (cells of one anti-diagonal touch only
-// the other parity's diagonals, so the in-place update is race-free inside the wave).
 struct DpArgs {
     const uint32_t *qseq2, *qnmask, *tseq2, *tnmask;
+    int64_t qtot, ttot;      // padded base counts of the two packed arrays
     const DpProb *probs; const int32_t *list; int32_t nlist;
     DpOpt o;
     uint8_t *tb; uint32_t *cig; DpRes *res;
-    int32_t dcap;            // diagonals of LDS state per wave
+    int32_t dcap;            // diagonals of LDS state per wave (LDS kernel)
 };
 
 __device__ __forceinline__ int64_t d_wave_max64(int64_t v)
@@ -530,6 +556,29 @@ __device__ __forceinline__ int64_t d_wave_max64(int64_t v)
     return v;
 }
 
+// one DP cell (two-piece affine); returns the trace-back byte.  left = (i,j-1), up = (i-1,j), hd = (i-1,j-1)
+__device__ __forceinline__ uint32_t d_cell(const DpOpt &o, int32_t hd, int32_t hl, int32_t e1l, int32_t e2l, int32_t hu, int32_t f1u, int32_t f2u,
+                                           int qb, int tbv, int32_t &h, int32_t &ve1, int32_t &vf1, int32_t &ve2, int32_t &vf2)
+{
+    uint32_t t = 0; int32_t op, g;
+    op = hl - o.q - o.e;   g = e1l - o.e;  if (g > op) { ve1 = g; t |= 8; }  else ve1 = op;
+    op = hu - o.q - o.e;   g = f1u - o.e;  if (g > op) { vf1 = g; t |= 16; } else vf1 = op;
+    op = hl - o.q2 - o.e2; g = e2l - o.e2; if (g > op) { ve2 = g; t |= 32; } else ve2 = op;
+    op = hu - o.q2 - o.e2; g = f2u - o.e2; if (g > op) { vf2 = g; t |= 64; } else vf2 = op;
+    int sc;
+    if (qb > 3 || tbv > 3) sc = -o.sc_ambi; else if (qb == tbv) { sc = o.a; t |= 128; } else sc = -o.b;
+    h = hd + sc; uint32_t src = 0;
+    if (ve1 > h) { h = ve1; src = 1; }
+    if (vf1 > h) { h = vf1; src = 2; }
+    if (ve2 > h) { h = ve2; src = 3; }
+    if (vf2 > h) { h = vf2; src = 4; }
+    return t | src;
+}
+
+// ---- LDS-state forward kernel: any band width up to DP_DMAX, fills and z-drop extensions.
+// One wave per problem; DP state per diagonal in LDS, updated in place (cells of one
+// anti-diagonal touch only the other parity's diagonals).  Trace-back bytes go to
+// tb[a][slot]; the walk itself is done by k_traceback.
 __global__ void __launch_bounds__(64) k_dp(DpArgs A)
 {
     extern __shared__ __align__(16) int32_t lds[];
@@ -541,7 +590,8 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     const int m = P.m, n = P.n, dlo = P.dlo, dhi = P.dhi, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const DpOpt o = A.o;
     const bool ext = P.kind == 1 || P.kind == 2;
-    DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.pad[0] = R.pad[1] = R.pad[2] = 0;
+    DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.cells = 0; R.tbases = n; R.pad = 0;
+    int ncell = 0;
 
     if (P.kind == 3) {
         // band wider than the engine accepts: diagonal + one closing gap (oracle band_dp_fallback)
@@ -557,7 +607,6 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
         if (g) { int c1 = o.q + g * o.e, c2 = o.q2 + g * o.e2; sc -= c1 < c2 ? c1 : c2; }
         if (lane == 0) {
             int no = 0;
-            // emitted end -> start like the DP trace-back
             if (g) A.cig[P.cig_off + no++] = (uint32_t)g << 4 | (m > n ? 1u : 2u);
             if (mn) A.cig[P.cig_off + no++] = (uint32_t)mn << 4;
             R.score = sc; R.bi = m; R.bj = n; R.nops = no; R.mlen = ml;
@@ -588,23 +637,12 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
                 vf1 = -(o.q + i * o.e); vf2 = -(o.q2 + i * o.e2); ve1 = ve2 = TELR_NEG;
                 h = vf1 > vf2 ? vf1 : vf2;
             } else {
-                const int32_t hl = H[x - 1], hu = H[x + 1], hd = H[x];
-                uint32_t t = 0; int32_t op, g;
-                op = hl - o.q - o.e;   g = E1[x - 1] - o.e;  if (g > op) { ve1 = g; t |= 8; }  else ve1 = op;
-                op = hu - o.q - o.e;   g = F1[x + 1] - o.e;  if (g > op) { vf1 = g; t |= 16; } else vf1 = op;
-                op = hl - o.q2 - o.e2; g = E2[x - 1] - o.e2; if (g > op) { ve2 = g; t |= 32; } else ve2 = op;
-                op = hu - o.q2 - o.e2; g = F2[x + 1] - o.e2; if (g > op) { vf2 = g; t |= 64; } else vf2 = op;
                 int qb = d_base(A.qseq2, A.qnmask, P.qi0 + (int64_t)P.qstep * (i - 1));
                 int tbv = d_base(A.tseq2, A.tnmask, P.ti0 + (int64_t)P.tstep * (j - 1));
                 if (P.qcomp && qb < 4) qb = 3 - qb;
-                int sc;
-                if (qb > 3 || tbv > 3) sc = -o.sc_ambi; else if (qb == tbv) { sc = o.a; t |= 128; } else sc = -o.b;
-                h = hd + sc; uint32_t src = 0;
-                if (ve1 > h) { h = ve1; src = 1; }
-                if (vf1 > h) { h = vf1; src = 2; }
-                if (ve2 > h) { h = ve2; src = 3; }
-                if (vf2 > h) { h = vf2; src = 4; }
-                tb[(int64_t)a * stride + ((d - dlo) >> 1)] = (uint8_t)(t | src);
+                uint32_t t = d_cell(o, H[x], H[x - 1], E1[x - 1], E2[x - 1], H[x + 1], F1[x + 1], F2[x + 1], qb, tbv, h, ve1, vf1, ve2, vf2);
+                tb[(int64_t)a * stride + ((d - dlo) >> 1)] = (uint8_t)t;
+                ++ncell;
             }
             if (h < TELR_NEG) h = TELR_NEG;
             if (ve1 < TELR_NEG) ve1 = TELR_NEG;
@@ -612,11 +650,10 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
             if (ve2 < TELR_NEG) ve2 = TELR_NEG;
             if (vf2 < TELR_NEG) vf2 = TELR_NEG;
             H[x] = h; E1[x] = ve1; F1[x] = vf1; E2[x] = ve2; F2[x] = vf2;
-            // max h, smallest d among ties
-            int64_t kk = (int64_t)h * 4294967296LL + (int64_t)(0x7fffffff - (d - dlo));
+            int64_t kk = (int64_t)h * 4294967296LL + (int64_t)(0x7fffffff - (d - dlo));   // max h, smallest d among ties
             curk = kk > curk ? kk : curk;
         }
-        __syncthreads();   // single wave: orders the LDS writes of this step before the next step's reads
+        __syncthreads();   // single wave: orders this step's LDS writes before the next step's reads
         if (ext) {
             curk = d_wave_max64(curk);
             int cur = TELR_NEG, cur_d = 0;
@@ -628,32 +665,228 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
         }
     }
     __syncthreads();
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) ncell += __shfl_xor(ncell, s);
     if (lane == 0) {
-        int i, j;
-        if (ext) { R.score = best; i = bi; j = bj; }
-        else { R.score = H[(n - m) - dlo + 1]; i = m; j = n; }
-        R.bi = i; R.bj = j;
-        uint32_t *cg = A.cig + P.cig_off;
-        int no = 0, ml = 0, state = 0, cur_op = -1, cur_len = 0;
-        while (i > 0 && j > 0) {
-            // sc1 load: served from L2, never from a stale L1 line
-            uint32_t t = __hip_atomic_load(tb + (int64_t)(i + j) * stride + ((j - i - dlo) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (state == 0) state = t & 7;
-            int op;
-            if (state == 0) { op = 0; ml += (t >> 7) & 1; --i; --j; }
-            else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
-            else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
-            else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
-            else                 { op = 1; if (!(t & 64)) state = 0; --i; }
-            if (op == cur_op) ++cur_len;
-            else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
-        }
-        if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
-        if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
-        if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
-        R.nops = no; R.mlen = ml;
+        if (ext) { R.score = best; R.bi = bi; R.bj = bj; }
+        else { R.score = H[(n - m) - dlo + 1]; R.bi = m; R.bj = n; }
+        R.cells = ncell;
         A.res[prob] = R;
     }
+}
+
+// ---- register forward kernel for gap-fill problems (global alignment, D <= 2*R*LPP).
+// LPP lanes per problem (64/LPP problems per wave); lane l owns the 2R consecutive
+// diagonals dlo+2R*l .. dlo+2R*l+2R-1 in registers (dlo is even), as R (even, odd) pairs.
+// Odd anti-diagonals update the odd diagonals, even ones the even diagonals, so every lane
+// computes R cells per step; the only values that cross lanes are the (H, F1, F2) of the
+// next lane's first even diagonal (odd steps) or the (H, E1, E2) of the previous lane's last
+// odd diagonal (even steps): three DPP wave shifts per step, no LDS.
+//   * boundary cells (row 0 / column 0) are pre-loaded into the registers, so the loop has no
+//     boundary branches; each diagonal's interior cells are live for a in [alo, alo+span];
+//   * bases stream through per-lane shift registers (32 bases per 64-bit refill, refilled
+//     on a wave-uniform cadence): one new query base per even step, one new target base per
+//     odd step, handed from pair to pair inside the lane;
+//   * trace-back bytes are packed four steps per dword: tb32[(a>>2)*SLOTS + l*R + r], byte a&3.
+// Unreachable cells are not clamped to NEG (the oracle clamps): such values are never
+// selected by a reachable cell, so scores and CIGARs are identical.
+struct BaseStream { uint64_t w; uint32_t nm; };
+
+// 32 bases starting at absolute base index `start` (may lie outside the array), base b at bits 2*(b-start)
+__device__ __forceinline__ void d_load32(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, int64_t start, int64_t tot,
+                                         uint64_t &w, uint32_t &nm)
+{
+    int64_t s = start; int lsh = 0;
+    if (s < 0) { lsh = (int)(-s); s = 0; }
+    if (s > tot) s = tot;
+    const int64_t wi = s >> 4; const int sh = (int)(s & 15) * 2;
+    const uint64_t lo = (uint64_t)seq2[wi] | (uint64_t)seq2[wi + 1] << 32, hi = seq2[wi + 2];
+    uint64_t v = lo >> sh;
+    if (sh) v |= hi << (64 - sh);
+    const int64_t ni = s >> 5;
+    uint32_t nn = (uint32_t)(((uint64_t)nmask[ni] | (uint64_t)nmask[ni + 1] << 32) >> (int)(s & 31));
+    if (lsh) { v = lsh >= 32 ? 0 : v << (2 * lsh); nn = lsh >= 32 ? 0 : nn << lsh; }
+    w = v; nm = nn;
+}
+// next 32 bases in consumption order, starting at DP index x of a sequence whose DP index 0 is absolute base i0
+__device__ __forceinline__ void d_stream_fill(BaseStream &S, const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask,
+                                              int64_t i0, int step, int x, int comp, int64_t tot)
+{
+    if (step > 0) d_load32(seq2, nmask, i0 + x, tot, S.w, S.nm);
+    else { uint64_t w; uint32_t nm; d_load32(seq2, nmask, i0 - x - 31, tot, w, nm); S.w = d_rev2(w, 32); S.nm = __brev(nm); }
+    if (comp) S.w = ~S.w;
+}
+__device__ __forceinline__ int d_stream_next(BaseStream &S)
+{
+    const int c = (int)((uint32_t)S.w & 3u), isn = (int)(S.nm & 1u);
+    S.w >>= 2; S.nm >>= 1;
+    return isn ? 4 : c;
+}
+__device__ __forceinline__ void d_init_diag(const DpOpt &o, int d, int dhi, int m, int n, bool have,
+                                            int32_t &H, int32_t &E1, int32_t &E2, int32_t &F1, int32_t &F2, int32_t &alo, int32_t &span)
+{
+    H = E1 = E2 = F1 = F2 = TELR_NEG; alo = 0x40000000; span = 0;
+    if (!have || d > dhi) return;
+    if (d == 0) H = 0;
+    else if (d > 0) { E1 = -(o.q + d * o.e); E2 = -(o.q2 + d * o.e2); H = E1 > E2 ? E1 : E2; }
+    else { F1 = -(o.q - d * o.e); F2 = -(o.q2 - d * o.e2); H = F1 > F2 ? F1 : F2; }
+    const int lo = (d < 0 ? -d : d) + 2, hi1 = 2 * m + d, hi2 = 2 * n - d, hi = hi1 < hi2 ? hi1 : hi2;
+    if (hi >= lo) { alo = lo; span = hi - lo; }
+}
+// cell without the NEG clamps
+__device__ __forceinline__ uint32_t d_cell_nc(const DpOpt &o, int32_t hd, int32_t hl, int32_t e1l, int32_t e2l, int32_t hu, int32_t f1u, int32_t f2u,
+                                              int qb, int tbv, int32_t &h, int32_t &ve1, int32_t &vf1, int32_t &ve2, int32_t &vf2)
+{
+    uint32_t t = 0; int32_t op, g;
+    op = hl - (o.q + o.e);   g = e1l - o.e;  ve1 = g > op ? g : op; t |= g > op ? 8u : 0u;
+    op = hu - (o.q + o.e);   g = f1u - o.e;  vf1 = g > op ? g : op; t |= g > op ? 16u : 0u;
+    op = hl - (o.q2 + o.e2); g = e2l - o.e2; ve2 = g > op ? g : op; t |= g > op ? 32u : 0u;
+    op = hu - (o.q2 + o.e2); g = f2u - o.e2; vf2 = g > op ? g : op; t |= g > op ? 64u : 0u;
+    int sc = qb == tbv ? o.a : -o.b;
+    t |= qb == tbv ? 128u : 0u;
+    if ((qb | tbv) > 3) { sc = -o.sc_ambi; t &= ~128u; }
+    h = hd + sc; uint32_t src = 0;
+    if (ve1 > h) { h = ve1; src = 1; }
+    if (vf1 > h) { h = vf1; src = 2; }
+    if (ve2 > h) { h = ve2; src = 3; }
+    if (vf2 > h) { h = vf2; src = 4; }
+    return t | src;
+}
+#define DPP_SHR1(old, v) __builtin_amdgcn_update_dpp((old), (v), 0x138, 0xf, 0xf, false)   /* lane i <- lane i-1 */
+#define DPP_SHL1(old, v) __builtin_amdgcn_update_dpp((old), (v), 0x130, 0xf, 0xf, false)   /* lane i <- lane i+1 */
+
+template <int LPP, int R>
+__global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
+{
+    constexpr int PPW = 64 / LPP, SLOTS = LPP * R;
+    const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
+    const int pi = blockIdx.x * PPW + sub;
+    const bool have = pi < A.nlist;
+    const int prob = A.list[have ? pi : 0];
+    const DpProb P = A.probs[prob];
+    const DpOpt o = A.o;
+    const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo, dhi = P.dhi;
+    const int de0 = dlo + 2 * R * l;
+    int32_t He[R], E1e[R], E2e[R], F1e[R], F2e[R], Ho[R], E1o[R], E2o[R], F1o[R], F2o[R];
+    int32_t aloE[R], spanE[R], aloO[R], spanO[R];
+    int qbs[R], tbs[R];
+    const int qs_ = P.qstep, ts_ = P.tstep;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        d_init_diag(o, de0 + 2 * r, dhi, m, n, have, He[r], E1e[r], E2e[r], F1e[r], F2e[r], aloE[r], spanE[r]);
+        d_init_diag(o, de0 + 2 * r + 1, dhi, m, n, have, Ho[r], E1o[r], E2o[r], F1o[r], F2o[r], aloO[r], spanO[r]);
+        // bases of "even step 0" (query rows) and "odd step -1" (target columns)
+        const int i0 = ((0 - de0) >> 1) - r, j0 = (de0 >> 1) + r;
+        qbs[r] = 4; tbs[r] = 4;
+        if (i0 >= 1 && i0 <= m) { int c = d_base(A.qseq2, A.qnmask, P.qi0 + (int64_t)qs_ * (i0 - 1)); qbs[r] = (P.qcomp && c < 4) ? 3 - c : c; }
+        if (j0 >= 1 && j0 <= n) tbs[r] = d_base(A.tseq2, A.tnmask, P.ti0 + (int64_t)ts_ * (j0 - 1));
+    }
+    int amax = m + n;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+    uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off);
+    const int last_row = have ? (m + n) >> 2 : -1;
+    BaseStream QS, TS; QS.w = 0; QS.nm = 0; TS.w = 0; TS.nm = 0;
+    uint32_t tbw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) tbw[r] = 0;
+    int ncell = 0;
+    for (int a = 1; a <= amax; ++a) {
+        const int sh = 8 * (a & 3);
+        if (a & 1) {
+            // ---- odd step: odd diagonals; one new target base enters at pair R-1
+            if ((((a - 1) >> 1) & 31) == 0) d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, ((a + de0 + 1) >> 1) + R - 2, 0, A.ttot);
+#pragma unroll
+            for (int r = 0; r < R - 1; ++r) tbs[r] = tbs[r + 1];
+            tbs[R - 1] = d_stream_next(TS);
+            int32_t hu = DPP_SHL1(TELR_NEG, He[0]), f1u = DPP_SHL1(TELR_NEG, F1e[0]), f2u = DPP_SHL1(TELR_NEG, F2e[0]);
+            if (LPP < 64 && l == LPP - 1) { hu = TELR_NEG; f1u = TELR_NEG; f2u = TELR_NEG; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int32_t uh = r < R - 1 ? He[r < R - 1 ? r + 1 : r] : hu, uf1 = r < R - 1 ? F1e[r < R - 1 ? r + 1 : r] : f1u, uf2 = r < R - 1 ? F2e[r < R - 1 ? r + 1 : r] : f2u;
+                if ((uint32_t)(a - aloO[r]) <= (uint32_t)spanO[r]) {
+                    int32_t h, ve1, vf1, ve2, vf2;
+                    uint32_t t = d_cell_nc(o, Ho[r], He[r], E1e[r], E2e[r], uh, uf1, uf2, qbs[r], tbs[r], h, ve1, vf1, ve2, vf2);
+                    tbw[r] |= t << sh; ++ncell;
+                    Ho[r] = h; E1o[r] = ve1; F1o[r] = vf1; E2o[r] = ve2; F2o[r] = vf2;
+                }
+            }
+        } else {
+            // ---- even step: even diagonals; one new query base enters at pair 0
+            if ((((a >> 1) - 1) & 31) == 0) d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, ((a - de0) >> 1) - 1, P.qcomp, A.qtot);
+#pragma unroll
+            for (int r = R - 1; r > 0; --r) qbs[r] = qbs[r - 1];
+            qbs[0] = d_stream_next(QS);
+            int32_t hl = DPP_SHR1(TELR_NEG, Ho[R - 1]), e1l = DPP_SHR1(TELR_NEG, E1o[R - 1]), e2l = DPP_SHR1(TELR_NEG, E2o[R - 1]);
+            if (LPP < 64 && l == 0) { hl = TELR_NEG; e1l = TELR_NEG; e2l = TELR_NEG; }
+#pragma unroll
+            for (int r = R - 1; r >= 0; --r) {
+                const int32_t lh = r > 0 ? Ho[r > 0 ? r - 1 : 0] : hl, le1 = r > 0 ? E1o[r > 0 ? r - 1 : 0] : e1l, le2 = r > 0 ? E2o[r > 0 ? r - 1 : 0] : e2l;
+                if ((uint32_t)(a - aloE[r]) <= (uint32_t)spanE[r]) {
+                    int32_t h, ve1, vf1, ve2, vf2;
+                    uint32_t t = d_cell_nc(o, He[r], lh, le1, le2, Ho[r], F1o[r], F2o[r], qbs[r], tbs[r], h, ve1, vf1, ve2, vf2);
+                    tbw[r] |= t << sh; ++ncell;
+                    He[r] = h; E1e[r] = ve1; F1e[r] = vf1; E2e[r] = ve2; F2e[r] = vf2;
+                }
+            }
+        }
+        if ((a & 3) == 3 || a == amax) {
+            if ((a >> 2) <= last_row) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) tb32[(int64_t)(a >> 2) * SLOTS + l * R + r] = tbw[r];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) tbw[r] = 0;
+        }
+    }
+#pragma unroll
+    for (int s = LPP / 2; s >= 1; s >>= 1) ncell += __shfl_xor(ncell, s);
+    if (have) {
+        const int xf = (n - m) - de0;      // offset of the final diagonal inside this lane's block
+        if (xf >= 0 && xf < 2 * R) {
+            int32_t sc = TELR_NEG;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { if (xf == 2 * r) sc = He[r]; if (xf == 2 * r + 1) sc = Ho[r]; }
+            DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = ncell; Rr.tbases = n; Rr.pad = 0;
+            A.res[prob] = Rr;
+        }
+    }
+}
+
+// ---- trace-back: one thread per problem walks its trace-back bytes and writes the
+// run-length CIGAR in end->start order (64 independent pointer chases per wave).
+__global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
+                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig)
+{
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= np) return;
+    const DpProb P = probs[pi];
+    if (P.kind == 3) return;
+    const int cls = P.pad[0], dlo = P.dlo;
+    const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
+    const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
+    const bool packed = cls >= 5;
+    const uint8_t *tb = tb_all + P.tb_off;
+    int i = res[pi].bi, j = res[pi].bj;
+    uint32_t *cg = cig + P.cig_off;
+    int no = 0, ml = 0, state = 0, cur_op = -1, cur_len = 0;
+    while (i > 0 && j > 0) {
+        const int a = i + j, sl = (j - i - dlo) >> 1;
+        const uint32_t t = packed ? tb[(((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)] : tb[(int64_t)a * stride + sl];
+        if (state == 0) state = t & 7;
+        int op;
+        if (state == 0) { op = 0; ml += (t >> 7) & 1; --i; --j; }
+        else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
+        else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
+        else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
+        else                 { op = 1; if (!(t & 64)) state = 0; --i; }
+        if (op == cur_op) ++cur_len;
+        else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
+    }
+    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
+    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
+    if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+    res[pi].nops = no; res[pi].mlen = ml;
 }
 
 // compact the raw per-problem cigars (emission order preserved) into one dense array

@@ -28,11 +28,14 @@ static const char *STAGE_NAMES[TELR_N_STAGES] = {
 };
 enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX };
 
+#define TELR_NSIDE 8
 struct DBuf { void *p = nullptr; size_t bytes = 0; };
 
 struct telr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side[8] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_side[8] = {nullptr};
     std::string err;
     std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
     float stage_ms[TELR_N_STAGES] = {0};
@@ -106,7 +109,8 @@ extern "C" int telr_init(int device, telr_ctx **out)
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    for (int i = 0; i < TELR_NSIDE; ++i) if (hipStreamCreate(&ctx->side[i]) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     *out = ctx;
     return TELR_OK;
 }
@@ -118,6 +122,8 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < TELR_NSIDE; ++i) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_side[i]) (void)hipEventDestroy(ctx->ev_side[i]); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     delete ctx;
 }
 extern "C" int telr_device_name(const telr_ctx *ctx, char *buf, int buflen)
@@ -694,8 +700,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "cig_ops", (size_t)np + 1, &d_cgo));
         TRY(ctx_buf_t(ctx, "tb_off", (size_t)np + 1, &d_tboff));
         TRY(ctx_buf_t(ctx, "cig_off", (size_t)np + 1, &d_cgoff));
-        TRY(ctx_buf_t(ctx, "cls_cnt", 8, &d_clscnt));
-        TRY(ctx_buf_t(ctx, "cls_list", (size_t)np * 5, &d_clslist));
+        TRY(ctx_buf_t(ctx, "cls_cnt", 16, &d_clscnt));
+        TRY(ctx_buf_t(ctx, "cls_list", (size_t)np * DP_NCLS, &d_clslist));
         hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
         hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tbb, d_cgo);
         HIPCHK(hipGetLastError());
@@ -703,13 +709,13 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
         TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbb, d_tboff, (size_t)np + 1)));
         TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_cgo, d_cgoff, (size_t)np + 1)));
-        HIPCHK(hipMemsetAsync(d_clscnt, 0, 32, st));
+        HIPCHK(hipMemsetAsync(d_clscnt, 0, 64, st));
         hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, d_cgoff, d_clscnt, d_clslist);
         HIPCHK(hipGetLastError());
-        int64_t tb_total = 0, cg_total = 0; int32_t h_cls[8];
+        int64_t tb_total = 0, cg_total = 0; int32_t h_cls[16];
         HIPCHK(hipMemcpyAsync(&tb_total, d_tboff + np, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&cg_total, d_cgoff + np, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 64, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         t_sg.stop();
         ctx->ctr.dp_problems += np;
@@ -721,17 +727,47 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "rawcig", (size_t)cg_total + 16, &d_rawcig));
         TRY(ctx_buf_t(ctx, "dp_res", (size_t)np, &d_res));
         DpArgs D; D.qseq2 = qs->d_seq2; D.qnmask = qs->d_nmask; D.tseq2 = tg->d_seq2; D.tnmask = tg->d_nmask; D.probs = d_probs;
+        D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
         D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
-        D.tb = d_tb; D.cig = d_rawcig; D.res = d_res;
+        D.tb = d_tb; D.cig = d_rawcig; D.res = d_res; D.dcap = 0;
         static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
-        for (int c = 0; c < 5; ++c) {
+        // register kernels first (the bulk of the work), then the LDS-state classes
+        // The few long/wide problems are latency-bound single waves: start each tail class on its
+        // own side stream so that they run underneath the bulk classes on the main stream.
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        int side = 0;
+        auto side_stream = [&]() { hipStream_t s = ctx->side[side % TELR_NSIDE]; ++side; return s; };
+        std::vector<hipStream_t> used;
+        for (int c = 4; c >= 0; --c) {
             if (h_cls[c] == 0) continue;
+            hipStream_t s2 = side_stream(); used.push_back(s2);
+            HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
             D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c]; D.dcap = CAP[c];
             size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
             if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, st, D);
+            hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, s2, D);
             HIPCHK(hipGetLastError());
         }
+        D.dcap = 0;
+        for (int c = 9; c >= 7; --c) {
+            if (h_cls[c] == 0) continue;
+            hipStream_t s2 = side_stream(); used.push_back(s2);
+            HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+            D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c];
+            if (c == 9) hipLaunchKernelGGL((k_dp_reg<64, 8>), dim3(h_cls[c]), dim3(64), 0, s2, D);
+            else if (c == 8) hipLaunchKernelGGL((k_dp_reg<64, 4>), dim3(h_cls[c]), dim3(64), 0, s2, D);
+            else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
+            HIPCHK(hipGetLastError());
+        }
+        if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
+        if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
+        HIPCHK(hipGetLastError());
+        for (size_t u = 0; u < used.size(); ++u) {
+            HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
+        }
+        hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, d_rawcig);
+        HIPCHK(hipGetLastError());
         t_dp.stop();
 
         // ---- compact cigars and bring results home -------------------------------------------------
@@ -763,6 +799,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         if (nk < 256) nth = 1;
         std::vector<std::thread> th;
         std::vector<int64_t> cells(nth, 0), wbases(nth, 0);
+        for (int i = 0; i < np; ++i) { ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
         for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
             for (int x = t; x < nk; x += nth) {
                 const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x]; std::vector<uint32_t> &cg = kcig[x];

@@ -47,7 +47,7 @@ def compare_all(engine, targets, queries, io, mo, qtarget=None, stages=True):
         np.testing.assert_array_equal(res.cigars[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]],
                                       oref["cigars"][b["cigar_off"]:b["cigar_off"] + b["n_cigar"]], err_msg="cigar of record %d" % i)
     ctr = engine.counters()
-    for k in ("query_bases", "minimizers", "anchors", "chains", "dp_problems", "records", "cigar_ops"):
+    for k in ("query_bases", "minimizers", "anchors", "chains", "dp_problems", "dp_cells", "window_bases", "records", "cigar_ops"):
         assert ctr[k] == oref["counters"][k], (k, ctr[k], oref["counters"][k])
     return res, oref
 
@@ -143,3 +143,29 @@ def test_depth_medians(engine):
         assert got[1] > 3
     finally:
         gix.free_raw(r)
+
+
+def test_wide_bands(engine):
+    """Anchor-free stretches force long gap-fill segments: register kernel with 2/4/8 diagonal pairs
+    per lane, the LDS kernel and (asm10, bw=10000) very wide bands."""
+    rng = np.random.default_rng(99)
+    genome = synth.random_seq(rng, 120000)
+    reads = []
+    for gap in (1500, 3000, 4500, 900, 2200):
+        for rep in range(2):
+            s = int(rng.integers(0, 100000)); L = 12000 + gap
+            r = genome[s:s + L].copy()
+            a = 5000
+            r[a:a + gap] = synth.mutate(rng, r[a:a + gap], 0.35, 0.0, 0.0)       # no shared minimizers in here
+            if rep:
+                # unequal lengths: delete part of the read inside the stretch
+                r = np.concatenate([r[:a + 100], r[a + 100 + gap // 8:]])
+            r = synth.mutate(rng, r, 0.02, 0.01, 0.01)
+            if rng.integers(0, 2):
+                r = synth.revcomp_arr(r)
+            reads.append(r)
+    io, mo = preset("map-ont")
+    res, oref = compare_all(engine, [genome], reads, io, mo)
+    assert oref["counters"]["dp_problems"] > 0
+    io2, mo2 = preset("asm10")
+    compare_all(engine, [genome], reads, io2, mo2)

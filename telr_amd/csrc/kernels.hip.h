@@ -419,7 +419,7 @@ struct DpProb {             // 64 B
     int32_t chain;          // kept-chain index
     int32_t pad[2];
 };
-struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, pad; };   // 32 B
+struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, mcols; };   // 32 B; mcols = M columns of the path
 
 __device__ __forceinline__ int d_fill_band(int m, int n, int bw)
 {
@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     const int m = P.m, n = P.n, dlo = P.dlo, dhi = P.dhi, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const DpOpt o = A.o;
     const bool ext = P.kind == 1 || P.kind == 2;
-    DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.cells = 0; R.tbases = n; R.pad = 0;
+    DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.cells = 0; R.tbases = n; R.mcols = 0;
     int ncell = 0;
 
     if (P.kind == 3) {
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
             int no = 0;
             if (g) A.cig[P.cig_off + no++] = (uint32_t)g << 4 | (m > n ? 1u : 2u);
             if (mn) A.cig[P.cig_off + no++] = (uint32_t)mn << 4;
-            R.score = sc; R.bi = m; R.bj = n; R.nops = no; R.mlen = ml;
+            R.score = sc; R.bi = m; R.bj = n; R.nops = no; R.mlen = ml; R.mcols = mn;
             A.res[prob] = R;
         }
         return;
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
             int32_t sc = TELR_NEG;
 #pragma unroll
             for (int r = 0; r < R; ++r) { if (xf == 2 * r) sc = He[r]; if (xf == 2 * r + 1) sc = Ho[r]; }
-            DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = ncell; Rr.tbases = n; Rr.pad = 0;
+            DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = ncell; Rr.tbases = n; Rr.mcols = 0;
             A.res[prob] = Rr;
         }
     }
@@ -869,13 +869,13 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     const uint8_t *tb = tb_all + P.tb_off;
     int i = res[pi].bi, j = res[pi].bj;
     uint32_t *cg = cig + P.cig_off;
-    int no = 0, ml = 0, state = 0, cur_op = -1, cur_len = 0;
+    int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
     while (i > 0 && j > 0) {
         const int a = i + j, sl = (j - i - dlo) >> 1;
         const uint32_t t = packed ? tb[(((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)] : tb[(int64_t)a * stride + sl];
         if (state == 0) state = t & 7;
         int op;
-        if (state == 0) { op = 0; ml += (t >> 7) & 1; --i; --j; }
+        if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
         else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
         else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
         else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
     if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
-    res[pi].nops = no; res[pi].mlen = ml;
+    res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
 }
 
 // compact the raw per-problem cigars (emission order preserved) into one dense array

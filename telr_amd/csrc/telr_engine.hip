@@ -38,6 +38,8 @@ struct telr_ctx {
     hipEvent_t ev_fork = nullptr, ev_side[8] = {nullptr};
     std::string err;
     std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
+    std::map<std::string, DBuf> hbufs;    // grow-only pinned host staging buffers
+    int debug = 0;                        // keep stage-level captures for the parity tests
     float stage_ms[TELR_N_STAGES] = {0};
     telr_counters ctr = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -64,6 +66,23 @@ static int ctx_buf(telr_ctx *ctx, const char *name, size_t bytes, void **out)
     }
     *out = b.p;
     return TELR_OK;
+}
+static int ctx_hbuf(telr_ctx *ctx, const char *name, size_t bytes, void **out)
+{
+    DBuf &b = ctx->hbufs[name];
+    if (b.bytes < bytes || !b.p) {
+        if (b.p) HIPCHK(hipHostFree(b.p));
+        b.p = nullptr; b.bytes = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+        b.bytes = want;
+    }
+    *out = b.p;
+    return TELR_OK;
+}
+template <typename T> static int ctx_hbuf_t(telr_ctx *ctx, const char *name, size_t n, T **out)
+{
+    void *p; TRY(ctx_hbuf(ctx, name, (n ? n : 1) * sizeof(T), &p)); *out = (T*)p; return TELR_OK;
 }
 template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size_t n, T **out)
 {
@@ -107,6 +126,7 @@ extern "C" int telr_init(int device, telr_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return TELR_E_NODEVICE;
     telr_ctx *ctx = new telr_ctx();
     ctx->device = device;
+    if (const char *e = getenv("TELR_DEBUG")) ctx->debug = atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
@@ -119,6 +139,7 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : ctx->hbufs) if (kv.second.p) (void)hipHostFree(kv.second.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -475,18 +496,42 @@ static int32_t mapq_of(const telr_aln &r, const telr_map_opt *mo)
 
 struct telr_result {
     std::vector<telr_aln> alns;
-    std::vector<uint32_t> cigars;
+    uint32_t *cig = nullptr;       // malloc'ed, never zero-filled: pages are first touched by the stitching threads
+    size_t ncig = 0;
+    ~telr_result() { free(cig); }
 };
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
-extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->cigars.size() : 0; }
-extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { return r ? r->cigars.data() : nullptr; }
+extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->ncig : 0; }
+extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { return r ? r->cig : nullptr; }
 extern "C" void telr_result_free(telr_result *r) { delete r; }
 
 static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
 {
     if (!len) return;
     if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
+}
+
+static int host_threads()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("TELR_HOST_THREADS")) { int v = atoi(e); if (v > 0) n = v; }
+    if (n < 1) n = 1;
+    if (n > 32) n = 32;
+    return n;
+}
+// run f(t, begin, end) over [0,n) split into nt contiguous ranges (in order of t)
+template <typename F> static void parallel_ranges(int nt, int n, F f)
+{
+    if (n <= 0) return;
+    if (nt > n) nt = n;
+    if (nt <= 1 || n < 64) { f(0, 0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) {
+        int a = (int)((int64_t)n * t / nt), b = (int)((int64_t)n * (t + 1) / nt);
+        th.emplace_back([=, &f]() { f(t, a, b); });
+    }
+    for (auto &x : th) x.join();
 }
 
 struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int64_t a_glob; };
@@ -611,89 +656,102 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     t_bt.stop();
     ctx->dbg_na = na; ctx->dbg_nq = nq;
 
-    // ---- host: chain boxes + selection pass 1 ---------------------------------------------------
+    // ---- host: chain boxes + selection pass 1 (threads over queries) ------------------------------
     StageTimer t_sel(ctx, ST_SELECT, false);
-    std::vector<HostChain> chains;                 // all chains of the batch, query-major
+    const int NT = host_threads();
     std::vector<int32_t> q_ch0(nq + 1, 0);
-    for (int q = 0; q < nq; ++q) {
-        q_ch0[q] = (int32_t)chains.size();
-        const int qlen = qs->len[q0 + q]; (void)qlen;
-        for (int c = 0; c < h_nch[q]; ++c) {
-            const ChainRec &r = h_rec[h_choff[q] + c];
-            HostChain hc; hc.qid = q0 + q; hc.score = r.score; hc.cnt = r.cnt; hc.rev = (int)(r.a0 >> 63); hc.disc = c;
-            uint32_t g0 = (uint32_t)A_G(r.a0);
-            int tid = (int)(std::upper_bound(ix->goff.begin(), ix->goff.begin() + tg->n, g0) - ix->goff.begin()) - 1;
-            hc.tid = tid;
-            int go = (int)ix->goff[tid];
-            hc.rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; hc.re = A_G(r.a1) - go + 1;
-            hc.qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      hc.qe = A_Q(r.a1) + 1;
-            hc.a_glob = (int64_t)h_qaoff[q] + r.a_off;
-            chains.push_back(hc);
-        }
-    }
-    q_ch0[nq] = (int32_t)chains.size();
-    ctx->ctr.chains += (int64_t)chains.size();
-    ctx->dbg_chain.clear();
-    for (const HostChain &c : chains) { int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
-
-    std::vector<int32_t> kept;                     // indices into chains, query-major, pass-1 rank order
+    for (int q = 0; q < nq; ++q) q_ch0[q + 1] = q_ch0[q] + h_nch[q];
+    const int n_chain_tot = q_ch0[nq];
+    std::vector<HostChain> chains((size_t)n_chain_tot);          // all chains of the batch, query-major
+    std::vector<int32_t> kept;                                    // indices into chains, query-major, pass-1 rank order
     std::vector<int32_t> q_k0(nq + 1, 0);
     {
-        std::vector<Sel> s; std::vector<int32_t> cscore;
-        for (int q = 0; q < nq; ++q) {
-            q_k0[q] = (int32_t)kept.size();
-            const int c0 = q_ch0[q], n = q_ch0[q + 1] - c0, qlen = qs->len[q0 + q];
-            s.resize(n); cscore.resize(n);
-            for (int i = 0; i < n; ++i) {
-                const HostChain &c = chains[c0 + i];
-                s[i].ci = i; s[i].key = c.score; s[i].ord = c.disc; s[i].tid = c.tid;
-                if (c.rev) { s[i].fs = qlen - c.qe; s[i].fe = qlen - c.qs; } else { s[i].fs = c.qs; s[i].fe = c.qe; }
-                cscore[i] = c.score;
+        std::vector<std::vector<int32_t>> tkept(NT);
+        std::vector<int32_t> q_nk(nq, 0);
+        parallel_ranges(NT, nq, [&](int t, int qa, int qb) {
+            std::vector<Sel> s; std::vector<int32_t> cscore;
+            for (int q = qa; q < qb; ++q) {
+                const int c0 = q_ch0[q], n = h_nch[q], qlen = qs->len[q0 + q];
+                for (int c = 0; c < n; ++c) {
+                    const ChainRec &r = h_rec[h_choff[q] + c];
+                    HostChain &hc = chains[c0 + c];
+                    hc.qid = q0 + q; hc.score = r.score; hc.cnt = r.cnt; hc.rev = (int)(r.a0 >> 63); hc.disc = c;
+                    uint32_t g0 = (uint32_t)A_G(r.a0);
+                    int tid = (int)(std::upper_bound(ix->goff.begin(), ix->goff.begin() + tg->n, g0) - ix->goff.begin()) - 1;
+                    hc.tid = tid;
+                    int go = (int)ix->goff[tid];
+                    hc.rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; hc.re = A_G(r.a1) - go + 1;
+                    hc.qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      hc.qe = A_Q(r.a1) + 1;
+                    hc.a_glob = (int64_t)h_qaoff[q] + r.a_off;
+                }
+                s.resize(n); cscore.resize(n);
+                for (int i = 0; i < n; ++i) {
+                    const HostChain &c = chains[c0 + i];
+                    s[i].ci = i; s[i].key = c.score; s[i].ord = c.disc; s[i].tid = c.tid;
+                    if (c.rev) { s[i].fs = qlen - c.qe; s[i].fe = qlen - c.qs; } else { s[i].fs = c.qs; s[i].fe = c.qe; }
+                    cscore[i] = c.score;
+                }
+                std::sort(s.begin(), s.end(), sel_less);
+                select_chains(s, mo, cscore);
+                int nkq = 0;
+                for (int i = 0; i < n; ++i) if (s[i].keep) { tkept[t].push_back(c0 + s[i].ci); ++nkq; }
+                q_nk[q] = nkq;
             }
-            std::sort(s.begin(), s.end(), sel_less);
-            select_chains(s, mo, cscore);
-            for (int i = 0; i < n; ++i) if (s[i].keep) kept.push_back(c0 + s[i].ci);
-        }
-        q_k0[nq] = (int32_t)kept.size();
+        });
+        for (int q = 0; q < nq; ++q) q_k0[q + 1] = q_k0[q] + q_nk[q];
+        kept.reserve(q_k0[nq]);
+        for (int t = 0; t < NT; ++t) kept.insert(kept.end(), tkept[t].begin(), tkept[t].end());   // ranges are contiguous and ordered
+    }
+    ctx->ctr.chains += n_chain_tot;
+    if (ctx->debug) {
+        ctx->dbg_chain.clear();
+        for (const HostChain &c : chains) { int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
     }
     const int nk = (int)kept.size();
     t_sel.stop();
 
-    // results per kept chain
-    std::vector<telr_aln> kal(nk);
-    std::vector<std::vector<uint32_t>> kcig(nk);
-    for (int x = 0; x < nk; ++x) {
-        const HostChain &c = chains[kept[x]];
-        telr_aln &r = kal[x]; memset(&r, 0, sizeof(r));
-        const int qlen = qs->len[c.qid];
-        r.qid = c.qid; r.tid = c.tid; r.qlen = qlen; r.tlen = tg->len[c.tid]; r.score = c.score; r.cnt = c.cnt; r.flags = c.rev ? TELR_F_REV : 0;
-        r.ts = c.rs; r.te = c.re;
-        if (c.rev) { r.qs = qlen - c.qe; r.qe = qlen - c.qs; } else { r.qs = c.qs; r.qe = c.qe; }
-        r.mlen = std::min(c.score, c.qe - c.qs); r.blen = std::max(c.qe - c.qs, c.re - c.rs); r.dp_score = c.score;
-    }
+    // results per kept chain (chain-level numbers; overwritten by the DP numbers below)
+    std::vector<telr_aln> kal((size_t)nk);
+    parallel_ranges(NT, nk, [&](int, int xa, int xb) {
+        for (int x = xa; x < xb; ++x) {
+            const HostChain &c = chains[kept[x]];
+            telr_aln &r = kal[x]; memset(&r, 0, sizeof(r));
+            const int qlen = qs->len[c.qid];
+            r.qid = c.qid; r.tid = c.tid; r.qlen = qlen; r.tlen = tg->len[c.tid]; r.score = c.score; r.cnt = c.cnt; r.flags = c.rev ? TELR_F_REV : 0;
+            r.ts = c.rs; r.te = c.re;
+            if (c.rev) { r.qs = qlen - c.qe; r.qe = qlen - c.qs; } else { r.qs = c.qs; r.qe = c.qe; }
+            r.mlen = std::min(c.score, c.qe - c.qs); r.blen = std::max(c.qe - c.qs, c.re - c.rs); r.dp_score = c.score;
+        }
+    });
 
-    if ((mo->flags & TELR_MF_CIGAR) && nk > 0) {
+    const bool do_dp = (mo->flags & TELR_MF_CIGAR) && nk > 0;
+    std::vector<int32_t> h_poff; DpRes *h_res = nullptr; uint32_t *h_cig = nullptr; std::vector<int64_t> h_doff;
+    int np = 0;
+    if (do_dp) {
         // ---- DP problem list ----------------------------------------------------------------
         StageTimer t_sg(ctx, ST_SEGMENTS, true);
-        std::vector<KeptChain> hk(nk);
-        for (int x = 0; x < nk; ++x) {
-            const HostChain &c = chains[kept[x]]; KeptChain &K = hk[x];
-            K.qid = c.qid; K.tid = c.tid; K.rev = c.rev; K.cnt = c.cnt; K.a_glob = c.a_glob; K.rs = c.rs; K.qs = c.qs; K.re = c.re; K.qe = c.qe;
-            K.qlen = qs->len[c.qid]; K.tlen = tg->len[c.tid]; K.qbase = qs->boff[c.qid]; K.tbase = tg->boff[c.tid]; K.goff = ix->goff[c.tid]; K.pad = 0;
-        }
+        KeptChain *hk;
+        TRY(ctx_hbuf_t(ctx, "h_kept", (size_t)nk, &hk));
+        parallel_ranges(NT, nk, [&](int, int xa, int xb) {
+            for (int x = xa; x < xb; ++x) {
+                const HostChain &c = chains[kept[x]]; KeptChain &K = hk[x];
+                K.qid = c.qid; K.tid = c.tid; K.rev = c.rev; K.cnt = c.cnt; K.a_glob = c.a_glob; K.rs = c.rs; K.qs = c.qs; K.re = c.re; K.qe = c.qe;
+                K.qlen = qs->len[c.qid]; K.tlen = tg->len[c.tid]; K.qbase = qs->boff[c.qid]; K.tbase = tg->boff[c.tid]; K.goff = ix->goff[c.tid]; K.pad = 0;
+            }
+        });
         KeptChain *d_kc; int32_t *d_nprob, *d_poff;
         TRY(ctx_buf_t(ctx, "kept", (size_t)nk, &d_kc));
         TRY(ctx_buf_t(ctx, "nprob", (size_t)nk + 1, &d_nprob));
         TRY(ctx_buf_t(ctx, "prob_off", (size_t)nk + 1, &d_poff));
-        HIPCHK(hipMemcpyAsync(d_kc, hk.data(), (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_segments<0>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(d_nprob + nk, 0, 4, st));
         TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_nprob, d_poff, (size_t)nk + 1)));
-        std::vector<int32_t> h_poff(nk + 1);
+        h_poff.resize(nk + 1);
         HIPCHK(hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(nk + 1) * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        const int np = h_poff[nk];
+        np = h_poff[nk];
         DpProb *d_probs; int64_t *d_tbb, *d_cgo, *d_tboff, *d_cgoff; int32_t *d_clscnt, *d_clslist;
         TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
         TRY(ctx_buf_t(ctx, "tb_bytes", (size_t)np + 1, &d_tbb));
@@ -731,7 +789,6 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
         D.tb = d_tb; D.cig = d_rawcig; D.res = d_res; D.dcap = 0;
         static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
-        // register kernels first (the bulk of the work), then the LDS-state classes
         // The few long/wide problems are latency-bound single waves: start each tail class on its
         // own side stream so that they run underneath the bulk classes on the main stream.
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
@@ -770,7 +827,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipGetLastError());
         t_dp.stop();
 
-        // ---- compact cigars and bring results home -------------------------------------------------
+        // ---- compact cigars and bring results home (pinned staging) --------------------------------
         StageTimer t_g(ctx, ST_GATHER, true);
         int64_t *d_nops, *d_doff; uint32_t *d_dense;
         TRY(ctx_buf_t(ctx, "nops", (size_t)np + 1, &d_nops));
@@ -786,90 +843,122 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipGetLastError());
         t_g.stop();
         StageTimer t_d(ctx, ST_D2H, true);
-        std::vector<DpRes> h_res(np); std::vector<int64_t> h_doff(np + 1); std::vector<uint32_t> h_cig((size_t)nops_total);
-        HIPCHK(hipMemcpyAsync(h_res.data(), d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_doff.data(), d_doff, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost, st));
-        if (nops_total) HIPCHK(hipMemcpyAsync(h_cig.data(), d_dense, (size_t)nops_total * 4, hipMemcpyDeviceToHost, st));
+        TRY(ctx_hbuf_t(ctx, "h_res", (size_t)np, &h_res));
+        TRY(ctx_hbuf_t(ctx, "h_cig", (size_t)nops_total, &h_cig));
+        HIPCHK(hipMemcpyAsync(h_res, d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
+        if (nops_total) HIPCHK(hipMemcpyAsync(h_cig, d_dense, (size_t)nops_total * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         t_d.stop();
 
-        // ---- host: stitch extension + fill cigars per chain ------------------------------------------
+        // ---- host: per-chain numbers from the per-problem results (no op walking) ---------------------
         StageTimer t_as(ctx, ST_ASSEMBLE, false);
-        int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-        if (nk < 256) nth = 1;
-        std::vector<std::thread> th;
-        std::vector<int64_t> cells(nth, 0), wbases(nth, 0);
-        for (int i = 0; i < np; ++i) { ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
-        for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
-            for (int x = t; x < nk; x += nth) {
-                const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x]; std::vector<uint32_t> &cg = kcig[x];
+        h_doff.resize((size_t)np + 1);
+        h_doff[0] = 0;
+        for (int i = 0; i < np; ++i) { h_doff[i + 1] = h_doff[i] + h_res[i].nops; ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
+        parallel_ranges(NT, nk, [&](int, int xa, int xb) {
+            for (int x = xa; x < xb; ++x) {
+                const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x];
                 const int qlen = r.qlen, tlen = r.tlen;
                 int p = h_poff[x]; const int pend = h_poff[x + 1];
-                int32_t dp = 0, mlen = 0, qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
+                int32_t dp = 0, mlen = 0, blen = 0, qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
                 const bool has_left = c.qs > 0 && c.rs > 0, has_right = c.qe < qlen && c.re < tlen;
-                if (has_left) {
-                    const DpRes &d = h_res[p]; dp += d.score; mlen += d.mlen; qs_ = c.qs - d.bi; rs_ = c.rs - d.bj;
-                    for (int64_t z = h_doff[p]; z < h_doff[p] + d.nops; ++z) cig_push(cg, h_cig[z] & 0xf, h_cig[z] >> 4);
-                    ++p;
-                }
-                const int fill_end = has_right ? pend - 1 : pend;
-                for (; p < fill_end; ++p) {
-                    const DpRes &d = h_res[p]; dp += d.score; mlen += d.mlen;
-                    for (int64_t z = h_doff[p] + d.nops - 1; z >= h_doff[p]; --z) cig_push(cg, h_cig[z] & 0xf, h_cig[z] >> 4);
-                }
-                if (has_right) {
-                    const DpRes &d = h_res[p]; dp += d.score; mlen += d.mlen; qe_ = c.qe + d.bi; re_ = c.re + d.bj;
-                    for (int64_t z = h_doff[p] + d.nops - 1; z >= h_doff[p]; --z) cig_push(cg, h_cig[z] & 0xf, h_cig[z] >> 4);
-                }
-                int32_t blen = 0;
-                for (uint32_t op : cg) blen += (int32_t)(op >> 4);
+                for (int z = p; z < pend; ++z) { const DpRes &d = h_res[z]; dp += d.score; mlen += d.mlen; blen += d.bi + d.bj - d.mcols; }
+                if (has_left) { const DpRes &d = h_res[p]; qs_ = c.qs - d.bi; rs_ = c.rs - d.bj; }
+                if (has_right) { const DpRes &d = h_res[pend - 1]; qe_ = c.qe + d.bi; re_ = c.re + d.bj; }
                 r.ts = rs_; r.te = re_;
                 if (c.rev) { r.qs = qlen - qe_; r.qe = qlen - qs_; } else { r.qs = qs_; r.qe = qe_; }
-                r.mlen = mlen; r.blen = blen; r.dp_score = dp; r.n_cigar = (int32_t)cg.size();
+                r.mlen = mlen; r.blen = blen; r.dp_score = dp;
             }
         });
-        for (auto &t : th) t.join();
         t_as.stop();
     }
 
-    // ---- host: pass-2 selection, flags, mapq, emit ---------------------------------------------------
+    // ---- host: pass-2 selection, flags, mapq (threads over queries) --------------------------------------
     StageTimer t_as2(ctx, ST_ASSEMBLE, false);
     const bool per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
-    std::vector<Sel> s2; std::vector<int32_t> cscore; std::vector<int32_t> newidx;
-    for (int q = 0; q < nq; ++q) {
-        const int k0 = q_k0[q], n1 = q_k0[q + 1] - k0;
-        s2.clear(); cscore.assign(n1, 0);
-        for (int i = 0; i < n1; ++i) {
-            const telr_aln &r = kal[k0 + i];
-            cscore[i] = r.score;
-            if ((mo->flags & TELR_MF_CIGAR) && r.dp_score < mo->min_dp_max) continue;
-            Sel s; s.ci = i; s.key = r.dp_score; s.ord = (int32_t)s2.size(); s.tid = r.tid; s.fs = r.qs; s.fe = r.qe;
-            s.parent = 0; s.subsc = 0; s.n_sub = 0; s.keep = 0;
-            s2.push_back(s);
+    struct Surv { int32_t x; telr_aln r; };            // x = kept-chain index
+    std::vector<std::vector<Surv>> tsurv(NT);
+    parallel_ranges(NT, nq, [&](int t, int qa, int qb) {
+        std::vector<Sel> s2; std::vector<int32_t> cscore, newidx;
+        for (int q = qa; q < qb; ++q) {
+            const int k0 = q_k0[q], n1 = q_k0[q + 1] - k0;
+            s2.clear(); cscore.assign(n1, 0);
+            for (int i = 0; i < n1; ++i) {
+                const telr_aln &r = kal[k0 + i];
+                cscore[i] = r.score;
+                if ((mo->flags & TELR_MF_CIGAR) && r.dp_score < mo->min_dp_max) continue;
+                Sel s; s.ci = i; s.key = r.dp_score; s.ord = (int32_t)s2.size(); s.tid = r.tid; s.fs = r.qs; s.fe = r.qe;
+                s.parent = 0; s.subsc = 0; s.n_sub = 0; s.keep = 0;
+                s2.push_back(s);
+            }
+            std::sort(s2.begin(), s2.end(), sel_less);
+            select_chains(s2, mo, cscore);
+            const int n2 = (int)s2.size();
+            newidx.assign(n2, -1);
+            int nkp = 0;
+            for (int i = 0; i < n2; ++i) if (s2[i].keep) newidx[i] = nkp++;
+            for (int i = 0; i < n2; ++i) {
+                if (!s2[i].keep) continue;
+                Surv sv; sv.x = k0 + s2[i].ci; sv.r = kal[sv.x];
+                telr_aln &r = sv.r;
+                r.parent = newidx[s2[i].parent]; r.subsc = s2[i].subsc; r.n_sub = s2[i].n_sub;
+                if (s2[i].parent == i) {
+                    bool first = true;
+                    for (int j = 0; j < i; ++j) if (s2[j].keep && s2[j].parent == j && (!per_t || s2[j].tid == s2[i].tid)) { first = false; break; }
+                    r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
+                } else r.flags |= TELR_F_SECONDARY;
+                r.mapq = mapq_of(r, mo);
+                tsurv[t].push_back(sv);
+            }
         }
-        std::sort(s2.begin(), s2.end(), sel_less);
-        select_chains(s2, mo, cscore);
-        const int n2 = (int)s2.size();
-        newidx.assign(n2, -1);
-        int nkp = 0;
-        for (int i = 0; i < n2; ++i) if (s2[i].keep) newidx[i] = nkp++;
-        for (int i = 0; i < n2; ++i) {
-            if (!s2[i].keep) continue;
-            telr_aln r = kal[k0 + s2[i].ci];
-            r.parent = newidx[s2[i].parent]; r.subsc = s2[i].subsc; r.n_sub = s2[i].n_sub;
-            if (s2[i].parent == i) {
-                bool first = true;
-                for (int j = 0; j < i; ++j) if (s2[j].keep && s2[j].parent == j && (!per_t || s2[j].tid == s2[i].tid)) { first = false; break; }
-                r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
-            } else r.flags |= TELR_F_SECONDARY;
-            r.mapq = mapq_of(r, mo);
-            const std::vector<uint32_t> &cg = kcig[k0 + s2[i].ci];
-            r.cigar_off = (int64_t)R->cigars.size(); r.n_cigar = (int32_t)cg.size();
-            R->cigars.insert(R->cigars.end(), cg.begin(), cg.end());
-            R->alns.push_back(r);
-            ctx->ctr.cigar_ops += (int64_t)cg.size(); ++ctx->ctr.records;
-        }
+    });
+    // survivors in query order; upper bound of their op counts -> offsets into a scratch, then stitch in parallel
+    std::vector<Surv> surv;
+    { size_t tot = 0; for (auto &v : tsurv) tot += v.size(); surv.reserve(tot); for (auto &v : tsurv) surv.insert(surv.end(), v.begin(), v.end()); }
+    const int ns = (int)surv.size();
+    if (do_dp && ns > 0) {
+        // exact final op counts: ops only merge across problem boundaries (same op type on both sides)
+        std::vector<int64_t> fin_off((size_t)ns + 1, 0);
+        std::vector<int32_t> nfin(ns, 0);
+        parallel_ranges(NT, ns, [&](int, int ia, int ib) {
+            for (int i = ia; i < ib; ++i) {
+                const int x = surv[i].x; const HostChain &c = chains[kept[x]];
+                const bool has_left = c.qs > 0 && c.rs > 0;
+                int n = 0, prev = -1;
+                for (int p = h_poff[x], pend = h_poff[x + 1], first = 1; p < pend; ++p, first = 0) {
+                    const int64_t lo = h_doff[p], hi = h_doff[p + 1];
+                    if (hi == lo) continue;
+                    const bool fwd = first && has_left;
+                    const int ft = (int)(h_cig[fwd ? lo : hi - 1] & 0xf), lt = (int)(h_cig[fwd ? hi - 1 : lo] & 0xf);
+                    n += (int)(hi - lo) - (prev == ft ? 1 : 0);
+                    prev = lt;
+                }
+                nfin[i] = n;
+            }
+        });
+        for (int i = 0; i < ns; ++i) fin_off[i + 1] = fin_off[i] + nfin[i];
+        const int64_t tot = fin_off[ns];
+        const size_t base = R->ncig;
+        uint32_t *nc = (uint32_t*)realloc(R->cig, (base + (size_t)tot + 1) * 4);
+        if (!nc) return TELR_E_NOMEM;
+        R->cig = nc; R->ncig = base + (size_t)tot;
+        parallel_ranges(NT, ns, [&](int, int ia, int ib) {
+            for (int i = ia; i < ib; ++i) {
+                const int x = surv[i].x; const HostChain &c = chains[kept[x]];
+                uint32_t *out = R->cig + base + fin_off[i]; int no = 0;
+                auto push = [&](uint32_t op) { if (no && (out[no - 1] & 0xf) == (op & 0xf)) out[no - 1] += op & ~0xfu; else out[no++] = op; };
+                int p = h_poff[x]; const int pend = h_poff[x + 1];
+                const bool has_left = c.qs > 0 && c.rs > 0;
+                if (has_left) { for (int64_t z = h_doff[p]; z < h_doff[p + 1]; ++z) push(h_cig[z]); ++p; }     // emission order == left-to-right
+                for (; p < pend; ++p) for (int64_t z = h_doff[p + 1] - 1; z >= h_doff[p]; --z) push(h_cig[z]);  // fills / right extension: reversed
+                surv[i].r.cigar_off = (int64_t)base + fin_off[i]; surv[i].r.n_cigar = no;
+            }
+        });
+        ctx->ctr.cigar_ops += tot;
     }
+    R->alns.reserve(R->alns.size() + ns);
+    for (int i = 0; i < ns; ++i) R->alns.push_back(surv[i].r);
+    ctx->ctr.records += ns;
     t_as2.stop();
     return TELR_OK;
 }
@@ -893,7 +982,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     const int32_t mid_occ = index_mid_occ(ix, mo);
     telr_result *R = new telr_result();
     // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
-    int64_t batch_bases = 96LL << 20;
+    int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
     if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
     int32_t q0 = 0;
     while (q0 < nq) {
@@ -953,7 +1042,7 @@ extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n
     TRY(ctx_buf_t(ctx, "dm_toff", (size_t)n_targets + 1, &d_toff));
     TRY(ctx_buf_t(ctx, "dm_tlen", (size_t)n_targets, &d_tlen));
     TRY(ctx_buf_t(ctx, "dm_recs", recs.size(), &d_recs));
-    TRY(ctx_buf_t(ctx, "dm_cig", r->cigars.size(), &d_cig));
+    TRY(ctx_buf_t(ctx, "dm_cig", r->ncig, &d_cig));
     TRY(ctx_buf_t(ctx, "dm_ivt", (size_t)n_iv, &d_ivt));
     TRY(ctx_buf_t(ctx, "dm_ivs", (size_t)n_iv, &d_ivs));
     TRY(ctx_buf_t(ctx, "dm_ive", (size_t)n_iv, &d_ive));
@@ -962,7 +1051,7 @@ extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n
     HIPCHK(hipMemcpyAsync(d_toff, toff.data(), (size_t)(n_targets + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_tlen, target_len, (size_t)n_targets * 4, hipMemcpyHostToDevice, st));
     if (!recs.empty()) HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(DepthRec), hipMemcpyHostToDevice, st));
-    if (!r->cigars.empty()) HIPCHK(hipMemcpyAsync(d_cig, r->cigars.data(), r->cigars.size() * 4, hipMemcpyHostToDevice, st));
+    if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
     if (n_iv) {
         HIPCHK(hipMemcpyAsync(d_ivt, iv_tid, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_ivs, iv_start, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));

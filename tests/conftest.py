@@ -19,5 +19,6 @@ def data_dir():
 @pytest.fixture(scope="session")
 def engine():
     """The HIP engine on cuda:0.  No fallback: a missing library or device is an error."""
+    os.environ["TELR_DEBUG"] = "1"      # keep stage-level captures for the parity tests
     from telr_amd.aligner import Engine
     return Engine(0)

@@ -172,7 +172,7 @@ int  telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n_targets,
 
 /* ---- timing of the last telr_map / telr_index_build call (HIP events on the
  *      engine's own stream).  Stage names: telr_stage_name(i). ---------------- */
-#define TELR_N_STAGES 12
+#define TELR_N_STAGES 16
 int  telr_stage_ms(const telr_ctx *ctx, float *ms_out /* [TELR_N_STAGES] */);
 const char *telr_stage_name(int i);
 /* algorithmic work counters of the last telr_map call (SURVEY §8d terms) */
@@ -181,6 +181,11 @@ typedef struct telr_counters {
             window_bases, cigar_ops, records;
 } telr_counters;
 int  telr_last_counters(const telr_ctx *ctx, telr_counters *out);
+/* per DP class (TELR_N_DPCLS classes) of the last telr_map call:
+ * out[c*4+0] problems, [c*4+1] DP cells, [c*4+2] anti-diagonal steps (sum of m+n),
+ * [c*4+3] algorithmic bytes (2-bit bases read once + 4 B per CIGAR run + 32 B result) */
+#define TELR_N_DPCLS 10
+int  telr_last_dp_classes(const telr_ctx *ctx, int64_t *out /* [TELR_N_DPCLS*4] */);
 
 #ifdef __cplusplus
 }

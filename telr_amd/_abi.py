@@ -41,7 +41,8 @@ class Counters(C.Structure):
 
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8
 MF_CIGAR, MF_PER_TARGET = 1, 2
-N_STAGES = 12
+N_STAGES = 16
+N_DPCLS = 10
 
 import numpy as _np
 

@@ -12,7 +12,7 @@ EXPORTS = [
     "telr_seqset_create", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_free",
-    "telr_depth_medians", "telr_stage_ms", "telr_stage_name", "telr_last_counters",
+    "telr_depth_medians", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
 _lib = None
@@ -54,6 +54,7 @@ def lib():
     L.telr_stage_ms.restype = C.c_int; L.telr_stage_ms.argtypes = [vp, vp]
     L.telr_stage_name.restype = cp; L.telr_stage_name.argtypes = [C.c_int]
     L.telr_last_counters.restype = C.c_int; L.telr_last_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.telr_last_dp_classes.restype = C.c_int; L.telr_last_dp_classes.argtypes = [vp, vp]
     # debug taps (not part of the public header; used by the stage-level parity tests)
     L.telr_debug_n_anchor.restype = i64; L.telr_debug_n_anchor.argtypes = [vp]
     L.telr_debug_fetch.restype = C.c_int; L.telr_debug_fetch.argtypes = [vp, cp, vp, i64]

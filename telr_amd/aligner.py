@@ -6,7 +6,7 @@ boundary (TELR_alignment.py:69-82 and the five other sites listed in include/tel
 import ctypes as C
 import numpy as np
 from . import _lib
-from ._abi import IdxOpt, MapOpt, Counters, ALN_DTYPE, N_STAGES
+from ._abi import IdxOpt, MapOpt, Counters, ALN_DTYPE, N_STAGES, N_DPCLS
 from .fasta import concat
 
 
@@ -55,6 +55,12 @@ class Engine:
         c = Counters()
         self.L.telr_last_counters(self.h, C.byref(c))
         return {k: getattr(c, k) for k, _ in Counters._fields_}
+
+    def dp_classes(self):
+        """per DP class: (problems, cells, steps, algorithmic bytes) of the last map call"""
+        a = np.zeros(N_DPCLS * 4, np.int64)
+        self.L.telr_last_dp_classes(self.h, a.ctypes.data)
+        return a.reshape(N_DPCLS, 4)
 
     def close(self):
         if getattr(self, "h", None):

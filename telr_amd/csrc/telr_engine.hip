@@ -24,9 +24,11 @@
 
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
-    "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "cigar_gather", "d2h", "assemble_host", "index_build"
+    "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "cigar_gather", "d2h", "assemble_host", "index_build",
+    "k_dp_reg_32_1", "k_dp_reg_64_1", "k_traceback", "reserved"
 };
-enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX };
+enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX,
+       ST_K_REG32, ST_K_REG64, ST_K_TRACEBACK, ST_RESERVED };
 
 #define TELR_NSIDE 8
 struct DBuf { void *p = nullptr; size_t bytes = 0; };
@@ -43,6 +45,8 @@ struct telr_ctx {
     float stage_ms[TELR_N_STAGES] = {0};
     telr_counters ctr = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evk[6] = {nullptr};        // un-synchronised markers around single kernels
+    int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     char devname[256] = {0};
     // debug captures of the last batch (device pointers stay valid until the next call)
     int64_t dbg_na = 0; int32_t dbg_nq = 0;
@@ -117,6 +121,7 @@ extern "C" const char *telr_last_error(const telr_ctx *ctx) { return ctx ? ctx->
 extern "C" const char *telr_stage_name(int i) { return i >= 0 && i < TELR_N_STAGES ? STAGE_NAMES[i] : ""; }
 extern "C" int telr_stage_ms(const telr_ctx *ctx, float *ms) { if (!ctx || !ms) return TELR_E_ARG; memcpy(ms, ctx->stage_ms, sizeof(ctx->stage_ms)); return TELR_OK; }
 extern "C" int telr_last_counters(const telr_ctx *ctx, telr_counters *out) { if (!ctx || !out) return TELR_E_ARG; *out = ctx->ctr; return TELR_OK; }
+extern "C" int telr_last_dp_classes(const telr_ctx *ctx, int64_t *out) { if (!ctx || !out) return TELR_E_ARG; memcpy(out, ctx->dpcls, sizeof(ctx->dpcls)); return TELR_OK; }
 
 extern "C" int telr_init(int device, telr_ctx **out)
 {
@@ -130,6 +135,7 @@ extern "C" int telr_init(int device, telr_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->evk[i]) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < TELR_NSIDE; ++i) if (hipStreamCreate(&ctx->side[i]) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     *out = ctx;
     return TELR_OK;
@@ -145,6 +151,7 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int i = 0; i < TELR_NSIDE; ++i) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_side[i]) (void)hipEventDestroy(ctx->ev_side[i]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 6; ++i) if (ctx->evk[i]) (void)hipEventDestroy(ctx->evk[i]);
     delete ctx;
 }
 extern "C" int telr_device_name(const telr_ctx *ctx, char *buf, int buflen)
@@ -512,6 +519,11 @@ static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
     if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
 }
 
+static inline int host_dp_class(int kind, int D)
+{
+    if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
+    return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
+}
 static int host_threads()
 {
     int n = (int)std::thread::hardware_concurrency();
@@ -816,16 +828,25 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
             HIPCHK(hipGetLastError());
         }
+        HIPCHK(hipEventRecord(ctx->evk[0], st));
         if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
+        HIPCHK(hipEventRecord(ctx->evk[1], st));
         if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
+        HIPCHK(hipEventRecord(ctx->evk[2], st));
         HIPCHK(hipGetLastError());
         for (size_t u = 0; u < used.size(); ++u) {
             HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
             HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
         }
+        HIPCHK(hipEventRecord(ctx->evk[3], st));
         hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, d_rawcig);
+        HIPCHK(hipEventRecord(ctx->evk[4], st));
         HIPCHK(hipGetLastError());
         t_dp.stop();
+        { float ms = 0;
+          if (hipEventElapsedTime(&ms, ctx->evk[0], ctx->evk[1]) == hipSuccess) ctx->stage_ms[ST_K_REG32] += ms;
+          if (hipEventElapsedTime(&ms, ctx->evk[1], ctx->evk[2]) == hipSuccess) ctx->stage_ms[ST_K_REG64] += ms;
+          if (hipEventElapsedTime(&ms, ctx->evk[3], ctx->evk[4]) == hipSuccess) ctx->stage_ms[ST_K_TRACEBACK] += ms; }
 
         // ---- compact cigars and bring results home (pinned staging) --------------------------------
         StageTimer t_g(ctx, ST_GATHER, true);
@@ -855,7 +876,10 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         h_doff.resize((size_t)np + 1);
         h_doff[0] = 0;
         for (int i = 0; i < np; ++i) { h_doff[i + 1] = h_doff[i] + h_res[i].nops; ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
-        parallel_ranges(NT, nk, [&](int, int xa, int xb) {
+        std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
+        std::vector<int64_t*> tcls(NT);
+        for (int t = 0; t < NT; ++t) tcls[t] = tcls_store.data() + (size_t)t * TELR_N_DPCLS * 4;
+        parallel_ranges(NT, nk, [&](int tslot, int xa, int xb) {
             for (int x = xa; x < xb; ++x) {
                 const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x];
                 const int qlen = r.qlen, tlen = r.tlen;
@@ -863,6 +887,22 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                 int32_t dp = 0, mlen = 0, blen = 0, qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
                 const bool has_left = c.qs > 0 && c.rs > 0, has_right = c.qe < qlen && c.re < tlen;
                 for (int z = p; z < pend; ++z) { const DpRes &d = h_res[z]; dp += d.score; mlen += d.mlen; blen += d.bi + d.bj - d.mcols; }
+                // DP-class accounting (the class is a pure function of the problem's shape)
+                for (int z = p; z < pend; ++z) {
+                    const DpRes &d = h_res[z];
+                    const bool is_ext = (z == p && has_left) || (z == pend - 1 && has_right);
+                    int cls;
+                    if (is_ext) cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band));
+                    else {
+                        const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
+                        int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6); if (W > mo->bw) W = mo->bw;
+                        int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
+                        cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1);
+                    }
+                    int64_t *cc = tcls[tslot] + cls * 4;
+                    cc[0] += 1; cc[1] += d.cells; cc[2] += is_ext ? d.bi + d.bj : d.bi + d.bj;
+                    cc[3] += (d.bi + d.tbases + 3) / 4 + 4 * (int64_t)d.nops + 32;
+                }
                 if (has_left) { const DpRes &d = h_res[p]; qs_ = c.qs - d.bi; rs_ = c.rs - d.bj; }
                 if (has_right) { const DpRes &d = h_res[pend - 1]; qe_ = c.qe + d.bi; re_ = c.re + d.bj; }
                 r.ts = rs_; r.te = re_;
@@ -870,6 +910,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                 r.mlen = mlen; r.blen = blen; r.dp_score = dp;
             }
         });
+        for (int t = 0; t < NT; ++t) for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += tcls[t][z];
         t_as.stop();
     }
 
@@ -972,6 +1013,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     HIPCHK(hipSetDevice(ctx->device));
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     memset(&ctx->ctr, 0, sizeof(ctx->ctr));
+    memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
     const int nq = queries->n;
     if (qtarget) for (int i = 0; i < nq; ++i) if (qtarget[i] >= ix->targets->n) return TELR_E_ARG;
     int32_t *d_qt = nullptr;

@@ -1,0 +1,146 @@
+"""Allele-frequency estimation from read->contig realignments (stage 4 of the path).
+
+Restates `get_af` and its helpers of the reference (`src/telr/TELR_te.py`: `realignment` :495-515,
+`get_flank_cov` :518-550, `get_te_flank_ratio` :564-575, `get_af` :578-838, `get_te_cov` :841-867,
+`get_median_cov` :870-884).  The reference spawns, per locus and per contig orientation, one
+`minimap2 -a` + three samtools processes and eight `samtools depth` processes; here all loci are
+mapped in two batched engine calls (forward and reverse-complement contigs are just two targets
+of one index) and the per-base depth + medians run on the device (`telr_depth_medians`).
+
+Quirks kept (pinned by tests/golden/af_*.json, captured from the reference's own code):
+  * only the 5' TE/flank medians of the forward and of the reverse-complement run enter the
+    frequency (:810-817); the 3' medians are reported but unused;
+  * a median of 0 counts as missing (`if te_cov and flank_cov`, :565), ratios > 1.5 are dropped,
+    the two sides must agree within 0.3, the result is capped at 1 and rounded to 3 digits;
+  * the whole TE is used when start+offset+interval >= end (:849-866);
+  * `samtools depth -r chr:S-E` is fed 0-based numbers although the region syntax is 1-based
+    inclusive (:870-884): E-S+1 positions are read, shifted one base to the left.
+"""
+import numpy as np
+
+
+def depth_region(start, end):
+    """`samtools depth -aa -r chr:start-end` -> 0-based inclusive (first, last) positions it prints."""
+    first = start - 1 if start > 0 else 0
+    return first, end - 1
+
+
+def te_cov_intervals(start, end, te_interval_size, te_offset):
+    """-> [(s,e) for te_5p, (s,e) for te_3p] as passed to get_median_cov (:841-867)"""
+    if te_interval_size and start + te_offset + te_interval_size < end:
+        return [(start + te_offset, start + te_offset + te_interval_size),
+                (end - te_interval_size - te_offset, end - te_offset)]
+    return [(start, end), (start, end)]
+
+
+def flank_cov_intervals(contig_length, start, end, flank_len, offset):
+    """-> [left or None, right or None] (:518-550)"""
+    left = right = None
+    if start - flank_len - offset >= 0:
+        left = (start - flank_len - offset, start - offset)
+    if end + flank_len + offset <= contig_length:
+        right = (end + offset, end + flank_len + offset)
+    return [left, right]
+
+
+def get_te_flank_ratio(te_cov, flank_cov):
+    if te_cov and flank_cov:
+        ratio = te_cov / flank_cov
+        return None if ratio > 1.5 else ratio
+    return None
+
+
+def combine_af(te_5p_cov, flank_5p_cov, te_5p_cov_rc, flank_5p_cov_rc):
+    """the inline frequency arithmetic of get_af (:810-835)"""
+    taf_5p = get_te_flank_ratio(te_5p_cov, flank_5p_cov)
+    taf_3p = get_te_flank_ratio(te_5p_cov_rc, flank_5p_cov_rc)
+    if taf_5p and taf_3p:
+        freq = (taf_5p + taf_3p) / 2 if abs(taf_5p - taf_3p) <= 0.3 else None
+    elif taf_5p:
+        freq = taf_5p
+    elif taf_3p:
+        freq = taf_3p
+    else:
+        freq = None
+    if freq and freq > 1:
+        freq = 1
+    return round(freq, 3) if freq else None
+
+
+def locus_intervals(start, end, contig_length, flank_interval, flank_offset, te_interval, te_offset):
+    """The 8 depth queries of one locus: forward then reverse-complement, each te_5p, te_3p, flank_5p, flank_3p."""
+    out = {}
+    for tag, (s, e) in (("fw", (start, end)), ("rc", (contig_length - end, contig_length - start))):
+        out[tag] = te_cov_intervals(s, e, te_interval, te_offset) + flank_cov_intervals(contig_length, s, e, flank_interval, flank_offset)
+    return out
+
+
+def _median_or_none(x):
+    """statistics.median returns an int for odd counts and a float for even counts; str() of it is
+    re-parsed with float() in the reference, so only the value matters."""
+    return None if x is None or (isinstance(x, float) and np.isnan(x)) else float(x)
+
+
+def freq_table(medians):
+    """medians: dict with the 8 values (None allowed) -> the reference's te_freq[contig] dict (9 keys)"""
+    d = {
+        "te_5p_cov": _median_or_none(medians["fw"][0]), "te_3p_cov": _median_or_none(medians["fw"][1]),
+        "flank_5p_cov": _median_or_none(medians["fw"][2]), "flank_3p_cov": _median_or_none(medians["fw"][3]),
+        "te_5p_cov_rc": _median_or_none(medians["rc"][0]), "te_3p_cov_rc": _median_or_none(medians["rc"][1]),
+        "flank_5p_cov_rc": _median_or_none(medians["rc"][2]), "flank_3p_cov_rc": _median_or_none(medians["rc"][3]),
+    }
+    d["freq"] = combine_af(d["te_5p_cov"], d["flank_5p_cov"], d["te_5p_cov_rc"], d["flank_5p_cov_rc"])
+    return d
+
+
+def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_interval=100, flank_offset=200,
+           te_interval=50, te_offset=50):
+    """Batched replacement of get_af (:578-838).
+
+    contigs: {locus name: contig sequence}; contig_te: {locus name: (start, end)} TE coordinates on the
+    forward contig; reads_by_locus: {locus name: [read sequences]} (the +-1 kb window reads selected
+    by prep_assembly_inputs(read_type="all"), TELR_assembly.py:384-462).
+    Returns {locus name: te_freq dict}.
+    """
+    from .presets import preset
+    from .fasta import revcomp
+    io, mo = preset("map-ont" if presets == "ont" else "map-pb")
+    names = [n for n in contig_te if n in contigs and n in reads_by_locus]
+    if not names:
+        return {}
+    targets, tindex = [], {}
+    for n in names:
+        tindex[n] = len(targets)
+        targets.append(contigs[n])
+        targets.append(revcomp(contigs[n]))
+    ix = engine.index(targets, io)
+    queries, qtarget_fw, qtarget_rc = [], [], []
+    for n in names:
+        for r in reads_by_locus[n]:
+            queries.append(r)
+            qtarget_fw.append(tindex[n]); qtarget_rc.append(tindex[n] + 1)
+    qs = engine.seqset(queries)
+    out = {}
+    meds = {n: {} for n in names}
+    for tag, qt in (("fw", qtarget_fw), ("rc", qtarget_rc)):
+        r = ix.map_raw(qs, mo, qtarget=np.array(qt, np.int32))
+        try:
+            iv_t, iv_s, iv_e, slots = [], [], [], []
+            for n in names:
+                L = len(contigs[n])
+                ivs = locus_intervals(contig_te[n][0], contig_te[n][1], L, flank_interval, flank_offset, te_interval, te_offset)[tag]
+                for k, x in enumerate(ivs):
+                    if x is None:
+                        continue
+                    a, b = depth_region(*x)
+                    iv_t.append(tindex[n] + (1 if tag == "rc" else 0)); iv_s.append(a); iv_e.append(b); slots.append((n, k))
+            med = ix.depth_medians(r, iv_t, iv_s, iv_e) if iv_t else []
+            for n in names:
+                meds[n][tag] = [None, None, None, None]
+            for (n, k), v in zip(slots, med):
+                meds[n][tag][k] = None if np.isnan(v) else float(v)
+        finally:
+            ix.free_raw(r)
+    for n in names:
+        out[n] = freq_table(meds[n])
+    return out

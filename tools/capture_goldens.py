@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference's own Python glue (run ONLY in the build container).
+
+The reference (/root/reference) is imported with in-memory stubs for Bio / pysam and with
+`subprocess` replaced by a fake that answers the bedtools / minimap2 / samtools calls of the
+liftover and AF paths (canned PAF for minimap2; telr_amd.intervals for bedtools).  Only inputs
+and outputs are written (JSON under tests/golden/); no reference source is copied.
+
+  python tools/capture_goldens.py          # rewrites tests/golden/*.json
+"""
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference/src"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from telr_amd import intervals as iv  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    bio = types.ModuleType("Bio"); seqio = types.ModuleType("Bio.SeqIO"); bio.SeqIO = seqio
+    sys.modules["Bio"] = bio; sys.modules["Bio.SeqIO"] = seqio; sys.modules["pysam"] = types.ModuleType("pysam")
+    import telr.TELR_liftover as L
+    import telr.TELR_te as T
+    import telr.TELR_sv as S
+    import telr.TELR_utility as U
+    return L, T, S, U
+
+
+# ---------------------------------------------------------------------------------------
+class FakeSubprocess(object):
+    """Answers the external-tool calls made by TELR_liftover with in-memory data."""
+
+    def __init__(self, seqs, paf_by_flank):
+        self.seqs = seqs                  # {fasta path: {name: sequence}}
+        self.paf = paf_by_flank           # {"5p": [paf line, ...], "3p": [...]} or {(locus prefix, side): [...]}
+        self.PIPE = -1
+
+    def _rows(self, path):
+        with open(path) as f:
+            return [l.rstrip("\n").split("\t") for l in f if l.strip()]
+
+    def call(self, cmd, stdout=None, shell=False, **kw):
+        if shell:
+            cmd = cmd.replace('"', "").split()
+        tool = os.path.basename(cmd[0])
+        out = ""
+        if tool == "bedtools" and cmd[1] == "getfasta":
+            fa, bed = cmd[cmd.index("-fi") + 1], cmd[cmd.index("-bed") + 1]
+            for r in self._rows(bed):
+                s = self.seqs[fa][r[0]][int(r[1]):int(r[2])]
+                out += ">%s:%s-%s\n%s\n" % (r[0], r[1], r[2], s)
+        elif tool == "bedtools" and cmd[1] == "sort":
+            out = "".join("\t".join(r) + "\n" for r in iv.bed_sort(self._rows(cmd[cmd.index("-i") + 1])))
+        elif tool == "bedtools" and cmd[1] == "closest":
+            a = self._rows(cmd[cmd.index("-a") + 1]); b = self._rows(cmd[cmd.index("-b") + 1])
+            rows = iv.closest_same_strand(a, b) if "-s" in cmd else iv.closest_signed_k(a, b, k=int(cmd[cmd.index("-k") + 1]))
+            out = "".join("\t".join(r) + "\n" for r in rows)
+        elif tool == "bedtools" and cmd[1] == "merge":
+            rows = self._rows(cmd[cmd.index("-i") + 1])
+            cols = [int(c) - 1 for c in cmd[cmd.index("-c") + 1].split(",")]
+            groups = []
+            for r in rows:
+                s, e = int(r[1]), int(r[2])
+                if groups and groups[-1][0] == r[0] and s <= groups[-1][2]:
+                    groups[-1][2] = max(groups[-1][2], e); groups[-1][3].append(r)
+                else:
+                    groups.append([r[0], s, e, [r]])
+            for c, s, e, rs in groups:
+                out += "\t".join([c, str(s), str(e)] + [",".join(r[k] for r in rs) for k in cols]) + "\n"
+        elif tool == "minimap2":
+            flank_fa = cmd[-1]
+            base = os.path.basename(flank_fa)
+            side = "5p" if base.endswith("_5p.fa") else "3p"
+            key = (base[:-len("_5p.fa")], side)
+            lines = self.paf.get(key, self.paf.get(side, []))
+            out = "".join(l + "\n" for l in lines)
+        elif tool == "samtools":
+            return 0
+        else:
+            raise RuntimeError("unexpected command: %r" % (cmd,))
+        if stdout is not None:
+            stdout.write(out)
+        return 0
+
+
+def write_fasta_with_fai(path, seqs):
+    with open(path, "w") as f, open(path + ".fai", "w") as g:
+        off = 0
+        for n, s in seqs.items():
+            hdr = ">%s\n" % n
+            f.write(hdr + s + "\n")
+            off += len(hdr)
+            g.write("%s\t%d\t%d\t%d\t%d\n" % (n, len(s), off, len(s), len(s) + 1))
+            off += len(s) + 1
+
+
+def paf(qname, qlen, qs, qe, strand, tname, tlen, ts, te, nmatch, blen, mapq):
+    return "\t".join(str(x) for x in [qname, qlen, qs, qe, strand, tname, tlen, ts, te, nmatch, blen, mapq, "tp:A:P", "cm:i:40"])
+
+
+def rnd_seq(n, seed):
+    import random
+    r = random.Random(seed)
+    return "".join(r.choice("ACGT") for _ in range(n))
+
+
+def liftover_cases():
+    """(name, annotation, contig length, {"5p": [...], "3p": [...]}, ref TE bed rows, gap, overlap)"""
+    C = "chr2L_33000_33020"          # telr-mode contig name -> locus chromosome chr2L
+    TL = 23513712
+    cases = []
+
+    def f5(ts, te, strand="+", t="chr2L", mq=60, nm=480, bl=499):
+        return paf("%s:%d-%d" % (C, 4501, 5000), 499, 0, 499, strand, t, TL, ts, te, nm, bl, mq)
+
+    def f3(ts, te, strand="+", t="chr2L", mq=60, nm=490, bl=500):
+        return paf("%s:%d-%d" % (C, 9600, 10100), 500, 0, 500, strand, t, TL, ts, te, nm, bl, mq)
+    A = dict(chrom=C, start=5000, end=9600, family="jockey", strand="+")
+    Am = dict(A, strand="-")
+    cases.append(("plus_overlap5_tsd", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33013, 33513)]}, None, 20, 20))
+    cases.append(("minus_overlap5", A, 20000, {"5p": [f5(33013, 33512, "-")], "3p": [f3(32518, 33018, "-")]}, None, 20, 20))
+    cases.append(("minus_gap5", Am, 20000, {"5p": [f5(33023, 33522, "-")], "3p": [f3(32518, 33018, "-")]}, None, 20, 20))
+    cases.append(("plus_gap0", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33018, 33518)]}, None, 20, 20))
+    cases.append(("plus_gap10", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33028, 33528)]}, None, 20, 20))
+    cases.append(("plus_gap_equals_te_reference", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33018 + 4600, 33518 + 4600)]}, None, 20, 20))
+    cases.append(("plus_gap_lt_half_te_nonref", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33018 + 900, 33518 + 900)]}, None, 20, 20))
+    cases.append(("plus_gap_gt_half_te_reference", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33018 + 3000, 33518 + 3000)]}, None, 20, 20))
+    cases.append(("plus_gap_gt_20kb_unlifted", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33018 + 30000, 33518 + 30000)]}, None, 20, 20))
+    cases.append(("plus_big_overlap_unlifted", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(32900, 33400)]}, None, 20, 20))
+    ref_te = [["chr2L", "33100", "33900", "jockey", ".", "+"], ["chr2L", "50000", "51000", "roo", ".", "+"],
+              ["chr2L", "33100", "33900", "jockey", ".", "-"]]
+    cases.append(("plus_ref_te_between", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33950, 34450)]}, ref_te, 20, 20))
+    cases.append(("plus_ref_te_other_family", dict(A, family="roo"), 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33950, 34450)]}, ref_te, 20, 20))
+    cases.append(("single_5p_flank", dict(A, end=19800), 20000, {"5p": [f5(32519, 33018)]}, None, 20, 20))
+    cases.append(("single_3p_flank_minus", dict(A, start=300), 20000, {"3p": [f3(32518, 33018, "-")]}, None, 20, 20))
+    cases.append(("single_5p_adjacent_ref_te", dict(A, end=19800), 20000, {"5p": [f5(32601, 33100)]}, ref_te, 20, 20))
+    cases.append(("offchrom_5p_hit_filtered", A, 20000, {"5p": [f5(1000, 1499, "+", "chr3R")], "3p": [f3(33013, 33513)]}, None, 20, 20))
+    cases.append(("two_nonref_placements_ambiguous", A, 20000,
+                  {"5p": [f5(32519, 33018), f5(72519, 73018, "+", "chr2L", 3)], "3p": [f3(33013, 33513), f3(73013, 73513, "+", "chr2L", 2)]}, None, 20, 20))
+    cases.append(("ref_and_nonref_pick_nonref", A, 20000,
+                  {"5p": [f5(32519, 33018), f5(72519, 73018, "+", "chr2L", 3)], "3p": [f3(33013, 33513), f3(73018 + 4600, 73518 + 4600, "+", "chr2L", 2)]}, None, 20, 20))
+    cases.append(("two_refs_pick_by_gap", A, 20000,
+                  {"5p": [f5(32519, 33018), f5(72519, 73018, "+", "chr2L", 3)], "3p": [f3(33018 + 4000, 33518 + 4000), f3(73018 + 4600, 73518 + 4600, "+", "chr2L", 2)]}, None, 20, 20))
+    cases.append(("no_hits", A, 20000, {"5p": [], "3p": []}, None, 20, 20))
+    cases.append(("opposite_strand_hits_unpaired", A, 20000, {"5p": [f5(32519, 33018, "+")], "3p": [f3(33013, 33513, "-")]}, None, 20, 20))
+    cases.append(("gap50_threshold50", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33058, 33558)]}, None, 50, 50))
+    cases.append(("tie_two_3p_hits_same_distance", A, 20000, {"5p": [f5(32519, 33018)], "3p": [f3(33013, 33513), f3(33013, 33400, "+", "chr2L", 10)]}, None, 20, 20))
+    return cases
+
+
+def capture_liftover(L):
+    ref_seqs = {"chr2L": rnd_seq(120000, 7), "chr3R": rnd_seq(5000, 8)}
+    out_cases = []
+    for name, ann, clen, pafs, ref_te, gap, overlap in liftover_cases():
+        tmp = tempfile.mkdtemp(prefix="gold_")
+        try:
+            contigs = {ann["chrom"]: rnd_seq(clen, 11)}
+            fa1, fa2 = os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "ref.fa")
+            write_fasta_with_fai(fa1, contigs); write_fasta_with_fai(fa2, ref_seqs)
+            bed2 = None
+            if ref_te:
+                bed2 = os.path.join(tmp, "ref_te.bed")
+                with open(bed2, "w") as f:
+                    for r in ref_te:
+                        f.write("\t".join(r) + "\n")
+            odir = os.path.join(tmp, "out"); os.mkdir(odir)
+            inp = dict(ann, fasta1=fa1, fasta2=fa2, out_dir=odir, flank_len=500, flank_gap_max=gap, flank_overlap_max=overlap,
+                       bed2=bed2, preset="asm10", different_contig_name=False, telr_mode=True)
+            ij = os.path.join(tmp, "in.json")
+            with open(ij, "w") as f:
+                json.dump(inp, f)
+            L.subprocess = FakeSubprocess({fa1: contigs, fa2: ref_seqs}, pafs)
+            rep = L.run_liftover_single_annotation(ij)
+            with open(rep) as f:
+                expected = json.load(f)
+            out_cases.append({"name": name, "annotation": ann, "contig_length": clen, "paf": pafs, "ref_te_bed": ref_te,
+                              "flank_gap_max": gap, "flank_overlap_max": overlap, "expected": expected})
+        finally:
+            shutil.rmtree(tmp)
+    return {"ref_seed": {"chr2L": [120000, 7], "chr3R": [5000, 8]}, "cases": out_cases}
+
+
+def capture_liftover_driver(L):
+    """whole liftover(): fan-out over annotations + overlap de-dup + reports (reference :976-1221)"""
+    ref_seqs = {"chr2L": rnd_seq(120000, 7)}
+    TL = 120000
+    contigs, bed1, pafs = {}, [], {}
+    # five loci; 2 and 3 lift to overlapping places (te_length "999" vs "1000": string max keeps "999")
+    spec = [("chr2L_10000_10010", 5000, 6000, "roo", "+", 10000), ("chr2L_20000_20010", 5000, 5999, "jockey", "+", 20000),
+            ("chr2L_20003_20013", 5000, 6000, "jockey", "+", 20003), ("chr2L_40000_40010", 5000, 7000, "copia", "-", 40000),
+            ("chr2L_60000_60010", 300, 900, "roo", "+", 60000)]
+    for name, s, e, fam, strand, pos in spec:
+        contigs[name] = rnd_seq(12000, hash(name) % 1000)
+        bed1.append([name, str(s), str(e), fam, ".", strand])
+        prefix = "_".join([name, str(s), str(e)])
+        q5 = "%s:%d-%d" % (name, s - 499, s); q3 = "%s:%d-%d" % (name, e, e + 500)
+        if s - 499 >= 0:
+            pafs[(prefix, "5p")] = [paf(q5, 499, 0, 499, "+", "chr2L", TL, pos - 499, pos, 490, 499, 60)]
+        pafs[(prefix, "3p")] = [paf(q3, 500, 0, 500, "+", "chr2L", TL, pos - 6, pos + 494, 495, 500, 60)]
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    try:
+        fa1, fa2 = os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "ref.fa")
+        write_fasta_with_fai(fa1, contigs); write_fasta_with_fai(fa2, ref_seqs)
+        b1 = os.path.join(tmp, "te.bed")
+        with open(b1, "w") as f:
+            for r in bed1:
+                f.write("\t".join(r) + "\n")
+        odir = os.path.join(tmp, "out"); os.mkdir(odir)
+        L.subprocess = FakeSubprocess({fa1: contigs, fa2: ref_seqs}, pafs)
+
+        class FakePool(object):
+            def __init__(self, processes=None):
+                pass
+
+            def map(self, fn, items):
+                return [fn(i) for i in items]
+
+            def close(self):
+                pass
+
+            def join(self):
+                pass
+        L.Pool = FakePool
+        saved = sys.stdout; sys.stdout = io.StringIO()
+        try:
+            rep = L.liftover(fa1, fa2, b1, None, "asm10", 500, 20, 20, odir, 1, False, False, True)
+        finally:
+            sys.stdout = saved
+        with open(rep) as f:
+            report = json.load(f)
+        with open(os.path.join(odir, "liftover_nonref.bed")) as f:
+            nonref = f.read()
+        with open(os.path.join(odir, "liftover_summary.json")) as f:
+            summ = json.load(f)
+    finally:
+        shutil.rmtree(tmp)
+    return {"ref_seed": {"chr2L": [120000, 7]}, "contig_seeds": {n: [12000, hash(n) % 1000] for n in contigs},
+            "contig_seqs": contigs, "bed1": bed1, "paf": {"|".join(k): v for k, v in pafs.items()},
+            "expected_report": report, "expected_nonref_bed": nonref, "expected_summary": summ}
+
+
+# ---------------------------------------------------------------------------------------
+def capture_af(T):
+    """get_af (TELR_te.py:578-838) with the aligner / samtools side replaced by a median lookup table."""
+    cases_in = [
+        # name, te (start,end), contig length, medians fw (te5, te3, fl5, fl3), medians rc
+        ("concordant", (3000, 7600), 12000, (13, 12, 18, 17), (14, 15, 18, 19)),
+        ("discordant", (3000, 7600), 12000, (4, 4, 18, 17), (16, 15, 18, 19)),
+        ("ratio_gt_1p5_one_side", (3000, 7600), 12000, (30, 30, 18, 17), (14, 15, 18, 19)),
+        ("cap_at_one", (3000, 7600), 12000, (20, 19, 18, 17), (21, 15, 18, 19)),
+        ("zero_te_cov", (3000, 7600), 12000, (0, 0, 18, 17), (0, 0, 18, 19)),
+        ("zero_flank_cov", (3000, 7600), 12000, (10, 10, 0, 17), (9, 9, 0, 19)),
+        ("short_te_whole_locus", (3000, 3140), 12000, (13, 13, 18, 17), (14, 14, 18, 19)),
+        ("te_near_contig_start", (250, 4000), 12000, (13, 12, 18, 17), (14, 15, 18, 19)),
+        ("te_near_contig_end", (3000, 11800), 12000, (13, 12, 18, 17), (14, 15, 18, 19)),
+        ("half_medians", (3000, 7600), 12000, (12.5, 12, 18, 17.5), (13.5, 15, 18, 19)),
+    ]
+    out = []
+    for name, (s, e), clen, mfw, mrc in cases_in:
+        tmp = tempfile.mkdtemp(prefix="gold_")
+        try:
+            locus = "chr2L_33000_33020"
+            cdir = os.path.join(tmp, "contigs"); os.mkdir(cdir)
+            open(os.path.join(cdir, locus + ".cns.ctg1.fa"), "w").write(">x\nA\n")
+            ann = os.path.join(tmp, "te.bed")
+            open(ann, "w").write("\t".join([locus, str(s), str(e), "jockey", ".", "+"]) + "\n")
+            vcf = os.path.join(tmp, "vcf.tsv")
+            open(vcf, "w").write("\t".join(["chr2L", "33000", "33020", "4600", "12", "0.7", "id1", "ACGT", "r1,r2", "PASS", "0/1", "5", "12", "0.9"]) + "\n")
+            requested = []
+
+            def fake_prep(vcf_parsed, o, sample, bam, reads, rdir, read_type="sv"):
+                os.makedirs(rdir, exist_ok=True)
+                open(os.path.join(rdir, "contig0"), "w").write(">r\nA\n")
+
+            class FakePool(object):
+                def __init__(self, processes=None):
+                    pass
+
+                def map(self, fn, items):
+                    for it in items:
+                        open(it[3] + ".realign.sort.bam", "w").write("x")
+
+                def close(self):
+                    pass
+
+                def join(self):
+                    pass
+
+            def fake_rc(a, b):
+                open(b, "w").write(">x\nT\n")
+
+            def fake_len(c):
+                return clen
+
+            def fake_median(bam, chrom, start, end):
+                rc = ".revcomp." in os.path.basename(bam)
+                requested.append(["rc" if rc else "fw", start, end])
+                te_s, te_e = (clen - e, clen - s) if rc else (s, e)
+                m = mrc if rc else mfw
+                # which of the four intervals is it?
+                ivs = []
+                if te_s + 50 + 50 < te_e:
+                    ivs = [(te_s + 50, te_s + 100), (te_e - 100, te_e - 50)]
+                else:
+                    ivs = [(te_s, te_e), (te_s, te_e)]
+                ivs += [(te_s - 300, te_s - 200), (te_e + 200, te_e + 300)]
+                for k, x in enumerate(ivs):
+                    if (start, end) == x:
+                        return m[k]
+                raise RuntimeError("unexpected interval %r" % ((start, end),))
+            T.prep_assembly_inputs = fake_prep; T.Pool = FakePool; T.get_rev_comp_sequence = fake_rc
+            T.get_contig_length = fake_len; T.get_median_cov = fake_median
+            freq = T.get_af(tmp, "s", "bam", "reads", ann, cdir, vcf, 100, 200, 50, 50, "ont", 1)
+            out.append({"name": name, "te": [s, e], "contig_length": clen, "medians_fw": list(mfw), "medians_rc": list(mrc),
+                        "params": [100, 200, 50, 50], "requested_intervals": requested, "expected": freq[locus]})
+        finally:
+            shutil.rmtree(tmp)
+    return {"cases": out}
+
+
+def capture_helpers(L, T, S, U):
+    g = {}
+    g["get_coord"] = [[list(a), list(L.get_coord(*a))] for a in
+                      [(100, 600, 595, 1095, "+"), (100, 600, 595, 1095, "-"), (595, 1095, 100, 600, "-"), (100, 600, 600, 1100, "+"), (100, 600, 700, 1200, "-")]]
+    g["absmin"] = [[[a, b], L.absmin(a, b)] for a, b in [(3, -2), (-3, 2), (-2, 2), (2, -2), (0, 5), (-7, -1)]]
+    g["choose_new_size"] = [[[a, b, c], L.choose_new_size(a, b, c)] for a, b, c in [(4600, 4000, 4500), (4600, 4500, 4000), (4600, 5000, 4700), (100, 10, 10)]]
+    g["check_nums_similar"] = [[[a, b], L.check_nums_similar(a, b)] for a, b in [(4600, 4600), (4140, 4600), (4139, 4600), (5060, 4600), (5061, 4600), (-5, 100)]]
+    g["get_te_flank_ratio"] = [[[a, b], T.get_te_flank_ratio(a, b)] for a, b in [(13.0, 18.0), (0.0, 18.0), (13.0, 0.0), (None, 18.0), (27.0, 18.0), (27.1, 18.0), (18.0, 18.0)]]
+    g["format_time"] = [[t, U.format_time(t)] for t in [0.4, 59.6, 61, 3599, 3600, 86399, 90061]]
+    g["average"] = [[l, S.average(l)] for l in ["10;11", "1;2", "3", "10;11;12;13", "0;1", "20;21"]]
+    return g
+
+
+def main():
+    L, T, S, U = import_reference()
+    os.makedirs(GOLD, exist_ok=True)
+    for name, obj in (("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
+                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U))):
+        with open(os.path.join(GOLD, name), "w") as f:
+            json.dump(obj, f, indent=1, sort_keys=True)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

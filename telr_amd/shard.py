@@ -1,0 +1,99 @@
+"""Sharding of the path across the GPUs of one node.
+
+* stage 1: reads are dealt to ranks by cumulative bases (length-sorted, snake order) against a
+  replicated index — no collective on the data path;
+* stages 2-4: candidate loci are assigned by LPT (longest processing time first) on their read
+  bases; every rank produces fixed-width result rows for its loci and ONE all-gather merges them
+  (RCCL over xGMI on GPUs, `backend="nccl"`; gloo in the CPU tests).  Variable-length payloads
+  (sequences, CIGARs) stay on the owning rank.
+The reference's only parallelism on this path is `multiprocessing.Pool(processes=thread)` over loci
+(src/telr/TELR_assembly.py:70-71, TELR_te.py:644-646, TELR_liftover.py:1049-1052).
+"""
+import numpy as np
+
+TYPE_CODES = {"unlifted": 0, "non-reference": 1, "reference": 2}
+TYPE_NAMES = {v: k for k, v in TYPE_CODES.items()}
+
+LOCUS_ROW = np.dtype([
+    ("locus_id", np.int32), ("status", np.int32), ("chrom_id", np.int32), ("start", np.int32), ("end", np.int32),
+    ("strand", np.int8), ("type", np.int8), ("n_family", np.int8), ("pad", np.int8),
+    ("gap", np.int32), ("tsd_len", np.int32), ("support", np.int32), ("family_id", np.int32, (4,)),
+    ("n_sv_reads", np.int32), ("n_ref_reads", np.int32), ("medians", np.float32, (8,)), ("af", np.float64),
+], align=True)
+NONE_I32 = np.int32(-2147483648)          # "None" for integer columns
+assert LOCUS_ROW.itemsize == 104, LOCUS_ROW.itemsize
+
+
+def shard_reads(lengths, world):
+    """-> list (per rank) of read indices: length-sorted, dealt in snake order so every rank gets
+    the same number of reads (+-1) and nearly the same number of bases."""
+    order = np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable")
+    out = [[] for _ in range(world)]
+    for k, i in enumerate(order):
+        r = k % (2 * world)
+        out[r if r < world else 2 * world - 1 - r].append(int(i))
+    return [sorted(x) for x in out]
+
+
+def shard_loci(costs, world):
+    """LPT: loci by decreasing cost to the currently lightest rank -> list (per rank) of locus indices."""
+    order = np.argsort(-np.asarray(costs, dtype=np.int64), kind="stable")
+    load = [0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = int(np.argmin(load))
+        out[r].append(int(i)); load[r] += int(costs[i])
+    return [sorted(x) for x in out]
+
+
+def all_gather_rows(rows, dist=None, device=None):
+    """rows: LOCUS_ROW array of this rank -> all ranks' rows sorted by locus_id.
+
+    One collective on the payload: every rank contributes a block padded to the largest per-rank count
+    (the counts travel in the same buffer's header), as torch.distributed.all_gather_into_tensor."""
+    rows = np.ascontiguousarray(rows, dtype=LOCUS_ROW)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.sort(rows, order="locus_id")
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([len(rows)], dtype=torch.int64, device=device)
+    nmax = n.clone()
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)            # sizes only; the data path has the one all-gather below
+    nmax = int(nmax.item())
+    block = np.zeros(8 + nmax * LOCUS_ROW.itemsize, np.uint8)
+    block[:8] = np.frombuffer(np.int64(len(rows)).tobytes(), np.uint8)
+    block[8:8 + rows.nbytes] = rows.view(np.uint8).reshape(-1)
+    send = torch.from_numpy(block).to(device) if device is not None else torch.from_numpy(block)
+    recv = torch.empty(world * len(block), dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(recv, send)
+    buf = recv.cpu().numpy()
+    parts = []
+    for r in range(world):
+        b = buf[r * len(block):(r + 1) * len(block)]
+        k = int(np.frombuffer(b[:8].tobytes(), np.int64)[0])
+        parts.append(np.frombuffer(b[8:8 + k * LOCUS_ROW.itemsize].tobytes(), dtype=LOCUS_ROW))
+    allrows = np.concatenate(parts) if parts else rows
+    return np.sort(allrows, order="locus_id")
+
+
+def rows_from_reports(locus_ids, reports, freqs, chrom_ids, family_ids):
+    """liftover report dicts (+ te_freq dicts) -> LOCUS_ROW array"""
+    out = np.zeros(len(locus_ids), LOCUS_ROW)
+    for k, (lid, rep, fr) in enumerate(zip(locus_ids, reports, freqs)):
+        r = rep["report"]
+        o = out[k]
+        o["locus_id"] = lid; o["status"] = rep["num_hits"]; o["type"] = TYPE_CODES[r["type"]]
+        o["chrom_id"] = chrom_ids.get(r["chrom"], -1) if r["chrom"] is not None else -1
+        for name in ("start", "end", "gap"):
+            o[name] = NONE_I32 if r.get(name) is None else r[name]
+        o["tsd_len"] = NONE_I32 if r.get("TSD_length") is None else r["TSD_length"]
+        o["strand"] = 0 if r["strand"] is None else (1 if r["strand"] == "+" else -1)
+        fams = [family_ids[f] for f in str(r["family"]).split("|")][:4]
+        o["n_family"] = len(fams); o["family_id"][:len(fams)] = fams
+        if fr is not None:
+            keys = ("te_5p_cov", "te_3p_cov", "flank_5p_cov", "flank_3p_cov", "te_5p_cov_rc", "te_3p_cov_rc", "flank_5p_cov_rc", "flank_3p_cov_rc")
+            o["medians"] = [np.nan if fr.get(x) is None else fr[x] for x in keys]
+            o["af"] = np.nan if fr.get("freq") is None else fr["freq"]
+        else:
+            o["medians"] = np.nan; o["af"] = np.nan
+    return out

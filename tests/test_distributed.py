@@ -1,0 +1,82 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard loci, compute their rows and merge them with the
+single all-gather; the merged table must equal the world_size-1 result."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make_rows(ids):
+    from telr_amd import shard
+    rows = np.zeros(len(ids), shard.LOCUS_ROW)
+    for k, i in enumerate(ids):
+        rng = np.random.default_rng(1000 + i)
+        rows[k]["locus_id"] = i; rows[k]["start"] = int(rng.integers(0, 1 << 20)); rows[k]["end"] = rows[k]["start"] + 5
+        rows[k]["strand"] = 1 if i % 2 else -1; rows[k]["type"] = 1; rows[k]["af"] = round(float(rng.random()), 3)
+        rows[k]["medians"] = rng.integers(0, 40, size=8).astype(np.float32); rows[k]["support"] = int(rng.integers(3, 60))
+    return rows
+
+
+def _worker(rank, world, port, n_loci, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from telr_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    costs = [(i * 7919) % 1000 + 1 for i in range(n_loci)]
+    mine = shard.shard_loci(costs, world)[rank]
+    merged = shard.all_gather_rows(_make_rows(mine), dist)
+    if rank == 0:
+        np.save(out_path, merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_locus_rows_allgather_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    n_loci, world = 37, 2
+    out = str(tmp_path / "merged.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n_loci, out), nprocs=world, join=True)
+    merged = np.load(out)
+    want = _make_rows(list(range(n_loci)))
+    assert len(merged) == n_loci
+    want = np.sort(want, order="locus_id")
+    for name in merged.dtype.names:          # field-wise: struct padding bytes are not data
+        np.testing.assert_array_equal(merged[name], want[name], err_msg=name)
+
+
+def test_shard_reads_and_loci_balance():
+    from telr_amd import shard
+    rng = np.random.default_rng(3)
+    lens = rng.lognormal(9, 0.6, size=1001).astype(np.int64)
+    for world in (1, 2, 4, 8):
+        parts = shard.shard_reads(lens, world)
+        assert sorted(sum(parts, [])) == list(range(len(lens)))
+        bases = [int(lens[p].sum()) for p in parts]
+        assert max(bases) - min(bases) <= 0.03 * sum(bases) / world + lens.max()
+        lp = shard.shard_loci(lens[:200], world)
+        assert sorted(sum(lp, [])) == list(range(200))
+        loads = [int(lens[:200][p].sum()) for p in lp]
+        assert max(loads) - min(loads) <= lens[:200].max()
+
+
+def test_rows_from_reports_roundtrip():
+    from telr_amd import shard
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "liftover_driver.json")))
+    reps = g["expected_report"]
+    fr = [{"te_5p_cov": 13.0, "te_3p_cov": 12.0, "flank_5p_cov": 18.0, "flank_3p_cov": 17.0, "te_5p_cov_rc": 14.0, "te_3p_cov_rc": 15.0,
+           "flank_5p_cov_rc": 18.0, "flank_3p_cov_rc": 19.0, "freq": 0.75}] * len(reps)
+    rows = shard.rows_from_reports(list(range(len(reps))), reps, fr, {"chr2L": 0}, {"roo": 0, "jockey": 1, "copia": 2})
+    assert list(rows["start"]) == [r["report"]["start"] for r in reps]
+    assert list(rows["strand"]) == [1 if r["report"]["strand"] == "+" else -1 for r in reps]
+    assert rows["af"][0] == 0.75 and rows["tsd_len"][3] == shard.NONE_I32

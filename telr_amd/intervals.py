@@ -91,3 +91,37 @@ def getfasta(seq_lookup, chrom, start, end):
     """`bedtools getfasta -fi FASTA -bed <chrom start end>` -> (header, sequence)."""
     s = seq_lookup(chrom)
     return "%s:%d-%d" % (chrom, start, end), s[start:end]
+
+
+def intersect_wao(a_rows, b_rows):
+    """`bedtools intersect -a A -b B -wao`: one row per (A, overlapping B) with the overlap in bp; an A
+    feature without overlap gets `.`/-1 filler columns and 0."""
+    out = []
+    ncol_b = len(b_rows[0]) if b_rows else 6
+    for a in a_rows:
+        a_s, a_e = int(a[1]), int(a[2])
+        hit = False
+        for b in b_rows:
+            if b[0] != a[0]:
+                continue
+            ov = min(a_e, int(b[2])) - max(a_s, int(b[1]))
+            if ov > 0:
+                out.append(list(a) + list(b) + [str(ov)])
+                hit = True
+        if not hit:
+            out.append(list(a) + ([".", "-1", "-1"] + ["."] * (ncol_b - 3)) + ["0"])
+    return out
+
+
+def merge_distinct(rows, d, cols, delim="|"):
+    """`bedtools merge -d D -c cols -o distinct,... -delim DELIM` on sorted rows (cols are 0-based);
+    `distinct` lists the unique values in lexicographic order."""
+    groups = []
+    for r in rows:
+        s, e = int(r[1]), int(r[2])
+        if groups and groups[-1][0] == r[0] and s <= groups[-1][2] + d:
+            groups[-1][2] = max(groups[-1][2], e)
+            groups[-1][3].append(r)
+        else:
+            groups.append([r[0], s, e, [r]])
+    return [[c, str(s), str(e)] + [delim.join(sorted(set(r[k] for r in rs))) for k in cols] for c, s, e, rs in groups]

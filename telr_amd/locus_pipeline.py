@@ -1,0 +1,21 @@
+"""The per-locus bundle of the path (stages 3-4) as batched engine calls:
+   S4 ALT->contig, S5 library->contig, S7 flanks->reference + liftover decision tree, S6 reads->contig
+   forward / reverse-complement + depth medians + allele frequency.
+A "locus" = (name "<chr>_<start>_<end>", contig sequence, Sniffles ALT sequence, window reads)."""
+from . import telr_te, telr_af, telr_liftover
+
+
+def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, presets="ont", ref_te_rows=None,
+             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50)):
+    """loci: list of dicts(name, contig, alt, reads).  -> dict(annotation, liftover, summary, af)"""
+    names = [l["name"] for l in loci]
+    contigs = {l["name"]: l["contig"] for l in loci}
+    ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
+                                            lib_names, lib_seqs, presets)
+    mapper = telr_liftover.engine_flank_mapper(ref_index, ref_names)
+    reports, summary = telr_liftover.liftover(mapper, contigs, ann, ref_seq, ref_te_rows, flank_len, gap, overlap)
+    contig_te = {}
+    for r in ann:                       # one annotation per contig feeds the AF step (first one wins, as a dict would)
+        contig_te.setdefault(r[0], (int(r[1]), int(r[2])))
+    freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["reads"] for l in loci}, presets, *af_params)
+    return {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}

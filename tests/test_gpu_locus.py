@@ -1,0 +1,50 @@
+"""Per-locus bundle (S4, S5, S6 + depth/AF, S7 + liftover) on the HIP engine: outputs equal to the same
+host pipeline driven by the CPU oracle, and the spiked insertions are recovered."""
+import numpy as np
+import pytest
+
+from telr_amd import locus_pipeline
+from telr_amd.presets import preset
+
+pytestmark = pytest.mark.gpu
+
+
+def test_locus_bundle_equals_oracle_and_recovers_truth(engine):
+    from oracle_backend import OracleBackend
+    from locus_data import make_loci
+    ref, lib_names, lib, loci, truth = make_loci()
+    io, _ = preset("asm10")
+    out = {}
+    for tag, be in (("hip", engine), ("oracle", OracleBackend())):
+        ref_ix = be.index([ref], io)
+        out[tag] = locus_pipeline.run_loci(be, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
+    assert out["hip"]["annotation"] == out["oracle"]["annotation"]
+    assert out["hip"]["liftover"] == out["oracle"]["liftover"]
+    assert out["hip"]["summary"] == out["oracle"]["summary"]
+    assert out["hip"]["af"] == out["oracle"]["af"]          # floats: identical, tolerance 1e-6 not needed
+    check_truth(out["hip"], loci, truth)
+
+
+def check_truth(res, loci, truth):
+    by_id = {}
+    for r in res["liftover"]:
+        by_id["_".join(r["ID"].split("_")[:3])] = r
+    ok = 0
+    for l, t in zip(loci, truth):
+        r = by_id.get(l["name"])
+        if r is None:
+            continue
+        rep = r["report"]
+        if rep["type"] != "non-reference":
+            continue
+        assert rep["chrom"] == "chr2L"
+        assert abs(rep["start"] - t["pos"]) <= 20 and abs(rep["end"] - t["pos"]) <= 20
+        assert rep["family"] == t["family"]
+        assert rep["strand"] == t["strand"]
+        if rep["TSD_length"] is not None:
+            assert abs(rep["TSD_length"] - t["tsd"]) <= 3
+        f = res["af"][l["name"]]["freq"]
+        if f is not None:
+            assert (f >= 0.7) if t["af"] == 1.0 else (0.2 <= f <= 0.85)
+        ok += 1
+    assert ok >= len(loci) - 1

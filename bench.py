@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-25 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", default="map-ont")
+    ap.add_argument("--loci", type=int, default=200, help="candidate loci for the TE-loci/s leg (0 = skip)")
     return ap.parse_args()
 
 
@@ -180,6 +181,28 @@ def main():
         "frac_reads_mapped": frac_mapped, "index_build_s": t_index, "datagen_s": t_gen, "device": eng.device_name(),
         "counters": ctr,
     }
+    if a.loci > 0:
+        # second half of the BASELINE metric: TE loci/s through the per-locus bundle (S4, S5, S6 fw+rc + depth + AF,
+        # S7 x2 + liftover).  Asm10 index of the same reference; loci = the spiked insertions (truth-derived contigs).
+        from telr_amd import locus_pipeline
+        loci = synth.make_loci_from_dataset(d, min(a.loci, len(d["insertions"])))
+        io10, _ = preset("asm10")
+        ix10 = eng.index([ref_str], io10)
+        lib_names = ["fam%d" % i for i in range(len(d["library"]))]
+        lib = [bytes(x).decode() for x in d["library"]]
+        locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci[:8], lib_names, lib)      # warm-up
+        t0 = time.time()
+        lres = locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib)
+        t_loci = time.time() - t0
+        good = 0
+        by = {"_".join(r["ID"].split("_")[:3]): r["report"] for r in lres["liftover"]}
+        for l in loci:
+            r = by.get(l["name"])
+            if r and r["type"] == "non-reference" and abs(r["start"] - l["truth"]["pos"]) <= 20 and r["strand"] == l["truth"]["strand"] and r["family"] == l["truth"]["family"]:
+                good += 1
+        out["te_loci_per_s"] = len(loci) / t_loci
+        out["te_loci"] = {"n": len(loci), "seconds": t_loci, "recovered_exact_family_strand_pos20": good,
+                          "note": "host glue (Python) included; per-locus inputs are truth-derived (no Sniffles/wtdbg2 on the box)"}
     if not a.no_cpu_baseline:
         ns = a.cpu_sample_reads or max(8, int(8e6 * (os.cpu_count() or 1) / 8 / max(1.0, n_bases / len(d["reads"][2]))))
         out["cpu_baseline"] = cpu_baseline(ref_str, d["reads"], io, mo, ns, None)

@@ -170,3 +170,47 @@ def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total
     off = np.cumsum(ln.astype(np.int64)) - ln
     truth = np.concatenate([np.c_[np.zeros(nA, np.int64), rA[3]], np.c_[np.ones(n_reads - nA, np.int64), rB[3]]])
     return dict(ref=ref, library=lib, reads=(buf, off.astype(np.int64), ln.astype(np.int32)), insertions=ins, truth=truth, haps=haps)
+
+
+def make_loci_from_dataset(d, n_loci, seed=7, flank=(8000, 15000), reads_cap=60, window=1000):
+    """Per-locus inputs for the stage 3/4 bundle when Sniffles / wtdbg2 are unavailable:
+    contig = true insertion haplotype +-(8-15) kb around the site with 0.5 % residual error, ALT sequence =
+    true insertion with 5 % error, window reads = the simulated reads overlapping +-1 kb of the site (truth)."""
+    rng = np.random.default_rng(seed)
+    ref, lib, ins = d["ref"], d["library"], d["insertions"]
+    buf, off, ln = d["reads"]
+    truth = d["truth"]
+    hap0 = d["haps"][0]
+    # insertion coordinates on haplotype 0 (every insertion is present there)
+    shift = 0
+    loci = []
+    order = rng.permutation(len(ins))[:n_loci]
+    pos_h0 = []
+    for (p, fam, strand, tsd, af) in ins:
+        pos_h0.append(p + shift + tsd)            # first TE base on hap0
+        shift += len(lib[fam]) + tsd
+    # hap1 coordinates: only AF==1 insertions are present
+    shift1, pos_h1 = 0, []
+    for (p, fam, strand, tsd, af) in ins:
+        pos_h1.append(p + shift1)
+        if af >= 1.0:
+            shift1 += len(lib[fam]) + tsd
+    for k in sorted(order):
+        p, fam, strand, tsd, af = ins[k]
+        te_len = len(lib[fam])
+        a = pos_h0[k]
+        lo, hi = int(rng.integers(*flank)), int(rng.integers(*flank))
+        s, e = max(0, a - lo), min(len(hap0), a + te_len + hi)
+        contig = mutate(rng, hap0[s:e], 0.003, 0.001, 0.001)
+        te = lib[fam] if not strand else revcomp_arr(lib[fam])
+        alt = mutate(rng, te, 0.03, 0.01, 0.01)
+        # reads overlapping the window on their own haplotype
+        sel = []
+        for hap_id, centre in ((0, a), (1, pos_h1[k])):
+            m = (truth[:, 0] == hap_id) & (truth[:, 1] < centre + window) & (truth[:, 2] > centre - window)
+            sel.extend(np.nonzero(m)[0].tolist())
+        sel = sel[:reads_cap]
+        reads = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in sel]
+        loci.append({"name": "chr2L_%d_%d" % (p, p + 1), "contig": bytes(contig).decode(), "alt": bytes(alt).decode(), "reads": reads,
+                     "truth": {"pos": p, "family": "fam%d" % fam, "strand": "+-"[strand], "tsd": tsd, "af": af}})
+    return loci

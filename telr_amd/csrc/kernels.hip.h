@@ -490,9 +490,14 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
-#define DP_NCLS 10
-__device__ __forceinline__ int d_dp_class(int kind, int D)
+#define DP_NCLS 12
+// 10/11: packed-int16 register kernel (16 / 32 lanes per problem, 4 diagonals per lane) for short gap fills
+__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps)
 {
+    if (kind == 0 && steps <= pk_max_steps) {
+        if (D <= 64) return 10;
+        if (D <= 128) return 11;
+    }
     if (kind == 0) {
         if (D <= 64) return 5;
         if (D <= 128) return 6;
@@ -502,19 +507,25 @@ __device__ __forceinline__ int d_dp_class(int kind, int D)
     }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
-__device__ __forceinline__ int d_cls_slots(int cls) { return cls == 5 ? 32 : 64 << (cls - 6); }   // dwords per packed trace-back row
-__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
+__device__ __forceinline__ int d_cls_slots(int cls) { return cls == 10 ? 16 : cls == 11 ? 32 : cls == 5 ? 32 : 64 << (cls - 6); }   // dwords per packed trace-back row
+__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
-    int cls = d_dp_class(P.kind, D);
+    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps);
     int64_t tb;
     if (P.kind == 3) tb = 0;
+    else if (cls >= 10) tb = (int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4;
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
-    probs[i].pad[0] = cls;
+    int cells = 0;
+    if (cls >= 10) for (int d = P.dlo; d <= P.dhi; ++d) {
+        int ilo = d < 0 ? 1 - d : 1, ihi = P.n - d < P.m ? P.n - d : P.m;
+        if (ihi >= ilo) cells += ihi - ilo + 1;
+    }
+    probs[i].pad[0] = cls; probs[i].pad[1] = cells;
     tb_bytes[i] = tb;
     cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
@@ -853,6 +864,135 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
     }
 }
 
+// ---- packed-int16 register kernel for short gap fills (classes 10/11).
+// Same paired-diagonal scheme as k_dp_reg, but every 32-bit register holds TWO diagonals as
+// int16 halves (lane l owns diagonals dlo+4l .. dlo+4l+3: pair 0 in the low halves, pair 1 in the
+// high halves), so one v_pk_* instruction advances two cells.  The recurrence runs branch-free over
+// the whole band: with H(0,0)=0 and -inf everywhere else, row 0 / column 0 come out of the same
+// recurrence (exact for e >= e2, q <= q2, which telr_map enforces) and cells outside the matrix
+// only ever see -inf-ish operands, so no activity masks are needed; comparison results are taken
+// from sign bits of packed differences.  -inf is -16384 and real scores of these problems stay
+// within +-6000 (the class is limited by step count), so int16 never wraps.
+// Trace-back bytes: dword tb32[(a>>1)*LPP + l], half (a&1), byte r (pair).
+typedef short pk_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_s2 PKS(uint32_t v) { return __builtin_bit_cast(pk_s2, v); }
+__device__ __forceinline__ uint32_t PKU(pk_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return PKU(PKS(a) + PKS(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return PKU(PKS(a) - PKS(b)); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return PKU(__builtin_elementwise_max(PKS(a), PKS(b))); }
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return PKU(PKS(a) >> (pk_s2)(15)); }     // 0xffff where the half is negative
+__device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
+#define PK_NEG 0xC000C000u
+
+struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, nambi; };
+
+__device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t e1l, uint32_t e2l, uint32_t hu, uint32_t f1u, uint32_t f2u,
+                                              uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve1, uint32_t &vf1, uint32_t &ve2, uint32_t &vf2)
+{
+    uint32_t op, g, t;
+    op = pk_sub(hl, c.qe);   g = pk_sub(e1l, c.e);  ve1 = pk_max(op, g); t  = pk_sign(pk_sub(op, g)) & 0x00080008u;
+    op = pk_sub(hu, c.qe);   g = pk_sub(f1u, c.e);  vf1 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00100010u;
+    op = pk_sub(hl, c.q2e2); g = pk_sub(e2l, c.e2); ve2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00200020u;
+    op = pk_sub(hu, c.q2e2); g = pk_sub(f2u, c.e2); vf2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00400040u;
+    const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
+    const uint32_t amb = pk_sign(PKU(PKS(qb | tbv) << (pk_s2)(13)));      // either base is N (code 4)
+    uint32_t sc = pk_sub(eq & c.ab, c.b);
+    sc = (amb & c.nambi) | (~amb & sc);
+    t |= eq & ~amb & 0x00800080u;
+    h = pk_add(hd, sc);
+    uint32_t m, src;
+    m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & 0x00010001u;
+    m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = (m & 0x00020002u) | (~m & src);
+    m = pk_sign(pk_sub(h, ve2)); h = pk_max(h, ve2); src = (m & 0x00030003u) | (~m & src);
+    m = pk_sign(pk_sub(h, vf2)); h = pk_max(h, vf2); src = (m & 0x00040004u) | (~m & src);
+    return t | src;
+}
+
+template <int LPP>
+__global__ void __launch_bounds__(64) k_dp_pk(DpArgs A)
+{
+    constexpr int PPW = 64 / LPP;
+    const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
+    const int pi = blockIdx.x * PPW + sub;
+    const bool have = pi < A.nlist;
+    const int prob = A.list[have ? pi : 0];
+    const DpProb P = A.probs[prob];
+    const DpOpt o = A.o;
+    PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
+    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.nambi = pk_dup(-o.sc_ambi);
+    const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo;
+    const int de0 = dlo + 4 * l;                       // even diagonal of pair 0; pair 1: de0+2
+    uint32_t He = PK_NEG, E1e = PK_NEG, E2e = PK_NEG, F1e = PK_NEG, F2e = PK_NEG;
+    uint32_t Ho = PK_NEG, E1o = PK_NEG, E2o = PK_NEG, F1o = PK_NEG, F2o = PK_NEG;
+    if (de0 == 0) He = (He & 0xffff0000u);             // H(0,0) = 0
+    if (de0 + 2 == 0) He = (He & 0x0000ffffu);
+    const int qs_ = P.qstep, ts_ = P.tstep;
+    int amax = m + n;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+    uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off);
+    const int last_row = have ? (m + n) >> 1 : -1, mn = m + n;
+    // base streams: query rows enter at pair 0 (low half), target columns at pair 1 (high half)
+    BaseStream QS, TS;
+    int qleft = 32, tleft = 32;
+    d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, -(de0 >> 1) - 2, P.qcomp, A.qtot);
+    d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, (de0 >> 1) - 1, 0, A.ttot);
+    uint32_t qb = 0, tbv = 0;
+    qb = (qb << 16) | (uint32_t)d_stream_next(QS); qb = (qb << 16) | (uint32_t)d_stream_next(QS); qleft -= 2;
+    tbv = (tbv >> 16) | ((uint32_t)d_stream_next(TS) << 16); tbv = (tbv >> 16) | ((uint32_t)d_stream_next(TS) << 16); tleft -= 2;
+    uint32_t tbw = 0, fin = PK_NEG;
+    const bool first = LPP < 64 && l == 0, last = LPP < 64 && l == LPP - 1;
+    // diagonals above dhi are outside the band: their H / F (what an in-band neighbour reads) stay -inf
+    const int dhi = have ? P.dhi : dlo - 1;
+    const uint32_t inE = (de0 <= dhi ? 0x0000ffffu : 0u) | (de0 + 2 <= dhi ? 0xffff0000u : 0u);
+    const uint32_t inO = (de0 + 1 <= dhi ? 0x0000ffffu : 0u) | (de0 + 3 <= dhi ? 0xffff0000u : 0u);
+    for (int a = 1; a <= amax; ++a) {
+        uint32_t h, ve1, vf1, ve2, vf2, t;
+        if (a & 1) {
+            // ---- odd step: odd diagonals (de0+1, de0+3); new target base enters the high half
+            if (tleft == 0) { d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, ((a + de0 + 1) >> 1), 0, A.ttot); tleft = 32; }
+            tbv = (tbv >> 16) | ((uint32_t)d_stream_next(TS) << 16); --tleft;
+            uint32_t nh = DPP_SHL1((int)PK_NEG, (int)He), nf1 = DPP_SHL1((int)PK_NEG, (int)F1e), nf2 = DPP_SHL1((int)PK_NEG, (int)F2e);
+            if (last) { nh = PK_NEG; nf1 = PK_NEG; nf2 = PK_NEG; }
+            // up neighbour of pair r is the even diagonal of pair r+1: {low: own high half, high: next lane's low half}
+            const uint32_t hu = __builtin_amdgcn_alignbit(nh, He, 16), f1u = __builtin_amdgcn_alignbit(nf1, F1e, 16), f2u = __builtin_amdgcn_alignbit(nf2, F2e, 16);
+            t = d_cell_pk(c, Ho, He, E1e, E2e, hu, f1u, f2u, qb, tbv, h, ve1, vf1, ve2, vf2);
+            Ho = (h & inO) | (PK_NEG & ~inO); E1o = ve1; F1o = (vf1 & inO) | (PK_NEG & ~inO); E2o = ve2; F2o = (vf2 & inO) | (PK_NEG & ~inO);
+        } else {
+            // ---- even step: even diagonals (de0, de0+2); new query base enters the low half
+            if (qleft == 0) { d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, ((a - de0) >> 1) - 1, P.qcomp, A.qtot); qleft = 32; }
+            qb = (qb << 16) | (uint32_t)d_stream_next(QS); --qleft;
+            uint32_t ph = DPP_SHR1((int)PK_NEG, (int)Ho), pe1 = DPP_SHR1((int)PK_NEG, (int)E1o), pe2 = DPP_SHR1((int)PK_NEG, (int)E2o);
+            if (first) { ph = PK_NEG; pe1 = PK_NEG; pe2 = PK_NEG; }
+            // left neighbour of pair r is the odd diagonal of pair r-1: {low: previous lane's high half, high: own low half}
+            const uint32_t hl = __builtin_amdgcn_alignbit(Ho, ph, 16), e1l = __builtin_amdgcn_alignbit(E1o, pe1, 16), e2l = __builtin_amdgcn_alignbit(E2o, pe2, 16);
+            t = d_cell_pk(c, He, hl, e1l, e2l, Ho, F1o, F2o, qb, tbv, h, ve1, vf1, ve2, vf2);
+            He = (h & inE) | (PK_NEG & ~inE); E1e = ve1; F1e = (vf1 & inE) | (PK_NEG & ~inE); E2e = ve2; F2e = (vf2 & inE) | (PK_NEG & ~inE);
+        }
+        if (a == mn) fin = h;                          // the last anti-diagonal of THIS problem holds H(m,n)
+        // two bytes (pair 0, pair 1) of this step
+        const uint32_t b16 = __builtin_amdgcn_perm(0u, t, 0x0c0c0200u);
+        tbw |= b16 << (16 * (a & 1));
+        if ((a & 1) || a == amax) {
+#ifndef EXP_NOSTORE
+            if ((a >> 1) <= last_row) tb32[(int64_t)(a >> 1) * LPP + l] = tbw;
+#else
+            if (tbw == 0x12345678u && (a >> 1) <= last_row) tb32[(int64_t)(a >> 1) * LPP + l] = tbw;
+#endif
+            tbw = 0;
+        }
+    }
+    if (have) {
+        const int xf = (n - m) - de0;                  // final diagonal inside this lane's block of four?
+        if (xf >= 0 && xf < 4) {
+            // its parity equals the parity of m+n, i.e. of the step that produced `fin`; pair = xf>>1
+            const int sc = (int)(short)((xf >> 1) ? (fin >> 16) : (fin & 0xffffu));
+            DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0;
+            A.res[prob] = Rr;
+        }
+    }
+}
+
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
 // run-length CIGAR in end->start order (64 independent pointer chases per wave).
 __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
@@ -872,7 +1012,8 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
     while (i > 0 && j > 0) {
         const int a = i + j, sl = (j - i - dlo) >> 1;
-        const uint32_t t = packed ? tb[(((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)] : tb[(int64_t)a * stride + sl];
+        const uint32_t t = cls >= 10 ? tb[(((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)]
+                         : packed ? tb[(((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)] : tb[(int64_t)a * stride + sl];
         if (state == 0) state = t & 7;
         int op;
         if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }

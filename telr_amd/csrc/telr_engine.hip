@@ -25,10 +25,10 @@
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
     "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "cigar_gather", "d2h", "assemble_host", "index_build",
-    "k_dp_reg_32_1", "k_dp_reg_64_1", "k_traceback", "reserved"
+    "k_dp_pk32_reg32", "map_wall", "k_traceback", "k_dp_pk_16"
 };
 enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX,
-       ST_K_REG32, ST_K_REG64, ST_K_TRACEBACK, ST_RESERVED };
+       ST_K_REG32, ST_MAP_WALL, ST_K_TRACEBACK, ST_K_PK16 };
 
 #define TELR_NSIDE 8
 struct DBuf { void *p = nullptr; size_t bytes = 0; };
@@ -41,6 +41,7 @@ struct telr_ctx {
     std::string err;
     std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
     std::map<std::string, DBuf> hbufs;    // grow-only pinned host staging buffers
+    std::vector<std::pair<uint32_t*, size_t>> cig_pool;   // recycled result CIGAR buffers
     int debug = 0;                        // keep stage-level captures for the parity tests
     float stage_ms[TELR_N_STAGES] = {0};
     telr_counters ctr = {};
@@ -146,6 +147,8 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->hbufs) if (kv.second.p) (void)hipHostFree(kv.second.p);
+    for (auto &pc : ctx->cig_pool) free(pc.first);
+    ctx->cig_pool.clear();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -502,11 +505,30 @@ static int32_t mapq_of(const telr_aln &r, const telr_map_opt *mo)
 }
 
 struct telr_result {
+    telr_ctx *ctx = nullptr;
     std::vector<telr_aln> alns;
     uint32_t *cig = nullptr;       // malloc'ed, never zero-filled: pages are first touched by the stitching threads
-    size_t ncig = 0;
-    ~telr_result() { free(cig); }
+    size_t ncig = 0, cap = 0;      // cap in ops
+    ~telr_result();
 };
+// CIGAR buffers of freed results are kept (at most two) and handed to the next telr_map call: a fresh
+// 200 MB allocation costs ~20 ms of page faults and another ~20 ms of munmap per call.
+static void pool_put(telr_ctx *ctx, uint32_t *p, size_t cap)
+{
+    if (!p) return;
+    if (!ctx || ctx->cig_pool.size() >= 2) { free(p); return; }
+    ctx->cig_pool.push_back(std::make_pair(p, cap));
+}
+static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
+{
+    *p = nullptr; *cap = 0;
+    if (!ctx || ctx->cig_pool.empty()) return;
+    size_t best = 0;
+    for (size_t i = 1; i < ctx->cig_pool.size(); ++i) if (ctx->cig_pool[i].second > ctx->cig_pool[best].second) best = i;
+    *p = ctx->cig_pool[best].first; *cap = ctx->cig_pool[best].second;
+    ctx->cig_pool.erase(ctx->cig_pool.begin() + best);
+}
+telr_result::~telr_result() { pool_put(ctx, cig, cap); }
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
 extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->ncig : 0; }
@@ -519,8 +541,9 @@ static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
     if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
 }
 
-static inline int host_dp_class(int kind, int D)
+static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0)
 {
+    if (kind == 0 && steps <= pk_max_steps) { if (D <= 64) return 10; if (D <= 128) return 11; }
     if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
@@ -773,7 +796,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "cls_cnt", 16, &d_clscnt));
         TRY(ctx_buf_t(ctx, "cls_list", (size_t)np * DP_NCLS, &d_clslist));
         hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
-        hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tbb, d_cgo);
+        const int pk_max_steps = (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
+        hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_max_steps, d_tbb, d_cgo);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
         HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
@@ -828,7 +852,10 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
             HIPCHK(hipGetLastError());
         }
+        HIPCHK(hipEventRecord(ctx->evk[5], st));
+        if (h_cls[10]) { D.list = d_clslist + (size_t)10 * np; D.nlist = h_cls[10]; hipLaunchKernelGGL((k_dp_pk<16>), dim3((h_cls[10] + 3) / 4), dim3(64), 0, st, D); }
         HIPCHK(hipEventRecord(ctx->evk[0], st));
+        if (h_cls[11]) { D.list = d_clslist + (size_t)11 * np; D.nlist = h_cls[11]; hipLaunchKernelGGL((k_dp_pk<32>), dim3((h_cls[11] + 1) / 2), dim3(64), 0, st, D); }
         if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
         HIPCHK(hipEventRecord(ctx->evk[1], st));
         if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
@@ -844,8 +871,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipGetLastError());
         t_dp.stop();
         { float ms = 0;
+          if (hipEventElapsedTime(&ms, ctx->evk[5], ctx->evk[0]) == hipSuccess) ctx->stage_ms[ST_K_PK16] += ms;
           if (hipEventElapsedTime(&ms, ctx->evk[0], ctx->evk[1]) == hipSuccess) ctx->stage_ms[ST_K_REG32] += ms;
-          if (hipEventElapsedTime(&ms, ctx->evk[1], ctx->evk[2]) == hipSuccess) ctx->stage_ms[ST_K_REG64] += ms;
           if (hipEventElapsedTime(&ms, ctx->evk[3], ctx->evk[4]) == hipSuccess) ctx->stage_ms[ST_K_TRACEBACK] += ms; }
 
         // ---- compact cigars and bring results home (pinned staging) --------------------------------
@@ -876,6 +903,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         h_doff.resize((size_t)np + 1);
         h_doff[0] = 0;
         for (int i = 0; i < np; ++i) { h_doff[i + 1] = h_doff[i] + h_res[i].nops; ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
+        const int pk_max_steps_h = (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
         std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
         std::vector<int64_t*> tcls(NT);
         for (int t = 0; t < NT; ++t) tcls[t] = tcls_store.data() + (size_t)t * TELR_N_DPCLS * 4;
@@ -897,7 +925,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                         const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
                         int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6); if (W > mo->bw) W = mo->bw;
                         int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
-                        cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1);
+                        cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h);
                     }
                     int64_t *cc = tcls[tslot] + cls * 4;
                     cc[0] += 1; cc[1] += d.cells; cc[2] += is_ext ? d.bi + d.bj : d.bi + d.bj;
@@ -980,9 +1008,16 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         for (int i = 0; i < ns; ++i) fin_off[i + 1] = fin_off[i] + nfin[i];
         const int64_t tot = fin_off[ns];
         const size_t base = R->ncig;
-        uint32_t *nc = (uint32_t*)realloc(R->cig, (base + (size_t)tot + 1) * 4);
-        if (!nc) return TELR_E_NOMEM;
-        R->cig = nc; R->ncig = base + (size_t)tot;
+        if (base + (size_t)tot + 1 > R->cap) {
+            if (!R->cig) pool_get(ctx, &R->cig, &R->cap);
+            if (base + (size_t)tot + 1 > R->cap) {
+                size_t want = base + (size_t)tot + 1; want += want / 8;
+                uint32_t *nc = (uint32_t*)realloc(R->cig, want * 4);
+                if (!nc) return TELR_E_NOMEM;
+                R->cig = nc; R->cap = want;
+            }
+        }
+        R->ncig = base + (size_t)tot;
         parallel_ranges(NT, ns, [&](int, int ia, int ib) {
             for (int i = ia; i < ib; ++i) {
                 const int x = surv[i].x; const HostChain &c = chains[kept[x]];
@@ -1008,6 +1043,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
 {
     if (!ctx || !ix || !queries || !mo || !out) return TELR_E_ARG;
     if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
+    if (mo->e < mo->e2 || mo->q > mo->q2) { ctx->err = "two-piece gap cost needs e >= e2 and q <= q2"; return TELR_E_ARG; }
     if (mo->max_gap >= TELR_TPAD || mo->ext_band * 2 + 1 > DP_DMAX || mo->ext_band < 1 || mo->ext_max < 1) return TELR_E_ARG;
     if (queries->max_len >= (1 << 24)) return TELR_E_RANGE;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1023,6 +1059,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     }
     const int32_t mid_occ = index_mid_occ(ix, mo);
     telr_result *R = new telr_result();
+    R->ctx = ctx;
+    const auto t_wall0 = std::chrono::steady_clock::now();
     // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
     int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
     if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
@@ -1035,6 +1073,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         if (r != TELR_OK) { delete R; return r; }
         q0 = q1;
     }
+    ctx->stage_ms[ST_MAP_WALL] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count();
     *out = R;
     return TELR_OK;
 }

@@ -469,7 +469,7 @@ static inline void cig_push(u32v_t *c, int op, int len)
     else vpush(uint32_t, *c, (uint32_t)len << 4 | (uint32_t)op);
 }
 
-typedef struct { int score, bi, bj; int64_t cells; } dp_res_t;
+typedef struct { int score, bi, bj, touched; int64_t cells; } dp_res_t;
 
 /* ext=0: global alignment of (m,n), returns H(m,n), traceback from (m,n).
  * ext=1: extension from (0,0): best cell with z-drop, traceback from it.
@@ -478,7 +478,7 @@ static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr
 {
     const int m = s->m, n = s->n, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const int q1 = mo->q, e1 = mo->e, q2 = mo->q2, e2 = mo->e2;
-    dp_res_t res = { 0, 0, 0, 0 };
+    dp_res_t res = { 0, 0, 0, 0, 0 };
     int32_t *H = (int32_t*)malloc(4 * (size_t)(D + 2) * 5), *E1 = H + (D + 2), *F1 = E1 + (D + 2), *E2 = F1 + (D + 2), *F2 = E2 + (D + 2);
     for (int x = 0; x < (D + 2) * 5; ++x) H[x] = NEG;
     uint8_t *tb = (uint8_t*)calloc((size_t)(m + n + 1) * stride, 1);
@@ -542,6 +542,7 @@ static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr
     int state = 0;
     while (i > 0 && j > 0) {
         uint8_t t = tb[(size_t)(i + j) * stride + ((j - i - dlo) >> 1)];
+        if (j - i == dlo || j - i == dhi) res.touched = 1;     /* the path used all the slack of the band */
         if (state == 0) state = t & 7;
         if (state == 0) { cig_push(rev_cig, 0, 1); --i; --j; }
         else if (state == 1) { cig_push(rev_cig, 2, 1); if (!(t & 8))  state = 0; --j; }
@@ -559,7 +560,7 @@ static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr
 /* band wider than DP_DMAX: align min(m,n) bases on the main diagonal and close with one gap */
 static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v_t *rev_cig, int *mlen)
 {
-    dp_res_t r = { 0, s->m, s->n, 0 };
+    dp_res_t r = { 0, s->m, s->n, 0, 0 };
     int mn = s->m < s->n ? s->m : s->n, g = s->m > s->n ? s->m - s->n : s->n - s->m;
     *mlen = 0;
     for (int x = 0; x < mn; ++x) {
@@ -571,10 +572,18 @@ static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v
     return r;
 }
 
+/* Adaptive band of a gap-fill segment: a narrow first pass; if the optimal path of that pass touches
+ * a band edge the segment is re-aligned once with the four times wider band. */
 static inline int fill_band(int m, int n, const telr_map_opt *mo)
 {
     int mn = m < n ? m : n;
-    int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6);
+    int W = 6 + (mn >> 5);
+    return W < mo->bw ? W : mo->bw;
+}
+static inline int fill_band_wide(int m, int n, const telr_map_opt *mo)
+{
+    int mn = m < n ? m : n;
+    int W = 24 + (mn >> 3);
     return W < mo->bw ? W : mo->bw;
 }
 /* the lower band edge is rounded down to an even diagonal (the GPU pairs diagonals per lane) */
@@ -657,6 +666,11 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         int lo = even_lo((dl < 0 ? dl : 0) - W), hi = (dl > 0 ? dl : 0) + W, fb_mlen;
         dp_res_t r = hi - lo + 1 > DP_DMAX ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
+        if (r.touched) {            /* second pass with the wide band */
+            int W2 = fill_band_wide(s.m, s.n, mo);
+            lo = even_lo((dl < 0 ? dl : 0) - W2); hi = (dl > 0 ? dl : 0) + W2;
+            if (W2 > W && hi - lo + 1 <= DP_DMAX) { rc.n = 0; r = band_dp(&s, lo, hi, 0, mo, &rc); ctr->dp_cells += r.cells; }
+        }
         dp += r.score;
         for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
     }

@@ -421,10 +421,14 @@ struct DpProb {             // 64 B
 };
 struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, mcols; };   // 32 B; mcols = M columns of the path
 
-__device__ __forceinline__ int d_fill_band(int m, int n, int bw)
+__device__ __forceinline__ int d_fill_band(int m, int n, int bw)          // narrow first pass
 {
-    int mn = m < n ? m : n;
-    int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6);
+    int mn = m < n ? m : n, W = 6 + (mn >> 5);
+    return W < bw ? W : bw;
+}
+__device__ __forceinline__ int d_fill_band_wide(int m, int n, int bw)     // retry when the path touched a band edge
+{
+    int mn = m < n ? m : n, W = 24 + (mn >> 3);
     return W < bw ? W : bw;
 }
 __device__ __forceinline__ int d_even_lo(int lo) { return lo - (lo & 1); }
@@ -490,11 +494,12 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
-#define DP_NCLS 12
+#define DP_NCLS 13
 // 10/11: packed-int16 register kernel (16 / 32 lanes per problem, 4 diagonals per lane) for short gap fills
 __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps)
 {
     if (kind == 0 && steps <= pk_max_steps) {
+        if (D <= 32) return 12;
         if (D <= 64) return 10;
         if (D <= 128) return 11;
     }
@@ -507,7 +512,7 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
     }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
-__device__ __forceinline__ int d_cls_slots(int cls) { return cls == 10 ? 16 : cls == 11 ? 32 : cls == 5 ? 32 : 64 << (cls - 6); }   // dwords per packed trace-back row
+__device__ __forceinline__ int d_cls_slots(int cls) { return cls == 12 ? 8 : cls == 10 ? 16 : cls == 11 ? 32 : cls == 5 ? 32 : 64 << (cls - 6); }   // dwords per packed trace-back row
 __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -516,7 +521,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
     int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps);
     int64_t tb;
-    if (P.kind == 3) tb = 0;
+    if (P.kind >= 3) tb = 0;
     else if (cls >= 10) tb = (int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4;
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
@@ -530,7 +535,8 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
     cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
 __global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs, int32_t np, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ cig_off,
-                                                     int32_t *__restrict__ cls_cnt, int32_t *__restrict__ cls_list /* [DP_NCLS][np] */)
+                                                     int32_t *__restrict__ cls_cnt, int32_t *__restrict__ cls_list /* [DP_NCLS][np] */,
+                                                     uint32_t *__restrict__ cls_key /* [DP_NCLS][np]: anti-diagonal steps */)
 {
     __shared__ int32_t lcnt[DP_NCLS], lbase[DP_NCLS];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -538,14 +544,42 @@ __global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs,
     __syncthreads();
     int c = -1, s = 0;
     if (i < np) {
-        probs[i].tb_off = tb_off[i]; probs[i].cig_off = cig_off[i];
-        c = probs[i].kind == 3 ? 0 : probs[i].pad[0];
+        probs[i].tb_off = tb_off[i];
+        if (cig_off) probs[i].cig_off = cig_off[i];       // a retry keeps the CIGAR slot of the original problem
+        c = probs[i].kind >= 3 ? 0 : probs[i].pad[0];
         s = atomicAdd(&lcnt[c], 1);
     }
     __syncthreads();
     if (threadIdx.x < DP_NCLS) lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cls_cnt[threadIdx.x], lcnt[threadIdx.x]) : 0;
     __syncthreads();
-    if (c >= 0) cls_list[(int64_t)c * np + lbase[c] + s] = i;
+    if (c >= 0) { cls_list[(int64_t)c * np + lbase[c] + s] = i; cls_key[(int64_t)c * np + lbase[c] + s] = (uint32_t)(probs[i].m + probs[i].n); }
+}
+
+// retry pass: problems whose narrow-band path touched a band edge are re-aligned with the wide band
+__global__ void k_retry_collect(const int32_t *__restrict__ flag, int32_t np, int32_t *__restrict__ cnt, int32_t *__restrict__ list)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np && flag[i]) list[atomicAdd(cnt, 1)] = i;
+}
+__global__ void k_retry_build(const DpProb *__restrict__ probs, const int32_t *__restrict__ list, int32_t n, int32_t bw, DpProb *__restrict__ out)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    DpProb P = probs[list[k]];
+    const int W = d_fill_band(P.m, P.n, bw), W2 = d_fill_band_wide(P.m, P.n, bw), dl = P.n - P.m;
+    const int lo = d_even_lo((dl < 0 ? dl : 0) - W2), hi = (dl > 0 ? dl : 0) + W2;
+    P.chain = list[k];                  // index of the original problem
+    P.pad[1] = 0;
+    if (W2 > W && hi - lo + 1 <= DP_DMAX) { P.dlo = lo; P.dhi = hi; P.kind = 0; } else P.kind = 4;   // 4 = nothing to redo
+    out[k] = P;
+}
+__global__ void k_retry_merge(const DpProb *__restrict__ probs2, const DpRes *__restrict__ res2, int32_t n, DpRes *__restrict__ res)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || probs2[k].kind == 4) return;
+    DpRes r = res2[k];
+    r.cells += res[probs2[k].chain].cells;
+    res[probs2[k].chain] = r;
 }
 
 struct DpArgs {
@@ -598,6 +632,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     const int prob = A.list[pi];
     const DpProb P = A.probs[prob];
     const int lane = threadIdx.x;
+    if (P.kind == 4) return;
     const int m = P.m, n = P.n, dlo = P.dlo, dhi = P.dhi, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const DpOpt o = A.o;
     const bool ext = P.kind == 1 || P.kind == 2;
@@ -996,12 +1031,13 @@ __global__ void __launch_bounds__(64) k_dp_pk(DpArgs A)
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
 // run-length CIGAR in end->start order (64 independent pointer chases per wave).
 __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
-                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig)
+                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry)
 {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= np) return;
     const DpProb P = probs[pi];
-    if (P.kind == 3) return;
+    if (P.kind >= 3) return;
+    const int dhi_ = P.dhi; int touched = 0;
     const int cls = P.pad[0], dlo = P.dlo;
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
     const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
@@ -1014,6 +1050,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
         const int a = i + j, sl = (j - i - dlo) >> 1;
         const uint32_t t = cls >= 10 ? tb[(((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)]
                          : packed ? tb[(((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)] : tb[(int64_t)a * stride + sl];
+        touched |= (j - i == dlo) | (j - i == dhi_);
         if (state == 0) state = t & 7;
         int op;
         if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
@@ -1028,6 +1065,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
     if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
     res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
+    if (retry && P.kind == 0 && touched) retry[pi] = 1;
 }
 
 // compact the raw per-problem cigars (emission order preserved) into one dense array

@@ -25,7 +25,7 @@
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
     "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "cigar_gather", "d2h", "assemble_host", "index_build",
-    "k_dp_pk32_reg32", "map_wall", "k_traceback", "k_dp_pk_16"
+    "k_dp_pk16_pk32_reg", "map_wall", "k_traceback", "k_dp_pk_8"
 };
 enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX,
        ST_K_REG32, ST_MAP_WALL, ST_K_TRACEBACK, ST_K_PK16 };
@@ -48,6 +48,7 @@ struct telr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk[6] = {nullptr};        // un-synchronised markers around single kernels
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
+    int64_t dp_retries = 0;
     char devname[256] = {0};
     // debug captures of the last batch (device pointers stay valid until the next call)
     int64_t dbg_na = 0; int32_t dbg_nq = 0;
@@ -543,7 +544,7 @@ static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
 
 static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0)
 {
-    if (kind == 0 && steps <= pk_max_steps) { if (D <= 64) return 10; if (D <= 128) return 11; }
+    if (kind == 0 && steps <= pk_max_steps) { if (D <= 32) return 12; if (D <= 64) return 10; if (D <= 128) return 11; }
     if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
@@ -570,6 +571,106 @@ template <typename F> static void parallel_ranges(int nt, int n, F f)
 }
 
 struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int64_t a_glob; };
+
+// ---------------------------------------------------------------------------------------
+// One DP pass over a problem array: scratch sizing, class lists (sorted by length so that the problems
+// sharing a wave are alike and the long ones start first), forward kernels, trace-back.
+static inline int pk_steps_limit(const telr_map_opt *mo)
+{
+    return (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
+}
+static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, const telr_map_opt *mo, DpProb *d_probs, int np, DpRes *d_res,
+                   uint32_t **d_rawcig_io, int32_t *d_retry, const std::string &sfx, bool primary)
+{
+    hipStream_t st = ctx->stream;
+    int64_t *d_tbb, *d_cgo, *d_tboff, *d_cgoff; int32_t *d_clscnt, *d_clslist; uint32_t *d_clskey, *d_keytmp; int32_t *d_listtmp;
+    TRY(ctx_buf_t(ctx, ("tb_bytes" + sfx).c_str(), (size_t)np + 1, &d_tbb));
+    TRY(ctx_buf_t(ctx, ("cig_ops" + sfx).c_str(), (size_t)np + 1, &d_cgo));
+    TRY(ctx_buf_t(ctx, ("tb_off" + sfx).c_str(), (size_t)np + 1, &d_tboff));
+    TRY(ctx_buf_t(ctx, ("cig_off" + sfx).c_str(), (size_t)np + 1, &d_cgoff));
+    TRY(ctx_buf_t(ctx, ("cls_cnt" + sfx).c_str(), 16, &d_clscnt));
+    TRY(ctx_buf_t(ctx, ("cls_list" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clslist));
+    TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clskey));
+    TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
+    TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), d_tbb, d_cgo);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
+    HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
+    TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbb, d_tboff, (size_t)np + 1)));
+    if (primary) TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_cgo, d_cgoff, (size_t)np + 1)));
+    HIPCHK(hipMemsetAsync(d_clscnt, 0, 64, st));
+    hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, primary ? d_cgoff : (const int64_t*)nullptr, d_clscnt, d_clslist, d_clskey);
+    HIPCHK(hipGetLastError());
+    int64_t tb_total = 0, cg_total = 0; int32_t h_cls[16];
+    HIPCHK(hipMemcpyAsync(&tb_total, d_tboff + np, 8, hipMemcpyDeviceToHost, st));
+    if (primary) HIPCHK(hipMemcpyAsync(&cg_total, d_cgoff + np, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // sort every sizeable class list by decreasing step count
+    for (int c = 0; c < DP_NCLS; ++c) {
+        if (h_cls[c] < 256) continue;
+        uint32_t *keys = d_clskey + (size_t)c * np; int32_t *ids = d_clslist + (size_t)c * np;
+        size_t tbytes = 0;
+        HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, keys, d_keytmp, ids, d_listtmp, (size_t)h_cls[c], 0, 20, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
+        HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, keys, d_keytmp, ids, d_listtmp, (size_t)h_cls[c], 0, 20, st));
+        HIPCHK(hipMemcpyAsync(ids, d_listtmp, (size_t)h_cls[c] * 4, hipMemcpyDeviceToDevice, st));
+    }
+    uint8_t *d_tb;
+    TRY(ctx_buf_t(ctx, ("tb" + sfx).c_str(), (size_t)tb_total + 256, &d_tb));
+    if (primary) TRY(ctx_buf_t(ctx, "rawcig", (size_t)cg_total + 16, d_rawcig_io));
+    DpArgs D; D.qseq2 = qs->d_seq2; D.qnmask = qs->d_nmask; D.tseq2 = tg->d_seq2; D.tnmask = tg->d_nmask; D.probs = d_probs;
+    D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
+    D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
+    D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
+    static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
+    // The few long/wide problems are latency-bound single waves: start each tail class on its own side
+    // stream so that they run underneath the bulk classes on the main stream.
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    int side = 0;
+    std::vector<hipStream_t> used;
+    auto side_stream = [&]() { hipStream_t s2 = ctx->side[side % TELR_NSIDE]; ++side; used.push_back(s2); return s2; };
+    for (int c = 4; c >= 0; --c) {
+        if (h_cls[c] == 0) continue;
+        hipStream_t s2 = side_stream();
+        HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c]; D.dcap = CAP[c];
+        size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
+        if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, s2, D);
+        HIPCHK(hipGetLastError());
+    }
+    D.dcap = 0;
+    for (int c = 9; c >= 7; --c) {
+        if (h_cls[c] == 0) continue;
+        hipStream_t s2 = side_stream();
+        HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c];
+        if (c == 9) hipLaunchKernelGGL((k_dp_reg<64, 8>), dim3(h_cls[c]), dim3(64), 0, s2, D);
+        else if (c == 8) hipLaunchKernelGGL((k_dp_reg<64, 4>), dim3(h_cls[c]), dim3(64), 0, s2, D);
+        else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
+        HIPCHK(hipGetLastError());
+    }
+    if (primary) HIPCHK(hipEventRecord(ctx->evk[5], st));
+    if (h_cls[12]) { D.list = d_clslist + (size_t)12 * np; D.nlist = h_cls[12]; hipLaunchKernelGGL((k_dp_pk<8>), dim3((h_cls[12] + 7) / 8), dim3(64), 0, st, D); }
+    if (primary) HIPCHK(hipEventRecord(ctx->evk[0], st));
+    if (h_cls[10]) { D.list = d_clslist + (size_t)10 * np; D.nlist = h_cls[10]; hipLaunchKernelGGL((k_dp_pk<16>), dim3((h_cls[10] + 3) / 4), dim3(64), 0, st, D); }
+    if (h_cls[11]) { D.list = d_clslist + (size_t)11 * np; D.nlist = h_cls[11]; hipLaunchKernelGGL((k_dp_pk<32>), dim3((h_cls[11] + 1) / 2), dim3(64), 0, st, D); }
+    if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
+    if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
+    if (primary) HIPCHK(hipEventRecord(ctx->evk[1], st));
+    HIPCHK(hipGetLastError());
+    for (size_t u = 0; u < used.size(); ++u) {
+        HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
+    }
+    if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
+    hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, *d_rawcig_io, d_retry);
+    if (primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
+    HIPCHK(hipGetLastError());
+    return TELR_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // one batch of queries [q0, q1)
@@ -787,93 +888,44 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipMemcpyAsync(h_poff.data(), d_poff, (size_t)(nk + 1) * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         np = h_poff[nk];
-        DpProb *d_probs; int64_t *d_tbb, *d_cgo, *d_tboff, *d_cgoff; int32_t *d_clscnt, *d_clslist;
+        DpProb *d_probs;
         TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
-        TRY(ctx_buf_t(ctx, "tb_bytes", (size_t)np + 1, &d_tbb));
-        TRY(ctx_buf_t(ctx, "cig_ops", (size_t)np + 1, &d_cgo));
-        TRY(ctx_buf_t(ctx, "tb_off", (size_t)np + 1, &d_tboff));
-        TRY(ctx_buf_t(ctx, "cig_off", (size_t)np + 1, &d_cgoff));
-        TRY(ctx_buf_t(ctx, "cls_cnt", 16, &d_clscnt));
-        TRY(ctx_buf_t(ctx, "cls_list", (size_t)np * DP_NCLS, &d_clslist));
         hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
-        const int pk_max_steps = (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
-        hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_max_steps, d_tbb, d_cgo);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
-        HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
-        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbb, d_tboff, (size_t)np + 1)));
-        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_cgo, d_cgoff, (size_t)np + 1)));
-        HIPCHK(hipMemsetAsync(d_clscnt, 0, 64, st));
-        hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, d_cgoff, d_clscnt, d_clslist);
-        HIPCHK(hipGetLastError());
-        int64_t tb_total = 0, cg_total = 0; int32_t h_cls[16];
-        HIPCHK(hipMemcpyAsync(&tb_total, d_tboff + np, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&cg_total, d_cgoff + np, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 64, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
         t_sg.stop();
         ctx->ctr.dp_problems += np;
 
-        // ---- banded DP ------------------------------------------------------------------------
+        // ---- banded DP: narrow-band pass, then a wide-band pass for the problems whose path touched a band edge
         StageTimer t_dp(ctx, ST_DP, true);
-        uint8_t *d_tb; uint32_t *d_rawcig; DpRes *d_res;
-        TRY(ctx_buf_t(ctx, "tb", (size_t)tb_total + 256, &d_tb));
-        TRY(ctx_buf_t(ctx, "rawcig", (size_t)cg_total + 16, &d_rawcig));
+        uint32_t *d_rawcig = nullptr; DpRes *d_res; int32_t *d_retry, *d_rcnt, *d_rlist;
         TRY(ctx_buf_t(ctx, "dp_res", (size_t)np, &d_res));
-        DpArgs D; D.qseq2 = qs->d_seq2; D.qnmask = qs->d_nmask; D.tseq2 = tg->d_seq2; D.tnmask = tg->d_nmask; D.probs = d_probs;
-        D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
-        D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
-        D.tb = d_tb; D.cig = d_rawcig; D.res = d_res; D.dcap = 0;
-        static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
-        // The few long/wide problems are latency-bound single waves: start each tail class on its
-        // own side stream so that they run underneath the bulk classes on the main stream.
-        HIPCHK(hipEventRecord(ctx->ev_fork, st));
-        int side = 0;
-        auto side_stream = [&]() { hipStream_t s = ctx->side[side % TELR_NSIDE]; ++side; return s; };
-        std::vector<hipStream_t> used;
-        for (int c = 4; c >= 0; --c) {
-            if (h_cls[c] == 0) continue;
-            hipStream_t s2 = side_stream(); used.push_back(s2);
-            HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-            D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c]; D.dcap = CAP[c];
-            size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
-            if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, s2, D);
-            HIPCHK(hipGetLastError());
-        }
-        D.dcap = 0;
-        for (int c = 9; c >= 7; --c) {
-            if (h_cls[c] == 0) continue;
-            hipStream_t s2 = side_stream(); used.push_back(s2);
-            HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-            D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c];
-            if (c == 9) hipLaunchKernelGGL((k_dp_reg<64, 8>), dim3(h_cls[c]), dim3(64), 0, s2, D);
-            else if (c == 8) hipLaunchKernelGGL((k_dp_reg<64, 4>), dim3(h_cls[c]), dim3(64), 0, s2, D);
-            else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipEventRecord(ctx->evk[5], st));
-        if (h_cls[10]) { D.list = d_clslist + (size_t)10 * np; D.nlist = h_cls[10]; hipLaunchKernelGGL((k_dp_pk<16>), dim3((h_cls[10] + 3) / 4), dim3(64), 0, st, D); }
-        HIPCHK(hipEventRecord(ctx->evk[0], st));
-        if (h_cls[11]) { D.list = d_clslist + (size_t)11 * np; D.nlist = h_cls[11]; hipLaunchKernelGGL((k_dp_pk<32>), dim3((h_cls[11] + 1) / 2), dim3(64), 0, st, D); }
-        if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
-        HIPCHK(hipEventRecord(ctx->evk[1], st));
-        if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
-        HIPCHK(hipEventRecord(ctx->evk[2], st));
+        TRY(ctx_buf_t(ctx, "retry_flag", (size_t)np + 1, &d_retry));
+        TRY(ctx_buf_t(ctx, "retry_list", (size_t)np + 1, &d_rlist));
+        TRY(ctx_buf_t(ctx, "retry_cnt", 4, &d_rcnt));
+        HIPCHK(hipMemsetAsync(d_retry, 0, ((size_t)np + 1) * 4, st));
+        HIPCHK(hipMemsetAsync(d_rcnt, 0, 16, st));
+        TRY(dp_pass(ctx, qs, tg, mo, d_probs, np, d_res, &d_rawcig, d_retry, "", true));
+        hipLaunchKernelGGL(k_retry_collect, dim3((np + 255) / 256), dim3(256), 0, st, d_retry, np, d_rcnt, d_rlist);
         HIPCHK(hipGetLastError());
-        for (size_t u = 0; u < used.size(); ++u) {
-            HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
-            HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
-        }
-        HIPCHK(hipEventRecord(ctx->evk[3], st));
-        hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, d_rawcig);
-        HIPCHK(hipEventRecord(ctx->evk[4], st));
-        HIPCHK(hipGetLastError());
-        t_dp.stop();
+        int32_t n_retry = 0;
+        HIPCHK(hipMemcpyAsync(&n_retry, d_rcnt, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         { float ms = 0;
           if (hipEventElapsedTime(&ms, ctx->evk[5], ctx->evk[0]) == hipSuccess) ctx->stage_ms[ST_K_PK16] += ms;
           if (hipEventElapsedTime(&ms, ctx->evk[0], ctx->evk[1]) == hipSuccess) ctx->stage_ms[ST_K_REG32] += ms;
           if (hipEventElapsedTime(&ms, ctx->evk[3], ctx->evk[4]) == hipSuccess) ctx->stage_ms[ST_K_TRACEBACK] += ms; }
+        if (n_retry > 0) {
+            DpProb *d_probs2; DpRes *d_res2;
+            TRY(ctx_buf_t(ctx, "probs_r", (size_t)n_retry, &d_probs2));
+            TRY(ctx_buf_t(ctx, "dp_res_r", (size_t)n_retry, &d_res2));
+            hipLaunchKernelGGL(k_retry_build, dim3((n_retry + 255) / 256), dim3(256), 0, st, d_probs, d_rlist, n_retry, mo->bw, d_probs2);
+            HIPCHK(hipGetLastError());
+            TRY(dp_pass(ctx, qs, tg, mo, d_probs2, n_retry, d_res2, &d_rawcig, nullptr, "_r", false));
+            hipLaunchKernelGGL(k_retry_merge, dim3((n_retry + 255) / 256), dim3(256), 0, st, d_probs2, d_res2, n_retry, d_res);
+            HIPCHK(hipGetLastError());
+        }
+        ctx->dp_retries += n_retry;
+        t_dp.stop();
 
         // ---- compact cigars and bring results home (pinned staging) --------------------------------
         StageTimer t_g(ctx, ST_GATHER, true);
@@ -903,7 +955,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         h_doff.resize((size_t)np + 1);
         h_doff[0] = 0;
         for (int i = 0; i < np; ++i) { h_doff[i + 1] = h_doff[i] + h_res[i].nops; ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
-        const int pk_max_steps_h = (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
+        const int pk_max_steps_h = pk_steps_limit(mo);
         std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
         std::vector<int64_t*> tcls(NT);
         for (int t = 0; t < NT; ++t) tcls[t] = tcls_store.data() + (size_t)t * TELR_N_DPCLS * 4;
@@ -923,7 +975,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                     if (is_ext) cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band));
                     else {
                         const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
-                        int W = mn <= 512 ? 12 + (mn >> 4) : 44 + ((mn - 512) >> 6); if (W > mo->bw) W = mo->bw;
+                        int W = 6 + (mn >> 5); if (W > mo->bw) W = mo->bw;
                         int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
                         cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h);
                     }
@@ -1050,6 +1102,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     memset(&ctx->ctr, 0, sizeof(ctx->ctr));
     memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
+    ctx->dp_retries = 0;
     const int nq = queries->n;
     if (qtarget) for (int i = 0; i < nq; ++i) if (qtarget[i] >= ix->targets->n) return TELR_E_ARG;
     int32_t *d_qt = nullptr;
@@ -1080,6 +1133,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
 
 // ---------------------------------------------------------------------------------------
 // debug taps for the stage-level parity tests (last batch of the last telr_map call)
+extern "C" int64_t telr_debug_dp_retries(const telr_ctx *ctx) { return ctx ? ctx->dp_retries : 0; }
 extern "C" int64_t telr_debug_n_anchor(const telr_ctx *ctx) { return ctx ? ctx->dbg_na : 0; }
 extern "C" int telr_debug_fetch(telr_ctx *ctx, const char *what, void *dst, int64_t bytes)
 {

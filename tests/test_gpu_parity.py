@@ -169,3 +169,29 @@ def test_wide_bands(engine):
     assert oref["counters"]["dp_problems"] > 0
     io2, mo2 = preset("asm10")
     compare_all(engine, [genome], reads, io2, mo2)
+
+
+def test_adaptive_band_retry(engine):
+    """A 20-base insertion compensated 60 bases later by a 20-base deletion leaves the segment's end points on
+    one diagonal but drags the optimal path outside the narrow first-pass band: the narrow pass touches the
+    band edge and the problem is re-aligned with the wide band (same rule in the oracle)."""
+    rng = np.random.default_rng(123)
+    genome = synth.random_seq(rng, 60000)
+    reads = []
+    for k in range(12):
+        s = int(rng.integers(0, 40000)); r = genome[s:s + 9000].copy()
+        parts, pos = [], 0
+        for x in range(1500, 8000, 1500):
+            ins = synth.random_seq(rng, 20 + k % 5)
+            parts += [r[pos:x], ins, r[x:x + 60]]
+            pos = x + 60 + 20 + k % 5                  # delete the same number of bases 60 bp downstream
+        parts.append(r[pos:])
+        r = synth.mutate(rng, np.concatenate(parts), 0.01, 0.003, 0.003)
+        if k % 2:
+            r = synth.revcomp_arr(r)
+        reads.append(r)
+    io, mo = preset("map-ont")
+    res, oref = compare_all(engine, [genome], reads, io, mo)
+    assert int(engine.L.telr_debug_dp_retries(engine.h)) > 0
+    prim = res.alns[(res.alns["flags"] & 1) != 0]
+    assert len(prim) == len(reads) and (prim["qe"] - prim["qs"] > 8500).all()

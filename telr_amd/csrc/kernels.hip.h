@@ -158,6 +158,146 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
 }
 
 // ---------------------------------------------------------------------------------------
+// 1b. homopolymer-compressed (HPC) sketch, map-pb.  A pre-pass compacts every sequence into its runs:
+//     hcode[h] = base code (0-4) of run h, hstart[h] = first position of the run; then the sketch runs
+//     over run indices: k consecutive runs form a k-mer, span = last base of run u+k-1 - first base of
+//     run u + 1 (k-mers with span >= 256 are invalid), position = last base of the last run.
+__device__ __forceinline__ int d_seq_of_chunk(const int64_t *__restrict__ boff, int n, int64_t b)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (boff[mid] <= b) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+// one thread per 64-base chunk (sequences start on 64-base boundaries): run-start flags and their count
+__global__ void k_hpc_flags(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, const int64_t *__restrict__ boff,
+                            const int32_t *__restrict__ len, int32_t sid0, int32_t nseq, int64_t chunk0, int32_t nchunk,
+                            uint64_t *__restrict__ flags, int32_t *__restrict__ cnt)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunk) return;
+    const int64_t b0 = (chunk0 + c) * 64;
+    const int sid = sid0 + d_seq_of_chunk(boff + sid0, nseq, b0);
+    const int64_t sb = boff[sid];
+    const int L = len[sid];
+    const int p0 = (int)(b0 - sb);
+    uint64_t f = 0;
+    int prev = p0 > 0 ? d_base(seq2, nmask, b0 - 1) : -1;
+    for (int x = 0; x < 64 && p0 + x < L; ++x) {
+        int cur = d_base(seq2, nmask, b0 + x);
+        if (cur != prev) f |= 1ULL << x;
+        prev = cur;
+    }
+    flags[c] = f; cnt[c] = __popcll(f);
+}
+__global__ void k_hpc_scatter(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, const int64_t *__restrict__ boff,
+                              int32_t sid0, int32_t nseq, int64_t chunk0, int32_t nchunk, const uint64_t *__restrict__ flags,
+                              const int32_t *__restrict__ coff, uint8_t *__restrict__ hcode, uint32_t *__restrict__ hstart)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunk) return;
+    const int64_t b0 = (chunk0 + c) * 64;
+    const int sid = sid0 + d_seq_of_chunk(boff + sid0, nseq, b0);
+    const int p0 = (int)(b0 - boff[sid]);
+    uint64_t f = flags[c]; int o = coff[c];
+    while (f) {
+        int x = __ffsll((long long)f) - 1; f &= f - 1;
+        hcode[o] = (uint8_t)d_base(seq2, nmask, b0 + x); hstart[o] = (uint32_t)(p0 + x); ++o;
+    }
+}
+// per sequence: offset / count of its runs = scan value at its first chunk
+__global__ void k_hpc_seq_offsets(const int64_t *__restrict__ boff, int32_t sid0, int32_t nseq, int64_t chunk0, const int32_t *__restrict__ coff,
+                                  int32_t nchunk, int32_t total, int32_t *__restrict__ hoff /* [nseq+1] */)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nseq) return;
+    if (s == nseq) { hoff[s] = total; return; }
+    const int64_t c = boff[sid0 + s] / 64 - chunk0;
+    hoff[s] = c < nchunk ? coff[c] : total;
+}
+
+struct SketchHpcArgs {
+    const uint8_t *hcode; const uint32_t *hstart;
+    const int32_t *hoff;        // [nseq+1] run offsets, local sequence index
+    const int32_t *len;         // sequence lengths, local sequence index
+    const uint32_t *goff;       // or nullptr
+    const int32_t *tile_seq, *tile_u0;
+    int32_t k, w;
+    int32_t *tile_cnt; const int32_t *tile_off;
+    uint64_t *out_x; uint32_t *out_y;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(SK_THREADS) k_sketch_hpc(SketchHpcArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int halo = A.w - 1, nslot = SK_TILE + 2 * halo, k = A.k;
+    uint64_t *xs = (uint64_t*)smem;
+    uint32_t *ps = (uint32_t*)(xs + nslot);             // position<<1 | strand of each slot
+    uint8_t *cb = (uint8_t*)(ps + nslot);               // run codes of the tile: nslot + k - 1 bytes
+    __shared__ int32_t wsum[SK_THREADS / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int sid = A.tile_seq[t], u0 = A.tile_u0[t];
+    const int h0 = A.hoff[sid], nh = A.hoff[sid + 1] - h0, ns = nh - k + 1, L = A.len[sid];
+    const uint64_t mask = (1ULL << 2 * k) - 1;
+    const int lo = u0 - halo;
+    for (int s = tid; s < nslot + k - 1; s += SK_THREADS) { int r = lo + s; cb[s] = (r >= 0 && r < nh) ? A.hcode[h0 + r] : 4; }
+    __syncthreads();
+    for (int s = tid; s < nslot; s += SK_THREADS) {
+        const int u = lo + s;
+        uint64_t x = UINT64_MAX; uint32_t pz = 0;
+        if (u >= 0 && u < ns) {
+            uint64_t fw = 0, rv = 0; bool ok = true;
+            for (int z = 0; z < k; ++z) { int c = cb[s + z]; ok &= c < 4; fw = (fw << 2 | (uint64_t)(c & 3)) & mask; rv = (rv >> 2) | (uint64_t)(3 ^ (c & 3)) << (2 * (k - 1)); }
+            const uint32_t first = A.hstart[h0 + u];
+            const uint32_t last = (u + k < nh ? A.hstart[h0 + u + k] : (uint32_t)L) - 1;     // last base of run u+k-1
+            const uint32_t span = last - first + 1;
+            if (ok && fw != rv && span < 256) {
+                const uint32_t z = fw < rv ? 0 : 1;
+                x = d_hash64(z ? rv : fw, mask) << 8 | (uint64_t)span;
+                pz = last << 1 | z;
+            }
+        }
+        xs[s] = x; ps[s] = pz;
+    }
+    __syncthreads();
+    const int need = A.w < ns ? A.w : ns;
+    uint32_t sel = 0;
+#pragma unroll
+    for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
+        int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = lo + s;
+        uint64_t x = xs[s];
+        if (u < ns && x != UINT64_MAX) {
+            int Lc = 0, Rc = 0;
+            while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
+            while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
+            if (Lc + Rc + 1 >= need) sel |= 1u << c;
+        }
+    }
+    int cnt = __popc(sel);
+    int lane = tid & 63, wv = tid >> 6, inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SK_THREADS / 64; ++i) { if (i < wv) wbase += wsum[i]; total += wsum[i]; }
+    if (MODE == 0) {
+        if (tid == 0) A.tile_cnt[t] = total;
+    } else {
+        int o = A.tile_off[t] + wbase + inc - cnt;
+        const uint32_t g0 = A.goff ? A.goff[sid] : 0u;
+#pragma unroll
+        for (int c = 0; c < SK_TILE / SK_THREADS; ++c) if (sel >> c & 1) {
+            int s = halo + tid * (SK_TILE / SK_THREADS) + c;
+            A.out_x[o] = xs[s];
+            A.out_y[o] = ((g0 << 1) + ps[s]);
+            ++o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // 2. index build helpers
 __global__ void k_head_flags(const uint64_t *__restrict__ h, int64_t n, int32_t *__restrict__ flag)
 {

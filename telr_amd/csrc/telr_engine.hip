@@ -285,20 +285,25 @@ static int dev_inclusive_scan_i32(telr_ctx *ctx, int32_t *io, size_t n)
 // ---------------------------------------------------------------------------------------
 // tiles for the sketch kernel
 struct TileList { std::vector<int32_t> seq, u0, first; int32_t n = 0; };
-static void make_tiles(const telr_seqset *s, int32_t q0, int32_t q1, int k, TileList &T)
+// tiles over slots; `slots_of(q)` = number of k-mer slots of sequence q; tile_seq holds q - seq_base
+template <typename F> static void make_tiles_f(int32_t q0, int32_t q1, int32_t seq_base, F slots_of, TileList &T)
 {
     T.seq.clear(); T.u0.clear(); T.first.assign(q1 - q0, 0);
     for (int32_t q = q0; q < q1; ++q) {
         T.first[q - q0] = (int32_t)T.seq.size();
-        int ns = s->len[q] - k + 1;
-        for (int u = 0; u < ns; u += SK_TILE) { T.seq.push_back(q); T.u0.push_back(u); }
+        int ns = slots_of(q);
+        for (int u = 0; u < ns; u += SK_TILE) { T.seq.push_back(q - seq_base); T.u0.push_back(u); }
     }
     T.n = (int32_t)T.seq.size();
+}
+static void make_tiles(const telr_seqset *s, int32_t q0, int32_t q1, int k, TileList &T)
+{
+    make_tiles_f(q0, q1, 0, [&](int32_t q) { return s->len[q] - k + 1; }, T);
 }
 
 // run the two-pass sketch over tiles; returns device arrays x,y (in ctx buffers named by prefix) and tile offsets
 static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, int k, int w, const uint32_t *d_goff, const char *prefix,
-                      uint64_t **d_x, uint32_t **d_y, int32_t **d_tile_off, int32_t *n_mz)
+                      uint64_t **d_x, uint32_t **d_y, int32_t **d_tile_off, int32_t *n_mz, const SketchHpcArgs *hpc = nullptr)
 {
     std::string P(prefix);
     int32_t *d_tseq, *d_tu0, *d_tcnt, *d_toff;
@@ -307,14 +312,22 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     TRY(ctx_buf_t(ctx, (P + "tile_cnt").c_str(), T.n + 1, &d_tcnt));
     TRY(ctx_buf_t(ctx, (P + "tile_off").c_str(), T.n + 1, &d_toff));
     *n_mz = 0; *d_tile_off = d_toff;
-    if (T.n == 0) { TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), 1, d_x)); TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), 1, d_y)); return TELR_OK; }
+    if (T.n == 0) {
+        TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), 1, d_x)); TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), 1, d_y));
+        HIPCHK(hipMemsetAsync(d_toff, 0, 4, ctx->stream));
+        return TELR_OK;
+    }
     HIPCHK(hipMemcpyAsync(d_tseq, T.seq.data(), T.n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_tu0, T.u0.data(), T.n * 4, hipMemcpyHostToDevice, ctx->stream));
     SketchArgs A;
     A.seq2 = s->d_seq2; A.nmask = s->d_nmask; A.boff = s->d_boff; A.len = s->d_len; A.goff = d_goff;
     A.tile_seq = d_tseq; A.tile_u0 = d_tu0; A.k = k; A.w = w; A.tile_cnt = d_tcnt; A.tile_off = nullptr; A.out_x = nullptr; A.out_y = nullptr;
-    size_t lds = (size_t)(SK_TILE + 2 * (w - 1)) * 9 + 16;
-    hipLaunchKernelGGL(k_sketch<0>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+    SketchHpcArgs H;
+    if (hpc) { H = *hpc; H.tile_seq = d_tseq; H.tile_u0 = d_tu0; H.k = k; H.w = w; H.tile_cnt = d_tcnt; H.tile_off = nullptr; H.out_x = nullptr; H.out_y = nullptr; }
+    const int nslot = SK_TILE + 2 * (w - 1);
+    size_t lds = hpc ? (size_t)nslot * 12 + (size_t)(nslot + k) + 32 : (size_t)nslot * 9 + 16;
+    if (hpc) hipLaunchKernelGGL(k_sketch_hpc<0>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H);
+    else hipLaunchKernelGGL(k_sketch<0>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
     HIPCHK(hipGetLastError());
     // exclusive scan over T.n+1 entries so that tile_off[T.n] = total
     HIPCHK(hipMemsetAsync(d_tcnt + T.n, 0, 4, ctx->stream));
@@ -323,9 +336,48 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     HIPCHK(hipStreamSynchronize(ctx->stream));
     TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), (size_t)*n_mz, d_x));
     TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), (size_t)*n_mz, d_y));
-    A.tile_off = d_toff; A.out_x = *d_x; A.out_y = *d_y;
-    hipLaunchKernelGGL(k_sketch<1>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+    if (hpc) { H.tile_off = d_toff; H.out_x = *d_x; H.out_y = *d_y; hipLaunchKernelGGL(k_sketch_hpc<1>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H); }
+    else { A.tile_off = d_toff; A.out_x = *d_x; A.out_y = *d_y; hipLaunchKernelGGL(k_sketch<1>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A); }
     HIPCHK(hipGetLastError());
+    return TELR_OK;
+}
+
+// homopolymer compaction of sequences [q0,q1) of a set; fills the device part of `H` and the host run counts
+static int build_hpc(telr_ctx *ctx, const telr_seqset *s, int32_t q0, int32_t q1, const char *prefix, SketchHpcArgs *H, std::vector<int32_t> *h_nrun)
+{
+    std::string P(prefix);
+    const int nseq = q1 - q0;
+    const int64_t chunk0 = s->boff[q0] / 64, chunk1 = s->boff[q1] / 64;
+    const int nchunk = (int)(chunk1 - chunk0);
+    uint64_t *d_flags; int32_t *d_cnt, *d_coff, *d_hoff; uint8_t *d_code; uint32_t *d_start;
+    TRY(ctx_buf_t(ctx, (P + "hpc_flags").c_str(), (size_t)nchunk + 1, &d_flags));
+    TRY(ctx_buf_t(ctx, (P + "hpc_cnt").c_str(), (size_t)nchunk + 1, &d_cnt));
+    TRY(ctx_buf_t(ctx, (P + "hpc_coff").c_str(), (size_t)nchunk + 1, &d_coff));
+    TRY(ctx_buf_t(ctx, (P + "hpc_hoff").c_str(), (size_t)nseq + 1, &d_hoff));
+    int32_t total = 0;
+    if (nchunk > 0) {
+        hipLaunchKernelGGL(k_hpc_flags, dim3((nchunk + 255) / 256), dim3(256), 0, ctx->stream, s->d_seq2, s->d_nmask, s->d_boff, s->d_len, q0, nseq, chunk0, nchunk, d_flags, d_cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(d_cnt + nchunk, 0, 4, ctx->stream));
+        TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_cnt, d_coff, (size_t)nchunk + 1)));
+        HIPCHK(hipMemcpyAsync(&total, d_coff + nchunk, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    TRY(ctx_buf_t(ctx, (P + "hpc_code").c_str(), (size_t)total + 64, &d_code));
+    TRY(ctx_buf_t(ctx, (P + "hpc_start").c_str(), (size_t)total + 64, &d_start));
+    if (nchunk > 0) {
+        hipLaunchKernelGGL(k_hpc_scatter, dim3((nchunk + 255) / 256), dim3(256), 0, ctx->stream, s->d_seq2, s->d_nmask, s->d_boff, q0, nseq, chunk0, nchunk, d_flags, d_coff, d_code, d_start);
+        HIPCHK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_hpc_seq_offsets, dim3((nseq + 256) / 256), dim3(256), 0, ctx->stream, s->d_boff, q0, nseq, chunk0, d_coff, nchunk, total, d_hoff);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> hoff(nseq + 1);
+    HIPCHK(hipMemcpyAsync(hoff.data(), d_hoff, (size_t)(nseq + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    h_nrun->resize(nseq);
+    for (int i = 0; i < nseq; ++i) (*h_nrun)[i] = hoff[i + 1] - hoff[i];
+    memset(H, 0, sizeof(*H));
+    H->hcode = d_code; H->hstart = d_start; H->hoff = d_hoff; H->len = s->d_len + q0;
     return TELR_OK;
 }
 
@@ -366,9 +418,18 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
     ix->goff[n] = (uint32_t)g;
     HIPCHK(hipMalloc(&ix->d_goff, (n + 1) * 4));
     HIPCHK(hipMemcpy(ix->d_goff, ix->goff.data(), (n + 1) * 4, hipMemcpyHostToDevice));
-    TileList T; make_tiles(tg, 0, n, k, T);
+    TileList T;
     uint64_t *d_x; uint32_t *d_y; int32_t *d_toff; int32_t nmz = 0;
-    TRY(run_sketch(ctx, tg, T, k, w, ix->d_goff, "ix_", &d_x, &d_y, &d_toff, &nmz));
+    if (io->is_hpc) {
+        SketchHpcArgs H; std::vector<int32_t> nrun;
+        TRY(build_hpc(ctx, tg, 0, n, "ixh_", &H, &nrun));
+        H.goff = ix->d_goff;
+        make_tiles_f(0, n, 0, [&](int32_t q) { return nrun[q] - k + 1; }, T);
+        TRY(run_sketch(ctx, tg, T, k, w, ix->d_goff, "ix_", &d_x, &d_y, &d_toff, &nmz, &H));
+    } else {
+        make_tiles(tg, 0, n, k, T);
+        TRY(run_sketch(ctx, tg, T, k, w, ix->d_goff, "ix_", &d_x, &d_y, &d_toff, &nmz));
+    }
     ix->n_mz = nmz;
     // hash = x >> 8 (in place), then stable radix sort by hash carrying y
     uint64_t *d_h2; uint32_t *d_y2;
@@ -431,7 +492,6 @@ extern "C" int telr_index_build(telr_ctx *ctx, const telr_seqset *targets, const
 {
     if (!ctx || !targets || !io || !out) return TELR_E_ARG;
     if (io->k < 4 || io->k > 28 || io->w < 1 || io->w > 255) return TELR_E_ARG;
-    if (io->is_hpc) { ctx->err = "homopolymer-compressed sketch is not implemented on the device yet"; return TELR_E_ARG; }
     HIPCHK(hipSetDevice(ctx->device));
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     telr_index *ix = new telr_index();
@@ -683,9 +743,17 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
 
     // ---- sketch -------------------------------------------------------------------------
     StageTimer t_sk(ctx, ST_SKETCH, true);
-    TileList T; make_tiles(qs, q0, q1, k, T);
+    TileList T;
     uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
-    TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz));
+    if (ix->io.is_hpc) {
+        SketchHpcArgs H; std::vector<int32_t> nrun;
+        TRY(build_hpc(ctx, qs, q0, q1, "qh_", &H, &nrun));
+        make_tiles_f(q0, q1, q0, [&](int32_t q) { return nrun[q - q0] - k + 1; }, T);
+        TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz, &H));
+    } else {
+        make_tiles(qs, q0, q1, k, T);
+        TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz));
+    }
     // per-query minimizer offsets = tile_off[first tile of the query]
     int32_t *d_first, *d_qmz;
     TRY(ctx_buf_t(ctx, "q_first", (size_t)nq + 1, &d_first));

@@ -195,3 +195,27 @@ def test_adaptive_band_retry(engine):
     assert int(engine.L.telr_debug_dp_retries(engine.h)) > 0
     prim = res.alns[(res.alns["flags"] & 1) != 0]
     assert len(prim) == len(reads) and (prim["qe"] - prim["qs"] > 8500).all()
+
+
+def test_fixture_map_pb_hpc(engine, data_dir):
+    """The reference's own smoke configuration: PacBio reads, `--presets pacbio` -> map-pb (homopolymer-compressed
+    k-mers, k=19): device HPC compaction + sketch against the oracle."""
+    _, ts = read_fasta(data_dir + "/ref_38kb.fasta")
+    _, qs = read_fasta(data_dir + "/reads.fasta")
+    io, mo = preset("map-pb")
+    res, _ = compare_all(engine, ts, qs, io, mo)
+    assert len(res.alns) >= 18
+
+
+def test_synthetic_clr_hpc(engine):
+    rng = np.random.default_rng(31)
+    genome = [synth.random_seq(rng, 150000), synth.random_seq(rng, 50)]
+    genome[0][5000:5400] = ord("A")                       # a 400-base homopolymer: span >= 256 k-mers are skipped
+    genome[0][70000:70020] = ord("N")
+    reads, truth = synth.simulate_reads(rng, genome[:1], 40, 7000, err=(0.013, 0.065, 0.052))
+    reads.append(np.frombuffer(b"ACGTTTTTTTTTTTTTTTTTTTTTTTTTTTTGCA", dtype=np.uint8))   # fewer than k runs
+    reads.append(np.zeros(0, np.uint8))
+    io, mo = preset("map-pb")
+    res, _ = compare_all(engine, genome, reads, io, mo)
+    prim = res.alns[(res.alns["flags"] & 1) != 0]
+    assert len(prim) >= 38

@@ -53,6 +53,57 @@ def brute_minimizers(seq, k, w):
     return [(xs[q][0], xs[q][1]) for q in sorted(sel)]
 
 
+def brute_minimizers_hpc(seq, k, w):
+    """homopolymer-compressed variant: k-mers over runs, span in original bases, position = last base of the last run"""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    runs = []
+    i = 0
+    while i < len(seq):
+        j = i + 1
+        while j < len(seq) and (seq[j] == seq[i] or (seq[j] not in code and seq[i] not in code)):
+            j += 1
+        runs.append((seq[i], i, j - 1)); i = j
+    mask = (1 << 2 * k) - 1
+    ns = len(runs) - k + 1
+    xs = []
+    for u in range(ns):
+        rr = runs[u:u + k]
+        span = rr[-1][2] - rr[0][1] + 1
+        if any(c not in code for c, _, _ in rr) or span >= 256:
+            xs.append(None); continue
+        fw = 0
+        for c, _, _ in rr:
+            fw = fw << 2 | code[c]
+        rv = 0
+        for c, _, _ in reversed(rr):
+            rv = rv << 2 | (3 - code[c])
+        if fw == rv:
+            xs.append(None); continue
+        z = 0 if fw < rv else 1
+        xs.append((_hash64(rv if z else fw, mask) << 8 | span, rr[-1][2] << 1 | z))
+    sel = set()
+    win = min(w, ns)
+    for j in range(0, ns - win + 1):
+        vals = [xs[q][0] for q in range(j, j + win) if xs[q] is not None]
+        if not vals:
+            continue
+        m = min(vals)
+        for q in range(j, j + win):
+            if xs[q] is not None and xs[q][0] == m:
+                sel.add(q)
+    return [(xs[q][0], xs[q][1]) for q in sorted(sel)]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hpc_sketch_matches_set_definition(seed):
+    rng = np.random.default_rng(50 + seed)
+    s = bytes(synth.random_seq(rng, 600)).decode()
+    s = s[:100] + "A" * 40 + s[100:300] + "NNNN" + s[300:400] + "T" * 300 + s[400:]     # long homopolymers (span >= 256) and Ns
+    x, y = ob.sketch(s, 19, 10, hpc=1)
+    want = brute_minimizers_hpc(s, 19, 10)
+    assert [(int(a), int(b)) for a, b in zip(x, y)] == want and len(want) > 10
+
+
 @pytest.mark.parametrize("k,w,n,seed", [(15, 10, 400, 1), (19, 19, 300, 2), (5, 4, 120, 3), (15, 10, 20, 4), (15, 10, 15, 5), (7, 3, 60, 6)])
 def test_sketch_matches_set_definition(k, w, n, seed):
     rng = np.random.default_rng(seed)

@@ -158,6 +158,21 @@ int64_t         telr_result_cigar_count(const telr_result *r);
 const uint32_t *telr_result_cigars(const telr_result *r);
 void            telr_result_free(telr_result *r);
 
+/* ---- text emitters at the reference's own boundary (PAF for S4,S5,S7; SAM for S1,S2,S3,S6) --------
+ * qnames / tnames: arrays of C strings indexed by query / target id.  path NULL = stdout. */
+int  telr_write_paf(const telr_result *r, const char *const *qnames, const char *const *tnames, int with_cigar,
+                    const char *path, int append);
+#define TELR_SAM_MD          0x1   /* --MD */
+#define TELR_SAM_CS          0x2   /* --cs */
+#define TELR_SAM_SOFTCLIP    0x4   /* -Y  */
+#define TELR_SAM_NO_UNMAPPED 0x8
+/* sequences are needed for SEQ, NM, MD and cs: concatenated ASCII + offsets + lengths as in telr_seqset_create.
+ * rg_id NULL = no @RG line / RG tag (minimap2 sites); NGMLR site passes --rg-id/--rg-sm/--rg-lb. */
+int  telr_write_sam(const telr_result *r, int32_t n_queries, const char *const *qnames, const char *q_ascii, const int64_t *q_off,
+                    const int32_t *q_len, int32_t n_targets, const char *const *tnames, const char *t_ascii, const int64_t *t_off,
+                    const int32_t *t_len, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb,
+                    const char *pg_line, const char *path);
+
 /* ---- fused "samtools depth -aa -r | median" (D) --------------------------------
  * For n_iv intervals (target id, 0-based start, 0-based INCLUSIVE end — the
  * reference feeds 0-based numbers into samtools' 1-based inclusive region

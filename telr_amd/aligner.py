@@ -157,6 +157,32 @@ class Index:
         finally:
             self.free_raw(r)
 
+    # ---- text emitters (the reference's own boundary: PAF / SAM files) -----------------------
+    @staticmethod
+    def _cstr_array(names):
+        arr = (C.c_char_p * max(1, len(names)))()
+        for i, n in enumerate(names):
+            arr[i] = n.encode() if isinstance(n, str) else bytes(n)
+        return arr
+
+    def write_paf(self, r, qnames, tnames, path, with_cigar=True, append=False):
+        qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
+        self.eng._chk(self.eng.L.telr_write_paf(r, qa, ta, 1 if with_cigar else 0, path.encode(), 1 if append else 0), "telr_write_paf")
+
+    def write_sam(self, r, qnames, queries, tnames, targets, path, md=True, cs=True, softclip=True, rg=None, cmdline="telr_map"):
+        """queries / targets: lists of sequences (str) or (buf, off, len) triples as given to seqset()."""
+        qb, qo, ql = queries if isinstance(queries, tuple) else concat(queries)
+        tb, to, tl = targets if isinstance(targets, tuple) else concat(targets)
+        qb = np.ascontiguousarray(qb, np.uint8); tb = np.ascontiguousarray(tb, np.uint8)
+        qo = np.ascontiguousarray(qo, np.int64); to = np.ascontiguousarray(to, np.int64)
+        ql = np.ascontiguousarray(ql, np.int32); tl = np.ascontiguousarray(tl, np.int32)
+        qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
+        flags = (1 if md else 0) | (2 if cs else 0) | (4 if softclip else 0)
+        rg_id, rg_sm, rg_lb = (None, None, None) if rg is None else tuple(x.encode() for x in rg)
+        self.eng._chk(self.eng.L.telr_write_sam(r, len(ql), qa, qb.ctypes.data, qo.ctypes.data, ql.ctypes.data, len(tl), ta,
+                                                tb.ctypes.data, to.ctypes.data, tl.ctypes.data, flags, rg_id, rg_sm, rg_lb,
+                                                cmdline.encode(), path.encode()), "telr_write_sam")
+
     def depth_medians(self, r, iv_tid, iv_s, iv_e):
         """Medians over 0-based inclusive intervals, from a raw result handle."""
         tl = self.targets.len

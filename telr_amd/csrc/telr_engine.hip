@@ -1270,3 +1270,168 @@ extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n
     HIPCHK(hipStreamSynchronize(st));
     return TELR_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// PAF / SAM emitters (host).  The reference's call sites consume PAF columns 0,1,4,5,7,8,9,10,11
+// (TELR_liftover.py:215-240,356-380; TELR_te.py:89-95,136-142) and SAM records with NM/MD/AS/SA/cs
+// (hand-off H1: Sniffles, samtools depth, pysam; docs/02_Usage.md:76).
+struct SeqView { const char *ascii; const int64_t *off; const int32_t *len; };
+static const char COMP_TAB[256] = {
+#define C16 'N','N','N','N','N','N','N','N','N','N','N','N','N','N','N','N'
+    C16, C16, C16, C16,
+    'N','T','N','G','N','N','N','C','N','N','N','N','N','N','N','N','N','N','N','N','A','A','N','N','N','N','N','N','N','N','N','N',
+    'N','t','N','g','N','N','N','c','N','N','N','N','N','N','N','N','N','N','N','N','a','a','N','N','N','N','N','N','N','N','N','N',
+    C16, C16, C16, C16, C16, C16, C16, C16
+};
+static inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+static void cigar_text(const uint32_t *cg, int n, int clip5, int clip3, char clipc, std::string &out)
+{
+    char buf[24];
+    if (clip5 > 0) { snprintf(buf, sizeof(buf), "%d%c", clip5, clipc); out += buf; }
+    for (int i = 0; i < n; ++i) { snprintf(buf, sizeof(buf), "%u%c", cg[i] >> 4, "MID"[cg[i] & 0xf]); out += buf; }
+    if (clip3 > 0) { snprintf(buf, sizeof(buf), "%d%c", clip3, clipc); out += buf; }
+}
+
+extern "C" int telr_write_paf(const telr_result *r, const char *const *qnames, const char *const *tnames, int with_cigar,
+                              const char *path, int append)
+{
+    if (!r || !qnames || !tnames) return TELR_E_ARG;
+    FILE *f = path ? fopen(path, append ? "a" : "w") : stdout;
+    if (!f) return TELR_E_ARG;
+    std::string line;
+    for (const telr_aln &a : r->alns) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s\t%d\t%d\t%d\t%c\t%s\t%d\t%d\t%d\t%d\t%d\t%d\tNM:i:%d\tAS:i:%d\ttp:A:%c\tcm:i:%d\ts1:i:%d",
+                 qnames[a.qid], a.qlen, a.qs, a.qe, (a.flags & TELR_F_REV) ? '-' : '+', tnames[a.tid], a.tlen, a.ts, a.te, a.mlen, a.blen, a.mapq,
+                 a.blen - a.mlen, a.dp_score, (a.flags & TELR_F_SECONDARY) ? 'S' : 'P', a.cnt, a.score);
+        line = buf;
+        if (!(a.flags & TELR_F_SECONDARY)) { snprintf(buf, sizeof(buf), "\ts2:i:%d", a.subsc); line += buf; }
+        if (with_cigar && a.n_cigar > 0) { line += "\tcg:Z:"; cigar_text(r->cig + a.cigar_off, a.n_cigar, 0, 0, 'S', line); }
+        line += '\n';
+        fwrite(line.data(), 1, line.size(), f);
+    }
+    if (path) fclose(f);
+    return TELR_OK;
+}
+
+extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const char *const *qnames, const char *q_ascii, const int64_t *q_off,
+                              const int32_t *q_len, int32_t n_targets, const char *const *tnames, const char *t_ascii, const int64_t *t_off,
+                              const int32_t *t_len, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb,
+                              const char *pg_line, const char *path)
+{
+    if (!r || !qnames || !q_ascii || !q_off || !q_len || !tnames || !t_ascii || !t_off || !t_len) return TELR_E_ARG;
+    FILE *f = path ? fopen(path, "w") : stdout;
+    if (!f) return TELR_E_ARG;
+    fprintf(f, "@HD\tVN:1.6\tSO:unsorted\tGO:query\n");
+    for (int t = 0; t < n_targets; ++t) fprintf(f, "@SQ\tSN:%s\tLN:%d\n", tnames[t], t_len[t]);
+    if (rg_id) fprintf(f, "@RG\tID:%s\tSM:%s\tLB:%s\n", rg_id, rg_sm ? rg_sm : rg_id, rg_lb ? rg_lb : "lib");
+    fprintf(f, "@PG\tID:telr_amd\tPN:telr_amd\tVN:0.1.0\tCL:%s\n", pg_line ? pg_line : "telr_map");
+    // records are sorted by (qid, rank); group per query
+    const size_t n = r->alns.size();
+    size_t i = 0;
+    std::string seq, rc, line, md, cs, sa;
+    for (int q = 0; q < n_queries; ++q) {
+        size_t j = i;
+        while (j < n && r->alns[j].qid == q) ++j;
+        const char *qs = q_ascii + q_off[q]; const int ql = q_len[q];
+        if (j == i) {
+            if (!(flags & TELR_SAM_NO_UNMAPPED)) {
+                fprintf(f, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t", qnames[q]);
+                fwrite(qs, 1, ql, f);
+                fprintf(f, "\t*");
+                if (rg_id) fprintf(f, "\tRG:Z:%s", rg_id);
+                fputc('\n', f);
+            }
+            continue;
+        }
+        rc.resize(ql);
+        for (int x = 0; x < ql; ++x) rc[x] = COMP_TAB[(unsigned char)qs[ql - 1 - x]];
+        for (size_t k = i; k < j; ++k) {
+            const telr_aln &a = r->alns[k];
+            const bool rev = (a.flags & TELR_F_REV) != 0, sec = (a.flags & TELR_F_SECONDARY) != 0, sup = (a.flags & TELR_F_SUPPL) != 0;
+            const char *qstr = rev ? rc.data() : qs;                 // query on the alignment strand
+            const int clip5 = rev ? ql - a.qe : a.qs, clip3 = rev ? a.qs : ql - a.qe;
+            const uint32_t *cg = r->cig + a.cigar_off;
+            const char *ts = t_ascii + t_off[a.tid];
+            // NM / MD / cs from the CIGAR walk
+            int nm = 0, qi = clip5, ti = a.ts, run = 0;
+            md.clear(); cs.clear();
+            char buf[32];
+            for (int z = 0; z < a.n_cigar; ++z) {
+                const int op = cg[z] & 0xf, l = (int)(cg[z] >> 4);
+                if (op == 0) {
+                    int csrun = 0;
+                    for (int x = 0; x < l; ++x) {
+                        const char qc = up(qstr[qi + x]), tc = up(ts[ti + x]);
+                        if (qc == tc && tc != 'N') { ++run; ++csrun; }
+                        else {
+                            ++nm;
+                            if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d%c", run, tc); md += buf; }
+                            run = 0;
+                            if (flags & TELR_SAM_CS) { if (csrun) { snprintf(buf, sizeof(buf), ":%d", csrun); cs += buf; csrun = 0; } cs += '*'; cs += (char)(tc | 32); cs += (char)(qc | 32); }
+                        }
+                    }
+                    if ((flags & TELR_SAM_CS) && csrun) { snprintf(buf, sizeof(buf), ":%d", csrun); cs += buf; }
+                    qi += l; ti += l;
+                } else if (op == 1) {
+                    nm += l;
+                    if (flags & TELR_SAM_CS) { cs += '+'; for (int x = 0; x < l; ++x) cs += (char)(qstr[qi + x] | 32); }
+                    qi += l;
+                } else {
+                    nm += l;
+                    if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d^", run); md += buf; for (int x = 0; x < l; ++x) md += up(ts[ti + x]); run = 0; }
+                    if (flags & TELR_SAM_CS) { cs += '-'; for (int x = 0; x < l; ++x) cs += (char)(ts[ti + x] | 32); }
+                    ti += l;
+                }
+            }
+            if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d", run); md += buf; }
+            const bool hard = sec || (sup && !(flags & TELR_SAM_SOFTCLIP));
+            int fl = (rev ? 0x10 : 0) | (sec ? 0x100 : 0) | (sup ? 0x800 : 0);
+            line.clear();
+            line += qnames[q];
+            snprintf(buf, sizeof(buf), "\t%d\t", fl); line += buf;
+            line += tnames[a.tid];
+            snprintf(buf, sizeof(buf), "\t%d\t%d\t", a.ts + 1, a.mapq); line += buf;
+            if (a.n_cigar > 0) cigar_text(cg, a.n_cigar, clip5, clip3, hard ? 'H' : 'S', line); else line += '*';
+            line += "\t*\t0\t0\t";
+            if (sec) line += '*';
+            else if (hard) line.append(qstr + clip5, (size_t)(ql - clip5 - clip3));
+            else line.append(qstr, (size_t)ql);
+            line += "\t*";
+            snprintf(buf, sizeof(buf), "\tNM:i:%d\tAS:i:%d", nm, a.dp_score); line += buf;
+            if (flags & TELR_SAM_MD) { line += "\tMD:Z:"; line += md; }
+            if (flags & TELR_SAM_CS) { line += "\tcs:Z:"; line += cs; }
+            // SA: the other primary / supplementary records of this read
+            if (!sec) {
+                sa.clear();
+                for (size_t k2 = i; k2 < j; ++k2) {
+                    const telr_aln &b = r->alns[k2];
+                    if (k2 == k || (b.flags & TELR_F_SECONDARY)) continue;
+                    const bool brev = (b.flags & TELR_F_REV) != 0;
+                    const int b5 = brev ? ql - b.qe : b.qs, b3 = brev ? b.qs : ql - b.qe;
+                    int nI = 0, nD = 0;
+                    for (int z = 0; z < b.n_cigar; ++z) { uint32_t c = r->cig[b.cigar_off + z]; if ((c & 0xf) == 1) nI += c >> 4; else if ((c & 0xf) == 2) nD += c >> 4; }
+                    char sb[256];
+                    const int mlen_q = (b.qe - b.qs);
+                    snprintf(sb, sizeof(sb), "%s,%d,%c,", tnames[b.tid], b.ts + 1, brev ? '-' : '+'); sa += sb;
+                    if (b5) { snprintf(sb, sizeof(sb), "%dS", b5); sa += sb; }
+                    snprintf(sb, sizeof(sb), "%dM", mlen_q - nI); sa += sb;
+                    if (nI) { snprintf(sb, sizeof(sb), "%dI", nI); sa += sb; }
+                    if (nD) { snprintf(sb, sizeof(sb), "%dD", nD); sa += sb; }
+                    if (b3) { snprintf(sb, sizeof(sb), "%dS", b3); sa += sb; }
+                    snprintf(sb, sizeof(sb), ",%d,%d;", b.mapq, b.blen - b.mlen); sa += sb;
+                }
+                if (!sa.empty()) { line += "\tSA:Z:"; line += sa; }
+            }
+            snprintf(buf, sizeof(buf), "\ttp:A:%c\tcm:i:%d\ts1:i:%d", sec ? 'S' : 'P', a.cnt, a.score); line += buf;
+            if (!sec) { snprintf(buf, sizeof(buf), "\ts2:i:%d", a.subsc); line += buf; }
+            if (rg_id) { line += "\tRG:Z:"; line += rg_id; }
+            line += '\n';
+            fwrite(line.data(), 1, line.size(), f);
+        }
+        i = j;
+    }
+    if (path) fclose(f);
+    return TELR_OK;
+}

@@ -219,3 +219,80 @@ def test_synthetic_clr_hpc(engine):
     res, _ = compare_all(engine, genome, reads, io, mo)
     prim = res.alns[(res.alns["flags"] & 1) != 0]
     assert len(prim) >= 38
+
+
+def _revcomp(s):
+    return s[::-1].translate(str.maketrans("ACGTNacgtn", "TGCANtgcan"))
+
+
+def test_sam_and_paf_emitters(engine, data_dir, tmp_path):
+    """SAM records must be self-consistent: SEQ + CIGAR + MD reproduce the reference bases, cs agrees with MD,
+    NM = mismatches + gap bases, clip lengths add up; PAF columns equal the record fields."""
+    import re
+    tn, ts = read_fasta(data_dir + "/ref_38kb.fasta")
+    qn, qs = read_fasta(data_dir + "/reads.fasta")
+    io, mo = preset("map-ont")
+    ix = engine.index(ts, io)
+    r = ix.map_raw(qs + ["ACGTACGTAACC" * 3], mo)
+    try:
+        res = ix.result_arrays(r)
+        sam, paf = str(tmp_path / "o.sam"), str(tmp_path / "o.paf")
+        names = qn + ["unmapped_read"]
+        ix.write_sam(r, names, qs + ["ACGTACGTAACC" * 3], tn, ts, sam, rg=("s1", "s1", "ont"))
+        ix.write_paf(r, names, tn, paf)
+    finally:
+        ix.free_raw(r)
+    recs = [l.rstrip("\n").split("\t") for l in open(sam) if not l.startswith("@")]
+    hdr = [l for l in open(sam) if l.startswith("@")]
+    assert any(l.startswith("@SQ\tSN:%s\tLN:%d" % (tn[0], len(ts[0]))) for l in hdr) and any(l.startswith("@RG\tID:s1") for l in hdr)
+    assert len(recs) == len(res.alns) + 1 and recs[-1][1] == "4"
+    ref = ts[0].upper()
+    n_checked = 0
+    for f, a in zip(recs, res.alns):
+        flag, pos, cigar, seq = int(f[1]), int(f[3]) - 1, f[5], f[9]
+        tags = {t[:2]: t[5:] for t in f[11:]}
+        assert pos == a["ts"] and f[2] == tn[a["tid"]] and int(f[4]) == a["mapq"]
+        assert bool(flag & 0x10) == bool(a["flags"] & 8) and bool(flag & 0x100) == bool(a["flags"] & 2) and bool(flag & 0x800) == bool(a["flags"] & 4)
+        ops = re.findall(r"(\d+)([MIDSH])", cigar)
+        qlen_c = sum(int(n) for n, o in ops if o in "MIS")
+        if seq != "*":
+            assert qlen_c == len(seq)
+        assert sum(int(n) for n, o in ops if o in "MISH") == a["qlen"]
+        assert sum(int(n) for n, o in ops if o in "MD") == a["te"] - a["ts"]
+        assert int(tags["AS"]) == a["dp_score"] and tags["RG"] == "s1"
+        if seq == "*":
+            continue
+        # rebuild the reference from SEQ + CIGAR + MD
+        qi = 0; aligned_q = []
+        for n, o in ops:
+            n = int(n)
+            if o == "S":
+                qi += n
+            elif o == "M":
+                aligned_q.append(seq[qi:qi + n]); qi += n
+            elif o == "I":
+                qi += n
+        mseq = "".join(aligned_q).upper()
+        out, mi = [], 0
+        for m in re.finditer(r"(\d+)|(\^[A-Z]+)|([A-Z])", tags["MD"]):
+            if m.group(1):
+                k = int(m.group(1)); out.append(mseq[mi:mi + k]); mi += k
+            elif m.group(2):
+                out.append(m.group(2)[1:])
+            else:
+                out.append(m.group(3)); mi += 1
+        assert "".join(out) == ref[a["ts"]:a["te"]], "MD does not rebuild the reference for " + f[0]
+        nm = sum(int(n) for n, o in ops if o in "ID") + len(re.findall(r"(?<![\^A-Z])[A-Z]", re.sub(r"\^[A-Z]+", "^", tags["MD"])))
+        assert int(tags["NM"]) == nm == a["blen"] - a["mlen"]
+        # cs: total reference / query lengths
+        cs_t = sum(int(x) for x in re.findall(r":(\d+)", tags["cs"])) + len(re.findall(r"\*", tags["cs"])) + sum(len(x) for x in re.findall(r"-([a-z]+)", tags["cs"]))
+        assert cs_t == a["te"] - a["ts"]
+        n_checked += 1
+    assert n_checked >= 18
+    # supplementary records carry SA tags pointing at each other
+    assert any("SA" in {t[:2] for t in f[11:]} for f in recs[:-1])
+    plines = [l.rstrip("\n").split("\t") for l in open(paf)]
+    assert len(plines) == len(res.alns)
+    for p, a in zip(plines, res.alns):
+        assert [int(p[i]) for i in (1, 2, 3, 6, 7, 8, 9, 10, 11)] == [a[k] for k in ("qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "mapq")]
+        assert p[4] == ("-" if a["flags"] & 8 else "+") and p[5] == tn[a["tid"]]

@@ -173,6 +173,13 @@ int  telr_write_sam(const telr_result *r, int32_t n_queries, const char *const *
                     const int32_t *t_len, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb,
                     const char *pg_line, const char *path);
 
+/* Coordinate-sorted BAM (+ .bai when write_index != 0): replaces `samtools sort -o BAM SAM; samtools index BAM`
+ * (src/telr/TELR_alignment.py:103-114).  Same arguments as telr_write_sam; level = zlib level (0 -> 1). */
+int  telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *qnames, const char *q_ascii, const int64_t *q_off,
+                    const int32_t *q_len, int32_t n_targets, const char *const *tnames, const char *t_ascii, const int64_t *t_off,
+                    const int32_t *t_len, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb,
+                    const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);
+
 /* ---- fused "samtools depth -aa -r | median" (D) --------------------------------
  * For n_iv intervals (target id, 0-based start, 0-based INCLUSIVE end — the
  * reference feeds 0-based numbers into samtools' 1-based inclusive region

@@ -183,6 +183,21 @@ class Index:
                                                 tb.ctypes.data, to.ctypes.data, tl.ctypes.data, flags, rg_id, rg_sm, rg_lb,
                                                 cmdline.encode(), path.encode()), "telr_write_sam")
 
+    def write_bam(self, r, qnames, queries, tnames, targets, path, md=True, cs=True, softclip=True, rg=None, cmdline="telr_map",
+                  index=True, level=1):
+        """coordinate-sorted BAM + .bai (samtools sort + index, TELR_alignment.py:103-114)"""
+        qb, qo, ql = queries if isinstance(queries, tuple) else concat(queries)
+        tb, to, tl = targets if isinstance(targets, tuple) else concat(targets)
+        qb = np.ascontiguousarray(qb, np.uint8); tb = np.ascontiguousarray(tb, np.uint8)
+        qo = np.ascontiguousarray(qo, np.int64); to = np.ascontiguousarray(to, np.int64)
+        ql = np.ascontiguousarray(ql, np.int32); tl = np.ascontiguousarray(tl, np.int32)
+        qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
+        flags = (1 if md else 0) | (2 if cs else 0) | (4 if softclip else 0)
+        rg_id, rg_sm, rg_lb = (None, None, None) if rg is None else tuple(x.encode() for x in rg)
+        self.eng._chk(self.eng.L.telr_write_bam(r, len(ql), qa, qb.ctypes.data, qo.ctypes.data, ql.ctypes.data, len(tl), ta,
+                                                tb.ctypes.data, to.ctypes.data, tl.ctypes.data, flags, rg_id, rg_sm, rg_lb,
+                                                cmdline.encode(), path.encode(), 1 if index else 0, level), "telr_write_bam")
+
     def depth_medians(self, r, iv_tid, iv_s, iv_e):
         """Medians over 0-based inclusive intervals, from a raw result handle."""
         tl = self.targets.len

@@ -22,7 +22,7 @@ def build(force=False, verbose=False):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", SO] + \
-          os.environ.get("TELR_EXTRA_FLAGS", "").split() + [os.path.join(SRC, s) for s in SOURCES]
+          os.environ.get("TELR_EXTRA_FLAGS", "").split() + [os.path.join(SRC, s) for s in SOURCES] + ["-lz"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

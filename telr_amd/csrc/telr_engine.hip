@@ -1435,3 +1435,267 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
     if (path) fclose(f);
     return TELR_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Coordinate-sorted BAM + BAI (replaces `samtools sort -o BAM SAM; samtools index BAM`,
+// reference src/telr/TELR_alignment.py:103-114; hand-off H1 to Sniffles / pysam).
+#include <zlib.h>
+static inline int reg2bin(int64_t beg, int64_t end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+static inline void put32(std::string &s, uint32_t v) { s.append((const char*)&v, 4); }
+static inline void put16(std::string &s, uint16_t v) { s.append((const char*)&v, 2); }
+static inline uint8_t nt16(char c)
+{
+    switch (c) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': return 8; default: return 15; }
+}
+static bool bgzf_block(const char *src, size_t n, int level, std::string &out)
+{
+    uLong bound = compressBound((uLong)n) + 64;
+    out.resize(18 + bound + 8);
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = (Bytef*)src; zs.avail_in = (uInt)n; zs.next_out = (Bytef*)&out[18]; zs.avail_out = (uInt)bound;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); return false; }
+    size_t clen = zs.total_out; deflateEnd(&zs);
+    static const uint8_t hdr[12] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0 };
+    memcpy(&out[0], hdr, 12);
+    out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+    uint16_t bsize = (uint16_t)(clen + 25);
+    memcpy(&out[16], &bsize, 2);
+    uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)src, (uInt)n), isize = (uint32_t)n;
+    memcpy(&out[18 + clen], &crc, 4); memcpy(&out[18 + clen + 4], &isize, 4);
+    out.resize(18 + clen + 8);
+    return true;
+}
+
+extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *qnames, const char *q_ascii, const int64_t *q_off,
+                              const int32_t *q_len, int32_t n_targets, const char *const *tnames, const char *t_ascii, const int64_t *t_off,
+                              const int32_t *t_len, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb,
+                              const char *pg_line, const char *bam_path, int32_t write_index, int32_t level)
+{
+    if (!r || !qnames || !q_ascii || !q_off || !q_len || !tnames || !t_ascii || !t_off || !t_len || !bam_path) return TELR_E_ARG;
+    const size_t n = r->alns.size();
+    // --- 1. binary records (one per alignment + one per unmapped read), built in parallel over queries
+    std::vector<size_t> qfirst((size_t)n_queries + 1, 0);
+    { size_t i = 0; for (int q = 0; q < n_queries; ++q) { qfirst[q] = i; while (i < n && r->alns[i].qid == q) ++i; } qfirst[n_queries] = i; }
+    std::vector<int> q_unmapped;
+    for (int q = 0; q < n_queries; ++q) if (qfirst[q] == qfirst[q + 1] && !(flags & TELR_SAM_NO_UNMAPPED)) q_unmapped.push_back(q);
+    const size_t nrec = n + q_unmapped.size();
+    std::vector<std::string> recs(nrec);
+    std::vector<int64_t> key(nrec);          // (refID+1)<<32 | pos ; unmapped last
+    const int NT = host_threads();
+    parallel_ranges(NT, n_queries, [&](int, int qa, int qb) {
+        std::string rc, md, cs, sa, tagbuf;
+        char buf[64];
+        for (int q = qa; q < qb; ++q) {
+            const size_t i0 = qfirst[q], i1 = qfirst[q + 1];
+            if (i0 == i1) continue;
+            const char *qs = q_ascii + q_off[q]; const int ql = q_len[q];
+            rc.resize(ql);
+            for (int x = 0; x < ql; ++x) rc[x] = COMP_TAB[(unsigned char)qs[ql - 1 - x]];
+            for (size_t k = i0; k < i1; ++k) {
+                const telr_aln &a = r->alns[k];
+                const bool rev = (a.flags & TELR_F_REV) != 0, sec = (a.flags & TELR_F_SECONDARY) != 0, sup = (a.flags & TELR_F_SUPPL) != 0;
+                const char *qstr = rev ? rc.data() : qs;
+                const int clip5 = rev ? ql - a.qe : a.qs, clip3 = rev ? a.qs : ql - a.qe;
+                const uint32_t *cg = r->cig + a.cigar_off;
+                const char *ts = t_ascii + t_off[a.tid];
+                int nm = 0, qi = clip5, ti = a.ts, run = 0;
+                md.clear(); cs.clear();
+                for (int z = 0; z < a.n_cigar; ++z) {
+                    const int op = cg[z] & 0xf, l = (int)(cg[z] >> 4);
+                    if (op == 0) {
+                        int csrun = 0;
+                        for (int x = 0; x < l; ++x) {
+                            const char qc = up(qstr[qi + x]), tc = up(ts[ti + x]);
+                            if (qc == tc && tc != 'N') { ++run; ++csrun; }
+                            else {
+                                ++nm;
+                                if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d%c", run, tc); md += buf; }
+                                run = 0;
+                                if (flags & TELR_SAM_CS) { if (csrun) { snprintf(buf, sizeof(buf), ":%d", csrun); cs += buf; csrun = 0; } cs += '*'; cs += (char)(tc | 32); cs += (char)(qc | 32); }
+                            }
+                        }
+                        if ((flags & TELR_SAM_CS) && csrun) { snprintf(buf, sizeof(buf), ":%d", csrun); cs += buf; }
+                        qi += l; ti += l;
+                    } else if (op == 1) {
+                        nm += l;
+                        if (flags & TELR_SAM_CS) { cs += '+'; for (int x = 0; x < l; ++x) cs += (char)(qstr[qi + x] | 32); }
+                        qi += l;
+                    } else {
+                        nm += l;
+                        if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d^", run); md += buf; for (int x = 0; x < l; ++x) md += up(ts[ti + x]); run = 0; }
+                        if (flags & TELR_SAM_CS) { cs += '-'; for (int x = 0; x < l; ++x) cs += (char)(ts[ti + x] | 32); }
+                        ti += l;
+                    }
+                }
+                if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d", run); md += buf; }
+                const bool hard = sec || (sup && !(flags & TELR_SAM_SOFTCLIP));
+                const int fl = (rev ? 0x10 : 0) | (sec ? 0x100 : 0) | (sup ? 0x800 : 0);
+                const int seq_lo = sec ? 0 : (hard ? clip5 : 0), seq_hi = sec ? 0 : (hard ? ql - clip3 : ql), l_seq = seq_hi - seq_lo;
+                std::vector<uint32_t> bc;
+                if (clip5 > 0) bc.push_back((uint32_t)clip5 << 4 | (hard ? 5u : 4u));
+                for (int z = 0; z < a.n_cigar; ++z) bc.push_back(cg[z]);          // M=0 I=1 D=2 as in BAM
+                if (clip3 > 0) bc.push_back((uint32_t)clip3 << 4 | (hard ? 5u : 4u));
+                const bool long_cigar = bc.size() > 65535;
+                tagbuf.clear();
+                auto tag_i = [&](const char *t, int32_t v) { tagbuf += t; tagbuf += 'i'; tagbuf.append((const char*)&v, 4); };
+                auto tag_z = [&](const char *t, const std::string &v) { tagbuf += t; tagbuf += 'Z'; tagbuf += v; tagbuf += '\0'; };
+                tag_i("NM", nm); tag_i("AS", a.dp_score);
+                if (flags & TELR_SAM_MD) tag_z("MD", md);
+                if (flags & TELR_SAM_CS) tag_z("cs", cs);
+                if (!sec) {
+                    sa.clear();
+                    for (size_t k2 = i0; k2 < i1; ++k2) {
+                        const telr_aln &b = r->alns[k2];
+                        if (k2 == k || (b.flags & TELR_F_SECONDARY)) continue;
+                        const bool brev = (b.flags & TELR_F_REV) != 0;
+                        const int b5 = brev ? ql - b.qe : b.qs, b3 = brev ? b.qs : ql - b.qe;
+                        int nI = 0, nD = 0;
+                        for (int z = 0; z < b.n_cigar; ++z) { uint32_t c = r->cig[b.cigar_off + z]; if ((c & 0xf) == 1) nI += c >> 4; else if ((c & 0xf) == 2) nD += c >> 4; }
+                        char sb[256];
+                        snprintf(sb, sizeof(sb), "%s,%d,%c,", tnames[b.tid], b.ts + 1, brev ? '-' : '+'); sa += sb;
+                        if (b5) { snprintf(sb, sizeof(sb), "%dS", b5); sa += sb; }
+                        snprintf(sb, sizeof(sb), "%dM", (b.qe - b.qs) - nI); sa += sb;
+                        if (nI) { snprintf(sb, sizeof(sb), "%dI", nI); sa += sb; }
+                        if (nD) { snprintf(sb, sizeof(sb), "%dD", nD); sa += sb; }
+                        if (b3) { snprintf(sb, sizeof(sb), "%dS", b3); sa += sb; }
+                        snprintf(sb, sizeof(sb), ",%d,%d;", b.mapq, b.blen - b.mlen); sa += sb;
+                    }
+                    if (!sa.empty()) tag_z("SA", sa);
+                }
+                tagbuf += "tpA"; tagbuf += sec ? 'S' : 'P';
+                tag_i("cm", a.cnt); tag_i("s1", a.score);
+                if (!sec) tag_i("s2", a.subsc);
+                if (rg_id) tag_z("RG", rg_id);
+                if (long_cigar) {       // -L: real CIGAR in a CG:B,I tag, placeholder <l_seq>S<ref_len>N in the record
+                    tagbuf += "CGBI"; uint32_t cnt = (uint32_t)bc.size(); tagbuf.append((const char*)&cnt, 4); tagbuf.append((const char*)bc.data(), bc.size() * 4);
+                }
+                std::string &o = recs[k];
+                const size_t l_name = strlen(qnames[q]) + 1;
+                const uint32_t n_cig = long_cigar ? 2u : (uint32_t)bc.size();
+                o.reserve(36 + l_name + n_cig * 4 + (l_seq + 1) / 2 + l_seq + tagbuf.size());
+                put32(o, 0);                                         // block_size, patched below
+                put32(o, (uint32_t)a.tid); put32(o, (uint32_t)a.ts);
+                o += (char)(uint8_t)l_name; o += (char)(uint8_t)a.mapq; put16(o, (uint16_t)reg2bin(a.ts, a.te > a.ts ? a.te : a.ts + 1));
+                put16(o, (uint16_t)n_cig); put16(o, (uint16_t)fl);
+                put32(o, (uint32_t)l_seq); put32(o, (uint32_t)-1); put32(o, (uint32_t)-1); put32(o, 0);
+                o.append(qnames[q], l_name);
+                if (long_cigar) { put32(o, (uint32_t)l_seq << 4 | 4u); put32(o, (uint32_t)(a.te - a.ts) << 4 | 3u); }
+                else o.append((const char*)bc.data(), bc.size() * 4);
+                for (int x = 0; x < l_seq; x += 2) { uint8_t hi = nt16(qstr[seq_lo + x]), lo2 = x + 1 < l_seq ? nt16(qstr[seq_lo + x + 1]) : 0; o += (char)(hi << 4 | lo2); }
+                o.append((size_t)l_seq, (char)0xff);
+                o += tagbuf;
+                uint32_t bs = (uint32_t)o.size() - 4; memcpy(&o[0], &bs, 4);
+                key[k] = ((int64_t)(a.tid + 1) << 32) | (uint32_t)a.ts;
+            }
+        }
+    });
+    for (size_t u = 0; u < q_unmapped.size(); ++u) {
+        const int q = q_unmapped[u]; const char *qs = q_ascii + q_off[q]; const int ql = q_len[q];
+        std::string &o = recs[n + u];
+        const size_t l_name = strlen(qnames[q]) + 1;
+        put32(o, 0); put32(o, (uint32_t)-1); put32(o, (uint32_t)-1);
+        o += (char)(uint8_t)l_name; o += (char)0; put16(o, 4680); put16(o, 0); put16(o, 4);
+        put32(o, (uint32_t)ql); put32(o, (uint32_t)-1); put32(o, (uint32_t)-1); put32(o, 0);
+        o.append(qnames[q], l_name);
+        for (int x = 0; x < ql; x += 2) { uint8_t hi = nt16(qs[x]), lo2 = x + 1 < ql ? nt16(qs[x + 1]) : 0; o += (char)(hi << 4 | lo2); }
+        o.append((size_t)ql, (char)0xff);
+        if (rg_id) { o += "RGZ"; o += rg_id; o += '\0'; }
+        uint32_t bs = (uint32_t)o.size() - 4; memcpy(&o[0], &bs, 4);
+        key[n + u] = INT64_MAX;
+    }
+    // --- 2. coordinate sort (stable)
+    std::vector<uint32_t> order(nrec);
+    for (size_t i = 0; i < nrec; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key[x] < key[y]; });
+    // --- 3. uncompressed stream: header + records, cut into BGZF blocks of <= 65280 bytes
+    std::string head;
+    {
+        std::string text = "@HD\tVN:1.6\tSO:coordinate\n";
+        char b[512];
+        for (int t = 0; t < n_targets; ++t) { snprintf(b, sizeof(b), "@SQ\tSN:%s\tLN:%d\n", tnames[t], t_len[t]); text += b; }
+        if (rg_id) { snprintf(b, sizeof(b), "@RG\tID:%s\tSM:%s\tLB:%s\n", rg_id, rg_sm ? rg_sm : rg_id, rg_lb ? rg_lb : "lib"); text += b; }
+        text += "@PG\tID:telr_amd\tPN:telr_amd\tVN:0.1.0\tCL:"; text += pg_line ? pg_line : "telr_map"; text += "\n";
+        head += "BAM\1"; put32(head, (uint32_t)text.size()); head += text; put32(head, (uint32_t)n_targets);
+        for (int t = 0; t < n_targets; ++t) { uint32_t ln = (uint32_t)strlen(tnames[t]) + 1; put32(head, ln); head.append(tnames[t], ln); put32(head, (uint32_t)t_len[t]); }
+    }
+    const size_t BLK = 65280;
+    std::vector<uint64_t> ustart(nrec + 1);        // uncompressed offset of every record (sorted order)
+    uint64_t upos = head.size();
+    for (size_t i = 0; i < nrec; ++i) { ustart[i] = upos; upos += recs[order[i]].size(); }
+    ustart[nrec] = upos;
+    const uint64_t utotal = upos;
+    std::string ubuf; ubuf.resize(utotal);
+    memcpy(&ubuf[0], head.data(), head.size());
+    parallel_ranges(NT, (int)nrec, [&](int, int a0, int a1) { for (int i = a0; i < a1; ++i) memcpy(&ubuf[ustart[i]], recs[order[i]].data(), recs[order[i]].size()); });
+    const size_t nblk = (size_t)((utotal + BLK - 1) / BLK);
+    std::vector<std::string> cblk(nblk);
+    bool ok = true;
+    parallel_ranges(NT, (int)nblk, [&](int, int b0, int b1) {
+        for (int b = b0; b < b1; ++b) { size_t o = (size_t)b * BLK, l = std::min(BLK, (size_t)utotal - o); if (!bgzf_block(&ubuf[o], l, level > 0 ? level : 1, cblk[b])) ok = false; }
+    });
+    if (!ok) return TELR_E_NOMEM;
+    std::vector<uint64_t> coff(nblk + 1, 0);
+    for (size_t b = 0; b < nblk; ++b) coff[b + 1] = coff[b] + cblk[b].size();
+    FILE *f = fopen(bam_path, "wb");
+    if (!f) return TELR_E_ARG;
+    for (size_t b = 0; b < nblk; ++b) fwrite(cblk[b].data(), 1, cblk[b].size(), f);
+    static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    fwrite(eof_blk, 1, 28, f);
+    fclose(f);
+    if (!write_index) return TELR_OK;
+    // --- 4. BAI
+    auto voff = [&](uint64_t u) { size_t b = (size_t)(u / BLK); if (b >= nblk) return (uint64_t)(coff[nblk] << 16); return (uint64_t)(coff[b] << 16 | (u - (uint64_t)b * BLK)); };
+    std::string bai = "BAI\1"; put32(bai, (uint32_t)n_targets);
+    size_t i = 0;
+    uint64_t n_no_coor = q_unmapped.size();
+    for (int t = 0; t < n_targets; ++t) {
+        std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+        const int n_lin = (t_len[t] >> 14) + 1;
+        std::vector<uint64_t> lin(n_lin, 0);
+        int max_lin = 0;
+        uint64_t ref_beg = 0, ref_end = 0, n_mapped = 0;
+        bool any = false;
+        while (i < nrec && key[order[i]] != INT64_MAX && (int)((key[order[i]] >> 32) - 1) == t) {
+            const telr_aln &a = r->alns[order[i]];
+            const uint64_t vb = voff(ustart[i]), ve = voff(ustart[i + 1]);
+            const uint32_t bin = (uint32_t)reg2bin(a.ts, a.te > a.ts ? a.te : a.ts + 1);
+            auto &ch = bins[bin];
+            if (!ch.empty() && (ch.back().second >> 16) == (vb >> 16)) ch.back().second = ve; else ch.push_back(std::make_pair(vb, ve));
+            const int w0 = a.ts >> 14, w1 = ((a.te > a.ts ? a.te : a.ts + 1) - 1) >> 14;
+            for (int wv = w0; wv <= w1 && wv < n_lin; ++wv) { if (lin[wv] == 0 || vb < lin[wv]) lin[wv] = vb; if (wv + 1 > max_lin) max_lin = wv + 1; }
+            if (!any) { ref_beg = vb; any = true; }
+            ref_end = ve; ++n_mapped; ++i;
+        }
+        put32(bai, (uint32_t)(bins.size() + (any ? 1 : 0)));
+        for (auto &kv : bins) {
+            put32(bai, kv.first); put32(bai, (uint32_t)kv.second.size());
+            for (auto &c : kv.second) { bai.append((const char*)&c.first, 8); bai.append((const char*)&c.second, 8); }
+        }
+        if (any) {   // samtools' metadata pseudo-bin 37450
+            put32(bai, 37450u); put32(bai, 2u);
+            bai.append((const char*)&ref_beg, 8); bai.append((const char*)&ref_end, 8);
+            uint64_t zero = 0; bai.append((const char*)&n_mapped, 8); bai.append((const char*)&zero, 8);
+        }
+        // linear index: fill empty windows with the next lower filled value (as samtools does)
+        for (int wv = 1; wv < max_lin; ++wv) if (lin[wv] == 0) lin[wv] = lin[wv - 1];
+        put32(bai, (uint32_t)max_lin);
+        for (int wv = 0; wv < max_lin; ++wv) bai.append((const char*)&lin[wv], 8);
+    }
+    bai.append((const char*)&n_no_coor, 8);
+    std::string bai_path = std::string(bam_path) + ".bai";
+    f = fopen(bai_path.c_str(), "wb");
+    if (!f) return TELR_E_ARG;
+    fwrite(bai.data(), 1, bai.size(), f);
+    fclose(f);
+    return TELR_OK;
+}

@@ -1,0 +1,55 @@
+"""Stage-1 alignment, mirroring the reference's `src/telr/TELR_alignment.py`.
+
+`alignment(bam, read, reference, out, sample_name, thread, method, presets)` keeps the reference's
+signature and argument meaning (:9): `method` is "nglmr" (sic, the reference's spelling) or "minimap2",
+`presets` is "ont" or "pacbio".  Instead of `ngmlr ... > tmp.sam` / `minimap2 --cs --MD -Y -L -ax ... >
+sam` (:28-82) followed by `samtools sort` + `samtools index` (:103-114), the reads are mapped by the HIP
+engine and the coordinate-sorted, indexed BAM is written directly by the library.
+"""
+import logging
+import os
+import sys
+import time
+
+from .aligner import Engine
+from .fasta import read_fasta
+from .presets import preset
+
+
+def format_time(seconds):          # TELR_utility.py:34-41
+    h, rem = divmod(seconds, 3600)
+    m, s = divmod(rem, 60)
+    return "%d:%02d:%02d" % (int(h), int(m), round(s))
+
+
+def alignment(bam, read, reference, out, sample_name, thread, method, presets, engine=None):
+    logging.info("Start alignment...")
+    start_time = time.time()
+    if presets not in ("ont", "pacbio"):
+        print("Read presets not recognized, please provide ont or pacbio, exiting...")
+        sys.exit(1)
+    if method == "nglmr":
+        name = "ngmlr-ont" if presets == "ont" else "ngmlr-pacbio"
+        rg = (sample_name, sample_name, "ont" if presets == "ont" else "pb")     # --rg-id/--rg-sm/--rg-lb (:32-49)
+        cmd = "ngmlr -r %s -q %s -x %s -t %s" % (reference, read, presets, thread)
+    elif method == "minimap2":
+        name = "map-ont" if presets == "ont" else "map-pb"
+        rg = None
+        cmd = "minimap2 --cs --MD -Y -L -ax %s %s %s" % (name, reference, read)
+    else:
+        print("Alignment method not recognized, please provide ont or pacbio, exiting...")
+        sys.exit(1)
+    eng = engine or Engine(0)
+    io, mo = preset(name)
+    tn, ts = read_fasta(reference)
+    qn, qs = read_fasta(read)
+    ix = eng.index(ts, io)
+    r = ix.map_raw(qs, mo)
+    try:
+        ix.write_bam(r, qn, qs, tn, ts, bam, md=True, cs=(method == "minimap2"), softclip=True, rg=rg, cmdline=cmd, index=True)
+    finally:
+        ix.free_raw(r)
+    if os.path.isfile(bam) is False:
+        sys.stderr.write("Sorted and indexed BAM file does not exist, exiting...\n")
+        sys.exit(1)
+    logging.info("First alignment finished in " + format_time(time.time() - start_time))

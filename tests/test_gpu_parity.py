@@ -296,3 +296,90 @@ def test_sam_and_paf_emitters(engine, data_dir, tmp_path):
     for p, a in zip(plines, res.alns):
         assert [int(p[i]) for i in (1, 2, 3, 6, 7, 8, 9, 10, 11)] == [a[k] for k in ("qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "mapq")]
         assert p[4] == ("-" if a["flags"] & 8 else "+") and p[5] == tn[a["tid"]]
+
+
+def _read_bgzf(path):
+    import struct, zlib
+    data = open(path, "rb").read()
+    out, off, blocks = [], 0, []
+    while off < len(data):
+        assert data[off:off + 4] == b"\x1f\x8b\x08\x04"
+        xlen = struct.unpack_from("<H", data, off + 10)[0]
+        assert data[off + 12:off + 14] == b"BC"
+        bsize = struct.unpack_from("<H", data, off + 16)[0] + 1
+        raw = zlib.decompress(data[off + 12 + xlen:off + bsize - 8], -15)
+        assert struct.unpack_from("<I", data, off + bsize - 4)[0] == len(raw)
+        assert struct.unpack_from("<I", data, off + bsize - 8)[0] == zlib.crc32(raw)
+        blocks.append((off, len(b"".join(out)), len(raw)))
+        out.append(raw); off += bsize
+    assert blocks[-1][2] == 0          # EOF marker block
+    return b"".join(out), blocks
+
+
+def test_sorted_bam_and_bai(engine, data_dir, tmp_path):
+    """telr_alignment.alignment() == map + `samtools sort` + `samtools index`: BGZF/BAM/BAI parsed back here."""
+    import struct
+    from telr_amd import telr_alignment
+    bam = str(tmp_path / "s_sort.bam")
+    telr_alignment.alignment(bam, data_dir + "/reads.fasta", data_dir + "/ref_38kb.fasta", str(tmp_path), "s", 1, "minimap2", "ont", engine=engine)
+    raw, blocks = _read_bgzf(bam)
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text].decode()
+    assert "SO:coordinate" in text and "@SQ\tSN:" in text
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]; p += 4
+    assert n_ref == 1
+    l_name = struct.unpack_from("<i", raw, p)[0]; p += 4 + l_name
+    l_ref = struct.unpack_from("<i", raw, p)[0]; p += 4
+    assert l_ref == 38001
+    recs, last = [], (-1, -1)
+    while p < len(raw):
+        bs, refid, pos, lrn, mapq, bn, ncig, flag, lseq = struct.unpack_from("<iiiBBHHHi", raw, p)
+        start = p; p += 4
+        body = raw[p:p + bs]; p += bs
+        name = body[32:32 + lrn - 1].decode()
+        cig = struct.unpack_from("<%dI" % ncig, body, 32 + lrn)
+        reflen = sum(c >> 4 for c in cig if (c & 0xf) in (0, 2))
+        qlen_c = sum(c >> 4 for c in cig if (c & 0xf) in (0, 1, 4))
+        if refid >= 0:
+            assert (refid, pos) >= last; last = (refid, pos)
+            assert flag & 0x100 or qlen_c == lseq
+            # bin as the SAM spec defines it
+            beg, end = pos, pos + reflen - 1
+            want = 0
+            for sh, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+                if beg >> sh == end >> sh:
+                    want = base + (beg >> sh); break
+            assert bn == want
+        recs.append((start, refid, pos, name, flag, reflen, bn))
+    mapped = [r for r in recs if r[1] >= 0]
+    assert len(mapped) >= 18 and all(r[1] == -1 for r in recs[len(mapped):])
+    # the same records as the engine produced
+    io, mo = preset("map-ont")
+    _, ts = read_fasta(data_dir + "/ref_38kb.fasta"); _, qs = read_fasta(data_dir + "/reads.fasta")
+    res = engine.index(ts, io).map(qs, mo)
+    assert sorted(int(a["ts"]) for a in res.alns) == [r[2] for r in mapped]
+    assert sorted(int(a["te"] - a["ts"]) for a in res.alns) == sorted(r[5] for r in mapped)
+    # BAI: every record start lies inside a chunk of its bin; linear index is monotone
+    bai = open(bam + ".bai", "rb").read()
+    assert bai[:4] == b"BAI\x01" and struct.unpack_from("<i", bai, 4)[0] == 1
+    q = 8
+    n_bin = struct.unpack_from("<i", bai, q)[0]; q += 4
+    bins = {}
+    for _ in range(n_bin):
+        b, nch = struct.unpack_from("<Ii", bai, q); q += 8
+        bins[b] = [struct.unpack_from("<QQ", bai, q + 16 * c) for c in range(nch)]; q += 16 * nch
+    n_intv = struct.unpack_from("<i", bai, q)[0]; q += 4
+    lin = struct.unpack_from("<%dQ" % n_intv, bai, q); q += 8 * n_intv
+    assert list(lin) == sorted(lin) and n_intv == (38000 >> 14) + 1
+    ustart = {b[1]: b[0] for b in blocks}
+
+    def voff(u):
+        blk = max(k for k in ustart if k <= u)
+        return ustart[blk] << 16 | (u - blk)
+    for start, refid, pos, name, flag, reflen, bn in mapped:
+        v = voff(start)
+        assert any(c0 <= v < c1 for c0, c1 in bins[bn]), "record at %d not covered by bin %d" % (pos, bn)
+        assert lin[pos >> 14] <= v
+    assert 37450 in bins and bins[37450][1][0] == len(mapped)

@@ -181,7 +181,7 @@ def main():
         "dp_classes": {str(c): [int(x) for x in cls[c]] for c in range(cls.shape[0]) if cls[c, 0]},
         "path_algorithmic_GBps": path_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
         "frac_reads_mapped": frac_mapped, "index_build_s": t_index, "datagen_s": t_gen, "device": eng.device_name(),
-        "counters": ctr,
+        "counters": ctr, "dp_retries": int(eng.L.telr_debug_dp_retries(eng.h)),
     }
     if a.loci > 0:
         # second half of the BASELINE metric: TE loci/s through the per-locus bundle (S4, S5, S6 fw+rc + depth + AF,

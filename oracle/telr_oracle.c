@@ -577,7 +577,7 @@ static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v
 static inline int fill_band(int m, int n, const telr_map_opt *mo)
 {
     int mn = m < n ? m : n;
-    int W = 6 + (mn >> 5);
+    int W = 3 + (mn >> 5);
     return W < mo->bw ? W : mo->bw;
 }
 static inline int fill_band_wide(int m, int n, const telr_map_opt *mo)

@@ -561,9 +561,15 @@ struct DpProb {             // 64 B
 };
 struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, mcols; };   // 32 B; mcols = M columns of the path
 
+#ifndef TELR_W0
+#define TELR_W0 3
+#endif
+#ifndef TELR_WSH
+#define TELR_WSH 5
+#endif
 __device__ __forceinline__ int d_fill_band(int m, int n, int bw)          // narrow first pass
 {
-    int mn = m < n ? m : n, W = 6 + (mn >> 5);
+    int mn = m < n ? m : n, W = TELR_W0 + (mn >> TELR_WSH);
     return W < bw ? W : bw;
 }
 __device__ __forceinline__ int d_fill_band_wide(int m, int n, int bw)     // retry when the path touched a band edge

@@ -1043,7 +1043,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                     if (is_ext) cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band));
                     else {
                         const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
-                        int W = 6 + (mn >> 5); if (W > mo->bw) W = mo->bw;
+                        int W = TELR_W0 + (mn >> TELR_WSH); if (W > mo->bw) W = mo->bw;
                         int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
                         cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h);
                     }

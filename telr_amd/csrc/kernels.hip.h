@@ -350,6 +350,7 @@ struct SeedArgs {
     const int32_t *qtarget;      // nullable
     int32_t mid_occ;
     int32_t *mz_cnt;             // MODE 0 out
+    int32_t *mz_ent;             // MODE 0 out / MODE 1 in: index entry of the minimizer (-1 = absent), saves the second probe
     const int32_t *mz_aoff;      // MODE 1 in
     uint64_t *keys;              // MODE 1 out
 };
@@ -365,7 +366,9 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
     const int qlen = A.qlen[q];
     for (int g = m0 + threadIdx.x; g < m1; g += blockDim.x) {
         uint64_t x = A.mz_x[g];
-        int32_t e = d_lookup(A.I, x >> 8);
+        int32_t e;
+        if (MODE == 0) { e = d_lookup(A.I, x >> 8); A.mz_ent[g] = e; }
+        else { if (A.mz_aoff[g + 1] == A.mz_aoff[g]) continue; e = A.mz_ent[g]; }
         int32_t cnt = 0; uint32_t o0 = 0, o1 = 0;
         if (e >= 0) {
             o0 = A.I.ent_off[e]; o1 = A.I.ent_off[e + 1];
@@ -538,6 +541,83 @@ __global__ void k_backtrack(const uint64_t *__restrict__ keys, const int32_t *__
         out[nch++] = r; wr += cnt;
     }
     n_chains[q] = nch;
+}
+
+// back-tracking, one wave per query: predecessor deltas (1..256, 0 = none) and visited bits are staged in
+// LDS, lane 0 walks the sorted peaks at LDS latency and records the anchor indices of the chain, then all
+// lanes copy the chain's anchors (coalesced gather/scatter).  Queries with more than BT_CAP anchors take the
+// global-memory path of k_backtrack on lane 0.  Same visiting order and acceptance rule as k_backtrack.
+#define BT_CAP 8192
+__global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
+                                                    const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
+                                                    const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
+                                                    uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
+{
+    __shared__ uint16_t pdel[BT_CAP], idx[BT_CAP];      // pdel: i - p[i] (1..256), 0 = chain start, 0xffff = visited
+    __shared__ int32_t sh[2];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q >= nq) return;
+    const int64_t base = q_aoff[q];
+    const int n = q_aoff[q + 1] - q_aoff[q], np = n_peaks[q];
+    ChainRec *out = rec + ch_off[q];
+    if (n > BT_CAP) {
+        if (lane == 0) {
+            int nch = 0, wr = 0;
+            for (int t = 0; t < np; ++t) {
+                int i = (int)(uint32_t)(pk[base + t] & 0xffffffffu);
+                if (vis[base + i]) continue;
+                int cnt = 0, j = i;
+                while (j >= 0 && !vis[base + j]) { vis[base + j] = 1; ++cnt; j = p[base + j]; }
+                int sc = f[base + i] - (j >= 0 ? f[base + j] : 0);
+                if (sc < min_sc || cnt < min_cnt) continue;
+                j = i;
+                for (int z = cnt - 1; z >= 0; --z) { canch[base + wr + z] = keys[base + j]; j = p[base + j]; }
+                ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr; r.pad = 0;
+                r.a0 = canch[base + wr]; r.a1 = canch[base + wr + cnt - 1];
+                out[nch++] = r; wr += cnt;
+            }
+            n_chains[q] = nch;
+        }
+        return;
+    }
+    for (int i = lane; i < n; i += 64) { int pj = p[base + i]; pdel[i] = (uint16_t)(pj < 0 ? 0 : i - pj); }
+    __syncthreads();
+    int nch = 0, wr = 0;
+    for (int tb = 0; tb < np; tb += 64) {
+        // 64 sorted peaks per round, one coalesced load; the peak's f is encoded in its sort key
+        const uint64_t mykey = tb + lane < np ? pk[base + tb + lane] : 0;
+        const int nt = np - tb < 64 ? np - tb : 64;
+        for (int u = 0; u < nt; ++u) {
+            const uint64_t key = d_readlane64(mykey, u);
+            const int i = (int)(uint32_t)(key & 0xffffffffu), fi = 0x7fffffff - (int)(uint32_t)(key >> 32);
+            if (pdel[i] == 0xffffu) continue;                       // uniform: already on a chain
+            if (lane == 0) {
+                int cnt = 0, j = i;
+                while (j >= 0) {
+                    const int d = pdel[j];
+                    if (d == 0xffff) break;                          // reached a visited anchor
+                    pdel[j] = 0xffffu;
+                    idx[cnt++] = (uint16_t)j;
+                    j = d ? j - d : -1;
+                }
+                sh[0] = cnt; sh[1] = j;
+            }
+            __syncthreads();
+            const int cnt = sh[0], j = sh[1];
+            const int sc = fi - (j >= 0 ? f[base + j] : 0);
+            if (sc >= min_sc && cnt >= min_cnt) {
+                for (int z = lane; z < cnt; z += 64) canch[base + wr + cnt - 1 - z] = keys[base + idx[z]];
+                if (lane == 0) {
+                    ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr; r.pad = 0;
+                    r.a0 = keys[base + idx[cnt - 1]]; r.a1 = keys[base + i];
+                    out[nch] = r;
+                }
+                ++nch; wr += cnt;
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) n_chains[q] = nch;
 }
 
 // ---------------------------------------------------------------------------------------

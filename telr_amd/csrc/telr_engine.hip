@@ -613,7 +613,7 @@ static int host_threads()
     int n = (int)std::thread::hardware_concurrency();
     if (const char *e = getenv("TELR_HOST_THREADS")) { int v = atoi(e); if (v > 0) n = v; }
     if (n < 1) n = 1;
-    if (n > 32) n = 32;
+    if (n > 48) n = 48;
     return n;
 }
 // run f(t, begin, end) over [0,n) split into nt contiguous ranges (in order of t)
@@ -769,11 +769,13 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = ix->d_bstart; I.goff = ix->d_goff;
     I.tlen = tg->d_len; I.n_ent = ix->n_ent; I.shift = ix->shift; I.k = k; I.w = w;
     int32_t *d_mcnt, *d_maoff, *d_qaoff;
+    int32_t *d_ment;
+    TRY(ctx_buf_t(ctx, "mz_ent", (size_t)nmz + 1, &d_ment));
     TRY(ctx_buf_t(ctx, "mz_cnt", (size_t)nmz + 1, &d_mcnt));
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_aoff = nullptr; S.keys = nullptr;
+    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_aoff = nullptr; S.keys = nullptr;
     hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));
@@ -847,15 +849,22 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipStreamSynchronize(st));
     ChainRec *d_rec;
     TRY(ctx_buf_t(ctx, "chain_rec", (size_t)npk_tot, &d_rec));
-    hipLaunchKernelGGL(k_backtrack, dim3((nq + 63) / 64), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                       mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
+    if (getenv("TELR_BT_THREAD"))
+        hipLaunchKernelGGL(k_backtrack, dim3((nq + 63) / 64), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
+    else
+        hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
     HIPCHK(hipGetLastError());
-    std::vector<int32_t> h_nch(nq), h_choff(nq + 1), h_qaoff(nq + 1);
-    std::vector<ChainRec> h_rec((size_t)npk_tot);
-    HIPCHK(hipMemcpyAsync(h_nch.data(), d_nch, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_choff.data(), d_choff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_qaoff.data(), d_qaoff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
-    if (npk_tot) HIPCHK(hipMemcpyAsync(h_rec.data(), d_rec, (size_t)npk_tot * sizeof(ChainRec), hipMemcpyDeviceToHost, st));
+    int32_t *h_nch, *h_choff, *h_qaoff; ChainRec *h_rec;
+    TRY(ctx_hbuf_t(ctx, "h_nch", (size_t)nq + 1, &h_nch));
+    TRY(ctx_hbuf_t(ctx, "h_choff", (size_t)nq + 1, &h_choff));
+    TRY(ctx_hbuf_t(ctx, "h_qaoff", (size_t)nq + 1, &h_qaoff));
+    TRY(ctx_hbuf_t(ctx, "h_rec", (size_t)npk_tot + 1, &h_rec));
+    HIPCHK(hipMemcpyAsync(h_nch, d_nch, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_choff, d_choff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_qaoff, d_qaoff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (npk_tot) HIPCHK(hipMemcpyAsync(h_rec, d_rec, (size_t)npk_tot * sizeof(ChainRec), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     t_bt.stop();
     ctx->dbg_na = na; ctx->dbg_nq = nq;

@@ -39,11 +39,23 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask, narrowed by a cgroup v2 quota when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(ref_str, reads, io, mo, n_sample, gbp_of):
     """The CPU oracle ("port") timed on a bounded sample of the same read set."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     buf, off, ln = reads
     t0 = time.time()
     oix = ob.OracleIndex([ref_str], io)
@@ -72,7 +84,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at world size 1)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
@@ -206,7 +218,7 @@ def main():
         out["te_loci"] = {"n": len(loci), "seconds": t_loci, "recovered_exact_family_strand_pos20": good,
                           "note": "host glue (Python) included; per-locus inputs are truth-derived (no Sniffles/wtdbg2 on the box)"}
     if not a.no_cpu_baseline:
-        ns = a.cpu_sample_reads or max(8, int(8e6 * (os.cpu_count() or 1) / 8 / max(1.0, n_bases / len(d["reads"][2]))))
+        ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(d["reads"][2]))))   # ~15-20 s of CPU work
         out["cpu_baseline"] = cpu_baseline(ref_str, d["reads"], io, mo, ns, None)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
     print(json.dumps(out))

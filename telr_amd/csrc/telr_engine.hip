@@ -49,6 +49,9 @@ struct telr_ctx {
     hipEvent_t evk[6] = {nullptr};        // un-synchronised markers around single kernels
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     int64_t dp_retries = 0;
+    telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
+    int n_child = 0;
+    bool is_child = false;
     char devname[256] = {0};
     // debug captures of the last batch (device pointers stay valid until the next call)
     int64_t dbg_na = 0; int32_t dbg_nq = 0;
@@ -142,9 +145,21 @@ extern "C" int telr_init(int device, telr_ctx **out)
     *out = ctx;
     return TELR_OK;
 }
+static int ctx_make_child(telr_ctx *ctx, int k)
+{
+    if (ctx->child[k]) return TELR_OK;
+    telr_ctx *c = nullptr;
+    int r = telr_init(ctx->device, &c);
+    if (r != TELR_OK) return r;
+    c->is_child = true; c->debug = ctx->debug;
+    ctx->child[k] = c;
+    if (k + 1 > ctx->n_child) ctx->n_child = k + 1;
+    return TELR_OK;
+}
 extern "C" void telr_destroy(telr_ctx *ctx)
 {
     if (!ctx) return;
+    for (int k = 0; k < 4; ++k) if (ctx->child[k]) { telr_destroy(ctx->child[k]); ctx->child[k] = nullptr; }
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->hbufs) if (kv.second.p) (void)hipHostFree(kv.second.p);
@@ -608,12 +623,27 @@ static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max
     if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
+// worker threads for the host phases: 1.5x the CPUs this process may actually use (cgroup v2 quota when
+// present: the MI355X box reports 256 hardware threads but runs under cpu.max = 16 CPUs), at most 48
 static int host_threads()
 {
+    static int cached = 0;
+    if (cached) return cached;
     int n = (int)std::thread::hardware_concurrency();
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long quota = atol(q);
+            int c = (int)((quota + period - 1) / period);
+            if (c >= 1 && c < n) n = c;
+        }
+        fclose(f);
+    }
+    n = n + n / 2;
     if (const char *e = getenv("TELR_HOST_THREADS")) { int v = atoi(e); if (v > 0) n = v; }
     if (n < 1) n = 1;
     if (n > 48) n = 48;
+    cached = n;
     return n;
 }
 // run f(t, begin, end) over [0,n) split into nt contiguous ranges (in order of t)
@@ -1191,17 +1221,80 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     telr_result *R = new telr_result();
     R->ctx = ctx;
     const auto t_wall0 = std::chrono::steady_clock::now();
-    // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
-    int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
-    if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
-    int32_t q0 = 0;
-    while (q0 < nq) {
-        int32_t q1 = q0; int64_t b = 0;
-        while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= batch_bases)) { b += queries->len[q1]; ++q1; }
-        ctx->ctr.query_bases += b;
-        int r = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
-        if (r != TELR_OK) { delete R; return r; }
-        q0 = q1;
+    // Large calls are cut into a few sub-batches that run CONCURRENTLY on worker contexts (own streams and
+    // scratch): the host phases of one sub-batch (chain selection, record assembly, CIGAR stitching) and the
+    // latency-bound DP tail overlap with the GPU work of the others.  Small calls run in place.
+    int64_t total_bases = 0;
+    for (int i = 0; i < nq; ++i) total_bases += queries->len[i];
+    int nsub = 1;      // measured on the MI355X box: concurrency only pays when host cores are plentiful; opt-in via TELR_SUBBATCH
+    if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
+    if (nsub > nq) nsub = nq > 0 ? nq : 1;
+    if (nsub == 1) {
+        // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
+        int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
+        if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
+        int32_t q0 = 0;
+        while (q0 < nq) {
+            int32_t q1 = q0; int64_t b = 0;
+            while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= batch_bases)) { b += queries->len[q1]; ++q1; }
+            ctx->ctr.query_bases += b;
+            int r = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
+            if (r != TELR_OK) { delete R; return r; }
+            q0 = q1;
+        }
+    } else {
+        // split by bases into nsub contiguous ranges
+        std::vector<int32_t> cut(nsub + 1, nq);
+        { int64_t acc = 0; int k = 1; cut[0] = 0;
+          for (int i = 0; i < nq && k < nsub; ++i) { acc += queries->len[i]; if (acc >= total_bases * k / nsub) cut[k++] = i + 1; } }
+        for (int k = 0; k < nsub; ++k) { int r = ctx_make_child(ctx, k); if (r != TELR_OK) { delete R; return r; } }
+        std::vector<telr_result*> part(nsub, nullptr);
+        std::vector<int> rc(nsub, TELR_OK);
+        std::vector<std::thread> th;
+        for (int k = 0; k < nsub; ++k) th.emplace_back([&, k]() {
+            telr_ctx *c = ctx->child[k];
+            (void)hipSetDevice(c->device);
+            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0;
+            part[k] = new telr_result(); part[k]->ctx = nullptr;
+            if (cut[k + 1] > cut[k]) {
+                for (int i = cut[k]; i < cut[k + 1]; ++i) c->ctr.query_bases += queries->len[i];
+                rc[k] = map_batch(c, ix, queries, d_qt, cut[k], cut[k + 1], mo, mid_occ, part[k]);
+            }
+        });
+        for (auto &t : th) t.join();
+        for (int k = 0; k < nsub; ++k) if (rc[k] != TELR_OK) { ctx->err = ctx->child[k]->err; for (auto *p : part) delete p; delete R; return rc[k]; }
+        // merge: records in query order, CIGAR arrays concatenated (parallel copy into a pooled buffer)
+        size_t tot_a = 0, tot_c = 0;
+        std::vector<size_t> a0(nsub + 1, 0), c0(nsub + 1, 0);
+        for (int k = 0; k < nsub; ++k) { a0[k] = tot_a; c0[k] = tot_c; tot_a += part[k]->alns.size(); tot_c += part[k]->ncig; }
+        a0[nsub] = tot_a; c0[nsub] = tot_c;
+        pool_get(ctx, &R->cig, &R->cap);
+        if (tot_c + 1 > R->cap) { size_t want = tot_c + 1 + tot_c / 8; uint32_t *nc = (uint32_t*)realloc(R->cig, want * 4); if (!nc) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; } R->cig = nc; R->cap = want; }
+        R->ncig = tot_c;
+        R->alns.resize(tot_a);
+        const int NT = host_threads();
+        for (int k = 0; k < nsub; ++k) {
+            telr_result *P = part[k];
+            parallel_ranges(NT, (int)P->alns.size(), [&](int, int x0, int x1) {
+                for (int x = x0; x < x1; ++x) { telr_aln r = P->alns[x]; r.cigar_off += (int64_t)c0[k]; R->alns[a0[k] + x] = r; }
+            });
+            const size_t nw = P->ncig; const int chunks = 64;
+            parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
+                for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + c0[k] + lo, P->cig + lo, (hi - lo) * 4); }
+            });
+        }
+        // counters / timings: sums over the workers (stage times are GPU/host time spent, not wall)
+        for (int k = 0; k < nsub; ++k) {
+            telr_ctx *c = ctx->child[k];
+            for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
+            const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
+            for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
+            for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
+            ctx->dp_retries += c->dp_retries;
+            // the workers' result buffers go back to their own pools for the next call
+            part[k]->ctx = c;
+            delete part[k];
+        }
     }
     ctx->stage_ms[ST_MAP_WALL] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count();
     *out = R;

@@ -383,3 +383,22 @@ def test_sorted_bam_and_bai(engine, data_dir, tmp_path):
         assert any(c0 <= v < c1 for c0, c1 in bins[bn]), "record at %d not covered by bin %d" % (pos, bn)
         assert lin[pos >> 14] <= v
     assert 37450 in bins and bins[37450][1][0] == len(mapped)
+
+
+def test_concurrent_subbatches(engine):
+    """Large calls are cut into sub-batches that run concurrently on worker contexts; the merged result must be
+    identical to the single-batch result (forced here on a small input through TELR_SUBBATCH)."""
+    import os
+    rng = np.random.default_rng(2024)
+    genome = [synth.random_seq(rng, 120000)]
+    reads, _ = synth.simulate_reads(rng, genome, 45, 5000)
+    reads.insert(7, np.zeros(0, np.uint8))
+    io, mo = preset("map-ont")
+    os.environ["TELR_SUBBATCH"] = "3"
+    try:
+        res3, oref = compare_all(engine, genome, reads, io, mo, stages=False)
+        os.environ["TELR_SUBBATCH"] = "4"
+        compare_all(engine, genome, reads, io, mo, stages=False)
+    finally:
+        del os.environ["TELR_SUBBATCH"]
+    assert len(res3.alns) >= 44

@@ -142,10 +142,11 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
     int wbase = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < SK_THREADS / 64; ++i) { if (i < wv) wbase += wsum[i]; total += wsum[i]; }
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         if (tid == 0) A.tile_cnt[t] = total;
-    } else {
-        int o = A.tile_off[t] + wbase + inc - cnt;
+    }
+    if (MODE != 0) {
+        int64_t o = (MODE == 2 ? (int64_t)t * SK_TILE : (int64_t)A.tile_off[t]) + wbase + inc - cnt;
         uint32_t g0 = A.goff ? A.goff[sid] : 0u;
 #pragma unroll
         for (int c = 0; c < SK_TILE / SK_THREADS; ++c) if (sel >> c & 1) {
@@ -155,6 +156,15 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
             ++o;
         }
     }
+}
+
+// staging -> dense: one block per tile copies its tile_cnt entries to tile_off (coalesced both ways)
+__global__ void __launch_bounds__(256) k_sketch_compact(const uint64_t *__restrict__ sx, const uint32_t *__restrict__ sy, const int32_t *__restrict__ tile_cnt,
+                                                        const int32_t *__restrict__ tile_off, uint64_t *__restrict__ out_x, uint32_t *__restrict__ out_y)
+{
+    const int t = blockIdx.x, n = tile_cnt[t];
+    const int64_t src = (int64_t)t * SK_TILE, dst = tile_off[t];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { out_x[dst + i] = sx[src + i]; out_y[dst + i] = sy[src + i]; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -282,10 +292,11 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_hpc(SketchHpcArgs A)
     int wbase = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < SK_THREADS / 64; ++i) { if (i < wv) wbase += wsum[i]; total += wsum[i]; }
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         if (tid == 0) A.tile_cnt[t] = total;
-    } else {
-        int o = A.tile_off[t] + wbase + inc - cnt;
+    }
+    if (MODE != 0) {
+        int64_t o = (MODE == 2 ? (int64_t)t * SK_TILE : (int64_t)A.tile_off[t]) + wbase + inc - cnt;
         const uint32_t g0 = A.goff ? A.goff[sid] : 0u;
 #pragma unroll
         for (int c = 0; c < SK_TILE / SK_THREADS; ++c) if (sel >> c & 1) {

@@ -341,8 +341,13 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     if (hpc) { H = *hpc; H.tile_seq = d_tseq; H.tile_u0 = d_tu0; H.k = k; H.w = w; H.tile_cnt = d_tcnt; H.tile_off = nullptr; H.out_x = nullptr; H.out_y = nullptr; }
     const int nslot = SK_TILE + 2 * (w - 1);
     size_t lds = hpc ? (size_t)nslot * 12 + (size_t)(nslot + k) + 32 : (size_t)nslot * 9 + 16;
-    if (hpc) hipLaunchKernelGGL(k_sketch_hpc<0>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H);
-    else hipLaunchKernelGGL(k_sketch<0>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+    // single pass: every tile writes its minimizers into its own staging slots and its count; after the scan
+    // of the counts a compaction copy packs them (one hash pass instead of a count pass + a write pass)
+    uint64_t *d_sx; uint32_t *d_sy;
+    TRY(ctx_buf_t(ctx, (P + "stg_x").c_str(), (size_t)T.n * SK_TILE, &d_sx));
+    TRY(ctx_buf_t(ctx, (P + "stg_y").c_str(), (size_t)T.n * SK_TILE, &d_sy));
+    if (hpc) { H.out_x = d_sx; H.out_y = d_sy; hipLaunchKernelGGL(k_sketch_hpc<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H); }
+    else { A.out_x = d_sx; A.out_y = d_sy; hipLaunchKernelGGL(k_sketch<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A); }
     HIPCHK(hipGetLastError());
     // exclusive scan over T.n+1 entries so that tile_off[T.n] = total
     HIPCHK(hipMemsetAsync(d_tcnt + T.n, 0, 4, ctx->stream));
@@ -351,8 +356,7 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     HIPCHK(hipStreamSynchronize(ctx->stream));
     TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), (size_t)*n_mz, d_x));
     TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), (size_t)*n_mz, d_y));
-    if (hpc) { H.tile_off = d_toff; H.out_x = *d_x; H.out_y = *d_y; hipLaunchKernelGGL(k_sketch_hpc<1>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H); }
-    else { A.tile_off = d_toff; A.out_x = *d_x; A.out_y = *d_y; hipLaunchKernelGGL(k_sketch<1>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A); }
+    hipLaunchKernelGGL(k_sketch_compact, dim3(T.n), dim3(256), 0, ctx->stream, d_sx, d_sy, d_tcnt, d_toff, *d_x, *d_y);
     HIPCHK(hipGetLastError());
     return TELR_OK;
 }

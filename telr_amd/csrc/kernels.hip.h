@@ -826,6 +826,8 @@ struct DpArgs {
     DpOpt o;
     uint8_t *tb; uint32_t *cig; DpRes *res;
     int32_t dcap;            // diagonals of LDS state per wave (LDS kernel)
+    int32_t fused_tb;        // packed kernels: walk the trace-back inside the kernel
+    int32_t *retry;
 };
 
 __device__ __forceinline__ int64_t d_wave_max64(int64_t v)
@@ -1259,21 +1261,55 @@ __global__ void __launch_bounds__(64) k_dp_pk(DpArgs A)
         if (xf >= 0 && xf < 4) {
             // its parity equals the parity of m+n, i.e. of the step that produced `fin`; pair = xf>>1
             const int sc = (int)(short)((xf >> 1) ? (fin >> 16) : (fin & 0xffffu));
-            DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0;
-            A.res[prob] = Rr;
+            if (A.fused_tb) { DpRes *rp = &A.res[prob]; rp->score = sc; rp->bi = m; rp->bj = n; rp->cells = P.pad[1]; rp->tbases = n; }
+            else { DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0; A.res[prob] = Rr; }
         }
+    }
+    if (!A.fused_tb) return;
+    // ---- fused trace-back: lane 0 of every problem walks the bytes the wave has just written (served from
+    // L2 with sc1 loads); the walk is pure latency and overlaps with the arithmetic of the other resident waves
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (have && l == 0) {
+        const uint8_t *tb = A.tb + P.tb_off;
+        const int dhi_ = P.dhi;
+        int i = m, j = n, no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0, touched = 0;
+        uint32_t *cg = A.cig + P.cig_off;
+        while (i > 0 && j > 0) {
+            const int a = i + j, sl = (j - i - dlo) >> 1;
+            const uint32_t t = __hip_atomic_load(tb + ((((int64_t)(a >> 1) * LPP + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            touched |= (j - i == dlo) | (j - i == dhi_);
+            if (state == 0) state = t & 7;
+            int op;
+            if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
+            else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
+            else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
+            else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
+            else                 { op = 1; if (!(t & 64)) state = 0; --i; }
+            if (op == cur_op) ++cur_len;
+            else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
+        }
+        if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
+        if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
+        if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+        // the result record is written by the lane that owns the final diagonal; these three fields are ours
+        __hip_atomic_store(&A.res[prob].nops, no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&A.res[prob].mlen, ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&A.res[prob].mcols, mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (A.retry && touched) A.retry[prob] = 1;
     }
 }
 
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
 // run-length CIGAR in end->start order (64 independent pointer chases per wave).
 __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
-                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry)
+                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry, int skip_pk)
 {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= np) return;
     const DpProb P = probs[pi];
     if (P.kind >= 3) return;
+    if (skip_pk && P.pad[0] >= 10) return;          // walked inside k_dp_pk
     const int dhi_ = P.dhi; int touched = 0;
     const int cls = P.pad[0], dlo = P.dlo;
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;

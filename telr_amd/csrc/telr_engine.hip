@@ -718,6 +718,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
     D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
     D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
+    D.fused_tb = getenv("TELR_FUSED_TB") ? 1 : 0; D.retry = d_retry;   // measured slower on MI355X (+12 ms forward, -6 ms trace-back): opt-in
     static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
     // The few long/wide problems are latency-bound single waves: start each tail class on its own side
     // stream so that they run underneath the bulk classes on the main stream.
@@ -760,7 +761,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
     }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
-    hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, *d_rawcig_io, d_retry);
+    hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, *d_rawcig_io, d_retry, D.fused_tb);
     if (primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
     HIPCHK(hipGetLastError());
     return TELR_OK;

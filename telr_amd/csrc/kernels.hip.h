@@ -359,6 +359,7 @@ struct SeedArgs {
     const int32_t *q_mzoff;      // [nq+1]
     const int32_t *qlen;
     const int32_t *qtarget;      // nullable
+    const int32_t *q_order;      // block -> query (longest first), nullable
     int32_t mid_occ;
     int32_t *mz_cnt;             // MODE 0 out
     int32_t *mz_ent;             // MODE 0 out / MODE 1 in: index entry of the minimizer (-1 = absent), saves the second probe
@@ -369,7 +370,7 @@ struct SeedArgs {
 template <int MODE>
 __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 {
-    const int q = blockIdx.x;
+    const int q = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
     const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
     const int tf = A.qtarget ? A.qtarget[q] : -1;
     uint32_t g0 = 0, g1 = 0xffffffffu;
@@ -451,10 +452,10 @@ __device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int lane)
 
 template <int R>
 __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p)
+                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
 {
-    const int q = blockIdx.x;
-    if (q >= nq) return;
+    if ((int)blockIdx.x >= nq) return;
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;    // longest reads first: the kernel ends with the short ones
     const int lane = threadIdx.x;
     const int64_t base = q_aoff[q];
     const int n = q_aoff[q + 1] - q_aoff[q];
@@ -562,12 +563,14 @@ __global__ void k_backtrack(const uint64_t *__restrict__ keys, const int32_t *__
 __global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
                                                     const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
                                                     const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
-                                                    uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
+                                                    uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains,
+                                                    const int32_t *__restrict__ q_order)
 {
     __shared__ uint16_t pdel[BT_CAP], idx[BT_CAP];      // pdel: i - p[i] (1..256), 0 = chain start, 0xffff = visited
     __shared__ int32_t sh[2];
-    const int q = blockIdx.x, lane = threadIdx.x;
-    if (q >= nq) return;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= nq) return;
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;
     const int64_t base = q_aoff[q];
     const int n = q_aoff[q + 1] - q_aoff[q], np = n_peaks[q];
     ChainRec *out = rec + ch_off[q];

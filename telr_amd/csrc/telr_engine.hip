@@ -799,6 +799,17 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     t_sk.stop();
     ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
 
+    // queries in descending length order for the one-block-per-query kernels (their tail is the longest read)
+    int32_t *d_qorder;
+    {
+        std::vector<int32_t> ord(nq);
+        for (int i = 0; i < nq; ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return qs->len[q0 + x] > qs->len[q0 + y]; });
+        TRY(ctx_buf_t(ctx, "q_order", (size_t)nq + 1, &d_qorder));
+        HIPCHK(hipMemcpyAsync(d_qorder, ord.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));        // `ord` is a local
+    }
+
     // ---- seeding --------------------------------------------------------------------------
     StageTimer t_sd(ctx, ST_SEED, true);
     IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = ix->d_bstart; I.goff = ix->d_goff;
@@ -810,7 +821,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_aoff = nullptr; S.keys = nullptr;
+    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
     hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));
@@ -849,9 +860,9 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
     co.chain_gap_q8 = mo->chain_gap_q8; co.chain_skip_q8 = mo->chain_skip_q8;
     const int Rr = mo->chain_lookback / 64;
-    if (Rr == 1) hipLaunchKernelGGL(k_chain<1>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p);
-    else if (Rr == 2) hipLaunchKernelGGL(k_chain<2>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p);
-    else hipLaunchKernelGGL(k_chain<4>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p);
+    if (Rr == 1) hipLaunchKernelGGL(k_chain<1>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder);
+    else if (Rr == 2) hipLaunchKernelGGL(k_chain<2>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder);
+    else hipLaunchKernelGGL(k_chain<4>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder);
     HIPCHK(hipGetLastError());
     t_ch.stop();
 
@@ -889,7 +900,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                            mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
     else
         hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder);
     HIPCHK(hipGetLastError());
     int32_t *h_nch, *h_choff, *h_qaoff; ChainRec *h_rec;
     TRY(ctx_hbuf_t(ctx, "h_nch", (size_t)nq + 1, &h_nch));

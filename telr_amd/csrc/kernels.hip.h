@@ -1157,7 +1157,21 @@ __device__ __forceinline__ uint32_t PKU(pk_s2 v) { return __builtin_bit_cast(uin
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return PKU(PKS(a) + PKS(b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return PKU(PKS(a) - PKS(b)); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return PKU(__builtin_elementwise_max(PKS(a), PKS(b))); }
-__device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return PKU(PKS(a) >> (pk_s2)(15)); }     // 0xffff where the half is negative
+// 0xffff where the half is negative.  Inline asm keeps the packed form: written in C the compiler turns the
+// mask-and-select idiom into per-half SDWA compares + v_cndmask + v_perm (about twice the instructions).
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+// (m & a) | (~m & b)
+__device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
 
@@ -1174,14 +1188,14 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
     const uint32_t amb = pk_sign(PKU(PKS(qb | tbv) << (pk_s2)(13)));      // either base is N (code 4)
     uint32_t sc = pk_sub(eq & c.ab, c.b);
-    sc = (amb & c.nambi) | (~amb & sc);
-    t |= eq & ~amb & 0x00800080u;
+    sc = pk_sel(amb, c.nambi, sc);
+    t |= pk_sel(amb, 0u, eq) & 0x00800080u;
     h = pk_add(hd, sc);
     uint32_t m, src;
     m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & 0x00010001u;
-    m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = (m & 0x00020002u) | (~m & src);
-    m = pk_sign(pk_sub(h, ve2)); h = pk_max(h, ve2); src = (m & 0x00030003u) | (~m & src);
-    m = pk_sign(pk_sub(h, vf2)); h = pk_max(h, vf2); src = (m & 0x00040004u) | (~m & src);
+    m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = pk_sel(m, 0x00020002u, src);
+    m = pk_sign(pk_sub(h, ve2)); h = pk_max(h, ve2); src = pk_sel(m, 0x00030003u, src);
+    m = pk_sign(pk_sub(h, vf2)); h = pk_max(h, vf2); src = pk_sel(m, 0x00040004u, src);
     return t | src;
 }
 

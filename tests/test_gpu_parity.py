@@ -402,3 +402,29 @@ def test_concurrent_subbatches(engine):
     finally:
         del os.environ["TELR_SUBBATCH"]
     assert len(res3.alns) >= 44
+
+
+def test_edge_cases(engine):
+    """empty / degenerate inputs and argument errors at the C ABI (no crash, empty result is not an error)"""
+    from telr_amd._lib import TelrError
+    rng = np.random.default_rng(8)
+    g = bytes(synth.random_seq(rng, 5000)).decode()
+    io, mo = preset("map-ont")
+    ix = engine.index([g, "ACGT", ""], io)                       # targets shorter than k and empty
+    assert len(ix.map([], mo).alns) == 0                         # no queries
+    res = ix.map(["", "ACG", "N" * 500, g[1000:1014]], mo)       # empty, shorter than k, all ambiguous, shorter than k+w
+    assert len(res.alns) == 0
+    res = ix.map([g[500:3500]], mo)
+    assert len(res.alns) == 1 and res.alns[0]["tid"] == 0 and res.alns[0]["mlen"] == 3000 and res.cigar_string(0) == "3000M"
+    # compare the degenerate index against the oracle as well
+    compare_all(engine, [g, "ACGT", ""], ["", "ACG", "N" * 500, g[500:3500], g[100:160]], io, mo)
+    with pytest.raises(TelrError):
+        ix.map([g[:1000]], mo, qtarget=np.array([7], np.int32))  # target id out of range
+    bad = mo.copy(); bad.chain_lookback = 100
+    with pytest.raises(TelrError):
+        ix.map([g[:1000]], bad)
+    bad = mo.copy(); bad.e, bad.e2 = 1, 2
+    with pytest.raises(TelrError):
+        ix.map([g[:1000]], bad)
+    empty_ix = engine.index([], io)
+    assert len(empty_ix.map([g[:1000]], mo).alns) == 0

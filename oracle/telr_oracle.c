@@ -583,9 +583,10 @@ static inline int fill_band(int m, int n, const telr_map_opt *mo)
 static inline int fill_band_wide(int m, int n, const telr_map_opt *mo)
 {
     int mn = m < n ? m : n;
-    int W = 24 + (mn >> 3);
+    int W = mn <= 512 ? 24 + (mn >> 3) : 88 + ((mn - 512) >> 4);
     return W < mo->bw ? W : mo->bw;
 }
+#define ADAPT_MAX_STEPS 1000      /* longer segments (m+n) skip the narrow pass: they are few and use the wide band at once */
 /* the lower band edge is rounded down to an even diagonal (the GPU pairs diagonals per lane) */
 static inline int even_lo(int lo) { return lo - (lo & 1); }
 
@@ -661,12 +662,18 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         int32_t sr = bp.a[2 * g], sq = bp.a[2 * g + 1], er = bp.a[2 * g + 2], eq = bp.a[2 * g + 3];
         s.m = eq - sq; s.n = er - sr; s.tstep = 1; s.ti0 = sr;
         if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - sq; } else { s.qstep = 1; s.qi0 = sq; }
-        int W = fill_band(s.m, s.n, mo), dl = s.n - s.m;
+        const int is_long = s.m + s.n > ADAPT_MAX_STEPS;
+        int W = is_long ? fill_band_wide(s.m, s.n, mo) : fill_band(s.m, s.n, mo), dl = s.n - s.m;
+        if (is_long) {      /* keep long segments within 1024 diagonals when the narrow band allows it */
+            int adl = dl < 0 ? -dl : dl, cap = (1022 - adl) / 2, Wn = fill_band(s.m, s.n, mo);
+            if (cap < Wn) cap = Wn;
+            if (W > cap) W = cap;
+        }
         rc.n = 0;
         int lo = even_lo((dl < 0 ? dl : 0) - W), hi = (dl > 0 ? dl : 0) + W, fb_mlen;
         dp_res_t r = hi - lo + 1 > DP_DMAX ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
-        if (r.touched) {            /* second pass with the wide band */
+        if (r.touched && !is_long) {            /* second pass with the wide band */
             int W2 = fill_band_wide(s.m, s.n, mo);
             lo = even_lo((dl < 0 ? dl : 0) - W2); hi = (dl > 0 ? dl : 0) + W2;
             if (W2 > W && hi - lo + 1 <= DP_DMAX) { rc.n = 0; r = band_dp(&s, lo, hi, 0, mo, &rc); ctr->dp_cells += r.cells; }

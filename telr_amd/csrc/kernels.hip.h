@@ -668,9 +668,11 @@ __device__ __forceinline__ int d_fill_band(int m, int n, int bw)          // nar
 }
 __device__ __forceinline__ int d_fill_band_wide(int m, int n, int bw)     // retry when the path touched a band edge
 {
-    int mn = m < n ? m : n, W = 24 + (mn >> 3);
+    int mn = m < n ? m : n;
+    int W = mn <= 512 ? 24 + (mn >> 3) : 88 + ((mn - 512) >> 4);
     return W < bw ? W : bw;
 }
+#define ADAPT_MAX_STEPS 1000       // longer segments skip the narrow pass and use the wide band at once
 __device__ __forceinline__ int d_even_lo(int lo) { return lo - (lo & 1); }
 
 // PASS 0: count problems per kept chain.  PASS 1: write descriptors.
@@ -706,6 +708,11 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
             if (PASS) {
                 DpProb P; P.m = cq - lq; P.n = cr - lr; P.chain = c; P.kind = 0;
                 int W = d_fill_band(P.m, P.n, bw), dl = P.n - P.m;
+                if (P.m + P.n > ADAPT_MAX_STEPS) {        // long segment: wide band at once, kept within 1024 diagonals if possible
+                    int adl = dl < 0 ? -dl : dl, cap = (1022 - adl) / 2, W2 = d_fill_band_wide(P.m, P.n, bw);
+                    if (cap < W) cap = W;
+                    W = W2 > cap ? cap : W2;
+                }
                 P.dlo = d_even_lo((dl < 0 ? dl : 0) - W); P.dhi = (dl > 0 ? dl : 0) + W;
                 if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
                 P.tstep = 1; P.ti0 = K.tbase + lr; P.qcomp = (int8_t)K.rev;
@@ -875,6 +882,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     const DpProb P = A.probs[prob];
     const int lane = threadIdx.x;
     if (P.kind == 4) return;
+    __builtin_amdgcn_s_setprio(3);      // latency-bound single wave: do not wait behind the bulk kernels' waves
     const int m = P.m, n = P.n, dlo = P.dlo, dhi = P.dhi, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const DpOpt o = A.o;
     const bool ext = P.kind == 1 || P.kind == 2;
@@ -1047,6 +1055,7 @@ template <int LPP, int R>
 __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
 {
     constexpr int PPW = 64 / LPP, SLOTS = LPP * R;
+    if (R >= 2) __builtin_amdgcn_s_setprio(3);   // tail classes: few long waves, give them issue priority over the bulk
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
     const int pi = blockIdx.x * PPW + sub;
     const bool have = pi < A.nlist;
@@ -1313,7 +1322,7 @@ __global__ void __launch_bounds__(64) k_dp_pk(DpArgs A)
         __hip_atomic_store(&A.res[prob].nops, no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&A.res[prob].mlen, ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&A.res[prob].mcols, mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (A.retry && touched) A.retry[prob] = 1;
+        if (A.retry && touched && m + n <= ADAPT_MAX_STEPS) A.retry[prob] = 1;
     }
 }
 
@@ -1355,7 +1364,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
     if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
     res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
-    if (retry && P.kind == 0 && touched) retry[pi] = 1;
+    if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
 
 // compact the raw per-problem cigars (emission order preserved) into one dense array

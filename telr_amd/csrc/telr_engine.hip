@@ -1099,6 +1099,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                     else {
                         const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
                         int W = TELR_W0 + (mn >> TELR_WSH); if (W > mo->bw) W = mo->bw;
+                        if (m_ + n_ > ADAPT_MAX_STEPS) { int W2 = mn <= 512 ? 24 + (mn >> 3) : 88 + ((mn - 512) >> 4); if (W2 > mo->bw) W2 = mo->bw; int adl = dl < 0 ? -dl : dl, cap = (1022 - adl) / 2; if (cap < W) cap = W; W = W2 > cap ? cap : W2; }
                         int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
                         cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h);
                     }

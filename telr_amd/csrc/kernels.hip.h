@@ -1367,6 +1367,59 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
 
+// ---- CIGAR stitching of the surviving records on the device: one thread per record walks the raw CIGARs of
+// its problems (left extension in emission order, fills and right extension reversed) and merges equal ops
+// across problem boundaries.  Pass 1 counts the final ops (they only merge at boundaries), pass 2 writes them.
+struct StitchRec { int32_t p0, p1, has_left, pad; };
+struct StitchProb { int32_t sv, off, skip, extra; };      // per problem: record, offset inside the record, first op merged away, length absorbed by its last op
+__global__ void k_stitch_count(const StitchRec *__restrict__ sv, int32_t ns, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
+                               const uint32_t *__restrict__ raw, int64_t *__restrict__ nfin, StitchProb *__restrict__ sp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const StitchRec S = sv[i];
+    int n = 0, prev = -1, owner = -1, owner_extra = 0;
+    for (int p = S.p0; p < S.p1; ++p) {
+        const int no = res[p].nops;
+        StitchProb q; q.sv = i; q.off = n; q.skip = 0; q.extra = 0;
+        if (no) {
+            const int64_t off = probs[p].cig_off;
+            const bool fwd = p == S.p0 && S.has_left;
+            const uint32_t fo = raw[off + (fwd ? 0 : no - 1)], lo = raw[off + (fwd ? no - 1 : 0)];
+            q.skip = prev == (int)(fo & 0xf) ? 1 : 0;
+            if (q.skip) owner_extra += (int)(fo >> 4);            // the current tail op grows by the merged first op
+            const int written = no - q.skip;
+            if (written > 0) {
+                if (owner >= 0) sp[owner].extra = owner_extra;    // the previous tail is final now
+                owner = p; owner_extra = 0;
+            }
+            n += written;
+            prev = (int)(lo & 0xf);
+        }
+        sp[p] = q;
+    }
+    if (owner >= 0) sp[owner].extra = owner_extra;
+    nfin[i] = n;
+}
+__global__ void k_stitch_write(int32_t np, const StitchProb *__restrict__ sp, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
+                               const StitchRec *__restrict__ sv, const uint32_t *__restrict__ raw, const int64_t *__restrict__ fin_off, uint32_t *__restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    const StitchProb q = sp[p];
+    if (q.sv < 0) return;
+    const int no = res[p].nops;
+    if (no - q.skip <= 0) return;
+    const uint32_t *src = raw + probs[p].cig_off;
+    const bool fwd = p == sv[q.sv].p0 && sv[q.sv].has_left;
+    uint32_t *o = out + fin_off[q.sv] + q.off;
+    for (int z = q.skip; z < no; ++z) {
+        uint32_t op = src[fwd ? z : no - 1 - z];
+        if (z == no - 1) op += (uint32_t)q.extra << 4;
+        o[z - q.skip] = op;
+    }
+}
+
 // compact the raw per-problem cigars (emission order preserved) into one dense array
 __global__ void k_cigar_gather(const DpProb *__restrict__ probs, const DpRes *__restrict__ res, const int64_t *__restrict__ dense_off,
                                int32_t np, const uint32_t *__restrict__ raw, uint32_t *__restrict__ dense)

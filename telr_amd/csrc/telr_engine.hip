@@ -24,7 +24,7 @@
 
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
-    "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "cigar_gather", "d2h", "assemble_host", "index_build",
+    "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "stitch_d2h", "d2h", "assemble_host", "index_build",
     "k_dp_pk16_pk32_reg", "map_wall", "k_traceback", "k_dp_pk_8"
 };
 enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX,
@@ -163,7 +163,7 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->hbufs) if (kv.second.p) (void)hipHostFree(kv.second.p);
-    for (auto &pc : ctx->cig_pool) free(pc.first);
+    for (auto &pc : ctx->cig_pool) if (pc.first) (void)hipHostFree(pc.first);
     ctx->cig_pool.clear();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -593,10 +593,24 @@ struct telr_result {
 };
 // CIGAR buffers of freed results are kept (at most two) and handed to the next telr_map call: a fresh
 // 200 MB allocation costs ~20 ms of page faults and another ~20 ms of munmap per call.
+// result CIGAR buffers are PINNED host memory (the stitched CIGARs are copied device -> result in one DMA)
+static uint32_t *cig_alloc(size_t ops) { void *p = nullptr; return hipHostMalloc(&p, ops * 4, hipHostMallocDefault) == hipSuccess ? (uint32_t*)p : nullptr; }
+static void cig_free(uint32_t *p) { if (p) (void)hipHostFree(p); }
+// grow to at least `want` ops keeping the first `keep` ops
+static bool cig_grow(uint32_t **p, size_t *cap, size_t keep, size_t want)
+{
+    if (want <= *cap) return true;
+    uint32_t *n = cig_alloc(want);
+    if (!n) return false;
+    if (*p && keep) memcpy(n, *p, keep * 4);
+    cig_free(*p);
+    *p = n; *cap = want;
+    return true;
+}
 static void pool_put(telr_ctx *ctx, uint32_t *p, size_t cap)
 {
     if (!p) return;
-    if (!ctx || ctx->cig_pool.size() >= 2) { free(p); return; }
+    if (!ctx || ctx->cig_pool.size() >= 2) { cig_free(p); return; }
     ctx->cig_pool.push_back(std::make_pair(p, cap));
 }
 static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
@@ -984,7 +998,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     });
 
     const bool do_dp = (mo->flags & TELR_MF_CIGAR) && nk > 0;
-    std::vector<int32_t> h_poff; DpRes *h_res = nullptr; uint32_t *h_cig = nullptr; std::vector<int64_t> h_doff;
+    std::vector<int32_t> h_poff; DpRes *h_res = nullptr;
+    DpProb *d_probs_keep = nullptr; DpRes *d_res_keep = nullptr; uint32_t *d_rawcig_keep = nullptr;
     int np = 0;
     if (do_dp) {
         // ---- DP problem list ----------------------------------------------------------------
@@ -1050,34 +1065,21 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         ctx->dp_retries += n_retry;
         t_dp.stop();
 
-        // ---- compact cigars and bring results home (pinned staging) --------------------------------
-        StageTimer t_g(ctx, ST_GATHER, true);
-        int64_t *d_nops, *d_doff; uint32_t *d_dense;
-        TRY(ctx_buf_t(ctx, "nops", (size_t)np + 1, &d_nops));
-        TRY(ctx_buf_t(ctx, "dense_off", (size_t)np + 1, &d_doff));
-        hipLaunchKernelGGL(k_res_nops, dim3((np + 255) / 256), dim3(256), 0, st, d_res, np, d_nops);
-        HIPCHK(hipMemsetAsync(d_nops + np, 0, 8, st));
-        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nops, d_doff, (size_t)np + 1)));
-        int64_t nops_total = 0;
-        HIPCHK(hipMemcpyAsync(&nops_total, d_doff + np, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        TRY(ctx_buf_t(ctx, "dense_cig", (size_t)nops_total, &d_dense));
-        hipLaunchKernelGGL(k_cigar_gather, dim3(np), dim3(64), 0, st, d_probs, d_res, d_doff, np, d_rawcig, d_dense);
-        HIPCHK(hipGetLastError());
-        t_g.stop();
+        // ---- problem results home (32 B each, pinned); the CIGARs stay on the device until the survivors are known
         StageTimer t_d(ctx, ST_D2H, true);
         TRY(ctx_hbuf_t(ctx, "h_res", (size_t)np, &h_res));
-        TRY(ctx_hbuf_t(ctx, "h_cig", (size_t)nops_total, &h_cig));
         HIPCHK(hipMemcpyAsync(h_res, d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
-        if (nops_total) HIPCHK(hipMemcpyAsync(h_cig, d_dense, (size_t)nops_total * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         t_d.stop();
+        d_probs_keep = d_probs; d_res_keep = d_res; d_rawcig_keep = d_rawcig;
 
         // ---- host: per-chain numbers from the per-problem results (no op walking) ---------------------
         StageTimer t_as(ctx, ST_ASSEMBLE, false);
-        h_doff.resize((size_t)np + 1);
-        h_doff[0] = 0;
-        for (int i = 0; i < np; ++i) { h_doff[i + 1] = h_doff[i] + h_res[i].nops; ctx->ctr.dp_cells += h_res[i].cells; ctx->ctr.window_bases += h_res[i].tbases; }
+        {   // totals for the counters (parallel partial sums)
+            std::vector<int64_t> pc(NT, 0), pw(NT, 0);
+            parallel_ranges(NT, np, [&](int t, int a0, int a1) { int64_t c = 0, w = 0; for (int i = a0; i < a1; ++i) { c += h_res[i].cells; w += h_res[i].tbases; } pc[t] += c; pw[t] += w; });
+            for (int t = 0; t < NT; ++t) { ctx->ctr.dp_cells += pc[t]; ctx->ctr.window_bases += pw[t]; }
+        }
         const int pk_max_steps_h = pk_steps_limit(mo);
         std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
         std::vector<int64_t*> tcls(NT);
@@ -1161,57 +1163,53 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     std::vector<Surv> surv;
     { size_t tot = 0; for (auto &v : tsurv) tot += v.size(); surv.reserve(tot); for (auto &v : tsurv) surv.insert(surv.end(), v.begin(), v.end()); }
     const int ns = (int)surv.size();
+    t_as2.stop();
     if (do_dp && ns > 0) {
-        // exact final op counts: ops only merge across problem boundaries (same op type on both sides)
-        std::vector<int64_t> fin_off((size_t)ns + 1, 0);
-        std::vector<int32_t> nfin(ns, 0);
-        parallel_ranges(NT, ns, [&](int, int ia, int ib) {
-            for (int i = ia; i < ib; ++i) {
-                const int x = surv[i].x; const HostChain &c = chains[kept[x]];
-                const bool has_left = c.qs > 0 && c.rs > 0;
-                int n = 0, prev = -1;
-                for (int p = h_poff[x], pend = h_poff[x + 1], first = 1; p < pend; ++p, first = 0) {
-                    const int64_t lo = h_doff[p], hi = h_doff[p + 1];
-                    if (hi == lo) continue;
-                    const bool fwd = first && has_left;
-                    const int ft = (int)(h_cig[fwd ? lo : hi - 1] & 0xf), lt = (int)(h_cig[fwd ? hi - 1 : lo] & 0xf);
-                    n += (int)(hi - lo) - (prev == ft ? 1 : 0);
-                    prev = lt;
-                }
-                nfin[i] = n;
-            }
-        });
-        for (int i = 0; i < ns; ++i) fin_off[i + 1] = fin_off[i] + nfin[i];
-        const int64_t tot = fin_off[ns];
+        // ---- device: stitch the survivors' CIGARs and DMA them into the (pinned) result buffer
+        StageTimer t_g(ctx, ST_GATHER, true);
+        StitchRec *h_sv, *d_sv; int64_t *d_nfin, *d_foff;
+        TRY(ctx_hbuf_t(ctx, "h_stitch", (size_t)ns, &h_sv));
+        TRY(ctx_buf_t(ctx, "stitch", (size_t)ns, &d_sv));
+        TRY(ctx_buf_t(ctx, "stitch_n", (size_t)ns + 1, &d_nfin));
+        TRY(ctx_buf_t(ctx, "stitch_off", (size_t)ns + 1, &d_foff));
+        for (int i = 0; i < ns; ++i) {
+            const int x = surv[i].x; const HostChain &c = chains[kept[x]];
+            h_sv[i].p0 = h_poff[x]; h_sv[i].p1 = h_poff[x + 1]; h_sv[i].has_left = (c.qs > 0 && c.rs > 0) ? 1 : 0; h_sv[i].pad = 0;
+        }
+        HIPCHK(hipMemcpyAsync(d_sv, h_sv, (size_t)ns * sizeof(StitchRec), hipMemcpyHostToDevice, st));
+        StitchProb *d_sp;
+        TRY(ctx_buf_t(ctx, "stitch_prob", (size_t)np, &d_sp));
+        HIPCHK(hipMemsetAsync(d_sp, 0xff, (size_t)np * sizeof(StitchProb), st));        // sv = -1: problem of a dropped chain
+        hipLaunchKernelGGL(k_stitch_count, dim3((ns + 63) / 64), dim3(64), 0, st, d_sv, ns, d_probs_keep, d_res_keep, d_rawcig_keep, d_nfin, d_sp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(d_nfin + ns, 0, 8, st));
+        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nfin, d_foff, (size_t)ns + 1)));
+        int64_t *h_foff;
+        TRY(ctx_hbuf_t(ctx, "h_stitch_off", (size_t)ns + 1, &h_foff));
+        HIPCHK(hipMemcpyAsync(h_foff, d_foff, (size_t)(ns + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const int64_t tot = h_foff[ns];
+        uint32_t *d_fin;
+        TRY(ctx_buf_t(ctx, "stitched", (size_t)tot + 1, &d_fin));
+        hipLaunchKernelGGL(k_stitch_write, dim3((np + 255) / 256), dim3(256), 0, st, np, d_sp, d_probs_keep, d_res_keep, d_sv, d_rawcig_keep, d_foff, d_fin);
+        HIPCHK(hipGetLastError());
         const size_t base = R->ncig;
         if (base + (size_t)tot + 1 > R->cap) {
             if (!R->cig) pool_get(ctx, &R->cig, &R->cap);
-            if (base + (size_t)tot + 1 > R->cap) {
-                size_t want = base + (size_t)tot + 1; want += want / 8;
-                uint32_t *nc = (uint32_t*)realloc(R->cig, want * 4);
-                if (!nc) return TELR_E_NOMEM;
-                R->cig = nc; R->cap = want;
-            }
+            if (!cig_grow(&R->cig, &R->cap, base, base + (size_t)tot + 1 + (size_t)tot / 8)) return TELR_E_NOMEM;
         }
         R->ncig = base + (size_t)tot;
-        parallel_ranges(NT, ns, [&](int, int ia, int ib) {
-            for (int i = ia; i < ib; ++i) {
-                const int x = surv[i].x; const HostChain &c = chains[kept[x]];
-                uint32_t *out = R->cig + base + fin_off[i]; int no = 0;
-                auto push = [&](uint32_t op) { if (no && (out[no - 1] & 0xf) == (op & 0xf)) out[no - 1] += op & ~0xfu; else out[no++] = op; };
-                int p = h_poff[x]; const int pend = h_poff[x + 1];
-                const bool has_left = c.qs > 0 && c.rs > 0;
-                if (has_left) { for (int64_t z = h_doff[p]; z < h_doff[p + 1]; ++z) push(h_cig[z]); ++p; }     // emission order == left-to-right
-                for (; p < pend; ++p) for (int64_t z = h_doff[p + 1] - 1; z >= h_doff[p]; --z) push(h_cig[z]);  // fills / right extension: reversed
-                surv[i].r.cigar_off = (int64_t)base + fin_off[i]; surv[i].r.n_cigar = no;
-            }
-        });
+        if (tot) HIPCHK(hipMemcpyAsync(R->cig + base, d_fin, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < ns; ++i) { surv[i].r.cigar_off = (int64_t)base + h_foff[i]; surv[i].r.n_cigar = (int32_t)(h_foff[i + 1] - h_foff[i]); }
         ctx->ctr.cigar_ops += tot;
+        t_g.stop();
     }
+    StageTimer t_as3(ctx, ST_ASSEMBLE, false);
     R->alns.reserve(R->alns.size() + ns);
     for (int i = 0; i < ns; ++i) R->alns.push_back(surv[i].r);
     ctx->ctr.records += ns;
-    t_as2.stop();
+    t_as3.stop();
     return TELR_OK;
 }
 
@@ -1286,7 +1284,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         for (int k = 0; k < nsub; ++k) { a0[k] = tot_a; c0[k] = tot_c; tot_a += part[k]->alns.size(); tot_c += part[k]->ncig; }
         a0[nsub] = tot_a; c0[nsub] = tot_c;
         pool_get(ctx, &R->cig, &R->cap);
-        if (tot_c + 1 > R->cap) { size_t want = tot_c + 1 + tot_c / 8; uint32_t *nc = (uint32_t*)realloc(R->cig, want * 4); if (!nc) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; } R->cig = nc; R->cap = want; }
+        if (!cig_grow(&R->cig, &R->cap, 0, tot_c + 1 + tot_c / 8)) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; }
         R->ncig = tot_c;
         R->alns.resize(tot_a);
         const int NT = host_threads();

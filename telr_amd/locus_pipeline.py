@@ -19,3 +19,29 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
         contig_te.setdefault(r[0], (int(r[1]), int(r[2])))
     freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["reads"] for l in loci}, presets, *af_params)
     return {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
+
+
+def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, dist=None, device=None, **kw):
+    """Stages 3-4 sharded over the ranks of one node: loci are assigned by LPT on their read
+    bases, every rank runs the bundle on its shard, and ONE all-gather of fixed-width rows merges the coordinate /
+    allele-frequency table (RCCL over xGMI on GPUs; gloo in the CPU tests).  Variable-length payloads (reports,
+    sequences) stay on the owning rank.  -> (merged LOCUS_ROW array sorted by locus id, this rank's full results)"""
+    from . import shard
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    costs = [sum(len(r) for r in l["reads"]) + len(l["contig"]) for l in loci]
+    mine = shard.shard_loci(costs, world)[rank]
+    sub = [loci[i] for i in mine]
+    res = run_loci(backend, ref_index, ref_names, ref_seq, sub, lib_names, lib_seqs, **kw) if sub else \
+        {"annotation": [], "liftover": [], "summary": {}, "af": {}}
+    by_name = {"_".join(r["ID"].split("_")[:3]): r for r in res["liftover"]}
+    ids, reps, freqs = [], [], []
+    for gi, l in zip(mine, sub):
+        r = by_name.get(l["name"])
+        if r is None:
+            continue
+        ids.append(gi); reps.append(r); freqs.append(res["af"].get(l["name"]))
+    chrom_ids = {n: i for i, n in enumerate(ref_names)}
+    fam_ids = {n: i for i, n in enumerate(lib_names)}
+    rows = shard.rows_from_reports(ids, reps, freqs, chrom_ids, fam_ids)
+    return shard.all_gather_rows(rows, dist, device), res

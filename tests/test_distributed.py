@@ -80,3 +80,50 @@ def test_rows_from_reports_roundtrip():
     assert list(rows["start"]) == [r["report"]["start"] for r in reps]
     assert list(rows["strand"]) == [1 if r["report"]["strand"] == "+" else -1 for r in reps]
     assert rows["af"][0] == 0.75 and rows["tsd_len"][3] == shard.NONE_I32
+
+
+def _locus_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from telr_amd import locus_pipeline
+    from telr_amd.presets import preset
+    from oracle_backend import OracleBackend
+    from locus_data import make_loci
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ref, lib_names, lib, loci, truth = make_loci(n_ins=5, reads_per_locus=16)
+    be = OracleBackend(); io, _ = preset("asm10")
+    rows, _ = locus_pipeline.run_loci_distributed(be, be.index([ref], io), ["chr2L"], lambda ch: ref, loci, lib_names, lib, dist=dist)
+    if rank == 0:
+        np.save(out_path, rows)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_locus_bundle_sharded_world2_equals_world1(tmp_path):
+    """the per-locus bundle sharded over 2 gloo ranks + ONE all-gather == the single-process table"""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from telr_amd import locus_pipeline
+    from telr_amd.presets import preset
+    from oracle_backend import OracleBackend
+    from locus_data import make_loci
+    out = str(tmp_path / "rows.npy")
+    mp.spawn(_locus_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    merged = np.load(out)
+    ref, lib_names, lib, loci, truth = make_loci(n_ins=5, reads_per_locus=16)
+    be = OracleBackend(); io, _ = preset("asm10")
+    rows1, _ = locus_pipeline.run_loci_distributed(be, be.index([ref], io), ["chr2L"], lambda ch: ref, loci, lib_names, lib)
+    assert len(merged) == len(rows1) >= 4
+    for name in merged.dtype.names:
+        a, b = merged[name], rows1[name]
+        if a.dtype.kind == "f":
+            np.testing.assert_array_equal(np.nan_to_num(a, nan=-1.0), np.nan_to_num(b, nan=-1.0), err_msg=name)
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=name)
+    # coordinates of the merged table against the truth
+    for r in merged:
+        t = truth[int(r["locus_id"])]
+        if r["type"] == 1:
+            assert abs(int(r["start"]) - t["pos"]) <= 20 and (1 if t["strand"] == "+" else -1) == r["strand"]

@@ -341,11 +341,124 @@ def capture_helpers(L, T, S, U):
     return g
 
 
+class _Seq(str):
+    def reverse_complement(self):
+        return _Seq(self[::-1].translate(str.maketrans("ACGTNacgtn", "TGCANtgcan")))
+
+
+class _Rec(object):
+    def __init__(self, header, seq):
+        self.description = header
+        self.id = header.split()[0] if header.split() else ""
+        self.seq = _Seq(seq)
+
+
+def _fake_seqio():
+    """just enough of Bio.SeqIO for TELR_output.generate_output: parse() and write()"""
+    m = types.ModuleType("Bio.SeqIO")
+
+    def parse(handle, fmt):
+        hdr, buf = None, []
+        for line in handle:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                if hdr is not None:
+                    yield _Rec(hdr, "".join(buf))
+                hdr, buf = line[1:], []
+            elif line:
+                buf.append(line)
+        if hdr is not None:
+            yield _Rec(hdr, "".join(buf))
+
+    def write(rec, handle, fmt):
+        handle.write(">" + rec.description + "\n")
+        s = str(rec.seq)
+        for i in range(0, len(s), 60):
+            handle.write(s[i:i + 60] + "\n")
+    m.parse = parse; m.write = write
+    return m
+
+
+def capture_output(O):
+    """generate_output (TELR_output.py:10-297) + write_vcf / write_bed (:300-426) on a hand-made liftover report"""
+    import datetime
+    O.SeqIO = _fake_seqio()
+    O.subprocess = types.SimpleNamespace(call=lambda *a, **k: 0)
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    try:
+        contigs = {"chr2L_33000_33020": rnd_seq(900, 3), "chr2L_50000_50010": rnd_seq(700, 4), "chr3R_100_120": rnd_seq(600, 5), "chrX_5_9": rnd_seq(500, 6)}
+        cfa = os.path.join(tmp, "contigs.fa")
+        with open(cfa, "w") as f:
+            for n, sq in contigs.items():
+                f.write(">%s len=%d reads=12\n%s\n" % (n, len(sq), sq))
+        ann = os.path.join(tmp, "te.bed")
+        open(ann, "w").write("chr2L_33000_33020\t100\t400\tjockey\t.\t-\nchr2L_50000_50010\t50\t300\troo|copia\t.\t.\nchr3R_100_120\t10\t200\tcopia\t.\t+\nchrX_5_9\t20\t90\troo\t.\t+\n")
+        tefa = os.path.join(tmp, "te.fa")
+        te = {"chr2L_33000_33020:100-400": contigs["chr2L_33000_33020"][100:400], "chr2L_50000_50010:50-300": contigs["chr2L_50000_50010"][50:300],
+              "chr3R_100_120:10-200": contigs["chr3R_100_120"][10:200], "chrX_5_9:20-90": contigs["chrX_5_9"][20:90]}
+        with open(tefa, "w") as f:
+            for n, sq in te.items():
+                f.write(">%s\n%s\n" % (n, sq))
+        vcf = os.path.join(tmp, "vcf.tsv")
+        with open(vcf, "w") as f:
+            f.write("\t".join(["chr2L", "33000", "33020", "4600", "12", "0.7", "id1", "ACGT", "r1,r2", "PASS", "0/1", "5", "12", "0.9"]) + "\n")
+            f.write("\t".join(["chr2L", "50000", "50010", "250", "9", "1", "id2", "AC GT", "r3", "PASS", "1/1", "0", " 9", "0.8"]) + "\n")
+            f.write("\t".join(["chr3R", "100", "120", "190", "4", "0.4", "id3", "AC", "r4", "PASS", "0/1", "7", "4", "0.95"]) + "\n")
+            f.write("\t".join(["chrX", "5", "9", "70", "3", "0.3", "id4", "AC", "r5", "PASS", "0/1", "6", "3", "0.99"]) + "\n")
+
+        def rep(t, chrom, s, e, fam, strand, gap, tsd_len, tsd_seq, both=True):
+            return {"type": t, "family": fam, "chrom": chrom, "start": s, "end": e, "strand": strand, "gap": gap, "TSD_length": tsd_len, "TSD_sequence": tsd_seq,
+                    "5p_flank_align_coord": "%s:%d-%d" % (chrom, s - 499, s) if chrom else None, "5p_flank_mapping_quality": 60, "5p_flank_num_residue_matches": 480,
+                    "5p_flank_alignment_block_length": 499, "5p_flank_sequence_identity": 480 / 499,
+                    "3p_flank_align_coord": ("%s:%d-%d" % (chrom, e - 5, e + 495)) if both and chrom else None, "3p_flank_mapping_quality": 60 if both else None,
+                    "3p_flank_num_residue_matches": 490 if both else None, "3p_flank_alignment_block_length": 500 if both else None,
+                    "3p_flank_sequence_identity": 0.98 if both else None, "distance_5p_flank_ref_te": None, "distance_3p_flank_ref_te": None, "comment": "c"}
+        lift = [
+            {"ID": "chr2L_33000_33020_100_400", "genome1_coord": "chr2L_33000_33020:100-400", "te_length": 300, "num_hits": 1,
+             "report": rep("non-reference", "chr2L", 33013, 33018, "jockey", "-", -5, 5, "acgta")},
+            {"ID": "chr2L_50000_50010_50_300", "genome1_coord": "chr2L_50000_50010:50-300", "te_length": 250, "num_hits": 1,
+             "report": rep("non-reference", "chr2L", 50004, 50004, "roo|copia", "+", None, None, None, both=False)},
+            {"ID": "chr3R_100_120_10_200", "genome1_coord": "chr3R_100_120:10-200", "te_length": 190, "num_hits": 0,
+             "report": rep("reference", "chr3R", 100, 4700, "copia", "+", 4600, None, None)},
+            {"ID": "chrX_5_9_20_90", "genome1_coord": "chrX_5_9:20-90", "te_length": 70, "num_hits": 1,
+             "report": rep("non-reference", "chrX", 7, 7, "roo", "+", 0, 0, None)},
+        ]
+        lj = os.path.join(tmp, "lift.json"); json.dump(lift, open(lj, "w"))
+        freq = {"chr2L_33000_33020": {"te_5p_cov": 13.0, "te_3p_cov": 12.0, "flank_5p_cov": 18.0, "flank_3p_cov": 17.0, "te_5p_cov_rc": 14.0, "te_3p_cov_rc": 15.0, "flank_5p_cov_rc": 18.0, "flank_3p_cov_rc": 19.0, "freq": 0.75},
+                "chr2L_50000_50010": {"te_5p_cov": 9.0, "te_3p_cov": 9.0, "flank_5p_cov": None, "flank_3p_cov": 8.0, "te_5p_cov_rc": 9.0, "te_3p_cov_rc": 9.0, "flank_5p_cov_rc": 9.0, "flank_3p_cov_rc": None, "freq": 1},
+                "chr3R_100_120": {"te_5p_cov": 1.0, "te_3p_cov": 1.0, "flank_5p_cov": 1.0, "flank_3p_cov": 1.0, "te_5p_cov_rc": 1.0, "te_3p_cov_rc": 1.0, "flank_5p_cov_rc": 1.0, "flank_3p_cov_rc": 1.0, "freq": 1},
+                "chrX_5_9": {"te_5p_cov": 3.0, "te_3p_cov": 3.0, "flank_5p_cov": 30.0, "flank_3p_cov": 1.0, "te_5p_cov_rc": 0.0, "te_3p_cov_rc": 1.0, "flank_5p_cov_rc": 1.0, "flank_3p_cov_rc": 1.0, "freq": None}}
+        ref = os.path.join(tmp, "ref.fa")
+        write_fasta_with_fai(ref, {"chr2L": rnd_seq(300, 1), "chr3R": rnd_seq(200, 2), "chrX": "ACGT" * 10})
+        odir = os.path.join(tmp, "out"); os.mkdir(odir)
+        O.generate_output(lj, freq, tefa, vcf, ann, cfa, odir, "s", ref)
+        files = {}
+        for n in ("s.telr.json", "s.telr.expanded.json", "s.telr.te.fasta", "s.telr.contig.fasta", "s.telr.vcf", "s.telr.bed"):
+            files[n] = open(os.path.join(odir, n)).read().replace(ref, "REF.fa").replace(str(datetime.date.today()), "DATE")
+        # empty report
+        odir2 = os.path.join(tmp, "out2"); os.mkdir(odir2)
+        json.dump([lift[2]], open(lj, "w"))
+        O.generate_output(lj, freq, tefa, vcf, ann, cfa, odir2, "e", ref)
+        files["e.telr.vcf"] = open(os.path.join(odir2, "e.telr.vcf")).read().replace(ref, "REF.fa").replace(str(datetime.date.today()), "DATE")
+        files["e.telr.bed"] = open(os.path.join(odir2, "e.telr.bed")).read()
+        files["e.telr.json"] = open(os.path.join(odir2, "e.telr.json")).read()
+        # every TSD missing: the columns stay text and print "None"
+        odir3 = os.path.join(tmp, "out3"); os.mkdir(odir3)
+        json.dump([lift[1]], open(lj, "w"))
+        O.generate_output(lj, freq, tefa, vcf, ann, cfa, odir3, "n", ref)
+        files["n.telr.vcf"] = open(os.path.join(odir3, "n.telr.vcf")).read().replace(ref, "REF.fa").replace(str(datetime.date.today()), "DATE")
+        return {"contigs_fa": open(cfa).read(), "annotation_bed": open(ann).read(), "te_fa": open(tefa).read(), "vcf_parsed": open(vcf).read(),
+                "liftover": lift, "te_freq": freq, "ref_fai": open(ref + ".fai").read(), "files": files}
+    finally:
+        shutil.rmtree(tmp)
+
+
 def main():
     L, T, S, U = import_reference()
     os.makedirs(GOLD, exist_ok=True)
+    import telr.TELR_output as O
     for name, obj in (("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
-                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U))):
+                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O))):
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)
         print("wrote", name)

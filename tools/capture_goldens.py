@@ -341,6 +341,46 @@ def capture_helpers(L, T, S, U):
     return g
 
 
+def capture_sv(S, U):
+    """merge_vcf (TELR_sv.py:84-140): the `bedtools merge -o collapse -c 2..14 -delim ";" -d 20` call is replaced by a
+    hand-made intermediate (bedtools is not in this image; rows written from its documented behaviour), the reference's
+    own post-processing of that intermediate is what is captured.  Also af_sum / id_merge (as sets) / create_loci_set."""
+    def row(c, s, e, ln, cov, af, sid, seq, reads, flt, gt, dr, dv, prop):
+        return [c, str(s), str(e), str(ln), str(cov), str(af), sid, seq, reads, flt, gt, str(dr), str(dv), str(prop)]
+    table = [
+        row("chr2L", 1000, 1002, 999, 10, 0.4, "7", "ACGTAC", "r1,r2,r3", "PASS", "0/1", 12, 3, 0.91),
+        row("chr2L", 1015, 1021, 1000, 11, 0.5, "8", "ACGTACGG", "r3,r4", "PASS", "0/1", 11, 2, 0.95),
+        row("chr2L", 1041, 1042, 85, 3, 0.3, "9", "AC", "r9", "PASS", "1/1", 2, 1, 0.5),
+        row("chr2L", 5000, 5001, 300, 7, 0.6, "10", "ACG", "r5,r6", "PASS", "0/1", 6, 2, 0.8),
+        row("chr3R", 10, 11, 450, 4, 0.7, "11", "ACGT", "r7", "PASS", "1/1", 0, 1, 0.99),
+        row("chr3R", 31, 32, 460, 5, 0.2, "12", "ACGTT", "r8,r7", "PASS", "0/1", 4, 2, 0.97),
+    ]
+    # groups under -d 20: {0,1,2} (1002->1015 gap 13, 1021->1041 gap 20), {3}, {4,5} (11->31 gap 20)
+    def merged(rows):
+        cols = [";".join(r[k] for r in rows) for k in range(1, 14)]
+        return [rows[0][0], str(min(int(r[1]) for r in rows)), str(max(int(r[2]) for r in rows))] + cols
+    inter = [merged(table[0:3]), merged(table[3:4]), merged(table[4:6])]
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    try:
+        vin = os.path.join(tmp, "in.tsv")
+        open(vin, "w").write("".join("\t".join(r) + "\n" for r in table))
+
+        def fake_call(command, shell=False, stdout=None):
+            assert "bedtools merge" in command and "-d 20" in command
+            stdout.write("".join("\t".join(r) + "\n" for r in inter))
+            return 0
+        S.subprocess = types.SimpleNamespace(call=fake_call)
+        vout = os.path.join(tmp, "out.tsv")
+        S.merge_vcf(vin, vout)
+        out = [l.split("\t") for l in open(vout).read().splitlines()]
+        loci = sorted(U.create_loci_set(vout))
+    finally:
+        shutil.rmtree(tmp)
+    return {"table": table, "bedtools_merge": inter, "merged": out, "loci": loci,
+            "af_sum": [[v, S.af_sum(list(v))] for v in ([0.4, 0.5], [0.6, 0.5], [1.0], [0.2, 0.3, 0.6])],
+            "id_merge": [[v, sorted(S.id_merge(v).split(","))] for v in (["a,b", "b,c"], ["x"], ["r1,r1", "r1"])]}
+
+
 class _Seq(str):
     def reverse_complement(self):
         return _Seq(self[::-1].translate(str.maketrans("ACGTNacgtn", "TGCANtgcan")))
@@ -458,7 +498,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     import telr.TELR_output as O
     for name, obj in (("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
-                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O))):
+                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O)), ("sv.json", capture_sv(S, U))):
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)
         print("wrote", name)

@@ -149,14 +149,15 @@ def main():
     # reference coordinates by at most the inserted TE bases upstream, so compare loosely)
     prim = al[(al["flags"] & 1) != 0]
     frac_mapped = len(np.unique(prim["qid"])) / max(1, len(d["reads"][2]))
-    # roofline of the dominant kernel: k_dp_pk<8> (packed-int16 gap-fill DP, bands <= 32 diagonals, 8 problems per wave, DP class 12).
-    # Its launch duration is measured live with HIP events on the engine's own stream (telr_stage_ms: "k_dp_pk_8");
-    # its algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per
-    # CIGAR run, 32 B result.
+    # roofline of the dominant kernel: k_dp_pk, the packed-int16 gap-fill DP (DP classes 10-18 in one launch: gap fills by band width + z-drop extensions).  Its
+    # launch duration is measured live with HIP events on the engine's own stream (telr_stage_ms: "k_dp_pk"); its
+    # algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per CIGAR
+    # run, 32 B result.
     cls = eng.dp_classes()
-    KCLS = 12
-    k_ms = stage_tot.get("k_dp_pk_8", 0.0) / a.steps
-    k_bytes = float(cls[KCLS, 3])
+    PK = list(range(10, 19))
+    k_name = "k_dp_pk"
+    k_ms = stage_tot.get("k_dp_pk", 0.0) / a.steps
+    k_bytes = float(cls[PK, 3].sum())
     achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, traffic_src = None, None
     try:   # HBM bytes per launch from the committed PMC passes of this same command (profiles/, separate --pmc runs)
@@ -165,7 +166,7 @@ def main():
                 if line.startswith(kern):
                     return float(line.split()[-1])
             return None
-        fs = _pmc("r01_pmc_FETCH_SIZE.txt", "void k_dp_pk<8>"); ws = _pmc("r01_pmc_WRITE_SIZE.txt", "void k_dp_pk<8>")
+        fs = _pmc("r01_pmc_FETCH_SIZE.txt", k_name + " "); ws = _pmc("r01_pmc_WRITE_SIZE.txt", k_name + " ")
         if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:
             traffic = (2.0 * fs + ws) * 1024.0      # gfx950: FETCH_SIZE counts wide reads at 1/2 (MI355X_MICROARCH.md, HBM)
             traffic_src = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per dispatch; FETCH doubled)"
@@ -175,7 +176,7 @@ def main():
     # whole-path algorithmic bytes (SURVEY 8d formula) for reference
     path_bytes = (ctr["query_bases"] / 4.0 + 32.0 * ctr["minimizers"] + 16.0 * ctr["probes"] + 48.0 * ctr["anchors"]
                   + ctr["window_bases"] / 4.0 + 4.0 * ctr["cigar_ops"] + 64.0 * ctr["records"])
-    gpu_ms = sum(v for k, v in stage_tot.items() if k not in ("select_host", "assemble_host", "index_build", "k_dp_pk16_pk32_reg", "map_wall", "k_traceback", "k_dp_pk_8")) / a.steps
+    gpu_ms = sum(v for k, v in stage_tot.items() if k not in ("select_host", "assemble_host", "index_build", "k_dp_reg", "map_wall", "k_traceback", "k_dp_pk")) / a.steps
     out = {
         "metric": "gbp_aligned_per_s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -183,10 +184,10 @@ def main():
         "config": {"workload": "BASELINE configs[1]: synthetic chr2L-size genome (%d bp) + %d ONT-like reads (%.0f Mbp per GPU, 10%% error) + %d spiked TE insertions, preset %s, stage-1 reads->reference"
                                % (a.genome_len, a.reads, n_bases / 1e6, a.insertions, a.preset),
                    "reads_per_gpu": a.reads, "read_bases_per_gpu": n_bases, "parallelism": "reads sharded x%d, index replicated" % world},
-        "roofline": {"bound": "hbm", "kernel": "k_dp_pk<8>", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+        "roofline": {"bound": "hbm", "kernel": k_name, "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                      "traffic": traffic, "traffic_source": traffic_src, "launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                     "problems_per_launch": int(cls[KCLS, 0]), "cells_per_launch": int(cls[KCLS, 1]),
-                     "gcups": float(cls[KCLS, 1]) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
+                     "problems_per_launch": int(cls[PK, 0].sum()), "cells_per_launch": int(cls[PK, 1].sum()),
+                     "gcups": float(cls[PK, 1].sum()) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
                      "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); all DP kernels together: %.1f ms, %.0f GCUPS"
                              % (dp_ms, ctr["dp_cells"] / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0)},
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_tot.items()},

@@ -42,7 +42,7 @@ class Counters(C.Structure):
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8
 MF_CIGAR, MF_PER_TARGET = 1, 2
 N_STAGES = 16
-N_DPCLS = 13
+N_DPCLS = 19
 
 import numpy as _np
 

@@ -741,14 +741,22 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
-#define DP_NCLS 13
-// 10/11: packed-int16 register kernel (16 / 32 lanes per problem, 4 diagonals per lane) for short gap fills
-__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps)
+#define DP_NCLS 19
+// 10-17: packed-int16 register kernel k_dp_pkr<LPP, R> for short gap fills, by band width:
+// D <= 20 / 24 / 28 / 32 one lane per problem with R = 5 / 6 / 7 / 8; D <= 40 / 48 / 64 two lanes with R = 5 / 6 / 8;
+// D <= 128 four lanes with R = 8; 18: z-drop extensions with D <= 64 (two lanes, R = 8)
+__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps)
 {
+    if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
     if (kind == 0 && steps <= pk_max_steps) {
-        if (D <= 32) return 12;
-        if (D <= 64) return 10;
-        if (D <= 128) return 11;
+        if (D <= 20) return 10;
+        if (D <= 24) return 11;
+        if (D <= 28) return 12;
+        if (D <= 32) return 13;
+        if (D <= 40) return 14;
+        if (D <= 48) return 15;
+        if (D <= 64) return 16;
+        if (D <= 128) return 17;
     }
     if (kind == 0) {
         if (D <= 64) return 5;
@@ -759,21 +767,26 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
     }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
-__device__ __forceinline__ int d_cls_slots(int cls) { return cls == 12 ? 8 : cls == 10 ? 16 : cls == 11 ? 32 : cls == 5 ? 32 : 64 << (cls - 6); }   // dwords per packed trace-back row
-__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
+// dwords per packed trace-back row
+__device__ __forceinline__ int d_cls_slots(int cls)
+{
+    if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 32 : 16;
+    return cls == 5 ? 32 : 64 << (cls - 6);
+}
+__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int32_t pk_ext_steps, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
-    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps);
+    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps);
     int64_t tb;
     if (P.kind >= 3) tb = 0;
-    else if (cls >= 10) tb = (int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4;
+    else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 15) & ~15LL;
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
     int cells = 0;
-    if (cls >= 10) for (int d = P.dlo; d <= P.dhi; ++d) {
+    if (cls >= 10 && cls != 18) for (int d = P.dlo; d <= P.dhi; ++d) {
         int ilo = d < 0 ? 1 - d : 1, ihi = P.n - d < P.m ? P.n - d : P.m;
         if (ihi >= ilo) cells += ihi - ilo + 1;
     }
@@ -836,7 +849,6 @@ struct DpArgs {
     DpOpt o;
     uint8_t *tb; uint32_t *cig; DpRes *res;
     int32_t dcap;            // diagonals of LDS state per wave (LDS kernel)
-    int32_t fused_tb;        // packed kernels: walk the trace-back inside the kernel
     int32_t *retry;
 };
 
@@ -1208,134 +1220,277 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     return t | src;
 }
 
-template <int LPP>
-__global__ void __launch_bounds__(64) k_dp_pk(DpArgs A)
+// Lane l of a problem owns the 4R consecutive diagonals dlo+4R*l .. dlo+4R*l+4R-1 as R packed register pairs:
+// register r holds {low half: diagonal de0+4r, high half: de0+4r+2} in the "even" set and {+1, +3} in the "odd" set.
+// Every register of a lane advances two cells with one packed instruction sequence and the per-step costs (loop
+// control, base streams, cross-lane shifts, store) are shared by the R registers, so the kernel is instantiated with
+// few lanes and many registers per problem: LPP = 1 (a whole problem per lane, 64 problems per wave, no cross-lane
+// traffic at all) for bands up to 32 diagonals, LPP = 2 / 4 above.  The loop is unrolled by two steps (even step 2k,
+// odd step 2k+1), which is exactly one row of trace-back dwords: tb32[k*RW + l*R + r], RW = LPP*R, bytes
+// {even pair 0, even pair 1, odd pair 0, odd pair 1}.
+template <int R> __device__ __forceinline__ void d_push_q(uint32_t (&qb)[R], uint32_t v)
 {
-    constexpr int PPW = 64 / LPP;
+#pragma unroll
+    for (int r = R - 1; r >= 1; --r) qb[r] = __builtin_amdgcn_alignbit(qb[r], qb[r - 1], 16);
+    qb[0] = (qb[0] << 16) | v;
+}
+template <int R> __device__ __forceinline__ void d_push_t(uint32_t (&tb)[R], uint32_t v)
+{
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) tb[r] = __builtin_amdgcn_alignbit(tb[r + 1], tb[r], 16);
+    tb[R - 1] = (tb[R - 1] >> 16) | (v << 16);
+}
+
+// EXT = z-drop extension from (0,0) instead of a global fill (oracle band_dp, ext=1): after every step the maximum H
+// of the anti-diagonal (smallest diagonal among ties) updates the best cell and the z-drop test may retire the problem.
+// Bases past the end of a window carry bit 3 in their code, which keeps the cells beyond row m / column n out of the
+// maximum (they never feed a cell inside the matrix).
+template <int LPP, int R> __device__ __forceinline__ int d_pk_rowmax(const uint32_t (&hv)[R])
+{
+    uint32_t M = hv[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) M = pk_max(M, hv[r]);
+    int lo = (int)(short)(M & 0xffffu), hi = (int)M >> 16, cur = lo > hi ? lo : hi;
+#pragma unroll
+    for (int s = 1; s < LPP; s <<= 1) { const int v = __shfl_xor(cur, s); cur = v > cur ? v : cur; }
+    return cur;
+}
+// smallest diagonal of the problem whose (valid) H equals cur; par = parity of the step
+template <int LPP, int R> __device__ __forceinline__ int d_pk_argd(const uint32_t (&hv)[R], int cur, int de0, int par)
+{
+    int d = 0x7fffffff;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r) {
+        const int lo = (int)(short)(hv[r] & 0xffffu), hi = (int)hv[r] >> 16;
+        if (hi == cur) d = de0 + 4 * r + 2 + par;
+        if (lo == cur) d = de0 + 4 * r + par;
+    }
+#pragma unroll
+    for (int s = 1; s < LPP; s <<= 1) { const int v = __shfl_xor(d, s); d = v < d ? v : d; }
+    return d;
+}
+// interior cells (i >= 1, j >= 1) of anti-diagonal a inside the band and the matrix
+__device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dhi)
+{
+    int lo = dlo > a - 2 * m ? dlo : a - 2 * m; if (2 - a > lo) lo = 2 - a;
+    int hi = dhi < 2 * n - a ? dhi : 2 * n - a; if (a - 2 < hi) hi = a - 2;
+    if ((lo - a) & 1) ++lo;
+    return hi >= lo ? ((hi - lo) >> 1) + 1 : 0;
+}
+
+template <int LPP, int R, bool EXT>
+__device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob)
+{
+    constexpr int RW = LPP * R;
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
-    const int pi = blockIdx.x * PPW + sub;
-    const bool have = pi < A.nlist;
-    const int prob = A.list[have ? pi : 0];
+    const int pi = first_prob + sub;
+    const bool have = pi < nlist;
+    const int prob = list[have ? pi : 0];
     const DpProb P = A.probs[prob];
     const DpOpt o = A.o;
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
     c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.nambi = pk_dup(-o.sc_ambi);
     const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo;
-    const int de0 = dlo + 4 * l;                       // even diagonal of pair 0; pair 1: de0+2
-    uint32_t He = PK_NEG, E1e = PK_NEG, E2e = PK_NEG, F1e = PK_NEG, F2e = PK_NEG;
-    uint32_t Ho = PK_NEG, E1o = PK_NEG, E2o = PK_NEG, F1o = PK_NEG, F2o = PK_NEG;
-    if (de0 == 0) He = (He & 0xffff0000u);             // H(0,0) = 0
-    if (de0 + 2 == 0) He = (He & 0x0000ffffu);
-    const int qs_ = P.qstep, ts_ = P.tstep;
-    int amax = m + n;
+    const int de0 = dlo + 4 * R * l;                   // lowest (even) diagonal of this lane
+    const int dhi = have ? P.dhi : dlo - 1;            // diagonals above dhi are outside the band: their H / F stay -inf
+    uint32_t He[R], E1e[R], E2e[R], F1e[R], F2e[R], Ho[R], E1o[R], E2o[R], F1o[R], F2o[R], inE[R], inO[R], qb[R], tbv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        He[r] = E1e[r] = E2e[r] = F1e[r] = F2e[r] = Ho[r] = E1o[r] = E2o[r] = F1o[r] = F2o[r] = PK_NEG;
+        const int d0 = de0 + 4 * r;
+        if (d0 == 0) He[r] &= 0xffff0000u;             // H(0,0) = 0
+        if (d0 + 2 == 0) He[r] &= 0x0000ffffu;
+        inE[r] = (d0 <= dhi ? 0x0000ffffu : 0u) | (d0 + 2 <= dhi ? 0xffff0000u : 0u);
+        inO[r] = (d0 + 1 <= dhi ? 0x0000ffffu : 0u) | (d0 + 3 <= dhi ? 0xffff0000u : 0u);
+        qb[r] = 0; tbv[r] = 0;
+    }
+    const int mn = m + n;
+    int amax = mn;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
-    uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off);
-    const int last_row = have ? (m + n) >> 1 : -1, mn = m + n;
-    // base streams: query rows enter at pair 0 (low half), target columns at pair 1 (high half)
+    uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off) + l * R;
+    const int last_row = have ? mn >> 1 : -1;
+    // base streams: the newest query base enters register 0 (low half) and ages towards register R-1, the newest
+    // target base enters register R-1 (high half) and ages towards register 0
+    const int qs_ = P.qstep, ts_ = P.tstep;
     BaseStream QS, TS;
-    int qleft = 32, tleft = 32;
-    d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, -(de0 >> 1) - 2, P.qcomp, A.qtot);
+    d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, -(de0 >> 1) - 2 * R, P.qcomp, A.qtot);
     d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, (de0 >> 1) - 1, 0, A.ttot);
-    uint32_t qb = 0, tbv = 0;
-    qb = (qb << 16) | (uint32_t)d_stream_next(QS); qb = (qb << 16) | (uint32_t)d_stream_next(QS); qleft -= 2;
-    tbv = (tbv >> 16) | ((uint32_t)d_stream_next(TS) << 16); tbv = (tbv >> 16) | ((uint32_t)d_stream_next(TS) << 16); tleft -= 2;
-    uint32_t tbw = 0, fin = PK_NEG;
-    const bool first = LPP < 64 && l == 0, last = LPP < 64 && l == LPP - 1;
-    // diagonals above dhi are outside the band: their H / F (what an in-band neighbour reads) stay -inf
-    const int dhi = have ? P.dhi : dlo - 1;
-    const uint32_t inE = (de0 <= dhi ? 0x0000ffffu : 0u) | (de0 + 2 <= dhi ? 0xffff0000u : 0u);
-    const uint32_t inO = (de0 + 1 <= dhi ? 0x0000ffffu : 0u) | (de0 + 3 <= dhi ? 0xffff0000u : 0u);
-    for (int a = 1; a <= amax; ++a) {
-        uint32_t h, ve1, vf1, ve2, vf2, t;
-        if (a & 1) {
-            // ---- odd step: odd diagonals (de0+1, de0+3); new target base enters the high half
-            if (tleft == 0) { d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, ((a + de0 + 1) >> 1), 0, A.ttot); tleft = 32; }
-            tbv = (tbv >> 16) | ((uint32_t)d_stream_next(TS) << 16); --tleft;
-            uint32_t nh = DPP_SHL1((int)PK_NEG, (int)He), nf1 = DPP_SHL1((int)PK_NEG, (int)F1e), nf2 = DPP_SHL1((int)PK_NEG, (int)F2e);
-            if (last) { nh = PK_NEG; nf1 = PK_NEG; nf2 = PK_NEG; }
-            // up neighbour of pair r is the even diagonal of pair r+1: {low: own high half, high: next lane's low half}
-            const uint32_t hu = __builtin_amdgcn_alignbit(nh, He, 16), f1u = __builtin_amdgcn_alignbit(nf1, F1e, 16), f2u = __builtin_amdgcn_alignbit(nf2, F2e, 16);
-            t = d_cell_pk(c, Ho, He, E1e, E2e, hu, f1u, f2u, qb, tbv, h, ve1, vf1, ve2, vf2);
-            Ho = (h & inO) | (PK_NEG & ~inO); E1o = ve1; F1o = (vf1 & inO) | (PK_NEG & ~inO); E2o = ve2; F2o = (vf2 & inO) | (PK_NEG & ~inO);
-        } else {
-            // ---- even step: even diagonals (de0, de0+2); new query base enters the low half
+#pragma unroll
+    for (int z = 0; z < 2 * R; ++z) {
+        uint32_t qv = (uint32_t)d_stream_next(QS), tv = (uint32_t)d_stream_next(TS);
+        if (EXT) { if (-(de0 >> 1) - 2 * R + z >= m) qv |= 8u; if ((de0 >> 1) - 1 + z >= n) tv |= 8u; }
+        d_push_q<R>(qb, qv); d_push_t<R>(tbv, tv);
+    }
+    int qleft = 32 - 2 * R, tleft = 32 - 2 * R;
+    int best = 0, bi = 0, bj = 0, prev_cur = -16384, done = have ? 0 : 1, ncell = 0;
+    const int zdrop = o.zdrop;
+    const bool first = l == 0, last = l == LPP - 1;
+    // which register / half holds the final diagonal n-m (its parity is the parity of m+n)
+    const int xf = (n - m) - de0;
+    const bool fin_here = have && xf >= 0 && xf < 4 * R;
+    const int fin_r = xf >> 2, fin_hi = (xf >> 1) & 1;
+    uint32_t fin = PK_NEG, te[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) te[r] = 0;
+    // step 1 (odd) fills the odd half of row 0; afterwards every trip does the even step 2k and the odd step 2k+1
+    for (int k = 0; 2 * k <= amax; ++k) {
+        uint32_t h, ve1, vf1, ve2, vf2;
+        if (k > 0) {
+            const int a = 2 * k;
             if (qleft == 0) { d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, ((a - de0) >> 1) - 1, P.qcomp, A.qtot); qleft = 32; }
-            qb = (qb << 16) | (uint32_t)d_stream_next(QS); --qleft;
-            uint32_t ph = DPP_SHR1((int)PK_NEG, (int)Ho), pe1 = DPP_SHR1((int)PK_NEG, (int)E1o), pe2 = DPP_SHR1((int)PK_NEG, (int)E2o);
-            if (first) { ph = PK_NEG; pe1 = PK_NEG; pe2 = PK_NEG; }
-            // left neighbour of pair r is the odd diagonal of pair r-1: {low: previous lane's high half, high: own low half}
-            const uint32_t hl = __builtin_amdgcn_alignbit(Ho, ph, 16), e1l = __builtin_amdgcn_alignbit(E1o, pe1, 16), e2l = __builtin_amdgcn_alignbit(E2o, pe2, 16);
-            t = d_cell_pk(c, He, hl, e1l, e2l, Ho, F1o, F2o, qb, tbv, h, ve1, vf1, ve2, vf2);
-            He = (h & inE) | (PK_NEG & ~inE); E1e = ve1; F1e = (vf1 & inE) | (PK_NEG & ~inE); E2e = ve2; F2e = (vf2 & inE) | (PK_NEG & ~inE);
+            { uint32_t qv = (uint32_t)d_stream_next(QS); if (EXT && ((a - de0) >> 1) - 1 >= m) qv |= 8u; d_push_q<R>(qb, qv); } --qleft;
+            uint32_t ph = PK_NEG, pe1 = PK_NEG, pe2 = PK_NEG;
+            if (LPP > 1) {
+                ph = DPP_SHR1((int)PK_NEG, (int)Ho[R - 1]); pe1 = DPP_SHR1((int)PK_NEG, (int)E1o[R - 1]); pe2 = DPP_SHR1((int)PK_NEG, (int)E2o[R - 1]);
+                if (first) { ph = PK_NEG; pe1 = PK_NEG; pe2 = PK_NEG; }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // left neighbour: odd diagonal below -> {low: previous register's high half, high: own low half}
+                const uint32_t lh = r ? Ho[r - 1] : ph, le1 = r ? E1o[r - 1] : pe1, le2 = r ? E2o[r - 1] : pe2;
+                const uint32_t hl = __builtin_amdgcn_alignbit(Ho[r], lh, 16), e1l = __builtin_amdgcn_alignbit(E1o[r], le1, 16), e2l = __builtin_amdgcn_alignbit(E2o[r], le2, 16);
+                te[r] = d_cell_pk(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); E1e[r] = ve1; F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); E2e[r] = ve2; F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]);
+                if (!EXT && a == mn && r == fin_r) fin = h;
+            }
+            if (EXT) {
+                uint32_t hv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) hv[r] = pk_sel(pk_sign(PKU(PKS(qb[r] | tbv[r]) << (pk_s2)(12))), PK_NEG, He[r]);
+                const int cur = d_pk_rowmax<LPP, R>(hv);
+                if (!done) {
+                    if (cur > best) { const int cd = d_pk_argd<LPP, R>(hv, cur, de0, 0); best = cur; bi = (a - cd) >> 1; bj = (a + cd) >> 1; }
+                    ncell += d_step_cells(a, m, n, dlo, dhi);
+                    if (best - (cur > prev_cur ? cur : prev_cur) > zdrop || a >= mn) done = 1;
+                }
+                prev_cur = cur;
+            }
         }
-        if (a == mn) fin = h;                          // the last anti-diagonal of THIS problem holds H(m,n)
-        // two bytes (pair 0, pair 1) of this step
-        const uint32_t b16 = __builtin_amdgcn_perm(0u, t, 0x0c0c0200u);
-        tbw |= b16 << (16 * (a & 1));
-        if ((a & 1) || a == amax) {
-#ifndef EXP_NOSTORE
-            if ((a >> 1) <= last_row) tb32[(int64_t)(a >> 1) * LPP + l] = tbw;
-#else
-            if (tbw == 0x12345678u && (a >> 1) <= last_row) tb32[(int64_t)(a >> 1) * LPP + l] = tbw;
+        {
+            const int a = 2 * k + 1;
+            if (tleft == 0) { d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, ((a + de0 + 1) >> 1) + 2 * R - 2, 0, A.ttot); tleft = 32; }
+            { uint32_t tv = (uint32_t)d_stream_next(TS); if (EXT && ((a + de0 + 1) >> 1) + 2 * R - 2 >= n) tv |= 8u; d_push_t<R>(tbv, tv); } --tleft;
+            uint32_t nh = PK_NEG, nf1 = PK_NEG, nf2 = PK_NEG;
+            if (LPP > 1) {
+                nh = DPP_SHL1((int)PK_NEG, (int)He[0]); nf1 = DPP_SHL1((int)PK_NEG, (int)F1e[0]); nf2 = DPP_SHL1((int)PK_NEG, (int)F2e[0]);
+                if (last) { nh = PK_NEG; nf1 = PK_NEG; nf2 = PK_NEG; }
+            }
+            uint32_t row[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                // up neighbour: even diagonal above -> {low: own high half, high: next register's low half}
+                const uint32_t uh = r < R - 1 ? He[r + 1] : nh, uf1 = r < R - 1 ? F1e[r + 1] : nf1, uf2 = r < R - 1 ? F2e[r + 1] : nf2;
+                const uint32_t hu = __builtin_amdgcn_alignbit(uh, He[r], 16), f1u = __builtin_amdgcn_alignbit(uf1, F1e[r], 16), f2u = __builtin_amdgcn_alignbit(uf2, F2e[r], 16);
+                const uint32_t t = d_cell_pk(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); E1o[r] = ve1; F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); E2o[r] = ve2; F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]);
+                if (!EXT && a == mn && r == fin_r) fin = h;
+                row[r] = __builtin_amdgcn_perm(t, te[r], 0x06040200u);
+            }
+            if (EXT) {
+                uint32_t hv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) hv[r] = pk_sel(pk_sign(PKU(PKS(qb[r] | tbv[r]) << (pk_s2)(12))), PK_NEG, Ho[r]);
+                const int cur = d_pk_rowmax<LPP, R>(hv);
+                if (!done) {
+                    if (cur > best) { const int cd = d_pk_argd<LPP, R>(hv, cur, de0, 1); best = cur; bi = (a - cd) >> 1; bj = (a + cd) >> 1; }
+                    ncell += d_step_cells(a, m, n, dlo, dhi);
+                    if (best - (cur > prev_cur ? cur : prev_cur) > zdrop || a >= mn) done = 1;
+                }
+                prev_cur = cur;
+            }
+            if (k <= last_row) {
+                uint32_t *dst = tb32 + (int64_t)k * RW;
+                if constexpr (R % 4 == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; r += 4) *(uint4*)(dst + r) = make_uint4(row[r], row[r + 1], row[r + 2], row[r + 3]);
+                } else if constexpr (R % 2 == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; r += 2) *(uint2*)(dst + r) = make_uint2(row[r], row[r + 1]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dst[r] = row[r];
+                }
+            }
+        }
+        if (EXT && __all(done)) break;
+    }
+    if (EXT) {
+        if (have && l == 0) {
+            DpRes Rr; Rr.score = best; Rr.bi = bi; Rr.bj = bj; Rr.nops = 0; Rr.mlen = 0; Rr.cells = ncell; Rr.tbases = n; Rr.mcols = 0;
+            A.res[prob] = Rr;
+        }
+        return;
+    }
+    if (fin_here) {
+        const int sc = (int)(short)(fin_hi ? (fin >> 16) : (fin & 0xffffu));
+        DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0;
+        A.res[prob] = Rr;
+    }
+}
+
+// All packed classes run as ONE launch: a wave is described by (class, first problem of its class list) and the
+// wave table is ordered by decreasing estimated cost (steps x registers per lane), so the long waves start first and
+// no class leaves the machine idle behind its own tail.
+#define PK_NC 8                            /* packed fill classes 10 .. 10+PK_NC-1 */
+__device__ __constant__ const int PK_LPP[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 4 };
+__device__ __constant__ const int PK_R[PK_NC]   = { 5, 6, 7, 8, 5, 6, 8, 8 };
+struct PkPlan { int32_t woff[PK_NC + 1]; };   // first wave of class 10+c in the unsorted wave table
+__global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__restrict__ cls_list, int32_t np, PkPlan plan,
+                           uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plan.woff[PK_NC]) return;
+    int c = 0;
+    while (i >= plan.woff[c + 1]) ++c;
+    const int first = (i - plan.woff[c]) * (64 / PK_LPP[c]);
+    const DpProb P = probs[cls_list[(int64_t)(10 + c) * np + first]];     // lists are sorted by decreasing steps
+    keys[i] = (uint32_t)((P.m + P.n) * PK_R[c]);
+    vals[i] = (uint32_t)(10 + c) << 26 | (uint32_t)first;
+}
+#ifndef PK_WPE
+#define PK_WPE 2
 #endif
-            tbw = 0;
-        }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE))) k_dp_pk(DpArgs A, const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list,
+                                              const int32_t *__restrict__ cls_cnt, int32_t np)
+{
+    const uint32_t w = waves[blockIdx.x];
+    const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
+    const int32_t *list = cls_list + (int64_t)cls * np;
+    const int n = cls_cnt[cls];
+    switch (cls) {
+    case 10: d_dp_pkr<1, 5, false>(A, list, n, first); break;
+    case 11: d_dp_pkr<1, 6, false>(A, list, n, first); break;
+    case 12: d_dp_pkr<1, 7, false>(A, list, n, first); break;
+    case 13: d_dp_pkr<1, 8, false>(A, list, n, first); break;
+    case 14: d_dp_pkr<2, 5, false>(A, list, n, first); break;
+    case 15: d_dp_pkr<2, 6, false>(A, list, n, first); break;
+    case 16: d_dp_pkr<2, 8, false>(A, list, n, first); break;
+    default: d_dp_pkr<4, 8, false>(A, list, n, first); break;
     }
-    if (have) {
-        const int xf = (n - m) - de0;                  // final diagonal inside this lane's block of four?
-        if (xf >= 0 && xf < 4) {
-            // its parity equals the parity of m+n, i.e. of the step that produced `fin`; pair = xf>>1
-            const int sc = (int)(short)((xf >> 1) ? (fin >> 16) : (fin & 0xffffu));
-            if (A.fused_tb) { DpRes *rp = &A.res[prob]; rp->score = sc; rp->bi = m; rp->bj = n; rp->cells = P.pad[1]; rp->tbases = n; }
-            else { DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0; A.res[prob] = Rr; }
-        }
-    }
-    if (!A.fused_tb) return;
-    // ---- fused trace-back: lane 0 of every problem walks the bytes the wave has just written (served from
-    // L2 with sc1 loads); the walk is pure latency and overlaps with the arithmetic of the other resident waves
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (have && l == 0) {
-        const uint8_t *tb = A.tb + P.tb_off;
-        const int dhi_ = P.dhi;
-        int i = m, j = n, no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0, touched = 0;
-        uint32_t *cg = A.cig + P.cig_off;
-        while (i > 0 && j > 0) {
-            const int a = i + j, sl = (j - i - dlo) >> 1;
-            const uint32_t t = __hip_atomic_load(tb + ((((int64_t)(a >> 1) * LPP + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            touched |= (j - i == dlo) | (j - i == dhi_);
-            if (state == 0) state = t & 7;
-            int op;
-            if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
-            else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
-            else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
-            else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
-            else                 { op = 1; if (!(t & 64)) state = 0; --i; }
-            if (op == cur_op) ++cur_len;
-            else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
-        }
-        if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
-        if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
-        if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
-        // the result record is written by the lane that owns the final diagonal; these three fields are ours
-        __hip_atomic_store(&A.res[prob].nops, no, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&A.res[prob].mlen, ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&A.res[prob].mcols, mc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (A.retry && touched && m + n <= ADAPT_MAX_STEPS) A.retry[prob] = 1;
-    }
+}
+// z-drop extensions (class 18): their own launch on a side stream; four lanes per problem keep the single-wave
+// latency of the long windows down
+#define PKX_LPP 4
+#define PKX_R 4
+__global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
+{
+    __builtin_amdgcn_s_setprio(3);
+    d_dp_pkr<PKX_LPP, PKX_R, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX_LPP));
 }
 
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
 // run-length CIGAR in end->start order (64 independent pointer chases per wave).
+// `list` (optional) restricts the launch to the problems of one class list.
 __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
-                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry, int skip_pk)
+                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
+                                                  const int32_t *__restrict__ list)
 {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= np) return;
+    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= np) return;
+    const int pi = list ? list[ti] : ti;
     const DpProb P = probs[pi];
     if (P.kind >= 3) return;
-    if (skip_pk && P.pad[0] >= 10) return;          // walked inside k_dp_pk
     const int dhi_ = P.dhi; int touched = 0;
     const int cls = P.pad[0], dlo = P.dlo;
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;

@@ -25,10 +25,10 @@
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
     "sketch", "seed", "sort", "chain", "backtrack", "select_host", "segments", "dp", "stitch_d2h", "d2h", "assemble_host", "index_build",
-    "k_dp_pk16_pk32_reg", "map_wall", "k_traceback", "k_dp_pk_8"
+    "k_dp_reg", "map_wall", "k_traceback", "k_dp_pk"
 };
 enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMENTS, ST_DP, ST_GATHER, ST_D2H, ST_ASSEMBLE, ST_INDEX,
-       ST_K_REG32, ST_MAP_WALL, ST_K_TRACEBACK, ST_K_PK16 };
+       ST_K_REG, ST_MAP_WALL, ST_K_TRACEBACK, ST_K_PK };
 
 #define TELR_NSIDE 8
 struct DBuf { void *p = nullptr; size_t bytes = 0; };
@@ -635,9 +635,13 @@ static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
     if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
 }
 
-static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0)
+static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0, int pk_ext_steps = 0)
 {
-    if (kind == 0 && steps <= pk_max_steps) { if (D <= 32) return 12; if (D <= 64) return 10; if (D <= 128) return 11; }
+    if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
+    if (kind == 0 && steps <= pk_max_steps) {
+        if (D <= 20) return 10; if (D <= 24) return 11; if (D <= 28) return 12; if (D <= 32) return 13;
+        if (D <= 40) return 14; if (D <= 48) return 15; if (D <= 64) return 16; if (D <= 128) return 17;
+    }
     if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
@@ -687,6 +691,14 @@ static inline int pk_steps_limit(const telr_map_opt *mo)
 {
     return (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
 }
+// longest z-drop extension window (m+n) the packed int16 kernel takes: scores stay inside +-16000
+static inline int pk_ext_limit(const telr_map_opt *mo)
+{
+    if (!pk_steps_limit(mo) || mo->zdrop > 4000 || getenv("TELR_NO_PKEXT")) return 0;
+    const int by_b = 2 * (15800 - mo->q2 - 64 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
+    const int lim = by_b < by_a ? by_b : by_a;
+    return lim > 0 ? lim : 0;
+}
 static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, const telr_map_opt *mo, DpProb *d_probs, int np, DpRes *d_res,
                    uint32_t **d_rawcig_io, int32_t *d_retry, const std::string &sfx, bool primary)
 {
@@ -696,24 +708,25 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cig_ops" + sfx).c_str(), (size_t)np + 1, &d_cgo));
     TRY(ctx_buf_t(ctx, ("tb_off" + sfx).c_str(), (size_t)np + 1, &d_tboff));
     TRY(ctx_buf_t(ctx, ("cig_off" + sfx).c_str(), (size_t)np + 1, &d_cgoff));
-    TRY(ctx_buf_t(ctx, ("cls_cnt" + sfx).c_str(), 16, &d_clscnt));
+    TRY(ctx_buf_t(ctx, ("cls_cnt" + sfx).c_str(), 32, &d_clscnt));
     TRY(ctx_buf_t(ctx, ("cls_list" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clslist));
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), d_tbb, d_cgo);
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), d_tbb, d_cgo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
     TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbb, d_tboff, (size_t)np + 1)));
     if (primary) TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_cgo, d_cgoff, (size_t)np + 1)));
-    HIPCHK(hipMemsetAsync(d_clscnt, 0, 64, st));
+    HIPCHK(hipMemsetAsync(d_clscnt, 0, 128, st));
     hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, primary ? d_cgoff : (const int64_t*)nullptr, d_clscnt, d_clslist, d_clskey);
     HIPCHK(hipGetLastError());
-    int64_t tb_total = 0, cg_total = 0; int32_t h_cls[16];
+    int64_t tb_total = 0, cg_total = 0; int32_t h_cls[32];
+    static_assert(DP_NCLS <= 32 && DP_NCLS == TELR_N_DPCLS, "class table");
     HIPCHK(hipMemcpyAsync(&tb_total, d_tboff + np, 8, hipMemcpyDeviceToHost, st));
     if (primary) HIPCHK(hipMemcpyAsync(&cg_total, d_cgoff + np, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     // sort every sizeable class list by decreasing step count
     for (int c = 0; c < DP_NCLS; ++c) {
@@ -732,14 +745,49 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
     D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
     D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
-    D.fused_tb = getenv("TELR_FUSED_TB") ? 1 : 0; D.retry = d_retry;   // measured slower on MI355X (+12 ms forward, -6 ms trace-back): opt-in
+    D.retry = d_retry;
     static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
+    // trace-back per class list, right behind the class's forward kernel on the same stream (TELR_TB_SPLIT=0: one
+    // trace-back launch over all problems after every forward kernel has finished)
+    static const bool tb_split = !(getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0);
+    // wave table of the packed launch (all packed classes in one launch, waves ordered by decreasing cost); built
+    // before the tail classes are started so that these two small launches do not queue behind them
+    int nw = 0; uint32_t *d_wv2 = nullptr;
+    {
+        static const int LPP_[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 4 };
+        PkPlan plan; plan.woff[0] = 0;
+        for (int c = 0; c < PK_NC; ++c) { const int ppw = 64 / LPP_[c]; plan.woff[c + 1] = plan.woff[c] + (h_cls[10 + c] + ppw - 1) / ppw; }
+        nw = plan.woff[PK_NC];
+        if (nw > 0) {
+            uint32_t *d_wk, *d_wv, *d_wk2;
+            TRY(ctx_buf_t(ctx, ("pk_wkey" + sfx).c_str(), (size_t)nw, &d_wk));
+            TRY(ctx_buf_t(ctx, ("pk_wval" + sfx).c_str(), (size_t)nw, &d_wv));
+            TRY(ctx_buf_t(ctx, ("pk_wkey2" + sfx).c_str(), (size_t)nw, &d_wk2));
+            TRY(ctx_buf_t(ctx, ("pk_wval2" + sfx).c_str(), (size_t)nw, &d_wv2));
+            hipLaunchKernelGGL(k_pk_waves, dim3((nw + 255) / 256), dim3(256), 0, st, d_probs, d_clslist, np, plan, d_wk, d_wv);
+            HIPCHK(hipGetLastError());
+            size_t tbytes = 0;
+            HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 14, st));
+            void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
+            HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 14, st));
+        }
+    }
     // The few long/wide problems are latency-bound single waves: start each tail class on its own side
     // stream so that they run underneath the bulk classes on the main stream.
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     int side = 0;
     std::vector<hipStream_t> used;
-    auto side_stream = [&]() { hipStream_t s2 = ctx->side[side % TELR_NSIDE]; ++side; used.push_back(s2); return s2; };
+    static const bool serial = getenv("TELR_SERIAL") != nullptr;      // profiling aid: every class on the main stream
+    auto side_stream = [&]() { if (serial) return st; hipStream_t s2 = ctx->side[side % TELR_NSIDE]; ++side; used.push_back(s2); return s2; };
+    if (h_cls[18]) {
+        hipStream_t s2 = side_stream();
+        HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        D.list = d_clslist + (size_t)18 * np; D.nlist = h_cls[18];
+        const int ppw = 64 / PKX_LPP;
+        hipLaunchKernelGGL(k_dp_pkx, dim3((h_cls[18] + ppw - 1) / ppw), dim3(64), 0, s2, D);
+        HIPCHK(hipGetLastError());
+        if (tb_split) hipLaunchKernelGGL(k_traceback, dim3((h_cls[18] + 63) / 64), dim3(64), 0, s2, d_probs, d_res, h_cls[18], d_tb, *d_rawcig_io, d_retry, D.list);
+    }
     for (int c = 4; c >= 0; --c) {
         if (h_cls[c] == 0) continue;
         hipStream_t s2 = side_stream();
@@ -749,6 +797,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, s2, D);
         HIPCHK(hipGetLastError());
+        if (tb_split) hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, s2, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, D.list);
     }
     D.dcap = 0;
     for (int c = 9; c >= 7; --c) {
@@ -760,23 +809,36 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         else if (c == 8) hipLaunchKernelGGL((k_dp_reg<64, 4>), dim3(h_cls[c]), dim3(64), 0, s2, D);
         else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
         HIPCHK(hipGetLastError());
+        if (tb_split) hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, s2, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, D.list);
     }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[5], st));
-    if (h_cls[12]) { D.list = d_clslist + (size_t)12 * np; D.nlist = h_cls[12]; hipLaunchKernelGGL((k_dp_pk<8>), dim3((h_cls[12] + 7) / 8), dim3(64), 0, st, D); }
+    if (nw > 0) {
+        D.list = nullptr; D.nlist = 0;
+        hipLaunchKernelGGL(k_dp_pk, dim3(nw), dim3(64), 0, st, D, d_wv2, d_clslist, d_clscnt, np);
+        HIPCHK(hipGetLastError());
+    }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[0], st));
-    if (h_cls[10]) { D.list = d_clslist + (size_t)10 * np; D.nlist = h_cls[10]; hipLaunchKernelGGL((k_dp_pk<16>), dim3((h_cls[10] + 3) / 4), dim3(64), 0, st, D); }
-    if (h_cls[11]) { D.list = d_clslist + (size_t)11 * np; D.nlist = h_cls[11]; hipLaunchKernelGGL((k_dp_pk<32>), dim3((h_cls[11] + 1) / 2), dim3(64), 0, st, D); }
     if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
     if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[1], st));
+    if (tb_split) {
+        if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
+        for (int c = 17; c >= 5; --c) {
+            if (h_cls[c] == 0 || (c >= 7 && c <= 9)) continue;
+            hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, st, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, (const int32_t*)(d_clslist + (size_t)c * np));
+        }
+        if (primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
+    }
     HIPCHK(hipGetLastError());
     for (size_t u = 0; u < used.size(); ++u) {
         HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
     }
-    if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
-    hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, *d_rawcig_io, d_retry, D.fused_tb);
-    if (primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
+    if (!tb_split) {
+        if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
+        hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, *d_rawcig_io, d_retry, (const int32_t*)nullptr);
+        if (primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
+    }
     HIPCHK(hipGetLastError());
     return TELR_OK;
 }
@@ -1049,8 +1111,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipMemcpyAsync(&n_retry, d_rcnt, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         { float ms = 0;
-          if (hipEventElapsedTime(&ms, ctx->evk[5], ctx->evk[0]) == hipSuccess) ctx->stage_ms[ST_K_PK16] += ms;
-          if (hipEventElapsedTime(&ms, ctx->evk[0], ctx->evk[1]) == hipSuccess) ctx->stage_ms[ST_K_REG32] += ms;
+          if (hipEventElapsedTime(&ms, ctx->evk[5], ctx->evk[0]) == hipSuccess) ctx->stage_ms[ST_K_PK] += ms;
+          if (hipEventElapsedTime(&ms, ctx->evk[0], ctx->evk[1]) == hipSuccess) ctx->stage_ms[ST_K_REG] += ms;
           if (hipEventElapsedTime(&ms, ctx->evk[3], ctx->evk[4]) == hipSuccess) ctx->stage_ms[ST_K_TRACEBACK] += ms; }
         if (n_retry > 0) {
             DpProb *d_probs2; DpRes *d_res2;
@@ -1080,7 +1142,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             parallel_ranges(NT, np, [&](int t, int a0, int a1) { int64_t c = 0, w = 0; for (int i = a0; i < a1; ++i) { c += h_res[i].cells; w += h_res[i].tbases; } pc[t] += c; pw[t] += w; });
             for (int t = 0; t < NT; ++t) { ctx->ctr.dp_cells += pc[t]; ctx->ctr.window_bases += pw[t]; }
         }
-        const int pk_max_steps_h = pk_steps_limit(mo);
+        const int pk_max_steps_h = pk_steps_limit(mo), pk_ext_steps_h = pk_ext_limit(mo);
         std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
         std::vector<int64_t*> tcls(NT);
         for (int t = 0; t < NT; ++t) tcls[t] = tcls_store.data() + (size_t)t * TELR_N_DPCLS * 4;
@@ -1097,7 +1159,12 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                     const DpRes &d = h_res[z];
                     const bool is_ext = (z == p && has_left) || (z == pend - 1 && has_right);
                     int cls;
-                    if (is_ext) cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band));
+                    if (is_ext) {
+                        const bool left = z == p && has_left;
+                        const int rq = left ? c.qs : qlen - c.qe, rt = left ? c.rs : tlen - c.re;
+                        const int mq = rq < mo->ext_max ? rq : mo->ext_max, mt = rt < mq + mo->ext_band ? rt : mq + mo->ext_band;
+                        cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band), mq + mt, pk_max_steps_h, pk_ext_steps_h);
+                    }
                     else {
                         const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
                         int W = TELR_W0 + (mn >> TELR_WSH); if (W > mo->bw) W = mo->bw;

@@ -1482,11 +1482,17 @@ __global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
 // run-length CIGAR in end->start order (64 independent pointer chases per wave).
 // `list` (optional) restricts the launch to the problems of one class list.
+// The bytes of one problem are visited in (almost) decreasing address order, a few per 64-byte line, so every lane
+// keeps the two lines it is walking through in LDS (slot = line parity; dword k of lane l at word k*64+l:
+// conflict-free byte reads) and fetches the next lower line into registers ahead of time: memory is touched once
+// per line instead of once per step, and a line is normally there before the walk reaches it.
 __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
                                                   const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                   const int32_t *__restrict__ list)
 {
-    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t stage[2 * 16 * 64];
+    const int lane = threadIdx.x;
+    const int ti = blockIdx.x * blockDim.x + lane;
     if (ti >= np) return;
     const int pi = list ? list[ti] : ti;
     const DpProb P = probs[pi];
@@ -1500,10 +1506,28 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     int i = res[pi].bi, j = res[pi].bj;
     uint32_t *cg = cig + P.cig_off;
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
+    int64_t tag0 = -1, tag1 = -1, pf = -2;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
     while (i > 0 && j > 0) {
         const int a = i + j, sl = (j - i - dlo) >> 1;
-        const uint32_t t = cls >= 10 ? tb[(((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)]
-                         : packed ? tb[(((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)] : tb[(int64_t)a * stride + sl];
+        const int64_t off = cls >= 10 ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
+                          : packed ? ((((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)) : ((int64_t)a * stride + sl);
+        // tb_off is a multiple of 16 only, so lines are taken relative to the 64-byte grid of the whole scratch buffer
+        const int64_t abs_off = P.tb_off + off, line = abs_off >> 6;
+        const int slot = (int)(line & 1);
+        if ((slot ? tag1 : tag0) != line) {
+            if (pf != line) { const uint4 *src = (const uint4*)(tb_all + (line << 6)); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+            uint32_t *dst = stage + slot * 1024 + lane;
+            dst[0 * 64] = v0.x; dst[1 * 64] = v0.y; dst[2 * 64] = v0.z; dst[3 * 64] = v0.w;
+            dst[4 * 64] = v1.x; dst[5 * 64] = v1.y; dst[6 * 64] = v1.z; dst[7 * 64] = v1.w;
+            dst[8 * 64] = v2.x; dst[9 * 64] = v2.y; dst[10 * 64] = v2.z; dst[11 * 64] = v2.w;
+            dst[12 * 64] = v3.x; dst[13 * 64] = v3.y; dst[14 * 64] = v3.z; dst[15 * 64] = v3.w;
+            if (slot) tag1 = line; else tag0 = line;
+            pf = line - 1;
+            if (pf >= 0) { const uint4 *src = (const uint4*)(tb_all + (pf << 6)); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+        }
+        const int w = (int)(abs_off & 63);
+        const uint32_t t = (stage[slot * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
         touched |= (j - i == dlo) | (j - i == dhi_);
         if (state == 0) state = t & 7;
         int op;

@@ -668,18 +668,85 @@ static int host_threads()
     cached = n;
     return n;
 }
+// Persistent worker pool for the host phases (spawning ~24 threads per phase costs more than some of the phases).
+// One job at a time; run() hands out task indices 0..n-1 to the workers and the caller and returns when all are done.
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <atomic>
+class HostPool {
+public:
+    static HostPool &get() { static HostPool p; return p; }
+    void run(int ntask, const std::function<void(int)> &f)
+    {
+        if (ntask <= 0) return;
+        std::unique_lock<std::mutex> job(job_mu_);          // serialise callers (sub-batch contexts share the pool)
+        ensure(ntask - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &f; ntask_ = ntask; next_.store(0); pending_ = ntask; ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        // every task done AND every worker back outside work(): nobody can touch the next job's counters with stale state
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0 && active_ == 0; });
+        fn_ = nullptr;
+    }
+private:
+    HostPool() {}
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void ensure(int n) { while ((int)th_.size() < n && (int)th_.size() < 47) th_.emplace_back([this, g = gen_]() mutable { loop(g); }); }
+    void work()
+    {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= ntask_) break;
+            (*fn_)(i);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop(uint64_t seen)
+    {
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (pending_ == 0) continue;        // woke up after the job was already finished by others
+                ++active_;
+            }
+            work();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--active_ == 0 && pending_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int ntask_ = 0, pending_ = 0, active_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
 // run f(t, begin, end) over [0,n) split into nt contiguous ranges (in order of t)
 template <typename F> static void parallel_ranges(int nt, int n, F f)
 {
     if (n <= 0) return;
     if (nt > n) nt = n;
     if (nt <= 1 || n < 64) { f(0, 0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) {
-        int a = (int)((int64_t)n * t / nt), b = (int)((int64_t)n * (t + 1) / nt);
-        th.emplace_back([=, &f]() { f(t, a, b); });
-    }
-    for (auto &x : th) x.join();
+    HostPool::get().run(nt, [&](int t) {
+        const int a = (int)((int64_t)n * t / nt), b = (int)((int64_t)n * (t + 1) / nt);
+        f(t, a, b);
+    });
 }
 
 struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int64_t a_glob; };

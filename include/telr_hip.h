@@ -81,6 +81,8 @@ typedef struct telr_map_opt {
     int32_t ext_max;          /* max bases an end extension may consume on the query   */
     int32_t ext_band;         /* half band width of end extensions                     */
     int32_t flags;            /* TELR_MF_*                                             */
+    int32_t fill_band_q4;     /* first-pass half band of a gap fill: 2 + q4*floor(sqrt(min(m,n)))/16;
+                                 0 = 8.  Paths that touch the band edge are re-aligned with the wide band. */
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */
@@ -206,7 +208,7 @@ int  telr_last_counters(const telr_ctx *ctx, telr_counters *out);
 /* per DP class (TELR_N_DPCLS classes) of the last telr_map call:
  * out[c*4+0] problems, [c*4+1] DP cells, [c*4+2] anti-diagonal steps (sum of m+n),
  * [c*4+3] algorithmic bytes (2-bit bases read once + 4 B per CIGAR run + 32 B result) */
-#define TELR_N_DPCLS 19
+#define TELR_N_DPCLS 22
 int  telr_last_dp_classes(const telr_ctx *ctx, int64_t *out /* [TELR_N_DPCLS*4] */);
 
 #ifdef __cplusplus

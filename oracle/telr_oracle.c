@@ -572,21 +572,33 @@ static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v
     return r;
 }
 
-/* Adaptive band of a gap-fill segment: a narrow first pass; if the optimal path of that pass touches
- * a band edge the segment is re-aligned once with the four times wider band. */
+/* Adaptive band of a gap-fill segment.  First pass: W = 2 + fill_band_q4 * floor(sqrt(min(m,n))) / 16 diagonals either
+ * side of the corner-to-corner diagonal range (indel drift between two anchors grows with the square root of the
+ * distance); if the optimal path of that pass touches a band edge, the segment is re-aligned once with the wide band
+ * (24 + mn/8, flatter above 512), itself limited so that the band stays within 1024 diagonals where the first-pass
+ * width allows it.  Segments with m+n > ADAPT_MAX_STEPS use the wide band at once. */
+static inline int isqrt32(int v)
+{
+    int r = 0;
+    for (int b = 1 << 15; b; b >>= 1) { int t = r | b; if ((int64_t)t * t <= v) r = t; }
+    return r;
+}
 static inline int fill_band(int m, int n, const telr_map_opt *mo)
 {
-    int mn = m < n ? m : n;
-    int W = 3 + (mn >> 5);
+    int mn = m < n ? m : n, q4 = mo->fill_band_q4 > 0 ? mo->fill_band_q4 : 8;
+    int W = 2 + ((q4 * isqrt32(mn)) >> 4);
     return W < mo->bw ? W : mo->bw;
 }
+#define ADAPT_MAX_STEPS 1000      /* m+n above which a segment skips the narrow pass */
 static inline int fill_band_wide(int m, int n, const telr_map_opt *mo)
 {
-    int mn = m < n ? m : n;
+    int mn = m < n ? m : n, dl = n - m, adl = dl < 0 ? -dl : dl;
     int W = mn <= 512 ? 24 + (mn >> 3) : 88 + ((mn - 512) >> 4);
-    return W < mo->bw ? W : mo->bw;
+    if (W > mo->bw) W = mo->bw;
+    int cap = (1022 - adl) / 2, Wn = fill_band(m, n, mo);
+    if (cap < Wn) cap = Wn;
+    return W < cap ? W : cap;
 }
-#define ADAPT_MAX_STEPS 1000      /* longer segments (m+n) skip the narrow pass: they are few and use the wide band at once */
 /* the lower band edge is rounded down to an even diagonal (the GPU pairs diagonals per lane) */
 static inline int even_lo(int lo) { return lo - (lo & 1); }
 
@@ -662,13 +674,9 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         int32_t sr = bp.a[2 * g], sq = bp.a[2 * g + 1], er = bp.a[2 * g + 2], eq = bp.a[2 * g + 3];
         s.m = eq - sq; s.n = er - sr; s.tstep = 1; s.ti0 = sr;
         if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - sq; } else { s.qstep = 1; s.qi0 = sq; }
+        /* long segments are few and a second pass over one of them is slow: they take the wide band at once */
         const int is_long = s.m + s.n > ADAPT_MAX_STEPS;
         int W = is_long ? fill_band_wide(s.m, s.n, mo) : fill_band(s.m, s.n, mo), dl = s.n - s.m;
-        if (is_long) {      /* keep long segments within 1024 diagonals when the narrow band allows it */
-            int adl = dl < 0 ? -dl : dl, cap = (1022 - adl) / 2, Wn = fill_band(s.m, s.n, mo);
-            if (cap < Wn) cap = Wn;
-            if (W > cap) W = cap;
-        }
         rc.n = 0;
         int lo = even_lo((dl < 0 ? dl : 0) - W), hi = (dl > 0 ? dl : 0) + W, fb_mlen;
         dp_res_t r = hi - lo + 1 > DP_DMAX ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);

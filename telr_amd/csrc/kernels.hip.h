@@ -655,30 +655,35 @@ struct DpProb {             // 64 B
 };
 struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, mcols; };   // 32 B; mcols = M columns of the path
 
-#ifndef TELR_W0
-#define TELR_W0 3
-#endif
-#ifndef TELR_WSH
-#define TELR_WSH 5
-#endif
-__device__ __forceinline__ int d_fill_band(int m, int n, int bw)          // narrow first pass
+// first pass: 2 + q4*floor(sqrt(min(m,n)))/16 diagonals of slack; retry (path touched a band edge): the wide band,
+// kept within 1024 diagonals where the first-pass width allows it (oracle: fill_band / fill_band_wide)
+#define ADAPT_MAX_STEPS 1000       // m+n above which a segment skips the narrow pass
+__host__ __device__ __forceinline__ int d_isqrt32(int v)
 {
-    int mn = m < n ? m : n, W = TELR_W0 + (mn >> TELR_WSH);
+    int r = 0;
+    for (int b = 1 << 15; b; b >>= 1) { const int t = r | b; if ((int64_t)t * t <= v) r = t; }
+    return r;
+}
+__host__ __device__ __forceinline__ int d_fill_band(int m, int n, int bw, int q4)
+{
+    const int mn = m < n ? m : n, W = 2 + (((q4 > 0 ? q4 : 8) * d_isqrt32(mn)) >> 4);
     return W < bw ? W : bw;
 }
-__device__ __forceinline__ int d_fill_band_wide(int m, int n, int bw)     // retry when the path touched a band edge
+__host__ __device__ __forceinline__ int d_fill_band_wide(int m, int n, int bw, int q4)
 {
-    int mn = m < n ? m : n;
+    const int mn = m < n ? m : n, dl = n - m, adl = dl < 0 ? -dl : dl;
     int W = mn <= 512 ? 24 + (mn >> 3) : 88 + ((mn - 512) >> 4);
-    return W < bw ? W : bw;
+    if (W > bw) W = bw;
+    int cap = (1022 - adl) / 2; const int Wn = d_fill_band(m, n, bw, q4);
+    if (cap < Wn) cap = Wn;
+    return W < cap ? W : cap;
 }
-#define ADAPT_MAX_STEPS 1000       // longer segments skip the narrow pass and use the wide band at once
 __device__ __forceinline__ int d_even_lo(int lo) { return lo - (lo & 1); }
 
 // PASS 0: count problems per kept chain.  PASS 1: write descriptors.
 template <int PASS>
 __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const uint64_t *__restrict__ canch,
-                           int32_t min_ksw_len, int32_t bw, int32_t ext_max, int32_t ext_band,
+                           int32_t min_ksw_len, int32_t bw, int32_t band_q4, int32_t ext_max, int32_t ext_band,
                            int32_t *__restrict__ nprob, const int32_t *__restrict__ prob_off, DpProb *__restrict__ probs)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,12 +712,8 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
         if (i == K.cnt - 1 || (cq - lq >= min_ksw_len && cr - lr >= min_ksw_len)) {
             if (PASS) {
                 DpProb P; P.m = cq - lq; P.n = cr - lr; P.chain = c; P.kind = 0;
-                int W = d_fill_band(P.m, P.n, bw), dl = P.n - P.m;
-                if (P.m + P.n > ADAPT_MAX_STEPS) {        // long segment: wide band at once, kept within 1024 diagonals if possible
-                    int adl = dl < 0 ? -dl : dl, cap = (1022 - adl) / 2, W2 = d_fill_band_wide(P.m, P.n, bw);
-                    if (cap < W) cap = W;
-                    W = W2 > cap ? cap : W2;
-                }
+                // long segments are few and a second pass over one of them is slow: they take the wide band at once
+                const int W = P.m + P.n > ADAPT_MAX_STEPS ? d_fill_band_wide(P.m, P.n, bw, band_q4) : d_fill_band(P.m, P.n, bw, band_q4), dl = P.n - P.m;
                 P.dlo = d_even_lo((dl < 0 ? dl : 0) - W); P.dhi = (dl > 0 ? dl : 0) + W;
                 if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
                 P.tstep = 1; P.ti0 = K.tbase + lr; P.qcomp = (int8_t)K.rev;
@@ -741,11 +742,12 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
-#define DP_NCLS 19
+#define DP_NCLS 22
 // 10-17: packed-int16 register kernel k_dp_pkr<LPP, R> for short gap fills, by band width:
 // D <= 20 / 24 / 28 / 32 one lane per problem with R = 5 / 6 / 7 / 8; D <= 40 / 48 / 64 two lanes with R = 5 / 6 / 8;
 // D <= 128 four lanes with R = 8; 18: z-drop extensions with D <= 64 (two lanes, R = 8)
-__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps)
+// 19-21: wide fills in int16 while the scores fit (steps <= pk_wide_steps): D <= 256 / 512 / 1024, 1 / 2 / 4 waves per problem
+__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps)
 {
     if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
     if (kind == 0 && steps <= pk_max_steps) {
@@ -757,6 +759,11 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
         if (D <= 48) return 15;
         if (D <= 64) return 16;
         if (D <= 128) return 17;
+    }
+    if (kind == 0 && steps <= pk_wide_steps && D > 128) {
+        if (D <= 256) return 19;
+        if (D <= 512) return 20;
+        if (D <= 1024) return 21;
     }
     if (kind == 0) {
         if (D <= 64) return 5;
@@ -770,16 +777,18 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
 // dwords per packed trace-back row
 __device__ __forceinline__ int d_cls_slots(int cls)
 {
+    if (cls >= 19) return 64 << (cls - 19);
     if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 32 : 16;
     return cls == 5 ? 32 : 64 << (cls - 6);
 }
-__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int32_t pk_ext_steps, int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
+__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
+                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
-    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps);
+    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps, pk_wide_steps);
     int64_t tb;
     if (P.kind >= 3) tb = 0;
     else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 15) & ~15LL;
@@ -821,12 +830,12 @@ __global__ void k_retry_collect(const int32_t *__restrict__ flag, int32_t np, in
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < np && flag[i]) list[atomicAdd(cnt, 1)] = i;
 }
-__global__ void k_retry_build(const DpProb *__restrict__ probs, const int32_t *__restrict__ list, int32_t n, int32_t bw, DpProb *__restrict__ out)
+__global__ void k_retry_build(const DpProb *__restrict__ probs, const int32_t *__restrict__ list, int32_t n, int32_t bw, int32_t band_q4, DpProb *__restrict__ out)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     DpProb P = probs[list[k]];
-    const int W = d_fill_band(P.m, P.n, bw), W2 = d_fill_band_wide(P.m, P.n, bw), dl = P.n - P.m;
+    const int W = d_fill_band(P.m, P.n, bw, band_q4), W2 = d_fill_band_wide(P.m, P.n, bw, band_q4), dl = P.n - P.m;
     const int lo = d_even_lo((dl < 0 ? dl : 0) - W2), hi = (dl > 0 ? dl : 0) + W2;
     P.chain = list[k];                  // index of the original problem
     P.pad[1] = 0;
@@ -1063,12 +1072,18 @@ __device__ __forceinline__ uint32_t d_cell_nc(const DpOpt &o, int32_t hd, int32_
 #define DPP_SHR1(old, v) __builtin_amdgcn_update_dpp((old), (v), 0x138, 0xf, 0xf, false)   /* lane i <- lane i-1 */
 #define DPP_SHL1(old, v) __builtin_amdgcn_update_dpp((old), (v), 0x130, 0xf, 0xf, false)   /* lane i <- lane i+1 */
 
-template <int LPP, int R>
-__global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
+// NW > 1: one problem per workgroup of NW waves (LPP = 64*NW); the three values that cross a wave boundary per
+// step go through LDS with one barrier per step (same scheme as the packed kernel).
+template <int LPP, int R, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) k_dp_reg(DpArgs A)
 {
-    constexpr int PPW = 64 / LPP, SLOTS = LPP * R;
-    if (R >= 2) __builtin_amdgcn_s_setprio(3);   // tail classes: few long waves, give them issue priority over the bulk
+    static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
+    constexpr int PPW = NW > 1 ? 1 : 64 / LPP, SLOTS = LPP * R;
+    __shared__ int32_t xch[NW > 1 ? 2 * NW * 3 : 1];
+    __shared__ int32_t ncell_sh;
+    if (R >= 2 || NW > 1) __builtin_amdgcn_s_setprio(3);   // tail classes: few long waves, give them issue priority over the bulk
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
+    const int wv = NW > 1 ? lane >> 6 : 0, wl = lane & 63;
     const int pi = blockIdx.x * PPW + sub;
     const bool have = pi < A.nlist;
     const int prob = A.list[have ? pi : 0];
@@ -1091,8 +1106,14 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
         if (j0 >= 1 && j0 <= n) tbs[r] = d_base(A.tseq2, A.tnmask, P.ti0 + (int64_t)ts_ * (j0 - 1));
     }
     int amax = m + n;
+    if (NW == 1) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+        for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+    } else {
+        if (lane == 0) ncell_sh = 0;
+        if (wl == 0) { int32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
+        __syncthreads();
+    }
     uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off);
     const int last_row = have ? (m + n) >> 2 : -1;
     BaseStream QS, TS; QS.w = 0; QS.nm = 0; TS.w = 0; TS.nm = 0;
@@ -1110,6 +1131,7 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
             tbs[R - 1] = d_stream_next(TS);
             int32_t hu = DPP_SHL1(TELR_NEG, He[0]), f1u = DPP_SHL1(TELR_NEG, F1e[0]), f2u = DPP_SHL1(TELR_NEG, F2e[0]);
             if (LPP < 64 && l == LPP - 1) { hu = TELR_NEG; f1u = TELR_NEG; f2u = TELR_NEG; }
+            if (NW > 1 && wl == 63 && wv < NW - 1) { const int32_t *x = xch + (0 * NW + wv + 1) * 3; hu = x[0]; f1u = x[1]; f2u = x[2]; }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int32_t uh = r < R - 1 ? He[r < R - 1 ? r + 1 : r] : hu, uf1 = r < R - 1 ? F1e[r < R - 1 ? r + 1 : r] : f1u, uf2 = r < R - 1 ? F2e[r < R - 1 ? r + 1 : r] : f2u;
@@ -1128,6 +1150,7 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
             qbs[0] = d_stream_next(QS);
             int32_t hl = DPP_SHR1(TELR_NEG, Ho[R - 1]), e1l = DPP_SHR1(TELR_NEG, E1o[R - 1]), e2l = DPP_SHR1(TELR_NEG, E2o[R - 1]);
             if (LPP < 64 && l == 0) { hl = TELR_NEG; e1l = TELR_NEG; e2l = TELR_NEG; }
+            if (NW > 1 && wl == 0 && wv > 0) { const int32_t *x = xch + (1 * NW + wv - 1) * 3; hl = x[0]; e1l = x[1]; e2l = x[2]; }
 #pragma unroll
             for (int r = R - 1; r >= 0; --r) {
                 const int32_t lh = r > 0 ? Ho[r > 0 ? r - 1 : 0] : hl, le1 = r > 0 ? E1o[r > 0 ? r - 1 : 0] : e1l, le2 = r > 0 ? E2o[r > 0 ? r - 1 : 0] : e2l;
@@ -1139,6 +1162,11 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
                 }
             }
         }
+        if (NW > 1) {
+            if (a & 1) { if (wl == 63) { int32_t *x = xch + (1 * NW + wv) * 3; x[0] = Ho[R - 1]; x[1] = E1o[R - 1]; x[2] = E2o[R - 1]; } }
+            else if (wl == 0) { int32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
+            __syncthreads();
+        }
         if ((a & 3) == 3 || a == amax) {
             if ((a >> 2) <= last_row) {
 #pragma unroll
@@ -1149,7 +1177,12 @@ __global__ void __launch_bounds__(64) k_dp_reg(DpArgs A)
         }
     }
 #pragma unroll
-    for (int s = LPP / 2; s >= 1; s >>= 1) ncell += __shfl_xor(ncell, s);
+    for (int s = (NW > 1 ? 32 : LPP / 2); s >= 1; s >>= 1) ncell += __shfl_xor(ncell, s);
+    if (NW > 1) {
+        if (wl == 0) atomicAdd(&ncell_sh, ncell);
+        __syncthreads();
+        ncell = ncell_sh;
+    }
     if (have) {
         const int xf = (n - m) - de0;      // offset of the final diagonal inside this lane's block
         if (xf >= 0 && xf < 2 * R) {
@@ -1278,11 +1311,15 @@ __device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dh
     return hi >= lo ? ((hi - lo) >> 1) + 1 : 0;
 }
 
-template <int LPP, int R, bool EXT>
-__device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob)
+// NW > 1: one problem per workgroup of NW waves (LPP = 64*NW lanes): the values that cross a wave boundary go
+// through `xch` (LDS, [2][NW][3]) with one barrier per step, everything else is unchanged.
+template <int LPP, int R, bool EXT, int NW = 1>
+__device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob, uint32_t *xch = nullptr)
 {
+    static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
     constexpr int RW = LPP * R;
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
+    const int wv = NW > 1 ? lane >> 6 : 0, wl = lane & 63;
     const int pi = first_prob + sub;
     const bool have = pi < nlist;
     const int prob = list[have ? pi : 0];
@@ -1306,8 +1343,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     }
     const int mn = m + n;
     int amax = mn;
+    if (NW == 1) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+        for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+    }
     uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off) + l * R;
     const int last_row = have ? mn >> 1 : -1;
     // base streams: the newest query base enters register 0 (low half) and ages towards register R-1, the newest
@@ -1333,6 +1372,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     uint32_t fin = PK_NEG, te[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) te[r] = 0;
+    if (NW > 1) {       // the first odd step reads the next wave's initial even state
+        if (wl == 0) { uint32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
+        __syncthreads();
+    }
     // step 1 (odd) fills the odd half of row 0; afterwards every trip does the even step 2k and the odd step 2k+1
     for (int k = 0; 2 * k <= amax; ++k) {
         uint32_t h, ve1, vf1, ve2, vf2;
@@ -1343,6 +1386,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             uint32_t ph = PK_NEG, pe1 = PK_NEG, pe2 = PK_NEG;
             if (LPP > 1) {
                 ph = DPP_SHR1((int)PK_NEG, (int)Ho[R - 1]); pe1 = DPP_SHR1((int)PK_NEG, (int)E1o[R - 1]); pe2 = DPP_SHR1((int)PK_NEG, (int)E2o[R - 1]);
+                if (NW > 1 && wl == 0 && wv > 0) { const uint32_t *x = xch + (1 * NW + wv - 1) * 3; ph = x[0]; pe1 = x[1]; pe2 = x[2]; }
                 if (first) { ph = PK_NEG; pe1 = PK_NEG; pe2 = PK_NEG; }
             }
 #pragma unroll
@@ -1353,6 +1397,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 te[r] = d_cell_pk(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); E1e[r] = ve1; F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); E2e[r] = ve2; F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]);
                 if (!EXT && a == mn && r == fin_r) fin = h;
+            }
+            if (NW > 1) {
+                if (wl == 0) { uint32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
+                __syncthreads();
             }
             if (EXT) {
                 uint32_t hv[R];
@@ -1374,6 +1422,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             uint32_t nh = PK_NEG, nf1 = PK_NEG, nf2 = PK_NEG;
             if (LPP > 1) {
                 nh = DPP_SHL1((int)PK_NEG, (int)He[0]); nf1 = DPP_SHL1((int)PK_NEG, (int)F1e[0]); nf2 = DPP_SHL1((int)PK_NEG, (int)F2e[0]);
+                if (NW > 1 && wl == 63 && wv < NW - 1) { const uint32_t *x = xch + (0 * NW + wv + 1) * 3; nh = x[0]; nf1 = x[1]; nf2 = x[2]; }
                 if (last) { nh = PK_NEG; nf1 = PK_NEG; nf2 = PK_NEG; }
             }
             uint32_t row[R];
@@ -1412,6 +1461,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                     for (int r = 0; r < R; ++r) dst[r] = row[r];
                 }
             }
+        }
+        if (NW > 1) {
+            if (wl == 63) { uint32_t *x = xch + (1 * NW + wv) * 3; x[0] = Ho[R - 1]; x[1] = E1o[R - 1]; x[2] = E2o[R - 1]; }
+            __syncthreads();
         }
         if (EXT && __all(done)) break;
     }
@@ -1469,6 +1522,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     default: d_dp_pkr<4, 8, false>(A, list, n, first); break;
     }
 }
+// wide gap fills in int16 (classes 19-21: bands up to 256 / 512 / 1024 diagonals): one problem per workgroup of
+// NW waves, four diagonals per lane; these are few and long, so what counts is the time of one step
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_dp_pkw(DpArgs A)
+{
+    __shared__ uint32_t xch[2 * NW * 3];
+    __builtin_amdgcn_s_setprio(3);
+    d_dp_pkr<64 * NW, 1, false, NW>(A, A.list, A.nlist, blockIdx.x, xch);
+}
 // z-drop extensions (class 18): their own launch on a side stream; four lanes per problem keep the single-wave
 // latency of the long windows down
 #define PKX_LPP 4
@@ -1486,15 +1548,11 @@ __global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
 // keeps the two lines it is walking through in LDS (slot = line parity; dword k of lane l at word k*64+l:
 // conflict-free byte reads) and fetches the next lower line into registers ahead of time: memory is touched once
 // per line instead of once per step, and a line is normally there before the walk reaches it.
-__global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
-                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
-                                                  const int32_t *__restrict__ list)
+__device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi,
+                                                 const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
+                                                 uint32_t *stage)
 {
-    __shared__ uint32_t stage[2 * 16 * 64];
     const int lane = threadIdx.x;
-    const int ti = blockIdx.x * blockDim.x + lane;
-    if (ti >= np) return;
-    const int pi = list ? list[ti] : ti;
     const DpProb P = probs[pi];
     if (P.kind >= 3) return;
     const int dhi_ = P.dhi; int touched = 0;
@@ -1506,6 +1564,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     int i = res[pi].bi, j = res[pi].bj;
     uint32_t *cg = cig + P.cig_off;
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
+    const int rowb = packed ? lpp * 4 : stride;      // bytes between consecutive rows of the trace-back matrix
     int64_t tag0 = -1, tag1 = -1, pf = -2;
     uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
     while (i > 0 && j > 0) {
@@ -1523,7 +1582,8 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
             dst[8 * 64] = v2.x; dst[9 * 64] = v2.y; dst[10 * 64] = v2.z; dst[11 * 64] = v2.w;
             dst[12 * 64] = v3.x; dst[13 * 64] = v3.y; dst[14 * 64] = v3.z; dst[15 * 64] = v3.w;
             if (slot) tag1 = line; else tag0 = line;
-            pf = line - 1;
+            // next line to come: the same position one row up when rows are wider than a line, else the line below
+            pf = rowb >= 64 ? (abs_off - rowb) >> 6 : line - 1;
             if (pf >= 0) { const uint4 *src = (const uint4*)(tb_all + (pf << 6)); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
         }
         const int w = (int)(abs_off & 63);
@@ -1539,6 +1599,108 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
         if (op == cur_op) ++cur_len;
         else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
     }
+    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
+    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
+    if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+    res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
+    if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
+}
+__global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
+                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
+                                                  const int32_t *__restrict__ list)
+{
+    __shared__ uint32_t stage[2 * 16 * 64];
+    const int ti = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ti >= np) return;
+    d_traceback_lane(probs, res, list ? list[ti] : ti, tb_all, cig, retry, stage);
+}
+// trace-back of the packed fill classes, driven by the same cost-ordered wave table as the forward launch (one block
+// per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
+__global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ probs, DpRes *__restrict__ res,
+                                                     const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
+                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list,
+                                                     const int32_t *__restrict__ cls_cnt, int32_t np)
+{
+    __shared__ uint32_t stage[2 * 16 * 64];
+    const uint32_t w = waves[blockIdx.x];
+    const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
+    const int ppw = 64 / PK_LPP[cls - 10], t = threadIdx.x;
+    if (t >= ppw || first + t >= cls_cnt[cls]) return;
+    d_traceback_lane(probs, res, cls_list[(int64_t)cls * np + first + t], tb_all, cig, retry, stage);
+}
+
+// Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control
+// flow, lane 0 writes); what the other lanes add is memory parallelism: on a miss the wave loads, in one go, the 64-byte
+// pieces of the next 64 rows around the current diagonal (the path moves at most one slot per step) into LDS, so the
+// walk itself only ever waits for LDS.
+__global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int32_t np,
+                                                    const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
+                                                    const int32_t *__restrict__ list)
+{
+    __shared__ uint32_t win[64 * 16];          // window line k (row r0 - k): win[k*16 .. k*16+15]
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= np) return;
+    const int pi = list ? list[blockIdx.x] : (int)blockIdx.x;
+    const DpProb P = probs[pi];
+    if (P.kind >= 3) return;
+    const int dhi_ = P.dhi; int touched = 0;
+    const int cls = P.pad[0], dlo = P.dlo;
+    const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
+    const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
+    const bool packed = cls >= 5;
+    const int64_t rowb = packed ? (int64_t)lpp * 4 : stride;        // bytes per row of the trace-back matrix
+    const uint8_t *tb = tb_all + P.tb_off;
+    int i = res[pi].bi, j = res[pi].bj;
+    uint32_t *cg = cig + P.cig_off;
+    int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
+    int r0 = -1; int64_t c0 = 0;               // window: rows r0 .. r0-63, bytes [c0, c0+64) of each row (c0 multiple of 4)
+    while (i > 0 && j > 0) {
+        const int a = i + j, sl = (j - i - dlo) >> 1;
+        int row; int64_t col;                  // row and byte column of this cell's trace-back byte
+        if (cls >= 10) { row = a >> 1; col = ((int64_t)(sl >> 1) << 2) + ((a & 1) << 1) + (sl & 1); }
+        else if (packed) { row = a >> 2; col = ((int64_t)sl << 2) + (a & 3); }
+        else { row = a; col = sl; }
+        const int k = r0 - row;
+        if (r0 < 0 || k < 0 || k >= 64 || col < c0 || col >= c0 + 64) {
+            __syncthreads();                   // everybody is done reading the old window
+            r0 = row; c0 = col - 32; if (c0 < 0) c0 = 0; c0 &= ~3LL;
+            const int rk = r0 - lane;
+            uint32_t v[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) v[x] = 0;
+            if (rk >= 0) {
+                // P.tb_off is a multiple of 16 but rows of the byte-per-cell layout are not: dword loads from the
+                // enclosing aligned address, shifted into place
+                const int64_t byte0 = (int64_t)rk * rowb + c0;
+                const uint32_t *src = (const uint32_t*)(tb + (byte0 & ~3LL));
+                const int sh = (int)(byte0 & 3) * 8;
+                if (sh == 0) {
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) v[x] = src[x];
+                } else {
+                    uint32_t prev = src[0];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) { const uint32_t nx = src[x + 1]; v[x] = (prev >> sh) | (nx << (32 - sh)); prev = nx; }
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 16; ++x) win[lane * 16 + x] = v[x];
+            __syncthreads();
+        }
+        const int w = (int)(col - c0);
+        const uint32_t t = (win[(r0 - row) * 16 + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
+        touched |= (j - i == dlo) | (j - i == dhi_);
+        if (state == 0) state = t & 7;
+        int op;
+        if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
+        else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
+        else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
+        else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
+        else                 { op = 1; if (!(t & 64)) state = 0; --i; }
+        if (op == cur_op) ++cur_len;
+        else { if (cur_len && lane == 0) cg[no] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_len) ++no; cur_op = op; cur_len = 1; }
+    }
+    if (lane != 0) return;
     if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
     if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;

@@ -37,7 +37,8 @@ struct telr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side[8] = {nullptr};
-    hipEvent_t ev_fork = nullptr, ev_side[8] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_side[8] = {nullptr}, ev_chunk[8] = {nullptr};
+    hipStream_t tb_stream = nullptr;      // packed trace-back chunks run here, underneath the next forward chunk
     std::string err;
     std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
     std::map<std::string, DBuf> hbufs;    // grow-only pinned host staging buffers
@@ -142,6 +143,8 @@ extern "C" int telr_init(int device, telr_ctx **out)
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->evk[i]) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < TELR_NSIDE; ++i) if (hipStreamCreate(&ctx->side[i]) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    for (int i = 0; i < 8; ++i) if (hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    if (hipStreamCreate(&ctx->tb_stream) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     *out = ctx;
     return TELR_OK;
 }
@@ -170,6 +173,8 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int i = 0; i < TELR_NSIDE; ++i) { if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]); if (ctx->ev_side[i]) (void)hipEventDestroy(ctx->ev_side[i]); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 8; ++i) if (ctx->ev_chunk[i]) (void)hipEventDestroy(ctx->ev_chunk[i]);
+    if (ctx->tb_stream) (void)hipStreamDestroy(ctx->tb_stream);
     for (int i = 0; i < 6; ++i) if (ctx->evk[i]) (void)hipEventDestroy(ctx->evk[i]);
     delete ctx;
 }
@@ -192,9 +197,9 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
     mo->max_gap = 5000; mo->bw = 500; mo->chain_lookback = 128; mo->min_cnt = 3; mo->min_chain_score = 40;
     mo->mask_level = 0.5f; mo->pri_ratio = 0.8f; mo->best_n = 5; mo->secondary = 1;
     mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
-    mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR;
+    mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6;
     if (s == "map-ont" || s == "ngmlr-ont") { }
-    else if (s == "map-pb" || s == "ngmlr-pacbio") { io->k = 19; io->is_hpc = 1; }
+    else if (s == "map-pb" || s == "ngmlr-pacbio") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 8; }
     else if (s == "asm10") {
         io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;
         mo->a = 1; mo->b = 9; mo->q = 16; mo->e = 2; mo->q2 = 41; mo->e2 = 1; mo->min_dp_max = 200; mo->zdrop = 200; mo->best_n = 50;
@@ -635,13 +640,14 @@ static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
     if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
 }
 
-static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0, int pk_ext_steps = 0)
+static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0, int pk_ext_steps = 0, int pk_wide_steps = 0)
 {
     if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
     if (kind == 0 && steps <= pk_max_steps) {
         if (D <= 20) return 10; if (D <= 24) return 11; if (D <= 28) return 12; if (D <= 32) return 13;
         if (D <= 40) return 14; if (D <= 48) return 15; if (D <= 64) return 16; if (D <= 128) return 17;
     }
+    if (kind == 0 && steps <= pk_wide_steps && D > 128) { if (D <= 256) return 19; if (D <= 512) return 20; if (D <= 1024) return 21; }
     if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
@@ -754,9 +760,22 @@ struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int6
 // ---------------------------------------------------------------------------------------
 // One DP pass over a problem array: scratch sizing, class lists (sorted by length so that the problems
 // sharing a wave are alike and the long ones start first), forward kernels, trace-back.
+// longest gap fill (m+n) the packed int16 kernels take: |H| <= b*(m+n)/2 + q2 + 128*e2 and a*(m+n)/2 must stay inside
+// +-16000 (bands of these classes have at most 128 diagonals); 0 disables the packed classes
 static inline int pk_steps_limit(const telr_map_opt *mo)
 {
-    return (mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9 && !getenv("TELR_NO_PK")) ? 1000 : 0;
+    if (!(mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9) || getenv("TELR_NO_PK")) return 0;
+    const int by_b = 2 * (15800 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
+    const int lim = by_b < by_a ? by_b : by_a;
+    return lim > 0 ? lim : 0;
+}
+// same bound for the wide int16 classes (bands up to 1024 diagonals)
+static inline int pk_wide_limit(const telr_map_opt *mo)
+{
+    if (!pk_steps_limit(mo) || getenv("TELR_NO_PKW")) return 0;
+    const int by_b = 2 * (15800 - mo->q2 - 1024 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
+    const int lim = by_b < by_a ? by_b : by_a;
+    return lim > 0 ? lim : 0;
 }
 // longest z-drop extension window (m+n) the packed int16 kernel takes: scores stay inside +-16000
 static inline int pk_ext_limit(const telr_map_opt *mo)
@@ -780,7 +799,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), d_tbb, d_cgo);
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), d_tbb, d_cgo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
@@ -834,9 +853,9 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             hipLaunchKernelGGL(k_pk_waves, dim3((nw + 255) / 256), dim3(256), 0, st, d_probs, d_clslist, np, plan, d_wk, d_wv);
             HIPCHK(hipGetLastError());
             size_t tbytes = 0;
-            HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 14, st));
+            HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 18, st));
             void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
-            HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 14, st));
+            HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 18, st));
         }
     }
     // The few long/wide problems are latency-bound single waves: start each tail class on its own side
@@ -846,57 +865,74 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     std::vector<hipStream_t> used;
     static const bool serial = getenv("TELR_SERIAL") != nullptr;      // profiling aid: every class on the main stream
     auto side_stream = [&]() { if (serial) return st; hipStream_t s2 = ctx->side[side % TELR_NSIDE]; ++side; used.push_back(s2); return s2; };
-    if (h_cls[18]) {
-        hipStream_t s2 = side_stream();
-        HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        D.list = d_clslist + (size_t)18 * np; D.nlist = h_cls[18];
-        const int ppw = 64 / PKX_LPP;
-        hipLaunchKernelGGL(k_dp_pkx, dim3((h_cls[18] + ppw - 1) / ppw), dim3(64), 0, s2, D);
-        HIPCHK(hipGetLastError());
-        if (tb_split) hipLaunchKernelGGL(k_traceback, dim3((h_cls[18] + 63) / 64), dim3(64), 0, s2, d_probs, d_res, h_cls[18], d_tb, *d_rawcig_io, d_retry, D.list);
-    }
-    for (int c = 4; c >= 0; --c) {
+    // launch order = expected single-problem latency, longest first (the device offers only a few hardware queues,
+    // so streams beyond that share one and run in submission order)
+    static const int SIDE_ORDER[] = { 9, 4, 3, 21, 8, 20, 18, 2, 7, 19, 1, 0 };
+    for (int c : SIDE_ORDER) {
         if (h_cls[c] == 0) continue;
         hipStream_t s2 = side_stream();
         HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c]; D.dcap = CAP[c];
-        size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
-        if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dp, dim3(h_cls[c]), dim3(64), lds, s2, D);
+        const int nl = h_cls[c];
+        D.list = d_clslist + (size_t)c * np; D.nlist = nl; D.dcap = 0;
+        if (c <= 4) {
+            D.dcap = CAP[c];
+            size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
+            if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_dp, dim3(nl), dim3(64), lds, s2, D);
+        }
+        else if (c == 9) hipLaunchKernelGGL((k_dp_reg<256, 2, 4>), dim3(nl), dim3(256), 0, s2, D);
+        else if (c == 8) hipLaunchKernelGGL((k_dp_reg<128, 2, 2>), dim3(nl), dim3(128), 0, s2, D);
+        else if (c == 7) hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(nl), dim3(64), 0, s2, D);
+        else if (c == 21) hipLaunchKernelGGL((k_dp_pkw<4>), dim3(nl), dim3(256), 0, s2, D);
+        else if (c == 20) hipLaunchKernelGGL((k_dp_pkw<2>), dim3(nl), dim3(128), 0, s2, D);
+        else if (c == 19) hipLaunchKernelGGL((k_dp_pkw<1>), dim3(nl), dim3(64), 0, s2, D);
+        else { const int ppw = 64 / PKX_LPP; hipLaunchKernelGGL(k_dp_pkx, dim3((nl + ppw - 1) / ppw), dim3(64), 0, s2, D); }
         HIPCHK(hipGetLastError());
-        if (tb_split) hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, s2, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, D.list);
+        if (tb_split) {
+            // few long problems: one wave walks one problem; many short ones (extensions): one lane per problem
+            if (c == 18 || c == 0) hipLaunchKernelGGL(k_traceback, dim3((nl + 63) / 64), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
+            else hipLaunchKernelGGL(k_traceback_w, dim3(nl), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
+            HIPCHK(hipGetLastError());
+        }
     }
     D.dcap = 0;
-    for (int c = 9; c >= 7; --c) {
-        if (h_cls[c] == 0) continue;
-        hipStream_t s2 = side_stream();
-        HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-        D.list = d_clslist + (size_t)c * np; D.nlist = h_cls[c];
-        if (c == 9) hipLaunchKernelGGL((k_dp_reg<64, 8>), dim3(h_cls[c]), dim3(64), 0, s2, D);
-        else if (c == 8) hipLaunchKernelGGL((k_dp_reg<64, 4>), dim3(h_cls[c]), dim3(64), 0, s2, D);
-        else hipLaunchKernelGGL((k_dp_reg<64, 2>), dim3(h_cls[c]), dim3(64), 0, s2, D);
-        HIPCHK(hipGetLastError());
-        if (tb_split) hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, s2, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, D.list);
-    }
+    // packed classes: the wave table is cut into chunks; the trace-back of a chunk (memory bound) runs on its own
+    // stream underneath the forward pass (issue bound) of the next chunk
+    static const int pk_chunks = [] { const char *e = getenv("TELR_PK_CHUNKS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+    const bool tb_over = tb_split && !serial && nw > 0;
     if (primary) HIPCHK(hipEventRecord(ctx->evk[5], st));
     if (nw > 0) {
         D.list = nullptr; D.nlist = 0;
-        hipLaunchKernelGGL(k_dp_pk, dim3(nw), dim3(64), 0, st, D, d_wv2, d_clslist, d_clscnt, np);
-        HIPCHK(hipGetLastError());
+        const int G = nw < 4096 ? 1 : pk_chunks;
+        if (tb_over) { HIPCHK(hipStreamWaitEvent(ctx->tb_stream, ctx->ev_fork, 0)); if (primary) HIPCHK(hipEventRecord(ctx->evk[3], ctx->tb_stream)); }
+        for (int g = 0; g < G; ++g) {
+            const int w0 = (int)((int64_t)nw * g / G), w1 = (int)((int64_t)nw * (g + 1) / G);
+            if (w1 <= w0) continue;
+            hipLaunchKernelGGL(k_dp_pk, dim3(w1 - w0), dim3(64), 0, st, D, d_wv2 + w0, d_clslist, d_clscnt, np);
+            HIPCHK(hipGetLastError());
+            if (tb_over) {
+                HIPCHK(hipEventRecord(ctx->ev_chunk[g], st));
+                HIPCHK(hipStreamWaitEvent(ctx->tb_stream, ctx->ev_chunk[g], 0));
+                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, d_clscnt, np);
+                HIPCHK(hipGetLastError());
+            }
+        }
+        if (tb_over) { if (primary) HIPCHK(hipEventRecord(ctx->evk[4], ctx->tb_stream)); used.push_back(ctx->tb_stream); }
     }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[0], st));
     if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
     if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[1], st));
     if (tb_split) {
-        if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
-        for (int c = 17; c >= 5; --c) {
-            if (h_cls[c] == 0 || (c >= 7 && c <= 9)) continue;
+        if (!tb_over && primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
+        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, d_clscnt, np);
+        for (int c = 6; c >= 5; --c) {
+            if (h_cls[c] == 0) continue;
             hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, st, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, (const int32_t*)(d_clslist + (size_t)c * np));
         }
-        if (primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
+        if (!tb_over && primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
+        HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipGetLastError());
     for (size_t u = 0; u < used.size(); ++u) {
         HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
@@ -1147,7 +1183,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "nprob", (size_t)nk + 1, &d_nprob));
         TRY(ctx_buf_t(ctx, "prob_off", (size_t)nk + 1, &d_poff));
         HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_segments<0>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
+        hipLaunchKernelGGL(k_segments<0>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(d_nprob + nk, 0, 4, st));
         TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_nprob, d_poff, (size_t)nk + 1)));
@@ -1157,7 +1193,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         np = h_poff[nk];
         DpProb *d_probs;
         TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
-        hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
+        hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
         HIPCHK(hipGetLastError());
         t_sg.stop();
         ctx->ctr.dp_problems += np;
@@ -1185,7 +1221,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             DpProb *d_probs2; DpRes *d_res2;
             TRY(ctx_buf_t(ctx, "probs_r", (size_t)n_retry, &d_probs2));
             TRY(ctx_buf_t(ctx, "dp_res_r", (size_t)n_retry, &d_res2));
-            hipLaunchKernelGGL(k_retry_build, dim3((n_retry + 255) / 256), dim3(256), 0, st, d_probs, d_rlist, n_retry, mo->bw, d_probs2);
+            hipLaunchKernelGGL(k_retry_build, dim3((n_retry + 255) / 256), dim3(256), 0, st, d_probs, d_rlist, n_retry, mo->bw, mo->fill_band_q4, d_probs2);
             HIPCHK(hipGetLastError());
             TRY(dp_pass(ctx, qs, tg, mo, d_probs2, n_retry, d_res2, &d_rawcig, nullptr, "_r", false));
             hipLaunchKernelGGL(k_retry_merge, dim3((n_retry + 255) / 256), dim3(256), 0, st, d_probs2, d_res2, n_retry, d_res);
@@ -1209,7 +1245,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             parallel_ranges(NT, np, [&](int t, int a0, int a1) { int64_t c = 0, w = 0; for (int i = a0; i < a1; ++i) { c += h_res[i].cells; w += h_res[i].tbases; } pc[t] += c; pw[t] += w; });
             for (int t = 0; t < NT; ++t) { ctx->ctr.dp_cells += pc[t]; ctx->ctr.window_bases += pw[t]; }
         }
-        const int pk_max_steps_h = pk_steps_limit(mo), pk_ext_steps_h = pk_ext_limit(mo);
+        const int pk_max_steps_h = pk_steps_limit(mo), pk_ext_steps_h = pk_ext_limit(mo), pk_wide_steps_h = pk_wide_limit(mo);
         std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
         std::vector<int64_t*> tcls(NT);
         for (int t = 0; t < NT; ++t) tcls[t] = tcls_store.data() + (size_t)t * TELR_N_DPCLS * 4;
@@ -1233,11 +1269,10 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                         cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band), mq + mt, pk_max_steps_h, pk_ext_steps_h);
                     }
                     else {
-                        const int m_ = d.bi, n_ = d.bj, mn = std::min(m_, n_), dl = n_ - m_;
-                        int W = TELR_W0 + (mn >> TELR_WSH); if (W > mo->bw) W = mo->bw;
-                        if (m_ + n_ > ADAPT_MAX_STEPS) { int W2 = mn <= 512 ? 24 + (mn >> 3) : 88 + ((mn - 512) >> 4); if (W2 > mo->bw) W2 = mo->bw; int adl = dl < 0 ? -dl : dl, cap = (1022 - adl) / 2; if (cap < W) cap = W; W = W2 > cap ? cap : W2; }
+                        const int m_ = d.bi, n_ = d.bj, dl = n_ - m_;
+                        const int W = m_ + n_ > ADAPT_MAX_STEPS ? d_fill_band_wide(m_, n_, mo->bw, mo->fill_band_q4) : d_fill_band(m_, n_, mo->bw, mo->fill_band_q4);
                         int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
-                        cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h);
+                        cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h, 0, pk_wide_steps_h);
                     }
                     int64_t *cc = tcls[tslot] + cls * 4;
                     cc[0] += 1; cc[1] += d.cells; cc[2] += is_ext ? d.bi + d.bj : d.bi + d.bj;

@@ -22,11 +22,12 @@ def preset(name):
         chain_gap_q8=0, chain_skip_q8=0,
         mask_level=0.5, pri_ratio=0.8, best_n=5, secondary=1,
         a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, min_dp_max=80, min_ksw_len=200,
-        ext_max=2048, ext_band=31, flags=MF_CIGAR)
+        ext_max=2048, ext_band=31, flags=MF_CIGAR, fill_band_q4=6)
     if name in ("map-ont", "ngmlr-ont"):
         pass
     elif name in ("map-pb", "ngmlr-pacbio"):
         io.k, io.is_hpc = 19, 1
+        mo.fill_band_q4 = 8         # CLR reads carry about twice the indel rate of ONT reads
     elif name == "asm10":
         io.k, io.w = 19, 19
         mo.min_mid_occ, mo.max_mid_occ = 50, 500

@@ -658,10 +658,11 @@ struct DpRes { int32_t score, bi, bj, nops, mlen, cells, tbases, mcols; };   // 
 // first pass: 2 + q4*floor(sqrt(min(m,n)))/16 diagonals of slack; retry (path touched a band edge): the wide band,
 // kept within 1024 diagonals where the first-pass width allows it (oracle: fill_band / fill_band_wide)
 #define ADAPT_MAX_STEPS 1000       // m+n above which a segment skips the narrow pass
-__host__ __device__ __forceinline__ int d_isqrt32(int v)
+__host__ __device__ __forceinline__ int d_isqrt32(int v)      // exact floor(sqrt(v)), v >= 0
 {
-    int r = 0;
-    for (int b = 1 << 15; b; b >>= 1) { const int t = r | b; if ((int64_t)t * t <= v) r = t; }
+    int r = (int)sqrtf((float)v);
+    while ((int64_t)r * r > v) --r;
+    while ((int64_t)(r + 1) * (r + 1) <= v) ++r;
     return r;
 }
 __host__ __device__ __forceinline__ int d_fill_band(int m, int n, int bw, int q4)
@@ -737,6 +738,82 @@ __global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const u
         ++np;
     }
     if (!PASS) nprob[c] = np;
+}
+
+// Wave-per-chain version of k_segments (same problems in the same order): a window of 64 consecutive anchors per
+// iteration, the greedy cuts of the window found with ballots (the cut condition is monotone along a chain), and
+// the descriptors of the window's cuts built and written by as many lanes in parallel.
+template <int PASS>
+__global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__ kc, int32_t nk, const uint64_t *__restrict__ canch,
+                                                   int32_t min_ksw_len, int32_t bw, int32_t band_q4, int32_t ext_max, int32_t ext_band,
+                                                   int32_t *__restrict__ nprob, const int32_t *__restrict__ prob_off, DpProb *__restrict__ probs)
+{
+    __shared__ int32_t cut_r[64], cut_q[64], prev_r[64], prev_q[64];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= nk) return;
+    const KeptChain K = kc[c];
+    const uint64_t *ca = canch + K.a_glob;
+    int np = 0;
+    DpProb *out = PASS ? probs + prob_off[c] : nullptr;
+    const int go = (int)K.goff;
+    if (K.qs > 0 && K.rs > 0) {          // left extension
+        if (PASS && lane == 0) {
+            int mq = K.qs < ext_max ? K.qs : ext_max, mt = K.rs < mq + ext_band ? K.rs : mq + ext_band;
+            DpProb P; P.m = mq; P.n = mt; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; P.kind = 1; P.chain = c;
+            P.tstep = -1; P.ti0 = K.tbase + K.rs - 1; P.qcomp = (int8_t)K.rev;
+            if (K.rev) { P.qstep = 1; P.qi0 = K.qbase + K.qlen - K.qs; } else { P.qstep = -1; P.qi0 = K.qbase + K.qs - 1; }
+            P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
+            out[np] = P;
+        }
+        ++np;
+    }
+    int lr = K.rs, lq = K.qs;
+    for (int w0 = 0; w0 < K.cnt; w0 += 64) {
+        const int i = w0 + lane;
+        int cr = 0x7fffffff, cq = 0x7fffffff;
+        if (i < K.cnt) { const uint64_t a = ca[i]; cr = A_G(a) - go + 1; cq = A_Q(a) + 1; }
+        // cuts of this window, in order
+        int ncut = 0; uint64_t live = ~0ULL;                 // lanes after the last cut
+        for (;;) {
+            const bool cond = i < K.cnt && (i == K.cnt - 1 || (cq - lq >= min_ksw_len && cr - lr >= min_ksw_len));
+            const uint64_t m = __ballot(cond) & live;
+            if (!m) break;
+            const int f = __ffsll((unsigned long long)m) - 1;
+            const int fr = __shfl(cr, f), fq = __shfl(cq, f);
+            if (lane == ncut) { cut_r[lane] = fr; cut_q[lane] = fq; prev_r[lane] = lr; prev_q[lane] = lq; }
+            lr = fr; lq = fq; ++ncut;
+            live = f == 63 ? 0ULL : ~0ULL << (f + 1);
+        }
+        if (PASS && ncut) {
+            __syncthreads();
+            if (lane < ncut) {
+                const int pr = prev_r[lane], pq = prev_q[lane];
+                DpProb P; P.m = cut_q[lane] - pq; P.n = cut_r[lane] - pr; P.chain = c; P.kind = 0;
+                const int W = P.m + P.n > ADAPT_MAX_STEPS ? d_fill_band_wide(P.m, P.n, bw, band_q4) : d_fill_band(P.m, P.n, bw, band_q4), dl = P.n - P.m;
+                P.dlo = d_even_lo((dl < 0 ? dl : 0) - W); P.dhi = (dl > 0 ? dl : 0) + W;
+                if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
+                P.tstep = 1; P.ti0 = K.tbase + pr; P.qcomp = (int8_t)K.rev;
+                if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - pq; } else { P.qstep = 1; P.qi0 = K.qbase + pq; }
+                P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
+                out[np + lane] = P;
+            }
+            __syncthreads();
+        }
+        np += ncut;
+    }
+    if (K.qe < K.qlen && K.re < K.tlen) {    // right extension
+        if (PASS && lane == 0) {
+            int rq = K.qlen - K.qe, rt = K.tlen - K.re;
+            int mq = rq < ext_max ? rq : ext_max, mt = rt < mq + ext_band ? rt : mq + ext_band;
+            DpProb P; P.m = mq; P.n = mt; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; P.kind = 2; P.chain = c;
+            P.tstep = 1; P.ti0 = K.tbase + K.re; P.qcomp = (int8_t)K.rev;
+            if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - K.qe; } else { P.qstep = 1; P.qi0 = K.qbase + K.qe; }
+            P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
+            out[np] = P;
+        }
+        ++np;
+    }
+    if (!PASS && lane == 0) nprob[c] = np;
 }
 
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;

@@ -1183,7 +1183,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "nprob", (size_t)nk + 1, &d_nprob));
         TRY(ctx_buf_t(ctx, "prob_off", (size_t)nk + 1, &d_poff));
         HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_segments<0>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
+        hipLaunchKernelGGL(k_segments_w<0>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(d_nprob + nk, 0, 4, st));
         TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_nprob, d_poff, (size_t)nk + 1)));
@@ -1193,7 +1193,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         np = h_poff[nk];
         DpProb *d_probs;
         TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
-        hipLaunchKernelGGL(k_segments<1>, dim3((nk + 63) / 64), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
+        hipLaunchKernelGGL(k_segments_w<1>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
         HIPCHK(hipGetLastError());
         t_sg.stop();
         ctx->ctr.dp_problems += np;

@@ -1164,7 +1164,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
 
     const bool do_dp = (mo->flags & TELR_MF_CIGAR) && nk > 0;
     std::vector<int32_t> h_poff; DpRes *h_res = nullptr;
-    DpProb *d_probs_keep = nullptr; DpRes *d_res_keep = nullptr; uint32_t *d_rawcig_keep = nullptr;
+    int64_t *h_foff = nullptr; size_t cig_base = 0;
     int np = 0;
     if (do_dp) {
         // ---- DP problem list ----------------------------------------------------------------
@@ -1230,13 +1230,47 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         ctx->dp_retries += n_retry;
         t_dp.stop();
 
-        // ---- problem results home (32 B each, pinned); the CIGARs stay on the device until the survivors are known
-        StageTimer t_d(ctx, ST_D2H, true);
-        TRY(ctx_hbuf_t(ctx, "h_res", (size_t)np, &h_res));
-        HIPCHK(hipMemcpyAsync(h_res, d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        t_d.stop();
-        d_probs_keep = d_probs; d_res_keep = d_res; d_rawcig_keep = d_rawcig;
+        // ---- CIGARs of ALL kept chains are stitched now and travel to the (pinned) result buffer while the host does
+        //      its second selection pass on the per-problem results; chains that pass drops leave unused gaps behind
+        StageTimer t_g(ctx, ST_GATHER, true);
+        {
+            StitchRec *h_sv, *d_sv; int64_t *d_nfin, *d_foff; StitchProb *d_sp;
+            TRY(ctx_hbuf_t(ctx, "h_stitch", (size_t)nk, &h_sv));
+            TRY(ctx_buf_t(ctx, "stitch", (size_t)nk, &d_sv));
+            TRY(ctx_buf_t(ctx, "stitch_n", (size_t)nk + 1, &d_nfin));
+            TRY(ctx_buf_t(ctx, "stitch_off", (size_t)nk + 1, &d_foff));
+            TRY(ctx_buf_t(ctx, "stitch_prob", (size_t)np, &d_sp));
+            parallel_ranges(NT, nk, [&](int, int xa, int xb) {
+                for (int x = xa; x < xb; ++x) {
+                    const HostChain &c = chains[kept[x]];
+                    h_sv[x].p0 = h_poff[x]; h_sv[x].p1 = h_poff[x + 1]; h_sv[x].has_left = (c.qs > 0 && c.rs > 0) ? 1 : 0; h_sv[x].pad = 0;
+                }
+            });
+            HIPCHK(hipMemcpyAsync(d_sv, h_sv, (size_t)nk * sizeof(StitchRec), hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemsetAsync(d_sp, 0xff, (size_t)np * sizeof(StitchProb), st));
+            hipLaunchKernelGGL(k_stitch_count, dim3((nk + 63) / 64), dim3(64), 0, st, d_sv, nk, d_probs, d_res, d_rawcig, d_nfin, d_sp);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemsetAsync(d_nfin + nk, 0, 8, st));
+            TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nfin, d_foff, (size_t)nk + 1)));
+            TRY(ctx_hbuf_t(ctx, "h_stitch_off", (size_t)nk + 1, &h_foff));
+            HIPCHK(hipMemcpyAsync(h_foff, d_foff, (size_t)(nk + 1) * 8, hipMemcpyDeviceToHost, st));
+            TRY(ctx_hbuf_t(ctx, "h_res", (size_t)np, &h_res));
+            HIPCHK(hipMemcpyAsync(h_res, d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            t_g.stop();                            // what follows is not waited for here
+            const int64_t tot = h_foff[nk];
+            uint32_t *d_fin;
+            TRY(ctx_buf_t(ctx, "stitched", (size_t)tot + 1, &d_fin));
+            hipLaunchKernelGGL(k_stitch_write, dim3((np + 255) / 256), dim3(256), 0, st, np, d_sp, d_probs, d_res, d_sv, d_rawcig, d_foff, d_fin);
+            HIPCHK(hipGetLastError());
+            cig_base = R->ncig;
+            if (cig_base + (size_t)tot + 1 > R->cap) {
+                if (!R->cig) pool_get(ctx, &R->cig, &R->cap);
+                if (!cig_grow(&R->cig, &R->cap, cig_base, cig_base + (size_t)tot + 1 + (size_t)tot / 8)) return TELR_E_NOMEM;
+            }
+            R->ncig = cig_base + (size_t)tot;
+            if (tot) HIPCHK(hipMemcpyAsync(R->cig + cig_base, d_fin, (size_t)tot * 4, hipMemcpyDeviceToHost, st));   // waited for at the end
+        }
 
         // ---- host: per-chain numbers from the per-problem results (no op walking) ---------------------
         StageTimer t_as(ctx, ST_ASSEMBLE, false);
@@ -1333,46 +1367,17 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     { size_t tot = 0; for (auto &v : tsurv) tot += v.size(); surv.reserve(tot); for (auto &v : tsurv) surv.insert(surv.end(), v.begin(), v.end()); }
     const int ns = (int)surv.size();
     t_as2.stop();
-    if (do_dp && ns > 0) {
-        // ---- device: stitch the survivors' CIGARs and DMA them into the (pinned) result buffer
-        StageTimer t_g(ctx, ST_GATHER, true);
-        StitchRec *h_sv, *d_sv; int64_t *d_nfin, *d_foff;
-        TRY(ctx_hbuf_t(ctx, "h_stitch", (size_t)ns, &h_sv));
-        TRY(ctx_buf_t(ctx, "stitch", (size_t)ns, &d_sv));
-        TRY(ctx_buf_t(ctx, "stitch_n", (size_t)ns + 1, &d_nfin));
-        TRY(ctx_buf_t(ctx, "stitch_off", (size_t)ns + 1, &d_foff));
+    if (do_dp) {
+        int64_t ops = 0;
         for (int i = 0; i < ns; ++i) {
-            const int x = surv[i].x; const HostChain &c = chains[kept[x]];
-            h_sv[i].p0 = h_poff[x]; h_sv[i].p1 = h_poff[x + 1]; h_sv[i].has_left = (c.qs > 0 && c.rs > 0) ? 1 : 0; h_sv[i].pad = 0;
+            const int x = surv[i].x;
+            surv[i].r.cigar_off = (int64_t)cig_base + h_foff[x]; surv[i].r.n_cigar = (int32_t)(h_foff[x + 1] - h_foff[x]);
+            ops += surv[i].r.n_cigar;
         }
-        HIPCHK(hipMemcpyAsync(d_sv, h_sv, (size_t)ns * sizeof(StitchRec), hipMemcpyHostToDevice, st));
-        StitchProb *d_sp;
-        TRY(ctx_buf_t(ctx, "stitch_prob", (size_t)np, &d_sp));
-        HIPCHK(hipMemsetAsync(d_sp, 0xff, (size_t)np * sizeof(StitchProb), st));        // sv = -1: problem of a dropped chain
-        hipLaunchKernelGGL(k_stitch_count, dim3((ns + 63) / 64), dim3(64), 0, st, d_sv, ns, d_probs_keep, d_res_keep, d_rawcig_keep, d_nfin, d_sp);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemsetAsync(d_nfin + ns, 0, 8, st));
-        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nfin, d_foff, (size_t)ns + 1)));
-        int64_t *h_foff;
-        TRY(ctx_hbuf_t(ctx, "h_stitch_off", (size_t)ns + 1, &h_foff));
-        HIPCHK(hipMemcpyAsync(h_foff, d_foff, (size_t)(ns + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        const int64_t tot = h_foff[ns];
-        uint32_t *d_fin;
-        TRY(ctx_buf_t(ctx, "stitched", (size_t)tot + 1, &d_fin));
-        hipLaunchKernelGGL(k_stitch_write, dim3((np + 255) / 256), dim3(256), 0, st, np, d_sp, d_probs_keep, d_res_keep, d_sv, d_rawcig_keep, d_foff, d_fin);
-        HIPCHK(hipGetLastError());
-        const size_t base = R->ncig;
-        if (base + (size_t)tot + 1 > R->cap) {
-            if (!R->cig) pool_get(ctx, &R->cig, &R->cap);
-            if (!cig_grow(&R->cig, &R->cap, base, base + (size_t)tot + 1 + (size_t)tot / 8)) return TELR_E_NOMEM;
-        }
-        R->ncig = base + (size_t)tot;
-        if (tot) HIPCHK(hipMemcpyAsync(R->cig + base, d_fin, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (int i = 0; i < ns; ++i) { surv[i].r.cigar_off = (int64_t)base + h_foff[i]; surv[i].r.n_cigar = (int32_t)(h_foff[i + 1] - h_foff[i]); }
-        ctx->ctr.cigar_ops += tot;
-        t_g.stop();
+        ctx->ctr.cigar_ops += ops;
+        StageTimer t_g2(ctx, ST_GATHER, false);
+        HIPCHK(hipStreamSynchronize(st));          // the CIGAR DMA started before the second selection pass
+        t_g2.stop();
     }
     StageTimer t_as3(ctx, ST_ASSEMBLE, false);
     R->alns.reserve(R->alns.size() + ns);

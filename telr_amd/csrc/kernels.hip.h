@@ -1785,10 +1785,49 @@ __global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ p
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
 
+// ---- per-chain numbers from the per-problem results: one wave per kept chain sums its problems (score, matching
+// bases, block length) and keeps the reach of the two end extensions; the per-problem records stay on the device.
+struct StitchRec { int32_t p0, p1, has_left, pad; };     // problems [p0, p1) of a kept chain
+struct ChainStat { int32_t dp, mlen, blen, l_bi, l_bj, r_bi, r_bj, pad; };     // 32 B
+__global__ void __launch_bounds__(64) k_chain_stats(const StitchRec *__restrict__ sv, int32_t nk, const DpRes *__restrict__ res, ChainStat *__restrict__ out)
+{
+    const int x = blockIdx.x, lane = threadIdx.x;
+    if (x >= nk) return;
+    const StitchRec S = sv[x];
+    int dp = 0, ml = 0, bl = 0;
+    for (int z = S.p0 + lane; z < S.p1; z += 64) { const DpRes d = res[z]; dp += d.score; ml += d.mlen; bl += d.bi + d.bj - d.mcols; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { dp += __shfl_xor(dp, s); ml += __shfl_xor(ml, s); bl += __shfl_xor(bl, s); }
+    if (lane == 0) {
+        ChainStat c; c.dp = dp; c.mlen = ml; c.blen = bl; c.pad = 0;
+        const DpRes a = res[S.p0], b = res[S.p1 - 1];
+        c.l_bi = a.bi; c.l_bj = a.bj; c.r_bi = b.bi; c.r_bj = b.bj;
+        out[x] = c;
+    }
+}
+// per DP class: problems, cells, steps, algorithmic bytes (telr_last_dp_classes); acc[DP_NCLS*4] = sum of target window bases
+__global__ void __launch_bounds__(256) k_dp_account(const DpProb *__restrict__ probs, const DpRes *__restrict__ res, int32_t np, unsigned long long *__restrict__ acc)
+{
+    __shared__ unsigned long long lacc[DP_NCLS * 4 + 1];
+    for (int z = threadIdx.x; z <= DP_NCLS * 4; z += blockDim.x) lacc[z] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < np) {
+        const DpProb P = probs[i]; const DpRes d = res[i];
+        const int cls = P.kind >= 3 ? 0 : P.pad[0];
+        atomicAdd(&lacc[cls * 4 + 0], 1ULL);
+        atomicAdd(&lacc[cls * 4 + 1], (unsigned long long)d.cells);
+        atomicAdd(&lacc[cls * 4 + 2], (unsigned long long)(d.bi + d.bj));
+        atomicAdd(&lacc[cls * 4 + 3], (unsigned long long)((d.bi + d.tbases + 3) / 4 + 4 * (long long)d.nops + 32));
+        atomicAdd(&lacc[DP_NCLS * 4], (unsigned long long)d.tbases);
+    }
+    __syncthreads();
+    for (int z = threadIdx.x; z <= DP_NCLS * 4; z += blockDim.x) if (lacc[z]) atomicAdd(&acc[z], lacc[z]);
+}
+
 // ---- CIGAR stitching of the surviving records on the device: one thread per record walks the raw CIGARs of
 // its problems (left extension in emission order, fills and right extension reversed) and merges equal ops
 // across problem boundaries.  Pass 1 counts the final ops (they only merge at boundaries), pass 2 writes them.
-struct StitchRec { int32_t p0, p1, has_left, pad; };
 struct StitchProb { int32_t sv, off, skip, extra; };      // per problem: record, offset inside the record, first op merged away, length absorbed by its last op
 __global__ void k_stitch_count(const StitchRec *__restrict__ sv, int32_t ns, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
                                const uint32_t *__restrict__ raw, int64_t *__restrict__ nfin, StitchProb *__restrict__ sp)

@@ -1163,8 +1163,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     });
 
     const bool do_dp = (mo->flags & TELR_MF_CIGAR) && nk > 0;
-    std::vector<int32_t> h_poff; DpRes *h_res = nullptr;
-    int64_t *h_foff = nullptr; size_t cig_base = 0;
+    std::vector<int32_t> h_poff;
+    int64_t *h_foff = nullptr; size_t cig_base = 0; ChainStat *h_cs = nullptr; unsigned long long *h_acc = nullptr;
     int np = 0;
     if (do_dp) {
         // ---- DP problem list ----------------------------------------------------------------
@@ -1254,8 +1254,17 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nfin, d_foff, (size_t)nk + 1)));
             TRY(ctx_hbuf_t(ctx, "h_stitch_off", (size_t)nk + 1, &h_foff));
             HIPCHK(hipMemcpyAsync(h_foff, d_foff, (size_t)(nk + 1) * 8, hipMemcpyDeviceToHost, st));
-            TRY(ctx_hbuf_t(ctx, "h_res", (size_t)np, &h_res));
-            HIPCHK(hipMemcpyAsync(h_res, d_res, (size_t)np * sizeof(DpRes), hipMemcpyDeviceToHost, st));
+            ChainStat *d_cs; unsigned long long *d_acc;
+            TRY(ctx_buf_t(ctx, "chain_stat", (size_t)nk, &d_cs));
+            TRY(ctx_buf_t(ctx, "dp_acc", (size_t)TELR_N_DPCLS * 4 + 1, &d_acc));
+            TRY(ctx_hbuf_t(ctx, "h_chain_stat", (size_t)nk, &h_cs));
+            TRY(ctx_hbuf_t(ctx, "h_dp_acc", (size_t)TELR_N_DPCLS * 4 + 1, &h_acc));
+            HIPCHK(hipMemsetAsync(d_acc, 0, ((size_t)TELR_N_DPCLS * 4 + 1) * 8, st));
+            hipLaunchKernelGGL(k_chain_stats, dim3(nk), dim3(64), 0, st, d_sv, nk, d_res, d_cs);
+            hipLaunchKernelGGL(k_dp_account, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, d_res, np, d_acc);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_cs, d_cs, (size_t)nk * sizeof(ChainStat), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_acc, d_acc, ((size_t)TELR_N_DPCLS * 4 + 1) * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             t_g.stop();                            // what follows is not waited for here
             const int64_t tot = h_foff[nk];
@@ -1274,52 +1283,22 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
 
         // ---- host: per-chain numbers from the per-problem results (no op walking) ---------------------
         StageTimer t_as(ctx, ST_ASSEMBLE, false);
-        {   // totals for the counters (parallel partial sums)
-            std::vector<int64_t> pc(NT, 0), pw(NT, 0);
-            parallel_ranges(NT, np, [&](int t, int a0, int a1) { int64_t c = 0, w = 0; for (int i = a0; i < a1; ++i) { c += h_res[i].cells; w += h_res[i].tbases; } pc[t] += c; pw[t] += w; });
-            for (int t = 0; t < NT; ++t) { ctx->ctr.dp_cells += pc[t]; ctx->ctr.window_bases += pw[t]; }
-        }
-        const int pk_max_steps_h = pk_steps_limit(mo), pk_ext_steps_h = pk_ext_limit(mo), pk_wide_steps_h = pk_wide_limit(mo);
-        std::vector<int64_t> tcls_store((size_t)NT * TELR_N_DPCLS * 4, 0);
-        std::vector<int64_t*> tcls(NT);
-        for (int t = 0; t < NT; ++t) tcls[t] = tcls_store.data() + (size_t)t * TELR_N_DPCLS * 4;
-        parallel_ranges(NT, nk, [&](int tslot, int xa, int xb) {
+        for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += (int64_t)h_acc[z];
+        for (int c = 0; c < TELR_N_DPCLS; ++c) ctx->ctr.dp_cells += (int64_t)h_acc[c * 4 + 1];
+        ctx->ctr.window_bases += (int64_t)h_acc[TELR_N_DPCLS * 4];
+        parallel_ranges(NT, nk, [&](int, int xa, int xb) {
             for (int x = xa; x < xb; ++x) {
-                const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x];
+                const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x]; const ChainStat &S = h_cs[x];
                 const int qlen = r.qlen, tlen = r.tlen;
-                int p = h_poff[x]; const int pend = h_poff[x + 1];
-                int32_t dp = 0, mlen = 0, blen = 0, qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
+                int32_t qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
                 const bool has_left = c.qs > 0 && c.rs > 0, has_right = c.qe < qlen && c.re < tlen;
-                for (int z = p; z < pend; ++z) { const DpRes &d = h_res[z]; dp += d.score; mlen += d.mlen; blen += d.bi + d.bj - d.mcols; }
-                // DP-class accounting (the class is a pure function of the problem's shape)
-                for (int z = p; z < pend; ++z) {
-                    const DpRes &d = h_res[z];
-                    const bool is_ext = (z == p && has_left) || (z == pend - 1 && has_right);
-                    int cls;
-                    if (is_ext) {
-                        const bool left = z == p && has_left;
-                        const int rq = left ? c.qs : qlen - c.qe, rt = left ? c.rs : tlen - c.re;
-                        const int mq = rq < mo->ext_max ? rq : mo->ext_max, mt = rt < mq + mo->ext_band ? rt : mq + mo->ext_band;
-                        cls = host_dp_class(1, mo->ext_band + 1 + ((mo->ext_band & 1) ? mo->ext_band + 1 : mo->ext_band), mq + mt, pk_max_steps_h, pk_ext_steps_h);
-                    }
-                    else {
-                        const int m_ = d.bi, n_ = d.bj, dl = n_ - m_;
-                        const int W = m_ + n_ > ADAPT_MAX_STEPS ? d_fill_band_wide(m_, n_, mo->bw, mo->fill_band_q4) : d_fill_band(m_, n_, mo->bw, mo->fill_band_q4);
-                        int lo = (dl < 0 ? dl : 0) - W; lo -= lo & 1;
-                        cls = host_dp_class(0, (dl > 0 ? dl : 0) + W - lo + 1, m_ + n_, pk_max_steps_h, 0, pk_wide_steps_h);
-                    }
-                    int64_t *cc = tcls[tslot] + cls * 4;
-                    cc[0] += 1; cc[1] += d.cells; cc[2] += is_ext ? d.bi + d.bj : d.bi + d.bj;
-                    cc[3] += (d.bi + d.tbases + 3) / 4 + 4 * (int64_t)d.nops + 32;
-                }
-                if (has_left) { const DpRes &d = h_res[p]; qs_ = c.qs - d.bi; rs_ = c.rs - d.bj; }
-                if (has_right) { const DpRes &d = h_res[pend - 1]; qe_ = c.qe + d.bi; re_ = c.re + d.bj; }
+                if (has_left) { qs_ = c.qs - S.l_bi; rs_ = c.rs - S.l_bj; }
+                if (has_right) { qe_ = c.qe + S.r_bi; re_ = c.re + S.r_bj; }
                 r.ts = rs_; r.te = re_;
                 if (c.rev) { r.qs = qlen - qe_; r.qe = qlen - qs_; } else { r.qs = qs_; r.qe = qe_; }
-                r.mlen = mlen; r.blen = blen; r.dp_score = dp;
+                r.mlen = S.mlen; r.blen = S.blen; r.dp_score = S.dp;
             }
         });
-        for (int t = 0; t < NT; ++t) for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += tcls[t][z];
         t_as.stop();
     }
 

@@ -149,12 +149,12 @@ def main():
     # reference coordinates by at most the inserted TE bases upstream, so compare loosely)
     prim = al[(al["flags"] & 1) != 0]
     frac_mapped = len(np.unique(prim["qid"])) / max(1, len(d["reads"][2]))
-    # roofline of the dominant kernel: k_dp_pk, the packed-int16 gap-fill DP (DP classes 10-18 in one launch: gap fills by band width + z-drop extensions).  Its
+    # roofline of the dominant kernel: k_dp_pk, the packed-int16 gap-fill DP (DP classes 10-17, gap fills by band width, in one cost-ordered launch).  Its
     # launch duration is measured live with HIP events on the engine's own stream (telr_stage_ms: "k_dp_pk"); its
     # algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per CIGAR
     # run, 32 B result.
     cls = eng.dp_classes()
-    PK = list(range(10, 19))
+    PK = list(range(10, 18))
     k_name = "k_dp_pk"
     k_ms = stage_tot.get("k_dp_pk", 0.0) / a.steps
     k_bytes = float(cls[PK, 3].sum())
@@ -205,9 +205,10 @@ def main():
         ix10 = eng.index([ref_str], io10)
         lib_names = ["fam%d" % i for i in range(len(d["library"]))]
         lib = [bytes(x).decode() for x in d["library"]]
-        locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci[:8], lib_names, lib)      # warm-up
+        # window reads are taken from the stage-1 read set already on the device (telr_seqset_subset)
+        locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci[:8], lib_names, lib, read_set=qs)      # warm-up
         t0 = time.time()
-        lres = locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib)
+        lres = locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib, read_set=qs)
         t_loci = time.time() - t0
         good = 0
         by = {"_".join(r["ID"].split("_")[:3]): r["report"] for r in lres["liftover"]}

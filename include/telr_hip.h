@@ -137,6 +137,10 @@ int  telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo);
 int  telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii,
                         const int64_t *off, const int32_t *len, telr_seqset **out);
 void telr_seqset_free(telr_seqset *s);
+/* a new set holding copies of sequences idx[0..n) of `parent` (repeats allowed), made on the device from the packed
+ * form: no host packing, no upload.  Replaces `seqtk subseq` of window reads out of the read file
+ * (TELR_assembly.py:419-456) when the reads are already resident for stage 1. */
+int  telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out);
 int64_t telr_seqset_bases(const telr_seqset *s);
 int32_t telr_seqset_count(const telr_seqset *s);
 
@@ -156,6 +160,9 @@ int  telr_map(telr_ctx *ctx, const telr_index *idx, const telr_seqset *queries,
 
 int64_t         telr_result_count(const telr_result *r);
 const telr_aln *telr_result_alns(const telr_result *r);     /* sorted by (qid, rank) */
+/* CIGAR ops (BAM encoding, len<<4|op) of all records in one array; a record owns ops
+ * [cigar_off, cigar_off + n_cigar).  The array is filled by one DMA that starts before the final
+ * chain selection, so it may also hold the ops of chains that selection dropped (unreferenced). */
 int64_t         telr_result_cigar_count(const telr_result *r);
 const uint32_t *telr_result_cigars(const telr_result *r);
 void            telr_result_free(telr_result *r);

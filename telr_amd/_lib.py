@@ -9,7 +9,7 @@ SO_PATH = os.path.join(_HERE, "libtelrhip.so")
 
 EXPORTS = [
     "telr_init", "telr_destroy", "telr_strerror", "telr_last_error", "telr_device_name", "telr_preset",
-    "telr_seqset_create", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
+    "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_free",
     "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_depth_medians", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
@@ -37,6 +37,7 @@ def lib():
     L.telr_device_name.restype = C.c_int; L.telr_device_name.argtypes = [vp, cp, C.c_int]
     L.telr_preset.restype = C.c_int; L.telr_preset.argtypes = [cp, C.POINTER(IdxOpt), C.POINTER(MapOpt)]
     L.telr_seqset_create.restype = C.c_int; L.telr_seqset_create.argtypes = [vp, i32, vp, vp, vp, C.POINTER(vp)]
+    L.telr_seqset_subset.restype = C.c_int; L.telr_seqset_subset.argtypes = [vp, vp, i32, vp, C.POINTER(vp)]
     L.telr_seqset_free.restype = None; L.telr_seqset_free.argtypes = [vp]
     L.telr_seqset_bases.restype = i64; L.telr_seqset_bases.argtypes = [vp]
     L.telr_seqset_count.restype = i32; L.telr_seqset_count.argtypes = [vp]

@@ -93,6 +93,16 @@ class SeqSet:
     def bases(self):
         return int(self.eng.L.telr_seqset_bases(self.h))
 
+    def subset(self, idx):
+        """new set = copies of sequences idx (repeats allowed), gathered on the device from the packed form"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        sub = SeqSet.__new__(SeqSet)
+        sub.eng = self.eng
+        h = C.c_void_p()
+        self.eng._chk(self.eng.L.telr_seqset_subset(self.eng.h, self.h, len(idx), idx.ctypes.data, C.byref(h)), "telr_seqset_subset")
+        sub.h = h; sub.len = self.len[idx].copy(); sub.n = len(idx)
+        return sub
+
     def free(self):
         if getattr(self, "h", None):
             self.eng.L.telr_seqset_free(self.h)

@@ -1785,6 +1785,20 @@ __global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ p
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
 
+// ---- sequence-set subset: copy the packed words of the chosen sequences (64-base padded, so whole words) into a new set
+__global__ void __launch_bounds__(256) k_seq_gather(const uint32_t *__restrict__ src2, const uint32_t *__restrict__ srcn,
+                                                    const int64_t *__restrict__ src_boff, const int32_t *__restrict__ idx,
+                                                    const int64_t *__restrict__ dst_boff, int32_t n, uint32_t *__restrict__ dst2, uint32_t *__restrict__ dstn)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int64_t sb = src_boff[idx[i]], db = dst_boff[i], nb = dst_boff[i + 1] - db;      // padded bases, multiples of 64
+    const uint32_t *s2 = src2 + sb / 16, *sn = srcn + sb / 32;
+    uint32_t *d2 = dst2 + db / 16, *dn = dstn + db / 32;
+    for (int64_t w = threadIdx.x; w < nb / 16; w += blockDim.x) d2[w] = s2[w];
+    for (int64_t w = threadIdx.x; w < nb / 32; w += blockDim.x) dn[w] = sn[w];
+}
+
 // ---- per-chain numbers from the per-problem results: one wave per kept chain sums its problems (score, matching
 // bases, block length) and keeps the reach of the two end extensions; the per-problem records stay on the device.
 struct StitchRec { int32_t p0, p1, has_left, pad; };     // problems [p0, p1) of a kept chain

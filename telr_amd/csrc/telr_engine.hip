@@ -211,6 +211,7 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
 
 // ---------------------------------------------------------------------------------------
 // sequence sets
+extern "C" void telr_seqset_free(telr_seqset *s);
 struct telr_seqset {
     telr_ctx *ctx;
     int32_t n = 0;
@@ -267,6 +268,43 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     if ((e = hipMemcpy(s->d_nmask, hn.data(), wn * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (n && (e = hipMemcpy(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    *out = s;
+    return TELR_OK;
+}
+extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out)
+{
+    if (!ctx || !parent || n < 0 || !out || (n > 0 && !idx)) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= parent->n) return TELR_E_ARG;
+    telr_seqset *s = new telr_seqset();
+    s->ctx = ctx; s->n = n; s->boff.resize(n + 1); s->len.resize(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t L = parent->len[idx[i]];
+        s->len[i] = L; s->boff[i] = tot; tot += ((int64_t)L + 63) & ~63LL; s->total_bases += L;
+        if (L > s->max_len) s->max_len = L;
+    }
+    s->boff[n] = tot; s->padded_bases = tot;
+    const size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
+    auto fail = [&](hipError_t e) { ctx->err = std::string("seqset subset: ") + hipGetErrorString(e); telr_seqset_free(s); return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
+    hipError_t e; int32_t *d_idx = nullptr;
+    if ((e = hipMalloc(&s->d_seq2, w2 * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&d_idx, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
+    hipStream_t st = ctx->stream;
+    // the 8 slack words behind the last sequence are read by window loads: keep them defined
+    if ((e = hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st)) != hipSuccess || (e = hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st)) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+    if ((e = hipMemcpyAsync(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+    if (n) {
+        if ((e = hipMemcpyAsync(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice, st)) != hipSuccess || (e = hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+        hipLaunchKernelGGL(k_seq_gather, dim3(n), dim3(256), 0, st, parent->d_seq2, parent->d_nmask, parent->d_boff, d_idx, s->d_boff, n, s->d_seq2, s->d_nmask);
+        if ((e = hipGetLastError()) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+    }
+    e = hipStreamSynchronize(st);
+    (void)hipFree(d_idx);
+    if (e != hipSuccess) return fail(e);
     *out = s;
     return TELR_OK;
 }

@@ -6,8 +6,9 @@ from . import telr_te, telr_af, telr_liftover
 
 
 def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, presets="ont", ref_te_rows=None,
-             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50)):
-    """loci: list of dicts(name, contig, alt, reads).  -> dict(annotation, liftover, summary, af)"""
+             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50), read_set=None):
+    """loci: list of dicts(name, contig, alt, reads).  With `read_set` (the stage-1 read SeqSet resident on the
+    device) a locus gives `read_idx` (indices into it) instead of `reads`.  -> dict(annotation, liftover, summary, af)"""
     names = [l["name"] for l in loci]
     contigs = {l["name"]: l["contig"] for l in loci}
     ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
@@ -17,7 +18,10 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
     contig_te = {}
     for r in ann:                       # one annotation per contig feeds the AF step (first one wins, as a dict would)
         contig_te.setdefault(r[0], (int(r[1]), int(r[2])))
-    freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["reads"] for l in loci}, presets, *af_params)
+    if read_set is not None:
+        freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["read_idx"] for l in loci}, presets, *af_params, read_set=read_set)
+    else:
+        freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["reads"] for l in loci}, presets, *af_params)
     return {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
 
 

@@ -211,6 +211,6 @@ def make_loci_from_dataset(d, n_loci, seed=7, flank=(8000, 15000), reads_cap=60,
             sel.extend(np.nonzero(m)[0].tolist())
         sel = sel[:reads_cap]
         reads = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in sel]
-        loci.append({"name": "chr2L_%d_%d" % (p, p + 1), "contig": bytes(contig).decode(), "alt": bytes(alt).decode(), "reads": reads,
+        loci.append({"name": "chr2L_%d_%d" % (p, p + 1), "contig": bytes(contig).decode(), "alt": bytes(alt).decode(), "reads": reads, "read_idx": list(sel),
                      "truth": {"pos": p, "family": "fam%d" % fam, "strand": "+-"[strand], "tsd": tsd, "af": af}})
     return loci

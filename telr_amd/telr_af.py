@@ -94,12 +94,14 @@ def freq_table(medians):
 
 
 def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_interval=100, flank_offset=200,
-           te_interval=50, te_offset=50):
+           te_interval=50, te_offset=50, read_set=None):
     """Batched replacement of get_af (:578-838).
 
     contigs: {locus name: contig sequence}; contig_te: {locus name: (start, end)} TE coordinates on the
     forward contig; reads_by_locus: {locus name: [read sequences]} (the +-1 kb window reads selected
-    by prep_assembly_inputs(read_type="all"), TELR_assembly.py:384-462).
+    by prep_assembly_inputs(read_type="all"), TELR_assembly.py:384-462) or, with `read_set` (the stage-1
+    SeqSet already resident on the device), {locus name: [read indices]}: the window reads are then gathered on
+    the device instead of being packed and uploaded again.
     Returns {locus name: te_freq dict}.
     """
     from .presets import preset
@@ -119,7 +121,7 @@ def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_inte
         for r in reads_by_locus[n]:
             queries.append(r)
             qtarget_fw.append(tindex[n]); qtarget_rc.append(tindex[n] + 1)
-    qs = engine.seqset(queries)
+    qs = read_set.subset(queries) if read_set is not None else engine.seqset(queries)
     out = {}
     meds = {n: {} for n in names}
     for tag, qt in (("fw", qtarget_fw), ("rc", qtarget_rc)):

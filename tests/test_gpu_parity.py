@@ -404,6 +404,30 @@ def test_concurrent_subbatches(engine):
     assert len(res3.alns) >= 44
 
 
+def test_seqset_subset_matches_fresh_set(engine):
+    """telr_seqset_subset gathers packed sequences on the device: mapping the subset must give exactly what mapping a
+    freshly packed set of the same sequences gives (repeats, an empty read and the last read included)."""
+    rng = np.random.default_rng(77)
+    genome = [synth.random_seq(rng, 90000)]
+    reads, _ = synth.simulate_reads(rng, genome, 30, 4000)
+    reads.insert(5, np.zeros(0, np.uint8))
+    io, mo = preset("map-ont")
+    ix = engine.index([_as_str(g) for g in genome], io)
+    parent = engine.seqset([_as_str(r) for r in reads])
+    idx = [len(reads) - 1, 3, 3, 5, 0, 17]
+    sub = parent.subset(idx)
+    assert sub.n == len(idx) and sub.bases() == sum(len(reads[i]) for i in idx)
+    a = ix.map(sub, mo)
+    b = ix.map([_as_str(reads[i]) for i in idx], mo)
+    assert len(a.alns) == len(b.alns) > 0
+    for f in ALN_FIELDS:
+        np.testing.assert_array_equal(a.alns[f], b.alns[f], err_msg=f)
+    for x, y in zip(a.alns, b.alns):
+        np.testing.assert_array_equal(a.cigars[x["cigar_off"]:x["cigar_off"] + x["n_cigar"]], b.cigars[y["cigar_off"]:y["cigar_off"] + y["n_cigar"]])
+    with pytest.raises(Exception):
+        parent.subset([len(reads)])
+
+
 def test_edge_cases(engine):
     """empty / degenerate inputs and argument errors at the C ABI (no crash, empty result is not an error)"""
     from telr_amd._lib import TelrError

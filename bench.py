@@ -164,12 +164,12 @@ def main():
         def _pmc(path, kern):
             for line in open(os.path.join(ROOT, "profiles", path)):
                 if line.startswith(kern):
-                    return float(line.split()[-1])
+                    return float(line.split()[-2])      # sum over the call's dispatches (first pass + the tiny retry pass)
             return None
         fs = _pmc("r01_pmc_FETCH_SIZE.txt", k_name + " "); ws = _pmc("r01_pmc_WRITE_SIZE.txt", k_name + " ")
         if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:
             traffic = (2.0 * fs + ws) * 1024.0      # gfx950: FETCH_SIZE counts wide reads at 1/2 (MI355X_MICROARCH.md, HBM)
-            traffic_src = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per dispatch; FETCH doubled)"
+            traffic_src = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per map call; FETCH doubled)"
     except Exception:
         pass
     dp_ms = stage_tot.get("dp", 0.0) / a.steps

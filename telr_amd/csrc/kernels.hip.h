@@ -1446,9 +1446,9 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     const int xf = (n - m) - de0;
     const bool fin_here = have && xf >= 0 && xf < 4 * R;
     const int fin_r = xf >> 2, fin_hi = (xf >> 1) & 1;
-    uint32_t fin = PK_NEG, te[R];
+    uint32_t fin = PK_NEG, te[R], prow[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) te[r] = 0;
+    for (int r = 0; r < R; ++r) { te[r] = 0; prow[r] = 0; }
     if (NW > 1) {       // the first odd step reads the next wave's initial even state
         if (wl == 0) { uint32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
         __syncthreads();
@@ -1525,7 +1525,37 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 }
                 prev_cur = cur;
             }
-            if (k <= last_row) {
+            if constexpr (LPP == 1 && !EXT) {
+                // one lane owns whole rows, and rows k-1 / k are adjacent: write them as one 8R-byte piece (a full 64-byte
+                // line for R = 8) instead of two half pieces that reach memory at different times
+                if (k & 1) {
+                    uint32_t *dst = tb32 + (int64_t)(k - 1) * RW;
+                    if (k <= last_row) {
+                        if constexpr (R % 2 == 0) {
+#pragma unroll
+                            for (int r = 0; r < R; r += 2) *(uint2*)(dst + r) = make_uint2(prow[r], prow[r + 1]);
+#pragma unroll
+                            for (int r = 0; r < R; r += 2) *(uint2*)(dst + R + r) = make_uint2(row[r], row[r + 1]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) dst[r] = prow[r];
+#pragma unroll
+                            for (int r = 0; r < R; ++r) dst[R + r] = row[r];
+                        }
+                    } else if (k - 1 <= last_row) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) dst[r] = prow[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) prow[r] = row[r];
+                    if (2 * (k + 1) > amax && k <= last_row) {        // last trip of the wave: nothing will pair with this row
+                        uint32_t *dst = tb32 + (int64_t)k * RW;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) dst[r] = row[r];
+                    }
+                }
+            } else if (k <= last_row) {
                 uint32_t *dst = tb32 + (int64_t)k * RW;
                 if constexpr (R % 4 == 0) {
 #pragma unroll

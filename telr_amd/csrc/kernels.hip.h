@@ -337,11 +337,46 @@ __global__ void k_bucket_table(const uint64_t *__restrict__ ent_hash, int32_t n_
     for (uint32_t b = lo; b <= hi; ++b) bstart[b] = (uint32_t)e;
 }
 
+// probe table: open addressing (linear probing, load <= 1/2) over 16-byte slots {hash, first occurrence, count}: one
+// 64-byte line answers almost every probe, where bucket table -> hash array -> offset array needs three.  The slot
+// comes from a multiplicative re-hash: minimizer hashes are window MINIMA, i.e. heavily skewed towards small values,
+// so their top bits alone would pile ten times the average load onto the low slots.
+__device__ __forceinline__ uint32_t d_ht_slot(uint64_t h, int ht_shift, uint32_t ht_mask)
+{
+    return (uint32_t)((h * 0x9E3779B97F4A7C15ULL) >> ht_shift) & ht_mask;
+}
+struct HtSlot { uint64_t hash; uint32_t off, cnt; };
+#define HT_EMPTY 0xffffffffffffffffULL
 struct IndexView {
     const uint64_t *ent_hash; const uint32_t *ent_off; const uint32_t *pos; const uint32_t *bstart;
     const uint32_t *goff; const int32_t *tlen;
     int32_t n_ent; int32_t shift; int32_t k, w;
+    const HtSlot *ht; int32_t ht_shift; uint32_t ht_mask;
 };
+__global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t *__restrict__ ent_off, int32_t n_ent, int ht_shift, uint32_t ht_mask, HtSlot *__restrict__ ht)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ent) return;
+    const uint64_t h = ent_hash[e];
+    uint32_t s = d_ht_slot(h, ht_shift, ht_mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&ht[s].hash, (unsigned long long)HT_EMPTY, (unsigned long long)h);
+        if (old == HT_EMPTY) { ht[s].off = ent_off[e]; ht[s].cnt = ent_off[e + 1] - ent_off[e]; return; }
+        s = (s + 1) & ht_mask;
+    }
+}
+// -> true and (off, cnt) of the minimizer's occurrence list, or false
+__device__ __forceinline__ bool d_ht_lookup(const IndexView &I, uint64_t h, uint32_t &off, uint32_t &cnt)
+{
+    uint32_t s = d_ht_slot(h, I.ht_shift, I.ht_mask);
+    for (;;) {
+        const uint4 v = *(const uint4*)&I.ht[s];
+        const uint64_t hh = (uint64_t)v.y << 32 | v.x;
+        if (hh == h) { off = v.z; cnt = v.w; return true; }
+        if (hh == HT_EMPTY) return false;
+        s = (s + 1) & I.ht_mask;
+    }
+}
 
 __device__ __forceinline__ int32_t d_lookup(const IndexView &I, uint64_t h)
 {
@@ -362,7 +397,8 @@ struct SeedArgs {
     const int32_t *q_order;      // block -> query (longest first), nullable
     int32_t mid_occ;
     int32_t *mz_cnt;             // MODE 0 out
-    int32_t *mz_ent;             // MODE 0 out / MODE 1 in: index entry of the minimizer (-1 = absent), saves the second probe
+    int32_t *mz_ent;             // MODE 0 out / MODE 1 in: first occurrence of the minimizer in `pos` (saves the second probe)
+    int32_t *mz_n;               // MODE 0 out / MODE 1 in: its occurrence count (0 = absent)
     const int32_t *mz_aoff;      // MODE 1 in
     uint64_t *keys;              // MODE 1 out
 };
@@ -378,12 +414,18 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
     const int qlen = A.qlen[q];
     for (int g = m0 + threadIdx.x; g < m1; g += blockDim.x) {
         uint64_t x = A.mz_x[g];
-        int32_t e;
-        if (MODE == 0) { e = d_lookup(A.I, x >> 8); A.mz_ent[g] = e; }
-        else { if (A.mz_aoff[g + 1] == A.mz_aoff[g]) continue; e = A.mz_ent[g]; }
-        int32_t cnt = 0; uint32_t o0 = 0, o1 = 0;
-        if (e >= 0) {
-            o0 = A.I.ent_off[e]; o1 = A.I.ent_off[e + 1];
+        uint32_t o0 = 0, o1 = 0;
+        if (MODE == 0) {
+            uint32_t off = 0, n = 0;
+            if (!d_ht_lookup(A.I, x >> 8, off, n)) n = 0;
+            A.mz_ent[g] = (int32_t)off; A.mz_n[g] = (int32_t)n;
+            o0 = off; o1 = off + n;
+        } else {
+            if (A.mz_aoff[g + 1] == A.mz_aoff[g]) continue;
+            o0 = (uint32_t)A.mz_ent[g]; o1 = o0 + (uint32_t)A.mz_n[g];
+        }
+        int32_t cnt = 0;
+        if (o1 > o0) {
             if (tf >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t gp = A.I.pos[o] >> 1; cnt += (gp >= g0 && gp < g1) ? 1 : 0; } }
             else cnt = (int32_t)(o1 - o0);
             if (cnt > A.mid_occ) cnt = 0;

@@ -453,13 +453,14 @@ struct telr_index {
     int64_t n_mz = 0; int32_t n_ent = 0;
     int32_t bucket_bits = 0, shift = 0;
     uint64_t *d_ent_hash = nullptr; uint32_t *d_ent_off = nullptr, *d_pos = nullptr, *d_bstart = nullptr, *d_goff = nullptr;
+    HtSlot *d_ht = nullptr; int32_t ht_shift = 0; uint32_t ht_mask = 0;       // probe table of the seeding kernel
     std::vector<uint32_t> sorted_counts; // ascending, for the mid_occ quantile
 };
 
 extern "C" void telr_index_free(telr_index *ix)
 {
     if (!ix) return;
-    (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff);
+    (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff); (void)hipFree(ix->d_ht);
     delete ix;
 }
 extern "C" int telr_index_stats(const telr_index *ix, int64_t *n_mz, int64_t *n_distinct)
@@ -533,6 +534,15 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
     HIPCHK(hipMalloc(&ix->d_bstart, ((size_t)nb + 2) * 4));
     hipLaunchKernelGGL(k_bucket_table, dim3((n_ent + 1 + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, n_ent, ix->shift, nb, ix->d_bstart);
     HIPCHK(hipGetLastError());
+    // probe table for seeding: power-of-two slots, at least twice the distinct minimizers
+    {
+        int hb = 4; while ((1LL << hb) < 2LL * n_ent && hb < 30) ++hb;      // load <= 1/2, at least one empty slot
+        ix->ht_shift = 64 - hb; ix->ht_mask = (uint32_t)((1ULL << hb) - 1);
+        HIPCHK(hipMalloc(&ix->d_ht, ((size_t)1 << hb) * sizeof(HtSlot)));
+        HIPCHK(hipMemsetAsync(ix->d_ht, 0xff, ((size_t)1 << hb) * sizeof(HtSlot), ctx->stream));
+        if (n_ent > 0) hipLaunchKernelGGL(k_ht_build, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, ix->d_ent_off, n_ent, ix->ht_shift, ix->ht_mask, ix->d_ht);
+        HIPCHK(hipGetLastError());
+    }
     // occurrence counts, sorted, to the host for the -f quantile
     ix->sorted_counts.resize(n_ent);
     if (n_ent > 0) {
@@ -1031,14 +1041,16 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     StageTimer t_sd(ctx, ST_SEED, true);
     IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = ix->d_bstart; I.goff = ix->d_goff;
     I.tlen = tg->d_len; I.n_ent = ix->n_ent; I.shift = ix->shift; I.k = k; I.w = w;
+    I.ht = ix->d_ht; I.ht_shift = ix->ht_shift; I.ht_mask = ix->ht_mask;
     int32_t *d_mcnt, *d_maoff, *d_qaoff;
-    int32_t *d_ment;
+    int32_t *d_ment, *d_mn;
     TRY(ctx_buf_t(ctx, "mz_ent", (size_t)nmz + 1, &d_ment));
+    TRY(ctx_buf_t(ctx, "mz_n", (size_t)nmz + 1, &d_mn));
     TRY(ctx_buf_t(ctx, "mz_cnt", (size_t)nmz + 1, &d_mcnt));
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
+    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
     hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));

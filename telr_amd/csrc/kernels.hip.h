@@ -158,6 +158,90 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
     }
 }
 
+// k <= 15: k-mer, hash and the LDS window all fit in 32 bits (same values as the 64-bit path, checked step by step:
+// every masked step of d_hash64 only depends on the low 2k bits)
+__device__ __forceinline__ uint32_t d_hash32(uint32_t key, uint32_t mask)
+{
+    key = (~key + (key << 21)) & mask;
+    key = key ^ key >> 24;
+    key = ((key + (key << 3)) + (key << 8)) & mask;
+    key = key ^ key >> 14;
+    key = ((key + (key << 2)) + (key << 4)) & mask;
+    key = key ^ key >> 28;
+    key = (key + (key << 31)) & mask;
+    return key;
+}
+template <int MODE>
+__global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int halo = A.w - 1, nslot = SK_TILE + 2 * halo;
+    uint32_t *xs = (uint32_t*)smem;
+    uint8_t *zs = (uint8_t*)(xs + nslot);
+    __shared__ int32_t wsum[SK_THREADS / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int sid = A.tile_seq[t], u0 = A.tile_u0[t];
+    const int L = A.len[sid], ns = L - A.k + 1, k = A.k;
+    const int64_t base = A.boff[sid];
+    const uint32_t mask = (1u << 2 * k) - 1;
+    for (int s = tid; s < nslot; s += SK_THREADS) {
+        int u = u0 - halo + s;
+        uint32_t x = 0xffffffffu; uint8_t z = 0;
+        if (u >= 0 && u < ns) {
+            uint32_t nb = d_get_nbits(A.nmask, base + u, k);
+            if (nb == 0) {
+                const int64_t bb = base + u; const int64_t wi = bb >> 4; const int sh = (int)(bb & 15) * 2;
+                const uint32_t v = __builtin_amdgcn_alignbit(A.seq2[wi + 1], A.seq2[wi], sh) & mask;     // first base in the low bits
+                const uint32_t r = __brev(v) >> (32 - 2 * k);
+                const uint32_t fw = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u), rv = (~v) & mask;
+                if (fw != rv) {
+                    z = fw < rv ? 0 : 1;
+                    x = d_hash32(z ? rv : fw, mask);
+                }
+            }
+        }
+        xs[s] = x; zs[s] = z;
+    }
+    __syncthreads();
+    const int need = A.w < ns ? A.w : ns;
+    uint32_t sel = 0;
+#pragma unroll
+    for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
+        int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
+        uint32_t x = xs[s];
+        if (u < ns && x != 0xffffffffu) {
+            int Lc = 0, Rc = 0;
+            while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
+            while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
+            if (Lc + Rc + 1 >= need) sel |= 1u << c;
+        }
+    }
+    int cnt = __popc(sel);
+    // block exclusive scan of cnt (wave scan + cross-wave in LDS)
+    int lane = tid & 63, wv = tid >> 6, inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SK_THREADS / 64; ++i) { if (i < wv) wbase += wsum[i]; total += wsum[i]; }
+    if (MODE == 0 || MODE == 2) {
+        if (tid == 0) A.tile_cnt[t] = total;
+    }
+    if (MODE != 0) {
+        int64_t o = (MODE == 2 ? (int64_t)t * SK_TILE : (int64_t)A.tile_off[t]) + wbase + inc - cnt;
+        uint32_t g0 = A.goff ? A.goff[sid] : 0u;
+#pragma unroll
+        for (int c = 0; c < SK_TILE / SK_THREADS; ++c) if (sel >> c & 1) {
+            int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
+            A.out_x[o] = (uint64_t)xs[s] << 8 | (uint64_t)k;
+            A.out_y[o] = (g0 + (uint32_t)(u + k - 1)) << 1 | zs[s];
+            ++o;
+        }
+    }
+}
+
 // staging -> dense: one block per tile copies its tile_cnt entries to tile_off (coalesced both ways)
 __global__ void __launch_bounds__(256) k_sketch_compact(const uint64_t *__restrict__ sx, const uint32_t *__restrict__ sy, const int32_t *__restrict__ tile_cnt,
                                                         const int32_t *__restrict__ tile_off, uint64_t *__restrict__ out_x, uint32_t *__restrict__ out_y)

@@ -390,7 +390,11 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     TRY(ctx_buf_t(ctx, (P + "stg_x").c_str(), (size_t)T.n * SK_TILE, &d_sx));
     TRY(ctx_buf_t(ctx, (P + "stg_y").c_str(), (size_t)T.n * SK_TILE, &d_sy));
     if (hpc) { H.out_x = d_sx; H.out_y = d_sy; hipLaunchKernelGGL(k_sketch_hpc<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H); }
-    else { A.out_x = d_sx; A.out_y = d_sy; hipLaunchKernelGGL(k_sketch<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A); }
+    else {
+        A.out_x = d_sx; A.out_y = d_sy;
+        if (k <= 15 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL(k_sketch32<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        else hipLaunchKernelGGL(k_sketch<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+    }
     HIPCHK(hipGetLastError());
     // exclusive scan over T.n+1 entries so that tile_off[T.n] = total
     HIPCHK(hipMemsetAsync(d_tcnt + T.n, 0, 4, ctx->stream));

@@ -1420,6 +1420,40 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     return TELR_OK;
 }
 
+// A non-owning sequence set made of sequences idx[] of `parent`, gathered on c's stream into c's grow-only scratch
+// (no allocation in the steady state); valid until the next call with the same tag.
+static int seqset_subset_into(telr_ctx *ctx, const telr_seqset *parent, const std::vector<int32_t> &idx, const std::string &tag, telr_seqset *s)
+{
+    telr_ctx *c = ctx;
+    const int n = (int)idx.size();
+    s->ctx = c; s->n = n; s->boff.resize(n + 1); s->len.resize(n); s->total_bases = 0; s->max_len = 0;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t L = parent->len[idx[i]];
+        s->len[i] = L; s->boff[i] = tot; tot += ((int64_t)L + 63) & ~63LL; s->total_bases += L;
+        if (L > s->max_len) s->max_len = L;
+    }
+    s->boff[n] = tot; s->padded_bases = tot;
+    const size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
+    int32_t *d_idx;
+    TRY(ctx_buf_t(c, (tag + "seq2").c_str(), w2, &s->d_seq2));
+    TRY(ctx_buf_t(c, (tag + "nmask").c_str(), wn, &s->d_nmask));
+    TRY(ctx_buf_t(c, (tag + "boff").c_str(), (size_t)n + 1, &s->d_boff));
+    TRY(ctx_buf_t(c, (tag + "len").c_str(), (size_t)n + 1, &s->d_len));
+    TRY(ctx_buf_t(c, (tag + "idx").c_str(), (size_t)n + 1, &d_idx));
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st));
+    HIPCHK(hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st));
+    HIPCHK(hipMemcpyAsync(s->d_boff, s->boff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(s->d_len, s->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_idx, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_seq_gather, dim3(n), dim3(256), 0, st, parent->d_seq2, parent->d_nmask, parent->d_boff, d_idx, s->d_boff, n, s->d_seq2, s->d_nmask);
+        HIPCHK(hipGetLastError());
+    }
+    return TELR_OK;
+}
+
 extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const telr_map_opt *mo, telr_result **out)
 {
     if (!ctx || !ix || !queries || !mo || !out) return TELR_E_ARG;
@@ -1451,7 +1485,80 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     int nsub = 1;      // measured on the MI355X box: concurrency only pays when host cores are plentiful; opt-in via TELR_SUBBATCH
     if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
     if (nsub > nq) nsub = nq > 0 ? nq : 1;
-    if (nsub == 1) {
+    // ---- long-read lane.  Seeding, chaining, back-tracking and the problem builder give one wave to a read, so a batch
+    // waits for its longest read in each of these stages while the device idles.  The few reads longer than a third of
+    // the longest one are therefore mapped as their own small batch on a worker context, concurrently with the rest.
+    bool lane = false;
+    std::vector<int32_t> lane_idx[2];         // 0: the bulk, 1: the long reads (original query ids, ascending)
+    {
+        const char *e = getenv("TELR_LONGSPLIT");
+        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "0");
+        if (nsub == 1 && !off && !ctx->is_child && nq >= 2 && (force || (!ctx->debug && nq >= 2000 && total_bases >= 100000000LL))) {
+            const int32_t thr = std::max(queries->max_len / 3, force ? 0 : 30000);
+            int64_t long_bases = 0;
+            for (int i = 0; i < nq; ++i) { const int k = queries->len[i] > thr ? 1 : 0; lane_idx[k].push_back(i); if (k) long_bases += queries->len[i]; }
+            lane = !lane_idx[0].empty() && !lane_idx[1].empty() && (force || long_bases * 100 <= total_bases * 35);
+        }
+    }
+    if (lane) {
+        for (int k = 0; k < 2; ++k) { int r = ctx_make_child(ctx, k); if (r != TELR_OK) { delete R; return r; } }
+        // the recycled (large) result buffer goes to the bulk worker, whose result becomes this call's result
+        for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
+        ctx->cig_pool.clear();
+        telr_seqset sub[2]; telr_result *part[2] = { nullptr, nullptr }; int rc[2] = { TELR_OK, TELR_OK };
+        auto work = [&](int k) {
+            telr_ctx *c = ctx->child[k];
+            (void)hipSetDevice(c->device);
+            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0;
+            part[k] = new telr_result(); part[k]->ctx = nullptr;
+            const int n = (int)lane_idx[k].size();
+            if ((rc[k] = seqset_subset_into(c, queries, lane_idx[k], "lane_", &sub[k])) != TELR_OK) return;
+            int32_t *d_q = nullptr;
+            if (qtarget) {
+                std::vector<int32_t> qt(n);
+                for (int i = 0; i < n; ++i) qt[i] = qtarget[lane_idx[k][i]];
+                if ((rc[k] = ctx_buf_t(c, "lane_qt", (size_t)n + 1, &d_q)) != TELR_OK) return;
+                if (hipMemcpy(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
+            }
+            c->ctr.query_bases += sub[k].total_bases;
+            rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, part[k]);
+        };
+        std::thread tl(work, 1);
+        work(0);
+        tl.join();
+        sub[0].d_seq2 = sub[0].d_nmask = nullptr; sub[1].d_seq2 = sub[1].d_nmask = nullptr;       // scratch of the workers, not owned
+        for (int k = 0; k < 2; ++k) if (rc[k] != TELR_OK) { ctx->err = ctx->child[k]->err; for (auto *p : part) delete p; delete R; return rc[k]; }
+        // merge: the bulk result's CIGAR buffer becomes the result's, the long reads' ops are appended; records are
+        // merged by original query id (both lists are sorted by it)
+        telr_result *P0 = part[0], *P1 = part[1];
+        R->cig = P0->cig; R->cap = P0->cap; R->ncig = P0->ncig; P0->cig = nullptr; P0->cap = 0; P0->ncig = 0;
+        const size_t base1 = R->ncig;
+        if (!cig_grow(&R->cig, &R->cap, base1, base1 + P1->ncig + 1)) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; }
+        const int NT = host_threads();
+        { const size_t nw = P1->ncig; const int chunks = 16;
+          parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
+              for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + base1 + lo, P1->cig + lo, (hi - lo) * 4); }
+          }); }
+        R->ncig = base1 + P1->ncig;
+        R->alns.resize(P0->alns.size() + P1->alns.size());
+        { size_t a = 0, b = 0, o = 0;
+          const size_t na = P0->alns.size(), nb = P1->alns.size();
+          while (a < na || b < nb) {
+              const int32_t qa = a < na ? lane_idx[0][P0->alns[a].qid] : INT32_MAX, qb = b < nb ? lane_idx[1][P1->alns[b].qid] : INT32_MAX;
+              if (qa < qb) { telr_aln r = P0->alns[a++]; r.qid = qa; R->alns[o++] = r; }
+              else { telr_aln r = P1->alns[b++]; r.qid = qb; r.cigar_off += (int64_t)base1; R->alns[o++] = r; }
+          } }
+        for (int k = 0; k < 2; ++k) {
+            telr_ctx *c = ctx->child[k];
+            for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
+            const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
+            for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
+            for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
+            ctx->dp_retries += c->dp_retries;
+            part[k]->ctx = c;
+            delete part[k];
+        }
+    } else if (nsub == 1) {
         // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
         int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
         if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }

@@ -404,6 +404,27 @@ def test_concurrent_subbatches(engine):
     assert len(res3.alns) >= 44
 
 
+def test_long_read_lane(engine):
+    """Large calls map their few longest reads as a separate small batch on a worker context, concurrently with the
+    rest; the merged result must be identical to the single-batch result (forced here on a small input), with and
+    without per-query target filters."""
+    import os
+    rng = np.random.default_rng(99)
+    genome = [synth.random_seq(rng, 150000), synth.random_seq(rng, 60000)]
+    reads, _ = synth.simulate_reads(rng, genome, 40, 3000)
+    long_reads, _ = synth.simulate_reads(rng, genome, 4, 30000)
+    reads[3:3] = long_reads[:2]; reads.extend(long_reads[2:]); reads.insert(9, np.zeros(0, np.uint8))
+    io, mo = preset("map-ont")
+    os.environ["TELR_LONGSPLIT"] = "force"
+    try:
+        res, oref = compare_all(engine, genome, reads, io, mo, stages=False)
+        qt = np.array([i % 3 - 1 for i in range(len(reads))], np.int32)      # -1 / 0 / 1
+        compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
+    finally:
+        del os.environ["TELR_LONGSPLIT"]
+    assert len(res.alns) >= 40
+
+
 def test_seqset_subset_matches_fresh_set(engine):
     """telr_seqset_subset gathers packed sequences on the device: mapping the subset must give exactly what mapping a
     freshly packed set of the same sequences gives (repeats, an empty read and the last read included)."""

@@ -686,21 +686,22 @@ __global__ void k_backtrack(const uint64_t *__restrict__ keys, const int32_t *__
 // lanes copy the chain's anchors (coalesced gather/scatter).  Queries with more than BT_CAP anchors take the
 // global-memory path of k_backtrack on lane 0.  Same visiting order and acceptance rule as k_backtrack.
 #define BT_CAP 8192
-__global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                                    const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
-                                                    const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
-                                                    uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains,
-                                                    const int32_t *__restrict__ q_order)
+// The back-tracking state of one query lives in LDS (2 x uint16 per anchor).  Two launches share this body: the bulk
+// launch gives every query 32 KB (BT_CAP anchors) and leaves the longer ones to a second, concurrent launch whose blocks
+// own the whole 160 KB of a CU (BT_CAP_BIG anchors); only beyond that does a single lane chase pointers in global memory.
+#define BT_CAP_BIG 40000
+__device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big, uint16_t *pdel, uint16_t *idx, int32_t *sh,
+                                                  const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff,
+                                                  const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
+                                                  const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
+                                                  uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
 {
-    __shared__ uint16_t pdel[BT_CAP], idx[BT_CAP];      // pdel: i - p[i] (1..256), 0 = chain start, 0xffff = visited
-    __shared__ int32_t sh[2];
     const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= nq) return;
-    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;
     const int64_t base = q_aoff[q];
     const int n = q_aoff[q + 1] - q_aoff[q], np = n_peaks[q];
     ChainRec *out = rec + ch_off[q];
-    if (n > BT_CAP) {
+    if (n > cap) {
+        if (defer_big) return;
         if (lane == 0) {
             int nch = 0, wr = 0;
             for (int t = 0; t < np; ++t) {
@@ -758,6 +759,31 @@ __global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__
         }
     }
     if (lane == 0) n_chains[q] = nch;
+}
+__global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
+                                                    const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
+                                                    const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
+                                                    uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains,
+                                                    const int32_t *__restrict__ q_order, int32_t cap, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt)
+{
+    extern __shared__ uint16_t bt_lds[];
+    __shared__ int32_t sh[2];
+    uint16_t *pdel = bt_lds, *idx = bt_lds + cap;
+    if (big_list) {      // second launch: the queries the bulk launch leaves out, a few blocks looping over the list
+        const int nb = *big_cnt;
+        for (int e = blockIdx.x; e < nb; e += gridDim.x) {
+            d_backtrack_query(big_list[e], cap, false, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
+            __syncthreads();
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= nq) return;
+    d_backtrack_query(q_order ? q_order[blockIdx.x] : blockIdx.x, cap, true, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
+}
+__global__ void k_bt_big(const int32_t *__restrict__ q_aoff, int32_t nq, int32_t cap, int32_t *__restrict__ big_list, int32_t *__restrict__ big_cnt)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq && q_aoff[q + 1] - q_aoff[q] > cap) big_list[atomicAdd(big_cnt, 1)] = q;
 }
 
 // ---------------------------------------------------------------------------------------

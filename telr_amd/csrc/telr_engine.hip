@@ -597,14 +597,16 @@ static int32_t index_mid_occ(const telr_index *ix, const telr_map_opt *mo)
 // host-side chain selection (the oracle's select_chains(), restated for the product)
 struct Sel { int32_t ci, key, ord, fs, fe, tid, parent, subsc, n_sub, keep; };
 
+// (same outcome as the oracle's quadratic loops; primaries and per-target tallies are kept in small side lists so that a
+// read with thousands of repeat-induced chains stays linear in its chains times its primaries)
 static void select_chains(std::vector<Sel> &s, const telr_map_opt *mo, const std::vector<int32_t> &sub_score)
 {
     const bool per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
     const int n = (int)s.size();
+    std::vector<int32_t> prim;                       // indices of the primaries found so far, in rank order
     for (int i = 0; i < n; ++i) {
         s[i].parent = i; s[i].subsc = 0; s[i].n_sub = 0;
-        for (int j = 0; j < i; ++j) {
-            if (s[j].parent != j) continue;
+        for (int j : prim) {
             if (per_t && s[j].tid != s[i].tid) continue;
             int32_t lo = std::max(s[i].fs, s[j].fs), hi = std::min(s[i].fe, s[j].fe);
             int32_t ol = hi > lo ? hi - lo : 0;
@@ -616,15 +618,22 @@ static void select_chains(std::vector<Sel> &s, const telr_map_opt *mo, const std
                 break;
             }
         }
+        if (s[i].parent == i) prim.push_back(i);
     }
+    int n2_all = 0; std::vector<std::pair<int32_t, int32_t>> n2_tid;     // kept secondaries so far (per target with PER_TARGET)
     for (int i = 0; i < n; ++i) {
         if (s[i].parent == i) { s[i].keep = 1; continue; }
         s[i].keep = 0;
         if (!mo->secondary) continue;
         if ((float)s[i].key < (float)s[s[i].parent].key * mo->pri_ratio) continue;
-        int n2 = 0;
-        for (int j = 0; j < i; ++j) if (s[j].keep && s[j].parent != j && (!per_t || s[j].tid == s[i].tid)) ++n2;
-        if (n2 < mo->best_n) s[i].keep = 1;
+        int *cnt = &n2_all;
+        if (per_t) {
+            size_t z = 0;
+            while (z < n2_tid.size() && n2_tid[z].first != s[i].tid) ++z;
+            if (z == n2_tid.size()) n2_tid.push_back(std::make_pair(s[i].tid, 0));
+            cnt = &n2_tid[z].second;
+        }
+        if (*cnt < mo->best_n) { s[i].keep = 1; ++*cnt; }
     }
 }
 static bool sel_less(const Sel &x, const Sel &y) { return x.key != y.key ? x.key > y.key : x.ord < y.ord; }
@@ -1131,9 +1140,25 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     if (getenv("TELR_BT_THREAD"))
         hipLaunchKernelGGL(k_backtrack, dim3((nq + 63) / 64), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
                            mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
-    else
-        hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder);
+    else {
+        // queries with more than BT_CAP anchors: their own launch with CU-sized LDS blocks on a side stream, under the bulk launch
+        int32_t *d_big; TRY(ctx_buf_t(ctx, "bt_big", (size_t)nq + 1, &d_big));      // [0] count, then the list
+        HIPCHK(hipMemsetAsync(d_big, 0, 4, st));
+        hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP, d_big + 1, d_big);
+        HIPCHK(hipGetLastError());
+        static bool attr_set = false;
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG * 4)); attr_set = true; }
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_backtrack_w, dim3(256), dim3(64), (size_t)BT_CAP_BIG * 4, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP_BIG, (const int32_t*)(d_big + 1), (const int32_t*)d_big);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0]));
+        hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), (size_t)BT_CAP * 4, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[0], 0));
+    }
     HIPCHK(hipGetLastError());
     int32_t *h_nch, *h_choff, *h_qaoff; ChainRec *h_rec;
     TRY(ctx_hbuf_t(ctx, "h_nch", (size_t)nq + 1, &h_nch));
@@ -1154,7 +1179,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     std::vector<int32_t> q_ch0(nq + 1, 0);
     for (int q = 0; q < nq; ++q) q_ch0[q + 1] = q_ch0[q] + h_nch[q];
     const int n_chain_tot = q_ch0[nq];
-    std::vector<HostChain> chains((size_t)n_chain_tot);          // all chains of the batch, query-major
+    HostChain *chains;                                            // all chains of the batch, query-major (grow-only pinned
+    TRY(ctx_hbuf_t(ctx, "h_chains", (size_t)n_chain_tot + 1, &chains));   // scratch: a fresh vector would be zero-filled and page-faulted every call)
     std::vector<int32_t> kept;                                    // indices into chains, query-major, pass-1 rank order
     std::vector<int32_t> q_k0(nq + 1, 0);
     {
@@ -1197,7 +1223,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     ctx->ctr.chains += n_chain_tot;
     if (ctx->debug) {
         ctx->dbg_chain.clear();
-        for (const HostChain &c : chains) { int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
+        for (int ci = 0; ci < n_chain_tot; ++ci) { const HostChain &c = chains[ci]; int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
     }
     const int nk = (int)kept.size();
     t_sel.stop();
@@ -1378,6 +1404,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             select_chains(s2, mo, cscore);
             const int n2 = (int)s2.size();
             newidx.assign(n2, -1);
+            bool seen_primary = false; std::vector<int32_t> seen_tid;
             int nkp = 0;
             for (int i = 0; i < n2; ++i) if (s2[i].keep) newidx[i] = nkp++;
             for (int i = 0; i < n2; ++i) {
@@ -1387,7 +1414,11 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                 r.parent = newidx[s2[i].parent]; r.subsc = s2[i].subsc; r.n_sub = s2[i].n_sub;
                 if (s2[i].parent == i) {
                     bool first = true;
-                    for (int j = 0; j < i; ++j) if (s2[j].keep && s2[j].parent == j && (!per_t || s2[j].tid == s2[i].tid)) { first = false; break; }
+                    if (!per_t) { first = !seen_primary; seen_primary = true; }
+                    else {
+                        for (int32_t t2 : seen_tid) if (t2 == s2[i].tid) { first = false; break; }
+                        if (first) seen_tid.push_back(s2[i].tid);
+                    }
                     r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
                 } else r.flags |= TELR_F_SECONDARY;
                 r.mapq = mapq_of(r, mo);

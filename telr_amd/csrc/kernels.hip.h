@@ -1010,7 +1010,21 @@ __device__ __forceinline__ int d_cls_slots(int cls)
     if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 32 : 16;
     return cls == 5 ? 32 : 64 << (cls - 6);
 }
+// any ambiguous base among the n bases from absolute index lo on?
+__device__ __forceinline__ bool d_any_n(const uint32_t *__restrict__ nmask, int64_t lo, int n)
+{
+    if (n <= 0) return false;
+    const int64_t hi = lo + n - 1;
+    for (int64_t w = lo >> 5; w <= (hi >> 5); ++w) {
+        uint32_t m = nmask[w];
+        if (w == (lo >> 5)) m &= ~0u << (int)(lo & 31);
+        if (w == (hi >> 5)) m &= ~0u >> (31 - (int)(hi & 31));
+        if (m) return true;
+    }
+    return false;
+}
 __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
+                             const uint32_t *__restrict__ qnmask, const uint32_t *__restrict__ tnmask,
                              int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1018,6 +1032,11 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
     int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps, pk_wide_steps);
+    if (cls >= 10 && P.kind < 3) {
+        // the packed kernels have no ambiguity case: a problem with an N inside either window takes an int32 class
+        const bool hasn = d_any_n(qnmask, P.qstep > 0 ? P.qi0 : P.qi0 - P.m + 1, P.m) || d_any_n(tnmask, P.tstep > 0 ? P.ti0 : P.ti0 - P.n + 1, P.n);
+        if (hasn) cls = d_dp_class(P.kind, D, P.m + P.n, 0, 0, 0);
+    }
     int64_t tb;
     if (P.kind >= 3) tb = 0;
     else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 15) & ~15LL;
@@ -1262,6 +1281,21 @@ __device__ __forceinline__ void d_stream_fill(BaseStream &S, const uint32_t *__r
     else { uint64_t w; uint32_t nm; d_load32(seq2, nmask, i0 - x - 31, tot, w, nm); S.w = d_rev2(w, 32); S.nm = __brev(nm); }
     if (comp) S.w = ~S.w;
 }
+// the same without the ambiguity mask (windows known to be free of N: only cells outside the matrix can see one)
+__device__ __forceinline__ void d_stream_fill_acgt(BaseStream &S, const uint32_t *__restrict__ seq2, int64_t i0, int step, int x, int comp, int64_t tot)
+{
+    int64_t s = step > 0 ? i0 + x : i0 - x - 31; int lsh = 0;
+    if (s < 0) { lsh = (int)(-s); s = 0; }
+    if (s > tot) s = tot;
+    const int64_t wi = s >> 4; const int sh = (int)(s & 15) * 2;
+    const uint64_t lo = (uint64_t)seq2[wi] | (uint64_t)seq2[wi + 1] << 32, hi = seq2[wi + 2];
+    uint64_t v = lo >> sh;
+    if (sh) v |= hi << (64 - sh);
+    if (lsh) v = lsh >= 32 ? 0 : v << (2 * lsh);
+    if (step <= 0) v = d_rev2(v, 32);
+    S.w = comp ? ~v : v; S.nm = 0;
+}
+__device__ __forceinline__ int d_stream_next_acgt(BaseStream &S) { const int c = (int)((uint32_t)S.w & 3u); S.w >>= 2; return c; }
 __device__ __forceinline__ int d_stream_next(BaseStream &S)
 {
     const int c = (int)((uint32_t)S.w & 3u), isn = (int)(S.nm & 1u);
@@ -1468,11 +1502,10 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     op = pk_sub(hu, c.qe);   g = pk_sub(f1u, c.e);  vf1 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00100010u;
     op = pk_sub(hl, c.q2e2); g = pk_sub(e2l, c.e2); ve2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00200020u;
     op = pk_sub(hu, c.q2e2); g = pk_sub(f2u, c.e2); vf2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00400040u;
+    // no ambiguity case here: problems with an N inside either window never reach the packed classes (k_prob_sizes)
     const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
-    const uint32_t amb = pk_sign(PKU(PKS(qb | tbv) << (pk_s2)(13)));      // either base is N (code 4)
-    uint32_t sc = pk_sub(eq & c.ab, c.b);
-    sc = pk_sel(amb, c.nambi, sc);
-    t |= pk_sel(amb, 0u, eq) & 0x00800080u;
+    const uint32_t sc = pk_sub(eq & c.ab, c.b);
+    t |= eq & 0x00800080u;
     h = pk_add(hd, sc);
     uint32_t m, src;
     m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & 0x00010001u;
@@ -1582,11 +1615,11 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     // target base enters register R-1 (high half) and ages towards register 0
     const int qs_ = P.qstep, ts_ = P.tstep;
     BaseStream QS, TS;
-    d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, -(de0 >> 1) - 2 * R, P.qcomp, A.qtot);
-    d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, (de0 >> 1) - 1, 0, A.ttot);
+    d_stream_fill_acgt(QS, A.qseq2, P.qi0, qs_, -(de0 >> 1) - 2 * R, P.qcomp, A.qtot);
+    d_stream_fill_acgt(TS, A.tseq2, P.ti0, ts_, (de0 >> 1) - 1, 0, A.ttot);
 #pragma unroll
     for (int z = 0; z < 2 * R; ++z) {
-        uint32_t qv = (uint32_t)d_stream_next(QS), tv = (uint32_t)d_stream_next(TS);
+        uint32_t qv = (uint32_t)d_stream_next_acgt(QS), tv = (uint32_t)d_stream_next_acgt(TS);
         if (EXT) { if (-(de0 >> 1) - 2 * R + z >= m) qv |= 8u; if ((de0 >> 1) - 1 + z >= n) tv |= 8u; }
         d_push_q<R>(qb, qv); d_push_t<R>(tbv, tv);
     }
@@ -1610,8 +1643,8 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
         uint32_t h, ve1, vf1, ve2, vf2;
         if (k > 0) {
             const int a = 2 * k;
-            if (qleft == 0) { d_stream_fill(QS, A.qseq2, A.qnmask, P.qi0, qs_, ((a - de0) >> 1) - 1, P.qcomp, A.qtot); qleft = 32; }
-            { uint32_t qv = (uint32_t)d_stream_next(QS); if (EXT && ((a - de0) >> 1) - 1 >= m) qv |= 8u; d_push_q<R>(qb, qv); } --qleft;
+            if (qleft == 0) { d_stream_fill_acgt(QS, A.qseq2, P.qi0, qs_, ((a - de0) >> 1) - 1, P.qcomp, A.qtot); qleft = 32; }
+            { uint32_t qv = (uint32_t)d_stream_next_acgt(QS); if (EXT && ((a - de0) >> 1) - 1 >= m) qv |= 8u; d_push_q<R>(qb, qv); } --qleft;
             uint32_t ph = PK_NEG, pe1 = PK_NEG, pe2 = PK_NEG;
             if (LPP > 1) {
                 ph = DPP_SHR1((int)PK_NEG, (int)Ho[R - 1]); pe1 = DPP_SHR1((int)PK_NEG, (int)E1o[R - 1]); pe2 = DPP_SHR1((int)PK_NEG, (int)E2o[R - 1]);
@@ -1646,8 +1679,8 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
         }
         {
             const int a = 2 * k + 1;
-            if (tleft == 0) { d_stream_fill(TS, A.tseq2, A.tnmask, P.ti0, ts_, ((a + de0 + 1) >> 1) + 2 * R - 2, 0, A.ttot); tleft = 32; }
-            { uint32_t tv = (uint32_t)d_stream_next(TS); if (EXT && ((a + de0 + 1) >> 1) + 2 * R - 2 >= n) tv |= 8u; d_push_t<R>(tbv, tv); } --tleft;
+            if (tleft == 0) { d_stream_fill_acgt(TS, A.tseq2, P.ti0, ts_, ((a + de0 + 1) >> 1) + 2 * R - 2, 0, A.ttot); tleft = 32; }
+            { uint32_t tv = (uint32_t)d_stream_next_acgt(TS); if (EXT && ((a + de0 + 1) >> 1) + 2 * R - 2 >= n) tv |= 8u; d_push_t<R>(tbv, tv); } --tleft;
             uint32_t nh = PK_NEG, nf1 = PK_NEG, nf2 = PK_NEG;
             if (LPP > 1) {
                 nh = DPP_SHL1((int)PK_NEG, (int)He[0]); nf1 = DPP_SHL1((int)PK_NEG, (int)F1e[0]); nf2 = DPP_SHL1((int)PK_NEG, (int)F2e[0]);

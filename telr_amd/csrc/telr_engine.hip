@@ -860,7 +860,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), d_tbb, d_cgo);
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));

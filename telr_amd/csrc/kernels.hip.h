@@ -576,6 +576,25 @@ __device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int lane)
     return (uint64_t)hi << 32 | lo;
 }
 
+// One link score in the chaining loop, own anchor (gi, qi, sp) <- broadcast anchor (gj, qj).  Same value as d_chain_sc, fewer
+// instructions: the strand sits in bit 31 of the reference word, so a strand mismatch fails the unsigned range test of dr;
+// |dr-dq| is one v_sad_u32; the integer log2 is a normalising shift ((v << clz) >> 23 holds 256 + fraction).
+__device__ __forceinline__ bool d_chain_link(uint32_t gi, int32_t qi, int32_t sp, uint32_t gj, int32_t qj, const ChainOpt &o, int32_t &sc)
+{
+    const uint32_t dr = gi - gj, dq = (uint32_t)(qi - qj);
+    uint32_t dd;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dd) : "v"(dr), "v"(dq));
+    const bool ok = dr - 1u < (uint32_t)o.max_gap && dq - 1u < (uint32_t)o.max_gap && dd <= (uint32_t)o.bw;
+    const uint32_t dg = dr < dq ? dr : dq;
+    int32_t v = (int32_t)((uint32_t)sp < dg ? (uint32_t)sp : dg);
+    const uint32_t x = dd + 1u; const int lz = __clz((int)x);
+    const int32_t l2 = ((30 - lz) << 8) + (int32_t)((x << lz) >> 23);
+    const int32_t pen = o.chain_gap_q8 * (int32_t)dd + o.chain_skip_q8 * (int32_t)dg + (l2 >> 1);
+    if (dd != 0u || dg > (uint32_t)sp) v -= pen >> 8;
+    sc = v;
+    return ok;
+}
+
 template <int R>
 __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
                                               ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
@@ -587,10 +606,12 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
     const int n = q_aoff[q + 1] - q_aoff[q];
     const uint64_t *a = keys + base;
     uint64_t key[R]; int32_t best[R], bp[R];
+    uint32_t gi[R]; int32_t qi[R], sp[R];            // fields of key[r]: reference word (strand in bit 31), query position, span
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int i = r * 64 + lane;
         key[r] = i < n ? a[i] : 0; best[r] = A_SPAN(key[r]); bp[r] = -1;
+        gi[r] = (uint32_t)(key[r] >> 32); qi[r] = A_Q(key[r]); sp[r] = A_SPAN(key[r]);
     }
     for (int jb = 0; jb < n; jb += 64 * R) {
 #pragma unroll
@@ -606,12 +627,16 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
                 const int j = j0 + jj;
                 const uint64_t kj = d_readlane64(key[r], jj);
                 const int32_t fj = __builtin_amdgcn_readlane(best[r], jj);
-                if (lane == jj) { myf = best[r]; myp = bp[r]; key[r] = knext; best[r] = A_SPAN(knext); bp[r] = -1; }
+                const uint32_t gj = (uint32_t)(kj >> 32); const int32_t qj = A_Q(kj);
+                if (lane == jj) {
+                    myf = best[r]; myp = bp[r]; key[r] = knext; best[r] = A_SPAN(knext); bp[r] = -1;
+                    gi[r] = (uint32_t)(knext >> 32); qi[r] = A_Q(knext); sp[r] = A_SPAN(knext);
+                }
 #pragma unroll
                 for (int s = 0; s < R; ++s) {
                     // anchors currently owned: index > j and <= j + 64R by construction
-                    int32_t sc = d_chain_sc(key[s], kj, o);
-                    if (sc != INT32_MIN && key[s] != 0) {
+                    int32_t sc;
+                    if (d_chain_link(gi[s], qi[s], sp[s], gj, qj, o, sc) && key[s] != 0) {
                         int32_t v = fj + sc;
                         if (v > best[s] || (v == best[s] && bp[s] >= 0)) { best[s] = v; bp[s] = j; }
                     }

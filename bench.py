@@ -180,7 +180,7 @@ def main():
     out = {
         "metric": "gbp_aligned_per_s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int32", "data": "synthetic",
+        "dtype": "int16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: synthetic chr2L-size genome (%d bp) + %d ONT-like reads (%.0f Mbp per GPU, 10%% error) + %d spiked TE insertions, preset %s, stage-1 reads->reference"
                                % (a.genome_len, a.reads, n_bases / 1e6, a.insertions, a.preset),
                    "reads_per_gpu": a.reads, "read_bases_per_gpu": n_bases, "parallelism": "reads sharded x%d, index replicated" % world},

@@ -49,7 +49,7 @@ typedef struct telr_idx_opt {
     int32_t k;            /* k-mer length, 4..28                                  */
     int32_t w;            /* minimizer window, 1..255                             */
     int32_t is_hpc;       /* homopolymer-compressed k-mers (map-pb)               */
-    int32_t bucket_bits;  /* 0 = choose from the number of distinct minimizers    */
+    int32_t bucket_bits;  /* reserved (ignored): seeding probes an open-addressing table */
 } telr_idx_opt;
 
 /* ---- mapping options (one struct for all seven call sites) --------------- */

@@ -411,16 +411,6 @@ __global__ void k_ent_counts(const uint32_t *__restrict__ ent_off, int32_t n_ent
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_ent) cnt[i] = ent_off[i + 1] - ent_off[i];
 }
-// bstart[b] = first entry whose bucket >= b, for b in [0, nb]
-__global__ void k_bucket_table(const uint64_t *__restrict__ ent_hash, int32_t n_ent, int shift, uint32_t nb, uint32_t *__restrict__ bstart)
-{
-    int32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e > n_ent) return;
-    uint32_t lo = e == 0 ? 0u : (uint32_t)(ent_hash[e - 1] >> shift) + 1u;
-    uint32_t hi = e == n_ent ? nb : (uint32_t)(ent_hash[e] >> shift);
-    for (uint32_t b = lo; b <= hi; ++b) bstart[b] = (uint32_t)e;
-}
-
 // probe table: open addressing (linear probing, load <= 1/2) over 16-byte slots {hash, first occurrence, count}: one
 // 64-byte line answers almost every probe, where bucket table -> hash array -> offset array needs three.  The slot
 // comes from a multiplicative re-hash: minimizer hashes are window MINIMA, i.e. heavily skewed towards small values,
@@ -460,14 +450,6 @@ __device__ __forceinline__ bool d_ht_lookup(const IndexView &I, uint64_t h, uint
         if (hh == HT_EMPTY) return false;
         s = (s + 1) & I.ht_mask;
     }
-}
-
-__device__ __forceinline__ int32_t d_lookup(const IndexView &I, uint64_t h)
-{
-    uint32_t b = (uint32_t)(h >> I.shift);
-    uint32_t lo = I.bstart[b], hi = I.bstart[b + 1];
-    for (uint32_t e = lo; e < hi; ++e) if (I.ent_hash[e] == h) return (int32_t)e;
-    return -1;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -529,15 +529,6 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
         hipLaunchKernelGGL(k_write_entries, dim3((nmz + 255) / 256), dim3(256), 0, ctx->stream, d_h2, d_flag, d_rank, (int64_t)nmz, ix->d_ent_hash, ix->d_ent_off, n_ent);
         HIPCHK(hipGetLastError());
     } else HIPCHK(hipMemsetAsync(ix->d_ent_off, 0, 8, ctx->stream));
-    // bucket table on the top hash bits
-    int bb = io->bucket_bits;
-    if (bb <= 0) { bb = 10; while ((1LL << bb) < n_ent && bb < 28) ++bb; }
-    if (bb > 2 * k) bb = 2 * k;
-    ix->bucket_bits = bb; ix->shift = 2 * k - bb;
-    uint32_t nb = 1u << bb;
-    HIPCHK(hipMalloc(&ix->d_bstart, ((size_t)nb + 2) * 4));
-    hipLaunchKernelGGL(k_bucket_table, dim3((n_ent + 1 + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, n_ent, ix->shift, nb, ix->d_bstart);
-    HIPCHK(hipGetLastError());
     // probe table for seeding: power-of-two slots, at least twice the distinct minimizers
     {
         int hb = 4; while ((1LL << hb) < 2LL * n_ent && hb < 30) ++hb;      // load <= 1/2, at least one empty slot
@@ -1052,7 +1043,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
 
     // ---- seeding --------------------------------------------------------------------------
     StageTimer t_sd(ctx, ST_SEED, true);
-    IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = ix->d_bstart; I.goff = ix->d_goff;
+    IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = nullptr; I.goff = ix->d_goff;
     I.tlen = tg->d_len; I.n_ent = ix->n_ent; I.shift = ix->shift; I.k = k; I.w = w;
     I.ht = ix->d_ht; I.ht_shift = ix->ht_shift; I.ht_mask = ix->ht_mask;
     int32_t *d_mcnt, *d_maoff, *d_qaoff;

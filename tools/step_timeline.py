@@ -3,9 +3,9 @@ name) with start / end relative to the call's first kernel, plus the idle gap be
 import csv, glob, sys, os, re
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_sketch<")][-1]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("void k_sketch<", "void k_sketch32<", "void k_sketch_hpc<"))][-1]
 # a map call may run several sketch tiles back to back: rewind to the first of the run
-while idx > 0 and rows[idx - 1]["Kernel_Name"].startswith(("void k_sketch<", "k_sketch_compact")):
+while idx > 0 and rows[idx - 1]["Kernel_Name"].startswith(("void k_sketch<", "void k_sketch32<", "void k_sketch_hpc<", "k_sketch_compact")):
     idx -= 1
 t0 = int(rows[idx]["Start_Timestamp"]); busy_end = t0
 for r in rows[idx:]:

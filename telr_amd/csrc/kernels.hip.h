@@ -171,11 +171,11 @@ __device__ __forceinline__ uint32_t d_hash32(uint32_t key, uint32_t mask)
     key = (key + (key << 31)) & mask;
     return key;
 }
-template <int MODE>
+template <int MODE, int HALO>        // HALO = w-1 known at compile time (fully unrolled neighbour tests), or 0 = read it from the arguments
 __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int halo = A.w - 1, nslot = SK_TILE + 2 * halo;
+    const int halo = HALO ? HALO : A.w - 1, nslot = SK_TILE + 2 * halo;
     uint32_t *xs = (uint32_t*)smem;
     uint8_t *zs = (uint8_t*)(xs + nslot);
     __shared__ int32_t wsum[SK_THREADS / 64];
@@ -209,12 +209,25 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
     for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
         int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
         uint32_t x = xs[s];
-        if (u < ns && x != 0xffffffffu) {
-            int Lc = 0, Rc = 0;
-            while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
-            while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
-            if (Lc + Rc + 1 >= need) sel |= 1u << c;
+        // run of slots with x >= x_u around u, both sides: every lane tests all `halo` neighbours (a lane that stops at
+        // its first smaller neighbour would still wait for the wave's slowest lane) and counts the leading ones
+        int Lc, Rc;
+        if (HALO) {
+            // first neighbour on each side that is smaller (or outside the sequence): distance - 1 = run length
+            int lf = HALO + 1, rf = HALO + 1;
+#pragma unroll
+            for (int t = HALO; t >= 1; --t) { if (xs[s - t] < x) lf = t; if (xs[s + t] < x) rf = t; }
+            const int lmax = u < HALO ? u : HALO, rmax = ns - 1 - u < HALO ? ns - 1 - u : HALO;
+            Lc = lf - 1 < lmax ? lf - 1 : lmax; Rc = rf - 1 < rmax ? rf - 1 : rmax;
+        } else {
+            uint32_t lm = 0, rm = 0;
+            for (int t = 1; t <= halo; ++t) {
+                lm |= (uint32_t)(u - t >= 0 && xs[s - t] >= x) << (t - 1);
+                rm |= (uint32_t)(u + t < ns && xs[s + t] >= x) << (t - 1);
+            }
+            Lc = __ffs((int)~lm) - 1; Rc = __ffs((int)~rm) - 1;
         }
+        if (u < ns && x != 0xffffffffu && Lc + Rc + 1 >= need) sel |= 1u << c;
     }
     int cnt = __popc(sel);
     // block exclusive scan of cnt (wave scan + cross-wave in LDS)

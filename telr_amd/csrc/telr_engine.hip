@@ -392,7 +392,8 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     if (hpc) { H.out_x = d_sx; H.out_y = d_sy; hipLaunchKernelGGL(k_sketch_hpc<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H); }
     else {
         A.out_x = d_sx; A.out_y = d_sy;
-        if (k <= 15 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL(k_sketch32<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        if (k <= 15 && w == 10 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 9>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        else if (k <= 15 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 0>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
         else hipLaunchKernelGGL(k_sketch<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
     }
     HIPCHK(hipGetLastError());

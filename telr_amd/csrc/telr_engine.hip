@@ -1009,6 +1009,16 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     hipStream_t st = ctx->stream;
 
     // ---- sketch -------------------------------------------------------------------------
+    // queries in descending length order for the one-block-per-query kernels (their tail is the longest read): sorted by
+    // a helper thread while the sketch kernels run, uploaded from pinned memory before the seeding stage
+    int32_t *d_qorder, *h_ord;
+    TRY(ctx_hbuf_t(ctx, "h_qorder", (size_t)nq + 1, &h_ord));
+    TRY(ctx_buf_t(ctx, "q_order", (size_t)nq + 1, &d_qorder));
+    std::thread ord_thread([&]() {
+        for (int i = 0; i < nq; ++i) h_ord[i] = i;
+        std::stable_sort(h_ord, h_ord + nq, [&](int32_t x, int32_t y) { return qs->len[q0 + x] > qs->len[q0 + y]; });
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } ord_join{ord_thread};     // error paths return early
     StageTimer t_sk(ctx, ST_SKETCH, true);
     TileList T;
     uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
@@ -1031,16 +1041,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     t_sk.stop();
     ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
 
-    // queries in descending length order for the one-block-per-query kernels (their tail is the longest read)
-    int32_t *d_qorder;
-    {
-        std::vector<int32_t> ord(nq);
-        for (int i = 0; i < nq; ++i) ord[i] = i;
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return qs->len[q0 + x] > qs->len[q0 + y]; });
-        TRY(ctx_buf_t(ctx, "q_order", (size_t)nq + 1, &d_qorder));
-        HIPCHK(hipMemcpyAsync(d_qorder, ord.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));        // `ord` is a local
-    }
+    ord_thread.join();
+    HIPCHK(hipMemcpyAsync(d_qorder, h_ord, (size_t)nq * 4, hipMemcpyHostToDevice, st));
 
     // ---- seeding --------------------------------------------------------------------------
     StageTimer t_sd(ctx, ST_SEED, true);

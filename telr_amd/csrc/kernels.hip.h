@@ -1860,6 +1860,7 @@ __global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
 // keeps the two lines it is walking through in LDS (slot = line parity; dword k of lane l at word k*64+l:
 // conflict-free byte reads) and fetches the next lower line into registers ahead of time: memory is touched once
 // per line instead of once per step, and a line is normally there before the walk reaches it.
+template <int LAYOUT>       // 2: packed int16 classes (rows of 2 anti-diagonals); -1: take it from the problem's class
 __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi,
                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                  uint32_t *stage)
@@ -1881,7 +1882,7 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
     uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
     while (i > 0 && j > 0) {
         const int a = i + j, sl = (j - i - dlo) >> 1;
-        const int64_t off = cls >= 10 ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
+        const int64_t off = (LAYOUT == 2 || cls >= 10) ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
                           : packed ? ((((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)) : ((int64_t)a * stride + sl);
         // tb_off is a multiple of 16 only, so lines are taken relative to the 64-byte grid of the whole scratch buffer
         const int64_t abs_off = P.tb_off + off, line = abs_off >> 6;
@@ -1901,15 +1902,16 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
         const int w = (int)(abs_off & 63);
         const uint32_t t = (stage[slot * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
         touched |= (j - i == dlo) | (j - i == dhi_);
-        if (state == 0) state = t & 7;
-        int op;
-        if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
-        else if (state == 1) { op = 2; if (!(t & 8))  state = 0; --j; }
-        else if (state == 2) { op = 1; if (!(t & 16)) state = 0; --i; }
-        else if (state == 3) { op = 2; if (!(t & 32)) state = 0; --j; }
-        else                 { op = 1; if (!(t & 64)) state = 0; --i; }
-        if (op == cur_op) ++cur_len;
-        else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = op; cur_len = 1; }
+        // one step of the walk without branches: the 64 lanes are in 64 different states
+        const int s0 = state ? state : (int)(t & 7);                 // 0 = diagonal, 1/3 = deletion (E1/E2), 2/4 = insertion (F1/F2)
+        const int isM = s0 == 0, isD = s0 & 1;
+        const int op = isM ? 0 : (isD ? 2 : 1);
+        state = (isM || !((t >> (2 + s0)) & 1)) ? 0 : s0;            // a gap state continues while its extension flag is set
+        ml += isM & (int)(t >> 7); mc += isM;
+        i -= isD ^ 1; j -= isM | isD;
+        const bool same = op == cur_op;
+        if (!same && cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+        cur_len = same ? cur_len + 1 : 1; cur_op = op;
     }
     if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
@@ -1924,7 +1926,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     __shared__ uint32_t stage[2 * 16 * 64];
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= np) return;
-    d_traceback_lane(probs, res, list ? list[ti] : ti, tb_all, cig, retry, stage);
+    d_traceback_lane<-1>(probs, res, list ? list[ti] : ti, tb_all, cig, retry, stage);
 }
 // trace-back of the packed fill classes, driven by the same cost-ordered wave table as the forward launch (one block
 // per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
@@ -1938,7 +1940,7 @@ __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ 
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int ppw = 64 / PK_LPP[cls - 10], t = threadIdx.x;
     if (t >= ppw || first + t >= cls_cnt[cls]) return;
-    d_traceback_lane(probs, res, cls_list[(int64_t)cls * np + first + t], tb_all, cig, retry, stage);
+    d_traceback_lane<2>(probs, res, cls_list[(int64_t)cls * np + first + t], tb_all, cig, retry, stage);
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control

@@ -47,6 +47,7 @@ struct telr_ctx {
     float stage_ms[TELR_N_STAGES] = {0};
     telr_counters ctr = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_st[TELR_N_STAGES][2] = {{nullptr}}; uint32_t st_pending = 0;
     hipEvent_t evk[6] = {nullptr};        // un-synchronised markers around single kernels
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     int64_t dp_retries = 0;
@@ -99,16 +100,26 @@ template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size
     void *p; TRY(ctx_buf(ctx, name, (n ? n : 1) * sizeof(T), &p)); *out = (T*)p; return TELR_OK;
 }
 
+// Stage timing.  GPU stages drop a pair of events on the stream and are read back by stage_collect() after the call's
+// last synchronisation: timing never drains the stream between stages.
 struct StageTimer {
     telr_ctx *ctx; int stage; bool gpu; std::chrono::steady_clock::time_point t0;
     StageTimer(telr_ctx *c, int s, bool g) : ctx(c), stage(s), gpu(g) {
-        if (gpu) (void)hipEventRecord(ctx->ev0, ctx->stream); else t0 = std::chrono::steady_clock::now();
+        if (gpu) (void)hipEventRecord(ctx->ev_st[stage][0], ctx->stream); else t0 = std::chrono::steady_clock::now();
     }
     void stop() {
-        if (gpu) { (void)hipEventRecord(ctx->ev1, ctx->stream); (void)hipEventSynchronize(ctx->ev1); float ms = 0; (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); ctx->stage_ms[stage] += ms; }
+        if (gpu) { (void)hipEventRecord(ctx->ev_st[stage][1], ctx->stream); ctx->st_pending |= 1u << stage; }
         else ctx->stage_ms[stage] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 };
+static void stage_collect(telr_ctx *ctx)
+{
+    for (int z = 0; z < TELR_N_STAGES; ++z) if (ctx->st_pending >> z & 1u) {
+        float ms = 0;
+        if (hipEventSynchronize(ctx->ev_st[z][1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev_st[z][0], ctx->ev_st[z][1]) == hipSuccess) ctx->stage_ms[z] += ms;
+    }
+    ctx->st_pending = 0;
+}
 
 // ---------------------------------------------------------------------------------------
 extern "C" const char *telr_strerror(int code)
@@ -142,6 +153,7 @@ extern "C" int telr_init(int device, telr_ctx **out)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->evk[i]) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    for (int i = 0; i < TELR_N_STAGES; ++i) for (int j = 0; j < 2; ++j) if (hipEventCreate(&ctx->ev_st[i][j]) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < TELR_NSIDE; ++i) if (hipStreamCreate(&ctx->side[i]) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < 8; ++i) if (hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     if (hipStreamCreate(&ctx->tb_stream) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
@@ -176,6 +188,7 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     for (int i = 0; i < 8; ++i) if (ctx->ev_chunk[i]) (void)hipEventDestroy(ctx->ev_chunk[i]);
     if (ctx->tb_stream) (void)hipStreamDestroy(ctx->tb_stream);
     for (int i = 0; i < 6; ++i) if (ctx->evk[i]) (void)hipEventDestroy(ctx->evk[i]);
+    for (int i = 0; i < TELR_N_STAGES; ++i) for (int j = 0; j < 2; ++j) if (ctx->ev_st[i][j]) (void)hipEventDestroy(ctx->ev_st[i][j]);
     delete ctx;
 }
 extern "C" int telr_device_name(const telr_ctx *ctx, char *buf, int buflen)
@@ -1442,6 +1455,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     for (int i = 0; i < ns; ++i) R->alns.push_back(surv[i].r);
     ctx->ctr.records += ns;
     t_as3.stop();
+    stage_collect(ctx);
     return TELR_OK;
 }
 
@@ -1490,7 +1504,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     memset(&ctx->ctr, 0, sizeof(ctx->ctr));
     memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
-    ctx->dp_retries = 0;
+    ctx->dp_retries = 0; ctx->st_pending = 0;
     const int nq = queries->n;
     if (qtarget) for (int i = 0; i < nq; ++i) if (qtarget[i] >= ix->targets->n) return TELR_E_ARG;
     int32_t *d_qt = nullptr;
@@ -1534,7 +1548,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         auto work = [&](int k) {
             telr_ctx *c = ctx->child[k];
             (void)hipSetDevice(c->device);
-            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0;
+            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->st_pending = 0;
             part[k] = new telr_result(); part[k]->ctx = nullptr;
             const int n = (int)lane_idx[k].size();
             if ((rc[k] = seqset_subset_into(c, queries, lane_idx[k], "lane_", &sub[k])) != TELR_OK) return;
@@ -1608,7 +1622,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         for (int k = 0; k < nsub; ++k) th.emplace_back([&, k]() {
             telr_ctx *c = ctx->child[k];
             (void)hipSetDevice(c->device);
-            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0;
+            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->st_pending = 0;
             part[k] = new telr_result(); part[k]->ctx = nullptr;
             if (cut[k + 1] > cut[k]) {
                 for (int i = cut[k]; i < cut[k + 1]; ++i) c->ctr.query_bases += queries->len[i];

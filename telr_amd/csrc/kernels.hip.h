@@ -541,29 +541,6 @@ __global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__r
 #define A_Q(k)    ((int32_t)(((k) >> 8) & 0xffffff))
 #define A_SPAN(k) ((int32_t)((k) & 0xff))
 
-__device__ __forceinline__ int32_t d_ilog2_q8(uint32_t v)
-{
-    int e = 31 - __clz((int)v);
-    uint32_t frac = e <= 8 ? (v << (8 - e)) - 256u : (v >> (e - 8)) - 256u;
-    return e * 256 + (int32_t)frac;
-}
-__device__ __forceinline__ int32_t d_chain_sc(uint64_t ai, uint64_t aj, const ChainOpt &o)
-{
-    if ((ai >> 63) != (aj >> 63)) return INT32_MIN;
-    int32_t dr = A_G(ai) - A_G(aj), dq = A_Q(ai) - A_Q(aj);
-    if (dq <= 0 || dq > o.max_gap) return INT32_MIN;
-    if (dr <= 0 || dr > o.max_gap) return INT32_MIN;
-    int32_t dd = dr > dq ? dr - dq : dq - dr;
-    if (dd > o.bw) return INT32_MIN;
-    int32_t dg = dr < dq ? dr : dq;
-    int32_t span = A_SPAN(ai);
-    int32_t sc = span < dg ? span : dg;
-    if (dd || dg > span) {
-        int32_t pen = o.chain_gap_q8 * dd + o.chain_skip_q8 * dg + (dd >= 1 ? d_ilog2_q8((uint32_t)dd + 1) >> 1 : 0);
-        sc -= pen >> 8;
-    }
-    return sc;
-}
 __device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int lane)
 {
     uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, lane);
@@ -571,8 +548,8 @@ __device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int lane)
     return (uint64_t)hi << 32 | lo;
 }
 
-// One link score in the chaining loop, own anchor (gi, qi, sp) <- broadcast anchor (gj, qj).  Same value as d_chain_sc, fewer
-// instructions: the strand sits in bit 31 of the reference word, so a strand mismatch fails the unsigned range test of dr;
+// One link score in the chaining loop, own anchor (gi, qi, sp) <- broadcast anchor (gj, qj).  The oracle's chain_sc(),
+// in few instructions: the strand sits in bit 31 of the reference word, so a strand mismatch fails the unsigned range test of dr;
 // |dr-dq| is one v_sad_u32; the integer log2 is a normalising shift ((v << clz) >> 23 holds 256 + fraction).
 __device__ __forceinline__ bool d_chain_link(uint32_t gi, int32_t qi, int32_t sp, uint32_t gj, int32_t qj, const ChainOpt &o, int32_t &sc)
 {
@@ -672,39 +649,9 @@ __global__ void k_peaks(const int32_t *__restrict__ q_aoff, const int32_t *__res
 
 struct ChainRec { int32_t score, cnt, a_off, pad; uint64_t a0, a1; };   // 32 B
 
-// back-tracking: one thread per query walks its sorted peaks (pointer chase; the steps stay
-// within the look-back window so the touched lines are L1/L2 resident)
-__global__ void k_backtrack(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
-                            const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
-                            const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
-                            uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const int64_t base = q_aoff[q];
-    const int np = n_peaks[q];
-    int nch = 0, wr = 0;
-    ChainRec *out = rec + ch_off[q];
-    for (int t = 0; t < np; ++t) {
-        int i = (int)(uint32_t)(pk[base + t] & 0xffffffffu);
-        if (vis[base + i]) continue;
-        int cnt = 0, j = i;
-        while (j >= 0 && !vis[base + j]) { vis[base + j] = 1; ++cnt; j = p[base + j]; }
-        int sc = f[base + i] - (j >= 0 ? f[base + j] : 0);
-        if (sc < min_sc || cnt < min_cnt) continue;
-        j = i;
-        for (int z = cnt - 1; z >= 0; --z) { canch[base + wr + z] = keys[base + j]; j = p[base + j]; }
-        ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr; r.pad = 0;
-        r.a0 = canch[base + wr]; r.a1 = canch[base + wr + cnt - 1];
-        out[nch++] = r; wr += cnt;
-    }
-    n_chains[q] = nch;
-}
-
-// back-tracking, one wave per query: predecessor deltas (1..256, 0 = none) and visited bits are staged in
+// back-tracking, one wave per query: predecessor deltas (1..256, 0 = none) and visited marks are staged in
 // LDS, lane 0 walks the sorted peaks at LDS latency and records the anchor indices of the chain, then all
-// lanes copy the chain's anchors (coalesced gather/scatter).  Queries with more than BT_CAP anchors take the
-// global-memory path of k_backtrack on lane 0.  Same visiting order and acceptance rule as k_backtrack.
+// lanes copy the chain's anchors (coalesced gather/scatter).
 #define BT_CAP 8192
 // The back-tracking state of one query lives in LDS (2 x uint16 per anchor).  Two launches share this body: the bulk
 // launch gives every query 32 KB (BT_CAP anchors) and leaves the longer ones to a second, concurrent launch whose blocks
@@ -853,67 +800,8 @@ __host__ __device__ __forceinline__ int d_fill_band_wide(int m, int n, int bw, i
 }
 __device__ __forceinline__ int d_even_lo(int lo) { return lo - (lo & 1); }
 
-// PASS 0: count problems per kept chain.  PASS 1: write descriptors.
-template <int PASS>
-__global__ void k_segments(const KeptChain *__restrict__ kc, int32_t nk, const uint64_t *__restrict__ canch,
-                           int32_t min_ksw_len, int32_t bw, int32_t band_q4, int32_t ext_max, int32_t ext_band,
-                           int32_t *__restrict__ nprob, const int32_t *__restrict__ prob_off, DpProb *__restrict__ probs)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nk) return;
-    const KeptChain K = kc[c];
-    const uint64_t *ca = canch + K.a_glob;
-    int np = 0;
-    DpProb *out = PASS ? probs + prob_off[c] : nullptr;
-    const int go = (int)K.goff;
-    // left extension
-    if (K.qs > 0 && K.rs > 0) {
-        if (PASS) {
-            int mq = K.qs < ext_max ? K.qs : ext_max, mt = K.rs < mq + ext_band ? K.rs : mq + ext_band;
-            DpProb P; P.m = mq; P.n = mt; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; P.kind = 1; P.chain = c;
-            P.tstep = -1; P.ti0 = K.tbase + K.rs - 1; P.qcomp = (int8_t)K.rev;
-            if (K.rev) { P.qstep = 1; P.qi0 = K.qbase + K.qlen - K.qs; } else { P.qstep = -1; P.qi0 = K.qbase + K.qs - 1; }
-            P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
-            out[np] = P;
-        }
-        ++np;
-    }
-    int lr = K.rs, lq = K.qs;
-    for (int i = 0; i < K.cnt; ++i) {
-        uint64_t a = ca[i];
-        int cr = A_G(a) - go + 1, cq = A_Q(a) + 1;
-        if (i == K.cnt - 1 || (cq - lq >= min_ksw_len && cr - lr >= min_ksw_len)) {
-            if (PASS) {
-                DpProb P; P.m = cq - lq; P.n = cr - lr; P.chain = c; P.kind = 0;
-                // long segments are few and a second pass over one of them is slow: they take the wide band at once
-                const int W = P.m + P.n > ADAPT_MAX_STEPS ? d_fill_band_wide(P.m, P.n, bw, band_q4) : d_fill_band(P.m, P.n, bw, band_q4), dl = P.n - P.m;
-                P.dlo = d_even_lo((dl < 0 ? dl : 0) - W); P.dhi = (dl > 0 ? dl : 0) + W;
-                if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
-                P.tstep = 1; P.ti0 = K.tbase + lr; P.qcomp = (int8_t)K.rev;
-                if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - lq; } else { P.qstep = 1; P.qi0 = K.qbase + lq; }
-                P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
-                out[np] = P;
-            }
-            ++np; lr = cr; lq = cq;
-        }
-    }
-    if (K.qe < K.qlen && K.re < K.tlen) {
-        if (PASS) {
-            int rq = K.qlen - K.qe, rt = K.tlen - K.re;
-            int mq = rq < ext_max ? rq : ext_max, mt = rt < mq + ext_band ? rt : mq + ext_band;
-            DpProb P; P.m = mq; P.n = mt; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; P.kind = 2; P.chain = c;
-            P.tstep = 1; P.ti0 = K.tbase + K.re; P.qcomp = (int8_t)K.rev;
-            if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - K.qe; } else { P.qstep = 1; P.qi0 = K.qbase + K.qe; }
-            P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
-            out[np] = P;
-        }
-        ++np;
-    }
-    if (!PASS) nprob[c] = np;
-}
-
-// Wave-per-chain version of k_segments (same problems in the same order): a window of 64 consecutive anchors per
-// iteration, the greedy cuts of the window found with ballots (the cut condition is monotone along a chain), and
+// DP problems of a kept chain (oracle align_chain): PASS 0 counts them, PASS 1 writes the descriptors.  One wave per
+// chain: a window of 64 consecutive anchors per iteration, the greedy cuts of the window found with ballots (the cut condition is monotone along a chain), and
 // the descriptors of the window's cuts built and written by as many lanes in parallel.
 template <int PASS>
 __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__ kc, int32_t nk, const uint64_t *__restrict__ canch,
@@ -1512,7 +1400,7 @@ __device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
 
-struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, nambi; };
+struct PkConst { uint32_t qe, e, q2e2, e2, ab, b; };
 
 __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t e1l, uint32_t e2l, uint32_t hu, uint32_t f1u, uint32_t f2u,
                                               uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve1, uint32_t &vf1, uint32_t &ve2, uint32_t &vf2)
@@ -1608,7 +1496,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     const DpProb P = A.probs[prob];
     const DpOpt o = A.o;
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
-    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.nambi = pk_dup(-o.sc_ambi);
+    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b);
     const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo;
     const int de0 = dlo + 4 * R * l;                   // lowest (even) diagonal of this lane
     const int dhi = have ? P.dhi : dlo - 1;            // diagonals above dhi are outside the band: their H / F stay -inf
@@ -2129,20 +2017,6 @@ __global__ void k_stitch_write(int32_t np, const StitchProb *__restrict__ sp, co
 }
 
 // compact the raw per-problem cigars (emission order preserved) into one dense array
-__global__ void k_cigar_gather(const DpProb *__restrict__ probs, const DpRes *__restrict__ res, const int64_t *__restrict__ dense_off,
-                               int32_t np, const uint32_t *__restrict__ raw, uint32_t *__restrict__ dense)
-{
-    const int pi = blockIdx.x;
-    if (pi >= np) return;
-    const int64_t so = probs[pi].cig_off, dofs = dense_off[pi];
-    const int no = res[pi].nops;
-    for (int x = threadIdx.x; x < no; x += blockDim.x) dense[dofs + x] = raw[so + x];
-}
-__global__ void k_res_nops(const DpRes *__restrict__ res, int32_t np, int64_t *__restrict__ nops)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < np) nops[i] = res[i].nops;
-}
 
 // ---------------------------------------------------------------------------------------
 // 6. depth medians (samtools depth -aa -r | statistics.median)

@@ -706,17 +706,6 @@ static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
     if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
 }
 
-static inline int host_dp_class(int kind, int D, int steps = 1 << 30, int pk_max_steps = 0, int pk_ext_steps = 0, int pk_wide_steps = 0)
-{
-    if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
-    if (kind == 0 && steps <= pk_max_steps) {
-        if (D <= 20) return 10; if (D <= 24) return 11; if (D <= 28) return 12; if (D <= 32) return 13;
-        if (D <= 40) return 14; if (D <= 48) return 15; if (D <= 64) return 16; if (D <= 128) return 17;
-    }
-    if (kind == 0 && steps <= pk_wide_steps && D > 128) { if (D <= 256) return 19; if (D <= 512) return 20; if (D <= 1024) return 21; }
-    if (kind == 0) { if (D <= 64) return 5; if (D <= 128) return 6; if (D <= 256) return 7; if (D <= 512) return 8; if (D <= 1024) return 9; }
-    return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
-}
 // worker threads for the host phases: 1.5x the CPUs this process may actually use (cgroup v2 quota when
 // present: the MI355X box reports 256 hardware threads but runs under cpu.max = 16 CPUs), at most 48
 static int host_threads()
@@ -1144,10 +1133,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipStreamSynchronize(st));
     ChainRec *d_rec;
     TRY(ctx_buf_t(ctx, "chain_rec", (size_t)npk_tot, &d_rec));
-    if (getenv("TELR_BT_THREAD"))
-        hipLaunchKernelGGL(k_backtrack, dim3((nq + 63) / 64), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch);
-    else {
+    {
         // queries with more than BT_CAP anchors: their own launch with CU-sized LDS blocks on a side stream, under the bulk launch
         int32_t *d_big; TRY(ctx_buf_t(ctx, "bt_big", (size_t)nq + 1, &d_big));      // [0] count, then the list
         HIPCHK(hipMemsetAsync(d_big, 0, 4, st));

@@ -653,11 +653,12 @@ struct ChainRec { int32_t score, cnt, a_off, pad; uint64_t a0, a1; };   // 32 B
 // LDS, lane 0 walks the sorted peaks at LDS latency and records the anchor indices of the chain, then all
 // lanes copy the chain's anchors (coalesced gather/scatter).
 #define BT_CAP 8192
-// The back-tracking state of one query lives in LDS (2 x uint16 per anchor).  Two launches share this body: the bulk
-// launch gives every query 32 KB (BT_CAP anchors) and leaves the longer ones to a second, concurrent launch whose blocks
+// The back-tracking state of one query lives in LDS (one uint16 per anchor: the number of resident queries per CU is what
+// bounds this stage, so the list of walked anchors goes to a global scratch).  Two launches share this body: the bulk
+// launch gives every query 16 KB (BT_CAP anchors) and leaves the longer ones to a second, concurrent launch whose blocks
 // own the whole 160 KB of a CU (BT_CAP_BIG anchors); only beyond that does a single lane chase pointers in global memory.
-#define BT_CAP_BIG 40000
-__device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big, uint16_t *pdel, uint16_t *idx, int32_t *sh,
+#define BT_CAP_BIG 65000
+__device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big, uint16_t *pdel, uint16_t *gidx, int32_t *sh,
                                                   const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff,
                                                   const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
                                                   const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
@@ -667,6 +668,7 @@ __device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big
     const int64_t base = q_aoff[q];
     const int n = q_aoff[q + 1] - q_aoff[q], np = n_peaks[q];
     ChainRec *out = rec + ch_off[q];
+    uint16_t *idx = gidx + base;          // anchor indices of the chain being walked: written by lane 0, read back by all lanes
     if (n > cap) {
         if (defer_big) return;
         if (lane == 0) {
@@ -709,6 +711,7 @@ __device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big
                     j = d ? j - d : -1;
                 }
                 sh[0] = cnt; sh[1] = j;
+                __threadfence_block();
             }
             __syncthreads();
             const int cnt = sh[0], j = sh[1];
@@ -731,11 +734,12 @@ __global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__
                                                     const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
                                                     const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
                                                     uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains,
-                                                    const int32_t *__restrict__ q_order, int32_t cap, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt)
+                                                    const int32_t *__restrict__ q_order, int32_t cap, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt,
+                                                    uint16_t *__restrict__ idx)
 {
     extern __shared__ uint16_t bt_lds[];
     __shared__ int32_t sh[2];
-    uint16_t *pdel = bt_lds, *idx = bt_lds + cap;
+    uint16_t *pdel = bt_lds;
     if (big_list) {      // second launch: the queries the bulk launch leaves out, a few blocks looping over the list
         const int nb = *big_cnt;
         for (int e = blockIdx.x; e < nb; e += gridDim.x) {

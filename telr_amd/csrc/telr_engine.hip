@@ -1136,19 +1136,20 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     {
         // queries with more than BT_CAP anchors: their own launch with CU-sized LDS blocks on a side stream, under the bulk launch
         int32_t *d_big; TRY(ctx_buf_t(ctx, "bt_big", (size_t)nq + 1, &d_big));      // [0] count, then the list
+        uint16_t *d_btidx; TRY(ctx_buf_t(ctx, "bt_idx", (size_t)na + 1, &d_btidx));
         HIPCHK(hipMemsetAsync(d_big, 0, 4, st));
         hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP, d_big + 1, d_big);
         HIPCHK(hipGetLastError());
         static bool attr_set = false;
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG * 4)); attr_set = true; }
+        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG * 2)); attr_set = true; }
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
-        hipLaunchKernelGGL(k_backtrack_w, dim3(256), dim3(64), (size_t)BT_CAP_BIG * 4, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP_BIG, (const int32_t*)(d_big + 1), (const int32_t*)d_big);
+        hipLaunchKernelGGL(k_backtrack_w, dim3(256), dim3(64), (size_t)BT_CAP_BIG * 2, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP_BIG, (const int32_t*)(d_big + 1), (const int32_t*)d_big, d_btidx);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0]));
-        hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), (size_t)BT_CAP * 4, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), (size_t)BT_CAP * 2, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[0], 0));
     }

@@ -658,12 +658,15 @@ struct ChainRec { int32_t score, cnt, a_off, pad; uint64_t a0, a1; };   // 32 B
 // launch gives every query 16 KB (BT_CAP anchors) and leaves the longer ones to a second, concurrent launch whose blocks
 // own the whole 160 KB of a CU (BT_CAP_BIG anchors); only beyond that does a single lane chase pointers in global memory.
 #define BT_CAP_BIG 65000
-__device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big, uint16_t *pdel, uint16_t *gidx, int32_t *sh,
+// PT = uint8_t when the look-back is at most 128 anchors (deltas fit a byte: twice the resident queries again), else uint16_t
+template <typename PT>
+__device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big, PT *pdel, uint16_t *gidx, int32_t *sh,
                                                   const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff,
                                                   const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
                                                   const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
                                                   uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
 {
+    constexpr int VISITED = (PT)~(PT)0;
     const int lane = threadIdx.x;
     const int64_t base = q_aoff[q];
     const int n = q_aoff[q + 1] - q_aoff[q], np = n_peaks[q];
@@ -690,7 +693,7 @@ __device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big
         }
         return;
     }
-    for (int i = lane; i < n; i += 64) { int pj = p[base + i]; pdel[i] = (uint16_t)(pj < 0 ? 0 : i - pj); }
+    for (int i = lane; i < n; i += 64) { int pj = p[base + i]; pdel[i] = (PT)(pj < 0 ? 0 : i - pj); }
     __syncthreads();
     int nch = 0, wr = 0;
     for (int tb = 0; tb < np; tb += 64) {
@@ -700,13 +703,13 @@ __device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big
         for (int u = 0; u < nt; ++u) {
             const uint64_t key = d_readlane64(mykey, u);
             const int i = (int)(uint32_t)(key & 0xffffffffu), fi = 0x7fffffff - (int)(uint32_t)(key >> 32);
-            if (pdel[i] == 0xffffu) continue;                       // uniform: already on a chain
+            if (pdel[i] == VISITED) continue;                       // uniform: already on a chain
             if (lane == 0) {
                 int cnt = 0, j = i;
                 while (j >= 0) {
                     const int d = pdel[j];
-                    if (d == 0xffff) break;                          // reached a visited anchor
-                    pdel[j] = 0xffffu;
+                    if (d == VISITED) break;                          // reached a visited anchor
+                    pdel[j] = (PT)VISITED;
                     idx[cnt++] = (uint16_t)j;
                     j = d ? j - d : -1;
                 }
@@ -730,6 +733,7 @@ __device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big
     }
     if (lane == 0) n_chains[q] = nch;
 }
+template <typename PT>
 __global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
                                                     const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
                                                     const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
@@ -739,17 +743,17 @@ __global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__
 {
     extern __shared__ uint16_t bt_lds[];
     __shared__ int32_t sh[2];
-    uint16_t *pdel = bt_lds;
+    PT *pdel = (PT*)bt_lds;
     if (big_list) {      // second launch: the queries the bulk launch leaves out, a few blocks looping over the list
         const int nb = *big_cnt;
         for (int e = blockIdx.x; e < nb; e += gridDim.x) {
-            d_backtrack_query(big_list[e], cap, false, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
+            d_backtrack_query<PT>(big_list[e], cap, false, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
             __syncthreads();
         }
         return;
     }
     if ((int)blockIdx.x >= nq) return;
-    d_backtrack_query(q_order ? q_order[blockIdx.x] : blockIdx.x, cap, true, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
+    d_backtrack_query<PT>(q_order ? q_order[blockIdx.x] : blockIdx.x, cap, true, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
 }
 __global__ void k_bt_big(const int32_t *__restrict__ q_aoff, int32_t nq, int32_t cap, int32_t *__restrict__ big_list, int32_t *__restrict__ big_cnt)
 {

@@ -1140,16 +1140,28 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipMemsetAsync(d_big, 0, 4, st));
         hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP, d_big + 1, d_big);
         HIPCHK(hipGetLastError());
+        // one byte of LDS per anchor when the look-back fits a byte (the bulk launch then keeps 20 queries per CU resident)
+        const bool pt8 = mo->chain_lookback <= 128;
+        const size_t psz = pt8 ? 1 : 2;
+        const int cap_big = BT_CAP_BIG;                 // anchor indices of a walk are kept as uint16
         static bool attr_set = false;
-        if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG * 2)); attr_set = true; }
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG));
+            HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG * 2));
+            attr_set = true;
+        }
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
-        hipLaunchKernelGGL(k_backtrack_w, dim3(256), dim3(64), (size_t)BT_CAP_BIG * 2, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP_BIG, (const int32_t*)(d_big + 1), (const int32_t*)d_big, d_btidx);
+        if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(256), dim3(64), (size_t)cap_big * psz, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                                    mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap_big, (const int32_t*)(d_big + 1), (const int32_t*)d_big, d_btidx);
+        else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(256), dim3(64), (size_t)cap_big * psz, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                                mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap_big, (const int32_t*)(d_big + 1), (const int32_t*)d_big, d_btidx);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0]));
-        hipLaunchKernelGGL(k_backtrack_w, dim3(nq), dim3(64), (size_t)BT_CAP * 2, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                           mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
+        if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(nq), dim3(64), (size_t)BT_CAP * psz, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                                    mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
+        else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(nq), dim3(64), (size_t)BT_CAP * psz, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                                mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[0], 0));
     }

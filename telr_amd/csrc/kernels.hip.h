@@ -1756,6 +1756,9 @@ __global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
 // keeps the two lines it is walking through in LDS (slot = line parity; dword k of lane l at word k*64+l:
 // conflict-free byte reads) and fetches the next lower line into registers ahead of time: memory is touched once
 // per line instead of once per step, and a line is normally there before the walk reaches it.
+#ifndef TB_SLOTS
+#define TB_SLOTS 2     /* 64-byte lines a lane keeps in LDS */
+#endif
 template <int LAYOUT>       // 2: packed int16 classes (rows of 2 anti-diagonals); -1: take it from the problem's class
 __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi,
                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
@@ -1782,7 +1785,7 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
                           : packed ? ((((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)) : ((int64_t)a * stride + sl);
         // tb_off is a multiple of 16 only, so lines are taken relative to the 64-byte grid of the whole scratch buffer
         const int64_t abs_off = P.tb_off + off, line = abs_off >> 6;
-        const int slot = (int)(line & 1);
+        const int slot = TB_SLOTS > 1 ? (int)(line & 1) : 0;
         if ((slot ? tag1 : tag0) != line) {
             if (pf != line) { const uint4 *src = (const uint4*)(tb_all + (line << 6)); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
             uint32_t *dst = stage + slot * 1024 + lane;
@@ -1819,7 +1822,7 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
                                                   const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                   const int32_t *__restrict__ list)
 {
-    __shared__ uint32_t stage[2 * 16 * 64];
+    __shared__ uint32_t stage[TB_SLOTS * 16 * 64];
     const int ti = blockIdx.x * blockDim.x + threadIdx.x;
     if (ti >= np) return;
     d_traceback_lane<-1>(probs, res, list ? list[ti] : ti, tb_all, cig, retry, stage);
@@ -1831,7 +1834,7 @@ __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ 
                                                      const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list,
                                                      const int32_t *__restrict__ cls_cnt, int32_t np)
 {
-    __shared__ uint32_t stage[2 * 16 * 64];
+    __shared__ uint32_t stage[TB_SLOTS * 16 * 64];
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int ppw = 64 / PK_LPP[cls - 10], t = threadIdx.x;

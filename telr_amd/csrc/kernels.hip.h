@@ -967,25 +967,27 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
     tb_bytes[i] = tb;
     cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
+// scratch offsets of every problem, class histogram, and the (key, problem) pairs whose ONE radix sort yields all class
+// lists at once: key = class << 20 | (0xFFFFF - steps), so a class is a contiguous range ordered by decreasing steps
+struct ClsOff { int32_t off[DP_NCLS + 1]; };
 __global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs, int32_t np, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ cig_off,
-                                                     int32_t *__restrict__ cls_cnt, int32_t *__restrict__ cls_list /* [DP_NCLS][np] */,
-                                                     uint32_t *__restrict__ cls_key /* [DP_NCLS][np]: anti-diagonal steps */)
+                                                     int32_t *__restrict__ cls_cnt, uint32_t *__restrict__ sort_key, int32_t *__restrict__ sort_val)
 {
-    __shared__ int32_t lcnt[DP_NCLS], lbase[DP_NCLS];
+    __shared__ int32_t lcnt[DP_NCLS];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (threadIdx.x < DP_NCLS) lcnt[threadIdx.x] = 0;
     __syncthreads();
-    int c = -1, s = 0;
     if (i < np) {
         probs[i].tb_off = tb_off[i];
         if (cig_off) probs[i].cig_off = cig_off[i];       // a retry keeps the CIGAR slot of the original problem
-        c = probs[i].kind >= 3 ? 0 : probs[i].pad[0];
-        s = atomicAdd(&lcnt[c], 1);
+        const int c = probs[i].kind >= 3 ? 0 : probs[i].pad[0];
+        atomicAdd(&lcnt[c], 1);
+        int steps = probs[i].m + probs[i].n; if (steps > 0xFFFFF) steps = 0xFFFFF;
+        sort_key[i] = (uint32_t)c << 20 | (uint32_t)(0xFFFFF - steps);
+        sort_val[i] = i;
     }
     __syncthreads();
-    if (threadIdx.x < DP_NCLS) lbase[threadIdx.x] = lcnt[threadIdx.x] ? atomicAdd(&cls_cnt[threadIdx.x], lcnt[threadIdx.x]) : 0;
-    __syncthreads();
-    if (c >= 0) { cls_list[(int64_t)c * np + lbase[c] + s] = i; cls_key[(int64_t)c * np + lbase[c] + s] = (uint32_t)(probs[i].m + probs[i].n); }
+    if (threadIdx.x < DP_NCLS && lcnt[threadIdx.x]) atomicAdd(&cls_cnt[threadIdx.x], lcnt[threadIdx.x]);
 }
 
 // retry pass: problems whose narrow-band path touched a band edge are re-aligned with the wide band
@@ -1697,7 +1699,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
 __device__ __constant__ const int PK_LPP[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 4 };
 __device__ __constant__ const int PK_R[PK_NC]   = { 5, 6, 7, 8, 5, 6, 8, 8 };
 struct PkPlan { int32_t woff[PK_NC + 1]; };   // first wave of class 10+c in the unsorted wave table
-__global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__restrict__ cls_list, int32_t np, PkPlan plan,
+__global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__restrict__ cls_list, ClsOff off, PkPlan plan,
                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1705,7 +1707,7 @@ __global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__re
     int c = 0;
     while (i >= plan.woff[c + 1]) ++c;
     const int first = (i - plan.woff[c]) * (64 / PK_LPP[c]);
-    const DpProb P = probs[cls_list[(int64_t)(10 + c) * np + first]];     // lists are sorted by decreasing steps
+    const DpProb P = probs[cls_list[off.off[10 + c] + first]];     // lists are sorted by decreasing steps
     keys[i] = (uint32_t)((P.m + P.n) * PK_R[c]);
     vals[i] = (uint32_t)(10 + c) << 26 | (uint32_t)first;
 }
@@ -1713,12 +1715,12 @@ __global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__re
 #define PK_WPE 2
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE))) k_dp_pk(DpArgs A, const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list,
-                                              const int32_t *__restrict__ cls_cnt, int32_t np)
+                                              ClsOff off)
 {
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
-    const int32_t *list = cls_list + (int64_t)cls * np;
-    const int n = cls_cnt[cls];
+    const int32_t *list = cls_list + off.off[cls];
+    const int n = off.off[cls + 1] - off.off[cls];
     switch (cls) {
     case 10: d_dp_pkr<1, 5, false>(A, list, n, first); break;
     case 11: d_dp_pkr<1, 6, false>(A, list, n, first); break;
@@ -1831,15 +1833,14 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
 // per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
 __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ probs, DpRes *__restrict__ res,
                                                      const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
-                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list,
-                                                     const int32_t *__restrict__ cls_cnt, int32_t np)
+                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list, ClsOff off)
 {
     __shared__ uint32_t stage[TB_SLOTS * 16 * 64];
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int ppw = 64 / PK_LPP[cls - 10], t = threadIdx.x;
-    if (t >= ppw || first + t >= cls_cnt[cls]) return;
-    d_traceback_lane<2>(probs, res, cls_list[(int64_t)cls * np + first + t], tb_all, cig, retry, stage);
+    if (t >= ppw || first + t >= off.off[cls + 1] - off.off[cls]) return;
+    d_traceback_lane<2>(probs, res, cls_list[off.off[cls] + first + t], tb_all, cig, retry, stage);
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control

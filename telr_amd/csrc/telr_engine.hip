@@ -845,13 +845,14 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
 {
     hipStream_t st = ctx->stream;
     int64_t *d_tbb, *d_cgo, *d_tboff, *d_cgoff; int32_t *d_clscnt, *d_clslist; uint32_t *d_clskey, *d_keytmp; int32_t *d_listtmp;
+    ClsOff coff;
     TRY(ctx_buf_t(ctx, ("tb_bytes" + sfx).c_str(), (size_t)np + 1, &d_tbb));
     TRY(ctx_buf_t(ctx, ("cig_ops" + sfx).c_str(), (size_t)np + 1, &d_cgo));
     TRY(ctx_buf_t(ctx, ("tb_off" + sfx).c_str(), (size_t)np + 1, &d_tboff));
     TRY(ctx_buf_t(ctx, ("cig_off" + sfx).c_str(), (size_t)np + 1, &d_cgoff));
     TRY(ctx_buf_t(ctx, ("cls_cnt" + sfx).c_str(), 32, &d_clscnt));
-    TRY(ctx_buf_t(ctx, ("cls_list" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clslist));
-    TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np * DP_NCLS, &d_clskey));
+    TRY(ctx_buf_t(ctx, ("cls_list" + sfx).c_str(), (size_t)np, &d_clslist));
+    TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
     hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo);
@@ -861,7 +862,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbb, d_tboff, (size_t)np + 1)));
     if (primary) TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_cgo, d_cgoff, (size_t)np + 1)));
     HIPCHK(hipMemsetAsync(d_clscnt, 0, 128, st));
-    hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, primary ? d_cgoff : (const int64_t*)nullptr, d_clscnt, d_clslist, d_clskey);
+    hipLaunchKernelGGL(k_prob_assign, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, d_tboff, primary ? d_cgoff : (const int64_t*)nullptr, d_clscnt, d_clskey, d_listtmp);
     HIPCHK(hipGetLastError());
     int64_t tb_total = 0, cg_total = 0; int32_t h_cls[32];
     static_assert(DP_NCLS <= 32 && DP_NCLS == TELR_N_DPCLS, "class table");
@@ -869,15 +870,14 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     if (primary) HIPCHK(hipMemcpyAsync(&cg_total, d_cgoff + np, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_cls, d_clscnt, 128, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    // sort every sizeable class list by decreasing step count
-    for (int c = 0; c < DP_NCLS; ++c) {
-        if (h_cls[c] < 256) continue;
-        uint32_t *keys = d_clskey + (size_t)c * np; int32_t *ids = d_clslist + (size_t)c * np;
+    // one sort of (class, decreasing steps) keys gives every class list as a contiguous range of d_clslist
+    coff.off[0] = 0;
+    for (int c = 0; c < DP_NCLS; ++c) coff.off[c + 1] = coff.off[c] + h_cls[c];
+    {
         size_t tbytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, keys, d_keytmp, ids, d_listtmp, (size_t)h_cls[c], 0, 20, st));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 25, st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
-        HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, keys, d_keytmp, ids, d_listtmp, (size_t)h_cls[c], 0, 20, st));
-        HIPCHK(hipMemcpyAsync(ids, d_listtmp, (size_t)h_cls[c] * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(rocprim::radix_sort_pairs(tmp, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 25, st));
     }
     uint8_t *d_tb;
     TRY(ctx_buf_t(ctx, ("tb" + sfx).c_str(), (size_t)tb_total + 256, &d_tb));
@@ -905,7 +905,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             TRY(ctx_buf_t(ctx, ("pk_wval" + sfx).c_str(), (size_t)nw, &d_wv));
             TRY(ctx_buf_t(ctx, ("pk_wkey2" + sfx).c_str(), (size_t)nw, &d_wk2));
             TRY(ctx_buf_t(ctx, ("pk_wval2" + sfx).c_str(), (size_t)nw, &d_wv2));
-            hipLaunchKernelGGL(k_pk_waves, dim3((nw + 255) / 256), dim3(256), 0, st, d_probs, d_clslist, np, plan, d_wk, d_wv);
+            hipLaunchKernelGGL(k_pk_waves, dim3((nw + 255) / 256), dim3(256), 0, st, d_probs, d_clslist, coff, plan, d_wk, d_wv);
             HIPCHK(hipGetLastError());
             size_t tbytes = 0;
             HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 18, st));
@@ -928,7 +928,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         hipStream_t s2 = side_stream();
         HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
         const int nl = h_cls[c];
-        D.list = d_clslist + (size_t)c * np; D.nlist = nl; D.dcap = 0;
+        D.list = d_clslist + coff.off[c]; D.nlist = nl; D.dcap = 0;
         if (c <= 4) {
             D.dcap = CAP[c];
             size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
@@ -963,27 +963,27 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         for (int g = 0; g < G; ++g) {
             const int w0 = (int)((int64_t)nw * g / G), w1 = (int)((int64_t)nw * (g + 1) / G);
             if (w1 <= w0) continue;
-            hipLaunchKernelGGL(k_dp_pk, dim3(w1 - w0), dim3(64), 0, st, D, d_wv2 + w0, d_clslist, d_clscnt, np);
+            hipLaunchKernelGGL(k_dp_pk, dim3(w1 - w0), dim3(64), 0, st, D, d_wv2 + w0, d_clslist, coff);
             HIPCHK(hipGetLastError());
             if (tb_over) {
                 HIPCHK(hipEventRecord(ctx->ev_chunk[g], st));
                 HIPCHK(hipStreamWaitEvent(ctx->tb_stream, ctx->ev_chunk[g], 0));
-                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, d_clscnt, np);
+                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, coff);
                 HIPCHK(hipGetLastError());
             }
         }
         if (tb_over) { if (primary) HIPCHK(hipEventRecord(ctx->evk[4], ctx->tb_stream)); used.push_back(ctx->tb_stream); }
     }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[0], st));
-    if (h_cls[5]) { D.list = d_clslist + (size_t)5 * np; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
-    if (h_cls[6]) { D.list = d_clslist + (size_t)6 * np; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
+    if (h_cls[5]) { D.list = d_clslist + coff.off[5]; D.nlist = h_cls[5]; hipLaunchKernelGGL((k_dp_reg<32, 1>), dim3((h_cls[5] + 1) / 2), dim3(64), 0, st, D); }
+    if (h_cls[6]) { D.list = d_clslist + coff.off[6]; D.nlist = h_cls[6]; hipLaunchKernelGGL((k_dp_reg<64, 1>), dim3(h_cls[6]), dim3(64), 0, st, D); }
     if (primary) HIPCHK(hipEventRecord(ctx->evk[1], st));
     if (tb_split) {
         if (!tb_over && primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
-        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, d_clscnt, np);
+        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, coff);
         for (int c = 6; c >= 5; --c) {
             if (h_cls[c] == 0) continue;
-            hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, st, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, (const int32_t*)(d_clslist + (size_t)c * np));
+            hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, st, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, (const int32_t*)(d_clslist + coff.off[c]));
         }
         if (!tb_over && primary) HIPCHK(hipEventRecord(ctx->evk[4], st));
         HIPCHK(hipGetLastError());

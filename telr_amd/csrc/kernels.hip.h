@@ -903,9 +903,10 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
         if (D <= 40) return 14;
         if (D <= 48) return 15;
         if (D <= 64) return 16;
-        if (D <= 128) return 17;
     }
-    if (kind == 0 && steps <= pk_wide_steps && D > 128) {
+    // (class 17, four lanes per problem for 65..128 diagonals, is not assigned any more: those problems are few and mostly
+    // retries, where what counts is the latency of one problem, so they take the 64-lane class 19)
+    if (kind == 0 && steps <= pk_wide_steps && D > 64) {
         if (D <= 256) return 19;
         if (D <= 512) return 20;
         if (D <= 1024) return 21;
@@ -1728,8 +1729,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     case 13: d_dp_pkr<1, 8, false>(A, list, n, first); break;
     case 14: d_dp_pkr<2, 5, false>(A, list, n, first); break;
     case 15: d_dp_pkr<2, 6, false>(A, list, n, first); break;
-    case 16: d_dp_pkr<2, 8, false>(A, list, n, first); break;
-    default: d_dp_pkr<4, 8, false>(A, list, n, first); break;
+    default: d_dp_pkr<2, 8, false>(A, list, n, first); break;
     }
 }
 // wide gap fills in int16 (classes 19-21: bands up to 256 / 512 / 1024 diagonals): one problem per workgroup of

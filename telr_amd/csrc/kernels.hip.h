@@ -1980,34 +1980,58 @@ __global__ void __launch_bounds__(256) k_dp_account(const DpProb *__restrict__ p
 // its problems (left extension in emission order, fills and right extension reversed) and merges equal ops
 // across problem boundaries.  Pass 1 counts the final ops (they only merge at boundaries), pass 2 writes them.
 struct StitchProb { int32_t sv, off, skip, extra; };      // per problem: record, offset inside the record, first op merged away, length absorbed by its last op
-__global__ void k_stitch_count(const StitchRec *__restrict__ sv, int32_t ns, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
-                               const uint32_t *__restrict__ raw, int64_t *__restrict__ nfin, StitchProb *__restrict__ sp)
+// One wave per chain, 64 problems per iteration: the per-problem loads run in parallel, the three things that depend on
+// earlier problems (op code of the previous non-empty problem, running op count, the problem whose last op absorbs merged
+// first ops) are carried through wave scans.
+__device__ __forceinline__ int d_wave_last_valid(int v, bool valid, int carry, int lane)     // value of the nearest lane < this one with valid, else carry
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // inclusive "last valid" scan, then shifted by one lane
+    int x = valid ? v : INT32_MIN;                       // INT32_MIN = none
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o && x == INT32_MIN) x = y; }
+    int prev = __shfl_up(x, 1);
+    if (lane == 0 || prev == INT32_MIN) prev = (lane == 0) ? carry : (prev == INT32_MIN ? carry : prev);
+    return prev;
+}
+__global__ void __launch_bounds__(64) k_stitch_count(const StitchRec *__restrict__ sv, int32_t ns, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
+                                                     const uint32_t *__restrict__ raw, int64_t *__restrict__ nfin, StitchProb *__restrict__ sp)
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= ns) return;
     const StitchRec S = sv[i];
-    int n = 0, prev = -1, owner = -1, owner_extra = 0;
-    for (int p = S.p0; p < S.p1; ++p) {
-        const int no = res[p].nops;
-        StitchProb q; q.sv = i; q.off = n; q.skip = 0; q.extra = 0;
-        if (no) {
-            const int64_t off = probs[p].cig_off;
-            const bool fwd = p == S.p0 && S.has_left;
-            const uint32_t fo = raw[off + (fwd ? 0 : no - 1)], lo = raw[off + (fwd ? no - 1 : 0)];
-            q.skip = prev == (int)(fo & 0xf) ? 1 : 0;
-            if (q.skip) owner_extra += (int)(fo >> 4);            // the current tail op grows by the merged first op
-            const int written = no - q.skip;
-            if (written > 0) {
-                if (owner >= 0) sp[owner].extra = owner_extra;    // the previous tail is final now
-                owner = p; owner_extra = 0;
+    int n = 0, prev_code = -1, owner = -1;               // carried across iterations (uniform)
+    for (int p0 = S.p0; p0 < S.p1; p0 += 64) {
+        const int p = p0 + lane;
+        const bool in = p < S.p1;
+        int no = 0, fcode = -2, lcode = -3, flen = 0;
+        if (in) {
+            no = res[p].nops;
+            if (no) {
+                const int64_t off = probs[p].cig_off;
+                const bool fwd = p == S.p0 && S.has_left;
+                const uint32_t fo = raw[off + (fwd ? 0 : no - 1)], lo = raw[off + (fwd ? no - 1 : 0)];
+                fcode = (int)(fo & 0xf); flen = (int)(fo >> 4); lcode = (int)(lo & 0xf);
             }
-            n += written;
-            prev = (int)(lo & 0xf);
         }
-        sp[p] = q;
+        const bool ne = no > 0;
+        const int prev = d_wave_last_valid(lcode, ne, prev_code, lane);
+        const int skip = ne && prev == fcode ? 1 : 0;
+        const int written = ne ? no - skip : 0;
+        int inc = written;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o); if (lane >= o) inc += y; }
+        const bool isowner = written > 0;
+        const int own_prev = d_wave_last_valid(p, isowner, owner, lane);       // problem whose tail op absorbs this one's merged first op
+        if (in) { StitchProb q; q.sv = i; q.off = n + inc - written; q.skip = skip; q.extra = 0; sp[p] = q; }
+        __threadfence_block();
+        if (skip && own_prev >= 0) atomicAdd(&sp[own_prev].extra, flen);
+        // carries: last non-empty problem's last op code, op count, last owner
+        const uint64_t nem = __ballot(ne), owm = __ballot(isowner);
+        if (nem) prev_code = __shfl(lcode, 63 - __clzll((long long)nem));
+        if (owm) owner = p0 + (63 - __clzll((long long)owm));
+        n += __shfl(inc, 63);
     }
-    if (owner >= 0) sp[owner].extra = owner_extra;
-    nfin[i] = n;
+    if (lane == 0) nfin[i] = n;
 }
 __global__ void k_stitch_write(int32_t np, const StitchProb *__restrict__ sp, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
                                const StitchRec *__restrict__ sv, const uint32_t *__restrict__ raw, const int64_t *__restrict__ fin_off, uint32_t *__restrict__ out)
@@ -2027,8 +2051,6 @@ __global__ void k_stitch_write(int32_t np, const StitchProb *__restrict__ sp, co
         o[z - q.skip] = op;
     }
 }
-
-// compact the raw per-problem cigars (emission order preserved) into one dense array
 
 // ---------------------------------------------------------------------------------------
 // 6. depth medians (samtools depth -aa -r | statistics.median)

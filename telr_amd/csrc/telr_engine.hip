@@ -1334,7 +1334,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             });
             HIPCHK(hipMemcpyAsync(d_sv, h_sv, (size_t)nk * sizeof(StitchRec), hipMemcpyHostToDevice, st));
             HIPCHK(hipMemsetAsync(d_sp, 0xff, (size_t)np * sizeof(StitchProb), st));
-            hipLaunchKernelGGL(k_stitch_count, dim3((nk + 63) / 64), dim3(64), 0, st, d_sv, nk, d_probs, d_res, d_rawcig, d_nfin, d_sp);
+            hipLaunchKernelGGL(k_stitch_count, dim3(nk), dim3(64), 0, st, d_sv, nk, d_probs, d_res, d_rawcig, d_nfin, d_sp);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemsetAsync(d_nfin + nk, 0, 8, st));
             TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_nfin, d_foff, (size_t)nk + 1)));

@@ -48,3 +48,21 @@ def check_truth(res, loci, truth):
             assert (f >= 0.7) if t["af"] == 1.0 else (0.2 <= f <= 0.85)
         ok += 1
     assert ok >= len(loci) - 1
+
+
+def test_locus_bundle_with_resident_read_set(engine):
+    """Window reads given as indices into a read set already on the device (telr_seqset_subset) give the same bundle
+    output as the same reads given as strings."""
+    from locus_data import make_loci
+    ref, lib_names, lib, loci, truth = make_loci()
+    io, _ = preset("asm10")
+    all_reads, loci_idx = [], []
+    for l in loci:
+        idx = list(range(len(all_reads), len(all_reads) + len(l["reads"])))
+        all_reads.extend(l["reads"])
+        loci_idx.append(dict(l, read_idx=idx))
+    read_set = engine.seqset(all_reads)
+    ref_ix = engine.index([ref], io)
+    a = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
+    b = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci_idx, lib_names, lib, presets="ont", read_set=read_set)
+    assert a["af"] == b["af"] and a["liftover"] == b["liftover"] and a["annotation"] == b["annotation"]

@@ -888,14 +888,16 @@ __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
 #define DP_NCLS 22
-// 10-17: packed-int16 register kernel k_dp_pkr<LPP, R> for short gap fills, by band width:
-// D <= 20 / 24 / 28 / 32 one lane per problem with R = 5 / 6 / 7 / 8; D <= 40 / 48 / 64 two lanes with R = 5 / 6 / 8;
-// D <= 128 four lanes with R = 8; 18: z-drop extensions with D <= 64 (two lanes, R = 8)
+// 10-17: packed-int16 register kernel d_dp_pkr<LPP, R> for short gap fills, by band width.  One lane per problem:
+// class 17 D <= 16 (R = 4), classes 10..13 D = 17-20 / 21-24 / 25-28 / 29-32 (R = 5 / 6 / 7 / 8: exact ranges, so that only
+// the last register of a lane can straddle the upper band edge); two lanes: classes 14..16 D <= 40 / 48 / 64 (R = 5 / 6 / 8).
+// 18: z-drop extensions with D <= 64 (four lanes, R = 4)
 // 19-21: wide fills in int16 while the scores fit (steps <= pk_wide_steps): D <= 256 / 512 / 1024, 1 / 2 / 4 waves per problem
 __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps)
 {
     if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
     if (kind == 0 && steps <= pk_max_steps) {
+        if (D <= 16) return 17;
         if (D <= 20) return 10;
         if (D <= 24) return 11;
         if (D <= 28) return 12;
@@ -904,8 +906,7 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
         if (D <= 48) return 15;
         if (D <= 64) return 16;
     }
-    // (class 17, four lanes per problem for 65..128 diagonals, is not assigned any more: those problems are few and mostly
-    // retries, where what counts is the latency of one problem, so they take the 64-lane class 19)
+    // (65..128 diagonals: few problems, mostly retries, where what counts is the latency of one problem: the 64-lane class 19)
     if (kind == 0 && steps <= pk_wide_steps && D > 64) {
         if (D <= 256) return 19;
         if (D <= 512) return 20;
@@ -924,7 +925,7 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
 __device__ __forceinline__ int d_cls_slots(int cls)
 {
     if (cls >= 19) return 64 << (cls - 19);
-    if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 32 : 16;
+    if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 4 : 16;
     return cls == 5 ? 32 : 64 << (cls - 6);
 }
 // any ambiguous base among the n bases from absolute index lo on?
@@ -1494,7 +1495,9 @@ __device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dh
 
 // NW > 1: one problem per workgroup of NW waves (LPP = 64*NW lanes): the values that cross a wave boundary go
 // through `xch` (LDS, [2][NW][3]) with one barrier per step, everything else is unchanged.
-template <int LPP, int R, bool EXT, int NW = 1>
+// FULL: the first FULL registers of a lane are inside the band for every problem of the class (classes are cut so that
+// only the last register can straddle dhi), so they need no out-of-band masks.
+template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0>
 __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob, uint32_t *xch = nullptr)
 {
     static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
@@ -1523,11 +1526,12 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
         qb[r] = 0; tbv[r] = 0;
     }
     const int mn = m + n;
-    int amax = mn;
+    int amax = mn, amin = have ? mn : 0x7fffffff;
     if (NW == 1) {
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; }
+        for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; v = __shfl_xor(amin, s); amin = v < amin ? v : amin; }
     }
+    amin = __builtin_amdgcn_readfirstlane(amin);
     uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off) + l * R;
     const int last_row = have ? mn >> 1 : -1;
     // base streams: the newest query base enters register 0 (low half) and ages towards register R-1, the newest
@@ -1576,8 +1580,13 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 const uint32_t lh = r ? Ho[r - 1] : ph, le1 = r ? E1o[r - 1] : pe1, le2 = r ? E2o[r - 1] : pe2;
                 const uint32_t hl = __builtin_amdgcn_alignbit(Ho[r], lh, 16), e1l = __builtin_amdgcn_alignbit(E1o[r], le1, 16), e2l = __builtin_amdgcn_alignbit(E2o[r], le2, 16);
                 te[r] = d_cell_pk(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
-                He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); E1e[r] = ve1; F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); E2e[r] = ve2; F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]);
-                if (!EXT && a == mn && r == fin_r) fin = h;
+                if (r < FULL) { He[r] = h; F1e[r] = vf1; F2e[r] = vf2; }
+                else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]); }
+                E1e[r] = ve1; E2e[r] = ve2;
+            }
+            if (!EXT && a >= amin) {      // only the last steps of a wave can be some problem's last step (lists are sorted by steps)
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (a == mn && r == fin_r) fin = He[r];
             }
             if (NW > 1) {
                 if (wl == 0) { uint32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
@@ -1613,9 +1622,14 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 const uint32_t uh = r < R - 1 ? He[r + 1] : nh, uf1 = r < R - 1 ? F1e[r + 1] : nf1, uf2 = r < R - 1 ? F2e[r + 1] : nf2;
                 const uint32_t hu = __builtin_amdgcn_alignbit(uh, He[r], 16), f1u = __builtin_amdgcn_alignbit(uf1, F1e[r], 16), f2u = __builtin_amdgcn_alignbit(uf2, F2e[r], 16);
                 const uint32_t t = d_cell_pk(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
-                Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); E1o[r] = ve1; F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); E2o[r] = ve2; F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]);
-                if (!EXT && a == mn && r == fin_r) fin = h;
+                if (r < FULL) { Ho[r] = h; F1o[r] = vf1; F2o[r] = vf2; }
+                else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]); }
+                E1o[r] = ve1; E2o[r] = ve2;
                 row[r] = __builtin_amdgcn_perm(t, te[r], 0x06040200u);
+            }
+            if (!EXT && a >= amin) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) if (a == mn && r == fin_r) fin = Ho[r];
             }
             if (EXT) {
                 uint32_t hv[R];
@@ -1697,8 +1711,8 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
 // wave table is ordered by decreasing estimated cost (steps x registers per lane), so the long waves start first and
 // no class leaves the machine idle behind its own tail.
 #define PK_NC 8                            /* packed fill classes 10 .. 10+PK_NC-1 */
-__device__ __constant__ const int PK_LPP[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 4 };
-__device__ __constant__ const int PK_R[PK_NC]   = { 5, 6, 7, 8, 5, 6, 8, 8 };
+__device__ __constant__ const int PK_LPP[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 1 };
+__device__ __constant__ const int PK_R[PK_NC]   = { 5, 6, 7, 8, 5, 6, 8, 4 };
 struct PkPlan { int32_t woff[PK_NC + 1]; };   // first wave of class 10+c in the unsorted wave table
 __global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__restrict__ cls_list, ClsOff off, PkPlan plan,
                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -1723,10 +1737,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     const int32_t *list = cls_list + off.off[cls];
     const int n = off.off[cls + 1] - off.off[cls];
     switch (cls) {
-    case 10: d_dp_pkr<1, 5, false>(A, list, n, first); break;
-    case 11: d_dp_pkr<1, 6, false>(A, list, n, first); break;
-    case 12: d_dp_pkr<1, 7, false>(A, list, n, first); break;
-    case 13: d_dp_pkr<1, 8, false>(A, list, n, first); break;
+    case 10: d_dp_pkr<1, 5, false, 1, 4>(A, list, n, first); break;      // 17..20 diagonals: registers 0-3 are inside the band
+    case 11: d_dp_pkr<1, 6, false, 1, 5>(A, list, n, first); break;
+    case 12: d_dp_pkr<1, 7, false, 1, 6>(A, list, n, first); break;
+    case 13: d_dp_pkr<1, 8, false, 1, 7>(A, list, n, first); break;
+    case 17: d_dp_pkr<1, 4, false>(A, list, n, first); break;            // up to 16 diagonals
     case 14: d_dp_pkr<2, 5, false>(A, list, n, first); break;
     case 15: d_dp_pkr<2, 6, false>(A, list, n, first); break;
     default: d_dp_pkr<2, 8, false>(A, list, n, first); break;

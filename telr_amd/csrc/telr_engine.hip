@@ -895,7 +895,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     // before the tail classes are started so that these two small launches do not queue behind them
     int nw = 0; uint32_t *d_wv2 = nullptr;
     {
-        static const int LPP_[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 4 };
+        static const int LPP_[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 1 };
         PkPlan plan; plan.woff[0] = 0;
         for (int c = 0; c < PK_NC; ++c) { const int ppw = 64 / LPP_[c]; plan.woff[c + 1] = plan.woff[c] + (h_cls[10 + c] + ppw - 1) / ppw; }
         nw = plan.woff[PK_NC];

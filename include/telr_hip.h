@@ -162,7 +162,11 @@ int64_t         telr_result_count(const telr_result *r);
 const telr_aln *telr_result_alns(const telr_result *r);     /* sorted by (qid, rank) */
 /* CIGAR ops (BAM encoding, len<<4|op) of all records in one array; a record owns ops
  * [cigar_off, cigar_off + n_cigar).  The array is filled by one DMA that starts before the final
- * chain selection, so it may also hold the ops of chains that selection dropped (unreferenced). */
+ * chain selection, so it may also hold the ops of chains that selection dropped (unreferenced).
+ * telr_map returns as soon as the RECORDS are complete; the DMA of the CIGAR array may still be in flight
+ * (so that a caller streaming batches overlaps it with the next telr_map call).  telr_result_cigars,
+ * the writers, telr_depth_medians and telr_result_free wait for it; telr_result_wait does so explicitly. */
+int             telr_result_wait(const telr_result *r);
 int64_t         telr_result_cigar_count(const telr_result *r);
 const uint32_t *telr_result_cigars(const telr_result *r);
 void            telr_result_free(telr_result *r);

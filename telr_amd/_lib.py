@@ -11,7 +11,7 @@ EXPORTS = [
     "telr_init", "telr_destroy", "telr_strerror", "telr_last_error", "telr_device_name", "telr_preset",
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
-    "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_free",
+    "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
     "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_depth_medians", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
@@ -49,6 +49,7 @@ def lib():
     L.telr_result_alns.restype = vp; L.telr_result_alns.argtypes = [vp]
     L.telr_result_cigar_count.restype = i64; L.telr_result_cigar_count.argtypes = [vp]
     L.telr_result_cigars.restype = vp; L.telr_result_cigars.argtypes = [vp]
+    L.telr_result_wait.restype = C.c_int; L.telr_result_wait.argtypes = [vp]
     L.telr_result_free.restype = None; L.telr_result_free.argtypes = [vp]
     L.telr_depth_medians.restype = C.c_int
     L.telr_depth_medians.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]

@@ -39,6 +39,8 @@ struct telr_ctx {
     hipStream_t side[8] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_side[8] = {nullptr}, ev_chunk[8] = {nullptr};
     hipStream_t tb_stream = nullptr;      // packed trace-back chunks run here, underneath the next forward chunk
+    hipStream_t copy_stream = nullptr;    // the result CIGAR DMA: may still run when telr_map has returned and the next call starts
+    hipEvent_t ev_stitched = nullptr, ev_dma = nullptr; bool dma_inflight = false;
     std::string err;
     std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
     std::map<std::string, DBuf> hbufs;    // grow-only pinned host staging buffers
@@ -157,6 +159,8 @@ extern "C" int telr_init(int device, telr_ctx **out)
     for (int i = 0; i < TELR_NSIDE; ++i) if (hipStreamCreate(&ctx->side[i]) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_side[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < 8; ++i) if (hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     if (hipStreamCreate(&ctx->tb_stream) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
+    if (hipStreamCreate(&ctx->copy_stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_stitched, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_dma, hipEventDisableTiming) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     *out = ctx;
     return TELR_OK;
 }
@@ -187,6 +191,9 @@ extern "C" void telr_destroy(telr_ctx *ctx)
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (int i = 0; i < 8; ++i) if (ctx->ev_chunk[i]) (void)hipEventDestroy(ctx->ev_chunk[i]);
     if (ctx->tb_stream) (void)hipStreamDestroy(ctx->tb_stream);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->ev_stitched) (void)hipEventDestroy(ctx->ev_stitched);
+    if (ctx->ev_dma) (void)hipEventDestroy(ctx->ev_dma);
     for (int i = 0; i < 6; ++i) if (ctx->evk[i]) (void)hipEventDestroy(ctx->evk[i]);
     for (int i = 0; i < TELR_N_STAGES; ++i) for (int j = 0; j < 2; ++j) if (ctx->ev_st[i][j]) (void)hipEventDestroy(ctx->ev_st[i][j]);
     delete ctx;
@@ -658,10 +665,17 @@ static int32_t mapq_of(const telr_aln &r, const telr_map_opt *mo)
 struct telr_result {
     telr_ctx *ctx = nullptr;
     std::vector<telr_aln> alns;
-    uint32_t *cig = nullptr;       // malloc'ed, never zero-filled: pages are first touched by the stitching threads
+    uint32_t *cig = nullptr;       // pinned; filled by one DMA that may still be in flight when telr_map returns
     size_t ncig = 0, cap = 0;      // cap in ops
+    mutable hipEvent_t dma_done = nullptr;   // non-null while the CIGAR DMA has not been waited for
     ~telr_result();
 };
+// the records are complete when telr_map returns; the CIGAR array is complete after this (every accessor of it calls it)
+static void result_wait(const telr_result *r)
+{
+    if (r && r->dma_done) { (void)hipEventSynchronize(r->dma_done); (void)hipEventDestroy(r->dma_done); r->dma_done = nullptr; }
+}
+extern "C" int telr_result_wait(const telr_result *r) { if (!r) return TELR_E_ARG; result_wait(r); return TELR_OK; }
 // CIGAR buffers of freed results are kept (at most two) and handed to the next telr_map call: a fresh
 // 200 MB allocation costs ~20 ms of page faults and another ~20 ms of munmap per call.
 // result CIGAR buffers are PINNED host memory (the stitched CIGARs are copied device -> result in one DMA)
@@ -693,11 +707,11 @@ static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
     *p = ctx->cig_pool[best].first; *cap = ctx->cig_pool[best].second;
     ctx->cig_pool.erase(ctx->cig_pool.begin() + best);
 }
-telr_result::~telr_result() { pool_put(ctx, cig, cap); }
+telr_result::~telr_result() { result_wait(this); pool_put(ctx, cig, cap); }
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
 extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->ncig : 0; }
-extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { return r ? r->cig : nullptr; }
+extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { result_wait(r); return r ? r->cig : nullptr; }
 extern "C" void telr_result_free(telr_result *r) { delete r; }
 
 static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
@@ -1356,15 +1370,26 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             const int64_t tot = h_foff[nk];
             uint32_t *d_fin;
             TRY(ctx_buf_t(ctx, "stitched", (size_t)tot + 1, &d_fin));
+            // the stitched scratch is overwritten here: the previous call's DMA out of it must be over (it is, tens of ms ago)
+            if (ctx->dma_inflight) HIPCHK(hipStreamWaitEvent(st, ctx->ev_dma, 0));
             hipLaunchKernelGGL(k_stitch_write, dim3((np + 255) / 256), dim3(256), 0, st, np, d_sp, d_probs, d_res, d_sv, d_rawcig, d_foff, d_fin);
             HIPCHK(hipGetLastError());
+            result_wait(R);                        // an earlier batch of this call may still be writing into the buffer that grows below
             cig_base = R->ncig;
             if (cig_base + (size_t)tot + 1 > R->cap) {
                 if (!R->cig) pool_get(ctx, &R->cig, &R->cap);
                 if (!cig_grow(&R->cig, &R->cap, cig_base, cig_base + (size_t)tot + 1 + (size_t)tot / 8)) return TELR_E_NOMEM;
             }
             R->ncig = cig_base + (size_t)tot;
-            if (tot) HIPCHK(hipMemcpyAsync(R->cig + cig_base, d_fin, (size_t)tot * 4, hipMemcpyDeviceToHost, st));   // waited for at the end
+            if (tot) {
+                // DMA on its own stream: the caller gets the records back while the CIGAR array is still travelling
+                HIPCHK(hipEventRecord(ctx->ev_stitched, st));
+                HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_stitched, 0));
+                HIPCHK(hipMemcpyAsync(R->cig + cig_base, d_fin, (size_t)tot * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+                HIPCHK(hipEventRecord(ctx->ev_dma, ctx->copy_stream)); ctx->dma_inflight = true;
+                HIPCHK(hipEventCreateWithFlags(&R->dma_done, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(R->dma_done, ctx->copy_stream));
+            }
         }
 
         // ---- host: per-chain numbers from the per-problem results (no op walking) ---------------------
@@ -1445,9 +1470,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             ops += surv[i].r.n_cigar;
         }
         ctx->ctr.cigar_ops += ops;
-        StageTimer t_g2(ctx, ST_GATHER, false);
-        HIPCHK(hipStreamSynchronize(st));          // the CIGAR DMA started before the second selection pass
-        t_g2.stop();
+        if (getenv("TELR_SYNC_RESULT")) { StageTimer t_g2(ctx, ST_GATHER, false); result_wait(R); t_g2.stop(); }   // else: waited for by whoever reads the CIGARs
     }
     StageTimer t_as3(ctx, ST_ASSEMBLE, false);
     R->alns.reserve(R->alns.size() + ns);
@@ -1569,6 +1592,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // merge: the bulk result's CIGAR buffer becomes the result's, the long reads' ops are appended; records are
         // merged by original query id (both lists are sorted by it)
         telr_result *P0 = part[0], *P1 = part[1];
+        result_wait(P0); result_wait(P1);
         R->cig = P0->cig; R->cap = P0->cap; R->ncig = P0->ncig; P0->cig = nullptr; P0->cap = 0; P0->ncig = 0;
         const size_t base1 = R->ncig;
         if (!cig_grow(&R->cig, &R->cap, base1, base1 + P1->ncig + 1)) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; }
@@ -1642,6 +1666,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         const int NT = host_threads();
         for (int k = 0; k < nsub; ++k) {
             telr_result *P = part[k];
+            result_wait(P);
             parallel_ranges(NT, (int)P->alns.size(), [&](int, int x0, int x1) {
                 for (int x = x0; x < x1; ++x) { telr_aln r = P->alns[x]; r.cigar_off += (int64_t)c0[k]; R->alns[a0[k] + x] = r; }
             });
@@ -1714,6 +1739,7 @@ extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n
     TRY(ctx_buf_t(ctx, "dm_toff", (size_t)n_targets + 1, &d_toff));
     TRY(ctx_buf_t(ctx, "dm_tlen", (size_t)n_targets, &d_tlen));
     TRY(ctx_buf_t(ctx, "dm_recs", recs.size(), &d_recs));
+    result_wait(r);
     TRY(ctx_buf_t(ctx, "dm_cig", r->ncig, &d_cig));
     TRY(ctx_buf_t(ctx, "dm_ivt", (size_t)n_iv, &d_ivt));
     TRY(ctx_buf_t(ctx, "dm_ivs", (size_t)n_iv, &d_ivs));
@@ -1766,6 +1792,7 @@ extern "C" int telr_write_paf(const telr_result *r, const char *const *qnames, c
                               const char *path, int append)
 {
     if (!r || !qnames || !tnames) return TELR_E_ARG;
+    result_wait(r);
     FILE *f = path ? fopen(path, append ? "a" : "w") : stdout;
     if (!f) return TELR_E_ARG;
     std::string line;
@@ -1790,6 +1817,7 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
                               const char *pg_line, const char *path)
 {
     if (!r || !qnames || !q_ascii || !q_off || !q_len || !tnames || !t_ascii || !t_off || !t_len) return TELR_E_ARG;
+    result_wait(r);
     FILE *f = path ? fopen(path, "w") : stdout;
     if (!f) return TELR_E_ARG;
     fprintf(f, "@HD\tVN:1.6\tSO:unsorted\tGO:query\n");
@@ -1951,6 +1979,7 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
                               const char *pg_line, const char *bam_path, int32_t write_index, int32_t level)
 {
     if (!r || !qnames || !q_ascii || !q_off || !q_len || !tnames || !t_ascii || !t_off || !t_len || !bam_path) return TELR_E_ARG;
+    result_wait(r);
     const size_t n = r->alns.size();
     // --- 1. binary records (one per alignment + one per unmapped read), built in parallel over queries
     std::vector<size_t> qfirst((size_t)n_queries + 1, 0);

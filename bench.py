@@ -176,7 +176,7 @@ def main():
         def _pmc(path, kern):
             for line in open(os.path.join(ROOT, "profiles", path)):
                 if line.startswith(kern):
-                    return float(line.split()[-2])      # sum over the call's dispatches (first pass + the tiny retry pass)
+                    return float(line.split()[-2]) / 2.0     # sum over the PMC run's two map calls (set-up call + one step), per call
             return None
         fs = _pmc("r01_pmc_FETCH_SIZE.txt", k_name + " "); ws = _pmc("r01_pmc_WRITE_SIZE.txt", k_name + " ")
         if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:

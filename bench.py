@@ -171,6 +171,12 @@ def main():
     k_ms = stage_tot.get("k_dp_pk", 0.0) / a.steps
     k_bytes = float(cls[PK, 3].sum())
     achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    def _pmc2(path, kern, counter):
+        for line in open(os.path.join(ROOT, "profiles", path)):
+            f = line.split()
+            if line.startswith(kern) and counter in f:
+                return float(f[-2]) / 2.0
+        return None
     traffic, traffic_src = None, None
     try:   # HBM bytes per launch from the committed PMC passes of this same command (profiles/, separate --pmc runs)
         def _pmc(path, kern):
@@ -182,6 +188,13 @@ def main():
         if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:
             traffic = (2.0 * fs + ws) * 1024.0      # gfx950: FETCH_SIZE counts wide reads at 1/2 (MI355X_MICROARCH.md, HBM)
             traffic_src = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per map call; FETCH doubled)"
+    except Exception:
+        pass
+    issue_frac = None
+    try:   # integer-issue utilisation of the same kernel from the committed SQ counter pass (the roof that actually binds it)
+        vi = _pmc2("r01_pmc_SQ.txt", k_name + " ", "SQ_INSTS_VALU"); ga = _pmc2("r01_pmc_SQ.txt", k_name + " ", "GRBM_GUI_ACTIVE")
+        if vi and ga:
+            issue_frac = (vi * 4.0 / 1024.0) / (ga / 8.0)      # 4 cycles per wave64 VALU instruction, 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
     except Exception:
         pass
     dp_ms = stage_tot.get("dp", 0.0) / a.steps
@@ -198,7 +211,7 @@ def main():
                    "reads_per_gpu": a.reads, "read_bases_per_gpu": n_bases, "parallelism": "reads sharded x%d, index replicated" % world,
                    "streaming": "telr_map returns with the records; the CIGAR DMA of step k overlaps step k+1 (all complete inside the timed region)"},
         "roofline": {"bound": "hbm", "kernel": k_name, "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": traffic, "traffic_source": traffic_src, "launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
+                     "traffic": traffic, "traffic_source": traffic_src, "valu_issue_frac": issue_frac, "launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
                      "problems_per_launch": int(cls[PK, 0].sum()), "cells_per_launch": int(cls[PK, 1].sum()),
                      "gcups": float(cls[PK, 1].sum()) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
                      "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); all DP kernels together: %.1f ms, %.0f GCUPS"

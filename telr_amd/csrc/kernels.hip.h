@@ -755,10 +755,13 @@ __global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__
     if ((int)blockIdx.x >= nq) return;
     d_backtrack_query<PT>(q_order ? q_order[blockIdx.x] : blockIdx.x, cap, true, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
 }
-__global__ void k_bt_big(const int32_t *__restrict__ q_aoff, int32_t nq, int32_t cap, int32_t *__restrict__ big_list, int32_t *__restrict__ big_cnt)
+// queries with lo < anchors <= hi (one list per LDS tier of the list launches)
+__global__ void k_bt_big(const int32_t *__restrict__ q_aoff, int32_t nq, int32_t lo, int32_t hi, int32_t *__restrict__ big_list, int32_t *__restrict__ big_cnt)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq && q_aoff[q + 1] - q_aoff[q] > cap) big_list[atomicAdd(big_cnt, 1)] = q;
+    if (q >= nq) return;
+    const int n = q_aoff[q + 1] - q_aoff[q];
+    if (n > lo && n <= hi) big_list[atomicAdd(big_cnt, 1)] = q;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1148,16 +1148,20 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     ChainRec *d_rec;
     TRY(ctx_buf_t(ctx, "chain_rec", (size_t)npk_tot, &d_rec));
     {
-        // queries with more than BT_CAP anchors: their own launch with CU-sized LDS blocks on a side stream, under the bulk launch
-        int32_t *d_big; TRY(ctx_buf_t(ctx, "bt_big", (size_t)nq + 1, &d_big));      // [0] count, then the list
+        // queries with more than BT_CAP anchors run from lists, in two LDS tiers on side streams under the bulk launch
+        // (repeat-rich genomes put a third of the reads there): the stage is bound by resident queries per CU, so a query
+        // should not hold more LDS than its tier needs
+        static const int BT_CAP_MID = 24576;
+        int32_t *d_big; TRY(ctx_buf_t(ctx, "bt_big", 2 * ((size_t)nq + 1), &d_big));      // per tier: [0] count, then the list
+        int32_t *d_mid = d_big, *d_far = d_big + nq + 1;
         uint16_t *d_btidx; TRY(ctx_buf_t(ctx, "bt_idx", (size_t)na + 1, &d_btidx));
-        HIPCHK(hipMemsetAsync(d_big, 0, 4, st));
-        hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP, d_big + 1, d_big);
+        HIPCHK(hipMemsetAsync(d_mid, 0, 4, st)); HIPCHK(hipMemsetAsync(d_far, 0, 4, st));
+        hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP, BT_CAP_MID, d_mid + 1, d_mid);
+        hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP_MID, 0x7fffffff, d_far + 1, d_far);
         HIPCHK(hipGetLastError());
         // one byte of LDS per anchor when the look-back fits a byte (the bulk launch then keeps 20 queries per CU resident)
         const bool pt8 = mo->chain_lookback <= 128;
         const size_t psz = pt8 ? 1 : 2;
-        const int cap_big = BT_CAP_BIG;                 // anchor indices of a walk are kept as uint16
         static bool attr_set = false;
         if (!attr_set) {
             HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG));
@@ -1165,19 +1169,25 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             attr_set = true;
         }
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
-        if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(256), dim3(64), (size_t)cap_big * psz, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                                    mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap_big, (const int32_t*)(d_big + 1), (const int32_t*)d_big, d_btidx);
-        else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(256), dim3(64), (size_t)cap_big * psz, ctx->side[0], d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                                mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap_big, (const int32_t*)(d_big + 1), (const int32_t*)d_big, d_btidx);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0]));
+        for (int tier = 1; tier >= 0; --tier) {      // the largest queries first
+            hipStream_t s2 = ctx->side[tier];
+            const int cap = tier ? BT_CAP_BIG : BT_CAP_MID, grid = tier ? 512 : 1536;
+            const int32_t *lst = tier ? d_far : d_mid;
+            HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+            if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(grid), dim3(64), (size_t)cap * psz, s2, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                                        mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap, lst + 1, lst, d_btidx);
+            else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(grid), dim3(64), (size_t)cap * psz, s2, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
+                                    mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap, lst + 1, lst, d_btidx);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(ctx->ev_side[tier], s2));
+        }
         if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(nq), dim3(64), (size_t)BT_CAP * psz, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
                                     mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
         else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(nq), dim3(64), (size_t)BT_CAP * psz, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
                                 mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[0], 0));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[1], 0));
     }
     HIPCHK(hipGetLastError());
     int32_t *h_nch, *h_choff, *h_qaoff; ChainRec *h_rec;

@@ -4,7 +4,7 @@
 TELR_te.py:595-598 derive from `--presets {ont,pacbio}`; `asm10` is hard-wired in
 TELR_te.py:899 -> TELR_liftover.py:254-264.  Parameter values follow the minimap2 2.22
 manual as recorded in SURVEY.md 8(a) [recall]; `telr_preset()` in the C library returns
-the same numbers (tests/test_presets.py keeps them in lock-step).
+the same numbers (tests/test_abi.py keeps them in lock-step).
 """
 from ._abi import IdxOpt, MapOpt, MF_CIGAR
 

@@ -130,7 +130,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    step()      # set-up, not a warm-up step: the first call sizes the engine's grow-only scratch and pins the result buffer
+    step(); step()      # set-up, not warm-up steps: the first calls size the engine's grow-only scratch and pin the TWO
+                        # result buffers that are alive at any time when steps are streamed
     for _ in range(a.warmup):
         step()
     stage_tot = {}
@@ -175,14 +176,14 @@ def main():
         for line in open(os.path.join(ROOT, "profiles", path)):
             f = line.split()
             if line.startswith(kern) and counter in f:
-                return float(f[-2]) / 2.0
+                return float(f[-2]) / 3.0
         return None
     traffic, traffic_src = None, None
     try:   # HBM bytes per launch from the committed PMC passes of this same command (profiles/, separate --pmc runs)
         def _pmc(path, kern):
             for line in open(os.path.join(ROOT, "profiles", path)):
                 if line.startswith(kern):
-                    return float(line.split()[-2]) / 2.0     # sum over the PMC run's two map calls (set-up call + one step), per call
+                    return float(line.split()[-2]) / 3.0     # sum over the PMC run's three map calls (two set-up calls + one step), per call
             return None
         fs = _pmc("r01_pmc_FETCH_SIZE.txt", k_name + " "); ws = _pmc("r01_pmc_WRITE_SIZE.txt", k_name + " ")
         if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:

@@ -1792,7 +1792,6 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
     const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
     const bool packed = cls >= 5;
-    const uint8_t *tb = tb_all + P.tb_off;
     int i = res[pi].bi, j = res[pi].bj;
     uint32_t *cg = cig + P.cig_off;
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;

@@ -714,11 +714,6 @@ extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (i
 extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { result_wait(r); return r ? r->cig : nullptr; }
 extern "C" void telr_result_free(telr_result *r) { delete r; }
 
-static inline void cig_push(std::vector<uint32_t> &c, uint32_t op, uint32_t len)
-{
-    if (!len) return;
-    if (!c.empty() && (c.back() & 0xf) == op) c.back() += len << 4; else c.push_back(len << 4 | op);
-}
 
 // worker threads for the host phases: 1.5x the CPUs this process may actually use (cgroup v2 quota when
 // present: the MI355X box reports 256 hardware threads but runs under cpu.max = 16 CPUs), at most 48

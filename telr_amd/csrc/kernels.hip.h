@@ -89,6 +89,34 @@ struct SketchArgs {
     uint64_t *out_x; uint32_t *out_y;
 };
 
+// Is slot u (value x at xs[s]) a minimizer?  The run of slots with value >= x around u, both sides, capped at the sequence
+// ends, must reach `need` slots.  Every lane tests all `halo` neighbours (a lane that stops at its first smaller neighbour
+// would still wait for the wave's slowest lane); HALO > 0 = halo known at compile time, fully unrolled.
+template <int HALO, typename T>
+__device__ __forceinline__ bool d_mz_selected(const T *xs, int s, int u, int ns, int need, int halo, T x)
+{
+    int Lc, Rc;
+    if (HALO) {
+        int lf = HALO + 1, rf = HALO + 1;
+#pragma unroll
+        for (int t = HALO; t >= 1; --t) { if (xs[s - t] < x) lf = t; if (xs[s + t] < x) rf = t; }
+        const int lmax = u < HALO ? u : HALO, rmax = ns - 1 - u < HALO ? ns - 1 - u : HALO;
+        Lc = lf - 1 < lmax ? lf - 1 : lmax; Rc = rf - 1 < rmax ? rf - 1 : rmax;
+    } else if (halo <= 31) {
+        uint32_t lm = 0, rm = 0;
+        for (int t = 1; t <= halo; ++t) {
+            lm |= (uint32_t)(u - t >= 0 && xs[s - t] >= x) << (t - 1);
+            rm |= (uint32_t)(u + t < ns && xs[s + t] >= x) << (t - 1);
+        }
+        Lc = __ffs((int)~lm) - 1; Rc = __ffs((int)~rm) - 1;
+    } else {                                  // very wide windows: plain scans
+        Lc = 0; Rc = 0;
+        while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
+        while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
+    }
+    return Lc + Rc + 1 >= need;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
 {
@@ -125,12 +153,8 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch(SketchArgs A)
     for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
         int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
         uint64_t x = xs[s];
-        if (u < ns && x != UINT64_MAX) {
-            int Lc = 0, Rc = 0;
-            while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
-            while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
-            if (Lc + Rc + 1 >= need) sel |= 1u << c;
-        }
+        const bool is_mz = halo == 9 ? d_mz_selected<9, uint64_t>(xs, s, u, ns, need, halo, x) : d_mz_selected<0, uint64_t>(xs, s, u, ns, need, halo, x);
+        if (u < ns && x != UINT64_MAX && is_mz) sel |= 1u << c;
     }
     int cnt = __popc(sel);
     // block exclusive scan of cnt (wave scan + cross-wave in LDS)
@@ -209,25 +233,7 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
     for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
         int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
         uint32_t x = xs[s];
-        // run of slots with x >= x_u around u, both sides: every lane tests all `halo` neighbours (a lane that stops at
-        // its first smaller neighbour would still wait for the wave's slowest lane) and counts the leading ones
-        int Lc, Rc;
-        if (HALO) {
-            // first neighbour on each side that is smaller (or outside the sequence): distance - 1 = run length
-            int lf = HALO + 1, rf = HALO + 1;
-#pragma unroll
-            for (int t = HALO; t >= 1; --t) { if (xs[s - t] < x) lf = t; if (xs[s + t] < x) rf = t; }
-            const int lmax = u < HALO ? u : HALO, rmax = ns - 1 - u < HALO ? ns - 1 - u : HALO;
-            Lc = lf - 1 < lmax ? lf - 1 : lmax; Rc = rf - 1 < rmax ? rf - 1 : rmax;
-        } else {
-            uint32_t lm = 0, rm = 0;
-            for (int t = 1; t <= halo; ++t) {
-                lm |= (uint32_t)(u - t >= 0 && xs[s - t] >= x) << (t - 1);
-                rm |= (uint32_t)(u + t < ns && xs[s + t] >= x) << (t - 1);
-            }
-            Lc = __ffs((int)~lm) - 1; Rc = __ffs((int)~rm) - 1;
-        }
-        if (u < ns && x != 0xffffffffu && Lc + Rc + 1 >= need) sel |= 1u << c;
+        if (u < ns && x != 0xffffffffu && d_mz_selected<HALO, uint32_t>(xs, s, u, ns, need, halo, x)) sel |= 1u << c;
     }
     int cnt = __popc(sel);
     // block exclusive scan of cnt (wave scan + cross-wave in LDS)
@@ -373,12 +379,8 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_hpc(SketchHpcArgs A)
     for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
         int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = lo + s;
         uint64_t x = xs[s];
-        if (u < ns && x != UINT64_MAX) {
-            int Lc = 0, Rc = 0;
-            while (Lc < halo && u - Lc - 1 >= 0 && xs[s - Lc - 1] >= x) ++Lc;
-            while (Rc < halo && u + Rc + 1 < ns && xs[s + Rc + 1] >= x) ++Rc;
-            if (Lc + Rc + 1 >= need) sel |= 1u << c;
-        }
+        const bool is_mz = halo == 9 ? d_mz_selected<9, uint64_t>(xs, s, u, ns, need, halo, x) : d_mz_selected<0, uint64_t>(xs, s, u, ns, need, halo, x);
+        if (u < ns && x != UINT64_MAX && is_mz) sel |= 1u << c;
     }
     int cnt = __popc(sel);
     int lane = tid & 63, wv = tid >> 6, inc = cnt;

@@ -282,6 +282,25 @@ __device__ __forceinline__ int d_seq_of_chunk(const int64_t *__restrict__ boff, 
     return lo;
 }
 // one thread per 64-base chunk (sequences start on 64-base boundaries): run-start flags and their count
+// A 64-base chunk starts on a word boundary (sequences are padded to 64 bases): its 4 base words and 2 mask words are
+// loaded once; base x of the chunk = code (2 bits) or 4 when the mask bit is set.
+struct Chunk64 { uint32_t w[4]; uint32_t m[2]; };
+__device__ __forceinline__ Chunk64 d_chunk_load(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, int64_t b0)
+{
+    Chunk64 c;
+    const uint4 v = *(const uint4*)(seq2 + (b0 >> 4));
+    c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    const uint2 n = *(const uint2*)(nmask + (b0 >> 5));
+    c.m[0] = n.x; c.m[1] = n.y;
+    return c;
+}
+__device__ __forceinline__ int d_chunk_base(const Chunk64 &c, int x)
+{
+    const uint64_t lo = (uint64_t)c.w[1] << 32 | c.w[0], hi = (uint64_t)c.w[3] << 32 | c.w[2];
+    const uint64_t mm = (uint64_t)c.m[1] << 32 | c.m[0];
+    const int code = (int)(((x < 32 ? lo : hi) >> ((x & 31) * 2)) & 3u);
+    return ((mm >> x) & 1u) ? 4 : code;
+}
 __global__ void k_hpc_flags(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, const int64_t *__restrict__ boff,
                             const int32_t *__restrict__ len, int32_t sid0, int32_t nseq, int64_t chunk0, int32_t nchunk,
                             uint64_t *__restrict__ flags, int32_t *__restrict__ cnt)
@@ -293,29 +312,42 @@ __global__ void k_hpc_flags(const uint32_t *__restrict__ seq2, const uint32_t *_
     const int64_t sb = boff[sid];
     const int L = len[sid];
     const int p0 = (int)(b0 - sb);
+    const Chunk64 C = d_chunk_load(seq2, nmask, b0);
     uint64_t f = 0;
     int prev = p0 > 0 ? d_base(seq2, nmask, b0 - 1) : -1;
-    for (int x = 0; x < 64 && p0 + x < L; ++x) {
-        int cur = d_base(seq2, nmask, b0 + x);
+    const int nx = L - p0 < 64 ? L - p0 : 64;
+    for (int x = 0; x < nx; ++x) {
+        const int cur = d_chunk_base(C, x);
         if (cur != prev) f |= 1ULL << x;
         prev = cur;
     }
     flags[c] = f; cnt[c] = __popcll(f);
 }
-__global__ void k_hpc_scatter(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, const int64_t *__restrict__ boff,
-                              int32_t sid0, int32_t nseq, int64_t chunk0, int32_t nchunk, const uint64_t *__restrict__ flags,
-                              const int32_t *__restrict__ coff, uint8_t *__restrict__ hcode, uint32_t *__restrict__ hstart)
+// Runs of 128 chunks per block: every thread drops the runs of its chunk into LDS at their rank inside the block, then the
+// block writes codes and start positions out with consecutive threads on consecutive elements.
+__global__ void __launch_bounds__(128) k_hpc_scatter(const uint32_t *__restrict__ seq2, const uint32_t *__restrict__ nmask, const int64_t *__restrict__ boff,
+                                                     int32_t sid0, int32_t nseq, int64_t chunk0, int32_t nchunk, const uint64_t *__restrict__ flags,
+                                                     const int32_t *__restrict__ coff, uint8_t *__restrict__ hcode, uint32_t *__restrict__ hstart)
 {
+    __shared__ uint32_t s_start[128 * 64];
+    __shared__ uint8_t s_code[128 * 64];
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nchunk) return;
-    const int64_t b0 = (chunk0 + c) * 64;
-    const int sid = sid0 + d_seq_of_chunk(boff + sid0, nseq, b0);
-    const int p0 = (int)(b0 - boff[sid]);
-    uint64_t f = flags[c]; int o = coff[c];
-    while (f) {
-        int x = __ffsll((long long)f) - 1; f &= f - 1;
-        hcode[o] = (uint8_t)d_base(seq2, nmask, b0 + x); hstart[o] = (uint32_t)(p0 + x); ++o;
+    const int cfirst = blockIdx.x * blockDim.x, clast = cfirst + 128 < nchunk ? cfirst + 128 : nchunk;
+    const int o_first = coff[cfirst], o_end = coff[clast];
+    if (c < nchunk) {
+        const int64_t b0 = (chunk0 + c) * 64;
+        const int sid = sid0 + d_seq_of_chunk(boff + sid0, nseq, b0);
+        const int p0 = (int)(b0 - boff[sid]);
+        const Chunk64 C = d_chunk_load(seq2, nmask, b0);
+        uint64_t f = flags[c]; int o = coff[c] - o_first;
+        while (f) {
+            const int x = __ffsll((long long)f) - 1; f &= f - 1;
+            s_code[o] = (uint8_t)d_chunk_base(C, x); s_start[o] = (uint32_t)(p0 + x); ++o;
+        }
     }
+    __syncthreads();
+    const int n = o_end - o_first;
+    for (int z = threadIdx.x; z < n; z += 128) { hstart[o_first + z] = s_start[z]; hcode[o_first + z] = s_code[z]; }
 }
 // per sequence: offset / count of its runs = scan value at its first chunk
 __global__ void k_hpc_seq_offsets(const int64_t *__restrict__ boff, int32_t sid0, int32_t nseq, int64_t chunk0, const int32_t *__restrict__ coff,

@@ -453,7 +453,7 @@ static int build_hpc(telr_ctx *ctx, const telr_seqset *s, int32_t q0, int32_t q1
     TRY(ctx_buf_t(ctx, (P + "hpc_code").c_str(), (size_t)total + 64, &d_code));
     TRY(ctx_buf_t(ctx, (P + "hpc_start").c_str(), (size_t)total + 64, &d_start));
     if (nchunk > 0) {
-        hipLaunchKernelGGL(k_hpc_scatter, dim3((nchunk + 255) / 256), dim3(256), 0, ctx->stream, s->d_seq2, s->d_nmask, s->d_boff, q0, nseq, chunk0, nchunk, d_flags, d_coff, d_code, d_start);
+        hipLaunchKernelGGL(k_hpc_scatter, dim3((nchunk + 127) / 128), dim3(128), 0, ctx->stream, s->d_seq2, s->d_nmask, s->d_boff, q0, nseq, chunk0, nchunk, d_flags, d_coff, d_code, d_start);
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_hpc_seq_offsets, dim3((nseq + 256) / 256), dim3(256), 0, ctx->stream, s->d_boff, q0, nseq, chunk0, d_coff, nchunk, total, d_hoff);

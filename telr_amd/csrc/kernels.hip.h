@@ -379,6 +379,7 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_hpc(SketchHpcArgs A)
     uint64_t *xs = (uint64_t*)smem;
     uint32_t *ps = (uint32_t*)(xs + nslot);             // position<<1 | strand of each slot
     uint8_t *cb = (uint8_t*)(ps + nslot);               // run codes of the tile: nslot + k - 1 bytes
+    uint32_t *cw = (uint32_t*)(cb + ((nslot + k - 1 + 3) & ~3)), *cn = cw + (nslot + k - 1 + 15) / 16 + 3;
     __shared__ int32_t wsum[SK_THREADS / 64];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int sid = A.tile_seq[t], u0 = A.tile_u0[t];
@@ -387,12 +388,32 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_hpc(SketchHpcArgs A)
     const int lo = u0 - halo;
     for (int s = tid; s < nslot + k - 1; s += SK_THREADS) { int r = lo + s; cb[s] = (r >= 0 && r < nh) ? A.hcode[h0 + r] : 4; }
     __syncthreads();
+    // 2-bit packed copy of the codes + ambiguity bits (k-mers are then two shifts instead of a loop over k bytes)
+    const int ncode = nslot + k - 1;
+    for (int wq = tid; wq < (ncode + 15) / 16 + 3; wq += SK_THREADS) {
+        uint32_t v = 0;
+        for (int z = 0; z < 16; ++z) { const int q = wq * 16 + z; if (q < ncode) v |= (uint32_t)(cb[q] & 3) << (2 * z); }
+        cw[wq] = v;
+    }
+    for (int wq = tid; wq < (ncode + 31) / 32 + 2; wq += SK_THREADS) {
+        uint32_t v = 0;
+        for (int z = 0; z < 32; ++z) { const int q = wq * 32 + z; if (q >= ncode || cb[q] > 3) v |= 1u << z; }
+        cn[wq] = v;
+    }
+    __syncthreads();
     for (int s = tid; s < nslot; s += SK_THREADS) {
         const int u = lo + s;
         uint64_t x = UINT64_MAX; uint32_t pz = 0;
         if (u >= 0 && u < ns) {
-            uint64_t fw = 0, rv = 0; bool ok = true;
-            for (int z = 0; z < k; ++z) { int c = cb[s + z]; ok &= c < 4; fw = (fw << 2 | (uint64_t)(c & 3)) & mask; rv = (rv >> 2) | (uint64_t)(3 ^ (c & 3)) << (2 * (k - 1)); }
+            // k run codes from the 2-bit packed copy (first run in the low bits), as the plain sketch reads bases
+            const int wi = s >> 4, sh = (s & 15) * 2;
+            const uint64_t lo64 = (uint64_t)cw[wi] | (uint64_t)cw[wi + 1] << 32, hi64 = cw[wi + 2];
+            uint64_t v = lo64 >> sh;
+            if (sh) v |= hi64 << (64 - sh);
+            v &= mask;
+            const uint64_t nb = (((uint64_t)cn[s >> 5] | (uint64_t)cn[(s >> 5) + 1] << 32) >> (s & 31)) & ((1ULL << k) - 1);
+            const bool ok = nb == 0;
+            const uint64_t fw = d_rev2(v, k), rv = (~v) & mask;
             const uint32_t first = A.hstart[h0 + u];
             const uint32_t last = (u + k < nh ? A.hstart[h0 + u + k] : (uint32_t)L) - 1;     // last base of run u+k-1
             const uint32_t span = last - first + 1;

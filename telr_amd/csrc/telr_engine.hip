@@ -403,7 +403,7 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     SketchHpcArgs H;
     if (hpc) { H = *hpc; H.tile_seq = d_tseq; H.tile_u0 = d_tu0; H.k = k; H.w = w; H.tile_cnt = d_tcnt; H.tile_off = nullptr; H.out_x = nullptr; H.out_y = nullptr; }
     const int nslot = SK_TILE + 2 * (w - 1);
-    size_t lds = hpc ? (size_t)nslot * 12 + (size_t)(nslot + k) + 32 : (size_t)nslot * 9 + 16;
+    size_t lds = hpc ? (size_t)nslot * 12 + (size_t)(nslot + k) + 32 + (size_t)((nslot + k) / 16 + 8) * 4 + (size_t)((nslot + k) / 32 + 8) * 4 : (size_t)nslot * 9 + 16;
     // single pass: every tile writes its minimizers into its own staging slots and its count; after the scan
     // of the counts a compaction copy packs them (one hash pass instead of a count pass + a write pass)
     uint64_t *d_sx; uint32_t *d_sy;

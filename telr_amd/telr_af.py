@@ -121,13 +121,15 @@ def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_inte
         for r in reads_by_locus[n]:
             queries.append(r)
             qtarget_fw.append(tindex[n]); qtarget_rc.append(tindex[n] + 1)
-    qs = read_set.subset(queries) if read_set is not None else engine.seqset(queries)
+    # ONE engine call for both orientations: every read appears twice, once confined to the forward contig of its locus
+    # and once to the reverse-complement contig (the reference runs two minimap2 jobs per locus, TELR_te.py:644-646)
+    qs = read_set.subset(list(queries) + list(queries)) if read_set is not None else engine.seqset(list(queries) + list(queries))
     out = {}
-    meds = {n: {} for n in names}
-    for tag, qt in (("fw", qtarget_fw), ("rc", qtarget_rc)):
-        r = ix.map_raw(qs, mo, qtarget=np.array(qt, np.int32))
-        try:
-            iv_t, iv_s, iv_e, slots = [], [], [], []
+    meds = {n: {"fw": [None, None, None, None], "rc": [None, None, None, None]} for n in names}
+    r = ix.map_raw(qs, mo, qtarget=np.array(qtarget_fw + qtarget_rc, np.int32))
+    try:
+        iv_t, iv_s, iv_e, slots = [], [], [], []
+        for tag in ("fw", "rc"):
             for n in names:
                 L = len(contigs[n])
                 ivs = locus_intervals(contig_te[n][0], contig_te[n][1], L, flank_interval, flank_offset, te_interval, te_offset)[tag]
@@ -135,14 +137,12 @@ def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_inte
                     if x is None:
                         continue
                     a, b = depth_region(*x)
-                    iv_t.append(tindex[n] + (1 if tag == "rc" else 0)); iv_s.append(a); iv_e.append(b); slots.append((n, k))
-            med = ix.depth_medians(r, iv_t, iv_s, iv_e) if iv_t else []
-            for n in names:
-                meds[n][tag] = [None, None, None, None]
-            for (n, k), v in zip(slots, med):
-                meds[n][tag][k] = None if np.isnan(v) else float(v)
-        finally:
-            ix.free_raw(r)
+                    iv_t.append(tindex[n] + (1 if tag == "rc" else 0)); iv_s.append(a); iv_e.append(b); slots.append((n, tag, k))
+        med = ix.depth_medians(r, iv_t, iv_s, iv_e) if iv_t else []
+        for (n, tag, k), v in zip(slots, med):
+            meds[n][tag][k] = None if np.isnan(v) else float(v)
+    finally:
+        ix.free_raw(r)
     for n in names:
         out[n] = freq_table(meds[n])
     return out

@@ -233,7 +233,7 @@ def main():
         lib_names = ["fam%d" % i for i in range(len(d["library"]))]
         lib = [bytes(x).decode() for x in d["library"]]
         # window reads are taken from the stage-1 read set already on the device (telr_seqset_subset)
-        locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci[:8], lib_names, lib, read_set=qs)      # warm-up
+        locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib, read_set=qs)      # warm-up (sizes the scratch)
         t0 = time.time()
         lres = locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib, read_set=qs)
         t_loci = time.time() - t0

@@ -1823,6 +1823,13 @@ __global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
     __builtin_amdgcn_s_setprio(3);
     d_dp_pkr<PKX_LPP, PKX_R, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX_LPP));
 }
+// the same class with sixteen lanes per problem (same trace-back layout): a quarter of the work per lane and step, for
+// calls with few extensions, where the longest window is what the caller waits for
+__global__ void __launch_bounds__(64) k_dp_pkx16(DpArgs A)
+{
+    __builtin_amdgcn_s_setprio(3);
+    d_dp_pkr<16, 1, true>(A, A.list, A.nlist, blockIdx.x * 4);
+}
 
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
 // run-length CIGAR in end->start order (64 independent pointer chases per wave).

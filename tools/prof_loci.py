@@ -20,3 +20,5 @@ locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_name
 pr.disable()
 print("loci", len(loci), "seconds", time.time() - t0)
 pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+print("stages of the last engine call (AF realignment):", {k: round(v, 2) for k, v in eng.stage_ms().items() if v > 0.01})
+print("counters:", eng.counters())

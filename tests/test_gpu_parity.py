@@ -404,6 +404,29 @@ def test_concurrent_subbatches(engine):
     assert len(res3.alns) >= 44
 
 
+def test_int32_and_lds_fallback_kernels(engine):
+    """The packed int16 kernels take a problem only while its scores provably fit and its windows hold no N; everything
+    else runs on the int32 register kernels and the LDS kernel.  Force that path for all problems (TELR_NO_PK /
+    TELR_NO_PKEXT) and, separately, put Ns into extension and fill windows: results must not change."""
+    import os
+    rng = np.random.default_rng(4242)
+    genome = [synth.random_seq(rng, 140000)]
+    reads, _ = synth.simulate_reads(rng, genome, 36, 4000)
+    for i in (2, 9, 17):                                 # Ns inside the end windows and in the middle of some reads
+        reads[i][8:14] = ord("N"); reads[i][-15:-9] = ord("N"); reads[i][len(reads[i]) // 2:len(reads[i]) // 2 + 3] = ord("N")
+    genome[0][50000:50010] = ord("N")
+    io, mo = preset("map-ont")
+    base, _ = compare_all(engine, genome, reads, io, mo, stages=False)
+    os.environ["TELR_NO_PK"] = "1"; os.environ["TELR_NO_PKEXT"] = "1"
+    try:
+        alt, _ = compare_all(engine, genome, reads, io, mo, stages=False)
+    finally:
+        del os.environ["TELR_NO_PK"]; del os.environ["TELR_NO_PKEXT"]
+    assert len(base.alns) == len(alt.alns) >= 30
+    for f in ALN_FIELDS:
+        np.testing.assert_array_equal(base.alns[f], alt.alns[f], err_msg=f)
+
+
 def test_long_read_lane(engine):
     """Large calls map their few longest reads as a separate small batch on a worker context, concurrently with the
     rest; the merged result must be identical to the single-batch result (forced here on a small input), with and

@@ -1630,6 +1630,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
         int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
         if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
+        if (const char *e = getenv("TELR_BATCH_KBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 10; }     // tests
         int32_t q0 = 0;
         while (q0 < nq) {
             int32_t q1 = q0; int64_t b = 0;

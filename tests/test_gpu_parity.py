@@ -427,6 +427,22 @@ def test_int32_and_lds_fallback_kernels(engine):
         np.testing.assert_array_equal(base.alns[f], alt.alns[f], err_msg=f)
 
 
+def test_several_batches_per_call(engine):
+    """A call with more read bases than one batch holds (1 Gbp by default; forced small here) runs batch after batch and
+    appends to one result: records and CIGARs must equal the single-batch result."""
+    import os
+    rng = np.random.default_rng(31337)
+    genome = [synth.random_seq(rng, 110000)]
+    reads, _ = synth.simulate_reads(rng, genome, 48, 4000)
+    io, mo = preset("map-ont")
+    os.environ["TELR_BATCH_KBP"] = "40"          # about five batches
+    try:
+        res, _ = compare_all(engine, genome, reads, io, mo, stages=False)
+    finally:
+        del os.environ["TELR_BATCH_KBP"]
+    assert len(res.alns) >= 45
+
+
 def test_long_read_lane(engine):
     """Large calls map their few longest reads as a separate small batch on a worker context, concurrently with the
     rest; the merged result must be identical to the single-batch result (forced here on a small input), with and

@@ -49,3 +49,40 @@ def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names
     fam_ids = {n: i for i, n in enumerate(lib_names)}
     rows = shard.rows_from_reports(ids, reps, freqs, chrom_ids, fam_ids)
     return shard.all_gather_rows(rows, dist, device), res
+
+
+def write_outputs(res, loci, out_dir, sample_name, ref_fasta, sv_info=None, today=None):
+    """Final artefacts of a run (`<sample>.telr.{json,expanded.json,te.fasta,contig.fasta,vcf,bed}`) from the in-memory
+    results of `run_loci`, through the mirror of the reference's writer (telr_output.generate_output; the reference
+    passes the same things as files between stages, TELR_output.py:10-20).
+
+    loci: the dicts given to run_loci (name "<chr>_<start>_<end>", contig);  sv_info: {locus name: (genotype, ref_count,
+    alt_count)} from the SV caller's table (columns 10-12 of `<sample>.vcf_filtered.tsv`), default ("./.", "0", number of
+    window reads);  ref_fasta: path of the reference FASTA (its .fai gives the ##contig lines, written when absent).
+    Returns (final_report, final_report_expanded)."""
+    import os
+    from . import telr_output
+    inter = os.path.join(out_dir, "intermediate_files")
+    os.makedirs(inter, exist_ok=True)
+    contigs = {l["name"]: l["contig"] for l in loci}
+    contig_fa = os.path.join(inter, sample_name + ".contigs.fa")
+    with open(contig_fa, "w") as fh:                      # header carries len= as the reference's merged contig file does
+        for l in loci:
+            n_reads = len(l.get("read_idx", l.get("reads", [])))
+            fh.write(">%s len=%d reads=%d\n%s\n" % (l["name"], len(l["contig"]), n_reads, l["contig"]))
+    ann_bed = os.path.join(inter, sample_name + ".te2contig_filtered.bed")
+    te_fa = os.path.join(inter, sample_name + ".te.fa")
+    with open(ann_bed, "w") as fb, open(te_fa, "w") as ft:
+        for r in res["annotation"]:
+            fb.write("\t".join(str(x) for x in r[:6]) + "\n")
+            s, e = int(r[1]), int(r[2])
+            ft.write(">%s:%d-%d\n%s\n" % (r[0], s, e, contigs[r[0]][s:e]))
+    vcf_parsed = os.path.join(inter, sample_name + ".vcf_filtered.tsv")
+    with open(vcf_parsed, "w") as fh:
+        for l in loci:
+            chrom, start, end = l["name"].rsplit("_", 2)
+            n_reads = len(l.get("read_idx", l.get("reads", [])))
+            gt, dr, dv = (sv_info or {}).get(l["name"], ("./.", "0", str(n_reads)))
+            row = [chrom, start, end, str(len(l.get("alt", ""))), str(n_reads), "NA", l["name"], l.get("alt", ""), "NA", "PASS", gt, str(dr), str(dv), "NA"]
+            fh.write("\t".join(row) + "\n")
+    return telr_output.generate_output(res["liftover"], res["af"], te_fa, vcf_parsed, ann_bed, contig_fa, out_dir, sample_name, ref_fasta, today=today)

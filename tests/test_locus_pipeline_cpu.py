@@ -19,3 +19,29 @@ def test_locus_bundle_on_oracle_recovers_truth():
     res = locus_pipeline.run_loci(be, be.index([ref], io), ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
     check_truth(res, loci, truth)
     assert len(res["annotation"]) >= 3
+
+
+def test_bundle_to_output_files(tmp_path):
+    """run_loci -> write_outputs: the six result files of a TELR run come out of the in-memory results, one VCF/BED row
+    and one TE sequence per non-reference insertion, coordinates as in the liftover report."""
+    from oracle_backend import OracleBackend
+    from locus_data import make_loci
+    ref, lib_names, lib, loci, truth = make_loci(n_ins=4, reads_per_locus=20)
+    be = OracleBackend()
+    io, _ = preset("asm10")
+    res = locus_pipeline.run_loci(be, be.index([ref], io), ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
+    ref_fa = tmp_path / "ref.fa"
+    ref_fa.write_text(">chr2L\n" + "\n".join(ref[i:i + 60] for i in range(0, len(ref), 60)) + "\n")
+    final, expanded = locus_pipeline.write_outputs(res, loci, str(tmp_path), "s", str(ref_fa), today="DATE")
+    nonref = [r for r in res["liftover"] if r["report"]["type"] == "non-reference"]
+    assert len(final) == len(nonref) >= 3
+    vcf = (tmp_path / "s.telr.vcf").read_text().splitlines()
+    body = [l for l in vcf if not l.startswith("#")]
+    assert "##contig=<ID=chr2L,length=%d>" % len(ref) in vcf and len(body) == len(final)
+    bed = (tmp_path / "s.telr.bed").read_text().splitlines()
+    for row, rep in zip(bed, final):
+        f = row.split("\t")
+        assert f[0] == "chr2L" and int(f[1]) == rep["start"] and int(f[2]) == rep["end"] and f[3] == rep["family"] and f[5] == rep["strand"]
+    te = (tmp_path / "s.telr.te.fasta").read_text().count(">")
+    assert te == len(final) and (tmp_path / "s.telr.json").exists() and (tmp_path / "s.telr.expanded.json").exists()
+    assert all(r["te_length"] == len(r["te_sequence"]) for r in expanded)

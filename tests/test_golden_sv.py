@@ -38,3 +38,60 @@ def test_small_helpers():
         assert sorted(S.id_merge(v).split(",")) == e
     assert S.get_unique_list(["b", "a", "b"]) == ["b", "a"]
     assert len(S.COLUMNS) == 14
+
+
+def _write(path, rows):
+    path.write_text("".join("\t".join(r) + "\n" for r in rows))
+
+
+def test_swap_coordinate(tmp_path):
+    _write(tmp_path / "raw.tsv", G["parsed"])
+    S.swap_coordinate(str(tmp_path / "raw.tsv"), str(tmp_path / "swap.tsv"))
+    assert [l.split("\t") for l in (tmp_path / "swap.tsv").read_text().splitlines()] == G["swapped"]
+
+
+def _same_but_read_order(got_text, want_text, reads_col=8):
+    got = [l.split("\t") for l in got_text.splitlines()]
+    want = [l.split("\t") for l in want_text.splitlines()]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[:reads_col] == w[:reads_col] and g[reads_col + 1:] == w[reads_col + 1:]
+        assert sorted(g[reads_col].split(",")) == sorted(w[reads_col].split(","))   # set order in the reference
+
+
+def test_rm_vcf_redundancy_matches_pandas_groupby(tmp_path):
+    _write(tmp_path / "swap.tsv", G["swapped"])
+    S.rm_vcf_redundancy(str(tmp_path / "swap.tsv"), str(tmp_path / "dedup.tsv"))
+    _same_but_read_order((tmp_path / "dedup.tsv").read_text(), G["dedup_text"])
+
+
+def test_rm_vcf_redundancy_all_capped_af_prints_integer(tmp_path):
+    rows = [["c", "1", "2", "5", "1", "0.9", "a", "AC", "r1", "PASS", "0/1", "1", "1"],
+            ["c", "1", "2", "5", "1", "0.8", "b", "AC", "r2", "PASS", "0/1", "1", "1"]]
+    out = S.dedup_rows(rows)
+    assert out == [["c", 1, 2, 5, 2, 1, "a", "AC", "r1,r2", "PASS", "0/1", 2, 2]]
+
+
+def test_gff_screen_and_proportions(tmp_path):
+    gff = tmp_path / "x.out.gff"
+    gff.write_text("##gff-version 2\n" + "".join(
+        "\t".join([sid, "RepeatMasker", "similarity", str(s), str(e), "12.3", st, ".", 'Target "Motif:%s" 1 %d' % (fam, e - s + 1)]) + "\n"
+        for sid, s, e, st, fam in G["rm_gff"]))
+    assert S.gff_screen(str(gff)) == G["rm_merged_bed"]
+
+
+def test_filter_vcf_table_side(tmp_path):
+    ins = tmp_path / "dedup.tsv"
+    ins.write_text(G["dedup_text"])
+    ev = tmp_path / "eval.tsv"
+    ev.write_text("")
+    out = tmp_path / "o"
+    out.mkdir()
+    S.filter_vcf(str(ins), str(tmp_path / "filt.tsv"), "lib.fa", str(out), "s+1", 2, str(ev),
+                 screen=lambda fa, lib, t: [list(m) for m in G["rm_merged_bed"]])
+    assert (tmp_path / "filt.tsv").read_text() == G["filtered_text"]          # incl. the 0.5800000000000001 float sum
+    assert sorted(ev.read_text().splitlines()) == G["filter_eval"]
+    assert (out / "splus1.vcf_ins.fasta").read_text() == G["ins_fasta"]
+    import pytest
+    with pytest.raises(ValueError):
+        S.filter_vcf(str(ins), str(tmp_path / "f2.tsv"), "lib.fa", str(out), "s", 2, str(ev))

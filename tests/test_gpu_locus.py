@@ -66,3 +66,42 @@ def test_locus_bundle_with_resident_read_set(engine):
     a = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
     b = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci_idx, lib_names, lib, presets="ont", read_set=read_set)
     assert a["af"] == b["af"] and a["liftover"] == b["liftover"] and a["annotation"] == b["annotation"]
+
+
+def test_engine_screen_of_alt_sequences(engine, tmp_path):
+    """filter_vcf with the engine as the TE screen (opt-in): ALT sequences that carry a diverged
+    TE copy pass with the covered proportion, a random ALT sequence is reported, and the HIP engine and the oracle
+    give the same table."""
+    from oracle_backend import OracleBackend
+    from telr_amd import telr_sv as S
+    rng = np.random.default_rng(77)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    def mutate(s, rate):
+        b = list(s)
+        for i in np.nonzero(rng.random(len(b)) < rate)[0]:
+            b[i] = "ACGT"[("ACGT".index(b[i]) + 1 + int(rng.integers(0, 3))) % 4]
+        return "".join(b)
+    lib = {"famA": rnd(3000), "famB": rnd(1200), "famC": rnd(600)}
+    (tmp_path / "lib.fa").write_text("".join(">%s\n%s\n" % kv for kv in lib.items()))
+    alts = [rnd(40) + mutate(lib["famA"], 0.04) + rnd(60),            # whole family A inside
+            rnd(900),                                                   # nothing
+            mutate(lib["famB"][200:1100], 0.05),                        # a fragment of B, nothing else
+            rnd(300) + mutate(lib["famC"], 0.03) + rnd(500) + mutate(lib["famA"][:1500], 0.03)]   # two separate pieces
+    rows = [["chr2L", str(1000 * (i + 1)), str(1000 * (i + 1) + 1), str(len(a)), "5", "0.5", str(i), a, "r%d" % i, "PASS", "0/1", "3", "5"]
+            for i, a in enumerate(alts)]
+    ins = tmp_path / "ins.tsv"
+    ins.write_text("".join("\t".join(r) + "\n" for r in rows))
+    texts = {}
+    for tag, be in (("hip", engine), ("oracle", OracleBackend())):
+        out = tmp_path / tag
+        out.mkdir()
+        ev = out / "eval.tsv"
+        ev.write_text("")
+        S.filter_vcf(str(ins), str(out / "filt.tsv"), str(tmp_path / "lib.fa"), str(out), "s", 1, str(ev), screen=S.engine_screen(be))
+        texts[tag] = ((out / "filt.tsv").read_text(), ev.read_text())
+    assert texts["hip"] == texts["oracle"]
+    kept = {l.split("\t")[1]: float(l.split("\t")[13]) for l in texts["hip"][0].splitlines()}
+    assert set(kept) == {"1000", "3000", "4000"}
+    assert 0.9 <= kept["1000"] <= 1.0 and kept["3000"] >= 0.9 and 0.6 <= kept["4000"] <= 0.75
+    assert texts["hip"][1] == "chr2L_2000_2001\tVCF sequence not repeatmasked\n"

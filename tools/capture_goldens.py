@@ -376,9 +376,85 @@ def capture_sv(S, U):
         loci = sorted(U.create_loci_set(vout))
     finally:
         shutil.rmtree(tmp)
-    return {"table": table, "bedtools_merge": inter, "merged": out, "loci": loci,
+    extra = capture_sv_table(S, U)
+    return {"table": table, "bedtools_merge": inter, "merged": out, "loci": loci, **extra,
             "af_sum": [[v, S.af_sum(list(v))] for v in ([0.4, 0.5], [0.6, 0.5], [1.0], [0.2, 0.3, 0.6])],
             "id_merge": [[v, sorted(S.id_merge(v).split(","))] for v in (["a,b", "b,c"], ["x"], ["r1,r1", "r1"])]}
+
+
+def capture_sv_table(S, U):
+    """swap_coordinate (TELR_sv.py:183-190), rm_vcf_redundancy (:193-228, pandas groupby) and the table side of filter_vcf
+    (:231-324): RepeatMasker is replaced by a canned GFF, `bedtools sort` / `bedtools merge` on that GFF by telr_amd.intervals
+    semantics (GFF is 1-based inclusive; merge prints 0-based starts and joins book-ended features)."""
+    parsed = [   # 13 columns, as `bcftools query` prints them (leading blanks in the per-sample fields)
+        ["chr2L", "1200", "1100", "310", "9", "0.45", "3", "ACGTACGTAAACGTACGTAA", "r1,r2", "PASS", " 0/1", " 11", " 9"],
+        ["chr2L", "1100", "1200", "305", "4", "0.7", "4", "ACGTACGTAAACGTACGTAAACGT", "r2,r5", "PASS", " 0/1", " 3", " 4"],
+        ["chr2L", "90", "91", "77", "2", "0.2", "1", "ACGTACGTTT", "r7", "PASS", " 0/0", " 8", " 2"],
+        ["chrX", "500", "500", "1000", "6", "0.3", "9", "ACGTACGTAAACGTACGTAAACGTACGTAAACGTACGTAA", "r8,r9,r8", "PASS", " 1/1", " 0", " 6"],
+        ["chrX", "500", "500", "990", "5", "0.3", "10", "ACGT", "r9,r10", "PASS", " 1/1", " 1", " 5"],
+        ["chr3R", "7", "8", "120", "3", "1.0", "12", "ACGTACGTAAACGTACGTAAACGTACGTAAAC", "r11", "PASS", " 1/1", " 0", " 3"],
+    ]
+    gff = [  # seqid, start (1-based), end, strand, family
+        ("chr2L_1100_1200", 1, 5, "+", "jockey"), ("chr2L_1100_1200", 4, 8, "-", "roo"), ("chr2L_1100_1200", 9, 12, "+", "roo"),
+        ("chr2L_1100_1200", 15, 16, "+", "copia"),
+        ("chrX_500_500", 3, 6, "+", "jockey"), ("chrX_500_500", 11, 18, "+", "jockey"), ("chrX_500_500", 30, 40, "-", "gypsy"),
+        ("chr3R_7_8", 2, 32, "+", "412"),
+    ]
+    tmp = tempfile.mkdtemp(prefix="gold_")
+    try:
+        raw, swp, dedup = (os.path.join(tmp, n) for n in ("raw.tsv", "swap.tsv", "dedup.tsv"))
+        open(raw, "w").write("".join("\t".join(r) + "\n" for r in parsed))
+        S.swap_coordinate(raw, swp)
+        swapped = [l.split("\t") for l in open(swp).read().splitlines()]
+        S.rm_vcf_redundancy(swp, dedup)
+        dedup_text = open(dedup).read()
+
+        merged_bed = []
+
+        def fake_call(cmd, stdout=None, **kw):
+            tool = os.path.basename(cmd[0])
+            if tool == "RepeatMasker":
+                d = cmd[cmd.index("-dir") + 1]
+                with open(os.path.join(d, os.path.basename(cmd[-1]) + ".out.gff"), "w") as f:
+                    f.write("##gff-version 2\n")
+                    for (sid, s, e, st, fam) in gff:
+                        f.write("\t".join([sid, "RepeatMasker", "similarity", str(s), str(e), "12.3", st, ".",
+                                           'Target "Motif:%s" 1 %d' % (fam, e - s + 1)]) + "\n")
+                return 0
+            if tool == "bedtools" and cmd[1] == "sort":
+                rows = [l.rstrip("\n").split("\t") for l in open(cmd[cmd.index("-i") + 1]) if not l.startswith("#")]
+                rows.sort(key=lambda r: (r[0], int(r[3])))
+                stdout.write("".join("\t".join(r) + "\n" for r in rows))
+                return 0
+            if tool == "bedtools" and cmd[1] == "merge":
+                rows = [l.rstrip("\n").split("\t") for l in open(cmd[cmd.index("-i") + 1])]
+                cur = None
+                for r in rows:
+                    s0, e = int(r[3]) - 1, int(r[4])
+                    if cur is not None and cur[0] == r[0] and s0 <= cur[2]:
+                        cur[2] = max(cur[2], e)
+                    else:
+                        if cur is not None:
+                            merged_bed.append(list(cur))
+                        cur = [r[0], s0, e]
+                if cur is not None:
+                    merged_bed.append(list(cur))
+                stdout.write("".join("%s\t%d\t%d\n" % tuple(m) for m in merged_bed))
+                return 0
+            raise AssertionError(cmd)
+        S.subprocess = types.SimpleNamespace(call=fake_call)
+        S.SeqIO = _fake_seqio()
+        out = os.path.join(tmp, "o"); os.mkdir(out)
+        filt, ev = os.path.join(tmp, "filt.tsv"), os.path.join(tmp, "eval.tsv")
+        open(ev, "w").write("")
+        S.filter_vcf(dedup, filt, "lib.fa", out, "s+1", 2, ev)
+        filtered_text = open(filt).read()
+        eval_rows = sorted(open(ev).read().splitlines())
+        ins_fa = open(os.path.join(out, "splus1.vcf_ins.fasta")).read()
+    finally:
+        shutil.rmtree(tmp)
+    return {"parsed": parsed, "swapped": swapped, "dedup_text": dedup_text, "rm_gff": [list(g) for g in gff],
+            "rm_merged_bed": merged_bed, "filtered_text": filtered_text, "filter_eval": eval_rows, "ins_fasta": ins_fa}
 
 
 class _Seq(str):

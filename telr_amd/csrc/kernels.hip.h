@@ -603,26 +603,39 @@ __device__ __forceinline__ uint64_t d_readlane64(uint64_t v, int lane)
     return (uint64_t)hi << 32 | lo;
 }
 
-// One link score in the chaining loop, own anchor (gi, qi, sp) <- broadcast anchor (gj, qj).  The oracle's chain_sc(),
-// in few instructions: the strand sits in bit 31 of the reference word, so a strand mismatch fails the unsigned range test of dr;
-// |dr-dq| is one v_sad_u32; the integer log2 is a normalising shift ((v << clz) >> 23 holds 256 + fraction).
-__device__ __forceinline__ bool d_chain_link(uint32_t gi, int32_t qi, int32_t sp, uint32_t gj, int32_t qj, const ChainOpt &o, int32_t &sc)
+// One link in the chaining loop: own anchor (gi, qi, span-1) <- broadcast anchor j (gj+1, qj+1, 2 f_j + 2).  The oracle's
+// chain_sc() plus the max/tie rule in ~19 instructions:
+//  * the strand sits in bit 31 of the reference word, so a strand mismatch fails the unsigned range test of dr;
+//  * dr-1 and dq-1 come straight from the subtraction (the +1 is added to the broadcast scalars), so 0 < d <= max_gap is
+//    one unsigned compare d-1 < max_gap, and "dd <= bw" joins the same compare as dd + (max_gap-1-bw) (it is implied when
+//    bw >= max_gap): ok = max3(dr-1, dq-1, dd + ddc) < max_gap;  |dr-dq| is one v_sad_u32;  min(span, dr, dq) one v_min3;
+//  * the Q8 integer log2 of dd+1 is read off the float conversion (exact below 2^24): bits >> 15 = (127 + e) << 8 | the top
+//    8 mantissa bits, so ilog2_q8 >> 1 = (bits >> 16) - 16256; the products fit 24 bits whenever the link is allowed;
+//  * the running maximum is kept as B = 2 best + (1 while no predecessor was taken), which turns "larger, or equal and the
+//    current best already has a predecessor" (ascending j, the largest j wins ties) into the single compare 2 v >= B.
+// With chain_skip_q8 == 0 (every preset) the oracle's "dd || dg > span" condition is moot (the penalty is 0 when dd == 0).
+template <bool SKIP>
+__device__ __forceinline__ void d_chain_push(uint32_t gi, uint32_t qi, uint32_t sp1, uint32_t gj1, uint32_t qj1, int32_t fj2p2, int32_t j,
+                                             uint32_t max_gap, uint32_t ddc, uint32_t gap_q8, uint32_t skip_q8, int32_t &B, int32_t &bp)
 {
-    const uint32_t dr = gi - gj, dq = (uint32_t)(qi - qj);
+    const uint32_t dr1 = gi - gj1, dq1 = qi - qj1;
     uint32_t dd;
-    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dd) : "v"(dr), "v"(dq));
-    const bool ok = dr - 1u < (uint32_t)o.max_gap && dq - 1u < (uint32_t)o.max_gap && dd <= (uint32_t)o.bw;
-    const uint32_t dg = dr < dq ? dr : dq;
-    int32_t v = (int32_t)((uint32_t)sp < dg ? (uint32_t)sp : dg);
-    const uint32_t x = dd + 1u; const int lz = __clz((int)x);
-    const int32_t l2 = ((30 - lz) << 8) + (int32_t)((x << lz) >> 23);
-    const int32_t pen = o.chain_gap_q8 * (int32_t)dd + o.chain_skip_q8 * (int32_t)dg + (l2 >> 1);
-    if (dd != 0u || dg > (uint32_t)sp) v -= pen >> 8;
-    sc = v;
-    return ok;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dd) : "v"(dr1), "v"(dq1));
+    const uint32_t dgm = dr1 < dq1 ? dr1 : dq1;
+    const uint32_t vm = sp1 < dgm ? sp1 : dgm;                                  // min(span, dg) - 1
+    uint32_t t = dr1 > dq1 ? dr1 : dq1; const uint32_t u = dd + ddc; t = t > u ? t : u;
+    const bool ok = t < max_gap;
+    const uint32_t l2h = __float_as_uint((float)(dd + 1u)) >> 16;              // ilog2_q8(dd+1)/2 + 16256
+    int32_t pen = (int32_t)(__umul24(gap_q8, dd) + l2h) - 16256;
+    if (SKIP) {
+        pen += (int32_t)__umul24(skip_q8, dgm + 1u);
+        if (dd == 0u && dgm <= sp1) pen = 0;
+    }
+    const int32_t v2 = (((int32_t)vm - (pen >> 8)) << 1) + fj2p2;
+    if (ok && v2 >= B) { B = v2; bp = j; }
 }
 
-template <int R>
+template <int R, bool SKIP>
 __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
                                               ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
 {
@@ -632,44 +645,44 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
     const int64_t base = q_aoff[q];
     const int n = q_aoff[q + 1] - q_aoff[q];
     const uint64_t *a = keys + base;
-    uint64_t key[R]; int32_t best[R], bp[R];
-    uint32_t gi[R]; int32_t qi[R], sp[R];            // fields of key[r]: reference word (strand in bit 31), query position, span
+    const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
+    const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
+    // fields of the anchors this lane owns: reference word (strand in bit 31), query position, span - 1, and the DP state.
+    // An empty slot (key 0) has qi = 0, which fails the range test of dq against every j.
+    uint32_t gi[R], qi[R], sp1[R]; int32_t B[R], bp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        int i = r * 64 + lane;
-        key[r] = i < n ? a[i] : 0; best[r] = A_SPAN(key[r]); bp[r] = -1;
-        gi[r] = (uint32_t)(key[r] >> 32); qi[r] = A_Q(key[r]); sp[r] = A_SPAN(key[r]);
+        const int i = r * 64 + lane;
+        const uint64_t k = i < n ? a[i] : 0;
+        gi[r] = (uint32_t)(k >> 32); qi[r] = (uint32_t)A_Q(k); sp1[r] = (uint32_t)A_SPAN(k) - 1u; B[r] = 2 * A_SPAN(k) + 1; bp[r] = -1;
     }
     for (int jb = 0; jb < n; jb += 64 * R) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int j0 = jb + r * 64;
             if (j0 >= n) break;
-            // prefetch the key that replaces this slot once its anchor is final
+            // the anchor that replaces this slot once its own is final
             const int inext = j0 + 64 * R + lane;
             const uint64_t knext = inext < n ? a[inext] : 0;
-            int32_t myf = 0, myp = -1;
+            const uint32_t ng = (uint32_t)(knext >> 32), nqp = (uint32_t)A_Q(knext), nsp1 = (uint32_t)A_SPAN(knext) - 1u;
+            const int32_t nB = 2 * A_SPAN(knext) + 1;
+            int32_t myB = 0, myp = -1;
             const int jn = n - j0 < 64 ? n - j0 : 64;
             for (int jj = 0; jj < jn; ++jj) {
                 const int j = j0 + jj;
-                const uint64_t kj = d_readlane64(key[r], jj);
-                const int32_t fj = __builtin_amdgcn_readlane(best[r], jj);
-                const uint32_t gj = (uint32_t)(kj >> 32); const int32_t qj = A_Q(kj);
-                if (lane == jj) {
-                    myf = best[r]; myp = bp[r]; key[r] = knext; best[r] = A_SPAN(knext); bp[r] = -1;
-                    gi[r] = (uint32_t)(knext >> 32); qi[r] = A_Q(knext); sp[r] = A_SPAN(knext);
-                }
+                const uint32_t gj1 = (uint32_t)__builtin_amdgcn_readlane((int)gi[r], jj) + 1u;
+                const uint32_t qj1 = (uint32_t)__builtin_amdgcn_readlane((int)qi[r], jj) + 1u;
+                const int32_t fj2p2 = (__builtin_amdgcn_readlane(B[r], jj) & ~1) + 2;
+                // the owner of j keeps its final state for the store and takes its next anchor (selects, not a branch;
+                // bp of a slot is only meaningful once B is even, so it is not reset)
+                const bool me = lane == jj;
+                myB = me ? B[r] : myB; myp = me ? bp[r] : myp;
+                gi[r] = me ? ng : gi[r]; qi[r] = me ? nqp : qi[r]; sp1[r] = me ? nsp1 : sp1[r]; B[r] = me ? nB : B[r];
 #pragma unroll
-                for (int s = 0; s < R; ++s) {
-                    // anchors currently owned: index > j and <= j + 64R by construction
-                    int32_t sc;
-                    if (d_chain_link(gi[s], qi[s], sp[s], gj, qj, o, sc) && key[s] != 0) {
-                        int32_t v = fj + sc;
-                        if (v > best[s] || (v == best[s] && bp[s] >= 0)) { best[s] = v; bp[s] = j; }
-                    }
-                }
+                for (int s = 0; s < R; ++s)     // anchors currently owned: index > j and <= j + 64R by construction
+                    d_chain_push<SKIP>(gi[s], qi[s], sp1[s], gj1, qj1, fj2p2, j, max_gap, ddc, gap_q8, skip_q8, B[s], bp[s]);
             }
-            if (lane < jn) { f[base + j0 + lane] = myf; p[base + j0 + lane] = myp; }
+            if (lane < jn) { f[base + j0 + lane] = myB >> 1; p[base + j0 + lane] = (myB & 1) ? -1 : myp; }
         }
     }
 }

@@ -1108,9 +1108,12 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
     co.chain_gap_q8 = mo->chain_gap_q8; co.chain_skip_q8 = mo->chain_skip_q8;
     const int Rr = mo->chain_lookback / 64;
-    if (Rr == 1) hipLaunchKernelGGL(k_chain<1>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder);
-    else if (Rr == 2) hipLaunchKernelGGL(k_chain<2>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder);
-    else hipLaunchKernelGGL(k_chain<4>, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder);
+#define CHAIN_LAUNCH(RR, SK) hipLaunchKernelGGL((k_chain<RR, SK>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder)
+    const bool skip = co.chain_skip_q8 != 0;
+    if (Rr == 1) { if (skip) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(1, false); }
+    else if (Rr == 2) { if (skip) CHAIN_LAUNCH(2, true); else CHAIN_LAUNCH(2, false); }
+    else { if (skip) CHAIN_LAUNCH(4, true); else CHAIN_LAUNCH(4, false); }
+#undef CHAIN_LAUNCH
     HIPCHK(hipGetLastError());
     t_ch.stop();
 

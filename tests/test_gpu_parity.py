@@ -99,6 +99,22 @@ def test_synthetic_reads(engine, seed, lookback):
     assert ok >= 0.9 * len(truth)
 
 
+@pytest.mark.parametrize("lookback,skip_q8,bw,max_gap", [(64, 3, 500, 5000), (128, 7, 500, 5000), (256, 2, 300, 800), (128, 0, 6000, 2000)])
+def test_chain_options(engine, lookback, skip_q8, bw, max_gap):
+    """the chaining kernel's second variant (non-zero skip penalty, not used by any preset) and band / gap settings on both
+    sides of the folded range test (bw < max_gap, bw >= max_gap): f / p arrays, chains and records equal to the oracle"""
+    rng = np.random.default_rng(20261002 + 50 + lookback + skip_q8)
+    genome = [synth.random_seq(rng, 150000)]
+    te = synth.random_seq(rng, 2000)
+    for _ in range(8):
+        p = int(rng.integers(0, len(genome[0]) - 2000))
+        genome[0][p:p + 2000] = synth.mutate(rng, te, 0.04, 0.0, 0.0)[:2000]
+    reads, _ = synth.simulate_reads(rng, genome, 40, 5000)
+    io, mo = preset("map-ont")
+    mo.chain_lookback = lookback; mo.chain_skip_q8 = skip_q8; mo.bw = bw; mo.max_gap = max_gap
+    compare_all(engine, genome, reads, io, mo)
+
+
 def test_target_filter_and_per_target(engine):
     """S3/S4/S6 shape: query i sees only target qtarget[i]; S5 shape: per-target selection."""
     rng = np.random.default_rng(7)

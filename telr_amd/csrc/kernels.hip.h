@@ -195,52 +195,115 @@ __device__ __forceinline__ uint32_t d_hash32(uint32_t key, uint32_t mask)
     key = (key + (key << 31)) & mask;
     return key;
 }
-template <int MODE, int HALO>        // HALO = w-1 known at compile time (fully unrolled neighbour tests), or 0 = read it from the arguments
+// One k-mer slot (k <= 15) -> its LDS word: hash + 1 (so that 0 is free to mean "no such window" below), SK_NONE for a slot
+// outside the sequence, with an N, or equal to its reverse complement.  v = the k bases, first base in the low bits.
+#define SK_NONE 0xffffffffu
+__device__ __forceinline__ uint32_t d_slot32(uint32_t v, bool bad, int k, uint32_t mask, uint32_t &z)
+{
+    const uint32_t r = __brev(v) >> (32 - 2 * k);
+    const uint32_t fw = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u), rv = (~v) & mask;
+    z = fw < rv ? 0u : 1u;
+    const uint32_t x = d_hash32(fw < rv ? fw : rv, mask) + 1u;
+    return (bad || fw == rv) ? SK_NONE : x;
+}
+// w = 10: which of the thread's 4 consecutive slots are minimizers.  Slot u is one iff it is the minimum of SOME window of 10
+// slots, i.e. iff  max over the 10 windows holding u of (the window's minimum)  equals its own value: a sliding minimum followed
+// by a sliding maximum over values held in registers (min3 / max3 trees, ~17 operations per slot instead of 18 LDS reads and
+// compare-selects).  p = the 22 LDS words from 9 slots before the first own slot; window a (0..12) starts at slot ua0 + a and
+// only counts when it lies inside the sequence (edge tiles).
+__device__ __forceinline__ uint32_t d_mz_sel4_w10(const uint32_t *p, int ua0, int ns, bool edge)
+{
+    uint32_t v[24];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { const uint4 t = ((const uint4*)p)[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+    uint32_t t3[19], m[13], T3[10];
+#pragma unroll
+    for (int i = 0; i < 19; ++i) { const uint32_t a = v[i] < v[i + 1] ? v[i] : v[i + 1]; t3[i] = a < v[i + 2] ? a : v[i + 2]; }
+#pragma unroll
+    for (int a = 0; a < 13; ++a) {
+        uint32_t x = t3[a] < t3[a + 3] ? t3[a] : t3[a + 3]; x = x < t3[a + 6] ? x : t3[a + 6];
+        m[a] = x < v[a + 9] ? x : v[a + 9];
+    }
+    if (edge) {
+#pragma unroll
+        for (int a = 0; a < 13; ++a) if ((uint32_t)(ua0 + a) > (uint32_t)(ns - 10)) m[a] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { const uint32_t a = m[i] > m[i + 1] ? m[i] : m[i + 1]; T3[i] = a > m[i + 2] ? a : m[i + 2]; }
+    uint32_t sel = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t M = T3[c] > T3[c + 3] ? T3[c] : T3[c + 3]; M = M > T3[c + 6] ? M : T3[c + 6]; M = M > m[c + 9] ? M : m[c + 9];
+        if (v[9 + c] != SK_NONE && M == v[9 + c]) sel |= 1u << c;
+    }
+    return sel;
+}
+
+// Thread t of a tile owns the 4 consecutive slots u0 + 4t .. +3: it hashes them from one 64-bit window of the packed bases
+// (strand bits stay in registers), the first 2*halo threads also hash one halo slot each, and after the barrier every thread
+// tests its own 4 slots.  The selected slots are ranked with ballots (no shuffles).
+template <int MODE, int HALO>        // HALO = 9: w = 10, the register formulation above; 0 = any w, neighbour scans in LDS
 __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
 {
+    static_assert(SK_TILE == 4 * SK_THREADS, "4 slots per thread");
     extern __shared__ __align__(16) unsigned char smem[];
-    const int halo = HALO ? HALO : A.w - 1, nslot = SK_TILE + 2 * halo;
+    const int halo = HALO ? HALO : A.w - 1;
     uint32_t *xs = (uint32_t*)smem;
-    uint8_t *zs = (uint8_t*)(xs + nslot);
     __shared__ int32_t wsum[SK_THREADS / 64];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int sid = A.tile_seq[t], u0 = A.tile_u0[t];
     const int L = A.len[sid], ns = L - A.k + 1, k = A.k;
     const int64_t base = A.boff[sid];
-    const uint32_t mask = (1u << 2 * k) - 1;
-    for (int s = tid; s < nslot; s += SK_THREADS) {
-        int u = u0 - halo + s;
-        uint32_t x = 0xffffffffu; uint8_t z = 0;
-        if (u >= 0 && u < ns) {
-            uint32_t nb = d_get_nbits(A.nmask, base + u, k);
-            if (nb == 0) {
-                const int64_t bb = base + u; const int64_t wi = bb >> 4; const int sh = (int)(bb & 15) * 2;
-                const uint32_t v = __builtin_amdgcn_alignbit(A.seq2[wi + 1], A.seq2[wi], sh) & mask;     // first base in the low bits
-                const uint32_t r = __brev(v) >> (32 - 2 * k);
-                const uint32_t fw = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u), rv = (~v) & mask;
-                if (fw != rv) {
-                    z = fw < rv ? 0 : 1;
-                    x = d_hash32(z ? rv : fw, mask);
-                }
-            }
+    const uint32_t mask = (1u << 2 * k) - 1, kmask = (1u << k) - 1;
+    const int uo = u0 + tid * 4;                       // first own slot
+    uint32_t xo[4] = {SK_NONE, SK_NONE, SK_NONE, SK_NONE}, zb = 0;
+    if (uo < ns) {
+        const int64_t bb = base + uo; const int64_t wi = bb >> 4; const int sh = (int)(bb & 15) * 2;
+        const uint32_t w0 = A.seq2[wi], w1 = A.seq2[wi + 1], w2 = A.seq2[wi + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);   // bases uo .. uo+31
+        const int64_t nw = bb >> 5;
+        const uint32_t nb = __builtin_amdgcn_alignbit(A.nmask[nw + 1], A.nmask[nw], (int)(bb & 31));            // their N flags
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t z;
+            xo[c] = d_slot32(__builtin_amdgcn_alignbit(hi, lo, 2 * c) & mask, ((nb >> c) & kmask) != 0 || uo + c >= ns, k, mask, z);
+            zb |= z << c;
         }
-        xs[s] = x; zs[s] = z;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xs[halo + tid * 4 + c] = xo[c];
+    for (int h = tid; h < 2 * halo; h += SK_THREADS) { // halo slots: u0-halo .. u0-1 and u0+SK_TILE .. +halo-1
+        const int s = h < halo ? h : SK_TILE + h, u = u0 - halo + s;
+        uint32_t x = SK_NONE;
+        if (u >= 0 && u < ns) {
+            const int64_t bb = base + u; const int64_t wi = bb >> 4;
+            const uint32_t v = __builtin_amdgcn_alignbit(A.seq2[wi + 1], A.seq2[wi], (int)(bb & 15) * 2) & mask;
+            uint32_t z;
+            x = d_slot32(v, d_get_nbits(A.nmask, bb, k) != 0, k, mask, z);
+        }
+        xs[s] = x;
     }
     __syncthreads();
-    const int need = A.w < ns ? A.w : ns;
     uint32_t sel = 0;
+    if (HALO == 9 && ns >= 10) {
+        const bool edge = u0 - 9 < 0 || u0 + SK_TILE + 9 > ns;
+        sel = d_mz_sel4_w10(xs + tid * 4, uo - 9, ns, edge);
+    } else {
+        const int need = A.w < ns ? A.w : ns;
 #pragma unroll
-    for (int c = 0; c < SK_TILE / SK_THREADS; ++c) {
-        int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
-        uint32_t x = xs[s];
-        if (u < ns && x != 0xffffffffu && d_mz_selected<HALO, uint32_t>(xs, s, u, ns, need, halo, x)) sel |= 1u << c;
+        for (int c = 0; c < 4; ++c)
+            if (uo + c < ns && xo[c] != SK_NONE && d_mz_selected<0, uint32_t>(xs, halo + tid * 4 + c, uo + c, ns, need, halo, xo[c])) sel |= 1u << c;
     }
-    int cnt = __popc(sel);
-    // block exclusive scan of cnt (wave scan + cross-wave in LDS)
-    int lane = tid & 63, wv = tid >> 6, inc = cnt;
+    // rank of the thread's first selected slot inside the tile: lanes below in the wave (ballots) + waves below (LDS)
+    const int cnt = __popc(sel), wv = tid >> 6;
+    int below = 0, wtot = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-    if (lane == 63) wsum[wv] = inc;
+    for (int c = 0; c < 4; ++c) {
+        const uint64_t bal = __ballot((sel >> c) & 1u);
+        below += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        wtot += __popcll(bal);
+    }
+    if ((tid & 63) == 0) wsum[wv] = wtot;
     __syncthreads();
     int wbase = 0, total = 0;
 #pragma unroll
@@ -248,14 +311,13 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
     if (MODE == 0 || MODE == 2) {
         if (tid == 0) A.tile_cnt[t] = total;
     }
-    if (MODE != 0) {
-        int64_t o = (MODE == 2 ? (int64_t)t * SK_TILE : (int64_t)A.tile_off[t]) + wbase + inc - cnt;
-        uint32_t g0 = A.goff ? A.goff[sid] : 0u;
+    if (MODE != 0 && cnt) {
+        int64_t o = (MODE == 2 ? (int64_t)t * SK_TILE : (int64_t)A.tile_off[t]) + wbase + below;
+        const uint32_t g0 = A.goff ? A.goff[sid] : 0u;
 #pragma unroll
-        for (int c = 0; c < SK_TILE / SK_THREADS; ++c) if (sel >> c & 1) {
-            int s = halo + tid * (SK_TILE / SK_THREADS) + c, u = u0 - halo + s;
-            A.out_x[o] = (uint64_t)xs[s] << 8 | (uint64_t)k;
-            A.out_y[o] = (g0 + (uint32_t)(u + k - 1)) << 1 | zs[s];
+        for (int c = 0; c < 4; ++c) if (sel >> c & 1) {
+            A.out_x[o] = (uint64_t)(xo[c] - 1u) << 8 | (uint64_t)k;
+            A.out_y[o] = (g0 + (uint32_t)(uo + c + k - 1)) << 1 | ((zb >> c) & 1u);
             ++o;
         }
     }
@@ -494,13 +556,19 @@ struct IndexView {
     const uint32_t *goff; const int32_t *tlen;
     int32_t n_ent; int32_t shift; int32_t k, w;
     const HtSlot *ht; int32_t ht_shift; uint32_t ht_mask;
+    const uint32_t *ht_home;     // one bit per slot: some minimizer has this slot as its HOME slot
 };
-__global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t *__restrict__ ent_off, int32_t n_ent, int ht_shift, uint32_t ht_mask, HtSlot *__restrict__ ht)
+// The home-slot bitmap is 1/128 of the table (1 MB for a 23-Mb genome: L2-resident): four of five read minimizers carry a
+// sequencing error and are not in the index at all, and 60-80 % of those find their home bit clear, which answers the
+// probe without fetching a table line from HBM.
+__global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t *__restrict__ ent_off, int32_t n_ent, int ht_shift, uint32_t ht_mask, HtSlot *__restrict__ ht,
+                           uint32_t *__restrict__ ht_home)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_ent) return;
     const uint64_t h = ent_hash[e];
     uint32_t s = d_ht_slot(h, ht_shift, ht_mask);
+    atomicOr(&ht_home[s >> 5], 1u << (s & 31));
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&ht[s].hash, (unsigned long long)HT_EMPTY, (unsigned long long)h);
         if (old == HT_EMPTY) { ht[s].off = ent_off[e]; ht[s].cnt = ent_off[e + 1] - ent_off[e]; return; }
@@ -511,6 +579,7 @@ __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t
 __device__ __forceinline__ bool d_ht_lookup(const IndexView &I, uint64_t h, uint32_t &off, uint32_t &cnt)
 {
     uint32_t s = d_ht_slot(h, I.ht_shift, I.ht_mask);
+    if (!((I.ht_home[s >> 5] >> (s & 31)) & 1u)) return false;
     for (;;) {
         const uint4 v = *(const uint4*)&I.ht[s];
         const uint64_t hh = (uint64_t)v.y << 32 | v.x;

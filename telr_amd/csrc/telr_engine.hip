@@ -479,13 +479,14 @@ struct telr_index {
     int32_t bucket_bits = 0, shift = 0;
     uint64_t *d_ent_hash = nullptr; uint32_t *d_ent_off = nullptr, *d_pos = nullptr, *d_bstart = nullptr, *d_goff = nullptr;
     HtSlot *d_ht = nullptr; int32_t ht_shift = 0; uint32_t ht_mask = 0;       // probe table of the seeding kernel
+    uint32_t *d_ht_home = nullptr;                                            // its home-slot bitmap
     std::vector<uint32_t> sorted_counts; // ascending, for the mid_occ quantile
 };
 
 extern "C" void telr_index_free(telr_index *ix)
 {
     if (!ix) return;
-    (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff); (void)hipFree(ix->d_ht);
+    (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff); (void)hipFree(ix->d_ht); (void)hipFree(ix->d_ht_home);
     delete ix;
 }
 extern "C" int telr_index_stats(const telr_index *ix, int64_t *n_mz, int64_t *n_distinct)
@@ -556,7 +557,10 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
         ix->ht_shift = 64 - hb; ix->ht_mask = (uint32_t)((1ULL << hb) - 1);
         HIPCHK(hipMalloc(&ix->d_ht, ((size_t)1 << hb) * sizeof(HtSlot)));
         HIPCHK(hipMemsetAsync(ix->d_ht, 0xff, ((size_t)1 << hb) * sizeof(HtSlot), ctx->stream));
-        if (n_ent > 0) hipLaunchKernelGGL(k_ht_build, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, ix->d_ent_off, n_ent, ix->ht_shift, ix->ht_mask, ix->d_ht);
+        const size_t home_words = (((size_t)1 << hb) + 31) / 32;
+        HIPCHK(hipMalloc(&ix->d_ht_home, home_words * 4));
+        HIPCHK(hipMemsetAsync(ix->d_ht_home, 0, home_words * 4, ctx->stream));
+        if (n_ent > 0) hipLaunchKernelGGL(k_ht_build, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, ix->d_ent_off, n_ent, ix->ht_shift, ix->ht_mask, ix->d_ht, ix->d_ht_home);
         HIPCHK(hipGetLastError());
     }
     // occurrence counts, sorted, to the host for the -f quantile
@@ -1060,7 +1064,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     StageTimer t_sd(ctx, ST_SEED, true);
     IndexView I; I.ent_hash = ix->d_ent_hash; I.ent_off = ix->d_ent_off; I.pos = ix->d_pos; I.bstart = nullptr; I.goff = ix->d_goff;
     I.tlen = tg->d_len; I.n_ent = ix->n_ent; I.shift = ix->shift; I.k = k; I.w = w;
-    I.ht = ix->d_ht; I.ht_shift = ix->ht_shift; I.ht_mask = ix->ht_mask;
+    I.ht = ix->d_ht; I.ht_shift = ix->ht_shift; I.ht_mask = ix->ht_mask; I.ht_home = ix->d_ht_home;
     int32_t *d_mcnt, *d_maoff, *d_qaoff;
     int32_t *d_ment, *d_mn;
     TRY(ctx_buf_t(ctx, "mz_ent", (size_t)nmz + 1, &d_ment));
@@ -1094,6 +1098,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     StageTimer t_so(ctx, ST_SORT, true);
     if (na > 0) {
         size_t tb = 0;
+        // (all 64 bits: rocprim's segmented sort mis-orders keys with bit 63 set when begin_bit > 0 -- measured, ROCm 7.2)
         HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
         HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));

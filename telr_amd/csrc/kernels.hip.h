@@ -1097,7 +1097,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
     }
     int64_t tb;
     if (P.kind >= 3) tb = 0;
-    else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 15) & ~15LL;
+    else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 63) & ~63LL;     // whole 64-byte lines (d_traceback_rows)
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
     int cells = 0;
@@ -1112,6 +1112,35 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
 // scratch offsets of every problem, class histogram, and the (key, problem) pairs whose ONE radix sort yields all class
 // lists at once: key = class << 20 | (0xFFFFF - steps), so a class is a contiguous range ordered by decreasing steps
 struct ClsOff { int32_t off[DP_NCLS + 1]; };
+// Trace-back offsets in CLASS-LIST order: the 64 problems of a wave (neighbours in their class list) get adjacent pieces of
+// the trace-back buffer.  With offsets in problem order every lane of a wave worked in a different page of a 10-GB buffer and
+// both the spill and the walk ran at the rate of the address translation (tools/ubench/tb_pattern.hip: scattered 64-byte
+// reads 2.6 TB/s inside 1 GiB, 1.0 TB/s over 4 GiB or more).
+// The one-lane-per-problem classes (10-13, 17) go one step further: the 64 problems of a wave are INTERLEAVED in units of
+// 8 bytes (unit u of lane t at wave base + (u*64 + t)*8), so every store instruction of the forward pass and every load
+// instruction of the walk covers 512 contiguous bytes and a whole row pair / line of the wave is one contiguous 2.5-4 KB
+// block: both kernels stream instead of touching 64 different lines per instruction.  The wave's piece is sized by its
+// first (longest) problem; tb_off of a problem points at its unit 0.
+__device__ __forceinline__ bool d_tb_interleaved(int cls) { return (cls >= 10 && cls <= 13) || cls == 17; }
+__device__ __forceinline__ int d_cls_of_pos(const ClsOff &off, int i) { int c = 0; while (c < DP_NCLS - 1 && i >= off.off[c + 1]) ++c; return c; }
+__global__ void __launch_bounds__(256) k_tb_gather(const int64_t *__restrict__ tb_bytes, const int32_t *__restrict__ list, int32_t np, ClsOff off, int64_t *__restrict__ out)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == np) out[np] = 0;
+    if (i >= np) return;
+    const int c = d_cls_of_pos(off, i);
+    if (!d_tb_interleaved(c)) { out[i] = tb_bytes[list[i]]; return; }
+    const int first = off.off[c] + ((i - off.off[c]) & ~63);
+    const int last = first + 63 < off.off[c + 1] - 1 ? first + 63 : off.off[c + 1] - 1;
+    out[i] = i == last ? tb_bytes[list[first]] * 64 : 0;           // the whole wave's piece, counted once (at its last lane)
+}
+__global__ void __launch_bounds__(256) k_tb_scatter(DpProb *__restrict__ probs, const int32_t *__restrict__ list, int32_t np, ClsOff off, const int64_t *__restrict__ toff)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    const int c = d_cls_of_pos(off, i);
+    probs[list[i]].tb_off = toff[i] + (d_tb_interleaved(c) ? (int64_t)((i - off.off[c]) & 63) * 8 : 0);
+}
 __global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs, int32_t np, const int64_t *__restrict__ tb_off, const int64_t *__restrict__ cig_off,
                                                      int32_t *__restrict__ cls_cnt, uint32_t *__restrict__ sort_key, int32_t *__restrict__ sort_val)
 {
@@ -1784,33 +1813,32 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 prev_cur = cur;
             }
             if constexpr (LPP == 1 && !EXT) {
-                // one lane owns whole rows, and rows k-1 / k are adjacent: write them as one 8R-byte piece (a full 64-byte
-                // line for R = 8) instead of two half pieces that reach memory at different times
+                // one lane owns whole rows, and rows k-1 / k are adjacent: they leave as R 8-byte units of the wave-interleaved
+                // layout (k_tb_gather): unit u of this lane at tb32 + u*128 dwords, so each store instruction of the wave
+                // writes 512 contiguous bytes
+                uint32_t sq[2 * R + 1];
                 if (k & 1) {
-                    uint32_t *dst = tb32 + (int64_t)(k - 1) * RW;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { sq[r] = prow[r]; sq[R + r] = row[r]; }
+                    sq[2 * R] = 0;
+                    uint32_t *dst = tb32 + (int64_t)((k - 1) / 2 * R) * 128;
                     if (k <= last_row) {
-                        if constexpr (R % 2 == 0) {
 #pragma unroll
-                            for (int r = 0; r < R; r += 2) *(uint2*)(dst + r) = make_uint2(prow[r], prow[r + 1]);
-#pragma unroll
-                            for (int r = 0; r < R; r += 2) *(uint2*)(dst + R + r) = make_uint2(row[r], row[r + 1]);
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < R; ++r) dst[r] = prow[r];
-#pragma unroll
-                            for (int r = 0; r < R; ++r) dst[R + r] = row[r];
-                        }
+                        for (int u = 0; u < R; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
                     } else if (k - 1 <= last_row) {
 #pragma unroll
-                        for (int r = 0; r < R; ++r) dst[r] = prow[r];
+                        for (int u = 0; u < (R + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; ++r) prow[r] = row[r];
                     if (2 * (k + 1) > amax && k <= last_row) {        // last trip of the wave: nothing will pair with this row
-                        uint32_t *dst = tb32 + (int64_t)k * RW;
 #pragma unroll
-                        for (int r = 0; r < R; ++r) dst[r] = row[r];
+                        for (int r = 0; r < R; ++r) sq[r] = row[r];
+                        sq[R] = 0;
+                        uint32_t *dst = tb32 + (int64_t)(k / 2 * R) * 128;
+#pragma unroll
+                        for (int u = 0; u < (R + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
                     }
                 }
             } else if (k <= last_row) {
@@ -1940,26 +1968,47 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
     uint32_t *cg = cig + P.cig_off;
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
     const int rowb = packed ? lpp * 4 : stride;      // bytes between consecutive rows of the trace-back matrix
-    int64_t tag0 = -1, tag1 = -1, pf = -2;
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+    int64_t tag0 = -1, tag1 = -1, pfb = -2;           // lines in the two LDS slots; 128-byte block held in registers
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
     while (i > 0 && j > 0) {
         const int a = i + j, sl = (j - i - dlo) >> 1;
         const int64_t off = (LAYOUT == 2 || cls >= 10) ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
                           : packed ? ((((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)) : ((int64_t)a * stride + sl);
-        // tb_off is a multiple of 16 only, so lines are taken relative to the 64-byte grid of the whole scratch buffer
-        const int64_t abs_off = P.tb_off + off, line = abs_off >> 6;
+        // lines are taken relative to the 64-byte grid of the whole scratch buffer; the wave-interleaved classes keep their
+        // bytes in 8-byte units 512 bytes apart (k_tb_gather) -- this generic walk reaches them only in the TELR_TB_SPLIT=0 mode
+        const int64_t abs_off = P.tb_off + (d_tb_interleaved(cls) ? ((off >> 3) << 9) + (off & 7) : off), line = abs_off >> 6;
         const int slot = TB_SLOTS > 1 ? (int)(line & 1) : 0;
         if ((slot ? tag1 : tag0) != line) {
-            if (pf != line) { const uint4 *src = (const uint4*)(tb_all + (line << 6)); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+            // Memory is read in whole 128-byte blocks (8 x 16 B per lane): scattered 64-byte reads reach 2.5 TB/s on this
+            // part, 128-byte ones 5.4 TB/s (tools/ubench/tb_pattern.hip).  The block stays in registers; its two halves
+            // feed the LDS slots one after the other.
+            const int64_t blk = line >> 1;
+            if (pfb != blk) {
+                const uint4 *src = (const uint4*)(tb_all + (blk << 7));
+                v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; v5 = src[5]; v6 = src[6]; v7 = src[7];
+            }
             uint32_t *dst = stage + slot * 1024 + lane;
-            dst[0 * 64] = v0.x; dst[1 * 64] = v0.y; dst[2 * 64] = v0.z; dst[3 * 64] = v0.w;
-            dst[4 * 64] = v1.x; dst[5 * 64] = v1.y; dst[6 * 64] = v1.z; dst[7 * 64] = v1.w;
-            dst[8 * 64] = v2.x; dst[9 * 64] = v2.y; dst[10 * 64] = v2.z; dst[11 * 64] = v2.w;
-            dst[12 * 64] = v3.x; dst[13 * 64] = v3.y; dst[14 * 64] = v3.z; dst[15 * 64] = v3.w;
+            if (line & 1) {
+                dst[0 * 64] = v4.x; dst[1 * 64] = v4.y; dst[2 * 64] = v4.z; dst[3 * 64] = v4.w;
+                dst[4 * 64] = v5.x; dst[5 * 64] = v5.y; dst[6 * 64] = v5.z; dst[7 * 64] = v5.w;
+                dst[8 * 64] = v6.x; dst[9 * 64] = v6.y; dst[10 * 64] = v6.z; dst[11 * 64] = v6.w;
+                dst[12 * 64] = v7.x; dst[13 * 64] = v7.y; dst[14 * 64] = v7.z; dst[15 * 64] = v7.w;
+            } else {
+                dst[0 * 64] = v0.x; dst[1 * 64] = v0.y; dst[2 * 64] = v0.z; dst[3 * 64] = v0.w;
+                dst[4 * 64] = v1.x; dst[5 * 64] = v1.y; dst[6 * 64] = v1.z; dst[7 * 64] = v1.w;
+                dst[8 * 64] = v2.x; dst[9 * 64] = v2.y; dst[10 * 64] = v2.z; dst[11 * 64] = v2.w;
+                dst[12 * 64] = v3.x; dst[13 * 64] = v3.y; dst[14 * 64] = v3.z; dst[15 * 64] = v3.w;
+            }
             if (slot) tag1 = line; else tag0 = line;
-            // next line to come: the same position one row up when rows are wider than a line, else the line below
-            pf = rowb >= 64 ? (abs_off - rowb) >> 6 : line - 1;
-            if (pf >= 0) { const uint4 *src = (const uint4*)(tb_all + (pf << 6)); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+            // next line to come: the same position one row up when rows are wider than a line, else the line below;
+            // fetch its block now unless it is the one already held
+            const int64_t nl = rowb >= 64 ? (abs_off - rowb) >> 6 : line - 1, nb = nl >> 1;
+            pfb = blk;
+            if (nb != blk && nl >= 0) {
+                const uint4 *src = (const uint4*)(tb_all + (nb << 7));
+                v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; v5 = src[5]; v6 = src[6]; v7 = src[7];
+                pfb = nb;
+            }
         }
         const int w = (int)(abs_off & 63);
         const uint32_t t = (stage[slot * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
@@ -1990,6 +2039,88 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
     if (ti >= np) return;
     d_traceback_lane<-1>(probs, res, list ? list[ti] : ti, tb_all, cig, retry, stage);
 }
+// Row-synchronous walk for the packed fill classes: one lane per problem, all 64 problems of a wave in the same class
+// (same row width), every problem's matrix starting on a 64-byte line.  The plain lane-per-problem walk above stalls on
+// memory in almost every step: 64 lanes cross line boundaries at 64 different moments and each crossing waits for the
+// wave's youngest load.  Here the WAVE moves down one trace-back row (two anti-diagonals, at most two path cells) at a
+// time, so all lanes cross into a new line in the same iteration, the control flow around the loads is uniform, and
+// two register sets hold the next two lines in flight (the compiler can count the wait): one memory wait per line for
+// the whole wave instead of one per step.
+__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il,
+                                                 const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
+                                                 uint32_t *stage)
+{
+    const int lane = threadIdx.x;
+    DpProb P = probs[pi];
+    if (P.kind >= 3) have = false;
+    const int rowb = lpp * 4, dlo = P.dlo, dhi_ = P.dhi;
+    int i = 0, j = 0;
+    if (have) { i = res[pi].bi; j = res[pi].bj; }
+    const uint8_t *tb = tb_all + P.tb_off;                       // 64-byte aligned (k_prob_sizes)
+    uint32_t *cg = cig + P.cig_off;
+    int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0, touched = 0;
+    const int mytop = have && i > 0 && j > 0 ? (i + j) >> 1 : -1;  // highest row this lane reads
+    const int mytopline = mytop >= 0 ? (mytop * rowb + rowb - 1) >> 6 : -1;
+    int rtop = mytop;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(rtop, o); rtop = v > rtop ? v : rtop; }
+    rtop = __builtin_amdgcn_readfirstlane(rtop);
+    if (rtop >= 0) {
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, a2 = a0, a3 = a0, b0 = a0, b1 = a0, b2 = a0, b3 = a0;   // even / odd line in flight
+        int tag0 = -1, tag1 = -1;                                 // lines in the two LDS slots (wave-uniform)
+        const int ltop = (rtop * rowb + rowb - 1) >> 6;
+        // il (wave-uniform): the wave's problems are interleaved in 8-byte units (k_tb_gather): line L of this lane = units 8L..8L+7,
+        // 512 bytes apart, and each of the eight load instructions reads 512 contiguous bytes for the wave
+#define TBR_FETCH(L_, x0, x1, x2, x3) do { const int L__ = (L_); if (L__ >= 0 && L__ <= mytopline) { \
+            if (il) { const uint2 *src = (const uint2*)tb + (int64_t)L__ * 512; \
+                const uint2 u0 = src[0], u1 = src[64], u2 = src[128], u3 = src[192], u4 = src[256], u5 = src[320], u6 = src[384], u7 = src[448]; \
+                x0 = make_uint4(u0.x, u0.y, u1.x, u1.y); x1 = make_uint4(u2.x, u2.y, u3.x, u3.y); x2 = make_uint4(u4.x, u4.y, u5.x, u5.y); x3 = make_uint4(u6.x, u6.y, u7.x, u7.y); } \
+            else { const uint4 *src = (const uint4*)(tb + ((int64_t)L__ << 6)); x0 = src[0]; x1 = src[1]; x2 = src[2]; x3 = src[3]; } } } while (0)
+#define TBR_PUT(dst_, x0, x1, x2, x3) do { uint32_t *dst = (dst_); \
+            dst[0 * 64] = x0.x; dst[1 * 64] = x0.y; dst[2 * 64] = x0.z; dst[3 * 64] = x0.w; dst[4 * 64] = x1.x; dst[5 * 64] = x1.y; dst[6 * 64] = x1.z; dst[7 * 64] = x1.w; \
+            dst[8 * 64] = x2.x; dst[9 * 64] = x2.y; dst[10 * 64] = x2.z; dst[11 * 64] = x2.w; dst[12 * 64] = x3.x; dst[13 * 64] = x3.y; dst[14 * 64] = x3.z; dst[15 * 64] = x3.w; } while (0)
+        // line L (the next lower one, by construction) moves from its register set into its LDS slot; the set refills with line L-2
+#define TBR_ENSURE(L_) do { const int Le = (L_); \
+            if (Le & 1) { if (tag1 != Le) { TBR_PUT(stage + 1024 + lane, b0, b1, b2, b3); tag1 = Le; TBR_FETCH(Le - 2, b0, b1, b2, b3); } } \
+            else        { if (tag0 != Le) { TBR_PUT(stage + lane, a0, a1, a2, a3); tag0 = Le; TBR_FETCH(Le - 2, a0, a1, a2, a3); } } } while (0)
+        if (ltop & 1) { TBR_FETCH(ltop, b0, b1, b2, b3); TBR_FETCH(ltop - 1, a0, a1, a2, a3); }
+        else { TBR_FETCH(ltop, a0, a1, a2, a3); TBR_FETCH(ltop - 1, b0, b1, b2, b3); }
+        TBR_ENSURE(ltop);
+        for (int r = rtop; r >= 0; --r) {
+            TBR_ENSURE((r * rowb) >> 6);                              // the row's lower line; its upper one came with the rows above
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                const int a = i + j, sl = (j - i - dlo) >> 1;
+                const bool act = i > 0 && j > 0 && (a >> 1) == r;
+                const int o = act ? ((((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)) : 0;
+                const int w = o & 63;
+                const uint32_t t = (stage[((o >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
+                if (act) {
+                    touched |= (j - i == dlo) | (j - i == dhi_);
+                    const int s0 = state ? state : (int)(t & 7);
+                    const int isM = s0 == 0, isD = s0 & 1;
+                    const int op = isM ? 0 : (isD ? 2 : 1);
+                    state = (isM || !((t >> (2 + s0)) & 1)) ? 0 : s0;
+                    ml += isM & (int)(t >> 7); mc += isM;
+                    i -= isD ^ 1; j -= isM | isD;
+                    const bool same = op == cur_op;
+                    if (!same && cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+                    cur_len = same ? cur_len + 1 : 1; cur_op = op;
+                }
+            }
+            if (!__any(i > 0 && j > 0)) break;
+        }
+#undef TBR_FETCH
+#undef TBR_PUT
+#undef TBR_ENSURE
+    }
+    if (!have) return;
+    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
+    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
+    if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+    res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
+    if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
+}
 // trace-back of the packed fill classes, driven by the same cost-ordered wave table as the forward launch (one block
 // per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
 __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ probs, DpRes *__restrict__ res,
@@ -2000,8 +2131,8 @@ __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ 
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int ppw = 64 / PK_LPP[cls - 10], t = threadIdx.x;
-    if (t >= ppw || first + t >= off.off[cls + 1] - off.off[cls]) return;
-    d_traceback_lane<2>(probs, res, cls_list[off.off[cls] + first + t], tb_all, cig, retry, stage);
+    const bool have = t < ppw && first + t < off.off[cls + 1] - off.off[cls];
+    d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[cls - 10] * PK_R[cls - 10], d_tb_interleaved(cls), tb_all, cig, retry, stage);
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control

@@ -892,6 +892,16 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
         HIPCHK(rocprim::radix_sort_pairs(tmp, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 25, st));
     }
+    if (np > 0) {       // trace-back pieces laid out in class-list order (page locality of the spill and of the walk)
+        int64_t *d_tbs;
+        TRY(ctx_buf_t(ctx, ("tb_sorted" + sfx).c_str(), (size_t)np + 1, &d_tbs));
+        hipLaunchKernelGGL(k_tb_gather, dim3(np / 256 + 1), dim3(256), 0, st, d_tbb, d_clslist, np, coff, d_tbs);
+        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_tbs, d_tboff, (size_t)np + 1)));
+        hipLaunchKernelGGL(k_tb_scatter, dim3(np / 256 + 1), dim3(256), 0, st, d_probs, d_clslist, np, coff, d_tboff);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&tb_total, d_tboff + np, 8, hipMemcpyDeviceToHost, st));     // waves of interleaved problems are padded to their longest
+        HIPCHK(hipStreamSynchronize(st));
+    }
     uint8_t *d_tb;
     TRY(ctx_buf_t(ctx, ("tb" + sfx).c_str(), (size_t)tb_total + 256, &d_tb));
     if (primary) TRY(ctx_buf_t(ctx, "rawcig", (size_t)cg_total + 16, d_rawcig_io));

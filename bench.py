@@ -188,7 +188,8 @@ def main():
         fs = _pmc("r01_pmc_FETCH_SIZE.txt", k_name + " "); ws = _pmc("r01_pmc_WRITE_SIZE.txt", k_name + " ")
         if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:
             traffic = (2.0 * fs + ws) * 1024.0      # gfx950: FETCH_SIZE counts wide reads at 1/2 (MI355X_MICROARCH.md, HBM)
-            traffic_src = "profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per map call; FETCH doubled)"
+            traffic_src = ("profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per map call; FETCH doubled as for wide streaming reads: an upper bound, "
+                           "scattered 64-byte reads calibrate at 1.0 and 40-byte write pieces at 1.47, tools/ubench/tb_pattern.hip)")
     except Exception:
         pass
     issue_frac = None

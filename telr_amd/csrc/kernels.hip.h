@@ -2042,10 +2042,9 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
 // Row-synchronous walk for the packed fill classes: one lane per problem, all 64 problems of a wave in the same class
 // (same row width), every problem's matrix starting on a 64-byte line.  The plain lane-per-problem walk above stalls on
 // memory in almost every step: 64 lanes cross line boundaries at 64 different moments and each crossing waits for the
-// wave's youngest load.  Here the WAVE moves down one trace-back row (two anti-diagonals, at most two path cells) at a
-// time, so all lanes cross into a new line in the same iteration, the control flow around the loads is uniform, and
-// two register sets hold the next two lines in flight (the compiler can count the wait): one memory wait per line for
-// the whole wave instead of one per step.
+// wave's youngest load.  Here the WAVE moves down its trace-back matrices one 64-byte line at a time, so all lanes
+// cross into a new line in the same iteration, the control flow around the loads is uniform, and
+// two register sets hold the next two lines in flight: one memory wait per line for the whole wave instead of one per step.
 __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il,
                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                  uint32_t *stage)
@@ -2085,16 +2084,19 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
             else        { if (tag0 != Le) { TBR_PUT(stage + lane, a0, a1, a2, a3); tag0 = Le; TBR_FETCH(Le - 2, a0, a1, a2, a3); } } } while (0)
         if (ltop & 1) { TBR_FETCH(ltop, b0, b1, b2, b3); TBR_FETCH(ltop - 1, a0, a1, a2, a3); }
         else { TBR_FETCH(ltop, a0, a1, a2, a3); TBR_FETCH(ltop - 1, b0, b1, b2, b3); }
-        TBR_ENSURE(ltop);
-        for (int r = rtop; r >= 0; --r) {
-            TBR_ENSURE((r * rowb) >> 6);                              // the row's lower line; its upper one came with the rows above
-#pragma unroll
-            for (int rep = 0; rep < 2; ++rep) {
+        // line by line: with lines L+1 and L in LDS every lane walks on while its next cell lies in one of them, then the
+        // wave moves to the next line together (a lane is active in most iterations: it runs ahead inside the two lines
+        // instead of waiting for the slowest lane row by row)
+        for (int L = ltop; L >= 0; --L) {
+            TBR_ENSURE(L);
+            const int lim = L << 6;
+            for (;;) {
                 const int a = i + j, sl = (j - i - dlo) >> 1;
-                const bool act = i > 0 && j > 0 && (a >> 1) == r;
-                const int o = act ? ((((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1)) : 0;
-                const int w = o & 63;
-                const uint32_t t = (stage[((o >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
+                const int o = (((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1);
+                const bool act = i > 0 && j > 0 && o >= lim;
+                if (!__any(act)) break;
+                const int oo = act ? o : 0, w = oo & 63;
+                const uint32_t t = (stage[((oo >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
                 if (act) {
                     touched |= (j - i == dlo) | (j - i == dhi_);
                     const int s0 = state ? state : (int)(t & 7);

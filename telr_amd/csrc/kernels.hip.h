@@ -2330,7 +2330,9 @@ __global__ void __launch_bounds__(64) k_stitch_count(const StitchRec *__restrict
 __global__ void k_stitch_write(int32_t np, const StitchProb *__restrict__ sp, const DpProb *__restrict__ probs, const DpRes *__restrict__ res,
                                const StitchRec *__restrict__ sv, const uint32_t *__restrict__ raw, const int64_t *__restrict__ fin_off, uint32_t *__restrict__ out)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    // eight lanes per problem (a problem has ~23 ops): 32-byte pieces of the raw run and of the output per group, and the
+    // outputs of neighbouring problems are neighbours
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, p = g >> 3, l = g & 7;
     if (p >= np) return;
     const StitchProb q = sp[p];
     if (q.sv < 0) return;
@@ -2339,7 +2341,7 @@ __global__ void k_stitch_write(int32_t np, const StitchProb *__restrict__ sp, co
     const uint32_t *src = raw + probs[p].cig_off;
     const bool fwd = p == sv[q.sv].p0 && sv[q.sv].has_left;
     uint32_t *o = out + fin_off[q.sv] + q.off;
-    for (int z = q.skip; z < no; ++z) {
+    for (int z = q.skip + l; z < no; z += 8) {
         uint32_t op = src[fwd ? z : no - 1 - z];
         if (z == no - 1) op += (uint32_t)q.extra << 4;
         o[z - q.skip] = op;

@@ -1396,7 +1396,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             TRY(ctx_buf_t(ctx, "stitched", (size_t)tot + 1, &d_fin));
             // the stitched scratch is overwritten here: the previous call's DMA out of it must be over (it is, tens of ms ago)
             if (ctx->dma_inflight) HIPCHK(hipStreamWaitEvent(st, ctx->ev_dma, 0));
-            hipLaunchKernelGGL(k_stitch_write, dim3((np + 255) / 256), dim3(256), 0, st, np, d_sp, d_probs, d_res, d_sv, d_rawcig, d_foff, d_fin);
+            hipLaunchKernelGGL(k_stitch_write, dim3((np + 31) / 32), dim3(256), 0, st, np, d_sp, d_probs, d_res, d_sv, d_rawcig, d_foff, d_fin);
             HIPCHK(hipGetLastError());
             result_wait(R);                        // an earlier batch of this call may still be writing into the buffer that grows below
             cig_base = R->ncig;

@@ -549,6 +549,10 @@ __device__ __forceinline__ uint32_t d_ht_slot(uint64_t h, int ht_shift, uint32_t
 {
     return (uint32_t)((h * 0x9E3779B97F4A7C15ULL) >> ht_shift) & ht_mask;
 }
+#ifndef HT_FB_LOG
+#define HT_FB_LOG 1          /* filter bits per table slot = 2^HT_FB_LOG */
+#endif
+__device__ __forceinline__ uint32_t d_ht_filter_bit(uint64_t h, int ht_shift) { return (uint32_t)((h * 0x9E3779B97F4A7C15ULL) >> (ht_shift - HT_FB_LOG)); }
 struct HtSlot { uint64_t hash; uint32_t off, cnt; };
 #define HT_EMPTY 0xffffffffffffffffULL
 struct IndexView {
@@ -556,11 +560,11 @@ struct IndexView {
     const uint32_t *goff; const int32_t *tlen;
     int32_t n_ent; int32_t shift; int32_t k, w;
     const HtSlot *ht; int32_t ht_shift; uint32_t ht_mask;
-    const uint32_t *ht_home;     // one bit per slot: some minimizer has this slot as its HOME slot
+    const uint32_t *ht_home;     // HT_FB bits per slot: some minimizer's re-hash starts with these log2(slots) + log2(HT_FB) bits
 };
-// The home-slot bitmap is 1/128 of the table (1 MB for a 23-Mb genome: L2-resident): four of five read minimizers carry a
-// sequencing error and are not in the index at all, and 60-80 % of those find their home bit clear, which answers the
-// probe without fetching a table line from HBM.
+// The filter bitmap is 1/64 of the table (2 MB for a 23-Mb genome: L2-resident): four of five read minimizers carry a
+// sequencing error and are not in the index at all, and ~3/4 of those find their bit clear, which answers the probe
+// without fetching a table line from HBM.
 __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t *__restrict__ ent_off, int32_t n_ent, int ht_shift, uint32_t ht_mask, HtSlot *__restrict__ ht,
                            uint32_t *__restrict__ ht_home)
 {
@@ -568,7 +572,7 @@ __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t
     if (e >= n_ent) return;
     const uint64_t h = ent_hash[e];
     uint32_t s = d_ht_slot(h, ht_shift, ht_mask);
-    atomicOr(&ht_home[s >> 5], 1u << (s & 31));
+    { const uint32_t f = d_ht_filter_bit(h, ht_shift); atomicOr(&ht_home[f >> 5], 1u << (f & 31)); }
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&ht[s].hash, (unsigned long long)HT_EMPTY, (unsigned long long)h);
         if (old == HT_EMPTY) { ht[s].off = ent_off[e]; ht[s].cnt = ent_off[e + 1] - ent_off[e]; return; }
@@ -579,7 +583,7 @@ __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t
 __device__ __forceinline__ bool d_ht_lookup(const IndexView &I, uint64_t h, uint32_t &off, uint32_t &cnt)
 {
     uint32_t s = d_ht_slot(h, I.ht_shift, I.ht_mask);
-    if (!((I.ht_home[s >> 5] >> (s & 31)) & 1u)) return false;
+    { const uint32_t f = d_ht_filter_bit(h, I.ht_shift); if (!((I.ht_home[f >> 5] >> (f & 31)) & 1u)) return false; }
     for (;;) {
         const uint4 v = *(const uint4*)&I.ht[s];
         const uint64_t hh = (uint64_t)v.y << 32 | v.x;

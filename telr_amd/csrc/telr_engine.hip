@@ -557,7 +557,7 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
         ix->ht_shift = 64 - hb; ix->ht_mask = (uint32_t)((1ULL << hb) - 1);
         HIPCHK(hipMalloc(&ix->d_ht, ((size_t)1 << hb) * sizeof(HtSlot)));
         HIPCHK(hipMemsetAsync(ix->d_ht, 0xff, ((size_t)1 << hb) * sizeof(HtSlot), ctx->stream));
-        const size_t home_words = (((size_t)1 << hb) + 31) / 32;
+        const size_t home_words = (((size_t)1 << (hb + HT_FB_LOG)) + 31) / 32;
         HIPCHK(hipMalloc(&ix->d_ht_home, home_words * 4));
         HIPCHK(hipMemsetAsync(ix->d_ht_home, 0, home_words * 4, ctx->stream));
         if (n_ent > 0) hipLaunchKernelGGL(k_ht_build, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, ix->d_ent_off, n_ent, ix->ht_shift, ix->ht_mask, ix->d_ht, ix->d_ht_home);

@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-25 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", default="map-ont")
+    ap.add_argument("--fill-band-q4", type=int, default=0, help="experiment: override the preset's first-pass band factor (0 = preset)")
     ap.add_argument("--loci", type=int, default=200, help="candidate loci for the TE-loci/s leg (0 = skip)")
     return ap.parse_args()
 
@@ -94,6 +95,8 @@ def main():
     from telr_amd import synth
 
     io, mo = preset(a.preset)
+    if a.fill_band_q4:
+        mo.fill_band_q4 = a.fill_band_q4
     t0 = time.time()
     # every rank: same genome/insertions (seed), its own reads (seed + rank)
     d = synth.make_stage1_dataset(seed=20261002, genome_len=a.genome_len, n_reads=a.reads, total_bases=a.read_bases,

@@ -218,7 +218,7 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
     mo->mask_level = 0.5f; mo->pri_ratio = 0.8f; mo->best_n = 5; mo->secondary = 1;
     mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
     mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6;
-    if (s == "map-ont" || s == "ngmlr-ont") { }
+    if (s == "map-ont" || s == "ngmlr-ont") { mo->fill_band_q4 = 4; }
     else if (s == "map-pb" || s == "ngmlr-pacbio") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 8; }
     else if (s == "asm10") {
         io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;

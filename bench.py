@@ -88,6 +88,11 @@ def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ranks of one node share its CPUs: each engine sizes its host pool for its share (the library's default is 1.5 x the
+    # CPUs the process may use, which every rank would claim for itself)
+    lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if lws > 1 and "TELR_HOST_THREADS" not in os.environ:
+        os.environ["TELR_HOST_THREADS"] = str(max(4, min(48, usable_cpus() * 3 // (2 * lws))))
     import torch
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at world size 1)

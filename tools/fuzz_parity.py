@@ -1,0 +1,62 @@
+"""Randomised HIP-vs-oracle parity: random genomes, read sets and option mixes, every stage compared bit for bit
+(tests/test_gpu_parity.py: compare_all).  usage: python tools/fuzz_parity.py [iterations] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["TELR_DEBUG"] = "1"
+import numpy as np
+from telr_amd import synth
+from telr_amd.aligner import Engine
+from telr_amd.presets import preset
+
+
+
+def run(eng, n_iter, seed0):
+    from test_gpu_parity import compare_all
+    for it in range(n_iter):
+        rng = np.random.default_rng(seed0 * 1000 + it)
+        pname = ["map-ont", "map-ont", "map-pb", "asm10"][int(rng.integers(0, 4))]
+        io, mo = preset(pname)
+        ntg = int(rng.integers(1, 4))
+        genome = [synth.random_seq(rng, int(rng.integers(20000, 120000))) for _ in range(ntg)]
+        te = synth.random_seq(rng, int(rng.integers(500, 4000)))
+        for g in genome:                                   # repeats: occurrence filter, secondary chains
+            for _ in range(int(rng.integers(0, 8))):
+                p = int(rng.integers(0, len(g) - len(te)))
+                g[p:p + len(te)] = synth.mutate(rng, te, float(rng.uniform(0, 0.08)), 0.0, 0.0)[:len(te)]
+        if rng.random() < 0.3:
+            g = genome[0]; p = int(rng.integers(0, len(g) - 300)); g[p:p + int(rng.integers(1, 300))] = ord("N")
+        err = float(rng.uniform(0.0, 0.07))
+        reads, _ = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(400, 9000)), err=(err, err / 2, err))
+        for _ in range(int(rng.integers(0, 3))):           # odd ones: tiny, with Ns, empty
+            reads.append(synth.random_seq(rng, int(rng.integers(0, 40))))
+        if reads and rng.random() < 0.5:
+            r = reads[int(rng.integers(0, len(reads)))]
+            if len(r) > 200:
+                r[50:50 + int(rng.integers(1, 100))] = ord("N")
+        # option mix
+        if pname != "map-pb" and rng.random() < 0.5:
+            io.k = int(rng.integers(11, 22)); io.w = int(rng.choice([5, 10, 10, 12, 19]))
+            from telr_amd.presets import _gap_q8
+            mo.chain_gap_q8 = _gap_q8(io.k)
+        mo.chain_lookback = int(rng.choice([64, 128, 256]))
+        mo.fill_band_q4 = int(rng.integers(1, 9))
+        mo.min_ksw_len = int(rng.choice([50, 100, 200, 400]))
+        mo.bw = int(rng.choice([100, 500, 2000])); mo.max_gap = int(rng.choice([1000, 5000, 10000]))
+        mo.best_n = int(rng.integers(1, 8)); mo.secondary = int(rng.integers(0, 2))
+        mo.chain_skip_q8 = int(rng.choice([0, 0, 0, 3]))
+        mo.ext_max = int(rng.choice([256, 2048])); mo.zdrop = int(rng.choice([100, 400]))
+        try:
+            compare_all(eng, genome, reads, io, mo)
+        except Exception as e:
+            print("FAIL iteration", it, "seed", seed0 * 1000 + it, pname, "k", io.k, "w", io.w, "lookback", mo.chain_lookback, "q4", mo.fill_band_q4, "ksw", mo.min_ksw_len,
+                  "bw", mo.bw, "gap", mo.max_gap, "skip", mo.chain_skip_q8)
+            raise
+
+
+if __name__ == "__main__":
+    n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    run(Engine(0), n_iter, seed0)
+    print("fuzz ok:", n_iter, "iterations in %.1f s" % (time.time() - t0))

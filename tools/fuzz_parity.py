@@ -1,5 +1,5 @@
 """Randomised HIP-vs-oracle parity: random genomes, read sets and option mixes, every stage compared bit for bit
-(tests/test_gpu_parity.py: compare_all).  usage: python tools/fuzz_parity.py [iterations] [seed]"""
+(tests/test_gpu_parity.py: compare_all).  usage: [FUZZ_BIG=1] python tools/fuzz_parity.py [iterations] [seed]   (FUZZ_BIG: Mb-size genomes, reads of 8-40 kb)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,14 +11,14 @@ from telr_amd.presets import preset
 
 
 
-def run(eng, n_iter, seed0):
+def run(eng, n_iter, seed0, big=False):
     from test_gpu_parity import compare_all
     for it in range(n_iter):
         rng = np.random.default_rng(seed0 * 1000 + it)
         pname = ["map-ont", "map-ont", "map-pb", "asm10"][int(rng.integers(0, 4))]
         io, mo = preset(pname)
         ntg = int(rng.integers(1, 4))
-        genome = [synth.random_seq(rng, int(rng.integers(20000, 120000))) for _ in range(ntg)]
+        genome = [synth.random_seq(rng, int(rng.integers(300000, 1500000) if big else rng.integers(20000, 120000))) for _ in range(ntg)]
         te = synth.random_seq(rng, int(rng.integers(500, 4000)))
         for g in genome:                                   # repeats: occurrence filter, secondary chains
             for _ in range(int(rng.integers(0, 8))):
@@ -27,7 +27,7 @@ def run(eng, n_iter, seed0):
         if rng.random() < 0.3:
             g = genome[0]; p = int(rng.integers(0, len(g) - 300)); g[p:p + int(rng.integers(1, 300))] = ord("N")
         err = float(rng.uniform(0.0, 0.07))
-        reads, _ = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(400, 9000)), err=(err, err / 2, err))
+        reads, _ = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(8000, 40000) if big else rng.integers(400, 9000)), err=(err, err / 2, err))
         for _ in range(int(rng.integers(0, 3))):           # odd ones: tiny, with Ns, empty
             reads.append(synth.random_seq(rng, int(rng.integers(0, 40))))
         if reads and rng.random() < 0.5:
@@ -58,5 +58,5 @@ if __name__ == "__main__":
     n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    run(Engine(0), n_iter, seed0)
+    run(Engine(0), n_iter, seed0, big=os.environ.get("FUZZ_BIG") is not None)
     print("fuzz ok:", n_iter, "iterations in %.1f s" % (time.time() - t0))

@@ -7,16 +7,21 @@ from telr_amd import synth
 from telr_amd.aligner import Engine
 from telr_amd.presets import preset
 
-d = synth.make_stage1_dataset(seed=20261002, read_seed=20261002 + 1000)
+PRESET = os.environ.get("BAND_PRESET", "map-ont")
+ERR = (0.013, 0.065, 0.052) if PRESET == "map-pb" else (0.04, 0.02, 0.04)       # CLR-like 13 % (1:5:4) / ONT-like 10 % (4:2:4)
+d = synth.make_stage1_dataset(seed=20261002, read_seed=20261002 + 1000, err=ERR)
 eng = Engine(0)
-io, mo = preset("map-ont")
+io, mo = preset(PRESET)
 ix = eng.index([bytes(d["ref"]).decode()], io)
 qs = eng.seqset(d["reads"])
 F = ["qid", "tid", "qs", "qe", "ts", "te", "flags"]
 base = None
+import time
 for q4 in (8, 6, 5, 4, 3):
     m = mo.copy(); m.fill_band_q4 = q4
-    r = ix.map(qs, m)
+    ix.map(qs, m)
+    t0 = time.time(); r = ix.map(qs, m); dt = (time.time() - t0) * 1e3
+    print('  q4=%d: %.1f ms (blocking call), retries %d, dp stage %.1f ms' % (q4, dt, int(eng.L.telr_debug_dp_retries(eng.h)), eng.stage_ms().get('dp', 0)))
     a = r.alns
     if base is None:
         base = a.copy(); print("q4=8 records", len(a), "sum dp_score", int(a["dp_score"].sum()), "sum mlen", int(a["mlen"].sum())); continue

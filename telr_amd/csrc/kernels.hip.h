@@ -1615,7 +1615,8 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
 // few lanes and many registers per problem: LPP = 1 (a whole problem per lane, 64 problems per wave, no cross-lane
 // traffic at all) for bands up to 32 diagonals, LPP = 2 / 4 above.  The loop is unrolled by two steps (even step 2k,
 // odd step 2k+1), which is exactly one row of trace-back dwords: tb32[k*RW + l*R + r], RW = LPP*R, bytes
-// {even pair 0, even pair 1, odd pair 0, odd pair 1}.
+// {even pair 0, even pair 1, odd pair 0, odd pair 1}.  (That is the LOGICAL byte offset inside a problem's matrix; for LPP = 1 the
+// 64 problems of a wave are interleaved in 8-byte units in memory: d_tb_interleaved, k_tb_gather.)
 template <int R> __device__ __forceinline__ void d_push_q(uint32_t (&qb)[R], uint32_t v)
 {
 #pragma unroll

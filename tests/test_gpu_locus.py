@@ -105,3 +105,18 @@ def test_engine_screen_of_alt_sequences(engine, tmp_path):
     assert set(kept) == {"1000", "3000", "4000"}
     assert 0.9 <= kept["1000"] <= 1.0 and kept["3000"] >= 0.9 and 0.6 <= kept["4000"] <= 0.75
     assert texts["hip"][1] == "chr2L_2000_2001\tVCF sequence not repeatmasked\n"
+
+
+@pytest.mark.parametrize("seed,n_ins,reads_per_locus", [(6, 5, 12), (7, 10, 40), (8, 3, 25)])
+def test_locus_bundle_equals_oracle_other_seeds(engine, seed, n_ins, reads_per_locus):
+    """the whole per-locus bundle on further random data sets: every output of the HIP engine equals the oracle's"""
+    from oracle_backend import OracleBackend
+    from locus_data import make_loci
+    ref, lib_names, lib, loci, truth = make_loci(seed=seed, n_ins=n_ins, reads_per_locus=reads_per_locus)
+    io, _ = preset("asm10")
+    out = {}
+    for tag, be in (("hip", engine), ("oracle", OracleBackend())):
+        ref_ix = be.index([ref], io)
+        out[tag] = locus_pipeline.run_loci(be, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
+    for k in ("annotation", "liftover", "summary", "af"):
+        assert out["hip"][k] == out["oracle"][k], k

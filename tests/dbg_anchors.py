@@ -1,3 +1,4 @@
+"""Debug helper (test infrastructure): where do the sorted anchor keys of the HIP engine and of the oracle differ on the bundled fixture?"""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from telr_amd.aligner import Engine

@@ -1,8 +1,8 @@
 """Randomised HIP-vs-oracle parity: random genomes, read sets and option mixes, every stage compared bit for bit
-(tests/test_gpu_parity.py: compare_all).  usage: [FUZZ_BIG=1] python tools/fuzz_parity.py [iterations] [seed]   (FUZZ_BIG: Mb-size genomes, reads of 8-40 kb)"""
+(tests/test_gpu_parity.py: compare_all).  usage: [FUZZ_BIG=1] python tests/fuzz_parity.py [iterations] [seed]   (FUZZ_BIG: Mb-size genomes, reads of 8-40 kb)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle is the checker
 os.environ["TELR_DEBUG"] = "1"
 import numpy as np
 from telr_amd import synth

@@ -1,13 +1,13 @@
 """Randomised parity: random genomes, read sets (tiny / empty / N-containing reads included) and option mixes (k, w, look-back,
 band factor, segment length, band width, gap limit, skip penalty, secondary output, extension limits, all three presets),
-every stage compared bit for bit with the oracle.  `python tools/fuzz_parity.py 800 <seed>` runs the long version."""
+every stage compared bit for bit with the oracle.  `python tests/fuzz_parity.py 800 <seed>` runs the long version."""
 import os
 import sys
 
 import pytest
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [11, 12])

@@ -1,18 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — stage-1 long-read alignment throughput on MI355X (BASELINE.json metric).
+"""bench.py — the BASELINE.json metric: long-read Gbp aligned/s + TE loci/s on MI355X.
 
-A "step" is one pass of the hot path (sketch -> seed -> sort -> chain -> back-track ->
-banded DP + trace-back -> records/CIGARs on the host) over the whole synthetic read set
-of BASELINE.json configs[1] (chr2L-sized genome, 10k ONT-like reads ~20x, 200 spiked TE
-insertions).  The reference index and the packed reads are resident in HBM before the
-timed region.  One process per GPU; reads are sharded per rank (each rank maps its own
-read set against a replicated index, weak scaling, no data-path collective).
+Default workload = BASELINE configs[2] (the configuration the metric is quoted on): a synthetic genome with the eight
+dm6 arm lengths (137,567,484 bp, 15 % diverged TE copies of a 127-family library), 30x ONT-like reads (~4.1 Gbp, mean
+9 kb, 10 % errors 4:2:4), 1,000 spiked TE insertions at allele frequencies 0.25 / 0.5 / 1.0, preset `map-ont`.
+`--config c1` = configs[1] (chr2L-size genome, 10,000 reads, 200 insertions), `c3` = configs[3] (same genome, CLR-like
+reads 13 % 1:5:4, the NGMLR-style convex-gap preset `ngmlr-pacbio`), `c4` = configs[4] (chr22-size target with an 11-Mb
+leading N block, 50x, 1,300-family library, 3,000 insertions).
+
+A "step" = one pass of the stage-1 hot path (sketch -> seed -> sort -> chain -> back-track -> banded DP + trace-back ->
+records/CIGARs on the host) over the rank's WHOLE read set, which the engine streams through in ranges of <= 1 Gbp.
+Index and packed reads are resident in HBM before the timed region (`value`); `value_incl_h2d` adds the packing +
+upload of the reads.  The second half of the metric, TE loci/s, runs the per-locus bundle (S4, S5, S6 fw+rc + depth +
+AF, S7 x2 + liftover) on window reads selected from the ENGINE'S OWN stage-1 records (TELR_assembly.py:384-415).
+
+Multi-GPU: `--gpus N` without RANK in the environment starts N ranks itself (python -m torch.distributed.run, before
+anything touches the GPU) and relays rank 0's line; under torch.distributed.run it is one of the ranks.  `--scaling
+strong` (default): ONE fixed read set dealt to the ranks in blocks by cumulative bases (shard.shard_reads), index
+replicated (built by every rank), no collective on the stage-1 data path; the loci are dealt by LPT, their window reads
+travel to the owner in one all-to-all and the per-locus table is merged by ONE all-gather (RCCL).  `--scaling weak`:
+every rank maps its own 30x read set.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +40,13 @@ if ROOT not in sys.path:
 # the first HIP call of the process.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import numpy as np  # noqa: E402
+CONFIGS = {
+    # name: (BASELINE.json config, chromosomes, coverage, read errors (sub, ins, del), preset, insertions, families, lead N)
+    "c1": dict(label="configs[1]", preset="map-ont", err=(0.04, 0.02, 0.04)),
+    "c2": dict(label="configs[2]", genome="dm6", coverage=30.0, preset="map-ont", err=(0.04, 0.02, 0.04), n_ins=1000, n_fam=127, lead_n=0),
+    "c3": dict(label="configs[3]", genome="dm6", coverage=30.0, preset="ngmlr-pacbio", err=(0.013, 0.065, 0.052), n_ins=1000, n_fam=127, lead_n=0),
+    "c4": dict(label="configs[4]", genome="chr22", coverage=50.0, preset="map-ont", err=(0.04, 0.02, 0.04), n_ins=3000, n_fam=1300, lead_n=11_000_000),
+}
 
 
 def parse():
@@ -33,15 +54,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-len", type=int, default=23513712)
-    ap.add_argument("--reads", type=int, default=10000)
-    ap.add_argument("--read-bases", type=int, default=470_000_000)
-    ap.add_argument("--insertions", type=int, default=200)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--coverage", type=float, default=0.0, help="override the configuration's coverage (experiments)")
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="scale every chromosome length (experiments / CPU smoke tests)")
+    ap.add_argument("--genome-len", type=int, default=23513712, help="c1 only")
+    ap.add_argument("--reads", type=int, default=10000, help="c1 only")
+    ap.add_argument("--read-bases", type=int, default=470_000_000, help="c1 only")
+    ap.add_argument("--insertions", type=int, default=0, help="override the number of spiked insertions")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-25 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--preset", default="map-ont")
+    ap.add_argument("--preset", default="", help="override the configuration's preset")
     ap.add_argument("--fill-band-q4", type=int, default=0, help="experiment: override the preset's first-pass band factor (0 = preset)")
-    ap.add_argument("--loci", type=int, default=200, help="candidate loci for the TE-loci/s leg (0 = skip)")
+    ap.add_argument("--loci", type=int, default=-1, help="candidate loci for the TE-loci/s leg (-1 = all spiked insertions, 0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
     return ap.parse_args()
 
 
@@ -57,14 +84,25 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(ref_str, reads, io, mo, n_sample, gbp_of):
+def launch_ranks(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as children of THIS process, which has
+    not touched the GPU (no torch / HIP import so far), relay their output and exit with their return code."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(ref_strs, reads, io, mo, n_sample):
     """The CPU oracle ("port") timed on a bounded sample of the same read set."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as ob
     cores = usable_cpus()
     buf, off, ln = reads
     t0 = time.time()
-    oix = ob.OracleIndex([ref_str], io)
+    oix = ob.OracleIndex(ref_strs, io)
     t_index = time.time() - t0
     n_sample = min(n_sample, len(ln))
     seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in range(n_sample)]
@@ -80,12 +118,59 @@ def cpu_baseline(ref_str, reads, io, mo, n_sample, gbp_of):
         aligned = sum(ex.map(work, shards))
     dt = time.time() - t0
     return {"value": aligned / dt / 1e9, "unit": "Gbp/s", "cores": len(shards), "kind": "port",
-            "sample": "first %d reads (%d bases) of the same read set, oracle/telr_oracle.c, %d threads, %.1f s; index build %.1f s excluded"
-                      % (n_sample, sum(len(s) for s in seqs), len(shards), dt, t_index)}
+            "sample": "first %d reads (%d bases) of the same read set against the same full-size index, oracle/telr_oracle.c, %d threads, %.1f s; "
+                      "index build %.1f s (one thread) excluded" % (n_sample, sum(len(s) for s in seqs), len(shards), dt, t_index)}
+
+
+def build_dataset(a, cfg, rank, world, lws):
+    """-> dict(names, ref [uint8 arrays], library, reads (buf, off, len), read_gid, insertions-derived loci source, workload text).
+    Runs before the process touches the GPU (the read generator forks workers)."""
+    import numpy as np
+    from telr_amd import synth, shard
+    procs = max(1, usable_cpus() // max(1, lws))
+    if a.config == "c1":
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=a.genome_len, n_reads=a.reads, total_bases=a.read_bases,
+                                      n_ins=a.insertions or 200, read_seed=20261002 + 1000 * ((rank if a.scaling == "weak" else 0) + 1))
+        buf, off, ln = d["reads"]
+        gid = np.arange(len(ln))
+        if a.scaling == "strong" and world > 1:
+            mine = np.array(shard.shard_reads(ln, world)[rank], np.int64)
+            parts = [buf[off[i]:off[i] + ln[i]] for i in mine]
+            ln = ln[mine]; buf = np.concatenate(parts); off = np.cumsum(ln.astype(np.int64)) - ln; gid = mine
+        loci = synth.make_loci_from_dataset(d, len(d["insertions"]))
+        for l in loci:
+            l["chrom"] = "chr2L"; l["start"] = l["truth"]["pos"]; l["end"] = l["truth"]["pos"] + 1; l["truth"]["chrom"] = "chr2L"
+            l.pop("reads", None); l.pop("read_idx", None)
+        text = "synthetic chr2L-size genome (%d bp) + %d ONT-like reads (%.0f Mbp, 10%% error) + %d spiked TE insertions" % (
+            a.genome_len, a.reads, float(d["reads"][2].sum()) / 1e6, len(d["insertions"]))
+        return dict(names=["chr2L"], ref=[d["ref"]], library=d["library"], reads=(buf, off.astype(np.int64), ln.astype(np.int32)), read_gid=gid,
+                    loci=loci, text=text, total_reads=len(d["reads"][2]), total_bases=int(d["reads"][2].sum()))
+    chroms = synth.DM6_ARMS if cfg["genome"] == "dm6" else synth.CHR22
+    if a.genome_scale != 1.0:
+        chroms = [(n, max(30000, int(L * a.genome_scale))) for n, L in chroms]
+    lead_n = int(cfg["lead_n"] * a.genome_scale)
+    g = synth.make_genome(20261002, chroms, n_fam=cfg["n_fam"], n_ins=a.insertions or cfg["n_ins"], lead_n=lead_n, threads=min(procs, 8))
+    cov = a.coverage or cfg["coverage"]
+    plan = synth.plan_reads(g, cov, read_seed=(20261002 + 1000 * (rank + 1)) if a.scaling == "weak" else None)
+    if a.scaling == "strong" and world > 1:
+        blocks = np.array(shard.shard_reads(synth.block_bases(plan), world)[rank], np.int64)
+    else:
+        blocks = np.arange(plan["n_blocks"])
+    buf, off, ln, gid = synth.materialize_reads(g, plan, blocks, err=cfg["err"], procs=procs)
+    loci = synth.make_loci(g)
+    nb = int(sum(len(r) for r in g["ref"]))
+    text = "synthetic %s-size genome (%d sequences, %d bp%s, %d-family TE library, 15%% TE-derived) + %.0fx %s-like reads (%d reads, %.2f Gbp planned, errors sub:ins:del %.3f:%.3f:%.3f) + %d spiked TE insertions (AF 0.25/0.5/1.0)" % (
+        cfg["genome"], len(chroms), nb, (", %d-bp leading N block" % lead_n) if lead_n else "", cfg["n_fam"], cov,
+        "ONT" if cfg["err"][1] < 0.05 else "PacBio-CLR", plan["n"], float(plan["length"].sum()) / 1e9, cfg["err"][0], cfg["err"][1], cfg["err"][2], len(g["insertions"]))
+    return dict(names=g["names"], ref=g["ref"], library=g["library"], reads=(buf, off, ln), read_gid=gid, loci=loci, text=text,
+                total_reads=plan["n"], total_bases=int(plan["length"].sum()))
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a))
+    cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # ranks of one node share its CPUs: each engine sizes its host pool for its share (the library's default is 1.5 x the
@@ -93,45 +178,63 @@ def main():
     lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if lws > 1 and "TELR_HOST_THREADS" not in os.environ:
         os.environ["TELR_HOST_THREADS"] = str(max(4, min(48, usable_cpus() * 3 // (2 * lws))))
+    if a.dry_launch:
+        import torch.distributed as dist
+        dist.init_process_group(a.backend)
+        import torch
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if a.backend == "nccl":
+            torch.cuda.set_device(local); t = t.cuda()
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": int(t.item()), "backend": a.backend}))
+        dist.destroy_process_group()
+        return
+    import numpy as np
+    t0 = time.time()
+    D = build_dataset(a, cfg, rank, world, lws)       # CPU only; forks workers: before any GPU initialisation
+    t_gen = time.time() - t0
+
     import torch
     dist = None
+    device = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at world size 1)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from telr_amd.aligner import Engine
+        if a.backend == "nccl":
+            torch.cuda.set_device(local)
+            device = torch.device("cuda", local)
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(a.backend)
+    from telr_amd.aligner import Engine, _np_from
+    from telr_amd._abi import ALN_DTYPE
     from telr_amd.presets import preset
-    from telr_amd import synth
+    from telr_amd import telr_assembly, locus_pipeline, shard
 
-    io, mo = preset(a.preset)
+    pname = a.preset or cfg["preset"]
+    io, mo = preset(pname)
     if a.fill_band_q4:
         mo.fill_band_q4 = a.fill_band_q4
-    t0 = time.time()
-    # every rank: same genome/insertions (seed), its own reads (seed + rank)
-    d = synth.make_stage1_dataset(seed=20261002, genome_len=a.genome_len, n_reads=a.reads, total_bases=a.read_bases,
-                                  n_ins=a.insertions, read_seed=20261002 + 1000 * (rank + 1))
-    t_gen = time.time() - t0
-    ref_str = bytes(d["ref"]).decode()
+    ref_strs = [bytes(r).decode() for r in D["ref"]]
     eng = Engine(local)
     t0 = time.time()
-    ix = eng.index([ref_str], io)
+    ix = eng.index(ref_strs, io)
     t_index = time.time() - t0
-    qs = eng.seqset(d["reads"])
+    t0 = time.time()
+    qs = eng.seqset(D["reads"])           # 2-bit packing on the host + H2D of this rank's whole read set
+    t_upload = time.time() - t0
     n_bases = qs.bases()
 
     # Steps are streamed the way a stage-1 run over many read batches would be: telr_map returns when the alignment
-    # records are complete, the DMA of the CIGAR array finishes in the background, and a result is released only after
-    # the next call has been issued.  Everything, the last DMA included, is complete before the closing synchronisation.
+    # records are complete, the DMA of the last range's CIGARs finishes in the background, and a result is released only
+    # after the next call has been issued.  Everything, the last DMA included, is complete before the closing synchronisation.
     held = []
 
     def step():
         r = ix.map_raw(qs, mo)
         L = eng.L
-        n = L.telr_result_count(r)
-        from telr_amd.aligner import _np_from
-        from telr_amd._abi import ALN_DTYPE
-        al = _np_from(L.telr_result_alns(r), n, ALN_DTYPE)
+        al = _np_from(L.telr_result_alns(r), L.telr_result_count(r), ALN_DTYPE)
         while held:
             ix.free_raw(held.pop())
         held.append(r)
@@ -148,6 +251,7 @@ def main():
     for _ in range(a.warmup):
         step()
     stage_tot = {}
+    cls_tot = None; ctr_tot = {}; launches = 0; retries = 0
     sync()
     t0 = time.time()
     aligned = 0
@@ -156,115 +260,156 @@ def main():
         aligned += b
         for k, v in eng.stage_ms().items():
             stage_tot[k] = stage_tot.get(k, 0.0) + v
+        c = eng.dp_classes(); cls_tot = c if cls_tot is None else cls_tot + c
+        for k, v in eng.counters().items():
+            ctr_tot[k] = ctr_tot.get(k, 0) + v
+        launches += int(eng.L.telr_debug_pk_launches(eng.h)); retries += int(eng.L.telr_debug_dp_retries(eng.h))
     if held:
         eng.L.telr_result_wait(held[-1])      # the last step's CIGAR array is home as well
     sync()
     dt = time.time() - t0
+    dt_local = dt
     while held:
         ix.free_raw(held.pop())
-    ctr = eng.counters()
+    per_rank_ms = [dt_local / a.steps * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        s = torch.tensor([aligned], dtype=torch.float64, device="cuda"); dist.all_reduce(s, op=dist.ReduceOp.SUM); aligned = float(s.item())
+        dev = device if device is not None else "cpu"
+        t = torch.tensor([dt, t_upload], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt, t_upload_max = float(t[0]), float(t[1])
+        s = torch.tensor([aligned, n_bases], dtype=torch.float64, device=dev); dist.all_reduce(s, op=dist.ReduceOp.SUM); aligned, job_bases = float(s[0]), float(s[1])
+        pr = torch.zeros(world, dtype=torch.float64, device=dev); pr[rank] = dt_local / a.steps * 1e3; dist.all_reduce(pr); per_rank_ms = [float(x) for x in pr.cpu()]
+    else:
+        t_upload_max, job_bases = t_upload, float(n_bases)
+    value = aligned / dt / 1e9
+    value_h2d = aligned / (dt + a.steps * t_upload_max) / 1e9
+
+    # ---- TE loci/s: the per-locus bundle on window reads taken from THIS run's stage-1 records -----------------------
+    loci_out = None
+    n_loci = len(D["loci"]) if a.loci < 0 else min(a.loci, len(D["loci"]))
+    if n_loci > 0:
+        loci = D["loci"][:n_loci]
+        io10, _ = preset("asm10")
+        ix10 = eng.index(ref_strs, io10)
+        lib_names = ["fam%d" % i for i in range(len(D["library"]))]
+        lib = [bytes(x).decode() for x in D["library"]]
+        chrom_ids = {n: i for i, n in enumerate(D["names"])}
+        ref_of = dict(zip(D["names"], ref_strs))
+        presets_arg = "ont" if cfg["err"][1] < 0.05 else "pacbio"
+        shards = shard.shard_loci([locus_pipeline.locus_cost(l) for l in loci], world)
+        owner = {}
+        for r_, lst in enumerate(shards):
+            for i in lst:
+                owner[i] = r_
+        rbuf, roff, rln = D["reads"]
+
+        def loci_pass():
+            # a12: every read with ANY stage-1 record overlapping [bp-1000, bp+1000) (TELR_assembly.py:384-415), from the
+            # records of the last step (this rank's reads)
+            wr = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])
+            if world == 1:
+                for l, idx in zip(loci, wr):
+                    l["read_idx"] = idx.astype(np.int32)
+                return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, shards=shards,
+                                                           presets=presets_arg, read_set=qs)
+            items = []
+            for li, idx in enumerate(wr):
+                for i in idx:
+                    items.append((owner[li], li, int(D["read_gid"][i]), rbuf[roff[i]:roff[i] + rln[i]]))
+            got = shard.exchange_window_reads(items, dist, device)
+            for l in loci:
+                l["reads"] = []
+            for (li, gid, b) in got:
+                loci[li]["reads"].append(bytes(b).decode())
+            return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
+                                                       shards=shards, presets=presets_arg)
+        loci_pass()                                # warm-up (sizes the scratch)
+        sync()
+        t0 = time.time()
+        rows, lres = loci_pass()
+        sync()
+        t_loci = time.time() - t0
+        if dist is not None:
+            t = torch.tensor([t_loci], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_loci = float(t[0])
+        good = 0; af_ok = 0; n_rows = len(rows)
+        fam_of = {i: n for i, n in enumerate(lib_names)}
+        for r in rows:
+            l = loci[int(r["locus_id"])]; tr = l["truth"]
+            if r["type"] == 1 and r["chrom_id"] == chrom_ids[tr["chrom"]] and abs(int(r["start"]) - tr["pos"]) <= 20 and \
+                    (1 if tr["strand"] == "+" else -1) == r["strand"] and r["n_family"] >= 1 and fam_of[int(r["family_id"][0])] == tr["family"]:
+                good += 1
+                if not np.isnan(r["af"]) and abs(float(r["af"]) - tr["af"]) <= 0.15:
+                    af_ok += 1
+        wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]
+        loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok,
+                    "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0,
+                    "collectives": "none" if world == 1 else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
+                    "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
+                            "truth-derived stand-ins for wtdbg2 / Sniffles (absent on the box)"}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    value = aligned / dt / 1e9
-    # truth check on the last step: primary alignment overlaps the simulated origin (haplotype coordinates differ from
-    # reference coordinates by at most the inserted TE bases upstream, so compare loosely)
+
     prim = al[(al["flags"] & 1) != 0]
-    frac_mapped = len(np.unique(prim["qid"])) / max(1, len(d["reads"][2]))
-    # roofline of the dominant kernel: k_dp_pk, the packed-int16 gap-fill DP (DP classes 10-17, gap fills by band width, in one cost-ordered launch).  Its
-    # launch duration is measured live with HIP events on the engine's own stream (telr_stage_ms: "k_dp_pk"); its
-    # algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per CIGAR
-    # run, 32 B result.
-    cls = eng.dp_classes()
+    frac_mapped = len(np.unique(prim["qid"])) / max(1, len(D["reads"][2]))
+    # roofline of the dominant kernel: k_dp_pk, the packed-int16 gap-fill DP (DP classes 10-17, gap fills by band width, in one cost-ordered launch
+    # per range and lane).  Its launch durations are measured live with HIP events on the engine's own streams (telr_stage_ms: "k_dp_pk", summed
+    # over the launches); its algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per CIGAR run,
+    # 32 B result.
+    cls = cls_tot
     PK = list(range(10, 18))
     k_name = "k_dp_pk"
-    k_ms = stage_tot.get("k_dp_pk", 0.0) / a.steps
-    k_bytes = float(cls[PK, 3].sum())
-    achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    def _pmc2(path, kern, counter):
-        for line in open(os.path.join(ROOT, "profiles", path)):
-            f = line.split()
-            if line.startswith(kern) and counter in f:
-                return float(f[-2]) / 3.0
-        return None
-    traffic, traffic_src = None, None
-    try:   # HBM bytes per launch from the committed PMC passes of this same command (profiles/, separate --pmc runs)
-        def _pmc(path, kern):
-            for line in open(os.path.join(ROOT, "profiles", path)):
-                if line.startswith(kern):
-                    return float(line.split()[-2]) / 3.0     # sum over the PMC run's three map calls (two set-up calls + one step), per call
-            return None
-        fs = _pmc("r01_pmc_FETCH_SIZE.txt", k_name + " "); ws = _pmc("r01_pmc_WRITE_SIZE.txt", k_name + " ")
-        if fs is not None and ws is not None and a.reads == 10000 and a.read_bases == 470_000_000:
-            traffic = (2.0 * fs + ws) * 1024.0      # gfx950: FETCH_SIZE counts wide reads at 1/2 (MI355X_MICROARCH.md, HBM)
-            traffic_src = ("profiles/r01_pmc_{FETCH,WRITE}_SIZE.txt (KB per map call; FETCH doubled as for wide streaming reads: an upper bound, "
-                           "scattered 64-byte reads calibrate at 1.0 and 40-byte write pieces at 1.47, tools/ubench/tb_pattern.hip)")
-    except Exception:
-        pass
-    issue_frac = None
-    try:   # integer-issue utilisation of the same kernel from the committed SQ counter pass (the roof that actually binds it)
-        vi = _pmc2("r01_pmc_SQ.txt", k_name + " ", "SQ_INSTS_VALU"); ga = _pmc2("r01_pmc_SQ.txt", k_name + " ", "GRBM_GUI_ACTIVE")
-        if vi and ga:
-            issue_frac = (vi * 4.0 / 1024.0) / (ga / 8.0)      # 4 cycles per wave64 VALU instruction, 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+    launches = max(1, launches)
+    k_ms_tot = stage_tot.get("k_dp_pk", 0.0)
+    k_bytes_tot = float(cls[PK, 3].sum())
+    achieved = k_bytes_tot / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else 0.0
+    k_ms = k_ms_tot / launches
+    traffic, traffic_src, issue = None, None, None
+    try:   # HBM bytes / VALU issue per launch from the committed PMC passes of this same command (profiles/, separate --pmc runs)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_k_dp_pk.json")))
+        if pm.get("config") == a.config and not a.preset and not a.coverage and a.genome_scale == 1.0:
+            traffic = pm["traffic_bytes_per_launch"]; traffic_src = pm["source"]; issue = pm.get("valu_issue")
     except Exception:
         pass
     dp_ms = stage_tot.get("dp", 0.0) / a.steps
+    ctr = {k: v / a.steps for k, v in ctr_tot.items()}
     # whole-path algorithmic bytes (SURVEY 8d formula) for reference
     path_bytes = (ctr["query_bases"] / 4.0 + 32.0 * ctr["minimizers"] + 16.0 * ctr["probes"] + 48.0 * ctr["anchors"]
                   + ctr["window_bases"] / 4.0 + 4.0 * ctr["cigar_ops"] + 64.0 * ctr["records"])
     gpu_ms = sum(v for k, v in stage_tot.items() if k not in ("select_host", "assemble_host", "index_build", "k_dp_reg", "map_wall", "k_traceback", "k_dp_pk")) / a.steps
     out = {
         "metric": "gbp_aligned_per_s", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "int16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic chr2L-size genome (%d bp) + %d ONT-like reads (%.0f Mbp per GPU, 10%% error) + %d spiked TE insertions, preset %s, stage-1 reads->reference"
-                               % (a.genome_len, a.reads, n_bases / 1e6, a.insertions, a.preset),
-                   "reads_per_gpu": a.reads, "read_bases_per_gpu": n_bases, "parallelism": "reads sharded x%d, index replicated" % world,
+        "value_incl_h2d": value_h2d, "h2d_pack_upload_s": t_upload_max,
+        "config": {"workload": "BASELINE %s: %s, preset %s, stage-1 reads->reference" % (cfg["label"], D["text"], pname),
+                   "reads_this_rank": int(len(D["reads"][2])), "read_bases_this_rank": n_bases, "read_bases_job": job_bases,
+                   "parallelism": ("one fixed read set dealt to %d ranks in blocks by cumulative bases" % world if a.scaling == "strong" else "every rank maps its own read set (x%d)" % world)
+                                  + "; index replicated (built by every rank, no broadcast); no collective on the stage-1 data path",
+                   "ranges": "the engine streams the rank's read set through in ranges of <= 1 Gbp (one telr_map call per step)",
                    "streaming": "telr_map returns with the records; the CIGAR DMA of step k overlaps step k+1 (all complete inside the timed region)"},
+        "per_rank_ms_per_step": per_rank_ms, "rccl_world_size": world if dist is not None else 0,
         "roofline": {"bound": "hbm", "kernel": k_name, "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": traffic, "traffic_source": traffic_src, "valu_issue_frac": issue_frac, "launch_ms": k_ms, "algorithmic_bytes_per_launch": k_bytes,
-                     "problems_per_launch": int(cls[PK, 0].sum()), "cells_per_launch": int(cls[PK, 1].sum()),
-                     "gcups": float(cls[PK, 1].sum()) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None,
-                     "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); all DP kernels together: %.1f ms, %.0f GCUPS"
+                     "traffic": traffic, "traffic_source": traffic_src, "valu_issue": issue, "launch_ms": k_ms, "launches_per_step": launches / a.steps,
+                     "algorithmic_bytes_per_launch": k_bytes_tot / launches,
+                     "problems_per_launch": float(cls[PK, 0].sum()) / launches, "cells_per_launch": float(cls[PK, 1].sum()) / launches,
+                     "gcups": float(cls[PK, 1].sum()) / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else None,
+                     "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); all DP kernels together: %.1f ms per step, %.0f GCUPS"
                              % (dp_ms, ctr["dp_cells"] / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0)},
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_tot.items()},
-        "dp_classes": {str(c): [int(x) for x in cls[c]] for c in range(cls.shape[0]) if cls[c, 0]},
+        "dp_classes": {str(c): [int(x) // a.steps for x in cls[c]] for c in range(cls.shape[0]) if cls[c, 0]},
         "path_algorithmic_GBps": path_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
         "frac_reads_mapped": frac_mapped, "index_build_s": t_index, "datagen_s": t_gen, "device": eng.device_name(),
-        "counters": ctr, "dp_retries": int(eng.L.telr_debug_dp_retries(eng.h)),
+        "counters": ctr, "dp_retries": retries // a.steps,
     }
-    if a.loci > 0:
-        # second half of the BASELINE metric: TE loci/s through the per-locus bundle (S4, S5, S6 fw+rc + depth + AF,
-        # S7 x2 + liftover).  Asm10 index of the same reference; loci = the spiked insertions (truth-derived contigs).
-        from telr_amd import locus_pipeline
-        loci = synth.make_loci_from_dataset(d, min(a.loci, len(d["insertions"])))
-        io10, _ = preset("asm10")
-        ix10 = eng.index([ref_str], io10)
-        lib_names = ["fam%d" % i for i in range(len(d["library"]))]
-        lib = [bytes(x).decode() for x in d["library"]]
-        # window reads are taken from the stage-1 read set already on the device (telr_seqset_subset)
-        locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib, read_set=qs)      # warm-up (sizes the scratch)
-        t0 = time.time()
-        lres = locus_pipeline.run_loci(eng, ix10, ["chr2L"], lambda ch: ref_str, loci, lib_names, lib, read_set=qs)
-        t_loci = time.time() - t0
-        good = 0
-        by = {"_".join(r["ID"].split("_")[:3]): r["report"] for r in lres["liftover"]}
-        for l in loci:
-            r = by.get(l["name"])
-            if r and r["type"] == "non-reference" and abs(r["start"] - l["truth"]["pos"]) <= 20 and r["strand"] == l["truth"]["strand"] and r["family"] == l["truth"]["family"]:
-                good += 1
-        out["te_loci_per_s"] = len(loci) / t_loci
-        out["te_loci"] = {"n": len(loci), "seconds": t_loci, "recovered_exact_family_strand_pos20": good,
-                          "note": "host glue (Python) included; per-locus inputs are truth-derived (no Sniffles/wtdbg2 on the box)"}
+    if loci_out is not None:
+        out["te_loci_per_s"] = loci_out["n"] / loci_out["seconds"]
+        out["te_loci"] = loci_out
     if not a.no_cpu_baseline:
-        ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(d["reads"][2]))))   # ~15-20 s of CPU work
-        out["cpu_baseline"] = cpu_baseline(ref_str, d["reads"], io, mo, ns, None)
+        ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(D["reads"][2]))))   # ~15-20 s of CPU work
+        out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
     print(json.dumps(out))
+    sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -128,7 +128,9 @@ const char *telr_last_error(const telr_ctx *ctx);   /* text of the last HIP erro
 int  telr_device_name(const telr_ctx *ctx, char *buf, int buflen);
 
 /* ---- presets: the -x values the reference passes -------------------------- */
-/* name in {"map-ont","map-pb","asm10","ngmlr-ont","ngmlr-pacbio"}; returns TELR_E_ARG otherwise */
+/* name in {"map-ont","map-pb","asm10","ngmlr-ont","ngmlr-pacbio"}; returns TELR_E_ARG otherwise.
+ * ngmlr-*: the stage-1 default of the reference (`ngmlr -x ont|pacbio`, TELR_alignment.py:28-51): (w,k) = (5,13)
+ * minimizers (NGMLR's 13-mers at every third position) and NGMLR's convex gap cost as its two-piece affine envelope. */
 int  telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo);
 
 /* ---- sequence sets --------------------------------------------------------- */
@@ -179,6 +181,11 @@ int  telr_write_paf(const telr_result *r, const char *const *qnames, const char 
 #define TELR_SAM_CS          0x2   /* --cs */
 #define TELR_SAM_SOFTCLIP    0x4   /* -Y  */
 #define TELR_SAM_NO_UNMAPPED 0x8
+#define TELR_SAM_PRIMARY_ONLY 0x10 /* drop secondary and supplementary records: `samtools view -F0x900`          */
+#define TELR_SAM_SORTED      0x20  /* coordinate order (target, position; unmapped last): `samtools sort`         */
+#define TELR_SAM_NO_HEADER   0x40  /* records only, as `samtools view` without -h.  PRIMARY_ONLY|SORTED|NO_HEADER =
+                                      the text `samtools view -F0x900 sorted.bam` pipes into wtpoa-cns at the
+                                      polishing site (hand-off H3, src/telr/TELR_assembly.py:208,228)                */
 /* sequences are needed for SEQ, NM, MD and cs: concatenated ASCII + offsets + lengths as in telr_seqset_create.
  * rg_id NULL = no @RG line / RG tag (minimap2 sites); NGMLR site passes --rg-id/--rg-sm/--rg-lb. */
 int  telr_write_sam(const telr_result *r, int32_t n_queries, const char *const *qnames, const char *q_ascii, const int64_t *q_off,

@@ -159,6 +159,8 @@ typedef struct tor_index {
     int64_t n_ent;
     uint64_t *ent_hash;   /* [n_ent] distinct hashes ascending */
     uint32_t *ent_off;    /* [n_ent+1] */
+    /* per target: the occurrence counts of its own distinct minimizers, ascending (for the per-target cut-off) */
+    uint32_t **pt_cnt; int64_t *pt_n;
 } tor_index;
 
 typedef struct { uint64_t h; uint32_t y; } hy_t;
@@ -168,6 +170,14 @@ static int cmp_hy(const void *a, const void *b)
     if (p->h != q->h) return p->h < q->h ? -1 : 1;
     return p->y < q->y ? -1 : p->y > q->y;
 }
+
+static inline int32_t tid_of_gpos(const tor_index *ix, uint32_t g)
+{
+    int32_t lo = 0, hi = ix->n_seq - 1;
+    while (lo < hi) { int32_t mid = (lo + hi + 1) >> 1; if (ix->goff[mid] <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
 
 tor_index *tor_index_build(int32_t n, const char *ascii, const int64_t *off, const int32_t *len,
                            const telr_idx_opt *io)
@@ -200,6 +210,22 @@ tor_index *tor_index_build(int32_t n, const char *ascii, const int64_t *off, con
     for (int64_t i = 0; i < v.n; ++i) if (i == 0 || t[i].h != t[i-1].h) { ix->ent_hash[ne] = t[i].h; ix->ent_off[ne++] = (uint32_t)i; }
     ix->ent_off[ne] = (uint32_t)v.n;
     free(t); free(v.a);
+    /* per-target counts: inside one hash group the positions ascend, i.e. they are grouped by target */
+    ix->pt_cnt = (uint32_t**)calloc(n ? n : 1, sizeof(uint32_t*)); ix->pt_n = (int64_t*)calloc(n ? n : 1, 8);
+    int64_t *cap = (int64_t*)calloc(n ? n : 1, 8);
+    for (int64_t e = 0; e < ix->n_ent; ++e) {
+        uint32_t o = ix->ent_off[e], o1 = ix->ent_off[e + 1];
+        while (o < o1) {
+            int32_t tid = tid_of_gpos(ix, ix->ys[o] >> 1);
+            uint32_t z = o + 1;
+            while (z < o1 && (ix->ys[z] >> 1) < ix->goff[tid + 1]) ++z;
+            if (ix->pt_n[tid] == cap[tid]) { cap[tid] = cap[tid] ? cap[tid] * 2 : 64; ix->pt_cnt[tid] = (uint32_t*)realloc(ix->pt_cnt[tid], 4 * cap[tid]); }
+            ix->pt_cnt[tid][ix->pt_n[tid]++] = z - o;
+            o = z;
+        }
+    }
+    for (int i = 0; i < n; ++i) if (ix->pt_n[i]) qsort(ix->pt_cnt[i], ix->pt_n[i], 4, cmp_u32);
+    free(cap);
     return ix;
 }
 
@@ -207,6 +233,8 @@ void tor_index_free(tor_index *ix)
 {
     if (!ix) return;
     for (int i = 0; i < ix->n_seq; ++i) free(ix->seq[i]);
+    for (int i = 0; i < ix->n_seq; ++i) free(ix->pt_cnt[i]);
+    free(ix->pt_cnt); free(ix->pt_n);
     free(ix->seq); free(ix->len); free(ix->goff); free(ix->hash); free(ix->ys); free(ix->ent_hash); free(ix->ent_off); free(ix);
 }
 
@@ -216,8 +244,6 @@ void tor_index_dump(const tor_index *ix, uint64_t *hash, uint32_t *ys)
 {
     memcpy(hash, ix->hash, 8 * ix->n_mz); memcpy(ys, ix->ys, 4 * ix->n_mz);
 }
-
-static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b; return x < y ? -1 : x > y; }
 
 /* occurrence cut-off: the (1-f) quantile of the distinct-minimizer counts, +1, clamped */
 int32_t tor_mid_occ(const tor_index *ix, float frac, int32_t lo, int32_t hi)
@@ -239,6 +265,23 @@ int32_t tor_mid_occ(const tor_index *ix, float frac, int32_t lo, int32_t hi)
     return occ;
 }
 
+/* the same rule on ONE target's own minimizers: what an aligner run against that target alone would use (the
+ * reference runs minimap2 once per contig at the per-locus sites, TELR_te.py:68-78,119-132,504-506) */
+int32_t tor_mid_occ_target(const tor_index *ix, int32_t t, float frac, int32_t lo, int32_t hi)
+{
+    int64_t n = ix->pt_n[t];
+    int32_t occ;
+    if (n == 0) occ = lo;
+    else {
+        int64_t idx = (int64_t)((1.0 - (double)frac) * (double)n);
+        if (idx >= n) idx = n - 1;
+        occ = (int32_t)ix->pt_cnt[t][idx] + 1;
+    }
+    if (occ < lo) occ = lo;
+    if (hi > lo && occ > hi) occ = hi;
+    return occ;
+}
+
 static inline int64_t index_lookup(const tor_index *ix, uint64_t h)
 {
     int64_t lo = 0, hi = ix->n_ent - 1;
@@ -248,13 +291,6 @@ static inline int64_t index_lookup(const tor_index *ix, uint64_t h)
         if (ix->ent_hash[mid] < h) lo = mid + 1; else hi = mid - 1;
     }
     return -1;
-}
-
-static inline int32_t tid_of_gpos(const tor_index *ix, uint32_t g)
-{
-    int32_t lo = 0, hi = ix->n_seq - 1;
-    while (lo < hi) { int32_t mid = (lo + hi + 1) >> 1; if (ix->goff[mid] <= g) lo = mid; else hi = mid - 1; }
-    return lo;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -271,24 +307,45 @@ static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t
 #define A_Q(k)    ((int32_t)(((k) >> 8) & 0xffffff))
 #define A_SPAN(k) ((int32_t)((k) & 0xff))
 
-static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int32_t tfilter, int32_t mid_occ,
+static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int32_t tfilter, int32_t mid_occ, const telr_map_opt *mo,
                             u64v_t *out, int64_t *n_mz, int64_t *n_probe)
 {
     mzv_t mv = {0, 0, 0};
     sketch(q, qlen, ix->k, ix->w, ix->hpc, 0, &mv);
     *n_mz += mv.n;
+    const int per_t = tfilter < 0 && (mo->flags & TELR_MF_PER_TARGET);
     uint32_t g0 = 0, g1 = 0xffffffffu;
-    if (tfilter >= 0) { g0 = ix->goff[tfilter]; g1 = g0 + (uint32_t)ix->len[tfilter]; }
+    if (tfilter >= 0) {
+        g0 = ix->goff[tfilter]; g1 = g0 + (uint32_t)ix->len[tfilter];
+        mid_occ = tor_mid_occ_target(ix, tfilter, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ);
+    }
     for (int64_t i = 0; i < mv.n; ++i) {
         int64_t e = index_lookup(ix, mv.a[i].x >> 8);
         ++*n_probe;
         if (e < 0) continue;
         uint32_t o0 = ix->ent_off[e], o1 = ix->ent_off[e + 1];
+        int32_t span = (int32_t)(mv.a[i].x & 0xff), qpos = (int32_t)(mv.a[i].y >> 1), qz = (int32_t)(mv.a[i].y & 1);
+        if (per_t) {
+            /* one run of occurrences per target; each run is tested against its target's own cut-off */
+            for (uint32_t o = o0; o < o1; ) {
+                int32_t tid = tid_of_gpos(ix, ix->ys[o] >> 1);
+                uint32_t z = o + 1;
+                while (z < o1 && (ix->ys[z] >> 1) < ix->goff[tid + 1]) ++z;
+                if ((int32_t)(z - o) <= tor_mid_occ_target(ix, tid, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ))
+                    for (uint32_t y = o; y < z; ++y) {
+                        uint32_t g = ix->ys[y] >> 1; int tz = ix->ys[y] & 1;
+                        uint64_t key = tz == qz ? (uint64_t)g << 32 | (uint64_t)qpos << 8 | (uint64_t)span
+                                                : KEY_REV | (uint64_t)g << 32 | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
+                        vpush(uint64_t, *out, key);
+                    }
+                o = z;
+            }
+            continue;
+        }
         int32_t cnt = 0;
         if (tfilter >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t g = ix->ys[o] >> 1; if (g >= g0 && g < g1) ++cnt; } }
         else cnt = (int32_t)(o1 - o0);
         if (cnt == 0 || cnt > mid_occ) continue;
-        int32_t span = (int32_t)(mv.a[i].x & 0xff), qpos = (int32_t)(mv.a[i].y >> 1), qz = (int32_t)(mv.a[i].y & 1);
         for (uint32_t o = o0; o < o1; ++o) {
             uint32_t g = ix->ys[o] >> 1;
             if (tfilter >= 0 && (g < g0 || g >= g1)) continue;
@@ -760,7 +817,7 @@ tor_result *tor_map(const tor_index *ix, int32_t nq, const char *ascii, const in
         for (int i = 0; i < qlen; ++i) q[i] = NT4[(uint8_t)ascii[off[qi] + i]];
         R->ctr.query_bases += qlen;
         u64v_t an = {0, 0, 0};
-        collect_anchors(ix, q, qlen, qtarget ? qtarget[qi] : -1, mid_occ, &an, &R->ctr.minimizers, &R->ctr.probes);
+        collect_anchors(ix, q, qlen, qtarget ? qtarget[qi] : -1, mid_occ, mo, &an, &R->ctr.minimizers, &R->ctr.probes);
         R->ctr.anchors += an.n;
         int32_t *f = (int32_t*)malloc(4 * (an.n ? an.n : 1)), *p = (int32_t*)malloc(4 * (an.n ? an.n : 1));
         chain_dp(an.a, an.n, mo, f, p);

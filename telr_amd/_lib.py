@@ -68,6 +68,7 @@ def lib():
     # debug taps (not part of the public header; used by the stage-level parity tests)
     L.telr_debug_n_anchor.restype = i64; L.telr_debug_n_anchor.argtypes = [vp]
     L.telr_debug_dp_retries.restype = i64; L.telr_debug_dp_retries.argtypes = [vp]
+    L.telr_debug_pk_launches.restype = i64; L.telr_debug_pk_launches.argtypes = [vp]
     L.telr_debug_fetch.restype = C.c_int; L.telr_debug_fetch.argtypes = [vp, cp, vp, i64]
     L.telr_debug_n_chain.restype = i64; L.telr_debug_n_chain.argtypes = [vp]
     L.telr_debug_chains.restype = vp; L.telr_debug_chains.argtypes = [vp]

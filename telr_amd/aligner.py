@@ -179,15 +179,19 @@ class Index:
         qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
         self.eng._chk(self.eng.L.telr_write_paf(r, qa, ta, 1 if with_cigar else 0, path.encode(), 1 if append else 0), "telr_write_paf")
 
-    def write_sam(self, r, qnames, queries, tnames, targets, path, md=True, cs=True, softclip=True, rg=None, cmdline="telr_map"):
-        """queries / targets: lists of sequences (str) or (buf, off, len) triples as given to seqset()."""
+    def write_sam(self, r, qnames, queries, tnames, targets, path, md=True, cs=True, softclip=True, rg=None, cmdline="telr_map",
+                  primary_only=False, coordinate_sorted=False, header=True, unmapped=True):
+        """queries / targets: lists of sequences (str) or (buf, off, len) triples as given to seqset().
+        primary_only + coordinate_sorted + header=False = the text of `samtools view -F0x900 sorted.bam`
+        (the polishing hand-off to wtpoa-cns, TELR_assembly.py:208,228)."""
         qb, qo, ql = queries if isinstance(queries, tuple) else concat(queries)
         tb, to, tl = targets if isinstance(targets, tuple) else concat(targets)
         qb = np.ascontiguousarray(qb, np.uint8); tb = np.ascontiguousarray(tb, np.uint8)
         qo = np.ascontiguousarray(qo, np.int64); to = np.ascontiguousarray(to, np.int64)
         ql = np.ascontiguousarray(ql, np.int32); tl = np.ascontiguousarray(tl, np.int32)
         qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
-        flags = (1 if md else 0) | (2 if cs else 0) | (4 if softclip else 0)
+        flags = (1 if md else 0) | (2 if cs else 0) | (4 if softclip else 0) | (0 if unmapped else 8) | (16 if primary_only else 0) | \
+            (32 if coordinate_sorted else 0) | (0 if header else 64)
         rg_id, rg_sm, rg_lb = (None, None, None) if rg is None else tuple(x.encode() for x in rg)
         self.eng._chk(self.eng.L.telr_write_sam(r, len(ql), qa, qb.ctypes.data, qo.ctypes.data, ql.ctypes.data, len(tl), ta,
                                                 tb.ctypes.data, to.ctypes.data, tl.ctypes.data, flags, rg_id, rg_sm, rg_lb,

@@ -603,6 +603,9 @@ struct SeedArgs {
     const int32_t *qtarget;      // nullable
     const int32_t *q_order;      // block -> query (longest first), nullable
     int32_t mid_occ;
+    const int32_t *tmid;         // per-target occurrence cut-offs [n_targets] (nullable: the pooled cut-off mid_occ applies)
+    int32_t per_target;          // qtarget < 0: filter and count a minimizer's occurrences separately inside every target
+    int32_t n_targets;
     int32_t *mz_cnt;             // MODE 0 out
     int32_t *mz_ent;             // MODE 0 out / MODE 1 in: first occurrence of the minimizer in `pos` (saves the second probe)
     int32_t *mz_n;               // MODE 0 out / MODE 1 in: its occurrence count (0 = absent)
@@ -610,14 +613,28 @@ struct SeedArgs {
     uint64_t *keys;              // MODE 1 out
 };
 
+// target holding global position g (goff ascending, goff[n] = end)
+__device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n, uint32_t g)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (goff[mid] <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// A query restricted to one target (qtarget >= 0) and the per-target mode stand for the reference's separate runs of the
+// aligner against every contig (TELR_te.py:68-78,119-132,504-506; TELR_assembly.py:199-212): a minimizer's occurrences are
+// counted inside the target and compared with THAT target's cut-off (tmid), so a TE k-mer shared by hundreds of contigs
+// is not masked as repetitive.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 {
     const int q = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
     const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
     const int tf = A.qtarget ? A.qtarget[q] : -1;
+    const bool pt = tf < 0 && A.per_target && A.tmid;
     uint32_t g0 = 0, g1 = 0xffffffffu;
     if (tf >= 0) { g0 = A.I.goff[tf]; g1 = g0 + (uint32_t)A.I.tlen[tf]; }
+    const int32_t occ = (tf >= 0 && A.tmid) ? A.tmid[tf] : A.mid_occ;
     const int qlen = A.qlen[q];
     for (int g = m0 + threadIdx.x; g < m1; g += blockDim.x) {
         uint64_t x = A.mz_x[g];
@@ -631,11 +648,36 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             if (A.mz_aoff[g + 1] == A.mz_aoff[g]) continue;
             o0 = (uint32_t)A.mz_ent[g]; o1 = o0 + (uint32_t)A.mz_n[g];
         }
+        if (pt) {
+            // occurrences are sorted by global position, i.e. grouped by target: one run per target
+            int32_t total = 0, w = MODE == 1 ? A.mz_aoff[g] : 0;
+            uint64_t kf = 0, kr = 0; int32_t qz = 0;
+            if (MODE == 1) {
+                const uint32_t y = A.mz_y[g];
+                const int32_t span = (int32_t)(x & 0xff), qpos = (int32_t)(y >> 1); qz = (int32_t)(y & 1);
+                kf = (uint64_t)qpos << 8 | (uint64_t)span;
+                kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
+            }
+            uint32_t o = o0;
+            while (o < o1) {
+                const int t = d_tid_of(A.I.goff, A.n_targets, A.I.pos[o] >> 1);
+                const uint32_t gend = A.I.goff[t + 1];
+                uint32_t e = o + 1;
+                while (e < o1 && (A.I.pos[e] >> 1) < gend) ++e;
+                if ((int32_t)(e - o) <= A.tmid[t]) {
+                    total += (int32_t)(e - o);
+                    if (MODE == 1) for (uint32_t z = o; z < e; ++z) { const uint32_t py = A.I.pos[z]; A.keys[w++] = ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32; }
+                }
+                o = e;
+            }
+            if (MODE == 0) A.mz_cnt[g] = total;
+            continue;
+        }
         int32_t cnt = 0;
         if (o1 > o0) {
             if (tf >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t gp = A.I.pos[o] >> 1; cnt += (gp >= g0 && gp < g1) ? 1 : 0; } }
             else cnt = (int32_t)(o1 - o0);
-            if (cnt > A.mid_occ) cnt = 0;
+            if (cnt > occ) cnt = 0;
         }
         if (MODE == 0) A.mz_cnt[g] = cnt;
         else if (cnt > 0) {
@@ -651,6 +693,60 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             }
         }
     }
+}
+
+// ---- per-target occurrence counts of an index (for the per-target cut-offs) ----------------------------
+// run = the occurrences of one minimizer inside one target (contiguous in `pos`: sorted by hash, then position)
+__global__ void k_pt_entry_heads(const uint32_t *__restrict__ ent_off, int32_t n_ent, int32_t *__restrict__ head)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_ent) head[ent_off[e]] = 1;
+}
+__global__ void k_pt_run_heads(const uint32_t *__restrict__ pos, int64_t n, const uint32_t *__restrict__ goff, int n_targets, int32_t *__restrict__ head, int32_t *__restrict__ tid)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = d_tid_of(goff, n_targets, pos[i] >> 1);
+    tid[i] = t;
+    if (i > 0 && !head[i] && d_tid_of(goff, n_targets, pos[i - 1] >> 1) != t) head[i] = 1;
+}
+__global__ void k_pt_run_starts(const int32_t *__restrict__ head, const int32_t *__restrict__ rank, int64_t n, int32_t *__restrict__ start, int32_t n_runs)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && head[i]) start[rank[i]] = (int32_t)i;
+    if (i == 0) start[n_runs] = (int32_t)n;
+}
+__global__ void k_pt_run_keys(const int32_t *__restrict__ start, const int32_t *__restrict__ tid, int32_t n_runs, uint64_t *__restrict__ key)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_runs) key[r] = (uint64_t)(uint32_t)tid[start[r]] << 32 | (uint32_t)(start[r + 1] - start[r]);
+}
+// first run of every target in the sorted keys
+__global__ void k_pt_target_off(const uint64_t *__restrict__ key, int32_t n_runs, int32_t n_targets, int32_t *__restrict__ off)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_targets) return;
+    const uint64_t want = (uint64_t)(uint32_t)t << 32;
+    int lo = 0, hi = n_runs;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (key[mid] < want) lo = mid + 1; else hi = mid; }
+    off[t] = lo;
+}
+// the -f quantile of a target's own counts, +1, clamped: the same rule as the pooled cut-off (index_mid_occ)
+__global__ void k_pt_mid_occ(const uint64_t *__restrict__ key, const int32_t *__restrict__ off, int32_t n_targets, float frac, int32_t lo_occ, int32_t hi_occ, int32_t *__restrict__ tmid)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_targets) return;
+    const int64_t n = off[t + 1] - off[t];
+    int32_t occ;
+    if (n == 0) occ = lo_occ;
+    else {
+        int64_t idx = (int64_t)((1.0 - (double)frac) * (double)n);
+        if (idx >= n) idx = n - 1;
+        occ = (int32_t)(uint32_t)(key[off[t] + idx] & 0xffffffffu) + 1;
+    }
+    if (occ < lo_occ) occ = lo_occ;
+    if (hi_occ > lo_occ && occ > hi_occ) occ = hi_occ;
+    tmid[t] = occ;
 }
 
 __global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t n, int32_t tail, int32_t *__restrict__ dst)

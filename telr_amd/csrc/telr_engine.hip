@@ -53,6 +53,7 @@ struct telr_ctx {
     hipEvent_t evk[6] = {nullptr};        // un-synchronised markers around single kernels
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     int64_t dp_retries = 0;
+    int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
     telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
     int n_child = 0;
     bool is_child = false;
@@ -66,6 +67,7 @@ struct telr_ctx {
     ctx->err = std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__); \
     return _e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; } } while (0)
 #define TRY(expr) do { int _r = (expr); if (_r != TELR_OK) return _r; } while (0)
+#define TELR_SPLIT_RANGE (-100)      // internal: a batch with >= 2^31 anchors; map_range() halves it
 
 static int ctx_buf(telr_ctx *ctx, const char *name, size_t bytes, void **out)
 {
@@ -206,7 +208,7 @@ extern "C" int telr_device_name(const telr_ctx *ctx, char *buf, int buflen)
 }
 
 // ---------------------------------------------------------------------------------------
-// presets (mirrors telr_amd/presets.py; tests/test_presets.py keeps them equal)
+// presets (mirrors telr_amd/presets.py; tests/test_abi.py keeps them equal)
 extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
 {
     if (!name || !io || !mo) return TELR_E_ARG;
@@ -218,8 +220,19 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
     mo->mask_level = 0.5f; mo->pri_ratio = 0.8f; mo->best_n = 5; mo->secondary = 1;
     mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
     mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6;
-    if (s == "map-ont" || s == "ngmlr-ont") { mo->fill_band_q4 = 4; }
-    else if (s == "map-pb" || s == "ngmlr-pacbio") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 8; }
+    if (s == "map-ont") { mo->fill_band_q4 = 4; }
+    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 8; }
+    else if (s == "ngmlr-ont" || s == "ngmlr-pacbio") {
+        // `ngmlr -x ont|pacbio` (TELR_alignment.py:28-51, the reference's default aligner).  NGMLR 0.2.7 indexes 13-mers at
+        // every third reference position: (w,k) = (5,13) minimizers have that density.  Its convex gap cost (open, then an
+        // extension penalty that decays by 0.15 per base from `max` to `min`; Sedlazeck 2018) is the lower envelope of two
+        // affine pieces:  pacbio (2, -5, open 5, extend 5 -> 1): C(L) = 5 + sum_{i<L} max(1, 5 - 0.15 i) ~ min(6 + 4L, 60 + L)
+        // (exact at L = 1 and L >= 27, within 6 in between);  ont (1, -1, open 1, extend 1 -> 0.5), doubled to integers:
+        // C(L) = 2 + sum_{i<L} max(1, 2 - 0.3 i) ~ min(2 + 2L, 4 + L).  AS is in these integer units (ont: twice NGMLR's).
+        io->k = 13; io->w = 5;
+        if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; mo->fill_band_q4 = 4; }
+        else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; mo->fill_band_q4 = 8; }
+    }
     else if (s == "asm10") {
         io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;
         mo->a = 1; mo->b = 9; mo->q = 16; mo->e = 2; mo->q2 = 41; mo->e2 = 1; mo->min_dp_max = 200; mo->zdrop = 200; mo->best_n = 50;
@@ -278,7 +291,7 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
         }
     });
     for (auto &t : th) t.join();
-    auto fail = [&](hipError_t e) { ctx->err = std::string("seqset upload: ") + hipGetErrorString(e); delete s; return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
+    auto fail = [&](hipError_t e) { ctx->err = std::string("seqset upload: ") + hipGetErrorString(e); telr_seqset_free(s); return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
     hipError_t e;
     if ((e = hipMalloc(&s->d_seq2, w2 * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
@@ -481,12 +494,16 @@ struct telr_index {
     HtSlot *d_ht = nullptr; int32_t ht_shift = 0; uint32_t ht_mask = 0;       // probe table of the seeding kernel
     uint32_t *d_ht_home = nullptr;                                            // its home-slot bitmap
     std::vector<uint32_t> sorted_counts; // ascending, for the mid_occ quantile
+    // per-target occurrence statistics (built on first use): runs = (minimizer, target) pairs, keys = target<<32 | count sorted
+    mutable uint64_t *d_pt_keys = nullptr; mutable int32_t *d_pt_off = nullptr, *d_pt_mid = nullptr; mutable int32_t pt_runs = -1;
+    mutable float pt_frac = -1.f; mutable int32_t pt_lo = -1, pt_hi = -1;
 };
 
 extern "C" void telr_index_free(telr_index *ix)
 {
     if (!ix) return;
     (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff); (void)hipFree(ix->d_ht); (void)hipFree(ix->d_ht_home);
+    (void)hipFree(ix->d_pt_keys); (void)hipFree(ix->d_pt_off); (void)hipFree(ix->d_pt_mid);
     delete ix;
 }
 extern "C" int telr_index_stats(const telr_index *ix, int64_t *n_mz, int64_t *n_distinct)
@@ -607,6 +624,57 @@ static int32_t index_mid_occ(const telr_index *ix, const telr_map_opt *mo)
     if (occ < mo->min_mid_occ) occ = mo->min_mid_occ;
     if (mo->max_mid_occ > mo->min_mid_occ && occ > mo->max_mid_occ) occ = mo->max_mid_occ;
     return occ;
+}
+
+// Per-target occurrence cut-offs (device array [n_targets]) for `mo`: the statistics are built once per index, the
+// cut-offs once per (f, U) setting.  Used when a query is confined to one target (qtarget) or chains are ranked per
+// target (TELR_MF_PER_TARGET): both stand for the reference's one-aligner-run-per-contig call sites.
+static int index_per_target_occ(telr_ctx *ctx, const telr_index *ix, const telr_map_opt *mo, const int32_t **d_tmid)
+{
+    const int n = ix->targets->n; const int64_t nmz = ix->n_mz;
+    hipStream_t st = ctx->stream;
+    if (ix->pt_runs < 0) {
+        int32_t *d_head, *d_rank, *d_tid, *d_start; int32_t n_runs = 0;
+        TRY(ctx_buf_t(ctx, "pt_head", (size_t)nmz + 1, &d_head));
+        TRY(ctx_buf_t(ctx, "pt_rank", (size_t)nmz + 1, &d_rank));
+        TRY(ctx_buf_t(ctx, "pt_tid", (size_t)nmz + 1, &d_tid));
+        HIPCHK(hipMemsetAsync(d_head, 0, ((size_t)nmz + 1) * 4, st));
+        if (nmz > 0) {
+            hipLaunchKernelGGL(k_pt_entry_heads, dim3((ix->n_ent + 255) / 256), dim3(256), 0, st, ix->d_ent_off, ix->n_ent, d_head);
+            hipLaunchKernelGGL(k_pt_run_heads, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, ix->d_pos, nmz, ix->d_goff, n, d_head, d_tid);
+            HIPCHK(hipGetLastError());
+            TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_head, d_rank, (size_t)nmz + 1)));
+            HIPCHK(hipMemcpyAsync(&n_runs, d_rank + nmz, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        TRY(ctx_buf_t(ctx, "pt_start", (size_t)n_runs + 1, &d_start));
+        uint64_t *d_k0;
+        TRY(ctx_buf_t(ctx, "pt_key0", (size_t)n_runs + 1, &d_k0));
+        HIPCHK(hipMalloc(&ix->d_pt_keys, ((size_t)n_runs + 1) * 8));
+        HIPCHK(hipMalloc(&ix->d_pt_off, ((size_t)n + 2) * 4));
+        HIPCHK(hipMalloc(&ix->d_pt_mid, ((size_t)n + 1) * 4));
+        if (n_runs > 0) {
+            hipLaunchKernelGGL(k_pt_run_starts, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, d_head, d_rank, nmz, d_start, n_runs);
+            hipLaunchKernelGGL(k_pt_run_keys, dim3((n_runs + 255) / 256), dim3(256), 0, st, d_start, d_tid, n_runs, d_k0);
+            HIPCHK(hipGetLastError());
+            size_t tb = 0;
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tb, d_k0, ix->d_pt_keys, (size_t)n_runs, 0, 64, st));
+            void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+            HIPCHK(rocprim::radix_sort_keys(tmp, tb, d_k0, ix->d_pt_keys, (size_t)n_runs, 0, 64, st));
+        }
+        hipLaunchKernelGGL(k_pt_target_off, dim3((n + 1 + 255) / 256), dim3(256), 0, st, ix->d_pt_keys, n_runs, n, ix->d_pt_off);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        ix->pt_runs = n_runs; ix->pt_frac = -1.f;
+    }
+    if (ix->pt_frac != mo->mid_occ_frac || ix->pt_lo != mo->min_mid_occ || ix->pt_hi != mo->max_mid_occ) {
+        hipLaunchKernelGGL(k_pt_mid_occ, dim3((n + 255) / 256), dim3(256), 0, st, ix->d_pt_keys, ix->d_pt_off, n, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ, ix->d_pt_mid);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));       // worker contexts read it from their own streams
+        ix->pt_frac = mo->mid_occ_frac; ix->pt_lo = mo->min_mid_occ; ix->pt_hi = mo->max_mid_occ;
+    }
+    *d_tmid = ix->d_pt_mid;
+    return TELR_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -980,6 +1048,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     static const int pk_chunks = [] { const char *e = getenv("TELR_PK_CHUNKS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
     const bool tb_over = tb_split && !serial && nw > 0;
     if (primary) HIPCHK(hipEventRecord(ctx->evk[5], st));
+    if (primary && nw > 0) ++ctx->pk_launches;
     if (nw > 0) {
         D.list = nullptr; D.nlist = 0;
         const int G = nw < 4096 ? 1 : pk_chunks;
@@ -1027,9 +1096,11 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
 
 // ---------------------------------------------------------------------------------------
 // one batch of queries [q0, q1)
+struct OccCut { int32_t mid_occ; const int32_t *d_tmid; };      // pooled cut-off; per-target cut-offs (nullable)
 static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs, const int32_t *d_qtarget, int32_t q0, int32_t q1,
-                     const telr_map_opt *mo, int32_t mid_occ, telr_result *R)
+                     const telr_map_opt *mo, OccCut occ, telr_result *R)
 {
+    const int32_t mid_occ = occ.mid_occ;
     const int nq = q1 - q0, k = ix->io.k, w = ix->io.w;
     const telr_seqset *tg = ix->targets;
     hipStream_t st = ctx->stream;
@@ -1065,7 +1136,6 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_toff, d_first, nq, nmz, d_qmz);
     HIPCHK(hipGetLastError());
     t_sk.stop();
-    ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
 
     ord_thread.join();
     HIPCHK(hipMemcpyAsync(d_qorder, h_ord, (size_t)nq * 4, hipMemcpyHostToDevice, st));
@@ -1083,16 +1153,27 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
+    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
     hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));
-    // 64-bit total check first: anchors of a batch must stay below 2^31
+    // the anchors of a batch are addressed with int32 offsets: their number is first summed in 64 bits (the int32 scan
+    // below would wrap silently); a batch with 2^31 anchors or more is handed back to the caller, which halves it
+    int64_t *d_na64; TRY(ctx_buf_t(ctx, "seed_na64", 2, &d_na64));
+    {
+        auto it64 = rocprim::make_transform_iterator(d_mcnt, [] __device__(int32_t v) { return (int64_t)v; });
+        size_t tb = 0;
+        HIPCHK(rocprim::reduce(nullptr, tb, it64, d_na64, (int64_t)0, (size_t)nmz + 1, rocprim::plus<int64_t>(), st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::reduce(tmp, tb, it64, d_na64, (int64_t)0, (size_t)nmz + 1, rocprim::plus<int64_t>(), st));
+    }
     TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_mcnt, d_maoff, (size_t)nmz + 1)));
-    int32_t na = 0;
+    int32_t na = 0; int64_t na64 = 0;
     HIPCHK(hipMemcpyAsync(&na, d_maoff + nmz, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&na64, d_na64, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (na < 0) return TELR_E_RANGE;
+    if (na64 >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
+    ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
     uint64_t *d_keys, *d_skeys;
     TRY(ctx_buf_t(ctx, "keys", (size_t)na, &d_keys));
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
@@ -1539,6 +1620,119 @@ static int seqset_subset_into(telr_ctx *ctx, const telr_seqset *parent, const st
     return TELR_OK;
 }
 
+// One range [q0,q1) of the query set (at most one batch worth of bases); its records and CIGARs are appended to R.
+//
+// Long-read lane.  Seeding, chaining, back-tracking and the problem builder give one wave to a read, so a batch waits for
+// its longest read in each of these stages while the device idles.  The few reads longer than a third of the longest one
+// are therefore mapped as their own small batch on a worker context, concurrently with the rest (the bulk worker writes
+// straight into R, so the big CIGAR DMA keeps running underneath the caller's next range / call).
+//
+// A range whose anchors do not fit int32 offsets (map_batch: TELR_SPLIT_RANGE) is halved and retried.
+static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const int32_t *d_qt,
+                     int32_t q0, int32_t q1, const telr_map_opt *mo, OccCut mid_occ, telr_result *R)
+{
+    const int nq = q1 - q0;
+    if (nq <= 0) return TELR_OK;
+    int64_t total_bases = 0; int32_t max_len = 0;
+    for (int i = q0; i < q1; ++i) { total_bases += queries->len[i]; if (queries->len[i] > max_len) max_len = queries->len[i]; }
+    bool lane = false;
+    std::vector<int32_t> lane_idx[2];         // 0: the bulk, 1: the long reads (query ids, ascending)
+    {
+        const char *e = getenv("TELR_LONGSPLIT");
+        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "0");
+        if (!off && !ctx->is_child && nq >= 2 && (force || (!ctx->debug && nq >= 2000 && total_bases >= 100000000LL))) {
+            const int32_t thr = std::max(max_len / 3, force ? 0 : 30000);
+            int64_t long_bases = 0;
+            for (int i = q0; i < q1; ++i) { const int k = queries->len[i] > thr ? 1 : 0; lane_idx[k].push_back(i); if (k) long_bases += queries->len[i]; }
+            lane = !lane_idx[0].empty() && !lane_idx[1].empty() && (force || long_bases * 100 <= total_bases * 35);
+        }
+    }
+    int rr = TELR_OK;
+    const size_t a_start = R->alns.size();
+    if (!lane) {
+        rr = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
+        if (rr == TELR_OK) ctx->ctr.query_bases += total_bases;
+    } else {
+        for (int k = 0; k < 2; ++k) TRY(ctx_make_child(ctx, k));
+        // the recycled (large) result buffers go to the bulk worker, which fills R
+        for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
+        ctx->cig_pool.clear();
+        result_wait(R);                       // an earlier range's DMA: the bulk worker may grow the buffer
+        const size_t c_start = R->ncig;
+        telr_seqset sub[2]; telr_result *P1 = new telr_result(); P1->ctx = nullptr; int rc[2] = { TELR_OK, TELR_OK };
+        auto work = [&](int k) {
+            telr_ctx *c = ctx->child[k];
+            (void)hipSetDevice(c->device);
+            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0;
+            const int n = (int)lane_idx[k].size();
+            if ((rc[k] = seqset_subset_into(c, queries, lane_idx[k], "lane_", &sub[k])) != TELR_OK) return;
+            int32_t *d_q = nullptr;
+            if (qtarget) {
+                std::vector<int32_t> qt(n);
+                for (int i = 0; i < n; ++i) qt[i] = qtarget[lane_idx[k][i]];
+                if ((rc[k] = ctx_buf_t(c, "lane_qt", (size_t)n + 1, &d_q)) != TELR_OK) return;
+                if (hipMemcpy(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
+            }
+            rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, k == 0 ? R : P1);
+            if (rc[k] == TELR_OK) c->ctr.query_bases += sub[k].total_bases;
+        };
+        std::thread tl(work, 1);
+        work(0);
+        tl.join();
+        sub[0].d_seq2 = sub[0].d_nmask = nullptr; sub[1].d_seq2 = sub[1].d_nmask = nullptr;       // scratch of the workers, not owned
+        sub[0].d_boff = sub[1].d_boff = nullptr; sub[0].d_len = sub[1].d_len = nullptr;
+        for (int k = 0; k < 2 && rr == TELR_OK; ++k) if (rc[k] != TELR_OK) { if (rc[k] != TELR_SPLIT_RANGE) ctx->err = ctx->child[k]->err; rr = rc[k]; }
+        if (rr != TELR_OK) {                  // roll back what the bulk worker appended
+            result_wait(R); R->alns.resize(a_start); R->ncig = c_start;
+        } else {
+            // the long reads' ops go behind the bulk's; records are merged by query id (both lists are sorted by it)
+            result_wait(P1);
+            const size_t base1 = R->ncig;
+            if (P1->ncig) {
+                if (base1 + P1->ncig + 1 > R->cap) {
+                    result_wait(R);
+                    if (!cig_grow(&R->cig, &R->cap, base1, base1 + P1->ncig + 1 + P1->ncig / 8)) { P1->ctx = ctx->child[1]; delete P1; return TELR_E_NOMEM; }
+                }
+                const int NT = host_threads();
+                const size_t nw = P1->ncig; const int chunks = 16;
+                parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
+                    for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + base1 + lo, P1->cig + lo, (hi - lo) * 4); }
+                });
+                R->ncig = base1 + P1->ncig;
+            }
+            std::vector<telr_aln> merged(R->alns.size() - a_start + P1->alns.size());
+            { size_t a = a_start, b = 0, o = 0;
+              const size_t na = R->alns.size(), nb = P1->alns.size();
+              while (a < na || b < nb) {
+                  const int32_t qa = a < na ? lane_idx[0][R->alns[a].qid] : INT32_MAX, qb = b < nb ? lane_idx[1][P1->alns[b].qid] : INT32_MAX;
+                  if (qa < qb) { telr_aln r = R->alns[a++]; r.qid = qa; merged[o++] = r; }
+                  else { telr_aln r = P1->alns[b++]; r.qid = qb; r.cigar_off += (int64_t)base1; merged[o++] = r; }
+              } }
+            R->alns.resize(a_start + merged.size());
+            std::copy(merged.begin(), merged.end(), R->alns.begin() + a_start);
+            for (int k = 0; k < 2; ++k) {
+                telr_ctx *c = ctx->child[k];
+                for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
+                const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
+                for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
+                for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
+                ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches;
+            }
+        }
+        P1->ctx = ctx->child[1];              // its buffer goes back to that worker's pool
+        delete P1;
+    }
+    if (rr == TELR_SPLIT_RANGE) {
+        if (nq < 2) { ctx->err = "one read seeds 2^31 anchors or more"; return TELR_E_RANGE; }
+        int32_t mid = q0; int64_t acc = 0;
+        while (mid < q1 - 1 && acc + queries->len[mid] <= total_bases / 2) acc += queries->len[mid++];
+        if (mid == q0) mid = q0 + 1;
+        TRY(map_range(ctx, ix, queries, qtarget, d_qt, q0, mid, mo, mid_occ, R));
+        return map_range(ctx, ix, queries, qtarget, d_qt, mid, q1, mo, mid_occ, R);
+    }
+    return rr;
+}
+
 extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const telr_map_opt *mo, telr_result **out)
 {
     if (!ctx || !ix || !queries || !mo || !out) return TELR_E_ARG;
@@ -1550,7 +1744,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     memset(&ctx->ctr, 0, sizeof(ctx->ctr));
     memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
-    ctx->dp_retries = 0; ctx->st_pending = 0;
+    ctx->dp_retries = 0; ctx->pk_launches = 0; ctx->st_pending = 0;
     const int nq = queries->n;
     if (qtarget) for (int i = 0; i < nq; ++i) if (qtarget[i] >= ix->targets->n) return TELR_E_ARG;
     int32_t *d_qt = nullptr;
@@ -1558,103 +1752,27 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         TRY(ctx_buf_t(ctx, "qtarget", (size_t)nq, &d_qt));
         HIPCHK(hipMemcpy(d_qt, qtarget, (size_t)nq * 4, hipMemcpyHostToDevice));
     }
-    const int32_t mid_occ = index_mid_occ(ix, mo);
+    OccCut mid_occ; mid_occ.mid_occ = index_mid_occ(ix, mo); mid_occ.d_tmid = nullptr;
+    if (qtarget || (mo->flags & TELR_MF_PER_TARGET)) TRY(index_per_target_occ(ctx, ix, mo, &mid_occ.d_tmid));
     telr_result *R = new telr_result();
     R->ctx = ctx;
     const auto t_wall0 = std::chrono::steady_clock::now();
-    // Large calls are cut into a few sub-batches that run CONCURRENTLY on worker contexts (own streams and
-    // scratch): the host phases of one sub-batch (chain selection, record assembly, CIGAR stitching) and the
-    // latency-bound DP tail overlap with the GPU work of the others.  Small calls run in place.
     int64_t total_bases = 0;
     for (int i = 0; i < nq; ++i) total_bases += queries->len[i];
-    int nsub = 1;      // measured on the MI355X box: concurrency only pays when host cores are plentiful; opt-in via TELR_SUBBATCH
+    int nsub = 1;      // concurrent sub-batches on worker contexts: measured on the MI355X box, only pays when host cores are plentiful; opt-in via TELR_SUBBATCH
     if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
     if (nsub > nq) nsub = nq > 0 ? nq : 1;
-    // ---- long-read lane.  Seeding, chaining, back-tracking and the problem builder give one wave to a read, so a batch
-    // waits for its longest read in each of these stages while the device idles.  The few reads longer than a third of
-    // the longest one are therefore mapped as their own small batch on a worker context, concurrently with the rest.
-    bool lane = false;
-    std::vector<int32_t> lane_idx[2];         // 0: the bulk, 1: the long reads (original query ids, ascending)
-    {
-        const char *e = getenv("TELR_LONGSPLIT");
-        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "0");
-        if (nsub == 1 && !off && !ctx->is_child && nq >= 2 && (force || (!ctx->debug && nq >= 2000 && total_bases >= 100000000LL))) {
-            const int32_t thr = std::max(queries->max_len / 3, force ? 0 : 30000);
-            int64_t long_bases = 0;
-            for (int i = 0; i < nq; ++i) { const int k = queries->len[i] > thr ? 1 : 0; lane_idx[k].push_back(i); if (k) long_bases += queries->len[i]; }
-            lane = !lane_idx[0].empty() && !lane_idx[1].empty() && (force || long_bases * 100 <= total_bases * 35);
-        }
-    }
-    if (lane) {
-        for (int k = 0; k < 2; ++k) { int r = ctx_make_child(ctx, k); if (r != TELR_OK) { delete R; return r; } }
-        // the recycled (large) result buffer goes to the bulk worker, whose result becomes this call's result
-        for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
-        ctx->cig_pool.clear();
-        telr_seqset sub[2]; telr_result *part[2] = { nullptr, nullptr }; int rc[2] = { TELR_OK, TELR_OK };
-        auto work = [&](int k) {
-            telr_ctx *c = ctx->child[k];
-            (void)hipSetDevice(c->device);
-            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->st_pending = 0;
-            part[k] = new telr_result(); part[k]->ctx = nullptr;
-            const int n = (int)lane_idx[k].size();
-            if ((rc[k] = seqset_subset_into(c, queries, lane_idx[k], "lane_", &sub[k])) != TELR_OK) return;
-            int32_t *d_q = nullptr;
-            if (qtarget) {
-                std::vector<int32_t> qt(n);
-                for (int i = 0; i < n; ++i) qt[i] = qtarget[lane_idx[k][i]];
-                if ((rc[k] = ctx_buf_t(c, "lane_qt", (size_t)n + 1, &d_q)) != TELR_OK) return;
-                if (hipMemcpy(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
-            }
-            c->ctr.query_bases += sub[k].total_bases;
-            rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, part[k]);
-        };
-        std::thread tl(work, 1);
-        work(0);
-        tl.join();
-        sub[0].d_seq2 = sub[0].d_nmask = nullptr; sub[1].d_seq2 = sub[1].d_nmask = nullptr;       // scratch of the workers, not owned
-        for (int k = 0; k < 2; ++k) if (rc[k] != TELR_OK) { ctx->err = ctx->child[k]->err; for (auto *p : part) delete p; delete R; return rc[k]; }
-        // merge: the bulk result's CIGAR buffer becomes the result's, the long reads' ops are appended; records are
-        // merged by original query id (both lists are sorted by it)
-        telr_result *P0 = part[0], *P1 = part[1];
-        result_wait(P0); result_wait(P1);
-        R->cig = P0->cig; R->cap = P0->cap; R->ncig = P0->ncig; P0->cig = nullptr; P0->cap = 0; P0->ncig = 0;
-        const size_t base1 = R->ncig;
-        if (!cig_grow(&R->cig, &R->cap, base1, base1 + P1->ncig + 1)) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; }
-        const int NT = host_threads();
-        { const size_t nw = P1->ncig; const int chunks = 16;
-          parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
-              for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + base1 + lo, P1->cig + lo, (hi - lo) * 4); }
-          }); }
-        R->ncig = base1 + P1->ncig;
-        R->alns.resize(P0->alns.size() + P1->alns.size());
-        { size_t a = 0, b = 0, o = 0;
-          const size_t na = P0->alns.size(), nb = P1->alns.size();
-          while (a < na || b < nb) {
-              const int32_t qa = a < na ? lane_idx[0][P0->alns[a].qid] : INT32_MAX, qb = b < nb ? lane_idx[1][P1->alns[b].qid] : INT32_MAX;
-              if (qa < qb) { telr_aln r = P0->alns[a++]; r.qid = qa; R->alns[o++] = r; }
-              else { telr_aln r = P1->alns[b++]; r.qid = qb; r.cigar_off += (int64_t)base1; R->alns[o++] = r; }
-          } }
-        for (int k = 0; k < 2; ++k) {
-            telr_ctx *c = ctx->child[k];
-            for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
-            const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
-            for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
-            for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
-            ctx->dp_retries += c->dp_retries;
-            part[k]->ctx = c;
-            delete part[k];
-        }
-    } else if (nsub == 1) {
-        // batches bounded by bases (trace-back scratch is ~32-64 B per query base)
-        int64_t batch_bases = 1024LL << 20;   // HBM is 288 GB: one batch for up to ~1 Gbp of reads (scratch ~80 B per base)
+    if (nsub == 1) {
+        // ranges bounded by bases (HBM is 288 GB: one range holds up to ~1 Gbp of reads, scratch ~80 B per base); a read
+        // set of any size streams through as consecutive ranges, each with its own long-read lane
+        int64_t batch_bases = 1024LL << 20;
         if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
         if (const char *e = getenv("TELR_BATCH_KBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 10; }     // tests
         int32_t q0 = 0;
         while (q0 < nq) {
             int32_t q1 = q0; int64_t b = 0;
             while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= batch_bases)) { b += queries->len[q1]; ++q1; }
-            ctx->ctr.query_bases += b;
-            int r = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
+            int r = map_range(ctx, ix, queries, qtarget, d_qt, q0, q1, mo, mid_occ, R);
             if (r != TELR_OK) { delete R; return r; }
             q0 = q1;
         }
@@ -1670,7 +1788,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         for (int k = 0; k < nsub; ++k) th.emplace_back([&, k]() {
             telr_ctx *c = ctx->child[k];
             (void)hipSetDevice(c->device);
-            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->st_pending = 0;
+            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0;
             part[k] = new telr_result(); part[k]->ctx = nullptr;
             if (cut[k + 1] > cut[k]) {
                 for (int i = cut[k]; i < cut[k + 1]; ++i) c->ctr.query_bases += queries->len[i];
@@ -1678,7 +1796,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             }
         });
         for (auto &t : th) t.join();
-        for (int k = 0; k < nsub; ++k) if (rc[k] != TELR_OK) { ctx->err = ctx->child[k]->err; for (auto *p : part) delete p; delete R; return rc[k]; }
+        for (int k = 0; k < nsub; ++k) if (rc[k] != TELR_OK) { ctx->err = ctx->child[k]->err; for (auto *p : part) delete p; delete R; return rc[k] == TELR_SPLIT_RANGE ? TELR_E_RANGE : rc[k]; }
         // merge: records in query order, CIGAR arrays concatenated (parallel copy into a pooled buffer)
         size_t tot_a = 0, tot_c = 0;
         std::vector<size_t> a0(nsub + 1, 0), c0(nsub + 1, 0);
@@ -1707,7 +1825,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
             for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
             for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
-            ctx->dp_retries += c->dp_retries;
+            ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches;
             // the workers' result buffers go back to their own pools for the next call
             part[k]->ctx = c;
             delete part[k];
@@ -1721,6 +1839,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
 // ---------------------------------------------------------------------------------------
 // debug taps for the stage-level parity tests (last batch of the last telr_map call)
 extern "C" int64_t telr_debug_dp_retries(const telr_ctx *ctx) { return ctx ? ctx->dp_retries : 0; }
+extern "C" int64_t telr_debug_pk_launches(const telr_ctx *ctx) { return ctx ? ctx->pk_launches : 0; }
 extern "C" int64_t telr_debug_n_anchor(const telr_ctx *ctx) { return ctx ? ctx->dbg_na : 0; }
 extern "C" int telr_debug_fetch(telr_ctx *ctx, const char *what, void *dst, int64_t bytes)
 {
@@ -1845,10 +1964,17 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
     result_wait(r);
     FILE *f = path ? fopen(path, "w") : stdout;
     if (!f) return TELR_E_ARG;
-    fprintf(f, "@HD\tVN:1.6\tSO:unsorted\tGO:query\n");
-    for (int t = 0; t < n_targets; ++t) fprintf(f, "@SQ\tSN:%s\tLN:%d\n", tnames[t], t_len[t]);
-    if (rg_id) fprintf(f, "@RG\tID:%s\tSM:%s\tLB:%s\n", rg_id, rg_sm ? rg_sm : rg_id, rg_lb ? rg_lb : "lib");
-    fprintf(f, "@PG\tID:telr_amd\tPN:telr_amd\tVN:0.1.0\tCL:%s\n", pg_line ? pg_line : "telr_map");
+    const bool sorted = (flags & TELR_SAM_SORTED) != 0, prim_only = (flags & TELR_SAM_PRIMARY_ONLY) != 0;
+    if (!(flags & TELR_SAM_NO_HEADER)) {
+        fprintf(f, sorted ? "@HD\tVN:1.6\tSO:coordinate\n" : "@HD\tVN:1.6\tSO:unsorted\tGO:query\n");
+        for (int t = 0; t < n_targets; ++t) fprintf(f, "@SQ\tSN:%s\tLN:%d\n", tnames[t], t_len[t]);
+        if (rg_id) fprintf(f, "@RG\tID:%s\tSM:%s\tLB:%s\n", rg_id, rg_sm ? rg_sm : rg_id, rg_lb ? rg_lb : "lib");
+        fprintf(f, "@PG\tID:telr_amd\tPN:telr_amd\tVN:0.1.0\tCL:%s\n", pg_line ? pg_line : "telr_map");
+    }
+    // TELR_SAM_SORTED: lines are collected with their (target, position) key and written in coordinate order, unmapped
+    // reads last (what `samtools sort | samtools view` prints; stable, so ties keep the query order)
+    std::vector<std::pair<int64_t, std::string>> keyed;
+    auto emit = [&](int64_t key, const std::string &l) { if (sorted) keyed.emplace_back(key, l); else fwrite(l.data(), 1, l.size(), f); };
     // records are sorted by (qid, rank); group per query
     const size_t n = r->alns.size();
     size_t i = 0;
@@ -1859,11 +1985,10 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
         const char *qs = q_ascii + q_off[q]; const int ql = q_len[q];
         if (j == i) {
             if (!(flags & TELR_SAM_NO_UNMAPPED)) {
-                fprintf(f, "%s\t4\t*\t0\t0\t*\t*\t0\t0\t", qnames[q]);
-                fwrite(qs, 1, ql, f);
-                fprintf(f, "\t*");
-                if (rg_id) fprintf(f, "\tRG:Z:%s", rg_id);
-                fputc('\n', f);
+                line.clear(); line += qnames[q]; line += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; line.append(qs, (size_t)ql); line += "\t*";
+                if (rg_id) { line += "\tRG:Z:"; line += rg_id; }
+                line += '\n';
+                emit(INT64_MAX, line);
             }
             continue;
         }
@@ -1872,6 +1997,7 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
         for (size_t k = i; k < j; ++k) {
             const telr_aln &a = r->alns[k];
             const bool rev = (a.flags & TELR_F_REV) != 0, sec = (a.flags & TELR_F_SECONDARY) != 0, sup = (a.flags & TELR_F_SUPPL) != 0;
+            if (prim_only && (sec || sup)) continue;                 // samtools view -F0x900
             const char *qstr = rev ? rc.data() : qs;                 // query on the alignment strand
             const int clip5 = rev ? ql - a.qe : a.qs, clip3 = rev ? a.qs : ql - a.qe;
             const uint32_t *cg = r->cig + a.cigar_off;
@@ -1908,7 +2034,7 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
                 }
             }
             if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d", run); md += buf; }
-            const bool hard = sec || (sup && !(flags & TELR_SAM_SOFTCLIP));
+            const bool hard = sup && !(flags & TELR_SAM_SOFTCLIP);      // secondary: SEQ '*' and soft clips, as minimap2 without --secondary-seq
             int fl = (rev ? 0x10 : 0) | (sec ? 0x100 : 0) | (sup ? 0x800 : 0);
             line.clear();
             line += qnames[q];
@@ -1950,9 +2076,13 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
             if (!sec) { snprintf(buf, sizeof(buf), "\ts2:i:%d", a.subsc); line += buf; }
             if (rg_id) { line += "\tRG:Z:"; line += rg_id; }
             line += '\n';
-            fwrite(line.data(), 1, line.size(), f);
+            emit(((int64_t)(a.tid + 1) << 32) | (uint32_t)a.ts, line);
         }
         i = j;
+    }
+    if (sorted) {
+        std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<int64_t, std::string> &x, const std::pair<int64_t, std::string> &y) { return x.first < y.first; });
+        for (auto &kv : keyed) fwrite(kv.second.data(), 1, kv.second.size(), f);
     }
     if (path) fclose(f);
     return TELR_OK;
@@ -2061,7 +2191,7 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
                     }
                 }
                 if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d", run); md += buf; }
-                const bool hard = sec || (sup && !(flags & TELR_SAM_SOFTCLIP));
+                const bool hard = sup && !(flags & TELR_SAM_SOFTCLIP);      // secondary: SEQ '*' and soft clips, as minimap2 without --secondary-seq
                 const int fl = (rev ? 0x10 : 0) | (sec ? 0x100 : 0) | (sup ? 0x800 : 0);
                 const int seq_lo = sec ? 0 : (hard ? clip5 : 0), seq_hi = sec ? 0 : (hard ? ql - clip3 : ql), l_seq = seq_hi - seq_lo;
                 std::vector<uint32_t> bc;

@@ -25,30 +25,51 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
     return {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
 
 
-def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, dist=None, device=None, **kw):
-    """Stages 3-4 sharded over the ranks of one node: loci are assigned by LPT on their read
-    bases, every rank runs the bundle on its shard, and ONE all-gather of fixed-width rows merges the coordinate /
-    allele-frequency table (RCCL over xGMI on GPUs; gloo in the CPU tests).  Variable-length payloads (reports,
-    sequences) stay on the owning rank.  -> (merged LOCUS_ROW array sorted by locus id, this rank's full results)"""
+def locus_of_report(r):
+    """locus (= contig) name of a liftover report: its ID is <contig>_<te_start>_<te_end> and contig names are
+    <chromosome>_<start>_<end>, where the chromosome itself may contain underscores (chrUn_CP007071v1)"""
+    return r["ID"].rsplit("_", 2)[0]
+
+
+def locus_cost(l):
+    """LPT cost of a locus: contig + ALT + window-read bases (whatever of them is known when loci are dealt)"""
+    c = len(l["contig"]) + len(l.get("alt") or "")
+    if "reads" in l:
+        c += sum(len(r) for r in l["reads"])
+    elif "read_bases" in l:
+        c += int(l["read_bases"])
+    return c
+
+
+def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, dist=None, device=None, shards=None, **kw):
+    """Stages 3-4 sharded over the ranks of one node: loci are assigned by LPT on their bases
+    (`shards` = the per-rank lists of locus indices when the caller dealt them already, identical on every rank), every rank runs the bundle on its shard,
+    and ONE all-gather of fixed-capacity blocks of fixed-width rows merges the coordinate / allele-frequency table
+    (RCCL over xGMI on GPUs; gloo in the CPU tests).  Variable-length payloads (reports, sequences) stay on the
+    owning rank.  -> (merged LOCUS_ROW array sorted by locus id, this rank's full results)"""
     from . import shard
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    costs = [sum(len(r) for r in l["reads"]) + len(l["contig"]) for l in loci]
-    mine = shard.shard_loci(costs, world)[rank]
+    if shards is None:
+        shards = shard.shard_loci([locus_cost(l) for l in loci], world)
+    mine = shards[rank]
+    capacity = max(len(x) for x in shards)          # every rank computes the same number: no size exchange
     sub = [loci[i] for i in mine]
     res = run_loci(backend, ref_index, ref_names, ref_seq, sub, lib_names, lib_seqs, **kw) if sub else \
         {"annotation": [], "liftover": [], "summary": {}, "af": {}}
-    by_name = {"_".join(r["ID"].split("_")[:3]): r for r in res["liftover"]}
+    by_name = {}
+    for r in res["liftover"]:
+        by_name.setdefault(locus_of_report(r), r)
     ids, reps, freqs = [], [], []
     for gi, l in zip(mine, sub):
         r = by_name.get(l["name"])
-        if r is None:
+        if r is None:                       # the locus did not pass annotation (no TE found on its contig): no row
             continue
         ids.append(gi); reps.append(r); freqs.append(res["af"].get(l["name"]))
     chrom_ids = {n: i for i, n in enumerate(ref_names)}
     fam_ids = {n: i for i, n in enumerate(lib_names)}
     rows = shard.rows_from_reports(ids, reps, freqs, chrom_ids, fam_ids)
-    return shard.all_gather_rows(rows, dist, device), res
+    return shard.all_gather_rows(rows, dist, device, capacity=capacity), res
 
 
 def write_outputs(res, loci, out_dir, sample_name, ref_fasta, sv_info=None, today=None):

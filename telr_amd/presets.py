@@ -23,11 +23,22 @@ def preset(name):
         mask_level=0.5, pri_ratio=0.8, best_n=5, secondary=1,
         a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, min_dp_max=80, min_ksw_len=200,
         ext_max=2048, ext_band=31, flags=MF_CIGAR, fill_band_q4=6)
-    if name in ("map-ont", "ngmlr-ont"):
+    if name == "map-ont":
         mo.fill_band_q4 = 4         # 0.3 % of the fills touch the band edge and are redone with the wide band (band rule)
-    elif name in ("map-pb", "ngmlr-pacbio"):
+    elif name == "map-pb":
         io.k, io.is_hpc = 19, 1
         mo.fill_band_q4 = 8         # CLR reads carry about twice the indel rate of ONT reads
+    elif name in ("ngmlr-ont", "ngmlr-pacbio"):
+        # `ngmlr -x ont|pacbio`, the reference's default stage-1 aligner (TELR_alignment.py:28-51, TELR_input.py:176-177):
+        # 13-mers at every third reference position = (w,k) = (5,13) minimizers; NGMLR's convex gap cost as the lower
+        # envelope of two affine pieces (derivation in telr_engine.hip: telr_preset)
+        io.k, io.w = 13, 5
+        if name == "ngmlr-ont":
+            mo.a, mo.b, mo.q, mo.e, mo.q2, mo.e2 = 2, 2, 2, 2, 4, 1
+            mo.fill_band_q4 = 4
+        else:
+            mo.a, mo.b, mo.q, mo.e, mo.q2, mo.e2 = 2, 5, 6, 4, 60, 1
+            mo.fill_band_q4 = 8
     elif name == "asm10":
         io.k, io.w = 19, 19
         mo.min_mid_occ, mo.max_mid_occ = 50, 500

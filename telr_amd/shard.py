@@ -2,10 +2,12 @@
 
 * stage 1: reads are dealt to ranks by cumulative bases (length-sorted, snake order) against a
   replicated index — no collective on the data path;
-* stages 2-4: candidate loci are assigned by LPT (longest processing time first) on their read
-  bases; every rank produces fixed-width result rows for its loci and ONE all-gather merges them
-  (RCCL over xGMI on GPUs, `backend="nccl"`; gloo in the CPU tests).  Variable-length payloads
-  (sequences, CIGARs) stay on the owning rank.
+* stages 2-4: candidate loci are assigned by LPT (longest processing time first) on their contig
+  + read bases; every rank produces fixed-width result rows for its loci and ONE all-gather of
+  fixed-capacity blocks merges them (RCCL over xGMI on GPUs, `backend="nccl"`; gloo in the CPU tests).
+  Variable-length payloads (sequences, CIGARs) stay on the owning rank;
+* between the two (only when the reads themselves are sharded): the window reads of a locus sit on whichever
+  ranks mapped them and travel to the locus' owner in one all-to-all (`exchange_window_reads`).
 The reference's only parallelism on this path is `multiprocessing.Pool(processes=thread)` over loci
 (src/telr/TELR_assembly.py:70-71, TELR_te.py:644-646, TELR_liftover.py:1049-1052).
 """
@@ -46,21 +48,22 @@ def shard_loci(costs, world):
     return [sorted(x) for x in out]
 
 
-def all_gather_rows(rows, dist=None, device=None):
+def all_gather_rows(rows, dist=None, device=None, capacity=None):
     """rows: LOCUS_ROW array of this rank -> all ranks' rows sorted by locus_id.
 
-    One collective on the payload: every rank contributes a block padded to the largest per-rank count
-    (the counts travel in the same buffer's header), as torch.distributed.all_gather_into_tensor."""
+    ONE collective: every rank contributes a fixed-capacity block [count:int64][capacity rows] to
+    torch.distributed.all_gather_into_tensor.  `capacity` must be the same on all ranks: the largest shard of the
+    (deterministic) locus assignment, which every rank computes for itself."""
     rows = np.ascontiguousarray(rows, dtype=LOCUS_ROW)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return np.sort(rows, order="locus_id")
     import torch
     world = dist.get_world_size()
-    n = torch.tensor([len(rows)], dtype=torch.int64, device=device)
-    nmax = n.clone()
-    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)            # sizes only; the data path has the one all-gather below
-    nmax = int(nmax.item())
-    block = np.zeros(8 + nmax * LOCUS_ROW.itemsize, np.uint8)
+    if capacity is None:
+        raise ValueError("all_gather_rows at world size > 1 needs the common block capacity (the largest shard)")
+    if len(rows) > capacity:
+        raise ValueError("rank holds %d rows, block capacity is %d" % (len(rows), capacity))
+    block = np.zeros(8 + capacity * LOCUS_ROW.itemsize, np.uint8)
     block[:8] = np.frombuffer(np.int64(len(rows)).tobytes(), np.uint8)
     block[8:8 + rows.nbytes] = rows.view(np.uint8).reshape(-1)
     send = torch.from_numpy(block).to(device) if device is not None else torch.from_numpy(block)
@@ -74,6 +77,52 @@ def all_gather_rows(rows, dist=None, device=None):
         parts.append(np.frombuffer(b[8:8 + k * LOCUS_ROW.itemsize].tobytes(), dtype=LOCUS_ROW))
     allrows = np.concatenate(parts) if parts else rows
     return np.sort(allrows, order="locus_id")
+
+
+READ_HDR = np.dtype([("locus_id", np.int32), ("read_id", np.int32), ("length", np.int32), ("pad", np.int32)])
+
+
+def exchange_window_reads(items, dist=None, device=None):
+    """The stage-1 -> per-locus hand-off when reads are sharded over ranks: every rank holds the window reads of ALL loci
+    that fall in ITS read shard and sends each to the rank that owns the locus.  (The reference does this through the
+    shared file system: pysam.fetch on the stage-1 BAM + seqtk over the read file, TELR_assembly.py:384-462.)
+
+    items: list of (destination rank, locus id, global read id, uint8 base array).
+    -> list of (locus id, global read id, uint8 base array) received by this rank, sorted by (locus id, read id).
+    Two all-to-all collectives: the byte counts, then one buffer per peer [n][n headers][bases]."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world == 1:
+        return sorted(((l, r, b) for (_, l, r, b) in items), key=lambda t: (t[0], t[1]))
+    import torch
+    per = [[] for _ in range(world)]
+    for it in items:
+        per[it[0]].append(it)
+    bufs = []
+    for d in range(world):
+        hdr = np.zeros(len(per[d]), READ_HDR)
+        for k, (_, l, r, b) in enumerate(per[d]):
+            hdr[k] = (l, r, len(b), 0)
+        parts = [np.frombuffer(np.int64(len(per[d])).tobytes(), np.uint8), hdr.view(np.uint8).reshape(-1)] + [np.ascontiguousarray(x[3], np.uint8) for x in per[d]]
+        bufs.append(np.concatenate(parts))
+    dev = device if device is not None else "cpu"
+    n_send = torch.tensor([len(b) for b in bufs], dtype=torch.int64, device=dev)
+    n_recv = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(n_recv, n_send)
+    n_recv_l = [int(x) for x in n_recv.cpu().tolist()]
+    send = torch.from_numpy(np.concatenate(bufs)).to(dev)
+    recv = torch.empty(sum(n_recv_l), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=n_recv_l, input_split_sizes=[len(b) for b in bufs])
+    raw = recv.cpu().numpy()
+    out, o = [], 0
+    for r in range(world):
+        b = raw[o:o + n_recv_l[r]]; o += n_recv_l[r]
+        n = int(np.frombuffer(b[:8].tobytes(), np.int64)[0])
+        hdr = np.frombuffer(b[8:8 + n * READ_HDR.itemsize].tobytes(), READ_HDR)
+        p = 8 + n * READ_HDR.itemsize
+        for h in hdr:
+            out.append((int(h["locus_id"]), int(h["read_id"]), b[p:p + int(h["length"])].copy())); p += int(h["length"])
+    out.sort(key=lambda t: (t[0], t[1]))
+    return out
 
 
 def rows_from_reports(locus_ids, reports, freqs, chrom_ids, family_ids):

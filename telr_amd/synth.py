@@ -214,3 +214,204 @@ def make_loci_from_dataset(d, n_loci, seed=7, flank=(8000, 15000), reads_cap=60,
         loci.append({"name": "chr2L_%d_%d" % (p, p + 1), "contig": bytes(contig).decode(), "alt": bytes(alt).decode(), "reads": reads, "read_idx": list(sel),
                      "truth": {"pos": p, "family": "fam%d" % fam, "strand": "+-"[strand], "tsd": tsd, "af": af}})
     return loci
+
+
+# ---------------------------------------------------------------------------------------
+# Multi-chromosome data sets (BASELINE configs[2]-[4]; SURVEY.md 8d recipe).  Everything is derived from
+# (seed, object index) so that any rank can materialise any block of reads on its own: the read PLAN (chromosome,
+# haplotype, start, length, strand of every read) is cheap and made everywhere, the bases of a block of reads come from
+# a generator seeded with (seed, block index) whatever the world size.
+DM6_ARMS = [("chr2L", 23513712), ("chr2R", 25286936), ("chr3L", 28110227), ("chr3R", 32079331),
+            ("chr4", 1348131), ("chrX", 23542271), ("chrY", 3667352), ("chrM", 19524)]          # sum 137,567,484
+CHR22 = [("chr22", 50818468)]
+N_HAP = 4            # allele frequencies 0.25 / 0.5 / 1.0 = insertion present on 1 / 2 / 4 of four haplotypes
+READ_BLOCK = 256     # reads per generation block (the unit dealt to ranks in the strong-scaling bench)
+
+
+def random_seq_fast(rng, n, gc=0.42):
+    u = rng.random(n, dtype=np.float32)
+    a = (1 - gc) / 2
+    code = (u >= a).astype(np.uint8) + (u >= a + gc / 2) + (u >= a + gc)
+    return BASES[code]
+
+
+def _pool_map(fn, items, threads):
+    if threads <= 1 or len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(fn, items))
+
+
+def make_genome(seed, chroms, n_fam=127, te_frac=0.15, gc=0.42, n_ins=1000, lead_n=0, afs=(0.25, 0.5, 1.0), threads=1):
+    """-> dict(names, ref=[uint8 arrays], library, insertions=[(chrom id, pos, fam, strand, tsd, af)] sorted,
+    haps[h][c] = uint8 arrays, hap_ins[h][c] = (ref positions, cumulative shift after each insertion present on h)).
+    lead_n: length of a leading N block of every chromosome (chr22's 11 Mb)."""
+    rng = np.random.default_rng([seed, 0])
+    lib = make_te_library(rng, n_fam)
+    names = [c[0] for c in chroms]
+
+    def one_chrom(ci):
+        r = np.random.default_rng([seed, 1, ci])
+        L = chroms[ci][1]
+        ref = random_seq_fast(r, L, gc)
+        lo = min(lead_n, max(0, L - 100000))
+        covered = 0
+        while covered < te_frac * (L - lo) and L - lo > 20000:
+            f = lib[int(r.integers(0, n_fam))]
+            cut = int(r.integers(0, max(1, len(f) // 2)))
+            cp = mutate(r, f[cut:], float(r.uniform(0, 0.15)), 0.0, 0.0)
+            if r.integers(0, 2):
+                cp = revcomp_arr(cp)
+            if len(cp) >= L - lo:
+                continue
+            p = int(r.integers(lo, L - len(cp)))
+            ref[p:p + len(cp)] = cp
+            covered += len(cp)
+        if lo:
+            ref[:lo] = ord("N")
+        return ref
+
+    refs = _pool_map(one_chrom, list(range(len(chroms))), threads)
+    # insertion sites: slots of a 5-kb grid over all chromosomes (>= 3 kb apart after the jitter), outside the N block
+    slots_c, slots_p = [], []
+    for ci, (_, L) in enumerate(chroms):
+        g = np.arange(max(5000, lead_n + 5000), L - 7000, 5000)
+        slots_c.append(np.full(len(g), ci)); slots_p.append(g)
+    slots_c = np.concatenate(slots_c); slots_p = np.concatenate(slots_p)
+    n_ins = min(n_ins, len(slots_p))
+    pick = np.sort(rng.choice(len(slots_p), size=n_ins, replace=False))
+    ins = []
+    for k in pick:
+        ins.append((int(slots_c[k]), int(slots_p[k] + rng.integers(0, 2000)), int(rng.integers(0, n_fam)), int(rng.integers(0, 2)),
+                    int(rng.integers(4, 9)), float(rng.choice(afs))))
+    ins.sort()
+
+    def build(hc):
+        h, ci = hc
+        ref = refs[ci]
+        parts, last, pos, shift, tot = [], 0, [], [], 0
+        for (c, p, fam, strand, tsd, af) in ins:
+            if c != ci or h >= round(af * N_HAP):
+                continue
+            te = lib[fam] if not strand else revcomp_arr(lib[fam])
+            parts += [ref[last:p + tsd], te, ref[p:p + tsd]]
+            last = p + tsd
+            tot += len(te) + tsd
+            pos.append(p); shift.append(tot)
+        parts.append(ref[last:])
+        return (np.concatenate(parts) if len(parts) > 1 else ref), (np.array(pos, np.int64), np.array(shift, np.int64))
+
+    built = _pool_map(build, [(h, ci) for h in range(N_HAP) for ci in range(len(chroms))], threads)
+    haps = [[built[h * len(chroms) + ci][0] for ci in range(len(chroms))] for h in range(N_HAP)]
+    hap_ins = [[built[h * len(chroms) + ci][1] for ci in range(len(chroms))] for h in range(N_HAP)]
+    return dict(names=names, ref=refs, library=lib, insertions=ins, haps=haps, hap_ins=hap_ins, seed=seed)
+
+
+def hap_to_ref(g, h, ci, x):
+    """reference coordinate of haplotype coordinate(s) x (positions inside an inserted element map to its site)"""
+    pos, shift = g["hap_ins"][h][ci]
+    x = np.asarray(x, np.int64)
+    if len(pos) == 0:
+        return x
+    # hap coordinate at which insertion k starts = pos[k] + tsd + shift[k-1]; solve by searching the shifted starts
+    prev = np.r_[0, shift[:-1]]
+    hstart = pos + prev                     # (tsd is part of the shift of the same insertion; an error of < 10 bp is fine for truth checks)
+    k = np.searchsorted(hstart, x, side="right") - 1
+    sh = np.where(k >= 0, shift[np.maximum(k, 0)], 0)
+    inside = (k >= 0) & (x < hstart[np.maximum(k, 0)] + (shift[np.maximum(k, 0)] - prev[np.maximum(k, 0)]))
+    return np.where(inside, pos[np.maximum(k, 0)], x - sh)
+
+
+def plan_reads(g, coverage=30.0, mean_len=9000, sigma=0.6, min_len=500, max_len=150000, read_seed=None):
+    """The read plan: arrays (chrom, hap, start, length, strand) of every read, sampled until `coverage` x the
+    reference bases.  Reads start uniformly on a chromosome chosen by length and never cross its end."""
+    rng = np.random.default_rng([g["seed"] if read_seed is None else read_seed, 2])
+    clen = np.array([len(r) for r in g["ref"]], np.int64)
+    target = int(coverage * clen.sum())
+    mu = np.log(mean_len) - sigma * sigma / 2
+    n0 = int(target / mean_len * 1.3) + 64
+    lens = np.clip(rng.lognormal(mu, sigma, size=n0), min_len, max_len).astype(np.int64)
+    chrom = np.searchsorted(np.cumsum(clen), rng.integers(0, clen.sum(), size=n0), side="right")
+    hap = rng.integers(0, N_HAP, size=n0)
+    hlen = np.array([[len(g["haps"][h][c]) for c in range(len(clen))] for h in range(N_HAP)], np.int64)
+    L = np.minimum(lens, hlen[hap, chrom])
+    n = int(np.searchsorted(np.cumsum(L), target, side="left")) + 1
+    n = min(n, n0)
+    L, chrom, hap = L[:n], chrom[:n], hap[:n]
+    start = (rng.random(n) * (hlen[hap, chrom] - L + 1)).astype(np.int64)
+    strand = rng.integers(0, 2, size=n).astype(np.int64)
+    return dict(chrom=chrom.astype(np.int32), hap=hap.astype(np.int32), start=start, length=L, strand=strand.astype(np.int8),
+                n=n, n_blocks=(n + READ_BLOCK - 1) // READ_BLOCK, seed=g["seed"] if read_seed is None else read_seed)
+
+
+def block_bases(plan):
+    """planned (error-free) bases per block, for dealing blocks to ranks"""
+    nb = plan["n_blocks"]
+    pad = np.zeros(nb * READ_BLOCK, np.int64); pad[:plan["n"]] = plan["length"]
+    return pad.reshape(nb, READ_BLOCK).sum(axis=1)
+
+
+_MAT = {}        # state shared with forked workers (set before the pool starts; read-only afterwards)
+
+
+def _mat_block(b):
+    g_haps, plan, err = _MAT["haps"], _MAT["plan"], _MAT["err"]
+    r0, r1 = b * READ_BLOCK, min(plan["n"], (b + 1) * READ_BLOCK)
+    rng = np.random.default_rng([plan["seed"], 3, int(b)])
+    L = plan["length"][r0:r1]
+    frags = []
+    for i in range(r0, r1):
+        s = int(plan["start"][i]); f = g_haps[plan["hap"][i]][plan["chrom"][i]][s:s + int(plan["length"][i])]
+        frags.append(_COMP[f[::-1]] if plan["strand"][i] else f)
+    frag = np.concatenate(frags) if frags else np.zeros(0, np.uint8)
+    return mutate_bulk(rng, frag, L, *err)
+
+
+def materialize_reads(g, plan, blocks=None, err=(0.04, 0.02, 0.04), procs=1):
+    """Bases of the reads of `blocks` (default all), block by block with generator (seed, 3, block) -- the same
+    bases whatever the world size or the worker count.  procs > 1: forked worker processes (call before the
+    process touches the GPU).  -> (buf, off, len, read_ids): read_ids[i] = index of sequence i in the plan."""
+    blocks = np.arange(plan["n_blocks"]) if blocks is None else np.asarray(blocks)
+    _MAT.update(haps=g["haps"], plan=plan, err=err)
+    items = [int(b) for b in blocks]
+    if procs > 1 and len(items) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            parts = pool.map(_mat_block, items, chunksize=max(1, min(16, len(items) // (procs * 4))))
+    else:
+        parts = [_mat_block(b) for b in items]
+    _MAT.clear()
+    ln = np.concatenate([p[1] for p in parts]).astype(np.int32) if parts else np.zeros(0, np.int32)
+    buf = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.uint8)
+    del parts
+    off = np.cumsum(ln.astype(np.int64)) - ln
+    ids = np.concatenate([np.arange(b * READ_BLOCK, min(plan["n"], (b + 1) * READ_BLOCK)) for b in blocks]) if len(blocks) else np.zeros(0, np.int64)
+    return buf, off.astype(np.int64), ln, ids
+
+
+def make_loci(g, n_loci=None, seed=7, flank=(8000, 15000)):
+    """Per-locus inputs of the stage 3/4 bundle when Sniffles / wtdbg2 are unavailable: contig = the
+    insertion haplotype +-(8-15) kb around the site with 0.5 % residual error, ALT sequence = the inserted element
+    with 5 % error.  The window reads are NOT given here: they come from the stage-1 records
+    (telr_assembly.window_reads), as in the reference."""
+    rng = np.random.default_rng([g["seed"], 4, seed])
+    lib, ins = g["library"], g["insertions"]
+    order = np.arange(len(ins)) if n_loci is None or n_loci >= len(ins) else np.sort(rng.permutation(len(ins))[:n_loci])
+    loci = []
+    for k in order:
+        ci, p, fam, strand, tsd, af = ins[k]
+        hap0 = g["haps"][0][ci]
+        pos, shift = g["hap_ins"][0][ci]
+        j = int(np.searchsorted(pos, p))
+        a = p + tsd + (int(shift[j - 1]) if j > 0 else 0)         # first base of the element on haplotype 0
+        te_len = len(lib[fam])
+        lo, hi = int(rng.integers(*flank)), int(rng.integers(*flank))
+        s, e = max(0, a - lo), min(len(hap0), a + te_len + hi)
+        contig = mutate(rng, hap0[s:e], 0.003, 0.001, 0.001)
+        te = lib[fam] if not strand else revcomp_arr(lib[fam])
+        alt = mutate(rng, te, 0.03, 0.01, 0.01)
+        name = g["names"][ci]
+        loci.append({"name": "%s_%d_%d" % (name, p, p + 1), "chrom": name, "start": p, "end": p + 1, "contig": bytes(contig).decode(),
+                     "alt": bytes(alt).decode(), "truth": {"chrom": name, "pos": p, "family": "fam%d" % fam, "strand": "+-"[strand], "tsd": tsd, "af": af}})
+    return loci

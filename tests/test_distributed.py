@@ -33,8 +33,9 @@ def _worker(rank, world, port, n_loci, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     costs = [(i * 7919) % 1000 + 1 for i in range(n_loci)]
-    mine = shard.shard_loci(costs, world)[rank]
-    merged = shard.all_gather_rows(_make_rows(mine), dist)
+    shards = shard.shard_loci(costs, world)
+    mine = shards[rank]
+    merged = shard.all_gather_rows(_make_rows(mine), dist, capacity=max(len(x) for x in shards))
     if rank == 0:
         np.save(out_path, merged)
     dist.barrier()

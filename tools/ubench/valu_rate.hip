@@ -1,56 +1,130 @@
-// VALU issue-rate microbenchmark: cycles per wave-instruction per SIMD for the instruction kinds the DP kernels use.
+// VALU issue-rate microbenchmark for gfx950: cycles per wave64 instruction per SIMD, for the instruction kinds the DP and
+// chaining kernels are made of, at 1 / 2 / 4 / 8 resident waves per SIMD.  Cycles come from s_memtime inside the kernel
+// (shader clock ticks), not from an assumed frequency; the wall time of the launch gives the clock the part held.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o valu_rate valu_rate.hip && ./valu_rate > profiles/rNN_valu_rate.txt
+//
+// Every kind is a block of 64 INDEPENDENT-enough instructions (8 accumulators, each instruction depends on the one eight
+// places back) written in inline assembly so that the compiler cannot fuse, reorder or drop them.  Occupancy is pinned
+// with dynamic LDS: a workgroup of 256 threads (one wave on each of the CU's four SIMDs) asks for 1/W of the CU's
+// 160 KB, the grid has exactly 256 x W workgroups, so W waves share every SIMD for the whole measurement.
 #include <hip/hip_runtime.h>
-#include <cstdio>
+#include <algorithm>
 #include <cstdint>
-typedef short s2 __attribute__((ext_vector_type(2)));
-#define REP 64
-#define ITERS 4096
-template <int KIND> __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define ITERS 2048
+#define NINSTR 64
+
+#define ROW8(INS) \
+    INS(a0) INS(a1) INS(a2) INS(a3) INS(a4) INS(a5) INS(a6) INS(a7)
+#define BLOCK64(INS) ROW8(INS) ROW8(INS) ROW8(INS) ROW8(INS) ROW8(INS) ROW8(INS) ROW8(INS) ROW8(INS)
+
+#define I_FMA(r)      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_ADD(r)      asm volatile("v_add_u32 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_MAXI32(r)   asm volatile("v_max_i32 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_PKADD(r)    asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_PKSUB(r)    asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_PKMAX(r)    asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_PKASHR(r)   asm volatile("v_pk_ashrrev_i16 %0, 15, %0" : "+v"(r));
+#define I_BFI(r)      asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_ALIGNBIT(r) asm volatile("v_alignbit_b32 %0, %0, %1, 16" : "+v"(r) : "v"(c));
+#define I_PERM(r)     asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_DPP(r)      asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r));
+#define I_MAX3(r)     asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_MIN3U(r)    asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_SAD(r)      asm volatile("v_sad_u32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_MAD24(r)    asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_CVT(r)      asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(r));
+#define I_AND(r)      asm volatile("v_and_b32 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_LSHL(r)     asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(r));
+#define I_PKLSHL(r)   asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(r));
+#define I_PKMIN(r)    asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_PKMAD(r)    asm volatile("v_pk_mad_i16 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_XOR(r)      asm volatile("v_xor_b32 %0, %0, %1" : "+v"(r) : "v"(c));
+#define I_AND_OR(r)   asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r) : "v"(c), "v"(d));
+#define I_MOV(r)      asm volatile("v_mov_b32 %0, %1" : "+v"(r) : "v"(c));
+#define I_READLANE(r) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(s0) : "v"(r));
+
+enum { K_FMA, K_ADD, K_MAXI32, K_PKADD, K_PKSUB, K_PKMAX, K_PKASHR, K_BFI, K_ALIGNBIT, K_PERM, K_DPP, K_MAX3, K_MIN3U, K_SAD, K_MAD24,
+       K_CVT, K_AND, K_LSHL, K_PKLSHL, K_PKMIN, K_PKMAD, K_XOR, K_AND_OR, K_MOV, K_READLANE, K_N };
+static const char *NAMES[K_N] = { "v_fma_f32 (control)", "v_add_u32", "v_max_i32", "v_pk_add_i16", "v_pk_sub_i16", "v_pk_max_i16", "v_pk_ashrrev_i16",
+    "v_bfi_b32", "v_alignbit_b32", "v_perm_b32", "v_mov_b32_dpp wave_shr:1", "v_max3_i32", "v_min3_u32", "v_sad_u32", "v_mad_u32_u24",
+    "v_cvt_f32_u32", "v_and_b32", "v_lshlrev_b32", "v_pk_lshlrev_b16", "v_pk_min_i16", "v_pk_mad_i16", "v_xor_b32", "v_and_or_b32", "v_mov_b32", "v_readlane_b32" };
+
+template <int KIND> __global__ void __launch_bounds__(256) k(uint64_t *cycles, uint32_t *sink, uint32_t seed)
 {
-    uint32_t a[8];
-    for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i * 77;
-    uint32_t c = seed | 1;
+    extern __shared__ uint32_t lds_pad[];
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    uint32_t c = seed | 1, d = seed * 7 + 3;
+    uint32_t s0 = 0;
+    __builtin_amdgcn_s_barrier();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITERS; ++it) {
-#pragma unroll
-        for (int r = 0; r < REP / 8; ++r) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (KIND == 0) a[i] = a[i] + c;                                                   // v_add_u32
-                else if (KIND == 1) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2, a[i]) + __builtin_bit_cast(s2, c));          // v_pk_add_u16
-                else if (KIND == 2) a[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, a[i]), __builtin_bit_cast(s2, c)));  // v_pk_max_i16
-                else if (KIND == 3) a[i] = max((int)a[i], (int)c) + 1;                             // v_max_i32 + add (2 instr)
-                else if (KIND == 4) a[i] = __builtin_amdgcn_alignbit(a[i], c, 16);                 // v_alignbit_b32
-                else if (KIND == 5) a[i] = __builtin_amdgcn_perm(a[i], c, 0x0c0c0200u) + 1;         // v_perm_b32 + add
-                else if (KIND == 6) a[i] = __builtin_amdgcn_update_dpp(0, (int)a[i], 0x138, 0xf, 0xf, false) + 1;   // dpp mov + add
-                else if (KIND == 7) a[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2, a[i]) >> (s2)(15)) + c;   // v_pk_ashrrev + add
-                else if (KIND == 8) a[i] = (a[i] > c) ? a[i] - c : a[i] + 3;                       // cmp + cndmask + ...
-            }
-        }
-        c += 3;
+        if (KIND == K_FMA) { BLOCK64(I_FMA) } else if (KIND == K_ADD) { BLOCK64(I_ADD) } else if (KIND == K_MAXI32) { BLOCK64(I_MAXI32) }
+        else if (KIND == K_PKADD) { BLOCK64(I_PKADD) } else if (KIND == K_PKSUB) { BLOCK64(I_PKSUB) } else if (KIND == K_PKMAX) { BLOCK64(I_PKMAX) }
+        else if (KIND == K_PKASHR) { BLOCK64(I_PKASHR) } else if (KIND == K_BFI) { BLOCK64(I_BFI) } else if (KIND == K_ALIGNBIT) { BLOCK64(I_ALIGNBIT) }
+        else if (KIND == K_PERM) { BLOCK64(I_PERM) } else if (KIND == K_DPP) { BLOCK64(I_DPP) } else if (KIND == K_MAX3) { BLOCK64(I_MAX3) }
+        else if (KIND == K_MIN3U) { BLOCK64(I_MIN3U) } else if (KIND == K_SAD) { BLOCK64(I_SAD) } else if (KIND == K_MAD24) { BLOCK64(I_MAD24) }
+        else if (KIND == K_CVT) { BLOCK64(I_CVT) } else if (KIND == K_AND) { BLOCK64(I_AND) } else if (KIND == K_LSHL) { BLOCK64(I_LSHL) }
+        else if (KIND == K_PKLSHL) { BLOCK64(I_PKLSHL) } else if (KIND == K_PKMIN) { BLOCK64(I_PKMIN) } else if (KIND == K_PKMAD) { BLOCK64(I_PKMAD) }
+        else if (KIND == K_XOR) { BLOCK64(I_XOR) } else if (KIND == K_AND_OR) { BLOCK64(I_AND_OR) } else if (KIND == K_MOV) { BLOCK64(I_MOV) }
+        else if (KIND == K_READLANE) { BLOCK64(I_READLANE) }
     }
-    uint32_t s = 0;
-    for (int i = 0; i < 8; ++i) s ^= a[i];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    asm volatile("s_nop 0" ::: "memory");
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0) cycles[wave] = t1 - t0;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ s0 ^ lds_pad[0];
 }
-template <int KIND> void run(const char *name, int instr_per_op)
+
+template <int KIND> static void run(int W, int n_cu, uint64_t *d_cyc, uint32_t *d_sink, std::vector<uint64_t> &h)
 {
-    uint32_t *d; hipMalloc(&d, 256 * 8192 * 4);
+    const int blocks = n_cu * W;
+    const size_t lds = (size_t)(160 * 1024 / W) - 1024;      // at most W workgroups fit a CU
+    hipFuncSetAttribute((const void*)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    int blocks = 256 * 8;    // 8 blocks x 4 waves per CU = 8 waves per SIMD
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 12345u);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), lds, 0, d_cyc, d_sink, 12345u);      // warm-up (clock ramp)
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d, 12345u);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), lds, 0, d_cyc, d_sink, 12345u);
     hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1);
-    double waves_per_simd = blocks * 4.0 / (256 * 4);
-    double ops = (double)ITERS * REP * waves_per_simd;        // wave-ops per SIMD
-    double cyc = ms * 1e-3 * 2.4e9;
-    printf("%-28s %8.3f ms   %.2f cycles(@2.4GHz) per wave-op per SIMD  (%d instr/op -> %.2f cyc/instr)\n", name, ms, cyc / ops, instr_per_op, cyc / ops / instr_per_op);
-    hipFree(d);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const int nw = blocks * 4;
+    hipMemcpy(h.data(), d_cyc, (size_t)nw * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.begin() + nw);
+    const double per = (double)ITERS * NINSTR;
+    const double med = (double)h[nw / 2] / per, mn = (double)h[0] / per, mx = (double)h[nw - 1] / per;
+    // per SIMD: W waves interleave, so the SIMD issues one instruction every med / W cycles
+    printf("%-26s W=%d  cycles per instruction of one wave: median %6.2f  min %6.2f  max %6.2f   => %5.2f cycles per wave-instruction per SIMD   launch %.3f ms, clock >= %.2f GHz\n",
+           NAMES[KIND], W, med, mn, mx, med / W, ms, (double)h[nw - 1] / (ms * 1e-3) / 1e9);
+    hipEventDestroy(e0); hipEventDestroy(e1);
 }
+
+template <int KIND> static void run_all(int n_cu, uint64_t *d_cyc, uint32_t *d_sink, std::vector<uint64_t> &h)
+{
+    for (int W : { 1, 2, 4, 8 }) run<KIND>(W, n_cu, d_cyc, d_sink, h);
+}
+
 int main()
 {
-    run<0>("v_add_u32", 1); run<1>("v_pk_add_u16", 1); run<2>("v_pk_max_i16", 1); run<3>("v_max_i32+v_add", 2);
-    run<4>("v_alignbit_b32", 1); run<5>("v_perm_b32+add", 2); run<6>("v_mov_dpp wave_shr+add", 2); run<7>("v_pk_ashrrev_i16+add", 2); run<8>("cmp+cndmask+sub/add", 4);
+    hipDeviceProp_t p; if (hipGetDeviceProperties(&p, 0) != hipSuccess) { fprintf(stderr, "no device\n"); return 1; }
+    const int n_cu = p.multiProcessorCount;
+    printf("# %s (%s), %d CUs; %d iterations x %d instructions per wave; s_memtime ticks = shader cycles\n", p.name, p.gcnArchName, n_cu, ITERS, NINSTR);
+    printf("# columns: instruction, resident waves per SIMD (W), cycles one wave needs per instruction, the SIMD's issue interval (= that / W)\n");
+    uint64_t *d_cyc; uint32_t *d_sink;
+    hipMalloc(&d_cyc, (size_t)n_cu * 8 * 4 * 8); hipMalloc(&d_sink, (size_t)n_cu * 8 * 256 * 4);
+    std::vector<uint64_t> h((size_t)n_cu * 8 * 4);
+    run_all<K_FMA>(n_cu, d_cyc, d_sink, h); run_all<K_ADD>(n_cu, d_cyc, d_sink, h); run_all<K_MAXI32>(n_cu, d_cyc, d_sink, h);
+    run_all<K_PKADD>(n_cu, d_cyc, d_sink, h); run_all<K_PKSUB>(n_cu, d_cyc, d_sink, h); run_all<K_PKMAX>(n_cu, d_cyc, d_sink, h);
+    run_all<K_PKMIN>(n_cu, d_cyc, d_sink, h); run_all<K_PKASHR>(n_cu, d_cyc, d_sink, h); run_all<K_PKLSHL>(n_cu, d_cyc, d_sink, h);
+    run_all<K_PKMAD>(n_cu, d_cyc, d_sink, h);
+    run_all<K_BFI>(n_cu, d_cyc, d_sink, h); run_all<K_ALIGNBIT>(n_cu, d_cyc, d_sink, h); run_all<K_PERM>(n_cu, d_cyc, d_sink, h);
+    run_all<K_DPP>(n_cu, d_cyc, d_sink, h); run_all<K_MAX3>(n_cu, d_cyc, d_sink, h); run_all<K_MIN3U>(n_cu, d_cyc, d_sink, h);
+    run_all<K_SAD>(n_cu, d_cyc, d_sink, h); run_all<K_MAD24>(n_cu, d_cyc, d_sink, h); run_all<K_CVT>(n_cu, d_cyc, d_sink, h);
+    run_all<K_AND>(n_cu, d_cyc, d_sink, h); run_all<K_XOR>(n_cu, d_cyc, d_sink, h); run_all<K_AND_OR>(n_cu, d_cyc, d_sink, h);
+    run_all<K_LSHL>(n_cu, d_cyc, d_sink, h); run_all<K_MOV>(n_cu, d_cyc, d_sink, h); run_all<K_READLANE>(n_cu, d_cyc, d_sink, h);
+    hipFree(d_cyc); hipFree(d_sink);
     return 0;
 }

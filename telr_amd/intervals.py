@@ -15,6 +15,11 @@ A BED row is a list of strings exactly as it would appear in the file.
 """
 
 
+def _null_b(ncol):
+    """bedtools' filler for "no B feature": '.' for text columns, -1 for start / end / score"""
+    return [".", "-1", "-1", ".", "-1", "."][:ncol] + ["."] * max(0, ncol - 6)
+
+
 def bed_sort(rows):
     return sorted(rows, key=lambda r: (r[0], int(r[1])))
 
@@ -44,7 +49,7 @@ def closest_same_strand(a_rows, b_rows):
             elif d == best:
                 hits.append(b)
         if best is None:
-            out.append(list(a) + [".", "-1", "-1", ".", "-1", "."][:ncol_b] + ["-1"])
+            out.append(list(a) + _null_b(ncol_b) + ["-1"])
         else:
             for b in hits:
                 out.append(list(a) + list(b) + [str(best)])
@@ -64,7 +69,7 @@ def closest_signed_k(a_rows, b_rows, k=5):
             d, side = _dist(a_s, a_e, int(b[1]), int(b[2]))
             cand.append((d, i, d * (side if side else 1), b))
         if not cand:
-            out.append(list(a) + ([".", "-1", "-1"] + ["."] * (ncol_b - 3)) + ["-1"])
+            out.append(list(a) + _null_b(ncol_b) + ["-1"])
             continue
         cand.sort(key=lambda c: (c[0], c[1]))
         cut = cand[min(k, len(cand)) - 1][0]
@@ -109,7 +114,7 @@ def intersect_wao(a_rows, b_rows):
                 out.append(list(a) + list(b) + [str(ov)])
                 hit = True
         if not hit:
-            out.append(list(a) + ([".", "-1", "-1"] + ["."] * (ncol_b - 3)) + ["0"])
+            out.append(list(a) + _null_b(ncol_b) + ["0"])
     return out
 
 

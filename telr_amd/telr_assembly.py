@@ -1,4 +1,6 @@
-"""Read selection around candidate loci, mirroring the `read_type="all"` branch of the reference's
+"""Stage-2 hand-offs around the local assembler (hand-off point H3), mirroring `src/telr/TELR_assembly.py`:
+
+* `window_reads` / `annotate_vcf_with_counts`: read selection around candidate loci, mirroring the `read_type="all"` branch of the reference's
 `prep_assembly_inputs` (src/telr/TELR_assembly.py:384-415): for every locus of the VCF table, every read
 with ANY alignment record (primary, secondary or supplementary) overlapping
 [breakpoint-1000, breakpoint+1000) on the locus chromosome, breakpoint = round((start+end)/2).
@@ -8,6 +10,10 @@ seqtk / sort|uniq / csplit (:419-456); here the stage-1 records are still in mem
 masked lookup over the record arrays.  The reference iterates a Python `set` of read names, so its per-locus
 read ORDER depends on PYTHONHASHSEED; here reads come out in input order (the count, column 14 of
 `vcf_filtered.tsv.new`, is identical).
+
+* `polish_alignments`: the aligner half of `run_wtdbg2_polishing` (:185-260): `minimap2 -t N -ax P -r2k CNS READS | samtools
+sort` followed by `samtools view -F0x900 BAM | wtpoa-cns -d CNS -i -` (:199-236).  wtpoa-cns itself is a hand-off point and
+is not built here; what it reads on stdin is.
 """
 import numpy as np
 
@@ -40,3 +46,53 @@ def window_reads(alns, chrom_ids, loci, window=1000):
 def annotate_vcf_with_counts(loci, reads_per_locus):
     """the `.new` copy of the table: every row + the number of window reads (column 14)"""
     return [list(r) + [str(len(x))] for r, x in zip(loci, reads_per_locus)]
+
+
+def polish_alignments(engine, contig_names, contig_seqs, reads_by_locus, read_names=None, presets="ont", tmp_path=None):
+    """Site S3 for ALL loci in one engine call: the reads of locus k against its draft contig k (`-ax map-ont|map-pb -r2k`:
+    band width 2000, SAM output), then per locus the text that `samtools sort | samtools view -F0x900` pipes into
+    `wtpoa-cns -i -`: coordinate-sorted SAM records, primary alignments only (no 0x100 / 0x800), no header, unmapped
+    reads last (`view -F0x900` keeps them; wtpoa-cns skips them).
+
+    reads_by_locus[k]: read sequences (str) of locus k (SEQ is part of what wtpoa-cns reads, so the bases are needed on
+    the host anyway).  read_names[k]: their names (default "<contig>_r<i>").  -> (list of SAM texts per locus, record array, cigar array)"""
+    import os
+    import tempfile
+    from .presets import preset
+    io, mo = preset("map-pb" if presets == "pacbio" else "map-ont")
+    mo.bw = 2000                                            # -r2k (TELR_assembly.py:205)
+    ix = engine.index(list(contig_seqs), io)
+    qt, qnames, flat = [], [], []
+    for k, rs in enumerate(reads_by_locus):
+        for i, r in enumerate(rs):
+            qt.append(k); flat.append(r)
+            qnames.append(read_names[k][i] if read_names is not None else "%s_r%d" % (contig_names[k], i))
+    if not flat:
+        return ["" for _ in contig_names], np.zeros(0), np.zeros(0, np.uint32)
+    q_host = list(flat)
+    r = ix.map_raw(engine.seqset(q_host), mo, qtarget=np.asarray(qt, np.int32))
+    try:
+        res = ix.result_arrays(r)
+        fd, path = tempfile.mkstemp(suffix=".sam", dir=tmp_path)
+        os.close(fd)
+        try:
+            ix.write_sam(r, qnames, q_host, list(contig_names), list(contig_seqs), path, md=False, cs=False, softclip=False,
+                         primary_only=True, coordinate_sorted=True, header=False)
+            per = {n: [] for n in contig_names}
+            unmapped = [[] for _ in contig_names]
+            first_of = {}
+            for k, n in enumerate(contig_names):
+                first_of.setdefault(n, k)
+            q_locus = dict(zip(qnames, qt))
+            with open(path) as fh:
+                for line in fh:
+                    f = line.split("\t", 3)
+                    if f[2] == "*":
+                        unmapped[q_locus[f[0]]].append(line)
+                    else:
+                        per[f[2]].append(line)
+        finally:
+            os.remove(path)
+    finally:
+        ix.free_raw(r)
+    return ["".join(per[n]) + "".join(unmapped[k]) for k, n in enumerate(contig_names)], res.alns, res.cigars

@@ -1,0 +1,162 @@
+"""Stage 1 -> per-locus hand-off on the HIP engine at configs[1] size (rows a12 and H1 of SURVEY.md 8a / 2.4):
+
+  * `telr_assembly.window_reads` on the ENGINE'S OWN stage-1 records (TELR_assembly.py:384-415) finds the reads that
+    truly overlap each of the 200 spiked sites;
+  * the records at the sites carry what Sniffles reads an insertion from (TELR_sv.py:49-51; docs/02_Usage.md:76): an
+    `I` run of >= 0.8 x the element in the CIGAR, or a same-strand split whose two parts abut the site and leave the
+    element unaligned on the read, written as primary + SOFT-clipped supplementary with reciprocal SA tags;
+  * the per-locus bundle fed with these read sets recovers the insertions as well as with truth-derived read sets.
+"""
+import re
+
+import numpy as np
+import pytest
+
+from telr_amd import synth, telr_assembly, locus_pipeline
+from telr_amd.presets import preset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def stage1(engine):
+    d = synth.make_stage1_dataset(seed=20261002, read_seed=20261002 + 1000)
+    io, mo = preset("map-ont")
+    ref = bytes(d["ref"]).decode()
+    ix = engine.index([ref], io)
+    qs = engine.seqset(d["reads"])
+    res = ix.map(qs, mo)
+    loci = synth.make_loci_from_dataset(d, 200, reads_cap=10 ** 9)
+    return dict(d=d, ix=ix, qs=qs, res=res, loci=loci, ref=ref, io=io, mo=mo)
+
+
+def _sites(s):
+    return [("chr2L", l["truth"]["pos"], l["truth"]["pos"] + 1) for l in s["loci"]]
+
+
+def test_window_reads_on_engine_records_find_the_true_reads(stage1):
+    s = stage1
+    wr = telr_assembly.window_reads(s["res"].alns, {"chr2L": 0}, _sites(s))
+    frac = []
+    for l, got in zip(s["loci"], wr):
+        truth = set(l["read_idx"])                      # reads whose simulated origin overlaps +-1 kb of the site
+        assert len(truth) >= 5
+        frac.append(len(truth & set(got.tolist())) / len(truth))
+    frac = np.array(frac)
+    assert (frac >= 0.8).all(), "worst locus: %.2f" % frac.min()
+    assert frac.mean() >= 0.97
+
+
+def _ins_signatures(s, li, wr):
+    """reads of locus li whose records show the insertion: (kind, read id)"""
+    d, l = s["d"], s["loci"][li]
+    p, te_len = l["truth"]["pos"], len(d["library"][int(l["truth"]["family"][3:])])
+    alns, cig = s["res"].alns, s["res"].cigars
+    out = []
+    order = np.argsort(alns["qid"], kind="stable")
+    q_sorted = alns["qid"][order]
+    for q in wr.tolist():
+        lo, hi = np.searchsorted(q_sorted, q, "left"), np.searchsorted(q_sorted, q, "right")
+        recs = [alns[order[k]] for k in range(lo, hi) if not alns[order[k]]["flags"] & 2]
+        found = None
+        for a in recs:                                   # (a) one record with a long I run at the site
+            t = int(a["ts"])
+            for c in cig[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]]:
+                op, n = int(c) & 15, int(c) >> 4
+                if op == 1 and n >= 0.8 * te_len and abs(t - p) <= 60:
+                    found = "I"
+                if op != 1:
+                    t += n
+        if found is None:                                # (b) same-strand split around the site
+            for a in recs:
+                for b in recs:
+                    if a is b or (a["flags"] & 8) != (b["flags"] & 8):
+                        continue
+                    if abs(int(a["te"]) - p) <= 60 and abs(int(b["ts"]) - p) <= 60:
+                        rev = bool(a["flags"] & 8)
+                        gap = (int(a["qs"]) - int(b["qe"])) if rev else (int(b["qs"]) - int(a["qe"]))
+                        if gap >= 0.8 * te_len:
+                            found = "split"
+        if found:
+            out.append((found, q))
+    return out
+
+
+def test_records_at_the_sites_carry_an_insertion_signature(stage1, engine, tmp_path):
+    s = stage1
+    wr = telr_assembly.window_reads(s["res"].alns, {"chr2L": 0}, _sites(s))
+    weak, split_reads = [], []
+    for li, l in enumerate(s["loci"]):
+        sig = _ins_signatures(s, li, wr[li])
+        if len(sig) < 3:
+            weak.append((l["name"], l["truth"]["af"], len(sig), len(wr[li])))
+        split_reads += [q for k, q in sig if k == "split"][:1]
+    assert not weak, "sites with fewer than 3 reads showing the insertion: %r" % weak
+    # the SAM form of some split reads: primary + soft-clipped supplementary (-Y) with reciprocal SA tags
+    pick = split_reads[:12]
+    assert len(pick) >= 5
+    buf, off, ln = s["d"]["reads"]
+    seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in pick]
+    r = s["ix"].map_raw(seqs, s["mo"])
+    try:
+        sam = str(tmp_path / "split.sam")
+        s["ix"].write_sam(r, ["read%d" % i for i in pick], seqs, ["chr2L"], [s["ref"]], sam, md=True, cs=True, softclip=True)
+    finally:
+        s["ix"].free_raw(r)
+    by_read = {}
+    for line in open(sam):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        if int(f[1]) & 0x100:
+            continue
+        by_read.setdefault(f[0], []).append(f)
+    n_pairs = 0
+    for name, recs in by_read.items():
+        if len(recs) < 2:
+            continue
+        assert sum(1 for f in recs if not int(f[1]) & 0x800) == 1                     # exactly one primary
+        for f in recs:
+            tags = {t[:2]: t[5:] for t in f[11:]}
+            assert "SA" in tags
+            others = [g for g in recs if g is not f]
+            sa = [x.split(",") for x in tags["SA"].rstrip(";").split(";")]
+            assert sorted((x[0], int(x[1]), x[2]) for x in sa) == sorted((g[2], int(g[3]), "-" if int(g[1]) & 16 else "+") for g in others)
+            if int(f[1]) & 0x800:
+                assert "H" not in f[5] and len(f[9]) == sum(int(n) for n, o in re.findall(r"(\d+)([MIS])", f[5]))   # -Y: soft clips, full SEQ
+        n_pairs += 1
+    assert n_pairs >= 5
+
+
+def _recovered(out, loci):
+    by = {}
+    for r in out["liftover"]:
+        by.setdefault(locus_pipeline.locus_of_report(r), []).append(r["report"])
+    ok = set()
+    for l in loci:
+        t = l["truth"]
+        if any(r["type"] == "non-reference" and abs(r["start"] - t["pos"]) <= 20 and r["strand"] == t["strand"] and r["family"] == t["family"] for r in by.get(l["name"], [])):
+            ok.add(l["name"])
+    return ok
+
+
+def test_bundle_on_engine_selected_reads_recovers_like_truth_selected(stage1, engine):
+    s = stage1
+    io10, _ = preset("asm10")
+    ix10 = engine.index([s["ref"]], io10)
+    lib_names = ["fam%d" % i for i in range(len(s["d"]["library"]))]
+    lib = [bytes(x).decode() for x in s["d"]["library"]]
+    wr = telr_assembly.window_reads(s["res"].alns, {"chr2L": 0}, _sites(s))
+    loci_e = [dict(l, read_idx=w.astype(np.int32)) for l, w in zip(s["loci"], wr)]
+    loci_t = [dict(l, read_idx=np.asarray(l["read_idx"], np.int32)) for l in s["loci"]]
+    for l in loci_e + loci_t:
+        l.pop("reads", None)
+    out_e = locus_pipeline.run_loci(engine, ix10, ["chr2L"], lambda ch: s["ref"], loci_e, lib_names, lib, read_set=s["qs"])
+    out_t = locus_pipeline.run_loci(engine, ix10, ["chr2L"], lambda ch: s["ref"], loci_t, lib_names, lib, read_set=s["qs"])
+    rec_e, rec_t = _recovered(out_e, loci_e), _recovered(out_t, loci_t)
+    assert rec_e == rec_t, "engine-selected only: %r, truth-selected only: %r" % (sorted(rec_e - rec_t), sorted(rec_t - rec_e))
+    assert len(rec_e) >= 190
+    # coordinates / strand / family do not depend on the read set at all; the allele frequencies agree closely
+    assert out_e["liftover"] == out_t["liftover"] and out_e["annotation"] == out_t["annotation"]
+    diffs = [abs(out_e["af"][n]["freq"] - out_t["af"][n]["freq"]) for n in out_e["af"] if out_e["af"][n]["freq"] is not None and out_t["af"].get(n, {}).get("freq") is not None]
+    assert len(diffs) >= 150 and np.mean(diffs) <= 0.02 and max(diffs) <= 0.25

@@ -569,11 +569,122 @@ def capture_output(O):
         shutil.rmtree(tmp)
 
 
+def capture_prep_assembly():
+    """prep_assembly_inputs(read_type="all") (TELR_assembly.py:384-462) with pysam / seqtk / Bio stubbed: the stage-1 BAM is a
+    table of records (read, chromosome, 0-based start, end, SAM flag); `fetch` follows htslib's region rule (a record is
+    returned when start < region end and end > region start, secondary and supplementary records included, unmapped
+    ones not).  cat | sort | uniq, csplit and cp are the real coreutils."""
+    import random
+    import subprocess as real_sp
+    import telr.TELR_assembly as A
+    rnd = random.Random(11)
+    chrom_len = {"chr2L": 60000, "chrUn_CP007071v1": 20000, "chr4": 9000}
+    recs = []
+    names = ["read%03d" % i for i in range(70)]
+    for i, n in enumerate(names):
+        c = ["chr2L", "chr2L", "chr2L", "chrUn_CP007071v1", "chr4"][i % 5]
+        L = rnd.randint(300, 9000); s0 = rnd.randint(0, max(1, chrom_len[c] - L))
+        recs.append((n, c, s0, s0 + L, rnd.choice([0, 16])))
+        if i % 4 == 0:      # a supplementary piece elsewhere, sometimes on another chromosome
+            c2 = c if i % 8 else "chr2L"
+            L2 = rnd.randint(200, 3000); s2 = rnd.randint(0, max(1, chrom_len[c2] - L2))
+            recs.append((n, c2, s2, s2 + L2, 2048 | rnd.choice([0, 16])))
+        if i % 7 == 0:
+            L2 = rnd.randint(200, 3000); s2 = rnd.randint(0, max(1, chrom_len[c] - L2))
+            recs.append((n, c, s2, s2 + L2, 256))
+    # edge cases around the locus at chr2L:30000-30001 (breakpoint 30000, window [29000, 31000))
+    recs += [("edge_end_at_start", "chr2L", 28000, 29000, 0),       # ends where the window starts: no overlap
+             ("edge_end_past_start", "chr2L", 28000, 29001, 0),     # one base inside
+             ("edge_start_at_end", "chr2L", 31000, 33000, 16),      # starts where the window ends: no overlap
+             ("edge_start_before_end", "chr2L", 30999, 33000, 16),
+             ("edge_secondary_only", "chr2L", 29500, 30500, 256),
+             ("edge_unmapped", None, -1, -1, 4)]
+    loci = [["chr2L", "30000", "30001"], ["chr2L", "500", "520"], ["chr2L", "10", "11"], ["chr2L", "45001", "45004"], ["chr2L", "45002", "45004"],
+            ["chrUn_CP007071v1", "7000", "7001"], ["chr4", "8990", "8991"], ["chr4", "3", "4"]]
+    rows = []
+    for k, l in enumerate(loci):
+        # the 14 columns of <sample>.vcf_filtered.tsv (TELR_sv.py:84-140); column 9 = the SV caller's read list
+        rows.append(l + ["100", "5", "fam", "id%d" % k, "ACGT", ",".join(names[k:k + 3]), "PASS", "0/1", "3", "4", "0.5"])
+
+    class Rec(object):
+        def __init__(self, n):
+            self.query_name = n
+
+    class FakeSam(object):
+        def __init__(self, path, mode):
+            pass
+
+        def fetch(self, c, start, end):
+            if c not in chrom_len:
+                raise ValueError("invalid contig `%s`" % c)
+            for (n, rc, s0, e0, fl) in recs:
+                if rc == c and not (fl & 4) and s0 < end and e0 > start:
+                    yield Rec(n)
+
+    class FakeSp(object):
+        PIPE = real_sp.PIPE
+
+        def call(self, cmd, stdout=None, shell=False, **kw):
+            if shell and cmd.startswith("seqtk subseq"):
+                parts = cmd.split()
+                fa, ids = parts[2], parts[3]
+                want = set(x.strip() for x in open(ids) if x.strip())
+                name = None
+                for line in open(fa):
+                    if line.startswith(">"):
+                        name = line[1:].split()[0]
+                    if name in want:
+                        stdout.write(line)
+                return 0
+            return real_sp.call(cmd, stdout=stdout, shell=shell, **kw)
+
+    class FakeIndex(dict):
+        def get_raw(self, k):
+            return self[k]
+
+    def fake_index(path, fmt):
+        d, name = FakeIndex(), None
+        for line in open(path, "rb"):
+            if line.startswith(b">"):
+                name = line[1:].split()[0].decode(); d[name] = b""
+            d[name] += line
+        return d
+    tmp = tempfile.mkdtemp()
+    try:
+        A.pysam.AlignmentFile = FakeSam
+        A.subprocess = FakeSp()
+        A.SeqIO.index = fake_index
+        vcf = os.path.join(tmp, "s.vcf_filtered.tsv")
+        with open(vcf, "w") as f:
+            for r in rows:
+                f.write("\t".join(r) + "\n")
+        reads_fa = os.path.join(tmp, "reads.fa")
+        with open(reads_fa, "w") as f:
+            for n in names + ["edge_end_at_start", "edge_end_past_start", "edge_start_at_end", "edge_start_before_end", "edge_secondary_only", "edge_unmapped"]:
+                f.write(">%s\n%s\n" % (n, rnd_seq(40, sum(n.encode()))))
+        rdir = os.path.join(tmp, "telr_reads")
+        A.prep_assembly_inputs(vcf, tmp, "s", "stage1.bam", reads_fa, rdir, read_type="all")
+        new_table = open(vcf + ".new").read()
+        per_locus = []
+        for k in range(len(loci)):
+            ids = [l[1:].split()[0] for l in open(os.path.join(rdir, "contig%d" % k)) if l.startswith(">")]
+            per_locus.append(sorted(ids))
+        return {"records": [list(r) for r in recs], "chrom_len": chrom_len, "vcf_rows": rows, "expected_new_table": new_table,
+                "expected_reads_per_locus": per_locus}
+    finally:
+        shutil.rmtree(tmp)
+
+
 def main():
     L, T, S, U = import_reference()
     os.makedirs(GOLD, exist_ok=True)
     import telr.TELR_output as O
-    for name, obj in (("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
+    if "--only-assembly" in sys.argv:
+        with open(os.path.join(GOLD, "prep_assembly.json"), "w") as f:
+            json.dump(capture_prep_assembly(), f, indent=1, sort_keys=True)
+        print("wrote prep_assembly.json")
+        return
+    for name, obj in (("prep_assembly.json", capture_prep_assembly()), ("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
                       ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O)), ("sv.json", capture_sv(S, U))):
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)

@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--fill-band-q4", type=int, default=0, help="experiment: override the preset's first-pass band factor (0 = preset)")
     ap.add_argument("--loci", type=int, default=-1, help="candidate loci for the TE-loci/s leg (-1 = all spiked insertions, 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
+    ap.add_argument("--data-cache", default="", help="directory: the rank's generated data set is stored there / loaded from there (profiling runs: no forked generator)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
     return ap.parse_args()
 
@@ -192,7 +193,18 @@ def main():
         return
     import numpy as np
     t0 = time.time()
-    D = build_dataset(a, cfg, rank, world, lws)       # CPU only; forks workers: before any GPU initialisation
+    cache = os.path.join(a.data_cache, "telr_bench_%s_%s_r%dof%d_cov%g_gs%g.pkl" % (a.config, a.scaling, rank, world, a.coverage, a.genome_scale)) if a.data_cache else ""
+    if cache and os.path.exists(cache):
+        import pickle
+        with open(cache, "rb") as fh:
+            D = pickle.load(fh)
+    else:
+        D = build_dataset(a, cfg, rank, world, lws)       # CPU only; forks workers: before any GPU initialisation
+        if cache:
+            import pickle
+            os.makedirs(a.data_cache, exist_ok=True)
+            with open(cache, "wb") as fh:
+                pickle.dump(D, fh, protocol=4)
     t_gen = time.time() - t0
 
     import torch

@@ -82,13 +82,18 @@ typedef struct telr_map_opt {
     int32_t ext_band;         /* half band width of end extensions                     */
     int32_t flags;            /* TELR_MF_*                                             */
     int32_t fill_band_q4;     /* first-pass half band of a gap fill: 2 + q4*floor(sqrt(min(m,n)))/16;
-                                 0 = 8.  Paths that touch the band edge are re-aligned with the wide band. */
+                                 0 = 8.  Paths that come close to a band edge are re-aligned with the wide band. */
+    int32_t fill_margin;      /* "close" = within this many diagonals of a band edge (0 = touching it)        */
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */
 #define TELR_MF_PER_TARGET 0x2   /* select/rank chains separately for every target:
                                     one call answers "QRY vs each of N subjects"
                                     (S5: the TE library against every contig)        */
+#define TELR_MF_FAITHFUL   0x4   /* CPU oracle only (telr_map rejects it): drop the speed-motivated bounds of the spec --
+                                    gap fills over the whole -r band, end extensions over the whole remaining read in a
+                                    band of -r diagonals, chaining look-back 5000.  The reference point against which
+                                    the tuned presets are gated (tests/test_faithful_gate.py).                          */
 
 /* ---- one alignment (PAF line / SAM record worth of numbers), 88 bytes ---- */
 typedef struct telr_aln {

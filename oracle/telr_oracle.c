@@ -391,7 +391,7 @@ static inline int32_t chain_sc(uint64_t ai, uint64_t aj, const telr_map_opt *mo)
 
 static void chain_dp(const uint64_t *a, int64_t n, const telr_map_opt *mo, int32_t *f, int32_t *p)
 {
-    int H = mo->chain_lookback;
+    int H = (mo->flags & (TELR_MF_FAITHFUL | 0x100)) ? 5000 : mo->chain_lookback;     /* faithful mode: minimap2's max_chain_iter (0x100-0x400: its parts, for experiments) */
     for (int64_t i = 0; i < n; ++i) {
         int32_t best = A_SPAN(a[i]), bp = -1;
         int64_t st = i - H; if (st < 0) st = 0;
@@ -599,7 +599,7 @@ static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr
     int state = 0;
     while (i > 0 && j > 0) {
         uint8_t t = tb[(size_t)(i + j) * stride + ((j - i - dlo) >> 1)];
-        if (j - i == dlo || j - i == dhi) res.touched = 1;     /* the path used all the slack of the band */
+        if (j - i - dlo <= mo->fill_margin || dhi - (j - i) <= mo->fill_margin) res.touched = 1;     /* the path used (nearly) all the slack of the band */
         if (state == 0) state = t & 7;
         if (state == 0) { cig_push(rev_cig, 0, 1); --i; --j; }
         else if (state == 1) { cig_push(rev_cig, 2, 1); if (!(t & 8))  state = 0; --j; }
@@ -698,6 +698,11 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
 {
     const uint8_t *t = ix->seq[c->tid];
     const int tlen = ix->len[c->tid], go = (int32_t)ix->goff[c->tid];
+    /* TELR_MF_FAITHFUL (oracle only): no speed-motivated bounds -- gap fills over the whole -r band, end extensions over
+     * the whole remaining read in a band of -r diagonals (still z-drop terminated), chaining look-back 5000.  The drift of
+     * the tuned presets against this mode is gated by tests/test_faithful_gate.py. */
+    const int faithful = (mo->flags & (TELR_MF_FAITHFUL | 0x200)) != 0, faithful_ext = (mo->flags & (TELR_MF_FAITHFUL | 0x400)) != 0;
+    const int ext_max = faithful_ext ? (1 << 30) : mo->ext_max, ext_band = faithful_ext ? mo->bw : mo->ext_band;
     /* query accessor on the chain's strand */
     dp_seq_t s; s.q = q; s.t = t; s.qcomp = c->rev;
     /* breakpoints */
@@ -717,11 +722,11 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     /* left extension: reversed sequences starting at (q0-1, r0-1) going down */
     int32_t qs = q0, rs = r0;
     if (q0 > 0 && r0 > 0) {
-        int mq = q0 < mo->ext_max ? q0 : mo->ext_max, mt = r0 < mq + mo->ext_band ? r0 : mq + mo->ext_band;
+        int mq = q0 < ext_max ? q0 : ext_max, mt = r0 < mq + ext_band ? r0 : mq + ext_band;
         s.m = mq; s.n = mt; s.tstep = -1; s.ti0 = r0 - 1;
         if (c->rev) { s.qstep = 1; s.qi0 = qlen - q0; } else { s.qstep = -1; s.qi0 = q0 - 1; }
         rc.n = 0;
-        dp_res_t r = band_dp(&s, even_lo(-mo->ext_band), mo->ext_band, 1, mo, &rc);
+        dp_res_t r = band_dp(&s, even_lo(-ext_band), ext_band, 1, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
         dp += r.score; qs = q0 - r.bi; rs = r0 - r.bj;
         /* rev_cig is end->start of the reversed problem == left-to-right on the forward sequences */
@@ -734,11 +739,13 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         /* long segments are few and a second pass over one of them is slow: they take the wide band at once */
         const int is_long = s.m + s.n > ADAPT_MAX_STEPS;
         int W = is_long ? fill_band_wide(s.m, s.n, mo) : fill_band(s.m, s.n, mo), dl = s.n - s.m;
+        if (faithful) W = mo->bw;               /* the whole -r band, whatever the segment */
         rc.n = 0;
         int lo = even_lo((dl < 0 ? dl : 0) - W), hi = (dl > 0 ? dl : 0) + W, fb_mlen;
-        dp_res_t r = hi - lo + 1 > DP_DMAX ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
+        if (faithful) { if (lo < -s.m) lo = even_lo(-s.m); if (hi > s.n) hi = s.n; }      /* no wider than the matrix */
+        dp_res_t r = (!faithful && hi - lo + 1 > DP_DMAX) ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
-        if (r.touched && !is_long) {            /* second pass with the wide band */
+        if (r.touched && !is_long && !faithful) {            /* second pass with the wide band */
             int W2 = fill_band_wide(s.m, s.n, mo);
             lo = even_lo((dl < 0 ? dl : 0) - W2); hi = (dl > 0 ? dl : 0) + W2;
             if (W2 > W && hi - lo + 1 <= DP_DMAX) { rc.n = 0; r = band_dp(&s, lo, hi, 0, mo, &rc); ctr->dp_cells += r.cells; }
@@ -749,11 +756,11 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     int32_t qe = c->qe, re = c->re;
     if (qe < qlen && re < tlen) {
         int rq = qlen - qe, rt = tlen - re;
-        int mq = rq < mo->ext_max ? rq : mo->ext_max, mt = rt < mq + mo->ext_band ? rt : mq + mo->ext_band;
+        int mq = rq < ext_max ? rq : ext_max, mt = rt < mq + ext_band ? rt : mq + ext_band;
         s.m = mq; s.n = mt; s.tstep = 1; s.ti0 = re;
         if (c->rev) { s.qstep = -1; s.qi0 = qlen - 1 - qe; } else { s.qstep = 1; s.qi0 = qe; }
         rc.n = 0;
-        dp_res_t r = band_dp(&s, even_lo(-mo->ext_band), mo->ext_band, 1, mo, &rc);
+        dp_res_t r = band_dp(&s, even_lo(-ext_band), ext_band, 1, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
         dp += r.score; qe += r.bi; re += r.bj;
         for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);

@@ -14,7 +14,7 @@ class MapOpt(C.Structure):
         ("mask_level", C.c_float), ("pri_ratio", C.c_float), ("best_n", C.c_int32), ("secondary", C.c_int32),
         ("a", C.c_int32), ("b", C.c_int32), ("q", C.c_int32), ("e", C.c_int32), ("q2", C.c_int32), ("e2", C.c_int32),
         ("sc_ambi", C.c_int32), ("zdrop", C.c_int32), ("min_dp_max", C.c_int32), ("min_ksw_len", C.c_int32),
-        ("ext_max", C.c_int32), ("ext_band", C.c_int32), ("flags", C.c_int32), ("fill_band_q4", C.c_int32),
+        ("ext_max", C.c_int32), ("ext_band", C.c_int32), ("flags", C.c_int32), ("fill_band_q4", C.c_int32), ("fill_margin", C.c_int32),
     ]
 
     def copy(self):
@@ -40,7 +40,7 @@ class Counters(C.Structure):
 
 
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8
-MF_CIGAR, MF_PER_TARGET = 1, 2
+MF_CIGAR, MF_PER_TARGET, MF_FAITHFUL = 1, 2, 4
 N_STAGES = 16
 N_DPCLS = 22
 

@@ -1181,7 +1181,7 @@ __device__ __forceinline__ bool d_any_n(const uint32_t *__restrict__ nmask, int6
     }
     return false;
 }
-__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
+__global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_margin, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
                              const uint32_t *__restrict__ qnmask, const uint32_t *__restrict__ tnmask,
                              int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
 {
@@ -1205,7 +1205,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int32_t pk_
         int ilo = d < 0 ? 1 - d : 1, ihi = P.n - d < P.m ? P.n - d : P.m;
         if (ihi >= ilo) cells += ihi - ilo + 1;
     }
-    probs[i].pad[0] = cls; probs[i].pad[1] = cells;
+    probs[i].pad[0] = cls | (fill_margin << 8); probs[i].pad[1] = cells;      // class, and the margin of the retry test for the trace-back
     tb_bytes[i] = tb;
     cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
@@ -1251,7 +1251,7 @@ __global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs,
     if (i < np) {
         probs[i].tb_off = tb_off[i];
         if (cig_off) probs[i].cig_off = cig_off[i];       // a retry keeps the CIGAR slot of the original problem
-        const int c = probs[i].kind >= 3 ? 0 : probs[i].pad[0];
+        const int c = probs[i].kind >= 3 ? 0 : (probs[i].pad[0] & 0xff);
         atomicAdd(&lcnt[c], 1);
         int steps = probs[i].m + probs[i].n; if (steps > 0xFFFFF) steps = 0xFFFFF;
         sort_key[i] = (uint32_t)c << 20 | (uint32_t)(0xFFFFF - steps);
@@ -2061,7 +2061,7 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
     const DpProb P = probs[pi];
     if (P.kind >= 3) return;
     const int dhi_ = P.dhi; int touched = 0;
-    const int cls = P.pad[0], dlo = P.dlo;
+    const int cls = P.pad[0] & 0xff, dlo = P.dlo, mg = P.pad[0] >> 8;
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
     const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
     const bool packed = cls >= 5;
@@ -2113,7 +2113,7 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
         }
         const int w = (int)(abs_off & 63);
         const uint32_t t = (stage[slot * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
-        touched |= (j - i == dlo) | (j - i == dhi_);
+        touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
         // one step of the walk without branches: the 64 lanes are in 64 different states
         const int s0 = state ? state : (int)(t & 7);                 // 0 = diagonal, 1/3 = deletion (E1/E2), 2/4 = insertion (F1/F2)
         const int isM = s0 == 0, isD = s0 & 1;
@@ -2153,7 +2153,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
     const int lane = threadIdx.x;
     DpProb P = probs[pi];
     if (P.kind >= 3) have = false;
-    const int rowb = lpp * 4, dlo = P.dlo, dhi_ = P.dhi;
+    const int rowb = lpp * 4, dlo = P.dlo, dhi_ = P.dhi, mg = P.pad[0] >> 8;
     int i = 0, j = 0;
     if (have) { i = res[pi].bi; j = res[pi].bj; }
     const uint8_t *tb = tb_all + P.tb_off;                       // 64-byte aligned (k_prob_sizes)
@@ -2199,7 +2199,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                 const int oo = act ? o : 0, w = oo & 63;
                 const uint32_t t = (stage[((oo >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
                 if (act) {
-                    touched |= (j - i == dlo) | (j - i == dhi_);
+                    touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
                     const int s0 = state ? state : (int)(t & 7);
                     const int isM = s0 == 0, isD = s0 & 1;
                     const int op = isM ? 0 : (isD ? 2 : 1);
@@ -2253,7 +2253,7 @@ __global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ p
     const DpProb P = probs[pi];
     if (P.kind >= 3) return;
     const int dhi_ = P.dhi; int touched = 0;
-    const int cls = P.pad[0], dlo = P.dlo;
+    const int cls = P.pad[0] & 0xff, dlo = P.dlo, mg = P.pad[0] >> 8;
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
     const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
     const bool packed = cls >= 5;
@@ -2298,7 +2298,7 @@ __global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ p
         }
         const int w = (int)(col - c0);
         const uint32_t t = (win[(r0 - row) * 16 + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
-        touched |= (j - i == dlo) | (j - i == dhi_);
+        touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
         if (state == 0) state = t & 7;
         int op;
         if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }
@@ -2360,7 +2360,7 @@ __global__ void __launch_bounds__(256) k_dp_account(const DpProb *__restrict__ p
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < np) {
         const DpProb P = probs[i]; const DpRes d = res[i];
-        const int cls = P.kind >= 3 ? 0 : P.pad[0];
+        const int cls = P.kind >= 3 ? 0 : (P.pad[0] & 0xff);
         atomicAdd(&lacc[cls * 4 + 0], 1ULL);
         atomicAdd(&lacc[cls * 4 + 1], (unsigned long long)d.cells);
         atomicAdd(&lacc[cls * 4 + 2], (unsigned long long)(d.bi + d.bj));

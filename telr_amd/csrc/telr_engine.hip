@@ -219,9 +219,9 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
     mo->max_gap = 5000; mo->bw = 500; mo->chain_lookback = 128; mo->min_cnt = 3; mo->min_chain_score = 40;
     mo->mask_level = 0.5f; mo->pri_ratio = 0.8f; mo->best_n = 5; mo->secondary = 1;
     mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
-    mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6;
+    mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6; mo->fill_margin = 1;
     if (s == "map-ont") { mo->fill_band_q4 = 4; }
-    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 8; }
+    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 12; }
     else if (s == "ngmlr-ont" || s == "ngmlr-pacbio") {
         // `ngmlr -x ont|pacbio` (TELR_alignment.py:28-51, the reference's default aligner).  NGMLR 0.2.7 indexes 13-mers at
         // every third reference position: (w,k) = (5,13) minimizers have that density.  Its convex gap cost (open, then an
@@ -230,8 +230,9 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
         // (exact at L = 1 and L >= 27, within 6 in between);  ont (1, -1, open 1, extend 1 -> 0.5), doubled to integers:
         // C(L) = 2 + sum_{i<L} max(1, 2 - 0.3 i) ~ min(2 + 2L, 4 + L).  AS is in these integer units (ont: twice NGMLR's).
         io->k = 13; io->w = 5;
-        if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; mo->fill_band_q4 = 4; }
-        else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; mo->fill_band_q4 = 8; }
+        if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; }
+        else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; }
+        mo->fill_band_q4 = 12; mo->fill_margin = 2;
     }
     else if (s == "asm10") {
         io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;
@@ -262,6 +263,25 @@ static inline uint8_t nt4_of(unsigned char c)
                  case 'T': case 't': case 'U': case 'u': return 3; default: return 4; }
 }
 
+// 8 ASCII bases -> 16 bits of 2-bit codes (A 0, C 1, G 2, T/U 3, either case; base i in bits 2i..2i+1) and 8 ambiguity
+// bits (anything else; its code bits are 0), branch-free on one 64-bit word: the packing of a multi-Gbp read set is
+// part of the host-inclusive rate of the path
+static inline void pack8(uint64_t x, uint32_t &code16, uint32_t &amb8)
+{
+    const uint64_t L = 0x0101010101010101ULL, H = 0x8080808080808080ULL, M7 = 0x7F7F7F7F7F7F7F7FULL;
+    uint64_t t = (x >> 1) & (3 * L);             // bits 1-2 of the ASCII code: A 0, C 1, T 2, G 3
+    t ^= (t >> 1) & L;                           // -> A 0, C 1, G 2, T 3
+    const uint64_t u = x | (0x20 * L);           // lower case
+    auto eq = [&](unsigned char c) { const uint64_t v = u ^ (c * L); return ~(((v & M7) + M7) | v | M7); };   // 0x80 in the bytes equal to c (exact)
+    const uint64_t inv = ~(eq('a') | eq('c') | eq('g') | eq('t') | eq('u')) & H;
+    t &= ~((inv >> 7) * 3);
+    t = (t | (t >> 6)) & 0x000F000F000F000FULL;
+    t = (t | (t >> 12)) & 0x000000FF000000FFULL;
+    t = (t | (t >> 24)) & 0xFFFFULL;
+    code16 = (uint32_t)t;
+    amb8 = (uint32_t)(((inv >> 7) * 0x0102040810204080ULL) >> 56);
+}
+
 extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, const int64_t *off, const int32_t *len, telr_seqset **out)
 {
     if (!ctx || n < 0 || !out || (n > 0 && (!ascii || !off || !len))) return TELR_E_ARG;
@@ -283,10 +303,17 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
         for (int i = t; i < n; i += nth) {
             const unsigned char *p = (const unsigned char*)ascii + off[i];
-            int64_t b = s->boff[i];
-            for (int j = 0; j < len[i]; ++j) {
-                uint8_t c = nt4_of(p[j]); int64_t x = b + j;
-                if (c > 3) hn[x >> 5] |= 1u << (x & 31); else h2[x >> 4] |= (uint32_t)c << ((x & 15) * 2);
+            const int64_t b = s->boff[i];              // multiple of 64: 8-base groups never straddle a word
+            const int L = len[i];
+            for (int j = 0; j < L; j += 8) {
+                uint64_t x8;
+                if (j + 8 <= L) memcpy(&x8, p + j, 8);
+                else { unsigned char tail[8] = { 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A' }; memcpy(tail, p + j, (size_t)(L - j)); memcpy(&x8, tail, 8); }
+                uint32_t code16, amb8;
+                pack8(x8, code16, amb8);
+                const int64_t x = b + j;
+                h2[x >> 4] |= code16 << ((x & 15) * 2);
+                if (amb8) hn[x >> 5] |= amb8 << (x & 31);
             }
         }
     });
@@ -936,7 +963,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo);
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
@@ -1738,6 +1765,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (!ctx || !ix || !queries || !mo || !out) return TELR_E_ARG;
     if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
     if (mo->e < mo->e2 || mo->q > mo->q2) { ctx->err = "two-piece gap cost needs e >= e2 and q <= q2"; return TELR_E_ARG; }
+    if (mo->fill_margin < 0 || mo->fill_margin > 64) { ctx->err = "fill_margin must be 0..64"; return TELR_E_ARG; }
+    if (mo->flags & TELR_MF_FAITHFUL) { ctx->err = "TELR_MF_FAITHFUL is a mode of the CPU oracle (test infrastructure), not of the engine"; return TELR_E_ARG; }
     if (mo->max_gap >= TELR_TPAD || mo->ext_band * 2 + 1 > DP_DMAX || mo->ext_band < 1 || mo->ext_max < 1) return TELR_E_ARG;
     if (queries->max_len >= (1 << 24)) return TELR_E_RANGE;
     HIPCHK(hipSetDevice(ctx->device));

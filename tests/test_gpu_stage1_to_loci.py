@@ -93,7 +93,7 @@ def test_records_at_the_sites_carry_an_insertion_signature(stage1, engine, tmp_p
         split_reads += [q for k, q in sig if k == "split"][:1]
     assert not weak, "sites with fewer than 3 reads showing the insertion: %r" % weak
     # the SAM form of some split reads: primary + soft-clipped supplementary (-Y) with reciprocal SA tags
-    pick = split_reads[:12]
+    pick = list(dict.fromkeys(split_reads))[:12]          # a read can support two neighbouring sites: once
     assert len(pick) >= 5
     buf, off, ln = s["d"]["reads"]
     seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in pick]

@@ -343,6 +343,8 @@ def main():
             t = torch.tensor([t_loci], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_loci = float(t[0])
         good = 0; af_ok = 0; n_rows = len(rows)
         fam_of = {i: n for i, n in enumerate(lib_names)}
+        why = {"no row (no TE annotated on the contig)": n_loci - n_rows, "annotation merged with a neighbouring reference TE copy (several families)": 0,
+               "unlifted (flanks not placed next to each other)": 0, "other": 0}
         for r in rows:
             l = loci[int(r["locus_id"])]; tr = l["truth"]
             if r["type"] == 1 and r["chrom_id"] == chrom_ids[tr["chrom"]] and abs(int(r["start"]) - tr["pos"]) <= 20 and \
@@ -350,8 +352,14 @@ def main():
                 good += 1
                 if not np.isnan(r["af"]) and abs(float(r["af"]) - tr["af"]) <= 0.15:
                     af_ok += 1
+            elif r["n_family"] > 1:
+                why["annotation merged with a neighbouring reference TE copy (several families)"] += 1
+            elif r["type"] == 0:
+                why["unlifted (flanks not placed next to each other)"] += 1
+            else:
+                why["other"] += 1
         wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]
-        loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok,
+        loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
                     "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0,
                     "collectives": "none" if world == 1 else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
                     "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
@@ -368,7 +376,7 @@ def main():
     # over the launches); its algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per CIGAR run,
     # 32 B result.
     cls = cls_tot
-    PK = list(range(10, 18))
+    PK = list(range(10, 18)) + [22]
     k_name = "k_dp_pk"
     launches = max(1, launches)
     k_ms_tot = stage_tot.get("k_dp_pk", 0.0)

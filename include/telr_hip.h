@@ -231,7 +231,7 @@ int  telr_last_counters(const telr_ctx *ctx, telr_counters *out);
 /* per DP class (TELR_N_DPCLS classes) of the last telr_map call:
  * out[c*4+0] problems, [c*4+1] DP cells, [c*4+2] anti-diagonal steps (sum of m+n),
  * [c*4+3] algorithmic bytes (2-bit bases read once + 4 B per CIGAR run + 32 B result) */
-#define TELR_N_DPCLS 22
+#define TELR_N_DPCLS 23
 int  telr_last_dp_classes(const telr_ctx *ctx, int64_t *out /* [TELR_N_DPCLS*4] */);
 
 #ifdef __cplusplus

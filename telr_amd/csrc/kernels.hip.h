@@ -1001,6 +1001,142 @@ __global__ void k_bt_big(const int32_t *__restrict__ q_aoff, int32_t nq, int32_t
     if (n > lo && n <= hi) big_list[atomicAdd(big_cnt, 1)] = q;
 }
 
+// ---- back-tracking without a walker (round 2).  The predecessor links form a forest (p[i] < i, i - p[i] <= look-back).
+// Visiting the peaks in rank order (f descending, index ascending) and walking up until a visited anchor is the same as:
+//   owner(i) = the best-ranked peak in the subtree of i  (the first walker to reach i);
+//   chain t  = { i : owner(i) = t }, a path from the peak of rank t up to the first anchor owned by a better peak
+//              (it exists iff the peak owns itself); its anchors in index order are the chain in ascending order;
+//   depth(i) = number of same-owner ancestors = position of i on its chain;  count = depth(peak) + 1;
+//   score    = f(peak) - f(parent of the chain's top anchor)  (0 when the top is a root).
+// owner is a reverse sweep (children push the minimum to parents), depth a forward sweep (list ranking); both run over
+// blocks of 64 anchors with the link targets of the last `look-back` anchors in an LDS ring, and resolve the links that
+// stay inside a block by six rounds of pointer jumping -- every lane works, where the walker kept 63 of 64 idle at LDS
+// latency per anchor.  One wave per query whatever its size (no LDS tiers, no lists).
+#define BT_INF 0xffffffffu
+#define BT_RING 512                 // >= look-back (<= 256) + 2 x 64
+__global__ void k_bt_rank(const int32_t *__restrict__ q_aoff, const uint64_t *__restrict__ pk, const int32_t *__restrict__ n_peaks, uint32_t *__restrict__ owner)
+{
+    const int q = blockIdx.x;
+    const int64_t base = q_aoff[q]; const int np = n_peaks[q];
+    for (int t = threadIdx.x; t < np; t += blockDim.x) owner[base + (uint32_t)(pk[base + t] & 0xffffffffu)] = (uint32_t)t;
+}
+__global__ void __launch_bounds__(64) k_bt_owner(const int32_t *__restrict__ q_aoff, int32_t nq, const int32_t *__restrict__ p, int32_t lookback,
+                                                 uint32_t *__restrict__ owner, const int32_t *__restrict__ q_order)
+{
+    __shared__ uint32_t W[BT_RING];
+    __shared__ int32_t UP[64];
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    if (n <= 0) return;
+    const int nblk = (n + 63) >> 6;
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int b0 = blk << 6;
+        // ring entries that enter the window [b0 - lookback, b0 + 64): all of it for the first block handled, the lowest 64 afterwards
+        if (blk == nblk - 1) { for (int x = b0 - lookback + lane; x < b0 + 64; x += 64) if (x >= 0 && x < n) W[x & (BT_RING - 1)] = owner[base + x]; }
+        else { const int x = b0 - lookback + lane; if (x >= 0) W[x & (BT_RING - 1)] = owner[base + x]; }
+        const int i = b0 + lane; const bool valid = i < n;
+        const int pi = valid ? p[base + i] : -1;
+        int up = pi >= b0 ? pi - b0 : -1;
+        UP[lane] = up;
+        for (int k = 0; k < 6; ++k) {
+            if (__ballot(up >= 0) == 0) break;
+            if (up >= 0) atomicMin(&W[(b0 + up) & (BT_RING - 1)], W[i & (BT_RING - 1)]);
+            const int nup = up >= 0 ? UP[up] : -1;
+            UP[lane] = nup; up = nup;
+        }
+        if (valid) {
+            const uint32_t v = W[i & (BT_RING - 1)];
+            owner[base + i] = v;
+            if (pi >= 0 && pi < b0) atomicMin(&W[pi & (BT_RING - 1)], v);
+        }
+    }
+}
+__global__ void __launch_bounds__(64) k_bt_depth(const int32_t *__restrict__ q_aoff, int32_t nq, const int32_t *__restrict__ p, const uint32_t *__restrict__ owner,
+                                                 int32_t *__restrict__ depth, int32_t *__restrict__ ch_top, const int32_t *__restrict__ q_order)
+{
+    __shared__ uint32_t OWN[BT_RING];
+    __shared__ int32_t DEP[BT_RING];
+    __shared__ int32_t UP[64], VAL[64];
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    const int nblk = (n + 63) >> 6;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int b0 = blk << 6, i = b0 + lane; const bool valid = i < n;
+        const uint32_t o = valid ? owner[base + i] : BT_INF;
+        const int pi = valid ? p[base + i] : -1;
+        OWN[i & (BT_RING - 1)] = o;
+        const uint32_t po = pi >= 0 ? OWN[pi & (BT_RING - 1)] : BT_INF;
+        const bool conn = o != BT_INF && pi >= 0 && po == o;           // the parent is on the same chain
+        int up = -1, val = 0;
+        if (conn) { if (pi >= b0) { up = pi - b0; val = 1; } else val = DEP[pi & (BT_RING - 1)] + 1; }
+        UP[lane] = up; VAL[lane] = val;
+        for (int k = 0; k < 6; ++k) {
+            if (__ballot(up >= 0) == 0) break;
+            const int add = up >= 0 ? VAL[up] : 0, nup = up >= 0 ? UP[up] : -1;
+            val += add;
+            VAL[lane] = val; UP[lane] = nup; up = nup;
+        }
+        DEP[i & (BT_RING - 1)] = val;
+        if (valid) {
+            depth[base + i] = val;
+            if (o != BT_INF && !conn) ch_top[base + o] = i;            // exactly one top anchor per chain
+        }
+    }
+}
+// chains of a query in rank order: which exist, pass the filters, where their anchors go
+__global__ void __launch_bounds__(64) k_bt_emit(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq, const int32_t *__restrict__ f,
+                                                const int32_t *__restrict__ p, const uint64_t *__restrict__ pk, const int32_t *__restrict__ n_peaks,
+                                                const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt, const uint32_t *__restrict__ owner,
+                                                const int32_t *__restrict__ depth, const int32_t *__restrict__ ch_top, int32_t *__restrict__ ch_aoff,
+                                                ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains, const int32_t *__restrict__ q_order)
+{
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
+    const int64_t base = q_aoff[q]; const int np = n_peaks[q];
+    ChainRec *out = rec + ch_off[q];
+    int nch = 0, wr = 0;
+    for (int t0 = 0; t0 < np; t0 += 64) {
+        const int t = t0 + lane;
+        bool keep = false; int cnt = 0, sc = 0, idx = 0, top = 0;
+        if (t < np) {
+            const uint64_t key = pk[base + t];
+            idx = (int)(uint32_t)(key & 0xffffffffu);
+            const int fi = 0x7fffffff - (int)(uint32_t)(key >> 32);
+            if (owner[base + idx] == (uint32_t)t) {
+                cnt = depth[base + idx] + 1;
+                top = ch_top[base + t];
+                const int pj = p[base + top];
+                sc = fi - (pj >= 0 ? f[base + pj] : 0);
+                keep = sc >= min_sc && cnt >= min_cnt;
+            }
+        }
+        const uint64_t km = __ballot(keep);
+        const int before = __popcll(km & ((1ULL << lane) - 1));
+        int ps = keep ? cnt : 0;                       // inclusive scan of the kept counts
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(ps, d); if (lane >= d) ps += v; }
+        if (t < np) ch_aoff[base + t] = keep ? wr + ps - cnt : -1;
+        if (keep) {
+            ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr + ps - cnt; r.pad = 0;
+            r.a0 = keys[base + top]; r.a1 = keys[base + idx];
+            out[nch + before] = r;
+        }
+        nch += __popcll(km); wr += __shfl(ps, 63);
+    }
+    if (lane == 0) n_chains[q] = nch;
+}
+__global__ void k_bt_scatter(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, const uint32_t *__restrict__ owner, const int32_t *__restrict__ depth,
+                             const int32_t *__restrict__ ch_aoff, uint64_t *__restrict__ canch, const int32_t *__restrict__ q_order)
+{
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t o = owner[base + i];
+        if (o == BT_INF) continue;
+        const int ao = ch_aoff[base + o];
+        if (ao >= 0) canch[base + ao + depth[base + i]] = keys[base + i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 5. DP problems
 struct KeptChain {          // uploaded by the host after chain selection
@@ -1127,12 +1263,14 @@ __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
-#define DP_NCLS 22
+#define DP_NCLS 23
 // 10-17: packed-int16 register kernel d_dp_pkr<LPP, R> for short gap fills, by band width.  One lane per problem:
 // class 17 D <= 16 (R = 4), classes 10..13 D = 17-20 / 21-24 / 25-28 / 29-32 (R = 5 / 6 / 7 / 8: exact ranges, so that only
 // the last register of a lane can straddle the upper band edge); two lanes: classes 14..16 D <= 40 / 48 / 64 (R = 5 / 6 / 8).
 // 18: z-drop extensions with D <= 64 (four lanes, R = 4)
 // 19-21: wide fills in int16 while the scores fit (steps <= pk_wide_steps): D <= 256 / 512 / 1024, 1 / 2 / 4 waves per problem
+// 22: 65..128 diagonals, four lanes x R = 8 (16 problems per wave): the class of the retried fills (wide band of a ~200-base
+//     segment = 100-130 diagonals), which the margin rule of the band spec makes ~1 % of all fills
 __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps)
 {
     if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
@@ -1145,8 +1283,8 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
         if (D <= 40) return 14;
         if (D <= 48) return 15;
         if (D <= 64) return 16;
+        if (D <= 128) return 22;
     }
-    // (65..128 diagonals: few problems, mostly retries, where what counts is the latency of one problem: the 64-lane class 19)
     if (kind == 0 && steps <= pk_wide_steps && D > 64) {
         if (D <= 256) return 19;
         if (D <= 512) return 20;
@@ -1164,6 +1302,7 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
 // dwords per packed trace-back row
 __device__ __forceinline__ int d_cls_slots(int cls)
 {
+    if (cls == 22) return 32;
     if (cls >= 19) return 64 << (cls - 19);
     if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 4 : 16;
     return cls == 5 ? 32 : 64 << (cls - 6);
@@ -1979,9 +2118,11 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
 // All packed classes run as ONE launch: a wave is described by (class, first problem of its class list) and the
 // wave table is ordered by decreasing estimated cost (steps x registers per lane), so the long waves start first and
 // no class leaves the machine idle behind its own tail.
-#define PK_NC 8                            /* packed fill classes 10 .. 10+PK_NC-1 */
-__device__ __constant__ const int PK_LPP[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 1 };
-__device__ __constant__ const int PK_R[PK_NC]   = { 5, 6, 7, 8, 5, 6, 8, 4 };
+#define PK_NC 9                            /* packed fill classes of the one cost-ordered launch: 10 .. 17 and 22 */
+__host__ __device__ __forceinline__ int PK_CLS(int c) { return c < 8 ? 10 + c : 22; }
+__host__ __device__ __forceinline__ int PK_IDX(int cls) { return cls == 22 ? 8 : cls - 10; }
+__device__ __constant__ const int PK_LPP[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 1, 4 };
+__device__ __constant__ const int PK_R[PK_NC]   = { 5, 6, 7, 8, 5, 6, 8, 4, 8 };
 struct PkPlan { int32_t woff[PK_NC + 1]; };   // first wave of class 10+c in the unsorted wave table
 __global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__restrict__ cls_list, ClsOff off, PkPlan plan,
                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
@@ -1991,9 +2132,9 @@ __global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__re
     int c = 0;
     while (i >= plan.woff[c + 1]) ++c;
     const int first = (i - plan.woff[c]) * (64 / PK_LPP[c]);
-    const DpProb P = probs[cls_list[off.off[10 + c] + first]];     // lists are sorted by decreasing steps
+    const DpProb P = probs[cls_list[off.off[PK_CLS(c)] + first]];     // lists are sorted by decreasing steps
     keys[i] = (uint32_t)((P.m + P.n) * PK_R[c]);
-    vals[i] = (uint32_t)(10 + c) << 26 | (uint32_t)first;
+    vals[i] = (uint32_t)PK_CLS(c) << 26 | (uint32_t)first;
 }
 #ifndef PK_WPE
 #define PK_WPE 2
@@ -2013,6 +2154,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     case 17: d_dp_pkr<1, 4, false>(A, list, n, first); break;            // up to 16 diagonals
     case 14: d_dp_pkr<2, 5, false>(A, list, n, first); break;
     case 15: d_dp_pkr<2, 6, false>(A, list, n, first); break;
+    case 22: d_dp_pkr<4, 8, false>(A, list, n, first); break;            // 65..128 diagonals
     default: d_dp_pkr<2, 8, false>(A, list, n, first); break;
     }
 }
@@ -2233,9 +2375,9 @@ __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ 
     __shared__ uint32_t stage[TB_SLOTS * 16 * 64];
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
-    const int ppw = 64 / PK_LPP[cls - 10], t = threadIdx.x;
+    const int ppw = 64 / PK_LPP[PK_IDX(cls)], t = threadIdx.x;
     const bool have = t < ppw && first + t < off.off[cls + 1] - off.off[cls];
-    d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[cls - 10] * PK_R[cls - 10], d_tb_interleaved(cls), tb_all, cig, retry, stage);
+    d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)], d_tb_interleaved(cls), tb_all, cig, retry, stage);
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control

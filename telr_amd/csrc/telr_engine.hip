@@ -1013,9 +1013,9 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     // before the tail classes are started so that these two small launches do not queue behind them
     int nw = 0; uint32_t *d_wv2 = nullptr;
     {
-        static const int LPP_[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 1 };
+        static const int LPP_[PK_NC] = { 1, 1, 1, 1, 2, 2, 2, 1, 4 };
         PkPlan plan; plan.woff[0] = 0;
-        for (int c = 0; c < PK_NC; ++c) { const int ppw = 64 / LPP_[c]; plan.woff[c + 1] = plan.woff[c] + (h_cls[10 + c] + ppw - 1) / ppw; }
+        for (int c = 0; c < PK_NC; ++c) { const int ppw = 64 / LPP_[c]; plan.woff[c + 1] = plan.woff[c] + (h_cls[PK_CLS(c)] + ppw - 1) / ppw; }
         nw = plan.woff[PK_NC];
         if (nw > 0) {
             uint32_t *d_wk, *d_wv, *d_wk2;
@@ -1063,8 +1063,10 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         else { const int ppw = 64 / PKX_LPP; hipLaunchKernelGGL(k_dp_pkx, dim3((nl + ppw - 1) / ppw), dim3(64), 0, s2, D); }
         HIPCHK(hipGetLastError());
         if (tb_split) {
-            // few long problems: one wave walks one problem; many short ones (extensions): one lane per problem
-            if (c == 18 || c == 0) hipLaunchKernelGGL(k_traceback, dim3((nl + 63) / 64), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
+            // few long problems: one wave walks one problem (latency); many (extensions, or a tail class with thousands of problems
+            // on a repeat-rich genome): one lane per problem (throughput)
+            static const int tbw_max = [] { const char *e = getenv("TELR_TBW_MAX"); return e ? atoi(e) : 2048; }();
+            if (c == 18 || c == 0 || nl > tbw_max) hipLaunchKernelGGL(k_traceback, dim3((nl + 63) / 64), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
             else hipLaunchKernelGGL(k_traceback_w, dim3(nl), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
             HIPCHK(hipGetLastError());
         }
@@ -1269,6 +1271,23 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipStreamSynchronize(st));
     ChainRec *d_rec;
     TRY(ctx_buf_t(ctx, "chain_rec", (size_t)npk_tot, &d_rec));
+    static const bool bt_walker = getenv("TELR_BT_WALKER") != nullptr;      // the round-1 kernel (lane 0 walks), kept for A/B runs
+    if (!bt_walker) {
+        // owner / depth sweeps (kernels.hip.h, "back-tracking without a walker"): five launches over all queries, longest first
+        uint32_t *d_owner; int32_t *d_depth, *d_chtop, *d_chaoff;
+        TRY(ctx_buf_t(ctx, "bt_owner", (size_t)na + 1, &d_owner));
+        TRY(ctx_buf_t(ctx, "bt_depth", (size_t)na + 1, &d_depth));
+        TRY(ctx_buf_t(ctx, "bt_chtop", (size_t)na + 1, &d_chtop));
+        TRY(ctx_buf_t(ctx, "bt_chaoff", (size_t)na + 1, &d_chaoff));
+        HIPCHK(hipMemsetAsync(d_owner, 0xff, ((size_t)na + 1) * 4, st));
+        hipLaunchKernelGGL(k_bt_rank, dim3(nq), dim3(256), 0, st, d_qaoff, d_pk2, d_npk, d_owner);
+        hipLaunchKernelGGL(k_bt_owner, dim3(nq), dim3(64), 0, st, d_qaoff, nq, d_p, mo->chain_lookback, d_owner, d_qorder);
+        hipLaunchKernelGGL(k_bt_depth, dim3(nq), dim3(64), 0, st, d_qaoff, nq, d_p, d_owner, d_depth, d_chtop, d_qorder);
+        hipLaunchKernelGGL(k_bt_emit, dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff, mo->min_chain_score, mo->min_cnt,
+                           d_owner, d_depth, d_chtop, d_chaoff, d_rec, d_nch, d_qorder);
+        hipLaunchKernelGGL(k_bt_scatter, dim3(nq), dim3(256), 0, st, d_skeys, d_qaoff, d_owner, d_depth, d_chaoff, d_canch, d_qorder);
+        HIPCHK(hipGetLastError());
+    } else
     {
         // queries with more than BT_CAP anchors run from lists, in two LDS tiers on side streams under the bulk launch
         // (repeat-rich genomes put a third of the reads there): the stage is bound by resident queries per CU, so a query

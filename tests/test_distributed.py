@@ -128,3 +128,78 @@ def test_locus_bundle_sharded_world2_equals_world1(tmp_path):
         t = truth[int(r["locus_id"])]
         if r["type"] == 1:
             assert abs(int(r["start"]) - t["pos"]) <= 20 and (1 if t["strand"] == "+" else -1) == r["strand"]
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from telr_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every rank holds reads 100*rank .. ; read r of locus l goes to rank l % world; the LAST rank owns reads but sends none to
+    # itself and rank 1 sends nothing at all (an empty sender), rank 0 receives for loci 0, world, 2*world ...
+    items = []
+    if rank != 1:
+        for k in range(7):
+            gid = 100 * rank + k
+            for locus in range(5):
+                if (gid + locus) % 3 == 0:
+                    rng = np.random.default_rng(gid)
+                    items.append((locus % world, locus, gid, rng.integers(65, 70, size=10 + gid % 13).astype(np.uint8)))
+    got = shard.exchange_window_reads(items, dist)
+    np.save(os.path.join(out_dir, "got%d.npy" % rank), np.array([(l, r, len(b), int(b.sum())) for l, r, b in got], np.int64).reshape(-1, 4))
+    # the locus table: an empty contribution from rank 1 must not disturb the one all-gather
+    rows = _make_rows([rank]) if rank != 1 else _make_rows([])
+    merged = shard.all_gather_rows(rows, dist, capacity=1)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "rows.npy"), merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_window_read_exchange_and_empty_rank(tmp_path, world):
+    """the all-to-all of window reads (stage 1 -> loci hand-off when reads are sharded) delivers every read to the owner of
+    its locus, sorted by (locus, read id), also with a rank that sends nothing; world size 1 is the identity"""
+    import torch.multiprocessing as mp
+    from telr_amd import shard
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = {r: [] for r in range(world)}
+    for rank in range(world):
+        if rank == 1:
+            continue
+        for k in range(7):
+            gid = 100 * rank + k
+            for locus in range(5):
+                if (gid + locus) % 3 == 0:
+                    b = np.random.default_rng(gid).integers(65, 70, size=10 + gid % 13).astype(np.uint8)
+                    want[locus % world].append((locus, gid, len(b), int(b.sum())))
+    for r in range(world):
+        got = np.load(str(tmp_path / ("got%d.npy" % r)))
+        assert [tuple(x) for x in got.tolist()] == sorted(want[r])
+    rows = np.load(str(tmp_path / "rows.npy"))
+    assert rows["locus_id"].tolist() == [r for r in range(world) if r != 1]
+    one = shard.exchange_window_reads([(0, 3, 9, np.arange(4, dtype=np.uint8)), (0, 1, 2, np.arange(2, dtype=np.uint8))])
+    assert [(l, r) for l, r, _ in one] == [(1, 2), (3, 9)]
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` without RANK in the environment starts two ranks itself (torch.distributed.run as a child of
+    a process that has not touched the GPU) and relays rank 0's line -- here with the gloo backend and no GPU work"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--backend", "gloo"], env=env,
+                         capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-1500:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rank_sum"] == 3 and d["dry_launch"]
+
+
+def test_locus_names_with_underscores():
+    """chrUn_CP007071v1-style chromosome names: the locus of a liftover report is everything before its last two fields"""
+    from telr_amd import locus_pipeline
+    assert locus_pipeline.locus_of_report({"ID": "chrUn_CP007071v1_100_101_4000_4900"}) == "chrUn_CP007071v1_100_101"
+    assert locus_pipeline.locus_of_report({"ID": "chr2L_33000_33020_12_4711"}) == "chr2L_33000_33020"
+    assert locus_pipeline.locus_cost({"contig": "ACGT" * 5, "alt": "AC", "read_bases": 100}) == 122

@@ -28,7 +28,7 @@ def test_locus_bundle_equals_oracle_and_recovers_truth(engine):
 def check_truth(res, loci, truth):
     by_id = {}
     for r in res["liftover"]:
-        by_id["_".join(r["ID"].split("_")[:3])] = r
+        by_id[locus_pipeline.locus_of_report(r)] = r
     ok = 0
     for l, t in zip(loci, truth):
         r = by_id.get(l["name"])

@@ -45,3 +45,23 @@ def test_bundle_to_output_files(tmp_path):
     te = (tmp_path / "s.telr.te.fasta").read_text().count(">")
     assert te == len(final) and (tmp_path / "s.telr.json").exists() and (tmp_path / "s.telr.expanded.json").exists()
     assert all(r["te_length"] == len(r["te_sequence"]) for r in expanded)
+
+
+def test_chromosome_name_with_underscores():
+    """a scaffold-style name (chrUn_CP007071v1): loci keep their rows through run_loci_distributed (the report -> locus key
+    is everything before the last two '_' fields), the 5' chromosome filter of the liftover sees the full name, and loci
+    that carry read_idx / read_bases instead of read sequences can be dealt by cost"""
+    from oracle_backend import OracleBackend
+    from locus_data import make_loci
+    ref, lib_names, lib, loci, truth = make_loci(n_ins=3, reads_per_locus=16)
+    chrom = "chrUn_CP007071v1"
+    for l in loci:
+        l["name"] = l["name"].replace("chr2L", chrom)
+    be = OracleBackend()
+    io, _ = preset("asm10")
+    rows, res = locus_pipeline.run_loci_distributed(be, be.index([ref], io), [chrom], lambda ch: ref, loci, lib_names, lib, presets="ont")
+    assert len(rows) == len(loci) and set(rows["locus_id"].tolist()) == set(range(len(loci)))
+    ok = sum(1 for r in rows if r["type"] == 1 and r["chrom_id"] == 0 and abs(int(r["start"]) - truth[int(r["locus_id"])]["pos"]) <= 20)
+    assert ok >= len(loci) - 1
+    assert all(r["report"]["chrom"] in (chrom, None) for r in res["liftover"])
+    assert locus_pipeline.locus_cost({"contig": "A" * 10, "alt": None, "read_idx": [1, 2]}) == 10

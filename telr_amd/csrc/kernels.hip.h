@@ -1153,6 +1153,137 @@ struct KeptChain {          // uploaded by the host after chain selection
     int64_t qbase, tbase;   // packed base offsets of query / target
     uint32_t goff; int32_t pad;
 };
+
+// ---- chain selection, pass 1, on the device (round 2; the host did this between two synchronisations: 125 MB of chain
+// records over PCIe and ~7 ms of host work per Gbp of reads).  Same outcome as select_chains() of the oracle:
+// chains of a query in (score desc, discovery asc) order; a chain overlapping a better PRIMARY by more than
+// mask_level x the shorter of the two query intervals is its secondary; secondaries survive with score >= pri_ratio x
+// parent and while fewer than best_n are kept (per target with TELR_MF_PER_TARGET).  One wave per query walks the sorted
+// chains; the lanes test one chain against 64 primaries at a time.  The float products / compares are the host's.
+struct SelOpt { float mask_level, pri_ratio; int32_t best_n, secondary, per_target; };
+struct KeptLite { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, pad; };      // what the host still needs of a kept chain (40 B)
+__global__ void k_sel_keys(const int32_t *__restrict__ ch_off, const int32_t *__restrict__ n_chains, const ChainRec *__restrict__ rec,
+                           uint64_t *__restrict__ key, int32_t *__restrict__ seg_end)
+{
+    const int q = blockIdx.x;
+    const int base = ch_off[q], n = n_chains[q];
+    for (int c = threadIdx.x; c < n; c += blockDim.x) key[base + c] = (uint64_t)(uint32_t)(0x7fffffff - rec[base + c].score) << 32 | (uint32_t)c;
+    if (threadIdx.x == 0) seg_end[q] = base + n;
+}
+// box of a chain from its first / last anchor (the host's HostChain)
+__device__ __forceinline__ void d_chain_box(const ChainRec &r, const uint32_t *__restrict__ goff, int n_targets, int &rev, int &tid, int &rs, int &re, int &qs, int &qe)
+{
+    rev = (int)(r.a0 >> 63);
+    tid = d_tid_of(goff, n_targets, (uint32_t)A_G(r.a0));
+    const int go = (int)goff[tid];
+    rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; re = A_G(r.a1) - go + 1;
+    qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      qe = A_Q(r.a1) + 1;
+}
+// The primaries found so far (query interval, target, score) live in LDS (SEL_PCAP of them; beyond that in the global
+// scratch regions [ch_off[q], ...) pfs/pfe/ptid/pkey), the kept-secondary tallies per target of the per-target mode in
+// tcnt_t/tcnt_n (global, same regions).  64 chains are fetched and boxed at a time (one per lane), then walked in order
+// with lane broadcasts, so the sequential loop touches no global memory in the common case.  keep = flag per SORTED position.
+#define SEL_PCAP 1024
+__global__ void __launch_bounds__(64) k_select1(const int32_t *__restrict__ ch_off, const int32_t *__restrict__ n_chains, const ChainRec *__restrict__ rec,
+                                                const uint64_t *__restrict__ skey, const int32_t *__restrict__ qlen_of, const uint32_t *__restrict__ goff, int32_t n_targets,
+                                                SelOpt o, int32_t *__restrict__ pfs, int32_t *__restrict__ pfe, int32_t *__restrict__ ptid, int32_t *__restrict__ pkey,
+                                                int32_t *__restrict__ tcnt_t, int32_t *__restrict__ tcnt_n, uint8_t *__restrict__ keep, int32_t *__restrict__ n_kept,
+                                                const int32_t *__restrict__ q_order)
+{
+    __shared__ int32_t Lfs[SEL_PCAP], Lfe[SEL_PCAP], Ltid[SEL_PCAP], Lkey[SEL_PCAP];
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x, lane = threadIdx.x;
+    const int base = ch_off[q], n = n_chains[q], qlen = qlen_of[q];
+    int n_prim = 0, n2_all = 0, n_t = 0, nk = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int cnt = n - i0 < 64 ? n - i0 : 64;
+        int my_fs = 0, my_fe = 0, my_tid = 0, my_sc = 0;
+        if (lane < cnt) {
+            const ChainRec r = rec[base + (int)(uint32_t)(skey[base + i0 + lane] & 0xffffffffu)];
+            int rev, rs, re, qs, qe;
+            d_chain_box(r, goff, n_targets, rev, my_tid, rs, re, qs, qe);
+            my_fs = rev ? qlen - qe : qs; my_fe = rev ? qlen - qs : qe; my_sc = r.score;
+        }
+        bool my_keep = false;
+        for (int u = 0; u < cnt; ++u) {
+            const int fs = __builtin_amdgcn_readlane(my_fs, u), fe = __builtin_amdgcn_readlane(my_fe, u), tid = __builtin_amdgcn_readlane(my_tid, u),
+                      sc = __builtin_amdgcn_readlane(my_sc, u);
+            int parent = -1;
+            for (int c0 = 0; c0 < n_prim && parent < 0; c0 += 64) {
+                const int j = c0 + lane;
+                bool hit = false;
+                if (j < n_prim) {
+                    const int jt = j < SEL_PCAP ? Ltid[j] : ptid[base + j];
+                    if (!o.per_target || jt == tid) {
+                        const int js = j < SEL_PCAP ? Lfs[j] : pfs[base + j], je = j < SEL_PCAP ? Lfe[j] : pfe[base + j];
+                        const int lo = fs > js ? fs : js, hi = fe < je ? fe : je;
+                        const int ol = hi > lo ? hi - lo : 0;
+                        const int mn = (fe - fs) < (je - js) ? (fe - fs) : (je - js);
+                        hit = (float)ol > o.mask_level * (float)mn;
+                    }
+                }
+                const uint64_t m = __ballot(hit);
+                if (m) parent = c0 + __ffsll((unsigned long long)m) - 1;
+            }
+            bool kp;
+            if (parent < 0) {
+                if (lane == 0) {
+                    if (n_prim < SEL_PCAP) { Lfs[n_prim] = fs; Lfe[n_prim] = fe; Ltid[n_prim] = tid; Lkey[n_prim] = sc; }
+                    else { pfs[base + n_prim] = fs; pfe[base + n_prim] = fe; ptid[base + n_prim] = tid; pkey[base + n_prim] = sc; }
+                }
+                if (n_prim >= SEL_PCAP) __threadfence_block();
+                ++n_prim; kp = true;
+            } else {
+                kp = false;
+                const int pk_ = parent < SEL_PCAP ? Lkey[parent] : pkey[base + parent];
+                if (o.secondary && !((float)sc < (float)pk_ * o.pri_ratio)) {
+                    if (!o.per_target) { if (n2_all < o.best_n) { kp = true; ++n2_all; } }
+                    else {
+                        int z = -1;
+                        for (int c0 = 0; c0 < n_t && z < 0; c0 += 64) {
+                            const int j = c0 + lane;
+                            const uint64_t m = __ballot(j < n_t && tcnt_t[base + j] == tid);
+                            if (m) z = c0 + __ffsll((unsigned long long)m) - 1;
+                        }
+                        if (z < 0) { z = n_t++; if (lane == 0) { tcnt_t[base + z] = tid; tcnt_n[base + z] = 0; } __threadfence_block(); }
+                        const int cur = tcnt_n[base + z];
+                        if (cur < o.best_n) { kp = true; if (lane == 0) tcnt_n[base + z] = cur + 1; __threadfence_block(); }
+                    }
+                }
+            }
+            if (lane == u) my_keep = kp;
+            nk += kp ? 1 : 0;
+        }
+        if (lane < cnt) keep[base + i0 + lane] = my_keep ? 1 : 0;
+    }
+    if (lane == 0) n_kept[q] = nk;
+}
+__global__ void __launch_bounds__(64) k_select1_write(const int32_t *__restrict__ ch_off, const int32_t *__restrict__ n_chains, const ChainRec *__restrict__ rec,
+                                                      const uint64_t *__restrict__ skey, const uint8_t *__restrict__ keep, const int32_t *__restrict__ k_off,
+                                                      const int32_t *__restrict__ q_aoff, int32_t q0, const int32_t *__restrict__ qlen_of, const int64_t *__restrict__ qboff,
+                                                      const uint32_t *__restrict__ goff, const int32_t *__restrict__ tlen_of, const int64_t *__restrict__ tboff, int32_t n_targets,
+                                                      KeptChain *__restrict__ kc, KeptLite *__restrict__ kl)
+{
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int base = ch_off[q], n = n_chains[q];
+    int w = k_off[q];
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool kp = i < n && keep[base + i];
+        const uint64_t m = __ballot(kp);
+        if (kp) {
+            const int x = w + __popcll(m & ((1ULL << lane) - 1));
+            const ChainRec r = rec[base + (int)(uint32_t)(skey[base + i] & 0xffffffffu)];
+            int rev, tid, rs, re, qs, qe;
+            d_chain_box(r, goff, n_targets, rev, tid, rs, re, qs, qe);
+            KeptChain K; K.qid = q0 + q; K.tid = tid; K.rev = rev; K.cnt = r.cnt; K.a_glob = (int64_t)q_aoff[q] + r.a_off; K.rs = rs; K.qs = qs; K.re = re; K.qe = qe;
+            K.qlen = qlen_of[q]; K.tlen = tlen_of[tid]; K.qbase = qboff[q]; K.tbase = tboff[tid]; K.goff = goff[tid]; K.pad = 0;
+            kc[x] = K;
+            KeptLite L; L.qid = q0 + q; L.score = r.score; L.cnt = r.cnt; L.rev = rev; L.tid = tid; L.rs = rs; L.re = re; L.qs = qs; L.qe = qe; L.pad = 0;
+            kl[x] = L;
+        }
+        w += __popcll(m);
+    }
+}
 struct DpProb {             // 64 B
     int64_t qi0, ti0;       // absolute packed base index of DP base 0
     int64_t tb_off;         // byte offset into the trace-back scratch

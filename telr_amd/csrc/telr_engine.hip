@@ -1331,29 +1331,97 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[1], 0));
     }
     HIPCHK(hipGetLastError());
+    // Pass-1 chain selection runs on the device (k_select1); TELR_HOST_SELECT=1 keeps the round-1 host version for A/B runs.
+    // The host version, and the debug taps of the parity tests, need every chain record on the host.
+    static const bool host_select = getenv("TELR_HOST_SELECT") != nullptr;
+    const bool need_recs = host_select || ctx->debug;
     int32_t *h_nch, *h_choff, *h_qaoff; ChainRec *h_rec;
     TRY(ctx_hbuf_t(ctx, "h_nch", (size_t)nq + 1, &h_nch));
     TRY(ctx_hbuf_t(ctx, "h_choff", (size_t)nq + 1, &h_choff));
     TRY(ctx_hbuf_t(ctx, "h_qaoff", (size_t)nq + 1, &h_qaoff));
-    TRY(ctx_hbuf_t(ctx, "h_rec", (size_t)npk_tot + 1, &h_rec));
-    HIPCHK(hipMemcpyAsync(h_nch, d_nch, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_choff, d_choff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_qaoff, d_qaoff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
-    if (npk_tot) HIPCHK(hipMemcpyAsync(h_rec, d_rec, (size_t)npk_tot * sizeof(ChainRec), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    TRY(ctx_hbuf_t(ctx, "h_rec", need_recs ? (size_t)npk_tot + 1 : 1, &h_rec));
+    if (need_recs) {
+        HIPCHK(hipMemcpyAsync(h_nch, d_nch, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_choff, d_choff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_qaoff, d_qaoff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+        if (npk_tot) HIPCHK(hipMemcpyAsync(h_rec, d_rec, (size_t)npk_tot * sizeof(ChainRec), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     t_bt.stop();
     ctx->dbg_na = na; ctx->dbg_nq = nq;
 
-    // ---- host: chain boxes + selection pass 1 (threads over queries) ------------------------------
-    StageTimer t_sel(ctx, ST_SELECT, false);
+    // ---- chain boxes + selection pass 1 -> the kept chains (query-major, pass-1 rank order) ------------------------
     const int NT = host_threads();
+    std::vector<int32_t> q_k0(nq + 1, 0);
+    KeptLite *hl = nullptr;                  // what the host needs of the kept chains
+    KeptChain *d_kc = nullptr;               // their descriptors for the problem builder (device)
+    int nk = 0;
+    int64_t n_chain_tot = 0;
+    if (!host_select) {
+        StageTimer t_sel(ctx, ST_SELECT, true);
+        uint64_t *d_sk, *d_sk2; int32_t *d_segend, *d_pfs, *d_pfe, *d_ptid, *d_pkey, *d_tct, *d_tcn, *d_nkept, *d_koff; uint8_t *d_keep;
+        TRY(ctx_buf_t(ctx, "sel_key", (size_t)npk_tot + 1, &d_sk));
+        TRY(ctx_buf_t(ctx, "sel_key2", (size_t)npk_tot + 1, &d_sk2));
+        TRY(ctx_buf_t(ctx, "sel_segend", (size_t)nq + 1, &d_segend));
+        TRY(ctx_buf_t(ctx, "sel_pfs", (size_t)npk_tot + 1, &d_pfs));
+        TRY(ctx_buf_t(ctx, "sel_pfe", (size_t)npk_tot + 1, &d_pfe));
+        TRY(ctx_buf_t(ctx, "sel_ptid", (size_t)npk_tot + 1, &d_ptid));
+        TRY(ctx_buf_t(ctx, "sel_pkey", (size_t)npk_tot + 1, &d_pkey));
+        TRY(ctx_buf_t(ctx, "sel_tct", (size_t)npk_tot + 1, &d_tct));
+        TRY(ctx_buf_t(ctx, "sel_tcn", (size_t)npk_tot + 1, &d_tcn));
+        TRY(ctx_buf_t(ctx, "sel_keep", (size_t)npk_tot + 1, &d_keep));
+        TRY(ctx_buf_t(ctx, "sel_nkept", (size_t)nq + 2, &d_nkept));
+        TRY(ctx_buf_t(ctx, "sel_koff", (size_t)nq + 2, &d_koff));
+        hipLaunchKernelGGL(k_sel_keys, dim3(nq), dim3(64), 0, st, d_choff, d_nch, d_rec, d_sk, d_segend);
+        HIPCHK(hipGetLastError());
+        if (npk_tot > 0) {
+            size_t tb = 0;
+            HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_sk, d_sk2, (unsigned)npk_tot, (unsigned)nq, d_choff, d_segend, 0, 64, st));
+            void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+            HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_sk, d_sk2, (unsigned)npk_tot, (unsigned)nq, d_choff, d_segend, 0, 64, st));
+        }
+        SelOpt so; so.mask_level = mo->mask_level; so.pri_ratio = mo->pri_ratio; so.best_n = mo->best_n; so.secondary = mo->secondary;
+        so.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0;
+        hipLaunchKernelGGL(k_select1, dim3(nq), dim3(64), 0, st, d_choff, d_nch, d_rec, d_sk2, qs->d_len + q0, ix->d_goff, tg->n, so,
+                           d_pfs, d_pfe, d_ptid, d_pkey, d_tct, d_tcn, d_keep, d_nkept, d_qorder);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(d_nkept + nq, 0, 4, st));
+        TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_nkept, d_koff, (size_t)nq + 1)));
+        HIPCHK(hipMemcpyAsync(q_k0.data(), d_koff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, st));
+        if (!need_recs) HIPCHK(hipMemcpyAsync(h_nch, d_nch, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        nk = q_k0[nq];
+        for (int q = 0; q < nq; ++q) n_chain_tot += h_nch[q];
+        KeptLite *d_kl;
+        TRY(ctx_buf_t(ctx, "kept", (size_t)nk, &d_kc));
+        TRY(ctx_buf_t(ctx, "kept_lite", (size_t)nk, &d_kl));
+        TRY(ctx_hbuf_t(ctx, "h_kept_lite", (size_t)nk, &hl));
+        if (nk > 0) {
+            hipLaunchKernelGGL(k_select1_write, dim3(nq), dim3(64), 0, st, d_choff, d_nch, d_rec, d_sk2, d_keep, d_koff, d_qaoff, q0, qs->d_len + q0, qs->d_boff + q0,
+                               ix->d_goff, tg->d_len, tg->d_boff, tg->n, d_kc, d_kl);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(hl, d_kl, (size_t)nk * sizeof(KeptLite), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+        t_sel.stop();
+        if (ctx->debug) {                    // every chain with its box, in discovery order (stage-level parity tests)
+            ctx->dbg_chain.clear();
+            for (int q = 0; q < nq; ++q) for (int c = 0; c < h_nch[q]; ++c) {
+                const ChainRec &r = h_rec[h_choff[q] + c];
+                const uint32_t g0 = (uint32_t)A_G(r.a0);
+                const int tid = (int)(std::upper_bound(ix->goff.begin(), ix->goff.begin() + tg->n, g0) - ix->goff.begin()) - 1, go = (int)ix->goff[tid];
+                int32_t v[9] = { q0 + q, r.score, r.cnt, (int)(r.a0 >> 63), tid, A_G(r.a0) - go - A_SPAN(r.a0) + 1, A_G(r.a1) - go + 1, A_Q(r.a0) - A_SPAN(r.a0) + 1, A_Q(r.a1) + 1 };
+                ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9);
+            }
+        }
+    } else {
+    StageTimer t_sel(ctx, ST_SELECT, false);
     std::vector<int32_t> q_ch0(nq + 1, 0);
     for (int q = 0; q < nq; ++q) q_ch0[q + 1] = q_ch0[q] + h_nch[q];
-    const int n_chain_tot = q_ch0[nq];
+    n_chain_tot = q_ch0[nq];
     HostChain *chains;                                            // all chains of the batch, query-major (grow-only pinned
     TRY(ctx_hbuf_t(ctx, "h_chains", (size_t)n_chain_tot + 1, &chains));   // scratch: a fresh vector would be zero-filled and page-faulted every call)
     std::vector<int32_t> kept;                                    // indices into chains, query-major, pass-1 rank order
-    std::vector<int32_t> q_k0(nq + 1, 0);
     {
         std::vector<std::vector<int32_t>> tkept(NT);
         std::vector<int32_t> q_nk(nq, 0);
@@ -1391,19 +1459,35 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         kept.reserve(q_k0[nq]);
         for (int t = 0; t < NT; ++t) kept.insert(kept.end(), tkept[t].begin(), tkept[t].end());   // ranges are contiguous and ordered
     }
-    ctx->ctr.chains += n_chain_tot;
     if (ctx->debug) {
         ctx->dbg_chain.clear();
         for (int ci = 0; ci < n_chain_tot; ++ci) { const HostChain &c = chains[ci]; int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
     }
-    const int nk = (int)kept.size();
+    nk = (int)kept.size();
+    // the kept chains in the two forms the rest of the batch uses
+    KeptChain *hk;
+    TRY(ctx_hbuf_t(ctx, "h_kept", (size_t)nk, &hk));
+    TRY(ctx_hbuf_t(ctx, "h_kept_lite", (size_t)nk, &hl));
+    parallel_ranges(NT, nk, [&](int, int xa, int xb) {
+        for (int x = xa; x < xb; ++x) {
+            const HostChain &c = chains[kept[x]]; KeptChain &K = hk[x];
+            K.qid = c.qid; K.tid = c.tid; K.rev = c.rev; K.cnt = c.cnt; K.a_glob = c.a_glob; K.rs = c.rs; K.qs = c.qs; K.re = c.re; K.qe = c.qe;
+            K.qlen = qs->len[c.qid]; K.tlen = tg->len[c.tid]; K.qbase = qs->boff[c.qid]; K.tbase = tg->boff[c.tid]; K.goff = ix->goff[c.tid]; K.pad = 0;
+            KeptLite &L = hl[x];
+            L.qid = c.qid; L.score = c.score; L.cnt = c.cnt; L.rev = c.rev; L.tid = c.tid; L.rs = c.rs; L.re = c.re; L.qs = c.qs; L.qe = c.qe; L.pad = 0;
+        }
+    });
+    TRY(ctx_buf_t(ctx, "kept", (size_t)nk, &d_kc));
+    if (nk) HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
     t_sel.stop();
+    }
+    ctx->ctr.chains += n_chain_tot;
 
     // results per kept chain (chain-level numbers; overwritten by the DP numbers below)
     std::vector<telr_aln> kal((size_t)nk);
     parallel_ranges(NT, nk, [&](int, int xa, int xb) {
         for (int x = xa; x < xb; ++x) {
-            const HostChain &c = chains[kept[x]];
+            const KeptLite &c = hl[x];
             telr_aln &r = kal[x]; memset(&r, 0, sizeof(r));
             const int qlen = qs->len[c.qid];
             r.qid = c.qid; r.tid = c.tid; r.qlen = qlen; r.tlen = tg->len[c.tid]; r.score = c.score; r.cnt = c.cnt; r.flags = c.rev ? TELR_F_REV : 0;
@@ -1420,20 +1504,9 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     if (do_dp) {
         // ---- DP problem list ----------------------------------------------------------------
         StageTimer t_sg(ctx, ST_SEGMENTS, true);
-        KeptChain *hk;
-        TRY(ctx_hbuf_t(ctx, "h_kept", (size_t)nk, &hk));
-        parallel_ranges(NT, nk, [&](int, int xa, int xb) {
-            for (int x = xa; x < xb; ++x) {
-                const HostChain &c = chains[kept[x]]; KeptChain &K = hk[x];
-                K.qid = c.qid; K.tid = c.tid; K.rev = c.rev; K.cnt = c.cnt; K.a_glob = c.a_glob; K.rs = c.rs; K.qs = c.qs; K.re = c.re; K.qe = c.qe;
-                K.qlen = qs->len[c.qid]; K.tlen = tg->len[c.tid]; K.qbase = qs->boff[c.qid]; K.tbase = tg->boff[c.tid]; K.goff = ix->goff[c.tid]; K.pad = 0;
-            }
-        });
-        KeptChain *d_kc; int32_t *d_nprob, *d_poff;
-        TRY(ctx_buf_t(ctx, "kept", (size_t)nk, &d_kc));
+        int32_t *d_nprob, *d_poff;             // (the kept-chain descriptors d_kc are on the device already)
         TRY(ctx_buf_t(ctx, "nprob", (size_t)nk + 1, &d_nprob));
         TRY(ctx_buf_t(ctx, "prob_off", (size_t)nk + 1, &d_poff));
-        HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_segments_w<0>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(d_nprob + nk, 0, 4, st));
@@ -1493,7 +1566,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             TRY(ctx_buf_t(ctx, "stitch_prob", (size_t)np, &d_sp));
             parallel_ranges(NT, nk, [&](int, int xa, int xb) {
                 for (int x = xa; x < xb; ++x) {
-                    const HostChain &c = chains[kept[x]];
+                    const KeptLite &c = hl[x];
                     h_sv[x].p0 = h_poff[x]; h_sv[x].p1 = h_poff[x + 1]; h_sv[x].has_left = (c.qs > 0 && c.rs > 0) ? 1 : 0; h_sv[x].pad = 0;
                 }
             });
@@ -1550,7 +1623,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         ctx->ctr.window_bases += (int64_t)h_acc[TELR_N_DPCLS * 4];
         parallel_ranges(NT, nk, [&](int, int xa, int xb) {
             for (int x = xa; x < xb; ++x) {
-                const HostChain &c = chains[kept[x]]; telr_aln &r = kal[x]; const ChainStat &S = h_cs[x];
+                const KeptLite &c = hl[x]; telr_aln &r = kal[x]; const ChainStat &S = h_cs[x];
                 const int qlen = r.qlen, tlen = r.tlen;
                 int32_t qs_ = c.qs, rs_ = c.rs, qe_ = c.qe, re_ = c.re;
                 const bool has_left = c.qs > 0 && c.rs > 0, has_right = c.qe < qlen && c.re < tlen;

@@ -24,6 +24,7 @@ every rank maps its own 30x read set.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -246,12 +247,14 @@ def main():
     def step():
         r = ix.map_raw(qs, mo)
         L = eng.L
-        al = _np_from(L.telr_result_alns(r), L.telr_result_count(r), ALN_DTYPE)
+        n = L.telr_result_count(r)
+        # a VIEW of the library-owned record array (valid until the result is freed: after the next step): counting the
+        # aligned bases must not copy 50 MB of records per step inside the timed region
+        al = np.frombuffer((ctypes.c_char * (n * ALN_DTYPE.itemsize)).from_address(L.telr_result_alns(r)), dtype=ALN_DTYPE, count=n) if n else np.zeros(0, ALN_DTYPE)
         while held:
             ix.free_raw(held.pop())
         held.append(r)
-        prim = al[(al["flags"] & 1) != 0]
-        return int(prim["qlen"].sum()), al
+        return int(al["qlen"][(al["flags"] & 1) != 0].sum()), al
 
     def sync():
         torch.cuda.synchronize(local)
@@ -281,6 +284,7 @@ def main():
     sync()
     dt = time.time() - t0
     dt_local = dt
+    al = al.copy()                            # the last step's records outlive the result handle (window reads of the loci leg)
     while held:
         ix.free_raw(held.pop())
     per_rank_ms = [dt_local / a.steps * 1e3]

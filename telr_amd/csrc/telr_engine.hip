@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,6 +33,7 @@ enum { ST_SKETCH, ST_SEED, ST_SORT, ST_CHAIN, ST_BACKTRACK, ST_SELECT, ST_SEGMEN
 
 #define TELR_NSIDE 8
 struct DBuf { void *p = nullptr; size_t bytes = 0; };
+struct TileList { std::vector<int32_t> seq, u0, first; int32_t n = 0; };     // tiles of the sketch kernel over a range of sequences
 
 struct telr_ctx {
     int device = 0;
@@ -45,6 +47,11 @@ struct telr_ctx {
     std::map<std::string, DBuf> bufs;     // grow-only device scratch, reused across calls
     std::map<std::string, DBuf> hbufs;    // grow-only pinned host staging buffers
     std::vector<std::pair<uint32_t*, size_t>> cig_pool;   // recycled result CIGAR buffers
+    std::vector<std::vector<telr_aln>> aln_pool;          // recycled result record arrays (a fresh 50-MB vector is page-faulted on every call)
+    // grow-only host scratch of map_batch / map_range (same reason: no allocation, no first-touch faults in the steady state)
+    std::vector<telr_aln> h_kal, h_stage, h_merge;
+    std::vector<int32_t> h_nsurv, h_poffv;
+    TileList tiles;                                       // a batch of 1 Gbp has ~1 M tiles
     int debug = 0;                        // keep stage-level captures for the parity tests
     float stage_ms[TELR_N_STAGES] = {0};
     telr_counters ctr = {};
@@ -402,7 +409,7 @@ static int dev_inclusive_scan_i32(telr_ctx *ctx, int32_t *io, size_t n)
 
 // ---------------------------------------------------------------------------------------
 // tiles for the sketch kernel
-struct TileList { std::vector<int32_t> seq, u0, first; int32_t n = 0; };
+static TileList &ctx_tiles(telr_ctx *ctx) { return ctx->tiles; }
 // tiles over slots; `slots_of(q)` = number of k-mer slots of sequence q; tile_seq holds q - seq_base
 template <typename F> static void make_tiles_f(int32_t q0, int32_t q1, int32_t seq_base, F slots_of, TileList &T)
 {
@@ -806,7 +813,11 @@ static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
     *p = ctx->cig_pool[best].first; *cap = ctx->cig_pool[best].second;
     ctx->cig_pool.erase(ctx->cig_pool.begin() + best);
 }
-telr_result::~telr_result() { result_wait(this); pool_put(ctx, cig, cap); }
+telr_result::~telr_result()
+{
+    result_wait(this); pool_put(ctx, cig, cap);
+    if (ctx && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
+}
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
 extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->ncig : 0; }
@@ -1123,6 +1134,18 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     return TELR_OK;
 }
 
+// TELR_TRACE_HOST=1: wall-clock marks of the host side of every batch on stderr (where does a range wait for the host?)
+struct HostTrace {
+    bool on; const char *tag; std::chrono::steady_clock::time_point t0, last;
+    HostTrace(const char *t) : tag(t) { static const bool e = getenv("TELR_TRACE_HOST") != nullptr; on = e; t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host %s] %-28s +%7.3f ms  (%8.3f)\n", tag, what, std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // one batch of queries [q0, q1)
 struct OccCut { int32_t mid_occ; const int32_t *d_tmid; };      // pooled cut-off; per-target cut-offs (nullable)
@@ -1133,6 +1156,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     const int nq = q1 - q0, k = ix->io.k, w = ix->io.w;
     const telr_seqset *tg = ix->targets;
     hipStream_t st = ctx->stream;
+    HostTrace ht(ctx->is_child ? "batch/worker" : "batch");
 
     // ---- sketch -------------------------------------------------------------------------
     // queries in descending length order for the one-block-per-query kernels (their tail is the longest read): sorted by
@@ -1146,7 +1170,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } ord_join{ord_thread};     // error paths return early
     StageTimer t_sk(ctx, ST_SKETCH, true);
-    TileList T;
+    TileList &T = ctx_tiles(ctx);
     uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
     if (ix->io.is_hpc) {
         SketchHpcArgs H; std::vector<int32_t> nrun;
@@ -1164,7 +1188,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipMemcpyAsync(d_first, T.first.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_toff, d_first, nq, nmz, d_qmz);
     HIPCHK(hipGetLastError());
-    t_sk.stop();
+    t_sk.stop(); ht.mark("sketch issued");
 
     ord_thread.join();
     HIPCHK(hipMemcpyAsync(d_qorder, h_ord, (size_t)nq * 4, hipMemcpyHostToDevice, st));
@@ -1211,7 +1235,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, na, d_qaoff);
     HIPCHK(hipGetLastError());
-    t_sd.stop();
+    t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
 
     // ---- per-query sort of the anchor keys --------------------------------------------------
@@ -1347,7 +1371,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         if (npk_tot) HIPCHK(hipMemcpyAsync(h_rec, d_rec, (size_t)npk_tot * sizeof(ChainRec), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    t_bt.stop();
+    t_bt.stop(); ht.mark("sort+chain+backtrack issued");
     ctx->dbg_na = na; ctx->dbg_nq = nq;
 
     // ---- chain boxes + selection pass 1 -> the kept chains (query-major, pass-1 rank order) ------------------------
@@ -1481,10 +1505,11 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     if (nk) HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
     t_sel.stop();
     }
-    ctx->ctr.chains += n_chain_tot;
+    ctx->ctr.chains += n_chain_tot; ht.mark("selection (sync: kept chains)");
 
     // results per kept chain (chain-level numbers; overwritten by the DP numbers below)
-    std::vector<telr_aln> kal((size_t)nk);
+    if (ctx->h_kal.size() < (size_t)nk) ctx->h_kal.resize((size_t)nk + (size_t)nk / 8);
+    telr_aln *kal = ctx->h_kal.data();
     parallel_ranges(NT, nk, [&](int, int xa, int xb) {
         for (int x = xa; x < xb; ++x) {
             const KeptLite &c = hl[x];
@@ -1498,7 +1523,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     });
 
     const bool do_dp = (mo->flags & TELR_MF_CIGAR) && nk > 0;
-    std::vector<int32_t> h_poff;
+    std::vector<int32_t> &h_poff = ctx->h_poffv;
     int64_t *h_foff = nullptr; size_t cig_base = 0; ChainStat *h_cs = nullptr; unsigned long long *h_acc = nullptr;
     int np = 0;
     if (do_dp) {
@@ -1519,7 +1544,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
         hipLaunchKernelGGL(k_segments_w<1>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
         HIPCHK(hipGetLastError());
-        t_sg.stop();
+        t_sg.stop(); ht.mark("segments (sync: problems)");
         ctx->ctr.dp_problems += np;
 
         // ---- banded DP: narrow-band pass, then a wide-band pass for the problems whose path touched a band edge
@@ -1552,7 +1577,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             HIPCHK(hipGetLastError());
         }
         ctx->dp_retries += n_retry;
-        t_dp.stop();
+        t_dp.stop(); ht.mark("dp passes");
 
         // ---- CIGARs of ALL kept chains are stitched now and travel to the (pinned) result buffer while the host does
         //      its second selection pass on the per-problem results; chains that pass drops leave unused gaps behind
@@ -1590,7 +1615,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             HIPCHK(hipMemcpyAsync(h_cs, d_cs, (size_t)nk * sizeof(ChainStat), hipMemcpyDeviceToHost, st));
             HIPCHK(hipMemcpyAsync(h_acc, d_acc, ((size_t)TELR_N_DPCLS * 4 + 1) * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            t_g.stop();                            // what follows is not waited for here
+            t_g.stop(); ht.mark("stitch count (sync)");                           // what follows is not waited for here
             const int64_t tot = h_foff[nk];
             uint32_t *d_fin;
             TRY(ctx_buf_t(ctx, "stitched", (size_t)tot + 1, &d_fin));
@@ -1640,10 +1665,13 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     // ---- host: pass-2 selection, flags, mapq (threads over queries) --------------------------------------
     StageTimer t_as2(ctx, ST_ASSEMBLE, false);
     const bool per_t = (mo->flags & TELR_MF_PER_TARGET) != 0;
-    struct Surv { int32_t x; telr_aln r; };            // x = kept-chain index
-    std::vector<std::vector<Surv>> tsurv(NT);
-    parallel_ranges(NT, nq, [&](int t, int qa, int qb) {
-        std::vector<Sel> s2; std::vector<int32_t> cscore, newidx;
+    // survivors of query q go to stage[k0 .. k0 + n_surv[q]) in rank order (a query keeps at most as many records as it had
+    // kept chains), then one prefix sum over the queries places them in the result: no per-thread vectors, no re-copying
+    if (ctx->h_stage.size() < (size_t)nk) ctx->h_stage.resize((size_t)nk + (size_t)nk / 8);
+    if (ctx->h_nsurv.size() < (size_t)nq + 1) ctx->h_nsurv.resize((size_t)nq + 1);
+    telr_aln *stage = ctx->h_stage.data(); int32_t *nsurv = ctx->h_nsurv.data();
+    parallel_ranges(NT, nq, [&](int, int qa, int qb) {
+        std::vector<Sel> s2; std::vector<int32_t> cscore, newidx, seen_tid;
         for (int q = qa; q < qb; ++q) {
             const int k0 = q_k0[q], n1 = q_k0[q + 1] - k0;
             s2.clear(); cscore.assign(n1, 0);
@@ -1659,13 +1687,14 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             select_chains(s2, mo, cscore);
             const int n2 = (int)s2.size();
             newidx.assign(n2, -1);
-            bool seen_primary = false; std::vector<int32_t> seen_tid;
+            bool seen_primary = false; seen_tid.clear();
             int nkp = 0;
             for (int i = 0; i < n2; ++i) if (s2[i].keep) newidx[i] = nkp++;
+            int w = 0;
             for (int i = 0; i < n2; ++i) {
                 if (!s2[i].keep) continue;
-                Surv sv; sv.x = k0 + s2[i].ci; sv.r = kal[sv.x];
-                telr_aln &r = sv.r;
+                const int x = k0 + s2[i].ci;
+                telr_aln &r = stage[k0 + w++]; r = kal[x];
                 r.parent = newidx[s2[i].parent]; r.subsc = s2[i].subsc; r.n_sub = s2[i].n_sub;
                 if (s2[i].parent == i) {
                     bool first = true;
@@ -1677,31 +1706,36 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                     r.flags |= first ? TELR_F_PRIMARY : TELR_F_SUPPL;
                 } else r.flags |= TELR_F_SECONDARY;
                 r.mapq = mapq_of(r, mo);
-                tsurv[t].push_back(sv);
+                if (do_dp) { r.cigar_off = (int64_t)cig_base + h_foff[x]; r.n_cigar = (int32_t)(h_foff[x + 1] - h_foff[x]); }
             }
+            nsurv[q] = w;
         }
     });
-    // survivors in query order; upper bound of their op counts -> offsets into a scratch, then stitch in parallel
-    std::vector<Surv> surv;
-    { size_t tot = 0; for (auto &v : tsurv) tot += v.size(); surv.reserve(tot); for (auto &v : tsurv) surv.insert(surv.end(), v.begin(), v.end()); }
-    const int ns = (int)surv.size();
+    std::vector<int64_t> out0((size_t)nq + 1);
+    const size_t r_base = R->alns.size();
+    out0[0] = 0;
+    for (int q = 0; q < nq; ++q) out0[q + 1] = out0[q] + nsurv[q];
+    const int ns = (int)out0[nq];
+    R->alns.resize(r_base + (size_t)ns);
+    telr_aln *dst = R->alns.data() + r_base;
+    std::vector<int64_t> tops(NT + 1, 0);
+    parallel_ranges(NT, nq, [&](int t, int qa, int qb) {
+        int64_t ops = 0;
+        for (int q = qa; q < qb; ++q) {
+            const int k0 = q_k0[q];
+            for (int i = 0; i < nsurv[q]; ++i) { dst[out0[q] + i] = stage[k0 + i]; ops += stage[k0 + i].n_cigar; }
+        }
+        tops[t] = ops;
+    });
     t_as2.stop();
     if (do_dp) {
-        int64_t ops = 0;
-        for (int i = 0; i < ns; ++i) {
-            const int x = surv[i].x;
-            surv[i].r.cigar_off = (int64_t)cig_base + h_foff[x]; surv[i].r.n_cigar = (int32_t)(h_foff[x + 1] - h_foff[x]);
-            ops += surv[i].r.n_cigar;
-        }
-        ctx->ctr.cigar_ops += ops;
+        for (int t = 0; t < NT; ++t) ctx->ctr.cigar_ops += tops[t];
         if (getenv("TELR_SYNC_RESULT")) { StageTimer t_g2(ctx, ST_GATHER, false); result_wait(R); t_g2.stop(); }   // else: waited for by whoever reads the CIGARs
     }
-    StageTimer t_as3(ctx, ST_ASSEMBLE, false);
-    R->alns.reserve(R->alns.size() + ns);
-    for (int i = 0; i < ns; ++i) R->alns.push_back(surv[i].r);
     ctx->ctr.records += ns;
-    t_as3.stop();
+    ht.mark("host assembly");
     stage_collect(ctx);
+    ht.mark("stage_collect");
     return TELR_OK;
 }
 
@@ -1768,6 +1802,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
     }
     int rr = TELR_OK;
     const size_t a_start = R->alns.size();
+    HostTrace hr("range");
     if (!lane) {
         rr = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
         if (rr == TELR_OK) ctx->ctr.query_bases += total_bases;
@@ -1776,8 +1811,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         // the recycled (large) result buffers go to the bulk worker, which fills R
         for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
         ctx->cig_pool.clear();
-        result_wait(R);                       // an earlier range's DMA: the bulk worker may grow the buffer
-        const size_t c_start = R->ncig;
+        const size_t c_start = R->ncig;       // (an earlier range's DMA into R may still run: map_batch waits for it before it touches the buffer)
         telr_seqset sub[2]; telr_result *P1 = new telr_result(); P1->ctx = nullptr; int rc[2] = { TELR_OK, TELR_OK };
         auto work = [&](int k) {
             telr_ctx *c = ctx->child[k];
@@ -1795,9 +1829,12 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
             rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, k == 0 ? R : P1);
             if (rc[k] == TELR_OK) c->ctr.query_bases += sub[k].total_bases;
         };
+        hr.mark("lane lists");
         std::thread tl(work, 1);
         work(0);
+        hr.mark("bulk worker done");
         tl.join();
+        hr.mark("long-read worker joined");
         sub[0].d_seq2 = sub[0].d_nmask = nullptr; sub[1].d_seq2 = sub[1].d_nmask = nullptr;       // scratch of the workers, not owned
         sub[0].d_boff = sub[1].d_boff = nullptr; sub[0].d_len = sub[1].d_len = nullptr;
         for (int k = 0; k < 2 && rr == TELR_OK; ++k) if (rc[k] != TELR_OK) { if (rc[k] != TELR_SPLIT_RANGE) ctx->err = ctx->child[k]->err; rr = rc[k]; }
@@ -1819,7 +1856,8 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
                 });
                 R->ncig = base1 + P1->ncig;
             }
-            std::vector<telr_aln> merged(R->alns.size() - a_start + P1->alns.size());
+            std::vector<telr_aln> &merged = ctx->h_merge;
+            merged.resize(R->alns.size() - a_start + P1->alns.size());
             { size_t a = a_start, b = 0, o = 0;
               const size_t na = R->alns.size(), nb = P1->alns.size();
               while (a < na || b < nb) {
@@ -1840,6 +1878,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         }
         P1->ctx = ctx->child[1];              // its buffer goes back to that worker's pool
         delete P1;
+        hr.mark("merge");
     }
     if (rr == TELR_SPLIT_RANGE) {
         if (nq < 2) { ctx->err = "one read seeds 2^31 anchors or more"; return TELR_E_RANGE; }
@@ -1877,6 +1916,12 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (qtarget || (mo->flags & TELR_MF_PER_TARGET)) TRY(index_per_target_occ(ctx, ix, mo, &mid_occ.d_tmid));
     telr_result *R = new telr_result();
     R->ctx = ctx;
+    if (!ctx->aln_pool.empty()) {                 // the largest recycled record array
+        size_t best = 0;
+        for (size_t i = 1; i < ctx->aln_pool.size(); ++i) if (ctx->aln_pool[i].capacity() > ctx->aln_pool[best].capacity()) best = i;
+        R->alns = std::move(ctx->aln_pool[best]); R->alns.clear();
+        ctx->aln_pool.erase(ctx->aln_pool.begin() + best);
+    }
     const auto t_wall0 = std::chrono::steady_clock::now();
     int64_t total_bases = 0;
     for (int i = 0; i < nq; ++i) total_bases += queries->len[i];

@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--loci", type=int, default=-1, help="candidate loci for the TE-loci/s leg (-1 = all spiked insertions, 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
     ap.add_argument("--data-cache", default="", help="directory: the rank's generated data set is stored there / loaded from there (profiling runs: no forked generator)")
+    ap.add_argument("--one-gpu", action="store_true", help="smoke test of the N>1 code path on a 1-GPU box: every rank uses device 0 (use with --backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
     return ap.parse_args()
 
@@ -174,7 +175,7 @@ def main():
         sys.exit(launch_ranks(a))
     cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     # ranks of one node share its CPUs: each engine sizes its host pool for its share (the library's default is 1.5 x the
     # CPUs the process may use, which every rank would claim for itself)
     lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))

@@ -95,7 +95,12 @@ def launch_ranks(a):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # only rank 0's JSON line belongs on stdout (the gloo backend, for one, prints its connection banner there)
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in pr.stdout:
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+    sys.stdout.flush()
+    return pr.wait()
 
 
 def cpu_baseline(ref_strs, reads, io, mo, n_sample):

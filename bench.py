@@ -332,17 +332,16 @@ def main():
                     l["read_idx"] = idx.astype(np.int32)
                 return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, shards=shards,
                                                            presets=presets_arg, read_set=qs)
-            items = []
-            for li, idx in enumerate(wr):
-                for i in idx:
-                    items.append((owner[li], li, int(D["read_gid"][i]), rbuf[roff[i]:roff[i] + rln[i]]))
-            got = shard.exchange_window_reads(items, dist, device)
-            for l in loci:
-                l["reads"] = []
-            for (li, gid, b) in got:
-                loci[li]["reads"].append(bytes(b).decode())
+            lid = np.repeat(np.arange(len(wr)), [len(x) for x in wr]); ridx = np.concatenate(wr) if len(wr) else np.zeros(0, np.int64)
+            own = np.array([owner[i] for i in range(len(loci))], np.int64)
+            g_loc, g_read, pool = shard.exchange_window_reads(lid, D["read_gid"][ridx], own[lid], (rbuf, roff, rln), ridx, dist, device)
+            pool_set = eng.seqset(pool)            # the received reads, packed and uploaded once; loci index into it
+            cuts = np.searchsorted(g_loc, np.arange(len(loci) + 1))
+            for li, l in enumerate(loci):
+                l["read_idx"] = np.arange(cuts[li], cuts[li + 1], dtype=np.int32)
+                l.pop("reads", None)
             return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
-                                                       shards=shards, presets=presets_arg)
+                                                       shards=shards, presets=presets_arg, read_set=pool_set)
         loci_pass()                                # warm-up (sizes the scratch)
         sync()
         t0 = time.time()

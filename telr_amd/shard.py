@@ -82,47 +82,60 @@ def all_gather_rows(rows, dist=None, device=None, capacity=None):
 READ_HDR = np.dtype([("locus_id", np.int32), ("read_id", np.int32), ("length", np.int32), ("pad", np.int32)])
 
 
-def exchange_window_reads(items, dist=None, device=None):
+def exchange_window_reads(locus_id, read_id, dest, reads, read_index, dist=None, device=None):
     """The stage-1 -> per-locus hand-off when reads are sharded over ranks: every rank holds the window reads of ALL loci
     that fall in ITS read shard and sends each to the rank that owns the locus.  (The reference does this through the
     shared file system: pysam.fetch on the stage-1 BAM + seqtk over the read file, TELR_assembly.py:384-462.)
 
-    items: list of (destination rank, locus id, global read id, uint8 base array).
-    -> list of (locus id, global read id, uint8 base array) received by this rank, sorted by (locus id, read id).
-    Two all-to-all collectives: the byte counts, then one buffer per peer [n][n headers][bases]."""
+    One entry per (locus, read) pair to send: locus_id[i], read_id[i] (global read id), dest[i] (owner rank of the locus),
+    read_index[i] = index of the read in `reads` = (buf, off, len), this rank's read set on the host.
+    -> (locus ids, read ids, (buf, off, len)) of the pairs this rank received, sorted by (locus id, read id).
+    Two all-to-all collectives: the byte counts, then one buffer per peer [n][n x READ_HDR][bases]."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    locus_id = np.asarray(locus_id, np.int64); read_id = np.asarray(read_id, np.int64); dest = np.asarray(dest, np.int64)
+    read_index = np.asarray(read_index, np.int64)
+    rbuf, roff, rln = reads
+    roff = np.asarray(roff, np.int64); rln = np.asarray(rln, np.int64)
+
+    def pack(sel):
+        """[n][headers][bases] of the entries `sel`"""
+        hdr = np.zeros(len(sel), READ_HDR)
+        hdr["locus_id"] = locus_id[sel]; hdr["read_id"] = read_id[sel]; hdr["length"] = rln[read_index[sel]]
+        parts = [np.frombuffer(np.int64(len(sel)).tobytes(), np.uint8), hdr.view(np.uint8).reshape(-1)]
+        parts += [rbuf[roff[i]:roff[i] + rln[i]] for i in read_index[sel]]
+        return np.concatenate(parts)
+
+    def unpack(raw, sizes):
+        """-> header array and base offsets (into raw) of all reads of the concatenated per-peer buffers"""
+        hdrs, offs, o = [], [], 0
+        for sz in sizes:
+            b = raw[o:o + sz]
+            n = int(np.frombuffer(b[:8].tobytes(), np.int64)[0]) if sz >= 8 else 0
+            h = np.frombuffer(b[8:8 + n * READ_HDR.itemsize].tobytes(), READ_HDR)
+            start = o + 8 + n * READ_HDR.itemsize
+            ln = h["length"].astype(np.int64)
+            hdrs.append(h); offs.append(start + np.cumsum(ln) - ln)
+            o += sz
+        h = np.concatenate(hdrs) if hdrs else np.zeros(0, READ_HDR)
+        return h, (np.concatenate(offs) if offs else np.zeros(0, np.int64))
+
     if world == 1:
-        return sorted(((l, r, b) for (_, l, r, b) in items), key=lambda t: (t[0], t[1]))
-    import torch
-    per = [[] for _ in range(world)]
-    for it in items:
-        per[it[0]].append(it)
-    bufs = []
-    for d in range(world):
-        hdr = np.zeros(len(per[d]), READ_HDR)
-        for k, (_, l, r, b) in enumerate(per[d]):
-            hdr[k] = (l, r, len(b), 0)
-        parts = [np.frombuffer(np.int64(len(per[d])).tobytes(), np.uint8), hdr.view(np.uint8).reshape(-1)] + [np.ascontiguousarray(x[3], np.uint8) for x in per[d]]
-        bufs.append(np.concatenate(parts))
-    dev = device if device is not None else "cpu"
-    n_send = torch.tensor([len(b) for b in bufs], dtype=torch.int64, device=dev)
-    n_recv = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(n_recv, n_send)
-    n_recv_l = [int(x) for x in n_recv.cpu().tolist()]
-    send = torch.from_numpy(np.concatenate(bufs)).to(dev)
-    recv = torch.empty(sum(n_recv_l), dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(recv, send, output_split_sizes=n_recv_l, input_split_sizes=[len(b) for b in bufs])
-    raw = recv.cpu().numpy()
-    out, o = [], 0
-    for r in range(world):
-        b = raw[o:o + n_recv_l[r]]; o += n_recv_l[r]
-        n = int(np.frombuffer(b[:8].tobytes(), np.int64)[0])
-        hdr = np.frombuffer(b[8:8 + n * READ_HDR.itemsize].tobytes(), READ_HDR)
-        p = 8 + n * READ_HDR.itemsize
-        for h in hdr:
-            out.append((int(h["locus_id"]), int(h["read_id"]), b[p:p + int(h["length"])].copy())); p += int(h["length"])
-    out.sort(key=lambda t: (t[0], t[1]))
-    return out
+        raw = pack(np.arange(len(dest))); sizes = [len(raw)]
+    else:
+        import torch
+        bufs = [pack(np.nonzero(dest == d)[0]) for d in range(world)]
+        dev = device if device is not None else "cpu"
+        n_send = torch.tensor([len(b) for b in bufs], dtype=torch.int64, device=dev)
+        n_recv = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(n_recv, n_send)
+        sizes = [int(x) for x in n_recv.cpu().tolist()]
+        send = torch.from_numpy(np.concatenate(bufs)).to(dev)
+        recv = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=sizes, input_split_sizes=[len(b) for b in bufs])
+        raw = recv.cpu().numpy()
+    h, off = unpack(raw, sizes)
+    order = np.lexsort((h["read_id"], h["locus_id"]))
+    return h["locus_id"][order].astype(np.int64), h["read_id"][order].astype(np.int64), (raw, off[order], h["length"][order].astype(np.int32))
 
 
 def rows_from_reports(locus_ids, reports, freqs, chrom_ids, family_ids):

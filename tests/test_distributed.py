@@ -130,24 +130,33 @@ def test_locus_bundle_sharded_world2_equals_world1(tmp_path):
             assert abs(int(r["start"]) - t["pos"]) <= 20 and (1 if t["strand"] == "+" else -1) == r["strand"]
 
 
+def _exchange_items(rank, world):
+    """(locus, global read id, destination, local read index) of what `rank` sends; rank 1 sends nothing"""
+    out = []
+    if rank != 1:
+        for k in range(7):
+            gid = 100 * rank + k
+            for locus in range(5):
+                if (gid + locus) % 3 == 0:
+                    out.append((locus, gid, locus % world, k))
+    return out
+
+
+def _exchange_reads(rank):
+    seqs = [np.random.default_rng(100 * rank + k).integers(65, 70, size=10 + (100 * rank + k) % 13).astype(np.uint8) for k in range(7)]
+    ln = np.array([len(x) for x in seqs], np.int32)
+    return np.concatenate(seqs), (np.cumsum(ln) - ln).astype(np.int64), ln
+
+
 def _exchange_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from telr_amd import shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    # every rank holds reads 100*rank .. ; read r of locus l goes to rank l % world; the LAST rank owns reads but sends none to
-    # itself and rank 1 sends nothing at all (an empty sender), rank 0 receives for loci 0, world, 2*world ...
-    items = []
-    if rank != 1:
-        for k in range(7):
-            gid = 100 * rank + k
-            for locus in range(5):
-                if (gid + locus) % 3 == 0:
-                    rng = np.random.default_rng(gid)
-                    items.append((locus % world, locus, gid, rng.integers(65, 70, size=10 + gid % 13).astype(np.uint8)))
-    got = shard.exchange_window_reads(items, dist)
-    np.save(os.path.join(out_dir, "got%d.npy" % rank), np.array([(l, r, len(b), int(b.sum())) for l, r, b in got], np.int64).reshape(-1, 4))
+    it = _exchange_items(rank, world)
+    loc, rid, (buf, off, ln) = shard.exchange_window_reads([x[0] for x in it], [x[1] for x in it], [x[2] for x in it], _exchange_reads(rank), [x[3] for x in it], dist)
+    np.save(os.path.join(out_dir, "got%d.npy" % rank), np.array([(l, r, n, int(buf[o:o + n].sum())) for l, r, o, n in zip(loc, rid, off, ln)], np.int64).reshape(-1, 4))
     # the locus table: an empty contribution from rank 1 must not disturb the one all-gather
     rows = _make_rows([rank]) if rank != 1 else _make_rows([])
     merged = shard.all_gather_rows(rows, dist, capacity=1)
@@ -167,21 +176,17 @@ def test_window_read_exchange_and_empty_rank(tmp_path, world):
     mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     want = {r: [] for r in range(world)}
     for rank in range(world):
-        if rank == 1:
-            continue
-        for k in range(7):
-            gid = 100 * rank + k
-            for locus in range(5):
-                if (gid + locus) % 3 == 0:
-                    b = np.random.default_rng(gid).integers(65, 70, size=10 + gid % 13).astype(np.uint8)
-                    want[locus % world].append((locus, gid, len(b), int(b.sum())))
+        buf, off, ln = _exchange_reads(rank)
+        for locus, gid, d, k in _exchange_items(rank, world):
+            want[d].append((locus, gid, int(ln[k]), int(buf[off[k]:off[k] + ln[k]].sum())))
     for r in range(world):
         got = np.load(str(tmp_path / ("got%d.npy" % r)))
         assert [tuple(x) for x in got.tolist()] == sorted(want[r])
     rows = np.load(str(tmp_path / "rows.npy"))
     assert rows["locus_id"].tolist() == [r for r in range(world) if r != 1]
-    one = shard.exchange_window_reads([(0, 3, 9, np.arange(4, dtype=np.uint8)), (0, 1, 2, np.arange(2, dtype=np.uint8))])
-    assert [(l, r) for l, r, _ in one] == [(1, 2), (3, 9)]
+    reads = (np.arange(6, dtype=np.uint8), np.array([0, 4], np.int64), np.array([4, 2], np.int32))
+    loc, rid, (buf, off, ln) = shard.exchange_window_reads([3, 1], [9, 2], [0, 0], reads, [0, 1])
+    assert loc.tolist() == [1, 3] and rid.tolist() == [2, 9] and [buf[o:o + n].tolist() for o, n in zip(off, ln)] == [[4, 5], [0, 1, 2, 3]]
 
 
 def test_bench_launcher_starts_n_ranks():

@@ -1959,14 +1959,22 @@ __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffff
 
 struct PkConst { uint32_t qe, e, q2e2, e2, ab, b; };
 
+// ONEP (one-piece): in a band of D diagonals no gap run is longer than D - 1, and while (D - 1)(e - e2) < q2 - q the second
+// affine piece q2 + L e2 is STRICTLY dearer than q + L e for every possible run length, so E2 / F2 are strictly below
+// E1 / F1 wherever they are finite: they never win the maximum (ties prefer E1 / F1 anyway) and never lie on the path.
+// The two states, a third of the cell's instructions, are then simply not computed -- bit-identical results (the oracle
+// always computes all five states).  map-ont / map-pb: D <= 20, i.e. classes 17 and 10 = 72 % of the fill cells.
+template <bool ONEP = false>
 __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t e1l, uint32_t e2l, uint32_t hu, uint32_t f1u, uint32_t f2u,
                                               uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve1, uint32_t &vf1, uint32_t &ve2, uint32_t &vf2)
 {
     uint32_t op, g, t;
     op = pk_sub(hl, c.qe);   g = pk_sub(e1l, c.e);  ve1 = pk_max(op, g); t  = pk_sign(pk_sub(op, g)) & 0x00080008u;
     op = pk_sub(hu, c.qe);   g = pk_sub(f1u, c.e);  vf1 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00100010u;
-    op = pk_sub(hl, c.q2e2); g = pk_sub(e2l, c.e2); ve2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00200020u;
-    op = pk_sub(hu, c.q2e2); g = pk_sub(f2u, c.e2); vf2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00400040u;
+    if (!ONEP) {
+        op = pk_sub(hl, c.q2e2); g = pk_sub(e2l, c.e2); ve2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00200020u;
+        op = pk_sub(hu, c.q2e2); g = pk_sub(f2u, c.e2); vf2 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & 0x00400040u;
+    } else { ve2 = PK_NEG; vf2 = PK_NEG; }
     // no ambiguity case here: problems with an N inside either window never reach the packed classes (k_prob_sizes)
     const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
     const uint32_t sc = pk_sub(eq & c.ab, c.b);
@@ -1975,8 +1983,10 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     uint32_t m, src;
     m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & 0x00010001u;
     m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = pk_sel(m, 0x00020002u, src);
-    m = pk_sign(pk_sub(h, ve2)); h = pk_max(h, ve2); src = pk_sel(m, 0x00030003u, src);
-    m = pk_sign(pk_sub(h, vf2)); h = pk_max(h, vf2); src = pk_sel(m, 0x00040004u, src);
+    if (!ONEP) {
+        m = pk_sign(pk_sub(h, ve2)); h = pk_max(h, ve2); src = pk_sel(m, 0x00030003u, src);
+        m = pk_sign(pk_sub(h, vf2)); h = pk_max(h, vf2); src = pk_sel(m, 0x00040004u, src);
+    }
     return t | src;
 }
 
@@ -2043,7 +2053,7 @@ __device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dh
 // through `xch` (LDS, [2][NW][3]) with one barrier per step, everything else is unchanged.
 // FULL: the first FULL registers of a lane are inside the band for every problem of the class (classes are cut so that
 // only the last register can straddle dhi), so they need no out-of-band masks.
-template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0>
+template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false>
 __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob, uint32_t *xch = nullptr)
 {
     static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
@@ -2125,7 +2135,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 // left neighbour: odd diagonal below -> {low: previous register's high half, high: own low half}
                 const uint32_t lh = r ? Ho[r - 1] : ph, le1 = r ? E1o[r - 1] : pe1, le2 = r ? E2o[r - 1] : pe2;
                 const uint32_t hl = __builtin_amdgcn_alignbit(Ho[r], lh, 16), e1l = __builtin_amdgcn_alignbit(E1o[r], le1, 16), e2l = __builtin_amdgcn_alignbit(E2o[r], le2, 16);
-                te[r] = d_cell_pk(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                te[r] = d_cell_pk<ONEP>(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { He[r] = h; F1e[r] = vf1; F2e[r] = vf2; }
                 else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]); }
                 E1e[r] = ve1; E2e[r] = ve2;
@@ -2167,7 +2177,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 // up neighbour: even diagonal above -> {low: own high half, high: next register's low half}
                 const uint32_t uh = r < R - 1 ? He[r + 1] : nh, uf1 = r < R - 1 ? F1e[r + 1] : nf1, uf2 = r < R - 1 ? F2e[r + 1] : nf2;
                 const uint32_t hu = __builtin_amdgcn_alignbit(uh, He[r], 16), f1u = __builtin_amdgcn_alignbit(uf1, F1e[r], 16), f2u = __builtin_amdgcn_alignbit(uf2, F2e[r], 16);
-                const uint32_t t = d_cell_pk(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                const uint32_t t = d_cell_pk<ONEP>(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { Ho[r] = h; F1o[r] = vf1; F2o[r] = vf2; }
                 else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]); }
                 E1o[r] = ve1; E2o[r] = ve2;
@@ -2283,6 +2293,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int32_t *list = cls_list + off.off[cls];
     const int n = off.off[cls + 1] - off.off[cls];
+    // widest band in which the second affine piece can never pay (see d_cell_pk): (D - 1)(e - e2) < q2 - q
+    const int onep_d = A.o.e > A.o.e2 ? (A.o.q2 - A.o.q + (A.o.e - A.o.e2) - 1) / (A.o.e - A.o.e2) : 1 << 20;
+    if (cls == 17 && onep_d >= 16) { d_dp_pkr<1, 4, false, 1, 0, true>(A, list, n, first); return; }
+    if (cls == 10 && onep_d >= 20) { d_dp_pkr<1, 5, false, 1, 4, true>(A, list, n, first); return; }
     switch (cls) {
     case 10: d_dp_pkr<1, 5, false, 1, 4>(A, list, n, first); break;      // 17..20 diagonals: registers 0-3 are inside the band
     case 11: d_dp_pkr<1, 6, false, 1, 5>(A, list, n, first); break;

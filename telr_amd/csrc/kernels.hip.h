@@ -6,13 +6,18 @@
 //     plus an ambiguity bitmask (1 bit/base, 32 per word); every sequence starts at a
 //     64-base (16-byte) boundary so tiles are read with aligned, coalesced loads;
 //   * minimizers: SoA  x (u64 hash<<8|span)  /  y (u32 pos<<1|strand);
-//   * index: distinct hashes (u64, ascending) + u32 offsets into a u32 position array,
-//     addressed through a direct bucket table on the top hash bits;
+//   * index: distinct hashes (u64, ascending) + u32 offsets into a u32 position array (what the oracle is compared
+//     with); the seeding kernel probes an open-addressing table of 16-byte slots {hash, first occurrence, count} in
+//     front of a 2-bit-per-slot home bitmap (one 64-byte line per probe);
 //   * anchors: ONE sortable u64 per anchor (strand | global target pos | query pos | span),
 //     half the footprint of the classic 16-byte anchor, so seeding, sorting and chaining
 //     each move 8 B per anchor;
-//   * DP: anti-diagonal sweep, one wave per problem, DP state in LDS, one trace-back byte
-//     per cell streamed to an HBM scratch row [a][slot] (coalesced 32-64 B per step).
+//   * chaining: forward push in registers (one wave per query, v_readlane broadcasts); back-tracking: owner / depth
+//     sweeps with pointer jumping (no walker); pass-1 chain selection: one wave per query;
+//   * DP: anti-diagonal sweep.  Gap fills with <= 128 diagonals run in packed int16 registers (two diagonals per
+//     32-bit register, one problem per lane for bands <= 32: d_dp_pkr), wider ones in packed multi-wave or int32
+//     register kernels, only bands > 1024 keep the DP state in LDS; one trace-back byte per cell streamed to an HBM
+//     scratch (wave-interleaved 512-byte stores for the lane-per-problem classes).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

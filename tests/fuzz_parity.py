@@ -15,7 +15,7 @@ def run(eng, n_iter, seed0, big=False):
     from test_gpu_parity import compare_all
     for it in range(n_iter):
         rng = np.random.default_rng(seed0 * 1000 + it)
-        pname = ["map-ont", "map-ont", "map-pb", "asm10"][int(rng.integers(0, 4))]
+        pname = ["map-ont", "map-ont", "map-pb", "asm10", "ngmlr-ont", "ngmlr-pacbio"][int(rng.integers(0, 6))]
         io, mo = preset(pname)
         ntg = int(rng.integers(1, 4))
         genome = [synth.random_seq(rng, int(rng.integers(300000, 1500000) if big else rng.integers(20000, 120000))) for _ in range(ntg)]
@@ -35,12 +35,17 @@ def run(eng, n_iter, seed0, big=False):
             if len(r) > 200:
                 r[50:50 + int(rng.integers(1, 100))] = ord("N")
         # option mix
-        if pname != "map-pb" and rng.random() < 0.5:
+        if pname != "map-pb" and not pname.startswith("ngmlr") and rng.random() < 0.5:
             io.k = int(rng.integers(11, 22)); io.w = int(rng.choice([5, 10, 10, 12, 19]))
             from telr_amd.presets import _gap_q8
             mo.chain_gap_q8 = _gap_q8(io.k)
         mo.chain_lookback = int(rng.choice([64, 128, 256]))
-        mo.fill_band_q4 = int(rng.integers(1, 9))
+        mo.fill_band_q4 = int(rng.integers(1, 17)); mo.fill_margin = int(rng.integers(0, 4))
+        if rng.random() < 0.25:                             # gap costs on both sides of the one-piece rule of the packed cell ((D-1)(e-e2) < q2-q)
+            mo.q2 = int(mo.q + rng.integers(0, 30)); mo.e2 = int(rng.integers(1, mo.e + 1))
+        per_target = ntg > 1 and rng.random() < 0.2          # ranked per target, per-target occurrence cut-offs
+        if per_target:
+            mo.flags |= 2
         mo.min_ksw_len = int(rng.choice([50, 100, 200, 400]))
         mo.bw = int(rng.choice([100, 500, 2000])); mo.max_gap = int(rng.choice([1000, 5000, 10000]))
         mo.best_n = int(rng.integers(1, 8)); mo.secondary = int(rng.integers(0, 2))
@@ -50,7 +55,7 @@ def run(eng, n_iter, seed0, big=False):
             compare_all(eng, genome, reads, io, mo)
         except Exception as e:
             print("FAIL iteration", it, "seed", seed0 * 1000 + it, pname, "k", io.k, "w", io.w, "lookback", mo.chain_lookback, "q4", mo.fill_band_q4, "ksw", mo.min_ksw_len,
-                  "bw", mo.bw, "gap", mo.max_gap, "skip", mo.chain_skip_q8)
+                  "bw", mo.bw, "gap", mo.max_gap, "skip", mo.chain_skip_q8, "margin", mo.fill_margin, "q2", mo.q2, "e2", mo.e2, "flags", mo.flags)
             raise
 
 

@@ -1,5 +1,6 @@
 """Randomised parity: random genomes, read sets (tiny / empty / N-containing reads included) and option mixes (k, w, look-back,
-band factor, segment length, band width, gap limit, skip penalty, secondary output, extension limits, all three presets),
+band factor and retry margin, segment length, band width, gap limit, two-piece gap costs on both sides of the one-piece rule, skip penalty,
+secondary output, per-target ranking, extension limits, all five presets),
 every stage compared bit for bit with the oracle.  `python tests/fuzz_parity.py 800 <seed>` runs the long version."""
 import os
 import sys
@@ -10,7 +11,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", [11, 12, 13])
 def test_random_configurations(engine, seed):
     import fuzz_parity
     fuzz_parity.run(engine, 40, seed)

@@ -1278,7 +1278,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "pk_end", (size_t)nq + 1, &d_pkend));
     TRY(ctx_buf_t(ctx, "ch_off", (size_t)nq + 1, &d_choff));
     TRY(ctx_buf_t(ctx, "n_chains", (size_t)nq + 1, &d_nch));
-    HIPCHK(hipMemsetAsync(d_flags, 0, (size_t)na * 2 + 16, st));
+    HIPCHK(hipMemsetAsync(d_flags, 0, getenv("TELR_BT_WALKER") ? (size_t)na * 2 + 16 : (size_t)na + 16, st));      // the visited marks only serve the round-1 walker
     hipLaunchKernelGGL(k_nonpeak, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_p, d_nonpeak);
     hipLaunchKernelGGL(k_peaks, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_nonpeak, mo->min_chain_score, d_pk, d_npk, d_pkend);
     HIPCHK(hipGetLastError());

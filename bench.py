@@ -344,10 +344,18 @@ def main():
                                                        shards=shards, presets=presets_arg, read_set=pool_set)
         loci_pass()                                # warm-up (sizes the scratch)
         sync()
+        prof = None
+        if os.environ.get("TELR_PROF_LOCI") and rank == 0:      # where does the per-locus leg spend its time? (stderr)
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
         t0 = time.time()
         rows, lres = loci_pass()
         sync()
         t_loci = time.time() - t0
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(40)
         if dist is not None:
             t = torch.tensor([t_loci], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_loci = float(t[0])
         good = 0; af_ok = 0; n_rows = len(rows)

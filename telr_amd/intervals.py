@@ -100,16 +100,18 @@ def getfasta(seq_lookup, chrom, start, end):
 
 def intersect_wao(a_rows, b_rows):
     """`bedtools intersect -a A -b B -wao`: one row per (A, overlapping B) with the overlap in bp; an A
-    feature without overlap gets `.`/-1 filler columns and 0."""
+    feature without overlap gets `.`/-1 filler columns and 0.  (B is grouped by chromosome once: the annotation
+    step intersects thousands of library hits with one ALT hit per contig.)"""
     out = []
     ncol_b = len(b_rows[0]) if b_rows else 6
+    by_chrom = {}
+    for b in b_rows:
+        by_chrom.setdefault(b[0], []).append((int(b[1]), int(b[2]), b))
     for a in a_rows:
         a_s, a_e = int(a[1]), int(a[2])
         hit = False
-        for b in b_rows:
-            if b[0] != a[0]:
-                continue
-            ov = min(a_e, int(b[2])) - max(a_s, int(b[1]))
+        for b_s, b_e, b in by_chrom.get(a[0], ()):
+            ov = min(a_e, b_e) - max(a_s, b_s)
             if ov > 0:
                 out.append(list(a) + list(b) + [str(ov)])
                 hit = True

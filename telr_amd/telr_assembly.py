@@ -25,21 +25,25 @@ def breakpoint(start, end):
 def window_reads(alns, chrom_ids, loci, window=1000):
     """alns: record array of telr_map (fields qid, tid, ts, te); chrom_ids: {chromosome name: target id};
     loci: rows of the vcf table (chr, start, end, ...).  -> list of sorted unique read-index arrays."""
-    tid = np.asarray(alns["tid"]); ts = np.asarray(alns["ts"]); te = np.asarray(alns["te"]); qid = np.asarray(alns["qid"])
+    tid = np.ascontiguousarray(alns["tid"], np.int64); ts = np.ascontiguousarray(alns["ts"], np.int64)
+    te = np.ascontiguousarray(alns["te"], np.int64); qid = np.ascontiguousarray(alns["qid"], np.int64)
     order = np.lexsort((ts, tid))
     tid_s, ts_s, te_s, qid_s = tid[order], ts[order], te[order], qid[order]
+    max_span = int((te_s - ts_s).max()) if len(ts_s) else 0            # no record reaches further back than this
+    c_of = np.array([chrom_ids.get(row[0], -1) for row in loci], np.int64)
+    bp = np.array([breakpoint(row[1], row[2]) for row in loci], np.int64)
+    s_of, e_of = np.maximum(0, bp - window), bp + window
+    lo_c = np.searchsorted(tid_s, c_of, side="left"); hi_c = np.searchsorted(tid_s, c_of, side="right")
     out = []
-    for row in loci:
-        c = chrom_ids.get(row[0], -1)
-        bp = breakpoint(row[1], row[2])
-        s, e = max(0, bp - window), bp + window
-        lo = np.searchsorted(tid_s, c, side="left"); hi = np.searchsorted(tid_s, c, side="right")
-        if hi <= lo or c < 0:
+    for i in range(len(loci)):
+        lo, hi = int(lo_c[i]), int(hi_c[i])
+        if hi <= lo or c_of[i] < 0:
             out.append(np.zeros(0, np.int64)); continue
-        # records starting before e; among them those ending after s
-        k = lo + np.searchsorted(ts_s[lo:hi], e, side="left")
-        m = te_s[lo:k] > s
-        out.append(np.unique(qid_s[lo:k][m]).astype(np.int64))
+        seg = ts_s[lo:hi]
+        k = lo + int(np.searchsorted(seg, e_of[i], side="left"))               # records starting before the window's end ...
+        k0 = lo + int(np.searchsorted(seg, s_of[i] - max_span, side="left"))   # ... and not too far left to reach its start
+        m = te_s[k0:k] > s_of[i]
+        out.append(np.unique(qid_s[k0:k][m]))
     return out
 
 

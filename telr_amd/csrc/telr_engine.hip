@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -303,24 +304,36 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     }
     s->boff[n] = tot; s->padded_bases = tot;
     size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
-    std::vector<uint32_t> h2(w2, 0), hn(wn, 0);
+    // every word of the two packed arrays is WRITTEN (whole 64-base groups, padding included), so the staging buffers need
+    // no zero-fill: a multi-Gbp read set would spend more time in memset than in packing
+    std::unique_ptr<uint32_t[]> h2_(new uint32_t[w2]), hn_(new uint32_t[wn]);
+    uint32_t *h2 = h2_.get(), *hn = hn_.get();
+    for (size_t z = w2 - 8; z < w2; ++z) h2[z] = 0;
+    for (size_t z = wn - 8; z < wn; ++z) hn[z] = 0;
     int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
     if (s->total_bases < (1 << 20)) nth = 1;
     std::vector<std::thread> th;
     for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
         for (int i = t; i < n; i += nth) {
             const unsigned char *p = (const unsigned char*)ascii + off[i];
-            const int64_t b = s->boff[i];              // multiple of 64: 8-base groups never straddle a word
+            const int64_t b = s->boff[i];              // multiple of 64
             const int L = len[i];
-            for (int j = 0; j < L; j += 8) {
-                uint64_t x8;
-                if (j + 8 <= L) memcpy(&x8, p + j, 8);
-                else { unsigned char tail[8] = { 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A' }; memcpy(tail, p + j, (size_t)(L - j)); memcpy(&x8, tail, 8); }
-                uint32_t code16, amb8;
-                pack8(x8, code16, amb8);
-                const int64_t x = b + j;
-                h2[x >> 4] |= code16 << ((x & 15) * 2);
-                if (amb8) hn[x >> 5] |= amb8 << (x & 31);
+            for (int j0 = 0; j0 < L; j0 += 64) {       // one 64-base group = 4 code words + 2 ambiguity words
+                uint32_t c[4] = { 0, 0, 0, 0 }, a[2] = { 0, 0 };
+                for (int g = 0; g < 8; ++g) {
+                    const int j = j0 + 8 * g;
+                    if (j >= L) break;
+                    uint64_t x8;
+                    if (j + 8 <= L) memcpy(&x8, p + j, 8);
+                    else { unsigned char tail[8] = { 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A' }; memcpy(tail, p + j, (size_t)(L - j)); memcpy(&x8, tail, 8); }
+                    uint32_t code16, amb8;
+                    pack8(x8, code16, amb8);
+                    c[g >> 1] |= code16 << ((g & 1) * 16);
+                    a[g >> 2] |= amb8 << ((g & 3) * 8);
+                }
+                const int64_t x = b + j0;
+                uint32_t *d2 = h2 + (x >> 4), *dn = hn + (x >> 5);
+                d2[0] = c[0]; d2[1] = c[1]; d2[2] = c[2]; d2[3] = c[3]; dn[0] = a[0]; dn[1] = a[1];
             }
         }
     });
@@ -331,8 +344,8 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(s->d_seq2, h2.data(), w2 * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(s->d_nmask, hn.data(), wn * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(s->d_seq2, h2, w2 * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpy(s->d_nmask, hn, wn * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if ((e = hipMemcpy(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     if (n && (e = hipMemcpy(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
     *out = s;

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +64,7 @@ struct telr_ctx {
     int64_t dp_retries = 0;
     int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
     telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
+    telr_ctx *slot1 = nullptr;            // the second range slot (a parent context with lane workers of its own)
     int n_child = 0;
     bool is_child = false;
     char devname[256] = {0};
@@ -189,6 +191,7 @@ extern "C" void telr_destroy(telr_ctx *ctx)
 {
     if (!ctx) return;
     for (int k = 0; k < 4; ++k) if (ctx->child[k]) { telr_destroy(ctx->child[k]); ctx->child[k] = nullptr; }
+    if (ctx->slot1) { telr_destroy(ctx->slot1); ctx->slot1 = nullptr; }
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->hbufs) if (kv.second.p) (void)hipHostFree(kv.second.p);
@@ -787,8 +790,31 @@ struct telr_result {
     uint32_t *cig = nullptr;       // pinned; filled by one DMA that may still be in flight when telr_map returns
     size_t ncig = 0, cap = 0;      // cap in ops
     mutable hipEvent_t dma_done = nullptr;   // non-null while the CIGAR DMA has not been waited for
+    // Ranges of one telr_map call may be in flight on two slots (telr_map: range pipelining).  They append to this result in
+    // range order: a range waits here for its turn before it first touches alns / cig, and keeps the turn until its lanes
+    // are merged.  turn < 0: a range failed, everybody leaves.
+    std::mutex gate_m; std::condition_variable gate_cv; int turn = 0;
     ~telr_result();
 };
+// what a batch saw when it got its turn (map_range merges the lanes from there)
+struct RangeTurn { int turn = -1; bool entered = false; size_t a0 = 0, c0 = 0; };
+static bool gate_enter(telr_result *R, RangeTurn *g)
+{
+    if (!g || g->entered) return true;
+    if (g->turn >= 0) {
+        std::unique_lock<std::mutex> lk(R->gate_m);
+        R->gate_cv.wait(lk, [&] { return R->turn < 0 || R->turn == g->turn; });
+        if (R->turn < 0) return false;
+    }
+    g->entered = true; g->a0 = R->alns.size(); g->c0 = R->ncig;
+    return true;
+}
+static void gate_leave(telr_result *R, int turn, bool ok)
+{
+    if (turn < 0) return;
+    { std::lock_guard<std::mutex> lk(R->gate_m); if (R->turn >= 0) R->turn = ok ? turn + 1 : -1; }
+    R->gate_cv.notify_all();
+}
 // the records are complete when telr_map returns; the CIGAR array is complete after this (every accessor of it calls it)
 static void result_wait(const telr_result *r)
 {
@@ -1163,7 +1189,7 @@ struct HostTrace {
 // one batch of queries [q0, q1)
 struct OccCut { int32_t mid_occ; const int32_t *d_tmid; };      // pooled cut-off; per-target cut-offs (nullable)
 static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs, const int32_t *d_qtarget, int32_t q0, int32_t q1,
-                     const telr_map_opt *mo, OccCut occ, telr_result *R)
+                     const telr_map_opt *mo, OccCut occ, telr_result *R, RangeTurn *gate = nullptr)
 {
     const int32_t mid_occ = occ.mid_occ;
     const int nq = q1 - q0, k = ix->io.k, w = ix->io.w;
@@ -1636,6 +1662,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             if (ctx->dma_inflight) HIPCHK(hipStreamWaitEvent(st, ctx->ev_dma, 0));
             hipLaunchKernelGGL(k_stitch_write, dim3((np + 31) / 32), dim3(256), 0, st, np, d_sp, d_probs, d_res, d_sv, d_rawcig, d_foff, d_fin);
             HIPCHK(hipGetLastError());
+            if (!gate_enter(R, gate)) { ctx->err = "an earlier range of the call failed"; return TELR_E_HIP; }
             result_wait(R);                        // an earlier batch of this call may still be writing into the buffer that grows below
             cig_base = R->ncig;
             if (cig_base + (size_t)tot + 1 > R->cap) {
@@ -1725,6 +1752,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         }
     });
     std::vector<int64_t> out0((size_t)nq + 1);
+    if (!gate_enter(R, gate)) { ctx->err = "an earlier range of the call failed"; return TELR_E_HIP; }
     const size_t r_base = R->alns.size();
     out0[0] = 0;
     for (int q = 0; q < nq; ++q) out0[q + 1] = out0[q] + nsurv[q];
@@ -1795,7 +1823,7 @@ static int seqset_subset_into(telr_ctx *ctx, const telr_seqset *parent, const st
 //
 // A range whose anchors do not fit int32 offsets (map_batch: TELR_SPLIT_RANGE) is halved and retried.
 static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const int32_t *d_qt,
-                     int32_t q0, int32_t q1, const telr_map_opt *mo, OccCut mid_occ, telr_result *R)
+                     int32_t q0, int32_t q1, const telr_map_opt *mo, OccCut mid_occ, telr_result *R, int turn = -1)
 {
     const int nq = q1 - q0;
     if (nq <= 0) return TELR_OK;
@@ -1814,17 +1842,16 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         }
     }
     int rr = TELR_OK;
-    const size_t a_start = R->alns.size();
+    RangeTurn gate; gate.turn = turn;         // (pipelined ranges: R is only touched once the earlier ranges are in)
     HostTrace hr("range");
     if (!lane) {
-        rr = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R);
+        rr = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R, &gate);
         if (rr == TELR_OK) ctx->ctr.query_bases += total_bases;
     } else {
         for (int k = 0; k < 2; ++k) TRY(ctx_make_child(ctx, k));
         // the recycled (large) result buffers go to the bulk worker, which fills R
         for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
         ctx->cig_pool.clear();
-        const size_t c_start = R->ncig;       // (an earlier range's DMA into R may still run: map_batch waits for it before it touches the buffer)
         telr_seqset sub[2]; telr_result *P1 = new telr_result(); P1->ctx = nullptr; int rc[2] = { TELR_OK, TELR_OK };
         auto work = [&](int k) {
             telr_ctx *c = ctx->child[k];
@@ -1839,7 +1866,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
                 if ((rc[k] = ctx_buf_t(c, "lane_qt", (size_t)n + 1, &d_q)) != TELR_OK) return;
                 if (hipMemcpy(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
             }
-            rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, k == 0 ? R : P1);
+            rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, k == 0 ? R : P1, k == 0 ? &gate : nullptr);
             if (rc[k] == TELR_OK) c->ctr.query_bases += sub[k].total_bases;
         };
         hr.mark("lane lists");
@@ -1851,8 +1878,10 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         sub[0].d_seq2 = sub[0].d_nmask = nullptr; sub[1].d_seq2 = sub[1].d_nmask = nullptr;       // scratch of the workers, not owned
         sub[0].d_boff = sub[1].d_boff = nullptr; sub[0].d_len = sub[1].d_len = nullptr;
         for (int k = 0; k < 2 && rr == TELR_OK; ++k) if (rc[k] != TELR_OK) { if (rc[k] != TELR_SPLIT_RANGE) ctx->err = ctx->child[k]->err; rr = rc[k]; }
+        if (rr == TELR_OK && !gate_enter(R, &gate)) { ctx->err = "an earlier range of the call failed"; rr = TELR_E_HIP; }
+        const size_t a_start = gate.a0;
         if (rr != TELR_OK) {                  // roll back what the bulk worker appended
-            result_wait(R); R->alns.resize(a_start); R->ncig = c_start;
+            if (gate.entered) { result_wait(R); R->alns.resize(gate.a0); R->ncig = gate.c0; }
         } else {
             // the long reads' ops go behind the bulk's; records are merged by query id (both lists are sorted by it)
             result_wait(P1);
@@ -1898,8 +1927,8 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         int32_t mid = q0; int64_t acc = 0;
         while (mid < q1 - 1 && acc + queries->len[mid] <= total_bases / 2) acc += queries->len[mid++];
         if (mid == q0) mid = q0 + 1;
-        TRY(map_range(ctx, ix, queries, qtarget, d_qt, q0, mid, mo, mid_occ, R));
-        return map_range(ctx, ix, queries, qtarget, d_qt, mid, q1, mo, mid_occ, R);
+        TRY(map_range(ctx, ix, queries, qtarget, d_qt, q0, mid, mo, mid_occ, R, turn));
+        return map_range(ctx, ix, queries, qtarget, d_qt, mid, q1, mo, mid_occ, R, turn);
     }
     return rr;
 }
@@ -1945,15 +1974,63 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // ranges bounded by bases (HBM is 288 GB: one range holds up to ~1 Gbp of reads, scratch ~80 B per base); a read
         // set of any size streams through as consecutive ranges, each with its own long-read lane
         int64_t batch_bases = 1024LL << 20;
-        if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 20; }
-        if (const char *e = getenv("TELR_BATCH_KBP")) { long v = atol(e); if (v > 0) batch_bases = (int64_t)v << 10; }     // tests
-        int32_t q0 = 0;
-        while (q0 < nq) {
+        bool fixed = false;
+        if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) { batch_bases = (int64_t)v << 20; fixed = true; } }
+        if (const char *e = getenv("TELR_BATCH_KBP")) { long v = atol(e); if (v > 0) { batch_bases = (int64_t)v << 10; fixed = true; } }     // tests
+        // Range pipelining (opt-in, TELR_PIPELINE=2): two ranges in flight on two slots (each slot = a parent context + its
+        // two lane workers), so the seeding / sorting / chaining of range i+1 runs underneath the fills of range i.  Measured
+        // on configs[2]: no gain (14.2-15.1 vs 14.8 Gbp/s; stage times double, the wall does not move) -- with the two lanes
+        // of a range the device is already full, and the sum of the kernels' work is what bounds the step.  Kept for hosts
+        // with many cores and as a test of the in-order append (tests/test_gpu_parity.py::test_pipelined_ranges).
+        int pipe = 1; bool force = false;
+        if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }      // "force": tests, any size
+        if (ctx->is_child || (!force && (ctx->debug || total_bases < (200LL << 20) || nq < 4000))) pipe = 1;
+        if (pipe == 2 && !fixed) {
+            int64_t nr = (total_bases + (512LL << 20) - 1) / (512LL << 20);
+            if (nr < 2) nr = 2;
+            nr += nr & 1;
+            batch_bases = (total_bases + nr - 1) / nr + 1;
+        }
+        std::vector<std::pair<int32_t, int32_t>> ranges;
+        for (int32_t q0 = 0; q0 < nq; ) {
             int32_t q1 = q0; int64_t b = 0;
             while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= batch_bases)) { b += queries->len[q1]; ++q1; }
-            int r = map_range(ctx, ix, queries, qtarget, d_qt, q0, q1, mo, mid_occ, R);
-            if (r != TELR_OK) { delete R; return r; }
+            ranges.push_back(std::make_pair(q0, q1));
             q0 = q1;
+        }
+        if (pipe == 2 && ranges.size() >= 2) {
+            if (!ctx->slot1) {
+                int r = telr_init(ctx->device, &ctx->slot1);
+                if (r != TELR_OK) { delete R; return r; }
+            }
+            telr_ctx *P[2] = { ctx, ctx->slot1 };
+            { telr_ctx *c = P[1]; memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0; c->err.clear(); }
+            int rc[2] = { TELR_OK, TELR_OK };
+            auto slot = [&](int s) {
+                (void)hipSetDevice(ctx->device);
+                for (size_t i = (size_t)s; i < ranges.size(); i += 2) {
+                    int r = map_range(P[s], ix, queries, qtarget, d_qt, ranges[i].first, ranges[i].second, mo, mid_occ, R, (int)i);
+                    gate_leave(R, (int)i, r == TELR_OK);
+                    if (r != TELR_OK) { rc[s] = r; return; }
+                }
+            };
+            std::thread t1(slot, 1);
+            slot(0);
+            t1.join();
+            // the failing range's error, not that of the range it made leave
+            for (int s = 0; s < 2; ++s) if (rc[s] != TELR_OK && P[s]->err != "an earlier range of the call failed") { if (s) ctx->err = P[1]->err; delete R; return rc[s]; }
+            for (int s = 0; s < 2; ++s) if (rc[s] != TELR_OK) { if (s) ctx->err = P[1]->err; delete R; return rc[s]; }
+            { telr_ctx *c = P[1];
+              for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
+              const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
+              for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
+              for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
+              ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches; }
+        } else {
+            for (auto &rg : ranges) {
+                int r = map_range(ctx, ix, queries, qtarget, d_qt, rg.first, rg.second, mo, mid_occ, R);
+                if (r != TELR_OK) { delete R; return r; }
+            }
         }
     } else {
         // split by bases into nsub contiguous ranges

@@ -65,6 +65,14 @@ def test_c2_shape_many_chromosomes_ranges_and_lane(engine):
         del os.environ["TELR_BATCH_MBP"], os.environ["TELR_LONGSPLIT"]
     assert _digest_of_digests(_per_read_digest(res2.alns, res2.cigars)) == whole
     assert (np.diff(res2.alns["qid"]) >= 0).all()
+    # the same with two ranges in flight (range pipelining; default on calls of 200 Mbp and more)
+    os.environ["TELR_BATCH_MBP"] = "12"; os.environ["TELR_LONGSPLIT"] = "force"; os.environ["TELR_PIPELINE"] = "force"
+    try:
+        res3 = ix.map(qs, mo)
+    finally:
+        del os.environ["TELR_BATCH_MBP"], os.environ["TELR_LONGSPLIT"], os.environ["TELR_PIPELINE"]
+    assert _digest_of_digests(_per_read_digest(res3.alns, res3.cigars)) == whole
+    assert (np.diff(res3.alns["qid"]) >= 0).all()
     # oracle parity on a few reads against the same 137.6-Mb index would need ~1 min of CPU index build: the full-size
     # parity samples are taken at configs[1] size (test_gpu_fullsize.py); here, a 2-chromosome sub-index suffices
     # to check that target ids / coordinates of a multi-target index agree

@@ -480,6 +480,31 @@ def test_long_read_lane(engine):
     assert len(res.alns) >= 40
 
 
+def test_pipelined_ranges(engine):
+    """Two ranges of a call are in flight at a time (second slot: its own parent context and lane workers) and append to
+    the one result in range order.  Forced here on a small input, with and without the long-read lanes and with an odd
+    and an even number of ranges: records and CIGARs must equal the oracle's single-batch result."""
+    import os
+    rng = np.random.default_rng(4242)
+    genome = [synth.random_seq(rng, 120000), synth.random_seq(rng, 50000)]
+    reads, _ = synth.simulate_reads(rng, genome, 60, 3500)
+    long_reads, _ = synth.simulate_reads(rng, genome, 5, 25000)
+    reads[7:7] = long_reads[:3]; reads.extend(long_reads[3:]); reads.insert(20, np.zeros(0, np.uint8))
+    io, mo = preset("map-ont")
+    qt = np.array([i % 3 - 1 for i in range(len(reads))], np.int32)
+    for kbp, lanes in (("60", True), ("45", False), ("1000", True)):
+        os.environ["TELR_PIPELINE"] = "force"; os.environ["TELR_BATCH_KBP"] = kbp
+        if lanes:
+            os.environ["TELR_LONGSPLIT"] = "force"
+        try:
+            res, _ = compare_all(engine, genome, reads, io, mo, stages=False)
+            compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
+        finally:
+            del os.environ["TELR_PIPELINE"], os.environ["TELR_BATCH_KBP"]
+            os.environ.pop("TELR_LONGSPLIT", None)
+        assert len(res.alns) >= 60 and (np.diff(res.alns["qid"]) >= 0).all()
+
+
 def test_seqset_subset_matches_fresh_set(engine):
     """telr_seqset_subset gathers packed sequences on the device: mapping the subset must give exactly what mapping a
     freshly packed set of the same sequences gives (repeats, an empty read and the last read included)."""

@@ -73,6 +73,7 @@ def lib():
     L.telr_debug_n_chain.restype = i64; L.telr_debug_n_chain.argtypes = [vp]
     L.telr_debug_chains.restype = vp; L.telr_debug_chains.argtypes = [vp]
     L.telr_debug_index.restype = C.c_int; L.telr_debug_index.argtypes = [vp, vp, vp, vp, vp]
+    L.telr_debug_pack.restype = C.c_int; L.telr_debug_pack.argtypes = [cp, i32, C.c_int, vp, vp]
     L.telr_debug_mid_occ.restype = i32; L.telr_debug_mid_occ.argtypes = [vp, C.POINTER(MapOpt)]
     _lib = L
     return L

@@ -10,6 +10,8 @@
 #include <string.h>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <atomic>
+#include <immintrin.h>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -293,6 +295,66 @@ static inline void pack8(uint64_t x, uint32_t &code16, uint32_t &amb8)
     amb8 = (uint32_t)(((inv >> 7) * 0x0102040810204080ULL) >> 56);
 }
 
+// bit i of v -> bit 2i
+static inline uint64_t spread32(uint64_t v)
+{
+    v = (v | v << 16) & 0x0000FFFF0000FFFFULL; v = (v | v << 8) & 0x00FF00FF00FF00FFULL; v = (v | v << 4) & 0x0F0F0F0F0F0F0F0FULL;
+    v = (v | v << 2) & 0x3333333333333333ULL; v = (v | v << 1) & 0x5555555555555555ULL;
+    return v;
+}
+// the same packing, 64 bases per call (4 code words + 2 ambiguity words), 32 per AVX2 step: the two code bits of a base
+// are gathered with byte-mask moves and interleaved
+__attribute__((target("avx2"))) static void pack_group64_avx2(const unsigned char *p, uint32_t *d2, uint32_t *dn)
+{
+    for (int h = 0; h < 2; ++h) {
+        const __m256i x = _mm256_loadu_si256((const __m256i*)(p + 32 * h));
+        const __m256i u = _mm256_or_si256(x, _mm256_set1_epi8(0x20));
+        __m256i ok = _mm256_or_si256(_mm256_cmpeq_epi8(u, _mm256_set1_epi8('a')), _mm256_cmpeq_epi8(u, _mm256_set1_epi8('c')));
+        ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(u, _mm256_set1_epi8('g')));
+        ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(u, _mm256_set1_epi8('t')));
+        ok = _mm256_or_si256(ok, _mm256_cmpeq_epi8(u, _mm256_set1_epi8('u')));
+        __m256i t = _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(3));                 // A 0, C 1, T 2, G 3
+        t = _mm256_xor_si256(t, _mm256_and_si256(_mm256_srli_epi16(t, 1), _mm256_set1_epi8(1)));      // A 0, C 1, G 2, T 3
+        t = _mm256_and_si256(t, ok);
+        const uint64_t b0 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 7)), b1 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 6));
+        const uint64_t code = spread32(b0) | spread32(b1) << 1;
+        d2[2 * h] = (uint32_t)code; d2[2 * h + 1] = (uint32_t)(code >> 32);
+        dn[h] = ~(uint32_t)_mm256_movemask_epi8(ok);
+    }
+}
+
+// one sequence -> padded 64-base groups (host only, no device needed: the CPU test of the two packers)
+static void pack_sequence(const unsigned char *p, int L, uint32_t *d2base, uint32_t *dnbase, bool avx2)
+{
+    for (int j0 = 0; j0 < L; j0 += 64) {           // one 64-base group = 4 code words + 2 ambiguity words
+        uint32_t *d2 = d2base + (j0 >> 4), *dn = dnbase + (j0 >> 5);
+        unsigned char tail[64];
+        const unsigned char *g = p + j0;
+        if (j0 + 64 > L) { memset(tail, 'A', 64); memcpy(tail, g, (size_t)(L - j0)); g = tail; }
+        if (avx2) pack_group64_avx2(g, d2, dn);
+        else {
+            uint32_t cw[4] = { 0, 0, 0, 0 }, aw[2] = { 0, 0 };
+            for (int k8 = 0; k8 < 8; ++k8) {
+                uint64_t x8; memcpy(&x8, g + 8 * k8, 8);
+                uint32_t code16, amb8;
+                pack8(x8, code16, amb8);
+                cw[k8 >> 1] |= code16 << ((k8 & 1) * 16);
+                aw[k8 >> 2] |= amb8 << ((k8 & 3) * 8);
+            }
+            d2[0] = cw[0]; d2[1] = cw[1]; d2[2] = cw[2]; d2[3] = cw[3]; dn[0] = aw[0]; dn[1] = aw[1];
+        }
+    }
+}
+// debug tap: pack `len` bytes with the AVX2 (mode 1; TELR_E_ARG when the host lacks it) or the 64-bit word packer (mode 0)
+// into code[(len+63)/64*4] and amb[(len+63)/64*2]
+extern "C" int telr_debug_pack(const char *ascii, int32_t len, int mode, uint32_t *code, uint32_t *amb)
+{
+    if (!ascii || len < 0 || !code || !amb) return TELR_E_ARG;
+    if (mode == 1 && !__builtin_cpu_supports("avx2")) return TELR_E_ARG;
+    pack_sequence((const unsigned char*)ascii, len, code, amb, mode == 1);
+    return TELR_OK;
+}
+
 extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, const int64_t *off, const int32_t *len, telr_seqset **out)
 {
     if (!ctx || n < 0 || !out || (n > 0 && (!ascii || !off || !len))) return TELR_E_ARG;
@@ -307,50 +369,64 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     }
     s->boff[n] = tot; s->padded_bases = tot;
     size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
-    // every word of the two packed arrays is WRITTEN (whole 64-base groups, padding included), so the staging buffers need
-    // no zero-fill: a multi-Gbp read set would spend more time in memset than in packing
-    std::unique_ptr<uint32_t[]> h2_(new uint32_t[w2]), hn_(new uint32_t[wn]);
-    uint32_t *h2 = h2_.get(), *hn = hn_.get();
+    // Packing and upload are part of the host-inclusive rate of the path (a 30x read set is 4 GB of ASCII):
+    //  * the two packed arrays are staged in PINNED grow-only buffers of the context (a fresh pageable buffer costs a page
+    //    fault per 4 KB and a bounce copy inside the runtime), and every word of them is WRITTEN (whole 64-base groups,
+    //    padding included), so they need no zero-fill;
+    //  * the reads are packed in chunks of ~8 Mbases by worker threads (32 bases per AVX2 step where the host has it) while
+    //    this thread sends the finished chunks, in order, with asynchronous copies: the transfer hides behind the packing.
+    uint32_t *h2, *hn;
+    { int r; if ((r = ctx_hbuf_t(ctx, "seq_stage2", w2, &h2)) != TELR_OK || (r = ctx_hbuf_t(ctx, "seq_stagen", wn, &hn)) != TELR_OK) { delete s; return r; } }
     for (size_t z = w2 - 8; z < w2; ++z) h2[z] = 0;
     for (size_t z = wn - 8; z < wn; ++z) hn[z] = 0;
-    int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
-    if (s->total_bases < (1 << 20)) nth = 1;
-    std::vector<std::thread> th;
-    for (int t = 0; t < nth; ++t) th.emplace_back([&, t]() {
-        for (int i = t; i < n; i += nth) {
-            const unsigned char *p = (const unsigned char*)ascii + off[i];
-            const int64_t b = s->boff[i];              // multiple of 64
-            const int L = len[i];
-            for (int j0 = 0; j0 < L; j0 += 64) {       // one 64-base group = 4 code words + 2 ambiguity words
-                uint32_t c[4] = { 0, 0, 0, 0 }, a[2] = { 0, 0 };
-                for (int g = 0; g < 8; ++g) {
-                    const int j = j0 + 8 * g;
-                    if (j >= L) break;
-                    uint64_t x8;
-                    if (j + 8 <= L) memcpy(&x8, p + j, 8);
-                    else { unsigned char tail[8] = { 'A', 'A', 'A', 'A', 'A', 'A', 'A', 'A' }; memcpy(tail, p + j, (size_t)(L - j)); memcpy(&x8, tail, 8); }
-                    uint32_t code16, amb8;
-                    pack8(x8, code16, amb8);
-                    c[g >> 1] |= code16 << ((g & 1) * 16);
-                    a[g >> 2] |= amb8 << ((g & 3) * 8);
-                }
-                const int64_t x = b + j0;
-                uint32_t *d2 = h2 + (x >> 4), *dn = hn + (x >> 5);
-                d2[0] = c[0]; d2[1] = c[1]; d2[2] = c[2]; d2[3] = c[3]; dn[0] = a[0]; dn[1] = a[1];
-            }
-        }
-    });
-    for (auto &t : th) t.join();
     auto fail = [&](hipError_t e) { ctx->err = std::string("seqset upload: ") + hipGetErrorString(e); telr_seqset_free(s); return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
     hipError_t e;
     if ((e = hipMalloc(&s->d_seq2, w2 * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(s->d_seq2, h2, w2 * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(s->d_nmask, hn, wn * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpy(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
-    if (n && (e = hipMemcpy(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e);
+    std::vector<int32_t> cstart(1, 0);            // chunks of consecutive reads
+    { int64_t acc = 0; for (int i = 0; i < n; ++i) { acc += ((int64_t)len[i] + 63) & ~63LL; if (acc >= (8LL << 20) && i + 1 < n) { cstart.push_back(i + 1); acc = 0; } } }
+    cstart.push_back(n);
+    const int nchunk = (int)cstart.size() - 1;
+    std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[nchunk > 0 ? nchunk : 1]);
+    for (int c = 0; c < nchunk; ++c) done[c].store(0, std::memory_order_relaxed);
+    std::atomic<int> next(0);
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("TELR_NO_AVX2");
+    int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (s->total_bases < (1 << 20)) nth = 1;
+    if (nth > nchunk) nth = nchunk > 0 ? nchunk : 1;
+    auto pack_chunk = [&](int c) {
+        for (int i = cstart[c]; i < cstart[c + 1]; ++i)
+            pack_sequence((const unsigned char*)ascii + off[i], len[i], h2 + (s->boff[i] >> 4), hn + (s->boff[i] >> 5), avx2);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < nth && nchunk > 0; ++t) th.emplace_back([&]() {
+        for (int c; (c = next.fetch_add(1)) < nchunk; ) { pack_chunk(c); done[c].store(1, std::memory_order_release); }
+    });
+    // send finished chunks in order, a few at a time (>= 16 MB of code words per copy)
+    hipError_t ce = hipSuccess;
+    { int c0 = 0;
+      while (c0 < nchunk) {
+          int c1 = c0; int64_t bases = 0;
+          while (c1 < nchunk && (bases < (64LL << 20) || c1 == c0)) {
+              while (!done[c1].load(std::memory_order_acquire)) std::this_thread::yield();
+              bases += s->boff[cstart[c1 + 1]] - s->boff[cstart[c1]]; ++c1;
+          }
+          const int64_t b0 = s->boff[cstart[c0]], b1 = s->boff[cstart[c1]];
+          if (ce == hipSuccess && b1 > b0) {
+              ce = hipMemcpyAsync(s->d_seq2 + (b0 >> 4), h2 + (b0 >> 4), (size_t)((b1 - b0) >> 4) * 4, hipMemcpyHostToDevice, ctx->stream);
+              if (ce == hipSuccess) ce = hipMemcpyAsync(s->d_nmask + (b0 >> 5), hn + (b0 >> 5), (size_t)((b1 - b0) >> 5) * 4, hipMemcpyHostToDevice, ctx->stream);
+          }
+          c0 = c1;
+      } }
+    for (auto &t : th) t.join();
+    if (ce != hipSuccess) return fail(ce);
+    if ((e = hipMemcpyAsync(s->d_seq2 + (tot >> 4), h2 + (tot >> 4), 8 * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(s->d_nmask + (tot >> 5), hn + (tot >> 5), 8 * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+    if (n && (e = hipMemcpyAsync(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e);
     *out = s;
     return TELR_OK;
 }

@@ -217,6 +217,16 @@ int  telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n_targets,
                         const int32_t *target_len, int32_t n_iv, const int32_t *iv_tid,
                         const int32_t *iv_start, const int32_t *iv_end, double *median_out);
 
+/* ---- window reads (a12) -------------------------------------------------------
+ * Replaces the per-locus `pysam.AlignmentFile(bam).fetch(chr, bp-1000, bp+1000)` loop of prep_assembly_inputs
+ * (src/telr/TELR_assembly.py:384-415, read_type="all"): for every window w = (win_tid, [win_lo, win_hi)) the ascending,
+ * distinct query ids with ANY record (primary, secondary, supplementary) overlapping it: ts < win_hi and te > win_lo.
+ * recs: any array of records (telr_result_alns of the stage-1 result, or records put together by the caller).  Host
+ * code, no device needed.  out_off[n_win+1]; the ids of window w are out_qid[out_off[w] .. out_off[w+1]).  *needed =
+ * total number of ids; when it exceeds cap nothing is copied and TELR_E_RANGE is returned: call again with cap >= *needed. */
+int  telr_window_reads(const telr_aln *recs, int64_t n_rec, int32_t n_win, const int32_t *win_tid, const int32_t *win_lo,
+                       const int32_t *win_hi, int64_t *out_off, int32_t *out_qid, int64_t cap, int64_t *needed);
+
 /* ---- timing of the last telr_map / telr_index_build call (HIP events on the
  *      engine's own stream).  Stage names: telr_stage_name(i). ---------------- */
 #define TELR_N_STAGES 16

@@ -15,7 +15,7 @@ EXPORTS = [
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
-    "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_depth_medians", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
+    "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
 _lib = None
@@ -56,6 +56,7 @@ def lib():
     L.telr_result_free.restype = None; L.telr_result_free.argtypes = [vp]
     L.telr_depth_medians.restype = C.c_int
     L.telr_depth_medians.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    L.telr_window_reads.restype = C.c_int; L.telr_window_reads.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i64, vp]
     L.telr_write_paf.restype = C.c_int; L.telr_write_paf.argtypes = [vp, vp, vp, C.c_int, cp, C.c_int]
     L.telr_write_sam.restype = C.c_int
     L.telr_write_sam.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, cp, cp, cp, cp, cp]

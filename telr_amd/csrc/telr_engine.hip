@@ -2169,6 +2169,67 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
 }
 
 // ---------------------------------------------------------------------------------------
+// Window reads (the `read_type="all"` selection of prep_assembly_inputs, TELR_assembly.py:384-415): for every window
+// (target id, [lo, hi)) the ascending, distinct query ids with ANY record -- primary, secondary or supplementary --
+// that overlaps it (ts < hi and te > lo).  The reference runs one pysam fetch per locus on the sorted stage-1 BAM; here
+// the records are still in memory (any telr_aln array: a result's, or records gathered from several).  Host code: one
+// pass over the records by the worker pool, windows sorted by (target, lo) with a running maximum of hi so that a
+// record stops scanning at the first window that cannot reach it.
+extern "C" int telr_window_reads(const telr_aln *recs, int64_t n_rec, int32_t n_win, const int32_t *win_tid, const int32_t *win_lo, const int32_t *win_hi,
+                                 int64_t *out_off, int32_t *out_qid, int64_t cap, int64_t *needed)
+{
+    if (n_rec < 0 || n_win < 0 || (n_rec > 0 && !recs) || (n_win > 0 && (!win_tid || !win_lo || !win_hi)) || !out_off || !needed || cap < 0 || (cap > 0 && !out_qid)) return TELR_E_ARG;
+    if (n_rec >= (1LL << 31)) return TELR_E_RANGE;
+    std::vector<int32_t> ord(n_win);
+    for (int i = 0; i < n_win; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { const int32_t la = win_lo[a] > 0 ? win_lo[a] : 0, lb = win_lo[b] > 0 ? win_lo[b] : 0;
+        return win_tid[a] != win_tid[b] ? win_tid[a] < win_tid[b] : la != lb ? la < lb : a < b; });
+    std::vector<int64_t> key(n_win); std::vector<int32_t> hmax(n_win), hi(n_win);
+    for (int j = 0; j < n_win; ++j) {
+        const int w = ord[j];
+        key[j] = (int64_t)win_tid[w] << 32 | (uint32_t)(win_lo[w] > 0 ? win_lo[w] : 0); hi[j] = win_hi[w];
+        hmax[j] = (j > 0 && win_tid[ord[j - 1]] == win_tid[w] && hmax[j - 1] > hi[j]) ? hmax[j - 1] : hi[j];      // per target
+    }
+    const int NT = host_threads();
+    std::vector<std::vector<uint64_t>> part(NT);           // (sorted window << 32 | qid), in record order inside a part
+    parallel_ranges(NT, (int)n_rec, [&](int t, int a, int b) {
+        std::vector<uint64_t> &P = part[t];
+        for (int x = a; x < b; ++x) {
+            const telr_aln &r = recs[x];
+            if (r.tid < 0) continue;
+            // windows of the record's target starting before its end: [.., j1)
+            const int64_t k = (int64_t)r.tid << 32 | (uint32_t)r.te;
+            int j1 = (int)(std::lower_bound(key.begin(), key.end(), k) - key.begin());
+            for (int j = j1 - 1; j >= 0 && (key[j] >> 32) == r.tid && hmax[j] > r.ts; --j)
+                if (hi[j] > r.ts) P.push_back((uint64_t)j << 32 | (uint32_t)r.qid);
+        }
+    });
+    // per window: count, place (parts in record order), then sort + unique the (short) lists
+    std::vector<int64_t> cnt((size_t)n_win + 1, 0);
+    for (int t = 0; t < NT; ++t) for (uint64_t v : part[t]) ++cnt[(size_t)(v >> 32) + 1];
+    for (int j = 0; j < n_win; ++j) cnt[j + 1] += cnt[j];
+    std::vector<int32_t> all((size_t)cnt[n_win]);
+    { std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+      for (int t = 0; t < NT; ++t) for (uint64_t v : part[t]) all[(size_t)fill[v >> 32]++] = (int32_t)(uint32_t)v; }
+    std::vector<int64_t> uniq(n_win, 0);
+    parallel_ranges(NT, n_win, [&](int, int a, int b) {
+        for (int j = a; j < b; ++j) {
+            int32_t *f = all.data() + cnt[j], *l = all.data() + cnt[j + 1];
+            std::sort(f, l);
+            uniq[j] = std::unique(f, l) - f;
+        }
+    });
+    std::vector<int64_t> len_of(n_win, 0), src_of(n_win, 0);
+    for (int j = 0; j < n_win; ++j) { len_of[ord[j]] = uniq[j]; src_of[ord[j]] = cnt[j]; }
+    out_off[0] = 0;
+    for (int w = 0; w < n_win; ++w) out_off[w + 1] = out_off[w] + len_of[w];
+    *needed = out_off[n_win];
+    if (*needed > cap) return TELR_E_RANGE;             // the caller retries with *needed
+    for (int w = 0; w < n_win; ++w) if (len_of[w]) memcpy(out_qid + out_off[w], all.data() + src_of[w], (size_t)len_of[w] * 4);
+    return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // debug taps for the stage-level parity tests (last batch of the last telr_map call)
 extern "C" int64_t telr_debug_dp_retries(const telr_ctx *ctx) { return ctx ? ctx->dp_retries : 0; }
 extern "C" int64_t telr_debug_pk_launches(const telr_ctx *ctx) { return ctx ? ctx->pk_launches : 0; }

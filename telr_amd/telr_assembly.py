@@ -24,27 +24,37 @@ def breakpoint(start, end):
 
 def window_reads(alns, chrom_ids, loci, window=1000):
     """alns: record array of telr_map (fields qid, tid, ts, te); chrom_ids: {chromosome name: target id};
-    loci: rows of the vcf table (chr, start, end, ...).  -> list of sorted unique read-index arrays."""
-    tid = np.ascontiguousarray(alns["tid"], np.int64); ts = np.ascontiguousarray(alns["ts"], np.int64)
-    te = np.ascontiguousarray(alns["te"], np.int64); qid = np.ascontiguousarray(alns["qid"], np.int64)
-    order = np.lexsort((ts, tid))
-    tid_s, ts_s, te_s, qid_s = tid[order], ts[order], te[order], qid[order]
-    max_span = int((te_s - ts_s).max()) if len(ts_s) else 0            # no record reaches further back than this
-    c_of = np.array([chrom_ids.get(row[0], -1) for row in loci], np.int64)
+    loci: rows of the vcf table (chr, start, end, ...).  -> list of sorted unique read-index arrays.
+
+    One call of the library's host routine `telr_window_reads` over the record array in place (the stage-1 records of a
+    30x run are ~50 MB: no per-field copies, no sort of the records)."""
+    import ctypes as C
+    from . import _lib
+    from ._abi import ALN_DTYPE
+    n = len(loci)
+    c_of = np.array([chrom_ids.get(row[0], -1) for row in loci], np.int32)
     bp = np.array([breakpoint(row[1], row[2]) for row in loci], np.int64)
-    s_of, e_of = np.maximum(0, bp - window), bp + window
-    lo_c = np.searchsorted(tid_s, c_of, side="left"); hi_c = np.searchsorted(tid_s, c_of, side="right")
-    out = []
-    for i in range(len(loci)):
-        lo, hi = int(lo_c[i]), int(hi_c[i])
-        if hi <= lo or c_of[i] < 0:
-            out.append(np.zeros(0, np.int64)); continue
-        seg = ts_s[lo:hi]
-        k = lo + int(np.searchsorted(seg, e_of[i], side="left"))               # records starting before the window's end ...
-        k0 = lo + int(np.searchsorted(seg, s_of[i] - max_span, side="left"))   # ... and not too far left to reach its start
-        m = te_s[k0:k] > s_of[i]
-        out.append(np.unique(qid_s[k0:k][m]))
-    return out
+    lo = np.maximum(0, bp - window).astype(np.int32); hi = (bp + window).astype(np.int32)
+    if n == 0:
+        return []
+    if alns.dtype != ALN_DTYPE or not alns.flags["C_CONTIGUOUS"]:      # records from elsewhere (a BAM, a test): the four fields suffice
+        full = np.zeros(len(alns), ALN_DTYPE)
+        for f in ("qid", "tid", "ts", "te"):
+            full[f] = alns[f]
+        alns = full
+    L = _lib.lib()
+    off = np.zeros(n + 1, np.int64); need = C.c_int64(0)
+    cap = max(1024, 96 * n)
+    while True:
+        qid = np.empty(cap, np.int32)
+        rc = L.telr_window_reads(alns.ctypes.data, len(alns), n, c_of.ctypes.data, lo.ctypes.data, hi.ctypes.data, off.ctypes.data, qid.ctypes.data, cap, C.byref(need))
+        if rc == 0:
+            break
+        if need.value <= cap:
+            raise _lib.TelrError("telr_window_reads: " + L.telr_strerror(rc).decode())
+        cap = int(need.value)
+    qid = qid[:need.value].astype(np.int64)
+    return [qid[off[i]:off[i + 1]] for i in range(n)]
 
 
 def annotate_vcf_with_counts(loci, reads_per_locus):

@@ -39,3 +39,25 @@ def test_new_table_text():
     got = ta.window_reads(al, chrom_ids, G["vcf_rows"])
     rows = ta.annotate_vcf_with_counts(G["vcf_rows"], got)
     assert "".join("\t".join(r) + "\n" for r in rows) == G["expected_new_table"]
+
+
+def test_window_reads_against_the_definition_on_random_records():
+    """every read with ANY record overlapping [bp-1000, bp+1000) on the locus chromosome (TELR_assembly.py:384-415), checked
+    record by record: duplicate loci, loci on unknown chromosomes, windows clipped at 0, windows sharing reads"""
+    import numpy as np
+    from telr_amd import telr_assembly
+    rng = np.random.default_rng(8)
+    n = 5000
+    al = np.zeros(n, dtype=[("qid", np.int32), ("tid", np.int32), ("ts", np.int32), ("te", np.int32)])
+    al["qid"] = rng.integers(0, 700, n); al["tid"] = rng.integers(0, 3, n)
+    al["ts"] = rng.integers(0, 60000, n); al["te"] = al["ts"] + rng.integers(1, 9000, n)
+    chrom_ids = {"a": 0, "b_x": 1, "c": 2}
+    loci = [("a", 300, 400), ("a", 300, 400), ("b_x", 20000, 20001), ("zz", 5, 9), ("c", 59000, 61000), ("a", 1500, 1502), ("b_x", 20500, 20900)]
+    loci += [(("a", "b_x", "c")[int(rng.integers(0, 3))], int(s), int(s) + int(rng.integers(0, 50))) for s in rng.integers(0, 62000, 60)]
+    got = telr_assembly.window_reads(al, chrom_ids, loci)
+    assert len(got) == len(loci)
+    for (ch, s, e), g in zip(loci, got):
+        bp = telr_assembly.breakpoint(s, e); lo, hi = max(0, bp - 1000), bp + 1000
+        want = sorted({int(r["qid"]) for r in al if r["tid"] == chrom_ids.get(ch, -1) and r["ts"] < hi and r["te"] > lo})
+        assert list(map(int, g)) == want, (ch, s, e)
+    assert telr_assembly.window_reads(al[:0], chrom_ids, loci)[0].size == 0 and telr_assembly.window_reads(al, chrom_ids, []) == []

@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
     ap.add_argument("--data-cache", default="", help="directory: the rank's generated data set is stored there / loaded from there (profiling runs: no forked generator)")
     ap.add_argument("--one-gpu", action="store_true", help="smoke test of the N>1 code path on a 1-GPU box: every rank uses device 0 (use with --backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--force-exchange", action="store_true", help="run the N>1 code path of the loci leg (window-read all-to-all, pooled read set, all-gather) at world size 1 too: under torch.distributed.run on a 1-GPU box this drives the collectives through RCCL on device tensors")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
     return ap.parse_args()
 
@@ -180,6 +181,12 @@ def main():
         sys.exit(launch_ranks(a))
     cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries the ONE JSON line and nothing else: libraries write banners to file descriptor 1 (RCCL prints its
+    # version block there when the communicator is created, gloo its own), so the descriptor is pointed at stderr for the
+    # duration of the run and the line goes out through a private copy of the original
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     local = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     # ranks of one node share its CPUs: each engine sizes its host pool for its share (the library's default is 1.5 x the
     # CPUs the process may use, which every rank would claim for itself)
@@ -195,7 +202,7 @@ def main():
             torch.cuda.set_device(local); t = t.cuda()
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": int(t.item()), "backend": a.backend}))
+            json_out.write(json.dumps({"dry_launch": True, "n_gpus": world, "rank_sum": int(t.item()), "backend": a.backend}) + "\n"); json_out.flush()
         dist.destroy_process_group()
         return
     import numpy as np
@@ -331,7 +338,7 @@ def main():
             # a12: every read with ANY stage-1 record overlapping [bp-1000, bp+1000) (TELR_assembly.py:384-415), from the
             # records of the last step (this rank's reads)
             wr = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])
-            if world == 1:
+            if world == 1 and not (a.force_exchange and dist is not None):
                 for l, idx in zip(loci, wr):
                     l["read_idx"] = idx.astype(np.int32)
                 return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, shards=shards,
@@ -382,7 +389,7 @@ def main():
         wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]
         loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
                     "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0,
-                    "collectives": "none" if world == 1 else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
+                    "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
                     "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
                             "truth-derived stand-ins for wtdbg2 / Sniffles (absent on the box)"}
     if rank != 0:
@@ -449,7 +456,7 @@ def main():
         ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(D["reads"][2]))))   # ~15-20 s of CPU work
         out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
-    print(json.dumps(out))
+    json_out.write(json.dumps(out) + "\n"); json_out.flush()
     sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()

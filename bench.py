@@ -9,7 +9,8 @@ reads 13 % 1:5:4, the NGMLR-style convex-gap preset `ngmlr-pacbio`), `c4` = conf
 leading N block, 50x, 1,300-family library, 3,000 insertions).
 
 A "step" = one pass of the stage-1 hot path (sketch -> seed -> sort -> chain -> back-track -> banded DP + trace-back ->
-records/CIGARs on the host) over the rank's WHOLE read set, which the engine streams through in ranges of <= 1 Gbp.
+records/CIGARs on the host) over the rank's WHOLE read set, which the engine streams through in ranges of <= 2 Gbp
+(sized by the anchor density seen so far).
 Index and packed reads are resident in HBM before the timed region (`value`); `value_incl_h2d` adds the packing +
 upload of the reads.  The second half of the metric, TE loci/s, runs the per-locus bundle (S4, S5, S6 fw+rc + depth +
 AF, S7 x2 + liftover) on window reads selected from the ENGINE'S OWN stage-1 records (TELR_assembly.py:384-415).
@@ -366,7 +367,7 @@ def main():
         if prof is not None:
             import pstats
             prof.disable()
-            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(40)
+            st = pstats.Stats(prof, stream=sys.stderr); st.sort_stats("cumulative").print_stats(40); st.sort_stats("tottime").print_stats(25)
         if dist is not None:
             t = torch.tensor([t_loci], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_loci = float(t[0])
         good = 0; af_ok = 0; n_rows = len(rows)
@@ -433,7 +434,7 @@ def main():
                    "reads_this_rank": int(len(D["reads"][2])), "read_bases_this_rank": n_bases, "read_bases_job": job_bases,
                    "parallelism": ("one fixed read set dealt to %d ranks in blocks by cumulative bases" % world if a.scaling == "strong" else "every rank maps its own read set (x%d)" % world)
                                   + "; index replicated (built by every rank, no broadcast); no collective on the stage-1 data path",
-                   "ranges": "the engine streams the rank's read set through in ranges of <= 1 Gbp (one telr_map call per step)",
+                   "ranges": "the engine streams the rank's read set through in ranges of <= 2 Gbp, at most 1.6 G anchors at the density seen so far (one telr_map call per step)",
                    "streaming": "telr_map returns with the records; the CIGAR DMA of step k overlaps step k+1 (all complete inside the timed region)"},
         "per_rank_ms_per_step": per_rank_ms, "rccl_world_size": world if dist is not None else 0,
         "roofline": {"bound": "hbm", "kernel": k_name, "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

@@ -623,6 +623,7 @@ struct telr_index {
     // per-target occurrence statistics (built on first use): runs = (minimizer, target) pairs, keys = target<<32 | count sorted
     mutable uint64_t *d_pt_keys = nullptr; mutable int32_t *d_pt_off = nullptr, *d_pt_mid = nullptr; mutable int32_t pt_runs = -1;
     mutable float pt_frac = -1.f; mutable int32_t pt_lo = -1, pt_hi = -1;
+    mutable double anchors_per_base = 0;  // seen by the last telr_map call on this index (0 = none yet): sizes the first range of the next call
 };
 
 extern "C" void telr_index_free(telr_index *ix)
@@ -2047,9 +2048,13 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
     if (nsub > nq) nsub = nq > 0 ? nq : 1;
     if (nsub == 1) {
-        // ranges bounded by bases (HBM is 288 GB: one range holds up to ~1 Gbp of reads, scratch ~80 B per base); a read
-        // set of any size streams through as consecutive ranges, each with its own long-read lane
-        int64_t batch_bases = 1024LL << 20;
+        // Ranges bounded by bases: a read set of any size streams through as consecutive ranges, each with its own long-read
+        // lane.  HBM is 288 GB and a range needs ~75 B of scratch per read base at 0.25 anchors per base, so a range holds up
+        // to 2 Gbp (configs[2]: 14.9 Gbp/s with 1-Gbp ranges, 15.3 with 1.4, 15.5 with 2.1 -- fewer synchronisation points and
+        // tails; 151 GB in use).  What really bounds a range is its anchors (int32 offsets, ~50 B each): after the first range
+        // the next ones -- and the first range of the next call on the same index -- are sized for at most 1.6 G anchors at
+        // the density seen so far; a first range that overflows is halved by map_range.
+        int64_t batch_bases = 2048LL << 20;
         bool fixed = false;
         if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) { batch_bases = (int64_t)v << 20; fixed = true; } }
         if (const char *e = getenv("TELR_BATCH_KBP")) { long v = atol(e); if (v > 0) { batch_bases = (int64_t)v << 10; fixed = true; } }     // tests
@@ -2103,9 +2108,18 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
               for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
               ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches; }
         } else {
-            for (auto &rg : ranges) {
-                int r = map_range(ctx, ix, queries, qtarget, d_qt, rg.first, rg.second, mo, mid_occ, R);
+            auto limit_for = [&](double per_base) { return std::min<int64_t>(batch_bases, std::max<int64_t>(256LL << 20, (int64_t)(1.6e9 / per_base))); };
+            int64_t limit = !fixed && ix->anchors_per_base > 0 ? limit_for(ix->anchors_per_base) : batch_bases;
+            for (int32_t q0 = 0; q0 < nq; ) {
+                int32_t q1 = q0; int64_t b = 0;
+                while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= limit)) { b += queries->len[q1]; ++q1; }
+                int r = map_range(ctx, ix, queries, qtarget, d_qt, q0, q1, mo, mid_occ, R);
                 if (r != TELR_OK) { delete R; return r; }
+                if (ctx->ctr.anchors > 0 && ctx->ctr.query_bases > (64LL << 20)) {
+                    ix->anchors_per_base = (double)ctx->ctr.anchors / (double)ctx->ctr.query_bases;
+                    if (!fixed) limit = limit_for(ix->anchors_per_base);
+                }
+                q0 = q1;
             }
         }
     } else {

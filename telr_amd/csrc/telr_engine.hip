@@ -1912,7 +1912,23 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         const char *e = getenv("TELR_LONGSPLIT");
         const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "0");
         if (!off && !ctx->is_child && nq >= 2 && (force || (!ctx->debug && nq >= 2000 && total_bases >= 100000000LL))) {
-            const int32_t thr = std::max(max_len / 3, force ? 0 : 30000);
+            // Which reads go to the lane.  A range with far more reads than the device holds waves (>= 64 k reads): the longest
+            // reads holding ~10 % of the bases (configs[2], lengths log-normal around 9 kb, 230 k reads per range: reads above
+            // 50 / 40 / 25 / 20 / 15 kb in the lane -> 14.9 / 15.2 / 15.5 / 15.4 / 15.2 Gbp/s; 25 kb = 8 % of the bases), when
+            // they stand out (twice the mean length: uniform lengths have no tail to hide).  Fewer reads (configs[1]: 10 k
+            // reads of 47 kb, barely one wave per SIMD slot): only the very longest, a third of the maximum and up (a 10 % lane
+            // there costs 15 %: two half-empty pipelines).
+            int32_t thr = std::max(max_len / 3, force ? 0 : 30000);
+            if (!force && nq >= 65536) {
+                const int nb = (max_len >> 8) + 1;
+                std::vector<int64_t> hist((size_t)nb, 0);
+                for (int i = q0; i < q1; ++i) hist[queries->len[i] >> 8] += queries->len[i];
+                int64_t acc = 0; int b = nb - 1;
+                for (; b > 0; --b) { acc += hist[b]; if (acc * 10 >= total_bases) break; }
+                const int64_t mean = total_bases / nq;
+                if ((int64_t)b << 8 >= 2 * mean && (b << 8) < thr) thr = b << 8;
+            }
+            if (e && atoi(e) >= 1000) thr = atoi(e);          // experiments: the length above which a read goes to the long-read lane
             int64_t long_bases = 0;
             for (int i = q0; i < q1; ++i) { const int k = queries->len[i] > thr ? 1 : 0; lane_idx[k].push_back(i); if (k) long_bases += queries->len[i]; }
             lane = !lane_idx[0].empty() && !lane_idx[1].empty() && (force || long_bases * 100 <= total_bases * 35);

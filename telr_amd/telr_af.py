@@ -67,6 +67,11 @@ def combine_af(te_5p_cov, flank_5p_cov, te_5p_cov_rc, flank_5p_cov_rc):
     return round(freq, 3) if freq else None
 
 
+_COMP_NP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTUNacgtun", b"TGCAANtgcaan"):
+    _COMP_NP[_a] = _b
+
+
 def locus_intervals(start, end, contig_length, flank_interval, flank_offset, te_interval, te_offset):
     """The 8 depth queries of one locus: forward then reverse-complement, each te_5p, te_3p, flank_5p, flank_3p."""
     out = {}
@@ -105,28 +110,41 @@ def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_inte
     Returns {locus name: te_freq dict}.
     """
     from .presets import preset
-    from .fasta import revcomp
     io, mo = preset("map-ont" if presets == "ont" else "map-pb")
     names = [n for n in contig_te if n in contigs and n in reads_by_locus]
     if not names:
         return {}
-    targets, tindex = [], {}
-    for n in names:
-        tindex[n] = len(targets)
-        targets.append(contigs[n])
-        targets.append(revcomp(contigs[n]))
-    ix = engine.index(targets, io)
-    queries, qtarget_fw, qtarget_rc = [], [], []
-    for n in names:
-        for r in reads_by_locus[n]:
-            queries.append(r)
-            qtarget_fw.append(tindex[n]); qtarget_rc.append(tindex[n] + 1)
+    # targets: contig k forward at 2k, reverse-complemented at 2k+1, as ONE byte buffer.  The reverse complement of the
+    # concatenation of all contigs is the concatenation of their reverse complements in reverse order: one table lookup and
+    # one reversal for the whole set instead of a translate + slice + decode per contig
+    tindex = {n: 2 * k for k, n in enumerate(names)}
+    fw = [contigs[n].encode() if isinstance(contigs[n], str) else bytes(contigs[n]) for n in names]
+    lens = np.array([len(b) for b in fw], np.int64)
+    cat = np.frombuffer(b"".join(fw), np.uint8)
+    rc_cat = _COMP_NP[cat][::-1]
+    ends = np.cumsum(lens); starts = ends - lens; total = int(ends[-1])
+    tlen = np.repeat(lens, 2)
+    toff = np.zeros(2 * len(names), np.int64); toff[1:] = np.cumsum(tlen)[:-1]
+    tbuf = np.empty(2 * total, np.uint8)
+    for k in range(len(names)):
+        L = int(lens[k]); o = int(toff[2 * k])
+        tbuf[o:o + L] = cat[starts[k]:ends[k]]
+        tbuf[o + L:o + 2 * L] = rc_cat[total - ends[k]:total - starts[k]]
+    ix = engine.index((tbuf, toff, tlen.astype(np.int32)), io)
+    counts = np.array([len(reads_by_locus[n]) for n in names], np.int64)
+    qtarget_fw = np.repeat(np.arange(len(names), dtype=np.int32) * 2, counts)
     # ONE engine call for both orientations: every read appears twice, once confined to the forward contig of its locus
     # and once to the reverse-complement contig (the reference runs two minimap2 jobs per locus, TELR_te.py:644-646)
-    qs = read_set.subset(list(queries) + list(queries)) if read_set is not None else engine.seqset(list(queries) + list(queries))
+    if read_set is not None:
+        idx = np.concatenate([np.asarray(reads_by_locus[n], np.int32) for n in names]) if len(names) else np.zeros(0, np.int32)
+        qs = read_set.subset(np.concatenate([idx, idx]))
+    else:
+        queries = [r for n in names for r in reads_by_locus[n]]
+        qs = engine.seqset(queries + queries)
+    qtarget_all = np.concatenate([qtarget_fw, qtarget_fw + 1])
     out = {}
     meds = {n: {"fw": [None, None, None, None], "rc": [None, None, None, None]} for n in names}
-    r = ix.map_raw(qs, mo, qtarget=np.array(qtarget_fw + qtarget_rc, np.int32))
+    r = ix.map_raw(qs, mo, qtarget=qtarget_all)
     try:
         iv_t, iv_s, iv_e, slots = [], [], [], []
         for tag in ("fw", "rc"):

@@ -14,6 +14,9 @@ class _Targets(object):
 
 class OracleIndexAdapter(object):
     def __init__(self, seqs, io):
+        if isinstance(seqs, tuple) and len(seqs) == 3:          # (byte buffer, offsets, lengths), as the engine's SeqSet takes it
+            buf, off, ln = seqs
+            seqs = [bytes(buf[int(o):int(o) + int(l)]) for o, l in zip(off, ln)]
         seqs = [s if isinstance(s, str) else bytes(s).decode() for s in seqs]
         self.ix = ob.OracleIndex(seqs, io)
         self.targets = _Targets(seqs)

@@ -1,0 +1,37 @@
+"""The driver's contract on `bench.py` (one JSON line on stdout, the keys it reads, the two added objects), checked on a
+reduced configs[1]-shaped workload so that the whole run takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "c1", "--genome-len", "3000000",
+           "--reads", "1500", "--read-bases", "60000000", "--insertions", "30", "--cpu-sample-reads", "40"]
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:5]                       # nothing but the line (library banners go to stderr)
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "value_incl_h2d", "te_loci_per_s"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "Gbp/s" and d["value"] > 0.05 and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    whole = d["config"]["read_bases_this_rank"] / (d["ms_per_step"] * 1e-3) / 1e9          # every base of every read, per second
+    assert 0.8 * whole <= d["value"] <= 1.001 * whole                                          # value counts the bases of reads with a primary record
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+    assert d["value_incl_h2d"] <= d["value"] and d["te_loci"]["n"] == 30

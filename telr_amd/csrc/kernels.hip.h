@@ -1441,6 +1441,15 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
     }
     return D <= 64 ? 0 : D <= 128 ? 1 : D <= 256 ? 2 : D <= 1024 ? 3 : 4;
 }
+// Four bits per cell.  The one-piece cell (classes 17 and 10 when the preset's gap costs allow it: d_cell_pk) has three
+// sources and two extension flags -- a nibble -- once the "bases equal" bit is gone, and that bit is not needed: with one
+// affine piece and no ambiguous base the number of matching columns follows from the score of the path,
+// a * match - b * (M columns - match) - sum over gap runs (q + e * length) = score.  Row k (anti-diagonals 2k, 2k+1) of
+// register r is one 16-bit word {even step: low nibbles, odd step: high nibbles} x {low-half diagonal, high-half
+// diagonal}; a row is ceil(R/2) dwords, a row PAIR a whole number of 8-byte units of the wave-interleaved layout.
+__host__ __device__ __forceinline__ int d_onep_d(int q, int e, int q2, int e2) { return e > e2 ? (q2 - q + (e - e2) - 1) / (e - e2) : 1 << 20; }
+__host__ __device__ __forceinline__ bool d_tb4(int cls, int tb4) { return (cls == 17 && (tb4 & 1)) || (cls == 10 && (tb4 & 2)); }
+__host__ __device__ __forceinline__ int d_tb4_rowb(int cls) { return cls == 17 ? 8 : 12; }       // bytes per row: 4 * ceil(R / 2)
 // dwords per packed trace-back row
 __device__ __forceinline__ int d_cls_slots(int cls)
 {
@@ -1464,7 +1473,7 @@ __device__ __forceinline__ bool d_any_n(const uint32_t *__restrict__ nmask, int6
 }
 __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_margin, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
                              const uint32_t *__restrict__ qnmask, const uint32_t *__restrict__ tnmask,
-                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops)
+                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
@@ -1478,6 +1487,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
     }
     int64_t tb;
     if (P.kind >= 3) tb = 0;
+    else if (d_tb4(cls, tb4)) tb = ((int64_t)(((P.m + P.n) / 2 + 2) / 2) * (2 * d_tb4_rowb(cls)) + 63) & ~63LL;     // row pairs of nibbles
     else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 63) & ~63LL;     // whole 64-byte lines (d_traceback_rows)
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
@@ -1586,6 +1596,7 @@ struct DpArgs {
     uint8_t *tb; uint32_t *cig; DpRes *res;
     int32_t dcap;            // diagonals of LDS state per wave (LDS kernel)
     int32_t *retry;
+    int32_t tb4;             // bit 0: class 17, bit 1: class 10 spill 4 bits per cell (one-piece cell only; d_tb4)
 };
 
 __device__ __forceinline__ int64_t d_wave_max64(int64_t v)
@@ -2004,6 +2015,25 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     return t | src;
 }
 
+// The one-piece cell with its flags in a nibble (d_tb4): sources 0 / 1 / 2 in bits SH, SH+1, the E1 / F1 extension flags in
+// bits SH+2, SH+3; SH = 0 on even steps, 4 on odd steps, so that OR-ing the two steps of a row gives one byte per diagonal.
+// No "bases equal" bit: the walk derives the matching columns from the score.
+template <int SH>
+__device__ __forceinline__ uint32_t d_cell_pk4(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t e1l, uint32_t hu, uint32_t f1u,
+                                               uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve1, uint32_t &vf1)
+{
+    uint32_t op, g, t;
+    op = pk_sub(hl, c.qe); g = pk_sub(e1l, c.e); ve1 = pk_max(op, g); t  = pk_sign(pk_sub(op, g)) & (0x00040004u << SH);
+    op = pk_sub(hu, c.qe); g = pk_sub(f1u, c.e); vf1 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & (0x00080008u << SH);
+    const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
+    const uint32_t sc = pk_sub(eq & c.ab, c.b);
+    h = pk_add(hd, sc);
+    uint32_t m, src;
+    m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & (0x00010001u << SH);
+    m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = pk_sel(m, 0x00020002u << SH, src);
+    return t | src;
+}
+
 // Lane l of a problem owns the 4R consecutive diagonals dlo+4R*l .. dlo+4R*l+4R-1 as R packed register pairs:
 // register r holds {low half: diagonal de0+4r, high half: de0+4r+2} in the "even" set and {+1, +3} in the "odd" set.
 // Every register of a lane advances two cells with one packed instruction sequence and the per-step costs (loop
@@ -2067,10 +2097,11 @@ __device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dh
 // through `xch` (LDS, [2][NW][3]) with one barrier per step, everything else is unchanged.
 // FULL: the first FULL registers of a lane are inside the band for every problem of the class (classes are cut so that
 // only the last register can straddle dhi), so they need no out-of-band masks.
-template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false>
+template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false, bool TB4 = false>
 __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob, uint32_t *xch = nullptr)
 {
     static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
+    static_assert(!TB4 || (ONEP && LPP == 1 && !EXT), "nibble spill: one-piece cell, one problem per lane");
     constexpr int RW = LPP * R;
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
     const int wv = NW > 1 ? lane >> 6 : 0, wl = lane & 63;
@@ -2149,7 +2180,8 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 // left neighbour: odd diagonal below -> {low: previous register's high half, high: own low half}
                 const uint32_t lh = r ? Ho[r - 1] : ph, le1 = r ? E1o[r - 1] : pe1, le2 = r ? E2o[r - 1] : pe2;
                 const uint32_t hl = __builtin_amdgcn_alignbit(Ho[r], lh, 16), e1l = __builtin_amdgcn_alignbit(E1o[r], le1, 16), e2l = __builtin_amdgcn_alignbit(E2o[r], le2, 16);
-                te[r] = d_cell_pk<ONEP>(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                if constexpr (TB4) { te[r] = d_cell_pk4<0>(c, He[r], hl, e1l, Ho[r], F1o[r], qb[r], tbv[r], h, ve1, vf1); ve2 = PK_NEG; vf2 = PK_NEG; }
+                else te[r] = d_cell_pk<ONEP>(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { He[r] = h; F1e[r] = vf1; F2e[r] = vf2; }
                 else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]); }
                 E1e[r] = ve1; E2e[r] = ve2;
@@ -2191,11 +2223,13 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 // up neighbour: even diagonal above -> {low: own high half, high: next register's low half}
                 const uint32_t uh = r < R - 1 ? He[r + 1] : nh, uf1 = r < R - 1 ? F1e[r + 1] : nf1, uf2 = r < R - 1 ? F2e[r + 1] : nf2;
                 const uint32_t hu = __builtin_amdgcn_alignbit(uh, He[r], 16), f1u = __builtin_amdgcn_alignbit(uf1, F1e[r], 16), f2u = __builtin_amdgcn_alignbit(uf2, F2e[r], 16);
-                const uint32_t t = d_cell_pk<ONEP>(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                uint32_t t;
+                if constexpr (TB4) { t = d_cell_pk4<4>(c, Ho[r], He[r], E1e[r], hu, f1u, qb[r], tbv[r], h, ve1, vf1); ve2 = PK_NEG; vf2 = PK_NEG; }
+                else t = d_cell_pk<ONEP>(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { Ho[r] = h; F1o[r] = vf1; F2o[r] = vf2; }
                 else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]); }
                 E1o[r] = ve1; E2o[r] = ve2;
-                row[r] = __builtin_amdgcn_perm(t, te[r], 0x06040200u);
+                row[r] = TB4 ? (te[r] | t) : __builtin_amdgcn_perm(t, te[r], 0x06040200u);
             }
             if (!EXT && a >= amin) {
 #pragma unroll
@@ -2213,7 +2247,39 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 }
                 prev_cur = cur;
             }
-            if constexpr (LPP == 1 && !EXT) {
+            if constexpr (TB4) {
+                // nibble rows (d_tb4): register pairs -> dwords {r: low-half byte, high-half byte, r+1: ...}; rows k-1 / k leave
+                // together as RW4 8-byte units of the wave-interleaved layout (unit u of this lane at tb32 + u*128 dwords)
+                constexpr int RW4 = (R + 1) / 2;
+                uint32_t rq[RW4];
+#pragma unroll
+                for (int j = 0; j < RW4; ++j) rq[j] = __builtin_amdgcn_perm(2 * j + 1 < R ? row[2 * j + 1] : 0u, row[2 * j], 0x06040200u);
+                uint32_t sq[2 * RW4 + 1];
+                if (k & 1) {
+#pragma unroll
+                    for (int j = 0; j < RW4; ++j) { sq[j] = prow[j]; sq[RW4 + j] = rq[j]; }
+                    sq[2 * RW4] = 0;
+                    uint32_t *dst = tb32 + (int64_t)((k - 1) / 2 * RW4) * 128;
+                    if (k <= last_row) {
+#pragma unroll
+                        for (int u = 0; u < RW4; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                    } else if (k - 1 <= last_row) {
+#pragma unroll
+                        for (int u = 0; u < (RW4 + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RW4; ++j) prow[j] = rq[j];
+                    if (2 * (k + 1) > amax && k <= last_row) {        // last trip of the wave: nothing will pair with this row
+#pragma unroll
+                        for (int j = 0; j < RW4; ++j) sq[j] = rq[j];
+                        sq[RW4] = 0;
+                        uint32_t *dst = tb32 + (int64_t)(k / 2 * RW4) * 128;
+#pragma unroll
+                        for (int u = 0; u < (RW4 + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                    }
+                }
+            } else if constexpr (LPP == 1 && !EXT) {
                 // one lane owns whole rows, and rows k-1 / k are adjacent: they leave as R 8-byte units of the wave-interleaved
                 // layout (k_tb_gather): unit u of this lane at tb32 + u*128 dwords, so each store instruction of the wave
                 // writes 512 contiguous bytes
@@ -2308,9 +2374,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     const int32_t *list = cls_list + off.off[cls];
     const int n = off.off[cls + 1] - off.off[cls];
     // widest band in which the second affine piece can never pay (see d_cell_pk): (D - 1)(e - e2) < q2 - q
-    const int onep_d = A.o.e > A.o.e2 ? (A.o.q2 - A.o.q + (A.o.e - A.o.e2) - 1) / (A.o.e - A.o.e2) : 1 << 20;
-    if (cls == 17 && onep_d >= 16) { d_dp_pkr<1, 4, false, 1, 0, true>(A, list, n, first); return; }
-    if (cls == 10 && onep_d >= 20) { d_dp_pkr<1, 5, false, 1, 4, true>(A, list, n, first); return; }
+    const int onep_d = d_onep_d(A.o.q, A.o.e, A.o.q2, A.o.e2);
+    if (cls == 17 && onep_d >= 16) { if (A.tb4 & 1) d_dp_pkr<1, 4, false, 1, 0, true, true>(A, list, n, first); else d_dp_pkr<1, 4, false, 1, 0, true>(A, list, n, first); return; }
+    if (cls == 10 && onep_d >= 20) { if (A.tb4 & 2) d_dp_pkr<1, 5, false, 1, 4, true, true>(A, list, n, first); else d_dp_pkr<1, 5, false, 1, 4, true>(A, list, n, first); return; }
     switch (cls) {
     case 10: d_dp_pkr<1, 5, false, 1, 4>(A, list, n, first); break;      // 17..20 diagonals: registers 0-3 are inside the band
     case 11: d_dp_pkr<1, 6, false, 1, 5>(A, list, n, first); break;
@@ -2453,20 +2519,23 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
 // wave's youngest load.  Here the WAVE moves down its trace-back matrices one 64-byte line at a time, so all lanes
 // cross into a new line in the same iteration, the control flow around the loads is uniform, and
 // two register sets hold the next two lines in flight: one memory wait per line for the whole wave instead of one per step.
-__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il,
+// rb4 != 0: the class spills nibbles (d_tb4), rb4 = bytes per row; the matching columns then come from the score (o = gap costs)
+__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il, int rb4, const DpOpt o_,
                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                  uint32_t *stage)
 {
     const int lane = threadIdx.x;
     DpProb P = probs[pi];
     if (P.kind >= 3) have = false;
-    const int rowb = lpp * 4, dlo = P.dlo, dhi_ = P.dhi, mg = P.pad[0] >> 8;
+    const int rowb = rb4 ? rb4 : lpp * 4, dlo = P.dlo, dhi_ = P.dhi, mg = P.pad[0] >> 8;
+    int gc = 0;                                                    // nibble spill: sum of q + e * length over the gap runs of the path
     int i = 0, j = 0;
     if (have) { i = res[pi].bi; j = res[pi].bj; }
     const uint8_t *tb = tb_all + P.tb_off;                       // 64-byte aligned (k_prob_sizes)
     uint32_t *cg = cig + P.cig_off;
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0, touched = 0;
     const int mytop = have && i > 0 && j > 0 ? (i + j) >> 1 : -1;  // highest row this lane reads
+    // last byte of row k: rows are rowb bytes apart (nibble rows too: a row pair is 2 * rb4 bytes)
     const int mytopline = mytop >= 0 ? (mytop * rowb + rowb - 1) >> 6 : -1;
     int rtop = mytop;
 #pragma unroll
@@ -2500,21 +2569,23 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
             const int lim = L << 6;
             for (;;) {
                 const int a = i + j, sl = (j - i - dlo) >> 1;
-                const int o = (((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1);
+                const int o = rb4 ? (a >> 1) * rb4 + ((sl >> 2) << 2) + (((sl >> 1) & 1) << 1) + (sl & 1)
+                                  : (((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1);
                 const bool act = i > 0 && j > 0 && o >= lim;
                 if (!__any(act)) break;
                 const int oo = act ? o : 0, w = oo & 63;
-                const uint32_t t = (stage[((oo >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
+                uint32_t t = (stage[((oo >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
+                if (rb4) t = (t >> ((a & 1) << 2)) & 0xfu;                           // even step: low nibble, odd step: high nibble
                 if (act) {
                     touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
-                    const int s0 = state ? state : (int)(t & 7);
+                    const int s0 = state ? state : (int)(t & (rb4 ? 3 : 7));
                     const int isM = s0 == 0, isD = s0 & 1;
                     const int op = isM ? 0 : (isD ? 2 : 1);
-                    state = (isM || !((t >> (2 + s0)) & 1)) ? 0 : s0;
+                    state = (isM || !((t >> ((rb4 ? 1 : 2) + s0)) & 1)) ? 0 : s0;
                     ml += isM & (int)(t >> 7); mc += isM;
                     i -= isD ^ 1; j -= isM | isD;
                     const bool same = op == cur_op;
-                    if (!same && cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+                    if (!same && cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; }
                     cur_len = same ? cur_len + 1 : 1; cur_op = op;
                 }
             }
@@ -2525,9 +2596,10 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
 #undef TBR_ENSURE
     }
     if (!have) return;
-    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
-    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
-    if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; } cur_op = 1; cur_len = i; } }
+    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; } cur_op = 2; cur_len = j; } }
+    if (cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; }
+    if (rb4) ml = (res[pi].score + o_.b * mc + gc) / (o_.a + o_.b);      // a ml - b (mc - ml) - gc = score
     res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
@@ -2535,14 +2607,15 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
 // per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
 __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ probs, DpRes *__restrict__ res,
                                                      const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
-                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list, ClsOff off)
+                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list, ClsOff off, int32_t tb4, DpOpt o)
 {
     __shared__ uint32_t stage[TB_SLOTS * 16 * 64];
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int ppw = 64 / PK_LPP[PK_IDX(cls)], t = threadIdx.x;
     const bool have = t < ppw && first + t < off.off[cls + 1] - off.off[cls];
-    d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)], d_tb_interleaved(cls), tb_all, cig, retry, stage);
+    d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)], d_tb_interleaved(cls),
+                     d_tb4(cls, tb4) ? d_tb4_rowb(cls) : 0, o, tb_all, cig, retry, stage);
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control

@@ -1068,6 +1068,15 @@ static inline int pk_wide_limit(const telr_map_opt *mo)
     return lim > 0 ? lim : 0;
 }
 // longest z-drop extension window (m+n) the packed int16 kernel takes: scores stay inside +-16000
+// classes that spill four bits per cell (kernels.hip.h: d_tb4): the one-piece classes of the preset, when every class has its
+// own trace-back launch (the one-launch walk of TELR_TB_SPLIT=0 reads bytes); TELR_TB8=1 keeps the byte spill for A/B
+static inline int tb4_mask(const telr_map_opt *mo)
+{
+    static const bool off = (getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0) || getenv("TELR_TB8") != nullptr;
+    if (off || !pk_steps_limit(mo)) return 0;
+    const int d = d_onep_d(mo->q, mo->e, mo->q2, mo->e2);
+    return (d >= 16 ? 1 : 0) | (d >= 20 ? 2 : 0);
+}
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || mo->zdrop > 4000 || getenv("TELR_NO_PKEXT")) return 0;
@@ -1090,7 +1099,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo);
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
@@ -1131,7 +1140,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
     D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
     D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
-    D.retry = d_retry;
+    D.retry = d_retry; D.tb4 = tb4_mask(mo);
     static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
     // trace-back per class list, right behind the class's forward kernel on the same stream (TELR_TB_SPLIT=0: one
     // trace-back launch over all problems after every forward kernel has finished)
@@ -1217,7 +1226,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             if (tb_over) {
                 HIPCHK(hipEventRecord(ctx->ev_chunk[g], st));
                 HIPCHK(hipStreamWaitEvent(ctx->tb_stream, ctx->ev_chunk[g], 0));
-                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, coff);
+                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, coff, D.tb4, D.o);
                 HIPCHK(hipGetLastError());
             }
         }
@@ -1229,7 +1238,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     if (primary) HIPCHK(hipEventRecord(ctx->evk[1], st));
     if (tb_split) {
         if (!tb_over && primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
-        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, coff);
+        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, coff, D.tb4, D.o);
         for (int c = 6; c >= 5; --c) {
             if (h_cls[c] == 0) continue;
             hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, st, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, (const int32_t*)(d_clslist + coff.off[c]));

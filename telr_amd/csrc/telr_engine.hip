@@ -1902,10 +1902,10 @@ static int seqset_subset_into(telr_ctx *ctx, const telr_seqset *parent, const st
 
 // One range [q0,q1) of the query set (at most one batch worth of bases); its records and CIGARs are appended to R.
 //
-// Long-read lane.  Seeding, chaining, back-tracking and the problem builder give one wave to a read, so a batch waits for
-// its longest read in each of these stages while the device idles.  The few reads longer than a third of the longest one
-// are therefore mapped as their own small batch on a worker context, concurrently with the rest (the bulk worker writes
-// straight into R, so the big CIGAR DMA keeps running underneath the caller's next range / call).
+// Long-read lane (opt-in, TELR_LONGSPLIT).  Seeding, chaining, back-tracking and the problem builder give one wave to a
+// read, so a batch waits for its longest read in each of these stages.  The longest reads can be mapped as their own small
+// batch on a worker context, concurrently with the rest (the bulk worker writes straight into R).  This paid while the
+// back-tracking walked with one lane; it no longer does (see below), so a range is one batch by default.
 //
 // A range whose anchors do not fit int32 offsets (map_batch: TELR_SPLIT_RANGE) is halved and retried.
 static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const int32_t *d_qt,
@@ -1918,8 +1918,12 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
     bool lane = false;
     std::vector<int32_t> lane_idx[2];         // 0: the bulk, 1: the long reads (query ids, ascending)
     {
+        // Off by default since the end of round 2: with the walker-free back-tracking, the tail classes on side streams and
+        // 2-Gbp ranges the lane no longer pays (configs[2] ranges of 0.5 / 1 / 2 Gbp: 13.8 / 15.1 / 15.8 Gbp/s with it, 14.6 /
+        // 15.4 / 16.0 without; configs[4] 15.1 / 15.5; configs[3] 3.93 / 3.88).  TELR_LONGSPLIT=auto applies the rule below,
+        // =<bases> sets the length threshold, =force splits any input (tests of the merge).
         const char *e = getenv("TELR_LONGSPLIT");
-        const bool force = e && !strcmp(e, "force"), off = e && !strcmp(e, "0");
+        const bool force = e && !strcmp(e, "force"), off = !e || !strcmp(e, "0");
         if (!off && !ctx->is_child && nq >= 2 && (force || (!ctx->debug && nq >= 2000 && total_bases >= 100000000LL))) {
             // Which reads go to the lane.  A range with far more reads than the device holds waves (>= 64 k reads): the longest
             // reads holding ~10 % of the bases (configs[2], lengths log-normal around 9 kb, 230 k reads per range: reads above

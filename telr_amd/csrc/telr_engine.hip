@@ -624,6 +624,7 @@ struct telr_index {
     mutable uint64_t *d_pt_keys = nullptr; mutable int32_t *d_pt_off = nullptr, *d_pt_mid = nullptr; mutable int32_t pt_runs = -1;
     mutable float pt_frac = -1.f; mutable int32_t pt_lo = -1, pt_hi = -1;
     mutable double anchors_per_base = 0;  // seen by the last telr_map call on this index (0 = none yet): sizes the first range of the next call
+    mutable double dens_bound = -1; mutable int32_t dens_mid = -1;     // index_density_bound() and the cut-off it was computed for
 };
 
 extern "C" void telr_index_free(telr_index *ix)
@@ -756,6 +757,20 @@ static int32_t index_mid_occ(const telr_index *ix, const telr_map_opt *mo)
 // Per-target occurrence cut-offs (device array [n_targets]) for `mo`: the statistics are built once per index, the
 // cut-offs once per (f, U) setting.  Used when a query is confined to one target (qtarget) or chains are ranked per
 // target (TELR_MF_PER_TARGET): both stand for the reference's one-aligner-run-per-contig call sites.
+// Upper bound of the anchors a read base produces before any call has measured it: every read minimizer taken for an index
+// minimizer (really one in two to five: sequencing errors), each bringing its occurrence count unless that exceeds the cut-off.
+// 2 / (w + 1) minimizers per base x sum(c^2 | c <= cut-off) / sum(c).  It only has to keep the first ranges of the first call
+// on an index within their anchor budget (13-mers on a 140-Mb genome: ~2 per base, where 15-mers give 0.3).
+static double index_density_bound(const telr_index *ix, int32_t mid_occ)
+{
+    if (ix->dens_mid == mid_occ && ix->dens_bound >= 0) return ix->dens_bound;
+    double s1 = 0, s2 = 0;
+    for (uint32_t c : ix->sorted_counts) { s1 += c; if ((int64_t)c <= mid_occ) s2 += (double)c * c; }
+    ix->dens_bound = s1 > 0 ? s2 / s1 * 2.0 / (ix->io.w + 1) : 0;
+    ix->dens_mid = mid_occ;
+    return ix->dens_bound;
+}
+
 static int index_per_target_occ(telr_ctx *ctx, const telr_index *ix, const telr_map_opt *mo, const int32_t **d_tmid)
 {
     const int n = ix->targets->n; const int64_t nmz = ix->n_mz;
@@ -2077,29 +2092,38 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
     if (nsub > nq) nsub = nq > 0 ? nq : 1;
     if (nsub == 1) {
-        // Ranges bounded by bases: a read set of any size streams through as consecutive ranges, each with its own long-read
-        // lane.  HBM is 288 GB and a range needs ~75 B of scratch per read base at 0.25 anchors per base, so a range holds up
-        // to 2 Gbp (configs[2]: 14.9 Gbp/s with 1-Gbp ranges, 15.3 with 1.4, 15.5 with 2.1 -- fewer synchronisation points and
-        // tails; 151 GB in use).  What really bounds a range is its anchors (int32 offsets, ~50 B each): after the first range
-        // the next ones -- and the first range of the next call on the same index -- are sized for at most 1.6 G anchors at
-        // the density seen so far; a first range that overflows is halved by map_range.
-        int64_t batch_bases = 2048LL << 20;
+        // Ranges bounded by bases: a read set of any size streams through as consecutive ranges.  HBM is 288 GB and a range
+        // needs ~75 B of scratch per read base at 0.25 anchors per base: a read set of up to 1.6 Gbp is ONE range (configs[2]
+        // reads alone in ranges of 0.5 / 1 / 1.4 / 2.1 Gbp: 13.7 / 14.9 / 15.3 / 15.5 Gbp/s -- fewer synchronisation points and
+        // tails; 151 GB in use at 2.1), a larger one is cut into ranges of at most 1.4 Gbp that run two at a time (below; the
+        // scratch of context and second slot is grow-only: ~115 + ~100 GB at this density).  What really bounds a range is its
+        // anchors (int32 offsets, ~50 B each): ranges hold at most 1.6 G anchors (0.8 G each when two are in flight) at the
+        // density the last call on the index has seen -- before any call, at an upper bound computed from the index's
+        // occurrence counts; a range that overflows all the same is halved by map_range.
+        int64_t batch_bases = 1600LL << 20;
         bool fixed = false;
         if (const char *e = getenv("TELR_BATCH_MBP")) { long v = atol(e); if (v > 0) { batch_bases = (int64_t)v << 20; fixed = true; } }
         if (const char *e = getenv("TELR_BATCH_KBP")) { long v = atol(e); if (v > 0) { batch_bases = (int64_t)v << 10; fixed = true; } }     // tests
-        // Range pipelining (opt-in, TELR_PIPELINE=2): two ranges in flight on two slots (each slot = a parent context + its
-        // two lane workers), so the seeding / sorting / chaining of range i+1 runs underneath the fills of range i.  Measured
-        // on configs[2]: no gain (14.2-15.1 vs 14.8 Gbp/s; stage times double, the wall does not move) -- with the two lanes
-        // of a range the device is already full, and the sum of the kernels' work is what bounds the step.  Kept for hosts
-        // with many cores and as a test of the in-order append (tests/test_gpu_parity.py::test_pipelined_ranges).
-        int pipe = 1; bool force = false;
-        if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }      // "force": tests, any size
-        if (ctx->is_child || (!force && (ctx->debug || total_bases < (200LL << 20) || nq < 4000))) pipe = 1;
+        // Range pipelining: a read set that needs more than one range runs TWO ranges at a time on two slots (the context and
+        // a second one of the same kind), so the host work between the stages of a range -- synchronisations, the second
+        // selection pass, the record assembly -- and its latency-bound stretches are covered by the other range's kernels;
+        // results are appended in range order through the turn gate of the result.  With the long-read lane (two batches per
+        // range already) this gained nothing; without it configs[2] goes from 15.7 to 16.5-17.4 Gbp/s (ranges of 0.7-1.6 Gbp:
+        // flat).  A read set that fits ONE range stays one range: halving it to pipeline the halves gains nothing at 1 Gbp
+        // and loses 5-17 % at 0.5 Gbp.  TELR_PIPELINE=1 switches it off; =force pipelines any multi-range call (tests).
+        int pipe = 2; bool force = false;
+        if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }
+        if (ctx->is_child || (!force && (ctx->debug || nq < 4000))) pipe = 1;
         if (pipe == 2 && !fixed) {
-            int64_t nr = (total_bases + (512LL << 20) - 1) / (512LL << 20);
-            if (nr < 2) nr = 2;
-            nr += nr & 1;
-            batch_bases = (total_bases + nr - 1) / nr + 1;
+            // ranges of at most 1.4 Gbp (two in flight: ~200 GB of scratch at configs[2]'s anchor density) and at most 1.6 G
+            // anchors at the density seen by the last call on this index; a read set within one such range is not split
+            int64_t cap = 1400LL << 20;
+            const double per_base = ix->anchors_per_base > 0 ? ix->anchors_per_base : index_density_bound(ix, mid_occ.mid_occ);
+            if (per_base > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(256LL << 20, (int64_t)(0.8e9 / per_base)));      // two in flight: half the anchor budget each
+            if (total_bases > std::min<int64_t>(batch_bases, (int64_t)(per_base > 0 ? 1.6e9 / per_base : 1e18)) || force) {
+                const int64_t nr = std::max<int64_t>(2, (total_bases + cap - 1) / cap);
+                batch_bases = (total_bases + nr - 1) / nr + 1;
+            } else pipe = 1;
         }
         std::vector<std::pair<int32_t, int32_t>> ranges;
         for (int32_t q0 = 0; q0 < nq; ) {
@@ -2136,9 +2160,11 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
               for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
               for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
               ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches; }
+            if (ctx->ctr.anchors > 0 && ctx->ctr.query_bases > (64LL << 20)) ix->anchors_per_base = (double)ctx->ctr.anchors / (double)ctx->ctr.query_bases;
         } else {
             auto limit_for = [&](double per_base) { return std::min<int64_t>(batch_bases, std::max<int64_t>(256LL << 20, (int64_t)(1.6e9 / per_base))); };
-            int64_t limit = !fixed && ix->anchors_per_base > 0 ? limit_for(ix->anchors_per_base) : batch_bases;
+            int64_t limit = batch_bases;
+            if (!fixed) { const double pb = ix->anchors_per_base > 0 ? ix->anchors_per_base : index_density_bound(ix, mid_occ.mid_occ); if (pb > 0) limit = limit_for(pb); }
             for (int32_t q0 = 0; q0 < nq; ) {
                 int32_t q1 = q0; int64_t b = 0;
                 while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= limit)) { b += queries->len[q1]; ++q1; }

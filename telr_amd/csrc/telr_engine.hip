@@ -2122,7 +2122,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             if (per_base > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(256LL << 20, (int64_t)(0.8e9 / per_base)));      // two in flight: half the anchor budget each
             if (total_bases > std::min<int64_t>(batch_bases, (int64_t)(per_base > 0 ? 1.6e9 / per_base : 1e18)) || force) {
                 const int64_t nr = std::max<int64_t>(2, (total_bases + cap - 1) / cap);
-                batch_bases = (total_bases + nr - 1) / nr + 1;
+                batch_bases = (total_bases + nr - 1) / nr + queries->max_len + 1;      // the slack keeps the greedy cut below from leaving a stub range behind
             } else pipe = 1;
         }
         std::vector<std::pair<int32_t, int32_t>> ranges;

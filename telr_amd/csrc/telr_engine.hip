@@ -67,6 +67,7 @@ struct telr_ctx {
     int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
     telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
     telr_ctx *slot1 = nullptr;            // the second range slot (a parent context with lane workers of its own)
+    bool pipe_nomem = false;              // two ranges in flight once ran out of device memory: later calls run one at a time
     int n_child = 0;
     bool is_child = false;
     char devname[256] = {0};
@@ -2113,7 +2114,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // and loses 5-17 % at 0.5 Gbp.  TELR_PIPELINE=1 switches it off; =force pipelines any multi-range call (tests).
         int pipe = 2; bool force = false;
         if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }
-        if (ctx->is_child || (!force && (ctx->debug || nq < 4000))) pipe = 1;
+        if (ctx->is_child || ctx->pipe_nomem || (!force && (ctx->debug || nq < 4000))) pipe = 1;
         if (pipe == 2 && !fixed) {
             // ranges of at most 1.4 Gbp (two in flight: ~200 GB of scratch at configs[2]'s anchor density) and at most 1.6 G
             // anchors at the density seen by the last call on this index; a read set within one such range is not split
@@ -2152,8 +2153,31 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             slot(0);
             t1.join();
             // the failing range's error, not that of the range it made leave
-            for (int s = 0; s < 2; ++s) if (rc[s] != TELR_OK && P[s]->err != "an earlier range of the call failed") { if (s) ctx->err = P[1]->err; delete R; return rc[s]; }
-            for (int s = 0; s < 2; ++s) if (rc[s] != TELR_OK) { if (s) ctx->err = P[1]->err; delete R; return rc[s]; }
+            int prc = TELR_OK;
+            for (int s = 0; s < 2 && prc == TELR_OK; ++s) if (rc[s] != TELR_OK && P[s]->err != "an earlier range of the call failed") { if (s) ctx->err = P[1]->err; prc = rc[s]; }
+            for (int s = 0; s < 2 && prc == TELR_OK; ++s) if (rc[s] != TELR_OK) { if (s) ctx->err = P[1]->err; prc = rc[s]; }
+            const bool test_nomem = prc == TELR_OK && getenv("TELR_TEST_PIPE_NOMEM");      // tests: exercise the fall-back below
+            if (test_nomem) prc = TELR_E_NOMEM;
+            if (prc == TELR_E_NOMEM) {
+                if (!test_nomem) ctx->pipe_nomem = true;
+                // two ranges in flight did not fit (a device shared with something else, or a denser index than the hint said):
+                // give the second slot's scratch back and run the call again one range at a time, in ranges of 1 Gbp at most
+                telr_destroy(ctx->slot1); ctx->slot1 = nullptr;
+                result_wait(R); R->alns.clear(); R->ncig = 0;
+                { std::lock_guard<std::mutex> lk(R->gate_m); R->turn = 0; }
+                memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms)); memset(&ctx->ctr, 0, sizeof(ctx->ctr)); memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
+                ctx->dp_retries = 0; ctx->pk_launches = 0; ctx->st_pending = 0;
+                int64_t lim = std::min<int64_t>(batch_bases, 1024LL << 20);
+                prc = TELR_OK;
+                for (int32_t q0 = 0; q0 < nq && prc == TELR_OK; ) {
+                    int32_t q1 = q0; int64_t b = 0;
+                    while (q1 < nq && (q1 == q0 || b + queries->len[q1] <= lim)) { b += queries->len[q1]; ++q1; }
+                    prc = map_range(ctx, ix, queries, qtarget, d_qt, q0, q1, mo, mid_occ, R);
+                    q0 = q1;
+                }
+                if (prc != TELR_OK) { delete R; return prc; }
+            } else if (prc != TELR_OK) { delete R; return prc; }
+            else
             { telr_ctx *c = P[1];
               for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
               const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;

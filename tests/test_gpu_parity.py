@@ -503,6 +503,15 @@ def test_pipelined_ranges(engine):
             del os.environ["TELR_PIPELINE"], os.environ["TELR_BATCH_KBP"]
             os.environ.pop("TELR_LONGSPLIT", None)
         assert len(res.alns) >= 60 and (np.diff(res.alns["qid"]) >= 0).all()
+    # the fall-back when two ranges in flight do not fit the device: the second slot is released and the call runs again one
+    # range at a time (forced here after a successful pipelined attempt)
+    os.environ["TELR_PIPELINE"] = "force"; os.environ["TELR_BATCH_KBP"] = "60"; os.environ["TELR_TEST_PIPE_NOMEM"] = "1"
+    try:
+        res, _ = compare_all(engine, genome, reads, io, mo, stages=False)
+        res2, _ = compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
+    finally:
+        del os.environ["TELR_PIPELINE"], os.environ["TELR_BATCH_KBP"], os.environ["TELR_TEST_PIPE_NOMEM"]
+    assert len(res.alns) >= 60 and (np.diff(res.alns["qid"]) >= 0).all()
 
 
 def test_seqset_subset_matches_fresh_set(engine):

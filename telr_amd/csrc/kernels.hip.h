@@ -1982,7 +1982,7 @@ __device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
 
-struct PkConst { uint32_t qe, e, q2e2, e2, ab, b; };
+struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab; };      // nab = -(a + b)
 
 // ONEP (one-piece): in a band of D diagonals no gap run is longer than D - 1, and while (D - 1)(e - e2) < q2 - q the second
 // affine piece q2 + L e2 is STRICTLY dearer than q + L e for every possible run length, so E2 / F2 are strictly below
@@ -2025,9 +2025,11 @@ __device__ __forceinline__ uint32_t d_cell_pk4(const PkConst &c, uint32_t hd, ui
     uint32_t op, g, t;
     op = pk_sub(hl, c.qe); g = pk_sub(e1l, c.e); ve1 = pk_max(op, g); t  = pk_sign(pk_sub(op, g)) & (0x00040004u << SH);
     op = pk_sub(hu, c.qe); g = pk_sub(f1u, c.e); vf1 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & (0x00080008u << SH);
-    const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
-    const uint32_t sc = pk_sub(eq & c.ab, c.b);
-    h = pk_add(hd, sc);
+    // score of the diagonal move without a mask: the codes differ in 0 or in 1..3 -> min(q ^ t, 1) is the mismatch bit, and
+    // h = (hd + a) - (a + b) * mismatch is one packed multiply-add (four instructions instead of six)
+    uint32_t ne, hda = pk_add(hd, c.a);
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(qb ^ tbv), "v"(0x00010001u));
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(ne), "v"(c.nab), "v"(hda));
     uint32_t m, src;
     m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & (0x00010001u << SH);
     m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = pk_sel(m, 0x00020002u << SH, src);
@@ -2111,7 +2113,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     const DpProb P = A.probs[prob];
     const DpOpt o = A.o;
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
-    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b);
+    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.a = pk_dup(o.a); c.nab = pk_dup(-(o.a + o.b));
     const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo;
     const int de0 = dlo + 4 * R * l;                   // lowest (even) diagonal of this lane
     const int dhi = have ? P.dhi : dlo - 1;            // diagonals above dhi are outside the band: their H / F stay -inf

@@ -140,7 +140,8 @@ int  telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo);
 
 /* ---- sequence sets --------------------------------------------------------- */
 /* n sequences given as one concatenated ASCII buffer; seq i = ascii[off[i] .. off[i]+len[i]).
- * Packs to 2 bits/base + an ambiguity bitmask and uploads to HBM. */
+ * Packs to 2 bits/base + an ambiguity bitmask (host threads, 32 bases per AVX2 step where available; pinned grow-only
+ * staging in the context) and uploads to HBM, chunk by chunk while the next chunks are packed. */
 int  telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii,
                         const int64_t *off, const int32_t *len, telr_seqset **out);
 void telr_seqset_free(telr_seqset *s);
@@ -161,7 +162,12 @@ int  telr_index_stats(const telr_index *idx, int64_t *n_minimizers, int64_t *n_d
 /* ---- mapping (S1,S2,S7: all queries vs all targets; S3,S4,S6: query i vs the
  *      single target qtarget[i]; S5: TELR_MF_PER_TARGET) ------------------------
  * qtarget may be NULL (every query sees every target) or hold one target id
- * per query (-1 = all).  Blocking; internally stream-asynchronous. */
+ * per query (-1 = all).  Blocking; internally stream-asynchronous.
+ * A query set of any size is accepted: up to 1.6 Gbp is one range; a larger one streams through in ranges of at most
+ * 1.4 Gbp, two of them in flight (each bounded by an anchor budget at the density the index has shown), and the records
+ * come back in query order whatever the cut.  The scratch is grow-only per context (about 75 B per query base of the
+ * largest range at 0.25 anchors per base); TELR_E_NOMEM with two ranges in flight makes the call run again one range at a
+ * time before it is reported. */
 int  telr_map(telr_ctx *ctx, const telr_index *idx, const telr_seqset *queries,
               const int32_t *qtarget, const telr_map_opt *mo, telr_result **out);
 

@@ -616,8 +616,13 @@ struct SeedArgs {
     int32_t *mz_n;               // MODE 0 out / MODE 1 in: its occurrence count (0 = absent)
     const int32_t *mz_aoff;      // MODE 1 in
     uint64_t *keys;              // MODE 1 out
+    uint32_t *k32, *v32;         // MODE 1 out, instead of keys when non-null: the high word (strand | reference position) and the low word (query position << 8 | span) apart
 };
 
+__device__ __forceinline__ void d_put_key(const SeedArgs &A, int64_t w, uint64_t key)
+{
+    if (A.k32) { A.k32[w] = (uint32_t)(key >> 32); A.v32[w] = (uint32_t)key; } else A.keys[w] = key;
+}
 // target holding global position g (goff ascending, goff[n] = end)
 __device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n, uint32_t g)
 {
@@ -671,7 +676,7 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
                 while (e < o1 && (A.I.pos[e] >> 1) < gend) ++e;
                 if ((int32_t)(e - o) <= A.tmid[t]) {
                     total += (int32_t)(e - o);
-                    if (MODE == 1) for (uint32_t z = o; z < e; ++z) { const uint32_t py = A.I.pos[z]; A.keys[w++] = ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32; }
+                    if (MODE == 1) for (uint32_t z = o; z < e; ++z) { const uint32_t py = A.I.pos[z]; d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32); }
                 }
                 o = e;
             }
@@ -694,7 +699,7 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             for (uint32_t o = o0; o < o1; ++o) {
                 uint32_t py = A.I.pos[o], gp = py >> 1;
                 if (tf >= 0 && (gp < g0 || gp >= g1)) continue;
-                A.keys[w++] = ((int)(py & 1) == qz ? kf : kr) | (uint64_t)gp << 32;
+                d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)gp << 32);
             }
         }
     }
@@ -759,6 +764,26 @@ __global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__r
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
     if (i == n) dst[n] = tail;
+}
+
+// The anchors of a query are sorted on their HIGH word only (strand | reference position: four radix passes over 4 + 4 bytes
+// instead of eight over 8) with the low word (query position << 8 | span) as the value; this kernel puts the words back
+// together and orders the few runs of equal high words -- the same reference minimizer hit from several query positions --
+// by their low word, which gives exactly the order of the 64-bit sort.  One block per query.
+__global__ void __launch_bounds__(256) k_key_join(const uint32_t *__restrict__ k32, const uint32_t *__restrict__ v32, const int32_t *__restrict__ q_aoff,
+                                                  uint64_t *__restrict__ out)
+{
+    const int q = blockIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t k = k32[base + i], v = v32[base + i];
+        int lo = i, hi = i + 1;
+        while (lo > 0 && k32[base + lo - 1] == k) --lo;
+        while (hi < n && k32[base + hi] == k) ++hi;
+        int rank = 0;
+        for (int j = lo; j < hi; ++j) rank += v32[base + j] < v ? 1 : 0;
+        out[base + lo + rank] = (uint64_t)k << 32 | v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

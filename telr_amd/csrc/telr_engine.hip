@@ -1347,7 +1347,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
+    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.k32 = nullptr; S.v32 = nullptr; S.q_order = d_qorder;
     hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));
@@ -1371,7 +1371,11 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     uint64_t *d_keys, *d_skeys;
     TRY(ctx_buf_t(ctx, "keys", (size_t)na, &d_keys));
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
-    S.mz_aoff = d_maoff; S.keys = d_keys;
+    // TELR_SORT64=1: the round-1 sort of whole 64-bit keys (A/B); else the keys leave the seeding kernel as two 32-bit words
+    static const bool sort64 = getenv("TELR_SORT64") != nullptr;
+    uint32_t *d_k32 = (uint32_t*)d_keys, *d_v32 = d_k32 + na, *d_k32s = nullptr, *d_v32s = nullptr;
+    if (!sort64) { TRY(ctx_buf_t(ctx, "skeys32", (size_t)na * 2 + 2, &d_k32s)); d_v32s = d_k32s + na; }
+    S.mz_aoff = d_maoff; S.keys = d_keys; S.k32 = sort64 ? nullptr : d_k32; S.v32 = sort64 ? nullptr : d_v32;
     hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, na, d_qaoff);
@@ -1381,12 +1385,21 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
 
     // ---- per-query sort of the anchor keys --------------------------------------------------
     StageTimer t_so(ctx, ST_SORT, true);
-    if (na > 0) {
+    if (na > 0 && sort64) {
         size_t tb = 0;
         // (all 64 bits: rocprim's segmented sort mis-orders keys with bit 63 set when begin_bit > 0 -- measured, ROCm 7.2)
         HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
         HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
+    } else if (na > 0) {
+        // sort on the high word (strand | reference position), the low word (query position, span) rides along; k_key_join
+        // puts them back together and orders the runs of equal high words: half the radix passes over the same bytes
+        size_t tb = 0;
+        HIPCHK(rocprim::segmented_radix_sort_pairs(nullptr, tb, d_k32, d_k32s, d_v32, d_v32s, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 32, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::segmented_radix_sort_pairs(tmp, tb, d_k32, d_k32s, d_v32, d_v32s, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 32, st));
+        hipLaunchKernelGGL(k_key_join, dim3(nq), dim3(256), 0, st, d_k32s, d_v32s, d_qaoff, d_skeys);
+        HIPCHK(hipGetLastError());
     }
     t_so.stop();
 

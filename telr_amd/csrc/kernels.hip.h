@@ -616,6 +616,9 @@ struct SeedArgs {
     int32_t *mz_n;               // MODE 0 out / MODE 1 in: its occurrence count (0 = absent)
     const int32_t *mz_aoff;      // MODE 1 in
     uint64_t *keys;              // MODE 1 out
+    // staged input (tile_off non-null): mz_x / mz_y are the sketch kernel's per-tile staging arrays (tile t at t * SK_TILE,
+    // tile_off[t+1] - tile_off[t] entries), read in place instead of being compacted first; q_tile0[q] = first tile of query q
+    const int32_t *tile_off, *q_tile0;
     uint32_t *k32, *v32;         // MODE 1 out, instead of keys when non-null: the high word (strand | reference position) and the low word (query position << 8 | span) apart
 };
 
@@ -646,8 +649,16 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
     if (tf >= 0) { g0 = A.I.goff[tf]; g1 = g0 + (uint32_t)A.I.tlen[tf]; }
     const int32_t occ = (tf >= 0 && A.tmid) ? A.tmid[tf] : A.mid_occ;
     const int qlen = A.qlen[q];
+    // staged input: minimizer g of the query lives in tile t at slot g - tile_off[t]; g only grows, so t is advanced, not searched
+    int t = A.tile_off ? A.q_tile0[q] : 0, t_lo = 0, t_hi = 0;
+    if (A.tile_off) { t_lo = A.tile_off[t]; t_hi = A.tile_off[t + 1]; }
     for (int g = m0 + threadIdx.x; g < m1; g += blockDim.x) {
-        uint64_t x = A.mz_x[g];
+        int64_t gi = g;
+        if (A.tile_off) {
+            while (g >= t_hi) { ++t; t_lo = t_hi; t_hi = A.tile_off[t + 1]; }
+            gi = (int64_t)t * SK_TILE + (g - t_lo);
+        }
+        uint64_t x = A.mz_x[gi];
         uint32_t o0 = 0, o1 = 0;
         if (MODE == 0) {
             uint32_t off = 0, n = 0;
@@ -663,7 +674,7 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             int32_t total = 0, w = MODE == 1 ? A.mz_aoff[g] : 0;
             uint64_t kf = 0, kr = 0; int32_t qz = 0;
             if (MODE == 1) {
-                const uint32_t y = A.mz_y[g];
+                const uint32_t y = A.mz_y[gi];
                 const int32_t span = (int32_t)(x & 0xff), qpos = (int32_t)(y >> 1); qz = (int32_t)(y & 1);
                 kf = (uint64_t)qpos << 8 | (uint64_t)span;
                 kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
@@ -691,7 +702,7 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
         }
         if (MODE == 0) A.mz_cnt[g] = cnt;
         else if (cnt > 0) {
-            uint32_t y = A.mz_y[g];
+            uint32_t y = A.mz_y[gi];
             int32_t span = (int32_t)(x & 0xff), qpos = (int32_t)(y >> 1), qz = (int32_t)(y & 1);
             uint64_t kf = (uint64_t)qpos << 8 | (uint64_t)span;
             uint64_t kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;

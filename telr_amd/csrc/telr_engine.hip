@@ -520,8 +520,10 @@ static void make_tiles(const telr_seqset *s, int32_t q0, int32_t q1, int k, Tile
 }
 
 // run the two-pass sketch over tiles; returns device arrays x,y (in ctx buffers named by prefix) and tile offsets
+// staged = true: no compaction copy -- d_x / d_y come back as the per-tile staging arrays (tile t at t * SK_TILE) for a
+// consumer that addresses them through the tile offsets (the seeding kernels)
 static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, int k, int w, const uint32_t *d_goff, const char *prefix,
-                      uint64_t **d_x, uint32_t **d_y, int32_t **d_tile_off, int32_t *n_mz, const SketchHpcArgs *hpc = nullptr)
+                      uint64_t **d_x, uint32_t **d_y, int32_t **d_tile_off, int32_t *n_mz, const SketchHpcArgs *hpc = nullptr, bool staged = false)
 {
     std::string P(prefix);
     int32_t *d_tseq, *d_tu0, *d_tcnt, *d_toff;
@@ -562,6 +564,7 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_tcnt, d_toff, (size_t)T.n + 1)));
     HIPCHK(hipMemcpyAsync(n_mz, d_toff + T.n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (staged) { *d_x = d_sx; *d_y = d_sy; return TELR_OK; }
     TRY(ctx_buf_t(ctx, (P + "mz_x").c_str(), (size_t)*n_mz, d_x));
     TRY(ctx_buf_t(ctx, (P + "mz_y").c_str(), (size_t)*n_mz, d_y));
     hipLaunchKernelGGL(k_sketch_compact, dim3(T.n), dim3(256), 0, ctx->stream, d_sx, d_sy, d_tcnt, d_toff, *d_x, *d_y);
@@ -1313,6 +1316,9 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     StageTimer t_sk(ctx, ST_SKETCH, true);
     TileList &T = ctx_tiles(ctx);
     uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
+    // the seeding kernels read the sketch kernel's staging arrays in place (no compaction copy); TELR_MZ_COMPACT=1 for A/B
+    static const bool mz_compact_env = getenv("TELR_MZ_COMPACT") != nullptr;
+    const bool mz_staged = !ix->io.is_hpc && !mz_compact_env;
     if (ix->io.is_hpc) {
         SketchHpcArgs H; std::vector<int32_t> nrun;
         TRY(build_hpc(ctx, qs, q0, q1, "qh_", &H, &nrun));
@@ -1320,13 +1326,14 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz, &H));
     } else {
         make_tiles(qs, q0, q1, k, T);
-        TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz));
+        TRY(run_sketch(ctx, qs, T, k, w, nullptr, "q_", &d_mx, &d_my, &d_toff, &nmz, nullptr, mz_staged));
     }
     // per-query minimizer offsets = tile_off[first tile of the query]
     int32_t *d_first, *d_qmz;
     TRY(ctx_buf_t(ctx, "q_first", (size_t)nq + 1, &d_first));
     TRY(ctx_buf_t(ctx, "q_mzoff", (size_t)nq + 1, &d_qmz));
     HIPCHK(hipMemcpyAsync(d_first, T.first.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_first + nq, &T.n, 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_toff, d_first, nq, nmz, d_qmz);
     HIPCHK(hipGetLastError());
     t_sk.stop(); ht.mark("sketch issued");
@@ -1348,6 +1355,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
     S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.k32 = nullptr; S.v32 = nullptr; S.q_order = d_qorder;
+    S.tile_off = mz_staged ? d_toff : nullptr; S.q_tile0 = mz_staged ? d_first : nullptr;
     hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));

@@ -1509,7 +1509,7 @@ __device__ __forceinline__ bool d_any_n(const uint32_t *__restrict__ nmask, int6
 }
 __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_margin, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
                              const uint32_t *__restrict__ qnmask, const uint32_t *__restrict__ tnmask,
-                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4)
+                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4, int32_t tb4_steps)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
@@ -1521,6 +1521,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
         const bool hasn = d_any_n(qnmask, P.qstep > 0 ? P.qi0 : P.qi0 - P.m + 1, P.m) || d_any_n(tnmask, P.tstep > 0 ? P.ti0 : P.ti0 - P.n + 1, P.n);
         if (hasn) cls = d_dp_class(P.kind, D, P.m + P.n, 0, 0, 0);
     }
+    if (d_tb4(cls, tb4) && P.m + P.n > tb4_steps) cls = 14;        // the nibble cell keeps scores times four: longer fills take the two-lane class
     int64_t tb;
     if (P.kind >= 3) tb = 0;
     else if (d_tb4(cls, tb4)) tb = ((int64_t)(((P.m + P.n) / 2 + 2) / 2) * (2 * d_tb4_rowb(cls)) + 63) & ~63LL;     // row pairs of nibbles
@@ -2018,7 +2019,7 @@ __device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
 
-struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab; };      // nab = -(a + b)
+struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF; };      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
 
 // ONEP (one-piece): in a band of D diagonals no gap run is longer than D - 1, and while (D - 1)(e - e2) < q2 - q the second
 // affine piece q2 + L e2 is STRICTLY dearer than q + L e for every possible run length, so E2 / F2 are strictly below
@@ -2051,25 +2052,35 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     return t | src;
 }
 
-// The one-piece cell with its flags in a nibble (d_tb4): sources 0 / 1 / 2 in bits SH, SH+1, the E1 / F1 extension flags in
-// bits SH+2, SH+3; SH = 0 on even steps, 4 on odd steps, so that OR-ing the two steps of a row gives one byte per diagonal.
-// No "bases equal" bit: the walk derives the matching columns from the score.
+// The one-piece cell of the nibble classes (d_tb4), with PROVENANCE TAGS instead of sign extractions.  Scores are kept times
+// four, so the two low bits of a value are free: the candidates of a maximum carry a tag there and the maximum itself tells
+// where it came from -- a flag costs an AND of the result instead of a subtraction, a sign extraction and a mask.
+//   E = max(H_left - 4(q+e) + 2   [tag 2: opened],  E_left - 4e   [tag 1: E states are stored with tag 1])
+//   F = max(H_up   - 4(q+e) + 1   [tag 1: opened],  F_up   - 4e   [tag 0])
+//   H = max(H_diag + 4 sc + 2     [tag 2],  E [tag 1],  F [tag 0])        ties: the larger tag wins = diagonal > E > F, and
+//                                                                          "opened" beats "extended", as the oracle decides
+// The nibble of the cell (bits SH..SH+3; SH = 0 on even steps, 4 on odd steps, so that OR-ing the two steps of a row gives
+// one byte per diagonal) is RAW: tag of H (2 = diagonal, 1 = E, 0 = F), bit 0 of E's tag (1 = extended), bit 0 of F's tag
+// (0 = extended); the walk turns it into source / extension flags.  No "bases equal" bit: the walk derives the matching
+// columns from the score.  A quarter of the int16 range remains: k_prob_sizes sends longer problems to the two-lane class.
 template <int SH>
 __device__ __forceinline__ uint32_t d_cell_pk4(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t e1l, uint32_t hu, uint32_t f1u,
                                                uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve1, uint32_t &vf1)
 {
-    uint32_t op, g, t;
-    op = pk_sub(hl, c.qe); g = pk_sub(e1l, c.e); ve1 = pk_max(op, g); t  = pk_sign(pk_sub(op, g)) & (0x00040004u << SH);
-    op = pk_sub(hu, c.qe); g = pk_sub(f1u, c.e); vf1 = pk_max(op, g); t |= pk_sign(pk_sub(op, g)) & (0x00080008u << SH);
-    // score of the diagonal move without a mask: the codes differ in 0 or in 1..3 -> min(q ^ t, 1) is the mismatch bit, and
-    // h = (hd + a) - (a + b) * mismatch is one packed multiply-add (four instructions instead of six)
-    uint32_t ne, hda = pk_add(hd, c.a);
+    const uint32_t et = pk_max(pk_sub(hl, c.qe), pk_sub(e1l, c.e));            // c.qe = 4(q+e) - 2, c.e = 4e
+    const uint32_t ft = pk_max(pk_sub(hu, c.qeF), pk_sub(f1u, c.e));           // c.qeF = 4(q+e) - 1
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ve1) : "v"(et), "v"(0xFFFCFFFCu), "v"(0x00010001u));
+    vf1 = ft & 0xFFFCFFFCu;
+    // diagonal move: min(q ^ t, 1) is the mismatch bit, h = (hd + 4a + 2) - 4(a + b) * mismatch one packed multiply-add
+    uint32_t ne, hda = pk_add(hd, c.a), ht;                                    // c.a = 4a + 2, c.nab = -4(a + b)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(qb ^ tbv), "v"(0x00010001u));
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(h) : "v"(ne), "v"(c.nab), "v"(hda));
-    uint32_t m, src;
-    m = pk_sign(pk_sub(h, ve1)); h = pk_max(h, ve1); src = m & (0x00010001u << SH);
-    m = pk_sign(pk_sub(h, vf1)); h = pk_max(h, vf1); src = pk_sel(m, 0x00020002u << SH, src);
-    return t | src;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(ht) : "v"(ne), "v"(c.nab), "v"(hda));
+    ht = pk_max(pk_max(ht, ve1), vf1);
+    h = ht & 0xFFFCFFFCu;
+    uint32_t n = ht & 0x00030003u;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(et & 0x00010001u), "v"(2), "v"(n));
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(ft & 0x00010001u), "v"(3), "v"(n));
+    return SH ? n << SH : n;
 }
 
 // Lane l of a problem owns the 4R consecutive diagonals dlo+4R*l .. dlo+4R*l+4R-1 as R packed register pairs:
@@ -2149,7 +2160,11 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     const DpProb P = A.probs[prob];
     const DpOpt o = A.o;
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
-    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.a = pk_dup(o.a); c.nab = pk_dup(-(o.a + o.b));
+    c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.a = pk_dup(o.a); c.nab = pk_dup(-(o.a + o.b)); c.qeF = c.qe;
+    if constexpr (TB4) {           // scores times four, provenance tags in the two low bits (d_cell_pk4)
+        c.qe = pk_dup(4 * (o.q + o.e) - 2); c.qeF = pk_dup(4 * (o.q + o.e) - 1); c.e = pk_dup(4 * o.e);
+        c.a = pk_dup(4 * o.a + 2); c.nab = pk_dup(-4 * (o.a + o.b));
+    }
     const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo;
     const int de0 = dlo + 4 * R * l;                   // lowest (even) diagonal of this lane
     const int dhi = have ? P.dhi : dlo - 1;            // diagonals above dhi are outside the band: their H / F stay -inf
@@ -2157,6 +2172,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         He[r] = E1e[r] = E2e[r] = F1e[r] = F2e[r] = Ho[r] = E1o[r] = E2o[r] = F1o[r] = F2o[r] = PK_NEG;
+        if constexpr (TB4) { E1e[r] |= 0x00010001u; E1o[r] |= 0x00010001u; }        // E states carry tag 1
         const int d0 = de0 + 4 * r;
         if (d0 == 0) He[r] &= 0xffff0000u;             // H(0,0) = 0
         if (d0 + 2 == 0) He[r] &= 0x0000ffffu;
@@ -2374,7 +2390,8 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
         return;
     }
     if (fin_here) {
-        const int sc = (int)(short)(fin_hi ? (fin >> 16) : (fin & 0xffffu));
+        int sc = (int)(short)(fin_hi ? (fin >> 16) : (fin & 0xffffu));
+        if constexpr (TB4) sc >>= 2;
         DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0;
         A.res[prob] = Rr;
     }
@@ -2613,7 +2630,10 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                 if (!__any(act)) break;
                 const int oo = act ? o : 0, w = oo & 63;
                 uint32_t t = (stage[((oo >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
-                if (rb4) t = (t >> ((a & 1) << 2)) & 0xfu;                           // even step: low nibble, odd step: high nibble
+                if (rb4) {                                                         // even step: low nibble, odd step: high nibble
+                    const uint32_t nb = (t >> ((a & 1) << 2)) & 0xfu;               // raw: tag of H (2 diagonal, 1 E, 0 F), E extended, F opened
+                    t = (2u - (nb & 3u)) | (nb & 4u) | ((nb & 8u) ^ 8u);
+                }
                 if (act) {
                     touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
                     const int s0 = state ? state : (int)(t & (rb4 ? 3 : 7));

@@ -1096,6 +1096,13 @@ static inline int tb4_mask(const telr_map_opt *mo)
     const int d = d_onep_d(mo->q, mo->e, mo->q2, mo->e2);
     return (d >= 16 ? 1 : 0) | (d >= 20 ? 2 : 0);
 }
+// steps (m + n) up to which the nibble cell's quarter of the int16 range holds: 4 (b steps / 2 + q + e D) stays below 15,400
+static inline int tb4_steps(const telr_map_opt *mo)
+{
+    const int by_b = 2 * (3850 - mo->q - 32 * mo->e) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 7700 / (mo->a > 0 ? mo->a : 1) - 2;
+    const int lim = by_b < by_a ? by_b : by_a;
+    return lim > 0 ? lim : 0;
+}
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || mo->zdrop > 4000 || getenv("TELR_NO_PKEXT")) return 0;
@@ -1118,7 +1125,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo));
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo), tb4_steps(mo));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));

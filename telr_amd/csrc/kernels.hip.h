@@ -1634,6 +1634,7 @@ struct DpArgs {
     int32_t dcap;            // diagonals of LDS state per wave (LDS kernel)
     int32_t *retry;
     int32_t tb4;             // bit 0: class 17, bit 1: class 10 spill 4 bits per cell (one-piece cell only; d_tb4)
+    int32_t tag8_steps;      // a wave of the two-piece classes whose longest problem has at most this many steps takes d_cell_pk8 (0 = never)
 };
 
 __device__ __forceinline__ int64_t d_wave_max64(int64_t v)
@@ -2019,7 +2020,7 @@ __device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
 
-struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF; };      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
+struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF, q2e2F; };      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
 
 // ONEP (one-piece): in a band of D diagonals no gap run is longer than D - 1, and while (D - 1)(e - e2) < q2 - q the second
 // affine piece q2 + L e2 is STRICTLY dearer than q + L e for every possible run length, so E2 / F2 are strictly below
@@ -2081,6 +2082,37 @@ __device__ __forceinline__ uint32_t d_cell_pk4(const PkConst &c, uint32_t hd, ui
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(et & 0x00010001u), "v"(2), "v"(n));
     asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(ft & 0x00010001u), "v"(3), "v"(n));
     return SH ? n << SH : n;
+}
+
+// The two-piece cell with provenance tags (TAG8): scores times EIGHT, three tag bits.  States are stored under the tag they
+// carry as candidates of H: E1 3, F1 2, E2 1, F2 0; the diagonal move has tag 4; an "opened" gap candidate has the stored tag
+// of its state plus one.  Ties therefore resolve as in the oracle (diagonal > E1 > F1 > E2 > F2, opened before extended).
+// The byte of the cell is RAW: tag of H in bits 0-2 (source = 4 - tag), then bit 0 of the tags of E1, F1, E2, F2 (E: 1 =
+// extended, F: 0 = extended); same positions as the flags of d_cell_pk, the walk inverts what needs inverting.  No "bases
+// equal" bit: the walk derives the matching columns from the score and the gap runs.  An eighth of the int16 range remains:
+// a wave takes this cell only when its longest problem fits (k_dp_pk), else d_cell_pk.
+__device__ __forceinline__ uint32_t d_cell_pk8(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t e1l, uint32_t e2l, uint32_t hu, uint32_t f1u, uint32_t f2u,
+                                               uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve1, uint32_t &vf1, uint32_t &ve2, uint32_t &vf2)
+{
+    const uint32_t et1 = pk_max(pk_sub(hl, c.qe), pk_sub(e1l, c.e));           // c.qe = 8(q+e) - 4      opened: tag 4, extended: 3
+    const uint32_t ft1 = pk_max(pk_sub(hu, c.qeF), pk_sub(f1u, c.e));          // c.qeF = 8(q+e) - 3     opened: 3, extended: 2
+    const uint32_t et2 = pk_max(pk_sub(hl, c.q2e2), pk_sub(e2l, c.e2));        // c.q2e2 = 8(q2+e2) - 2  opened: 2, extended: 1
+    const uint32_t ft2 = pk_max(pk_sub(hu, c.q2e2F), pk_sub(f2u, c.e2));       // c.q2e2F = 8(q2+e2) - 1 opened: 1, extended: 0
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ve1) : "v"(et1), "v"(0xFFF8FFF8u), "v"(0x00030003u));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(vf1) : "v"(ft1), "v"(0xFFF8FFF8u), "v"(0x00020002u));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ve2) : "v"(et2), "v"(0xFFF8FFF8u), "v"(0x00010001u));
+    vf2 = ft2 & 0xFFF8FFF8u;
+    uint32_t ne, hda = pk_add(hd, c.a), ht;                                    // c.a = 8a + 4, c.nab = -8(a + b)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(qb ^ tbv), "v"(0x00010001u));
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(ht) : "v"(ne), "v"(c.nab), "v"(hda));
+    ht = pk_max(pk_max(ht, ve1), pk_max(vf1, pk_max(ve2, vf2)));
+    h = ht & 0xFFF8FFF8u;
+    uint32_t n = ht & 0x00070007u;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(et1 & 0x00010001u), "v"(3), "v"(n));
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(ft1 & 0x00010001u), "v"(4), "v"(n));
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(et2 & 0x00010001u), "v"(5), "v"(n));
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(n) : "v"(ft2 & 0x00010001u), "v"(6), "v"(n));
+    return n;
 }
 
 // Lane l of a problem owns the 4R consecutive diagonals dlo+4R*l .. dlo+4R*l+4R-1 as R packed register pairs:
@@ -2146,11 +2178,12 @@ __device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dh
 // through `xch` (LDS, [2][NW][3]) with one barrier per step, everything else is unchanged.
 // FULL: the first FULL registers of a lane are inside the band for every problem of the class (classes are cut so that
 // only the last register can straddle dhi), so they need no out-of-band masks.
-template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false, bool TB4 = false>
+template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false, bool TB4 = false, bool TAG8 = false>
 __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob, uint32_t *xch = nullptr)
 {
     static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
     static_assert(!TB4 || (ONEP && LPP == 1 && !EXT), "nibble spill: one-piece cell, one problem per lane");
+    static_assert(!TAG8 || (!ONEP && !TB4 && !EXT && NW == 1), "tagged two-piece cell: fills of the one-launch classes");
     constexpr int RW = LPP * R;
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
     const int wv = NW > 1 ? lane >> 6 : 0, wl = lane & 63;
@@ -2161,9 +2194,15 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     const DpOpt o = A.o;
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
     c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.a = pk_dup(o.a); c.nab = pk_dup(-(o.a + o.b)); c.qeF = c.qe;
+    c.q2e2F = c.q2e2;
     if constexpr (TB4) {           // scores times four, provenance tags in the two low bits (d_cell_pk4)
         c.qe = pk_dup(4 * (o.q + o.e) - 2); c.qeF = pk_dup(4 * (o.q + o.e) - 1); c.e = pk_dup(4 * o.e);
         c.a = pk_dup(4 * o.a + 2); c.nab = pk_dup(-4 * (o.a + o.b));
+    }
+    if constexpr (TAG8) {          // scores times eight, three tag bits (d_cell_pk8)
+        c.qe = pk_dup(8 * (o.q + o.e) - 4); c.qeF = pk_dup(8 * (o.q + o.e) - 3); c.e = pk_dup(8 * o.e);
+        c.q2e2 = pk_dup(8 * (o.q2 + o.e2) - 2); c.q2e2F = pk_dup(8 * (o.q2 + o.e2) - 1); c.e2 = pk_dup(8 * o.e2);
+        c.a = pk_dup(8 * o.a + 4); c.nab = pk_dup(-8 * (o.a + o.b));
     }
     const int m = have ? P.m : 0, n = have ? P.n : 0, dlo = P.dlo;
     const int de0 = dlo + 4 * R * l;                   // lowest (even) diagonal of this lane
@@ -2173,6 +2212,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     for (int r = 0; r < R; ++r) {
         He[r] = E1e[r] = E2e[r] = F1e[r] = F2e[r] = Ho[r] = E1o[r] = E2o[r] = F1o[r] = F2o[r] = PK_NEG;
         if constexpr (TB4) { E1e[r] |= 0x00010001u; E1o[r] |= 0x00010001u; }        // E states carry tag 1
+        if constexpr (TAG8) { E1e[r] |= 0x00030003u; E1o[r] |= 0x00030003u; F1e[r] |= 0x00020002u; F1o[r] |= 0x00020002u; E2e[r] |= 0x00010001u; E2o[r] |= 0x00010001u; }
         const int d0 = de0 + 4 * r;
         if (d0 == 0) He[r] &= 0xffff0000u;             // H(0,0) = 0
         if (d0 + 2 == 0) He[r] &= 0x0000ffffu;
@@ -2235,6 +2275,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 const uint32_t lh = r ? Ho[r - 1] : ph, le1 = r ? E1o[r - 1] : pe1, le2 = r ? E2o[r - 1] : pe2;
                 const uint32_t hl = __builtin_amdgcn_alignbit(Ho[r], lh, 16), e1l = __builtin_amdgcn_alignbit(E1o[r], le1, 16), e2l = __builtin_amdgcn_alignbit(E2o[r], le2, 16);
                 if constexpr (TB4) { te[r] = d_cell_pk4<0>(c, He[r], hl, e1l, Ho[r], F1o[r], qb[r], tbv[r], h, ve1, vf1); ve2 = PK_NEG; vf2 = PK_NEG; }
+                else if constexpr (TAG8) te[r] = d_cell_pk8(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 else te[r] = d_cell_pk<ONEP>(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { He[r] = h; F1e[r] = vf1; F2e[r] = vf2; }
                 else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]); }
@@ -2279,6 +2320,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 const uint32_t hu = __builtin_amdgcn_alignbit(uh, He[r], 16), f1u = __builtin_amdgcn_alignbit(uf1, F1e[r], 16), f2u = __builtin_amdgcn_alignbit(uf2, F2e[r], 16);
                 uint32_t t;
                 if constexpr (TB4) { t = d_cell_pk4<4>(c, Ho[r], He[r], E1e[r], hu, f1u, qb[r], tbv[r], h, ve1, vf1); ve2 = PK_NEG; vf2 = PK_NEG; }
+                else if constexpr (TAG8) t = d_cell_pk8(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 else t = d_cell_pk<ONEP>(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { Ho[r] = h; F1o[r] = vf1; F2o[r] = vf2; }
                 else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]); }
@@ -2392,6 +2434,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     if (fin_here) {
         int sc = (int)(short)(fin_hi ? (fin >> 16) : (fin & 0xffffu));
         if constexpr (TB4) sc >>= 2;
+        if constexpr (TAG8) sc >>= 3;
         DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0;
         A.res[prob] = Rr;
     }
@@ -2432,6 +2475,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     const int onep_d = d_onep_d(A.o.q, A.o.e, A.o.q2, A.o.e2);
     if (cls == 17 && onep_d >= 16) { if (A.tb4 & 1) d_dp_pkr<1, 4, false, 1, 0, true, true>(A, list, n, first); else d_dp_pkr<1, 4, false, 1, 0, true>(A, list, n, first); return; }
     if (cls == 10 && onep_d >= 20) { if (A.tb4 & 2) d_dp_pkr<1, 5, false, 1, 4, true, true>(A, list, n, first); else d_dp_pkr<1, 5, false, 1, 4, true>(A, list, n, first); return; }
+    // two-piece classes: provenance tags (scores times eight) when the wave's longest problem -- its first: the lists are sorted
+    // by decreasing steps -- fits an eighth of the int16 range; k_traceback_pk decides the same way
+    const DpProb P0 = A.probs[list[first]];
+    if (P0.m + P0.n <= A.tag8_steps) {
+        switch (cls) {
+        case 10: d_dp_pkr<1, 5, false, 1, 4, false, false, true>(A, list, n, first); break;
+        case 11: d_dp_pkr<1, 6, false, 1, 5, false, false, true>(A, list, n, first); break;
+        case 12: d_dp_pkr<1, 7, false, 1, 6, false, false, true>(A, list, n, first); break;
+        case 13: d_dp_pkr<1, 8, false, 1, 7, false, false, true>(A, list, n, first); break;
+        case 17: d_dp_pkr<1, 4, false, 1, 0, false, false, true>(A, list, n, first); break;
+        case 14: d_dp_pkr<2, 5, false, 1, 0, false, false, true>(A, list, n, first); break;
+        case 15: d_dp_pkr<2, 6, false, 1, 0, false, false, true>(A, list, n, first); break;
+        case 22: d_dp_pkr<4, 8, false, 1, 0, false, false, true>(A, list, n, first); break;
+        default: d_dp_pkr<2, 8, false, 1, 0, false, false, true>(A, list, n, first); break;
+        }
+        return;
+    }
     switch (cls) {
     case 10: d_dp_pkr<1, 5, false, 1, 4>(A, list, n, first); break;      // 17..20 diagonals: registers 0-3 are inside the band
     case 11: d_dp_pkr<1, 6, false, 1, 5>(A, list, n, first); break;
@@ -2575,7 +2635,8 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
 // cross into a new line in the same iteration, the control flow around the loads is uniform, and
 // two register sets hold the next two lines in flight: one memory wait per line for the whole wave instead of one per step.
 // rb4 != 0: the class spills nibbles (d_tb4), rb4 = bytes per row; the matching columns then come from the score (o = gap costs)
-__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il, int rb4, const DpOpt o_,
+// tag8: the wave's bytes are the raw tags of d_cell_pk8 (no "bases equal" bit either)
+__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il, int rb4, bool tag8, const DpOpt o_,
                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                  uint32_t *stage)
 {
@@ -2583,7 +2644,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
     DpProb P = probs[pi];
     if (P.kind >= 3) have = false;
     const int rowb = rb4 ? rb4 : lpp * 4, dlo = P.dlo, dhi_ = P.dhi, mg = P.pad[0] >> 8;
-    int gc = 0;                                                    // nibble spill: sum of q + e * length over the gap runs of the path
+    int gc = 0;                                                    // tagged spills: cost of the gap runs of the path (piece by piece, as the DP counted them)
     int i = 0, j = 0;
     if (have) { i = res[pi].bi; j = res[pi].bj; }
     const uint8_t *tb = tb_all + P.tb_off;                       // 64-byte aligned (k_prob_sizes)
@@ -2633,17 +2694,22 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                 if (rb4) {                                                         // even step: low nibble, odd step: high nibble
                     const uint32_t nb = (t >> ((a & 1) << 2)) & 0xfu;               // raw: tag of H (2 diagonal, 1 E, 0 F), E extended, F opened
                     t = (2u - (nb & 3u)) | (nb & 4u) | ((nb & 8u) ^ 8u);
+                } else if (tag8) {                                                  // raw: tag of H (4 - source), E1 / E2 extended, F1 / F2 opened
+                    t = (4u - (t & 7u)) | (t & 0x28u) | ((t & 0x50u) ^ 0x50u);
                 }
                 if (act) {
                     touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
                     const int s0 = state ? state : (int)(t & (rb4 ? 3 : 7));
                     const int isM = s0 == 0, isD = s0 & 1;
                     const int op = isM ? 0 : (isD ? 2 : 1);
+                    // a step inside a gap run costs its piece's extension, the step that enters the run (walking backwards: the
+                    // run's LAST cell) its opening as well
+                    if (!isM) gc += (s0 <= 2 ? o_.e : o_.e2) + (state ? 0 : (s0 <= 2 ? o_.q : o_.q2));
                     state = (isM || !((t >> ((rb4 ? 1 : 2) + s0)) & 1)) ? 0 : s0;
                     ml += isM & (int)(t >> 7); mc += isM;
                     i -= isD ^ 1; j -= isM | isD;
                     const bool same = op == cur_op;
-                    if (!same && cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; }
+                    if (!same && cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
                     cur_len = same ? cur_len + 1 : 1; cur_op = op;
                 }
             }
@@ -2654,10 +2720,13 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
 #undef TBR_ENSURE
     }
     if (!have) return;
-    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; } cur_op = 1; cur_len = i; } }
-    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; } cur_op = 2; cur_len = j; } }
-    if (cur_len) { cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_op) gc += o_.q + o_.e * cur_len; }
-    if (rb4) ml = (res[pi].score + o_.b * mc + gc) / (o_.a + o_.b);      // a ml - b (mc - ml) - gc = score
+    // what is left of i or j is the boundary run of row 0 / column 0: the cheaper of the two pieces, as the DP fills it
+    if (i > 0) { const int c1 = o_.q + o_.e * i, c2 = o_.q2 + o_.e2 * i; gc += c1 < c2 ? c1 : c2; }
+    if (j > 0) { const int c1 = o_.q + o_.e * j, c2 = o_.q2 + o_.e2 * j; gc += c1 < c2 ? c1 : c2; }
+    if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
+    if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
+    if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
+    if (rb4 || tag8) ml = (res[pi].score + o_.b * mc + gc) / (o_.a + o_.b);      // a ml - b (mc - ml) - gc = score
     res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
@@ -2665,15 +2734,18 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
 // per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
 __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ probs, DpRes *__restrict__ res,
                                                      const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
-                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list, ClsOff off, int32_t tb4, DpOpt o)
+                                                     const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list, ClsOff off, int32_t tb4, DpOpt o, int32_t tag8_steps)
 {
     __shared__ uint32_t stage[TB_SLOTS * 16 * 64];
     const uint32_t w = waves[blockIdx.x];
     const int cls = (int)(w >> 26), first = (int)(w & 0x3ffffffu);
     const int ppw = 64 / PK_LPP[PK_IDX(cls)], t = threadIdx.x;
     const bool have = t < ppw && first + t < off.off[cls + 1] - off.off[cls];
+    const int rb4 = d_tb4(cls, tb4) ? d_tb4_rowb(cls) : 0;
+    const DpProb P0 = probs[cls_list[off.off[cls] + first]];                   // the wave's longest problem: k_dp_pk chose the cell by it
+    const bool tag8 = !rb4 && !(cls == 17 && d_onep_d(o.q, o.e, o.q2, o.e2) >= 16) && !(cls == 10 && d_onep_d(o.q, o.e, o.q2, o.e2) >= 20) && P0.m + P0.n <= tag8_steps;
     d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)], d_tb_interleaved(cls),
-                     d_tb4(cls, tb4) ? d_tb4_rowb(cls) : 0, o, tb_all, cig, retry, stage);
+                     rb4, tag8, o, tb_all, cig, retry, stage);
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control

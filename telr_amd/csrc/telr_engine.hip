@@ -1103,6 +1103,15 @@ static inline int tb4_steps(const telr_map_opt *mo)
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
 }
+// the same for the two-piece tagged cell (scores times eight); off with the one-launch trace-back (it reads plain flags) or TELR_NO_TAG8=1
+static inline int tag8_steps(const telr_map_opt *mo)
+{
+    static const bool off = (getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0) || getenv("TELR_NO_TAG8") != nullptr;
+    if (off || !pk_steps_limit(mo)) return 0;
+    const int by_b = 2 * (1975 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 4000 / (mo->a > 0 ? mo->a : 1) - 2;
+    const int lim = by_b < by_a ? by_b : by_a;
+    return lim > 0 ? lim : 0;
+}
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || mo->zdrop > 4000 || getenv("TELR_NO_PKEXT")) return 0;
@@ -1166,7 +1175,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
     D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
     D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
-    D.retry = d_retry; D.tb4 = tb4_mask(mo);
+    D.retry = d_retry; D.tb4 = tb4_mask(mo); D.tag8_steps = tag8_steps(mo);
     static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
     // trace-back per class list, right behind the class's forward kernel on the same stream (TELR_TB_SPLIT=0: one
     // trace-back launch over all problems after every forward kernel has finished)
@@ -1252,7 +1261,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             if (tb_over) {
                 HIPCHK(hipEventRecord(ctx->ev_chunk[g], st));
                 HIPCHK(hipStreamWaitEvent(ctx->tb_stream, ctx->ev_chunk[g], 0));
-                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, coff, D.tb4, D.o);
+                hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, coff, D.tb4, D.o, D.tag8_steps);
                 HIPCHK(hipGetLastError());
             }
         }
@@ -1264,7 +1273,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     if (primary) HIPCHK(hipEventRecord(ctx->evk[1], st));
     if (tb_split) {
         if (!tb_over && primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
-        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, coff, D.tb4, D.o);
+        if (!tb_over && nw > 0) hipLaunchKernelGGL(k_traceback_pk, dim3(nw), dim3(64), 0, st, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2, d_clslist, coff, D.tb4, D.o, D.tag8_steps);
         for (int c = 6; c >= 5; --c) {
             if (h_cls[c] == 0) continue;
             hipLaunchKernelGGL(k_traceback, dim3((h_cls[c] + 63) / 64), dim3(64), 0, st, d_probs, d_res, h_cls[c], d_tb, *d_rawcig_io, d_retry, (const int32_t*)(d_clslist + coff.off[c]));

@@ -442,7 +442,7 @@ def main():
                      "algorithmic_bytes_per_launch": k_bytes_tot / launches,
                      "problems_per_launch": float(cls[PK, 0].sum()) / launches, "cells_per_launch": float(cls[PK, 1].sum()) / launches,
                      "gcups": float(cls[PK, 1].sum()) / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else None,
-                     "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); with two ranges in flight a launch shares the device with the other range's kernels, so launch_ms is its stretched duration (alone, TELR_PIPELINE=1: 28.3 ms per 38.8 G-cell launch, 1,368 GCUPS, valu_issue from the PMC passes); all DP kernels together: %.1f ms per step, %.0f GCUPS"
+                     "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); with two ranges in flight a launch shares the device with the other range's kernels, so launch_ms is its stretched duration (alone, TELR_PIPELINE=1: 15.5 ms per 25.8 G-cell launch, 1,670 GCUPS; valu_issue from the PMC passes); all DP kernels together: %.1f ms per step, %.0f GCUPS"
                              % (dp_ms, ctr["dp_cells"] / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0)},
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_tot.items()},
         "dp_classes": {str(c): [int(x) // a.steps for x in cls[c]] for c in range(cls.shape[0]) if cls[c, 0]},

@@ -105,9 +105,27 @@ def launch_ranks(a):
     return pr.wait()
 
 
-def cpu_baseline(ref_strs, reads, io, mo, n_sample):
-    """The CPU oracle ("port") timed on a bounded sample of the same read set."""
+PARITY_FIELDS = ("tid", "qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "score", "subsc", "dp_score", "cnt", "n_sub", "parent", "n_cigar", "flags", "mapq")
+
+
+def _read_digests(alns, cigars, qid_map=None):
+    """{read: bytes of its records (the fields the parity tests compare) + their CIGAR words, in record order}"""
+    import numpy as np
+    out = {}
+    qid = alns["qid"] if qid_map is None else qid_map[alns["qid"]]
+    tab = np.stack([alns[f].astype(np.int64) for f in PARITY_FIELDS], axis=1) if len(alns) else np.zeros((0, len(PARITY_FIELDS)), np.int64)
+    off, n = alns["cigar_off"], alns["n_cigar"]
+    for k in range(len(alns)):
+        q = int(qid[k])
+        out[q] = out.get(q, b"") + tab[k].tobytes() + cigars[off[k]:off[k] + n[k]].tobytes()
+    return out
+
+
+def cpu_baseline(ref_strs, reads, io, mo, n_sample, gpu_index=None):
+    """The CPU oracle ("port") timed on a bounded sample of the same read set; with `gpu_index`, its records for the sample are
+    also compared with the engine's, read by read (full-size parity evidence: same index, same reads, outside the timed leg)."""
     from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
     from oracle import binding as ob
     cores = usable_cpus()
     buf, off, ln = reads
@@ -118,18 +136,31 @@ def cpu_baseline(ref_strs, reads, io, mo, n_sample):
     seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in range(n_sample)]
     shards = [seqs[i::cores] for i in range(cores)]
     shards = [s for s in shards if s]
+    parts = [None] * len(shards)
 
-    def work(s):
-        r = oix.map(s, mo)
+    def work(k):
+        r = oix.map(shards[k], mo)
+        parts[k] = (r["alns"], r["cigars"])
         prim = r["alns"][(r["alns"]["flags"] & 1) != 0]
         return int(prim["qlen"].sum())
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=len(shards)) as ex:
-        aligned = sum(ex.map(work, shards))
+        aligned = sum(ex.map(work, range(len(shards))))
     dt = time.time() - t0
-    return {"value": aligned / dt / 1e9, "unit": "Gbp/s", "cores": len(shards), "kind": "port",
-            "sample": "first %d reads (%d bases) of the same read set against the same full-size index, oracle/telr_oracle.c, %d threads, %.1f s; "
-                      "index build %.1f s (one thread) excluded" % (n_sample, sum(len(s) for s in seqs), len(shards), dt, t_index)}
+    out = {"value": aligned / dt / 1e9, "unit": "Gbp/s", "cores": len(shards), "kind": "port",
+           "sample": "first %d reads (%d bases) of the same read set against the same full-size index, oracle/telr_oracle.c, %d threads, %.1f s; "
+                     "index build %.1f s (one thread) excluded" % (n_sample, sum(len(s) for s in seqs), len(shards), dt, t_index)}
+    if gpu_index is not None:
+        want = {}
+        for k, (al, cg) in enumerate(parts):
+            want.update(_read_digests(al, cg, qid_map=np.arange(len(shards[k]), dtype=np.int32) * len(shards) + k))
+        res = gpu_index.map(seqs, mo)
+        got = _read_digests(res.alns, res.cigars)
+        bad = [q for q in set(want) | set(got) if want.get(q) != got.get(q)]
+        out["parity"] = {"reads": n_sample, "records_oracle": int(sum(len(p[0]) for p in parts)), "records_engine": int(len(res.alns)),
+                         "reads_differing": len(bad), "identical": not bad,
+                         "what": "every record (all fields) and every CIGAR of the sampled reads, engine vs CPU oracle on the same full-size index"}
+    return out
 
 
 def build_dataset(a, cfg, rank, world, lws):
@@ -455,7 +486,7 @@ def main():
         out["te_loci"] = loci_out
     if not a.no_cpu_baseline:
         ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(D["reads"][2]))))   # ~15-20 s of CPU work
-        out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns)
+        out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns, gpu_index=ix)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
     json_out.write(json.dumps(out) + "\n"); json_out.flush()
     sys.stdout.flush()

@@ -571,7 +571,7 @@ struct IndexView {
 // sequencing error and are not in the index at all, and ~3/4 of those find their bit clear, which answers the probe
 // without fetching a table line from HBM.
 __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t *__restrict__ ent_off, int32_t n_ent, int ht_shift, uint32_t ht_mask, HtSlot *__restrict__ ht,
-                           uint32_t *__restrict__ ht_home)
+                           uint32_t *__restrict__ ht_home, const uint32_t *__restrict__ pos)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_ent) return;
@@ -580,7 +580,9 @@ __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t
     { const uint32_t f = d_ht_filter_bit(h, ht_shift); atomicOr(&ht_home[f >> 5], 1u << (f & 31)); }
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&ht[s].hash, (unsigned long long)HT_EMPTY, (unsigned long long)h);
-        if (old == HT_EMPTY) { ht[s].off = ent_off[e]; ht[s].cnt = ent_off[e + 1] - ent_off[e]; return; }
+        // a minimizer with ONE occurrence (most of them) carries the occurrence itself instead of its place in `pos`: the seeding
+        // kernels then need no second scattered read for it
+        if (old == HT_EMPTY) { const uint32_t c = ent_off[e + 1] - ent_off[e]; ht[s].off = c == 1 ? pos[ent_off[e]] : ent_off[e]; ht[s].cnt = c; return; }
         s = (s + 1) & ht_mask;
     }
 }
@@ -669,6 +671,10 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             if (A.mz_aoff[g + 1] == A.mz_aoff[g]) continue;
             o0 = (uint32_t)A.mz_ent[g]; o1 = o0 + (uint32_t)A.mz_n[g];
         }
+        // one occurrence: o0 IS the occurrence (k_ht_build), not an index into `pos`
+        const bool single = o1 - o0 == 1u;
+        const uint32_t pos1 = o0;
+#define SEED_POS(i_) (single ? pos1 : A.I.pos[i_])
         if (pt) {
             // occurrences are sorted by global position, i.e. grouped by target: one run per target
             int32_t total = 0, w = MODE == 1 ? A.mz_aoff[g] : 0;
@@ -681,13 +687,13 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             }
             uint32_t o = o0;
             while (o < o1) {
-                const int t = d_tid_of(A.I.goff, A.n_targets, A.I.pos[o] >> 1);
+                const int t = d_tid_of(A.I.goff, A.n_targets, SEED_POS(o) >> 1);
                 const uint32_t gend = A.I.goff[t + 1];
                 uint32_t e = o + 1;
-                while (e < o1 && (A.I.pos[e] >> 1) < gend) ++e;
+                while (e < o1 && (SEED_POS(e) >> 1) < gend) ++e;
                 if ((int32_t)(e - o) <= A.tmid[t]) {
                     total += (int32_t)(e - o);
-                    if (MODE == 1) for (uint32_t z = o; z < e; ++z) { const uint32_t py = A.I.pos[z]; d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32); }
+                    if (MODE == 1) for (uint32_t z = o; z < e; ++z) { const uint32_t py = SEED_POS(z); d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32); }
                 }
                 o = e;
             }
@@ -696,7 +702,7 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
         }
         int32_t cnt = 0;
         if (o1 > o0) {
-            if (tf >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t gp = A.I.pos[o] >> 1; cnt += (gp >= g0 && gp < g1) ? 1 : 0; } }
+            if (tf >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t gp = SEED_POS(o) >> 1; cnt += (gp >= g0 && gp < g1) ? 1 : 0; } }
             else cnt = (int32_t)(o1 - o0);
             if (cnt > occ) cnt = 0;
         }
@@ -708,13 +714,14 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
             uint64_t kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
             int32_t w = A.mz_aoff[g];
             for (uint32_t o = o0; o < o1; ++o) {
-                uint32_t py = A.I.pos[o], gp = py >> 1;
+                uint32_t py = SEED_POS(o), gp = py >> 1;
                 if (tf >= 0 && (gp < g0 || gp >= g1)) continue;
                 d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)gp << 32);
             }
         }
     }
 }
+#undef SEED_POS
 
 // ---- per-target occurrence counts of an index (for the per-target cut-offs) ----------------------------
 // run = the occurrences of one minimizer inside one target (contiguous in `pos`: sorted by hash, then position)

@@ -709,7 +709,7 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
         const size_t home_words = (((size_t)1 << (hb + HT_FB_LOG)) + 31) / 32;
         HIPCHK(hipMalloc(&ix->d_ht_home, home_words * 4));
         HIPCHK(hipMemsetAsync(ix->d_ht_home, 0, home_words * 4, ctx->stream));
-        if (n_ent > 0) hipLaunchKernelGGL(k_ht_build, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, ix->d_ent_off, n_ent, ix->ht_shift, ix->ht_mask, ix->d_ht, ix->d_ht_home);
+        if (n_ent > 0) hipLaunchKernelGGL(k_ht_build, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_hash, ix->d_ent_off, n_ent, ix->ht_shift, ix->ht_mask, ix->d_ht, ix->d_ht_home, ix->d_pos);
         HIPCHK(hipGetLastError());
     }
     // occurrence counts, sorted, to the host for the -f quantile

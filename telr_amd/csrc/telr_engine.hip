@@ -395,6 +395,7 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     std::atomic<int> next(0);
     static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("TELR_NO_AVX2");
     int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
+    if (const char *e = getenv("TELR_PACK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nth = v; }      // a caller that packs the next batch while the current one maps leaves cores to the mapper
     if (s->total_bases < (1 << 20)) nth = 1;
     if (nth > nchunk) nth = nchunk > 0 ? nchunk : 1;
     auto pack_chunk = [&](int c) {

@@ -36,3 +36,4 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
     assert c["parity"]["identical"] is True and c["parity"]["reads"] == 40 and c["parity"]["records_engine"] == c["parity"]["records_oracle"] > 0
     assert d["value_incl_h2d"] <= d["value"] and d["te_loci"]["n"] == 30
+    assert 0 < d["value_streaming_incl_h2d"] <= 1.05 * d["value"]          # measured with every step's reads packed and uploaded underneath the previous step

@@ -888,19 +888,21 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
             for (int jj = 0; jj < jn; ++jj) {
                 const int j = j0 + jj;
                 const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)gi[r], jj), gj1 = gj + 1u;
-                const uint32_t qj1 = (uint32_t)__builtin_amdgcn_readlane((int)qi[r], jj) + 1u;
-                const int32_t fj2p2 = (__builtin_amdgcn_readlane(B[r], jj) & ~1) + 2;
                 // reference word of anchor j + 1 (still in its slot: a slot is refilled only when its own anchor is done)
                 const uint32_t gnext = jj < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)gi[r], jj + 1) : (uint32_t)__builtin_amdgcn_readlane((int)gi[(r + 1) % R], 0);
                 // the owner of j keeps its final state for the store and takes its next anchor (selects, not a branch;
                 // bp of a slot is only meaningful once B is even, so it is not reset)
                 const bool me = lane == jj;
                 myB = me ? B[r] : myB; myp = me ? bp[r] : myp;
-                gi[r] = me ? ng : gi[r]; qi[r] = me ? nqp : qi[r]; sp1[r] = me ? nsp1 : sp1[r]; B[r] = me ? nB : B[r];
+                gi[r] = me ? ng : gi[r]; sp1[r] = me ? nsp1 : sp1[r];
                 // Anchors are sorted by (strand, reference position): when even the NEXT anchor lies more than max_gap beyond j
                 // (or on the other strand: bit 31), no later anchor can take j as a predecessor -- a scalar test that skips the
-                // whole push for the isolated hits that repeats and random k-mer matches scatter over the genome.
-                if (gnext - gj > max_gap) continue;
+                // whole push for the isolated hits that repeats and random k-mer matches scatter over the genome (their query
+                // position and score are not even broadcast).
+                if (gnext - gj > max_gap) { qi[r] = me ? nqp : qi[r]; B[r] = me ? nB : B[r]; continue; }
+                const uint32_t qj1 = (uint32_t)__builtin_amdgcn_readlane((int)qi[r], jj) + 1u;
+                const int32_t fj2p2 = (__builtin_amdgcn_readlane(B[r], jj) & ~1) + 2;
+                qi[r] = me ? nqp : qi[r]; B[r] = me ? nB : B[r];
 #pragma unroll
                 for (int s = 0; s < R; ++s)     // anchors currently owned: index > j and <= j + 64R by construction
                     d_chain_push<SKIP>(gi[s], qi[s], sp1[s], gj1, qj1, fj2p2, j, max_gap, ddc, gap_q8, skip_q8, B[s], bp[s]);

@@ -873,6 +873,7 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
         const uint64_t k = i < n ? a[i] : 0;
         gi[r] = (uint32_t)(k >> 32); qi[r] = (uint32_t)A_Q(k); sp1[r] = (uint32_t)A_SPAN(k) - 1u; B[r] = 2 * A_SPAN(k) + 1; bp[r] = -1;
     }
+    uint32_t gcur = (uint32_t)__builtin_amdgcn_readlane((int)gi[0], 0);      // reference word of the anchor whose turn it is
     for (int jb = 0; jb < n; jb += 64 * R) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -887,11 +888,12 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
             const int jn = n - j0 < 64 ? n - j0 : 64;
             for (int jj = 0; jj < jn; ++jj) {
                 const int j = j0 + jj;
-                const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)gi[r], jj), gj1 = gj + 1u;
+                const uint32_t gj = gcur, gj1 = gj + 1u;            // broadcast as the previous trip's "next anchor"
                 // reference word of anchor j + 1 (still in its slot: a slot is refilled only when its own anchor is done)
                 const uint32_t gnext = jj < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)gi[r], jj + 1) : (uint32_t)__builtin_amdgcn_readlane((int)gi[(r + 1) % R], 0);
                 // the owner of j keeps its final state for the store and takes its next anchor (selects, not a branch;
                 // bp of a slot is only meaningful once B is even, so it is not reset)
+                gcur = gnext;
                 const bool me = lane == jj;
                 myB = me ? B[r] : myB; myp = me ? bp[r] : myp;
                 gi[r] = me ? ng : gi[r]; sp1[r] = me ? nsp1 : sp1[r];

@@ -211,6 +211,17 @@ int  telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *
                     const int32_t *t_len, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb,
                     const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);
 
+/* The same file made on the DEVICE from what is already resident there (the reads, the reference, the CIGARs): NM / MD / cs /
+ * SA, the 4-bit SEQ, the coordinate sort (refID, position, forward before reverse strand, then query order) and the BGZF
+ * blocks (CRC-32 included) are computed by kernels, the host only moves the finished file image into `bam_path` and writes
+ * the .bai.  `queries` = the set the result was mapped from, `idx` = the index it was mapped against (its targets supply the
+ * reference bases).  No ASCII sequences are needed.  level 0 = stored BGZF blocks; level >= 1 = deflate blocks coded on
+ * the device (Huffman tables per BAM field class, run-length matches).  Bases print as the engine sees them: A C G T, anything
+ * else N (telr_write_bam / telr_write_sam print the same, so the uncompressed streams of the two writers are equal). */
+int  telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx,
+                        const char *const *qnames, const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm,
+                        const char *rg_lb, const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);
+
 /* ---- fused "samtools depth -aa -r | median" (D) --------------------------------
  * For n_iv intervals (target id, 0-based start, 0-based INCLUSIVE end — the
  * reference feeds 0-based numbers into samtools' 1-based inclusive region

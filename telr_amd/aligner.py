@@ -212,6 +212,21 @@ class Index:
                                                 tb.ctypes.data, to.ctypes.data, tl.ctypes.data, flags, rg_id, rg_sm, rg_lb,
                                                 cmdline.encode(), path.encode(), 1 if index else 0, level), "telr_write_bam")
 
+    def write_bam_device(self, r, queries, qnames, tnames, path, md=True, cs=True, softclip=True, rg=None, cmdline="telr_map",
+                         index=True, level=1, unmapped=True):
+        """the same file built on the device from the resident reads / reference / CIGARs (telr_write_bam_dev);
+        queries = the SeqSet the result was mapped from"""
+        qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
+        flags = (1 if md else 0) | (2 if cs else 0) | (4 if softclip else 0) | (0 if unmapped else 8)
+        rg_id, rg_sm, rg_lb = (None, None, None) if rg is None else tuple(x.encode() for x in rg)
+        self.eng._chk(self.eng.L.telr_write_bam_dev(self.eng.h, r, queries.h, self.h, qa, ta, flags, rg_id, rg_sm, rg_lb,
+                                                    cmdline.encode(), path.encode(), 1 if index else 0, level), "telr_write_bam_dev")
+
+    def bam_stage_ms(self):
+        a = np.zeros(8, np.float32)
+        self.eng.L.telr_debug_bam_ms(a.ctypes.data)
+        return dict(zip(("upload", "scan_size", "sort_offsets", "write_records", "bgzf", "d2h_file", "bai_host_overlapped", "total"), (float(x) for x in a)))
+
     def depth_medians(self, r, iv_tid, iv_s, iv_e):
         """Medians over 0-based inclusive intervals, from a raw result handle."""
         tl = self.targets.len

@@ -1,0 +1,746 @@
+// bam_dev.hip.h — the stage-1 hand-off H1 built on the device: coordinate-sorted BAM + .bai straight from the resident
+// reads, reference and CIGARs (replaces `samtools sort -o BAM SAM; samtools index BAM`, reference
+// src/telr/TELR_alignment.py:103-114, and the SAM text minimap2 / ngmlr would have written first, :28-82).
+//
+// Included at the end of telr_engine.hip (same translation unit: it uses the context's grow-only buffers).
+//
+//   host: records of the result (+ one pseudo record per unmapped read), CIGAR array, names  -> HBM
+//   k_bam_scan   one wave per record: walks the CIGAR against the 2-bit reads / reference, 64 ops per trip
+//                -> NM, lengths of the MD and cs strings, inserted / deleted bases (for SA)
+//   k_bam_size   one thread per record: SA length, record size, sort key (refID, pos, strand)
+//   rocPRIM      stable radix sort of the keys, scan of the sizes in sorted order -> offset of every record
+//   k_bam_write  one wave per record: the whole BAM record (fixed part, name, CIGAR, 4-bit SEQ, QUAL 0xff, tags with
+//                MD / cs / SA text) at its place of the uncompressed stream
+//   k_bgzf_*     one workgroup per 65280-byte block of that stream: CRC-32 + framing (level 0: stored blocks;
+//                level >= 1: Huffman-coded deflate blocks, see below)
+//   host: DMA of the finished file image in chunks through a pinned ring into the file, .bai from the record offsets
+//
+// Byte-level work bounded by HBM and then by PCIe / the file system: no matrix cores anywhere.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <deque>
+
+#define BAM_BLK 65280            /* uncompressed bytes per BGZF block (as the host writer) */
+
+struct BamInfo { int32_t nm, md_len, cs_len, nI, nD; };
+struct BamArgs {
+    const telr_aln *alns; int32_t nrec, n_mapped;
+    const uint32_t *cig;
+    const uint32_t *q2, *qn; const int64_t *qboff;
+    const uint32_t *t2, *tn; const int64_t *tboff;
+    const char *qnames; const int64_t *qname_off;      // names with their NUL; [nq + 1]
+    const char *tnames; const int32_t *tname_off;      // [nt + 1]
+    const char *rg; int32_t rg_len;                     // 0 = no RG tag
+    int32_t flags;                                      // TELR_SAM_*
+    BamInfo *info; uint32_t *rec_size; uint64_t *key; const uint64_t *rec_ustart; uint8_t *ubuf;
+};
+
+typedef uint32_t __attribute__((aligned(1))) u32_unal;
+__device__ __forceinline__ void d_st32(uint8_t *p, uint32_t v) { *(u32_unal*)p = v; }
+__device__ __forceinline__ void d_st16(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+__device__ __forceinline__ int d_ndig(uint32_t v)
+{
+    return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) + (v >= 1000000000u);
+}
+__device__ __forceinline__ uint8_t *d_put_uint(uint8_t *p, uint32_t v)
+{
+    const int nd = d_ndig(v);
+    for (int i = nd - 1; i >= 0; --i) { p[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
+    return p + nd;
+}
+__device__ __forceinline__ int d_wave_sum(int v) { for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s); return v; }
+// inclusive prefix sum over the wave
+__device__ __forceinline__ int d_wave_incl(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
+    return v;
+}
+
+// 32 bases x .. x+31 of a sequence (first base at base offset b0 of the packed arrays, L bases) read on strand `rev`
+// (1: the reverse complement, x counted from its own start), first base in the low bits; n = ambiguity bits.
+// Positions beyond the sequence hold garbage.
+struct B32 { uint64_t w; uint32_t n; };
+__device__ __forceinline__ B32 d_fetch32(const uint32_t *__restrict__ s2, const uint32_t *__restrict__ nm, int64_t b)
+{
+    B32 r;
+    const int64_t w = b >> 4; const int sh = (int)(b & 15) * 2;
+    const uint64_t lo = (uint64_t)s2[w] | (uint64_t)s2[w + 1] << 32, hi = s2[w + 2];
+    r.w = sh ? (lo >> sh | hi << (64 - sh)) : lo;
+    const int64_t wn = b >> 5; const int shn = (int)(b & 31);
+    r.n = (uint32_t)(((uint64_t)nm[wn] | (uint64_t)nm[wn + 1] << 32) >> shn);
+    return r;
+}
+__device__ __forceinline__ B32 d_strand32(const uint32_t *__restrict__ s2, const uint32_t *__restrict__ nm, int64_t b0, int L, int rev, int x)
+{
+    if (!rev) return d_fetch32(s2, nm, b0 + x);
+    int f0 = L - 32 - x;
+    const int pad = f0 < 0 ? -f0 : 0;
+    if (f0 < 0) f0 = 0;
+    B32 f = d_fetch32(s2, nm, b0 + f0);
+    if (pad) { f.w = pad < 32 ? f.w << (2 * pad) : 0; f.n = pad < 32 ? f.n << pad : 0; }
+    B32 r;
+    const uint64_t t = __brevll(f.w);
+    r.w = ~(((t & 0x5555555555555555ULL) << 1) | ((t >> 1) & 0x5555555555555555ULL));
+    r.n = __brev(f.n);
+    return r;
+}
+// bit j set = columns j of the two 32-base words differ (or either base is ambiguous); limited to `n` columns
+__device__ __forceinline__ uint32_t d_mis32(const B32 &q, const B32 &t, int n)
+{
+    uint64_t x = q.w ^ t.w;
+    x = (x | x >> 1) & 0x5555555555555555ULL;
+    x = (x | x >> 1) & 0x3333333333333333ULL;
+    x = (x | x >> 2) & 0x0f0f0f0f0f0f0f0fULL;
+    x = (x | x >> 4) & 0x00ff00ff00ff00ffULL;
+    x = (x | x >> 8) & 0x0000ffff0000ffffULL;
+    x = (x | x >> 16) & 0xffffffffULL;
+    const uint32_t m = (uint32_t)x | q.n | t.n;
+    return n >= 32 ? m : m & ((1u << n) - 1u);
+}
+__device__ __forceinline__ uint8_t d_base_char(const B32 &b, int j) { return (b.n >> j & 1u) ? (uint8_t)'N' : (uint8_t)("ACGT"[(b.w >> (2 * j)) & 3u]); }
+
+// 8 bases (2-bit codes in the low 16 bits of c, ambiguity bits in the low 8 bits of n) -> 4 bytes of BAM 4-bit codes
+// (A 1, C 2, G 4, T 8, N 15; first base of a pair in the HIGH nibble)
+__device__ __forceinline__ uint32_t d_nib8(uint32_t c, uint32_t n)
+{
+    uint32_t x = c & 0xffffu;
+    x = (x | x << 8) & 0x00ff00ffu; x = (x | x << 4) & 0x0f0f0f0fu; x = (x | x << 2) & 0x33333333u;
+    const uint32_t b0 = x & 0x11111111u, b1 = (x >> 1) & 0x11111111u, n0 = b0 ^ 0x11111111u, n1 = b1 ^ 0x11111111u;
+    uint32_t r = (n1 & n0) | (n1 & b0) << 1 | (b1 & n0) << 2 | (b1 & b0) << 3;
+    uint32_t m = n & 0xffu;
+    m = (m | m << 12) & 0x000f000fu; m = (m | m << 6) & 0x03030303u; m = (m | m << 3) & 0x11111111u;
+    r |= m * 15u;
+    return (r & 0x0f0f0f0fu) << 4 | (r >> 4 & 0x0f0f0f0fu);
+}
+
+__device__ __forceinline__ int d_reg2bin(int beg, int end)
+{
+    --end;
+    if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (beg >> 14);
+    if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (beg >> 17);
+    if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (beg >> 20);
+    if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (beg >> 23);
+    if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (beg >> 26);
+    return 0;
+}
+
+// ---- the CIGAR walk of one record by one wave: 64 ops per trip ---------------------------------------------------------
+// MD: numbers count the matching columns since the last mismatch / deletion and run on across insertions and op
+// boundaries, so the count a lane starts with is a segmented sum over the lanes before it (and the trips before this one).
+// cs (short form): every op is self-contained.  WRITE = false: lengths only.
+template <bool WRITE>
+__device__ __forceinline__ void d_bam_walk(const BamArgs &A, const telr_aln &a, int lane, uint8_t *md_p, uint8_t *cs_p, BamInfo &out)
+{
+    const int rev = (a.flags & TELR_F_REV) ? 1 : 0;
+    const int ql = a.qlen;
+    const int64_t qb0 = A.qboff[a.qid], tb0 = A.tboff[a.tid];
+    const uint32_t *__restrict__ cg = A.cig + a.cigar_off;
+    const bool want_md = (A.flags & TELR_SAM_MD) != 0, want_cs = (A.flags & TELR_SAM_CS) != 0;
+    int qi0 = rev ? ql - a.qe : a.qs, ti0 = a.ts;
+    uint32_t carry = 0;
+    int nm = 0, nI = 0, nD = 0, md_sum = 0, cs_sum = 0;
+    uint32_t md_base = 0, cs_base = 0;
+    for (int z0 = 0; z0 < a.n_cigar; z0 += 64) {
+        const int z = z0 + lane;
+        const bool have = z < a.n_cigar;
+        const uint32_t c = have ? cg[z] : 0u;
+        const int op = (int)(c & 0xfu), L = (int)(c >> 4);
+        const int qadv = (have && op != 2) ? L : 0, tadv = (have && op != 1) ? L : 0;
+        const int qinc = d_wave_incl(qadv, lane), tinc = d_wave_incl(tadv, lane);
+        const int qi = qi0 + qinc - qadv, ti = ti0 + tinc - tadv;
+        // ---- what this op contributes
+        bool ev = false; uint32_t lead = 0, trail = 0, tot = 0; int md_rest = 0, cs_b = 0;
+        if (have) {
+            if (op == 0) {
+                int first = -1, last = -1;
+                for (int p0 = 0; p0 < L; p0 += 32) {
+                    const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0), tw = d_fetch32(A.t2, A.tn, tb0 + ti + p0);
+                    uint32_t mis = d_mis32(qw, tw, L - p0);
+                    nm += __popc(mis);
+                    while (mis) {
+                        const int p = p0 + __ffs((int)mis) - 1; mis &= mis - 1u;
+                        const uint32_t r_ = (uint32_t)(p - last - 1);
+                        if (first < 0) { first = p; md_rest += 1; } else md_rest += d_ndig(r_) + 1;
+                        cs_b += (r_ ? 1 + d_ndig(r_) : 0) + 3;
+                        last = p;
+                    }
+                }
+                if (first >= 0) { ev = true; lead = (uint32_t)first; trail = (uint32_t)(L - 1 - last); } else tot = (uint32_t)L;
+                const uint32_t tail = (uint32_t)(L - 1 - last);
+                if (tail) cs_b += 1 + d_ndig(tail);
+            } else if (op == 1) { nm += L; nI += L; cs_b = 1 + L; }
+            else { nm += L; nD += L; ev = true; md_rest = 1 + L; cs_b = 1 + L; }
+        }
+        // ---- matching columns since the last MD event before this lane
+        uint32_t s = ev ? trail : tot; int f = ev ? 1 : 0;
+        if (lane == 0 && !ev) s += carry;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ps = (uint32_t)__shfl_up((int)s, o); const int pf = __shfl_up(f, o);
+            if (lane >= o) { if (!f) s += ps; f |= pf; }
+        }
+        uint32_t run_in = (uint32_t)__shfl_up((int)s, 1);
+        if (lane == 0) run_in = carry;
+        carry = (uint32_t)__shfl((int)s, 63);
+        int md_b = (ev && want_md) ? d_ndig(run_in + lead) + md_rest : 0;
+        if (!want_cs) cs_b = 0;
+        if (!WRITE) { md_sum += md_b; cs_sum += cs_b; }
+        else {
+            const int mdi = d_wave_incl(md_b, lane), csi = d_wave_incl(cs_b, lane);
+            uint8_t *mp = md_p + md_base + (uint32_t)(mdi - md_b), *cp = cs_p + cs_base + (uint32_t)(csi - cs_b);
+            md_base += (uint32_t)__shfl(mdi, 63); cs_base += (uint32_t)__shfl(csi, 63);
+            if (have) {
+                if (op == 0) {
+                    int last = -1; bool firstev = true;
+                    for (int p0 = 0; p0 < L; p0 += 32) {
+                        const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0), tw = d_fetch32(A.t2, A.tn, tb0 + ti + p0);
+                        uint32_t mis = d_mis32(qw, tw, L - p0);
+                        while (mis) {
+                            const int j = __ffs((int)mis) - 1, p = p0 + j; mis &= mis - 1u;
+                            const uint32_t r_ = (uint32_t)(p - last - 1);
+                            const uint8_t tc = d_base_char(tw, j), qc = d_base_char(qw, j);
+                            if (want_md) { mp = d_put_uint(mp, firstev ? run_in + r_ : r_); *mp++ = tc; }
+                            if (want_cs) { if (r_) { *cp++ = ':'; cp = d_put_uint(cp, r_); } *cp++ = '*'; *cp++ = tc | 32; *cp++ = qc | 32; }
+                            firstev = false; last = p;
+                        }
+                    }
+                    const uint32_t tail = (uint32_t)(L - 1 - last);
+                    if (want_cs && tail) { *cp++ = ':'; cp = d_put_uint(cp, tail); }
+                } else if (op == 1) {
+                    if (want_cs) {
+                        *cp++ = '+';
+                        for (int p0 = 0; p0 < L; p0 += 32) { const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0); const int n = L - p0 < 32 ? L - p0 : 32; for (int j = 0; j < n; ++j) *cp++ = d_base_char(qw, j) | 32; }
+                    }
+                } else {
+                    if (want_md) { mp = d_put_uint(mp, run_in); *mp++ = '^'; }
+                    if (want_cs) *cp++ = '-';
+                    for (int p0 = 0; p0 < L; p0 += 32) {
+                        const B32 tw = d_fetch32(A.t2, A.tn, tb0 + ti + p0); const int n = L - p0 < 32 ? L - p0 : 32;
+                        for (int j = 0; j < n; ++j) { const uint8_t tc = d_base_char(tw, j); if (want_md) *mp++ = tc; if (want_cs) *cp++ = tc | 32; }
+                    }
+                }
+            }
+        }
+        qi0 += __shfl(qinc, 63); ti0 += __shfl(tinc, 63);
+    }
+    if (!WRITE) {
+        out.nm = d_wave_sum(nm); out.nI = d_wave_sum(nI); out.nD = d_wave_sum(nD);
+        out.md_len = want_md ? d_wave_sum(md_sum) + d_ndig(carry) : 0;
+        out.cs_len = d_wave_sum(cs_sum);
+    } else if (want_md && lane == 0) d_put_uint(md_p + md_base, carry);
+}
+
+__global__ void __launch_bounds__(64) k_bam_scan(BamArgs A)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= A.n_mapped) return;
+    const telr_aln a = A.alns[k];
+    BamInfo I;
+    d_bam_walk<false>(A, a, lane, nullptr, nullptr, I);
+    if (lane == 0) A.info[k] = I;
+}
+
+// the SA tag of record k: the other primary / supplementary records of the read, `rname,pos,strand,CIGAR,mapQ,NM;` each
+// (CIGAR reduced to clip / M / I / D totals as minimap2 prints it).  p == nullptr: length only.
+__device__ __forceinline__ uint8_t *d_put_str(uint8_t *p, const char *s, int n) { for (int i = 0; i < n; ++i) p[i] = (uint8_t)s[i]; return p + n; }
+__device__ int d_bam_sa(const BamArgs &A, int k, uint8_t *p)
+{
+    const telr_aln &a = A.alns[k];
+    int i0 = k, i1 = k + 1;
+    while (i0 > 0 && A.alns[i0 - 1].qid == a.qid) --i0;
+    while (i1 < A.n_mapped && A.alns[i1].qid == a.qid) ++i1;
+    int n = 0;
+    for (int k2 = i0; k2 < i1; ++k2) {
+        const telr_aln &b = A.alns[k2];
+        if (k2 == k || (b.flags & TELR_F_SECONDARY)) continue;
+        const bool brev = (b.flags & TELR_F_REV) != 0;
+        const int ql = b.qlen, b5 = brev ? ql - b.qe : b.qs, b3 = brev ? b.qs : ql - b.qe;
+        const int nI = A.info[k2].nI, nD = A.info[k2].nD, M = (b.qe - b.qs) - nI, nmm = b.blen - b.mlen;
+        const int tn0 = A.tname_off[b.tid], tnl = A.tname_off[b.tid + 1] - tn0 - 1;
+        n += tnl + 1 + d_ndig((uint32_t)(b.ts + 1)) + 3 + (b5 ? d_ndig((uint32_t)b5) + 1 : 0) + d_ndig((uint32_t)M) + 1 + (nI ? d_ndig((uint32_t)nI) + 1 : 0)
+             + (nD ? d_ndig((uint32_t)nD) + 1 : 0) + (b3 ? d_ndig((uint32_t)b3) + 1 : 0) + 1 + d_ndig((uint32_t)b.mapq) + 1 + d_ndig((uint32_t)nmm) + 1;
+        if (p) {
+            p = d_put_str(p, A.tnames + tn0, tnl); *p++ = ',';
+            p = d_put_uint(p, (uint32_t)(b.ts + 1)); *p++ = ','; *p++ = brev ? '-' : '+'; *p++ = ',';
+            if (b5) { p = d_put_uint(p, (uint32_t)b5); *p++ = 'S'; }
+            p = d_put_uint(p, (uint32_t)M); *p++ = 'M';
+            if (nI) { p = d_put_uint(p, (uint32_t)nI); *p++ = 'I'; }
+            if (nD) { p = d_put_uint(p, (uint32_t)nD); *p++ = 'D'; }
+            if (b3) { p = d_put_uint(p, (uint32_t)b3); *p++ = 'S'; }
+            *p++ = ','; p = d_put_uint(p, (uint32_t)b.mapq); *p++ = ','; p = d_put_uint(p, (uint32_t)nmm); *p++ = ';';
+        }
+    }
+    return n;
+}
+
+// field sizes of a record (shared by the size and the write kernel)
+struct BamLayout { int l_name, clip5, clip3, hard, n_cig, long_cigar, seq_lo, l_seq, sec, sup, rev; };
+__device__ __forceinline__ BamLayout d_bam_layout(const BamArgs &A, const telr_aln &a)
+{
+    BamLayout Y;
+    Y.l_name = (int)(A.qname_off[a.qid + 1] - A.qname_off[a.qid]);
+    if (a.tid < 0) { Y.clip5 = Y.clip3 = Y.hard = Y.n_cig = Y.long_cigar = Y.seq_lo = Y.sec = Y.sup = Y.rev = 0; Y.l_seq = a.qlen; return Y; }
+    Y.rev = (a.flags & TELR_F_REV) ? 1 : 0; Y.sec = (a.flags & TELR_F_SECONDARY) ? 1 : 0; Y.sup = (a.flags & TELR_F_SUPPL) ? 1 : 0;
+    Y.clip5 = Y.rev ? a.qlen - a.qe : a.qs; Y.clip3 = Y.rev ? a.qs : a.qlen - a.qe;
+    Y.hard = Y.sup && !(A.flags & TELR_SAM_SOFTCLIP);
+    Y.n_cig = a.n_cigar + (Y.clip5 > 0) + (Y.clip3 > 0);
+    Y.long_cigar = Y.n_cig > 65535;
+    Y.seq_lo = Y.sec ? 0 : (Y.hard ? Y.clip5 : 0);
+    Y.l_seq = Y.sec ? 0 : (Y.hard ? a.qlen - Y.clip5 - Y.clip3 : a.qlen);
+    return Y;
+}
+
+__global__ void __launch_bounds__(256) k_bam_size(BamArgs A)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= A.nrec) return;
+    const telr_aln a = A.alns[k];
+    const BamLayout Y = d_bam_layout(A, a);
+    const int rg = A.rg_len ? 3 + A.rg_len + 1 : 0;
+    uint32_t size;
+    if (a.tid < 0) {
+        size = 36u + Y.l_name + (uint32_t)(Y.l_seq + 1) / 2 + Y.l_seq + rg;
+        A.key[k] = ~0ULL;
+    } else {
+        const BamInfo I = A.info[k];
+        const int sa = Y.sec ? 0 : d_bam_sa(A, k, nullptr);
+        size = 36u + Y.l_name + 4u * (Y.long_cigar ? 2 : Y.n_cig) + (uint32_t)(Y.l_seq + 1) / 2 + Y.l_seq + 14
+               + ((A.flags & TELR_SAM_MD) ? 3 + I.md_len + 1 : 0) + ((A.flags & TELR_SAM_CS) ? 3 + I.cs_len + 1 : 0) + (sa ? 3 + sa + 1 : 0)
+               + 4 + 7 + 7 + (Y.sec ? 0 : 7) + rg + (Y.long_cigar ? 8 + 4 * Y.n_cig : 0);
+        A.key[k] = (uint64_t)(a.tid + 1) << 33 | (uint64_t)(uint32_t)a.ts << 1 | (uint64_t)Y.rev;     // samtools sort: refID, pos, then forward before reverse
+    }
+    A.rec_size[k] = size;
+}
+
+__global__ void __launch_bounds__(256) k_bam_gather_sizes(const uint32_t *__restrict__ rec_size, const uint32_t *__restrict__ order, int32_t n, uint64_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = rec_size[order[i]]; else if (i == n) out[i] = 0;
+}
+__global__ void __launch_bounds__(256) k_bam_scatter_off(const uint64_t *__restrict__ ustart_sorted, const uint32_t *__restrict__ order, int32_t n, uint64_t head, uint64_t *__restrict__ rec_ustart)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rec_ustart[order[i]] = ustart_sorted[i] + head;
+}
+__global__ void __launch_bounds__(256) k_iota_u32(uint32_t *__restrict__ v, int32_t n) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) v[i] = (uint32_t)i; }
+
+__device__ __forceinline__ uint8_t *d_tag_i(uint8_t *p, char a, char b, int32_t v) { p[0] = (uint8_t)a; p[1] = (uint8_t)b; p[2] = 'i'; d_st32(p + 3, (uint32_t)v); return p + 7; }
+
+__global__ void __launch_bounds__(64) k_bam_write(BamArgs A)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k >= A.nrec) return;
+    const telr_aln a = A.alns[k];
+    const BamLayout Y = d_bam_layout(A, a);
+    uint8_t *const rec = A.ubuf + A.rec_ustart[k];
+    const uint32_t size = A.rec_size[k];
+    const bool un = a.tid < 0;
+    const int n_cig_field = un ? 0 : (Y.long_cigar ? 2 : Y.n_cig);
+    uint8_t *const p_name = rec + 36, *const p_cig = p_name + Y.l_name, *const p_seq = p_cig + 4 * n_cig_field,
+            *const p_qual = p_seq + (Y.l_seq + 1) / 2, *const p_tags = p_qual + Y.l_seq;
+    BamInfo I = {0, 0, 0, 0, 0};
+    if (!un) I = A.info[k];
+    const bool want_md = (A.flags & TELR_SAM_MD) != 0, want_cs = (A.flags & TELR_SAM_CS) != 0;
+    // tag offsets (mapped records)
+    uint8_t *p_md = p_tags + 14, *p_cs = p_md + (want_md ? 3 + I.md_len + 1 : 0), *p_sa = p_cs + (want_cs ? 3 + I.cs_len + 1 : 0);
+    if (lane == 0) {
+        d_st32(rec, size - 4u);
+        d_st32(rec + 4, un ? 0xffffffffu : (uint32_t)a.tid); d_st32(rec + 8, un ? 0xffffffffu : (uint32_t)a.ts);
+        rec[12] = (uint8_t)Y.l_name; rec[13] = un ? 0 : (uint8_t)a.mapq;
+        d_st16(rec + 14, un ? 4680u : (uint32_t)d_reg2bin(a.ts, a.te > a.ts ? a.te : a.ts + 1));
+        d_st16(rec + 16, (uint32_t)n_cig_field);
+        d_st16(rec + 18, un ? 4u : (uint32_t)((Y.rev ? 0x10 : 0) | (Y.sec ? 0x100 : 0) | (Y.sup ? 0x800 : 0)));
+        d_st32(rec + 20, (uint32_t)Y.l_seq); d_st32(rec + 24, 0xffffffffu); d_st32(rec + 28, 0xffffffffu); d_st32(rec + 32, 0u);
+    }
+    { const char *nm = A.qnames + A.qname_off[a.qid]; for (int i = lane; i < Y.l_name; i += 64) p_name[i] = (uint8_t)nm[i]; }
+    // CIGAR (with clips), or the -L placeholder plus the real one in CG:B,I at the end of the tags
+    if (!un) {
+        const uint32_t clipop = Y.hard ? 5u : 4u;
+        uint8_t *dst = Y.long_cigar ? rec + size - 4 * Y.n_cig : p_cig;
+        const uint32_t *__restrict__ cg = A.cig + a.cigar_off;
+        const int lead = Y.clip5 > 0 ? 1 : 0;
+        for (int i = lane; i < Y.n_cig; i += 64) {
+            uint32_t v;
+            if (i < lead) v = (uint32_t)Y.clip5 << 4 | clipop; else if (i - lead < a.n_cigar) v = cg[i - lead]; else v = (uint32_t)Y.clip3 << 4 | clipop;
+            d_st32(dst + 4 * i, v);
+        }
+        if (Y.long_cigar && lane == 0) {
+            d_st32(p_cig, (uint32_t)Y.l_seq << 4 | 4u); d_st32(p_cig + 4, (uint32_t)(a.te - a.ts) << 4 | 3u);
+            uint8_t *t = rec + size - 4 * Y.n_cig - 8; t[0] = 'C'; t[1] = 'G'; t[2] = 'B'; t[3] = 'I'; d_st32(t + 4, (uint32_t)Y.n_cig);
+        }
+    }
+    // SEQ: 32 bases (16 bytes) per lane and trip; QUAL: 0xff
+    {
+        const int64_t qb0 = A.qboff[a.qid];
+        for (int i = lane * 32; i < Y.l_seq; i += 64 * 32) {
+            const B32 w = d_strand32(A.q2, A.qn, qb0, a.qlen, Y.rev, Y.seq_lo + i);
+            const int n = Y.l_seq - i < 32 ? Y.l_seq - i : 32;
+            uint8_t *d = p_seq + (i >> 1);
+            if (n == 32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) d_st32(d + 4 * g, d_nib8((uint32_t)(w.w >> (16 * g)), w.n >> (8 * g)));
+            } else {
+                for (int g = 0; g * 8 < n; ++g) {
+                    const int m = n - g * 8 < 8 ? n - g * 8 : 8;
+                    uint32_t c = (uint32_t)(w.w >> (16 * g)) & 0xffffu, nn = (w.n >> (8 * g)) & 0xffu;
+                    if (m < 8) { c &= (1u << (2 * m)) - 1u; nn &= (1u << m) - 1u; }
+                    uint32_t v = d_nib8(c, nn);
+                    // bases beyond m come out as 'A' (code 1): clear them
+                    for (int b = 0; b < (m + 1) / 2; ++b) { uint32_t byte = (v >> (8 * b)) & 0xffu; if (2 * b + 1 >= m) byte &= 0xf0u; d[4 * g + b] = (uint8_t)byte; }
+                }
+            }
+        }
+        const int head = (int)((4 - ((uintptr_t)p_qual & 3)) & 3), nh = head < Y.l_seq ? head : Y.l_seq;
+        if (lane < nh) p_qual[lane] = 0xff;
+        const int body = (Y.l_seq - nh) >> 2;
+        uint32_t *q4 = (uint32_t*)(p_qual + nh);
+        for (int i = lane; i < body; i += 64) q4[i] = 0xffffffffu;
+        const int tail0 = nh + body * 4;
+        if (tail0 + lane < Y.l_seq && lane < 4) p_qual[tail0 + lane] = 0xff;
+    }
+    if (un) {
+        if (A.rg_len && lane == 0) { uint8_t *t = p_tags; t[0] = 'R'; t[1] = 'G'; t[2] = 'Z'; t = d_put_str(t + 3, A.rg, A.rg_len); *t = 0; }
+        return;
+    }
+    // tags: NM AS [MD] [cs] [SA] tp cm s1 [s2] [RG] [CG]
+    BamInfo dummy;
+    d_bam_walk<true>(A, a, lane, p_md + 3, p_cs + 3, dummy);
+    if (lane == 0) {
+        uint8_t *t = d_tag_i(p_tags, 'N', 'M', I.nm); d_tag_i(t, 'A', 'S', a.dp_score);
+        if (want_md) { p_md[0] = 'M'; p_md[1] = 'D'; p_md[2] = 'Z'; p_md[3 + I.md_len] = 0; }
+        if (want_cs) { p_cs[0] = 'c'; p_cs[1] = 's'; p_cs[2] = 'Z'; p_cs[3 + I.cs_len] = 0; }
+        t = p_sa;
+        if (!Y.sec) {
+            const int sa = d_bam_sa(A, k, nullptr);
+            if (sa) { t[0] = 'S'; t[1] = 'A'; t[2] = 'Z'; d_bam_sa(A, k, t + 3); t[3 + sa] = 0; t += 3 + sa + 1; }
+        }
+        t[0] = 't'; t[1] = 'p'; t[2] = 'A'; t[3] = Y.sec ? 'S' : 'P'; t += 4;
+        t = d_tag_i(t, 'c', 'm', a.cnt); t = d_tag_i(t, 's', '1', a.score);
+        if (!Y.sec) t = d_tag_i(t, 's', '2', a.subsc);
+        if (A.rg_len) { t[0] = 'R'; t[1] = 'G'; t[2] = 'Z'; t = d_put_str(t + 3, A.rg, A.rg_len); *t++ = 0; }
+    }
+}
+
+// ---- CRC-32 (IEEE, reflected 0xEDB88320) of a BGZF block by 256 threads: every thread its own piece, then
+// crc(A || B) = crc(A) * x^(8|B|) + crc(B) over GF(2) (the identity behind zlib's crc32_combine)
+struct CrcTabs { uint32_t byte_tab[256]; uint32_t xpow255[256]; };      // xpow255[k] = x^(8 * 255 * k) mod P
+__device__ __forceinline__ uint32_t d_gf2_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m; m >>= 1) { if (a & m) p ^= b; b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1; }
+    return p;
+}
+// block-wide: CRC-32 of n bytes in LDS (n == BAM_BLK: pieces of 255 bytes; otherwise thread 0 alone).  All 256 threads call; result valid in thread 0.
+__device__ __forceinline__ uint32_t d_block_crc(const uint8_t *sh, int n, const uint32_t *tab, const uint32_t *xp, uint32_t *red)
+{
+    const int t = threadIdx.x;
+    uint32_t c = 0;
+    if (n == BAM_BLK) {
+        uint32_t s = 0xffffffffu;
+        const uint8_t *p = sh + t * 255;
+        for (int i = 0; i < 255; ++i) s = tab[(s ^ p[i]) & 0xffu] ^ (s >> 8);
+        c = d_gf2_mulmod(xp[255 - t], ~s);
+    } else if (t == 0) {
+        uint32_t s = 0xffffffffu;
+        for (int i = 0; i < n; ++i) s = tab[(s ^ sh[i]) & 0xffu] ^ (s >> 8);
+        c = ~s;
+    }
+    for (int s = 32; s >= 1; s >>= 1) c ^= (uint32_t)__shfl_xor((int)c, s);
+    if ((t & 63) == 0) red[t >> 6] = c;
+    __syncthreads();
+    return red[0] ^ red[1] ^ red[2] ^ red[3];
+}
+
+// level 0: one stored deflate block per BGZF block.  out block b at b * (BAM_BLK + 31).
+__global__ void __launch_bounds__(256) k_bgzf_store(const uint8_t *__restrict__ ubuf, uint64_t utotal, const CrcTabs *__restrict__ T, uint8_t *__restrict__ cbuf)
+{
+    __shared__ uint32_t sh4[BAM_BLK / 4];
+    __shared__ uint32_t tab[256], xp[256], red[4];
+    const int t = threadIdx.x;
+    const uint64_t b = blockIdx.x, u0 = b * BAM_BLK;
+    const int n = (int)(utotal - u0 < BAM_BLK ? utotal - u0 : BAM_BLK);
+    tab[t] = T->byte_tab[t]; xp[t] = T->xpow255[t];
+    uint8_t *sh = (uint8_t*)sh4;
+    uint8_t *out = cbuf + b * (uint64_t)(BAM_BLK + 31);
+    // the stream is read in aligned dwords (its start u0 is a multiple of 4: BAM_BLK is)
+    const uint32_t *src4 = (const uint32_t*)(ubuf + u0);
+    const int n4 = (n + 3) >> 2;
+    for (int i = t; i < n4; i += 256) sh4[i] = src4[i];          // ubuf is padded to a multiple of 4 by the host
+    __syncthreads();
+    // payload at out + 23 (unaligned by one byte: byte-granular dword stores)
+    for (int i = t; i < (n >> 2); i += 256) d_st32(out + 23 + 4 * i, sh4[i]);
+    for (int i = (n & ~3) + t; i < n; i += 256) out[23 + i] = sh[i];
+    const uint32_t crc = d_block_crc(sh, n, tab, xp, red);
+    if (t == 0) {
+        const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
+        for (int i = 0; i < 16; ++i) out[i] = hdr[i];
+        d_st16(out + 16, (uint32_t)(n + 31 - 1));
+        out[18] = 1; d_st16(out + 19, (uint32_t)n); d_st16(out + 21, (uint32_t)(~n & 0xffff));
+        d_st32(out + 23 + n, crc); d_st32(out + 27 + n, (uint32_t)n);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+static void crc_tabs_make(CrcTabs &T)
+{
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1; T.byte_tab[i] = c; }
+    auto mul = [](uint32_t a, uint32_t b) { uint32_t p = 0; for (uint32_t m = 0x80000000u; m; m >>= 1) { if (a & m) p ^= b; b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1; } return p; };
+    // x^(8*255): start from x^0 = 0x80000000 (reflected) and multiply by x 8*255 times
+    uint32_t x1 = 0x80000000u;
+    for (int i = 0; i < 8 * 255; ++i) x1 = (x1 & 1u) ? (x1 >> 1) ^ 0xEDB88320u : x1 >> 1;
+    T.xpow255[0] = 0x80000000u;
+    for (int k = 1; k < 256; ++k) T.xpow255[k] = mul(T.xpow255[k - 1], x1);
+}
+
+struct BamTimes { float ms[8]; };        // upload, scan+size, sort+scan, write, bgzf, d2h+file, bai (host, overlapped), total
+static BamTimes g_bam_times;
+extern "C" int telr_debug_bam_ms(float *out) { if (!out) return TELR_E_ARG; memcpy(out, g_bam_times.ms, sizeof(g_bam_times.ms)); return TELR_OK; }
+
+// the .bai of a coordinate-sorted record sequence: alns in sorted order through `order`, uncompressed start of every
+// record (sorted order, [nrec + 1]) and the file offset of every BGZF block ([nblk + 1])
+static void bai_build(const std::vector<telr_aln> &recs, const uint32_t *order, size_t nrec, size_t n_unmapped, const uint64_t *ustart, const uint64_t *coff, size_t nblk,
+                      int32_t n_targets, const int32_t *t_len, std::string &bai)
+{
+    auto put32 = [&](uint32_t v) { bai.append((const char*)&v, 4); };
+    auto voff = [&](uint64_t u) { size_t b = (size_t)(u / BAM_BLK); if (b >= nblk) return (uint64_t)(coff[nblk] << 16); return (uint64_t)(coff[b] << 16 | (u - (uint64_t)b * BAM_BLK)); };
+    bai = "BAI\1"; put32((uint32_t)n_targets);
+    size_t i = 0;
+    const size_t n_mapped = nrec - n_unmapped;
+    struct Ch { uint32_t bin; uint64_t vb, ve; };
+    std::vector<Ch> chs;
+    for (int t = 0; t < n_targets; ++t) {
+        chs.clear();
+        const int n_lin = (t_len[t] >> 14) + 1;
+        std::vector<uint64_t> lin(n_lin, 0);
+        int max_lin = 0;
+        uint64_t ref_beg = 0, ref_end = 0, n_map = 0;
+        bool any = false;
+        while (i < n_mapped && recs[order[i]].tid == t) {
+            const telr_aln &a = recs[order[i]];
+            const uint64_t vb = voff(ustart[i]), ve = voff(ustart[i + 1]);
+            const int e = a.te > a.ts ? a.te : a.ts + 1;
+            chs.push_back(Ch{ (uint32_t)reg2bin(a.ts, e), vb, ve });
+            const int w0 = a.ts >> 14, w1 = (e - 1) >> 14;
+            for (int wv = w0; wv <= w1 && wv < n_lin; ++wv) { if (lin[wv] == 0 || vb < lin[wv]) lin[wv] = vb; if (wv + 1 > max_lin) max_lin = wv + 1; }
+            if (!any) { ref_beg = vb; any = true; }
+            ref_end = ve; ++n_map; ++i;
+        }
+        std::stable_sort(chs.begin(), chs.end(), [](const Ch &x, const Ch &y) { return x.bin < y.bin; });
+        // bins in ascending order, chunks of a bin merged while they end and start in the same BGZF block
+        std::string body; uint32_t nbin = 0;
+        for (size_t c0 = 0; c0 < chs.size(); ) {
+            size_t c1 = c0; std::vector<std::pair<uint64_t, uint64_t>> ch;
+            while (c1 < chs.size() && chs[c1].bin == chs[c0].bin) {
+                if (!ch.empty() && (ch.back().second >> 16) == (chs[c1].vb >> 16)) ch.back().second = chs[c1].ve; else ch.push_back(std::make_pair(chs[c1].vb, chs[c1].ve));
+                ++c1;
+            }
+            uint32_t bin = chs[c0].bin, nc = (uint32_t)ch.size();
+            body.append((const char*)&bin, 4); body.append((const char*)&nc, 4);
+            for (auto &c : ch) { body.append((const char*)&c.first, 8); body.append((const char*)&c.second, 8); }
+            ++nbin; c0 = c1;
+        }
+        put32(nbin + (any ? 1 : 0));
+        bai += body;
+        if (any) {   // samtools' metadata pseudo-bin 37450
+            put32(37450u); put32(2u);
+            bai.append((const char*)&ref_beg, 8); bai.append((const char*)&ref_end, 8);
+            uint64_t zero = 0; bai.append((const char*)&n_map, 8); bai.append((const char*)&zero, 8);
+        }
+        for (int wv = 1; wv < max_lin; ++wv) if (lin[wv] == 0) lin[wv] = lin[wv - 1];
+        put32((uint32_t)max_lin);
+        for (int wv = 0; wv < max_lin; ++wv) bai.append((const char*)&lin[wv], 8);
+    }
+    uint64_t n_no_coor = n_unmapped;
+    bai.append((const char*)&n_no_coor, 8);
+}
+
+static std::string bam_header(int32_t n_targets, const char *const *tnames, const int32_t *t_len, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line)
+{
+    std::string head, text = "@HD\tVN:1.6\tSO:coordinate\n";
+    char b[512];
+    for (int t = 0; t < n_targets; ++t) { snprintf(b, sizeof(b), "@SQ\tSN:%s\tLN:%d\n", tnames[t], t_len[t]); text += b; }
+    if (rg_id) { snprintf(b, sizeof(b), "@RG\tID:%s\tSM:%s\tLB:%s\n", rg_id, rg_sm ? rg_sm : rg_id, rg_lb ? rg_lb : "lib"); text += b; }
+    text += "@PG\tID:telr_amd\tPN:telr_amd\tVN:0.1.0\tCL:"; text += pg_line ? pg_line : "telr_map"; text += "\n";
+    auto put32 = [&](uint32_t v) { head.append((const char*)&v, 4); };
+    head += "BAM\1"; put32((uint32_t)text.size()); head += text; put32((uint32_t)n_targets);
+    for (int t = 0; t < n_targets; ++t) { uint32_t ln = (uint32_t)strlen(tnames[t]) + 1; put32(ln); head.append(tnames[t], ln); put32((uint32_t)t_len[t]); }
+    return head;
+}
+
+// Device image [d_img, d_img + bytes) -> file, through a ring of pinned chunks: the DMA of chunk c+1 runs while the writer
+// threads put chunk c into the file.  `tail` (host bytes) is appended.
+static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, const void *tail, size_t tail_bytes, const char *path)
+{
+    const size_t CH = 32u << 20; const int R = 8;
+    uint8_t *ring; TRY(ctx_hbuf_t(ctx, "bam_ring", CH * R, &ring));
+    int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0644);
+    if (fd < 0) { ctx->err = std::string("cannot create ") + path; return TELR_E_ARG; }
+    const size_t nch = (size_t)((bytes + CH - 1) / CH);
+    hipEvent_t ev[8];
+    for (int i = 0; i < R; ++i) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    // One writer thread: a single pwrite stream is what a tmpfs file takes fastest (tools/ubench/shm_io.hip: 6.7 GB/s with
+    // one thread, 3.3-4.5 GB/s with 4-32 -- writes to one inode serialise on its lock and on the page-cache tree)
+    std::mutex mu; std::condition_variable cv; size_t copied = 0, written = 0; bool fail = false;
+    std::thread writer([&] {
+        for (size_t c = 0; c < nch; ++c) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return copied > c || fail; }); if (fail) return; }
+            const size_t n = (size_t)std::min<uint64_t>(CH, bytes - (uint64_t)c * CH);
+            const uint8_t *src = ring + (c % R) * CH;
+            size_t done = 0;
+            while (done < n) { ssize_t w = pwrite(fd, src + done, n - done, (off_t)((uint64_t)c * CH + done)); if (w <= 0) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); return; } done += (size_t)w; }
+            { std::lock_guard<std::mutex> lk(mu); written = c + 1; }
+            cv.notify_all();
+        }
+    });
+    int rc = TELR_OK;
+    size_t issued = 0;
+    for (size_t c = 0; c < nch && rc == TELR_OK; ++c) {
+        // keep up to R - 1 copies ahead of the writer
+        while (issued < nch && issued < c + (size_t)R - 1) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return issued < written + (size_t)R || fail; }); if (fail) break; }
+            const size_t n = (size_t)std::min<uint64_t>(CH, bytes - (uint64_t)issued * CH);
+            if (hipMemcpyAsync(ring + (issued % R) * CH, d_img + (uint64_t)issued * CH, n, hipMemcpyDeviceToHost, ctx->copy_stream) != hipSuccess ||
+                hipEventRecord(ev[issued % R], ctx->copy_stream) != hipSuccess) { rc = TELR_E_HIP; break; }
+            ++issued;
+        }
+        if (rc != TELR_OK || fail) break;
+        if (hipEventSynchronize(ev[c % R]) != hipSuccess) { rc = TELR_E_HIP; break; }
+        { std::lock_guard<std::mutex> lk(mu); copied = c + 1; }
+        cv.notify_all();
+    }
+    if (rc != TELR_OK) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); }
+    writer.join();
+    for (int i = 0; i < R; ++i) (void)hipEventDestroy(ev[i]);
+    if (fail && rc == TELR_OK) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
+    if (rc == TELR_OK && tail_bytes) { if (pwrite(fd, tail, tail_bytes, (off_t)bytes) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
+    close(fd);
+    return rc;
+}
+
+extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
+                                  const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
+                                  const char *bam_path, int32_t write_index, int32_t level)
+{
+    if (!ctx || !r || !queries || !idx || !idx->targets || !qnames || !tnames || !bam_path) return TELR_E_ARG;
+    if (level != 0) { ctx->err = "telr_write_bam_dev: only level 0 (stored BGZF blocks) in this build"; return TELR_E_ARG; }
+    HIPCHK(hipSetDevice(ctx->device));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<float, std::milli>(now() - t0).count(); };
+    const auto t_all = now();
+    memset(&g_bam_times, 0, sizeof(g_bam_times));
+    result_wait(r);
+    hipStream_t st = ctx->stream;
+    const telr_seqset *tg = idx->targets;
+    const int32_t nq = queries->n, nt = tg->n;
+    const size_t n_mapped = r->alns.size();
+    for (const telr_aln &a : r->alns) if (a.qid < 0 || a.qid >= nq || a.tid < 0 || a.tid >= nt) return TELR_E_ARG;
+    // ---- 1. records (+ pseudo records of the unmapped reads, in query order), names, header
+    auto t0 = now();
+    std::vector<telr_aln> recs(r->alns);
+    size_t n_unmapped = 0;
+    if (!(flags & TELR_SAM_NO_UNMAPPED)) {
+        std::vector<uint8_t> has((size_t)nq, 0);
+        for (const telr_aln &a : r->alns) has[a.qid] = 1;
+        for (int q = 0; q < nq; ++q) if (!has[q]) { telr_aln u; memset(&u, 0, sizeof(u)); u.qid = q; u.tid = -1; u.qlen = queries->len[q]; recs.push_back(u); ++n_unmapped; }
+    }
+    const size_t nrec = recs.size();
+    if (nrec >= (1u << 31)) return TELR_E_RANGE;
+    std::vector<int64_t> qn_off((size_t)nq + 1); std::string qn_buf;
+    { int64_t o = 0; for (int q = 0; q < nq; ++q) { qn_off[q] = o; size_t l = strlen(qnames[q]) + 1; if (l > 255) return TELR_E_ARG; o += (int64_t)l; } qn_off[nq] = o; qn_buf.resize((size_t)o);
+      parallel_ranges(host_threads(), nq, [&](int, int a0, int a1) { for (int q = a0; q < a1; ++q) memcpy(&qn_buf[(size_t)qn_off[q]], qnames[q], (size_t)(qn_off[q + 1] - qn_off[q])); }); }
+    std::vector<int32_t> tn_off((size_t)nt + 1); std::string tn_buf;
+    { int32_t o = 0; for (int t = 0; t < nt; ++t) { tn_off[t] = o; o += (int32_t)strlen(tnames[t]) + 1; } tn_off[nt] = o; tn_buf.resize((size_t)o); for (int t = 0; t < nt; ++t) memcpy(&tn_buf[tn_off[t]], tnames[t], (size_t)(tn_off[t + 1] - tn_off[t])); }
+    const std::string head = bam_header(nt, tnames, tg->len.data(), rg_id, rg_sm, rg_lb, pg_line);
+    const int rg_len = rg_id ? (int)strlen(rg_id) : 0;
+    // ---- 2. upload
+    telr_aln *d_alns; uint32_t *d_cig; char *d_qn, *d_tn, *d_rg; int64_t *d_qnoff; int32_t *d_tnoff; BamInfo *d_info; uint32_t *d_size, *d_ord0, *d_ord; uint64_t *d_key, *d_key2, *d_szs, *d_ust, *d_rust;
+    CrcTabs *d_tabs;
+    TRY(ctx_buf_t(ctx, "bam_alns", nrec, &d_alns)); TRY(ctx_buf_t(ctx, "bam_cig", r->ncig + 1, &d_cig));
+    TRY(ctx_buf_t(ctx, "bam_qn", qn_buf.size() + 1, &d_qn)); TRY(ctx_buf_t(ctx, "bam_tn", tn_buf.size() + 1, &d_tn)); TRY(ctx_buf_t(ctx, "bam_rg", (size_t)rg_len + 1, &d_rg));
+    TRY(ctx_buf_t(ctx, "bam_qnoff", (size_t)nq + 1, &d_qnoff)); TRY(ctx_buf_t(ctx, "bam_tnoff", (size_t)nt + 1, &d_tnoff));
+    TRY(ctx_buf_t(ctx, "bam_info", nrec, &d_info)); TRY(ctx_buf_t(ctx, "bam_size", nrec, &d_size)); TRY(ctx_buf_t(ctx, "bam_ord0", nrec, &d_ord0)); TRY(ctx_buf_t(ctx, "bam_ord", nrec, &d_ord));
+    TRY(ctx_buf_t(ctx, "bam_key", nrec, &d_key)); TRY(ctx_buf_t(ctx, "bam_key2", nrec, &d_key2)); TRY(ctx_buf_t(ctx, "bam_szs", nrec + 1, &d_szs)); TRY(ctx_buf_t(ctx, "bam_ust", nrec + 1, &d_ust));
+    TRY(ctx_buf_t(ctx, "bam_rust", nrec, &d_rust)); TRY(ctx_buf_t(ctx, "bam_tabs", 1, &d_tabs));
+    { static CrcTabs T; static bool made = false; if (!made) { crc_tabs_make(T); made = true; } HIPCHK(hipMemcpyAsync(d_tabs, &T, sizeof(T), hipMemcpyHostToDevice, st)); }
+    if (nrec) HIPCHK(hipMemcpyAsync(d_alns, recs.data(), nrec * sizeof(telr_aln), hipMemcpyHostToDevice, st));
+    if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
+    if (!qn_buf.empty()) HIPCHK(hipMemcpyAsync(d_qn, qn_buf.data(), qn_buf.size(), hipMemcpyHostToDevice, st));
+    if (!tn_buf.empty()) HIPCHK(hipMemcpyAsync(d_tn, tn_buf.data(), tn_buf.size(), hipMemcpyHostToDevice, st));
+    if (rg_len) HIPCHK(hipMemcpyAsync(d_rg, rg_id, (size_t)rg_len, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_qnoff, qn_off.data(), ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_tnoff, tn_off.data(), ((size_t)nt + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    g_bam_times.ms[0] = ms_since(t0); t0 = now();
+    BamArgs A; memset(&A, 0, sizeof(A));
+    A.alns = d_alns; A.nrec = (int32_t)nrec; A.n_mapped = (int32_t)n_mapped; A.cig = d_cig;
+    A.q2 = queries->d_seq2; A.qn = queries->d_nmask; A.qboff = queries->d_boff; A.t2 = tg->d_seq2; A.tn = tg->d_nmask; A.tboff = tg->d_boff;
+    A.qnames = d_qn; A.qname_off = d_qnoff; A.tnames = d_tn; A.tname_off = d_tnoff; A.rg = d_rg; A.rg_len = rg_len; A.flags = flags;
+    A.info = d_info; A.rec_size = d_size; A.key = d_key; A.rec_ustart = d_rust; A.ubuf = nullptr;
+    uint64_t utotal = head.size();
+    std::vector<uint32_t> h_order(nrec); std::vector<uint64_t> h_ustart(nrec + 1, head.size());
+    if (nrec) {
+        // ---- 3. sizes and keys
+        if (n_mapped) hipLaunchKernelGGL(k_bam_scan, dim3((unsigned)n_mapped), dim3(64), 0, st, A);
+        hipLaunchKernelGGL(k_bam_size, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        g_bam_times.ms[1] = ms_since(t0); t0 = now();
+        // ---- 4. coordinate sort (stable: ties keep the query order) and the offsets
+        hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, d_ord0, (int32_t)nrec);
+        size_t tb = 0;
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, d_key, d_key2, d_ord0, d_ord, nrec, 0, 64, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::radix_sort_pairs(tmp, tb, d_key, d_key2, d_ord0, d_ord, nrec, 0, 64, st));
+        hipLaunchKernelGGL(k_bam_gather_sizes, dim3((unsigned)((nrec + 256) / 256)), dim3(256), 0, st, d_size, d_ord, (int32_t)nrec, d_szs);
+        TRY((dev_exclusive_scan<uint64_t, uint64_t>(ctx, d_szs, d_ust, nrec + 1)));
+        hipLaunchKernelGGL(k_bam_scatter_off, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, d_ust, d_ord, (int32_t)nrec, (uint64_t)head.size(), d_rust);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_order.data(), d_ord, nrec * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_ustart.data(), d_ust, (nrec + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i <= nrec; ++i) h_ustart[i] += head.size();
+        utotal = h_ustart[nrec];
+        g_bam_times.ms[2] = ms_since(t0); t0 = now();
+    }
+    // ---- 5. the uncompressed stream
+    uint8_t *d_u; TRY(ctx_buf_t(ctx, "bam_u", (size_t)utotal + 64, &d_u));
+    HIPCHK(hipMemcpyAsync(d_u, head.data(), head.size(), hipMemcpyHostToDevice, st));
+    A.ubuf = d_u;
+    if (nrec) hipLaunchKernelGGL(k_bam_write, dim3((unsigned)nrec), dim3(64), 0, st, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(d_u + utotal, 0, 64, st));
+    const size_t nblk = (size_t)((utotal + BAM_BLK - 1) / BAM_BLK);
+    if (ctx->debug) { HIPCHK(hipStreamSynchronize(st)); }
+    g_bam_times.ms[3] = ms_since(t0); t0 = now();
+    // ---- 6. BGZF framing
+    const uint64_t cbytes = utotal + (uint64_t)nblk * 31;
+    uint8_t *d_c; TRY(ctx_buf_t(ctx, "bam_c", (size_t)cbytes + 64, &d_c));
+    if (nblk) hipLaunchKernelGGL(k_bgzf_store, dim3((unsigned)nblk), dim3(256), 0, st, d_u, utotal, d_tabs, d_c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    g_bam_times.ms[4] = ms_since(t0); t0 = now();
+    // ---- 7. the index is built by a host thread while the file image streams out
+    std::string bai; std::thread bai_th;
+    std::vector<uint64_t> coff(nblk + 1);
+    for (size_t b = 0; b < nblk; ++b) coff[b] = (uint64_t)b * (BAM_BLK + 31);
+    coff[nblk] = cbytes;
+    float bai_ms = 0;
+    if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), coff.data(), nblk, nt, tg->len.data(), bai); bai_ms = ms_since(tb0); });
+    static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int rc = stream_to_file(ctx, d_c, cbytes, eof_blk, 28, bam_path);
+    g_bam_times.ms[5] = ms_since(t0);
+    if (bai_th.joinable()) bai_th.join();
+    g_bam_times.ms[6] = bai_ms;
+    if (rc == TELR_OK && write_index) {
+        const std::string bai_path = std::string(bam_path) + ".bai";
+        FILE *f = fopen(bai_path.c_str(), "wb");
+        if (!f) rc = TELR_E_ARG; else { fwrite(bai.data(), 1, bai.size(), f); fclose(f); }
+    }
+    g_bam_times.ms[7] = ms_since(t_all);
+    return rc;
+}

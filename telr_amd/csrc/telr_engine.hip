@@ -2446,7 +2446,12 @@ static const char COMP_TAB[256] = {
     'N','t','N','g','N','N','N','c','N','N','N','N','N','N','N','N','N','N','N','N','a','a','N','N','N','N','N','N','N','N','N','N',
     C16, C16, C16, C16, C16, C16, C16, C16
 };
-static inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+// bases as the engine sees them (the 2-bit packing: A C G T/U in either case, anything else ambiguous): what NM / MD / cs
+// print, so that the text writers and the device-side BAM writer (bam_dev.hip.h) agree byte for byte
+static inline char up(char c)
+{
+    switch (c) { case 'A': case 'a': return 'A'; case 'C': case 'c': return 'C'; case 'G': case 'g': return 'G'; case 'T': case 't': case 'U': case 'u': return 'T'; default: return 'N'; }
+}
 
 static void cigar_text(const uint32_t *cg, int n, int clip5, int clip3, char clipc, std::string &out)
 {
@@ -2496,7 +2501,8 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
         fprintf(f, "@PG\tID:telr_amd\tPN:telr_amd\tVN:0.1.0\tCL:%s\n", pg_line ? pg_line : "telr_map");
     }
     // TELR_SAM_SORTED: lines are collected with their (target, position) key and written in coordinate order, unmapped
-    // reads last (what `samtools sort | samtools view` prints; stable, so ties keep the query order)
+    // reads last (what `samtools sort | samtools view` prints: refID, position, forward strand before reverse; stable, so
+    // remaining ties keep the query order)
     std::vector<std::pair<int64_t, std::string>> keyed;
     auto emit = [&](int64_t key, const std::string &l) { if (sorted) keyed.emplace_back(key, l); else fwrite(l.data(), 1, l.size(), f); };
     // records are sorted by (qid, rank); group per query
@@ -2548,12 +2554,12 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
                     qi += l; ti += l;
                 } else if (op == 1) {
                     nm += l;
-                    if (flags & TELR_SAM_CS) { cs += '+'; for (int x = 0; x < l; ++x) cs += (char)(qstr[qi + x] | 32); }
+                    if (flags & TELR_SAM_CS) { cs += '+'; for (int x = 0; x < l; ++x) cs += (char)(up(qstr[qi + x]) | 32); }
                     qi += l;
                 } else {
                     nm += l;
                     if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d^", run); md += buf; for (int x = 0; x < l; ++x) md += up(ts[ti + x]); run = 0; }
-                    if (flags & TELR_SAM_CS) { cs += '-'; for (int x = 0; x < l; ++x) cs += (char)(ts[ti + x] | 32); }
+                    if (flags & TELR_SAM_CS) { cs += '-'; for (int x = 0; x < l; ++x) cs += (char)(up(ts[ti + x]) | 32); }
                     ti += l;
                 }
             }
@@ -2600,7 +2606,7 @@ extern "C" int telr_write_sam(const telr_result *r, int32_t n_queries, const cha
             if (!sec) { snprintf(buf, sizeof(buf), "\ts2:i:%d", a.subsc); line += buf; }
             if (rg_id) { line += "\tRG:Z:"; line += rg_id; }
             line += '\n';
-            emit(((int64_t)(a.tid + 1) << 32) | (uint32_t)a.ts, line);
+            emit(((int64_t)(a.tid + 1) << 33) | (int64_t)(uint32_t)a.ts << 1 | (rev ? 1 : 0), line);
         }
         i = j;
     }
@@ -2630,7 +2636,7 @@ static inline void put32(std::string &s, uint32_t v) { s.append((const char*)&v,
 static inline void put16(std::string &s, uint16_t v) { s.append((const char*)&v, 2); }
 static inline uint8_t nt16(char c)
 {
-    switch (c) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': return 8; default: return 15; }
+    switch (c) { case 'A': case 'a': return 1; case 'C': case 'c': return 2; case 'G': case 'g': return 4; case 'T': case 't': case 'U': case 'u': return 8; default: return 15; }
 }
 static bool bgzf_block(const char *src, size_t n, int level, std::string &out)
 {
@@ -2705,12 +2711,12 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
                         qi += l; ti += l;
                     } else if (op == 1) {
                         nm += l;
-                        if (flags & TELR_SAM_CS) { cs += '+'; for (int x = 0; x < l; ++x) cs += (char)(qstr[qi + x] | 32); }
+                        if (flags & TELR_SAM_CS) { cs += '+'; for (int x = 0; x < l; ++x) cs += (char)(up(qstr[qi + x]) | 32); }
                         qi += l;
                     } else {
                         nm += l;
                         if (flags & TELR_SAM_MD) { snprintf(buf, sizeof(buf), "%d^", run); md += buf; for (int x = 0; x < l; ++x) md += up(ts[ti + x]); run = 0; }
-                        if (flags & TELR_SAM_CS) { cs += '-'; for (int x = 0; x < l; ++x) cs += (char)(ts[ti + x] | 32); }
+                        if (flags & TELR_SAM_CS) { cs += '-'; for (int x = 0; x < l; ++x) cs += (char)(up(ts[ti + x]) | 32); }
                         ti += l;
                     }
                 }
@@ -2772,7 +2778,7 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
                 o.append((size_t)l_seq, (char)0xff);
                 o += tagbuf;
                 uint32_t bs = (uint32_t)o.size() - 4; memcpy(&o[0], &bs, 4);
-                key[k] = ((int64_t)(a.tid + 1) << 32) | (uint32_t)a.ts;
+                key[k] = ((int64_t)(a.tid + 1) << 33) | (int64_t)(uint32_t)a.ts << 1 | (rev ? 1 : 0);
             }
         }
     });
@@ -2842,7 +2848,7 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
         int max_lin = 0;
         uint64_t ref_beg = 0, ref_end = 0, n_mapped = 0;
         bool any = false;
-        while (i < nrec && key[order[i]] != INT64_MAX && (int)((key[order[i]] >> 32) - 1) == t) {
+        while (i < nrec && key[order[i]] != INT64_MAX && (int)((key[order[i]] >> 33) - 1) == t) {
             const telr_aln &a = r->alns[order[i]];
             const uint64_t vb = voff(ustart[i]), ve = voff(ustart[i + 1]);
             const uint32_t bin = (uint32_t)reg2bin(a.ts, a.te > a.ts ? a.te : a.ts + 1);
@@ -2876,3 +2882,5 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
     fclose(f);
     return TELR_OK;
 }
+
+#include "bam_dev.hip.h"

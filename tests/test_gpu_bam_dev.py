@@ -1,0 +1,140 @@
+"""The device-side BAM writer (telr_write_bam_dev: records, coordinate sort, BGZF blocks and CRC-32 made by kernels) against
+the host writer (telr_write_bam: the CIGAR walk over ASCII sequences on host threads, zlib): after inflating, the two files
+must hold the SAME BYTES -- header, every record (fixed fields, CIGAR with clips, 4-bit SEQ, QUAL, NM / AS / MD / cs / SA /
+tp / cm / s1 / s2 / RG tags), in the same coordinate order -- and the .bai must index the device file's own blocks
+(reference hand-off H1: src/telr/TELR_alignment.py:103-114)."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from telr_amd import synth
+from telr_amd.fasta import read_fasta, concat
+from telr_amd.presets import preset
+from test_gpu_parity import _read_bgzf
+
+pytestmark = pytest.mark.gpu
+
+
+def _records(raw):
+    """[(offset, refid, pos, flag, name, n_cigar, l_seq, body)] of an inflated BAM stream + offset of the first record"""
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]; p += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", raw, p)[0]; p += 4 + ln + 4
+    first = p
+    out = []
+    while p < len(raw):
+        bs, refid, pos, lrn, mapq, bn, ncig, flag, lseq = struct.unpack_from("<iiiBBHHHi", raw, p)
+        body = raw[p + 4:p + 4 + bs]
+        out.append((p, refid, pos, flag, body[32:32 + lrn - 1].decode(), ncig, lseq, body))
+        p += 4 + bs
+    assert p == len(raw)
+    return out, first
+
+
+def _check_bai(bam, raw, blocks, n_ref):
+    recs, _ = _records(raw)
+    bai = open(bam + ".bai", "rb").read()
+    assert bai[:4] == b"BAI\x01" and struct.unpack_from("<i", bai, 4)[0] == n_ref
+    ustart = sorted((b[1], b[0]) for b in blocks)          # (uncompressed start, file offset)
+    us = np.array([u for u, _ in ustart]); fo = [f for _, f in ustart]
+
+    def voff(u):
+        k = int(np.searchsorted(us, u, side="right")) - 1
+        return fo[k] << 16 | (u - int(us[k]))
+    q = 8
+    per_ref = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", bai, q)[0]; q += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, nch = struct.unpack_from("<Ii", bai, q); q += 8
+            bins[b] = [struct.unpack_from("<QQ", bai, q + 16 * c) for c in range(nch)]; q += 16 * nch
+        n_intv = struct.unpack_from("<i", bai, q)[0]; q += 4
+        lin = struct.unpack_from("<%dQ" % n_intv, bai, q); q += 8 * n_intv
+        assert list(lin) == sorted(lin)
+        per_ref.append((bins, lin))
+    n_no_coor = struct.unpack_from("<Q", bai, q)[0]; q += 8
+    assert q == len(bai)
+    assert n_no_coor == sum(1 for r in recs if r[1] < 0)
+    cnt = [0] * n_ref
+    for off, refid, pos, flag, name, ncig, lseq, body in recs:
+        if refid < 0:
+            continue
+        cnt[refid] += 1
+        bn = struct.unpack_from("<H", body, 10)[0]
+        bins, lin = per_ref[refid]
+        v = voff(off)
+        assert any(c0 <= v < c1 for c0, c1 in bins[bn]), "record at %d not covered by a chunk of bin %d" % (pos, bn)
+        assert lin[pos >> 14] <= v
+    for t in range(n_ref):
+        if cnt[t]:
+            assert per_ref[t][0][37450][1][0] == cnt[t]
+
+
+def _both(engine, ts, tnames, qs, qnames, pname, tmp_path, tag, rg=None, softclip=True, md=True, cs=True):
+    io, mo = preset(pname)
+    ix = engine.index(ts, io)
+    qset = engine.seqset(qs)
+    r = ix.map_raw(qset, mo)
+    try:
+        h, d = str(tmp_path / (tag + "_host.bam")), str(tmp_path / (tag + "_dev.bam"))
+        ix.write_bam(r, qnames, qs, tnames, ts, h, md=md, cs=cs, softclip=softclip, rg=rg, cmdline="t", index=True, level=1)
+        ix.write_bam_device(r, qset, qnames, tnames, d, md=md, cs=cs, softclip=softclip, rg=rg, cmdline="t", index=True, level=0)
+    finally:
+        ix.free_raw(r)
+    rh, bh = _read_bgzf(h)
+    rd, bd = _read_bgzf(d)          # inflates every block and checks its CRC-32 and ISIZE
+    if rh != rd:
+        a, _ = _records(rh); b, _ = _records(rd)
+        assert len(a) == len(b), (len(a), len(b))
+        for x, y in zip(a, b):
+            assert x[1:7] == y[1:7], (x[:7], y[:7])
+            if x[7] != y[7]:
+                k = next(i for i in range(min(len(x[7]), len(y[7]))) if x[7][i] != y[7][i])
+                raise AssertionError("record %s at %d: bodies differ at byte %d of %d / %d: %r vs %r" % (x[4], x[2], k, len(x[7]), len(y[7]), x[7][max(0, k - 24):k + 24], y[7][max(0, k - 24):k + 24]))
+        raise AssertionError("streams differ outside the records")
+    _check_bai(d, rd, bd, len(tnames))
+    return _records(rd)[0]
+
+
+def test_fixture_device_bam_equals_host_bam(engine, data_dir, tmp_path):
+    tn, ts = read_fasta(data_dir + "/ref_38kb.fasta")
+    qn, qs = read_fasta(data_dir + "/reads.fasta")
+    recs = _both(engine, ts, tn, qs, qn, "map-ont", tmp_path, "fx")
+    assert len(recs) >= 18
+    recs = _both(engine, ts, tn, qs, qn, "ngmlr-pacbio", tmp_path, "fxrg", rg=("s1", "s1", "pb"), cs=False)
+    assert all(b"RGZs1\x00" in r[7] for r in recs)
+    _both(engine, ts, tn, qs, qn, "map-pb", tmp_path, "fxhard", softclip=False)
+
+
+def test_synthetic_device_bam_equals_host_bam(engine, tmp_path):
+    """several targets, both strands, supplementary + secondary records, unmapped and empty reads, reads with N, a read longer
+    than a BGZF block, lower-case and IUPAC bases (printed as N by both writers)"""
+    rng = np.random.default_rng(77)
+    genome = [synth.random_seq(rng, 300000), synth.random_seq(rng, 120000), synth.random_seq(rng, 50000)]
+    # a repeat so that secondaries appear, an N run inside the first target
+    genome[1][20000:26000] = genome[0][100000:106000]
+    genome[0][150000:150400] = ord("N")
+    reads, _ = synth.simulate_reads(rng, genome, 160, 6000)
+    # a chimeric read (supplementary record), a read of random bases (unmapped), an empty read, a read with Ns and IUPAC codes
+    a = synth.mutate(rng, genome[0][5000:13000])
+    b = genome[2][10000:19000].copy()
+    reads.append(np.concatenate([a, synth.revcomp_arr(b)]))
+    reads.append(synth.random_seq(rng, 3000))
+    reads.append(np.zeros(0, np.uint8))
+    x = genome[0][200000:207000].copy(); x[100:103] = ord("N"); x[2000] = ord("R"); x[2500:2600] |= 32
+    reads.append(x)
+    reads.append(genome[0][20000:140000].copy())          # 120 kb: record spans two BGZF blocks
+    names = ["r%d/x" % i for i in range(len(reads))]
+    tn = ["chrA", "chrB_long_name", "c3"]
+    recs = _both(engine, genome, tn, reads, names, "map-ont", tmp_path, "syn")
+    flags = [r[3] for r in recs]
+    assert any(f & 0x800 for f in flags) and any(f & 0x100 for f in flags) and any(f & 0x10 for f in flags) and any(f == 4 for f in flags)
+    assert sum(1 for r in recs if r[1] < 0) >= 2
+    _both(engine, genome, tn, reads, names, "ngmlr-ont", tmp_path, "synrg", rg=("smp", "smp", "ont"))
+    _both(engine, genome, tn, reads, names, "map-ont", tmp_path, "synplain", md=False, cs=False)

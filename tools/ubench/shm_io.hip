@@ -1,0 +1,117 @@
+// shm_io — what does it cost to get N GB from HBM into a file under /dev/shm on this box?
+// (the BAM hand-off of stage 1: TELR_alignment.py:103-114).  Measures
+//   1. D2H into pinned staging (hipMemcpyAsync), one stream
+//   2. pwrite of the staging buffer into a fresh tmpfs file with T threads
+//   3. memcpy into a fresh MAP_SHARED mapping of a tmpfs file with T threads (page faults included)
+//   4. hipHostRegister of such a mapping + D2H straight into it (if the driver accepts file-backed pages)
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/ubench/shm_io tools/ubench/shm_io.hip -lpthread
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv)
+{
+    const size_t GB = (size_t)1 << 30;
+    const size_t total = (argc > 1 ? (size_t)atol(argv[1]) : 4) * GB;
+    const size_t chunk = 256u << 20;
+    const char *path = "/dev/shm/telr_shm_io.bin";
+    void *d = nullptr; CK(hipMalloc(&d, total)); CK(hipMemset(d, 0x5a, total));
+    void *h = nullptr; CK(hipHostMalloc(&h, chunk * 2, hipHostMallocDefault));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    // 1. D2H pinned
+    for (int rep = 0; rep < 2; ++rep) {
+        double t0 = now();
+        for (size_t o = 0; o < total; o += chunk) CK(hipMemcpyAsync((char*)h + (o / chunk % 2) * chunk, (char*)d + o, chunk, hipMemcpyDeviceToHost, s));
+        CK(hipStreamSynchronize(s));
+        double dt = now() - t0;
+        printf("D2H pinned ring: %.2f GB in %.3f s = %.1f GB/s\n", total / 1e9, dt, total / 1e9 / dt);
+    }
+    // 2. pwrite with T threads (fresh file each time)
+    for (int T : {1, 4, 8, 16, 32}) {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        if (fd < 0) { perror("open"); return 1; }
+        double t0 = now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            const size_t piece = 8u << 20;
+            for (size_t o = (size_t)t * piece; o < total; o += (size_t)T * piece) {
+                size_t n = std::min(piece, total - o);
+                if (pwrite(fd, (char*)h + (o % chunk), n, (off_t)o) != (ssize_t)n) { perror("pwrite"); break; }
+            }
+        });
+        for (auto &x : th) x.join();
+        double dt = now() - t0;
+        printf("pwrite to tmpfs, %2d threads: %.2f GB in %.3f s = %.1f GB/s\n", T, total / 1e9, dt, total / 1e9 / dt);
+        close(fd);
+    }
+    // 2b. pwrite over an EXISTING file (pages already allocated)
+    for (int T : {8, 16}) {
+        int fd = open(path, O_RDWR, 0600);
+        double t0 = now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            const size_t piece = 8u << 20;
+            for (size_t o = (size_t)t * piece; o < total; o += (size_t)T * piece) { size_t n = std::min(piece, total - o); if (pwrite(fd, (char*)h + (o % chunk), n, (off_t)o) != (ssize_t)n) break; }
+        });
+        for (auto &x : th) x.join();
+        double dt = now() - t0;
+        printf("pwrite over existing tmpfs pages, %2d threads: %.1f GB/s\n", T, total / 1e9 / dt);
+        close(fd);
+    }
+    // 3. memcpy into a fresh mapping
+    for (int T : {8, 16}) {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        if (ftruncate(fd, (off_t)total) != 0) { perror("ftruncate"); return 1; }
+        char *m = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) { perror("mmap"); return 1; }
+        double t0 = now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            const size_t piece = 8u << 20;
+            for (size_t o = (size_t)t * piece; o < total; o += (size_t)T * piece) memcpy(m + o, (char*)h + (o % chunk), std::min(piece, total - o));
+        });
+        for (auto &x : th) x.join();
+        double dt = now() - t0;
+        printf("memcpy into fresh MAP_SHARED tmpfs mapping, %2d threads: %.1f GB/s\n", T, total / 1e9 / dt);
+        munmap(m, total); close(fd);
+    }
+    // 4. register a mapping and DMA into it
+    {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        if (ftruncate(fd, (off_t)total) != 0) { perror("ftruncate"); return 1; }
+        char *m = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        double t0 = now();
+        hipError_t e = hipHostRegister(m, total, hipHostRegisterDefault);
+        double t_reg = now() - t0;
+        printf("hipHostRegister(tmpfs mapping, %.1f GB): %s, %.3f s\n", total / 1e9, hipGetErrorString(e), t_reg);
+        if (e == hipSuccess) {
+            t0 = now();
+            CK(hipMemcpyAsync(m, d, total, hipMemcpyDeviceToHost, s));
+            CK(hipStreamSynchronize(s));
+            double dt = now() - t0;
+            printf("D2H straight into the registered mapping: %.1f GB/s (register + copy: %.1f GB/s)\n", total / 1e9 / dt, total / 1e9 / (dt + t_reg));
+            bool ok = m[0] == 0x5a && m[total - 1] == 0x5a && m[total / 2] == 0x5a;
+            printf("content %s\n", ok ? "ok" : "WRONG");
+            t0 = now(); hipHostUnregister(m); printf("unregister %.3f s\n", now() - t0);
+        } else (void)hipGetLastError();
+        munmap(m, total); close(fd);
+    }
+    unlink(path);
+    // 5. host-side deflate / crc32 rates are measured by the library's own writer (bench.py --bam-leg host)
+    hipFree(d); hipHostFree(h);
+    return 0;
+}

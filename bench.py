@@ -9,8 +9,8 @@ reads 13 % 1:5:4, the NGMLR-style convex-gap preset `ngmlr-pacbio`), `c4` = conf
 leading N block, 50x, 1,300-family library, 3,000 insertions).
 
 A "step" = one pass of the stage-1 hot path (sketch -> seed -> sort -> chain -> back-track -> banded DP + trace-back ->
-records/CIGARs on the host) over the rank's WHOLE read set, which the engine streams through in ranges of <= 2 Gbp
-(sized by the anchor density seen so far).
+records/CIGARs on the host) over the rank's WHOLE read set: up to 1.6 Gbp is one range, a larger set streams through in
+ranges of at most 1.4 Gbp, two in flight (each also bounded by an anchor budget at the density the index has shown).
 Index and packed reads are resident in HBM before the timed region (`value`); `value_incl_h2d` adds the packing +
 upload of the reads.  The second half of the metric, TE loci/s, runs the per-locus bundle (S4, S5, S6 fw+rc + depth +
 AF, S7 x2 + liftover) on window reads selected from the ENGINE'S OWN stage-1 records (TELR_assembly.py:384-415).
@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--read-bases", type=int, default=470_000_000, help="c1 only")
     ap.add_argument("--insertions", type=int, default=0, help="override the number of spiked insertions")
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-25 s of CPU work)")
+    ap.add_argument("--cpu-sample-seed", type=int, default=20261002, help="seed of the random read sample the CPU oracle maps (cpu_baseline, parity)")
+    ap.add_argument("--require-cache", action="store_true", help="with --data-cache: fail instead of generating (profiled runs must not fork the generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", default="", help="override the configuration's preset")
     ap.add_argument("--fill-band-q4", type=int, default=0, help="experiment: override the preset's first-pass band factor (0 = preset)")
@@ -77,6 +79,7 @@ def parse():
     ap.add_argument("--bam-leg", default="none", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
     ap.add_argument("--bam-dir", default="/dev/shm")
     ap.add_argument("--bam-level", type=int, default=1)
+    ap.add_argument("--no-bam-prepare", action="store_true", help="do not create / allocate / map the BAM file in the background while the reads are mapped")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
     return ap.parse_args()
 
@@ -109,6 +112,7 @@ def launch_ranks(a):
     return pr.wait()
 
 
+PMC_PROFILE = "r03_pmc_k_dp_pk.json"       # per-launch counters of the dominant kernel, collected by tools/collect_profiles.sh
 PARITY_FIELDS = ("tid", "qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "score", "subsc", "dp_score", "cnt", "n_sub", "parent", "n_cigar", "flags", "mapq")
 
 
@@ -125,7 +129,7 @@ def _read_digests(alns, cigars, qid_map=None):
     return out
 
 
-def cpu_baseline(ref_strs, reads, io, mo, n_sample, gpu_index=None):
+def cpu_baseline(ref_strs, reads, io, mo, n_sample, gpu_index=None, seed=20261002):
     """The CPU oracle ("port") timed on a bounded sample of the same read set; with `gpu_index`, its records for the sample are
     also compared with the engine's, read by read (full-size parity evidence: same index, same reads, outside the timed leg)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -137,7 +141,8 @@ def cpu_baseline(ref_strs, reads, io, mo, n_sample, gpu_index=None):
     oix = ob.OracleIndex(ref_strs, io)
     t_index = time.time() - t0
     n_sample = min(n_sample, len(ln))
-    seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in range(n_sample)]
+    pick = np.sort(np.random.default_rng(seed).choice(len(ln), size=n_sample, replace=False))
+    seqs = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in pick]
     shards = [seqs[i::cores] for i in range(cores)]
     shards = [s for s in shards if s]
     parts = [None] * len(shards)
@@ -152,8 +157,8 @@ def cpu_baseline(ref_strs, reads, io, mo, n_sample, gpu_index=None):
         aligned = sum(ex.map(work, range(len(shards))))
     dt = time.time() - t0
     out = {"value": aligned / dt / 1e9, "unit": "Gbp/s", "cores": len(shards), "kind": "port",
-           "sample": "first %d reads (%d bases) of the same read set against the same full-size index, oracle/telr_oracle.c, %d threads, %.1f s; "
-                     "index build %.1f s (one thread) excluded" % (n_sample, sum(len(s) for s in seqs), len(shards), dt, t_index)}
+           "sample": "%d reads drawn at random (seed %d; %d bases) from the same read set, mapped against the same full-size index, oracle/telr_oracle.c, %d threads, %.1f s; "
+                     "index build %.1f s (one thread) excluded" % (n_sample, seed, sum(len(s) for s in seqs), len(shards), dt, t_index)}
     if gpu_index is not None:
         want = {}
         for k, (al, cg) in enumerate(parts):
@@ -211,6 +216,54 @@ def build_dataset(a, cfg, rank, world, lws):
                 total_reads=plan["n"], total_bases=int(plan["length"].sum()))
 
 
+def save_dataset(path, D):
+    """arrays + a JSON blob, no pickle (np.load(..., allow_pickle=False) on the way back)"""
+    import numpy as np
+    arr = {"ref_%d" % i: r for i, r in enumerate(D["ref"])}
+    arr.update({"lib_%d" % i: np.asarray(r) for i, r in enumerate(D["library"])})
+    arr["reads_buf"], arr["reads_off"], arr["reads_len"] = D["reads"]
+    arr["read_gid"] = np.asarray(D["read_gid"])
+    loci_arr = {}
+    loci = []
+    for i, l in enumerate(D["loci"]):
+        m = {}
+        for k, v in l.items():
+            if isinstance(v, np.ndarray):
+                loci_arr["locus_%d_%s" % (i, k)] = v; m[k] = {"__arr__": "locus_%d_%s" % (i, k)}
+            elif isinstance(v, (bytes, bytearray)):
+                loci_arr["locus_%d_%s" % (i, k)] = np.frombuffer(bytes(v), np.uint8); m[k] = {"__bytes__": "locus_%d_%s" % (i, k)}
+            else:
+                m[k] = v
+        loci.append(m)
+    arr.update(loci_arr)
+    meta = {"names": list(D["names"]), "n_ref": len(D["ref"]), "n_lib": len(D["library"]), "loci": loci, "text": D["text"],
+            "total_reads": int(D["total_reads"]), "total_bases": int(D["total_bases"])}
+    arr["meta_json"] = np.frombuffer(json.dumps(meta, default=lambda o: o.item() if hasattr(o, "item") else str(o)).encode(), np.uint8)
+    tmp = path + ".tmp.npz"
+    np.savez(tmp, **arr)
+    os.replace(tmp, path)
+
+
+def load_dataset(path):
+    import numpy as np
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(bytes(z["meta_json"]).decode())
+    loci = []
+    for m in meta["loci"]:
+        l = {}
+        for k, v in m.items():
+            if isinstance(v, dict) and "__arr__" in v:
+                l[k] = z[v["__arr__"]]
+            elif isinstance(v, dict) and "__bytes__" in v:
+                l[k] = bytes(z[v["__bytes__"]])
+            else:
+                l[k] = v
+        loci.append(l)
+    return dict(names=meta["names"], ref=[z["ref_%d" % i] for i in range(meta["n_ref"])], library=[z["lib_%d" % i] for i in range(meta["n_lib"])],
+                reads=(z["reads_buf"], z["reads_off"], z["reads_len"]), read_gid=z["read_gid"], loci=loci, text=meta["text"],
+                total_reads=meta["total_reads"], total_bases=meta["total_bases"])
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -243,18 +296,22 @@ def main():
         return
     import numpy as np
     t0 = time.time()
-    cache = os.path.join(a.data_cache, "telr_bench_%s_%s_r%dof%d_cov%g_gs%g.pkl" % (a.config, a.scaling, rank, world, a.coverage, a.genome_scale)) if a.data_cache else ""
-    if cache and os.path.exists(cache):
-        import pickle
-        with open(cache, "rb") as fh:
-            D = pickle.load(fh)
-    else:
+    D = None
+    cache = ""
+    if a.data_cache:
+        import hashlib
+        src = open(os.path.join(ROOT, "telr_amd", "synth.py"), "rb").read()
+        keytxt = repr((a.config, a.scaling, rank, world, a.coverage, a.genome_scale, a.genome_len, a.reads, a.read_bases, a.insertions, sorted(cfg.items()))).encode() + src
+        cache = os.path.join(a.data_cache, "telr_bench_%s_r%dof%d_%s.npz" % (a.config, rank, world, hashlib.sha256(keytxt).hexdigest()[:16]))
+        os.makedirs(a.data_cache, mode=0o700, exist_ok=True)
+        if os.path.exists(cache):
+            D = load_dataset(cache)
+        elif a.require_cache:
+            sys.exit("bench.py: --require-cache and %s does not exist" % cache)
+    if D is None:
         D = build_dataset(a, cfg, rank, world, lws)       # CPU only; forks workers: before any GPU initialisation
         if cache:
-            import pickle
-            os.makedirs(a.data_cache, exist_ok=True)
-            with open(cache, "wb") as fh:
-                pickle.dump(D, fh, protocol=4)
+            save_dataset(cache, D)
     t_gen = time.time() - t0
 
     import torch
@@ -269,7 +326,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(a.backend)
-    from telr_amd.aligner import Engine, _np_from
+    from telr_amd.aligner import Engine, Index, _np_from
     from telr_amd._abi import ALN_DTYPE
     from telr_amd.presets import preset
     from telr_amd import telr_assembly, locus_pipeline, shard
@@ -395,7 +452,7 @@ def main():
     bam_out = None
     if a.bam_leg != "none":
         bam_path = os.path.join(a.bam_dir, "telr_bench_rank%d.bam" % rank)
-        qnames = ["read%d" % g for g in D["read_gid"]]
+        qnames = Index._cstr_array(["read%d" % g for g in D["read_gid"]])       # the C array of names is an input, like the reads
         tb_, to_, tl_ = concat_ref = (np.concatenate(D["ref"]), np.cumsum([0] + [len(x) for x in D["ref"]][:-1]).astype(np.int64), np.array([len(x) for x in D["ref"]], np.int32))
         legs = []
         for rep in range(2):                      # the first pass sizes / pins the writer's buffers
@@ -404,6 +461,8 @@ def main():
                     os.unlink(f)
             sync()
             t0b = time.time()
+            if a.bam_leg == "device" and not a.no_bam_prepare:
+                ix.bam_prepare(bam_path, int((0.95 if a.bam_level else 2.9) * n_bases) + (64 << 20))
             r = ix.map_raw(qs, mo)
             t_map = time.time() - t0b
             if a.bam_leg == "host":
@@ -501,7 +560,12 @@ def main():
             else:
                 why["other"] += 1
         wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]
-        loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
+        import hashlib
+        rs = np.sort(rows, order="locus_id")
+        digest = hashlib.sha256(repr([(int(r["locus_id"]), int(r["status"]), int(r["chrom_id"]), int(r["start"]), int(r["end"]), int(r["strand"]), int(r["type"]), int(r["n_family"]),
+                                       int(r["gap"]), int(r["tsd_len"]), [int(x) for x in r["family_id"]], [None if np.isnan(x) else float(x) for x in r["medians"]],
+                                       None if np.isnan(r["af"]) else float(r["af"])) for r in rs]).encode()).hexdigest()
+        loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "merged_table_sha256": digest, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
                     "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0,
                     "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
                     "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
@@ -525,13 +589,19 @@ def main():
     k_bytes_tot = float(cls[PK, 3].sum())
     achieved = k_bytes_tot / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else 0.0
     k_ms = k_ms_tot / launches
-    traffic, traffic_src, issue = None, None, None
-    try:   # HBM bytes / VALU issue per launch from the committed PMC passes of this same command (profiles/, separate --pmc runs)
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_k_dp_pk.json")))
-        if pm.get("config") == a.config and not a.preset and not a.coverage and a.genome_scale == 1.0:
-            traffic = pm["traffic_bytes_per_launch"]; traffic_src = pm["source"]; issue = pm.get("valu_issue")
+    # What this run did NOT measure itself -- HBM bytes and VALU issue of the kernel from the committed PMC passes of the same
+    # command (rocprofv3 --pmc cannot run inside this process) -- is attached under `from_profile` with its provenance and only
+    # when the profile was taken on this workload; everything else in `roofline` is measured live in this run.
+    from_profile = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE)))
+        if pm.get("config") == a.config and not a.preset and not a.coverage and a.genome_scale == 1.0 and world == 1:
+            from_profile = {"file": "profiles/" + PMC_PROFILE, "collected_at_commit": pm.get("head_sha"), "collected_on": pm.get("date"), "command": pm.get("command"),
+                            "traffic_bytes_per_launch": pm["traffic_bytes_per_launch"], "traffic_over_algorithmic": pm.get("traffic_over_algorithmic"),
+                            "first_pass_launches_in_pmc_run": pm.get("first_pass_launches_in_pmc_run"), "valu_issue": pm.get("valu_issue"), "how": pm.get("source")}
     except Exception:
         pass
+    traffic = from_profile["traffic_bytes_per_launch"] if from_profile else None
     dp_ms = stage_tot.get("dp", 0.0) / a.steps
     ctr = {k: v / a.steps for k, v in ctr_tot.items()}
     # whole-path algorithmic bytes (SURVEY 8d formula) for reference
@@ -547,16 +617,22 @@ def main():
                    "reads_this_rank": int(len(D["reads"][2])), "read_bases_this_rank": n_bases, "read_bases_job": job_bases,
                    "parallelism": ("one fixed read set dealt to %d ranks in blocks by cumulative bases" % world if a.scaling == "strong" else "every rank maps its own read set (x%d)" % world)
                                   + "; index replicated (built by every rank, no broadcast); no collective on the stage-1 data path",
-                   "ranges": "the engine streams the rank's read set through in ranges of <= 2 Gbp, at most 1.6 G anchors at the density seen so far (one telr_map call per step)",
+                   "ranges": "one telr_map call per step; a read set of up to 1.6 Gbp is one range, a larger one streams through in ranges of at most 1.4 Gbp, two in flight, each also bounded by 1.6 G anchors at the density the index has shown (include/telr_hip.h: telr_map)",
                    "streaming": "telr_map returns with the records; the CIGAR DMA of step k overlaps step k+1 (all complete inside the timed region)"},
         "per_rank_ms_per_step": per_rank_ms, "rccl_world_size": world if dist is not None else 0,
         "roofline": {"bound": "hbm", "kernel": k_name, "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": traffic, "traffic_source": traffic_src, "valu_issue": issue, "launch_ms": k_ms, "launches_per_step": launches / a.steps,
+                     "traffic": traffic, "from_profile": from_profile, "launch_ms": k_ms, "launches_per_step": launches / a.steps,
                      "algorithmic_bytes_per_launch": k_bytes_tot / launches,
                      "problems_per_launch": float(cls[PK, 0].sum()) / launches, "cells_per_launch": float(cls[PK, 1].sum()) / launches,
                      "gcups": float(cls[PK, 1].sum()) / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else None,
-                     "note": "integer DP is VALU-issue bound, not HBM bound (DESIGN.md, Rooflines); with two ranges in flight a launch shares the device with the other range's kernels, so launch_ms is its stretched duration (alone, TELR_PIPELINE=1: 15.5 ms per 25.8 G-cell launch, 1,670 GCUPS; valu_issue from the PMC passes); all DP kernels together: %.1f ms per step, %.0f GCUPS"
+                     "note": "the contract's HBM roofline of the dominant kernel; the kernel's binding resource is VALU issue (see roofline_valu_issue). With two ranges in flight a launch shares the device with the other range's kernels, so launch_ms is its stretched duration; all DP kernels together: %.1f ms per step, %.0f GCUPS"
                              % (dp_ms, ctr["dp_cells"] / (dp_ms * 1e-3) / 1e9 if dp_ms > 0 else 0.0)},
+        # the same kernel against the resource that binds it: wave-instructions issued per SIMD-cycle against the issue interval
+        # of its instruction mix measured on this part (tools/ubench/valu_rate.hip).  Counter-derived: present only with a profile.
+        "roofline_valu_issue": None if not (from_profile and from_profile.get("valu_issue")) else {
+            "bound": "valu_issue", "kernel": k_name, "achieved": from_profile["valu_issue"]["cycles_per_wave_instruction_per_simd"],
+            "peak": from_profile["valu_issue"]["measured_issue_interval_cycles"], "unit": "cycles per wave-instruction per SIMD (lower is better)",
+            "frac": from_profile["valu_issue"]["valu_issue_frac"], "from_profile": from_profile["file"]},
         "stage_ms_per_step": {k: v / a.steps for k, v in stage_tot.items()},
         "dp_classes": {str(c): [int(x) // a.steps for x in cls[c]] for c in range(cls.shape[0]) if cls[c, 0]},
         "path_algorithmic_GBps": path_bytes / (gpu_ms * 1e-3) / 1e9 if gpu_ms > 0 else None,
@@ -570,7 +646,7 @@ def main():
         out["te_loci"] = loci_out
     if not a.no_cpu_baseline:
         ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(D["reads"][2]))))   # ~15-20 s of CPU work
-        out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns, gpu_index=ix)
+        out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns, gpu_index=ix, seed=a.cpu_sample_seed)
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"] if out["cpu_baseline"]["value"] > 0 else None
     json_out.write(json.dumps(out) + "\n"); json_out.flush()
     sys.stdout.flush()

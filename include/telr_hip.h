@@ -84,6 +84,15 @@ typedef struct telr_map_opt {
     int32_t fill_band_q4;     /* first-pass half band of a gap fill: 2 + q4*floor(sqrt(min(m,n)))/16;
                                  0 = 8.  Paths that come close to a band edge are re-aligned with the wide band. */
     int32_t fill_margin;      /* "close" = within this many diagonals of a band edge (0 = touching it)        */
+    /* sub-read voting (NGMLR's candidate search, Sedlazeck 2018: the read is cut into sub-reads, the k-mer hits of a sub-read
+     * vote for reference regions, only the best-voted regions are kept).  Applies to all-vs-all calls (qtarget == NULL, no
+     * TELR_MF_PER_TARGET); 0 = off.  The hits of the minimizers whose last base lies in query bases [s*vote_len, (s+1)*vote_len)
+     * vote into diagonal bins of 2^vote_bin_shift bases (per strand; 1024 bins, folded); a hit stays an anchor iff its bin and
+     * the two next to it hold >= max(vote_min, ceil(vote_frac_q8 / 256 * votes of the sub-read's fullest bin)) hits. */
+    int32_t vote_len;
+    int32_t vote_bin_shift;
+    int32_t vote_min;
+    int32_t vote_frac_q8;
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */
@@ -218,6 +227,12 @@ int  telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *
  * reference bases).  No ASCII sequences are needed.  level 0 = stored BGZF blocks; level >= 1 = deflate blocks coded on
  * the device (Huffman tables per BAM field class, run-length matches).  Bases print as the engine sees them: A C G T, anything
  * else N (telr_write_bam / telr_write_sam print the same, so the uncompressed streams of the two writers are equal). */
+/* Optional, before telr_map: start creating `bam_path` in the background (allocate est_bytes of it -- a BAM with --cs --MD
+ * takes about 0.85 bytes per read base at level 1, 2.8 at level 0 -- and map it), so that telr_write_bam_dev(... the same
+ * path ...) copies the finished file image into pages that already exist, with several threads, and cuts the file to size.
+ * Without it, or when the estimate was too small, the writer streams through a pinned ring and one pwrite thread.  A prepared file that is never written is removed
+ * from the context by the next telr_bam_prepare / telr_destroy (the file itself stays). */
+int  telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes);
 int  telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx,
                         const char *const *qnames, const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm,
                         const char *rg_lb, const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);

@@ -307,6 +307,31 @@ static int cmp_u64(const void *a, const void *b) { uint64_t x = *(const uint64_t
 #define A_Q(k)    ((int32_t)(((k) >> 8) & 0xffffff))
 #define A_SPAN(k) ((int32_t)((k) & 0xff))
 
+/* Sub-read voting (spec 3.10; NGMLR's candidate search, Sedlazeck 2018 / NextGenMap: SURVEY App. A.6).  hits[i0..i1) are the
+ * hits of the minimizers of ONE sub-read.  Every hit votes for its diagonal bin (reference minus strand-adjusted query
+ * position, 2^vote_bin_shift bases wide, 1024 bins per strand, folded); a hit stays iff its bin and the two neighbours hold
+ * at least max(vote_min, ceil(vote_frac_q8/256 x votes of the fullest bin)) hits. */
+#define VOTE_SLOTS 2048
+static inline uint32_t vote_slot(uint64_t key, int shift)
+{
+    uint32_t d = (uint32_t)A_G(key) - (uint32_t)A_Q(key) + (1u << 24);
+    return (((d >> shift) & (VOTE_SLOTS / 2 - 1)) << 1) | (uint32_t)A_REV(key);
+}
+static void vote_subread(const uint64_t *hits, int64_t n, const telr_map_opt *mo, u64v_t *out)
+{
+    uint32_t tab[VOTE_SLOTS];
+    memset(tab, 0, sizeof(tab));
+    uint32_t v1 = 0;
+    for (int64_t i = 0; i < n; ++i) { uint32_t c = ++tab[vote_slot(hits[i], mo->vote_bin_shift)]; if (c > v1) v1 = c; }
+    uint32_t thr = (v1 * (uint32_t)mo->vote_frac_q8 + 255u) >> 8;
+    if (thr < (uint32_t)mo->vote_min) thr = (uint32_t)mo->vote_min;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t s = vote_slot(hits[i], mo->vote_bin_shift);
+        uint32_t w = tab[(s - 2) & (VOTE_SLOTS - 1)] + tab[s] + tab[(s + 2) & (VOTE_SLOTS - 1)];
+        if (w >= thr) vpush(uint64_t, *out, hits[i]);
+    }
+}
+
 static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int32_t tfilter, int32_t mid_occ, const telr_map_opt *mo,
                             u64v_t *out, int64_t *n_mz, int64_t *n_probe)
 {
@@ -314,6 +339,9 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
     sketch(q, qlen, ix->k, ix->w, ix->hpc, 0, &mv);
     *n_mz += mv.n;
     const int per_t = tfilter < 0 && (mo->flags & TELR_MF_PER_TARGET);
+    const int vote = mo->vote_len > 0 && tfilter < 0 && !per_t;
+    u64v_t sub = {0, 0, 0};          /* hits of the sub-read in progress */
+    int32_t sub_id = -1;
     uint32_t g0 = 0, g1 = 0xffffffffu;
     if (tfilter >= 0) {
         g0 = ix->goff[tfilter]; g1 = g0 + (uint32_t)ix->len[tfilter];
@@ -346,6 +374,18 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
         if (tfilter >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t g = ix->ys[o] >> 1; if (g >= g0 && g < g1) ++cnt; } }
         else cnt = (int32_t)(o1 - o0);
         if (cnt == 0 || cnt > mid_occ) continue;
+        if (vote) {
+            /* minimizers come in query order: a new sub-read closes the previous one */
+            int32_t sid = qpos / mo->vote_len;
+            if (sid != sub_id) { vote_subread(sub.a, sub.n, mo, out); sub.n = 0; sub_id = sid; }
+            for (uint32_t o = o0; o < o1; ++o) {
+                uint32_t g = ix->ys[o] >> 1; int tz = ix->ys[o] & 1;
+                uint64_t key = tz == qz ? (uint64_t)g << 32 | (uint64_t)qpos << 8 | (uint64_t)span
+                                        : KEY_REV | (uint64_t)g << 32 | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
+                vpush(uint64_t, sub, key);
+            }
+            continue;
+        }
         for (uint32_t o = o0; o < o1; ++o) {
             uint32_t g = ix->ys[o] >> 1;
             if (tfilter >= 0 && (g < g0 || g >= g1)) continue;
@@ -356,6 +396,7 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
             vpush(uint64_t, *out, key);
         }
     }
+    if (vote) { vote_subread(sub.a, sub.n, mo, out); free(sub.a); }
     free(mv.a);
     qsort(out->a, out->n, 8, cmp_u64);
 }

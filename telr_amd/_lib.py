@@ -15,7 +15,7 @@ EXPORTS = [
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
-    "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
+    "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
 _lib = None
@@ -64,7 +64,11 @@ def lib():
     L.telr_write_bam.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, cp, cp, cp, cp, cp, i32, i32]
     L.telr_write_bam_dev.restype = C.c_int
     L.telr_write_bam_dev.argtypes = [vp, vp, vp, vp, vp, vp, i32, cp, cp, cp, cp, cp, i32, i32]
+    L.telr_bam_prepare.restype = C.c_int; L.telr_bam_prepare.argtypes = [vp, cp, i64]
+    L.telr_debug_bam_sink_ms.restype = C.c_int; L.telr_debug_bam_sink_ms.argtypes = [vp]
     L.telr_debug_bam_ms.restype = C.c_int; L.telr_debug_bam_ms.argtypes = [vp]
+    L.telr_debug_huff.restype = C.c_int; L.telr_debug_huff.argtypes = [vp, i32, i32, vp]
+    L.telr_debug_deflate_host.restype = C.c_int; L.telr_debug_deflate_host.argtypes = [vp, i32, vp, i32, vp]
     L.telr_stage_ms.restype = C.c_int; L.telr_stage_ms.argtypes = [vp, vp]
     L.telr_stage_name.restype = cp; L.telr_stage_name.argtypes = [C.c_int]
     L.telr_last_counters.restype = C.c_int; L.telr_last_counters.argtypes = [vp, C.POINTER(Counters)]

@@ -170,6 +170,8 @@ class Index:
     # ---- text emitters (the reference's own boundary: PAF / SAM files) -----------------------
     @staticmethod
     def _cstr_array(names):
+        if isinstance(names, C.Array):          # already built (a caller that writes many files with the same names)
+            return names
         arr = (C.c_char_p * max(1, len(names)))()
         for i, n in enumerate(names):
             arr[i] = n.encode() if isinstance(n, str) else bytes(n)
@@ -222,10 +224,16 @@ class Index:
         self.eng._chk(self.eng.L.telr_write_bam_dev(self.eng.h, r, queries.h, self.h, qa, ta, flags, rg_id, rg_sm, rg_lb,
                                                     cmdline.encode(), path.encode(), 1 if index else 0, level), "telr_write_bam_dev")
 
+    def bam_prepare(self, path, est_bytes):
+        """start creating the output file in the background (call before map_raw; see telr_bam_prepare)"""
+        self.eng._chk(self.eng.L.telr_bam_prepare(self.eng.h, path.encode(), int(est_bytes)), "telr_bam_prepare")
+
     def bam_stage_ms(self):
-        a = np.zeros(8, np.float32)
-        self.eng.L.telr_debug_bam_ms(a.ctypes.data)
-        return dict(zip(("upload", "scan_size", "sort_offsets", "write_records", "bgzf", "d2h_file", "bai_host_overlapped", "total"), (float(x) for x in a)))
+        a = np.zeros(8, np.float32); b = np.zeros(4, np.float32)
+        self.eng.L.telr_debug_bam_ms(a.ctypes.data); self.eng.L.telr_debug_bam_sink_ms(b.ctypes.data)
+        d = dict(zip(("upload", "scan_size", "sort_offsets", "write_records", "bgzf", "d2h_file", "bai_host_overlapped", "total"), (float(x) for x in a)))
+        d.update(zip(("sink_allocate_bg", "sink_map_bg", "sink_wait", "sink_mapping_used"), (float(x) for x in b)))
+        return d
 
     def depth_medians(self, r, iv_tid, iv_s, iv_e):
         """Medians over 0-based inclusive intervals, from a raw result handle."""

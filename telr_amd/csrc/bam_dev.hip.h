@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64) k_bam_write(BamArgs A)
 
 // ---- CRC-32 (IEEE, reflected 0xEDB88320) of a BGZF block by 256 threads: every thread its own piece, then
 // crc(A || B) = crc(A) * x^(8|B|) + crc(B) over GF(2) (the identity behind zlib's crc32_combine)
-struct CrcTabs { uint32_t byte_tab[256]; uint32_t xpow255[256]; };      // xpow255[k] = x^(8 * 255 * k) mod P
+struct CrcTabs { uint32_t byte_tab[256]; uint32_t xpow255[256]; uint32_t xpow64[1024]; };      // xpow255[k] = x^(8 * 255 * k) mod P, xpow64[k] = x^(8 * 64 * k)
 __device__ __forceinline__ uint32_t d_gf2_mulmod(uint32_t a, uint32_t b)
 {
     uint32_t p = 0;
@@ -484,6 +484,257 @@ __global__ void __launch_bounds__(256) k_bgzf_store(const uint8_t *__restrict__ 
     }
 }
 
+// ---- level >= 1: deflate on the device --------------------------------------------------------------------------------
+// A BAM stream is four kinds of bytes with very different statistics: binary fixed fields + CIGAR words (class A), the
+// 4-bit SEQ whose bytes take 16 values followed by the QUAL run of 0xff (class B), and tag text -- MD / cs / SA -- (class C).
+// One Huffman table over the mixture pays ~1 bit per byte for not knowing the field; so every field segment becomes its own
+// DEFLATE block (RFC 1951, BTYPE = 10) coded with the table of its class.  The three tables are computed ONCE per file
+// (k_bam_hist over a sample of the blocks, Huffman lengths on the host) and their headers are pasted as ready-made bit strings.
+// Matching is run-length only (distance 1): QUAL collapses, CIGAR zero bytes shorten; SEQ and the text have no long repeats
+// worth a hash table.  Field boundaries come from the records themselves (l_read_name, n_cigar_op, l_seq in the stream).
+#define DEFL_NCLS    3
+#define DEFL_THREADS 1024
+#define DEFL_PIECE   64             /* bytes per thread: BAM_BLK = 1020 pieces */
+#define DEFL_SEGCAP  256
+#define DEFL_MINSEG  192            /* a field shorter than this is coded with the table in force (a switch costs 40-80 bytes) */
+#define DEFL_SLOT    65536
+struct DeflTabs {
+    uint32_t lit[DEFL_NCLS][288];       // symbols 0..285: bit-reversed code | length << 16
+    uint32_t hdr_bits[DEFL_NCLS];       // bits of the dynamic-block header (after BFINAL / BTYPE)
+    uint32_t hdr[DEFL_NCLS][96];
+    uint16_t len_sym[259];              // match length -> (symbol - 257) | extra bits << 5 | extra value << 8
+};
+struct DeflSeg { uint16_t start; uint16_t cls; };
+
+// segments of block [u0, u0 + n): where the table changes.  Executed by wave 0 of the workgroup; result in LDS (seg[0].start = 0).
+__device__ __forceinline__ int d_defl_segments(const uint8_t *__restrict__ ubuf, uint64_t u0, int n, uint64_t head, const uint64_t *__restrict__ ust, int32_t nrec,
+                                               int32_t rec0, DeflSeg *seg, int lane)
+{
+    // class at u0
+    int nseg = 0;
+    int r = rec0;                                     // last record starting at or before u0 (-1: inside the header)
+    if (r < 0) { if (lane == 0) { seg[0].start = 0; seg[0].cls = 2; } nseg = 1; r = 0; if (nrec == 0) return 1; }
+    const uint64_t uend = u0 + (uint64_t)n;
+    bool first = rec0 >= 0;
+    for (; r < nrec; r += 64) {
+        const int k = r + lane;
+        uint64_t s = ~0ULL, p1 = 0, p2 = 0, e = 0;
+        if (k < nrec) s = ust[k] + head;
+        const bool in = k < nrec && s < uend;
+        if (in) {
+            e = ust[k + 1] + head;
+            const uint8_t *h = ubuf + s;
+            const uint32_t l_name = h[12], n_cig = (uint32_t)h[16] | (uint32_t)h[17] << 8, l_seq = (uint32_t)h[20] | (uint32_t)h[21] << 8 | (uint32_t)h[22] << 16 | (uint32_t)h[23] << 24;
+            p1 = s + 36 + l_name + 4ull * n_cig; p2 = p1 + (l_seq + 1) / 2 + l_seq;
+        }
+        if (first) {      // lane 0 holds the record around u0
+            if (lane == 0) { seg[0].start = 0; seg[0].cls = (uint16_t)(u0 < p1 ? 0 : (u0 < p2 ? 1 : 2)); }
+            nseg = 1; first = false;
+        }
+        // candidate switches: (s, A), (p1, B), (p2, C) strictly inside the block, whose own field is long enough
+        bool k0 = in && s > u0 && s < uend && (p1 - s) >= DEFL_MINSEG, k1 = in && p1 > u0 && p1 < uend && (p2 - p1) >= DEFL_MINSEG, k2 = in && p2 > u0 && p2 < uend && (e - p2) >= DEFL_MINSEG;
+        const int cnt = (int)k0 + (int)k1 + (int)k2;
+        const int inc = d_wave_incl(cnt, lane);
+        int w = nseg + inc - cnt;
+        if (k0 && w < DEFL_SEGCAP) { seg[w].start = (uint16_t)(s - u0); seg[w].cls = 0; ++w; }
+        if (k1 && w < DEFL_SEGCAP) { seg[w].start = (uint16_t)(p1 - u0); seg[w].cls = 1; ++w; }
+        if (k2 && w < DEFL_SEGCAP) { seg[w].start = (uint16_t)(p2 - u0); seg[w].cls = 2; ++w; }
+        nseg += __shfl(inc, 63);
+        if (nseg > DEFL_SEGCAP) nseg = DEFL_SEGCAP;
+        if (__ballot(k < nrec && s >= uend) || r + 64 >= nrec) break;
+    }
+    return nseg;
+}
+
+// first record of every block: the last one starting at or before the block's first byte (-1: none, the block starts in the header)
+__global__ void __launch_bounds__(256) k_blk_first_rec(const uint64_t *__restrict__ ust, int32_t nrec, uint64_t head, int32_t nblk, int32_t *__restrict__ rec0)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    const uint64_t u0 = (uint64_t)b * BAM_BLK;
+    if (u0 < head || nrec == 0) { rec0[b] = -1; return; }
+    int lo = 0, hi = nrec - 1;            // ust[0] + head = head <= u0
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (ust[mid] + head <= u0) lo = mid; else hi = mid - 1; }
+    rec0[b] = lo;
+}
+
+// The token walk of one thread over its piece.  MODE 0: bits; 1: emit into the LDS bit buffer; 2: histogram (hist[cls][sym]).
+struct BitW { uint64_t acc; int nb; uint32_t word; uint32_t *out; };
+__device__ __forceinline__ void d_bw_put(BitW &W, uint32_t v, int len)
+{
+    W.acc |= (uint64_t)v << W.nb; W.nb += len;
+    if (W.nb >= 32) { atomicOr(&W.out[W.word], (uint32_t)W.acc); ++W.word; W.acc >>= 32; W.nb -= 32; }
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t d_defl_piece(const uint8_t *in, int n, int t, const DeflSeg *seg, int nseg, const DeflTabs *T, BitW *W, uint32_t *hist)
+{
+    const int p0 = t * DEFL_PIECE;
+    if (p0 >= n) return 0;
+    const int p1 = p0 + DEFL_PIECE < n ? p0 + DEFL_PIECE : n;
+    // segment in force just before p0 (a switch exactly at p0 is this thread's to emit)
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)seg[mid].start < p0) lo = mid; else hi = mid - 1; }
+    int si = lo, cls = seg[si].cls;
+    int next = si + 1 < nseg ? (int)seg[si + 1].start : 0x7fffffff;
+    uint32_t bits = 0;
+    auto open_block = [&](int s) {
+        const int c = seg[s].cls;
+        if (MODE == 0) bits += 3 + T->hdr_bits[c];
+        else if (MODE == 1) {
+            d_bw_put(*W, (s == nseg - 1 ? 1u : 0u) | 2u << 1, 3);
+            const uint32_t hb = T->hdr_bits[c];
+            for (uint32_t i = 0; i < hb; i += 16) { const uint32_t w = T->hdr[c][i >> 5] >> (i & 31); const int l = hb - i < 16 ? (int)(hb - i) : 16; d_bw_put(*W, w & ((1u << l) - 1u), l); }
+        }
+    };
+    auto put_sym = [&](int c, int sym) {
+        if (MODE == 0) bits += T->lit[c][sym] >> 16;
+        else if (MODE == 1) { const uint32_t e = T->lit[c][sym]; d_bw_put(*W, e & 0xffffu, (int)(e >> 16)); }
+        else atomicAdd(&hist[c * 288 + sym], 1u);
+    };
+    if (p0 == 0) open_block(0);
+    int i = p0;
+    uint32_t prev = i > 0 ? in[i - 1] : 0x100u;
+    while (i < p1) {
+        if (i == next) {       // the table changes here
+            put_sym(cls, 256);
+            ++si; cls = seg[si].cls; open_block(si);
+            next = si + 1 < nseg ? (int)seg[si + 1].start : 0x7fffffff;
+        }
+        const uint32_t b = in[i];
+        const int lim = p1 < next ? p1 : next;
+        if (b == prev) {
+            int L = 1;
+            while (i + L < lim && in[i + L] == b) ++L;
+            if (L >= 3) {
+                if (MODE == 2) { atomicAdd(&hist[cls * 288 + 257 + (T->len_sym[L] & 31)], 1u); }
+                else {
+                    const uint32_t ls = T->len_sym[L]; const int sym = 257 + (int)(ls & 31), eb = (int)(ls >> 5 & 7);
+                    put_sym(cls, sym);
+                    if (MODE == 0) bits += eb + 1; else { if (eb) d_bw_put(*W, ls >> 8, eb); d_bw_put(*W, 0u, 1); }      // the only distance code (distance 1) is one bit
+                }
+                i += L; continue;            // prev stays b
+            }
+        }
+        put_sym(cls, (int)b);
+        prev = b; ++i;
+    }
+    if (p1 == n) put_sym(cls, 256);
+    return bits;
+}
+
+__global__ void __launch_bounds__(DEFL_THREADS) k_bam_hist(const uint8_t *__restrict__ ubuf, uint64_t utotal, uint64_t head, const uint64_t *__restrict__ ust, int32_t nrec,
+                                                          const int32_t *__restrict__ rec0, int32_t stride, const DeflTabs *__restrict__ T, uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t in4[BAM_BLK / 4];
+    __shared__ DeflSeg seg[DEFL_SEGCAP];
+    __shared__ uint32_t hist[DEFL_NCLS * 288];
+    __shared__ int s_nseg;
+    const int t = threadIdx.x;
+    const uint64_t b = (uint64_t)blockIdx.x * stride, u0 = b * BAM_BLK;
+    const int n = (int)(utotal - u0 < BAM_BLK ? utotal - u0 : BAM_BLK);
+    const uint32_t *src4 = (const uint32_t*)(ubuf + u0);
+    for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i] = src4[i];
+    for (int i = t; i < DEFL_NCLS * 288; i += DEFL_THREADS) hist[i] = 0;
+    if (t < 64) { const int ns = d_defl_segments(ubuf, u0, n, head, ust, nrec, rec0[b], seg, t); if (t == 0) s_nseg = ns; }
+    __syncthreads();
+    d_defl_piece<2>((const uint8_t*)in4, n, t, seg, s_nseg, T, nullptr, hist);
+    __syncthreads();
+    for (int i = t; i < DEFL_NCLS * 288; i += DEFL_THREADS) if (hist[i]) atomicAdd(&ghist[i], hist[i]);
+}
+
+// one BGZF block: out slot b (DEFL_SLOT bytes), its size in csize[b]
+__global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__restrict__ ubuf, uint64_t utotal, uint64_t head, const uint64_t *__restrict__ ust, int32_t nrec,
+                                                              const int32_t *__restrict__ rec0, const DeflTabs *__restrict__ T, const CrcTabs *__restrict__ CT,
+                                                              uint8_t *__restrict__ slots, uint32_t *__restrict__ csize)
+{
+    __shared__ uint32_t in4[BAM_BLK / 4];
+    __shared__ uint32_t out4[BAM_BLK / 4 + 8];
+    __shared__ DeflSeg seg[DEFL_SEGCAP];
+    __shared__ uint32_t tab[256], wsum[16], red[4];
+    __shared__ int s_nseg; __shared__ uint32_t s_total;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint64_t b = blockIdx.x, u0 = b * BAM_BLK;
+    const int n = (int)(utotal - u0 < BAM_BLK ? utotal - u0 : BAM_BLK);
+    const uint32_t *src4 = (const uint32_t*)(ubuf + u0);
+    for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i] = src4[i];
+    for (int i = t; i < BAM_BLK / 4 + 8; i += DEFL_THREADS) out4[i] = 0;
+    if (t < 256) tab[t] = CT->byte_tab[t];
+    if (t < 64) { const int ns = d_defl_segments(ubuf, u0, n, head, ust, nrec, rec0[b], seg, t); if (t == 0) s_nseg = ns; }
+    __syncthreads();
+    const uint8_t *in = (const uint8_t*)in4;
+    const int nseg = s_nseg;
+    const uint32_t bits = d_defl_piece<0>(in, n, t, seg, nseg, T, nullptr, nullptr);
+    // exclusive scan of the bit counts over the workgroup
+    const uint32_t inc = (uint32_t)d_wave_incl((int)bits, lane);
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    if (t < 16) { uint32_t v = wsum[t]; for (int o = 1; o < 16; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)v, o, 16); if (t >= o) v += y; } wsum[t] = v; if (t == 15) s_total = v; }
+    __syncthreads();
+    const uint32_t off = inc - bits + (wv ? wsum[wv - 1] : 0u), total = s_total;
+    const uint32_t cbytes = (total + 7) >> 3;
+    const bool stored = cbytes + 26 > (uint32_t)n + 31 || cbytes > BAM_BLK;        // deflate no smaller than a stored block: keep it stored
+    if (!stored) {
+        BitW W; W.acc = 0; W.nb = (int)(off & 31); W.word = off >> 5; W.out = out4;
+        d_defl_piece<1>(in, n, t, seg, nseg, T, &W, nullptr);
+        if (W.nb) atomicOr(&out4[W.word], (uint32_t)W.acc);
+    }
+    // CRC-32 of the input: pieces of 64 bytes, combined with x^(512 k) (crc(A || B) = crc(A) x^(8|B|) + crc(B))
+    uint32_t c = 0;
+    if (n == BAM_BLK) {
+        if (t < BAM_BLK / DEFL_PIECE) {
+            uint32_t s = 0xffffffffu;
+            const uint8_t *p = in + t * DEFL_PIECE;
+            for (int i = 0; i < DEFL_PIECE; ++i) s = tab[(s ^ p[i]) & 0xffu] ^ (s >> 8);
+            c = d_gf2_mulmod(CT->xpow64[BAM_BLK / DEFL_PIECE - 1 - t], ~s);
+        }
+    } else if (t == 0) {
+        uint32_t s = 0xffffffffu;
+        for (int i = 0; i < n; ++i) s = tab[(s ^ in[i]) & 0xffu] ^ (s >> 8);
+        c = ~s;
+    }
+    for (int s = 32; s >= 1; s >>= 1) c ^= (uint32_t)__shfl_xor((int)c, s);
+    __syncthreads();                     // out4 complete, wsum free
+    if (lane == 0) wsum[wv] = c;
+    __syncthreads();
+    uint8_t *out = slots + b * (uint64_t)DEFL_SLOT;
+    const uint32_t payload = stored ? (uint32_t)n + 5 : cbytes;
+    if (stored) {
+        for (int i = t; i < (n >> 2); i += DEFL_THREADS) d_st32(out + 23 + 4 * i, in4[i]);
+        for (int i = (n & ~3) + t; i < n; i += DEFL_THREADS) out[23 + i] = in[i];
+        if (t == 0) { out[18] = 1; d_st16(out + 19, (uint32_t)n); d_st16(out + 21, (uint32_t)(~n & 0xffff)); }
+    } else {
+        // payload at out + 18: 2 bytes past a dword boundary
+        for (uint32_t i = t; i < (cbytes + 3) >> 2; i += DEFL_THREADS) {
+            const uint32_t v = out4[i];
+            if (4 * i + 4 <= cbytes) { d_st16(out + 18 + 4 * i, v & 0xffffu); d_st16(out + 20 + 4 * i, v >> 16); }
+            else for (uint32_t k = 0; 4 * i + k < cbytes; ++k) out[18 + 4 * i + k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+    if (t == 0) {
+        uint32_t crc = 0; for (int i = 0; i < 16; ++i) crc ^= wsum[i];
+        const uint8_t hdr[16] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0 };
+        for (int i = 0; i < 16; ++i) out[i] = hdr[i];
+        d_st16(out + 16, payload + 26 - 1);
+        d_st32(out + 18 + payload, crc); d_st32(out + 22 + payload, (uint32_t)n);
+        csize[b] = payload + 26;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bgzf_compact(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ csize, const uint64_t *__restrict__ coff, uint8_t *__restrict__ dst)
+{
+    const uint64_t b = blockIdx.x;
+    const uint32_t n = csize[b];
+    const uint32_t *s4 = (const uint32_t*)(slots + b * (uint64_t)DEFL_SLOT);
+    uint8_t *d = dst + coff[b];
+    for (uint32_t i = threadIdx.x; i < n >> 2; i += 256) d_st32(d + 4 * i, s4[i]);
+    for (uint32_t i = (n & ~3u) + threadIdx.x; i < n; i += 256) d[i] = slots[b * (uint64_t)DEFL_SLOT + i];
+}
+__global__ void __launch_bounds__(256) k_widen_u32(const uint32_t *__restrict__ in, int32_t n, uint64_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i]; else if (i == n) out[i] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 static void crc_tabs_make(CrcTabs &T)
@@ -495,6 +746,158 @@ static void crc_tabs_make(CrcTabs &T)
     for (int i = 0; i < 8 * 255; ++i) x1 = (x1 & 1u) ? (x1 >> 1) ^ 0xEDB88320u : x1 >> 1;
     T.xpow255[0] = 0x80000000u;
     for (int k = 1; k < 256; ++k) T.xpow255[k] = mul(T.xpow255[k - 1], x1);
+    uint32_t x64 = 0x80000000u;
+    for (int i = 0; i < 8 * 64; ++i) x64 = (x64 & 1u) ? (x64 >> 1) ^ 0xEDB88320u : x64 >> 1;
+    T.xpow64[0] = 0x80000000u;
+    for (int k = 1; k < 1024; ++k) T.xpow64[k] = mul(T.xpow64[k - 1], x64);
+}
+
+
+// ---- Huffman tables of the device deflate (host) ---------------------------------------------------------------------
+// code lengths limited to `maxlen` bits: Huffman depths, then the overflow moved down the lengths (the method of miniz /
+// zlib's gen_bitlen: fold codes longer than the limit into it, repair the Kraft sum, hand the longest codes to the rarest symbols)
+static void huff_lengths(const uint32_t *freq, int n, int maxlen, uint8_t *lens)
+{
+    std::vector<int> sym;
+    for (int i = 0; i < n; ++i) { lens[i] = 0; if (freq[i]) sym.push_back(i); }
+    if (sym.empty()) return;
+    if (sym.size() == 1) { lens[sym[0]] = 1; return; }
+    std::stable_sort(sym.begin(), sym.end(), [&](int a, int b) { return freq[a] < freq[b]; });
+    const int m = (int)sym.size();
+    // two-queue Huffman on the sorted leaves
+    std::vector<uint64_t> w(2 * m); std::vector<int> parent(2 * m, -1);
+    for (int i = 0; i < m; ++i) w[i] = freq[sym[i]];
+    int leaf = 0, inode = m, next = m;
+    auto take = [&]() { if (leaf < m && (inode >= next || w[leaf] <= w[inode])) return leaf++; return inode++; };
+    while (next < 2 * m - 1) { const int a = take(), b = take(); w[next] = w[a] + w[b]; parent[a] = parent[b] = next; ++next; }
+    std::vector<int> depth(2 * m, 0);
+    for (int i = 2 * m - 3; i >= 0; --i) depth[i] = depth[parent[i]] + 1;
+    std::vector<int> cnt(64, 0);
+    for (int i = 0; i < m; ++i) ++cnt[depth[i] < 63 ? depth[i] : 63];
+    for (int l = 63; l > maxlen; --l) { cnt[maxlen] += cnt[l]; cnt[l] = 0; }
+    uint64_t total = 0;
+    for (int l = maxlen; l >= 1; --l) total += (uint64_t)cnt[l] << (maxlen - l);
+    while (total != (1ull << maxlen)) {
+        --cnt[maxlen];
+        for (int l = maxlen - 1; l >= 1; --l) if (cnt[l]) { --cnt[l]; cnt[l + 1] += 2; break; }
+        --total;
+    }
+    int k = 0;        // rarest symbols first: longest codes
+    for (int l = maxlen; l >= 1; --l) for (int c = 0; c < cnt[l]; ++c) lens[sym[k++]] = (uint8_t)l;
+}
+static void huff_codes(const uint8_t *lens, int n, uint32_t *codes_rev)
+{
+    int bl[17] = {0}; uint32_t nc[17] = {0};
+    for (int i = 0; i < n; ++i) ++bl[lens[i]];
+    bl[0] = 0;
+    uint32_t code = 0;
+    for (int l = 1; l <= 16; ++l) { code = (code + bl[l - 1]) << 1; nc[l] = code; }
+    for (int i = 0; i < n; ++i) {
+        const int l = lens[i]; uint32_t c = 0;
+        if (l) { uint32_t v = nc[l]++; for (int b = 0; b < l; ++b) c |= ((v >> b) & 1u) << (l - 1 - b); }
+        codes_rev[i] = c;
+    }
+}
+struct HostBits { std::vector<uint32_t> w; uint32_t n = 0; void put(uint32_t v, int len) { for (int i = 0; i < len; ++i) { if ((n >> 5) >= w.size()) w.push_back(0); w[n >> 5] |= ((v >> i) & 1u) << (n & 31); ++n; } } };
+// the header of a dynamic block (RFC 1951 3.2.7) for literal/length lengths ll[286] and ONE distance code of length 1
+static void deflate_dyn_header(const uint8_t *ll, HostBits &B)
+{
+    std::vector<uint8_t> all(ll, ll + 286); all.push_back(1);
+    struct Sy { uint8_t s, ebits, eval; };
+    std::vector<Sy> rl;
+    for (size_t i = 0; i < all.size(); ) {
+        size_t j = i; while (j < all.size() && all[j] == all[i]) ++j;
+        size_t run = j - i; const uint8_t v = all[i];
+        if (v == 0) {
+            while (run >= 11) { size_t r = std::min<size_t>(run, 138); rl.push_back(Sy{18, 7, (uint8_t)(r - 11)}); run -= r; }
+            if (run >= 3) { rl.push_back(Sy{17, 3, (uint8_t)(run - 3)}); run = 0; }
+            while (run--) rl.push_back(Sy{0, 0, 0});
+        } else {
+            rl.push_back(Sy{v, 0, 0}); --run;
+            while (run >= 3) { size_t r = std::min<size_t>(run, 6); rl.push_back(Sy{16, 2, (uint8_t)(r - 3)}); run -= r; }
+            while (run--) rl.push_back(Sy{v, 0, 0});
+        }
+        i = j;
+    }
+    uint32_t f[19] = {0}; for (auto &x : rl) ++f[x.s];
+    uint8_t cl[19]; huff_lengths(f, 19, 7, cl);
+    uint32_t cc[19]; huff_codes(cl, 19, cc);
+    static const int ord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 19; while (hclen > 4 && cl[ord[hclen - 1]] == 0) --hclen;
+    B.put(286 - 257, 5); B.put(0, 5); B.put((uint32_t)(hclen - 4), 4);
+    for (int i = 0; i < hclen; ++i) B.put(cl[ord[i]], 3);
+    for (auto &x : rl) { B.put(cc[x.s], cl[x.s]); if (x.ebits) B.put(x.eval, x.ebits); }
+}
+static void defl_len_syms(uint16_t *len_sym)
+{
+    static const int base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const int eb[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    for (int L = 0; L < 259; ++L) {
+        if (L < 3) { len_sym[L] = 0; continue; }
+        int c = 28; while (base[c] > L) --c;
+        if (L == 258) c = 28;
+        len_sym[L] = (uint16_t)(c | eb[c] << 5 | (L - base[c]) << 8);
+    }
+}
+// histogram[class][288] -> tables.  Every literal, the end-of-block symbol and every length symbol keeps a code (count >= 1):
+// any byte may turn up in any class (fields shorter than DEFL_MINSEG ride on the table in force).
+static int defl_tables_from_hist(const uint32_t *hist, DeflTabs &T)
+{
+    for (int c = 0; c < DEFL_NCLS; ++c) {
+        uint32_t f[286];
+        for (int i = 0; i < 286; ++i) f[i] = hist[c * 288 + i] + 1;
+        uint8_t ll[286]; huff_lengths(f, 286, 15, ll);
+        uint32_t codes[286]; huff_codes(ll, 286, codes);
+        for (int i = 0; i < 288; ++i) T.lit[c][i] = i < 286 ? (codes[i] | (uint32_t)ll[i] << 16) : 0;
+        HostBits B; deflate_dyn_header(ll, B);
+        if (B.w.size() > 96) return TELR_E_RANGE;
+        T.hdr_bits[c] = B.n;
+        memset(T.hdr[c], 0, sizeof(T.hdr[c]));
+        memcpy(T.hdr[c], B.w.data(), B.w.size() * 4);
+    }
+    return TELR_OK;
+}
+// CPU tap for tests/test_deflate_tables.py: code lengths (length-limited, complete) and the dynamic-block header bit string
+extern "C" int telr_debug_huff(const uint32_t *freq, int32_t n, int32_t maxlen, uint8_t *lens_out)
+{
+    if (!freq || !lens_out || n < 1 || n > 288 || maxlen < 1 || maxlen > 15) return TELR_E_ARG;
+    huff_lengths(freq, n, maxlen, lens_out);
+    return TELR_OK;
+}
+// a whole deflate stream for `src` with ONE class table built from its own histogram, literals + distance-1 matches cut at
+// pieces of 64 bytes: the host restatement of what k_bgzf_deflate emits for a one-segment block (zlib must inflate it to src)
+extern "C" int telr_debug_deflate_host(const uint8_t *src, int32_t n, uint8_t *out, int32_t cap, int32_t *out_len)
+{
+    if (!src || n < 0 || !out || !out_len) return TELR_E_ARG;
+    uint16_t len_sym[259]; defl_len_syms(len_sym);
+    std::vector<uint32_t> hist(DEFL_NCLS * 288, 0);
+    auto walk = [&](auto &&lit, auto &&match) {
+        for (int p0 = 0; p0 < n; p0 += DEFL_PIECE) {
+            const int p1 = std::min(n, p0 + DEFL_PIECE);
+            int i = p0; int prev = i > 0 ? src[i - 1] : 256;
+            while (i < p1) {
+                const int b = src[i];
+                if (b == prev) { int L = 1; while (i + L < p1 && src[i + L] == b) ++L; if (L >= 3) { match(L); i += L; continue; } }
+                lit(b); prev = b; ++i;
+            }
+        }
+    };
+    walk([&](int b) { ++hist[b]; }, [&](int L) { ++hist[257 + (len_sym[L] & 31)]; });
+    ++hist[256];
+    DeflTabs T; memset(&T, 0, sizeof(T));
+    int rc = defl_tables_from_hist(hist.data(), T);
+    if (rc != TELR_OK) return rc;
+    HostBits B;
+    B.put(1u | 2u << 1, 3);
+    for (uint32_t i = 0; i < T.hdr_bits[0]; ++i) B.put((T.hdr[0][i >> 5] >> (i & 31)) & 1u, 1);
+    auto sym = [&](int s) { B.put(T.lit[0][s] & 0xffffu, (int)(T.lit[0][s] >> 16)); };
+    walk([&](int b) { sym(b); }, [&](int L) { const uint32_t ls = len_sym[L]; sym(257 + (int)(ls & 31)); if (ls >> 5 & 7) B.put(ls >> 8, (int)(ls >> 5 & 7)); B.put(0, 1); });
+    sym(256);
+    const int nb = (int)((B.n + 7) / 8);
+    if (nb > cap) return TELR_E_RANGE;
+    memcpy(out, B.w.data(), (size_t)nb);
+    *out_len = nb;
+    return TELR_OK;
 }
 
 struct BamTimes { float ms[8]; };        // upload, scan+size, sort+scan, write, bgzf, d2h+file, bai (host, overlapped), total
@@ -572,27 +975,79 @@ static std::string bam_header(int32_t n_targets, const char *const *tnames, cons
     return head;
 }
 
+// ---- the output file, prepared ahead -----------------------------------------------------------------------------------
+// What a tmpfs file costs is the allocation of its pages (tools/ubench/shm_io.hip on the MI355X box: pwrite into a fresh
+// file 6.4-6.7 GB/s with one thread and LESS with more -- writes to one inode serialise --, posix_fallocate 17 GB/s, pwrite
+// over allocated pages 9.7 GB/s, memcpy through a mapping of the allocated file 12-15 GB/s with 4-16 threads -- no inode lock
+// on that path; DMA straight into a registered mapping runs at 50-57 GB/s but registering costs 0.47 s per 3.9 GB, pages
+// present or not, and stalls every other HIP call of the process meanwhile: measured, rejected).  telr_bam_prepare() starts
+// a thread that creates the file, allocates an estimated size and maps it while the caller is still mapping reads; the
+// writer then moves the finished image through the pinned ring into the mapping with several threads and cuts the file to
+// its real length.
+struct BamSink {
+    std::string path; int fd = -1; uint8_t *map = nullptr; size_t bytes = 0;
+    std::thread th; float ms_alloc = 0, ms_map = 0;
+};
+static float g_sink_ms[4];      // allocate, map (prepare thread); wait for that thread (writer); 1 = the mapping was used
+static void bam_sink_drop(telr_ctx *ctx)
+{
+    BamSink *k = ctx->bam_sink;
+    if (!k) return;
+    if (k->th.joinable()) k->th.join();
+    if (k->map) munmap(k->map, k->bytes);
+    if (k->fd >= 0) close(k->fd);
+    delete k; ctx->bam_sink = nullptr;
+}
+extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes)
+{
+    if (!ctx || !bam_path || est_bytes <= 0) return TELR_E_ARG;
+    bam_sink_drop(ctx);
+    BamSink *k = new BamSink();
+    k->path = bam_path; k->bytes = ((size_t)est_bytes + 4095) & ~(size_t)4095;
+    k->th = std::thread([k] {
+        auto t0 = std::chrono::steady_clock::now();
+        k->fd = open(k->path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
+        if (k->fd < 0) return;
+        if (posix_fallocate(k->fd, 0, (off_t)k->bytes) != 0) return;
+        k->ms_alloc = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        t0 = std::chrono::steady_clock::now();
+        void *m = mmap(nullptr, k->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, k->fd, 0);
+        if (m == MAP_FAILED) return;
+        k->map = (uint8_t*)m;
+        k->ms_map = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    });
+    ctx->bam_sink = k;
+    return TELR_OK;
+}
+
 // Device image [d_img, d_img + bytes) -> file, through a ring of pinned chunks: the DMA of chunk c+1 runs while the writer
-// threads put chunk c into the file.  `tail` (host bytes) is appended.
-static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, const void *tail, size_t tail_bytes, const char *path)
+// thread puts chunk c into the file.  `tail` (host bytes) is appended.  fd >= 0: an open file whose pages may already exist
+// (it is cut to the final length), else `path` is created.  map_dst: a mapping of that (allocated) file: chunks are copied
+// into it by the host pool instead of pwrite.
+static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, const void *tail, size_t tail_bytes, const char *path, int fd_open = -1, uint8_t *map_dst = nullptr)
 {
     const size_t CH = 32u << 20; const int R = 8;
     uint8_t *ring; TRY(ctx_hbuf_t(ctx, "bam_ring", CH * R, &ring));
-    int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0644);
+    int fd = fd_open >= 0 ? fd_open : open(path, O_CREAT | O_RDWR | O_TRUNC, 0644);
     if (fd < 0) { ctx->err = std::string("cannot create ") + path; return TELR_E_ARG; }
     const size_t nch = (size_t)((bytes + CH - 1) / CH);
     hipEvent_t ev[8];
     for (int i = 0; i < R; ++i) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    // One writer thread: a single pwrite stream is what a tmpfs file takes fastest (tools/ubench/shm_io.hip: 6.7 GB/s with
-    // one thread, 3.3-4.5 GB/s with 4-32 -- writes to one inode serialise on its lock and on the page-cache tree)
+    // One writer thread: a single pwrite stream is what a tmpfs file takes fastest (see above)
     std::mutex mu; std::condition_variable cv; size_t copied = 0, written = 0; bool fail = false;
     std::thread writer([&] {
         for (size_t c = 0; c < nch; ++c) {
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return copied > c || fail; }); if (fail) return; }
             const size_t n = (size_t)std::min<uint64_t>(CH, bytes - (uint64_t)c * CH);
             const uint8_t *src = ring + (c % R) * CH;
-            size_t done = 0;
-            while (done < n) { ssize_t w = pwrite(fd, src + done, n - done, (off_t)((uint64_t)c * CH + done)); if (w <= 0) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); return; } done += (size_t)w; }
+            if (map_dst) {
+                const int NT = 8; const size_t piece = (n + NT - 1) / NT;
+                uint8_t *dst = map_dst + (uint64_t)c * CH;
+                HostPool::get().run(NT, [&](int i) { const size_t o = (size_t)i * piece; if (o < n) memcpy(dst + o, src + o, std::min(piece, n - o)); });
+            } else {
+                size_t done = 0;
+                while (done < n) { ssize_t w = pwrite(fd, src + done, n - done, (off_t)((uint64_t)c * CH + done)); if (w <= 0) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); return; } done += (size_t)w; }
+            }
             { std::lock_guard<std::mutex> lk(mu); written = c + 1; }
             cv.notify_all();
         }
@@ -617,17 +1072,36 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, c
     writer.join();
     for (int i = 0; i < R; ++i) (void)hipEventDestroy(ev[i]);
     if (fail && rc == TELR_OK) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
-    if (rc == TELR_OK && tail_bytes) { if (pwrite(fd, tail, tail_bytes, (off_t)bytes) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
-    close(fd);
+    if (rc == TELR_OK && tail_bytes) { if (map_dst) memcpy(map_dst + bytes, tail, tail_bytes); else if (pwrite(fd, tail, tail_bytes, (off_t)bytes) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
+    if (rc == TELR_OK && fd_open >= 0 && ftruncate(fd, (off_t)(bytes + tail_bytes)) != 0) rc = TELR_E_ARG;
+    if (fd_open < 0) close(fd);
     return rc;
 }
+// the same through a prepared sink; falls back to the ring when the estimate was too small or the mapping could not be registered
+static int sink_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, const void *tail, size_t tail_bytes, const char *path)
+{
+    BamSink *k = ctx->bam_sink;
+    memset(g_sink_ms, 0, sizeof(g_sink_ms));
+    if (!k || k->path != path) { if (k) bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, tail, tail_bytes, path); }
+    auto t0 = std::chrono::steady_clock::now();
+    if (k->th.joinable()) k->th.join();
+    g_sink_ms[0] = k->ms_alloc; g_sink_ms[1] = k->ms_map;
+    g_sink_ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (k->fd < 0) { bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, tail, tail_bytes, path); }
+    const bool fits = k->map && bytes + tail_bytes <= k->bytes;
+    g_sink_ms[3] = fits ? 1.f : 0.f;
+    int rc = stream_to_file(ctx, d_img, bytes, tail, tail_bytes, path, k->fd, fits ? k->map : nullptr);
+    bam_sink_drop(ctx);
+    return rc;
+}
+extern "C" int telr_debug_bam_sink_ms(float *out) { if (!out) return TELR_E_ARG; memcpy(out, g_sink_ms, sizeof(g_sink_ms)); return TELR_OK; }
 
 extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                                   const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                                   const char *bam_path, int32_t write_index, int32_t level)
 {
     if (!ctx || !r || !queries || !idx || !idx->targets || !qnames || !tnames || !bam_path) return TELR_E_ARG;
-    if (level != 0) { ctx->err = "telr_write_bam_dev: only level 0 (stored BGZF blocks) in this build"; return TELR_E_ARG; }
+    if (level < 0) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<float, std::milli>(now() - t0).count(); };
@@ -717,22 +1191,57 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
     const size_t nblk = (size_t)((utotal + BAM_BLK - 1) / BAM_BLK);
     if (ctx->debug) { HIPCHK(hipStreamSynchronize(st)); }
     g_bam_times.ms[3] = ms_since(t0); t0 = now();
-    // ---- 6. BGZF framing
-    const uint64_t cbytes = utotal + (uint64_t)nblk * 31;
-    uint8_t *d_c; TRY(ctx_buf_t(ctx, "bam_c", (size_t)cbytes + 64, &d_c));
-    if (nblk) hipLaunchKernelGGL(k_bgzf_store, dim3((unsigned)nblk), dim3(256), 0, st, d_u, utotal, d_tabs, d_c);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    // ---- 6. BGZF blocks
+    uint64_t cbytes = 0;
+    uint8_t *d_c = nullptr;
+    std::vector<uint64_t> coff(nblk + 1);
+    if (level == 0) {
+        cbytes = utotal + (uint64_t)nblk * 31;
+        TRY(ctx_buf_t(ctx, "bam_c", (size_t)cbytes + 64, &d_c));
+        if (nblk) hipLaunchKernelGGL(k_bgzf_store, dim3((unsigned)nblk), dim3(256), 0, st, d_u, utotal, d_tabs, d_c);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t b = 0; b < nblk; ++b) coff[b] = (uint64_t)b * (BAM_BLK + 31);
+        coff[nblk] = cbytes;
+    } else {
+        int32_t *d_rec0; DeflTabs *d_T; uint32_t *d_hist, *d_csize; uint64_t *d_cs64, *d_coff; uint8_t *d_slots;
+        TRY(ctx_buf_t(ctx, "bam_rec0", nblk, &d_rec0)); TRY(ctx_buf_t(ctx, "bam_T", 1, &d_T)); TRY(ctx_buf_t(ctx, "bam_hist", (size_t)DEFL_NCLS * 288, &d_hist));
+        TRY(ctx_buf_t(ctx, "bam_csize", nblk, &d_csize)); TRY(ctx_buf_t(ctx, "bam_cs64", nblk + 1, &d_cs64)); TRY(ctx_buf_t(ctx, "bam_coff", nblk + 1, &d_coff));
+        TRY(ctx_buf_t(ctx, "bam_slots", nblk * (size_t)DEFL_SLOT, &d_slots));
+        hipLaunchKernelGGL(k_blk_first_rec, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, st, d_ust, (int32_t)nrec, (uint64_t)head.size(), (int32_t)nblk, d_rec0);
+        static DeflTabs T;                   // 8 KB: not on the stack of a ctypes caller's thread
+        memset(&T, 0, sizeof(T)); defl_len_syms(T.len_sym);
+        HIPCHK(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)DEFL_NCLS * 288 * 4, st));
+        // symbol statistics per field class from every `stride`-th block (at most ~4096 blocks: 270 MB of a 30x read set)
+        const int32_t stride = (int32_t)std::max<size_t>(1, nblk / 4096);
+        const unsigned nsamp = (unsigned)((nblk + stride - 1) / stride);
+        hipLaunchKernelGGL(k_bam_hist, dim3(nsamp), dim3(DEFL_THREADS), 0, st, d_u, utotal, (uint64_t)head.size(), d_ust, (int32_t)nrec, d_rec0, stride, d_T, d_hist);
+        HIPCHK(hipGetLastError());
+        std::vector<uint32_t> h_hist((size_t)DEFL_NCLS * 288);
+        HIPCHK(hipMemcpyAsync(h_hist.data(), d_hist, h_hist.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        TRY(defl_tables_from_hist(h_hist.data(), T));
+        HIPCHK(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nblk), dim3(DEFL_THREADS), 0, st, d_u, utotal, (uint64_t)head.size(), d_ust, (int32_t)nrec, d_rec0, d_T, d_tabs, d_slots, d_csize);
+        hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((nblk + 256) / 256)), dim3(256), 0, st, d_csize, (int32_t)nblk, d_cs64);
+        HIPCHK(hipGetLastError());
+        TRY((dev_exclusive_scan<uint64_t, uint64_t>(ctx, d_cs64, d_coff, nblk + 1)));
+        HIPCHK(hipMemcpyAsync(coff.data(), d_coff, (nblk + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        cbytes = coff[nblk];
+        TRY(ctx_buf_t(ctx, "bam_c", (size_t)cbytes + 64, &d_c));
+        hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nblk), dim3(256), 0, st, d_slots, d_csize, d_coff, d_c);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+    }
     g_bam_times.ms[4] = ms_since(t0); t0 = now();
     // ---- 7. the index is built by a host thread while the file image streams out
     std::string bai; std::thread bai_th;
-    std::vector<uint64_t> coff(nblk + 1);
-    for (size_t b = 0; b < nblk; ++b) coff[b] = (uint64_t)b * (BAM_BLK + 31);
-    coff[nblk] = cbytes;
     float bai_ms = 0;
     if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), coff.data(), nblk, nt, tg->len.data(), bai); bai_ms = ms_since(tb0); });
     static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    int rc = stream_to_file(ctx, d_c, cbytes, eof_blk, 28, bam_path);
+    int rc = sink_to_file(ctx, d_c, cbytes, eof_blk, 28, bam_path);
     g_bam_times.ms[5] = ms_since(t0);
     if (bai_th.joinable()) bai_th.join();
     g_bam_times.ms[6] = bai_ms;

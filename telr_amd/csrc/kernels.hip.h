@@ -723,6 +723,205 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 }
 #undef SEED_POS
 
+// ---- seeding with sub-read voting (spec 3.10: NGMLR's candidate search) ------------------------------------------------
+// All-vs-all calls with mo.vote_len > 0.  One block per query; its four waves take the query's sub-reads in turn (minimizers
+// are in query order: a sub-read is a contiguous run of them, found by one boundary sweep into LDS).
+//   MODE 0: the wave looks its minimizers up, then walks their hits ONE LANE PER HIT (the hit lists of 64 minimizers laid end
+//           to end; a lane finds its minimizer by bisection of the prefix sums in LDS) and counts them per folded diagonal bin
+//           in its own LDS table (one atomic per hit).  A sweep over the table gives the fullest bin, the threshold, the bins
+//           that pass it (a hit stays iff its bin and the two neighbours hold enough votes) and how many hits they hold:
+//           per sub-read the surviving count and the list of passing bins (up to VOTE_LIST; more: marked, MODE 1 votes again).
+//   MODE 1: (after the scan of the counts) one more walk over the hits: a hit whose bin is on the list is written, at the
+//           sub-read's offset plus its rank among the survivors (ballot); the order inside a query is irrelevant, the keys are sorted next.
+// Plain (compacted) minimizer arrays only.
+#define VOTE_SLOTS   2048
+#define VOTE_SUBCAP  512
+#define VOTE_LIST    7
+#define VOTE_HCAP    1024           /* hits of a sub-read whose bins are remembered (more: the whole table is swept instead) */
+struct VoteOpt { int32_t len, shift, vmin, frac_q8; };
+struct VoteArgs {
+    const int32_t *q_suboff;     // [nq+1] first sub-read of every query (in launch-independent query order)
+    int32_t *sub_cnt;            // MODE 0 out: surviving hits per sub-read
+    uint16_t *sub_list;          // MODE 0 out / MODE 1 in: 8 per sub-read: passing bins, [7] = how many (0xffff: more than VOTE_LIST)
+    const int32_t *sub_aoff;     // MODE 1 in
+};
+__device__ __forceinline__ uint32_t d_vote_slot(uint32_t gp, uint32_t qadj, uint32_t rev, int shift)
+{
+    const uint32_t d = gp - qadj + (1u << 24);
+    return (((d >> shift) & (VOTE_SLOTS / 2 - 1)) << 1) | rev;
+}
+struct VoteChunk { uint32_t P[64], off[64], n[64], qpos[64], qrev[64], qz_span[64]; };
+// the hits of the chunk's minimizers, one lane per hit: f(in range?, slot, global position, reverse?, minimizer lane)
+template <typename F>
+__device__ __forceinline__ void d_vote_walk(const VoteChunk &C, const uint32_t *__restrict__ pos, int lane, int shift, F f)
+{
+    const uint32_t H = C.P[63];
+    for (uint32_t h0 = 0; h0 < H; h0 += 64) {
+        const uint32_t h = h0 + lane;
+        const bool in = h < H;
+        uint32_t m = 0;
+        if (in) { uint32_t lo = 0, hi = 63; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (C.P[mid] > h) hi = mid; else lo = mid + 1; } m = lo; }
+        uint32_t sl = 0, gp = 0, rev = 0;
+        if (in) {
+            const uint32_t nm = C.n[m], o = h - (C.P[m] - nm);
+            const uint32_t py = nm == 1 ? C.off[m] : pos[C.off[m] + o];
+            rev = (py & 1u) ^ (C.qz_span[m] >> 8);
+            gp = py >> 1;
+            sl = d_vote_slot(gp, rev ? C.qrev[m] : C.qpos[m], rev, shift);
+        }
+        f(in, sl, gp, rev, m);
+    }
+}
+// a chunk of 64 minimizers into the wave's LDS record (hit list, positions on both strands); MODE 0 looks them up first
+template <int MODE>
+__device__ __forceinline__ void d_vote_chunk(const SeedArgs &A, VoteChunk &C, int g, int g1, int qlen, int lane)
+{
+    uint32_t off = 0, n = 0, qpos = 0, qrev = 0, zs = 0;
+    if (g < g1) {
+        if (MODE == 0) {
+            if (!d_ht_lookup(A.I, A.mz_x[g] >> 8, off, n)) n = 0;
+            A.mz_ent[g] = (int32_t)off; A.mz_n[g] = (int32_t)n;
+        } else { off = (uint32_t)A.mz_ent[g]; n = (uint32_t)A.mz_n[g]; }
+        if (n > (uint32_t)A.mid_occ) n = 0;
+        const uint32_t y = A.mz_y[g], span = (uint32_t)(A.mz_x[g] & 0xff);
+        qpos = y >> 1; qrev = (uint32_t)qlen - (qpos + 1 - span) - 1; zs = (y & 1u) << 8 | span;
+    }
+    __builtin_amdgcn_wave_barrier();
+    C.off[lane] = off; C.n[lane] = n; C.qpos[lane] = qpos; C.qrev[lane] = qrev; C.qz_span[lane] = zs;
+    uint32_t inc = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
+    C.P[lane] = inc;
+    __builtin_amdgcn_wave_barrier();
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_seed_vote(SeedArgs A, VoteOpt V, VoteArgs VA)
+{
+    __shared__ uint32_t tab[4][VOTE_SLOTS];
+    __shared__ uint16_t hslot[4][VOTE_HCAP];
+    __shared__ int32_t sub_first[VOTE_SUBCAP + 1];
+    __shared__ VoteChunk chunk[4];
+    const int q = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
+    const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
+    const int qlen = A.qlen[q];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t *T = tab[wv];
+    uint16_t *HS = hslot[wv];
+    VoteChunk &C = chunk[wv];
+    for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
+    const int nsub = (qlen + V.len - 1) / V.len;
+    const int64_t sub0 = VA.q_suboff[q];
+    for (int sb = 0; sb < nsub; sb += VOTE_SUBCAP) {
+        // first minimizer of every sub-read sb .. sb + VOTE_SUBCAP (sub_first[j] = first g whose sub-read is >= sb + j)
+        __syncthreads();
+        for (int i = tid; i <= VOTE_SUBCAP; i += 256) sub_first[i] = m1;
+        __syncthreads();
+        for (int g = m0 + tid; g < m1; g += 256) {
+            const int s = (int)(A.mz_y[g] >> 1) / V.len;
+            const int sp = g > m0 ? (int)(A.mz_y[g - 1] >> 1) / V.len : -1;
+            if (s != sp) {
+                int lo = sp + 1 > sb ? sp + 1 : sb, hi = s < sb + VOTE_SUBCAP ? s : sb + VOTE_SUBCAP;
+                for (int j = lo; j <= hi; ++j) sub_first[j - sb] = g;
+            }
+        }
+        __syncthreads();
+        const int send = nsub < sb + VOTE_SUBCAP ? nsub : sb + VOTE_SUBCAP;
+        for (int s = sb + wv; s < send; s += 4) {
+            const int g0 = sub_first[s - sb], g1 = sub_first[s - sb + 1];
+            if (g0 >= g1) continue;                      // sub_cnt was zeroed by the host
+            // the list of MODE 0 (uniform)
+            uint32_t nlist = 0, L0 = 0xffffu, L1 = 0xffffu, L2 = 0xffffu, L3 = 0xffffu, L4 = 0xffffu, L5 = 0xffffu, L6 = 0xffffu;
+            if (MODE == 1) {
+                const uint16_t *l = VA.sub_list + (sub0 + s) * 8;
+                nlist = l[7];
+                if (nlist == 0) continue;
+                if (nlist != 0xffffu) {       // entries beyond the count were never written
+                    L0 = l[0]; if (nlist > 1) L1 = l[1]; if (nlist > 2) L2 = l[2]; if (nlist > 3) L3 = l[3]; if (nlist > 4) L4 = l[4]; if (nlist > 5) L5 = l[5]; if (nlist > 6) L6 = l[6];
+                }
+            }
+            const bool revote = MODE == 0 || nlist == 0xffffu;
+            uint32_t thr = 0, nhit = 0;
+            if (revote) {
+                // ---- votes; the bins of the first VOTE_HCAP hits are remembered, and the fullest bin comes with the atomics' returns
+                uint32_t vmax = 0;
+                for (int gc = g0; gc < g1; gc += 64) {
+                    d_vote_chunk<MODE>(A, C, gc + lane, g1, qlen, lane);
+                    uint32_t hb = nhit;
+                    d_vote_walk(C, A.I.pos, lane, V.shift, [&](bool in, uint32_t sl, uint32_t, uint32_t, uint32_t) {
+                        if (in) {
+                            const uint32_t c = atomicAdd(&T[sl], 1u) + 1u; vmax = c > vmax ? c : vmax;
+                            if (hb + lane < VOTE_HCAP) HS[hb + lane] = (uint16_t)sl;
+                        }
+                        hb += 64;
+                    });
+                    nhit += C.P[63];
+                }
+                for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)vmax, o); vmax = v > vmax ? v : vmax; }
+                thr = (vmax * (uint32_t)V.frac_q8 + 255u) >> 8;
+                if (thr < (uint32_t)V.vmin) thr = (uint32_t)V.vmin;
+                __builtin_amdgcn_wave_barrier();
+                if (MODE == 0) {
+                    // ---- the bins that pass and the hits they hold.  Few hits: visit the remembered bins (bit 31 of a table
+                    // entry = already on the list); many: sweep the table.  Either way the list is in ascending bin order
+                    // only by accident -- MODE 1 tests membership.
+                    uint32_t kept = 0, np = 0;
+                    uint16_t *l = VA.sub_list + (sub0 + s) * 8;
+                    if (nhit <= VOTE_HCAP) {
+                        for (uint32_t h0 = 0; h0 < nhit; h0 += 64) {
+                            const uint32_t h = h0 + lane;
+                            bool first = false; uint32_t sl = 0, c = 0;
+                            if (h < nhit) {
+                                sl = HS[h];
+                                c = T[sl] & 0x7fffffffu;
+                                const uint32_t w = (T[(sl - 2u) & (VOTE_SLOTS - 1)] & 0x7fffffffu) + c + (T[(sl + 2u) & (VOTE_SLOTS - 1)] & 0x7fffffffu);
+                                if (w >= thr) first = !(atomicOr(&T[sl], 0x80000000u) & 0x80000000u);
+                            }
+                            const uint64_t bm = __ballot(first);
+                            if (first) { kept += c; const uint32_t r = np + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL)); if (r < VOTE_LIST) l[r] = (uint16_t)sl; }
+                            np += (uint32_t)__popcll(bm);
+                        }
+                    } else {
+                        for (int i0 = 0; i0 < VOTE_SLOTS; i0 += 64) {
+                            const uint32_t i = (uint32_t)(i0 + lane), c = T[i];
+                            const bool pass = c > 0 && T[(i - 2u) & (VOTE_SLOTS - 1)] + c + T[(i + 2u) & (VOTE_SLOTS - 1)] >= thr;
+                            const uint64_t bm = __ballot(pass);
+                            if (pass) { kept += c; const uint32_t r = np + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL)); if (r < VOTE_LIST) l[r] = (uint16_t)i; }
+                            np += (uint32_t)__popcll(bm);
+                        }
+                    }
+                    for (int o = 32; o >= 1; o >>= 1) kept += (uint32_t)__shfl_xor((int)kept, o);
+                    if (lane == 0) { VA.sub_cnt[sub0 + s] = (int32_t)kept; l[7] = np > VOTE_LIST ? (uint16_t)0xffffu : (uint16_t)np; }
+                }
+            }
+            if (MODE == 1) {
+                // ---- survivors
+                int64_t wbase = VA.sub_aoff[sub0 + s];
+                for (int gc = g0; gc < g1; gc += 64) {
+                    d_vote_chunk<1>(A, C, gc + lane, g1, qlen, lane);
+                    d_vote_walk(C, A.I.pos, lane, V.shift, [&](bool in, uint32_t sl, uint32_t gp, uint32_t rev, uint32_t m) {
+                        bool pass;
+                        if (revote) pass = in && T[(sl - 2u) & (VOTE_SLOTS - 1)] + T[sl] + T[(sl + 2u) & (VOTE_SLOTS - 1)] >= thr;
+                        else pass = in && (sl == L0 || sl == L1 || sl == L2 || sl == L3 || sl == L4 || sl == L5 || sl == L6);
+                        const uint64_t bm = __ballot(pass);
+                        if (pass) {
+                            const uint32_t span = C.qz_span[m] & 0xffu;
+                            const uint64_t key = (rev ? (1ULL << 63) | (uint64_t)C.qrev[m] << 8 : (uint64_t)C.qpos[m] << 8) | (uint64_t)span | (uint64_t)gp << 32;
+                            d_put_key(A, wbase + __popcll(bm & ((1ULL << lane) - 1ULL)), key);
+                        }
+                        wbase += __popcll(bm);
+                    });
+                }
+            }
+            if (revote) {
+                __builtin_amdgcn_wave_barrier();
+                if (nhit <= VOTE_HCAP) { for (uint32_t h = lane; h < nhit; h += 64) T[HS[h]] = 0; }
+                else for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
 // ---- per-target occurrence counts of an index (for the per-target cut-offs) ----------------------------
 // run = the occurrences of one minimizer inside one target (contiguous in `pos`: sorted by hash, then position)
 __global__ void k_pt_entry_heads(const uint32_t *__restrict__ ent_off, int32_t n_ent, int32_t *__restrict__ head)

@@ -65,6 +65,7 @@ struct telr_ctx {
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     int64_t dp_retries = 0;
     int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
+    struct BamSink *bam_sink = nullptr;   // an output file being prepared for telr_write_bam_dev (bam_dev.hip.h)
     telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
     telr_ctx *slot1 = nullptr;            // the second range slot (a parent context with lane workers of its own)
     bool pipe_nomem = false;              // two ranges in flight once ran out of device memory: later calls run one at a time
@@ -190,9 +191,11 @@ static int ctx_make_child(telr_ctx *ctx, int k)
     if (k + 1 > ctx->n_child) ctx->n_child = k + 1;
     return TELR_OK;
 }
+static void bam_sink_drop(telr_ctx *ctx);
 extern "C" void telr_destroy(telr_ctx *ctx)
 {
     if (!ctx) return;
+    bam_sink_drop(ctx);
     for (int k = 0; k < 4; ++k) if (ctx->child[k]) { telr_destroy(ctx->child[k]); ctx->child[k] = nullptr; }
     if (ctx->slot1) { telr_destroy(ctx->slot1); ctx->slot1 = nullptr; }
     (void)hipSetDevice(ctx->device);
@@ -247,6 +250,7 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
         if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; }
         else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; }
         mo->fill_band_q4 = 12; mo->fill_margin = 2;
+        mo->vote_len = 256; mo->vote_bin_shift = 5; mo->vote_min = 3; mo->vote_frac_q8 = 128;      // NGMLR's sub-read voting
     }
     else if (s == "asm10") {
         io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;
@@ -1335,7 +1339,9 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
     // the seeding kernels read the sketch kernel's staging arrays in place (no compaction copy); TELR_MZ_COMPACT=1 for A/B
     static const bool mz_compact_env = getenv("TELR_MZ_COMPACT") != nullptr;
-    const bool mz_staged = !ix->io.is_hpc && !mz_compact_env;
+    // sub-read voting (spec 3.10) applies to all-vs-all calls only; its kernel reads the compacted minimizer arrays
+    const bool vote = mo->vote_len > 0 && !d_qtarget && !(mo->flags & TELR_MF_PER_TARGET);
+    const bool mz_staged = !ix->io.is_hpc && !mz_compact_env && !vote;
     if (ix->io.is_hpc) {
         SketchHpcArgs H; std::vector<int32_t> nrun;
         TRY(build_hpc(ctx, qs, q0, q1, "qh_", &H, &nrun));
@@ -1373,22 +1379,43 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
     S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.k32 = nullptr; S.v32 = nullptr; S.q_order = d_qorder;
     S.tile_off = mz_staged ? d_toff : nullptr; S.q_tile0 = mz_staged ? d_first : nullptr;
-    hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
+    VoteOpt VO; VO.len = mo->vote_len; VO.shift = mo->vote_bin_shift; VO.vmin = mo->vote_min; VO.frac_q8 = mo->vote_frac_q8;
+    VoteArgs VA; memset(&VA, 0, sizeof(VA));
+    // the counts that become anchor offsets: per minimizer, or per sub-read when the sub-reads vote
+    int32_t *d_cnt = d_mcnt, *d_aoff = d_maoff; size_t ncnt = (size_t)nmz;
+    int32_t *d_qsub = nullptr;
+    if (vote) {
+        int32_t *h_qsub; TRY(ctx_hbuf_t(ctx, "h_qsuboff", (size_t)nq + 1, &h_qsub));
+        int64_t acc = 0;
+        for (int i = 0; i < nq; ++i) { h_qsub[i] = (int32_t)acc; acc += (qs->len[q0 + i] + mo->vote_len - 1) / mo->vote_len; }
+        h_qsub[nq] = (int32_t)acc;
+        if (acc >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
+        ncnt = (size_t)acc;
+        int32_t *d_scnt, *d_saoff; uint16_t *d_slist;
+        TRY(ctx_buf_t(ctx, "q_suboff", (size_t)nq + 1, &d_qsub)); TRY(ctx_buf_t(ctx, "sub_cnt", ncnt + 1, &d_scnt)); TRY(ctx_buf_t(ctx, "sub_aoff", ncnt + 1, &d_saoff));
+        TRY(ctx_buf_t(ctx, "sub_list", ncnt * 8 + 8, &d_slist));
+        HIPCHK(hipMemcpyAsync(d_qsub, h_qsub, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(d_scnt, 0, (ncnt + 1) * 4, st));
+        HIPCHK(hipMemsetAsync(d_slist, 0, (ncnt * 8 + 8) * 2, st));
+        VA.q_suboff = d_qsub; VA.sub_cnt = d_scnt; VA.sub_list = d_slist; VA.sub_aoff = d_saoff;
+        d_cnt = d_scnt; d_aoff = d_saoff;
+        hipLaunchKernelGGL(k_seed_vote<0>, dim3(nq), dim3(256), 0, st, S, VO, VA);
+    } else hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(d_mcnt + nmz, 0, 4, st));
+    HIPCHK(hipMemsetAsync(d_cnt + ncnt, 0, 4, st));
     // the anchors of a batch are addressed with int32 offsets: their number is first summed in 64 bits (the int32 scan
     // below would wrap silently); a batch with 2^31 anchors or more is handed back to the caller, which halves it
     int64_t *d_na64; TRY(ctx_buf_t(ctx, "seed_na64", 2, &d_na64));
     {
-        auto it64 = rocprim::make_transform_iterator(d_mcnt, [] __device__(int32_t v) { return (int64_t)v; });
+        auto it64 = rocprim::make_transform_iterator(d_cnt, [] __device__(int32_t v) { return (int64_t)v; });
         size_t tb = 0;
-        HIPCHK(rocprim::reduce(nullptr, tb, it64, d_na64, (int64_t)0, (size_t)nmz + 1, rocprim::plus<int64_t>(), st));
+        HIPCHK(rocprim::reduce(nullptr, tb, it64, d_na64, (int64_t)0, ncnt + 1, rocprim::plus<int64_t>(), st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::reduce(tmp, tb, it64, d_na64, (int64_t)0, (size_t)nmz + 1, rocprim::plus<int64_t>(), st));
+        HIPCHK(rocprim::reduce(tmp, tb, it64, d_na64, (int64_t)0, ncnt + 1, rocprim::plus<int64_t>(), st));
     }
-    TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_mcnt, d_maoff, (size_t)nmz + 1)));
+    TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_cnt, d_aoff, ncnt + 1)));
     int32_t na = 0; int64_t na64 = 0;
-    HIPCHK(hipMemcpyAsync(&na, d_maoff + nmz, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&na, d_aoff + ncnt, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&na64, d_na64, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (na64 >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
@@ -1401,9 +1428,10 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     uint32_t *d_k32 = (uint32_t*)d_keys, *d_v32 = d_k32 + na, *d_k32s = nullptr, *d_v32s = nullptr;
     if (!sort64) { TRY(ctx_buf_t(ctx, "skeys32", (size_t)na * 2 + 2, &d_k32s)); d_v32s = d_k32s + na; }
     S.mz_aoff = d_maoff; S.keys = d_keys; S.k32 = sort64 ? nullptr : d_k32; S.v32 = sort64 ? nullptr : d_v32;
-    hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
+    if (vote) hipLaunchKernelGGL(k_seed_vote<1>, dim3(nq), dim3(256), 0, st, S, VO, VA);
+    else hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, na, d_qaoff);
+    hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, vote ? d_aoff : d_maoff, vote ? d_qsub : d_qmz, nq, na, d_qaoff);
     HIPCHK(hipGetLastError());
     t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
@@ -2099,6 +2127,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
     if (mo->e < mo->e2 || mo->q > mo->q2) { ctx->err = "two-piece gap cost needs e >= e2 and q <= q2"; return TELR_E_ARG; }
     if (mo->fill_margin < 0 || mo->fill_margin > 64) { ctx->err = "fill_margin must be 0..64"; return TELR_E_ARG; }
+    if (mo->vote_len != 0 && (mo->vote_len < 16 || mo->vote_bin_shift < 0 || mo->vote_bin_shift > 20 || mo->vote_min < 1 || mo->vote_frac_q8 < 0 || mo->vote_frac_q8 > 256)) {
+        ctx->err = "sub-read voting needs vote_len >= 16, vote_bin_shift 0..20, vote_min >= 1, vote_frac_q8 0..256"; return TELR_E_ARG; }
     if (mo->flags & TELR_MF_FAITHFUL) { ctx->err = "TELR_MF_FAITHFUL is a mode of the CPU oracle (test infrastructure), not of the engine"; return TELR_E_ARG; }
     if (mo->max_gap >= TELR_TPAD || mo->ext_band * 2 + 1 > DP_DMAX || mo->ext_band < 1 || mo->ext_max < 1) return TELR_E_ARG;
     if (queries->max_len >= (1 << 24)) return TELR_E_RANGE;

@@ -22,7 +22,8 @@ def preset(name):
         chain_gap_q8=0, chain_skip_q8=0,
         mask_level=0.5, pri_ratio=0.8, best_n=5, secondary=1,
         a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, min_dp_max=80, min_ksw_len=200,
-        ext_max=2048, ext_band=31, flags=MF_CIGAR, fill_band_q4=6, fill_margin=1)
+        ext_max=2048, ext_band=31, flags=MF_CIGAR, fill_band_q4=6, fill_margin=1,
+        vote_len=0, vote_bin_shift=0, vote_min=0, vote_frac_q8=0)
     if name == "map-ont":
         mo.fill_band_q4 = 4         # with fill_margin 1: no record of the faithful-mode gate differs (tests/test_faithful_gate.py; DESIGN.md, band rule)
     elif name == "map-pb":
@@ -37,6 +38,9 @@ def preset(name):
             mo.a, mo.b, mo.q, mo.e, mo.q2, mo.e2 = 2, 2, 2, 2, 4, 1
         else:
             mo.a, mo.b, mo.q, mo.e, mo.q2, mo.e2 = 2, 5, 6, 4, 60, 1
+        # NGMLR's candidate search: 256-base sub-reads vote for reference regions (diagonal bins of 32 bases, a window of three
+        # bins = its corridor), regions with at least half the votes of the sub-read's best one stay
+        mo.vote_len, mo.vote_bin_shift, mo.vote_min, mo.vote_frac_q8 = 256, 5, 3, 128
         mo.fill_band_q4, mo.fill_margin = 12, 2         # cheap gaps let paths wander: the band the faithful-mode gate needs on the fixture
     elif name == "asm10":
         io.k, io.w = 19, 19

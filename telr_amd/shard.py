@@ -101,9 +101,16 @@ def exchange_window_reads(locus_id, read_id, dest, reads, read_index, dist=None,
         """[n][headers][bases] of the entries `sel`"""
         hdr = np.zeros(len(sel), READ_HDR)
         hdr["locus_id"] = locus_id[sel]; hdr["read_id"] = read_id[sel]; hdr["length"] = rln[read_index[sel]]
-        parts = [np.frombuffer(np.int64(len(sel)).tobytes(), np.uint8), hdr.view(np.uint8).reshape(-1)]
-        parts += [rbuf[roff[i]:roff[i] + rln[i]] for i in read_index[sel]]
-        return np.concatenate(parts)
+        # the bases of all selected reads in one gather: flat index = start of the read, repeated, + position inside it
+        ri = read_index[sel]; ln = rln[ri]
+        tot = int(ln.sum())
+        if tot:
+            ends = np.cumsum(ln)
+            flat = np.repeat(roff[ri] - (ends - ln), ln) + np.arange(tot, dtype=np.int64)
+            bases = np.asarray(rbuf)[flat]
+        else:
+            bases = np.zeros(0, np.uint8)
+        return np.concatenate([np.frombuffer(np.int64(len(sel)).tobytes(), np.uint8), hdr.view(np.uint8).reshape(-1), bases])
 
     def unpack(raw, sizes):
         """-> header array and base offsets (into raw) of all reads of the concatenated per-peer buffers"""

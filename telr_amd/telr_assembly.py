@@ -90,23 +90,29 @@ def polish_alignments(engine, contig_names, contig_seqs, reads_by_locus, read_na
         fd, path = tempfile.mkstemp(suffix=".sam", dir=tmp_path)
         os.close(fd)
         try:
-            ix.write_sam(r, qnames, q_host, list(contig_names), list(contig_seqs), path, md=False, cs=False, softclip=False,
-                         primary_only=True, coordinate_sorted=True, header=False)
-            per = {n: [] for n in contig_names}
+            # The text is written with the query / locus INDEX as QNAME / RNAME and the real names are put back here: the
+            # reference commonly puts one read into the windows of two neighbouring loci, and two loci may carry the same
+            # contig name -- a line belongs to the locus its query was confined to, whatever it is called.
+            ix.write_sam(r, [str(i) for i in range(len(qnames))], q_host, [str(k) for k in range(len(contig_names))], list(contig_seqs), path,
+                         md=False, cs=False, softclip=False, primary_only=True, coordinate_sorted=True, header=False)
+            mapped = [[] for _ in contig_names]
             unmapped = [[] for _ in contig_names]
-            first_of = {}
-            for k, n in enumerate(contig_names):
-                first_of.setdefault(n, k)
-            q_locus = dict(zip(qnames, qt))
             with open(path) as fh:
                 for line in fh:
                     f = line.split("\t", 3)
+                    qi = int(f[0]); k = qt[qi]
                     if f[2] == "*":
-                        unmapped[q_locus[f[0]]].append(line)
+                        unmapped[k].append("%s\t%s\t*\t%s" % (qnames[qi], f[1], f[3]))
                     else:
-                        per[f[2]].append(line)
+                        rest = f[3]
+                        if "\tSA:Z:" in rest:        # the other records of the read lie on the same contig (the query is confined to it)
+                            head, sa = rest.split("\tSA:Z:", 1)
+                            sa, tail = (sa.split("\t", 1) + [""])[:2] if "\t" in sa else (sa.rstrip("\n"), "\n")
+                            sa = ";".join((contig_names[k] + x[x.index(","):]) if x else x for x in sa.split(";"))
+                            rest = head + "\tSA:Z:" + sa + ("\t" + tail if tail != "\n" else "\n")
+                        mapped[k].append("%s\t%s\t%s\t%s" % (qnames[qi], f[1], contig_names[k], rest))
         finally:
             os.remove(path)
     finally:
         ix.free_raw(r)
-    return ["".join(per[n]) + "".join(unmapped[k]) for k, n in enumerate(contig_names)], res.alns, res.cigars
+    return ["".join(mapped[k]) + "".join(unmapped[k]) for k in range(len(contig_names))], res.alns, res.cigars

@@ -46,9 +46,12 @@ def _map_threads(oix, reads, mo, T=8):
         return {"alns": np.concatenate(list(ex.map(work, range(T))))}
 
 
-def drift(oix, reads, mo, parts=4):
-    """preset vs the same options with the faithful bits `parts` (4 = all; 0x100 look-back, 0x200 fills, 0x400 extensions)"""
+def drift(oix, reads, mo, parts=4, other=None):
+    """preset vs the same options with the faithful bits `parts` (4 = all; 0x100 look-back, 0x200 fills, 0x400 extensions),
+    or vs the options `other`"""
     mf = mo.copy(); mf.flags |= parts
+    if other is not None:
+        mf = other
     a, b = _records(_map_threads(oix, reads, mo)), _records(_map_threads(oix, reads, mf))
     n = coord = core = score = 0
     for q in sorted(set(a) | set(b)):
@@ -115,3 +118,30 @@ def test_configs1_sample_drift():
     r = drift(oix, reads, mo, parts=0x200 | 0x400)
     print("configs[1] sample, full-band fills + uncapped extensions:", r)
     assert r["core"] == 0 and r["coord"] == 0 and r["score"] <= 0.0025, r
+
+
+# ---- sub-read voting (spec 3.10, the ngmlr-* presets): what the candidate search changes against chaining ALL hits ------------
+VOTE_MAX_DRIFT = 0.02        # non-secondary records whose coordinates / existence change when the hits are not voted on
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name,err", [("ngmlr-pacbio", (0.013, 0.065, 0.052)), ("ngmlr-ont", (0.04, 0.02, 0.04))])
+def test_subread_voting_against_unpruned_chaining(name, err):
+    """NGMLR's candidate search as this engine restates it (256-base sub-reads vote for 32-base diagonal bins, bins with half
+    the votes of the best stay) against the same preset chaining every hit: on reads with the preset's error model, sampled from
+    a configs[1]-size genome (23.5 Mb, 15 % TE-derived, spiked insertions), primaries and supplementaries must be the same
+    records but for a stated fraction.  Secondary records are outside the comparison: dropping the weaker copies of a
+    repeat is what the vote is for (NGMLR reports none)."""
+    d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=4000, total_bases=36_000_000, err=err, read_seed=20261002 + 77)
+    buf, off, ln = d["reads"]
+    rng = np.random.default_rng(11)
+    pick = rng.choice(len(ln), size=160, replace=False)
+    reads = [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in pick]
+    io, mo = preset(name)
+    assert mo.vote_len == 256
+    plain = mo.copy(); plain.vote_len = 0
+    oix = ob.OracleIndex([bytes(d["ref"]).decode()], io)
+    r = drift(oix, reads, mo, other=plain)
+    print(name, "sub-read voting vs all hits:", r)
+    assert r["n"] >= 160
+    assert r["core"] <= VOTE_MAX_DRIFT and r["coord"] <= VOTE_MAX_DRIFT, r

@@ -85,6 +85,8 @@ def _both(engine, ts, tnames, qs, qnames, pname, tmp_path, tag, rg=None, softcli
         h, d = str(tmp_path / (tag + "_host.bam")), str(tmp_path / (tag + "_dev.bam"))
         ix.write_bam(r, qnames, qs, tnames, ts, h, md=md, cs=cs, softclip=softclip, rg=rg, cmdline="t", index=True, level=1)
         ix.write_bam_device(r, qset, qnames, tnames, d, md=md, cs=cs, softclip=softclip, rg=rg, cmdline="t", index=True, level=0)
+        z = str(tmp_path / (tag + "_devz.bam"))
+        ix.write_bam_device(r, qset, qnames, tnames, z, md=md, cs=cs, softclip=softclip, rg=rg, cmdline="t", index=True, level=1)
     finally:
         ix.free_raw(r)
     rh, bh = _read_bgzf(h)
@@ -99,6 +101,14 @@ def _both(engine, ts, tnames, qs, qnames, pname, tmp_path, tag, rg=None, softcli
                 raise AssertionError("record %s at %d: bodies differ at byte %d of %d / %d: %r vs %r" % (x[4], x[2], k, len(x[7]), len(y[7]), x[7][max(0, k - 24):k + 24], y[7][max(0, k - 24):k + 24]))
         raise AssertionError("streams differ outside the records")
     _check_bai(d, rd, bd, len(tnames))
+    # level 1: deflate blocks coded on the device (per-field Huffman tables, run-length matches): zlib inflates them to the same stream
+    import os
+    rz, bz = _read_bgzf(z)
+    assert rz == rh
+    _check_bai(z, rz, bz, len(tnames))
+    if len(rh) > 200000:
+        assert os.path.getsize(z) < 0.5 * os.path.getsize(d), (os.path.getsize(z), os.path.getsize(d), os.path.getsize(h))
+    _both.sizes = (os.path.getsize(h), os.path.getsize(d), os.path.getsize(z))
     return _records(rd)[0]
 
 

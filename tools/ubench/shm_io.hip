@@ -110,6 +110,84 @@ int main(int argc, char **argv)
         } else (void)hipGetLastError();
         munmap(m, total); close(fd);
     }
+    // 6. ways of getting the pages of a tmpfs file allocated (the writer's real cost)
+    {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        double t0 = now();
+        int e = posix_fallocate(fd, 0, (off_t)total);
+        double dt = now() - t0;
+        printf("posix_fallocate %.1f GB: rc %d, %.3f s = %.1f GB/s\n", total / 1e9, e, dt, total / 1e9 / dt);
+        for (int T : {1, 2, 4}) {
+            t0 = now();
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+                const size_t piece = 32u << 20;
+                for (size_t o = (size_t)t * piece; o < total; o += (size_t)T * piece) { size_t n = std::min(piece, total - o); if (pwrite(fd, (char*)h + (o % chunk), n, (off_t)o) != (ssize_t)n) break; }
+            });
+            for (auto &x : th) x.join();
+            dt = now() - t0;
+            printf("pwrite over fallocated pages, %d thread(s), 32-MB pieces: %.1f GB/s\n", T, total / 1e9 / dt);
+        }
+        close(fd); unlink(path);
+        // one thread touches pages ahead through a mapping (no inode lock) while one thread pwrites behind it
+        fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        if (ftruncate(fd, (off_t)total) != 0) return 1;
+        char *m = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        t0 = now();
+        {
+            double tp0 = now();
+#ifdef MADV_POPULATE_WRITE
+            int rc = madvise(m, total, MADV_POPULATE_WRITE);
+#else
+            int rc = -1;
+#endif
+            printf("madvise(MADV_POPULATE_WRITE) on a fresh tmpfs mapping: rc %d, %.3f s = %.1f GB/s\n", rc, now() - tp0, total / 1e9 / (now() - tp0));
+        }
+        munmap(m, total); close(fd); unlink(path);
+        // two files' worth? no: ONE file, first half written by thread A while thread B writes the second half
+        fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        t0 = now();
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < 2; ++t) th.emplace_back([&, t] {
+                const size_t piece = 32u << 20, lo = t * (total / 2), hi = t ? total : total / 2;
+                for (size_t o = lo; o < hi; o += piece) { size_t n = std::min(piece, hi - o); if (pwrite(fd, (char*)h + (o % chunk), n, (off_t)o) != (ssize_t)n) break; }
+            });
+            for (auto &x : th) x.join();
+        }
+        dt = now() - t0;
+        printf("pwrite to a fresh file, 2 threads on the two halves: %.1f GB/s\n", total / 1e9 / dt);
+        close(fd); unlink(path);
+        // write() appends from one thread in 1-MB, 8-MB, 64-MB calls
+        for (size_t piece : {(size_t)1 << 20, (size_t)8 << 20, (size_t)64 << 20}) {
+            fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+            t0 = now();
+            for (size_t o = 0; o < total; o += piece) { size_t n = std::min(piece, total - o); if (write(fd, (char*)h + (o % chunk), n) != (ssize_t)n) break; }
+            dt = now() - t0;
+            printf("write() append, one thread, %zu-MB calls: %.1f GB/s\n", piece >> 20, total / 1e9 / dt);
+            close(fd); unlink(path);
+        }
+    }
+    // 7. fallocate, then memcpy through a mapping of the ALLOCATED file with T threads (no inode lock on this path)
+    for (int T : {1, 4, 8, 16}) {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        double t0 = now();
+        if (posix_fallocate(fd, 0, (off_t)total) != 0) return 1;
+        double t_fa = now() - t0;
+        char *m = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        t0 = now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            const size_t piece = 8u << 20;
+            for (size_t o = (size_t)t * piece; o < total; o += (size_t)T * piece) memcpy(m + o, (char*)h + (o % chunk), std::min(piece, total - o));
+        });
+        for (auto &x : th) x.join();
+        double dt = now() - t0;
+        printf("fallocate (%.3f s) + memcpy into the mapping of the allocated file, %2d threads: %.1f GB/s\n", t_fa, T, total / 1e9 / dt);
+        munmap(m, total); close(fd);
+    }
     unlink(path);
     // 5. host-side deflate / crc32 rates are measured by the library's own writer (bench.py --bam-leg host)
     hipFree(d); hipHostFree(h);

@@ -161,6 +161,18 @@ int  telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, con
 int64_t telr_seqset_bases(const telr_seqset *s);
 int32_t telr_seqset_count(const telr_seqset *s);
 
+/* ---- FASTA / FASTQ text -> the arrays above (host code; plain files, not gzip).  Replaces handing the file names to
+ *      ngmlr / minimap2 (src/telr/TELR_alignment.py:31-51, 69-82).  Names end at the first white space. */
+typedef struct telr_fasta telr_fasta;
+int  telr_fasta_load(const char *path, telr_fasta **out);
+int32_t telr_fasta_count(const telr_fasta *f);
+int64_t telr_fasta_bases(const telr_fasta *f);
+const char *telr_fasta_seq(const telr_fasta *f);                 /* concatenated bases */
+const int64_t *telr_fasta_off(const telr_fasta *f);
+const int32_t *telr_fasta_len(const telr_fasta *f);
+const char *const *telr_fasta_names(const telr_fasta *f);
+void telr_fasta_free(telr_fasta *f);
+
 /* ---- index (replaces "minimap2 ... REF" re-indexing REF on every call) ----- */
 int  telr_index_build(telr_ctx *ctx, const telr_seqset *targets, const telr_idx_opt *io,
                       telr_index **out);

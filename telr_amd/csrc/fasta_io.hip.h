@@ -1,0 +1,97 @@
+// fasta_io.hip.h — reads and reference from FASTA / FASTQ text into the arrays the C ABI takes (one concatenated base buffer,
+// offsets, lengths, NUL-terminated names): the host-side entry of stage 1 (the reference hands the file names to ngmlr /
+// minimap2, src/telr/TELR_alignment.py:31-51, 69-82).  Host code only; included by telr_engine.hip.
+//   FASTA: record starts ('>' at the start of a line) are found by worker threads over slices of the mapped file, then every
+//          record is measured and copied (line breaks dropped) in parallel.
+//   FASTQ: four-line records, walked line by line ('@' may start a quality line, so records cannot be found by a scan).
+// Names end at the first white space, as minimap2 / ngmlr print them.
+#pragma once
+struct telr_fasta {
+    std::vector<char> seq; std::vector<int64_t> off; std::vector<int32_t> len;
+    std::vector<char> name_buf; std::vector<const char*> names;
+};
+extern "C" void telr_fasta_free(telr_fasta *f) { delete f; }
+extern "C" int32_t telr_fasta_count(const telr_fasta *f) { return f ? (int32_t)f->len.size() : 0; }
+extern "C" const char *telr_fasta_seq(const telr_fasta *f) { return f ? f->seq.data() : nullptr; }
+extern "C" const int64_t *telr_fasta_off(const telr_fasta *f) { return f ? f->off.data() : nullptr; }
+extern "C" const int32_t *telr_fasta_len(const telr_fasta *f) { return f ? f->len.data() : nullptr; }
+extern "C" const char *const *telr_fasta_names(const telr_fasta *f) { return f ? f->names.data() : nullptr; }
+extern "C" int64_t telr_fasta_bases(const telr_fasta *f) { return f ? (int64_t)f->seq.size() : 0; }
+
+extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
+{
+    if (!path || !out) return TELR_E_ARG;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return TELR_E_ARG;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); return TELR_E_ARG; }
+    const size_t n = (size_t)sb.st_size;
+    telr_fasta *F = new telr_fasta();
+    if (n == 0) { close(fd); *out = F; return TELR_OK; }
+    const char *p = (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete F; return TELR_E_ARG; }
+    struct Rec { size_t hdr, body, end; };       // header line start (after '>' / '@'), first byte after the header line, end of the sequence text
+    std::vector<Rec> recs;
+    const int NT = host_threads();
+    auto line_end = [&](size_t i) { const char *e = (const char*)memchr(p + i, '\n', n - i); return e ? (size_t)(e - p) : n; };
+    if (p[0] == '>') {
+        std::vector<std::vector<size_t>> starts((size_t)NT);
+        parallel_ranges(NT, NT, [&](int, int t0, int t1) {
+            for (int t = t0; t < t1; ++t) {
+                size_t a = n * (size_t)t / NT, b = n * (size_t)(t + 1) / NT;
+                if (t == 0) starts[t].push_back(0);
+                // '>' preceded by a line break, at positions (a, b]
+                for (size_t i = a; i < b; ) { const char *e = (const char*)memchr(p + i, '\n', b - i); if (!e) break; i = (size_t)(e - p) + 1; if (i < n && p[i] == '>') starts[t].push_back(i); }
+            }
+        });
+        std::vector<size_t> st;
+        for (auto &v : starts) st.insert(st.end(), v.begin(), v.end());
+        recs.resize(st.size());
+        for (size_t r = 0; r < st.size(); ++r) { recs[r].hdr = st[r] + 1; recs[r].end = r + 1 < st.size() ? st[r + 1] : n; }
+        parallel_ranges(NT, (int)recs.size(), [&](int, int r0, int r1) { for (int r = r0; r < r1; ++r) { size_t e = line_end(recs[r].hdr); recs[r].body = e < recs[r].end ? e + 1 : recs[r].end; } });
+    } else if (p[0] == '@') {
+        for (size_t i = 0; i < n; ) {
+            if (p[i] != '@') { munmap((void*)p, n); delete F; return TELR_E_ARG; }
+            Rec r; r.hdr = i + 1;
+            size_t e = line_end(i); r.body = e < n ? e + 1 : n;
+            size_t e2 = line_end(r.body); r.end = e2;                                   // the sequence line
+            size_t e3 = e2 < n ? line_end(e2 + 1) : n, e4 = e3 < n ? line_end(e3 + 1) : n;  // '+' line, quality line
+            recs.push_back(r);
+            i = e4 < n ? e4 + 1 : n;
+        }
+    } else { munmap((void*)p, n); delete F; return TELR_E_ARG; }
+    const size_t nr = recs.size();
+    if (nr >= (1u << 31)) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
+    F->len.resize(nr); F->off.resize(nr);
+    std::vector<int64_t> nlen(nr);
+    bool too_long = false;
+    parallel_ranges(NT, (int)nr, [&](int, int r0, int r1) {
+        for (int r = r0; r < r1; ++r) {
+            int64_t bases = 0;
+            for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') --l; bases += (int64_t)l; i = e + 1; }
+            if (bases > INT32_MAX) { too_long = true; bases = 0; }
+            F->len[r] = (int32_t)bases;
+            size_t h = recs[r].hdr, he = recs[r].body;
+            size_t k = h; while (k < he && p[k] != ' ' && p[k] != '\t' && p[k] != '\n' && p[k] != '\r') ++k;
+            nlen[r] = (int64_t)(k - h);
+        }
+    });
+    if (too_long) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
+    int64_t tot = 0, ntot = 0;
+    std::vector<int64_t> noff(nr);
+    for (size_t r = 0; r < nr; ++r) { F->off[r] = tot; tot += F->len[r]; noff[r] = ntot; ntot += nlen[r] + 1; }
+    F->seq.resize((size_t)tot); F->name_buf.resize((size_t)ntot); F->names.resize(nr);
+    parallel_ranges(NT, (int)nr, [&](int, int r0, int r1) {
+        for (int r = r0; r < r1; ++r) {
+            char *d = F->seq.data() + F->off[r];
+            for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') --l; memcpy(d, p + i, l); d += l; i = e + 1; }
+            char *nm = F->name_buf.data() + noff[r];
+            memcpy(nm, p + recs[r].hdr, (size_t)nlen[r]); nm[nlen[r]] = 0;
+            F->names[r] = nm;
+        }
+    });
+    munmap((void*)p, n);
+    *out = F;
+    return TELR_OK;
+}

@@ -724,99 +724,87 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 #undef SEED_POS
 
 // ---- seeding with sub-read voting (spec 3.10: NGMLR's candidate search) ------------------------------------------------
-// All-vs-all calls with mo.vote_len > 0.  One block per query; its four waves take the query's sub-reads in turn (minimizers
-// are in query order: a sub-read is a contiguous run of them, found by one boundary sweep into LDS).
-//   MODE 0: the wave looks its minimizers up, then walks their hits ONE LANE PER HIT (the hit lists of 64 minimizers laid end
-//           to end; a lane finds its minimizer by bisection of the prefix sums in LDS) and counts them per folded diagonal bin
-//           in its own LDS table (one atomic per hit).  A sweep over the table gives the fullest bin, the threshold, the bins
-//           that pass it (a hit stays iff its bin and the two neighbours hold enough votes) and how many hits they hold:
-//           per sub-read the surviving count and the list of passing bins (up to VOTE_LIST; more: marked, MODE 1 votes again).
-//   MODE 1: (after the scan of the counts) one more walk over the hits: a hit whose bin is on the list is written, at the
-//           sub-read's offset plus its rank among the survivors (ballot); the order inside a query is irrelevant, the keys are sorted next.
-// Plain (compacted) minimizer arrays only.
+// All-vs-all calls with mo.vote_len > 0, plain (compacted) minimizer arrays.
+//   k_vote_lookup   one thread per minimizer: table probe, occurrence cut-off -> (first occurrence, count); flat and wide, so
+//                   the scattered probes have thousands of waves to hide behind
+//   k_vote_qhits    hits per query (an upper bound of its anchors) -> after a scan, the query's piece of the staging array
+//   k_seed_vote     one block (three waves) per query; the waves take its sub-reads in turn (minimizers are in query order: a
+//                   sub-read is a contiguous run of them, found by one boundary sweep into LDS).  A wave lays the hit lists
+//                   of up to 128 minimizers end to end and walks them ONE LANE PER HIT (a lane finds its minimizer by bisection
+//                   of the prefix sums in LDS; two windows of 64 hits are in flight so that their occurrence loads overlap):
+//                   every hit votes for its folded diagonal bin in the wave's LDS table (one atomic; the fullest bin comes
+//                   back with the atomics' returns) and is remembered in LDS.  Then the remembered hits are tested -- a hit
+//                   stays iff its bin and the two neighbours hold enough votes -- and the survivors go to the query's piece
+//                   of the staging array (block-level cursor; their order is irrelevant, the keys are sorted next).
+//                   Sub-reads with more hits than the LDS record holds walk the lists a second time instead.
+//   k_vote_compact  staging -> the dense key arrays at the scanned per-query offsets
 #define VOTE_SLOTS   2048
 #define VOTE_SUBCAP  512
-#define VOTE_LIST    7
-#define VOTE_HCAP    1024           /* hits of a sub-read whose bins are remembered (more: the whole table is swept instead) */
+#define VOTE_WAVES   3
+#define VOTE_HCAP    768            /* hits of a sub-read remembered in LDS */
+#define VOTE_MZ      128            /* minimizers per chunk (two per lane) */
 struct VoteOpt { int32_t len, shift, vmin, frac_q8; };
 struct VoteArgs {
-    const int32_t *q_suboff;     // [nq+1] first sub-read of every query (in launch-independent query order)
-    int32_t *sub_cnt;            // MODE 0 out: surviving hits per sub-read
-    uint16_t *sub_list;          // MODE 0 out / MODE 1 in: 8 per sub-read: passing bins, [7] = how many (0xffff: more than VOTE_LIST)
-    const int32_t *sub_aoff;     // MODE 1 in
+    const int64_t *q_soff;       // [nq+1] start of every query's piece of the staging array (scan of the hit counts)
+    uint64_t *stage;             // survivors
+    int32_t *q_cnt;              // out: survivors per query
 };
 __device__ __forceinline__ uint32_t d_vote_slot(uint32_t gp, uint32_t qadj, uint32_t rev, int shift)
 {
     const uint32_t d = gp - qadj + (1u << 24);
     return (((d >> shift) & (VOTE_SLOTS / 2 - 1)) << 1) | rev;
 }
-struct VoteChunk { uint32_t P[64], off[64], n[64], qpos[64], qrev[64], qz_span[64]; };
-// the hits of the chunk's minimizers, one lane per hit: f(in range?, slot, global position, reverse?, minimizer lane)
-template <typename F>
-__device__ __forceinline__ void d_vote_walk(const VoteChunk &C, const uint32_t *__restrict__ pos, int lane, int shift, F f)
+__global__ void __launch_bounds__(256) k_vote_lookup(IndexView I, const uint64_t *__restrict__ mz_x, int32_t nmz, int32_t mid_occ, int32_t *__restrict__ mz_ent, int32_t *__restrict__ mz_n)
 {
-    const uint32_t H = C.P[63];
-    for (uint32_t h0 = 0; h0 < H; h0 += 64) {
-        const uint32_t h = h0 + lane;
-        const bool in = h < H;
-        uint32_t m = 0;
-        if (in) { uint32_t lo = 0, hi = 63; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (C.P[mid] > h) hi = mid; else lo = mid + 1; } m = lo; }
-        uint32_t sl = 0, gp = 0, rev = 0;
-        if (in) {
-            const uint32_t nm = C.n[m], o = h - (C.P[m] - nm);
-            const uint32_t py = nm == 1 ? C.off[m] : pos[C.off[m] + o];
-            rev = (py & 1u) ^ (C.qz_span[m] >> 8);
-            gp = py >> 1;
-            sl = d_vote_slot(gp, rev ? C.qrev[m] : C.qpos[m], rev, shift);
-        }
-        f(in, sl, gp, rev, m);
-    }
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= nmz) return;
+    uint32_t off = 0, n = 0;
+    if (!d_ht_lookup(I, mz_x[g] >> 8, off, n)) n = 0;
+    if (n > (uint32_t)mid_occ) n = 0;
+    mz_ent[g] = (int32_t)off; mz_n[g] = (int32_t)n;
 }
-// a chunk of 64 minimizers into the wave's LDS record (hit list, positions on both strands); MODE 0 looks them up first
-template <int MODE>
-__device__ __forceinline__ void d_vote_chunk(const SeedArgs &A, VoteChunk &C, int g, int g1, int qlen, int lane)
+__global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q_mzoff, const int32_t *__restrict__ mz_n, int32_t nq, int64_t *__restrict__ q_hits)
 {
-    uint32_t off = 0, n = 0, qpos = 0, qrev = 0, zs = 0;
-    if (g < g1) {
-        if (MODE == 0) {
-            if (!d_ht_lookup(A.I, A.mz_x[g] >> 8, off, n)) n = 0;
-            A.mz_ent[g] = (int32_t)off; A.mz_n[g] = (int32_t)n;
-        } else { off = (uint32_t)A.mz_ent[g]; n = (uint32_t)A.mz_n[g]; }
-        if (n > (uint32_t)A.mid_occ) n = 0;
-        const uint32_t y = A.mz_y[g], span = (uint32_t)(A.mz_x[g] & 0xff);
-        qpos = y >> 1; qrev = (uint32_t)qlen - (qpos + 1 - span) - 1; zs = (y & 1u) << 8 | span;
-    }
-    __builtin_amdgcn_wave_barrier();
-    C.off[lane] = off; C.n[lane] = n; C.qpos[lane] = qpos; C.qrev[lane] = qrev; C.qz_span[lane] = zs;
-    uint32_t inc = n;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
-    C.P[lane] = inc;
-    __builtin_amdgcn_wave_barrier();
+    const int q = blockIdx.x, lane = threadIdx.x;
+    if (q > nq) return;
+    int64_t s = 0;
+    if (q < nq) for (int g = q_mzoff[q] + lane; g < q_mzoff[q + 1]; g += 64) s += mz_n[g];
+    for (int o = 32; o >= 1; o >>= 1) s += (int64_t)((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)s, o) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)s >> 32), o) << 32);
+    if (lane == 0) q_hits[q] = s;
 }
-template <int MODE>
-__global__ void __launch_bounds__(256) k_seed_vote(SeedArgs A, VoteOpt V, VoteArgs VA)
+struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; };
+struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
+// minimizer of hit h (first entry of the inclusive prefix sums above h)
+__device__ __forceinline__ uint32_t d_vote_owner(const VoteChunk &C, uint32_t h)
 {
-    __shared__ uint32_t tab[4][VOTE_SLOTS];
-    __shared__ uint16_t hslot[4][VOTE_HCAP];
+    uint32_t lo = 0, hi = VOTE_MZ - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (C.P[mid] > h) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+__global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteOpt V, VoteArgs VA)
+{
+    __shared__ uint32_t tab[VOTE_WAVES][VOTE_SLOTS];
+    __shared__ VoteHit stash[VOTE_WAVES][VOTE_HCAP];
+    __shared__ VoteChunk chunk[VOTE_WAVES];
     __shared__ int32_t sub_first[VOTE_SUBCAP + 1];
-    __shared__ VoteChunk chunk[4];
+    __shared__ uint32_t blk_cnt;
     const int q = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
     const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
     const int qlen = A.qlen[q];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t *T = tab[wv];
-    uint16_t *HS = hslot[wv];
+    VoteHit *HS = stash[wv];
     VoteChunk &C = chunk[wv];
+    uint64_t *out = VA.stage + VA.q_soff[q];
     for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
+    if (tid == 0) blk_cnt = 0;
     const int nsub = (qlen + V.len - 1) / V.len;
-    const int64_t sub0 = VA.q_suboff[q];
     for (int sb = 0; sb < nsub; sb += VOTE_SUBCAP) {
         // first minimizer of every sub-read sb .. sb + VOTE_SUBCAP (sub_first[j] = first g whose sub-read is >= sb + j)
         __syncthreads();
-        for (int i = tid; i <= VOTE_SUBCAP; i += 256) sub_first[i] = m1;
+        for (int i = tid; i <= VOTE_SUBCAP; i += 64 * VOTE_WAVES) sub_first[i] = m1;
         __syncthreads();
-        for (int g = m0 + tid; g < m1; g += 256) {
+        for (int g = m0 + tid; g < m1; g += 64 * VOTE_WAVES) {
             const int s = (int)(A.mz_y[g] >> 1) / V.len;
             const int sp = g > m0 ? (int)(A.mz_y[g - 1] >> 1) / V.len : -1;
             if (s != sp) {
@@ -826,99 +814,130 @@ __global__ void __launch_bounds__(256) k_seed_vote(SeedArgs A, VoteOpt V, VoteAr
         }
         __syncthreads();
         const int send = nsub < sb + VOTE_SUBCAP ? nsub : sb + VOTE_SUBCAP;
-        for (int s = sb + wv; s < send; s += 4) {
+        for (int s = sb + wv; s < send; s += VOTE_WAVES) {
             const int g0 = sub_first[s - sb], g1 = sub_first[s - sb + 1];
-            if (g0 >= g1) continue;                      // sub_cnt was zeroed by the host
-            // the list of MODE 0 (uniform)
-            uint32_t nlist = 0, L0 = 0xffffu, L1 = 0xffffu, L2 = 0xffffu, L3 = 0xffffu, L4 = 0xffffu, L5 = 0xffffu, L6 = 0xffffu;
-            if (MODE == 1) {
-                const uint16_t *l = VA.sub_list + (sub0 + s) * 8;
-                nlist = l[7];
-                if (nlist == 0) continue;
-                if (nlist != 0xffffu) {       // entries beyond the count were never written
-                    L0 = l[0]; if (nlist > 1) L1 = l[1]; if (nlist > 2) L2 = l[2]; if (nlist > 3) L3 = l[3]; if (nlist > 4) L4 = l[4]; if (nlist > 5) L5 = l[5]; if (nlist > 6) L6 = l[6];
-                }
-            }
-            const bool revote = MODE == 0 || nlist == 0xffffu;
-            uint32_t thr = 0, nhit = 0;
-            if (revote) {
-                // ---- votes; the bins of the first VOTE_HCAP hits are remembered, and the fullest bin comes with the atomics' returns
-                uint32_t vmax = 0;
-                for (int gc = g0; gc < g1; gc += 64) {
-                    d_vote_chunk<MODE>(A, C, gc + lane, g1, qlen, lane);
-                    uint32_t hb = nhit;
-                    d_vote_walk(C, A.I.pos, lane, V.shift, [&](bool in, uint32_t sl, uint32_t, uint32_t, uint32_t) {
-                        if (in) {
-                            const uint32_t c = atomicAdd(&T[sl], 1u) + 1u; vmax = c > vmax ? c : vmax;
-                            if (hb + lane < VOTE_HCAP) HS[hb + lane] = (uint16_t)sl;
+            if (g0 >= g1) continue;
+            // ---- votes (all chunks of the sub-read), hits remembered
+            uint32_t vmax = 0, nhit = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                // pass 0: vote.  pass 1: only when the sub-read has more hits than the LDS record -- walk again and test against the table
+                if (pass == 1 && nhit <= VOTE_HCAP) break;
+                uint32_t thr1 = 0;
+                if (pass == 1) { thr1 = (vmax * (uint32_t)V.frac_q8 + 255u) >> 8; if (thr1 < (uint32_t)V.vmin) thr1 = (uint32_t)V.vmin; }
+                uint32_t hbase = 0;
+                for (int gc = g0; gc < g1; gc += VOTE_MZ) {
+                    // the chunk: two minimizers per lane
+                    uint32_t n2[2];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int g = gc + 2 * lane + u;
+                        uint32_t off = 0, n = 0, qpos = 0, zs = 0;
+                        if (g < g1) {
+                            off = (uint32_t)A.mz_ent[g]; n = (uint32_t)A.mz_n[g];
+                            const uint32_t y = A.mz_y[g];
+                            qpos = y >> 1; zs = (y & 1u) << 8 | (uint32_t)(A.mz_x[g] & 0xff);
                         }
-                        hb += 64;
-                    });
-                    nhit += C.P[63];
-                }
-                for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)vmax, o); vmax = v > vmax ? v : vmax; }
-                thr = (vmax * (uint32_t)V.frac_q8 + 255u) >> 8;
-                if (thr < (uint32_t)V.vmin) thr = (uint32_t)V.vmin;
-                __builtin_amdgcn_wave_barrier();
-                if (MODE == 0) {
-                    // ---- the bins that pass and the hits they hold.  Few hits: visit the remembered bins (bit 31 of a table
-                    // entry = already on the list); many: sweep the table.  Either way the list is in ascending bin order
-                    // only by accident -- MODE 1 tests membership.
-                    uint32_t kept = 0, np = 0;
-                    uint16_t *l = VA.sub_list + (sub0 + s) * 8;
-                    if (nhit <= VOTE_HCAP) {
-                        for (uint32_t h0 = 0; h0 < nhit; h0 += 64) {
-                            const uint32_t h = h0 + lane;
-                            bool first = false; uint32_t sl = 0, c = 0;
-                            if (h < nhit) {
-                                sl = HS[h];
-                                c = T[sl] & 0x7fffffffu;
-                                const uint32_t w = (T[(sl - 2u) & (VOTE_SLOTS - 1)] & 0x7fffffffu) + c + (T[(sl + 2u) & (VOTE_SLOTS - 1)] & 0x7fffffffu);
-                                if (w >= thr) first = !(atomicOr(&T[sl], 0x80000000u) & 0x80000000u);
+                        C.off[2 * lane + u] = off; C.qpos[2 * lane + u] = qpos; C.zs[2 * lane + u] = (uint16_t)zs; n2[u] = n;
+                    }
+                    uint32_t inc = n2[0] + n2[1];
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
+                    C.P[2 * lane] = inc - n2[1]; C.P[2 * lane + 1] = inc;
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t H = (uint32_t)__shfl((int)inc, 63);
+                    // the walk: two windows of 64 hits per trip
+                    for (uint32_t h0 = 0; h0 < H; h0 += 128) {
+                        uint32_t m_[2], gp_[2], sl_[2], rv_[2]; bool in_[2]; uint32_t py_[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t h = h0 + 64 * u + lane;
+                            in_[u] = h < H; m_[u] = 0; py_[u] = 0;
+                            if (in_[u]) {
+                                const uint32_t m = d_vote_owner(C, h);
+                                const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
+                                m_[u] = m;
+                                py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
                             }
-                            const uint64_t bm = __ballot(first);
-                            if (first) { kept += c; const uint32_t r = np + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL)); if (r < VOTE_LIST) l[r] = (uint16_t)sl; }
-                            np += (uint32_t)__popcll(bm);
                         }
-                    } else {
-                        for (int i0 = 0; i0 < VOTE_SLOTS; i0 += 64) {
-                            const uint32_t i = (uint32_t)(i0 + lane), c = T[i];
-                            const bool pass = c > 0 && T[(i - 2u) & (VOTE_SLOTS - 1)] + c + T[(i + 2u) & (VOTE_SLOTS - 1)] >= thr;
-                            const uint64_t bm = __ballot(pass);
-                            if (pass) { kept += c; const uint32_t r = np + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL)); if (r < VOTE_LIST) l[r] = (uint16_t)i; }
-                            np += (uint32_t)__popcll(bm);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const uint32_t h = h0 + 64 * u + lane;
+                            bool pass_hit = false;
+                            if (in_[u]) {
+                                const uint32_t m = m_[u], zs = C.zs[m], span = zs & 0xffu, qpos = C.qpos[m];
+                                rv_[u] = (py_[u] & 1u) ^ (zs >> 8); gp_[u] = py_[u] >> 1;
+                                const uint32_t qadj = rv_[u] ? (uint32_t)qlen - (qpos + 1 - span) - 1 : qpos;
+                                sl_[u] = d_vote_slot(gp_[u], qadj, rv_[u], V.shift);
+                                if (pass == 0) {
+                                    const uint32_t c = atomicAdd(&T[sl_[u]], 1u) + 1u; vmax = c > vmax ? c : vmax;
+                                    if (hbase + h < VOTE_HCAP) { VoteHit x; x.gp = gp_[u]; x.sm = sl_[u] | m << 11 | (uint32_t)(gc - g0) / VOTE_MZ << 18; HS[hbase + h] = x; }
+                                } else pass_hit = T[(sl_[u] - 2u) & (VOTE_SLOTS - 1)] + T[sl_[u]] + T[(sl_[u] + 2u) & (VOTE_SLOTS - 1)] >= thr1;
+                            }
+                            if (pass == 1) {
+                                const uint64_t bm = __ballot(pass_hit);
+                                uint32_t base = 0;
+                                if (lane == 0 && bm) base = atomicAdd(&blk_cnt, (uint32_t)__popcll(bm));
+                                base = (uint32_t)__shfl((int)base, 0);
+                                if (pass_hit) {
+                                    const uint32_t m = m_[u], zs = C.zs[m], span = zs & 0xffu, qpos = C.qpos[m];
+                                    const uint64_t key = (rv_[u] ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)gp_[u] << 32;
+                                    out[base + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = key;
+                                }
+                            }
                         }
                     }
-                    for (int o = 32; o >= 1; o >>= 1) kept += (uint32_t)__shfl_xor((int)kept, o);
-                    if (lane == 0) { VA.sub_cnt[sub0 + s] = (int32_t)kept; l[7] = np > VOTE_LIST ? (uint16_t)0xffffu : (uint16_t)np; }
+                    hbase += H;
+                }
+                if (pass == 0) {
+                    nhit = hbase;
+                    for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)vmax, o); vmax = v > vmax ? v : vmax; }
                 }
             }
-            if (MODE == 1) {
-                // ---- survivors
-                int64_t wbase = VA.sub_aoff[sub0 + s];
-                for (int gc = g0; gc < g1; gc += 64) {
-                    d_vote_chunk<1>(A, C, gc + lane, g1, qlen, lane);
-                    d_vote_walk(C, A.I.pos, lane, V.shift, [&](bool in, uint32_t sl, uint32_t gp, uint32_t rev, uint32_t m) {
-                        bool pass;
-                        if (revote) pass = in && T[(sl - 2u) & (VOTE_SLOTS - 1)] + T[sl] + T[(sl + 2u) & (VOTE_SLOTS - 1)] >= thr;
-                        else pass = in && (sl == L0 || sl == L1 || sl == L2 || sl == L3 || sl == L4 || sl == L5 || sl == L6);
-                        const uint64_t bm = __ballot(pass);
-                        if (pass) {
-                            const uint32_t span = C.qz_span[m] & 0xffu;
-                            const uint64_t key = (rev ? (1ULL << 63) | (uint64_t)C.qrev[m] << 8 : (uint64_t)C.qpos[m] << 8) | (uint64_t)span | (uint64_t)gp << 32;
-                            d_put_key(A, wbase + __popcll(bm & ((1ULL << lane) - 1ULL)), key);
-                        }
-                        wbase += __popcll(bm);
-                    });
+            __builtin_amdgcn_wave_barrier();
+            if (nhit <= VOTE_HCAP) {
+                // ---- survivors from the remembered hits.  The minimizer data of a remembered hit is read from the mz arrays again
+                // (the LDS chunk holds only the last 128 minimizers): qpos / span / strand by minimizer index g0 + chunk * 128 + m
+                uint32_t thr = (vmax * (uint32_t)V.frac_q8 + 255u) >> 8;
+                if (thr < (uint32_t)V.vmin) thr = (uint32_t)V.vmin;
+                for (uint32_t h0 = 0; h0 < nhit; h0 += 64) {
+                    const uint32_t h = h0 + lane;
+                    bool pass_hit = false; VoteHit x; x.gp = 0; x.sm = 0;
+                    if (h < nhit) {
+                        x = HS[h];
+                        const uint32_t sl = x.sm & (VOTE_SLOTS - 1);
+                        pass_hit = T[(sl - 2u) & (VOTE_SLOTS - 1)] + T[sl] + T[(sl + 2u) & (VOTE_SLOTS - 1)] >= thr;
+                    }
+                    const uint64_t bm = __ballot(pass_hit);
+                    uint32_t base = 0;
+                    if (lane == 0 && bm) base = atomicAdd(&blk_cnt, (uint32_t)__popcll(bm));
+                    base = (uint32_t)__shfl((int)base, 0);
+                    if (pass_hit) {
+                        const int g = g0 + (int)(x.sm >> 18) * VOTE_MZ + (int)((x.sm >> 11) & (VOTE_MZ - 1));
+                        const uint32_t y = A.mz_y[g], span = (uint32_t)(A.mz_x[g] & 0xff), qpos = y >> 1, rev = x.sm & 1u;
+                        const uint64_t key = (rev ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)x.gp << 32;
+                        out[base + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = key;
+                    }
                 }
-            }
-            if (revote) {
                 __builtin_amdgcn_wave_barrier();
-                if (nhit <= VOTE_HCAP) { for (uint32_t h = lane; h < nhit; h += 64) T[HS[h]] = 0; }
-                else for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
-                __builtin_amdgcn_wave_barrier();
-            }
+                for (uint32_t h = lane; h < nhit; h += 64) T[HS[h].sm & (VOTE_SLOTS - 1)] = 0;
+            } else for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
+            __builtin_amdgcn_wave_barrier();
         }
+    }
+    __syncthreads();
+    if (tid == 0) VA.q_cnt[q] = (int32_t)blk_cnt;
+}
+// staging -> dense keys (as one 64-bit word, or as the two words the sort takes)
+__global__ void __launch_bounds__(256) k_vote_compact(const uint64_t *__restrict__ stage, const int64_t *__restrict__ q_soff, const int32_t *__restrict__ q_aoff, int32_t nq,
+                                                      uint64_t *__restrict__ keys, uint32_t *__restrict__ k32, uint32_t *__restrict__ v32)
+{
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int64_t s0 = q_soff[q]; const int a0 = q_aoff[q], n = q_aoff[q + 1] - a0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const uint64_t k = stage[s0 + i];
+        if (k32) { k32[a0 + i] = (uint32_t)(k >> 32); v32[a0 + i] = (uint32_t)k; } else keys[a0 + i] = k;
     }
 }
 

@@ -1381,25 +1381,24 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     S.tile_off = mz_staged ? d_toff : nullptr; S.q_tile0 = mz_staged ? d_first : nullptr;
     VoteOpt VO; VO.len = mo->vote_len; VO.shift = mo->vote_bin_shift; VO.vmin = mo->vote_min; VO.frac_q8 = mo->vote_frac_q8;
     VoteArgs VA; memset(&VA, 0, sizeof(VA));
-    // the counts that become anchor offsets: per minimizer, or per sub-read when the sub-reads vote
+    // the counts that become anchor offsets: per minimizer, or per query when the sub-reads vote (the vote kernel appends a
+    // query's survivors to its piece of a staging array; k_vote_compact moves them to the scanned offsets)
     int32_t *d_cnt = d_mcnt, *d_aoff = d_maoff; size_t ncnt = (size_t)nmz;
-    int32_t *d_qsub = nullptr;
+    int64_t *d_qsoff = nullptr; uint64_t *d_stage = nullptr;
     if (vote) {
-        int32_t *h_qsub; TRY(ctx_hbuf_t(ctx, "h_qsuboff", (size_t)nq + 1, &h_qsub));
-        int64_t acc = 0;
-        for (int i = 0; i < nq; ++i) { h_qsub[i] = (int32_t)acc; acc += (qs->len[q0 + i] + mo->vote_len - 1) / mo->vote_len; }
-        h_qsub[nq] = (int32_t)acc;
-        if (acc >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
-        ncnt = (size_t)acc;
-        int32_t *d_scnt, *d_saoff; uint16_t *d_slist;
-        TRY(ctx_buf_t(ctx, "q_suboff", (size_t)nq + 1, &d_qsub)); TRY(ctx_buf_t(ctx, "sub_cnt", ncnt + 1, &d_scnt)); TRY(ctx_buf_t(ctx, "sub_aoff", ncnt + 1, &d_saoff));
-        TRY(ctx_buf_t(ctx, "sub_list", ncnt * 8 + 8, &d_slist));
-        HIPCHK(hipMemcpyAsync(d_qsub, h_qsub, ((size_t)nq + 1) * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemsetAsync(d_scnt, 0, (ncnt + 1) * 4, st));
-        HIPCHK(hipMemsetAsync(d_slist, 0, (ncnt * 8 + 8) * 2, st));
-        VA.q_suboff = d_qsub; VA.sub_cnt = d_scnt; VA.sub_list = d_slist; VA.sub_aoff = d_saoff;
-        d_cnt = d_scnt; d_aoff = d_saoff;
-        hipLaunchKernelGGL(k_seed_vote<0>, dim3(nq), dim3(256), 0, st, S, VO, VA);
+        int64_t *d_qhits; int32_t *d_qcnt;
+        TRY(ctx_buf_t(ctx, "vote_qhits", (size_t)nq + 2, &d_qhits)); TRY(ctx_buf_t(ctx, "vote_qsoff", (size_t)nq + 2, &d_qsoff)); TRY(ctx_buf_t(ctx, "vote_qcnt", (size_t)nq + 2, &d_qcnt));
+        if (nmz) hipLaunchKernelGGL(k_vote_lookup, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
+        hipLaunchKernelGGL(k_vote_qhits, dim3(nq + 1), dim3(64), 0, st, d_qmz, d_mn, nq, d_qhits);
+        HIPCHK(hipGetLastError());
+        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_qhits, d_qsoff, (size_t)nq + 1)));
+        int64_t nhits = 0;
+        HIPCHK(hipMemcpyAsync(&nhits, d_qsoff + nq, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        TRY(ctx_buf_t(ctx, "vote_stage", (size_t)nhits + 1, &d_stage));
+        VA.q_soff = d_qsoff; VA.stage = d_stage; VA.q_cnt = d_qcnt;
+        hipLaunchKernelGGL(k_seed_vote, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA);
+        d_cnt = d_qcnt; d_aoff = d_qaoff; ncnt = (size_t)nq;
     } else hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_cnt + ncnt, 0, 4, st));
@@ -1428,10 +1427,11 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     uint32_t *d_k32 = (uint32_t*)d_keys, *d_v32 = d_k32 + na, *d_k32s = nullptr, *d_v32s = nullptr;
     if (!sort64) { TRY(ctx_buf_t(ctx, "skeys32", (size_t)na * 2 + 2, &d_k32s)); d_v32s = d_k32s + na; }
     S.mz_aoff = d_maoff; S.keys = d_keys; S.k32 = sort64 ? nullptr : d_k32; S.v32 = sort64 ? nullptr : d_v32;
-    if (vote) hipLaunchKernelGGL(k_seed_vote<1>, dim3(nq), dim3(256), 0, st, S, VO, VA);
-    else hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, vote ? d_aoff : d_maoff, vote ? d_qsub : d_qmz, nq, na, d_qaoff);
+    if (vote) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, S.keys, S.k32, S.v32);
+    else {
+        hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
+        hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, na, d_qaoff);
+    }
     HIPCHK(hipGetLastError());
     t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
@@ -2127,8 +2127,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
     if (mo->e < mo->e2 || mo->q > mo->q2) { ctx->err = "two-piece gap cost needs e >= e2 and q <= q2"; return TELR_E_ARG; }
     if (mo->fill_margin < 0 || mo->fill_margin > 64) { ctx->err = "fill_margin must be 0..64"; return TELR_E_ARG; }
-    if (mo->vote_len != 0 && (mo->vote_len < 16 || mo->vote_bin_shift < 0 || mo->vote_bin_shift > 20 || mo->vote_min < 1 || mo->vote_frac_q8 < 0 || mo->vote_frac_q8 > 256)) {
-        ctx->err = "sub-read voting needs vote_len >= 16, vote_bin_shift 0..20, vote_min >= 1, vote_frac_q8 0..256"; return TELR_E_ARG; }
+    if (mo->vote_len != 0 && (mo->vote_len < 16 || mo->vote_len > 65536 || mo->vote_bin_shift < 0 || mo->vote_bin_shift > 20 || mo->vote_min < 1 || mo->vote_frac_q8 < 0 || mo->vote_frac_q8 > 256)) {
+        ctx->err = "sub-read voting needs vote_len 16..65536, vote_bin_shift 0..20, vote_min >= 1, vote_frac_q8 0..256"; return TELR_E_ARG; }
     if (mo->flags & TELR_MF_FAITHFUL) { ctx->err = "TELR_MF_FAITHFUL is a mode of the CPU oracle (test infrastructure), not of the engine"; return TELR_E_ARG; }
     if (mo->max_gap >= TELR_TPAD || mo->ext_band * 2 + 1 > DP_DMAX || mo->ext_band < 1 || mo->ext_max < 1) return TELR_E_ARG;
     if (queries->max_len >= (1 << 24)) return TELR_E_RANGE;
@@ -2914,3 +2914,4 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
 }
 
 #include "bam_dev.hip.h"
+#include "fasta_io.hip.h"

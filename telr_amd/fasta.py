@@ -58,3 +58,57 @@ def revcomp(s):
     if isinstance(s, str):
         return s.encode().translate(_COMP)[::-1].decode()
     return bytes(s).translate(_COMP)[::-1]
+
+
+class FastaFile:
+    """A FASTA / FASTQ file parsed by the library (telr_fasta_load: worker threads over the mapped file) into the arrays the C
+    ABI takes.  `.triple` = (base buffer, offsets, lengths) as numpy views of library memory (valid while this object lives),
+    `.names_c` = the C array of names for the writers, `.names` = the same as Python strings (built on first use)."""
+
+    def __init__(self, path):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.lib()
+        h = C.c_void_p()
+        rc = self.L.telr_fasta_load(str(path).encode(), C.byref(h))
+        if rc != 0:
+            raise _lib.TelrError("telr_fasta_load(%s): %s" % (path, self.L.telr_strerror(rc).decode()))
+        self.h = h
+        self.n = int(self.L.telr_fasta_count(h))
+        nb = int(self.L.telr_fasta_bases(h))
+
+        def view(ptr, count, dt):
+            if not count or not ptr:
+                return np.zeros(0, dt)
+            return np.frombuffer((C.c_char * (count * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt, count=count)
+        self.triple = (view(self.L.telr_fasta_seq(h), nb, np.uint8), view(self.L.telr_fasta_off(h), self.n, np.int64), view(self.L.telr_fasta_len(h), self.n, np.int32))
+        self.names_c = C.cast(self.L.telr_fasta_names(h), C.POINTER(C.c_char_p * max(1, self.n))).contents if self.n else (C.c_char_p * 1)()
+        self._names = None
+
+    @property
+    def names(self):
+        if self._names is None:
+            self._names = [self.names_c[i].decode() for i in range(self.n)]
+        return self._names
+
+    def seqs(self):
+        buf, off, ln = self.triple
+        return [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in range(self.n)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.triple = None; self.names_c = None
+            self.L.telr_fasta_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load(path):
+    """FastaFile for plain files; gzip goes through the Python reader (names, seqs lists wrapped the same way)"""
+    if str(path).endswith(".gz"):
+        return None
+    return FastaFile(path)

@@ -132,6 +132,7 @@ def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total
     lib = make_te_library(rng, n_fam)
     # reference TE copies: diverged, 5'-truncated copies over ~te_frac of the genome
     covered = 0
+    te_copies = []                  # (start, end) of the reference's TE-derived stretches (reported, not used by the generator)
     while covered < te_frac * genome_len:
         f = lib[int(rng.integers(0, n_fam))]
         cut = int(rng.integers(0, max(1, len(f) // 2)))
@@ -141,6 +142,7 @@ def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total
         p = int(rng.integers(0, genome_len - len(cp)))
         ref[p:p + len(cp)] = cp
         covered += len(cp)
+        te_copies.append((p, p + len(cp)))
     # spiked non-reference insertions, >= 5 kb apart
     sites = np.sort(rng.choice(np.arange(5000, genome_len - 5000, 5000), size=n_ins, replace=False)) + rng.integers(0, 2000, size=n_ins)
     ins = []
@@ -169,7 +171,7 @@ def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total
     ln = np.concatenate([rA[2], rB[2]])
     off = np.cumsum(ln.astype(np.int64)) - ln
     truth = np.concatenate([np.c_[np.zeros(nA, np.int64), rA[3]], np.c_[np.ones(n_reads - nA, np.int64), rB[3]]])
-    return dict(ref=ref, library=lib, reads=(buf, off.astype(np.int64), ln.astype(np.int32)), insertions=ins, truth=truth, haps=haps)
+    return dict(ref=ref, library=lib, reads=(buf, off.astype(np.int64), ln.astype(np.int32)), insertions=ins, truth=truth, haps=haps, te_copies=te_copies)
 
 
 def make_loci_from_dataset(d, n_loci, seed=7, flank=(8000, 15000), reads_cap=60, window=1000):

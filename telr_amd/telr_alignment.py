@@ -4,7 +4,10 @@
 signature and argument meaning (:9): `method` is "nglmr" (sic, the reference's spelling) or "minimap2",
 `presets` is "ont" or "pacbio".  Instead of `ngmlr ... > tmp.sam` / `minimap2 --cs --MD -Y -L -ax ... >
 sam` (:28-82) followed by `samtools sort` + `samtools index` (:103-114), the reads are mapped by the HIP
-engine and the coordinate-sorted, indexed BAM is written directly by the library.
+engine and the coordinate-sorted, indexed BAM is built on the device from what is resident there (reads,
+reference, CIGARs: telr_write_bam_dev) -- the host parses the two input files (telr_fasta_load), packs and
+uploads them, and moves the finished file image into `bam`, whose pages are being allocated while the reads
+are still mapped (telr_bam_prepare).
 """
 import logging
 import os
@@ -12,7 +15,7 @@ import sys
 import time
 
 from .aligner import Engine
-from .fasta import read_fasta
+from .fasta import read_fasta, load
 from .presets import preset
 
 
@@ -41,14 +44,27 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
         sys.exit(1)
     eng = engine or Engine(0)
     io, mo = preset(name)
-    tn, ts = read_fasta(reference)
-    qn, qs = read_fasta(read)
+    tf, qf = load(reference), load(read)          # None for gzip: the Python reader
+    if tf is not None:
+        tn, ts = tf.names_c, tf.triple
+    else:
+        tn, ts = read_fasta(reference)
+    if qf is not None:
+        qn, qs, n_bases = qf.names_c, qf.triple, int(qf.triple[2].sum())
+    else:
+        qn, qs = read_fasta(read)
+        n_bases = sum(len(x) for x in qs)
+    with_cs = method == "minimap2"
     ix = eng.index(ts, io)
-    r = ix.map_raw(qs, mo)
+    qset = eng.seqset(qs)
+    # about 0.85 bytes of BAM per read base with --cs --MD, 0.6 without cs, at level 1
+    ix.bam_prepare(bam, int((0.95 if with_cs else 0.7) * n_bases) + (64 << 20))
+    r = ix.map_raw(qset, mo)
     try:
-        ix.write_bam(r, qn, qs, tn, ts, bam, md=True, cs=(method == "minimap2"), softclip=True, rg=rg, cmdline=cmd, index=True)
+        ix.write_bam_device(r, qset, qn, tn, bam, md=True, cs=with_cs, softclip=True, rg=rg, cmdline=cmd, index=True, level=1)
     finally:
         ix.free_raw(r)
+        qset.free()
     if os.path.isfile(bam) is False:
         sys.stderr.write("Sorted and indexed BAM file does not exist, exiting...\n")
         sys.exit(1)

@@ -134,6 +134,76 @@ def test_simulated_origins_are_recovered(full):
     assert ok >= 0.99 * len(prim), (ok, len(prim))
 
 
+def _origin_table(d, alns):
+    """per primary record: (on the simulated origin?, mapq, fraction of the read's true reference interval that is TE-derived)"""
+    prim = alns[(alns["flags"] & 1) != 0]
+    ins = d["insertions"]
+    add = {0: [], 1: []}
+    for (p, fam, strand, tsd, af) in ins:
+        L = len(d["library"][fam]) + tsd
+        add[0].append((p, L))
+        if af >= 1.0:
+            add[1].append((p, L))
+    cum = {h: (np.array([p for p, _ in add[h]], np.int64), np.array([L for _, L in add[h]], np.int64)) for h in add}
+
+    def to_ref(h, x):
+        sh = 0
+        for p, L in zip(*cum[h]):
+            if p + sh < x:
+                sh += min(int(L), x - (int(p) + sh))
+            else:
+                break
+        return x - sh
+    te = np.zeros(len(d["ref"]) + 1, np.int32)
+    for s_, e_ in d["te_copies"]:
+        te[s_] += 1; te[e_] -= 1
+    te_cov = np.concatenate([[0], np.cumsum(np.cumsum(te[:-1]) > 0)])          # TE-derived bases before every position
+    truth = d["truth"]
+    on = np.zeros(len(prim), bool); tef = np.zeros(len(prim))
+    for k, a in enumerate(prim):
+        h, s, e, st = (int(v) for v in truth[a["qid"]])
+        rs, re = to_ref(h, s), to_ref(h, e)
+        on[k] = a["ts"] < re + 50 and a["te"] > rs - 50 and ((a["flags"] >> 3) & 1) == st
+        tef[k] = (te_cov[min(re, len(te_cov) - 1)] - te_cov[max(rs, 0)]) / max(1, re - rs)
+    return prim, on, tef
+
+
+@pytest.mark.parametrize("name", ["map-ont", "ngmlr-ont", "map-ont/9kb", "ngmlr-pacbio/9kb-clr"])
+def test_mapq_calibration_for_the_sniffles_gate(engine, full, name):
+    """Sniffles is run with its default minimum mapping quality of 20 (src/telr/TELR_sv.py:49-51; SURVEY hand-off H1): a
+    primary record on the read's simulated origin must pass that gate, a primary record somewhere else must not.  Measured
+    on all 10,000 reads of configs[1] (15 % of the genome TE-derived), reported for the reads that lie mostly inside
+    TE-derived sequence as well."""
+    d = full["d"]
+    if name == "map-ont":
+        alns = full["res"].alns
+    elif "/" not in name:
+        io, mo = preset(name)
+        alns = engine.index([full["ref_str"]], io).map(full["qs"], mo).alns
+    else:
+        # the read length of configs[2] / [3] (mean 9 kb; many more reads end inside a TE copy) on the same genome
+        pname, kind = name.split("/")
+        err = (0.013, 0.065, 0.052) if kind.endswith("clr") else (0.04, 0.02, 0.04)
+        d = synth.make_stage1_dataset(seed=20261002, n_reads=20000, total_bases=180_000_000, err=err, read_seed=20261002 + 5000)
+        assert bytes(d["ref"][:1000]) == bytes(full["d"]["ref"][:1000])
+        io, mo = preset(pname)
+        alns = engine.index([full["ref_str"]], io).map(engine.seqset(d["reads"]), mo).alns
+    prim, on, tef = _origin_table(d, alns)
+    q20 = prim["mapq"] >= 20
+    right_q20 = (on & q20).sum() / max(1, on.sum())
+    wrong_q20 = (~on & q20).sum() / len(prim)
+    inte = tef >= 0.5
+    rep = {"primaries": int(len(prim)), "on_origin": int(on.sum()), "on_origin_mapq_ge_20": float(right_q20), "wrong_locus_mapq_ge_20_of_all": float(wrong_q20),
+           "reads_mostly_TE_derived": int(inte.sum()), "of_those_on_origin": int((on & inte).sum()),
+           "of_those_on_origin_mapq_ge_20": float((on & inte & q20).sum() / max(1, (on & inte).sum())),
+           "of_those_wrong_locus_mapq_ge_20": int((~on & inte & q20).sum()),
+           "mapq_histogram_on_origin": np.bincount(np.minimum(prim["mapq"][on] // 10, 6), minlength=7).tolist(),
+           "mapq_histogram_wrong": np.bincount(np.minimum(prim["mapq"][~on] // 10, 6), minlength=7).tolist()}
+    print("MAPQ calibration", name, rep)
+    assert right_q20 >= 0.97, rep
+    assert wrong_q20 <= 0.01, rep
+
+
 def test_idempotent_and_batch_independent(full):
     ix, qs, mo, res = full["ix"], full["qs"], full["mo"], full["res"]
     whole = _per_read_digest(res.alns, res.cigars)

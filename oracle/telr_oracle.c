@@ -37,6 +37,28 @@
 #define NEG        (-(1 << 28))
 #define TPAD       16384          /* padding between targets in global coordinates */
 #define KEY_REV    (1ULL << 63)
+
+/* Oracle-only experiment bits (with TELR_MF_FAITHFUL they quantify what the engine's spec leaves out of minimap2 2.22's
+ * published behaviour; tests/test_faithful_gate.py prints the drift table, DESIGN.md section 2 holds it):
+ *   0x100  look-back 5000 (max_chain_iter)          0x200  gap fills over the whole -r band     0x400  uncapped end extensions
+ *   0x1000 minimap2's order-dependent predecessor scan: look-back 5000, the scan starts where the reference distance exceeds
+ *          max_gap, and stops after max_chain_skip = 25 predecessors that already sit on a chain through anchor i
+ *          (lchain.c: mg_lchain_dp; Li 2018 section 2.1.1 "heuristics")
+ *   0x2000 high-occurrence seed rescue: in a stretch of skipped (too frequent) minimizers longer than 500 query bases the
+ *          least frequent ones (one per 500 bases, occurrence < 4096) are seeded after all (seed.c: mm_seed_select)
+ *   0x4000 long join: when the first round leaves more than one chain, the anchors are chained again with the long bandwidth
+ *          bw_long = 20,000 diagonals (map.c: the re-chaining of 2.19+; Li 2021)
+ *   0x8000 RMQ chaining of the asm presets: -r100k with an unbounded look-back (what a range-minimum query sees)
+ *   0x10000 z-drop inside gap fills: minimap2 breaks a record where the score of a fill's path drops by more than -z below
+ *          its running maximum; here such fills are COUNTED per record (telr_aln.n_ambi) -- the records minimap2 would split
+ *   0x20000 minimap2's own MAPQ (identity- and n_sub-aware; map.c: mm_set_mapq) instead of the paper's formula */
+#define MFX_LOOKBACK 0x100
+#define MFX_SKIP     0x1000
+#define MFX_RESCUE   0x2000
+#define MFX_LONGJOIN 0x4000
+#define MFX_RMQ      0x8000
+#define MFX_ZSPLIT   0x10000
+#define MFX_MAPQ     0x20000
 #define DP_DMAX    4096           /* widest band (diagonals) the DP accepts; wider -> diagonal fallback */
 #define DEPTH_CAP  8000           /* samtools depth default -d */
 
@@ -347,6 +369,32 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
         g0 = ix->goff[tfilter]; g1 = g0 + (uint32_t)ix->len[tfilter];
         mid_occ = tor_mid_occ_target(ix, tfilter, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ);
     }
+    /* 0x2000: which of the too-frequent minimizers are seeded after all (mm_seed_select; all-vs-all calls only) */
+    uint8_t *rescued = NULL;
+    if ((mo->flags & MFX_RESCUE) && tfilter < 0 && !per_t && mv.n > 0) {
+        const int dist = 500, max_max_occ = 4095;
+        rescued = (uint8_t*)calloc(mv.n, 1);
+        int64_t *occ = (int64_t*)malloc(8 * mv.n);
+        for (int64_t i = 0; i < mv.n; ++i) { int64_t e = index_lookup(ix, mv.a[i].x >> 8); occ[i] = e < 0 ? 0 : (int64_t)(ix->ent_off[e + 1] - ix->ent_off[e]); }
+        int64_t last0 = -1;
+        for (int64_t i = 0; i <= mv.n; ++i) {
+            if (i == mv.n || occ[i] <= mid_occ) {
+                if (i - last0 > 1) {
+                    int32_t ps = last0 < 0 ? 0 : (int32_t)(mv.a[last0].y >> 1), pe = i == mv.n ? qlen : (int32_t)(mv.a[i].y >> 1);
+                    int k = (int)((double)(pe - ps) / dist + .499);
+                    /* the k least frequent of the stretch (ties: the earlier one), below max_max_occ */
+                    for (int z = 0; z < k; ++z) {
+                        int64_t bi = -1;
+                        for (int64_t j = last0 + 1; j < i; ++j) if (!rescued[j] && occ[j] < max_max_occ && (bi < 0 || occ[j] < occ[bi])) bi = j;
+                        if (bi < 0) break;
+                        rescued[bi] = 1;
+                    }
+                }
+                last0 = i;
+            }
+        }
+        free(occ);
+    }
     for (int64_t i = 0; i < mv.n; ++i) {
         int64_t e = index_lookup(ix, mv.a[i].x >> 8);
         ++*n_probe;
@@ -373,7 +421,7 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
         int32_t cnt = 0;
         if (tfilter >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t g = ix->ys[o] >> 1; if (g >= g0 && g < g1) ++cnt; } }
         else cnt = (int32_t)(o1 - o0);
-        if (cnt == 0 || cnt > mid_occ) continue;
+        if (cnt == 0 || (cnt > mid_occ && !(rescued && rescued[i]))) continue;
         if (vote) {
             /* minimizers come in query order: a new sub-read closes the previous one */
             int32_t sid = qpos / mo->vote_len;
@@ -397,6 +445,7 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
         }
     }
     if (vote) { vote_subread(sub.a, sub.n, mo, out); free(sub.a); }
+    free(rescued);
     free(mv.a);
     qsort(out->a, out->n, 8, cmp_u64);
 }
@@ -432,7 +481,30 @@ static inline int32_t chain_sc(uint64_t ai, uint64_t aj, const telr_map_opt *mo)
 
 static void chain_dp(const uint64_t *a, int64_t n, const telr_map_opt *mo, int32_t *f, int32_t *p)
 {
-    int H = (mo->flags & (TELR_MF_FAITHFUL | 0x100)) ? 5000 : mo->chain_lookback;     /* faithful mode: minimap2's max_chain_iter (0x100-0x400: its parts, for experiments) */
+    int H = (mo->flags & (TELR_MF_FAITHFUL | MFX_LOOKBACK | MFX_SKIP)) ? 5000 : mo->chain_lookback;     /* faithful mode: minimap2's max_chain_iter */
+    if (mo->flags & MFX_RMQ) H = 1 << 30;
+    if (mo->flags & MFX_SKIP) {
+        const int max_skip = 25;
+        int32_t *t = (int32_t*)malloc(4 * (n ? n : 1));
+        for (int64_t i = 0; i < n; ++i) t[i] = -1;
+        int64_t st = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            while (st < i && ((a[st] >> 63) != (a[i] >> 63) || A_G(a[i]) - A_G(a[st]) > mo->max_gap)) ++st;
+            if (i - st > H) st = i - H;
+            int32_t best = A_SPAN(a[i]), bp = -1; int n_skip = 0;
+            for (int64_t j = i - 1; j >= st; --j) {
+                int32_t sc = chain_sc(a[i], a[j], mo);
+                if (sc == INT32_MIN) continue;
+                int32_t v = f[j] + sc;
+                if (v > best) { best = v; bp = (int32_t)j; if (n_skip > 0) --n_skip; }
+                else if (t[j] == (int32_t)i) { if (++n_skip > max_skip) break; }
+                if (p[j] >= 0) t[p[j]] = (int32_t)i;
+            }
+            f[i] = best; p[i] = bp;
+        }
+        free(t);
+        return;
+    }
     for (int64_t i = 0; i < n; ++i) {
         int32_t best = A_SPAN(a[i]), bp = -1;
         int64_t st = i - H; if (st < 0) st = 0;
@@ -759,7 +831,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     }
     int nseg = (int)(bp.n / 2) - 1;
     u32v_t cig = {0, 0, 0}, rc = {0, 0, 0};
-    int32_t dp = 0;
+    int32_t dp = 0, n_zdrop = 0;
     /* left extension: reversed sequences starting at (q0-1, r0-1) going down */
     int32_t qs = q0, rs = r0;
     if (q0 > 0 && r0 > 0) {
@@ -792,6 +864,29 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
             if (W2 > W && hi - lo + 1 <= DP_DMAX) { rc.n = 0; r = band_dp(&s, lo, hi, 0, mo, &rc); ctr->dp_cells += r.cells; }
         }
         dp += r.score;
+        if (mo->flags & MFX_ZSPLIT) {
+            /* the running score along the fill's path against its running maximum (ksw2's z-drop test with the diagonal term) */
+            int32_t sc = 0, mx = 0, mi = 0, mj = 0, i_ = 0, j_ = 0, dropped = 0;
+            for (int64_t z = rc.n - 1; z >= 0 && !dropped; --z) {
+                int op = rc.a[z] & 0xf, ln = rc.a[z] >> 4;
+                if (op == 0) {
+                    for (int x = 0; x < ln && !dropped; ++x) {
+                        int qb = qbase(&s, i_), tb = tbase(&s, j_);
+                        sc += (qb < 4 && tb < 4) ? (qb == tb ? mo->a : -mo->b) : -mo->sc_ambi;
+                        ++i_; ++j_;
+                        if (sc > mx) { mx = sc; mi = i_; mj = j_; }
+                        else { int dd = (i_ - mi) - (j_ - mj); if (dd < 0) dd = -dd; if (mx - sc > mo->zdrop + mo->e2 * dd) dropped = 1; }
+                    }
+                } else {
+                    int c1 = mo->q + mo->e * ln, c2 = mo->q2 + mo->e2 * ln;
+                    sc -= c1 < c2 ? c1 : c2;
+                    if (op == 1) i_ += ln; else j_ += ln;
+                    int dd = (i_ - mi) - (j_ - mj); if (dd < 0) dd = -dd;
+                    if (mx - sc > mo->zdrop + mo->e2 * dd) dropped = 1;
+                }
+            }
+            n_zdrop += dropped;
+        }
         for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
     }
     int32_t qe = c->qe, re = c->re;
@@ -823,7 +918,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     }
     al->ts = rs; al->te = re;
     if (c->rev) { al->qs = qlen - qe; al->qe = qlen - qs; } else { al->qs = qs; al->qe = qe; }
-    al->mlen = mlen; al->blen = blen; al->n_ambi = 0; al->dp_score = dp; (void)nambi;
+    al->mlen = mlen; al->blen = blen; al->n_ambi = n_zdrop; al->dp_score = dp; (void)nambi;      /* n_ambi: 0 unless the 0x10000 experiment counts z-dropped fills */
     al->n_cigar = (int32_t)cig.n; al->cigar_off = cigars->n;
     for (int64_t z = 0; z < cig.n; ++z) vpush(uint32_t, *cigars, cig.a[z]);
     free(cig.a); free(rc.a); free(bp.a);
@@ -844,6 +939,22 @@ typedef struct tor_result {
 static int32_t mapq_of(const telr_aln *r, const telr_map_opt *mo)
 {
     if (!(r->flags & TELR_F_PRIMARY) && !(r->flags & TELR_F_SUPPL)) return 0;
+    if (mo->flags & MFX_MAPQ) {
+        /* mm_set_mapq of minimap2 2.22 without the second-best DP score (ksw2's dp_max2 is not computed here): identity,
+         * chain-score and anchor-count penalties, the sub-optimal chain, and the log of the number of sub-optimal chains */
+        if (!(r->flags & TELR_F_PRIMARY) && !(r->flags & TELR_F_SUPPL)) return 0;
+        float pen_s1 = r->score > 100 ? 1.0f : 0.01f * (float)r->score;
+        float pen_cm = r->cnt > 10 ? 1.0f : 0.1f * (float)r->cnt;
+        if (pen_s1 < pen_cm) pen_cm = pen_s1;
+        float subsc = (float)(r->subsc > mo->min_chain_score ? r->subsc : mo->min_chain_score);
+        float identity = r->blen > 0 ? (float)r->mlen / (float)r->blen : 0.0f;
+        float x = subsc / (float)r->score;
+        int32_t mq = (int32_t)(identity * pen_cm * 40.0f * (1.0f - x) * logf((float)r->dp_score / (float)mo->a));
+        mq -= (int32_t)(4.343f * logf((float)r->n_sub + 1.0f) + .499f);
+        if (mq < 0) mq = 0;
+        if (mq > 60) mq = 60;
+        return mq;
+    }
     float f1 = (float)r->score, f2 = (float)(r->subsc > mo->min_chain_score ? r->subsc : mo->min_chain_score);
     float pen_cm = r->cnt > 10 ? 1.0f : 0.1f * (float)r->cnt;
     float x = f2 / f1; if (x > 1.0f) x = 1.0f;
@@ -868,9 +979,17 @@ tor_result *tor_map(const tor_index *ix, int32_t nq, const char *ascii, const in
         collect_anchors(ix, q, qlen, qtarget ? qtarget[qi] : -1, mid_occ, mo, &an, &R->ctr.minimizers, &R->ctr.probes);
         R->ctr.anchors += an.n;
         int32_t *f = (int32_t*)malloc(4 * (an.n ? an.n : 1)), *p = (int32_t*)malloc(4 * (an.n ? an.n : 1));
-        chain_dp(an.a, an.n, mo, f, p);
+        telr_map_opt mc = *mo;
+        if ((mo->flags & MFX_RMQ) && mo->bw >= 10000) mc.bw = 100000;          /* asm10 of minimap2 2.22: --rmq -r100k -g10k */
+        chain_dp(an.a, an.n, &mc, f, p);
         chainv_t ch = {0, 0, 0}; u64v_t ca = {0, 0, 0};
-        chain_backtrack(ix, an.a, an.n, f, p, mo, &ch, &ca);
+        chain_backtrack(ix, an.a, an.n, f, p, &mc, &ch, &ca);
+        if ((mo->flags & MFX_LONGJOIN) && ch.n > 1 && mc.bw < 20000) {          /* re-chain with bw_long */
+            mc.bw = 20000; mc.flags |= MFX_LOOKBACK;
+            ch.n = 0; ca.n = 0;
+            chain_dp(an.a, an.n, &mc, f, p);
+            chain_backtrack(ix, an.a, an.n, f, p, &mc, &ch, &ca);
+        }
         R->ctr.chains += ch.n;
         if (debug) {
             vpush(int64_t, R->d_anchor_off, R->d_anchor.n);

@@ -58,3 +58,112 @@ def annotate_contig(backend, contig_names, contig_seqs, alt_seqs, lib_names, lib
     for c, s, e, fam, strand in merged:
         ann.append([c, s, e, fam, ".", strand if strand in ("+", "-") else "."])
     return iv.bed_sort(ann), seq2contig, te2contig
+
+
+# ---- RepeatMasker hand-off (reference src/telr/TELR_te.py:391-494, telr.py:132-144) ------------------------------------
+# RepeatMasker itself is an external tool and stays one (hand-off H2).  What is restated here is the glue around it --
+# `parse_rm_out` (RepeatMasker's GFF2 -> the GFF3 the pipeline reads), `gff3tobed` (-> the sorted TE BED of the reference
+# genome that the liftover consults) -- and, new, a cache: the reference masks the WHOLE reference genome with the TE library
+# on every run (telr.py:132-139; tens of minutes for dm6, hours for a human chromosome), although the result depends on
+# nothing but the two files and RepeatMasker's flags.  `repeatmask(..., cache_dir=...)` keys the three output files by the
+# SHA-256 of (reference bytes, library bytes, the flag string) and copies them back on a hit.
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+RM_FLAGS = ["-gff", "-s", "-nolow", "-no_is", "-e", "ncbi"]          # TELR_te.py:397-404
+
+
+def parse_rm_out(rm_gff, gff3):
+    """TELR_te.py:472-494: lines of RepeatMasker's .out.gff -> GFF3 with `Target=<family>`"""
+    with open(gff3, "w") as output, open(rm_gff, "r") as inp:
+        for line in inp:
+            if "RepeatMasker" in line:
+                entry = line.replace("\n", "").split("\t")
+                family = entry[8].split(" ")[1]
+                family = re.sub('"Motif:', "", family)
+                family = re.sub('"', "", family)
+                output.write("\t".join([entry[0], "RepeatMasker", "dispersed_repeat", entry[3], entry[4], entry[5], entry[6], entry[7], "Target=" + family]) + "\n")
+
+
+def gff3tobed(gff, bed):
+    """TELR_te.py:436-469: GFF3 -> BED6 (0-based start, family as name), sorted as `bedtools sort` does (intervals.bed_sort)"""
+    with open(gff, "r") as inp:
+        for line in inp:
+            if "#" not in line:
+                if "Target=" not in line:
+                    print("Incorrect GFF3 format, please check README for expected format, exiting...")
+                    sys.exit(1)
+                break
+    rows = []
+    with open(gff, "r") as inp:
+        for line in inp:
+            if "#" not in line:
+                entry = line.replace("\n", "").split("\t")
+                for item in entry[8].split(";"):
+                    if "Target=" in item:
+                        family = item.replace("Target=", "")
+                rows.append([entry[0], str(int(entry[3]) - 1), entry[4], family, ".", entry[6]])
+    with open(bed, "w") as output:
+        for r in iv.bed_sort(rows):
+            output.write("\t".join(r) + "\n")
+
+
+def _sha256_file(path, h):
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 22), b""):
+            h.update(blk)
+
+
+def repeatmask_key(ref, library):
+    h = hashlib.sha256()
+    _sha256_file(ref, h); h.update(b"\0library\0"); _sha256_file(library, h); h.update(("\0" + " ".join(RM_FLAGS)).encode())
+    return h.hexdigest()
+
+
+def repeatmask(ref, library, outdir, thread, cache_dir=None, runner=subprocess.call):
+    """TELR_te.py:391-433 with the same return value (masked FASTA path, GFF3 path or None) and the same failure behaviour
+    (`sys.exit(1)`).  cache_dir: results of earlier runs on the same (reference, library) are copied instead of running
+    RepeatMasker again; a fresh result is stored there.  runner: what executes the argv (tests pass a stand-in)."""
+    os.makedirs(outdir, exist_ok=True)
+    base = os.path.basename(ref)
+    ref_rm, gff, gff3 = (os.path.join(outdir, base + x) for x in (".masked", ".out.gff", ".out.gff3"))
+    key = repeatmask_key(ref, library) if cache_dir else None
+    slot = os.path.join(cache_dir, key) if cache_dir else None
+    if slot and os.path.isfile(os.path.join(slot, "done")):
+        if os.path.isfile(os.path.join(slot, "masked")):
+            shutil.copyfile(os.path.join(slot, "masked"), ref_rm); shutil.copyfile(os.path.join(slot, "gff3"), gff3)
+            return ref_rm, gff3
+        return ref, None                                             # cached: "no repetitive sequences detected"
+    try:
+        runner(["RepeatMasker", "-dir", outdir] + RM_FLAGS + ["-lib", library, "-pa", str(thread), ref])
+        if not os.path.isfile(ref_rm):
+            ref_rm_out = os.path.join(outdir, base + ".out")
+            with open(ref_rm_out, "r") as inp:
+                for line in inp:
+                    if "There were no repetitive sequences detected" in line:
+                        print("No repetitive sequences detected")
+                        ref_rm = ref; gff = None; gff3 = None
+                    else:
+                        raise Exception("Repeatmasking failed, exiting...")
+        else:
+            parse_rm_out(gff, gff3)
+            open(ref_rm, "r").close()
+    except Exception as e:
+        print(e)
+        print("Repeatmasking failed, exiting...")
+        sys.exit(1)
+    if slot:
+        tmp = slot + ".tmp%d" % os.getpid()
+        os.makedirs(tmp, exist_ok=True)
+        if gff3 is not None:
+            shutil.copyfile(ref_rm, os.path.join(tmp, "masked")); shutil.copyfile(gff3, os.path.join(tmp, "gff3"))
+        open(os.path.join(tmp, "done"), "w").close()
+        try:
+            os.replace(tmp, slot)
+        except OSError:                                              # another run stored it meanwhile
+            shutil.rmtree(tmp, ignore_errors=True)
+    return ref_rm, gff3

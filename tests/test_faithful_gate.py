@@ -46,9 +46,10 @@ def _map_threads(oix, reads, mo, T=8):
         return {"alns": np.concatenate(list(ex.map(work, range(T))))}
 
 
-def drift(oix, reads, mo, parts=4, other=None):
+def drift(oix, reads, mo, parts=4, other=None, forgive_zdrop=False):
     """preset vs the same options with the faithful bits `parts` (4 = all; 0x100 look-back, 0x200 fills, 0x400 extensions),
-    or vs the options `other`"""
+    or vs the options `other`.  forgive_zdrop: reads whose faithful records contain a z-dropped gap fill (n_ambi > 0 under
+    the 0x10000 experiment: minimap2 would break the record there again) are left out of the comparison."""
     mf = mo.copy(); mf.flags |= parts
     if other is not None:
         mf = other
@@ -56,6 +57,9 @@ def drift(oix, reads, mo, parts=4, other=None):
     n = coord = core = score = 0
     for q in sorted(set(a) | set(b)):
         ra, rb = a.get(q, []), b.get(q, [])
+        if forgive_zdrop and any(int(y["n_ambi"]) > 0 for y in rb):
+            n += max(len(ra), len(rb))
+            continue
         n += max(len(ra), len(rb))
         core += abs(len(ra) - len(rb))
         for x in ra:
@@ -145,3 +149,97 @@ def test_subread_voting_against_unpruned_chaining(name, err):
     print(name, "sub-read voting vs all hits:", r)
     assert r["n"] >= 160
     assert r["core"] <= VOTE_MAX_DRIFT and r["coord"] <= VOTE_MAX_DRIFT, r
+
+
+# ---- FAITHFUL v2: what the spec leaves out of minimap2 2.22's published behaviour, bit by bit ------------------------------------
+# (oracle/telr_oracle.c: MFX_* experiment bits).  tools/faithful_table.py prints the whole table for DESIGN.md; the tests below
+# assert the part of it that a CPU run of a few minutes can hold.
+BITS = [("look-back 5000", 0x100), ("full-band fills + uncapped extensions", 0x200 | 0x400), ("max_chain_skip scan (look-back 5000, 25 skips)", 0x1000),
+        ("high-occurrence seed rescue", 0x2000), ("long join (re-chain with bw_long 20,000)", 0x4000), ("RMQ-style chaining (-r100k, unbounded look-back)", 0x8000)]
+
+
+def workload(kind, n):
+    """(index options, map options, reference strings, read strings) of a gate workload"""
+    if kind == "flanks-asm10":
+        # 500-base flanks as the liftover cuts them (TELR_liftover.py:167-266), from TE-free and TE-derived reference sequence
+        # alike, 0.5 % substitutions (a polished contig), asm10 -N 10
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10, total_bases=100000)
+        rng = np.random.default_rng(21)
+        ref = d["ref"]
+        reads = []
+        for _ in range(n):
+            p = int(rng.integers(0, len(ref) - 500))
+            f = synth.mutate(rng, ref[p:p + 500], 0.005, 0.0, 0.0)
+            reads.append(bytes(synth.revcomp_arr(f) if rng.integers(0, 2) else f).decode())
+        io, mo = preset("asm10"); mo.best_n = 10
+        return io, mo, [bytes(ref).decode()], reads
+    if kind in ("clr-map-pb", "clr-ngmlr-pacbio"):
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=4000, total_bases=36_000_000, err=(0.013, 0.065, 0.052), read_seed=20261002 + 77)
+        io, mo = preset("map-pb" if kind == "clr-map-pb" else "ngmlr-pacbio")
+    elif kind == "ont-ngmlr-ont":
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=4000, total_bases=36_000_000, read_seed=20261002 + 78)
+        io, mo = preset("ngmlr-ont")
+    elif kind == "c4-density":
+        # the repeat density of configs[4]: a 1,300-family library, 45 % of the sequence TE-derived
+        d = synth.make_stage1_dataset(seed=20261002 + 4, genome_len=12_000_000, n_reads=3000, total_bases=27_000_000, n_ins=100, n_fam=1300, te_frac=0.45, gc=0.47, read_seed=20261002 + 79)
+        io, mo = preset("map-ont")
+    else:
+        raise ValueError(kind)
+    buf, off, ln = d["reads"]
+    pick = np.random.default_rng(13).choice(len(ln), size=n, replace=False)
+    return io, mo, [bytes(d["ref"]).decode()], [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in pick]
+
+
+def bit_table(kind, n, bits=None):
+    io, mo, ref, reads = workload(kind, n)
+    oix = ob.OracleIndex(ref, io)
+    rows = []
+    base = _map_threads(oix, reads, mo)
+    for name, b in (bits or BITS):
+        if b == 0x8000 and mo.bw < 10000:
+            continue
+        if b == 0x4000 and mo.bw >= 20000:
+            continue
+        mf = mo.copy(); mf.flags |= b
+        r = drift(oix, reads, mo, other=mf)
+        rows.append((name, r))
+    if mo.bw < 20000:
+        mf = mo.copy(); mf.flags |= 0x4000 | 0x10000
+        rows.append(("long join, not counting reads whose joined record z-drops in a fill (minimap2 splits it again)", drift(oix, reads, mo, other=mf, forgive_zdrop=True)))
+    # z-drop inside fills: records minimap2 would break; MAPQ: decisions of the Sniffles gate (>= 20) that change
+    mz = mo.copy(); mz.flags |= 0x10000
+    z = _map_threads(oix, reads, mz)["alns"]
+    nz = int(((z["flags"] & 2) == 0).sum())
+    rows.append(("z-drop inside a gap fill (records minimap2 would split)", dict(n=nz, core=float(((z["n_ambi"] > 0) & ((z["flags"] & 2) == 0)).sum()) / max(1, nz), coord=0.0, score=0.0)))
+    mq = mo.copy(); mq.flags |= 0x20000
+    a, b2 = base["alns"], _map_threads(oix, reads, mq)["alns"]
+    assert len(a) == len(b2)
+    ka = {(int(x["qid"]), int(x["tid"]), int(x["ts"]), int(x["te"]), int(x["flags"])): int(x["mapq"]) for x in a if not x["flags"] & 2}
+    kb = {(int(x["qid"]), int(x["tid"]), int(x["ts"]), int(x["te"]), int(x["flags"])): int(x["mapq"]) for x in b2 if not x["flags"] & 2}
+    flip = sum(1 for k in ka if (ka[k] >= 20) != (kb.get(k, 0) >= 20))
+    rows.append(("minimap2's own MAPQ (records whose MAPQ >= 20 decision changes)", dict(n=len(ka), core=flip / max(1, len(ka)), coord=0.0, score=0.0)))
+    return rows
+
+
+LONG_JOIN = ("long join (re-chain with bw_long 20,000)", "long join, not counting reads whose joined record z-drops in a fill (minimap2 splits it again)")
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("kind,n", [("flanks-asm10", 600), ("clr-map-pb", 300), ("clr-ngmlr-pacbio", 300), ("ont-ngmlr-ont", 300), ("c4-density", 300)])
+def test_faithful_v2_bits(kind, n):
+    """every omission, on every preset the reference uses: at most 0.5 % of the non-secondary records may change existence or
+    coordinates -- except the rows listed in EXPLAINED, whose figures DESIGN.md section 2 states and explains:
+      * long join: a read that spans a spiked multi-kb insertion (3-7 % of the reads of these samples: 200 / 100 insertions
+        at 20x) is ONE record with a long I under minimap2 2.19+'s re-chaining and a primary + supplementary pair here -- the
+        representation NGMLR, the reference's default aligner, gives (it splits reads at SV breakpoints); Sniffles reads both;
+      * z-drop inside a fill on the repeat-dense sample and full-band fills under the cheap gaps of ngmlr-ont: 2-4 records
+        of a 300-read sample.  (The samples are the ones tools/faithful_table.py prints for DESIGN.md.)"""
+    EXPLAINED = {(k, nm): 0.09 for k in ("clr-map-pb", "clr-ngmlr-pacbio", "ont-ngmlr-ont", "c4-density") for nm in LONG_JOIN}
+    EXPLAINED[("c4-density", "z-drop inside a gap fill (records minimap2 would split)")] = 0.02
+    EXPLAINED[("ont-ngmlr-ont", "full-band fills + uncapped extensions")] = 0.015
+    rows = bit_table(kind, n)
+    for name, r in rows:
+        print("%-16s %-70s n=%4d  records changed %.4f  coordinates %.4f  DP score %.4f" % (kind, name, r["n"], r["core"], r["coord"], r["score"]))
+    for name, r in rows:
+        lim = EXPLAINED.get((kind, name), 0.005)
+        assert r["core"] <= lim and r["coord"] <= lim, (kind, name, r)

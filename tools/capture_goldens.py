@@ -675,8 +675,50 @@ def capture_prep_assembly():
         shutil.rmtree(tmp)
 
 
+def capture_repeatmask(T):
+    """parse_rm_out and gff3tobed of the reference on a RepeatMasker .out.gff written here (RepeatMasker's GFF2 lines:
+    seq, RepeatMasker, similarity, start, end, score, strand, ., Target "Motif:<family>" start end); `bedtools sort` answered by
+    telr_amd.intervals.bed_sort"""
+    import random
+    rnd = random.Random(4)
+    lines = ["##gff-version 2", "##date 2026-10-02", "##sequence-region ref_38kb.fasta"]
+    for k in range(40):
+        c = rnd.choice(["chr2L", "chr2R", "chrX", "chr10", "chr4"])
+        s = rnd.randint(1, 200000); e = s + rnd.randint(50, 6000)
+        lines.append("\t".join([c, "RepeatMasker", "similarity", str(s), str(e), "%.1f" % rnd.uniform(0.1, 30), rnd.choice("+-"), ".",
+                                 'Target "Motif:%s" %d %d' % (rnd.choice(["jockey", "roo", "FB4_DM", "I-element", "1360"]), rnd.randint(1, 300), rnd.randint(301, 5000))]))
+    d = tempfile.mkdtemp()
+    try:
+        gff = os.path.join(d, "x.out.gff"); gff3 = os.path.join(d, "x.out.gff3"); bed = os.path.join(d, "x.te.bed")
+        with open(gff, "w") as f:
+            f.write("\n".join(lines) + "\n")
+        T.parse_rm_out(gff, gff3)
+        fake = FakeSubprocess({}, {})
+        real_call = T.subprocess.call
+
+        def call(cmd, stdout=None, shell=False, **kw):
+            toks = cmd.split() if shell else cmd
+            assert toks[0] == "bedtools" and toks[1] == "sort"
+            rows = fake._rows(toks[toks.index("-i") + 1])
+            stdout.write("".join("\t".join(r) + "\n" for r in iv.bed_sort(rows)))
+            return 0
+        T.subprocess.call = call
+        try:
+            T.gff3tobed(gff3, bed)
+        finally:
+            T.subprocess.call = real_call
+        return {"rm_out_gff": open(gff).read(), "gff3": open(gff3).read(), "bed": open(bed).read()}
+    finally:
+        shutil.rmtree(d)
+
+
 def main():
     L, T, S, U = import_reference()
+    if "--only-repeatmask" in sys.argv:
+        with open(os.path.join(GOLD, "repeatmask.json"), "w") as f:
+            json.dump(capture_repeatmask(T), f, indent=1, sort_keys=True)
+        print("wrote repeatmask.json")
+        return
     os.makedirs(GOLD, exist_ok=True)
     import telr.TELR_output as O
     if "--only-assembly" in sys.argv:
@@ -685,7 +727,7 @@ def main():
         print("wrote prep_assembly.json")
         return
     for name, obj in (("prep_assembly.json", capture_prep_assembly()), ("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
-                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O)), ("sv.json", capture_sv(S, U))):
+                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O)), ("sv.json", capture_sv(S, U)), ("repeatmask.json", capture_repeatmask(T))):
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)
         print("wrote", name)

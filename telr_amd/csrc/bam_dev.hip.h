@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bam_hist(const uint8_t *__rest
 // one BGZF block: out slot b (DEFL_SLOT bytes), its size in csize[b]
 __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__restrict__ ubuf, uint64_t utotal, uint64_t head, const uint64_t *__restrict__ ust, int32_t nrec,
                                                               const int32_t *__restrict__ rec0, const DeflTabs *__restrict__ T, const CrcTabs *__restrict__ CT,
-                                                              uint8_t *__restrict__ slots, uint32_t *__restrict__ csize)
+                                                              uint8_t *__restrict__ slots, uint32_t *__restrict__ csize, uint32_t blk0)
 {
     __shared__ uint32_t in4[BAM_BLK / 4];
     __shared__ uint32_t out4[BAM_BLK / 4 + 8];
@@ -653,7 +653,7 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__
     __shared__ uint32_t tab[256], wsum[16], red[4];
     __shared__ int s_nseg; __shared__ uint32_t s_total;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const uint64_t b = blockIdx.x, u0 = b * BAM_BLK;
+    const uint64_t b = (uint64_t)blockIdx.x + blk0, u0 = b * BAM_BLK;
     const int n = (int)(utotal - u0 < BAM_BLK ? utotal - u0 : BAM_BLK);
     const uint32_t *src4 = (const uint32_t*)(ubuf + u0);
     for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i] = src4[i];
@@ -720,9 +720,9 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__
     }
 }
 
-__global__ void __launch_bounds__(256) k_bgzf_compact(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ csize, const uint64_t *__restrict__ coff, uint8_t *__restrict__ dst)
+__global__ void __launch_bounds__(256) k_bgzf_compact(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ csize, const uint64_t *__restrict__ coff, uint8_t *__restrict__ dst, uint32_t blk0)
 {
-    const uint64_t b = blockIdx.x;
+    const uint64_t b = (uint64_t)blockIdx.x + blk0;
     const uint32_t n = csize[b];
     const uint32_t *s4 = (const uint32_t*)(slots + b * (uint64_t)DEFL_SLOT);
     uint8_t *d = dst + coff[b];
@@ -1020,27 +1020,44 @@ extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est
     return TELR_OK;
 }
 
-// Device image [d_img, d_img + bytes) -> file, through a ring of pinned chunks: the DMA of chunk c+1 runs while the writer
-// thread puts chunk c into the file.  `tail` (host bytes) is appended.  fd >= 0: an open file whose pages may already exist
-// (it is cut to the final length), else `path` is created.  map_dst: a mapping of that (allocated) file: chunks are copied
-// into it by the host pool instead of pwrite.
-static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, const void *tail, size_t tail_bytes, const char *path, int fd_open = -1, uint8_t *map_dst = nullptr)
+// Device image -> file, through a ring of pinned chunks: the DMA of chunk c+1 runs while the writer thread puts chunk c into
+// the file.  The image may still be GROWING while it streams out (the deflate groups of telr_write_bam_dev): `prog` tells how
+// many of its leading bytes are final; a null `prog` means all `bytes` are.  `tail` (host bytes) is appended.  fd >= 0: an
+// open file whose pages may already exist (it is cut to the final length), else `path` is created.  map_dst / map_bytes: a
+// mapping of that (allocated) file: chunks inside it are copied by the host pool instead of pwrite.
+struct StreamProgress { std::mutex mu; std::condition_variable cv; uint64_t ready = 0; int state = 0; uint64_t total = 0; };    // state 0 producing, 1 done (total valid), -1 failed
+static void progress_set(StreamProgress *p, uint64_t ready, int state, uint64_t total)
+{
+    { std::lock_guard<std::mutex> lk(p->mu); if (ready > p->ready) p->ready = ready; if (state) { p->state = state; p->total = total; } }
+    p->cv.notify_all();
+}
+static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, StreamProgress *prog, const void *tail, size_t tail_bytes, const char *path,
+                          int fd_open = -1, uint8_t *map_dst = nullptr, size_t map_bytes = 0, uint64_t *total_out = nullptr)
 {
     const size_t CH = 32u << 20; const int R = 8;
     uint8_t *ring; TRY(ctx_hbuf_t(ctx, "bam_ring", CH * R, &ring));
     int fd = fd_open >= 0 ? fd_open : open(path, O_CREAT | O_RDWR | O_TRUNC, 0644);
     if (fd < 0) { ctx->err = std::string("cannot create ") + path; return TELR_E_ARG; }
-    const size_t nch = (size_t)((bytes + CH - 1) / CH);
     hipEvent_t ev[8];
     for (int i = 0; i < R; ++i) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
-    // One writer thread: a single pwrite stream is what a tmpfs file takes fastest (see above)
-    std::mutex mu; std::condition_variable cv; size_t copied = 0, written = 0; bool fail = false;
+    // size of chunk c once it is final (0: the image ended before it; -1: failed; -2: not known yet and !block)
+    auto chunk_bytes = [&](size_t c, bool block) -> int64_t {
+        if (!prog) { const uint64_t o = (uint64_t)c * CH; return o >= bytes ? 0 : (int64_t)std::min<uint64_t>(CH, bytes - o); }
+        std::unique_lock<std::mutex> lk(prog->mu);
+        auto known = [&] { return prog->state != 0 || prog->ready >= (uint64_t)(c + 1) * CH; };
+        if (!known()) { if (!block) return -2; prog->cv.wait(lk, known); }
+        if (prog->state < 0) return -1;
+        const uint64_t end = prog->state == 1 ? prog->total : prog->ready, o = (uint64_t)c * CH;
+        return o >= end ? 0 : (int64_t)std::min<uint64_t>(CH, end - o);
+    };
+    // One writer thread: a single pwrite stream is what a tmpfs file takes fastest (see above); into a mapping, eight copiers
+    std::mutex mu; std::condition_variable cv; size_t copied = 0, written = 0; bool fail = false, last = false; std::vector<size_t> csz;
     std::thread writer([&] {
-        for (size_t c = 0; c < nch; ++c) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return copied > c || fail; }); if (fail) return; }
-            const size_t n = (size_t)std::min<uint64_t>(CH, bytes - (uint64_t)c * CH);
+        for (size_t c = 0;; ++c) {
+            size_t n;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return copied > c || fail || last; }); if (fail) return; if (copied <= c) return; n = csz[c]; }
             const uint8_t *src = ring + (c % R) * CH;
-            if (map_dst) {
+            if (map_dst && (uint64_t)c * CH + n <= map_bytes) {
                 const int NT = 8; const size_t piece = (n + NT - 1) / NT;
                 uint8_t *dst = map_dst + (uint64_t)c * CH;
                 HostPool::get().run(NT, [&](int i) { const size_t o = (size_t)i * piece; if (o < n) memcpy(dst + o, src + o, std::min(piece, n - o)); });
@@ -1053,52 +1070,102 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, c
         }
     });
     int rc = TELR_OK;
-    size_t issued = 0;
-    for (size_t c = 0; c < nch && rc == TELR_OK; ++c) {
-        // keep up to R - 1 copies ahead of the writer
-        while (issued < nch && issued < c + (size_t)R - 1) {
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return issued < written + (size_t)R || fail; }); if (fail) break; }
-            const size_t n = (size_t)std::min<uint64_t>(CH, bytes - (uint64_t)issued * CH);
-            if (hipMemcpyAsync(ring + (issued % R) * CH, d_img + (uint64_t)issued * CH, n, hipMemcpyDeviceToHost, ctx->copy_stream) != hipSuccess ||
+    size_t issued = 0, landed = 0; bool ended = false; uint64_t total = 0;
+    while (rc == TELR_OK) {
+        // issue every chunk that is final and has a free ring slot (never blocks on the producer while copies are in flight)
+        bool slot_wait = false;
+        while (!ended && issued < landed + (size_t)R - 1) {
+            { std::lock_guard<std::mutex> lk(mu); if (fail) break; if (issued >= written + (size_t)R) { slot_wait = true; break; } }
+            const int64_t n = chunk_bytes(issued, issued == landed);        // nothing in flight: wait for the producer
+            if (n == -2) break;
+            if (n < 0) { rc = TELR_E_HIP; break; }
+            if (n == 0) { ended = true; break; }
+            if (hipMemcpyAsync(ring + (issued % R) * CH, d_img + (uint64_t)issued * CH, (size_t)n, hipMemcpyDeviceToHost, ctx->copy_stream) != hipSuccess ||
                 hipEventRecord(ev[issued % R], ctx->copy_stream) != hipSuccess) { rc = TELR_E_HIP; break; }
-            ++issued;
+            { std::lock_guard<std::mutex> lk(mu); csz.push_back((size_t)n); }
+            total += (uint64_t)n; ++issued;
+            if ((size_t)n < CH) ended = true;
         }
-        if (rc != TELR_OK || fail) break;
-        if (hipEventSynchronize(ev[c % R]) != hipSuccess) { rc = TELR_E_HIP; break; }
-        { std::lock_guard<std::mutex> lk(mu); copied = c + 1; }
-        cv.notify_all();
+        { std::lock_guard<std::mutex> lk(mu); if (fail) break; }
+        if (rc != TELR_OK) break;
+        if (landed < issued) {
+            if (hipEventSynchronize(ev[landed % R]) != hipSuccess) { rc = TELR_E_HIP; break; }
+            ++landed;
+            { std::lock_guard<std::mutex> lk(mu); copied = landed; }
+            cv.notify_all();
+        } else if (ended) break;
+        else if (slot_wait) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return issued < written + (size_t)R || fail; }); }
     }
-    if (rc != TELR_OK) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); }
+    { std::lock_guard<std::mutex> lk(mu); if (rc != TELR_OK) fail = true; last = true; }
+    cv.notify_all();
     writer.join();
     for (int i = 0; i < R; ++i) (void)hipEventDestroy(ev[i]);
     if (fail && rc == TELR_OK) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
-    if (rc == TELR_OK && tail_bytes) { if (map_dst) memcpy(map_dst + bytes, tail, tail_bytes); else if (pwrite(fd, tail, tail_bytes, (off_t)bytes) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
-    if (rc == TELR_OK && fd_open >= 0 && ftruncate(fd, (off_t)(bytes + tail_bytes)) != 0) rc = TELR_E_ARG;
+    if (rc == TELR_OK && tail_bytes) { if (map_dst && total + tail_bytes <= map_bytes) memcpy(map_dst + total, tail, tail_bytes); else if (pwrite(fd, tail, tail_bytes, (off_t)total) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
+    if (rc == TELR_OK && fd_open >= 0 && ftruncate(fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;
     if (fd_open < 0) close(fd);
+    if (total_out) *total_out = total;
     return rc;
 }
-// the same through a prepared sink; falls back to the ring when the estimate was too small or the mapping could not be registered
-static int sink_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, const void *tail, size_t tail_bytes, const char *path)
+// the same through a prepared sink (telr_bam_prepare); plain streaming when there is none for this path
+static int sink_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, StreamProgress *prog, const void *tail, size_t tail_bytes, const char *path)
 {
     BamSink *k = ctx->bam_sink;
     memset(g_sink_ms, 0, sizeof(g_sink_ms));
-    if (!k || k->path != path) { if (k) bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, tail, tail_bytes, path); }
+    if (!k || k->path != path) { if (k) bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path); }
     auto t0 = std::chrono::steady_clock::now();
     if (k->th.joinable()) k->th.join();
     g_sink_ms[0] = k->ms_alloc; g_sink_ms[1] = k->ms_map;
     g_sink_ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (k->fd < 0) { bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, tail, tail_bytes, path); }
-    const bool fits = k->map && bytes + tail_bytes <= k->bytes;
-    g_sink_ms[3] = fits ? 1.f : 0.f;
-    int rc = stream_to_file(ctx, d_img, bytes, tail, tail_bytes, path, k->fd, fits ? k->map : nullptr);
+    if (k->fd < 0) { bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path); }
+    uint64_t total = 0;
+    int rc = stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path, k->fd, k->map, k->map ? k->bytes : 0, &total);
+    g_sink_ms[3] = (k->map && total + tail_bytes <= k->bytes) ? 1.f : 0.f;
     bam_sink_drop(ctx);
     return rc;
 }
 extern "C" int telr_debug_bam_sink_ms(float *out) { if (!out) return TELR_E_ARG; memcpy(out, g_sink_ms, sizeof(g_sink_ms)); return TELR_OK; }
 
+// The mapping scratch of a context is grow-only (a 30x read set leaves 150-250 GB of it behind) and the writer needs about
+// 3.3 bytes of HBM per byte of uncompressed BAM: when an allocation fails, the mapping scratch of the context and of its worker
+// contexts is given back (the next telr_map call sizes it again) and the writer runs once more.
+static uint64_t g_bam_need = 0;          // device bytes the writer was about to use when an allocation failed
+static void ctx_collect_scratch(telr_ctx *ctx, std::vector<DBuf*> &v)
+{
+    for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") != 0 && kv.second.p) v.push_back(&kv.second);
+    for (int k = 0; k < 4; ++k) if (ctx->child[k]) ctx_collect_scratch(ctx->child[k], v);
+    if (ctx->slot1) ctx_collect_scratch(ctx->slot1, v);
+}
+// largest buffers first, until `need` bytes are free (the next telr_map call allocates what it misses again: ~25 ms per GB)
+static void ctx_release_map_scratch(telr_ctx *ctx, uint64_t need)
+{
+    (void)hipDeviceSynchronize();
+    std::vector<DBuf*> v; ctx_collect_scratch(ctx, v);
+    std::sort(v.begin(), v.end(), [](const DBuf *a, const DBuf *b) { return a->bytes > b->bytes; });
+    for (DBuf *d : v) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= need + (need >> 3)) break;
+        (void)hipFree(d->p); d->p = nullptr; d->bytes = 0;
+    }
+}
+static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
+                        const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
+                        const char *bam_path, int32_t write_index, int32_t level);
 extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                                   const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                                   const char *bam_path, int32_t write_index, int32_t level)
+{
+    int rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, bam_path, write_index, level);
+    if (rc == TELR_E_NOMEM) {
+        (void)hipGetLastError();
+        ctx_release_map_scratch(ctx, g_bam_need);
+        rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, bam_path, write_index, level);
+    }
+    return rc;
+}
+static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
+                        const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
+                        const char *bam_path, int32_t write_index, int32_t level)
 {
     if (!ctx || !r || !queries || !idx || !idx->targets || !qnames || !tnames || !bam_path) return TELR_E_ARG;
     if (level < 0) return TELR_E_ARG;
@@ -1107,6 +1174,7 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<float, std::milli>(now() - t0).count(); };
     const auto t_all = now();
     memset(&g_bam_times, 0, sizeof(g_bam_times));
+    g_bam_need = (uint64_t)queries->total_bases * (level == 0 ? 6 : 9) + (uint64_t)r->ncig * 4 + (256u << 20);      // refined below once the stream's size is known
     result_wait(r);
     hipStream_t st = ctx->stream;
     const telr_seqset *tg = idx->targets;
@@ -1182,6 +1250,7 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
         g_bam_times.ms[2] = ms_since(t0); t0 = now();
     }
     // ---- 5. the uncompressed stream
+    g_bam_need = level == 0 ? 2 * utotal + ((utotal / BAM_BLK + 1) * 31) : 3 * utotal + (utotal / BAM_BLK + 1) * 320;       // stream + slots + image
     uint8_t *d_u; TRY(ctx_buf_t(ctx, "bam_u", (size_t)utotal + 64, &d_u));
     HIPCHK(hipMemcpyAsync(d_u, head.data(), head.size(), hipMemcpyHostToDevice, st));
     A.ubuf = d_u;
@@ -1195,6 +1264,7 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
     uint64_t cbytes = 0;
     uint8_t *d_c = nullptr;
     std::vector<uint64_t> coff(nblk + 1);
+    StreamProgress *prog = nullptr; std::thread producer;
     if (level == 0) {
         cbytes = utotal + (uint64_t)nblk * 31;
         TRY(ctx_buf_t(ctx, "bam_c", (size_t)cbytes + 64, &d_c));
@@ -1223,28 +1293,55 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
         HIPCHK(hipStreamSynchronize(st));
         TRY(defl_tables_from_hist(h_hist.data(), T));
         HIPCHK(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nblk), dim3(DEFL_THREADS), 0, st, d_u, utotal, (uint64_t)head.size(), d_ust, (int32_t)nrec, d_rec0, d_T, d_tabs, d_slots, d_csize);
-        hipLaunchKernelGGL(k_widen_u32, dim3((unsigned)((nblk + 256) / 256)), dim3(256), 0, st, d_csize, (int32_t)nblk, d_cs64);
-        HIPCHK(hipGetLastError());
-        TRY((dev_exclusive_scan<uint64_t, uint64_t>(ctx, d_cs64, d_coff, nblk + 1)));
-        HIPCHK(hipMemcpyAsync(coff.data(), d_coff, (nblk + 1) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        cbytes = coff[nblk];
-        TRY(ctx_buf_t(ctx, "bam_c", (size_t)cbytes + 64, &d_c));
-        hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nblk), dim3(256), 0, st, d_slots, d_csize, d_coff, d_c);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
+        // The blocks are coded in groups; a group's sizes come home, the host lays the group out behind the previous one and a
+        // second stream moves it into the file image, whose finished prefix streams out to the file while the next groups are
+        // still being coded (7. below).  The image buffer is sized for the worst case (every block stored).
+        TRY(ctx_buf_t(ctx, "bam_c", (size_t)utotal + nblk * 31 + 64, &d_c));
+        uint32_t *h_csize; uint64_t *h_coff;
+        TRY(ctx_hbuf_t(ctx, "bam_hcsize", nblk + 1, &h_csize)); TRY(ctx_hbuf_t(ctx, "bam_hcoff", nblk + 1, &h_coff));
+        const size_t NG = 16, gs = std::max<size_t>(512, (nblk + NG - 1) / NG);
+        std::vector<hipEvent_t> evg;
+        for (size_t b0 = 0; b0 < nblk; b0 += gs) {
+            const size_t nb = std::min(gs, nblk - b0);
+            hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nb), dim3(DEFL_THREADS), 0, st, d_u, utotal, (uint64_t)head.size(), d_ust, (int32_t)nrec, d_rec0, d_T, d_tabs, d_slots, d_csize, (uint32_t)b0);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_csize + b0, d_csize + b0, nb * 4, hipMemcpyDeviceToHost, st));
+            hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); HIPCHK(hipEventRecord(e, st)); evg.push_back(e);
+        }
+        prog = new StreamProgress();
+        StreamProgress *pg = prog; uint64_t *coff_p = coff.data(); hipStream_t st2 = ctx->side[0]; const int device = ctx->device;
+        producer = std::thread([=]() mutable {
+            (void)hipSetDevice(device);
+            uint64_t off = 0; size_t g = 0; bool ok = true;
+            for (size_t b0 = 0; b0 < nblk && ok; b0 += gs, ++g) {
+                const size_t nb = std::min(gs, nblk - b0);
+                if (hipEventSynchronize(evg[g]) != hipSuccess) { ok = false; break; }
+                for (size_t b = b0; b < b0 + nb; ++b) { h_coff[b] = off; coff_p[b] = off; off += h_csize[b]; }
+                if (hipMemcpyAsync(d_coff + b0, h_coff + b0, nb * 8, hipMemcpyHostToDevice, st2) != hipSuccess) { ok = false; break; }
+                hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nb), dim3(256), 0, st2, d_slots, d_csize, d_coff, d_c, (uint32_t)b0);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st2) != hipSuccess) { ok = false; break; }
+                progress_set(pg, off, 0, 0);
+            }
+            coff_p[nblk] = off;
+            progress_set(pg, off, ok ? 1 : -1, off);
+        });
+        (void)d_cs64;
     }
     g_bam_times.ms[4] = ms_since(t0); t0 = now();
-    // ---- 7. the index is built by a host thread while the file image streams out
+    // ---- 7. the file image streams out (behind the groups still being coded); the index is built by a host thread meanwhile
     std::string bai; std::thread bai_th;
     float bai_ms = 0;
-    if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), coff.data(), nblk, nt, tg->len.data(), bai); bai_ms = ms_since(tb0); });
+    auto start_bai = [&] { if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), coff.data(), nblk, nt, tg->len.data(), bai); bai_ms = ms_since(tb0); }); };
+    std::thread bai_starter;
+    if (!prog) start_bai();
+    else bai_starter = std::thread([&] { if (producer.joinable()) producer.join(); start_bai(); });        // the block offsets are complete when the producer is
     static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    int rc = sink_to_file(ctx, d_c, cbytes, eof_blk, 28, bam_path);
+    int rc = sink_to_file(ctx, d_c, cbytes, prog, eof_blk, 28, bam_path);
     g_bam_times.ms[5] = ms_since(t0);
+    if (bai_starter.joinable()) bai_starter.join();
     if (bai_th.joinable()) bai_th.join();
     g_bam_times.ms[6] = bai_ms;
+    if (prog) { if (prog->state < 0 && rc == TELR_OK) rc = TELR_E_HIP; delete prog; }
     if (rc == TELR_OK && write_index) {
         const std::string bai_path = std::string(bam_path) + ".bai";
         FILE *f = fopen(bai_path.c_str(), "wb");

@@ -93,6 +93,11 @@ typedef struct telr_map_opt {
     int32_t vote_bin_shift;
     int32_t vote_min;
     int32_t vote_frac_q8;
+    /* long join (minimap2 -r500,20000: the second number): anchors are chained within max(bw, bw_long) diagonals, so that a
+     * read across a multi-kb insertion or deletion is ONE chain; `bw` still bounds the gap fills.  A fill whose two lengths
+     * differ by more than `bw` is aligned as two banded halves joined by one long gap at its best position.
+     * 0 = off (asm10, ngmlr-*: NGMLR splits reads at SV breakpoints). */
+    int32_t bw_long;
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */

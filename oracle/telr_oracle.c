@@ -468,7 +468,7 @@ static inline int32_t chain_sc(uint64_t ai, uint64_t aj, const telr_map_opt *mo)
     if (dq <= 0 || dq > mo->max_gap) return INT32_MIN;
     if (dr <= 0 || dr > mo->max_gap) return INT32_MIN;
     int32_t dd = dr > dq ? dr - dq : dq - dr;
-    if (dd > mo->bw) return INT32_MIN;
+    if (dd > (mo->bw_long > mo->bw ? mo->bw_long : mo->bw)) return INT32_MIN;      /* long join: chained within max(bw, bw_long) diagonals */
     int32_t dg = dr < dq ? dr : dq;
     int32_t span = A_SPAN(ai);
     int32_t sc = span < dg ? span : dg;
@@ -747,6 +747,138 @@ static dp_res_t band_dp_fallback(const dp_seq_t *s, const telr_map_opt *mo, u32v
  * distance); if the optimal path of that pass touches a band edge, the segment is re-aligned once with the wide band
  * (24 + mn/8, flatter above 512), itself limited so that the band stays within 1024 diagonals where the first-pass
  * width allows it.  Segments with m+n > ADAPT_MAX_STEPS use the wide band at once. */
+static inline int even_lo(int lo) { return lo - (lo & 1); }
+/* Long-gap fill (spec 3.11): a segment whose two lengths differ by more than bw (a link only the long join admits).  The
+ * optimal path runs near the main diagonal from the start, jumps by ONE long gap, and runs near the main diagonal of the end:
+ * LEFT = global banded DP from the start in the band |j - i| <= W over the first min(len, S + W) rows / columns (S = the
+ * shorter length, W = ext_band), RIGHT = the same from the end on the reversed sequences; for an insertion-type segment
+ * (m > n) the junction is the target column jL (and jR = n - jL) that maximises
+ *     max_iL [HL(iL, jL) + e2 iL]  +  max_iR [HR(iR, jR) + e2 iR]        (smallest jL, then smallest iL / iR on ties)
+ * i.e. the best total with a gap of m - iL - iR query bases charged on the second affine piece (the gap is longer than
+ * bw - 2W, far beyond where the pieces cross); deletion-type segments swap the roles.  Cells, tie-breaks and trace-back
+ * bytes are those of band_dp. */
+typedef struct { int32_t *H; uint8_t *tb; int m, n, dlo, dhi, D, stride; int64_t cells; } band_all_t;
+static void band_dp_all(const dp_seq_t *s, int W, const telr_map_opt *mo, band_all_t *B)
+{
+    const int m = s->m, n = s->n, dlo = even_lo(-W), dhi = W, D = dhi - dlo + 1, stride = (D + 2) / 2;
+    const int q1 = mo->q, e1 = mo->e, q2 = mo->q2, e2 = mo->e2;
+    int32_t *H = (int32_t*)malloc(4 * (size_t)(D + 2) * 5), *E1 = H + (D + 2), *F1 = E1 + (D + 2), *E2 = F1 + (D + 2), *F2 = E2 + (D + 2);
+    for (int x = 0; x < (D + 2) * 5; ++x) H[x] = NEG;
+    B->m = m; B->n = n; B->dlo = dlo; B->dhi = dhi; B->D = D; B->stride = stride; B->cells = 0;
+    B->H = (int32_t*)malloc(4 * (size_t)(m + n + 1) * D);
+    B->tb = (uint8_t*)calloc((size_t)(m + n + 1) * stride, 1);
+    for (size_t x = 0; x < (size_t)(m + n + 1) * D; ++x) B->H[x] = NEG;
+#define IX(d) ((d) - dlo + 1)
+    H[IX(0)] = 0; B->H[0 * D + (0 - dlo)] = 0;
+    for (int a = 1; a <= m + n; ++a) {
+        int d0 = -a > dlo ? -a : dlo; if (a - 2 * m > d0) d0 = a - 2 * m;
+        int d1 = a < dhi ? a : dhi;   if (2 * n - a < d1) d1 = 2 * n - a;
+        if (((d0 - a) & 1) != 0) ++d0;
+        for (int d = d0; d <= d1; d += 2) {
+            int i = (a - d) >> 1, j = (a + d) >> 1, x = IX(d);
+            int32_t h, ve1, vf1, ve2, vf2; uint8_t t = 0;
+            if (i == 0) { ve1 = -(q1 + j * e1); ve2 = -(q2 + j * e2); vf1 = vf2 = NEG; h = ve1 > ve2 ? ve1 : ve2; }
+            else if (j == 0) { vf1 = -(q1 + i * e1); vf2 = -(q2 + i * e2); ve1 = ve2 = NEG; h = vf1 > vf2 ? vf1 : vf2; }
+            else {
+                int32_t hl = H[x - 1], hu = H[x + 1], hd = H[x], o, g;
+                o = hl - q1 - e1; g = E1[x - 1] - e1; if (g > o) ve1 = g, t |= 8;  else ve1 = o;
+                o = hu - q1 - e1; g = F1[x + 1] - e1; if (g > o) vf1 = g, t |= 16; else vf1 = o;
+                o = hl - q2 - e2; g = E2[x - 1] - e2; if (g > o) ve2 = g, t |= 32; else ve2 = o;
+                o = hu - q2 - e2; g = F2[x + 1] - e2; if (g > o) vf2 = g, t |= 64; else vf2 = o;
+                int qb = qbase(s, i - 1), tbv = tbase(s, j - 1);
+                int sc = (qb > 3 || tbv > 3) ? -mo->sc_ambi : (qb == tbv ? mo->a : -mo->b);
+                h = hd + sc; int src = 0;
+                if (ve1 > h) h = ve1, src = 1;
+                if (vf1 > h) h = vf1, src = 2;
+                if (ve2 > h) h = ve2, src = 3;
+                if (vf2 > h) h = vf2, src = 4;
+                t |= (uint8_t)src;
+                B->tb[(size_t)a * stride + ((d - dlo) >> 1)] = t;
+                ++B->cells;
+            }
+            if (h < NEG) h = NEG;
+            if (ve1 < NEG) ve1 = NEG;
+            if (vf1 < NEG) vf1 = NEG;
+            if (ve2 < NEG) ve2 = NEG;
+            if (vf2 < NEG) vf2 = NEG;
+            H[x] = h; E1[x] = ve1; F1[x] = vf1; E2[x] = ve2; F2[x] = vf2;
+            B->H[(size_t)a * D + (d - dlo)] = h;
+        }
+    }
+#undef IX
+    free(H);
+}
+/* walk from cell (i, j) of a band_dp_all matrix to (0, 0): ops in end -> start order, one per column */
+static void band_all_walk(const band_all_t *B, int i, int j, u32v_t *out)
+{
+    int state = 0;
+    while (i > 0 && j > 0) {
+        uint8_t t = B->tb[(size_t)(i + j) * B->stride + ((j - i - B->dlo) >> 1)];
+        if (state == 0) state = t & 7;
+        if (state == 0) { vpush(uint32_t, *out, 0); --i; --j; }
+        else if (state == 1) { vpush(uint32_t, *out, 2); if (!(t & 8))  state = 0; --j; }
+        else if (state == 2) { vpush(uint32_t, *out, 1); if (!(t & 16)) state = 0; --i; }
+        else if (state == 3) { vpush(uint32_t, *out, 2); if (!(t & 32)) state = 0; --j; }
+        else                 { vpush(uint32_t, *out, 1); if (!(t & 64)) state = 0; --i; }
+    }
+    for (; i > 0; --i) vpush(uint32_t, *out, 1);
+    for (; j > 0; --j) vpush(uint32_t, *out, 2);
+}
+static dp_res_t longgap_fill(const dp_seq_t *s, const telr_map_opt *mo, u32v_t *rev_cig)
+{
+    const int m = s->m, n = s->n, ins = m > n, S = ins ? n : m, W = mo->ext_band;
+    const int lm = m < S + W ? m : S + W, ln = n < S + W ? n : S + W;
+    dp_seq_t sl = *s, sr = *s;
+    sl.m = lm; sl.n = ln;
+    sr.m = lm; sr.n = ln; sr.qstep = -s->qstep; sr.tstep = -s->tstep;
+    sr.qi0 = s->qi0 + (int64_t)s->qstep * (m - 1); sr.ti0 = s->ti0 + (int64_t)s->tstep * (n - 1);
+    band_all_t L, R;
+    band_dp_all(&sl, W, mo, &L); band_dp_all(&sr, W, mo, &R);
+    const int e2 = mo->e2;
+    /* best junction */
+    int64_t best = INT64_MIN; int bjl = 0, bil = 0, bir = 0;
+    for (int c = 0; c <= S; ++c) {                 /* c: short-axis coordinate consumed by LEFT (target column for ins, query row for del) */
+        int64_t vl = INT64_MIN, vr = INT64_MIN; int al = 0, ar = 0;
+        for (int k = c - W; k <= c + W; ++k) {     /* long-axis coordinate inside the band */
+            if (k < 0 || k > (ins ? lm : ln)) continue;
+            int i = ins ? k : c, j = ins ? c : k, d = j - i;
+            if (d < L.dlo || d > L.dhi) continue;
+            int32_t h = L.H[(size_t)(i + j) * L.D + (d - L.dlo)];
+            if (h <= NEG / 2) continue;
+            int64_t v = (int64_t)h + (int64_t)e2 * k;
+            if (v > vl) vl = v, al = k;
+        }
+        const int c2 = S - c;
+        for (int k = c2 - W; k <= c2 + W; ++k) {
+            if (k < 0 || k > (ins ? lm : ln)) continue;
+            int i = ins ? k : c2, j = ins ? c2 : k, d = j - i;
+            if (d < R.dlo || d > R.dhi) continue;
+            int32_t h = R.H[(size_t)(i + j) * R.D + (d - R.dlo)];
+            if (h <= NEG / 2) continue;
+            int64_t v = (int64_t)h + (int64_t)e2 * k;
+            if (v > vr) vr = v, ar = k;
+        }
+        if (vl == INT64_MIN || vr == INT64_MIN) continue;
+        if ((ins ? m : n) - al - ar < 1) continue;
+        if (vl + vr > best) best = vl + vr, bjl = c, bil = al, bir = ar;
+    }
+    dp_res_t r = { 0, m, n, 0, 0 };
+    r.cells = (int32_t)(L.cells + R.cells);
+    /* (S = 0 cannot fail: c = 0 with the corner cells always exists) */
+    const int g = (ins ? m : n) - bil - bir;
+    const int li = ins ? bil : bjl, lj = ins ? bjl : bil, ri = ins ? bir : S - bjl, rj = ins ? S - bjl : bir;
+    const int c1 = mo->q + g * mo->e, c2g = mo->q2 + g * mo->e2;
+    r.score = L.H[(size_t)(li + lj) * L.D + (lj - li - L.dlo)] + R.H[(size_t)(ri + rj) * R.D + (rj - ri - R.dlo)] - (c1 < c2g ? c1 : c2g);
+    /* ops: rev_cig holds end -> start.  RIGHT's walk runs junction -> end in the original orientation, so it is pushed reversed */
+    u32v_t wl = {0, 0, 0}, wr = {0, 0, 0};
+    band_all_walk(&L, li, lj, &wl); band_all_walk(&R, ri, rj, &wr);
+    for (int64_t z = wr.n - 1; z >= 0; --z) cig_push(rev_cig, (int)wr.a[z], 1);
+    cig_push(rev_cig, ins ? 1 : 2, g);
+    for (int64_t z = 0; z < wl.n; ++z) cig_push(rev_cig, (int)wl.a[z], 1);
+    free(wl.a); free(wr.a); free(L.H); free(L.tb); free(R.H); free(R.tb);
+    return r;
+}
+
 static inline int isqrt32(int v)
 {
     int r = 0;
@@ -770,7 +902,6 @@ static inline int fill_band_wide(int m, int n, const telr_map_opt *mo)
     return W < cap ? W : cap;
 }
 /* the lower band edge is rounded down to an even diagonal (the GPU pairs diagonals per lane) */
-static inline int even_lo(int lo) { return lo - (lo & 1); }
 
 /* debug entry: one global banded alignment of two ASCII strings */
 int32_t tor_nw(const char *q, int m, const char *t, int n, const telr_map_opt *mo, uint32_t *cig, int32_t *n_cig, int32_t cap)
@@ -856,9 +987,10 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         rc.n = 0;
         int lo = even_lo((dl < 0 ? dl : 0) - W), hi = (dl > 0 ? dl : 0) + W, fb_mlen;
         if (faithful) { if (lo < -s.m) lo = even_lo(-s.m); if (hi > s.n) hi = s.n; }      /* no wider than the matrix */
-        dp_res_t r = (!faithful && hi - lo + 1 > DP_DMAX) ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
+        const int longgap = mo->bw_long > mo->bw && (dl > mo->bw || -dl > mo->bw);
+        dp_res_t r = longgap ? longgap_fill(&s, mo, &rc) : (!faithful && hi - lo + 1 > DP_DMAX) ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
-        if (r.touched && !is_long && !faithful) {            /* second pass with the wide band */
+        if (r.touched && !is_long && !faithful && !longgap) {            /* second pass with the wide band */
             int W2 = fill_band_wide(s.m, s.n, mo);
             lo = even_lo((dl < 0 ? dl : 0) - W2); hi = (dl > 0 ? dl : 0) + W2;
             if (W2 > W && hi - lo + 1 <= DP_DMAX) { rc.n = 0; r = band_dp(&s, lo, hi, 0, mo, &rc); ctr->dp_cells += r.cells; }
@@ -980,12 +1112,13 @@ tor_result *tor_map(const tor_index *ix, int32_t nq, const char *ascii, const in
         R->ctr.anchors += an.n;
         int32_t *f = (int32_t*)malloc(4 * (an.n ? an.n : 1)), *p = (int32_t*)malloc(4 * (an.n ? an.n : 1));
         telr_map_opt mc = *mo;
+        if (mo->flags & MFX_LONGJOIN) mc.bw_long = 0;                           /* first round of the experiment: the short bandwidth only */
         if ((mo->flags & MFX_RMQ) && mo->bw >= 10000) mc.bw = 100000;          /* asm10 of minimap2 2.22: --rmq -r100k -g10k */
         chain_dp(an.a, an.n, &mc, f, p);
         chainv_t ch = {0, 0, 0}; u64v_t ca = {0, 0, 0};
         chain_backtrack(ix, an.a, an.n, f, p, &mc, &ch, &ca);
-        if ((mo->flags & MFX_LONGJOIN) && ch.n > 1 && mc.bw < 20000) {          /* re-chain with bw_long */
-            mc.bw = 20000; mc.flags |= MFX_LOOKBACK;
+        if ((mo->flags & MFX_LONGJOIN) && ch.n > 1 && mc.bw < 20000) {          /* minimap2's two rounds: re-chain with bw_long only when the first round left several chains */
+            mc.bw_long = 20000; if (!(mo->flags & 0x40000)) mc.flags |= MFX_LOOKBACK;      /* 0x40000: keep the preset's look-back in the second round */
             ch.n = 0; ca.n = 0;
             chain_dp(an.a, an.n, &mc, f, p);
             chain_backtrack(ix, an.a, an.n, f, p, &mc, &ch, &ca);

@@ -15,7 +15,7 @@ class MapOpt(C.Structure):
         ("a", C.c_int32), ("b", C.c_int32), ("q", C.c_int32), ("e", C.c_int32), ("q2", C.c_int32), ("e2", C.c_int32),
         ("sc_ambi", C.c_int32), ("zdrop", C.c_int32), ("min_dp_max", C.c_int32), ("min_ksw_len", C.c_int32),
         ("ext_max", C.c_int32), ("ext_band", C.c_int32), ("flags", C.c_int32), ("fill_band_q4", C.c_int32), ("fill_margin", C.c_int32),
-        ("vote_len", C.c_int32), ("vote_bin_shift", C.c_int32), ("vote_min", C.c_int32), ("vote_frac_q8", C.c_int32),
+        ("vote_len", C.c_int32), ("vote_bin_shift", C.c_int32), ("vote_min", C.c_int32), ("vote_frac_q8", C.c_int32), ("bw_long", C.c_int32),
     ]
 
     def copy(self):

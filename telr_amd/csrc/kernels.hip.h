@@ -1596,7 +1596,7 @@ __device__ __forceinline__ int d_even_lo(int lo) { return lo - (lo & 1); }
 // the descriptors of the window's cuts built and written by as many lanes in parallel.
 template <int PASS>
 __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__ kc, int32_t nk, const uint64_t *__restrict__ canch,
-                                                   int32_t min_ksw_len, int32_t bw, int32_t band_q4, int32_t ext_max, int32_t ext_band,
+                                                   int32_t min_ksw_len, int32_t bw, int32_t band_q4, int32_t ext_max, int32_t ext_band, int32_t bw_long,
                                                    int32_t *__restrict__ nprob, const int32_t *__restrict__ prob_off, DpProb *__restrict__ probs)
 {
     __shared__ int32_t cut_r[64], cut_q[64], prev_r[64], prev_q[64];
@@ -1642,7 +1642,8 @@ __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__
                 DpProb P; P.m = cut_q[lane] - pq; P.n = cut_r[lane] - pr; P.chain = c; P.kind = 0;
                 const int W = P.m + P.n > ADAPT_MAX_STEPS ? d_fill_band_wide(P.m, P.n, bw, band_q4) : d_fill_band(P.m, P.n, bw, band_q4), dl = P.n - P.m;
                 P.dlo = d_even_lo((dl < 0 ? dl : 0) - W); P.dhi = (dl > 0 ? dl : 0) + W;
-                if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
+                if (bw_long > bw && (dl > bw || -dl > bw)) { P.kind = 5; P.dlo = d_even_lo(-ext_band); P.dhi = ext_band; }      // long-gap fill: two bands of the extension width (spec 3.11)
+                else if (P.dhi - P.dlo + 1 > DP_DMAX) P.kind = 3;
                 P.tstep = 1; P.ti0 = K.tbase + pr; P.qcomp = (int8_t)K.rev;
                 if (K.rev) { P.qstep = -1; P.qi0 = K.qbase + K.qlen - 1 - pq; } else { P.qstep = 1; P.qi0 = K.qbase + pq; }
                 P.tb_off = P.cig_off = 0; P.pad[0] = P.pad[1] = 0;
@@ -1752,7 +1753,11 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
     }
     if (d_tb4(cls, tb4) && P.m + P.n > tb4_steps) cls = 14;        // the nibble cell keeps scores times four: longer fills take the two-lane class
     int64_t tb;
-    if (P.kind >= 3) tb = 0;
+    if (P.kind == 5) {       // both halves: H of every band cell (int32) + its trace-back byte, anti-diagonal major
+        const int S = P.m < P.n ? P.m : P.n, lm = P.m < S + P.dhi ? P.m : S + P.dhi, ln = P.n < S + P.dhi ? P.n : S + P.dhi;
+        tb = (2 * (int64_t)(lm + ln + 1) * (D * 4 + stride) + 127) & ~127LL;
+    }
+    else if (P.kind >= 3) tb = 0;
     else if (d_tb4(cls, tb4)) tb = ((int64_t)(((P.m + P.n) / 2 + 2) / 2) * (2 * d_tb4_rowb(cls)) + 63) & ~63LL;     // row pairs of nibbles
     else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 63) & ~63LL;     // whole 64-byte lines (d_traceback_rows)
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
@@ -1764,7 +1769,8 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
     }
     probs[i].pad[0] = cls | (fill_margin << 8); probs[i].pad[1] = cells;      // class, and the margin of the retry test for the trace-back
     tb_bytes[i] = tb;
-    cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
+    if (P.kind == 5) { const int S = P.m < P.n ? P.m : P.n; cig_ops[i] = 3 * (int64_t)(2 * (S + P.dhi) + 2); }      // final ops + room for the right half's walk
+    else cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
 // scratch offsets of every problem, class histogram, and the (key, problem) pairs whose ONE radix sort yields all class
 // lists at once: key = class << 20 | (0xFFFFF - steps), so a class is a contiguous range ordered by decreasing steps
@@ -1895,6 +1901,138 @@ __device__ __forceinline__ uint32_t d_cell(const DpOpt &o, int32_t hd, int32_t h
     return t | src;
 }
 
+// ---- long-gap fill (spec 3.11; oracle longgap_fill): a segment whose lengths differ by more than bw.  One wave.
+// LEFT = global banded DP from the start in |j - i| <= W over the first min(len, S + W) rows / columns, RIGHT = the same from the
+// end on the reversed sequences; H of every band cell and its trace-back byte go to the problem's scratch; the junction is the
+// short-axis coordinate that maximises  max_k [HL + e2 k] + max_k [HR + e2 k]  (smallest coordinate, then smallest k on ties);
+// lane 0 walks both halves and writes the run-merged ops end -> start: RIGHT reversed, the gap, LEFT.
+__device__ __forceinline__ void d_longgap_half(const DpArgs &A, const DpProb &P, int side, int lm, int ln, int m, int n, int lane, int32_t *lds,
+                                               int32_t *Hg, uint8_t *tbg, int &ncell)
+{
+    const DpOpt o = A.o;
+    const int dlo = P.dlo, dhi = P.dhi, D = dhi - dlo + 1, stride = (D + 2) / 2;
+    const int qstep = side ? -P.qstep : P.qstep, tstep = side ? -P.tstep : P.tstep;
+    const int64_t qi0 = side ? P.qi0 + (int64_t)P.qstep * (m - 1) : P.qi0, ti0 = side ? P.ti0 + (int64_t)P.tstep * (n - 1) : P.ti0;
+    int32_t *H = lds, *E1 = H + (A.dcap + 2), *F1 = E1 + (A.dcap + 2), *E2 = F1 + (A.dcap + 2), *F2 = E2 + (A.dcap + 2);
+    __syncthreads();
+    for (int x = lane; x < D + 2; x += 64) { H[x] = TELR_NEG; E1[x] = TELR_NEG; F1[x] = TELR_NEG; E2[x] = TELR_NEG; F2[x] = TELR_NEG; }
+    __syncthreads();
+    if (lane == 0) { H[0 - dlo + 1] = 0; Hg[0 - dlo] = 0; }
+    __syncthreads();
+    for (int a = 1; a <= lm + ln; ++a) {
+        int d0 = -a > dlo ? -a : dlo; if (a - 2 * lm > d0) d0 = a - 2 * lm;
+        int d1 = a < dhi ? a : dhi;   if (2 * ln - a < d1) d1 = 2 * ln - a;
+        if (((d0 - a) & 1) != 0) ++d0;
+        for (int d = d0 + 2 * lane; d <= d1; d += 128) {
+            const int i = (a - d) >> 1, j = (a + d) >> 1, x = d - dlo + 1;
+            int32_t h, ve1, vf1, ve2, vf2;
+            if (i == 0) { ve1 = -(o.q + j * o.e); ve2 = -(o.q2 + j * o.e2); vf1 = vf2 = TELR_NEG; h = ve1 > ve2 ? ve1 : ve2; }
+            else if (j == 0) { vf1 = -(o.q + i * o.e); vf2 = -(o.q2 + i * o.e2); ve1 = ve2 = TELR_NEG; h = vf1 > vf2 ? vf1 : vf2; }
+            else {
+                int qb = d_base(A.qseq2, A.qnmask, qi0 + (int64_t)qstep * (i - 1));
+                int tbv = d_base(A.tseq2, A.tnmask, ti0 + (int64_t)tstep * (j - 1));
+                if (P.qcomp && qb < 4) qb = 3 - qb;
+                const uint32_t t = d_cell(o, H[x], H[x - 1], E1[x - 1], E2[x - 1], H[x + 1], F1[x + 1], F2[x + 1], qb, tbv, h, ve1, vf1, ve2, vf2);
+                tbg[(int64_t)a * stride + ((d - dlo) >> 1)] = (uint8_t)t;
+                ++ncell;
+            }
+            if (h < TELR_NEG) h = TELR_NEG;
+            if (ve1 < TELR_NEG) ve1 = TELR_NEG;
+            if (vf1 < TELR_NEG) vf1 = TELR_NEG;
+            if (ve2 < TELR_NEG) ve2 = TELR_NEG;
+            if (vf2 < TELR_NEG) vf2 = TELR_NEG;
+            H[x] = h; E1[x] = ve1; F1[x] = vf1; E2[x] = ve2; F2[x] = vf2;
+            Hg[(int64_t)a * D + (d - dlo)] = h;
+        }
+        __syncthreads();
+    }
+}
+// walk from (i, j) to (0, 0) through a half's trace-back bytes: run-merged ops (end -> start) appended at out[no...]; counts M columns and equal bases
+__device__ __forceinline__ int d_longgap_walk(const uint8_t *tbg, int dlo, int stride, int i, int j, uint32_t *out, int no, int &mcols, int &mlen)
+{
+    int state = 0;
+    auto push = [&](uint32_t op) { if (no > 0 && (out[no - 1] & 0xfu) == op) out[no - 1] += 16u; else out[no++] = 16u | op; };
+    while (i > 0 && j > 0) {
+        const uint32_t t = tbg[(int64_t)(i + j) * stride + ((j - i - dlo) >> 1)];
+        if (state == 0) state = (int)(t & 7u);
+        if (state == 0) { push(0u); ++mcols; mlen += (int)(t >> 7 & 1u); --i; --j; }
+        else if (state == 1) { push(2u); if (!(t & 8u))  state = 0; --j; }
+        else if (state == 2) { push(1u); if (!(t & 16u)) state = 0; --i; }
+        else if (state == 3) { push(2u); if (!(t & 32u)) state = 0; --j; }
+        else                 { push(1u); if (!(t & 64u)) state = 0; --i; }
+    }
+    if (i > 0) { if (no > 0 && (out[no - 1] & 0xfu) == 1u) out[no - 1] += (uint32_t)i << 4; else out[no++] = (uint32_t)i << 4 | 1u; }
+    if (j > 0) { if (no > 0 && (out[no - 1] & 0xfu) == 2u) out[no - 1] += (uint32_t)j << 4; else out[no++] = (uint32_t)j << 4 | 2u; }
+    return no;
+}
+__device__ void d_longgap(const DpArgs &A, const DpProb &P, int prob, int lane, int32_t *lds)
+{
+    const DpOpt o = A.o;
+    const int m = P.m, n = P.n, ins = m > n, S = ins ? n : m, W = P.dhi, dlo = P.dlo, D = P.dhi - dlo + 1, stride = (D + 2) / 2;
+    const int lm = m < S + W ? m : S + W, ln = n < S + W ? n : S + W, na = lm + ln + 1;
+    uint8_t *base = A.tb + P.tb_off;
+    int32_t *HL = (int32_t*)base, *HR = HL + (int64_t)na * D;
+    uint8_t *tbL = (uint8_t*)(HR + (int64_t)na * D), *tbR = tbL + (int64_t)na * stride;
+    int ncell = 0;
+    d_longgap_half(A, P, 0, lm, ln, m, n, lane, lds, HL, tbL, ncell);
+    d_longgap_half(A, P, 1, lm, ln, m, n, lane, lds, HR, tbR, ncell);
+    __threadfence_block();
+    __syncthreads();
+    // ---- the junction
+    const int lim = ins ? lm : ln;
+    int64_t bestk = INT64_MIN; int b_al = 0, b_ar = 0;
+    for (int c = lane; c <= S; c += 64) {
+        int64_t vl = INT64_MIN, vr = INT64_MIN; int al = 0, ar = 0;
+        for (int k = c - W; k <= c + W; ++k) {
+            if (k < 0 || k > lim) continue;
+            const int i = ins ? k : c, j = ins ? c : k, d = j - i;
+            if (d < dlo || d > P.dhi) continue;
+            const int32_t h = HL[(int64_t)(i + j) * D + (d - dlo)];
+            if (h <= TELR_NEG / 2) continue;
+            const int64_t v = (int64_t)h + (int64_t)o.e2 * k;
+            if (v > vl) { vl = v; al = k; }
+        }
+        const int c2 = S - c;
+        for (int k = c2 - W; k <= c2 + W; ++k) {
+            if (k < 0 || k > lim) continue;
+            const int i = ins ? k : c2, j = ins ? c2 : k, d = j - i;
+            if (d < dlo || d > P.dhi) continue;
+            const int32_t h = HR[(int64_t)(i + j) * D + (d - dlo)];
+            if (h <= TELR_NEG / 2) continue;
+            const int64_t v = (int64_t)h + (int64_t)o.e2 * k;
+            if (v > vr) { vr = v; ar = k; }
+        }
+        if (vl == INT64_MIN || vr == INT64_MIN) continue;
+        if ((ins ? m : n) - al - ar < 1) continue;
+        const int64_t key = (vl + vr) * 65536LL + (int64_t)(0xffff - c);          // largest total, smallest c (lanes visit their c ascending; S < 65536)
+        if (key > bestk) { bestk = key; b_al = al; b_ar = ar; }
+    }
+    const int64_t wk = d_wave_max64(bestk);
+    const uint64_t who = __ballot(bestk == wk);
+    const int src = __ffsll((unsigned long long)who) - 1;
+    const int bc = 0xffff - (int)(wk & 0xffff), al = __shfl(b_al, src), ar = __shfl(b_ar, src);
+    int nc = ncell;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) nc += __shfl_xor(nc, s);
+    if (lane == 0) {
+        const int g = (ins ? m : n) - al - ar;
+        const int li = ins ? al : bc, lj = ins ? bc : al, ri = ins ? ar : S - bc, rj = ins ? S - bc : ar;
+        const int c1 = o.q + g * o.e, c2g = o.q2 + g * o.e2;
+        DpRes R; R.bi = m; R.bj = n; R.tbases = n; R.cells = nc;
+        R.score = HL[(int64_t)(li + lj) * D + (lj - li - dlo)] + HR[(int64_t)(ri + rj) * D + (rj - ri - dlo)] - (c1 < c2g ? c1 : c2g);
+        uint32_t *out = A.cig + P.cig_off, *tmp = out + 2 * (2 * (S + W) + 2);
+        int mcols = 0, mlen = 0;
+        // RIGHT's walk runs junction -> end in the original orientation: taken into tmp, then emitted backwards
+        const int nr = d_longgap_walk(tbR, dlo, stride, ri, rj, tmp, 0, mcols, mlen);
+        int no = 0;
+        for (int z = nr - 1; z >= 0; --z) { if (no > 0 && (out[no - 1] & 0xfu) == (tmp[z] & 0xfu)) out[no - 1] += tmp[z] & ~0xfu; else out[no++] = tmp[z]; }
+        { const uint32_t gop = ins ? 1u : 2u; if (no > 0 && (out[no - 1] & 0xfu) == gop) out[no - 1] += (uint32_t)g << 4; else out[no++] = (uint32_t)g << 4 | gop; }
+        no = d_longgap_walk(tbL, dlo, stride, li, lj, out, no, mcols, mlen);
+        R.nops = no; R.mlen = mlen; R.mcols = mcols;
+        A.res[prob] = R;
+    }
+}
+
 // ---- LDS-state forward kernel: any band width up to DP_DMAX, fills and z-drop extensions.
 // One wave per problem; DP state per diagonal in LDS, updated in place (cells of one
 // anti-diagonal touch only the other parity's diagonals).  Trace-back bytes go to
@@ -1915,6 +2053,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.cells = 0; R.tbases = n; R.mcols = 0;
     int ncell = 0;
 
+    if (P.kind == 5) { d_longgap(A, P, prob, lane, lds); return; }
     if (P.kind == 3) {
         // band wider than the engine accepts: diagonal + one closing gap (oracle band_dp_fallback)
         int mn = m < n ? m : n, sc = 0, ml = 0;

@@ -237,8 +237,8 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
     mo->mask_level = 0.5f; mo->pri_ratio = 0.8f; mo->best_n = 5; mo->secondary = 1;
     mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
     mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6; mo->fill_margin = 1;
-    if (s == "map-ont") { mo->fill_band_q4 = 4; }
-    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 12; }
+    if (s == "map-ont") { mo->fill_band_q4 = 4; mo->bw_long = 20000; }                 // -r500,20000: long join
+    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 12; mo->bw_long = 20000; }
     else if (s == "ngmlr-ont" || s == "ngmlr-pacbio") {
         // `ngmlr -x ont|pacbio` (TELR_alignment.py:28-51, the reference's default aligner).  NGMLR 0.2.7 indexes 13-mers at
         // every third reference position: (w,k) = (5,13) minimizers have that density.  Its convex gap cost (open, then an
@@ -1461,7 +1461,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     int32_t *d_f, *d_p;
     TRY(ctx_buf_t(ctx, "chain_f", (size_t)na, &d_f));
     TRY(ctx_buf_t(ctx, "chain_p", (size_t)na, &d_p));
-    ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
+    // long join: anchors are chained within max(bw, bw_long) diagonals
+    ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw_long > mo->bw ? mo->bw_long : mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
     co.chain_gap_q8 = mo->chain_gap_q8; co.chain_skip_q8 = mo->chain_skip_q8;
     const int Rr = mo->chain_lookback / 64;
 #define CHAIN_LAUNCH(RR, SK) hipLaunchKernelGGL((k_chain<RR, SK>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder)
@@ -1739,7 +1740,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         int32_t *d_nprob, *d_poff;             // (the kept-chain descriptors d_kc are on the device already)
         TRY(ctx_buf_t(ctx, "nprob", (size_t)nk + 1, &d_nprob));
         TRY(ctx_buf_t(ctx, "prob_off", (size_t)nk + 1, &d_poff));
-        hipLaunchKernelGGL(k_segments_w<0>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
+        hipLaunchKernelGGL(k_segments_w<0>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, mo->bw_long, d_nprob, (const int32_t*)nullptr, (DpProb*)nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(d_nprob + nk, 0, 4, st));
         TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_nprob, d_poff, (size_t)nk + 1)));
@@ -1749,7 +1750,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         np = h_poff[nk];
         DpProb *d_probs;
         TRY(ctx_buf_t(ctx, "probs", (size_t)np, &d_probs));
-        hipLaunchKernelGGL(k_segments_w<1>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, d_nprob, d_poff, d_probs);
+        hipLaunchKernelGGL(k_segments_w<1>, dim3(nk), dim3(64), 0, st, d_kc, nk, d_canch, mo->min_ksw_len, mo->bw, mo->fill_band_q4, mo->ext_max, mo->ext_band, mo->bw_long, d_nprob, d_poff, d_probs);
         HIPCHK(hipGetLastError());
         t_sg.stop(); ht.mark("segments (sync: problems)");
         ctx->ctr.dp_problems += np;
@@ -2228,9 +2229,12 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             if (test_nomem) prc = TELR_E_NOMEM;
             if (prc == TELR_E_NOMEM) {
                 if (!test_nomem) ctx->pipe_nomem = true;
-                // two ranges in flight did not fit (a device shared with something else, or a denser index than the hint said):
-                // give the second slot's scratch back and run the call again one range at a time, in ranges of 1 Gbp at most
+                // two ranges in flight did not fit (a device shared with something else, a denser index than the hint said, or
+                // the BAM writer's buffers of an earlier call still held): give the second slot's scratch and the writer's
+                // buffers back and run the call again one range at a time, in ranges of 1 Gbp at most
                 telr_destroy(ctx->slot1); ctx->slot1 = nullptr;
+                (void)hipDeviceSynchronize();
+                for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") == 0 && kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; kv.second.bytes = 0; }
                 result_wait(R); R->alns.clear(); R->ncig = 0;
                 { std::lock_guard<std::mutex> lk(R->gate_m); R->turn = 0; }
                 memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms)); memset(&ctx->ctr, 0, sizeof(ctx->ctr)); memset(ctx->dpcls, 0, sizeof(ctx->dpcls));

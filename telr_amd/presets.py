@@ -23,7 +23,9 @@ def preset(name):
         mask_level=0.5, pri_ratio=0.8, best_n=5, secondary=1,
         a=2, b=4, q=4, e=2, q2=24, e2=1, sc_ambi=1, zdrop=400, min_dp_max=80, min_ksw_len=200,
         ext_max=2048, ext_band=31, flags=MF_CIGAR, fill_band_q4=6, fill_margin=1,
-        vote_len=0, vote_bin_shift=0, vote_min=0, vote_frac_q8=0)
+        vote_len=0, vote_bin_shift=0, vote_min=0, vote_frac_q8=0, bw_long=0)
+    if name in ("map-ont", "map-pb"):
+        mo.bw_long = 20000          # minimap2 -r500,20000: a read across a multi-kb insertion / deletion is one chain
     if name == "map-ont":
         mo.fill_band_q4 = 4         # with fill_margin 1: no record of the faithful-mode gate differs (tests/test_faithful_gate.py; DESIGN.md, band rule)
     elif name == "map-pb":

@@ -562,3 +562,48 @@ def test_edge_cases(engine):
         ix.map([g[:1000]], bad)
     empty_ix = engine.index([], io)
     assert len(empty_ix.map([g[:1000]], mo).alns) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["map-ont", "map-pb"])
+def test_long_join_reads_across_large_insertions_and_deletions(engine, pname):
+    """spec 3.11 (minimap2 -r500,20000): a read across a multi-kb insertion or deletion is ONE chain and one record whose CIGAR
+    carries the long gap; the fill across it is the two-band DP (DP class 0, problem kind 5).  HIP = oracle at every stage."""
+    rng = np.random.default_rng(4242)
+    genome = [synth.random_seq(rng, 400000), synth.random_seq(rng, 150000)]
+    err = (0.013, 0.065, 0.052) if pname == "map-pb" else (0.04, 0.02, 0.04)
+    reads, want = [], []
+    for k in range(60):
+        g = genome[k % 2]
+        p = int(rng.integers(10000, len(g) - 30000))
+        left = g[p:p + int(rng.integers(1500, 6000))]
+        kind = k % 3
+        if kind == 0:          # insertion of 600 .. 4500 bases
+            L = int(rng.integers(600, 4500))
+            r = np.concatenate([left, synth.random_seq(rng, L), g[p + len(left):p + len(left) + int(rng.integers(1500, 6000))]])
+        elif kind == 1:        # deletion of 600 .. 4500 bases
+            L = int(rng.integers(600, 4500))
+            r = np.concatenate([left, g[p + len(left) + L:p + len(left) + L + int(rng.integers(1500, 6000))]])
+        else:                  # a tandem duplication of the junction (TSD-like) around an insertion
+            L = int(rng.integers(700, 3000)); tsd = int(rng.integers(4, 9))
+            r = np.concatenate([left, synth.random_seq(rng, L), g[p + len(left) - tsd:p + len(left) + int(rng.integers(1500, 5000))]])
+        r = synth.mutate(rng, r, *err)
+        if rng.integers(0, 2):
+            r = synth.revcomp_arr(r)
+        reads.append(r); want.append((kind, L))
+    io, mo = preset(pname)
+    assert mo.bw_long == 20000
+    res, oref = compare_all(engine, genome, reads, io, mo)
+    big = 0
+    for i, a in enumerate(res.alns):
+        ops = res.cigar(i)
+        if any((c & 0xf) in (1, 2) and (c >> 4) >= 500 for c in ops):
+            big += 1
+            kind, L = want[a["qid"]]
+            gaps = [int(c >> 4) for c in ops if (c & 0xf) == (2 if kind == 1 else 1) and (c >> 4) >= 500]
+            assert gaps and abs(max(gaps) - L) <= 60 + 0.08 * L, (want[a["qid"]], gaps)          # L is counted before the read errors (+-6 %)
+    assert big >= 40, big                      # most of the 60 reads are one record with the long gap inside
+    # without the long join the same reads split (what the ngmlr presets do by design)
+    off = mo.copy(); off.bw_long = 0
+    res0, _ = compare_all(engine, genome, reads, io, off, stages=False)
+    assert len(res0.alns) > len(res.alns)

@@ -91,7 +91,11 @@ def test_records_at_the_sites_carry_an_insertion_signature(stage1, engine, tmp_p
         if len(sig) < 3:
             weak.append((l["name"], l["truth"]["af"], len(sig), len(wr[li])))
         split_reads += [q for k, q in sig if k == "split"][:1]
-    assert not weak, "sites with fewer than 3 reads showing the insertion: %r" % weak
+    # With the long join (spec 3.11) a read whose element ends in sequence that also lies a few kb upstream on the reference (a
+    # diverged copy of the same family next to the site) chains THROUGH that copy: one record with a long D instead of a split at
+    # the site.  One of the 200 sites is such a neighbourhood (chr2L_17621875: a 6.8-kb element, its last 3.3 kb a reference copy
+    # 3 kb upstream); minimap2 2.19+ joins the same way.
+    assert len(weak) <= 2, "sites with fewer than 3 reads showing the insertion: %r" % weak
     # the SAM form of some split reads: primary + soft-clipped supplementary (-Y) with reciprocal SA tags
     pick = list(dict.fromkeys(split_reads))[:12]          # a read can support two neighbouring sites: once
     assert len(pick) >= 5
@@ -155,7 +159,12 @@ def test_bundle_on_engine_selected_reads_recovers_like_truth_selected(stage1, en
     out_t = locus_pipeline.run_loci(engine, ix10, ["chr2L"], lambda ch: s["ref"], loci_t, lib_names, lib, read_set=s["qs"])
     rec_e, rec_t = _recovered(out_e, loci_e), _recovered(out_t, loci_t)
     assert rec_e == rec_t, "engine-selected only: %r, truth-selected only: %r" % (sorted(rec_e - rec_t), sorted(rec_t - rec_e))
-    assert len(rec_e) >= 190
+    # 192 before the long join reached the per-locus calls; with it (as minimap2 2.19+ runs them: -r500,20000 is the map-ont / map-pb
+    # default at S4 - S6 too) 9 insertions that landed INSIDE a reference copy of another family are annotated with both families:
+    # the library hit of the host element, two hits either side of the insertion before, is one hit across it now, overlaps the ALT
+    # sequence, `bedtools merge` joins the families and the decision tree calls the locus "reference" (TELR_te.py:143-236,
+    # TELR_liftover.py:587-720; tools/debug_lj_loci.py prints them)
+    assert len(rec_e) >= 180
     # coordinates / strand / family do not depend on the read set at all; the allele frequencies agree closely
     assert out_e["liftover"] == out_t["liftover"] and out_e["annotation"] == out_t["annotation"]
     diffs = [abs(out_e["af"][n]["freq"] - out_t["af"][n]["freq"]) for n in out_e["af"] if out_e["af"][n]["freq"] is not None and out_t["af"].get(n, {}).get("freq") is not None]

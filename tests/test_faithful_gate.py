@@ -88,7 +88,7 @@ def test_fixture_gap_fills_equal_the_full_band(data_dir, name):
     _, qs = read_fasta(data_dir + "/reads.fasta")
     io, mo = preset(name)
     d = drift(ob.OracleIndex(ts, io), qs, mo, parts=0x200)
-    assert d["n"] >= 20 and d["core"] == 0 and d["coord"] == 0 and d["score"] == 0, d
+    assert d["n"] >= 18 and d["core"] == 0 and d["coord"] == 0 and d["score"] == 0, d          # (19 records with the long join: four of the reads across the jockey copy are one record each)
     # what the bounded look-back costs on these reads: nothing
     d = drift(ob.OracleIndex(ts, io), qs, mo, parts=0x100)
     assert d["core"] == 0 and d["coord"] == 0 and d["score"] == 0, d
@@ -121,7 +121,7 @@ def test_configs1_sample_drift():
     # 600-read sample: 1 of 905)
     r = drift(oix, reads, mo, parts=0x200 | 0x400)
     print("configs[1] sample, full-band fills + uncapped extensions:", r)
-    assert r["core"] == 0 and r["coord"] == 0 and r["score"] <= 0.0025, r
+    assert r["core"] == 0 and r["coord"] <= 0.005 and r["score"] <= 0.005, r          # (one of 333 records since the long join: a joined record whose uncapped end extension reaches further)
 
 
 # ---- sub-read voting (spec 3.10, the ngmlr-* presets): what the candidate search changes against chaining ALL hits ------------
@@ -229,13 +229,13 @@ LONG_JOIN = ("long join (re-chain with bw_long 20,000)", "long join, not countin
 def test_faithful_v2_bits(kind, n):
     """every omission, on every preset the reference uses: at most 0.5 % of the non-secondary records may change existence or
     coordinates -- except the rows listed in EXPLAINED, whose figures DESIGN.md section 2 states and explains:
-      * long join: a read that spans a spiked multi-kb insertion (3-7 % of the reads of these samples: 200 / 100 insertions
-        at 20x) is ONE record with a long I under minimap2 2.19+'s re-chaining and a primary + supplementary pair here -- the
-        representation NGMLR, the reference's default aligner, gives (it splits reads at SV breakpoints); Sniffles reads both;
-      * z-drop inside a fill on the repeat-dense sample and full-band fills under the cheap gaps of ngmlr-ont: 2-4 records
-        of a 300-read sample.  (The samples are the ones tools/faithful_table.py prints for DESIGN.md.)"""
-    EXPLAINED = {(k, nm): 0.09 for k in ("clr-map-pb", "clr-ngmlr-pacbio", "ont-ngmlr-ont", "c4-density") for nm in LONG_JOIN}
-    EXPLAINED[("c4-density", "z-drop inside a gap fill (records minimap2 would split)")] = 0.02
+      * long join on the `ngmlr-*` presets: NGMLR, the aligner these presets stand for, splits a read at an SV breakpoint by
+        design, so they keep bw_long = 0 and a read across a spiked multi-kb insertion (3-6 % of the reads of these samples) is
+        primary + supplementary where the minimap2 heuristic would give one record.  (For `map-ont` / `map-pb` the long join IS
+        the spec since round 3 -- section 3.11 -- and the row reads 0.00 %: the one-pass chaining within bw_long equals minimap2's
+        two rounds with look-back 5000 on every record of the samples.);
+      * full-band fills under the cheap gaps of ngmlr-ont: 2 records of a 300-read sample move by a few bases."""
+    EXPLAINED = {(k, nm): 0.09 for k in ("clr-ngmlr-pacbio", "ont-ngmlr-ont") for nm in LONG_JOIN}
     EXPLAINED[("ont-ngmlr-ont", "full-band fills + uncapped extensions")] = 0.015
     rows = bit_table(kind, n)
     for name, r in rows:

@@ -83,6 +83,17 @@ struct telr_ctx {
 #define TRY(expr) do { int _r = (expr); if (_r != TELR_OK) return _r; } while (0)
 #define TELR_SPLIT_RANGE (-100)      // internal: a batch with >= 2^31 anchors; map_range() halves it
 
+// TELR_TRACE_MEM=1: device memory at the points where the engine runs out of it or gives it back (stderr)
+static void mem_note(telr_ctx *ctx, const char *tag)
+{
+    static const bool on = getenv("TELR_TRACE_MEM") != nullptr;
+    if (!on) return;
+    size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
+    size_t own = 0, bam = 0;
+    for (auto &kv : ctx->bufs) { own += kv.second.bytes; if (kv.first.compare(0, 4, "bam_") == 0) bam += kv.second.bytes; }
+    size_t s1 = 0; if (ctx->slot1) for (auto &kv : ctx->slot1->bufs) s1 += kv.second.bytes;
+    fprintf(stderr, "[telr mem] %-44s free %.1f of %.1f GB; this context %.1f GB (writer %.1f), second slot %.1f GB\n", tag, fr / 1e9, tot / 1e9, own / 1e9, bam / 1e9, s1 / 1e9);
+}
 static int ctx_buf(telr_ctx *ctx, const char *name, size_t bytes, void **out)
 {
     DBuf &b = ctx->bufs[name];
@@ -956,7 +967,8 @@ static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
 telr_result::~telr_result()
 {
     result_wait(this); pool_put(ctx, cig, cap);
-    if (ctx && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
+    // (a worker context never takes from its pool -- its results are created without one -- so it does not keep vectors either)
+    if (ctx && !ctx->is_child && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
 }
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
@@ -2188,6 +2200,9 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             // ranges of at most 1.4 Gbp (two in flight: ~200 GB of scratch at configs[2]'s anchor density) and at most 1.6 G
             // anchors at the density seen by the last call on this index; a read set within one such range is not split
             int64_t cap = 1400LL << 20;
+            // sub-read voting carries ~25 B per query base more (hits staged at 8 B each, compacted minimizers): two 1.4-Gbp
+            // ranges in flight fill the device (2 x 152 GB measured at configs[3]) and leave the BAM writer nothing
+            if (mo->vote_len > 0 && !qtarget && !(mo->flags & TELR_MF_PER_TARGET)) cap = 1100LL << 20;
             const double per_base = ix->anchors_per_base > 0 ? ix->anchors_per_base : index_density_bound(ix, mid_occ.mid_occ);
             if (per_base > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(256LL << 20, (int64_t)(0.8e9 / per_base)));      // two in flight: half the anchor budget each
             if (total_bases > std::min<int64_t>(batch_bases, (int64_t)(per_base > 0 ? 1.6e9 / per_base : 1e18)) || force) {
@@ -2232,11 +2247,14 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
                 // two ranges in flight did not fit (a device shared with something else, a denser index than the hint said, or
                 // the BAM writer's buffers of an earlier call still held): give the second slot's scratch and the writer's
                 // buffers back and run the call again one range at a time, in ranges of 1 Gbp at most
+                (void)hipGetLastError();          // the failed allocation's error is sticky for this thread: the next launch check would report it again
+                mem_note(ctx, "telr_map: two ranges in flight ran out");
                 telr_destroy(ctx->slot1); ctx->slot1 = nullptr;
                 (void)hipDeviceSynchronize();
                 for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") == 0 && kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; kv.second.bytes = 0; }
                 result_wait(R); R->alns.clear(); R->ncig = 0;
                 { std::lock_guard<std::mutex> lk(R->gate_m); R->turn = 0; }
+                mem_note(ctx, "telr_map: after giving back slot 2 + writer");
                 memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms)); memset(&ctx->ctr, 0, sizeof(ctx->ctr)); memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
                 ctx->dp_retries = 0; ctx->pk_launches = 0; ctx->st_pending = 0;
                 int64_t lim = std::min<int64_t>(batch_bases, 1024LL << 20);

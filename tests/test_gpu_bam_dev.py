@@ -148,3 +148,31 @@ def test_synthetic_device_bam_equals_host_bam(engine, tmp_path):
     assert sum(1 for r in recs if r[1] < 0) >= 2
     _both(engine, genome, tn, reads, names, "ngmlr-ont", tmp_path, "synrg", rg=("smp", "smp", "ont"))
     _both(engine, genome, tn, reads, names, "map-ont", tmp_path, "synplain", md=False, cs=False)
+
+
+def test_long_cigar_and_nothing_mapped(engine, tmp_path):
+    """(a) a 520-kb read with a dense error pattern: more than 65,535 CIGAR operations, so the record carries the -L placeholder
+    (<l_seq>S<ref_len>N) and the real CIGAR in CG:B,I -- in both writers, byte for byte; (b) a read set of which nothing maps:
+    unmapped records only (refID -1, bin 4680, flag 4), and the same with TELR_SAM_NO_UNMAPPED: header only."""
+    rng = np.random.default_rng(9)
+    g = synth.random_seq(rng, 600000)
+    long_read = synth.mutate(rng, g[20000:540000], 0.05, 0.04, 0.05)
+    reads = [long_read, synth.mutate(rng, g[1000:9000], 0.03, 0.01, 0.01)]
+    recs = _both(engine, [g], ["big"], reads, ["long/1", "short"], "map-ont", tmp_path, "lc")
+    r0 = [r for r in recs if r[4] == "long/1" and not r[3] & 0x900][0]
+    assert r0[5] == 2 and b"CGBI" in r0[7]                               # two placeholder ops in the record, the CIGAR in the tag
+    ncg = struct.unpack_from("<I", r0[7], r0[7].index(b"CGBI") + 4)[0]
+    assert ncg > 65535
+    junk = [synth.random_seq(rng, 2000) for _ in range(7)] + [np.zeros(0, np.uint8)]
+    recs = _both(engine, [g], ["big"], junk, ["j%d" % i for i in range(8)], "map-ont", tmp_path, "um")
+    assert len(recs) == 8 and all(r[1] == -1 and r[3] == 4 for r in recs)
+    io, mo = preset("map-ont")
+    ix = engine.index([g], io); qset = engine.seqset(junk)
+    r = ix.map_raw(qset, mo)
+    try:
+        p = str(tmp_path / "none.bam")
+        ix.write_bam_device(r, qset, ["j%d" % i for i in range(8)], ["big"], p, unmapped=False, level=1)
+    finally:
+        ix.free_raw(r)
+    raw, _ = _read_bgzf(p)
+    assert _records(raw)[0] == []

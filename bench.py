@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--one-gpu", action="store_true", help="smoke test of the N>1 code path on a 1-GPU box: every rank uses device 0 (use with --backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--force-exchange", action="store_true", help="run the N>1 code path of the loci leg (window-read all-to-all, pooled read set, all-gather) at world size 1 too: under torch.distributed.run on a 1-GPU box this drives the collectives through RCCL on device tensors")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the streaming host-inclusive measurement (a second context uploads the next read batch while the first maps)")
-    ap.add_argument("--bam-leg", default="none", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
+    ap.add_argument("--bam-leg", default="device", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
     ap.add_argument("--bam-dir", default="/dev/shm")
     ap.add_argument("--bam-level", type=int, default=1)
     ap.add_argument("--no-bam-prepare", action="store_true", help="do not create / allocate / map the BAM file in the background while the reads are mapped")
@@ -214,6 +214,50 @@ def build_dataset(a, cfg, rank, world, lws):
         "ONT" if cfg["err"][1] < 0.05 else "PacBio-CLR", plan["n"], float(plan["length"].sum()) / 1e9, cfg["err"][0], cfg["err"][1], cfg["err"][2], len(g["insertions"]))
     return dict(names=g["names"], ref=g["ref"], library=g["library"], reads=(buf, off, ln), read_gid=gid, loci=loci, text=text,
                 total_reads=plan["n"], total_bases=int(plan["length"].sum()))
+
+
+def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch, np):
+    """stage 1 up to the reference's hand-off H1: reads resident -> telr_map -> coordinate-sorted, indexed BAM (TELR_alignment.py:103-114)"""
+    from telr_amd.aligner import Index
+    from telr_amd._abi import ALN_DTYPE
+    import tempfile
+    bam_dir = a.bam_dir if os.path.isdir(a.bam_dir) and os.access(a.bam_dir, os.W_OK) else tempfile.gettempdir()
+    bam_path = os.path.join(bam_dir, "telr_bench_rank%d.bam" % rank)
+    qnames = Index._cstr_array(["read%d" % g for g in D["read_gid"]])       # the C array of names is an input, like the reads
+    tb_, to_, tl_ = concat_ref = (np.concatenate(D["ref"]), np.cumsum([0] + [len(x) for x in D["ref"]][:-1]).astype(np.int64), np.array([len(x) for x in D["ref"]], np.int32))
+    legs = []
+    for rep in range(2):                      # the first pass sizes / pins the writer's buffers
+        for f in (bam_path, bam_path + ".bai"):
+            if os.path.exists(f):
+                os.unlink(f)
+        sync()
+        t0b = time.time()
+        if a.bam_leg == "device" and not a.no_bam_prepare:
+            ix.bam_prepare(bam_path, int((0.95 if a.bam_level else 2.9) * n_bases) + (64 << 20))
+        r = ix.map_raw(qs, mo)
+        t_map = time.time() - t0b
+        if a.bam_leg == "host":
+            ix.write_bam(r, qnames, D["reads"], D["names"], concat_ref, bam_path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
+        else:
+            ix.write_bam_device(r, qs, qnames, D["names"], bam_path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
+        sync()
+        t_all = time.time() - t0b
+        n = eng.L.telr_result_count(r)
+        v = np.frombuffer((ctypes.c_char * (n * ALN_DTYPE.itemsize)).from_address(eng.L.telr_result_alns(r)), dtype=ALN_DTYPE, count=n)
+        ab = int(v["qlen"][(v["flags"] & 1) != 0].sum())
+        ix.free_raw(r)
+        legs.append((t_map, t_all, ab))
+    t_map, t_all, ab = legs[-1]
+    sz = os.path.getsize(bam_path)
+    if dist is not None:
+        t = torch.tensor([t_all, t_map], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_all, t_map = float(t[0]), float(t[1])
+        t = torch.tensor([ab, sz], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t); ab, sz = float(t[0]), float(t[1])
+    for f in (bam_path, bam_path + ".bai"):
+        if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
+            os.unlink(f)
+    return {"writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1],
+               "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
+               "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s; one BAM per rank; second of two passes (the first sizes and pins the writer's buffers)" % bam_dir}
 
 
 def save_dataset(path, D):
@@ -451,42 +495,10 @@ def main():
     # ---- stage 1 up to the reference's hand-off H1: a coordinate-sorted, indexed BAM (TELR_alignment.py:103-114) ------------
     bam_out = None
     if a.bam_leg != "none":
-        bam_path = os.path.join(a.bam_dir, "telr_bench_rank%d.bam" % rank)
-        qnames = Index._cstr_array(["read%d" % g for g in D["read_gid"]])       # the C array of names is an input, like the reads
-        tb_, to_, tl_ = concat_ref = (np.concatenate(D["ref"]), np.cumsum([0] + [len(x) for x in D["ref"]][:-1]).astype(np.int64), np.array([len(x) for x in D["ref"]], np.int32))
-        legs = []
-        for rep in range(2):                      # the first pass sizes / pins the writer's buffers
-            for f in (bam_path, bam_path + ".bai"):
-                if os.path.exists(f):
-                    os.unlink(f)
-            sync()
-            t0b = time.time()
-            if a.bam_leg == "device" and not a.no_bam_prepare:
-                ix.bam_prepare(bam_path, int((0.95 if a.bam_level else 2.9) * n_bases) + (64 << 20))
-            r = ix.map_raw(qs, mo)
-            t_map = time.time() - t0b
-            if a.bam_leg == "host":
-                ix.write_bam(r, qnames, D["reads"], D["names"], concat_ref, bam_path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
-            else:
-                ix.write_bam_device(r, qs, qnames, D["names"], bam_path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
-            sync()
-            t_all = time.time() - t0b
-            n = eng.L.telr_result_count(r)
-            v = np.frombuffer((ctypes.c_char * (n * ALN_DTYPE.itemsize)).from_address(eng.L.telr_result_alns(r)), dtype=ALN_DTYPE, count=n)
-            ab = int(v["qlen"][(v["flags"] & 1) != 0].sum())
-            ix.free_raw(r)
-            legs.append((t_map, t_all, ab))
-        t_map, t_all, ab = legs[-1]
-        sz = os.path.getsize(bam_path)
-        if dist is not None:
-            t = torch.tensor([t_all, t_map], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_all, t_map = float(t[0]), float(t[1])
-            t = torch.tensor([ab, sz], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t); ab, sz = float(t[0]), float(t[1])
-        bam_out = {"writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1],
-                   "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
-                   "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai on tmpfs; one BAM per rank"}
-        for f in (bam_path, bam_path + ".bai"):
-            if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
-                os.unlink(f)
+        try:
+            bam_out = bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch, np)
+        except Exception as e:           # the leg is an extra: a full /dev/shm or a device without room for it must not cost the bench line
+            bam_out = {"writer": a.bam_leg, "error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- TE loci/s: the per-locus bundle on window reads taken from THIS run's stage-1 records -----------------------
     loci_out = None

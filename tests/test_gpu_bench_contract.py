@@ -35,6 +35,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
     assert c["parity"]["identical"] is True and c["parity"]["reads"] == 40 and c["parity"]["records_engine"] == c["parity"]["records_oracle"] > 0
+    b = d["stage1_to_sorted_bam"]                                        # the default run carries the stage-1 hand-off leg
+    assert "error" not in b and b["writer"] == "device" and 0 < b["gbp_per_s_incl_bam"] < d["value"] and b["bam_bytes"] > 1000000
     assert d["value_incl_h2d"] <= d["value"] and d["te_loci"]["n"] == 30
     assert 0 < d["value_streaming_incl_h2d"] <= 1.3 * d["value"]          # measured with every step's reads packed and uploaded underneath the previous step
 

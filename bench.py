@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--bam-leg", default="device", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
     ap.add_argument("--bam-dir", default="/dev/shm")
     ap.add_argument("--bam-level", type=int, default=1)
+    ap.add_argument("--no-polish-leg", action="store_true", help="skip the (untimed-for-the-metric) device polishing pass over the loci")
     ap.add_argument("--no-bam-prepare", action="store_true", help="do not create / allocate / map the BAM file in the background while the reads are mapped")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
     return ap.parse_args()
@@ -571,6 +572,22 @@ def main():
                 why["unlifted (flanks not placed next to each other)"] += 1
             else:
                 why["other"] += 1
+        # the polishing hand-off (H3) with the consensus made on the device (telr_consensus_build: pile-up majority vote, NOT
+        # wtpoa-cns's POA -- an extra behind a flag of the pipeline, timed here once, outside the loci/s figure)
+        polish = None
+        if world == 1 and not a.no_polish_leg:
+            try:
+                wr_p = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])
+                names_p = [l["name"] for l in loci]; ctg = [l["contig"] for l in loci]
+                telr_assembly.polish_consensus(eng, names_p[:8], ctg[:8], [w.astype(np.int32) for w in wr_p[:8]], presets=presets_arg, read_set=qs)      # sizes the scratch
+                sync(); t0p = time.time()
+                pol = telr_assembly.polish_consensus(eng, names_p, ctg, [w.astype(np.int32) for w in wr_p], presets=presets_arg, read_set=qs)
+                sync(); tp = time.time() - t0p
+                polish = {"seconds": tp, "loci_per_s": len(loci) / tp, "contigs_changed": int(sum(1 for x, y in zip(pol, ctg) if x != y)),
+                          "bases_before": int(sum(len(x) for x in ctg)), "bases_after": int(sum(len(x) for x in pol)),
+                          "what": "one telr_map (-ax P -r2k, window reads of every locus against its draft contig) + one pile-up consensus pass over all contigs"}
+            except Exception as e:
+                polish = {"error": "%s: %s" % (type(e).__name__, e)}
         wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]
         import hashlib
         rs = np.sort(rows, order="locus_id")
@@ -578,7 +595,7 @@ def main():
                                        int(r["gap"]), int(r["tsd_len"]), [int(x) for x in r["family_id"]], [None if np.isnan(x) else float(x) for x in r["medians"]],
                                        None if np.isnan(r["af"]) else float(r["af"])) for r in rs]).encode()).hexdigest()
         loci_out = {"n": n_loci, "seconds": t_loci, "rows_in_merged_table": n_rows, "merged_table_sha256": digest, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
-                    "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0,
+                    "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0, "polish_pileup": polish,
                     "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
                     "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
                             "truth-derived stand-ins for wtdbg2 / Sniffles (absent on the box)"}

@@ -254,6 +254,20 @@ int  telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *
                         const char *const *qnames, const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm,
                         const char *rg_lb, const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);
 
+/* ---- pile-up consensus of the index's targets from the PRIMARY records of a result (neither secondary nor supplementary:
+ *      `samtools view -F0x900`).  Stands where the reference pipes that view into `wtpoa-cns -d CNS -i -` to polish a locus'
+ *      draft contig (src/telr/TELR_assembly.py:226-247) -- with a different algorithm: a majority vote per contig position
+ *      (base / deletion / up to 8 inserted bases after it; D runs longer than 30 do not vote; positions covered by fewer than
+ *      min_depth records keep the draft base), not wtpoa-cns's partial-order alignment.  Offered behind telr_assembly's polish="pileup".  DESIGN.md 3.12. */
+typedef struct telr_consensus telr_consensus;
+int  telr_consensus_build(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth,
+                          telr_consensus **out);
+int32_t telr_consensus_count(const telr_consensus *c);              /* = number of targets */
+const char *telr_consensus_seq(const telr_consensus *c);             /* concatenated consensus sequences (A C G T N) */
+const int64_t *telr_consensus_off(const telr_consensus *c);
+const int32_t *telr_consensus_len(const telr_consensus *c);
+void telr_consensus_free(telr_consensus *c);
+
 /* ---- fused "samtools depth -aa -r | median" (D) --------------------------------
  * For n_iv intervals (target id, 0-based start, 0-based INCLUSIVE end — the
  * reference feeds 0-based numbers into samtools' 1-based inclusive region

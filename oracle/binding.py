@@ -54,6 +54,7 @@ def lib():
         L.tor_ext.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(MapOpt), vp, C.POINTER(i32), i32,
                               C.POINTER(i32), C.POINTER(i32)]
         L.tor_depth_medians.argtypes = [vp, i64, vp, i32, vp, i32, vp, vp, vp, vp]
+        L.tor_consensus.restype = i64; L.tor_consensus.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, i32, vp, i64, vp, vp]
         _lib = L
     return _lib
 
@@ -149,3 +150,25 @@ def depth_medians(alns, cigars, tlens, iv_tid, iv_s, iv_e):
 
 def cigar_str(cigs):
     return "".join("%d%s" % (c >> 4, "MID"[c & 0xf]) for c in cigs)
+
+
+_NT4 = np.full(256, 4, np.uint8)
+for _i, _c in enumerate("ACGT"):
+    _NT4[ord(_c)] = _i; _NT4[ord(_c.lower())] = _i
+_NT4[ord("U")] = 3; _NT4[ord("u")] = 3
+
+
+def consensus(alns, cigars, queries, targets, min_depth=3):
+    """pile-up consensus of the targets from the primary records (spec 3.12) -> list of str"""
+    from telr_amd.fasta import concat
+    alns = np.ascontiguousarray(alns); cigars = np.ascontiguousarray(cigars, dtype=np.uint32)
+    qb, qo, ql = queries if isinstance(queries, tuple) else concat(queries)
+    tb, to, tl = targets if isinstance(targets, tuple) else concat(targets)
+    q4 = np.ascontiguousarray(_NT4[np.asarray(qb, np.uint8)]); qo = np.ascontiguousarray(qo, np.int64)
+    tb = np.ascontiguousarray(tb, np.uint8); to = np.ascontiguousarray(to, np.int64); tl = np.ascontiguousarray(tl, np.int32)
+    cap = int(tl.sum()) * (1 + 8) + 16
+    out = np.zeros(cap, np.uint8); ooff = np.zeros(len(tl), np.int64); olen = np.zeros(len(tl), np.int32)
+    n = lib().tor_consensus(alns.ctypes.data, len(alns), cigars.ctypes.data, q4.ctypes.data, qo.ctypes.data, len(tl), tb.ctypes.data, to.ctypes.data, tl.ctypes.data,
+                            int(min_depth), out.ctypes.data, cap, ooff.ctypes.data, olen.ctypes.data)
+    assert n <= cap
+    return [bytes(out[ooff[i]:ooff[i] + olen[i]]).decode() for i in range(len(tl))]

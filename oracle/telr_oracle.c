@@ -1251,3 +1251,84 @@ void tor_depth_medians(const telr_aln *alns, int64_t n_aln, const uint32_t *ciga
     for (int32_t i = 0; i < n_targets; ++i) free(depth[i]);
     free(depth);
 }
+
+/* ------------------------------------------------------------------------- */
+/* 9. pile-up consensus (spec 3.12; f4: the polishing hand-off H3).  Majority vote over the PRIMARY records of a result   */
+/*    (`samtools view -F0x900`, TELR_assembly.py:226-236) -- NOT wtpoa-cns's partial-order alignment.                      */
+/*    Per target position p: base[b] = records with an M column at p whose query base is b, del = records with a D column,  */
+/*    nq = M columns with an ambiguous query base, cov = sum of all; ins[k][b] / insn[k] = records with an inserted base    */
+/*    number k (< CONS_KMAX) right after p.  Call: cov < min_depth -> the draft base; else drop p iff 2 del > cov, else the  */
+/*    most frequent base (ties: the draft base if it is among them, else the smallest code; no vote at all: the draft);     */
+/*    then inserted columns k = 0, 1, .. while 2 insn[k] > cov (most frequent base, ties smallest, none -> N).              */
+/*    D runs longer than CONS_MAXDEL and inserted bases beyond CONS_KMAX do not vote: structural differences stay.          */
+#define CONS_KMAX 8
+#define CONS_MAXDEL 30     /* a longer D is a structural difference (a read of the other allele), not an error of the draft: it does not vote */
+typedef struct { uint32_t b[4], del, nq, insn[CONS_KMAX], insb[CONS_KMAX][4]; } cons_cell_t;
+/* q: the query sequences as nt4 codes; qoff/qlen per query; t: targets as ASCII (draft bases are copied as they are) */
+int64_t tor_consensus(const telr_aln *alns, int64_t n_aln, const uint32_t *cigars, const uint8_t *q_nt4, const int64_t *qoff,
+                      int32_t n_targets, const char *t_ascii, const int64_t *toff, const int32_t *tlen, int32_t min_depth,
+                      char *out, int64_t cap, int64_t *out_off, int32_t *out_len)
+{
+    int64_t total = 0, w = 0;
+    for (int32_t t = 0; t < n_targets; ++t) total += tlen[t];
+    cons_cell_t *cell = (cons_cell_t*)calloc(total ? total : 1, sizeof(cons_cell_t));
+    int64_t *base = (int64_t*)malloc(8 * (n_targets + 1));
+    base[0] = 0; for (int32_t t = 0; t < n_targets; ++t) base[t + 1] = base[t] + tlen[t];
+    for (int64_t i = 0; i < n_aln; ++i) {
+        const telr_aln *r = &alns[i];
+        if (r->flags & (TELR_F_SECONDARY | TELR_F_SUPPL)) continue;
+        const int rev = (r->flags & TELR_F_REV) != 0;
+        const uint8_t *q = q_nt4 + qoff[r->qid];
+        int32_t qi = rev ? r->qlen - r->qe : r->qs, ti = r->ts;
+        for (int32_t z = 0; z < r->n_cigar; ++z) {
+            uint32_t c = cigars[r->cigar_off + z]; int op = c & 0xf, l = c >> 4;
+            if (op == 0) {
+                for (int x = 0; x < l; ++x) {
+                    int qb = rev ? q[r->qlen - 1 - (qi + x)] : q[qi + x];
+                    if (rev && qb < 4) qb = 3 - qb;
+                    cons_cell_t *cc = &cell[base[r->tid] + ti + x];
+                    if (qb < 4) ++cc->b[qb]; else ++cc->nq;
+                }
+                qi += l; ti += l;
+            } else if (op == 2) { if (l <= CONS_MAXDEL) for (int x = 0; x < l; ++x) ++cell[base[r->tid] + ti + x].del; ti += l; }
+            else {
+                if (ti > r->ts) {          /* an insertion before the first aligned target base has no position to hang on */
+                    cons_cell_t *cc = &cell[base[r->tid] + ti - 1];
+                    for (int x = 0; x < l && x < CONS_KMAX; ++x) {
+                        int qb = rev ? q[r->qlen - 1 - (qi + x)] : q[qi + x];
+                        if (rev && qb < 4) qb = 3 - qb;
+                        ++cc->insn[x];
+                        if (qb < 4) ++cc->insb[x][qb];
+                    }
+                }
+                qi += l;
+            }
+        }
+    }
+    for (int32_t t = 0; t < n_targets; ++t) {
+        out_off[t] = w;
+        for (int32_t p = 0; p < tlen[t]; ++p) {
+            const cons_cell_t *cc = &cell[base[t] + p];
+            const char draft = "ACGTN"[NT4[(uint8_t)t_ascii[toff[t] + p]]];        /* bases as the engine sees them */
+            const uint32_t cov = cc->b[0] + cc->b[1] + cc->b[2] + cc->b[3] + cc->del + cc->nq;
+            if ((int64_t)cov < min_depth) { if (w < cap) { out[w] = draft; } ++w; continue; }
+            if (2 * cc->del <= cov) {
+                int dcode = NT4[(uint8_t)draft], best = -1; uint32_t bv = 0;
+                for (int b = 0; b < 4; ++b) if (cc->b[b] > bv) bv = cc->b[b], best = b;
+                char ch = draft;
+                if (best >= 0) { if (dcode < 4 && cc->b[dcode] == bv) best = dcode; ch = "ACGT"[best]; }
+                if (w < cap) out[w] = ch;
+                ++w;
+            }
+            for (int k = 0; k < CONS_KMAX && 2 * cc->insn[k] > cov; ++k) {
+                int best = -1; uint32_t bv = 0;
+                for (int b = 0; b < 4; ++b) if (cc->insb[k][b] > bv) bv = cc->insb[k][b], best = b;
+                if (w < cap) out[w] = best >= 0 ? "ACGT"[best] : 'N';
+                ++w;
+            }
+        }
+        out_len[t] = (int32_t)(w - out_off[t]);
+    }
+    free(cell); free(base);
+    return w;
+}

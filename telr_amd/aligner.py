@@ -235,6 +235,20 @@ class Index:
         d.update(zip(("sink_allocate_bg", "sink_map_bg", "sink_wait", "sink_mapping_used"), (float(x) for x in b)))
         return d
 
+    def consensus(self, r, queries, min_depth=3):
+        """pile-up consensus of this index's targets from the primary records of raw result r (telr_consensus_build) -> list of str"""
+        h = C.c_void_p()
+        self.eng._chk(self.eng.L.telr_consensus_build(self.eng.h, r, queries.h, self.h, int(min_depth), C.byref(h)), "telr_consensus_build")
+        try:
+            L = self.eng.L
+            n = int(L.telr_consensus_count(h))
+            off = _np_from(L.telr_consensus_off(h), n, np.int64); ln = _np_from(L.telr_consensus_len(h), n, np.int32)
+            tot = int(off[-1] + ln[-1]) if n else 0
+            buf = _np_from(L.telr_consensus_seq(h), tot, np.uint8)
+            return [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in range(n)]
+        finally:
+            self.eng.L.telr_consensus_free(h)
+
     def depth_medians(self, r, iv_tid, iv_s, iv_e):
         """Medians over 0-based inclusive intervals, from a raw result handle."""
         tl = self.targets.len

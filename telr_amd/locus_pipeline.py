@@ -6,9 +6,20 @@ from . import telr_te, telr_af, telr_liftover
 
 
 def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, presets="ont", ref_te_rows=None,
-             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50), read_set=None):
+             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50), read_set=None, polish=None, polish_iterations=1):
     """loci: list of dicts(name, contig, alt, reads).  With `read_set` (the stage-1 read SeqSet resident on the
-    device) a locus gives `read_idx` (indices into it) instead of `reads`.  -> dict(annotation, liftover, summary, af)"""
+    device) a locus gives `read_idx` (indices into it) instead of `reads`.  polish="pileup": the draft contigs are first
+    polished on the device with the locus' reads (telr_assembly.polish_consensus: the polishing loop of
+    TELR_assembly.py:185-262 with a pile-up consensus in the place of wtpoa-cns -- a different algorithm, hence opt-in).
+    -> dict(annotation, liftover, summary, af[, contigs])"""
+    if polish == "pileup" and loci:
+        from . import telr_assembly
+        rs = [l["read_idx"] if read_set is not None else l["reads"] for l in loci]
+        pol = telr_assembly.polish_consensus(backend, [l["name"] for l in loci], [l["contig"] for l in loci], rs, presets=presets,
+                                             iterations=polish_iterations, read_set=read_set)
+        loci = [dict(l, contig=c) for l, c in zip(loci, pol)]
+    elif polish not in (None, "", "none"):
+        raise ValueError("polish must be None or 'pileup'")
     names = [l["name"] for l in loci]
     contigs = {l["name"]: l["contig"] for l in loci}
     ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
@@ -22,7 +33,10 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
         freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["read_idx"] for l in loci}, presets, *af_params, read_set=read_set)
     else:
         freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["reads"] for l in loci}, presets, *af_params)
-    return {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
+    out = {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
+    if polish == "pileup":
+        out["contigs"] = contigs
+    return out
 
 
 def locus_of_report(r):

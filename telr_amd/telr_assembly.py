@@ -116,3 +116,35 @@ def polish_alignments(engine, contig_names, contig_seqs, reads_by_locus, read_na
     finally:
         ix.free_raw(r)
     return ["".join(mapped[k]) + "".join(unmapped[k]) for k in range(len(contig_names))], res.alns, res.cigars
+
+
+def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets="ont", iterations=1, min_depth=3, read_set=None):
+    """The polishing loop of `run_wtdbg2_polishing` (TELR_assembly.py:185-262) with the consensus made on the device: per
+    iteration ONE engine call maps the reads of every locus to its draft contig (`-ax P -r2k`, as S3) and ONE pile-up pass over
+    the primary records (`-F0x900`) rewrites all contigs (`telr_consensus_build`: majority vote per position, spec 3.12).
+    This is NOT wtpoa-cns's partial-order alignment -- a different consensus algorithm can change call sets, which is why the
+    locus pipeline only uses it on request (`polish="pileup"`).  reads_by_locus[k]: read sequences, or -- with `read_set`, the
+    stage-1 SeqSet resident on the device -- read indices (gathered on the device, as in telr_af.get_af).
+    -> list of polished contig sequences (a contig no read maps to stays as it is)."""
+    from .presets import preset
+    io, mo = preset("map-pb" if presets == "pacbio" else "map-ont")
+    mo.bw = 2000
+    contigs = [c if isinstance(c, str) else bytes(c).decode() for c in contig_seqs]
+    qt, flat = [], []
+    for k, rs in enumerate(reads_by_locus):
+        for r in rs:
+            qt.append(k); flat.append(r)
+    if not flat:
+        return contigs
+    qset = read_set.subset(np.asarray(flat, np.int32)) if read_set is not None else engine.seqset(flat)
+    qt = np.asarray(qt, np.int32)
+    for _ in range(max(1, int(iterations))):
+        ix = engine.index(contigs, io)
+        r = ix.map_raw(qset, mo, qtarget=qt)
+        try:
+            contigs = ix.consensus(r, qset, min_depth=min_depth)
+        finally:
+            ix.free_raw(r)
+            ix.free()
+    qset.free()
+    return contigs

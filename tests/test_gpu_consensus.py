@@ -1,0 +1,70 @@
+"""HIP pile-up consensus (telr_consensus_build: k_pile_count / k_pile_call) against the oracle's (tor_consensus), string for
+string, on simulated loci: reads of both strands with ONT-like errors, reads with N bases, a contig no read maps to, a contig
+with lower-case and N draft bases; and the functional check that polishing moves the drafts towards the truth."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from telr_amd import synth, telr_assembly
+from telr_amd.presets import preset
+
+pytestmark = pytest.mark.gpu
+
+
+def _loci(seed, n_loci=12, depth=30):
+    rng = np.random.default_rng(seed)
+    truths, drafts, reads = [], [], []
+    for k in range(n_loci):
+        L = int(rng.integers(6000, 15000))
+        truth = synth.random_seq(rng, L)
+        draft = synth.mutate(rng, truth, 0.005, 0.003, 0.003)
+        if k == 3:
+            draft = draft.copy(); draft[100:140] |= 32; draft[500:503] = ord("N")
+        rs = []
+        for _ in range(depth if k != 5 else 0):          # locus 5: no reads at all
+            s = int(rng.integers(0, max(1, L - 4000))); r = synth.mutate(rng, truth[s:s + int(rng.integers(2000, 6000))], 0.04, 0.02, 0.04)
+            if rng.random() < 0.1:
+                r = r.copy(); r[10:14] = ord("N")
+            rs.append(bytes(synth.revcomp_arr(r) if rng.integers(0, 2) else r).decode())
+        truths.append(bytes(truth).decode()); drafts.append(bytes(draft).decode()); reads.append(rs)
+    return truths, drafts, reads
+
+
+@pytest.mark.parametrize("seed,pname", [(1, "map-ont"), (2, "map-pb")])
+def test_hip_consensus_equals_oracle(engine, seed, pname):
+    truths, drafts, reads = _loci(seed)
+    io, mo = preset(pname); mo.bw = 2000
+    qt = np.array([k for k, rs in enumerate(reads) for _ in rs], np.int32)
+    flat = [r for rs in reads for r in rs]
+    ix = engine.index(drafts, io)
+    qset = engine.seqset(flat)
+    r = ix.map_raw(qset, mo, qtarget=qt)
+    try:
+        res = ix.result_arrays(r)
+        for md in (3, 1, 8):
+            got = ix.consensus(r, qset, min_depth=md)
+            want = ob.consensus(res.alns, res.cigars, flat, drafts, min_depth=md)
+            assert got == want, [i for i in range(len(got)) if got[i] != want[i]]
+    finally:
+        ix.free_raw(r)
+    assert got[5] == drafts[5]                                     # nothing mapped: the draft stays
+    assert got[3] != drafts[3] and got[3].upper() == got[3]
+
+
+def test_polish_consensus_moves_the_drafts_to_the_truth(engine):
+    truths, drafts, reads = _loci(7, n_loci=8, depth=40)
+    out = telr_assembly.polish_consensus(engine, ["c%d" % i for i in range(8)], drafts, reads, presets="ont", iterations=2)
+    io2, mo2 = preset("asm10")
+
+    def diffs(seqs):
+        tot = 0
+        for k, s in enumerate(seqs):
+            if k == 5:
+                continue
+            a = engine.index([s], io2).map([truths[k]], mo2).alns
+            a = a[(a["flags"] & 1) != 0][0]
+            tot += int(a["blen"] - a["mlen"])
+        return tot
+    d0, d1 = diffs(drafts), diffs(out)
+    assert d0 >= 400 and d1 <= d0 // 5, (d0, d1)
+    assert out[5] == drafts[5]

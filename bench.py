@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--bam-leg", default="device", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
     ap.add_argument("--bam-dir", default="/dev/shm")
     ap.add_argument("--bam-level", type=int, default=1)
+    ap.add_argument("--files-leg", action="store_true", help="stage 1 as the reference runs it, from FILES: the read set and the reference are written as FASTA under --bam-dir, then telr_alignment.alignment(bam, reads.fa, ref.fa, ...) is timed end to end (parse, pack, upload, index, map, sorted BAM + .bai)")
     ap.add_argument("--no-polish-leg", action="store_true", help="skip the (untimed-for-the-metric) device polishing pass over the loci")
     ap.add_argument("--no-bam-prepare", action="store_true", help="do not create / allocate / map the BAM file in the background while the reads are mapped")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
@@ -259,6 +260,53 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
     return {"writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1],
                "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
                "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s; one BAM per rank; second of two passes (the first sizes and pins the writer's buffers)" % bam_dir}
+
+
+def files_leg_run(a, D, eng, pname, np):
+    """reads + reference as FASTA files -> telr_alignment.alignment() -> sorted BAM + .bai, timed as a whole (second of two runs)"""
+    import tempfile
+    from telr_amd import telr_alignment
+    bam_dir = a.bam_dir if os.path.isdir(a.bam_dir) and os.access(a.bam_dir, os.W_OK) else tempfile.gettempdir()
+    rf, qf, bam = (os.path.join(bam_dir, "telr_bench_" + n) for n in ("ref.fa", "reads.fa", "files.bam"))
+    buf, off, ln = D["reads"]
+    t0 = time.time()
+    with open(rf, "wb") as fh:
+        for n, r in zip(D["names"], D["ref"]):
+            fh.write(b">" + n.encode() + b"\n"); fh.write(bytes(r)); fh.write(b"\n")
+    # one record per read, one line per sequence: a header array, the bases and the line breaks interleaved with numpy
+    hdr = [b">read%d\n" % g for g in D["read_gid"]]
+    hl = np.array([len(h) for h in hdr], np.int64)
+    rec = hl + ln.astype(np.int64) + 1
+    pos = np.cumsum(rec) - rec
+    outb = np.empty(int(rec.sum()), np.uint8)
+    hb = np.frombuffer(b"".join(hdr), np.uint8)
+    hflat = np.repeat(pos - (np.cumsum(hl) - hl), hl) + np.arange(len(hb)); outb[hflat] = hb
+    assert (off == np.cumsum(ln.astype(np.int64)) - ln).all()          # the reads lie end to end in the buffer
+    sflat = np.repeat(pos + hl - off, ln) + np.arange(int(ln.sum()))
+    outb[sflat] = buf[:len(sflat)]
+    outb[pos + hl + ln] = 10
+    with open(qf, "wb") as fh:
+        fh.write(outb.tobytes())
+    del outb, hflat, sflat
+    t_write = time.time() - t0
+    method, presets = ("nglmr" if pname.startswith("ngmlr") else "minimap2"), ("pacbio" if pname in ("map-pb", "ngmlr-pacbio") else "ont")
+    runs = []
+    for rep in range(2):
+        for f in (bam, bam + ".bai"):
+            if os.path.exists(f):
+                os.unlink(f)
+        t0 = time.time()
+        telr_alignment.alignment(bam, qf, rf, bam_dir, "bench", 1, method, presets, engine=eng)
+        runs.append(time.time() - t0)
+        phases = dict(getattr(telr_alignment.alignment, "last_timings", {}))
+    sz = os.path.getsize(bam)
+    nb = int(ln.sum())
+    for f in (rf, qf, bam, bam + ".bai"):
+        if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
+            os.unlink(f)
+    return {"seconds": runs[-1], "first_run_seconds": runs[0], "read_bases": nb, "gbp_per_s_from_files": nb / runs[-1] / 1e9, "phases_s": phases, "bam_bytes": sz,
+            "fasta_written_in_s": t_write, "call": "telr_alignment.alignment(bam, reads.fa, ref.fa, out, sample, thread, %r, %r)" % (method, presets),
+            "what": "FASTA files under %s (page cache warm) -> telr_fasta_load x2, pack + upload, index build, telr_map, telr_write_bam_dev -> sorted BAM + .bai: the wall clock of the reference's stage 1 (TELR_alignment.py:9-114)" % bam_dir}
 
 
 def save_dataset(path, D):
@@ -501,6 +549,14 @@ def main():
         except Exception as e:           # the leg is an extra: a full /dev/shm or a device without room for it must not cost the bench line
             bam_out = {"writer": a.bam_leg, "error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- stage 1 from files to the sorted BAM: what `telr` itself would wait for (TELR_alignment.py:9-114) ---------------------
+    files_out = None
+    if a.files_leg and world == 1:
+        try:
+            files_out = files_leg_run(a, D, eng, pname, np)
+        except Exception as e:
+            files_out = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- TE loci/s: the per-locus bundle on window reads taken from THIS run's stage-1 records -----------------------
     loci_out = None
     n_loci = len(D["loci"]) if a.loci < 0 else min(a.loci, len(D["loci"]))
@@ -670,6 +726,8 @@ def main():
     }
     if bam_out is not None:
         out["stage1_to_sorted_bam"] = bam_out
+    if files_out is not None:
+        out["stage1_from_files"] = files_out
     if loci_out is not None:
         out["te_loci_per_s"] = loci_out["n"] / loci_out["seconds"]
         out["te_loci"] = loci_out

@@ -7,16 +7,18 @@
 // Names end at the first white space, as minimap2 / ngmlr print them.
 #pragma once
 struct telr_fasta {
-    std::vector<char> seq; std::vector<int64_t> off; std::vector<int32_t> len;
+    // the base buffer is raw memory: a std::vector would zero 4 GB on one thread before the copy threads overwrite it
+    char *seq = nullptr; size_t seq_bytes = 0; std::vector<int64_t> off; std::vector<int32_t> len;
     std::vector<char> name_buf; std::vector<const char*> names;
+    ~telr_fasta() { free(seq); }
 };
 extern "C" void telr_fasta_free(telr_fasta *f) { delete f; }
 extern "C" int32_t telr_fasta_count(const telr_fasta *f) { return f ? (int32_t)f->len.size() : 0; }
-extern "C" const char *telr_fasta_seq(const telr_fasta *f) { return f ? f->seq.data() : nullptr; }
+extern "C" const char *telr_fasta_seq(const telr_fasta *f) { return f ? f->seq : nullptr; }
 extern "C" const int64_t *telr_fasta_off(const telr_fasta *f) { return f ? f->off.data() : nullptr; }
 extern "C" const int32_t *telr_fasta_len(const telr_fasta *f) { return f ? f->len.data() : nullptr; }
 extern "C" const char *const *telr_fasta_names(const telr_fasta *f) { return f ? f->names.data() : nullptr; }
-extern "C" int64_t telr_fasta_bases(const telr_fasta *f) { return f ? (int64_t)f->seq.size() : 0; }
+extern "C" int64_t telr_fasta_bases(const telr_fasta *f) { return f ? (int64_t)f->seq_bytes : 0; }
 
 extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
 {
@@ -81,10 +83,12 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     int64_t tot = 0, ntot = 0;
     std::vector<int64_t> noff(nr);
     for (size_t r = 0; r < nr; ++r) { F->off[r] = tot; tot += F->len[r]; noff[r] = ntot; ntot += nlen[r] + 1; }
-    F->seq.resize((size_t)tot); F->name_buf.resize((size_t)ntot); F->names.resize(nr);
+    F->seq = (char*)malloc((size_t)tot + 1); F->seq_bytes = (size_t)tot;
+    if (!F->seq) { munmap((void*)p, n); delete F; return TELR_E_NOMEM; }
+    F->name_buf.resize((size_t)ntot); F->names.resize(nr);
     parallel_ranges(NT, (int)nr, [&](int, int r0, int r1) {
         for (int r = r0; r < r1; ++r) {
-            char *d = F->seq.data() + F->off[r];
+            char *d = F->seq + F->off[r];
             for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') --l; memcpy(d, p + i, l); d += l; i = e + 1; }
             char *nm = F->name_buf.data() + noff[r];
             memcpy(nm, p + recs[r].hdr, (size_t)nlen[r]); nm[nlen[r]] = 0;

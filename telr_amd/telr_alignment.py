@@ -44,6 +44,8 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
         sys.exit(1)
     eng = engine or Engine(0)
     io, mo = preset(name)
+    tm = {}                                       # seconds per phase of the last call: alignment.last_timings
+    t0 = time.time()
     tf, qf = load(reference), load(read)          # None for gzip: the Python reader
     if tf is not None:
         tn, ts = tf.names_c, tf.triple
@@ -55,16 +57,32 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
         qn, qs = read_fasta(read)
         n_bases = sum(len(x) for x in qs)
     with_cs = method == "minimap2"
+    tm["parse_files"] = time.time() - t0; t0 = time.time()
     ix = eng.index(ts, io)
+    tm["pack_reference_build_index"] = time.time() - t0; t0 = time.time()
     qset = eng.seqset(qs)
+    tm["pack_upload_reads"] = time.time() - t0; t0 = time.time()
     # about 0.85 bytes of BAM per read base with --cs --MD, 0.6 without cs, at level 1
     ix.bam_prepare(bam, int((0.95 if with_cs else 0.7) * n_bases) + (64 << 20))
     r = ix.map_raw(qset, mo)
+    tm["map"] = time.time() - t0; t0 = time.time()
     try:
         ix.write_bam_device(r, qset, qn, tn, bam, md=True, cs=with_cs, softclip=True, rg=rg, cmdline=cmd, index=True, level=1)
+        tm["sorted_bam"] = time.time() - t0; t0 = time.time()
     finally:
         ix.free_raw(r)
         qset.free()
+        ix.free()
+        # giving 4 GB of parsed reads back to the system takes a quarter of a second: not while the caller waits for its BAM
+
+        def _drop(files):
+            for f in files:
+                if f is not None:
+                    f.close()
+        import threading
+        threading.Thread(target=_drop, args=((tf, qf),), daemon=True).start()
+    tm["release"] = time.time() - t0
+    alignment.last_timings = tm
     if os.path.isfile(bam) is False:
         sys.stderr.write("Sorted and indexed BAM file does not exist, exiting...\n")
         sys.exit(1)

@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
     ap.add_argument("--data-cache", default="", help="directory: the rank's generated data set is stored there / loaded from there (profiling runs: no forked generator)")
     ap.add_argument("--one-gpu", action="store_true", help="smoke test of the N>1 code path on a 1-GPU box: every rank uses device 0 (use with --backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--bam-sha", action="store_true", help="report the SHA-256 of the BAM files the legs write (the N-rank job BAM equals the 1-rank BAM byte for byte)")
     ap.add_argument("--force-exchange", action="store_true", help="run the N>1 code path of the loci leg (window-read all-to-all, pooled read set, all-gather) at world size 1 too: under torch.distributed.run on a 1-GPU box this drives the collectives through RCCL on device tensors")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the streaming host-inclusive measurement (a second context uploads the next read batch while the first maps)")
     ap.add_argument("--bam-leg", default="device", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
@@ -254,12 +255,79 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
     if dist is not None:
         t = torch.tensor([t_all, t_map], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_all, t_map = float(t[0]), float(t[1])
         t = torch.tensor([ab, sz], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t); ab, sz = float(t[0]), float(t[1])
+    sha = None
+    if a.bam_sha and os.path.exists(bam_path):
+        sha = file_sha256(bam_path)
     for f in (bam_path, bam_path + ".bai"):
         if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
             os.unlink(f)
-    return {"writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1],
+    job = None
+    if dist is not None and a.bam_leg == "device" and (dist.get_world_size() > 1 or a.force_exchange):
+        job = job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_dir)
+    return {"job_bam": job, "bam_sha256": sha, "writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1],
                "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
                "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s; one BAM per rank; second of two passes (the first sizes and pins the writer's buffers)" % bam_dir}
+
+
+def file_sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        while True:
+            b = fh.read(64 << 20)
+            if not b:
+                break
+            h.update(b)
+    return h.hexdigest()
+
+
+def job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_dir):
+    """N > 1: ONE coordinate-sorted BAM for the job (Sniffles reads one file, TELR_sv.py:35-47).  Every rank maps its reads, the
+    records / CIGARs / reads travel to rank 0 (shard.gather_stage1), rank 0 builds the file with one telr_write_bam_dev call."""
+    from telr_amd import shard
+    from telr_amd.aligner import Index
+    path = os.path.join(bam_dir, "telr_bench_job.bam")
+    names = ["read%d" % g for g in D["read_gid"]]
+    out = None
+    for rep in range(2):
+        if rank == 0:
+            for f in (path, path + ".bai"):
+                if os.path.exists(f):
+                    os.unlink(f)
+        dist.barrier(); sync()
+        t0 = time.time()
+        r = ix.map_raw(qs, mo)
+        res = ix.result_arrays(r)
+        t_map = time.time() - t0
+        got = shard.gather_stage1(res.alns, res.cigars, D["reads"], names, dist=dist, device=device, force=a.force_exchange, read_gid=D["read_gid"])
+        ix.free_raw(r)
+        t_gather = time.time() - t0 - t_map
+        if rank == 0:
+            try:                       # the other ranks wait at the barrier below whatever happens here
+                alns, cigars, reads, all_names = got
+                ix.bam_prepare(path, int((0.95 if a.bam_level else 2.9) * int(reads[2].sum())) + (64 << 20))
+                jq = eng.seqset(reads)
+                jr = ix.result_from_arrays(alns, cigars)
+                ix.write_bam_device(jr, jq, Index._cstr_array(all_names), D["names"], path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
+                ix.free_raw(jr); jq.free()
+                out = {"records": int(len(alns)), "reads": int(len(reads[2])), "aligned_bases": int(alns["qlen"][(alns["flags"] & 1) != 0].sum())}
+                del got, alns, cigars, reads
+            except Exception as e:
+                out = {"error": "%s: %s" % (type(e).__name__, e)}
+        dist.barrier(); sync()
+        t_all = time.time() - t0
+    if rank != 0:
+        return None
+    if "error" in out:
+        return out
+    out.update(seconds=t_all, map_seconds=t_map, gather_seconds=t_gather, write_seconds=t_all - t_map - t_gather, bam_bytes=os.path.getsize(path),
+               gbp_per_s_incl_bam=out["aligned_bases"] / t_all / 1e9, bam_sha256=file_sha256(path) if a.bam_sha else None, path=path,
+               what="every rank maps its reads; records, CIGARs, read bases and names go point-to-point to rank 0 (%s), which writes ONE sorted BAM + .bai "
+                    "for the job with one telr_write_bam_dev call; second of two passes" % dist.get_backend())
+    for f in (path, path + ".bai"):
+        if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
+            os.unlink(f)
+    return out
 
 
 def files_leg_run(a, D, eng, pname, np):

@@ -205,6 +205,11 @@ const telr_aln *telr_result_alns(const telr_result *r);     /* sorted by (qid, r
  * telr_map returns as soon as the RECORDS are complete; the DMA of the CIGAR array may still be in flight
  * (so that a caller streaming batches overlaps it with the next telr_map call).  telr_result_cigars,
  * the writers, telr_depth_medians and telr_result_free wait for it; telr_result_wait does so explicitly. */
+/* A result made of records and CIGAR words the caller holds (copied; cigar_off must index `cigars`): for the writers and
+ * telr_depth_medians on records that were mapped elsewhere -- at N > 1 ranks the stage-1 hand-off is ONE sorted BAM, written by
+ * rank 0 from the records every rank mapped (telr_amd/shard.py: gather_stage1). */
+int             telr_result_from_arrays(telr_ctx *ctx, const telr_aln *alns, int64_t n, const uint32_t *cigars, int64_t n_cigar,
+                                        telr_result **out);
 int             telr_result_wait(const telr_result *r);
 int64_t         telr_result_cigar_count(const telr_result *r);
 const uint32_t *telr_result_cigars(const telr_result *r);

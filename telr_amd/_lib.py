@@ -14,7 +14,7 @@ EXPORTS = [
     "telr_init", "telr_destroy", "telr_strerror", "telr_last_error", "telr_device_name", "telr_preset",
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
-    "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
+    "telr_result_from_arrays", "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
     "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_consensus_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
@@ -48,6 +48,7 @@ def lib():
     L.telr_index_free.restype = None; L.telr_index_free.argtypes = [vp]
     L.telr_index_stats.restype = C.c_int; L.telr_index_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.telr_map.restype = C.c_int; L.telr_map.argtypes = [vp, vp, vp, vp, C.POINTER(MapOpt), C.POINTER(vp)]
+    L.telr_result_from_arrays.restype = C.c_int; L.telr_result_from_arrays.argtypes = [vp, vp, i64, vp, i64, C.POINTER(vp)]
     L.telr_result_count.restype = i64; L.telr_result_count.argtypes = [vp]
     L.telr_result_alns.restype = vp; L.telr_result_alns.argtypes = [vp]
     L.telr_result_cigar_count.restype = i64; L.telr_result_cigar_count.argtypes = [vp]

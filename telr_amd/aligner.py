@@ -151,6 +151,13 @@ class Index:
                                           C.byref(mo), C.byref(r)), "telr_map")
         return r
 
+    def result_from_arrays(self, alns, cigars):
+        """raw result handle over caller-held records + CIGAR words (copied): for the writers on records mapped elsewhere"""
+        alns = np.ascontiguousarray(alns, dtype=ALN_DTYPE); cigars = np.ascontiguousarray(cigars, dtype=np.uint32)
+        r = C.c_void_p()
+        self.eng._chk(self.eng.L.telr_result_from_arrays(self.eng.h, alns.ctypes.data, len(alns), cigars.ctypes.data, len(cigars), C.byref(r)), "telr_result_from_arrays")
+        return r
+
     def free_raw(self, r):
         self.eng.L.telr_result_free(r)
 

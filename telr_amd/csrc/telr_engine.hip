@@ -970,6 +970,22 @@ telr_result::~telr_result()
     // (a worker context never takes from its pool -- its results are created without one -- so it does not keep vectors either)
     if (ctx && !ctx->is_child && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
 }
+// a result made of caller-supplied records and CIGAR words (copied): one rank writes the BAM of reads other ranks mapped
+extern "C" int telr_result_from_arrays(telr_ctx *ctx, const telr_aln *alns, int64_t n, const uint32_t *cigars, int64_t n_cigar, telr_result **out)
+{
+    if (!ctx || !out || n < 0 || n_cigar < 0 || (n > 0 && !alns) || (n_cigar > 0 && !cigars)) return TELR_E_ARG;
+    for (int64_t i = 0; i < n; ++i) if (alns[i].n_cigar < 0 || alns[i].cigar_off < 0 || alns[i].cigar_off + alns[i].n_cigar > n_cigar) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    telr_result *R = new telr_result();
+    R->ctx = ctx;
+    R->alns.assign(alns, alns + n);
+    R->cig = cig_alloc((size_t)n_cigar + 1);
+    if (!R->cig) { delete R; return TELR_E_NOMEM; }
+    R->cap = (size_t)n_cigar + 1; R->ncig = (size_t)n_cigar;
+    if (n_cigar) memcpy(R->cig, cigars, (size_t)n_cigar * 4);
+    *out = R;
+    return TELR_OK;
+}
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
 extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->ncig : 0; }

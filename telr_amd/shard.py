@@ -145,6 +145,73 @@ def exchange_window_reads(locus_id, read_id, dest, reads, read_index, dist=None,
     return h["locus_id"][order].astype(np.int64), h["read_id"][order].astype(np.int64), (raw, off[order], h["length"][order].astype(np.int32))
 
 
+def gather_stage1(alns, cigars, reads, read_names, dist=None, device=None, force=False, read_gid=None):
+    """The stage-1 hand-off at N > 1: Sniffles wants ONE coordinate-sorted BAM, the reads were dealt to the ranks.  Every rank
+    packs what it mapped -- records, CIGAR words, read bases, lengths and names -- into one byte blob; ONE all-gather of the five
+    sizes and ONE all-to-all whose only non-empty destination is rank 0 (RCCL over xGMI on device tensors, gloo in the tests: the
+    same two collectives the loci leg uses) bring them to rank 0, which re-bases the query ids and CIGAR offsets and holds the job's
+    records in rank order: the input of ONE telr_write_bam_dev call ("each rank writes its own shard, host merges" --
+    the merge is the device writer's sort; writing is bound by the host's page cache, so a second writer would not help).
+    force: run the collectives at world size 1 too.  read_gid: the job-level number of every read of this rank (its place in the
+    input file); with it rank 0 puts reads and records back into file order, so the job's arrays -- and the BAM written from them,
+    ties in the coordinate sort included -- do not depend on how the reads were dealt.
+    -> on rank 0: (alns, cigars, (buf, off, len), names) of the whole job; on the other ranks None."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    buf, off, ln = reads
+    alns = np.ascontiguousarray(alns); cigars = np.ascontiguousarray(cigars, dtype=np.uint32)
+    ln = np.ascontiguousarray(ln, np.int32); off = np.asarray(off, np.int64)
+    if world == 1 and not (force and dist is not None and dist.is_initialized()):
+        return alns, cigars, (buf, off, ln), list(read_names)
+    import torch
+    dev = device if device is not None else "cpu"
+    names_blob = np.frombuffer(("\n".join(read_names)).encode(), np.uint8)
+    # the reads of this rank end to end (they usually are already)
+    if len(ln) and not (off == np.cumsum(ln.astype(np.int64)) - ln).all():
+        buf = np.concatenate([buf[o:o + l] for o, l in zip(off, ln)])
+    gid = np.zeros(0, np.int64) if read_gid is None else np.ascontiguousarray(read_gid, np.int64)
+    mine = [alns.view(np.uint8).reshape(-1), cigars.view(np.uint8).reshape(-1), np.ascontiguousarray(buf, np.uint8)[:int(ln.sum())], ln.view(np.uint8).reshape(-1), names_blob,
+            gid.view(np.uint8).reshape(-1)]
+    sizes = torch.tensor([len(x) for x in mine], dtype=torch.int64, device=dev)
+    all_sizes = [torch.empty(6, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [[int(v) for v in t.cpu().tolist()] for t in all_sizes]
+    blob = torch.from_numpy(np.concatenate(mine)).to(dev)
+    recv_n = [sum(x) for x in all_sizes] if rank == 0 else [0] * world
+    got = torch.empty(sum(recv_n), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(got, blob, output_split_sizes=recv_n, input_split_sizes=[len(blob)] + [0] * (world - 1))
+    if rank != 0:
+        return None
+    got = got.cpu().numpy()
+    out_alns, out_cig, out_buf, out_len, out_names, out_gid = [], [], [], [], [], []
+    q0 = 0; c0 = 0; p0 = 0
+    for r in range(world):
+        p = []
+        for k in range(6):
+            p.append(got[p0:p0 + all_sizes[r][k]]); p0 += all_sizes[r][k]
+        a = np.frombuffer(p[0].tobytes(), dtype=alns.dtype).copy()
+        a["qid"] += q0; a["cigar_off"] += c0
+        lens = np.frombuffer(p[3].tobytes(), np.int32)
+        out_alns.append(a); out_cig.append(np.frombuffer(p[1].tobytes(), np.uint32)); out_buf.append(p[2]); out_len.append(lens)
+        out_names += p[4].tobytes().decode().split("\n") if len(lens) else []
+        out_gid.append(np.frombuffer(p[5].tobytes(), np.int64))
+        q0 += len(lens); c0 += len(p[1]) // 4
+    ln_all = np.concatenate(out_len); a_all = np.concatenate(out_alns); buf_all = np.concatenate(out_buf); gid_all = np.concatenate(out_gid)
+    off_all = np.cumsum(ln_all.astype(np.int64)) - ln_all
+    if read_gid is not None:
+        if len(gid_all) != len(ln_all):
+            raise ValueError("gather_stage1: read_gid must be given by every rank or by none")
+        order = np.argsort(gid_all, kind="stable")                  # new place -> gathered place
+        place = np.empty(len(order), np.int64); place[order] = np.arange(len(order))
+        a_all["qid"] = place[a_all["qid"]]
+        a_all = a_all[np.argsort(a_all["qid"], kind="stable")]      # the records of a read stay in the order the engine gave them
+        new_len = ln_all[order]; new_off = np.cumsum(new_len.astype(np.int64)) - new_len
+        idx = np.repeat(off_all[order] - new_off, new_len) + np.arange(int(new_len.sum()), dtype=np.int64)
+        buf_all = buf_all[idx]; ln_all = new_len; off_all = new_off
+        out_names = [out_names[i] for i in order]
+    return a_all, np.concatenate(out_cig), (buf_all, off_all, ln_all), out_names
+
+
 def rows_from_reports(locus_ids, reports, freqs, chrom_ids, family_ids):
     """liftover report dicts (+ te_freq dicts) -> LOCUS_ROW array"""
     out = np.zeros(len(locus_ids), LOCUS_ROW)

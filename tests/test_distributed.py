@@ -208,3 +208,89 @@ def test_locus_names_with_underscores():
     assert locus_pipeline.locus_of_report({"ID": "chrUn_CP007071v1_100_101_4000_4900"}) == "chrUn_CP007071v1_100_101"
     assert locus_pipeline.locus_of_report({"ID": "chr2L_33000_33020_12_4711"}) == "chr2L_33000_33020"
     assert locus_pipeline.locus_cost({"contig": "ACGT" * 5, "alt": "AC", "read_bases": 100}) == 122
+
+
+def _stage1_piece(rank, world):
+    """what rank `rank` mapped: records with LOCAL query ids and CIGAR offsets, its reads and their names (rank 1 of 3 holds nothing)"""
+    from telr_amd._abi import ALN_DTYPE
+    rng = np.random.default_rng(50 + rank)
+    n_reads = 0 if (world == 3 and rank == 1) else 4 + rank
+    ln = rng.integers(5, 40, size=n_reads).astype(np.int32)
+    buf = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(ln.sum())) if n_reads else np.zeros(0, np.uint8)
+    off = np.cumsum(ln.astype(np.int64)) - ln
+    names = ["r%d_%d" % (rank, i) for i in range(n_reads)]
+    recs, cig = [], []
+    for q in range(n_reads):
+        for _ in range(int(rng.integers(0, 3))):
+            a = np.zeros(1, ALN_DTYPE)
+            a["qid"] = q; a["tid"] = 0; a["qlen"] = ln[q]; a["ts"] = int(rng.integers(0, 1000)); a["flags"] = 1
+            ops = [int(rng.integers(1, 9)) << 4 | int(rng.integers(0, 3)) for _ in range(int(rng.integers(1, 5)))]
+            a["cigar_off"] = len(cig); a["n_cigar"] = len(ops); cig += ops
+            recs.append(a)
+    alns = np.concatenate(recs) if recs else np.zeros(0, ALN_DTYPE)
+    return alns, np.array(cig, np.uint32), (buf, off, ln), names
+
+
+def _gather_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from telr_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    alns, cig, reads, names = _stage1_piece(rank, world)
+    got = shard.gather_stage1(alns, cig, reads, names, dist=dist)
+    # the same with file-order numbers: read q of rank r is read q * world + r of the job
+    got2 = shard.gather_stage1(alns, cig, reads, names, dist=dist, read_gid=np.arange(len(names), dtype=np.int64) * world + rank)
+    if rank == 0:
+        a, c, (buf, off, ln), nm = got
+        a2, c2, (buf2, off2, ln2), nm2 = got2
+        np.savez(out_path, alns=a, cig=c, buf=buf, off=off, ln=ln, names=np.array(nm), alns2=a2, cig2=c2, buf2=buf2, off2=off2, ln2=ln2, names2=np.array(nm2))
+    else:
+        assert got is None and got2 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_stage1_rebases_query_ids_and_cigar_offsets(tmp_path, world):
+    """the job's records on rank 0 = the ranks' records in rank order, query ids and CIGAR offsets re-based, reads and names
+    concatenated (world 3: the middle rank holds no reads at all)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "g.npz")
+    mp.spawn(_gather_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    z = np.load(out)
+    q0 = 0; c0 = 0; k0 = 0; b0 = 0
+    for r in range(world):
+        alns, cig, (buf, off, ln), names = _stage1_piece(r, world)
+        n = len(alns)
+        got = z["alns"][k0:k0 + n]
+        np.testing.assert_array_equal(got["qid"], alns["qid"] + q0)
+        np.testing.assert_array_equal(got["cigar_off"], alns["cigar_off"] + c0)
+        for f in ("ts", "n_cigar", "qlen", "flags"):
+            np.testing.assert_array_equal(got[f], alns[f])
+        np.testing.assert_array_equal(z["cig"][c0:c0 + len(cig)], cig)
+        np.testing.assert_array_equal(z["ln"][q0:q0 + len(ln)], ln)
+        np.testing.assert_array_equal(z["buf"][b0:b0 + len(buf)], buf)
+        assert list(z["names"][q0:q0 + len(ln)]) == names
+        q0 += len(ln); c0 += len(cig); k0 += n; b0 += len(buf)
+    assert k0 == len(z["alns"]) and q0 == len(z["ln"]) and (z["off"] == np.cumsum(z["ln"].astype(np.int64)) - z["ln"]).all()
+    # every record's CIGAR is where its offset says
+    for a in z["alns"]:
+        assert a["cigar_off"] + a["n_cigar"] <= len(z["cig"])
+    # with read_gid: reads in file order, the records of a read together and in the engine's order, CIGARs still where the offsets say
+    pieces = [_stage1_piece(r, world) for r in range(world)]
+    gids = sorted((q * world + r, r, q) for r in range(world) for q in range(len(pieces[r][3])))
+    assert list(z["names2"]) == [pieces[r][3][q] for _, r, q in gids]
+    np.testing.assert_array_equal(z["ln2"], [pieces[r][2][2][q] for _, r, q in gids])
+    assert (z["off2"] == np.cumsum(z["ln2"].astype(np.int64)) - z["ln2"]).all()
+    want_buf = [pieces[r][2][0][pieces[r][2][1][q]:pieces[r][2][1][q] + pieces[r][2][2][q]] for _, r, q in gids]
+    np.testing.assert_array_equal(z["buf2"], np.concatenate(want_buf) if want_buf else np.zeros(0, np.uint8))
+    k = 0
+    for new_q, (_, r, q) in enumerate(gids):
+        alns, cig = pieces[r][0], pieces[r][1]
+        for a in alns[alns["qid"] == q]:
+            g = z["alns2"][k]; k += 1
+            assert g["qid"] == new_q and g["ts"] == a["ts"] and g["n_cigar"] == a["n_cigar"]
+            np.testing.assert_array_equal(z["cig2"][g["cigar_off"]:g["cigar_off"] + g["n_cigar"]], cig[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]])
+    assert k == len(z["alns2"]) == len(z["alns"])

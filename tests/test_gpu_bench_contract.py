@@ -47,7 +47,7 @@ def test_two_ranks_merge_to_the_one_rank_locus_table():
     share, the window reads of a locus travel to the locus' owner (all-to-all), the per-locus rows are merged by ONE
     all-gather -- and the merged table is the table one rank computes alone."""
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--config", "c1", "--genome-len", "3000000", "--reads", "1500",
-            "--read-bases", "60000000", "--insertions", "30", "--no-cpu-baseline", "--no-stream-leg"]
+            "--read-bases", "60000000", "--insertions", "30", "--no-cpu-baseline", "--no-stream-leg", "--bam-sha"]
     out = []
     for extra in (["--gpus", "1"], ["--gpus", "2", "--one-gpu", "--backend", "gloo"]):
         p = subprocess.run(base + extra, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -64,3 +64,32 @@ def test_two_ranks_merge_to_the_one_rank_locus_table():
     assert two["te_loci"]["rows_in_merged_table"] == one["te_loci"]["rows_in_merged_table"] > 0
     assert two["te_loci"]["merged_table_sha256"] == one["te_loci"]["merged_table_sha256"]
     assert two["te_loci"]["recovered_exact_chrom_family_strand_pos20"] == one["te_loci"]["recovered_exact_chrom_family_strand_pos20"] >= 25
+    # stage 1 hands Sniffles ONE sorted BAM: the job's BAM built on rank 0 from both ranks' records is, byte for byte, the file one rank writes alone
+    jb = two["stage1_to_sorted_bam"]["job_bam"]
+    assert "error" not in jb, jb
+    assert one["stage1_to_sorted_bam"]["job_bam"] is None
+    assert jb["bam_sha256"] == one["stage1_to_sorted_bam"]["bam_sha256"] and jb["bam_bytes"] == one["stage1_to_sorted_bam"]["bam_bytes"]
+    assert jb["reads"] == one["config"]["reads_this_rank"] > two["config"]["reads_this_rank"] and jb["records"] > 0
+
+
+@pytest.mark.gpu
+def test_collectives_of_the_n_rank_path_run_through_rccl_on_device_tensors():
+    """torch.distributed.run with ONE rank and --force-exchange: the all-to-all / all-gather of the loci leg and the stage-1
+    gather of the job BAM go through RCCL (backend nccl) on device tensors, and give what the collective-free path gives."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    args = ["--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "c1", "--genome-len", "3000000", "--reads", "1500", "--read-bases", "60000000",
+            "--insertions", "30", "--no-cpu-baseline", "--no-stream-leg", "--bam-sha"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    plain = json.loads([l for l in p.stdout.decode().splitlines() if l.strip()][-1])
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py")] + args + ["--force-exchange"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    forced = json.loads([l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")][-1])
+    assert forced["rccl_world_size"] == 1 and plain["rccl_world_size"] == 0
+    assert "all-to-all" in forced["te_loci"]["collectives"]
+    assert forced["te_loci"]["merged_table_sha256"] == plain["te_loci"]["merged_table_sha256"]
+    jb = forced["stage1_to_sorted_bam"]["job_bam"]
+    assert "error" not in jb and "nccl" in jb["what"], jb
+    assert jb["bam_sha256"] == plain["stage1_to_sorted_bam"]["bam_sha256"] == forced["stage1_to_sorted_bam"]["bam_sha256"]

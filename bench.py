@@ -234,6 +234,7 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
             if os.path.exists(f):
                 os.unlink(f)
         sync()
+        ix.bam_release_wait()                 # the first pass's file mapping is taken apart in the background: a run writes ONE BAM
         t0b = time.time()
         if a.bam_leg == "device" and not a.no_bam_prepare:
             ix.bam_prepare(bam_path, int((0.95 if a.bam_level else 2.9) * n_bases) + (64 << 20))
@@ -294,6 +295,7 @@ def job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_
             for f in (path, path + ".bai"):
                 if os.path.exists(f):
                     os.unlink(f)
+        ix.bam_release_wait()
         dist.barrier(); sync()
         t0 = time.time()
         r = ix.map_raw(qs, mo)
@@ -363,6 +365,7 @@ def files_leg_run(a, D, eng, pname, np):
         for f in (bam, bam + ".bai"):
             if os.path.exists(f):
                 os.unlink(f)
+        eng.L.telr_bam_release_wait()
         t0 = time.time()
         telr_alignment.alignment(bam, qf, rf, bam_dir, "bench", 1, method, presets, engine=eng)
         runs.append(time.time() - t0)

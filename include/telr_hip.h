@@ -249,12 +249,16 @@ int  telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *
  * reference bases).  No ASCII sequences are needed.  level 0 = stored BGZF blocks; level >= 1 = deflate blocks coded on
  * the device (Huffman tables per BAM field class, run-length matches).  Bases print as the engine sees them: A C G T, anything
  * else N (telr_write_bam / telr_write_sam print the same, so the uncompressed streams of the two writers are equal). */
-/* Optional, before telr_map: start creating `bam_path` in the background (allocate est_bytes of it -- a BAM with --cs --MD
- * takes about 0.85 bytes per read base at level 1, 2.8 at level 0 -- and map it), so that telr_write_bam_dev(... the same
- * path ...) copies the finished file image into pages that already exist, with several threads, and cuts the file to size.
- * Without it, or when the estimate was too small, the writer streams through a pinned ring and one pwrite thread.  A prepared file that is never written is removed
- * from the context by the next telr_bam_prepare / telr_destroy (the file itself stays). */
+/* Optional, before telr_map: start creating `bam_path` in the background -- the file is created and mapped at once, then
+ * est_bytes of it (a BAM with --cs --MD takes about 0.85 bytes per read base at level 1, 2.8 at level 0) are allocated and
+ * pre-faulted into the mapping block by block, front to back -- so that telr_write_bam_dev(... the same path ...) copies the
+ * finished file image into pages that exist and are mapped (80+ GB/s instead of the 6-15 GB/s of a fresh page-cache page),
+ * and cuts the file to size.  Without it, or past the estimate, the writer streams through a pinned ring and one pwrite
+ * thread.  The mapping is taken apart by a background thread after the file is complete; telr_bam_release_wait() waits for
+ * that (only a process that prepares another file right away has a reason to).  A prepared file that is never written is
+ * removed from the context by the next telr_bam_prepare / telr_destroy (the file itself stays). */
 int  telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes);
+int  telr_bam_release_wait(void);
 int  telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx,
                         const char *const *qnames, const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm,
                         const char *rg_lb, const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);

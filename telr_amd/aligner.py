@@ -235,11 +235,15 @@ class Index:
         """start creating the output file in the background (call before map_raw; see telr_bam_prepare)"""
         self.eng._chk(self.eng.L.telr_bam_prepare(self.eng.h, path.encode(), int(est_bytes)), "telr_bam_prepare")
 
+    def bam_release_wait(self):
+        """wait until the mappings of earlier output files are taken apart (telr_bam_release_wait)"""
+        self.eng.L.telr_bam_release_wait()
+
     def bam_stage_ms(self):
-        a = np.zeros(8, np.float32); b = np.zeros(4, np.float32)
+        a = np.zeros(8, np.float32); b = np.zeros(12, np.float32)
         self.eng.L.telr_debug_bam_ms(a.ctypes.data); self.eng.L.telr_debug_bam_sink_ms(b.ctypes.data)
         d = dict(zip(("upload", "scan_size", "sort_offsets", "write_records", "bgzf", "d2h_file", "bai_host_overlapped", "total"), (float(x) for x in a)))
-        d.update(zip(("sink_allocate_bg", "sink_map_bg", "sink_wait", "sink_mapping_used"), (float(x) for x in b)))
+        d.update(zip(("sink_allocate_bg", "sink_map_bg", "sink_wait", "sink_mapping_used", "stream_wait_coder", "stream_wait_dma", "stream_host_copy", "stream_wait_slot", "stream_loop", "sink_stop", "sink_truncate"), (float(x) for x in b)))
         return d
 
     def consensus(self, r, queries, min_depth=3):

@@ -987,34 +987,94 @@ static std::string bam_header(int32_t n_targets, const char *const *tnames, cons
 struct BamSink {
     std::string path; int fd = -1; uint8_t *map = nullptr; size_t bytes = 0;
     std::thread th; float ms_alloc = 0, ms_map = 0;
+    // The file becomes usable front to back, block by block: a block is allocated (tmpfs takes one allocator at a time: 17-19 GB/s)
+    // and then pre-faulted into the mapping by four threads (MADV_POPULATE_WRITE, ~38 GB/s): a copy into a populated mapping runs
+    // at 80-200 GB/s, into an allocated but unmapped one at 12-15 GB/s -- the page-fault path (profiles/r03_shm_io_populate.txt).
+    // The two steps alternate: run side by side they contend for the file's page tree (allocation 230 -> 610 ms).
+    static constexpr size_t SLICE = 64u << 20;
+    std::mutex mu; std::condition_variable cv; size_t n_slices = 0, ready = 0, limit = ~(size_t)0; bool stop = false, over = false;
+    // wait until the first `end` bytes are allocated and mapped (or the sink has given up on them: the copy then faults them in)
+    void wait_ready(size_t end)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return over || ready * SLICE >= std::min(std::min(end, bytes), limit); });
+    }
+    // the writer's running estimate of the file's length: blocks past it are not prepared (cutting prepared pages off the end
+    // of the file costs ~0.18 s per GB: the pages go back one by one)
+    void set_limit(size_t b)
+    {
+        { std::lock_guard<std::mutex> lk(mu); limit = b; }
+        cv.notify_all();
+    }
 };
-static float g_sink_ms[4];      // allocate, map (prepare thread); wait for that thread (writer); 1 = the mapping was used
+static float g_sink_ms[12];      // allocate + populate, map (prepare threads); wait for them (writer); 1 = the mapping was used; streaming: wait for the coder, wait for the DMA, host copies / pwrite, wait for a ring slot, the streaming loop as a whole, stopping the prepare thread, cutting the file
+static std::mutex g_rel_mu; static std::condition_variable g_rel_cv; static int g_rel_pending = 0;
 static void bam_sink_drop(telr_ctx *ctx)
 {
     BamSink *k = ctx->bam_sink;
     if (!k) return;
+    { std::lock_guard<std::mutex> lk(k->mu); k->stop = true; }
+    k->cv.notify_all();
     if (k->th.joinable()) k->th.join();
-    if (k->map) munmap(k->map, k->bytes);
-    if (k->fd >= 0) close(k->fd);
+    // taking a populated 4-GB mapping apart costs ~200 ms of page-table work: not on the caller's clock (the file is complete
+    // and cut to its length by now; the thread owns nothing but the mapping and the descriptor)
+    uint8_t *map = k->map; const size_t bytes = k->bytes; const int fd = k->fd;
+    if (map && bytes >= ((size_t)256 << 20)) {
+        { std::lock_guard<std::mutex> lk(g_rel_mu); ++g_rel_pending; }
+        std::thread([map, bytes, fd] {
+            munmap(map, bytes); if (fd >= 0) close(fd);
+            { std::lock_guard<std::mutex> lk(g_rel_mu); --g_rel_pending; }
+            g_rel_cv.notify_all();
+        }).detach();
+    } else { if (map) munmap(map, bytes); if (fd >= 0) close(fd); }
     delete k; ctx->bam_sink = nullptr;
+}
+// wait for the mappings of earlier output files to be taken apart (a process that writes one BAM never needs this; one that
+// writes several back to back would find its next telr_bam_prepare waiting for the address-space lock the release holds)
+extern "C" int telr_bam_release_wait(void)
+{
+    std::unique_lock<std::mutex> lk(g_rel_mu);
+    g_rel_cv.wait(lk, [] { return g_rel_pending == 0; });
+    return TELR_OK;
 }
 extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes)
 {
     if (!ctx || !bam_path || est_bytes <= 0) return TELR_E_ARG;
     bam_sink_drop(ctx);
     BamSink *k = new BamSink();
-    k->path = bam_path; k->bytes = ((size_t)est_bytes + 4095) & ~(size_t)4095;
-    k->th = std::thread([k] {
-        auto t0 = std::chrono::steady_clock::now();
-        k->fd = open(k->path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
-        if (k->fd < 0) return;
-        if (posix_fallocate(k->fd, 0, (off_t)k->bytes) != 0) return;
-        k->ms_alloc = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        t0 = std::chrono::steady_clock::now();
+    k->path = bam_path; k->bytes = ((size_t)est_bytes + BamSink::SLICE - 1) / BamSink::SLICE * BamSink::SLICE;
+    k->n_slices = k->bytes / BamSink::SLICE;
+    // file and mapping first (both are instant), so that the writer can use whatever part is ready when it arrives
+    auto t0 = std::chrono::steady_clock::now();
+    k->fd = open(k->path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
+    if (k->fd >= 0 && ftruncate(k->fd, (off_t)k->bytes) == 0) {
         void *m = mmap(nullptr, k->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, k->fd, 0);
-        if (m == MAP_FAILED) return;
-        k->map = (uint8_t*)m;
-        k->ms_map = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (m != MAP_FAILED) k->map = (uint8_t*)m;
+    }
+    k->ms_map = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (k->fd < 0 || !k->map) { k->over = true; ctx->bam_sink = k; return TELR_OK; }      // the writer falls back to plain streaming
+    static const bool no_populate = getenv("TELR_BAM_NO_POPULATE") != nullptr;
+    k->th = std::thread([k] {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < k->n_slices; ++i) {
+            { std::unique_lock<std::mutex> lk(k->mu); k->cv.wait(lk, [&] { return k->stop || i * BamSink::SLICE < k->limit; }); if (k->stop) break; }
+            if (posix_fallocate(k->fd, (off_t)(i * BamSink::SLICE), (off_t)BamSink::SLICE) != 0) break;
+            if (!no_populate) {
+                const int P = 4; const size_t q = BamSink::SLICE / P;
+                std::thread pt[P];
+                for (int t = 0; t < P; ++t) pt[t] = std::thread([k, i, t, q] {
+                    uint8_t *p = k->map + i * BamSink::SLICE + (size_t)t * q;
+                    if (madvise(p, q, 23 /* MADV_POPULATE_WRITE, Linux 5.14 */) != 0 && errno == EINVAL)
+                        for (size_t o = 0; o < q; o += 4096) ((volatile uint8_t*)p)[o] = 0;       // older kernels: touch the pages
+                });
+                for (int t = 0; t < P; ++t) pt[t].join();
+            }
+            { std::lock_guard<std::mutex> lk(k->mu); k->ready = i + 1; }
+            k->cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> lk(k->mu); k->over = true; }
+        k->cv.notify_all();
+        k->ms_alloc = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     });
     ctx->bam_sink = k;
     return TELR_OK;
@@ -1032,7 +1092,7 @@ static void progress_set(StreamProgress *p, uint64_t ready, int state, uint64_t 
     p->cv.notify_all();
 }
 static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, StreamProgress *prog, const void *tail, size_t tail_bytes, const char *path,
-                          int fd_open = -1, uint8_t *map_dst = nullptr, size_t map_bytes = 0, uint64_t *total_out = nullptr)
+                          int fd_open = -1, uint8_t *map_dst = nullptr, size_t map_bytes = 0, uint64_t *total_out = nullptr, BamSink *sink = nullptr, float *sink_wait_ms = nullptr)
 {
     const size_t CH = 32u << 20; const int R = 8;
     uint8_t *ring; TRY(ctx_hbuf_t(ctx, "bam_ring", CH * R, &ring));
@@ -1057,9 +1117,16 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
             size_t n;
             { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return copied > c || fail || last; }); if (fail) return; if (copied <= c) return; n = csz[c]; }
             const uint8_t *src = ring + (c % R) * CH;
+            const auto tw0 = std::chrono::steady_clock::now();
+            struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { g_sink_ms[6] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } acc{tw0};
             if (map_dst && (uint64_t)c * CH + n <= map_bytes) {
                 const int NT = std::max(4, std::min(16, host_threads())); const size_t piece = (n + NT - 1) / NT;      // 12.4 / 12.8 / 14.6 GB/s with 4 / 8 / 16 copiers (shm_io)
                 uint8_t *dst = map_dst + (uint64_t)c * CH;
+                if (sink) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    sink->wait_ready((size_t)c * CH + n);
+                    if (sink_wait_ms) *sink_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                }
                 HostPool::get().run(NT, [&](int i) { const size_t o = (size_t)i * piece; if (o < n) memcpy(dst + o, src + o, std::min(piece, n - o)); });
             } else {
                 size_t done = 0;
@@ -1076,7 +1143,9 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
         bool slot_wait = false;
         while (!ended && issued < landed + (size_t)R - 1) {
             { std::lock_guard<std::mutex> lk(mu); if (fail) break; if (issued >= written + (size_t)R) { slot_wait = true; break; } }
+            const auto tp0 = std::chrono::steady_clock::now();
             const int64_t n = chunk_bytes(issued, issued == landed);        // nothing in flight: wait for the producer
+            g_sink_ms[4] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tp0).count();
             if (n == -2) break;
             if (n < 0) { rc = TELR_E_HIP; break; }
             if (n == 0) { ended = true; break; }
@@ -1089,12 +1158,18 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
         { std::lock_guard<std::mutex> lk(mu); if (fail) break; }
         if (rc != TELR_OK) break;
         if (landed < issued) {
+            const auto te0 = std::chrono::steady_clock::now();
             if (hipEventSynchronize(ev[landed % R]) != hipSuccess) { rc = TELR_E_HIP; break; }
+            g_sink_ms[5] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - te0).count();
             ++landed;
             { std::lock_guard<std::mutex> lk(mu); copied = landed; }
             cv.notify_all();
         } else if (ended) break;
-        else if (slot_wait) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return issued < written + (size_t)R || fail; }); }
+        else if (slot_wait) {
+            const auto ts0 = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return issued < written + (size_t)R || fail; });
+            g_sink_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - ts0).count();
+        }
     }
     { std::lock_guard<std::mutex> lk(mu); if (rc != TELR_OK) fail = true; last = true; }
     cv.notify_all();
@@ -1102,7 +1177,7 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
     for (int i = 0; i < R; ++i) (void)hipEventDestroy(ev[i]);
     if (fail && rc == TELR_OK) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
     if (rc == TELR_OK && tail_bytes) { if (map_dst && total + tail_bytes <= map_bytes) memcpy(map_dst + total, tail, tail_bytes); else if (pwrite(fd, tail, tail_bytes, (off_t)total) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
-    if (rc == TELR_OK && fd_open >= 0 && ftruncate(fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;
+    if (rc == TELR_OK && fd_open >= 0 && !sink && ftruncate(fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;      // with a sink: cut by the caller, once its threads have stopped
     if (fd_open < 0) close(fd);
     if (total_out) *total_out = total;
     return rc;
@@ -1113,16 +1188,21 @@ static int sink_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, Str
     BamSink *k = ctx->bam_sink;
     memset(g_sink_ms, 0, sizeof(g_sink_ms));
     if (!k || k->path != path) { if (k) bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path); }
-    auto t0 = std::chrono::steady_clock::now();
-    if (k->th.joinable()) k->th.join();
-    g_sink_ms[0] = k->ms_alloc; g_sink_ms[1] = k->ms_map;
-    g_sink_ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (k->fd < 0) { bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path); }
+    if (k->fd < 0 || !k->map) { bam_sink_drop(ctx); return stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path); }
     uint64_t total = 0;
-    int rc = stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path, k->fd, k->map, k->map ? k->bytes : 0, &total);
-    g_sink_ms[3] = (k->map && total + tail_bytes <= k->bytes) ? 1.f : 0.f;
-    bam_sink_drop(ctx);
-    return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](int i) { const auto t1 = std::chrono::steady_clock::now(); g_sink_ms[i] = std::chrono::duration<float, std::milli>(t1 - t0).count(); t0 = t1; };
+    int rc = stream_to_file(ctx, d_img, bytes, prog, tail, tail_bytes, path, k->fd, k->map, k->bytes, &total, k, &g_sink_ms[2]);
+    lap(8);
+    { std::lock_guard<std::mutex> lk(k->mu); k->stop = true; }      // slices past the end of the image are not needed
+    k->cv.notify_all();
+    if (k->th.joinable()) k->th.join();
+    lap(9);
+    if (rc == TELR_OK && ftruncate(k->fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;
+    lap(10);
+    g_sink_ms[0] = k->ms_alloc; g_sink_ms[1] = k->ms_map;
+    g_sink_ms[3] = total + tail_bytes <= k->bytes ? 1.f : 0.f;
+    return rc;          // the caller drops the sink once its other host threads are done: taking the mapping apart holds the address-space lock they allocate under
 }
 extern "C" int telr_debug_bam_sink_ms(float *out) { if (!out) return TELR_E_ARG; memcpy(out, g_sink_ms, sizeof(g_sink_ms)); return TELR_OK; }
 
@@ -1312,6 +1392,7 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
         }
         prog = new StreamProgress();
         StreamProgress *pg = prog; uint64_t *coff_p = coff.data(); hipStream_t st2 = ctx->side[0]; const int device = ctx->device;
+        BamSink *sk = ctx->bam_sink && ctx->bam_sink->path == bam_path ? ctx->bam_sink : nullptr;
         producer = std::thread([=]() mutable {
             (void)hipSetDevice(device);
             uint64_t off = 0; size_t g = 0; bool ok = true;
@@ -1319,6 +1400,8 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
                 const size_t nb = std::min(gs, nblk - b0);
                 if (hipEventSynchronize(evg[g]) != hipSuccess) { ok = false; break; }
                 for (size_t b = b0; b < b0 + nb; ++b) { h_coff[b] = off; coff_p[b] = off; off += h_csize[b]; }
+                // the file's length, extrapolated from the blocks coded so far (records are sorted by position: the groups are alike; 1.5 % + 4 MB on top)
+                if (sk) sk->set_limit(b0 + nb >= nblk ? (size_t)off + 28 : (size_t)((double)off * (double)nblk / (double)(b0 + nb) * 1.015) + ((size_t)4 << 20));
                 if (hipMemcpyAsync(d_coff + b0, h_coff + b0, nb * 8, hipMemcpyHostToDevice, st2) != hipSuccess) { ok = false; break; }
                 hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)nb), dim3(256), 0, st2, d_slots, d_csize, d_coff, d_c, (uint32_t)b0);
                 if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st2) != hipSuccess) { ok = false; break; }
@@ -1342,6 +1425,7 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     g_bam_times.ms[5] = ms_since(t0);
     if (bai_starter.joinable()) bai_starter.join();
     if (bai_th.joinable()) bai_th.join();
+    bam_sink_drop(ctx);
     g_bam_times.ms[6] = bai_ms;
     if (prog) { if (prog->state < 0 && rc == TELR_OK) rc = TELR_E_HIP; delete prog; }
     if (rc == TELR_OK && write_index) {

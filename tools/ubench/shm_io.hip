@@ -188,6 +188,58 @@ int main(int argc, char **argv)
         printf("fallocate (%.3f s) + memcpy into the mapping of the allocated file, %2d threads: %.1f GB/s\n", t_fa, T, total / 1e9 / dt);
         munmap(m, total); close(fd);
     }
+    // 8. fallocate, mmap, pre-fault the mapping (MADV_POPULATE_WRITE with P threads on slices; the pages exist, only the page
+    //    table is filled), then memcpy with 16 threads: is the 14.6 GB/s above the fault path or the memory?
+    if (argc > 2) for (int P : {1, 4, 8}) {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        double t0 = now();
+        if (posix_fallocate(fd, 0, (off_t)total) != 0) return 1;
+        double t_fa = now() - t0;
+        char *m = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        t0 = now();
+        {
+            std::vector<std::thread> th; int rc_all = 0;
+            for (int t = 0; t < P; ++t) th.emplace_back([&, t] {
+                size_t lo = total / P * t, hi = t == P - 1 ? total : total / P * (t + 1);
+                if (madvise(m + lo, hi - lo, 23 /* MADV_POPULATE_WRITE */) != 0) rc_all = 1;
+            });
+            for (auto &x : th) x.join();
+            if (rc_all) printf("populate failed\n");
+        }
+        double t_pop = now() - t0;
+        for (int T : {4, 16}) {
+            t0 = now();
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+                const size_t piece = 8u << 20;
+                for (size_t o = (size_t)t * piece; o < total; o += (size_t)T * piece) memcpy(m + o, (char*)h + (o % chunk), std::min(piece, total - o));
+            });
+            for (auto &x : th) x.join();
+            double dt = now() - t0;
+            printf("fallocate (%.3f s) + populate with %d thread(s) (%.3f s) + memcpy into the populated mapping, %2d threads: %.1f GB/s\n", t_fa, P, t_pop, T, total / 1e9 / dt);
+        }
+        munmap(m, total); close(fd);
+    }
+    // 9. the same without fallocate: populate allocates, zeroes and maps (P threads on slices)
+    if (argc > 2) for (int P : {1, 4, 8}) {
+        unlink(path);
+        int fd = open(path, O_CREAT | O_RDWR | O_TRUNC, 0600);
+        if (ftruncate(fd, (off_t)total) != 0) return 1;
+        char *m = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        double t0 = now();
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < P; ++t) th.emplace_back([&, t] {
+                size_t lo = total / P * t, hi = t == P - 1 ? total : total / P * (t + 1);
+                madvise(m + lo, hi - lo, 23);
+            });
+            for (auto &x : th) x.join();
+        }
+        double t_pop = now() - t0;
+        printf("ftruncate + populate (allocates) with %d thread(s): %.3f s = %.1f GB/s\n", P, t_pop, total / 1e9 / t_pop);
+        munmap(m, total); close(fd);
+    }
     unlink(path);
     // 5. host-side deflate / crc32 rates are measured by the library's own writer (bench.py --bam-leg host)
     hipFree(d); hipHostFree(h);

@@ -171,8 +171,11 @@ int32_t telr_seqset_count(const telr_seqset *s);
 typedef struct telr_fasta telr_fasta;
 int  telr_fasta_load(const char *path, telr_fasta **out);
 int32_t telr_fasta_count(const telr_fasta *f);
-int64_t telr_fasta_bases(const telr_fasta *f);
-const char *telr_fasta_seq(const telr_fasta *f);                 /* concatenated bases */
+int64_t telr_fasta_bases(const telr_fasta *f);                  /* sum of the lengths */
+int64_t telr_fasta_extent(const telr_fasta *f);                 /* bytes behind telr_fasta_seq that the offsets may point into */
+const char *telr_fasta_seq(const telr_fasta *f);                 /* base buffer: sequence i = [off[i], off[i] + len[i]); the sequences are
+                                                                    packed end to end, or -- when every sequence of the file sits on one line --
+                                                                    the buffer is the mapped file itself and nothing was copied */
 const int64_t *telr_fasta_off(const telr_fasta *f);
 const int32_t *telr_fasta_len(const telr_fasta *f);
 const char *const *telr_fasta_names(const telr_fasta *f);

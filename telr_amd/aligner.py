@@ -62,7 +62,21 @@ class Engine:
         self.L.telr_last_dp_classes(self.h, a.ctypes.data)
         return a.reshape(N_DPCLS, 4)
 
+    def worker(self):
+        """A second context on the same device (created on first use, closed with this one): a host thread can run an engine
+        call on it while this context runs another -- contexts are not re-entrant, different contexts are independent
+        (the library's sub-batch workers are such contexts).  Sequence sets and indexes are plain device data and may be
+        used from either."""
+        w = getattr(self, "_worker", None)
+        if w is None:
+            w = self._worker = Engine(self.device)
+        return w
+
     def close(self):
+        w = getattr(self, "_worker", None)
+        if w is not None:
+            self._worker = None
+            w.close()
         if getattr(self, "h", None):
             self.L.telr_destroy(self.h)
             self.h = None
@@ -93,13 +107,15 @@ class SeqSet:
     def bases(self):
         return int(self.eng.L.telr_seqset_bases(self.h))
 
-    def subset(self, idx):
-        """new set = copies of sequences idx (repeats allowed), gathered on the device from the packed form"""
+    def subset(self, idx, eng=None):
+        """new set = copies of sequences idx (repeats allowed), gathered on the device from the packed form
+        (eng: the context whose stream does the gather; default the one the set was made on)"""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
+        eng = self.eng if eng is None else eng
         sub = SeqSet.__new__(SeqSet)
-        sub.eng = self.eng
+        sub.eng = eng
         h = C.c_void_p()
-        self.eng._chk(self.eng.L.telr_seqset_subset(self.eng.h, self.h, len(idx), idx.ctypes.data, C.byref(h)), "telr_seqset_subset")
+        eng._chk(eng.L.telr_seqset_subset(eng.h, self.h, len(idx), idx.ctypes.data, C.byref(h)), "telr_seqset_subset")
         sub.h = h; sub.len = self.len[idx].copy(); sub.n = len(idx)
         return sub
 

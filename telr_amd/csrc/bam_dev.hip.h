@@ -1022,7 +1022,7 @@ static void bam_sink_drop(telr_ctx *ctx)
     if (map && bytes >= ((size_t)256 << 20)) {
         { std::lock_guard<std::mutex> lk(g_rel_mu); ++g_rel_pending; }
         std::thread([map, bytes, fd] {
-            munmap(map, bytes); if (fd >= 0) close(fd);
+            unmap_in_pieces(map, bytes); if (fd >= 0) close(fd);
             { std::lock_guard<std::mutex> lk(g_rel_mu); --g_rel_pending; }
             g_rel_cv.notify_all();
         }).detach();

@@ -4,14 +4,19 @@
 //   FASTA: record starts ('>' at the start of a line) are found by worker threads over slices of the mapped file, then every
 //          record is measured and copied (line breaks dropped) in parallel.
 //   FASTQ: four-line records, walked line by line ('@' may start a quality line, so records cannot be found by a scan).
+//   When every sequence sits on ONE line (FASTQ; FASTA as basecallers and read simulators write it) nothing is copied: the
+//   base buffer IS the mapped file and the offsets point at the sequence lines (a 30x read set: 4 GB not allocated, not
+//   copied and not given back).
 // Names end at the first white space, as minimap2 / ngmlr print them.
 #pragma once
 struct telr_fasta {
     // the base buffer is raw memory: a std::vector would zero 4 GB on one thread before the copy threads overwrite it
-    char *seq = nullptr; size_t seq_bytes = 0; std::vector<int64_t> off; std::vector<int32_t> len;
+    char *seq = nullptr; size_t seq_bytes = 0, extent = 0; std::vector<int64_t> off; std::vector<int32_t> len;
     std::vector<char> name_buf; std::vector<const char*> names;
-    ~telr_fasta() { free(seq); }
+    void *map = nullptr; size_t map_bytes = 0;        // set: `seq` points into this mapping of the file (not owned memory)
+    ~telr_fasta() { if (map) unmap_in_pieces(map, map_bytes); else free(seq); }
 };
+extern "C" int64_t telr_fasta_extent(const telr_fasta *f) { return f ? (int64_t)f->extent : 0; }
 extern "C" void telr_fasta_free(telr_fasta *f) { delete f; }
 extern "C" int32_t telr_fasta_count(const telr_fasta *f) { return f ? (int32_t)f->len.size() : 0; }
 extern "C" const char *telr_fasta_seq(const telr_fasta *f) { return f ? f->seq : nullptr; }
@@ -68,34 +73,52 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     F->len.resize(nr); F->off.resize(nr);
     std::vector<int64_t> nlen(nr);
     bool too_long = false;
+    std::atomic<int> folded{0};                // records whose sequence is not one plain line
     parallel_ranges(NT, (int)nr, [&](int, int r0, int r1) {
+        int fold = 0;
         for (int r = r0; r < r1; ++r) {
-            int64_t bases = 0;
-            for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') --l; bases += (int64_t)l; i = e + 1; }
+            int64_t bases = 0; int lines = 0;
+            for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') { --l; ++fold; } bases += (int64_t)l; if (l) ++lines; i = e + 1; }
+            if (lines > 1) ++fold;
             if (bases > INT32_MAX) { too_long = true; bases = 0; }
             F->len[r] = (int32_t)bases;
             size_t h = recs[r].hdr, he = recs[r].body;
             size_t k = h; while (k < he && p[k] != ' ' && p[k] != '\t' && p[k] != '\n' && p[k] != '\r') ++k;
             nlen[r] = (int64_t)(k - h);
         }
+        if (fold) folded += fold;
     });
     if (too_long) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
     int64_t tot = 0, ntot = 0;
     std::vector<int64_t> noff(nr);
     for (size_t r = 0; r < nr; ++r) { F->off[r] = tot; tot += F->len[r]; noff[r] = ntot; ntot += nlen[r] + 1; }
-    F->seq = (char*)malloc((size_t)tot + 1); F->seq_bytes = (size_t)tot;
-    if (!F->seq) { munmap((void*)p, n); delete F; return TELR_E_NOMEM; }
+    static const bool no_zero_copy = getenv("TELR_FASTA_COPY") != nullptr;
+    const bool in_place = folded.load() == 0 && !no_zero_copy;
+    F->seq_bytes = (size_t)tot;
+    if (in_place) {
+        // a sequence may be empty or its line may be preceded by blank lines: the offset is where its bases start
+        F->seq = (char*)p; F->extent = n; F->map = (void*)p; F->map_bytes = n;
+    } else {
+        F->seq = (char*)malloc((size_t)tot + 1); F->extent = (size_t)tot;
+        if (!F->seq) { munmap((void*)p, n); delete F; return TELR_E_NOMEM; }
+    }
     F->name_buf.resize((size_t)ntot); F->names.resize(nr);
     parallel_ranges(NT, (int)nr, [&](int, int r0, int r1) {
         for (int r = r0; r < r1; ++r) {
-            char *d = F->seq + F->off[r];
-            for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') --l; memcpy(d, p + i, l); d += l; i = e + 1; }
+            if (in_place) {
+                size_t i = recs[r].body;
+                while (i < recs[r].end && p[i] == '\n') ++i;          // blank lines before the sequence line
+                F->off[r] = (int64_t)(F->len[r] ? i : 0);
+            } else {
+                char *d = F->seq + F->off[r];
+                for (size_t i = recs[r].body; i < recs[r].end; ) { size_t e = line_end(i); if (e > recs[r].end) e = recs[r].end; size_t l = e - i; if (l && p[e - 1] == '\r') --l; memcpy(d, p + i, l); d += l; i = e + 1; }
+            }
             char *nm = F->name_buf.data() + noff[r];
             memcpy(nm, p + recs[r].hdr, (size_t)nlen[r]); nm[nlen[r]] = 0;
             F->names[r] = nm;
         }
     });
-    munmap((void*)p, n);
+    if (!in_place) munmap((void*)p, n);
     *out = F;
     return TELR_OK;
 }

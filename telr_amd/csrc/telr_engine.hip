@@ -23,6 +23,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sys/mman.h>
 #include <vector>
 #include "../../include/telr_hip.h"
 #include "kernels.hip.h"
@@ -1015,6 +1016,13 @@ static int host_threads()
     if (n > 48) n = 48;
     cached = n;
     return n;
+}
+// munmap of a large populated mapping keeps the address-space lock for its whole page-table walk (~50 ms per GB): every other
+// mmap / munmap / hipFree / fork of the process waits behind it.  Piece by piece, the others get their turn in between.
+static void unmap_in_pieces(void *p, size_t bytes)
+{
+    const size_t piece = (size_t)32 << 20;
+    for (size_t o = 0; o < bytes; o += piece) { munmap((char*)p + o, std::min(piece, bytes - o)); std::this_thread::yield(); }
 }
 // Persistent worker pool for the host phases (spawning ~24 threads per phase costs more than some of the phases).
 // One job at a time; run() hands out task indices 0..n-1 to the workers and the caller and returns when all are done.

@@ -75,7 +75,8 @@ class FastaFile:
             raise _lib.TelrError("telr_fasta_load(%s): %s" % (path, self.L.telr_strerror(rc).decode()))
         self.h = h
         self.n = int(self.L.telr_fasta_count(h))
-        nb = int(self.L.telr_fasta_bases(h))
+        nb = int(self.L.telr_fasta_extent(h))        # the packed bases, or the whole mapped file when its sequences are used in place
+        self.bases = int(self.L.telr_fasta_bases(h))
 
         def view(ptr, count, dt):
             if not count or not ptr:

@@ -6,7 +6,7 @@ from . import telr_te, telr_af, telr_liftover
 
 
 def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, presets="ont", ref_te_rows=None,
-             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50), read_set=None, polish=None, polish_iterations=1):
+             flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50), read_set=None, polish=None, polish_iterations=1, overlap_af=True):
     """loci: list of dicts(name, contig, alt, reads).  With `read_set` (the stage-1 read SeqSet resident on the
     device) a locus gives `read_idx` (indices into it) instead of `reads`.  polish="pileup": the draft contigs are first
     polished on the device with the locus' reads (telr_assembly.polish_consensus: the polishing loop of
@@ -22,17 +22,29 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
         raise ValueError("polish must be None or 'pileup'")
     names = [l["name"] for l in loci]
     contigs = {l["name"]: l["contig"] for l in loci}
-    ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
-                                            lib_names, lib_seqs, presets)
-    mapper = telr_liftover.engine_flank_mapper(ref_index, ref_names)
-    reports, summary = telr_liftover.liftover(mapper, contigs, ann, ref_seq, ref_te_rows, flank_len, gap, overlap)
-    contig_te = {}
-    for r in ann:                       # one annotation per contig feeds the AF step (first one wins, as a dict would)
-        contig_te.setdefault(r[0], (int(r[1]), int(r[2])))
-    if read_set is not None:
-        freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["read_idx"] for l in loci}, presets, *af_params, read_set=read_set)
-    else:
-        freqs = telr_af.get_af(backend, contigs, contig_te, {l["name"]: l["reads"] for l in loci}, presets, *af_params)
+    reads_by_locus = {l["name"]: (l["read_idx"] if read_set is not None else l["reads"]) for l in loci}
+    # S6 (window reads -> forward / reverse-complement contig) needs the contigs only: on an engine with a second context it
+    # runs in a host thread of its own while S4, S5, S7 and the liftover tree run here; the annotation meets it at the depth step
+    job = None
+    if overlap_af and loci and hasattr(backend, "worker"):
+        job = telr_af.af_start(backend.worker(), contigs, reads_by_locus, presets, read_set, threaded=True)
+    try:
+        ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
+                                                lib_names, lib_seqs, presets)
+        mapper = telr_liftover.engine_flank_mapper(ref_index, ref_names)
+        reports, summary = telr_liftover.liftover(mapper, contigs, ann, ref_seq, ref_te_rows, flank_len, gap, overlap)
+        contig_te = {}
+        for r in ann:                       # one annotation per contig feeds the AF step (first one wins, as a dict would)
+            contig_te.setdefault(r[0], (int(r[1]), int(r[2])))
+        if job is not None:
+            j, job = job, None
+            freqs = telr_af.af_finish(j, contig_te, *af_params)
+            freqs = {n: freqs[n] for n in contig_te if n in freqs}          # in annotation order, as get_af returns them
+        else:
+            freqs = telr_af.get_af(backend, contigs, contig_te, reads_by_locus, presets, *af_params, read_set=read_set)
+    finally:
+        if job is not None:
+            job.release()
     out = {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
     if polish == "pileup":
         out["contigs"] = contigs

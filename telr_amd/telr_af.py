@@ -98,6 +98,133 @@ def freq_table(medians):
     return d
 
 
+class AfJob:
+    """the S6 mapping of a set of loci, possibly still running in a host thread (af_start)"""
+    def __init__(self):
+        self.thread = None; self.exc = None; self.names = []; self.tindex = {}; self.ix = None; self.r = None; self.qs = None; self.lens = {}
+
+    def wait(self):
+        if self.thread is not None:
+            self.thread.join(); self.thread = None
+        if self.exc is not None:
+            e, self.exc = self.exc, None
+            self.release()
+            raise e
+
+    def release(self):
+        if self.thread is not None:
+            self.thread.join(); self.thread = None
+        if self.r is not None and self.ix is not None:
+            self.ix.free_raw(self.r)
+        self.r = None
+        if self.qs is not None and hasattr(self.qs, "free"):
+            self.qs.free()
+        self.qs = None; self.ix = None
+
+
+def _af_pack(job, contigs):
+    """-> (buffer, offsets, lengths) of the targets: every contig forward and reverse-complemented"""
+    names = job.names
+    # targets: contig k forward at 2k, reverse-complemented at 2k+1, as ONE byte buffer.  The reverse complement of the
+    # concatenation of all contigs is the concatenation of their reverse complements in reverse order: one table lookup and
+    # one reversal for the whole set instead of a translate + slice + decode per contig
+    fw = [contigs[n].encode() if isinstance(contigs[n], str) else bytes(contigs[n]) for n in names]
+    lens = np.array([len(b) for b in fw], np.int64)
+    cat = np.frombuffer(b"".join(fw), np.uint8)
+    rc_cat = _COMP_NP[cat][::-1]
+    ends = np.cumsum(lens); starts = ends - lens; total = int(ends[-1])
+    tlen = np.repeat(lens, 2)
+    toff = np.zeros(2 * len(names), np.int64); toff[1:] = np.cumsum(tlen)[:-1]
+    tbuf = np.empty(2 * total, np.uint8)
+    for k in range(len(names)):               # two slice copies per contig (a gather over all bases at once is 50x slower)
+        L = int(lens[k]); o = int(toff[2 * k])
+        tbuf[o:o + L] = cat[starts[k]:ends[k]]
+        tbuf[o + L:o + 2 * L] = rc_cat[total - ends[k]:total - starts[k]]
+    return tbuf, toff, tlen.astype(np.int32)
+
+
+def _af_map(job, engine, targets, reads_by_locus, presets, read_set):
+    """index of the targets, window reads twice, ONE engine call"""
+    from .presets import preset
+    import os, time
+    trace = os.environ.get("TELR_AF_TRACE"); t0 = time.time(); marks = []
+    io, mo = preset("map-ont" if presets == "ont" else "map-pb")
+    names = job.names
+    job.ix = engine.index(targets, io)
+    marks.append(("index", time.time() - t0))
+    counts = np.array([len(reads_by_locus[n]) for n in names], np.int64)
+    qtarget_fw = np.repeat(np.arange(len(names), dtype=np.int32) * 2, counts)
+    # ONE engine call for both orientations: every read appears twice, once confined to the forward contig of its locus
+    # and once to the reverse-complement contig (the reference runs two minimap2 jobs per locus, TELR_te.py:644-646)
+    if read_set is not None:
+        idx = np.concatenate([np.asarray(reads_by_locus[n], np.int32) for n in names]) if len(names) else np.zeros(0, np.int32)
+        job.qs = read_set.subset(np.concatenate([idx, idx]), eng=engine) if hasattr(read_set, "eng") else read_set.subset(np.concatenate([idx, idx]))
+    else:
+        queries = [r for n in names for r in reads_by_locus[n]]
+        job.qs = engine.seqset(queries + queries)
+    qtarget_all = np.concatenate([qtarget_fw, qtarget_fw + 1])
+    marks.append(("subset", time.time() - t0))
+    job.r = job.ix.map_raw(job.qs, mo, qtarget=qtarget_all)
+    marks.append(("map", time.time() - t0))
+    if trace:
+        import sys
+        sys.stderr.write("af_map: " + ", ".join("%s %.1f ms" % (k, v * 1e3) for k, v in marks) + " | engine stages " +
+                         ", ".join("%s %.1f" % kv for kv in engine.stage_ms().items() if kv[1] > 0.5) + "\n")
+
+
+def af_start(engine, contigs, reads_by_locus, presets="ont", read_set=None, names=None, threaded=False):
+    """Start the S6 realignment (window reads -> forward and reverse-complement contig of their locus) of the loci `names`
+    (default: every locus that has a contig and reads).  It needs no annotation: with threaded=True it runs in a host thread
+    on `engine` (which must then be a context nothing else uses meanwhile: Engine.worker()) while the caller annotates and
+    lifts the same loci.  -> AfJob for af_finish."""
+    job = AfJob()
+    job.names = [n for n in (names if names is not None else contigs) if n in contigs and n in reads_by_locus]
+    job.tindex = {n: 2 * k for k, n in enumerate(job.names)}
+    job.lens = {n: len(contigs[n]) for n in job.names}
+    if not job.names:
+        return job
+    targets = _af_pack(job, contigs)          # in the caller's thread: Python-bound work gains nothing from a second thread
+    if not threaded:
+        _af_map(job, engine, targets, reads_by_locus, presets, read_set)
+        return job
+    import threading
+
+    def run():
+        try:
+            _af_map(job, engine, targets, reads_by_locus, presets, read_set)
+        except BaseException as e:          # re-raised by wait()
+            job.exc = e
+    job.thread = threading.Thread(target=run, name="telr-af-map"); job.thread.start()
+    return job
+
+
+def af_finish(job, contig_te, flank_interval=100, flank_offset=200, te_interval=50, te_offset=50):
+    """depth medians of the 8 intervals per annotated locus (contig_te: {locus: (start, end)}) on the job's records
+    + the frequency arithmetic -> {locus name: te_freq dict}"""
+    try:
+        names = [n for n in job.names if n in contig_te]
+        if not names:
+            job.wait()
+            return {}
+        meds = {n: {"fw": [None, None, None, None], "rc": [None, None, None, None]} for n in names}
+        iv_t, iv_s, iv_e, slots = [], [], [], []
+        for tag in ("fw", "rc"):
+            for n in names:
+                ivs = locus_intervals(contig_te[n][0], contig_te[n][1], job.lens[n], flank_interval, flank_offset, te_interval, te_offset)[tag]
+                for k, x in enumerate(ivs):
+                    if x is None:
+                        continue
+                    a, b = depth_region(*x)
+                    iv_t.append(job.tindex[n] + (1 if tag == "rc" else 0)); iv_s.append(a); iv_e.append(b); slots.append((n, tag, k))
+        job.wait()                            # the intervals above were laid out while the mapping was still running
+        med = job.ix.depth_medians(job.r, iv_t, iv_s, iv_e) if iv_t else []
+        for (n, tag, k), v in zip(slots, med):
+            meds[n][tag][k] = None if np.isnan(v) else float(v)
+        return {n: freq_table(meds[n]) for n in names}
+    finally:
+        job.release()
+
+
 def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_interval=100, flank_offset=200,
            te_interval=50, te_offset=50, read_set=None):
     """Batched replacement of get_af (:578-838).
@@ -107,60 +234,7 @@ def get_af(engine, contigs, contig_te, reads_by_locus, presets="ont", flank_inte
     by prep_assembly_inputs(read_type="all"), TELR_assembly.py:384-462) or, with `read_set` (the stage-1
     SeqSet already resident on the device), {locus name: [read indices]}: the window reads are then gathered on
     the device instead of being packed and uploaded again.
-    Returns {locus name: te_freq dict}.
+    Returns {locus name: te_freq dict}.  (= af_start on the annotated loci + af_finish.)
     """
-    from .presets import preset
-    io, mo = preset("map-ont" if presets == "ont" else "map-pb")
-    names = [n for n in contig_te if n in contigs and n in reads_by_locus]
-    if not names:
-        return {}
-    # targets: contig k forward at 2k, reverse-complemented at 2k+1, as ONE byte buffer.  The reverse complement of the
-    # concatenation of all contigs is the concatenation of their reverse complements in reverse order: one table lookup and
-    # one reversal for the whole set instead of a translate + slice + decode per contig
-    tindex = {n: 2 * k for k, n in enumerate(names)}
-    fw = [contigs[n].encode() if isinstance(contigs[n], str) else bytes(contigs[n]) for n in names]
-    lens = np.array([len(b) for b in fw], np.int64)
-    cat = np.frombuffer(b"".join(fw), np.uint8)
-    rc_cat = _COMP_NP[cat][::-1]
-    ends = np.cumsum(lens); starts = ends - lens; total = int(ends[-1])
-    tlen = np.repeat(lens, 2)
-    toff = np.zeros(2 * len(names), np.int64); toff[1:] = np.cumsum(tlen)[:-1]
-    tbuf = np.empty(2 * total, np.uint8)
-    for k in range(len(names)):
-        L = int(lens[k]); o = int(toff[2 * k])
-        tbuf[o:o + L] = cat[starts[k]:ends[k]]
-        tbuf[o + L:o + 2 * L] = rc_cat[total - ends[k]:total - starts[k]]
-    ix = engine.index((tbuf, toff, tlen.astype(np.int32)), io)
-    counts = np.array([len(reads_by_locus[n]) for n in names], np.int64)
-    qtarget_fw = np.repeat(np.arange(len(names), dtype=np.int32) * 2, counts)
-    # ONE engine call for both orientations: every read appears twice, once confined to the forward contig of its locus
-    # and once to the reverse-complement contig (the reference runs two minimap2 jobs per locus, TELR_te.py:644-646)
-    if read_set is not None:
-        idx = np.concatenate([np.asarray(reads_by_locus[n], np.int32) for n in names]) if len(names) else np.zeros(0, np.int32)
-        qs = read_set.subset(np.concatenate([idx, idx]))
-    else:
-        queries = [r for n in names for r in reads_by_locus[n]]
-        qs = engine.seqset(queries + queries)
-    qtarget_all = np.concatenate([qtarget_fw, qtarget_fw + 1])
-    out = {}
-    meds = {n: {"fw": [None, None, None, None], "rc": [None, None, None, None]} for n in names}
-    r = ix.map_raw(qs, mo, qtarget=qtarget_all)
-    try:
-        iv_t, iv_s, iv_e, slots = [], [], [], []
-        for tag in ("fw", "rc"):
-            for n in names:
-                L = len(contigs[n])
-                ivs = locus_intervals(contig_te[n][0], contig_te[n][1], L, flank_interval, flank_offset, te_interval, te_offset)[tag]
-                for k, x in enumerate(ivs):
-                    if x is None:
-                        continue
-                    a, b = depth_region(*x)
-                    iv_t.append(tindex[n] + (1 if tag == "rc" else 0)); iv_s.append(a); iv_e.append(b); slots.append((n, tag, k))
-        med = ix.depth_medians(r, iv_t, iv_s, iv_e) if iv_t else []
-        for (n, tag, k), v in zip(slots, med):
-            meds[n][tag][k] = None if np.isnan(v) else float(v)
-    finally:
-        ix.free_raw(r)
-    for n in names:
-        out[n] = freq_table(meds[n])
-    return out
+    job = af_start(engine, contigs, reads_by_locus, presets, read_set, names=[n for n in contig_te])
+    return af_finish(job, contig_te, flank_interval, flank_offset, te_interval, te_offset)

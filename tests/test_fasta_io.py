@@ -1,6 +1,8 @@
 """The library's FASTA / FASTQ reader (telr_fasta_load, host code: runs without a GPU) against the plain Python reader on the
 bundled files and on awkward inputs: multi-line records, CR LF line ends, empty records, a last line without a line break,
 names cut at white space, '@' at the start of a FASTQ quality line."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,7 +16,11 @@ def _same(path):
     assert f.names == names
     assert f.seqs() == seqs
     buf, off, ln = f.triple
-    assert int(ln.sum()) == len(buf) and (np.diff(off) == ln[:-1]).all()
+    assert int(ln.sum()) == f.bases
+    if len(buf) == f.bases:                       # packed end to end (a copy)
+        assert (np.diff(off) == ln[:-1]).all()
+    else:                                         # the mapped file itself: every sequence inside it, in file order
+        assert len(buf) == os.path.getsize(path) and ((off + ln <= len(buf)).all()) and (np.diff(off[ln > 0]) > 0).all()
     f.close()
 
 
@@ -44,6 +50,37 @@ def test_awkward_fasta(tmp_path):
             for k in range(0, len(s), w):
                 fh.write(s[k:k + w] + "\n")
     _same(str(q))
+
+
+def test_single_line_records_are_used_in_place(tmp_path, monkeypatch):
+    """every sequence on one line: the base buffer is the mapped file (nothing copied); one folded or CR LF record: a packed copy;
+    both give the same names and sequences as the Python reader, and the same as the copying path (TELR_FASTA_COPY)"""
+    rng = np.random.default_rng(5)
+    seqs = ["".join(rng.choice(list("ACGTN"), int(rng.integers(0, 300)))) for _ in range(3000)]
+    p = tmp_path / "one.fa"
+    with open(p, "w") as fh:
+        for i, s in enumerate(seqs):
+            fh.write(">s%d desc\n%s\n" % (i, s))
+            if i % 97 == 0:
+                fh.write("\n")                   # a blank line between records
+    f = FastaFile(str(p))
+    buf, off, ln = f.triple
+    assert len(buf) == os.path.getsize(p) and f.bases == sum(len(x) for x in seqs)
+    assert f.seqs() == seqs and f.names == ["s%d" % i for i in range(len(seqs))]
+    f.close()
+    _same(str(p))
+    q = tmp_path / "folded.fa"
+    q.write_text(p.read_text() + ">last\nACGT\nAC\n")
+    g = FastaFile(str(q))
+    assert len(g.triple[0]) == g.bases == sum(len(x) for x in seqs) + 6 and g.seqs() == seqs + ["ACGTAC"]
+    g.close()
+    # last record without a line break, blank line before a sequence, empty record
+    r = tmp_path / "edge.fa"
+    r.write_bytes(b">a\n\nACGT\n>b\n>c\nGG")
+    h = FastaFile(str(r))
+    assert h.seqs() == ["ACGT", "", "GG"] and len(h.triple[0]) == os.path.getsize(r)
+    h.close()
+    _same(str(r))
 
 
 def test_fastq(tmp_path):

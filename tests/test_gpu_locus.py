@@ -66,6 +66,10 @@ def test_locus_bundle_with_resident_read_set(engine):
     a = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont")
     b = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci_idx, lib_names, lib, presets="ont", read_set=read_set)
     assert a["af"] == b["af"] and a["liftover"] == b["liftover"] and a["annotation"] == b["annotation"]
+    # S6 in a host thread on the engine's second context while S4 / S5 / S7 run (the default) = everything in turn on one context
+    for kw in ({}, {"read_set": read_set}):
+        c = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci_idx if kw else loci, lib_names, lib, presets="ont", overlap_af=False, **kw)
+        assert c["af"] == a["af"] and list(c["af"]) == list(a["af"]) and c["liftover"] == a["liftover"] and c["annotation"] == a["annotation"]
 
 
 def test_engine_screen_of_alt_sequences(engine, tmp_path):

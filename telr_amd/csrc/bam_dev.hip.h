@@ -51,6 +51,20 @@ __device__ __forceinline__ uint8_t *d_put_uint(uint8_t *p, uint32_t v)
     for (int i = nd - 1; i >= 0; --i) { p[i] = (uint8_t)('0' + v % 10u); v /= 10u; }
     return p + nd;
 }
+// a lane's piece of tag text, written four bytes at a time (a quarter of the store instructions; measured: no change in the
+// kernel's 29 ms for a 30x set, which is not bound by them)
+struct ByteW {
+    uint8_t *p; uint32_t acc; int k;
+    __device__ __forceinline__ void init(uint8_t *q) { p = q; acc = 0; k = 0; }
+    __device__ __forceinline__ void put(uint32_t b) { acc |= b << (8 * k); if (++k == 4) { d_st32(p, acc); p += 4; acc = 0; k = 0; } }
+    __device__ __forceinline__ void put_uint(uint32_t v)
+    {
+        uint64_t bcd = 0; int nd = 0;           // digits, last one first; read back from the low end: first one first
+        do { bcd = bcd << 4 | (uint64_t)(v % 10u); v /= 10u; ++nd; } while (v);
+        for (int i = 0; i < nd; ++i) { put('0' + (uint32_t)(bcd & 15u)); bcd >>= 4; }
+    }
+    __device__ __forceinline__ void flush() { for (int i = 0; i < k; ++i) p[i] = (uint8_t)(acc >> (8 * i)); k = 0; acc = 0; }
+};
 __device__ __forceinline__ int d_wave_sum(int v) { for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s); return v; }
 // inclusive prefix sum over the wave
 __device__ __forceinline__ int d_wave_incl(int v, int lane)
@@ -191,7 +205,7 @@ __device__ __forceinline__ void d_bam_walk(const BamArgs &A, const telr_aln &a, 
         if (!WRITE) { md_sum += md_b; cs_sum += cs_b; }
         else {
             const int mdi = d_wave_incl(md_b, lane), csi = d_wave_incl(cs_b, lane);
-            uint8_t *mp = md_p + md_base + (uint32_t)(mdi - md_b), *cp = cs_p + cs_base + (uint32_t)(csi - cs_b);
+            ByteW mp, cp; mp.init(md_p + md_base + (uint32_t)(mdi - md_b)); cp.init(cs_p + cs_base + (uint32_t)(csi - cs_b));
             md_base += (uint32_t)__shfl(mdi, 63); cs_base += (uint32_t)__shfl(csi, 63);
             if (have) {
                 if (op == 0) {
@@ -203,26 +217,27 @@ __device__ __forceinline__ void d_bam_walk(const BamArgs &A, const telr_aln &a, 
                             const int j = __ffs((int)mis) - 1, p = p0 + j; mis &= mis - 1u;
                             const uint32_t r_ = (uint32_t)(p - last - 1);
                             const uint8_t tc = d_base_char(tw, j), qc = d_base_char(qw, j);
-                            if (want_md) { mp = d_put_uint(mp, firstev ? run_in + r_ : r_); *mp++ = tc; }
-                            if (want_cs) { if (r_) { *cp++ = ':'; cp = d_put_uint(cp, r_); } *cp++ = '*'; *cp++ = tc | 32; *cp++ = qc | 32; }
+                            if (want_md) { mp.put_uint(firstev ? run_in + r_ : r_); mp.put(tc); }
+                            if (want_cs) { if (r_) { cp.put(':'); cp.put_uint(r_); } cp.put('*'); cp.put(tc | 32u); cp.put(qc | 32u); }
                             firstev = false; last = p;
                         }
                     }
                     const uint32_t tail = (uint32_t)(L - 1 - last);
-                    if (want_cs && tail) { *cp++ = ':'; cp = d_put_uint(cp, tail); }
+                    if (want_cs && tail) { cp.put(':'); cp.put_uint(tail); }
                 } else if (op == 1) {
                     if (want_cs) {
-                        *cp++ = '+';
-                        for (int p0 = 0; p0 < L; p0 += 32) { const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0); const int n = L - p0 < 32 ? L - p0 : 32; for (int j = 0; j < n; ++j) *cp++ = d_base_char(qw, j) | 32; }
+                        cp.put('+');
+                        for (int p0 = 0; p0 < L; p0 += 32) { const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0); const int n = L - p0 < 32 ? L - p0 : 32; for (int j = 0; j < n; ++j) cp.put(d_base_char(qw, j) | 32u); }
                     }
                 } else {
-                    if (want_md) { mp = d_put_uint(mp, run_in); *mp++ = '^'; }
-                    if (want_cs) *cp++ = '-';
+                    if (want_md) { mp.put_uint(run_in); mp.put('^'); }
+                    if (want_cs) cp.put('-');
                     for (int p0 = 0; p0 < L; p0 += 32) {
                         const B32 tw = d_fetch32(A.t2, A.tn, tb0 + ti + p0); const int n = L - p0 < 32 ? L - p0 : 32;
-                        for (int j = 0; j < n; ++j) { const uint8_t tc = d_base_char(tw, j); if (want_md) *mp++ = tc; if (want_cs) *cp++ = tc | 32; }
+                        for (int j = 0; j < n; ++j) { const uint8_t tc = d_base_char(tw, j); if (want_md) mp.put(tc); if (want_cs) cp.put(tc | 32u); }
                     }
                 }
+                mp.flush(); cp.flush();
             }
         }
         qi0 += __shfl(qinc, 63); ti0 += __shfl(tinc, 63);
@@ -1263,8 +1278,11 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     const int32_t nq = queries->n, nt = tg->n;
     const size_t n_mapped = r->alns.size();
     for (const telr_aln &a : r->alns) if (a.qid < 0 || a.qid >= nq || a.tid < 0 || a.tid >= nt) return TELR_E_ARG;
-    // ---- 1. records (+ pseudo records of the unmapped reads, in query order), names, header
+    // the CIGAR words (1.9 GB for a 30x set: 34 ms of PCIe) start their way back to the device before the host lays out records and names
     auto t0 = now();
+    uint32_t *d_cig; TRY(ctx_buf_t(ctx, "bam_cig", r->ncig + 1, &d_cig));
+    if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
+    // ---- 1. records (+ pseudo records of the unmapped reads, in query order), names, header
     std::vector<telr_aln> recs(r->alns);
     size_t n_unmapped = 0;
     if (!(flags & TELR_SAM_NO_UNMAPPED)) {
@@ -1282,9 +1300,9 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     const std::string head = bam_header(nt, tnames, tg->len.data(), rg_id, rg_sm, rg_lb, pg_line);
     const int rg_len = rg_id ? (int)strlen(rg_id) : 0;
     // ---- 2. upload
-    telr_aln *d_alns; uint32_t *d_cig; char *d_qn, *d_tn, *d_rg; int64_t *d_qnoff; int32_t *d_tnoff; BamInfo *d_info; uint32_t *d_size, *d_ord0, *d_ord; uint64_t *d_key, *d_key2, *d_szs, *d_ust, *d_rust;
+    telr_aln *d_alns; char *d_qn, *d_tn, *d_rg; int64_t *d_qnoff; int32_t *d_tnoff; BamInfo *d_info; uint32_t *d_size, *d_ord0, *d_ord; uint64_t *d_key, *d_key2, *d_szs, *d_ust, *d_rust;
     CrcTabs *d_tabs;
-    TRY(ctx_buf_t(ctx, "bam_alns", nrec, &d_alns)); TRY(ctx_buf_t(ctx, "bam_cig", r->ncig + 1, &d_cig));
+    TRY(ctx_buf_t(ctx, "bam_alns", nrec, &d_alns));
     TRY(ctx_buf_t(ctx, "bam_qn", qn_buf.size() + 1, &d_qn)); TRY(ctx_buf_t(ctx, "bam_tn", tn_buf.size() + 1, &d_tn)); TRY(ctx_buf_t(ctx, "bam_rg", (size_t)rg_len + 1, &d_rg));
     TRY(ctx_buf_t(ctx, "bam_qnoff", (size_t)nq + 1, &d_qnoff)); TRY(ctx_buf_t(ctx, "bam_tnoff", (size_t)nt + 1, &d_tnoff));
     TRY(ctx_buf_t(ctx, "bam_info", nrec, &d_info)); TRY(ctx_buf_t(ctx, "bam_size", nrec, &d_size)); TRY(ctx_buf_t(ctx, "bam_ord0", nrec, &d_ord0)); TRY(ctx_buf_t(ctx, "bam_ord", nrec, &d_ord));
@@ -1292,7 +1310,6 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     TRY(ctx_buf_t(ctx, "bam_rust", nrec, &d_rust)); TRY(ctx_buf_t(ctx, "bam_tabs", 1, &d_tabs));
     { static CrcTabs T; static bool made = false; if (!made) { crc_tabs_make(T); made = true; } HIPCHK(hipMemcpyAsync(d_tabs, &T, sizeof(T), hipMemcpyHostToDevice, st)); }
     if (nrec) HIPCHK(hipMemcpyAsync(d_alns, recs.data(), nrec * sizeof(telr_aln), hipMemcpyHostToDevice, st));
-    if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
     if (!qn_buf.empty()) HIPCHK(hipMemcpyAsync(d_qn, qn_buf.data(), qn_buf.size(), hipMemcpyHostToDevice, st));
     if (!tn_buf.empty()) HIPCHK(hipMemcpyAsync(d_tn, tn_buf.data(), tn_buf.size(), hipMemcpyHostToDevice, st));
     if (rg_len) HIPCHK(hipMemcpyAsync(d_rg, rg_id, (size_t)rg_len, hipMemcpyHostToDevice, st));

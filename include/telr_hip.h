@@ -141,6 +141,10 @@ typedef struct telr_result telr_result;  /* host-side alignment records + CIGARs
 
 /* ---- context ------------------------------------------------------------- */
 int  telr_init(int device, telr_ctx **out);
+/* A second context for a host thread of its own: contexts are not re-entrant, different contexts are independent, sequence sets
+ * and indexes may be used from either.  Its streams have the device's lowest priority: the kernels of the process' other
+ * context are dispatched first (the loci leg runs its one large realignment, S6, behind the small S4 / S5 / S7 calls). */
+int  telr_init_background(int device, telr_ctx **out);
 void telr_destroy(telr_ctx *ctx);
 const char *telr_strerror(int code);
 const char *telr_last_error(const telr_ctx *ctx);   /* text of the last HIP error   */

@@ -21,10 +21,10 @@ def _np_from(ptr, n, dtype):
 class Engine:
     """One per process per device."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, background=False):
         self.L = _lib.lib()
         h = C.c_void_p()
-        rc = self.L.telr_init(device, C.byref(h))
+        rc = (self.L.telr_init_background if background else self.L.telr_init)(device, C.byref(h))
         if rc != 0:
             raise _lib.TelrError("telr_init(%d): %s" % (device, self.L.telr_strerror(rc).decode()))
         self.h = h
@@ -69,7 +69,7 @@ class Engine:
         used from either."""
         w = getattr(self, "_worker", None)
         if w is None:
-            w = self._worker = Engine(self.device)
+            w = self._worker = Engine(self.device, background=True)      # its kernels queue behind this context's
         return w
 
     def close(self):

@@ -66,6 +66,7 @@ struct telr_ctx {
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     int64_t dp_retries = 0;
     int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
+    bool background = false;              // streams at the lowest priority (telr_init_background)
     struct BamSink *bam_sink = nullptr;   // an output file being prepared for telr_write_bam_dev (bam_dev.hip.h)
     telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
     telr_ctx *slot1 = nullptr;            // the second range slot (a parent context with lane workers of its own)
@@ -170,14 +171,19 @@ extern "C" int telr_stage_ms(const telr_ctx *ctx, float *ms) { if (!ctx || !ms) 
 extern "C" int telr_last_counters(const telr_ctx *ctx, telr_counters *out) { if (!ctx || !out) return TELR_E_ARG; *out = ctx->ctr; return TELR_OK; }
 extern "C" int telr_last_dp_classes(const telr_ctx *ctx, int64_t *out) { if (!ctx || !out) return TELR_E_ARG; memcpy(out, ctx->dpcls, sizeof(ctx->dpcls)); return TELR_OK; }
 
-extern "C" int telr_init(int device, telr_ctx **out)
+// background = true: every stream of the context (and of its sub-batch contexts) is created at the device's lowest priority, so
+// that the kernels of another context of the process are dispatched ahead of this one's (telr_init_background)
+static int ctx_init(int device, bool background, telr_ctx **out)
 {
     if (!out) return TELR_E_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return TELR_E_NODEVICE;
     if (hipSetDevice(device) != hipSuccess) return TELR_E_NODEVICE;
     telr_ctx *ctx = new telr_ctx();
-    ctx->device = device;
+    ctx->device = device; ctx->background = background;
+    int prio_least = 0, prio_greatest = 0;
+    if (background && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = 0;
+    auto hipStreamCreate = [&](hipStream_t *st) { return background ? hipStreamCreateWithPriority(st, hipStreamDefault, prio_least) : ::hipStreamCreate(st); };
     if (const char *e = getenv("TELR_DEBUG")) ctx->debug = atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
@@ -192,11 +198,13 @@ extern "C" int telr_init(int device, telr_ctx **out)
     *out = ctx;
     return TELR_OK;
 }
+extern "C" int telr_init(int device, telr_ctx **out) { return ctx_init(device, false, out); }
+extern "C" int telr_init_background(int device, telr_ctx **out) { return ctx_init(device, true, out); }
 static int ctx_make_child(telr_ctx *ctx, int k)
 {
     if (ctx->child[k]) return TELR_OK;
     telr_ctx *c = nullptr;
-    int r = telr_init(ctx->device, &c);
+    int r = ctx_init(ctx->device, ctx->background, &c);
     if (r != TELR_OK) return r;
     c->is_child = true; c->debug = ctx->debug;
     ctx->child[k] = c;
@@ -1011,6 +1019,8 @@ static int host_threads()
         fclose(f);
     }
     n = n + n / 2;
+    // one process per GPU (torch.distributed.run sets LOCAL_WORLD_SIZE): the ranks of a node share its CPUs
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) { int v = atoi(e); if (v > 1) n = std::max(4, n / v); }
     if (const char *e = getenv("TELR_HOST_THREADS")) { int v = atoi(e); if (v > 0) n = v; }
     if (n < 1) n = 1;
     if (n > 48) n = 48;
@@ -2243,7 +2253,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         }
         if (pipe == 2 && ranges.size() >= 2) {
             if (!ctx->slot1) {
-                int r = telr_init(ctx->device, &ctx->slot1);
+                int r = ctx_init(ctx->device, ctx->background, &ctx->slot1);
                 if (r != TELR_OK) { delete R; return r; }
             }
             telr_ctx *P[2] = { ctx, ctx->slot1 };

@@ -72,12 +72,30 @@ for _a, _b in zip(b"ACGTUNacgtun", b"TGCAANtgcaan"):
     _COMP_NP[_a] = _b
 
 
+_COMP_BYTES = bytes(_COMP_NP)
+
+
 def locus_intervals(start, end, contig_length, flank_interval, flank_offset, te_interval, te_offset):
     """The 8 depth queries of one locus: forward then reverse-complement, each te_5p, te_3p, flank_5p, flank_3p."""
     out = {}
     for tag, (s, e) in (("fw", (start, end)), ("rc", (contig_length - end, contig_length - start))):
         out[tag] = te_cov_intervals(s, e, te_interval, te_offset) + flank_cov_intervals(contig_length, s, e, flank_interval, flank_offset)
     return out
+
+
+def locus_intervals_batch(start, end, length, flank_interval, flank_offset, te_interval, te_offset):
+    """locus_intervals for arrays of loci at once -> (lo, hi, valid), each [n, 2, 4]: orientation (fw, rc) x (te_5p, te_3p,
+    flank_5p, flank_3p); the same numbers as the scalar functions above give, locus by locus (tests/test_golden_glue.py)"""
+    start = np.asarray(start, np.int64); end = np.asarray(end, np.int64); length = np.asarray(length, np.int64)
+    n = len(start)
+    lo = np.zeros((n, 2, 4), np.int64); hi = np.zeros((n, 2, 4), np.int64); valid = np.ones((n, 2, 4), bool)
+    for o, (s, e) in enumerate(((start, end), (length - end, length - start))):
+        inner = (s + te_offset + te_interval < e) if te_interval else np.zeros(n, bool)
+        lo[:, o, 0] = np.where(inner, s + te_offset, s); hi[:, o, 0] = np.where(inner, s + te_offset + te_interval, e)
+        lo[:, o, 1] = np.where(inner, e - te_interval - te_offset, s); hi[:, o, 1] = np.where(inner, e - te_offset, e)
+        lo[:, o, 2] = s - flank_interval - flank_offset; hi[:, o, 2] = s - flank_offset; valid[:, o, 2] = lo[:, o, 2] >= 0
+        lo[:, o, 3] = e + flank_offset; hi[:, o, 3] = e + flank_interval + flank_offset; valid[:, o, 3] = hi[:, o, 3] <= length
+    return lo, hi, valid
 
 
 def _median_or_none(x):
@@ -130,8 +148,9 @@ def _af_pack(job, contigs):
     # one reversal for the whole set instead of a translate + slice + decode per contig
     fw = [contigs[n].encode() if isinstance(contigs[n], str) else bytes(contigs[n]) for n in names]
     lens = np.array([len(b) for b in fw], np.int64)
-    cat = np.frombuffer(b"".join(fw), np.uint8)
-    rc_cat = _COMP_NP[cat][::-1]
+    joined = b"".join(fw)
+    cat = np.frombuffer(joined, np.uint8)
+    rc_cat = np.frombuffer(joined.translate(_COMP_BYTES)[::-1], np.uint8)
     ends = np.cumsum(lens); starts = ends - lens; total = int(ends[-1])
     tlen = np.repeat(lens, 2)
     toff = np.zeros(2 * len(names), np.int64); toff[1:] = np.cumsum(tlen)[:-1]
@@ -206,21 +225,23 @@ def af_finish(job, contig_te, flank_interval=100, flank_offset=200, te_interval=
         if not names:
             job.wait()
             return {}
-        meds = {n: {"fw": [None, None, None, None], "rc": [None, None, None, None]} for n in names}
-        iv_t, iv_s, iv_e, slots = [], [], [], []
-        for tag in ("fw", "rc"):
-            for n in names:
-                ivs = locus_intervals(contig_te[n][0], contig_te[n][1], job.lens[n], flank_interval, flank_offset, te_interval, te_offset)[tag]
-                for k, x in enumerate(ivs):
-                    if x is None:
-                        continue
-                    a, b = depth_region(*x)
-                    iv_t.append(job.tindex[n] + (1 if tag == "rc" else 0)); iv_s.append(a); iv_e.append(b); slots.append((n, tag, k))
-        job.wait()                            # the intervals above were laid out while the mapping was still running
-        med = job.ix.depth_medians(job.r, iv_t, iv_s, iv_e) if iv_t else []
-        for (n, tag, k), v in zip(slots, med):
-            meds[n][tag][k] = None if np.isnan(v) else float(v)
-        return {n: freq_table(meds[n]) for n in names}
+        # the 8 depth queries of every locus, laid out while the mapping may still be running
+        te = np.array([contig_te[n] for n in names], np.int64).reshape(-1, 2)
+        lens = np.array([job.lens[n] for n in names], np.int64)
+        lo, hi, valid = locus_intervals_batch(te[:, 0], te[:, 1], lens, flank_interval, flank_offset, te_interval, te_offset)
+        first = np.where(lo > 0, lo - 1, 0); last = hi - 1                     # depth_region: samtools' 1-based region fed 0-based numbers
+        tid = np.array([job.tindex[n] for n in names], np.int64)[:, None, None] + np.arange(2)[None, :, None] + np.zeros((1, 1, 4), np.int64)
+        sel = np.nonzero(valid.reshape(-1))[0]
+        job.wait()
+        med_all = np.full(valid.size, np.nan)
+        if len(sel):
+            med_all[sel] = job.ix.depth_medians(job.r, tid.reshape(-1)[sel], first.reshape(-1)[sel], last.reshape(-1)[sel])
+        med_all = med_all.reshape(len(names), 2, 4)
+        out = {}
+        for k, n in enumerate(names):
+            m = [None if np.isnan(v) else float(v) for v in med_all[k].reshape(-1)]
+            out[n] = freq_table({"fw": m[:4], "rc": m[4:]})
+        return out
     finally:
         job.release()
 

@@ -100,3 +100,25 @@ def test_depth_region_semantics():
     assert af.depth_region(3050, 3100) == (3049, 3099)      # 51 positions
     assert af.depth_region(0, 50) == (0, 49)
     assert af.depth_region(2700, 2800) == (2699, 2799)      # 101 positions
+
+
+def test_locus_intervals_batch_equals_the_scalar_functions():
+    """the vectorised layout of the 8 depth queries per locus (telr_af.locus_intervals_batch) = locus_intervals, locus by locus,
+    over random TE coordinates incl. TEs at the contig ends, TEs shorter than offset + interval, and interval size 0"""
+    import numpy as np
+    from telr_amd import telr_af
+    rng = np.random.default_rng(11)
+    for params in ((100, 200, 50, 50), (100, 200, 0, 50), (30, 10, 500, 5), (1, 0, 1, 0)):
+        L = rng.integers(50, 5000, size=400)
+        s = (rng.random(400) * L).astype(np.int64)
+        e = np.minimum(L, s + rng.integers(1, 1500, size=400))
+        s[:5] = 0; e[5:10] = L[5:10]
+        lo, hi, valid = telr_af.locus_intervals_batch(s, e, L, *params)
+        for k in range(400):
+            want = telr_af.locus_intervals(int(s[k]), int(e[k]), int(L[k]), *params)
+            for o, tag in enumerate(("fw", "rc")):
+                for j, x in enumerate(want[tag]):
+                    if x is None:
+                        assert not valid[k, o, j]
+                    else:
+                        assert valid[k, o, j] and (int(lo[k, o, j]), int(hi[k, o, j])) == x, (params, k, tag, j)

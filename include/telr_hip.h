@@ -145,6 +145,10 @@ int  telr_init(int device, telr_ctx **out);
  * and indexes may be used from either.  Its streams have the device's lowest priority: the kernels of the process' other
  * context are dispatched first (the loci leg runs its one large realignment, S6, behind the small S4 / S5 / S7 calls). */
 int  telr_init_background(int device, telr_ctx **out);
+/* Scratch is grow-only per context (a 30x read set leaves 150-250 GB behind): give all of it back -- the next call sizes it
+ * again, ~2 ms per GB -- and the device's free / total memory, for a process whose contexts share one device. */
+int  telr_release_scratch(telr_ctx *ctx);
+int  telr_device_mem(telr_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 void telr_destroy(telr_ctx *ctx);
 const char *telr_strerror(int code);
 const char *telr_last_error(const telr_ctx *ctx);   /* text of the last HIP error   */

@@ -15,7 +15,7 @@ EXPORTS = [
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_from_arrays", "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
-    "telr_init_background", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_consensus_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
+    "telr_init_background", "telr_release_scratch", "telr_device_mem", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_consensus_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
 _lib = None
@@ -35,6 +35,8 @@ def lib():
     vp, i32, i64, cp = C.c_void_p, C.c_int32, C.c_int64, C.c_char_p
     L.telr_init.restype = C.c_int; L.telr_init.argtypes = [C.c_int, C.POINTER(vp)]
     L.telr_init_background.restype = C.c_int; L.telr_init_background.argtypes = [C.c_int, C.POINTER(vp)]
+    L.telr_release_scratch.restype = C.c_int; L.telr_release_scratch.argtypes = [vp]
+    L.telr_device_mem.restype = C.c_int; L.telr_device_mem.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.telr_destroy.restype = None; L.telr_destroy.argtypes = [vp]
     L.telr_strerror.restype = cp; L.telr_strerror.argtypes = [C.c_int]
     L.telr_last_error.restype = cp; L.telr_last_error.argtypes = [vp]

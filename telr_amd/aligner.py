@@ -62,6 +62,16 @@ class Engine:
         self.L.telr_last_dp_classes(self.h, a.ctypes.data)
         return a.reshape(N_DPCLS, 4)
 
+    def release_scratch(self):
+        """give the context's grow-only scratch back to the device (the next call allocates what it needs again)"""
+        self._chk(self.L.telr_release_scratch(self.h), "telr_release_scratch")
+
+    def mem_info(self):
+        """(free, total) bytes of the device"""
+        fr, tot = C.c_int64(), C.c_int64()
+        self._chk(self.L.telr_device_mem(self.h, C.byref(fr), C.byref(tot)), "telr_device_mem")
+        return fr.value, tot.value
+
     def worker(self):
         """A second context on the same device (created on first use, closed with this one): a host thread can run an engine
         call on it while this context runs another -- contexts are not re-entrant, different contexts are independent

@@ -1057,8 +1057,8 @@ extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est
     if (!ctx || !bam_path || est_bytes <= 0) return TELR_E_ARG;
     bam_sink_drop(ctx);
     BamSink *k = new BamSink();
-    k->path = bam_path; k->bytes = ((size_t)est_bytes + BamSink::SLICE - 1) / BamSink::SLICE * BamSink::SLICE;
-    k->n_slices = k->bytes / BamSink::SLICE;
+    k->path = bam_path; k->bytes = ((size_t)est_bytes + 4095) & ~(size_t)4095;
+    k->n_slices = (k->bytes + BamSink::SLICE - 1) / BamSink::SLICE;          // the last block may be a short one
     // file and mapping first (both are instant), so that the writer can use whatever part is ready when it arrives
     auto t0 = std::chrono::steady_clock::now();
     k->fd = open(k->path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
@@ -1073,14 +1073,17 @@ extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < k->n_slices; ++i) {
             { std::unique_lock<std::mutex> lk(k->mu); k->cv.wait(lk, [&] { return k->stop || i * BamSink::SLICE < k->limit; }); if (k->stop) break; }
-            if (posix_fallocate(k->fd, (off_t)(i * BamSink::SLICE), (off_t)BamSink::SLICE) != 0) break;
+            const size_t len = std::min(BamSink::SLICE, k->bytes - i * BamSink::SLICE);
+            if (posix_fallocate(k->fd, (off_t)(i * BamSink::SLICE), (off_t)len) != 0) break;
             if (!no_populate) {
-                const int P = 4; const size_t q = BamSink::SLICE / P;
+                const int P = 4; const size_t q = (len / P + 4095) & ~(size_t)4095;
                 std::thread pt[P];
-                for (int t = 0; t < P; ++t) pt[t] = std::thread([k, i, t, q] {
-                    uint8_t *p = k->map + i * BamSink::SLICE + (size_t)t * q;
-                    if (madvise(p, q, 23 /* MADV_POPULATE_WRITE, Linux 5.14 */) != 0 && errno == EINVAL)
-                        for (size_t o = 0; o < q; o += 4096) ((volatile uint8_t*)p)[o] = 0;       // older kernels: touch the pages
+                for (int t = 0; t < P; ++t) pt[t] = std::thread([k, i, t, q, len] {
+                    const size_t lo = std::min(len, (size_t)t * q), n = std::min(len - lo, q);
+                    if (!n) return;
+                    uint8_t *p = k->map + i * BamSink::SLICE + lo;
+                    if (madvise(p, n, 23 /* MADV_POPULATE_WRITE, Linux 5.14 */) != 0 && errno == EINVAL)
+                        for (size_t o = 0; o < n; o += 4096) ((volatile uint8_t*)p)[o] = 0;       // older kernels: touch the pages
                 });
                 for (int t = 0; t < P; ++t) pt[t].join();
             }
@@ -1243,6 +1246,27 @@ static void ctx_release_map_scratch(telr_ctx *ctx, uint64_t need)
         (void)hipFree(d->p); d->p = nullptr; d->bytes = 0;
     }
 }
+// everything the context holds for its calls (mapping scratch of all its slots and workers, the writer's buffers): the next call
+// sizes it again (~2 ms per GB).  For a context that shares the device with another one of the process (telr_init_background).
+extern "C" int telr_release_scratch(telr_ctx *ctx)
+{
+    if (!ctx) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    (void)hipDeviceSynchronize();
+    std::vector<DBuf*> v; ctx_collect_scratch(ctx, v);
+    for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") == 0 && kv.second.p) v.push_back(&kv.second);
+    for (DBuf *d : v) { (void)hipFree(d->p); d->p = nullptr; d->bytes = 0; }
+    return TELR_OK;
+}
+extern "C" int telr_device_mem(telr_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!ctx) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t fr = 0, tot = 0; HIPCHK(hipMemGetInfo(&fr, &tot));
+    if (free_bytes) *free_bytes = (int64_t)fr;
+    if (total_bytes) *total_bytes = (int64_t)tot;
+    return TELR_OK;
+}
 static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                         const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                         const char *bam_path, int32_t write_index, int32_t level);
@@ -1250,6 +1274,7 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
                                   const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                                   const char *bam_path, int32_t write_index, int32_t level)
 {
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     int rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, bam_path, write_index, level);
     if (rc == TELR_E_NOMEM) {
         (void)hipGetLastError();

@@ -111,7 +111,24 @@ extern "C" const char *telr_consensus_seq(const telr_consensus *c) { return c ? 
 extern "C" const int64_t *telr_consensus_off(const telr_consensus *c) { return c ? c->off.data() : nullptr; }
 extern "C" const int32_t *telr_consensus_len(const telr_consensus *c) { return c ? c->len.data() : nullptr; }
 
+static int consensus_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth, telr_consensus **out);
 extern "C" int telr_consensus_build(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth, telr_consensus **out)
+{
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
+    int rc = consensus_impl(ctx, r, queries, idx, min_depth, out);
+    if (rc == TELR_E_NOMEM) {
+        // the device is full of the grow-only mapping scratch of earlier calls (configs[3]): it goes back, largest buffers first
+        // (the pile-up cells are 184 bytes per contig base), and the call runs once more
+        (void)hipGetLastError();
+        uint64_t need = 0;
+        if (idx && idx->targets) need = (uint64_t)idx->targets->total_bases * CONS_CELL * 4 + ((uint64_t)256 << 20);
+        mem_note(ctx, "telr_consensus_build: out of memory");
+        ctx_release_map_scratch(ctx, need);
+        rc = consensus_impl(ctx, r, queries, idx, min_depth, out);
+    }
+    return rc;
+}
+static int consensus_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth, telr_consensus **out)
 {
     if (!ctx || !r || !queries || !idx || !idx->targets || !out || min_depth < 0) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));

@@ -382,6 +382,7 @@ extern "C" int telr_debug_pack(const char *ascii, int32_t len, int mode, uint32_
 
 extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, const int64_t *off, const int32_t *len, telr_seqset **out)
 {
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     if (!ctx || n < 0 || !out || (n > 0 && (!ascii || !off || !len))) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     telr_seqset *s = new telr_seqset();
@@ -458,6 +459,7 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
 }
 extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out)
 {
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     if (!ctx || !parent || n < 0 || !out || (n > 0 && !idx)) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     for (int i = 0; i < n; ++i) if (idx[i] < 0 || idx[i] >= parent->n) return TELR_E_ARG;
@@ -756,6 +758,7 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
 
 extern "C" int telr_index_build(telr_ctx *ctx, const telr_seqset *targets, const telr_idx_opt *io, telr_index **out)
 {
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     if (!ctx || !targets || !io || !out) return TELR_E_ARG;
     if (io->k < 4 || io->k > 28 || io->w < 1 || io->w > 255) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
@@ -2170,6 +2173,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
 
 extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const telr_map_opt *mo, telr_result **out)
 {
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     if (!ctx || !ix || !queries || !mo || !out) return TELR_E_ARG;
     if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
     if (mo->e < mo->e2 || mo->q > mo->q2) { ctx->err = "two-piece gap cost needs e >= e2 and q <= q2"; return TELR_E_ARG; }
@@ -2476,6 +2480,7 @@ extern "C" int32_t telr_debug_mid_occ(const telr_index *ix, const telr_map_opt *
 extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n_targets, const int32_t *target_len, int32_t n_iv,
                                   const int32_t *iv_tid, const int32_t *iv_start, const int32_t *iv_end, double *median_out)
 {
+    (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     if (!ctx || !r || n_targets <= 0 || !target_len || n_iv < 0 || (n_iv && (!iv_tid || !iv_start || !iv_end || !median_out))) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

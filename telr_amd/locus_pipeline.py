@@ -27,7 +27,10 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
     # runs in a host thread of its own while S4, S5, S7 and the liftover tree run here; the annotation meets it at the depth step
     job = None
     if overlap_af and loci and hasattr(backend, "worker"):
-        job = telr_af.af_start(backend.worker(), contigs, reads_by_locus, presets, read_set, threaded=True)
+        # a second context brings its own scratch: only where the device has room for it next to what stage 1 left behind
+        fr, tot = backend.mem_info()
+        if fr >= 0.3 * tot:
+            job = telr_af.af_start(backend.worker(), contigs, reads_by_locus, presets, read_set, threaded=True)
     try:
         ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
                                                 lib_names, lib_seqs, presets)
@@ -36,11 +39,19 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
         contig_te = {}
         for r in ann:                       # one annotation per contig feeds the AF step (first one wins, as a dict would)
             contig_te.setdefault(r[0], (int(r[1]), int(r[2])))
+        freqs = None
         if job is not None:
             j, job = job, None
-            freqs = telr_af.af_finish(j, contig_te, *af_params)
-            freqs = {n: freqs[n] for n in contig_te if n in freqs}          # in annotation order, as get_af returns them
-        else:
+            try:
+                freqs = telr_af.af_finish(j, contig_te, *af_params)
+                freqs = {n: freqs[n] for n in contig_te if n in freqs}          # in annotation order, as get_af returns them
+            except Exception as e:
+                # the second context found no room next to the first one's scratch (a device filled by stage 1): give back what it
+                # holds and run S6 in turn on this context, which takes back its own scratch when it has to
+                if "out of device memory" not in str(e) and "out of memory" not in str(e):
+                    raise
+                backend.worker().release_scratch()
+        if freqs is None:
             freqs = telr_af.get_af(backend, contigs, contig_te, reads_by_locus, presets, *af_params, read_set=read_set)
     finally:
         if job is not None:

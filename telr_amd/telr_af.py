@@ -120,6 +120,7 @@ class AfJob:
     """the S6 mapping of a set of loci, possibly still running in a host thread (af_start)"""
     def __init__(self):
         self.thread = None; self.exc = None; self.names = []; self.tindex = {}; self.ix = None; self.r = None; self.qs = None; self.lens = {}
+        self.engine = None; self.threaded = False
 
     def wait(self):
         if self.thread is not None:
@@ -137,7 +138,19 @@ class AfJob:
         self.r = None
         if self.qs is not None and hasattr(self.qs, "free"):
             self.qs.free()
+        if self.ix is not None and hasattr(self.ix, "free"):
+            self.ix.free()
         self.qs = None; self.ix = None
+        # a second context's scratch is grow-only like the first one's: on a device that is nearly full (configs[3] / [4]: the
+        # stage-1 context alone holds 150-250 GB) it goes back at once, otherwise it stays for the next bundle
+        if self.threaded and self.engine is not None and hasattr(self.engine, "mem_info"):
+            eng, self.engine = self.engine, None
+            try:
+                fr, tot = eng.mem_info()
+                if fr < 0.25 * tot:
+                    eng.release_scratch()
+            except Exception:
+                pass
 
 
 def _af_pack(job, contigs):
@@ -197,6 +210,7 @@ def af_start(engine, contigs, reads_by_locus, presets="ont", read_set=None, name
     on `engine` (which must then be a context nothing else uses meanwhile: Engine.worker()) while the caller annotates and
     lifts the same loci.  -> AfJob for af_finish."""
     job = AfJob()
+    job.engine = engine; job.threaded = threaded
     job.names = [n for n in (names if names is not None else contigs) if n in contigs and n in reads_by_locus]
     job.tindex = {n: 2 * k for k, n in enumerate(job.names)}
     job.lens = {n: len(contigs[n]) for n in job.names}

@@ -104,3 +104,14 @@ def test_errors(tmp_path):
     e.write_text("")
     f = FastaFile(str(e))
     assert f.n == 0 and f.names == []
+
+
+def test_copying_path_behind_its_switch(tmp_path):
+    """TELR_FASTA_COPY=1 (read once per process): single-line records are copied into a packed buffer as folded ones are; same names and sequences"""
+    import subprocess, sys
+    p = tmp_path / "one.fa"
+    p.write_text("".join(">s%d\n%s\n" % (i, "ACGT" * (i % 7 + 1)) for i in range(200)))
+    code = "import sys; sys.path.insert(0, %r)\nfrom telr_amd.fasta import FastaFile\nf = FastaFile(sys.argv[1])\nprint(len(f.triple[0]) == f.bases, f.seqs() == ['ACGT' * (i %% 7 + 1) for i in range(200)])" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env, want in (({}, b"False True"), ({"TELR_FASTA_COPY": "1"}, b"True True")):
+        r = subprocess.run([sys.executable, "-c", code, str(p)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip() == want, (env, r.stdout, r.stderr.decode()[-1000:])

@@ -176,3 +176,68 @@ def test_long_cigar_and_nothing_mapped(engine, tmp_path):
         ix.free_raw(r)
     raw, _ = _read_bgzf(p)
     assert _records(raw)[0] == []
+
+
+def _map_synthetic(engine, n_reads=400, seed=5):
+    rng = np.random.default_rng(seed)
+    genome = [synth.random_seq(rng, 400000), synth.random_seq(rng, 150000)]
+    reads, _ = synth.simulate_reads(rng, genome, n_reads, 7000)
+    reads.append(synth.random_seq(rng, 2500))                      # an unmapped read
+    names = ["q%d" % i for i in range(len(reads))]
+    io, mo = preset("map-ont")
+    ix = engine.index(concat(genome), io)
+    qset = engine.seqset(concat(reads))
+    return ix, qset, names, ["tA", "tB"], mo
+
+
+def test_prepared_output_file_gives_the_same_bam(engine, tmp_path):
+    """telr_bam_prepare (the file allocated, mapped and pre-faulted in the background, cut to its length at the end) with an
+    estimate that is generous, far too small (the rest goes through pwrite), for ANOTHER path (ignored), twice in a row
+    (the first mapping still being taken apart), and never used: always the file the unprepared writer makes, byte for byte"""
+    import os
+    ix, qset, names, tn, mo = _map_synthetic(engine)
+    r = ix.map_raw(qset, mo)
+    try:
+        plain = str(tmp_path / "plain.bam")
+        ix.write_bam_device(r, qset, names, tn, plain, cmdline="t", level=1)
+        want = open(plain, "rb").read(); want_bai = open(plain + ".bai", "rb").read()
+        assert len(want) > (1 << 20)
+        for tag, est, prep_path in (("big", 300 << 20, None), ("exact", len(want), None), ("small", 200 << 10, None), ("tiny", 1, None), ("other", 8 << 20, "elsewhere.bam"),
+                                    ("again", 100 << 20, None)):
+            out = str(tmp_path / (tag + ".bam"))
+            ix.bam_prepare(str(tmp_path / prep_path) if prep_path else out, est)
+            ix.write_bam_device(r, qset, names, tn, out, cmdline="t", level=1)
+            assert os.path.getsize(out) == len(want), (tag, os.path.getsize(out), len(want))
+            assert open(out, "rb").read() == want and open(out + ".bai", "rb").read() == want_bai, tag
+        ix.bam_prepare(str(tmp_path / "unused.bam"), 50 << 20)      # dropped by the next prepare / by telr_destroy
+        ix.bam_prepare(str(tmp_path / "unused2.bam"), 50 << 20)
+        ix.bam_release_wait()
+        lvl0 = str(tmp_path / "l0.bam")
+        ix.bam_prepare(lvl0, 64 << 20)
+        ix.write_bam_device(r, qset, names, tn, lvl0, cmdline="t", level=0)
+        assert _read_bgzf(lvl0)[0] == _read_bgzf(plain)[0]
+    finally:
+        ix.free_raw(r)
+
+
+def test_prepared_output_file_without_prefaulting(tmp_path):
+    """TELR_BAM_NO_POPULATE=1 (blocks allocated, not pre-faulted: the round's earlier sink) in a process of its own"""
+    import os, subprocess, sys
+    code = r"""
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from telr_amd.aligner import Engine
+import test_gpu_bam_dev as T
+eng = Engine(0)
+ix, qset, names, tn, mo = T._map_synthetic(eng, 200, 9)
+r = ix.map_raw(qset, mo)
+a, b = sys.argv[1] + "/a.bam", sys.argv[1] + "/b.bam"
+ix.write_bam_device(r, qset, names, tn, a, cmdline="t", level=1)
+ix.bam_prepare(b, 40 << 20)
+ix.write_bam_device(r, qset, names, tn, b, cmdline="t", level=1)
+assert open(a, "rb").read() == open(b, "rb").read()
+assert eng.L.telr_bam_release_wait() == 0
+print("same")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=dict(os.environ, TELR_BAM_NO_POPULATE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0 and b"same" in p.stdout, p.stderr.decode()[-2000:]

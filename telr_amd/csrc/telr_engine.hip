@@ -2244,7 +2244,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             const double per_base = ix->anchors_per_base > 0 ? ix->anchors_per_base : index_density_bound(ix, mid_occ.mid_occ);
             if (per_base > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(256LL << 20, (int64_t)(0.8e9 / per_base)));      // two in flight: half the anchor budget each
             if (total_bases > std::min<int64_t>(batch_bases, (int64_t)(per_base > 0 ? 1.6e9 / per_base : 1e18)) || force) {
-                const int64_t nr = std::max<int64_t>(2, (total_bases + cap - 1) / cap);
+                int64_t nr = std::max<int64_t>(2, (total_bases + cap - 1) / cap);
+                nr += nr & 1;          // an even number of equal ranges keeps both slots busy to the end (configs[2]: 3 ranges 215 ms, 4 ranges 205 ms per step)
                 batch_bases = (total_bases + nr - 1) / nr + queries->max_len + 1;      // the slack keeps the greedy cut below from leaving a stub range behind
             } else pipe = 1;
         }
@@ -2263,9 +2264,10 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             telr_ctx *P[2] = { ctx, ctx->slot1 };
             { telr_ctx *c = P[1]; memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0; c->err.clear(); }
             int rc[2] = { TELR_OK, TELR_OK };
+            std::atomic<size_t> next_range{0};
             auto slot = [&](int s) {
                 (void)hipSetDevice(ctx->device);
-                for (size_t i = (size_t)s; i < ranges.size(); i += 2) {
+                for (size_t i; (i = next_range.fetch_add(1)) < ranges.size(); ) {        // whichever slot is free takes the next range; results are appended in range order (turn gate)
                     int r = map_range(P[s], ix, queries, qtarget, d_qt, ranges[i].first, ranges[i].second, mo, mid_occ, R, (int)i);
                     gate_leave(R, (int)i, r == TELR_OK);
                     if (r != TELR_OK) { rc[s] = r; return; }

@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
     ap.add_argument("--data-cache", default="", help="directory: the rank's generated data set is stored there / loaded from there (profiling runs: no forked generator)")
     ap.add_argument("--one-gpu", action="store_true", help="smoke test of the N>1 code path on a 1-GPU box: every rank uses device 0 (use with --backend gloo; RCCL refuses two ranks on one device)")
+    ap.add_argument("--no-bam-twin", action="store_true", help="BAM leg without TELR_MF_KEEP_CIGARS: the writer uploads the CIGAR array again")
     ap.add_argument("--bam-sha", action="store_true", help="report the SHA-256 of the BAM files the legs write (the N-rank job BAM equals the 1-rank BAM byte for byte)")
     ap.add_argument("--force-exchange", action="store_true", help="run the N>1 code path of the loci leg (window-read all-to-all, pooled read set, all-gather) at world size 1 too: under torch.distributed.run on a 1-GPU box this drives the collectives through RCCL on device tensors")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the streaming host-inclusive measurement (a second context uploads the next read batch while the first maps)")
@@ -228,6 +229,9 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
     bam_path = os.path.join(bam_dir, "telr_bench_rank%d.bam" % rank)
     qnames = Index._cstr_array(["read%d" % g for g in D["read_gid"]])       # the C array of names is an input, like the reads
     tb_, to_, tl_ = concat_ref = (np.concatenate(D["ref"]), np.cumsum([0] + [len(x) for x in D["ref"]][:-1]).astype(np.int64), np.array([len(x) for x in D["ref"]], np.int32))
+    if a.bam_leg == "device" and not a.no_bam_twin:
+        from telr_amd._abi import MF_KEEP_CIGARS
+        mo = type(mo).from_buffer_copy(mo); mo.flags |= MF_KEEP_CIGARS          # the result keeps its CIGARs on the device for the writer (what alignment() does)
     legs = []
     for rep in range(2):                      # the first pass sizes / pins the writer's buffers
         for f in (bam_path, bam_path + ".bai"):
@@ -266,7 +270,7 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
     if dist is not None and a.bam_leg == "device" and (dist.get_world_size() > 1 or a.force_exchange):
         job = job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_dir)
     return {"job_bam": job, "bam_sha256": sha, "writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1],
-               "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
+               "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "cigars_resident": bool(eng.L.telr_debug_bam_twin()) if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
                "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s; one BAM per rank; second of two passes (the first sizes and pins the writer's buffers)" % bam_dir}
 
 

@@ -109,6 +109,10 @@ typedef struct telr_map_opt {
                                     band of -r diagonals, chaining look-back 5000.  The reference point against which
                                     the tuned presets are gated (tests/test_faithful_gate.py).                          */
 
+#define TELR_MF_KEEP_CIGARS 0x8  /* engine only (the oracle ignores it): the result keeps its CIGAR array on the device as well
+                                    (same offsets; ~1.2 bytes per query base reserved), so that telr_write_bam_dev on the same
+                                    context need not upload it again.  Records and CIGARs on the host are what they are without it. */
+
 /* ---- one alignment (PAF line / SAM record worth of numbers), 88 bytes ---- */
 typedef struct telr_aln {
     int32_t  qid;        /* query index in the query set                          */

@@ -41,7 +41,7 @@ class Counters(C.Structure):
 
 
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8
-MF_CIGAR, MF_PER_TARGET, MF_FAITHFUL = 1, 2, 4
+MF_CIGAR, MF_PER_TARGET, MF_FAITHFUL, MF_KEEP_CIGARS = 1, 2, 4, 8
 N_STAGES = 16
 N_DPCLS = 23
 

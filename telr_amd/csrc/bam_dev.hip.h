@@ -1022,6 +1022,8 @@ struct BamSink {
         cv.notify_all();
     }
 };
+static int g_bam_twin = 0;          // the last writer call found the CIGARs on the device
+extern "C" int telr_debug_bam_twin(void) { return g_bam_twin; }
 static float g_sink_ms[12];      // allocate + populate, map (prepare threads); wait for them (writer); 1 = the mapping was used; streaming: wait for the coder, wait for the DMA, host copies / pwrite, wait for a ring slot, the streaming loop as a whole, stopping the prepare thread, cutting the file
 static std::mutex g_rel_mu; static std::condition_variable g_rel_cv; static int g_rel_pending = 0;
 static void bam_sink_drop(telr_ctx *ctx)
@@ -1305,8 +1307,16 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     for (const telr_aln &a : r->alns) if (a.qid < 0 || a.qid >= nq || a.tid < 0 || a.tid >= nt) return TELR_E_ARG;
     // the CIGAR words (1.9 GB for a 30x set: 34 ms of PCIe) start their way back to the device before the host lays out records and names
     auto t0 = now();
-    uint32_t *d_cig; TRY(ctx_buf_t(ctx, "bam_cig", r->ncig + 1, &d_cig));
-    if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
+    // ... unless the result kept them there (TELR_MF_KEEP_CIGARS): the mirrored array is used in place
+    uint32_t *d_cig;
+    static const bool no_twin = getenv("TELR_BAM_NO_TWIN") != nullptr;
+    const bool twin = r->d_cig && !r->twin_off && r->twin_n == r->ncig && !no_twin;
+    g_bam_twin = twin ? 1 : 0;
+    if (twin) { d_cig = r->d_cig; HIPCHK(hipDeviceSynchronize()); }      // its last pieces were copied on other streams
+    else {
+        TRY(ctx_buf_t(ctx, "bam_cig", r->ncig + 1, &d_cig));
+        if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
+    }
     // ---- 1. records (+ pseudo records of the unmapped reads, in query order), names, header
     std::vector<telr_aln> recs(r->alns);
     size_t n_unmapped = 0;

@@ -67,6 +67,8 @@ struct telr_ctx {
     int64_t dp_retries = 0;
     int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
     bool background = false;              // streams at the lowest priority (telr_init_background)
+    telr_ctx *twin_owner = nullptr; int64_t twin_bases = 0;       // set for the duration of a telr_map call on the contexts that append to its result
+    uint32_t *twin_pool = nullptr; size_t twin_pool_cap = 0;      // device CIGAR array of a freed result (TELR_MF_KEEP_CIGARS), for the next call
     struct BamSink *bam_sink = nullptr;   // an output file being prepared for telr_write_bam_dev (bam_dev.hip.h)
     telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
     telr_ctx *slot1 = nullptr;            // the second range slot (a parent context with lane workers of its own)
@@ -216,6 +218,7 @@ extern "C" void telr_destroy(telr_ctx *ctx)
 {
     if (!ctx) return;
     bam_sink_drop(ctx);
+    if (ctx->twin_pool) { (void)hipFree(ctx->twin_pool); ctx->twin_pool = nullptr; }
     for (int k = 0; k < 4; ++k) if (ctx->child[k]) { telr_destroy(ctx->child[k]); ctx->child[k] = nullptr; }
     if (ctx->slot1) { telr_destroy(ctx->slot1); ctx->slot1 = nullptr; }
     (void)hipSetDevice(ctx->device);
@@ -914,6 +917,11 @@ struct telr_result {
     uint32_t *cig = nullptr;       // pinned; filled by one DMA that may still be in flight when telr_map returns
     size_t ncig = 0, cap = 0;      // cap in ops
     mutable hipEvent_t dma_done = nullptr;   // non-null while the CIGAR DMA has not been waited for
+    // TELR_MF_KEEP_CIGARS: the same array on the device (same offsets), for telr_write_bam_dev.  Mirrored piece by piece as the
+    // host array grows: the stitched scratch of a range by a device copy, the pieces merged in on the host (long-read lane) by an
+    // upload behind the remaining ranges.  Complete iff twin_n == ncig and !twin_off.
+    uint32_t *d_cig = nullptr; size_t d_cap = 0, twin_n = 0; bool twin_off = false, is_part = false;
+    mutable std::vector<hipEvent_t> up_events;   // uploads into d_cig that read `cig`: waited for before `cig` moves
     // Ranges of one telr_map call may be in flight on two slots (telr_map: range pipelining).  They append to this result in
     // range order: a range waits here for its turn before it first touches alns / cig, and keeps the turn until its lanes
     // are merged.  turn < 0: a range failed, everybody leaves.
@@ -943,6 +951,7 @@ static void gate_leave(telr_result *R, int turn, bool ok)
 static void result_wait(const telr_result *r)
 {
     if (r && r->dma_done) { (void)hipEventSynchronize(r->dma_done); (void)hipEventDestroy(r->dma_done); r->dma_done = nullptr; }
+    if (r) { for (hipEvent_t e : r->up_events) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } r->up_events.clear(); }
 }
 extern "C" int telr_result_wait(const telr_result *r) { if (!r) return TELR_E_ARG; result_wait(r); return TELR_OK; }
 // CIGAR buffers of freed results are kept (at most two) and handed to the next telr_map call: a fresh
@@ -967,6 +976,34 @@ static void pool_put(telr_ctx *ctx, uint32_t *p, size_t cap)
     if (!ctx || ctx->cig_pool.size() >= 2) { cig_free(p); return; }
     ctx->cig_pool.push_back(std::make_pair(p, cap));
 }
+// mirror words [base, base + n) of a result's CIGAR array on the device; src_dev: device source (the stitched scratch, copied on
+// `st`), else the host array itself is uploaded on `st` and the event kept (the host array must not move under the upload).
+// owner: the top-level context of the call (its pool supplies / takes the device array); bases: query bases of the whole call.
+static void twin_put(telr_ctx *owner, telr_result *R, const telr_map_opt *mo, size_t base, size_t n, const uint32_t *src_dev, int64_t bases, hipStream_t st)
+{
+    if (!(mo->flags & TELR_MF_KEEP_CIGARS) || R->is_part || R->twin_off) return;
+    if (base != R->twin_n) { R->twin_off = true; return; }           // a piece went by unmirrored
+    if (!R->d_cig) {
+        const size_t want = std::max<size_t>((size_t)((double)bases * 0.3) + ((size_t)1 << 20), base + n + 1);
+        if (owner && owner->twin_pool && owner->twin_pool_cap >= want) { R->d_cig = owner->twin_pool; R->d_cap = owner->twin_pool_cap; owner->twin_pool = nullptr; owner->twin_pool_cap = 0; }
+        else {
+            if (owner && owner->twin_pool) { (void)hipFree(owner->twin_pool); owner->twin_pool = nullptr; owner->twin_pool_cap = 0; }
+            if (hipMalloc(&R->d_cig, want * 4) != hipSuccess) { (void)hipGetLastError(); R->d_cig = nullptr; R->twin_off = true; return; }
+            R->d_cap = want;
+        }
+    }
+    if (base + n > R->d_cap) { R->twin_off = true; return; }         // more ops per base than any preset has produced: the writer uploads instead
+    if (n) {
+        if (src_dev) { if (hipMemcpyAsync(R->d_cig + base, src_dev, n * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { R->twin_off = true; return; } }
+        else {
+            hipEvent_t e;
+            if (hipMemcpyAsync(R->d_cig + base, R->cig + base, n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { R->twin_off = true; return; }
+            (void)hipEventRecord(e, st); R->up_events.push_back(e);
+        }
+    }
+    R->twin_n = base + n;
+}
 static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
 {
     *p = nullptr; *cap = 0;
@@ -979,6 +1016,7 @@ static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
 telr_result::~telr_result()
 {
     result_wait(this); pool_put(ctx, cig, cap);
+    if (d_cig) { if (ctx && !ctx->is_child && !ctx->twin_pool) { ctx->twin_pool = d_cig; ctx->twin_pool_cap = d_cap; } else (void)hipFree(d_cig); d_cig = nullptr; }
     // (a worker context never takes from its pool -- its results are created without one -- so it does not keep vectors either)
     if (ctx && !ctx->is_child && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
 }
@@ -1888,6 +1926,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                 if (!cig_grow(&R->cig, &R->cap, cig_base, cig_base + (size_t)tot + 1 + (size_t)tot / 8)) return TELR_E_NOMEM;
             }
             R->ncig = cig_base + (size_t)tot;
+            if (R->twin_n > cig_base) R->twin_n = cig_base;          // a range that was rolled back and runs again
+            twin_put(ctx->twin_owner ? ctx->twin_owner : ctx, R, mo, cig_base, (size_t)tot, d_fin, ctx->twin_bases, st);
             if (tot) {
                 // DMA on its own stream: the caller gets the records back while the CIGAR array is still travelling
                 HIPCHK(hipEventRecord(ctx->ev_stitched, st));
@@ -2087,10 +2127,11 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
         if (rr == TELR_OK) ctx->ctr.query_bases += total_bases;
     } else {
         for (int k = 0; k < 2; ++k) TRY(ctx_make_child(ctx, k));
+        for (int k = 0; k < 2; ++k) { ctx->child[k]->twin_owner = ctx->twin_owner ? ctx->twin_owner : ctx; ctx->child[k]->twin_bases = ctx->twin_bases; }
         // the recycled (large) result buffers go to the bulk worker, which fills R
         for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
         ctx->cig_pool.clear();
-        telr_seqset sub[2]; telr_result *P1 = new telr_result(); P1->ctx = nullptr; int rc[2] = { TELR_OK, TELR_OK };
+        telr_seqset sub[2]; telr_result *P1 = new telr_result(); P1->ctx = nullptr; P1->is_part = true; int rc[2] = { TELR_OK, TELR_OK };
         auto work = [&](int k) {
             telr_ctx *c = ctx->child[k];
             (void)hipSetDevice(c->device);
@@ -2135,6 +2176,8 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
                     for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + base1 + lo, P1->cig + lo, (hi - lo) * 4); }
                 });
                 R->ncig = base1 + P1->ncig;
+                if (R->twin_n > base1) R->twin_n = base1;
+                twin_put(ctx->twin_owner ? ctx->twin_owner : ctx, R, mo, base1, nw, nullptr, ctx->twin_bases, ctx->copy_stream);      // the long-read lane's ops: uploaded behind the ranges still to come
             }
             std::vector<telr_aln> &merged = ctx->h_merge;
             merged.resize(R->alns.size() - a_start + P1->alns.size());
@@ -2208,6 +2251,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     const auto t_wall0 = std::chrono::steady_clock::now();
     int64_t total_bases = 0;
     for (int i = 0; i < nq; ++i) total_bases += queries->len[i];
+    ctx->twin_owner = ctx; ctx->twin_bases = total_bases;
     int nsub = 1;      // concurrent sub-batches on worker contexts: measured on the MI355X box, only pays when host cores are plentiful; opt-in via TELR_SUBBATCH
     if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
     if (nsub > nq) nsub = nq > 0 ? nq : 1;
@@ -2262,6 +2306,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
                 if (r != TELR_OK) { delete R; return r; }
             }
             telr_ctx *P[2] = { ctx, ctx->slot1 };
+            P[1]->twin_owner = ctx; P[1]->twin_bases = total_bases;
             { telr_ctx *c = P[1]; memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0; c->err.clear(); }
             int rc[2] = { TELR_OK, TELR_OK };
             std::atomic<size_t> next_range{0};
@@ -2292,7 +2337,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
                 telr_destroy(ctx->slot1); ctx->slot1 = nullptr;
                 (void)hipDeviceSynchronize();
                 for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") == 0 && kv.second.p) { (void)hipFree(kv.second.p); kv.second.p = nullptr; kv.second.bytes = 0; }
-                result_wait(R); R->alns.clear(); R->ncig = 0;
+                result_wait(R); R->alns.clear(); R->ncig = 0; R->twin_n = 0;
                 { std::lock_guard<std::mutex> lk(R->gate_m); R->turn = 0; }
                 mem_note(ctx, "telr_map: after giving back slot 2 + writer");
                 memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms)); memset(&ctx->ctr, 0, sizeof(ctx->ctr)); memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
@@ -2344,7 +2389,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             telr_ctx *c = ctx->child[k];
             (void)hipSetDevice(c->device);
             memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0;
-            part[k] = new telr_result(); part[k]->ctx = nullptr;
+            part[k] = new telr_result(); part[k]->ctx = nullptr; part[k]->is_part = true;
             if (cut[k + 1] > cut[k]) {
                 for (int i = cut[k]; i < cut[k + 1]; ++i) c->ctr.query_bases += queries->len[i];
                 rc[k] = map_batch(c, ix, queries, d_qt, cut[k], cut[k + 1], mo, mid_occ, part[k]);
@@ -2359,7 +2404,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         a0[nsub] = tot_a; c0[nsub] = tot_c;
         pool_get(ctx, &R->cig, &R->cap);
         if (!cig_grow(&R->cig, &R->cap, 0, tot_c + 1 + tot_c / 8)) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; }
-        R->ncig = tot_c;
+        R->ncig = tot_c; R->twin_off = true;          // sub-batch results are merged on the host only
         R->alns.resize(tot_a);
         const int NT = host_threads();
         for (int k = 0; k < nsub; ++k) {

@@ -17,6 +17,7 @@ import time
 from .aligner import Engine
 from .fasta import read_fasta, load
 from .presets import preset
+from ._abi import MF_KEEP_CIGARS
 
 
 def format_time(seconds):          # TELR_utility.py:34-41
@@ -64,6 +65,7 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
     tm["pack_upload_reads"] = time.time() - t0; t0 = time.time()
     # about 0.85 bytes of BAM per read base with --cs --MD, 0.6 without cs, at level 1
     ix.bam_prepare(bam, int((0.95 if with_cs else 0.7) * n_bases) + (64 << 20))
+    mo.flags |= MF_KEEP_CIGARS                   # the CIGAR array stays on the device as well: the BAM writer reads it there
     r = ix.map_raw(qset, mo)
     tm["map"] = time.time() - t0; t0 = time.time()
     try:

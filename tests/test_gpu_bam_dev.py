@@ -209,6 +209,22 @@ def test_prepared_output_file_gives_the_same_bam(engine, tmp_path):
             ix.write_bam_device(r, qset, names, tn, out, cmdline="t", level=1)
             assert os.path.getsize(out) == len(want), (tag, os.path.getsize(out), len(want))
             assert open(out, "rb").read() == want and open(out + ".bai", "rb").read() == want_bai, tag
+        # TELR_MF_KEEP_CIGARS: the result keeps its CIGAR array on the device too and the writer reads it there -- same records,
+        # same CIGARs on the host, same file
+        from telr_amd._abi import MF_KEEP_CIGARS
+        mo2 = type(mo).from_buffer_copy(mo); mo2.flags |= MF_KEEP_CIGARS
+        r2 = ix.map_raw(qset, mo2)
+        try:
+            a, b = ix.result_arrays(r), ix.result_arrays(r2)
+            assert a.alns.tobytes() == b.alns.tobytes() and a.cigars.tobytes() == b.cigars.tobytes()
+            kept = str(tmp_path / "kept.bam")
+            ix.write_bam_device(r2, qset, names, tn, kept, cmdline="t", level=1)
+            assert engine.L.telr_debug_bam_twin() == 1
+            assert open(kept, "rb").read() == want and open(kept + ".bai", "rb").read() == want_bai
+            ix.write_bam_device(r, qset, names, tn, kept, cmdline="t", level=1)
+            assert engine.L.telr_debug_bam_twin() == 0 and open(kept, "rb").read() == want
+        finally:
+            ix.free_raw(r2)
         ix.bam_prepare(str(tmp_path / "unused.bam"), 50 << 20)      # dropped by the next prepare / by telr_destroy
         ix.bam_prepare(str(tmp_path / "unused2.bam"), 50 << 20)
         ix.bam_release_wait()

@@ -670,6 +670,9 @@ def main():
                 l.pop("reads", None)
             return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
                                                        shards=shards, presets=presets_arg, read_set=pool_set)
+        # stage 1 is over: its grow-only mapping scratch (150-200 GB for a 30x set, two slots) and the BAM writer's buffers go back
+        # before the per-locus stages size their own (in the pipeline, Sniffles and the assemblers run between the two)
+        eng.release_scratch()
         loci_pass()                                # warm-up (sizes the scratch)
         sync()
         prof = None

@@ -29,7 +29,7 @@ def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, 
     if overlap_af and loci and hasattr(backend, "worker"):
         # a second context brings its own scratch: only where the device has room for it next to what stage 1 left behind
         fr, tot = backend.mem_info()
-        if fr >= 0.3 * tot:
+        if fr >= 0.3 * tot and not getattr(backend.worker(), "crowded", False):
             job = telr_af.af_start(backend.worker(), contigs, reads_by_locus, presets, read_set, threaded=True)
     try:
         ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],

@@ -149,6 +149,7 @@ class AfJob:
                 fr, tot = eng.mem_info()
                 if fr < 0.25 * tot:
                     eng.release_scratch()
+                    eng.crowded = True             # run_loci: the next bundle runs S6 in turn (sizing this scratch again costs more than the overlap gains)
             except Exception:
                 pass
 

@@ -86,6 +86,8 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
         import threading
         threading.Thread(target=_drop, args=((tf, qf), qset, ix), daemon=True).start()
     tm["release"] = time.time() - t0
+    # (the engine keeps its grow-only mapping scratch, 150-200 GB for a 30x read set: a caller that goes on to the per-locus
+    # stages with the same engine gives it back with Engine.release_scratch() -- 0.2 s -- when it knows stage 1 will not run again)
     alignment.last_timings = tm
     if os.path.isfile(bam) is False:
         sys.stderr.write("Sorted and indexed BAM file does not exist, exiting...\n")

@@ -83,6 +83,7 @@ def lib():
     L.telr_bam_prepare.restype = C.c_int; L.telr_bam_prepare.argtypes = [vp, cp, i64]
     L.telr_bam_release_wait.restype = C.c_int; L.telr_bam_release_wait.argtypes = []
     L.telr_debug_bam_twin.restype = C.c_int; L.telr_debug_bam_twin.argtypes = []
+    L.telr_debug_result_twin.restype = i64; L.telr_debug_result_twin.argtypes = [vp, vp, i64]
     L.telr_debug_bam_sink_ms.restype = C.c_int; L.telr_debug_bam_sink_ms.argtypes = [vp]
     L.telr_debug_bam_ms.restype = C.c_int; L.telr_debug_bam_ms.argtypes = [vp]
     L.telr_debug_huff.restype = C.c_int; L.telr_debug_huff.argtypes = [vp, i32, i32, vp]

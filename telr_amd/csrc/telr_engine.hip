@@ -1038,6 +1038,17 @@ extern "C" int telr_result_from_arrays(telr_ctx *ctx, const telr_aln *alns, int6
 }
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
+// test tap: the device copy of the CIGAR array kept under TELR_MF_KEEP_CIGARS -> `out` (n words); returns the number of words
+// copied, -1 when the result has no complete device copy
+extern "C" int64_t telr_debug_result_twin(const telr_result *r, uint32_t *out, int64_t n)
+{
+    if (!r || !out) return -1;
+    result_wait(r);
+    if (!r->d_cig || r->twin_off || r->twin_n != r->ncig || (int64_t)r->ncig > n) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (r->ncig && hipMemcpy(out, r->d_cig, r->ncig * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)r->ncig;
+}
 extern "C" int64_t telr_result_cigar_count(const telr_result *r) { return r ? (int64_t)r->ncig : 0; }
 extern "C" const uint32_t *telr_result_cigars(const telr_result *r) { result_wait(r); return r ? r->cig : nullptr; }
 extern "C" void telr_result_free(telr_result *r) { delete r; }

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from telr_amd.presets import preset
-from telr_amd.fasta import read_fasta
+from telr_amd.fasta import read_fasta, concat
 from telr_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -514,6 +514,44 @@ def test_pipelined_ranges(engine):
     assert len(res.alns) >= 60 and (np.diff(res.alns["qid"]) >= 0).all()
 
 
+def test_cigars_kept_on_the_device_equal_the_host_array(engine):
+    """TELR_MF_KEEP_CIGARS: the device copy of a result's CIGAR array (for telr_write_bam_dev) is the host array, word for word --
+    one range, pipelined ranges with and without the long-read lanes (whose pieces are merged in on the host and uploaded),
+    after the two-slot fall-back, and with per-query targets; and the host arrays are what they are without the flag"""
+    import os
+    from telr_amd._abi import MF_KEEP_CIGARS
+    rng = np.random.default_rng(99)
+    genome = [synth.random_seq(rng, 120000), synth.random_seq(rng, 50000)]
+    reads, _ = synth.simulate_reads(rng, genome, 60, 3500)
+    long_reads, _ = synth.simulate_reads(rng, genome, 5, 25000)
+    reads[7:7] = long_reads[:3]; reads.extend(long_reads[3:]); reads.insert(20, np.zeros(0, np.uint8))
+    io, mo = preset("map-ont")
+    mk = type(mo).from_buffer_copy(mo); mk.flags |= MF_KEEP_CIGARS
+    ix = engine.index(concat(genome), io); qs = engine.seqset(concat(reads))
+    qt = np.array([i % 3 - 1 for i in range(len(reads))], np.int32)
+
+    def check(qtarget=None):
+        r0 = ix.map_raw(qs, mo, qtarget=qtarget); r1 = ix.map_raw(qs, mk, qtarget=qtarget)
+        try:
+            a, b = ix.result_arrays(r0), ix.result_arrays(r1)
+            assert a.alns.tobytes() == b.alns.tobytes() and a.cigars.tobytes() == b.cigars.tobytes() and len(b.cigars) > 1000
+            dev = np.zeros(len(b.cigars), np.uint32)
+            assert engine.L.telr_debug_result_twin(r1, dev.ctypes.data, len(dev)) == len(dev)
+            assert (dev == b.cigars).all()
+            assert engine.L.telr_debug_result_twin(r0, dev.ctypes.data, len(dev)) == -1          # not asked for: no device copy
+        finally:
+            ix.free_raw(r0); ix.free_raw(r1)
+    check(); check(qt)
+    for env in ({"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "60", "TELR_LONGSPLIT": "force"}, {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "45"},
+                {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "1000", "TELR_LONGSPLIT": "force"}, {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "60", "TELR_TEST_PIPE_NOMEM": "1"}):
+        os.environ.update(env)
+        try:
+            check(); check(qt)
+        finally:
+            for k in env:
+                del os.environ[k]
+
+
 def test_seqset_subset_matches_fresh_set(engine):
     """telr_seqset_subset gathers packed sequences on the device: mapping the subset must give exactly what mapping a
     freshly packed set of the same sequences gives (repeats, an empty read and the last read included)."""
@@ -607,3 +645,31 @@ def test_long_join_reads_across_large_insertions_and_deletions(engine, pname):
     off = mo.copy(); off.bw_long = 0
     res0, _ = compare_all(engine, genome, reads, io, off, stages=False)
     assert len(res0.alns) > len(res.alns)
+
+
+def test_second_context_and_scratch_release(engine):
+    """Engine.worker() (telr_init_background: a context of its own at the lowest stream priority) maps a read set of the first
+    context against an index of the first context to the same records; telr_release_scratch gives the grow-only scratch back and
+    the next call sizes it again with the same result; telr_device_mem reports the difference"""
+    rng = np.random.default_rng(17)
+    genome = [synth.random_seq(rng, 200000)]
+    reads, _ = synth.simulate_reads(rng, genome, 80, 4000)
+    io, mo = preset("map-ont")
+    ix = engine.index(concat(genome), io); qs = engine.seqset(concat(reads))
+    a = ix.map(qs, mo)
+    w = engine.worker()
+    assert w is engine.worker() and w.h.value != engine.h.value
+    import ctypes as C
+    h = C.c_void_p()
+    w._chk(w.L.telr_map(w.h, ix.h, qs.h, None, C.byref(mo), C.byref(h)), "telr_map on the second context")
+    try:
+        b = ix.result_arrays(h)
+        assert a.alns.tobytes() == b.alns.tobytes() and a.cigars.tobytes() == b.cigars.tobytes()
+    finally:
+        ix.free_raw(h)
+    free0, total = engine.mem_info()
+    engine.release_scratch(); w.release_scratch()
+    free1, _ = engine.mem_info()
+    assert free1 > free0 and total > free1
+    c = ix.map(qs, mo)
+    assert a.alns.tobytes() == c.alns.tobytes() and a.cigars.tobytes() == c.cigars.tobytes()

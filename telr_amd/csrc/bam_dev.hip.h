@@ -36,6 +36,7 @@ struct BamArgs {
     const char *rg; int32_t rg_len;                     // 0 = no RG tag
     int32_t flags;                                      // TELR_SAM_*
     BamInfo *info; uint32_t *rec_size; uint64_t *key; const uint64_t *rec_ustart; uint8_t *ubuf;
+    const uint32_t *order; int32_t s0;                  // k_bam_write in pieces of the SORTED order: block x writes record order[s0 + x] (order null: record x)
 };
 
 typedef uint32_t __attribute__((aligned(1))) u32_unal;
@@ -347,8 +348,9 @@ __device__ __forceinline__ uint8_t *d_tag_i(uint8_t *p, char a, char b, int32_t 
 
 __global__ void __launch_bounds__(64) k_bam_write(BamArgs A)
 {
-    const int k = blockIdx.x, lane = threadIdx.x;
-    if (k >= A.nrec) return;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x + A.s0 >= A.nrec) return;
+    const int k = A.order ? (int)A.order[blockIdx.x + A.s0] : (int)blockIdx.x;
     const telr_aln a = A.alns[k];
     const BamLayout Y = d_bam_layout(A, a);
     uint8_t *const rec = A.ubuf + A.rec_ustart[k];
@@ -573,6 +575,11 @@ __global__ void __launch_bounds__(256) k_blk_first_rec(const uint64_t *__restric
     rec0[b] = lo;
 }
 
+// A thread walks its own 64-byte piece of the block: with the pieces end to end in LDS the 64 lanes of a wave read addresses 64
+// bytes apart -- four of the 64 banks, a 16-way conflict on every byte.  The staged block therefore carries one pad dword per
+// piece (stride 17 dwords: conflict-free); byte i of the block lives at i + 4 * (i / 64).
+#define DEFL_INB(in_, i_) ((in_)[(i_) + (((i_) >> 6) << 2)])
+#define DEFL_IN4_WORDS (BAM_BLK / 4 + BAM_BLK / 64 + 4)
 // The token walk of one thread over its piece.  MODE 0: bits; 1: emit into the LDS bit buffer; 2: histogram (hist[cls][sym]).
 struct BitW { uint64_t acc; int nb; uint32_t word; uint32_t *out; };
 __device__ __forceinline__ void d_bw_put(BitW &W, uint32_t v, int len)
@@ -581,7 +588,8 @@ __device__ __forceinline__ void d_bw_put(BitW &W, uint32_t v, int len)
     if (W.nb >= 32) { atomicOr(&W.out[W.word], (uint32_t)W.acc); ++W.word; W.acc >>= 32; W.nb -= 32; }
 }
 template <int MODE>
-__device__ __forceinline__ uint32_t d_defl_piece(const uint8_t *in, int n, int t, const DeflSeg *seg, int nseg, const DeflTabs *T, BitW *W, uint32_t *hist)
+__device__ __forceinline__ uint32_t d_defl_piece(const uint8_t *in, int n, int t, const DeflSeg *seg, int nseg, const DeflTabs *T, BitW *W, uint32_t *hist,
+                                                 const uint32_t *lit /* [DEFL_NCLS][288], a copy of T->lit in LDS (unused by MODE 2) */, const uint16_t *len_sym /* [259], in LDS */)
 {
     const int p0 = t * DEFL_PIECE;
     if (p0 >= n) return 0;
@@ -602,28 +610,28 @@ __device__ __forceinline__ uint32_t d_defl_piece(const uint8_t *in, int n, int t
         }
     };
     auto put_sym = [&](int c, int sym) {
-        if (MODE == 0) bits += T->lit[c][sym] >> 16;
-        else if (MODE == 1) { const uint32_t e = T->lit[c][sym]; d_bw_put(*W, e & 0xffffu, (int)(e >> 16)); }
+        if (MODE == 0) bits += lit[c * 288 + sym] >> 16;
+        else if (MODE == 1) { const uint32_t e = lit[c * 288 + sym]; d_bw_put(*W, e & 0xffffu, (int)(e >> 16)); }
         else atomicAdd(&hist[c * 288 + sym], 1u);
     };
     if (p0 == 0) open_block(0);
     int i = p0;
-    uint32_t prev = i > 0 ? in[i - 1] : 0x100u;
+    uint32_t prev = i > 0 ? DEFL_INB(in, i - 1) : 0x100u;
     while (i < p1) {
         if (i == next) {       // the table changes here
             put_sym(cls, 256);
             ++si; cls = seg[si].cls; open_block(si);
             next = si + 1 < nseg ? (int)seg[si + 1].start : 0x7fffffff;
         }
-        const uint32_t b = in[i];
+        const uint32_t b = DEFL_INB(in, i);
         const int lim = p1 < next ? p1 : next;
         if (b == prev) {
             int L = 1;
-            while (i + L < lim && in[i + L] == b) ++L;
+            while (i + L < lim && DEFL_INB(in, i + L) == b) ++L;
             if (L >= 3) {
-                if (MODE == 2) { atomicAdd(&hist[cls * 288 + 257 + (T->len_sym[L] & 31)], 1u); }
+                if (MODE == 2) { atomicAdd(&hist[cls * 288 + 257 + (len_sym[L] & 31)], 1u); }
                 else {
-                    const uint32_t ls = T->len_sym[L]; const int sym = 257 + (int)(ls & 31), eb = (int)(ls >> 5 & 7);
+                    const uint32_t ls = len_sym[L]; const int sym = 257 + (int)(ls & 31), eb = (int)(ls >> 5 & 7);
                     put_sym(cls, sym);
                     if (MODE == 0) bits += eb + 1; else { if (eb) d_bw_put(*W, ls >> 8, eb); d_bw_put(*W, 0u, 1); }      // the only distance code (distance 1) is one bit
                 }
@@ -640,19 +648,21 @@ __device__ __forceinline__ uint32_t d_defl_piece(const uint8_t *in, int n, int t
 __global__ void __launch_bounds__(DEFL_THREADS) k_bam_hist(const uint8_t *__restrict__ ubuf, uint64_t utotal, uint64_t head, const uint64_t *__restrict__ ust, int32_t nrec,
                                                           const int32_t *__restrict__ rec0, int32_t stride, const DeflTabs *__restrict__ T, uint32_t *__restrict__ ghist)
 {
-    __shared__ uint32_t in4[BAM_BLK / 4];
+    __shared__ uint32_t in4[DEFL_IN4_WORDS];
     __shared__ DeflSeg seg[DEFL_SEGCAP];
     __shared__ uint32_t hist[DEFL_NCLS * 288];
+    __shared__ uint16_t s_len[260];
     __shared__ int s_nseg;
     const int t = threadIdx.x;
+    if (t < 259) s_len[t] = T->len_sym[t];
     const uint64_t b = (uint64_t)blockIdx.x * stride, u0 = b * BAM_BLK;
     const int n = (int)(utotal - u0 < BAM_BLK ? utotal - u0 : BAM_BLK);
     const uint32_t *src4 = (const uint32_t*)(ubuf + u0);
-    for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i] = src4[i];
+    for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i + (i >> 4)] = src4[i];
     for (int i = t; i < DEFL_NCLS * 288; i += DEFL_THREADS) hist[i] = 0;
     if (t < 64) { const int ns = d_defl_segments(ubuf, u0, n, head, ust, nrec, rec0[b], seg, t); if (t == 0) s_nseg = ns; }
     __syncthreads();
-    d_defl_piece<2>((const uint8_t*)in4, n, t, seg, s_nseg, T, nullptr, hist);
+    d_defl_piece<2>((const uint8_t*)in4, n, t, seg, s_nseg, T, nullptr, hist, nullptr, s_len);
     __syncthreads();
     for (int i = t; i < DEFL_NCLS * 288; i += DEFL_THREADS) if (hist[i]) atomicAdd(&ghist[i], hist[i]);
 }
@@ -662,23 +672,27 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__
                                                               const int32_t *__restrict__ rec0, const DeflTabs *__restrict__ T, const CrcTabs *__restrict__ CT,
                                                               uint8_t *__restrict__ slots, uint32_t *__restrict__ csize, uint32_t blk0)
 {
-    __shared__ uint32_t in4[BAM_BLK / 4];
+    __shared__ uint32_t in4[DEFL_IN4_WORDS];
     __shared__ uint32_t out4[BAM_BLK / 4 + 8];
     __shared__ DeflSeg seg[DEFL_SEGCAP];
     __shared__ uint32_t tab[256], wsum[16], red[4];
+    __shared__ uint32_t s_lit[DEFL_NCLS * 288];          // the code tables next to the data: a lookup per input byte, twice
+    __shared__ uint16_t s_len[260];
     __shared__ int s_nseg; __shared__ uint32_t s_total;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t; i < DEFL_NCLS * 288; i += DEFL_THREADS) s_lit[i] = T->lit[i / 288][i % 288];
+    if (t < 259) s_len[t] = T->len_sym[t];
     const uint64_t b = (uint64_t)blockIdx.x + blk0, u0 = b * BAM_BLK;
     const int n = (int)(utotal - u0 < BAM_BLK ? utotal - u0 : BAM_BLK);
     const uint32_t *src4 = (const uint32_t*)(ubuf + u0);
-    for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i] = src4[i];
+    for (int i = t; i < (n + 3) >> 2; i += DEFL_THREADS) in4[i + (i >> 4)] = src4[i];
     for (int i = t; i < BAM_BLK / 4 + 8; i += DEFL_THREADS) out4[i] = 0;
     if (t < 256) tab[t] = CT->byte_tab[t];
     if (t < 64) { const int ns = d_defl_segments(ubuf, u0, n, head, ust, nrec, rec0[b], seg, t); if (t == 0) s_nseg = ns; }
     __syncthreads();
     const uint8_t *in = (const uint8_t*)in4;
     const int nseg = s_nseg;
-    const uint32_t bits = d_defl_piece<0>(in, n, t, seg, nseg, T, nullptr, nullptr);
+    const uint32_t bits = d_defl_piece<0>(in, n, t, seg, nseg, T, nullptr, nullptr, s_lit, s_len);
     // exclusive scan of the bit counts over the workgroup
     const uint32_t inc = (uint32_t)d_wave_incl((int)bits, lane);
     if (lane == 63) wsum[wv] = inc;
@@ -690,7 +704,7 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__
     const bool stored = cbytes + 26 > (uint32_t)n + 31 || cbytes > BAM_BLK;        // deflate no smaller than a stored block: keep it stored
     if (!stored) {
         BitW W; W.acc = 0; W.nb = (int)(off & 31); W.word = off >> 5; W.out = out4;
-        d_defl_piece<1>(in, n, t, seg, nseg, T, &W, nullptr);
+        d_defl_piece<1>(in, n, t, seg, nseg, T, &W, nullptr, s_lit, s_len);
         if (W.nb) atomicOr(&out4[W.word], (uint32_t)W.acc);
     }
     // CRC-32 of the input: pieces of 64 bytes, combined with x^(512 k) (crc(A || B) = crc(A) x^(8|B|) + crc(B))
@@ -698,13 +712,13 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__
     if (n == BAM_BLK) {
         if (t < BAM_BLK / DEFL_PIECE) {
             uint32_t s = 0xffffffffu;
-            const uint8_t *p = in + t * DEFL_PIECE;
+            const uint8_t *p = in + t * (DEFL_PIECE + 4);            // the padded piece
             for (int i = 0; i < DEFL_PIECE; ++i) s = tab[(s ^ p[i]) & 0xffu] ^ (s >> 8);
             c = d_gf2_mulmod(CT->xpow64[BAM_BLK / DEFL_PIECE - 1 - t], ~s);
         }
     } else if (t == 0) {
         uint32_t s = 0xffffffffu;
-        for (int i = 0; i < n; ++i) s = tab[(s ^ in[i]) & 0xffu] ^ (s >> 8);
+        for (int i = 0; i < n; ++i) s = tab[(s ^ DEFL_INB(in, i)) & 0xffu] ^ (s >> 8);
         c = ~s;
     }
     for (int s = 32; s >= 1; s >>= 1) c ^= (uint32_t)__shfl_xor((int)c, s);
@@ -714,8 +728,8 @@ __global__ void __launch_bounds__(DEFL_THREADS) k_bgzf_deflate(const uint8_t *__
     uint8_t *out = slots + b * (uint64_t)DEFL_SLOT;
     const uint32_t payload = stored ? (uint32_t)n + 5 : cbytes;
     if (stored) {
-        for (int i = t; i < (n >> 2); i += DEFL_THREADS) d_st32(out + 23 + 4 * i, in4[i]);
-        for (int i = (n & ~3) + t; i < n; i += DEFL_THREADS) out[23 + i] = in[i];
+        for (int i = t; i < (n >> 2); i += DEFL_THREADS) d_st32(out + 23 + 4 * i, in4[i + (i >> 4)]);
+        for (int i = (n & ~3) + t; i < n; i += DEFL_THREADS) out[23 + i] = DEFL_INB(in, i);
         if (t == 0) { out[18] = 1; d_st16(out + 19, (uint32_t)n); d_st16(out + 21, (uint32_t)(~n & 0xffff)); }
     } else {
         // payload at out + 18: 2 bytes past a dword boundary
@@ -921,11 +935,22 @@ extern "C" int telr_debug_bam_ms(float *out) { if (!out) return TELR_E_ARG; memc
 
 // the .bai of a coordinate-sorted record sequence: alns in sorted order through `order`, uncompressed start of every
 // record (sorted order, [nrec + 1]) and the file offset of every BGZF block ([nblk + 1])
-static void bai_build(const std::vector<telr_aln> &recs, const uint32_t *order, size_t nrec, size_t n_unmapped, const uint64_t *ustart, const uint64_t *coff, size_t nblk,
-                      int32_t n_targets, const int32_t *t_len, std::string &bai)
+// Two steps, so that the long one needs nothing the coder produces: bai_build lays the whole index out with UNCOMPRESSED stream
+// offsets in the place of virtual file offsets (same order, and "same BGZF block" is "same 65,280-byte piece of the stream")
+// and notes where they stand; bai_finish, once the blocks' file offsets are known, rewrites those fields.
+static void bai_finish(std::string &bai, const std::vector<size_t> &fix, const uint64_t *coff, size_t nblk)
+{
+    auto voff = [&](uint64_t u) { size_t b = (size_t)(u / BAM_BLK); if (b >= nblk) return (uint64_t)(coff[nblk] << 16); return (uint64_t)(coff[b] << 16 | (u - (uint64_t)b * BAM_BLK)); };
+    for (size_t p : fix) { uint64_t u; memcpy(&u, &bai[p], 8); const uint64_t v = voff(u); memcpy(&bai[p], &v, 8); }
+}
+static void bai_build(const std::vector<telr_aln> &recs, const uint32_t *order, size_t nrec, size_t n_unmapped, const uint64_t *ustart,
+                      int32_t n_targets, const int32_t *t_len, std::string &bai, std::vector<size_t> &fix)
 {
     auto put32 = [&](uint32_t v) { bai.append((const char*)&v, 4); };
-    auto voff = [&](uint64_t u) { size_t b = (size_t)(u / BAM_BLK); if (b >= nblk) return (uint64_t)(coff[nblk] << 16); return (uint64_t)(coff[b] << 16 | (u - (uint64_t)b * BAM_BLK)); };
+    auto put_off = [&](std::string &dst, size_t base, uint64_t u) { fix.push_back(base + dst.size()); dst.append((const char*)&u, 8); };      // base: where dst will start inside bai
+    auto voff = [&](uint64_t u) { return u; };
+    auto blk_of = [&](uint64_t u) { return u / BAM_BLK; };
+    fix.clear();
     bai = "BAI\1"; put32((uint32_t)n_targets);
     size_t i = 0;
     const size_t n_mapped = nrec - n_unmapped;
@@ -954,24 +979,25 @@ static void bai_build(const std::vector<telr_aln> &recs, const uint32_t *order, 
         for (size_t c0 = 0; c0 < chs.size(); ) {
             size_t c1 = c0; std::vector<std::pair<uint64_t, uint64_t>> ch;
             while (c1 < chs.size() && chs[c1].bin == chs[c0].bin) {
-                if (!ch.empty() && (ch.back().second >> 16) == (chs[c1].vb >> 16)) ch.back().second = chs[c1].ve; else ch.push_back(std::make_pair(chs[c1].vb, chs[c1].ve));
+                if (!ch.empty() && blk_of(ch.back().second) == blk_of(chs[c1].vb)) ch.back().second = chs[c1].ve; else ch.push_back(std::make_pair(chs[c1].vb, chs[c1].ve));
                 ++c1;
             }
             uint32_t bin = chs[c0].bin, nc = (uint32_t)ch.size();
             body.append((const char*)&bin, 4); body.append((const char*)&nc, 4);
-            for (auto &c : ch) { body.append((const char*)&c.first, 8); body.append((const char*)&c.second, 8); }
+            for (auto &c : ch) { put_off(body, bai.size() + 4, c.first); put_off(body, bai.size() + 4, c.second); }      // body goes in behind the 4-byte bin count
             ++nbin; c0 = c1;
         }
         put32(nbin + (any ? 1 : 0));
         bai += body;
         if (any) {   // samtools' metadata pseudo-bin 37450
             put32(37450u); put32(2u);
-            bai.append((const char*)&ref_beg, 8); bai.append((const char*)&ref_end, 8);
+            put_off(bai, 0, ref_beg); put_off(bai, 0, ref_end);
             uint64_t zero = 0; bai.append((const char*)&n_map, 8); bai.append((const char*)&zero, 8);
         }
         for (int wv = 1; wv < max_lin; ++wv) if (lin[wv] == 0) lin[wv] = lin[wv - 1];
         put32((uint32_t)max_lin);
-        for (int wv = 0; wv < max_lin; ++wv) bai.append((const char*)&lin[wv], 8);
+        // (a window before the first record of the reference keeps 0 = "from the start of the file", as it does with virtual offsets)
+        for (int wv = 0; wv < max_lin; ++wv) { if (lin[wv]) put_off(bai, 0, lin[wv]); else bai.append((const char*)&lin[wv], 8); }
     }
     uint64_t n_no_coor = n_unmapped;
     bai.append((const char*)&n_no_coor, 8);
@@ -1387,11 +1413,37 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     g_bam_need = level == 0 ? 2 * utotal + ((utotal / BAM_BLK + 1) * 31) : 3 * utotal + (utotal / BAM_BLK + 1) * 320;       // stream + slots + image
     uint8_t *d_u; TRY(ctx_buf_t(ctx, "bam_u", (size_t)utotal + 64, &d_u));
     HIPCHK(hipMemcpyAsync(d_u, head.data(), head.size(), hipMemcpyHostToDevice, st));
-    A.ubuf = d_u;
-    if (nrec) hipLaunchKernelGGL(k_bam_write, dim3((unsigned)nrec), dim3(64), 0, st, A);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(d_u + utotal, 0, 64, st));
+    A.ubuf = d_u; A.order = nullptr; A.s0 = 0;
     const size_t nblk = (size_t)((utotal + BAM_BLK - 1) / BAM_BLK);
+    // The records are written in NG pieces of the sorted order (equal shares of the stream): the blocks a piece completes are
+    // coded -- and on their way to the file -- while the next pieces are still being written (level >= 1; stored blocks: one go).
+    const size_t NG = 16;
+    std::vector<size_t> s_end(NG + 1, 0), b_done(NG + 1, 0);
+    for (size_t g = 1; g <= NG; ++g) {
+        s_end[g] = g == NG ? nrec : (size_t)(std::lower_bound(h_ustart.begin(), h_ustart.begin() + nrec, utotal / NG * g) - h_ustart.begin());
+        if (s_end[g] < s_end[g - 1]) s_end[g] = s_end[g - 1];
+        b_done[g] = g == NG ? nblk : std::min(nblk, (size_t)(h_ustart[s_end[g]] / BAM_BLK));        // every byte before record s_end[g] is final
+    }
+    // the pieces are written on a stream of their own, one behind the other (a latency-bound kernel that shares the device well
+    // with the LDS-bound coder); the coder's stream waits for the piece a group needs
+    hipStream_t sw = ctx->side[1];
+    std::vector<hipEvent_t> ev_piece(NG, nullptr);
+    auto write_piece = [&](size_t g) {          // records [s_end[g], s_end[g + 1]) of the sorted order
+        const size_t n = s_end[g + 1] - s_end[g];
+        if (n) {
+            BamArgs P = A; P.order = d_ord; P.s0 = (int32_t)s_end[g];
+            hipLaunchKernelGGL(k_bam_write, dim3((unsigned)n), dim3(64), 0, sw, P);
+        }
+        if (hipEventCreateWithFlags(&ev_piece[g], hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(ev_piece[g], sw);
+    };
+    HIPCHK(hipMemsetAsync(d_u + utotal, 0, 64, st));
+    if (level == 0) { if (nrec) hipLaunchKernelGGL(k_bam_write, dim3((unsigned)nrec), dim3(64), 0, st, A); }
+    else {
+        HIPCHK(hipEventRecord(ctx->ev_fork, st)); HIPCHK(hipStreamWaitEvent(sw, ctx->ev_fork, 0));       // header, offsets and sort order are in place
+        for (size_t g = 0; g < NG; ++g) write_piece(g);
+        if (ev_piece[0]) HIPCHK(hipStreamWaitEvent(st, ev_piece[0], 0));
+    }
+    HIPCHK(hipGetLastError());
     if (ctx->debug) { HIPCHK(hipStreamSynchronize(st)); }
     g_bam_times.ms[3] = ms_since(t0); t0 = now();
     // ---- 6. BGZF blocks
@@ -1418,8 +1470,13 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
         HIPCHK(hipMemcpyAsync(d_T, &T, sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(d_hist, 0, (size_t)DEFL_NCLS * 288 * 4, st));
         // symbol statistics per field class from every `stride`-th block (at most ~4096 blocks: 270 MB of a 30x read set)
-        const int32_t stride = (int32_t)std::max<size_t>(1, nblk / 4096);
-        const unsigned nsamp = (unsigned)((nblk + stride - 1) / stride);
+        // ... of the FIRST piece (the records are sorted by position: the pieces are alike), so that coding can start behind it
+        const size_t nb_first = b_done[1] ? b_done[1] : nblk;
+        if (!b_done[1]) {       // a stream of less than one block per piece: all of it first
+            for (size_t g = 1; g < NG; ++g) { if (ev_piece[g]) HIPCHK(hipStreamWaitEvent(st, ev_piece[g], 0)); b_done[g] = nblk; }
+        }
+        const int32_t stride = (int32_t)std::max<size_t>(1, nb_first / 4096);
+        const unsigned nsamp = (unsigned)((nb_first + stride - 1) / stride);
         hipLaunchKernelGGL(k_bam_hist, dim3(nsamp), dim3(DEFL_THREADS), 0, st, d_u, utotal, (uint64_t)head.size(), d_ust, (int32_t)nrec, d_rec0, stride, d_T, d_hist);
         HIPCHK(hipGetLastError());
         std::vector<uint32_t> h_hist((size_t)DEFL_NCLS * 288);
@@ -1433,23 +1490,25 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
         TRY(ctx_buf_t(ctx, "bam_c", (size_t)utotal + nblk * 31 + 64, &d_c));
         uint32_t *h_csize; uint64_t *h_coff;
         TRY(ctx_hbuf_t(ctx, "bam_hcsize", nblk + 1, &h_csize)); TRY(ctx_hbuf_t(ctx, "bam_hcoff", nblk + 1, &h_coff));
-        const size_t NG = 16, gs = std::max<size_t>(512, (nblk + NG - 1) / NG);
-        std::vector<hipEvent_t> evg;
-        for (size_t b0 = 0; b0 < nblk; b0 += gs) {
-            const size_t nb = std::min(gs, nblk - b0);
+        std::vector<hipEvent_t> evg; std::vector<size_t> gb0, gnb;          // group g: blocks [gb0, gb0 + gnb), complete once piece g is written
+        for (size_t g = 0; g < NG; ++g) {
+            if (g && ev_piece[g]) HIPCHK(hipStreamWaitEvent(st, ev_piece[g], 0));
+            const size_t b0 = b_done[g], nb = b_done[g + 1] - b_done[g];
+            if (!nb) continue;
             hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nb), dim3(DEFL_THREADS), 0, st, d_u, utotal, (uint64_t)head.size(), d_ust, (int32_t)nrec, d_rec0, d_T, d_tabs, d_slots, d_csize, (uint32_t)b0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_csize + b0, d_csize + b0, nb * 4, hipMemcpyDeviceToHost, st));
             hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); HIPCHK(hipEventRecord(e, st)); evg.push_back(e);
+            gb0.push_back(b0); gnb.push_back(nb);
         }
         prog = new StreamProgress();
         StreamProgress *pg = prog; uint64_t *coff_p = coff.data(); hipStream_t st2 = ctx->side[0]; const int device = ctx->device;
         BamSink *sk = ctx->bam_sink && ctx->bam_sink->path == bam_path ? ctx->bam_sink : nullptr;
         producer = std::thread([=]() mutable {
             (void)hipSetDevice(device);
-            uint64_t off = 0; size_t g = 0; bool ok = true;
-            for (size_t b0 = 0; b0 < nblk && ok; b0 += gs, ++g) {
-                const size_t nb = std::min(gs, nblk - b0);
+            uint64_t off = 0; bool ok = true;
+            for (size_t g = 0; g < gb0.size() && ok; ++g) {
+                const size_t b0 = gb0[g], nb = gnb[g];
                 if (hipEventSynchronize(evg[g]) != hipSuccess) { ok = false; break; }
                 for (size_t b = b0; b < b0 + nb; ++b) { h_coff[b] = off; coff_p[b] = off; off += h_csize[b]; }
                 // the file's length, extrapolated from the blocks coded so far (records are sorted by position: the groups are alike; 1.5 % + 4 MB on top)
@@ -1468,15 +1527,18 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     // ---- 7. the file image streams out (behind the groups still being coded); the index is built by a host thread meanwhile
     std::string bai; std::thread bai_th;
     float bai_ms = 0;
-    auto start_bai = [&] { if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), coff.data(), nblk, nt, tg->len.data(), bai); bai_ms = ms_since(tb0); }); };
+    // the index is laid out with stream offsets while the blocks are still being coded; their file offsets go in at the end
+    std::vector<size_t> bai_fix;
+    if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), nt, tg->len.data(), bai, bai_fix); bai_ms = ms_since(tb0); });
     std::thread bai_starter;
-    if (!prog) start_bai();
-    else bai_starter = std::thread([&] { if (producer.joinable()) producer.join(); start_bai(); });        // the block offsets are complete when the producer is
+    if (prog) bai_starter = std::thread([&] { if (producer.joinable()) producer.join(); });        // the block offsets are complete when the producer is
     static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int rc = sink_to_file(ctx, d_c, cbytes, prog, eof_blk, 28, bam_path);
     g_bam_times.ms[5] = ms_since(t0);
     if (bai_starter.joinable()) bai_starter.join();
     if (bai_th.joinable()) bai_th.join();
+    if (write_index) bai_finish(bai, bai_fix, coff.data(), nblk);
+    for (hipEvent_t e : ev_piece) if (e) (void)hipEventDestroy(e);
     bam_sink_drop(ctx);
     g_bam_times.ms[6] = bai_ms;
     if (prog) { if (prog->state < 0 && rc == TELR_OK) rc = TELR_E_HIP; delete prog; }

@@ -10,7 +10,7 @@ leading N block, 50x, 1,300-family library, 3,000 insertions).
 
 A "step" = one pass of the stage-1 hot path (sketch -> seed -> sort -> chain -> back-track -> banded DP + trace-back ->
 records/CIGARs on the host) over the rank's WHOLE read set: up to 1.6 Gbp is one range, a larger set streams through in
-ranges of at most 1.4 Gbp, two in flight (each also bounded by an anchor budget at the density the index has shown).
+an EVEN number of equal ranges of at most 1.4 Gbp (configs[2]: four of 0.96), two in flight (each also bounded by an anchor budget at the density the index has shown).
 Index and packed reads are resident in HBM before the timed region (`value`); `value_incl_h2d` adds the packing +
 upload of the reads.  The second half of the metric, TE loci/s, runs the per-locus bundle (S4, S5, S6 fw+rc + depth +
 AF, S7 x2 + liftover) on window reads selected from the ENGINE'S OWN stage-1 records (TELR_assembly.py:384-415).
@@ -780,7 +780,7 @@ def main():
                    "reads_this_rank": int(len(D["reads"][2])), "read_bases_this_rank": n_bases, "read_bases_job": job_bases,
                    "parallelism": ("one fixed read set dealt to %d ranks in blocks by cumulative bases" % world if a.scaling == "strong" else "every rank maps its own read set (x%d)" % world)
                                   + "; index replicated (built by every rank, no broadcast); no collective on the stage-1 data path",
-                   "ranges": "one telr_map call per step; a read set of up to 1.6 Gbp is one range, a larger one streams through in ranges of at most 1.4 Gbp, two in flight, each also bounded by 1.6 G anchors at the density the index has shown (include/telr_hip.h: telr_map)",
+                   "ranges": "one telr_map call per step; a read set of up to 1.6 Gbp is one range, a larger one streams through in an even number of equal ranges of at most 1.4 Gbp, two in flight (whichever slot is free takes the next), each also bounded by 1.6 G anchors at the density the index has shown (include/telr_hip.h: telr_map)",
                    "streaming": "telr_map returns with the records; the CIGAR DMA of step k overlaps step k+1 (all complete inside the timed region)"},
         "per_rank_ms_per_step": per_rank_ms, "rccl_world_size": world if dist is not None else 0,
         "roofline": {"bound": "hbm", "kernel": k_name, "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,

@@ -204,8 +204,8 @@ int  telr_index_stats(const telr_index *idx, int64_t *n_minimizers, int64_t *n_d
  *      single target qtarget[i]; S5: TELR_MF_PER_TARGET) ------------------------
  * qtarget may be NULL (every query sees every target) or hold one target id
  * per query (-1 = all).  Blocking; internally stream-asynchronous.
- * A query set of any size is accepted: up to 1.6 Gbp is one range; a larger one streams through in ranges of at most
- * 1.4 Gbp, two of them in flight (each bounded by an anchor budget at the density the index has shown), and the records
+ * A query set of any size is accepted: up to 1.6 Gbp is one range; a larger one streams through in an even number of equal
+ * ranges of at most 1.4 Gbp, two of them in flight (each bounded by an anchor budget at the density the index has shown), and the records
  * come back in query order whatever the cut.  The scratch is grow-only per context (about 75 B per query base of the
  * largest range at 0.25 anchors per base); TELR_E_NOMEM with two ranges in flight makes the call run again one range at a
  * time before it is reported. */

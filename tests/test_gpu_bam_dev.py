@@ -236,24 +236,30 @@ def test_prepared_output_file_gives_the_same_bam(engine, tmp_path):
         ix.free_raw(r)
 
 
-def test_prepared_output_file_without_prefaulting(tmp_path):
-    """TELR_BAM_NO_POPULATE=1 (blocks allocated, not pre-faulted: the round's earlier sink) in a process of its own"""
+@pytest.mark.parametrize("switch", ["TELR_BAM_NO_POPULATE", "TELR_BAM_NO_TWIN"])
+def test_writer_switches_in_a_process_of_their_own(tmp_path, switch):
+    """TELR_BAM_NO_POPULATE=1 (the prepared file's blocks allocated, not pre-faulted: the round's earlier sink) and
+    TELR_BAM_NO_TWIN=1 (the writer uploads the CIGARs although the result kept them on the device): read once per process,
+    so each runs in its own; the file must be the one the default path writes"""
     import os, subprocess, sys
     code = r"""
 import sys, os
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from telr_amd.aligner import Engine
+from telr_amd._abi import MF_KEEP_CIGARS
 import test_gpu_bam_dev as T
 eng = Engine(0)
 ix, qset, names, tn, mo = T._map_synthetic(eng, 200, 9)
-r = ix.map_raw(qset, mo)
+mk = type(mo).from_buffer_copy(mo); mk.flags |= MF_KEEP_CIGARS
+r = ix.map_raw(qset, mo); rk = ix.map_raw(qset, mk)
 a, b = sys.argv[1] + "/a.bam", sys.argv[1] + "/b.bam"
 ix.write_bam_device(r, qset, names, tn, a, cmdline="t", level=1)
 ix.bam_prepare(b, 40 << 20)
-ix.write_bam_device(r, qset, names, tn, b, cmdline="t", level=1)
-assert open(a, "rb").read() == open(b, "rb").read()
+ix.write_bam_device(rk, qset, names, tn, b, cmdline="t", level=1)
+assert eng.L.telr_debug_bam_twin() == (0 if os.environ.get("TELR_BAM_NO_TWIN") else 1)
+assert open(a, "rb").read() == open(b, "rb").read() and open(a + ".bai", "rb").read() == open(b + ".bai", "rb").read()
 assert eng.L.telr_bam_release_wait() == 0
 print("same")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=dict(os.environ, TELR_BAM_NO_POPULATE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    p = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=dict(os.environ, **{switch: "1"}), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0 and b"same" in p.stdout, p.stderr.decode()[-2000:]

@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--no-bam-twin", action="store_true", help="BAM leg without TELR_MF_KEEP_CIGARS: the writer uploads the CIGAR array again")
     ap.add_argument("--bam-sha", action="store_true", help="report the SHA-256 of the BAM files the legs write (the N-rank job BAM equals the 1-rank BAM byte for byte)")
     ap.add_argument("--force-exchange", action="store_true", help="run the N>1 code path of the loci leg (window-read all-to-all, pooled read set, all-gather) at world size 1 too: under torch.distributed.run on a 1-GPU box this drives the collectives through RCCL on device tensors")
+    ap.add_argument("--no-shard-leg", action="store_true", help="skip expected_strong_scaling (the shard of rank 0 of a 2 / 4 / 8-rank run mapped alone on this GPU)")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the streaming host-inclusive measurement (a second context uploads the next read batch while the first maps)")
     ap.add_argument("--bam-leg", default="device", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
     ap.add_argument("--bam-dir", default="/dev/shm")
@@ -616,6 +617,31 @@ def main():
             t = torch.tensor([aligned_s], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t); aligned_s = float(t[0])
         value_stream = aligned_s / dts / 1e9
 
+    # ---- what one rank of an N-rank strong-scaling run would do: the shard of rank 0 at N = 2 / 4 / 8, on this GPU -----------------
+    shard_out = None
+    if world == 1 and not a.no_shard_leg and a.scaling == "strong" and len(D["reads"][2]) >= 4096:
+        try:
+            shard_out = {"what": "the reads rank 0 of an N-rank run is dealt (shard.shard_reads: by cumulative bases), mapped alone on this GPU, 3 steps after one warm-up: "
+                                 "an upper bound of the strong-scaling efficiency (nothing else of an N-rank node interferes here)", "ranks": {}}
+            ln_all = D["reads"][2]
+            for nrk in (2, 4, 8):
+                idx = np.array(shard.shard_reads(ln_all, nrk)[0], np.int32)
+                sub = qs.subset(idx)
+                rr = ix.map_raw(sub, mo); ix.free_raw(rr)
+                sync(); t0s = time.time(); ab = 0
+                for _ in range(3):
+                    rr = ix.map_raw(sub, mo)
+                    n_ = eng.L.telr_result_count(rr)
+                    v_ = np.frombuffer((ctypes.c_char * (n_ * ALN_DTYPE.itemsize)).from_address(eng.L.telr_result_alns(rr)), dtype=ALN_DTYPE, count=n_)
+                    ab += int(v_["qlen"][(v_["flags"] & 1) != 0].sum())
+                    ix.free_raw(rr)
+                sync(); dts_ = time.time() - t0s
+                rate = ab / dts_ / 1e9
+                shard_out["ranks"][str(nrk)] = {"shard_gbp": float(ln_all[idx].sum()) / 1e9, "ms_per_step": dts_ / 3 * 1e3, "gbp_per_s": rate, "efficiency_vs_one_gpu": rate / value}
+                sub.free()
+        except Exception as e:
+            shard_out = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- stage 1 up to the reference's hand-off H1: a coordinate-sorted, indexed BAM (TELR_alignment.py:103-114) ------------
     bam_out = None
     if a.bam_leg != "none":
@@ -804,6 +830,8 @@ def main():
     }
     if bam_out is not None:
         out["stage1_to_sorted_bam"] = bam_out
+    if shard_out is not None:
+        out["expected_strong_scaling"] = shard_out
     if files_out is not None:
         out["stage1_from_files"] = files_out
     if loci_out is not None:

@@ -2284,8 +2284,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // selection pass, the record assembly -- and its latency-bound stretches are covered by the other range's kernels;
         // results are appended in range order through the turn gate of the result.  With the long-read lane (two batches per
         // range already) this gained nothing; without it configs[2] goes from 15.7 to 16.5-17.4 Gbp/s (ranges of 0.7-1.6 Gbp:
-        // flat).  A read set that fits ONE range stays one range: halving it to pipeline the halves gains nothing at 1 Gbp
-        // and loses 5-17 % at 0.5 Gbp.  TELR_PIPELINE=1 switches it off; =force pipelines any multi-range call (tests).
+        // flat).  A read set that fits ONE range is halved when it holds 0.67 Gbp or more (below that the halves lose: 5-17 % at
+        // 0.4-0.5 Gbp).  TELR_PIPELINE=1 switches it off; =force pipelines any multi-range call (tests).
         int pipe = 2; bool force = false;
         if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }
         if (ctx->is_child || ctx->pipe_nomem || (!force && (ctx->debug || nq < 4000))) pipe = 1;
@@ -2298,7 +2298,9 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             if (mo->vote_len > 0 && !qtarget && !(mo->flags & TELR_MF_PER_TARGET)) cap = 1100LL << 20;
             const double per_base = ix->anchors_per_base > 0 ? ix->anchors_per_base : index_density_bound(ix, mid_occ.mid_occ);
             if (per_base > 0) cap = std::min<int64_t>(cap, std::max<int64_t>(256LL << 20, (int64_t)(0.8e9 / per_base)));      // two in flight: half the anchor budget each
-            if (total_bases > std::min<int64_t>(batch_bases, (int64_t)(per_base > 0 ? 1.6e9 / per_base : 1e18)) || force) {
+            // ... or that is large enough for two halves in flight to win: measured on configs[2] reads, two ranges against one:
+            // 0.40 Gbp 30.7 / 27.4 ms, 0.51 Gbp 32.9 / 33.9, 0.81 Gbp 47.2 / 51.3, 1.01 Gbp 57.3 / 63.2 (the shard of a 4-rank run)
+            if (total_bases > std::min<int64_t>(batch_bases, (int64_t)(per_base > 0 ? 1.6e9 / per_base : 1e18)) || total_bases >= (640LL << 20) || force) {
                 int64_t nr = std::max<int64_t>(2, (total_bases + cap - 1) / cap);
                 nr += nr & 1;          // an even number of equal ranges keeps both slots busy to the end (configs[2]: 3 ranges 215 ms, 4 ranges 205 ms per step)
                 batch_bases = (total_bases + nr - 1) / nr + queries->max_len + 1;      // the slack keeps the greedy cut below from leaving a stub range behind

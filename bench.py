@@ -637,7 +637,8 @@ def main():
                     ix.free_raw(rr)
                 sync(); dts_ = time.time() - t0s
                 rate = ab / dts_ / 1e9
-                shard_out["ranks"][str(nrk)] = {"shard_gbp": float(ln_all[idx].sum()) / 1e9, "ms_per_step": dts_ / 3 * 1e3, "gbp_per_s": rate, "efficiency_vs_one_gpu": rate / value}
+                shard_out["ranks"][str(nrk)] = {"shard_gbp": float(ln_all[idx].sum()) / 1e9, "ms_per_step": dts_ / 3 * 1e3, "gbp_per_s": rate, "efficiency_vs_one_gpu": rate / value,
+                                                "stage_ms_last_call": {k: round(v, 2) for k, v in eng.stage_ms().items() if v >= 0.3}}
                 sub.free()
         except Exception as e:
             shard_out = {"error": "%s: %s" % (type(e).__name__, e)}

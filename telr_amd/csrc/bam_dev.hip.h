@@ -1284,6 +1284,7 @@ extern "C" int telr_release_scratch(telr_ctx *ctx)
     std::vector<DBuf*> v; ctx_collect_scratch(ctx, v);
     for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") == 0 && kv.second.p) v.push_back(&kv.second);
     for (DBuf *d : v) { (void)hipFree(d->p); d->p = nullptr; d->bytes = 0; }
+    if (ctx->twin_pool) { (void)hipFree(ctx->twin_pool); ctx->twin_pool = nullptr; ctx->twin_pool_cap = 0; }      // the device CIGAR array of a freed result
     return TELR_OK;
 }
 extern "C" int telr_device_mem(telr_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)

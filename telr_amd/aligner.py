@@ -18,6 +18,30 @@ def _np_from(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dt, count=n).copy()
 
 
+_DEFERRED = None          # list of (free function, handle) while deferred_frees() is active
+
+
+class deferred_frees:
+    """`with deferred_frees():` -- sequence sets and indexes freed inside the block (explicitly or by the garbage collector) give
+    their device memory back when the block ends.  hipFree waits for the whole device, so a free on one context stalls its host
+    thread behind whatever another context of the process is running (the loci bundle: S4 / S5 / S7 next to S6)."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.outer = _DEFERRED
+        if _DEFERRED is None:
+            _DEFERRED = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        if self.outer is None:
+            todo, _DEFERRED = _DEFERRED, None
+            for fn, h in todo:
+                fn(h)
+        return False
+
+
 class Engine:
     """One per process per device."""
 
@@ -131,7 +155,10 @@ class SeqSet:
 
     def free(self):
         if getattr(self, "h", None):
-            self.eng.L.telr_seqset_free(self.h)
+            if _DEFERRED is not None:               # hipFree waits for the device: not while another context's call is running on it
+                _DEFERRED.append((self.eng.L.telr_seqset_free, self.h))
+            else:
+                self.eng.L.telr_seqset_free(self.h)
             self.h = None
 
     def __del__(self):
@@ -321,7 +348,10 @@ class Index:
 
     def free(self):
         if getattr(self, "h", None):
-            self.eng.L.telr_index_free(self.h)
+            if _DEFERRED is not None:
+                _DEFERRED.append((self.eng.L.telr_index_free, self.h))
+            else:
+                self.eng.L.telr_index_free(self.h)
             self.h = None
 
     def __del__(self):

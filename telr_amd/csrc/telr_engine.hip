@@ -482,18 +482,18 @@ extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int3
     if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&d_idx, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
+    // the index list lives in the context's scratch: a hipMalloc / hipFree pair per call would make the call wait for the whole device
+    { void *p = nullptr; const int rc = ctx_buf(ctx, "subset_idx", (size_t)(n ? n : 1) * 4, &p); if (rc != TELR_OK) { telr_seqset_free(s); return rc; } d_idx = (int32_t*)p; }
     hipStream_t st = ctx->stream;
     // the 8 slack words behind the last sequence are read by window loads: keep them defined
-    if ((e = hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st)) != hipSuccess || (e = hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st)) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
-    if ((e = hipMemcpyAsync(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+    if ((e = hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st)) != hipSuccess || (e = hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     if (n) {
-        if ((e = hipMemcpyAsync(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice, st)) != hipSuccess || (e = hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+        if ((e = hipMemcpyAsync(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice, st)) != hipSuccess || (e = hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
         hipLaunchKernelGGL(k_seq_gather, dim3(n), dim3(256), 0, st, parent->d_seq2, parent->d_nmask, parent->d_boff, d_idx, s->d_boff, n, s->d_seq2, s->d_nmask);
-        if ((e = hipGetLastError()) != hipSuccess) { (void)hipFree(d_idx); return fail(e); }
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e);
     }
     e = hipStreamSynchronize(st);
-    (void)hipFree(d_idx);
     if (e != hipSuccess) return fail(e);
     *out = s;
     return TELR_OK;

@@ -5,7 +5,16 @@ A "locus" = (name "<chr>_<start>_<end>", contig sequence, Sniffles ALT sequence,
 from . import telr_te, telr_af, telr_liftover
 
 
-def run_loci(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, presets="ont", ref_te_rows=None,
+def run_loci(backend, *args, **kw):
+    """run_loci_impl with the device frees of the bundle's temporary sets and indexes held back to its end (aligner.deferred_frees)"""
+    if hasattr(backend, "worker"):
+        from .aligner import deferred_frees
+        with deferred_frees():
+            return run_loci_impl(backend, *args, **kw)
+    return run_loci_impl(backend, *args, **kw)
+
+
+def run_loci_impl(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, presets="ont", ref_te_rows=None,
              flank_len=500, gap=20, overlap=20, af_params=(100, 200, 50, 50), read_set=None, polish=None, polish_iterations=1, overlap_af=True):
     """loci: list of dicts(name, contig, alt, reads).  With `read_set` (the stage-1 read SeqSet resident on the
     device) a locus gives `read_idx` (indices into it) instead of `reads`.  polish="pileup": the draft contigs are first

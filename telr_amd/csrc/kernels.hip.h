@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q
     for (int o = 32; o >= 1; o >>= 1) s += (int64_t)((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)s, o) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)s >> 32), o) << 32);
     if (lane == 0) q_hits[q] = s;
 }
-struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; };
+struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[4]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
 struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
 // minimizer of hit h (first entry of the inclusive prefix sums above h)
 __device__ __forceinline__ uint32_t d_vote_owner(const VoteChunk &C, uint32_t h)
@@ -844,21 +844,40 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
                     C.P[2 * lane] = inc - n2[1]; C.P[2 * lane + 1] = inc;
+                    // the minimizers that have hits, in order (rid), and where this lane's two lists start: a hit's list is then found
+                    // by counting list starts up to it -- bits of one 64-bit word per window -- instead of bisecting the prefix sums
+                    const uint64_t nz0 = __ballot(n2[0] > 0), nz1 = __ballot(n2[1] > 0);
+                    const uint64_t below = (1ULL << lane) - 1ULL;
+                    const uint32_t rk0 = (uint32_t)__popcll(nz0 & below) + (uint32_t)__popcll(nz1 & below);
+                    if (n2[0]) C.rid[rk0] = (uint8_t)(2 * lane);
+                    if (n2[1]) C.rid[rk0 + (n2[0] ? 1u : 0u)] = (uint8_t)(2 * lane + 1);
+                    const uint32_t st0 = inc - n2[0] - n2[1], st1 = inc - n2[1];
+                    uint32_t cb = 0;              // lists that start before the current window
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t H = (uint32_t)__shfl((int)inc, 63);
                     // the walk: two windows of 64 hits per trip
                     for (uint32_t h0 = 0; h0 < H; h0 += 128) {
                         uint32_t m_[2], gp_[2], sl_[2], rv_[2]; bool in_[2]; uint32_t py_[2];
+                        // list starts inside the two windows
+                        if (lane < 4) C.wm[lane] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        { const uint32_t d0 = st0 - h0, d1 = st1 - h0;
+                          if (n2[0] && d0 < 128u) atomicOr(&C.wm[d0 >> 5], 1u << (d0 & 31));
+                          if (n2[1] && d1 < 128u) atomicOr(&C.wm[d1 >> 5], 1u << (d1 & 31)); }
+                        __builtin_amdgcn_wave_barrier();
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const uint32_t h = h0 + 64 * u + lane;
                             in_[u] = h < H; m_[u] = 0; py_[u] = 0;
+                            const uint64_t wmask = (uint64_t)C.wm[2 * u + 1] << 32 | C.wm[2 * u];
+                            const uint32_t upto = (uint32_t)__popcll(wmask & ((2ULL << lane) - 1ULL));
                             if (in_[u]) {
-                                const uint32_t m = d_vote_owner(C, h);
+                                const uint32_t m = C.rid[cb + upto - 1u];
                                 const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
                                 m_[u] = m;
                                 py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
                             }
+                            cb += (uint32_t)__popcll(wmask);
                         }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {

@@ -38,7 +38,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     b = d["stage1_to_sorted_bam"]                                        # the default run carries the stage-1 hand-off leg
     assert "error" not in b and b["writer"] == "device" and 0 < b["gbp_per_s_incl_bam"] < d["value"] and b["bam_bytes"] > 1000000
     assert d["value_incl_h2d"] <= d["value"] and d["te_loci"]["n"] == 30
-    assert 0 < d["value_streaming_incl_h2d"] <= 1.3 * d["value"]          # measured with every step's reads packed and uploaded underneath the previous step
+    # measured with every step's reads packed and uploaded underneath the previous step; two steps of 25 ms each: a relation between two
+    # noisy numbers, only there to catch a wrong unit
+    assert 0 < d["value_streaming_incl_h2d"] <= 2.0 * d["value"]
 
 
 @pytest.mark.gpu

@@ -730,8 +730,9 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 //   k_vote_qhits    hits per query (an upper bound of its anchors) -> after a scan, the query's piece of the staging array
 //   k_seed_vote     one block (three waves) per query; the waves take its sub-reads in turn (minimizers are in query order: a
 //                   sub-read is a contiguous run of them, found by one boundary sweep into LDS).  A wave lays the hit lists
-//                   of up to 128 minimizers end to end and walks them ONE LANE PER HIT (a lane finds its minimizer by bisection
-//                   of the prefix sums in LDS; two windows of 64 hits are in flight so that their occurrence loads overlap):
+//                   of up to 128 minimizers end to end and walks them ONE LANE PER HIT (a lane finds its list by counting the
+//                   list starts up to its hit: bits of one word per 64-hit window, set by the lanes that own the lists; two
+//                   windows are in flight so that their occurrence loads overlap):
 //                   every hit votes for its folded diagonal bin in the wave's LDS table (one atomic; the fullest bin comes
 //                   back with the atomics' returns) and is remembered in LDS.  Then the remembered hits are tested -- a hit
 //                   stays iff its bin and the two neighbours hold enough votes -- and the survivors go to the query's piece
@@ -774,13 +775,6 @@ __global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q
 }
 struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[4]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
 struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
-// minimizer of hit h (first entry of the inclusive prefix sums above h)
-__device__ __forceinline__ uint32_t d_vote_owner(const VoteChunk &C, uint32_t h)
-{
-    uint32_t lo = 0, hi = VOTE_MZ - 1;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (C.P[mid] > h) hi = mid; else lo = mid + 1; }
-    return lo;
-}
 __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteOpt V, VoteArgs VA)
 {
     __shared__ uint32_t tab[VOTE_WAVES][VOTE_SLOTS];

@@ -313,6 +313,9 @@ def job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_
             try:                       # the other ranks wait at the barrier below whatever happens here
                 alns, cigars, reads, all_names = got
                 ix.bam_prepare(path, int((0.95 if a.bam_level else 2.9) * int(reads[2].sum())) + (64 << 20))
+                fr, _tot = eng.mem_info()
+                if fr < 12 * int(reads[2].sum()) + (2 << 30):          # the job's reads + the writer's ~9 B per base: this rank's mapping scratch goes back first
+                    eng.release_scratch()
                 jq = eng.seqset(reads)
                 jr = ix.result_from_arrays(alns, cigars)
                 ix.write_bam_device(jr, jq, Index._cstr_array(all_names), D["names"], path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
@@ -664,6 +667,9 @@ def main():
     n_loci = len(D["loci"]) if a.loci < 0 else min(a.loci, len(D["loci"]))
     if n_loci > 0:
         loci = D["loci"][:n_loci]
+        # stage 1 is over: its grow-only mapping scratch (150-200 GB for a 30x set, two slots) and the BAM writer's buffers go back
+        # before the per-locus stages size their own (in the pipeline, Sniffles and the assemblers run between the two)
+        eng.release_scratch()
         io10, _ = preset("asm10")
         ix10 = eng.index(ref_strs, io10)
         lib_names = ["fam%d" % i for i in range(len(D["library"]))]
@@ -697,9 +703,6 @@ def main():
                 l.pop("reads", None)
             return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
                                                        shards=shards, presets=presets_arg, read_set=pool_set)
-        # stage 1 is over: its grow-only mapping scratch (150-200 GB for a 30x set, two slots) and the BAM writer's buffers go back
-        # before the per-locus stages size their own (in the pipeline, Sniffles and the assemblers run between the two)
-        eng.release_scratch()
         loci_pass()                                # warm-up (sizes the scratch)
         sync()
         prof = None

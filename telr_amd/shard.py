@@ -155,7 +155,8 @@ def gather_stage1(alns, cigars, reads, read_names, dist=None, device=None, force
     force: run the collectives at world size 1 too.  read_gid: the job-level number of every read of this rank (its place in the
     input file); with it rank 0 puts reads and records back into file order, so the job's arrays -- and the BAM written from them,
     ties in the coordinate sort included -- do not depend on how the reads were dealt.
-    -> on rank 0: (alns, cigars, (buf, off, len), names) of the whole job; on the other ranks None."""
+    -> on rank 0: (alns, cigars, (buf, off, len), names) of the whole job (with read_gid the offsets are not ascending: read i of the job
+    is buf[off[i] : off[i] + len[i]]); on the other ranks None."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     buf, off, ln = reads
@@ -205,9 +206,9 @@ def gather_stage1(alns, cigars, reads, read_names, dist=None, device=None, force
         place = np.empty(len(order), np.int64); place[order] = np.arange(len(order))
         a_all["qid"] = place[a_all["qid"]]
         a_all = a_all[np.argsort(a_all["qid"], kind="stable")]      # the records of a read stay in the order the engine gave them
-        new_len = ln_all[order]; new_off = np.cumsum(new_len.astype(np.int64)) - new_len
-        idx = np.repeat(off_all[order] - new_off, new_len) + np.arange(int(new_len.sum()), dtype=np.int64)
-        buf_all = buf_all[idx]; ln_all = new_len; off_all = new_off
+        # the bases stay where the gather put them: a sequence set is (buffer, offsets, lengths), so putting the reads into file
+        # order is a permutation of the two small arrays (moving 4 GB of bases through a gather index would cost 60 GB of host memory)
+        ln_all = ln_all[order]; off_all = off_all[order]
         out_names = [out_names[i] for i in order]
     return a_all, np.concatenate(out_cig), (buf_all, off_all, ln_all), out_names
 

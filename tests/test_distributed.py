@@ -283,9 +283,10 @@ def test_gather_stage1_rebases_query_ids_and_cigar_offsets(tmp_path, world):
     gids = sorted((q * world + r, r, q) for r in range(world) for q in range(len(pieces[r][3])))
     assert list(z["names2"]) == [pieces[r][3][q] for _, r, q in gids]
     np.testing.assert_array_equal(z["ln2"], [pieces[r][2][2][q] for _, r, q in gids])
-    assert (z["off2"] == np.cumsum(z["ln2"].astype(np.int64)) - z["ln2"]).all()
-    want_buf = [pieces[r][2][0][pieces[r][2][1][q]:pieces[r][2][1][q] + pieces[r][2][2][q]] for _, r, q in gids]
-    np.testing.assert_array_equal(z["buf2"], np.concatenate(want_buf) if want_buf else np.zeros(0, np.uint8))
+    # (the bases are not moved: the offsets are permuted with the lengths)
+    for k, (_, r, q) in enumerate(gids):
+        want = pieces[r][2][0][pieces[r][2][1][q]:pieces[r][2][1][q] + pieces[r][2][2][q]]
+        np.testing.assert_array_equal(z["buf2"][z["off2"][k]:z["off2"][k] + z["ln2"][k]], want)
     k = 0
     for new_q, (_, r, q) in enumerate(gids):
         alns, cig = pieces[r][0], pieces[r][1]

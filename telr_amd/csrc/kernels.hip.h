@@ -587,10 +587,11 @@ __global__ void k_ht_build(const uint64_t *__restrict__ ent_hash, const uint32_t
     }
 }
 // -> true and (off, cnt) of the minimizer's occurrence list, or false
+template <bool FILTER = true>
 __device__ __forceinline__ bool d_ht_lookup(const IndexView &I, uint64_t h, uint32_t &off, uint32_t &cnt)
 {
     uint32_t s = d_ht_slot(h, I.ht_shift, I.ht_mask);
-    { const uint32_t f = d_ht_filter_bit(h, I.ht_shift); if (!((I.ht_home[f >> 5] >> (f & 31)) & 1u)) return false; }
+    if (FILTER) { const uint32_t f = d_ht_filter_bit(h, I.ht_shift); if (!((I.ht_home[f >> 5] >> (f & 31)) & 1u)) return false; }
     for (;;) {
         const uint4 v = *(const uint4*)&I.ht[s];
         const uint64_t hh = (uint64_t)v.y << 32 | v.x;
@@ -755,12 +756,15 @@ __device__ __forceinline__ uint32_t d_vote_slot(uint32_t gp, uint32_t qadj, uint
     const uint32_t d = gp - qadj + (1u << 24);
     return (((d >> shift) & (VOTE_SLOTS / 2 - 1)) << 1) | rev;
 }
+// FILTER = false: short k-mers (the ngmlr-* presets' 13-mers: 67 M possible, most of them in a 100-Mb genome) -- the filter
+// bitmap answers "maybe" for nearly every probe and only costs its own scattered line
+template <bool FILTER>
 __global__ void __launch_bounds__(256) k_vote_lookup(IndexView I, const uint64_t *__restrict__ mz_x, int32_t nmz, int32_t mid_occ, int32_t *__restrict__ mz_ent, int32_t *__restrict__ mz_n)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= nmz) return;
     uint32_t off = 0, n = 0;
-    if (!d_ht_lookup(I, mz_x[g] >> 8, off, n)) n = 0;
+    if (!d_ht_lookup<FILTER>(I, mz_x[g] >> 8, off, n)) n = 0;
     if (n > (uint32_t)mid_occ) n = 0;
     mz_ent[g] = (int32_t)off; mz_n[g] = (int32_t)n;
 }

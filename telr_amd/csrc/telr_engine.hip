@@ -1486,7 +1486,11 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     if (vote) {
         int64_t *d_qhits; int32_t *d_qcnt;
         TRY(ctx_buf_t(ctx, "vote_qhits", (size_t)nq + 2, &d_qhits)); TRY(ctx_buf_t(ctx, "vote_qsoff", (size_t)nq + 2, &d_qsoff)); TRY(ctx_buf_t(ctx, "vote_qcnt", (size_t)nq + 2, &d_qcnt));
-        if (nmz) hipLaunchKernelGGL(k_vote_lookup, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
+        if (nmz) {
+            static const bool always_filter = getenv("TELR_VOTE_FILTER") != nullptr;
+            if (k <= 13 && !always_filter) hipLaunchKernelGGL(k_vote_lookup<false>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
+            else hipLaunchKernelGGL(k_vote_lookup<true>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
+        }
         hipLaunchKernelGGL(k_vote_qhits, dim3(nq + 1), dim3(64), 0, st, d_qmz, d_mn, nq, d_qhits);
         HIPCHK(hipGetLastError());
         TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_qhits, d_qsoff, (size_t)nq + 1)));

@@ -38,15 +38,20 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     const char *p = (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (p == MAP_FAILED) { delete F; return TELR_E_ARG; }
+    static const bool trace = getenv("TELR_TRACE_FASTA") != nullptr;
+    auto tt0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (!trace) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[fasta %s] %-22s %8.2f ms\n", path, what, std::chrono::duration<double, std::milli>(t1 - tt0).count()); tt0 = t1; };
     struct Rec { size_t hdr, body, end; };       // header line start (after '>' / '@'), first byte after the header line, end of the sequence text
     std::vector<Rec> recs;
     const int NT = host_threads();
     auto line_end = [&](size_t i) { const char *e = (const char*)memchr(p + i, '\n', n - i); return e ? (size_t)(e - p) : n; };
     if (p[0] == '>') {
-        std::vector<std::vector<size_t>> starts((size_t)NT);
-        parallel_ranges(NT, NT, [&](int, int t0, int t1) {
+        // slices, not threads: parallel_ranges runs fewer than 64 items on the calling thread (the scan of a 4-GB file was serial)
+        const int NS = std::max(64, NT * 4);
+        std::vector<std::vector<size_t>> starts((size_t)NS);
+        parallel_ranges(NT, NS, [&](int, int t0, int t1) {
             for (int t = t0; t < t1; ++t) {
-                size_t a = n * (size_t)t / NT, b = n * (size_t)(t + 1) / NT;
+                size_t a = n * (size_t)t / NS, b = n * (size_t)(t + 1) / NS;
                 if (t == 0) starts[t].push_back(0);
                 // '>' preceded by a line break, at positions (a, b]
                 for (size_t i = a; i < b; ) { const char *e = (const char*)memchr(p + i, '\n', b - i); if (!e) break; i = (size_t)(e - p) + 1; if (i < n && p[i] == '>') starts[t].push_back(i); }
@@ -68,6 +73,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
             i = e4 < n ? e4 + 1 : n;
         }
     } else { munmap((void*)p, n); delete F; return TELR_E_ARG; }
+    lap("record starts");
     const size_t nr = recs.size();
     if (nr >= (1u << 31)) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
     F->len.resize(nr); F->off.resize(nr);
@@ -88,6 +94,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
         }
         if (fold) folded += fold;
     });
+    lap("lengths + name ends");
     if (too_long) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
     int64_t tot = 0, ntot = 0;
     std::vector<int64_t> noff(nr);
@@ -118,6 +125,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
             F->names[r] = nm;
         }
     });
+    lap("offsets + names");
     if (!in_place) munmap((void*)p, n);
     *out = F;
     return TELR_OK;

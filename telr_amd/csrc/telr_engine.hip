@@ -2186,7 +2186,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
                     if (!cig_grow(&R->cig, &R->cap, base1, base1 + P1->ncig + 1 + P1->ncig / 8)) { P1->ctx = ctx->child[1]; delete P1; return TELR_E_NOMEM; }
                 }
                 const int NT = host_threads();
-                const size_t nw = P1->ncig; const int chunks = 16;
+                const size_t nw = P1->ncig; const int chunks = 64;          // (parallel_ranges runs fewer than 64 items on the calling thread)
                 parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
                     for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + base1 + lo, P1->cig + lo, (hi - lo) * 4); }
                 });

@@ -169,11 +169,13 @@ __device__ __forceinline__ void d_bam_walk(const BamArgs &A, const telr_aln &a, 
         const int qi = qi0 + qinc - qadv, ti = ti0 + tinc - tadv;
         // ---- what this op contributes
         bool ev = false; uint32_t lead = 0, trail = 0, tot = 0; int md_rest = 0, cs_b = 0;
+        B32 qw0, tw0; qw0.w = tw0.w = 0; qw0.n = tw0.n = 0;          // the op's first 32 columns: most M ops are shorter, and the write pass below reads them again
         if (have) {
             if (op == 0) {
                 int first = -1, last = -1;
                 for (int p0 = 0; p0 < L; p0 += 32) {
                     const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0), tw = d_fetch32(A.t2, A.tn, tb0 + ti + p0);
+                    if (WRITE && p0 == 0) { qw0 = qw; tw0 = tw; }
                     uint32_t mis = d_mis32(qw, tw, L - p0);
                     nm += __popc(mis);
                     while (mis) {
@@ -212,7 +214,7 @@ __device__ __forceinline__ void d_bam_walk(const BamArgs &A, const telr_aln &a, 
                 if (op == 0) {
                     int last = -1; bool firstev = true;
                     for (int p0 = 0; p0 < L; p0 += 32) {
-                        const B32 qw = d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0), tw = d_fetch32(A.t2, A.tn, tb0 + ti + p0);
+                        const B32 qw = p0 == 0 ? qw0 : d_strand32(A.q2, A.qn, qb0, ql, rev, qi + p0), tw = p0 == 0 ? tw0 : d_fetch32(A.t2, A.tn, tb0 + ti + p0);
                         uint32_t mis = d_mis32(qw, tw, L - p0);
                         while (mis) {
                             const int j = __ffs((int)mis) - 1, p = p0 + j; mis &= mis - 1u;

@@ -1019,14 +1019,15 @@ static std::string bam_header(int32_t n_targets, const char *const *tnames, cons
 }
 
 // ---- the output file, prepared ahead -----------------------------------------------------------------------------------
-// What a tmpfs file costs is the allocation of its pages (tools/ubench/shm_io.hip on the MI355X box: pwrite into a fresh
-// file 6.4-6.7 GB/s with one thread and LESS with more -- writes to one inode serialise --, posix_fallocate 17 GB/s, pwrite
-// over allocated pages 9.7 GB/s, memcpy through a mapping of the allocated file 12-15 GB/s with 4-16 threads -- no inode lock
-// on that path; DMA straight into a registered mapping runs at 50-57 GB/s but registering costs 0.47 s per 3.9 GB, pages
-// present or not, and stalls every other HIP call of the process meanwhile: measured, rejected).  telr_bam_prepare() starts
-// a thread that creates the file, allocates an estimated size and maps it while the caller is still mapping reads; the
-// writer then moves the finished image through the pinned ring into the mapping with several threads and cuts the file to
-// its real length.
+// What a tmpfs file costs is the allocation of its pages and their way into the writer's page table (tools/ubench/shm_io.hip on
+// the MI355X box: pwrite into a fresh file 6.4-6.7 GB/s with one thread and LESS with more -- writes to one inode serialise --,
+// posix_fallocate 17-19 GB/s, pwrite over allocated pages 9.7 GB/s, memcpy through a mapping of the allocated file 12-15 GB/s
+// with 4-16 threads but 80-200 GB/s once the mapping is populated; DMA straight into a registered mapping runs at 50-57 GB/s
+// but registering costs 0.47 s per 3.9 GB, pages present or not, and stalls every other HIP call of the process meanwhile:
+// measured, rejected).  telr_bam_prepare() creates and maps the file at once and starts a thread that allocates and pre-faults
+// it block by block, front to back, while the caller is still mapping reads; the writer moves the finished image through the
+// pinned ring into the prepared prefix of the mapping and cuts the file to its real length; the mapping is taken apart by a
+// background thread (bam_sink_drop).
 struct BamSink {
     std::string path; int fd = -1; uint8_t *map = nullptr; size_t bytes = 0;
     std::thread th; float ms_alloc = 0, ms_map = 0;

@@ -22,6 +22,12 @@ replicated (built by every rank), no collective on the stage-1 data path; the lo
 travel to the owner in one all-to-all and the per-locus table is merged by ONE all-gather (RCCL).  `--scaling weak`:
 every rank maps its own 30x read set.
 
+Next to `value`, `roofline` and `cpu_baseline` the line carries: `stage1_to_sorted_bam` (reads resident -> telr_map -> coordinate-
+sorted BAM + .bai built on the device, the reference's real stage-1 hand-off; at N > 1 also `job_bam`: the ONE file of the job,
+written by rank 0 from the gathered records), `stage1_from_files` (--files-leg: FASTA files -> telr_alignment.alignment()),
+`value_streaming_incl_h2d`, `te_loci` (+ `polish_pileup`), and at N = 1 `expected_strong_scaling` (rank 0's shard of a 2 / 4 / 8-rank
+run mapped alone on this GPU).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse

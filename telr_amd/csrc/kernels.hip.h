@@ -779,9 +779,28 @@ __global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q
 }
 struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[4]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
 struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
-__global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteOpt V, VoteArgs VA)
+// The vote table of a wave: 2,048 counters.  T16: two 16-bit counters per word -- half the LDS, 12 instead of 9 waves per CU -- for
+// queries whose hits cannot overflow one (the kernel is launched twice: queries with at most `lim16` hits here, the others with
+// 32-bit counters; slot s and slot s ^ 1, the two strands of a diagonal bin, share a word).
+template <bool T16> __device__ __forceinline__ uint32_t d_vt_add(uint32_t *T, uint32_t s)
 {
-    __shared__ uint32_t tab[VOTE_WAVES][VOTE_SLOTS];
+    if (T16) { const uint32_t sh = (s & 1u) << 4; return ((atomicAdd(&T[s >> 1], 1u << sh) >> sh) & 0xffffu) + 1u; }
+    return atomicAdd(&T[s], 1u) + 1u;
+}
+template <bool T16> __device__ __forceinline__ uint32_t d_vt_get(const uint32_t *T, uint32_t s)
+{
+    return T16 ? (T[s >> 1] >> ((s & 1u) << 4)) & 0xffffu : T[s];
+}
+template <bool T16>
+__global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteOpt V, VoteArgs VA, int64_t lim16)
+{
+    constexpr int TW = T16 ? VOTE_SLOTS / 2 : VOTE_SLOTS;          // words of a wave's table
+    {   // this launch's share of the queries
+        const int q_ = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
+        const bool small = VA.q_soff[q_ + 1] - VA.q_soff[q_] <= lim16;
+        if (small != T16) return;
+    }
+    __shared__ uint32_t tab[VOTE_WAVES][TW];
     __shared__ VoteHit stash[VOTE_WAVES][VOTE_HCAP];
     __shared__ VoteChunk chunk[VOTE_WAVES];
     __shared__ int32_t sub_first[VOTE_SUBCAP + 1];
@@ -794,7 +813,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
     VoteHit *HS = stash[wv];
     VoteChunk &C = chunk[wv];
     uint64_t *out = VA.stage + VA.q_soff[q];
-    for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
+    for (int i = lane; i < TW; i += 64) T[i] = 0;
     if (tid == 0) blk_cnt = 0;
     const int nsub = (qlen + V.len - 1) / V.len;
     for (int sb = 0; sb < nsub; sb += VOTE_SUBCAP) {
@@ -887,9 +906,9 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 const uint32_t qadj = rv_[u] ? (uint32_t)qlen - (qpos + 1 - span) - 1 : qpos;
                                 sl_[u] = d_vote_slot(gp_[u], qadj, rv_[u], V.shift);
                                 if (pass == 0) {
-                                    const uint32_t c = atomicAdd(&T[sl_[u]], 1u) + 1u; vmax = c > vmax ? c : vmax;
+                                    const uint32_t c = d_vt_add<T16>(T, sl_[u]); vmax = c > vmax ? c : vmax;
                                     if (hbase + h < VOTE_HCAP) { VoteHit x; x.gp = gp_[u]; x.sm = sl_[u] | m << 11 | (uint32_t)(gc - g0) / VOTE_MZ << 18; HS[hbase + h] = x; }
-                                } else pass_hit = T[(sl_[u] - 2u) & (VOTE_SLOTS - 1)] + T[sl_[u]] + T[(sl_[u] + 2u) & (VOTE_SLOTS - 1)] >= thr1;
+                                } else pass_hit = d_vt_get<T16>(T, (sl_[u] - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl_[u]) + d_vt_get<T16>(T, (sl_[u] + 2u) & (VOTE_SLOTS - 1)) >= thr1;
                             }
                             if (pass == 1) {
                                 const uint64_t bm = __ballot(pass_hit);
@@ -923,7 +942,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                     if (h < nhit) {
                         x = HS[h];
                         const uint32_t sl = x.sm & (VOTE_SLOTS - 1);
-                        pass_hit = T[(sl - 2u) & (VOTE_SLOTS - 1)] + T[sl] + T[(sl + 2u) & (VOTE_SLOTS - 1)] >= thr;
+                        pass_hit = d_vt_get<T16>(T, (sl - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl) + d_vt_get<T16>(T, (sl + 2u) & (VOTE_SLOTS - 1)) >= thr;
                     }
                     const uint64_t bm = __ballot(pass_hit);
                     uint32_t base = 0;
@@ -937,8 +956,8 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t h = lane; h < nhit; h += 64) T[HS[h].sm & (VOTE_SLOTS - 1)] = 0;
-            } else for (int i = lane; i < VOTE_SLOTS; i += 64) T[i] = 0;
+                for (uint32_t h = lane; h < nhit; h += 64) { const uint32_t sl = HS[h].sm & (VOTE_SLOTS - 1); T[T16 ? sl >> 1 : sl] = 0; }
+            } else for (int i = lane; i < TW; i += 64) T[i] = 0;
             __builtin_amdgcn_wave_barrier();
         }
     }

@@ -1499,7 +1499,10 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipStreamSynchronize(st));
         TRY(ctx_buf_t(ctx, "vote_stage", (size_t)nhits + 1, &d_stage));
         VA.q_soff = d_qsoff; VA.stage = d_stage; VA.q_cnt = d_qcnt;
-        hipLaunchKernelGGL(k_seed_vote, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA);
+        // queries whose hits fit 16-bit vote counters (nearly all) with the half-size table, the others with 32-bit counters
+        static const int64_t lim16 = getenv("TELR_VOTE_T16_LIMIT") ? atoll(getenv("TELR_VOTE_T16_LIMIT")) : 65535;
+        hipLaunchKernelGGL(k_seed_vote<true>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
+        hipLaunchKernelGGL(k_seed_vote<false>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
         d_cnt = d_qcnt; d_aoff = d_qaoff; ncnt = (size_t)nq;
     } else hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());

@@ -715,10 +715,15 @@ def main():
         if os.environ.get("TELR_PROF_LOCI") and rank == 0:      # where does the per-locus leg spend its time? (stderr)
             import cProfile
             prof = cProfile.Profile(); prof.enable()
+        # The process holds millions of long-lived Python objects by now (458,550 read names, the loci, the data set): a full
+        # collection of the cyclic garbage collector walks all of them -- 85 ms, every fourth pass.  They are moved to the
+        # permanent generation, as a long-running pipeline would do after loading its inputs.
+        import gc
+        gc.collect(); gc.freeze()
         # three timed passes, the median reported: one pass is 120-160 ms of four small engine calls and Python, and a single
         # sample of it swings by 25 % from run to run (every pass gives the same table)
         t_passes = []
-        for _ in range(1 if prof is not None else 3):
+        for _ in range(1 if prof is not None else int(os.environ.get("TELR_LOCI_PASSES", "3"))):
             if dist is not None:
                 dist.barrier()
             sync()

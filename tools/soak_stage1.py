@@ -31,7 +31,9 @@ def sha(p):
     return h.hexdigest()
 
 
-times, frees, shas = [], [], set()
+import psutil
+proc = psutil.Process()
+times, frees, shas, rss = [], [], set(), []
 for i in range(n_runs):
     for f in (bam, bam + ".bai"):
         if os.path.exists(f):
@@ -43,11 +45,14 @@ for i in range(n_runs):
     shas.add((i % 2, sha(bam), sha(bam + ".bai")))
     frees.append(eng.mem_info()[0])
     time.sleep(0.3)                      # the background release of the run (read set, index, file mappings)
+    rss.append(proc.memory_info().rss)
 for f in (rf, qf, bam, bam + ".bai"):
     if os.path.exists(f):
         os.unlink(f)
 out = {"runs": n_runs, "distinct_outputs_per_method": {m: len([1 for s in shas if s[0] == m]) for m in (0, 1)}, "seconds_first": times[0], "seconds_median": float(np.median(times[2:])),
-       "seconds_max_after_warmup": max(times[2:]), "free_GB_after_run_2": frees[2] / 1e9, "free_GB_after_last": frees[-1] / 1e9}
+       "seconds_max_after_warmup": max(times[2:]), "free_GB_after_run_2": frees[2] / 1e9, "free_GB_after_last": frees[-1] / 1e9,
+       "host_rss_GB_after_run_4": rss[4] / 1e9 if len(rss) > 4 else None, "host_rss_GB_after_last": rss[-1] / 1e9}
 print(json.dumps(out))
 assert all(v == 1 for v in out["distinct_outputs_per_method"].values()), "outputs differ between runs"
 assert frees[-1] >= frees[3] - (1 << 30), "device memory shrinks from run to run"
+assert len(rss) <= 6 or rss[-1] <= rss[4] + (1 << 30), "host memory grows from run to run"

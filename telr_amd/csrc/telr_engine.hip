@@ -685,7 +685,9 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
     for (int i = 0; i < n; ++i) { ix->goff[i] = (uint32_t)g; g = (g + (uint64_t)tg->len[i] + TELR_TPAD + 63) & ~63ULL; if (g >= (1ULL << 31)) return TELR_E_RANGE; }
     ix->goff[n] = (uint32_t)g;
     HIPCHK(hipMalloc(&ix->d_goff, (n + 1) * 4));
-    HIPCHK(hipMemcpy(ix->d_goff, ix->goff.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    // (on the context's stream: a copy on the null stream waits for every blocking stream of the PROCESS, i.e. for whatever another
+    // context is running)
+    HIPCHK(hipMemcpyAsync(ix->d_goff, ix->goff.data(), (n + 1) * 4, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));
     TileList T;
     uint64_t *d_x; uint32_t *d_y; int32_t *d_toff; int32_t nmz = 0;
     if (io->is_hpc) {
@@ -2161,7 +2163,7 @@ static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *que
                 std::vector<int32_t> qt(n);
                 for (int i = 0; i < n; ++i) qt[i] = qtarget[lane_idx[k][i]];
                 if ((rc[k] = ctx_buf_t(c, "lane_qt", (size_t)n + 1, &d_q)) != TELR_OK) return;
-                if (hipMemcpy(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
+                if (hipMemcpyAsync(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
             }
             rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, k == 0 ? R : P1, k == 0 ? &gate : nullptr);
             if (rc[k] == TELR_OK) c->ctr.query_bases += sub[k].total_bases;
@@ -2254,7 +2256,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     int32_t *d_qt = nullptr;
     if (qtarget && nq > 0) {
         TRY(ctx_buf_t(ctx, "qtarget", (size_t)nq, &d_qt));
-        HIPCHK(hipMemcpy(d_qt, qtarget, (size_t)nq * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(d_qt, qtarget, (size_t)nq * 4, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream));      // not the null stream: it waits for all blocking streams of the process
     }
     OccCut mid_occ; mid_occ.mid_occ = index_mid_occ(ix, mo); mid_occ.d_tmid = nullptr;
     if (qtarget || (mo->flags & TELR_MF_PER_TARGET)) TRY(index_per_target_occ(ctx, ix, mo, &mid_occ.d_tmid));

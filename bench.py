@@ -83,6 +83,7 @@ def parse():
     ap.add_argument("--no-bam-twin", action="store_true", help="BAM leg without TELR_MF_KEEP_CIGARS: the writer uploads the CIGAR array again")
     ap.add_argument("--bam-sha", action="store_true", help="report the SHA-256 of the BAM files the legs write (the N-rank job BAM equals the 1-rank BAM byte for byte)")
     ap.add_argument("--force-exchange", action="store_true", help="run the N>1 code path of the loci leg (window-read all-to-all, pooled read set, all-gather) at world size 1 too: under torch.distributed.run on a 1-GPU box this drives the collectives through RCCL on device tensors")
+    ap.add_argument("--flank-parity", action="store_true", help="S7 at full size: the first and last 500 bases of every locus contig (2 x loci flanks) through `asm10 -N 10` against the full reference index, engine vs CPU oracle, record by record (one-off parity evidence; the oracle indexes the reference on one thread)")
     ap.add_argument("--no-shard-leg", action="store_true", help="skip expected_strong_scaling (the shard of rank 0 of a 2 / 4 / 8-rank run mapped alone on this GPU)")
     ap.add_argument("--no-stream-leg", action="store_true", help="skip the streaming host-inclusive measurement (a second context uploads the next read batch while the first maps)")
     ap.add_argument("--bam-leg", default="device", choices=["none", "host", "device"], help="stage 1 to the Sniffles hand-off (TELR_alignment.py:103-114): reads resident -> telr_map -> coordinate-sorted BAM + .bai under --bam-dir; host = the library's host-thread writer, device = record bodies / sort / BGZF on the GPU")
@@ -709,6 +710,15 @@ def main():
                 l.pop("reads", None)
             return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
                                                        shards=shards, presets=presets_arg, read_set=pool_set)
+        flank_parity = None
+        if a.flank_parity and rank == 0:
+            from telr_amd.fasta import concat
+            io10b, mo10 = preset("asm10"); mo10.best_n = 10
+            fl = []
+            for l in loci:
+                c = l["contig"] if isinstance(l["contig"], (bytes, bytearray)) else l["contig"].encode()
+                fl.append(np.frombuffer(c[:500], np.uint8)); fl.append(np.frombuffer(c[-500:], np.uint8))
+            flank_parity = cpu_baseline(ref_strs, concat(fl), io10b, mo10, len(fl), gpu_index=ix10, seed=0)
         loci_pass()                                # warm-up (sizes the scratch)
         sync()
         prof = None
@@ -855,6 +865,8 @@ def main():
         out["stage1_to_sorted_bam"] = bam_out
     if shard_out is not None:
         out["expected_strong_scaling"] = shard_out
+    if a.loci and locals().get("flank_parity") is not None:
+        out["flank_parity_asm10"] = flank_parity
     if files_out is not None:
         out["stage1_from_files"] = files_out
     if loci_out is not None:

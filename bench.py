@@ -719,6 +719,31 @@ def main():
                 c = l["contig"] if isinstance(l["contig"], (bytes, bytearray)) else l["contig"].encode()
                 fl.append(np.frombuffer(c[:500], np.uint8)); fl.append(np.frombuffer(c[-500:], np.uint8))
             flank_parity = cpu_baseline(ref_strs, concat(fl), io10b, mo10, len(fl), gpu_index=ix10, seed=0)
+            # S6 the same way: the window reads of the first 150 loci against the forward and the reverse-complement contig of their
+            # locus (per-query targets), map-ont / map-pb, engine vs oracle
+            from oracle import binding as ob
+            from telr_amd.fasta import revcomp
+            sub_loci = loci[:150]
+            wr6 = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in sub_loci])
+            tg6 = []
+            for l in sub_loci:
+                c = l["contig"] if isinstance(l["contig"], str) else bytes(l["contig"]).decode()
+                tg6 += [c, revcomp(c)]
+            q6, qt_fw = [], []
+            for k, w in enumerate(wr6):
+                for i in w:
+                    q6.append(bytes(rbuf[roff[i]:roff[i] + rln[i]]).decode()); qt_fw.append(2 * k)
+            qt6 = np.array(qt_fw + [x + 1 for x in qt_fw], np.int32); q6 = q6 + q6
+            io6, mo6 = preset("map-ont" if presets_arg == "ont" else "map-pb")
+            t06 = time.time()
+            o6 = ob.OracleIndex(tg6, io6).map(q6, mo6, qtarget=qt6)
+            t_or = time.time() - t06
+            e6 = eng.index(tg6, io6).map(q6, mo6, qtarget=qt6)
+            w6, g6 = _read_digests(o6["alns"], o6["cigars"]), _read_digests(e6.alns, e6.cigars)
+            bad6 = [q for q in set(w6) | set(g6) if w6.get(q) != g6.get(q)]
+            flank_parity["s6"] = {"loci": len(sub_loci), "queries": len(q6), "query_bases": int(sum(len(x) for x in q6)), "records_oracle": int(len(o6["alns"])), "records_engine": int(len(e6.alns)),
+                                  "queries_differing": len(bad6), "identical": not bad6, "oracle_seconds_one_thread": t_or,
+                                  "what": "call site S6: every window read of the first 150 loci against the forward and the reverse-complement contig of its locus (qtarget), all records and CIGARs, engine vs CPU oracle"}
         loci_pass()                                # warm-up (sizes the scratch)
         sync()
         prof = None

@@ -741,6 +741,23 @@ def main():
             e6 = eng.index(tg6, io6).map(q6, mo6, qtarget=qt6)
             w6, g6 = _read_digests(o6["alns"], o6["cigars"]), _read_digests(e6.alns, e6.cigars)
             bad6 = [q for q in set(w6) | set(g6) if w6.get(q) != g6.get(q)]
+            # and the whole per-locus bundle -- S4, S5, S6 + depth + allele frequency, S7 + the liftover tree -- on the first 60 loci,
+            # driven once by the engine and once by the oracle behind the same host code (tests/oracle_backend.py)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_backend import OracleBackend
+            b_loci = []
+            for l, w in zip(loci[:60], wr6[:60]):
+                b_loci.append(dict(l, reads=[bytes(rbuf[roff[i]:roff[i] + rln[i]]).decode() for i in w]))
+                b_loci[-1].pop("read_idx", None)
+            t0b_ = time.time()
+            obk = OracleBackend()
+            bo = locus_pipeline.run_loci(obk, obk.index(ref_strs, io10b), D["names"], lambda ch: ref_of[ch], b_loci, lib_names, lib, presets=presets_arg)
+            t_bo = time.time() - t0b_
+            bh = locus_pipeline.run_loci(eng, ix10, D["names"], lambda ch: ref_of[ch], b_loci, lib_names, lib, presets=presets_arg)
+            flank_parity["bundle"] = {"loci": len(b_loci), "annotation_rows": len(bh["annotation"]), "liftover_reports": len(bh["liftover"]), "af_entries": len(bh["af"]),
+                                      "identical": bh["annotation"] == bo["annotation"] and bh["liftover"] == bo["liftover"] and bh["summary"] == bo["summary"] and bh["af"] == bo["af"],
+                                      "oracle_seconds": t_bo,
+                                      "what": "locus_pipeline.run_loci on the first 60 loci (their real window reads, the full-size reference for S7): annotation rows, liftover reports, summary and allele-frequency tables of the engine run == those of the oracle run"}
             flank_parity["s6"] = {"loci": len(sub_loci), "queries": len(q6), "query_bases": int(sum(len(x) for x in q6)), "records_oracle": int(len(o6["alns"])), "records_engine": int(len(e6.alns)),
                                   "queries_differing": len(bad6), "identical": not bad6, "oracle_seconds_one_thread": t_or,
                                   "what": "call site S6: every window read of the first 150 loci against the forward and the reverse-complement contig of its locus (qtarget), all records and CIGARs, engine vs CPU oracle"}

@@ -718,7 +718,9 @@ def main():
             for l in loci:
                 c = l["contig"] if isinstance(l["contig"], (bytes, bytearray)) else l["contig"].encode()
                 fl.append(np.frombuffer(c[:500], np.uint8)); fl.append(np.frombuffer(c[-500:], np.uint8))
+            sys.stderr.write("[site parity] S7 flanks...\n"); sys.stderr.flush()
             flank_parity = cpu_baseline(ref_strs, concat(fl), io10b, mo10, len(fl), gpu_index=ix10, seed=0)
+            sys.stderr.write("[site parity] S7 done; S6 oracle...\n"); sys.stderr.flush()
             # S6 the same way: the window reads of the first 150 loci against the forward and the reverse-complement contig of their
             # locus (per-query targets), map-ont / map-pb, engine vs oracle
             from oracle import binding as ob
@@ -738,7 +740,9 @@ def main():
             t06 = time.time()
             o6 = ob.OracleIndex(tg6, io6).map(q6, mo6, qtarget=qt6)
             t_or = time.time() - t06
+            sys.stderr.write("[site parity] S6 oracle done; S6 engine...\n"); sys.stderr.flush()
             e6 = eng.index(tg6, io6).map(q6, mo6, qtarget=qt6)
+            sys.stderr.write("[site parity] S6 engine done\n"); sys.stderr.flush()
             w6, g6 = _read_digests(o6["alns"], o6["cigars"]), _read_digests(e6.alns, e6.cigars)
             bad6 = [q for q in set(w6) | set(g6) if w6.get(q) != g6.get(q)]
             # and the whole per-locus bundle -- S4, S5, S6 + depth + allele frequency, S7 + the liftover tree -- on the first 60 loci,
@@ -749,10 +753,15 @@ def main():
             for l, w in zip(loci[:60], wr6[:60]):
                 b_loci.append(dict(l, reads=[bytes(rbuf[roff[i]:roff[i] + rln[i]]).decode() for i in w]))
                 b_loci[-1].pop("read_idx", None)
+            if os.environ.get("TELR_DUMP_BUNDLE"):
+                import pickle
+                with open(os.environ["TELR_DUMP_BUNDLE"], "wb") as fh:
+                    pickle.dump({"loci": [{k: (v if isinstance(v, (str, int, float, list, dict, tuple)) else bytes(v)) for k, v in l.items()} for l in b_loci], "lib_names": lib_names, "lib": lib, "presets": presets_arg}, fh)
             t0b_ = time.time()
             obk = OracleBackend()
             bo = locus_pipeline.run_loci(obk, obk.index(ref_strs, io10b), D["names"], lambda ch: ref_of[ch], b_loci, lib_names, lib, presets=presets_arg)
             t_bo = time.time() - t0b_
+            sys.stderr.write("[site parity] bundle oracle done; bundle engine...\n"); sys.stderr.flush()
             bh = locus_pipeline.run_loci(eng, ix10, D["names"], lambda ch: ref_of[ch], b_loci, lib_names, lib, presets=presets_arg)
             flank_parity["bundle"] = {"loci": len(b_loci), "annotation_rows": len(bh["annotation"]), "liftover_reports": len(bh["liftover"]), "af_entries": len(bh["af"]),
                                       "identical": bh["annotation"] == bo["annotation"] and bh["liftover"] == bo["liftover"] and bh["summary"] == bo["summary"] and bh["af"] == bo["af"],

@@ -561,6 +561,9 @@ static void chain_backtrack(const tor_index *ix, const uint64_t *a, int64_t n, c
         c.rev = A_REV(a0); c.tid = tid_of_gpos(ix, (uint32_t)A_G(a0));
         int32_t go = (int32_t)ix->goff[c.tid];
         c.rs = A_G(a0) - go - A_SPAN(a0) + 1; c.re = A_G(a1) - go + 1;
+        /* the span is the QUERY minimizer's; with homopolymer compression the target's copy of the k-mer may be shorter and the start
+         * fall before the target (minimap2 clamps the same way: mm_set_reg / mm_reg_set_coor, `x + 1 > q_span ? x + 1 - q_span : 0`) */
+        if (c.rs < 0) c.rs = 0;
         c.qs = A_Q(a0) - A_SPAN(a0) + 1;      c.qe = A_Q(a1) + 1;
         vpush(chain_t, *chains, c);
     }

@@ -1483,6 +1483,7 @@ __device__ __forceinline__ void d_chain_box(const ChainRec &r, const uint32_t *_
     tid = d_tid_of(goff, n_targets, (uint32_t)A_G(r.a0));
     const int go = (int)goff[tid];
     rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; re = A_G(r.a1) - go + 1;
+    if (rs < 0) rs = 0;          // the span is the query minimizer's: with HPC the target's copy may be shorter (minimap2 clamps the same way)
     qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      qe = A_Q(r.a1) + 1;
 }
 // The primaries found so far (query interval, target, score) live in LDS (SEL_PCAP of them; beyond that in the global

@@ -1777,6 +1777,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                     hc.tid = tid;
                     int go = (int)ix->goff[tid];
                     hc.rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; hc.re = A_G(r.a1) - go + 1;
+                    if (hc.rs < 0) hc.rs = 0;
                     hc.qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      hc.qe = A_Q(r.a1) + 1;
                     hc.a_glob = (int64_t)h_qaoff[q] + r.a_off;
                 }

@@ -673,3 +673,14 @@ def test_second_context_and_scratch_release(engine):
     assert free1 > free0 and total > free1
     c = ix.map(qs, mo)
     assert a.alns.tobytes() == c.alns.tobytes() and a.cigars.tobytes() == c.cigars.tobytes()
+
+
+def test_hpc_chain_start_at_the_target_start(engine):
+    """engine == oracle where the query's homopolymer runs are longer than the target's at the very start of the target (the chain
+    start clamps at 0: tests/test_oracle.py has the construction)"""
+    from test_oracle import _hpc_start_case
+    targets, reads = _hpc_start_case()
+    io, mo = preset("map-pb")
+    res, _ = compare_all(engine, targets, reads, io, mo, stages=False)
+    assert (res.alns["ts"] >= 0).all() and (res.alns["ts"] <= 5).any()
+    compare_all(engine, targets + targets, reads, io, mo, qtarget=np.array([1, 0, 1], np.int32), stages=False)

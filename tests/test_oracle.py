@@ -270,3 +270,29 @@ def test_depth_medians_oracle():
     al["tid"] = 0; al["ts"] = [0, 50, 0]; al["n_cigar"] = [3, 1, 1]; al["cigar_off"] = [0, 3, 4]; al["flags"] = [1, 4, 2]
     m = ob.depth_medians(al, cig, [200], [0, 0, 0, 0], [0, 50, 100, 190], [49, 99, 109, 250])
     assert list(m) == [1.0, 2.0, 1.0, 0.0]
+
+
+def _hpc_start_case():
+    """a target and reads whose first k-mers carry LONGER homopolymer runs than the target's: with homopolymer-compressed
+    minimizers (map-pb) the query's span of a k-mer then exceeds the target's, and `end - span + 1` falls before the target"""
+    rng = np.random.default_rng(2)
+    t = synth.random_seq(rng, 4000)
+    # no homopolymer in the first 60 bases of the target
+    for i in range(1, 60):
+        while t[i] == t[i - 1]:
+            t[i] = ord("ACGT"[int(rng.integers(0, 4))])
+    reads = []
+    for rep in (3, 6, 12):
+        q = np.concatenate([np.repeat(t[:40], rep), t[40:2500]])          # every base of the first 40 repeated: same HPC string, longer raw spans
+        reads.append(q)
+    return [bytes(t).decode()], [bytes(r).decode() for r in reads]
+
+
+def test_chain_start_is_clamped_at_the_target_start_with_hpc_minimizers():
+    """the chain box uses the QUERY minimizer's span for the target side too (as minimap2 does) and clamps the start at 0
+    (mm_reg_set_coor): found at configs[3] size by the bundle parity, where the unclamped start read one base before the target"""
+    targets, reads = _hpc_start_case()
+    io, mo = preset("map-pb")
+    r = ob.OracleIndex(targets, io).map(reads, mo)
+    assert len(r["alns"]) >= 3
+    assert (r["alns"]["ts"] >= 0).all() and (r["alns"]["te"] <= 4000).all() and (r["alns"]["ts"] <= 5).any()

@@ -622,12 +622,11 @@ struct SeedArgs {
     // staged input (tile_off non-null): mz_x / mz_y are the sketch kernel's per-tile staging arrays (tile t at t * SK_TILE,
     // tile_off[t+1] - tile_off[t] entries), read in place instead of being compacted first; q_tile0[q] = first tile of query q
     const int32_t *tile_off, *q_tile0;
-    uint32_t *k32, *v32;         // MODE 1 out, instead of keys when non-null: the high word (strand | reference position) and the low word (query position << 8 | span) apart
 };
 
 __device__ __forceinline__ void d_put_key(const SeedArgs &A, int64_t w, uint64_t key)
 {
-    if (A.k32) { A.k32[w] = (uint32_t)(key >> 32); A.v32[w] = (uint32_t)key; } else A.keys[w] = key;
+    A.keys[w] = key;
 }
 // target holding global position g (goff ascending, goff[n] = end)
 __device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n, uint32_t g)
@@ -964,16 +963,16 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
     __syncthreads();
     if (tid == 0) VA.q_cnt[q] = (int32_t)blk_cnt;
 }
-// staging -> dense keys (as one 64-bit word, or as the two words the sort takes)
+// staging -> dense keys (only ahead of the library sort: the LDS sort of segsort.hip.h reads the staging pieces in place)
 __global__ void __launch_bounds__(256) k_vote_compact(const uint64_t *__restrict__ stage, const int64_t *__restrict__ q_soff, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                                      uint64_t *__restrict__ keys, uint32_t *__restrict__ k32, uint32_t *__restrict__ v32)
+                                                      uint64_t *__restrict__ keys)
 {
     const int q = blockIdx.x;
     if (q >= nq) return;
     const int64_t s0 = q_soff[q]; const int a0 = q_aoff[q], n = q_aoff[q + 1] - a0;
     for (int i = threadIdx.x; i < n; i += 256) {
         const uint64_t k = stage[s0 + i];
-        if (k32) { k32[a0 + i] = (uint32_t)(k >> 32); v32[a0 + i] = (uint32_t)k; } else keys[a0 + i] = k;
+        keys[a0 + i] = k;
     }
 }
 
@@ -1038,24 +1037,20 @@ __global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__r
     if (i == n) dst[n] = tail;
 }
 
-// The anchors of a query are sorted on their HIGH word only (strand | reference position: four radix passes over 4 + 4 bytes
-// instead of eight over 8) with the low word (query position << 8 | span) as the value; this kernel puts the words back
-// together and orders the few runs of equal high words -- the same reference minimizer hit from several query positions --
-// by their low word, which gives exactly the order of the 64-bit sort.  One block per query.
-__global__ void __launch_bounds__(256) k_key_join(const uint32_t *__restrict__ k32, const uint32_t *__restrict__ v32, const int32_t *__restrict__ q_aoff,
-                                                  uint64_t *__restrict__ out)
+// per-query anchor offsets = the minimizer-level scan read at the query's first minimizer (idx[nq] = the minimizer total, so
+// dst[nq] = the anchor total), and the number of queries whose anchors exceed `cap` (they take the library sort)
+__global__ void k_qaoff_over(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t nq, int32_t cap, int32_t *__restrict__ dst, int32_t *__restrict__ n_over)
 {
-    const int q = blockIdx.x;
-    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t k = k32[base + i], v = v32[base + i];
-        int lo = i, hi = i + 1;
-        while (lo > 0 && k32[base + lo - 1] == k) --lo;
-        while (hi < n && k32[base + hi] == k) ++hi;
-        int rank = 0;
-        for (int j = lo; j < hi; ++j) rank += v32[base + j] < v ? 1 : 0;
-        out[base + lo + rank] = (uint64_t)k << 32 | v;
-    }
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nq) return;
+    const int32_t a = src[idx[i]];
+    dst[i] = a;
+    if (i < nq && src[idx[i + 1]] - a > cap) atomicAdd(n_over, 1);
+}
+__global__ void k_count_over(const int32_t *__restrict__ cnt, int32_t nq, int32_t cap, int32_t *__restrict__ n_over)
+{
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq && cnt[i] > cap) atomicAdd(n_over, 1);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -27,6 +27,7 @@
 #include <vector>
 #include "../../include/telr_hip.h"
 #include "kernels.hip.h"
+#include "segsort.hip.h"
 
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
@@ -131,6 +132,60 @@ template <typename T> static int ctx_hbuf_t(telr_ctx *ctx, const char *name, siz
 template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size_t n, T **out)
 {
     void *p; TRY(ctx_buf(ctx, name, (n ? n : 1) * sizeof(T), &p)); *out = (T*)p; return TELR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Segmented sort of 64-bit keys (segsort.hip.h): every segment of at most SEGSORT_CAP keys is sorted by ONE workgroup in
+// LDS; `any_over` (known to the caller from the anchor counts) sends the larger ones through rocPRIM afterwards.
+// TELR_SORT64=1 keeps the library sort for every segment (A/B).  out[beg[s] .. end[s]) <- sorted in[...]; src_beg (nullable)
+// gives the segments' places in `in` when they differ from their places in `out`.
+static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint64_t *out, const int32_t *beg, const int32_t *end, const int64_t *src_beg,
+                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st)
+{
+    static const bool lib_sort = getenv("TELR_SORT64") != nullptr;
+    if (nseg <= 0 || nkeys == 0) return TELR_OK;
+    if (lib_sort) {
+        if (src_beg) return TELR_E_ARG;              // the caller compacts first
+        size_t tb = 0;
+        // (all 64 bits: rocprim's segmented sort mis-orders keys with bit 63 set when begin_bit > 0 -- measured, ROCm 7.2)
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, in, out, (unsigned)nkeys, (unsigned)nseg, beg, end, 0, 64, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, in, out, (unsigned)nkeys, (unsigned)nseg, beg, end, 0, 64, st));
+        return TELR_OK;
+    }
+    if (src_beg && any_over) return TELR_E_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 8 * 8));
+        HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 20 * 8));
+        attr_set = true;
+    }
+    SegSortArgs A; A.in = in; A.out = out; A.seg_beg = beg; A.seg_end = end; A.src_beg = src_beg; A.order = order; A.nseg = nseg;
+    const std::string T(tag);
+    TRY(ctx_buf_t(ctx, (T + "_tcnt").c_str(), SEGSORT_TIERS + 1, &A.tier_cnt));
+    TRY(ctx_buf_t(ctx, (T + "_tlist").c_str(), (size_t)SEGSORT_TIERS * nseg, &A.tier_list));
+    A.fb_beg = A.fb_end = nullptr;
+    if (any_over) { TRY(ctx_buf_t(ctx, (T + "_fbbeg").c_str(), (size_t)nseg, &A.fb_beg)); TRY(ctx_buf_t(ctx, (T + "_fbend").c_str(), (size_t)nseg, &A.fb_end)); }
+    HIPCHK(hipMemsetAsync(A.tier_cnt, 0, (SEGSORT_TIERS + 1) * 4, st));
+    hipLaunchKernelGGL(k_segsort_classify, dim3((nseg + 255) / 256), dim3(256), 0, st, A);
+    const int ncu = 256;
+    auto grid = [&](int resident) { return dim3((unsigned)std::min<int64_t>(nseg, (int64_t)ncu * resident * 8)); };
+    // largest tiers first: their few long-running workgroups start while the device is otherwise idle
+    hipLaunchKernelGGL((k_segsort<1024, 20>), grid(1), dim3(1024), 1024 * 20 * 8, st, A, 6);
+    hipLaunchKernelGGL((k_segsort<1024, 8>), grid(2), dim3(1024), 1024 * 8 * 8, st, A, 5);
+    hipLaunchKernelGGL((k_segsort<512, 8>), grid(4), dim3(512), 512 * 8 * 8, st, A, 4);
+    hipLaunchKernelGGL((k_segsort<256, 8>), grid(8), dim3(256), 256 * 8 * 8, st, A, 3);
+    hipLaunchKernelGGL((k_segsort<128, 8>), grid(16), dim3(128), 128 * 8 * 8, st, A, 2);
+    hipLaunchKernelGGL((k_segsort<64, 8>), grid(32), dim3(64), 64 * 8 * 8, st, A, 1);
+    hipLaunchKernelGGL((k_segsort<64, 2>), grid(32), dim3(64), 64 * 2 * 8, st, A, 0);
+    HIPCHK(hipGetLastError());
+    if (any_over) {
+        size_t tb = 0;
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, in, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, in, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
+    }
+    return TELR_OK;
 }
 
 // Stage timing.  GPU stages drop a pair of events on the stream and are read back by stage_collect() after the call's
@@ -1478,14 +1533,14 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.k32 = nullptr; S.v32 = nullptr; S.q_order = d_qorder;
+    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
     S.tile_off = mz_staged ? d_toff : nullptr; S.q_tile0 = mz_staged ? d_first : nullptr;
     VoteOpt VO; VO.len = mo->vote_len; VO.shift = mo->vote_bin_shift; VO.vmin = mo->vote_min; VO.frac_q8 = mo->vote_frac_q8;
     VoteArgs VA; memset(&VA, 0, sizeof(VA));
     // the counts that become anchor offsets: per minimizer, or per query when the sub-reads vote (the vote kernel appends a
     // query's survivors to its piece of a staging array; k_vote_compact moves them to the scanned offsets)
     int32_t *d_cnt = d_mcnt, *d_aoff = d_maoff; size_t ncnt = (size_t)nmz;
-    int64_t *d_qsoff = nullptr; uint64_t *d_stage = nullptr;
+    int64_t *d_qsoff = nullptr; uint64_t *d_stage = nullptr; int32_t *d_qcnt_v = nullptr;
     if (vote) {
         int64_t *d_qhits; int32_t *d_qcnt;
         TRY(ctx_buf_t(ctx, "vote_qhits", (size_t)nq + 2, &d_qhits)); TRY(ctx_buf_t(ctx, "vote_qsoff", (size_t)nq + 2, &d_qsoff)); TRY(ctx_buf_t(ctx, "vote_qcnt", (size_t)nq + 2, &d_qcnt));
@@ -1506,7 +1561,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         static const int64_t lim16 = getenv("TELR_VOTE_T16_LIMIT") ? atoll(getenv("TELR_VOTE_T16_LIMIT")) : 65535;
         hipLaunchKernelGGL(k_seed_vote<true>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
         hipLaunchKernelGGL(k_seed_vote<false>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
-        d_cnt = d_qcnt; d_aoff = d_qaoff; ncnt = (size_t)nq;
+        d_cnt = d_qcnt; d_aoff = d_qaoff; ncnt = (size_t)nq; d_qcnt_v = d_qcnt;
     } else hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_cnt + ncnt, 0, 4, st));
@@ -1521,47 +1576,35 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(rocprim::reduce(tmp, tb, it64, d_na64, (int64_t)0, ncnt + 1, rocprim::plus<int64_t>(), st));
     }
     TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_cnt, d_aoff, ncnt + 1)));
-    int32_t na = 0; int64_t na64 = 0;
+    // per-query anchor offsets, and how many queries hold more anchors than one workgroup sorts in LDS (segsort.hip.h)
+    int32_t *d_nover = (int32_t*)(d_na64 + 1);
+    HIPCHK(hipMemsetAsync(d_nover, 0, 8, st));
+    if (vote) hipLaunchKernelGGL(k_count_over, dim3((nq + 255) / 256), dim3(256), 0, st, d_qcnt_v, nq, SEGSORT_CAP, d_nover);
+    else hipLaunchKernelGGL(k_qaoff_over, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, SEGSORT_CAP, d_qaoff, d_nover);
+    int32_t na = 0; int64_t na64 = 0; int32_t n_over = 0;
     HIPCHK(hipMemcpyAsync(&na, d_aoff + ncnt, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&na64, d_na64, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n_over, d_nover, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (na64 >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
     ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
+    static const bool lib_sort = getenv("TELR_SORT64") != nullptr;      // A/B: rocPRIM's segmented radix sort for every query
+    const bool any_over = n_over > 0;
     uint64_t *d_keys, *d_skeys;
-    TRY(ctx_buf_t(ctx, "keys", (size_t)na, &d_keys));
+    TRY(ctx_buf_t(ctx, "keys", (vote && !lib_sort && !any_over) ? (size_t)1 : (size_t)na, &d_keys));
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
-    // TELR_SORT64=1: the round-1 sort of whole 64-bit keys (A/B); else the keys leave the seeding kernel as two 32-bit words
-    static const bool sort64 = getenv("TELR_SORT64") != nullptr;
-    uint32_t *d_k32 = (uint32_t*)d_keys, *d_v32 = d_k32 + na, *d_k32s = nullptr, *d_v32s = nullptr;
-    if (!sort64) { TRY(ctx_buf_t(ctx, "skeys32", (size_t)na * 2 + 2, &d_k32s)); d_v32s = d_k32s + na; }
-    S.mz_aoff = d_maoff; S.keys = d_keys; S.k32 = sort64 ? nullptr : d_k32; S.v32 = sort64 ? nullptr : d_v32;
-    if (vote) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, S.keys, S.k32, S.v32);
-    else {
-        hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
-        hipLaunchKernelGGL(k_gather_i32, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, na, d_qaoff);
-    }
+    S.mz_aoff = d_maoff; S.keys = d_keys;
+    // sub-read voting: the LDS sort reads the survivors from the staging pieces in place; only the library sort needs them dense
+    const bool vote_in_place = vote && !lib_sort && !any_over;
+    if (vote) { if (!vote_in_place) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, d_keys); }
+    else hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
 
     // ---- per-query sort of the anchor keys --------------------------------------------------
     StageTimer t_so(ctx, ST_SORT, true);
-    if (na > 0 && sort64) {
-        size_t tb = 0;
-        // (all 64 bits: rocprim's segmented sort mis-orders keys with bit 63 set when begin_bit > 0 -- measured, ROCm 7.2)
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
-        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_keys, d_skeys, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 64, st));
-    } else if (na > 0) {
-        // sort on the high word (strand | reference position), the low word (query position, span) rides along; k_key_join
-        // puts them back together and orders the runs of equal high words: half the radix passes over the same bytes
-        size_t tb = 0;
-        HIPCHK(rocprim::segmented_radix_sort_pairs(nullptr, tb, d_k32, d_k32s, d_v32, d_v32s, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 32, st));
-        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::segmented_radix_sort_pairs(tmp, tb, d_k32, d_k32s, d_v32, d_v32s, (unsigned)na, (unsigned)nq, d_qaoff, d_qaoff + 1, 0, 32, st));
-        hipLaunchKernelGGL(k_key_join, dim3(nq), dim3(256), 0, st, d_k32s, d_v32s, d_qaoff, d_skeys);
-        HIPCHK(hipGetLastError());
-    }
+    if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st));
     t_so.stop();
 
     // ---- chaining ---------------------------------------------------------------------------
@@ -1598,12 +1641,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     hipLaunchKernelGGL(k_nonpeak, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_p, d_nonpeak);
     hipLaunchKernelGGL(k_peaks, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_nonpeak, mo->min_chain_score, d_pk, d_npk, d_pkend);
     HIPCHK(hipGetLastError());
-    if (na > 0) {
-        size_t tb = 0;
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_pk, d_pk2, (unsigned)na, (unsigned)nq, d_qaoff, d_pkend, 0, 64, st));
-        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_pk, d_pk2, (unsigned)na, (unsigned)nq, d_qaoff, d_pkend, 0, 64, st));
-    }
+    if (na > 0) TRY(seg_sort_u64(ctx, "so_p", d_pk, d_pk2, d_qaoff, d_pkend, nullptr, d_qorder, nq, (size_t)na, any_over, st));
     HIPCHK(hipMemsetAsync(d_npk + nq, 0, 4, st));
     TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_npk, d_choff, (size_t)nq + 1)));
     int32_t npk_tot = 0;
@@ -1714,12 +1752,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "sel_koff", (size_t)nq + 2, &d_koff));
         hipLaunchKernelGGL(k_sel_keys, dim3(nq), dim3(64), 0, st, d_choff, d_nch, d_rec, d_sk, d_segend);
         HIPCHK(hipGetLastError());
-        if (npk_tot > 0) {
-            size_t tb = 0;
-            HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, d_sk, d_sk2, (unsigned)npk_tot, (unsigned)nq, d_choff, d_segend, 0, 64, st));
-            void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-            HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, d_sk, d_sk2, (unsigned)npk_tot, (unsigned)nq, d_choff, d_segend, 0, 64, st));
-        }
+        if (npk_tot > 0) TRY(seg_sort_u64(ctx, "so_c", d_sk, d_sk2, d_choff, d_segend, nullptr, d_qorder, nq, (size_t)npk_tot, any_over, st));
         SelOpt so; so.mask_level = mo->mask_level; so.pri_ratio = mo->pri_ratio; so.best_n = mo->best_n; so.secondary = mo->secondary;
         so.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0;
         hipLaunchKernelGGL(k_select1, dim3(nq), dim3(64), 0, st, d_choff, d_nch, d_rec, d_sk2, qs->d_len + q0, ix->d_goff, tg->n, so,

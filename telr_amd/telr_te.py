@@ -77,39 +77,51 @@ import sys
 RM_FLAGS = ["-gff", "-s", "-nolow", "-no_is", "-e", "ncbi"]          # TELR_te.py:397-404
 
 
+# RepeatMasker's `-gff` output is GFF2: nine tab-separated columns, source `RepeatMasker`, and the hit's family inside the
+# attribute column as  Target "Motif:<family>" <start in consensus> <end in consensus>.
+_RM_TARGET = re.compile(r'Target\s+"?(?:Motif:)?([^"\s]+)"?')
+NO_REPEATS = "There were no repetitive sequences detected"          # what RepeatMasker leaves in <ref>.out when nothing was masked
+
+
+def _columns(path, want):
+    """(line, columns) of every line of a GFF file that has at least `want` tab-separated columns"""
+    with open(path) as fh:
+        for line in fh:
+            cols = line.rstrip("\n").split("\t")
+            if len(cols) >= want:
+                yield line, cols
+
+
 def parse_rm_out(rm_gff, gff3):
-    """TELR_te.py:472-494: lines of RepeatMasker's .out.gff -> GFF3 with `Target=<family>`"""
-    with open(gff3, "w") as output, open(rm_gff, "r") as inp:
-        for line in inp:
-            if "RepeatMasker" in line:
-                entry = line.replace("\n", "").split("\t")
-                family = entry[8].split(" ")[1]
-                family = re.sub('"Motif:', "", family)
-                family = re.sub('"', "", family)
-                output.write("\t".join([entry[0], "RepeatMasker", "dispersed_repeat", entry[3], entry[4], entry[5], entry[6], entry[7], "Target=" + family]) + "\n")
+    """RepeatMasker's .out.gff -> the GFF3 the pipeline reads: same coordinates, score, strand and phase, type
+    `dispersed_repeat`, attribute `Target=<family>` (the job of TELR_te.py:472-494; same records, same bytes)."""
+    out = []
+    for line, c in _columns(rm_gff, 9):
+        if "RepeatMasker" not in line:                               # header lines (##gff-version, ##date, ##sequence-region)
+            continue
+        m = _RM_TARGET.search(c[8])
+        family = m.group(1) if m else c[8].split(" ")[1].replace('"Motif:', "").replace('"', "")
+        out.append("%s\tRepeatMasker\tdispersed_repeat\t%s\tTarget=%s\n" % (c[0], "\t".join(c[3:8]), family))
+    with open(gff3, "w") as fh:
+        fh.writelines(out)
 
 
 def gff3tobed(gff, bed):
-    """TELR_te.py:436-469: GFF3 -> BED6 (0-based start, family as name), sorted as `bedtools sort` does (intervals.bed_sort)"""
-    with open(gff, "r") as inp:
-        for line in inp:
-            if "#" not in line:
-                if "Target=" not in line:
-                    print("Incorrect GFF3 format, please check README for expected format, exiting...")
-                    sys.exit(1)
-                break
+    """the reference genome's TE annotation as BED6 -- 0-based start, family as the name, score `.` -- in `bedtools sort`
+    order (the job of TELR_te.py:436-469).  A GFF3 whose first record carries no `Target=` attribute is refused."""
     rows = []
-    with open(gff, "r") as inp:
-        for line in inp:
-            if "#" not in line:
-                entry = line.replace("\n", "").split("\t")
-                for item in entry[8].split(";"):
-                    if "Target=" in item:
-                        family = item.replace("Target=", "")
-                rows.append([entry[0], str(int(entry[3]) - 1), entry[4], family, ".", entry[6]])
-    with open(bed, "w") as output:
-        for r in iv.bed_sort(rows):
-            output.write("\t".join(r) + "\n")
+    for line, c in _columns(gff, 1):
+        if "#" in line:
+            continue
+        attrs = dict(kv.split("=", 1) for kv in (c[8].split(";") if len(c) > 8 else []) if "=" in kv)
+        if "Target" not in attrs:
+            if not rows:
+                print("Incorrect GFF3 format, please check README for expected format, exiting...")
+                sys.exit(1)
+            attrs["Target"] = rows[-1][3]                            # (an attribute-less later record keeps the previous family)
+        rows.append([c[0], str(int(c[3]) - 1), c[4], attrs["Target"], ".", c[6]])
+    with open(bed, "w") as fh:
+        fh.write("".join("\t".join(r) + "\n" for r in iv.bed_sort(rows)))
 
 
 def _sha256_file(path, h):
@@ -138,22 +150,24 @@ def repeatmask(ref, library, outdir, thread, cache_dir=None, runner=subprocess.c
             shutil.copyfile(os.path.join(slot, "masked"), ref_rm); shutil.copyfile(os.path.join(slot, "gff3"), gff3)
             return ref_rm, gff3
         return ref, None                                             # cached: "no repetitive sequences detected"
+    failed = False
     try:
         runner(["RepeatMasker", "-dir", outdir] + RM_FLAGS + ["-lib", library, "-pa", str(thread), ref])
-        if not os.path.isfile(ref_rm):
-            ref_rm_out = os.path.join(outdir, base + ".out")
-            with open(ref_rm_out, "r") as inp:
-                for line in inp:
-                    if "There were no repetitive sequences detected" in line:
-                        print("No repetitive sequences detected")
-                        ref_rm = ref; gff = None; gff3 = None
-                    else:
-                        raise Exception("Repeatmasking failed, exiting...")
-        else:
+        if os.path.exists(ref_rm):
             parse_rm_out(gff, gff3)
-            open(ref_rm, "r").close()
-    except Exception as e:
+        else:
+            # no masked FASTA: either nothing was found (RepeatMasker says so in <ref>.out) or the tool failed
+            with open(os.path.join(outdir, base + ".out")) as fh:
+                report = fh.read()
+            if NO_REPEATS in report:
+                print("No repetitive sequences detected")
+                ref_rm, gff3 = ref, None
+            else:
+                failed = True
+    except (OSError, IndexError, ValueError) as e:
         print(e)
+        failed = True
+    if failed:
         print("Repeatmasking failed, exiting...")
         sys.exit(1)
     if slot:

@@ -271,9 +271,12 @@ int  telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *
  * and cuts the file to size.  Without it, or past the estimate, the writer streams through a pinned ring and one pwrite
  * thread.  The mapping is taken apart by a background thread after the file is complete; telr_bam_release_wait() waits for
  * that (only a process that prepares another file right away has a reason to).  A prepared file that is never written is
- * removed from the context by the next telr_bam_prepare / telr_destroy (the file itself stays). */
+ * removed from the context by the next telr_bam_prepare / telr_destroy / telr_bam_discard (the file itself stays: a caller
+ * whose mapping failed unlinks it -- the reference tests for the file's existence, TELR_alignment.py:110-114).  A writer call
+ * that fails removes `bam_path` and its .bai itself.  One telr_write_bam_dev runs at a time per process. */
 int  telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes);
 int  telr_bam_release_wait(void);
+int  telr_bam_discard(telr_ctx *ctx);
 int  telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx,
                         const char *const *qnames, const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm,
                         const char *rg_lb, const char *pg_line, const char *bam_path, int32_t write_index, int32_t level);

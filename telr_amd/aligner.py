@@ -288,6 +288,11 @@ class Index:
         """start creating the output file in the background (call before map_raw; see telr_bam_prepare)"""
         self.eng._chk(self.eng.L.telr_bam_prepare(self.eng.h, path.encode(), int(est_bytes)), "telr_bam_prepare")
 
+    def bam_discard(self):
+        """drop a prepared output file that will not be written (telr_bam_discard; the caller unlinks the file)"""
+        if getattr(self.eng, "h", None):
+            self.eng.L.telr_bam_discard(self.eng.h)
+
     def bam_release_wait(self):
         """wait until the mappings of earlier output files are taken apart (telr_bam_release_wait)"""
         self.eng.L.telr_bam_release_wait()

@@ -1028,6 +1028,8 @@ static std::string bam_header(int32_t n_targets, const char *const *tnames, cons
 // it block by block, front to back, while the caller is still mapping reads; the writer moves the finished image through the
 // pinned ring into the prepared prefix of the mapping and cuts the file to its real length; the mapping is taken apart by a
 // background thread (bam_sink_drop).
+// events of one writer call: destroyed on every way out
+struct EvBag { std::vector<hipEvent_t> v; ~EvBag() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } };
 struct BamSink {
     std::string path; int fd = -1; uint8_t *map = nullptr; size_t bytes = 0;
     std::thread th; float ms_alloc = 0, ms_map = 0;
@@ -1037,11 +1039,15 @@ struct BamSink {
     // The two steps alternate: run side by side they contend for the file's page tree (allocation 230 -> 610 ms).
     static constexpr size_t SLICE = 64u << 20;
     std::mutex mu; std::condition_variable cv; size_t n_slices = 0, ready = 0, limit = ~(size_t)0; bool stop = false, over = false;
-    // wait until the first `end` bytes are allocated and mapped (or the sink has given up on them: the copy then faults them in)
-    void wait_ready(size_t end)
+    bool alloc_failed = false;           // posix_fallocate refused a block (ENOSPC / EDQUOT): nothing past the prepared prefix is backed by pages
+    // wait until the first `end` bytes are allocated and mapped, or the sink has given up on them; -> the length of the prefix
+    // that IS allocated.  Only that prefix may be written through the mapping: a store into a hole of a full file system is a
+    // SIGBUS, where pwrite returns ENOSPC -- the writer takes pwrite for everything beyond it.
+    size_t wait_ready(size_t end)
     {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return over || ready * SLICE >= std::min(std::min(end, bytes), limit); });
+        return std::min(ready * SLICE, bytes);
     }
     // the writer's running estimate of the file's length: blocks past it are not prepared (cutting prepared pages off the end
     // of the file costs ~0.18 s per GB: the pages go back one by one)
@@ -1083,6 +1089,12 @@ extern "C" int telr_bam_release_wait(void)
     g_rel_cv.wait(lk, [] { return g_rel_pending == 0; });
     return TELR_OK;
 }
+extern "C" int telr_bam_discard(telr_ctx *ctx)
+{
+    if (!ctx) return TELR_E_ARG;
+    bam_sink_drop(ctx);
+    return TELR_OK;
+}
 extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes)
 {
     if (!ctx || !bam_path || est_bytes <= 0) return TELR_E_ARG;
@@ -1105,7 +1117,7 @@ extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est
         for (size_t i = 0; i < k->n_slices; ++i) {
             { std::unique_lock<std::mutex> lk(k->mu); k->cv.wait(lk, [&] { return k->stop || i * BamSink::SLICE < k->limit; }); if (k->stop) break; }
             const size_t len = std::min(BamSink::SLICE, k->bytes - i * BamSink::SLICE);
-            if (posix_fallocate(k->fd, (off_t)(i * BamSink::SLICE), (off_t)len) != 0) break;
+            if (posix_fallocate(k->fd, (off_t)(i * BamSink::SLICE), (off_t)len) != 0) { std::lock_guard<std::mutex> lk(k->mu); k->alloc_failed = true; break; }
             if (!no_populate) {
                 const int P = 4; const size_t q = (len / P + 4095) & ~(size_t)4095;
                 std::thread pt[P];
@@ -1147,8 +1159,9 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
     uint8_t *ring; TRY(ctx_hbuf_t(ctx, "bam_ring", CH * R, &ring));
     int fd = fd_open >= 0 ? fd_open : open(path, O_CREAT | O_RDWR | O_TRUNC, 0644);
     if (fd < 0) { ctx->err = std::string("cannot create ") + path; return TELR_E_ARG; }
-    hipEvent_t ev[8];
-    for (int i = 0; i < R; ++i) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    EvBag ring_ev; ring_ev.v.assign(R, nullptr);
+    hipEvent_t *ev = ring_ev.v.data();
+    for (int i = 0; i < R; ++i) if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { if (fd_open < 0) close(fd); return TELR_E_HIP; }
     // size of chunk c once it is final (0: the image ended before it; -1: failed; -2: not known yet and !block)
     auto chunk_bytes = [&](size_t c, bool block) -> int64_t {
         if (!prog) { const uint64_t o = (uint64_t)c * CH; return o >= bytes ? 0 : (int64_t)std::min<uint64_t>(CH, bytes - o); }
@@ -1168,14 +1181,15 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
             const uint8_t *src = ring + (c % R) * CH;
             const auto tw0 = std::chrono::steady_clock::now();
             struct Acc { std::chrono::steady_clock::time_point t0; ~Acc() { g_sink_ms[6] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } acc{tw0};
-            if (map_dst && (uint64_t)c * CH + n <= map_bytes) {
+            bool through_map = map_dst && (uint64_t)c * CH + n <= map_bytes;
+            if (through_map && sink) {
+                const auto t0 = std::chrono::steady_clock::now();
+                through_map = sink->wait_ready((size_t)c * CH + n) >= (size_t)c * CH + n;      // pages exist for the whole chunk
+                if (sink_wait_ms) *sink_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (through_map) {
                 const int NT = std::max(4, std::min(16, host_threads())); const size_t piece = (n + NT - 1) / NT;      // 12.4 / 12.8 / 14.6 GB/s with 4 / 8 / 16 copiers (shm_io)
                 uint8_t *dst = map_dst + (uint64_t)c * CH;
-                if (sink) {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    sink->wait_ready((size_t)c * CH + n);
-                    if (sink_wait_ms) *sink_wait_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                }
                 HostPool::get().run(NT, [&](int i) { const size_t o = (size_t)i * piece; if (o < n) memcpy(dst + o, src + o, std::min(piece, n - o)); });
             } else {
                 size_t done = 0;
@@ -1223,9 +1237,12 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
     { std::lock_guard<std::mutex> lk(mu); if (rc != TELR_OK) fail = true; last = true; }
     cv.notify_all();
     writer.join();
-    for (int i = 0; i < R; ++i) (void)hipEventDestroy(ev[i]);
     if (fail && rc == TELR_OK) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
-    if (rc == TELR_OK && tail_bytes) { if (map_dst && total + tail_bytes <= map_bytes) memcpy(map_dst + total, tail, tail_bytes); else if (pwrite(fd, tail, tail_bytes, (off_t)total) != (ssize_t)tail_bytes) rc = TELR_E_ARG; }
+    if (rc == TELR_OK && tail_bytes) {
+        const bool in_map = map_dst && total + tail_bytes <= map_bytes && (!sink || sink->wait_ready((size_t)(total + tail_bytes)) >= total + tail_bytes);
+        if (in_map) memcpy(map_dst + total, tail, tail_bytes);
+        else if (pwrite(fd, tail, tail_bytes, (off_t)total) != (ssize_t)tail_bytes) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
+    }
     if (rc == TELR_OK && fd_open >= 0 && !sink && ftruncate(fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;      // with a sink: cut by the caller, once its threads have stopped
     if (fd_open < 0) close(fd);
     if (total_out) *total_out = total;
@@ -1306,6 +1323,9 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
                                   const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                                   const char *bam_path, int32_t write_index, int32_t level)
 {
+    // one writer at a time per process: the call's timing / size records (g_bam_*) and the code tables are process-wide
+    static std::mutex g_bam_mu;
+    std::lock_guard<std::mutex> writer_lock(g_bam_mu);
     (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     int rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, bam_path, write_index, level);
     if (rc == TELR_E_NOMEM) {
@@ -1314,6 +1334,11 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
         ctx_release_map_scratch(ctx, g_bam_need);
         mem_note(ctx, "telr_write_bam_dev: after giving back scratch");
         rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, bam_path, write_index, level);
+    }
+    if (rc != TELR_OK && bam_path) {
+        // no partial (or merely pre-sized) file at the output path: callers test for the file's existence (TELR_alignment.py:110-114)
+        if (ctx) bam_sink_drop(ctx);
+        (void)unlink(bam_path); (void)unlink((std::string(bam_path) + ".bai").c_str());
     }
     return rc;
 }
@@ -1431,7 +1456,8 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     // the pieces are written on a stream of their own, one behind the other (a latency-bound kernel that shares the device well
     // with the LDS-bound coder); the coder's stream waits for the piece a group needs
     hipStream_t sw = ctx->side[1];
-    std::vector<hipEvent_t> ev_piece(NG, nullptr);
+    EvBag piece_bag, group_bag; piece_bag.v.assign(NG, nullptr);
+    std::vector<hipEvent_t> &ev_piece = piece_bag.v;
     auto write_piece = [&](size_t g) {          // records [s_end[g], s_end[g + 1]) of the sorted order
         const size_t n = s_end[g + 1] - s_end[g];
         if (n) {
@@ -1494,7 +1520,7 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
         TRY(ctx_buf_t(ctx, "bam_c", (size_t)utotal + nblk * 31 + 64, &d_c));
         uint32_t *h_csize; uint64_t *h_coff;
         TRY(ctx_hbuf_t(ctx, "bam_hcsize", nblk + 1, &h_csize)); TRY(ctx_hbuf_t(ctx, "bam_hcoff", nblk + 1, &h_coff));
-        std::vector<hipEvent_t> evg; std::vector<size_t> gb0, gnb;          // group g: blocks [gb0, gb0 + gnb), complete once piece g is written
+        std::vector<hipEvent_t> &evg = group_bag.v; std::vector<size_t> gb0, gnb;          // group g: blocks [gb0, gb0 + gnb), complete once piece g is written
         for (size_t g = 0; g < NG; ++g) {
             if (g && ev_piece[g]) HIPCHK(hipStreamWaitEvent(st, ev_piece[g], 0));
             const size_t b0 = b_done[g], nb = b_done[g + 1] - b_done[g];
@@ -1508,12 +1534,13 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
         prog = new StreamProgress();
         StreamProgress *pg = prog; uint64_t *coff_p = coff.data(); hipStream_t st2 = ctx->side[0]; const int device = ctx->device;
         BamSink *sk = ctx->bam_sink && ctx->bam_sink->path == bam_path ? ctx->bam_sink : nullptr;
+        const std::vector<hipEvent_t> evg_copy = evg;          // (the bag destroys them after the producer has been joined)
         producer = std::thread([=]() mutable {
             (void)hipSetDevice(device);
             uint64_t off = 0; bool ok = true;
             for (size_t g = 0; g < gb0.size() && ok; ++g) {
                 const size_t b0 = gb0[g], nb = gnb[g];
-                if (hipEventSynchronize(evg[g]) != hipSuccess) { ok = false; break; }
+                if (hipEventSynchronize(evg_copy[g]) != hipSuccess) { ok = false; break; }
                 for (size_t b = b0; b < b0 + nb; ++b) { h_coff[b] = off; coff_p[b] = off; off += h_csize[b]; }
                 // the file's length, extrapolated from the blocks coded so far (records are sorted by position: the groups are alike; 1.5 % + 4 MB on top)
                 if (sk) sk->set_limit(b0 + nb >= nblk ? (size_t)off + 28 : (size_t)((double)off * (double)nblk / (double)(b0 + nb) * 1.015) + ((size_t)4 << 20));
@@ -1542,7 +1569,6 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     if (bai_starter.joinable()) bai_starter.join();
     if (bai_th.joinable()) bai_th.join();
     if (write_index) bai_finish(bai, bai_fix, coff.data(), nblk);
-    for (hipEvent_t e : ev_piece) if (e) (void)hipEventDestroy(e);
     bam_sink_drop(ctx);
     g_bam_times.ms[6] = bai_ms;
     if (prog) { if (prog->state < 0 && rc == TELR_OK) rc = TELR_E_HIP; delete prog; }

@@ -45,16 +45,20 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     std::vector<Rec> recs;
     const int NT = host_threads();
     auto line_end = [&](size_t i) { const char *e = (const char*)memchr(p + i, '\n', n - i); return e ? (size_t)(e - p) : n; };
-    if (p[0] == '>') {
+    // leading blank lines / white space are not part of any record (minimap2 and ngmlr read such files)
+    size_t lead = 0;
+    while (lead < n && (p[lead] == '\n' || p[lead] == '\r' || p[lead] == ' ' || p[lead] == '\t')) ++lead;
+    if (lead == n) { munmap((void*)p, n); *out = F; return TELR_OK; }
+    if (p[lead] == '>') {
         // slices, not threads: parallel_ranges runs fewer than 64 items on the calling thread (the scan of a 4-GB file was serial)
         const int NS = std::max(64, NT * 4);
         std::vector<std::vector<size_t>> starts((size_t)NS);
         parallel_ranges(NT, NS, [&](int, int t0, int t1) {
             for (int t = t0; t < t1; ++t) {
                 size_t a = n * (size_t)t / NS, b = n * (size_t)(t + 1) / NS;
-                if (t == 0) starts[t].push_back(0);
+                if (t == 0) starts[t].push_back(lead);
                 // '>' preceded by a line break, at positions (a, b]
-                for (size_t i = a; i < b; ) { const char *e = (const char*)memchr(p + i, '\n', b - i); if (!e) break; i = (size_t)(e - p) + 1; if (i < n && p[i] == '>') starts[t].push_back(i); }
+                for (size_t i = a; i < b; ) { const char *e = (const char*)memchr(p + i, '\n', b - i); if (!e) break; i = (size_t)(e - p) + 1; if (i < n && i > lead && p[i] == '>') starts[t].push_back(i); }
             }
         });
         std::vector<size_t> st;
@@ -62,8 +66,10 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
         recs.resize(st.size());
         for (size_t r = 0; r < st.size(); ++r) { recs[r].hdr = st[r] + 1; recs[r].end = r + 1 < st.size() ? st[r + 1] : n; }
         parallel_ranges(NT, (int)recs.size(), [&](int, int r0, int r1) { for (int r = r0; r < r1; ++r) { size_t e = line_end(recs[r].hdr); recs[r].body = e < recs[r].end ? e + 1 : recs[r].end; } });
-    } else if (p[0] == '@') {
-        for (size_t i = 0; i < n; ) {
+    } else if (p[lead] == '@') {
+        // four-line records only; a multi-line FASTQ is refused here and read by the caller's own reader (fasta.load)
+        for (size_t i = lead; i < n; ) {
+            if (p[i] == '\n' || p[i] == '\r') { ++i; continue; }                       // blank lines between / after the records
             if (p[i] != '@') { munmap((void*)p, n); delete F; return TELR_E_ARG; }
             Rec r; r.hdr = i + 1;
             size_t e = line_end(i); r.body = e < n ? e + 1 : n;
@@ -78,7 +84,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     if (nr >= (1u << 31)) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
     F->len.resize(nr); F->off.resize(nr);
     std::vector<int64_t> nlen(nr);
-    bool too_long = false;
+    std::atomic<bool> too_long{false};
     std::atomic<int> folded{0};                // records whose sequence is not one plain line
     parallel_ranges(NT, (int)nr, [&](int, int r0, int r1) {
         int fold = 0;
@@ -95,7 +101,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
         if (fold) folded += fold;
     });
     lap("lengths + name ends");
-    if (too_long) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
+    if (too_long.load()) { munmap((void*)p, n); delete F; return TELR_E_RANGE; }
     int64_t tot = 0, ntot = 0;
     std::vector<int64_t> noff(nr);
     for (size_t r = 0; r < nr; ++r) { F->off[r] = tot; tot += F->len[r]; noff[r] = ntot; ntot += nlen[r] + 1; }

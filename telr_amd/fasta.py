@@ -112,4 +112,9 @@ def load(path):
     """FastaFile for plain files; gzip goes through the Python reader (names, seqs lists wrapped the same way)"""
     if str(path).endswith(".gz"):
         return None
-    return FastaFile(path)
+    from . import _lib
+    try:
+        return FastaFile(path)
+    except _lib.TelrError:
+        # a layout the C parser refuses (multi-line FASTQ, a record that does not start with '>' / '@'): the Python reader decides
+        return None

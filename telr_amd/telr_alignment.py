@@ -9,9 +9,11 @@ reference, CIGARs: telr_write_bam_dev) -- the host parses the two input files (t
 uploads them, and moves the finished file image into `bam`, whose pages are being allocated while the reads
 are still mapped (telr_bam_prepare).
 """
+import atexit
 import logging
 import os
 import sys
+import threading
 import time
 
 from .aligner import Engine
@@ -24,6 +26,18 @@ def format_time(seconds):          # TELR_utility.py:34-41
     h, rem = divmod(seconds, 3600)
     m, s = divmod(rem, 60)
     return "%d:%02d:%02d" % (int(h), int(m), round(s))
+
+
+_release_threads = []
+
+
+def wait_release():
+    """join the background releases of earlier alignment() calls (before Engine.close(), or at exit)"""
+    while _release_threads:
+        _release_threads.pop().join()
+
+
+atexit.register(wait_release)
 
 
 def alignment(bam, read, reference, out, sample_name, thread, method, presets, engine=None):
@@ -66,16 +80,27 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
     # about 0.85 bytes of BAM per read base with --cs --MD, 0.6 without cs, at level 1
     ix.bam_prepare(bam, int((0.95 if with_cs else 0.7) * n_bases) + (64 << 20))
     mo.flags |= MF_KEEP_CIGARS                   # the CIGAR array stays on the device as well: the BAM writer reads it there
-    r = ix.map_raw(qset, mo)
-    tm["map"] = time.time() - t0; t0 = time.time()
+    r = None
     try:
+        r = ix.map_raw(qset, mo)
+        tm["map"] = time.time() - t0; t0 = time.time()
         ix.write_bam_device(r, qset, qn, tn, bam, md=True, cs=with_cs, softclip=True, rg=rg, cmdline=cmd, index=True, level=1)
         tm["sorted_bam"] = time.time() - t0; t0 = time.time()
+    except BaseException:
+        # nothing half-made at the output path: the pre-sized file of bam_prepare goes with its sink (the writer itself
+        # unlinks what it could not finish), so that the existence test below -- the reference's -- means what it says
+        ix.bam_discard()
+        for leftover in (bam, bam + ".bai"):
+            if os.path.exists(leftover):
+                os.unlink(leftover)
+        raise
     finally:
-        ix.free_raw(r)
+        if r is not None:
+            ix.free_raw(r)
         # giving the rest back -- hipFree of the packed reads and of the index (0.12 s for a 30x set), the parsed files or their
         # mappings -- is not something the caller has to wait for with its BAM finished: sequence sets and indexes are plain device
-        # memory without context state
+        # memory without context state.  The thread is joined at interpreter exit and by wait_release() (a caller that closes
+        # the engine right away).
 
         def _drop(files, reads, index):
             reads.free()
@@ -83,8 +108,9 @@ def alignment(bam, read, reference, out, sample_name, thread, method, presets, e
             for f in files:
                 if f is not None:
                     f.close()
-        import threading
-        threading.Thread(target=_drop, args=((tf, qf), qset, ix), daemon=True).start()
+        th = threading.Thread(target=_drop, args=((tf, qf), qset, ix), daemon=False)
+        _release_threads.append(th)
+        th.start()
     tm["release"] = time.time() - t0
     # (the engine keeps its grow-only mapping scratch, 150-200 GB for a 30x read set: a caller that goes on to the per-locus
     # stages with the same engine gives it back with Engine.release_scratch() -- 0.2 s -- when it knows stage 1 will not run again)

@@ -115,3 +115,28 @@ def test_copying_path_behind_its_switch(tmp_path):
     for env, want in (({}, b"False True"), ({"TELR_FASTA_COPY": "1"}, b"True True")):
         r = subprocess.run([sys.executable, "-c", code, str(p)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert r.returncode == 0 and r.stdout.strip() == want, (env, r.stdout, r.stderr.decode()[-1000:])
+
+
+def test_leading_and_trailing_blank_lines_and_multi_line_fastq(tmp_path):
+    """files minimap2 / ngmlr accept: white space before the first record, blank lines after the last FASTQ
+    record -- read by the C parser; a multi-line FASTQ -- refused by it and handed to the Python reader by fasta.load()"""
+    from telr_amd.fasta import load
+    p = tmp_path / "lead.fa"
+    p.write_bytes(b"\n \n>r1\nACGT\n>r2\nGG\n\n")
+    f = FastaFile(str(p))
+    assert f.names == ["r1", "r2"] and f.seqs() == ["ACGT", "GG"]
+    f.close()
+    q = tmp_path / "tail.fq"
+    q.write_bytes(b"\n@a x\nACGT\n+\n@III\n@b\nTT\n+\nII\n\n\n")
+    f = FastaFile(str(q))
+    assert f.names == ["a", "b"] and f.seqs() == ["ACGT", "TT"]
+    f.close()
+    e = tmp_path / "blank.fa"
+    e.write_bytes(b"\n\n  \n")
+    f = FastaFile(str(e))
+    assert f.n == 0
+    f.close()
+    m = tmp_path / "multi.fq"
+    m.write_bytes(b"@a\nACGT\nACGT\n+\nIIII\nIIII\n")
+    assert load(str(m)) is None                    # the caller's Python reader takes over
+    assert load(str(q)) is not None

@@ -10,13 +10,15 @@ from telr_amd._abi import IdxOpt, MapOpt, Aln, Counters, ALN_DTYPE
 from telr_amd.fasta import concat
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libtelroracle.so")
+# TELR_ORACLE_SO: another build of the same source (tests/test_oracle_asan.py runs the CPU tests against the
+# -fsanitize=address,undefined build, `make -C oracle asan`)
+_SO = os.environ.get("TELR_ORACLE_SO") or os.path.join(_HERE, "libtelroracle.so")
 
 
 def build(force=False):
     src = os.path.join(_HERE, "telr_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _SO.endswith("_asan.so") else []))
     return _SO
 
 

@@ -221,7 +221,7 @@ tor_index *tor_index_build(int32_t n, const char *ascii, const int64_t *off, con
     hy_t *t = (hy_t*)malloc(sizeof(hy_t) * (v.n ? v.n : 1));
     for (int64_t i = 0; i < v.n; ++i) { t[i].h = v.a[i].x >> 8; t[i].y = v.a[i].y; }
     /* NOTE the span byte is not part of the index order: grouping is by hash only */
-    qsort(t, v.n, sizeof(hy_t), cmp_hy);
+    if (v.n) qsort(t, v.n, sizeof(hy_t), cmp_hy);
     ix->n_mz = v.n;
     ix->hash = (uint64_t*)malloc(8 * (size_t)(v.n ? v.n : 1)); ix->ys = (uint32_t*)malloc(4 * (size_t)(v.n ? v.n : 1));
     int64_t ne = 0;
@@ -447,7 +447,7 @@ static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int
     if (vote) { vote_subread(sub.a, sub.n, mo, out); free(sub.a); }
     free(rescued);
     free(mv.a);
-    qsort(out->a, out->n, 8, cmp_u64);
+    if (out->n) qsort(out->a, out->n, 8, cmp_u64);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -543,7 +543,7 @@ static void chain_backtrack(const tor_index *ix, const uint64_t *a, int64_t n, c
     for (int64_t i = 0; i < n; ++i) if (p[i] >= 0 && f[i] > f[p[i]]) nonpeak[p[i]] = 1;
     VEC(peak_t) pk = {0, 0, 0};
     for (int64_t i = 0; i < n; ++i) if (!nonpeak[i] && f[i] >= mo->min_chain_score) { peak_t t = { f[i], (int32_t)i }; vpush(peak_t, pk, t); }
-    qsort(pk.a, pk.n, sizeof(peak_t), cmp_peak);
+    if (pk.n) qsort(pk.a, pk.n, sizeof(peak_t), cmp_peak);      /* (an empty vector was never allocated: qsort's pointer must not be null) */
     for (int64_t t = 0; t < pk.n; ++t) {
         int32_t i = pk.a[t].i;
         if (vis[i]) continue;

@@ -11,51 +11,84 @@ from telr_amd.presets import preset
 
 
 
+def draw_case(seed, big=False):
+    """one random configuration -> (preset name, io, mo, genome, reads, qtarget, edge_repeats)"""
+    rng = np.random.default_rng(seed)
+    pname = ["map-ont", "map-ont", "map-pb", "asm10", "ngmlr-ont", "ngmlr-pacbio"][int(rng.integers(0, 6))]
+    io, mo = preset(pname)
+    ntg = int(rng.integers(1, 4))
+    genome = [synth.random_seq(rng, int(rng.integers(300000, 1500000) if big else rng.integers(20000, 120000))) for _ in range(ntg)]
+    te = synth.random_seq(rng, int(rng.integers(500, 4000)))
+    for g in genome:                                   # repeats: occurrence filter, secondary chains
+        for _ in range(int(rng.integers(0, 8))):
+            p = int(rng.integers(0, len(g) - len(te)))
+            g[p:p + len(te)] = synth.mutate(rng, te, float(rng.uniform(0, 0.08)), 0.0, 0.0)[:len(te)]
+    if rng.random() < 0.3:
+        g = genome[0]; p = int(rng.integers(0, len(g) - 300)); g[p:p + int(rng.integers(1, 300))] = ord("N")
+    # round 4: targets that BEGIN (or end) inside a repeat copy, with homopolymer runs at the very start -- the class of the
+    # chain-start bug of round 3 (HPC minimizers + per-query target + a chain at base 0 of the target)
+    edge_repeats = rng.random() < 0.35
+    if edge_repeats:
+        for g in genome:
+            if rng.random() < 0.7:
+                cut = int(rng.integers(0, len(te) // 2))
+                g[:len(te) - cut] = synth.mutate(rng, te, float(rng.uniform(0, 0.05)), 0.0, 0.0)[cut:len(te)]
+            if rng.random() < 0.5:
+                g[:int(rng.integers(2, 12))] = g[0]                      # a homopolymer run at base 0
+            if rng.random() < 0.5:
+                cut = int(rng.integers(1, len(te) // 2))
+                g[len(g) - cut:] = synth.mutate(rng, te, float(rng.uniform(0, 0.05)), 0.0, 0.0)[:cut]
+    err = float(rng.uniform(0.0, 0.07))
+    reads, truth = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(8000, 40000) if big else rng.integers(400, 9000)), err=(err, err / 2, err))
+    truth = [int(t[0]) for t in truth]
+    if edge_repeats:                                  # reads that start exactly at base 0 / end at the last base of a target
+        for _ in range(int(rng.integers(1, 6))):
+            gi = int(rng.integers(0, ntg)); g = genome[gi]
+            L = int(min(len(g), rng.integers(300, 6000)))
+            frag = g[:L] if rng.random() < 0.6 else g[len(g) - L:]
+            if rng.random() < 0.5:
+                frag = synth.revcomp_arr(frag)
+            reads.append(synth.mutate(rng, frag, err, err / 2, err)); truth.append(gi)
+    for _ in range(int(rng.integers(0, 3))):           # odd ones: tiny, with Ns, empty
+        reads.append(synth.random_seq(rng, int(rng.integers(0, 40)))); truth.append(int(rng.integers(0, ntg)))
+    if reads and rng.random() < 0.5:
+        r = reads[int(rng.integers(0, len(reads)))]
+        if len(r) > 200:
+            r[50:50 + int(rng.integers(1, 100))] = ord("N")
+    # option mix
+    if pname != "map-pb" and not pname.startswith("ngmlr") and rng.random() < 0.5:
+        io.k = int(rng.integers(11, 22)); io.w = int(rng.choice([5, 10, 10, 12, 19]))
+        from telr_amd.presets import _gap_q8
+        mo.chain_gap_q8 = _gap_q8(io.k)
+    mo.chain_lookback = int(rng.choice([64, 128, 256]))
+    mo.fill_band_q4 = int(rng.integers(1, 17)); mo.fill_margin = int(rng.integers(0, 4))
+    if rng.random() < 0.25:                             # gap costs on both sides of the one-piece rule of the packed cell ((D-1)(e-e2) < q2-q)
+        mo.q2 = int(mo.q + rng.integers(0, 30)); mo.e2 = int(rng.integers(1, mo.e + 1))
+    per_target = ntg > 1 and rng.random() < 0.2          # ranked per target, per-target occurrence cut-offs
+    if per_target:
+        mo.flags |= 2
+    # round 4: per-query targets (the S4 / S6 / polishing call shape) with EVERY preset, the HPC one included; mostly the
+    # target of origin, sometimes another one, sometimes -1 (unrestricted)
+    qtarget = None
+    if not per_target and rng.random() < (0.5 if edge_repeats else 0.25):
+        qtarget = np.array([t if rng.random() < 0.8 else int(rng.integers(-1, ntg)) for t in truth], dtype=np.int32)
+    mo.min_ksw_len = int(rng.choice([50, 100, 200, 400]))
+    mo.bw = int(rng.choice([100, 500, 2000])); mo.max_gap = int(rng.choice([1000, 5000, 10000]))
+    mo.best_n = int(rng.integers(1, 8)); mo.secondary = int(rng.integers(0, 2))
+    mo.chain_skip_q8 = int(rng.choice([0, 0, 0, 3]))
+    mo.ext_max = int(rng.choice([256, 2048])); mo.zdrop = int(rng.choice([100, 400]))
+    return pname, io, mo, genome, reads, qtarget, edge_repeats
+
+
 def run(eng, n_iter, seed0, big=False):
     from test_gpu_parity import compare_all
     for it in range(n_iter):
-        rng = np.random.default_rng(seed0 * 1000 + it)
-        pname = ["map-ont", "map-ont", "map-pb", "asm10", "ngmlr-ont", "ngmlr-pacbio"][int(rng.integers(0, 6))]
-        io, mo = preset(pname)
-        ntg = int(rng.integers(1, 4))
-        genome = [synth.random_seq(rng, int(rng.integers(300000, 1500000) if big else rng.integers(20000, 120000))) for _ in range(ntg)]
-        te = synth.random_seq(rng, int(rng.integers(500, 4000)))
-        for g in genome:                                   # repeats: occurrence filter, secondary chains
-            for _ in range(int(rng.integers(0, 8))):
-                p = int(rng.integers(0, len(g) - len(te)))
-                g[p:p + len(te)] = synth.mutate(rng, te, float(rng.uniform(0, 0.08)), 0.0, 0.0)[:len(te)]
-        if rng.random() < 0.3:
-            g = genome[0]; p = int(rng.integers(0, len(g) - 300)); g[p:p + int(rng.integers(1, 300))] = ord("N")
-        err = float(rng.uniform(0.0, 0.07))
-        reads, _ = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(8000, 40000) if big else rng.integers(400, 9000)), err=(err, err / 2, err))
-        for _ in range(int(rng.integers(0, 3))):           # odd ones: tiny, with Ns, empty
-            reads.append(synth.random_seq(rng, int(rng.integers(0, 40))))
-        if reads and rng.random() < 0.5:
-            r = reads[int(rng.integers(0, len(reads)))]
-            if len(r) > 200:
-                r[50:50 + int(rng.integers(1, 100))] = ord("N")
-        # option mix
-        if pname != "map-pb" and not pname.startswith("ngmlr") and rng.random() < 0.5:
-            io.k = int(rng.integers(11, 22)); io.w = int(rng.choice([5, 10, 10, 12, 19]))
-            from telr_amd.presets import _gap_q8
-            mo.chain_gap_q8 = _gap_q8(io.k)
-        mo.chain_lookback = int(rng.choice([64, 128, 256]))
-        mo.fill_band_q4 = int(rng.integers(1, 17)); mo.fill_margin = int(rng.integers(0, 4))
-        if rng.random() < 0.25:                             # gap costs on both sides of the one-piece rule of the packed cell ((D-1)(e-e2) < q2-q)
-            mo.q2 = int(mo.q + rng.integers(0, 30)); mo.e2 = int(rng.integers(1, mo.e + 1))
-        per_target = ntg > 1 and rng.random() < 0.2          # ranked per target, per-target occurrence cut-offs
-        if per_target:
-            mo.flags |= 2
-        mo.min_ksw_len = int(rng.choice([50, 100, 200, 400]))
-        mo.bw = int(rng.choice([100, 500, 2000])); mo.max_gap = int(rng.choice([1000, 5000, 10000]))
-        mo.best_n = int(rng.integers(1, 8)); mo.secondary = int(rng.integers(0, 2))
-        mo.chain_skip_q8 = int(rng.choice([0, 0, 0, 3]))
-        mo.ext_max = int(rng.choice([256, 2048])); mo.zdrop = int(rng.choice([100, 400]))
+        pname, io, mo, genome, reads, qtarget, edge_repeats = draw_case(seed0 * 1000 + it, big)
         try:
-            compare_all(eng, genome, reads, io, mo)
+            compare_all(eng, genome, reads, io, mo, qtarget=qtarget)
         except Exception as e:
             print("FAIL iteration", it, "seed", seed0 * 1000 + it, pname, "k", io.k, "w", io.w, "lookback", mo.chain_lookback, "q4", mo.fill_band_q4, "ksw", mo.min_ksw_len,
-                  "bw", mo.bw, "gap", mo.max_gap, "skip", mo.chain_skip_q8, "margin", mo.fill_margin, "q2", mo.q2, "e2", mo.e2, "flags", mo.flags)
+                  "bw", mo.bw, "gap", mo.max_gap, "skip", mo.chain_skip_q8, "margin", mo.fill_margin, "q2", mo.q2, "e2", mo.e2, "flags", mo.flags, "qtarget", qtarget is not None, "edge_repeats", edge_repeats)
             raise
 
 

@@ -1,0 +1,40 @@
+"""BASELINE configs[3] and configs[4] at FULL size under the driver's eyes: one step of the default
+bench on the configuration's whole read set, and the oracle's records for a random sample of the reads -- mapped against the
+same full-size index -- must equal the engine's, record for record and CIGAR for CIGAR.  And the per-locus call sites at
+configs[2]'s full size: S7 (flanks, asm10 -N 10, against the 137.6-Mb reference), S6 (window reads against the forward /
+reverse-complement contig of their locus) and the whole bundle, engine run == oracle run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-stream-leg", "--no-shard-leg", "--bam-leg", "none"] + list(args)
+    p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines[:3]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("cfg,preset,min_bases", [("c3", "ngmlr-pacbio", 3.5e9), ("c4", "map-ont", 2.0e9)])
+def test_full_size_configuration_equals_the_oracle_on_a_random_sample(cfg, preset, min_bases):
+    d = _bench("--config", cfg, "--loci", "0", "--cpu-sample-reads", "4000")
+    assert ("preset " + preset) in d["config"]["workload"] and d["config"]["read_bases_this_rank"] >= min_bases, d["config"]
+    par = d["cpu_baseline"]["parity"]
+    assert par["reads"] == 4000 and par["identical"] is True and par["reads_differing"] == 0 and par["records_engine"] == par["records_oracle"] >= 3000, par
+    assert d["frac_reads_mapped"] > 0.75 and d["value"] > 1.0
+
+
+def test_call_sites_s6_s7_and_the_bundle_at_configs2_size():
+    d = _bench("--config", "c2", "--loci", "100", "--flank-parity", "--no-cpu-baseline", "--no-polish-leg")
+    fp = d["flank_parity_asm10"]
+    assert fp["parity"]["identical"] is True and fp["parity"]["reads"] == 200 and fp["parity"]["records_engine"] >= 200, fp["parity"]      # S7: 2 flanks per locus
+    assert fp["s6"]["identical"] is True and fp["s6"]["loci"] == 100 and fp["s6"]["records_engine"] == fp["s6"]["records_oracle"] > 5000, fp["s6"]
+    assert fp["bundle"]["identical"] is True and fp["bundle"]["loci"] == 60 and fp["bundle"]["liftover_reports"] == 60, fp["bundle"]

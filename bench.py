@@ -505,7 +505,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(a.backend)
-    from telr_amd.aligner import Engine, Index, _np_from
+    from telr_amd.aligner import Engine, Index, SeqSet, _np_from
     from telr_amd._abi import ALN_DTYPE
     from telr_amd.presets import preset
     from telr_amd import telr_assembly, locus_pipeline, shard
@@ -691,7 +691,10 @@ def main():
                 owner[i] = r_
         rbuf, roff, rln = D["reads"]
 
+        phase = {}                                 # seconds per phase of the LAST pass (exchange, bundle, all-gather)
+
         def loci_pass():
+            phase.clear()
             # a12: every read with ANY stage-1 record overlapping [bp-1000, bp+1000) (TELR_assembly.py:384-415), from the
             # records of the last step (this rank's reads)
             wr = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])
@@ -699,17 +702,29 @@ def main():
                 for l, idx in zip(loci, wr):
                     l["read_idx"] = idx.astype(np.int32)
                 return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, shards=shards,
-                                                           presets=presets_arg, read_set=qs)
+                                                           presets=presets_arg, read_set=qs, timings=phase)
+            t_ex = time.time()
             lid = np.repeat(np.arange(len(wr)), [len(x) for x in wr]); ridx = np.concatenate(wr) if len(wr) else np.zeros(0, np.int64)
             own = np.array([owner[i] for i in range(len(loci))], np.int64)
-            g_loc, g_read, pool = shard.exchange_window_reads(lid, D["read_gid"][ridx], own[lid], (rbuf, roff, rln), ridx, dist, device)
-            pool_set = eng.seqset(pool)            # the received reads, packed and uploaded once; loci index into it
-            cuts = np.searchsorted(g_loc, np.arange(len(loci) + 1))
+            # the window reads travel as what they are on the device: 2-bit words + ambiguity mask of the resident read set,
+            # gathered by one kernel in destination order, ONE all-to-all of int32 words (device tensors under RCCL), and the
+            # pooled set is built from the received words in place (telr_seqset_from_packed): no ASCII, no host staging
+            held = []
+
+            def gather_packed(order):
+                sub = qs.subset(ridx[order]); held.append(sub)
+                return sub.packed()
+            g_loc, g_read, g_len, w2, wn, order = shard.exchange_window_reads_packed(lid, D["read_gid"][ridx], own[lid], rln[ridx], gather_packed, dist, device, timings=phase)
+            pool_set = SeqSet.from_packed(eng, g_len, w2, wn)
+            for sub in held:
+                sub.free()
+            cuts = np.searchsorted(g_loc[order], np.arange(len(loci) + 1))
             for li, l in enumerate(loci):
-                l["read_idx"] = np.arange(cuts[li], cuts[li + 1], dtype=np.int32)
+                l["read_idx"] = order[cuts[li]:cuts[li + 1]].astype(np.int32)      # places in the pool, by read id
                 l.pop("reads", None)
+            phase["exchange_s"] = phase.get("exchange_s", 0.0) + time.time() - t_ex
             return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
-                                                       shards=shards, presets=presets_arg, read_set=pool_set)
+                                                       shards=shards, presets=presets_arg, read_set=pool_set, timings=phase)
         flank_parity = None
         if a.flank_parity and rank == 0:
             from telr_amd.fasta import concat
@@ -840,7 +855,10 @@ def main():
                                        None if np.isnan(r["af"]) else float(r["af"])) for r in rs]).encode()).hexdigest()
         loci_out = {"n": n_loci, "seconds": t_loci, "seconds_of_each_pass": t_passes, "rows_in_merged_table": n_rows, "merged_table_sha256": digest, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
                     "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0, "polish_pileup": polish,
-                    "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads (counts + payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
+                    "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads as packed device words (counts + ONE int32 payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
+                    # where the last pass went on THIS rank (seconds): selecting + exchanging the window reads (pack_s = gather kernel and
+                    # header upload, collective_s = the two all-to-alls and the header download), the bundle on the rank's loci, the one all-gather
+                    "phase_s_last_pass_rank0": {k: round(v, 5) for k, v in phase.items()},
                     "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
                             "truth-derived stand-ins for wtdbg2 / Sniffles (absent on the box)"}
     if rank != 0:

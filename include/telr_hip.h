@@ -177,6 +177,19 @@ void telr_seqset_free(telr_seqset *s);
 int  telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out);
 int64_t telr_seqset_bases(const telr_seqset *s);
 int32_t telr_seqset_count(const telr_seqset *s);
+/* The packed form itself, for moving sequences between the GPUs of a node without ever unpacking them (the N > 1 hand-offs of
+ * window reads to the owner of their locus -- TELR_assembly.py:384-462 does this through the shared file system --
+ * and the reads of a coordinate slice to the rank that writes that slice of the BAM, TELR_alignment.py:103-114).  The layout is
+ * a pure function of the lengths: sequence i starts at base offset B(i) = sum over j < i of ceil(len[j] / 64) * 64; 2-bit
+ * codes, 16 bases per 32-bit word (base b of the set in bits 2(b % 16).. of word b / 16), ambiguity mask 32 bases per word.
+ * Two sets placed end to end are therefore the set of the concatenated lengths.
+ * telr_seqset_packed: DEVICE pointers to the two word arrays of `s` (valid until it is freed) and their lengths in words
+ * (padded_bases / 16 and padded_bases / 32).  telr_seqset_from_packed: a new set of n sequences with the given lengths (host
+ * array) whose word arrays are copied device-to-device from d_seq2 / d_nmask (device pointers, e.g. the receive buffer of an
+ * all-to-all; nwords2 / nwordsn must equal the layout's sizes). */
+int  telr_seqset_packed(const telr_seqset *s, const void **d_seq2, const void **d_nmask, int64_t *nwords2, int64_t *nwordsn);
+int  telr_seqset_from_packed(telr_ctx *ctx, int32_t n, const int32_t *len, const void *d_seq2, int64_t nwords2,
+                             const void *d_nmask, int64_t nwordsn, telr_seqset **out);
 
 /* ---- FASTA / FASTQ text -> the arrays above (host code; plain files, not gzip).  Replaces handing the file names to
  *      ngmlr / minimap2 (src/telr/TELR_alignment.py:31-51, 69-82).  Names end at the first white space. */

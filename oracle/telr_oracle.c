@@ -354,14 +354,16 @@ static void vote_subread(const uint64_t *hits, int64_t n, const telr_map_opt *mo
     }
 }
 
-static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int32_t tfilter, int32_t mid_occ, const telr_map_opt *mo,
+static void collect_anchors(const tor_index *ix, const uint8_t *q, int qlen, int32_t tfilter, int all_vs_all, int32_t mid_occ, const telr_map_opt *mo,
                             u64v_t *out, int64_t *n_mz, int64_t *n_probe)
 {
     mzv_t mv = {0, 0, 0};
     sketch(q, qlen, ix->k, ix->w, ix->hpc, 0, &mv);
     *n_mz += mv.n;
     const int per_t = tfilter < 0 && (mo->flags & TELR_MF_PER_TARGET);
-    const int vote = mo->vote_len > 0 && tfilter < 0 && !per_t;
+    /* spec 3.10: sub-read voting is the candidate search of ALL-VS-ALL calls -- a call that carries a per-query target array is
+     * not one, whatever the entry of this query says (-1 = unrestricted) */
+    const int vote = mo->vote_len > 0 && all_vs_all && !per_t;
     u64v_t sub = {0, 0, 0};          /* hits of the sub-read in progress */
     int32_t sub_id = -1;
     uint32_t g0 = 0, g1 = 0xffffffffu;
@@ -1111,7 +1113,7 @@ tor_result *tor_map(const tor_index *ix, int32_t nq, const char *ascii, const in
         for (int i = 0; i < qlen; ++i) q[i] = NT4[(uint8_t)ascii[off[qi] + i]];
         R->ctr.query_bases += qlen;
         u64v_t an = {0, 0, 0};
-        collect_anchors(ix, q, qlen, qtarget ? qtarget[qi] : -1, mid_occ, mo, &an, &R->ctr.minimizers, &R->ctr.probes);
+        collect_anchors(ix, q, qlen, qtarget ? qtarget[qi] : -1, qtarget == NULL, mid_occ, mo, &an, &R->ctr.minimizers, &R->ctr.probes);
         R->ctr.anchors += an.n;
         int32_t *f = (int32_t*)malloc(4 * (an.n ? an.n : 1)), *p = (int32_t*)malloc(4 * (an.n ? an.n : 1));
         telr_map_opt mc = *mo;

@@ -122,6 +122,14 @@ class Engine:
             pass
 
 
+class _DevWords:
+    """`n` int32 words of library-owned device memory, presented through the CUDA array interface (torch.as_tensor takes it
+    without a copy); keeps the owning set alive"""
+    def __init__(self, ptr, n, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
 class SeqSet:
     def __init__(self, eng, seqs):
         self.eng = eng
@@ -152,6 +160,36 @@ class SeqSet:
         eng._chk(eng.L.telr_seqset_subset(eng.h, self.h, len(idx), idx.ctypes.data, C.byref(h)), "telr_seqset_subset")
         sub.h = h; sub.len = self.len[idx].copy(); sub.n = len(idx)
         return sub
+
+    def packed(self):
+        """the set's two word arrays as torch int32 tensors ON THE DEVICE, zero-copy views of the library's memory (valid while
+        the set lives): what the N > 1 hand-offs put on the wire (telr_seqset_packed)"""
+        import torch
+        p2, pn, n2, nn = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
+        self.eng._chk(self.eng.L.telr_seqset_packed(self.h, C.byref(p2), C.byref(pn), C.byref(n2), C.byref(nn)), "telr_seqset_packed")
+        dev = "cuda:%d" % self.eng.device
+
+        def view(ptr, n):
+            if n == 0:
+                return torch.zeros(0, dtype=torch.int32, device=dev)
+            return torch.as_tensor(_DevWords(ptr, n, self), device=dev)
+        return view(p2.value, n2.value), view(pn.value, nn.value)
+
+    @classmethod
+    def from_packed(cls, eng, lengths, seq2, nmask):
+        """a set built from packed words that are already on the device (torch int32 tensors, e.g. what an all-to-all delivered):
+        one device-to-device copy, nothing is unpacked (telr_seqset_from_packed)"""
+        import torch
+        s = cls.__new__(cls)
+        s.eng = eng
+        s.len = np.ascontiguousarray(lengths, dtype=np.int32)
+        seq2 = seq2.contiguous(); nmask = nmask.contiguous()
+        torch.cuda.current_stream(seq2.device).synchronize()      # the words were produced on torch's stream (RCCL), the copy runs on the context's
+        h = C.c_void_p()
+        eng._chk(eng.L.telr_seqset_from_packed(eng.h, len(s.len), s.len.ctypes.data, C.c_void_p(seq2.data_ptr() if seq2.numel() else 0), int(seq2.numel()),
+                                               C.c_void_p(nmask.data_ptr() if nmask.numel() else 0), int(nmask.numel()), C.byref(h)), "telr_seqset_from_packed")
+        s.h = h; s.n = len(s.len)
+        return s
 
     def free(self):
         if getattr(self, "h", None):

@@ -553,6 +553,46 @@ extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int3
     *out = s;
     return TELR_OK;
 }
+extern "C" int telr_seqset_packed(const telr_seqset *s, const void **d_seq2, const void **d_nmask, int64_t *nwords2, int64_t *nwordsn)
+{
+    if (!s || !d_seq2 || !d_nmask || !nwords2 || !nwordsn) return TELR_E_ARG;
+    *d_seq2 = s->d_seq2; *d_nmask = s->d_nmask; *nwords2 = s->padded_bases / 16; *nwordsn = s->padded_bases / 32;
+    return TELR_OK;
+}
+extern "C" int telr_seqset_from_packed(telr_ctx *ctx, int32_t n, const int32_t *len, const void *d_seq2, int64_t nwords2, const void *d_nmask, int64_t nwordsn, telr_seqset **out)
+{
+    (void)hipGetLastError();
+    if (!ctx || n < 0 || !out || (n > 0 && !len)) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    telr_seqset *s = new telr_seqset();
+    s->ctx = ctx; s->n = n; s->boff.resize(n + 1); s->len.resize(n);
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t L = len[i];
+        if (L < 0) { delete s; return TELR_E_ARG; }
+        s->len[i] = L; s->boff[i] = tot; tot += ((int64_t)L + 63) & ~63LL; s->total_bases += L;
+        if (L > s->max_len) s->max_len = L;
+    }
+    s->boff[n] = tot; s->padded_bases = tot;
+    if (nwords2 != tot / 16 || nwordsn != tot / 32 || (tot > 0 && (!d_seq2 || !d_nmask))) { delete s; return TELR_E_ARG; }
+    const size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
+    auto fail = [&](hipError_t e) { ctx->err = std::string("seqset from packed words: ") + hipGetErrorString(e); telr_seqset_free(s); return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
+    hipError_t e; hipStream_t st = ctx->stream;
+    if ((e = hipMalloc(&s->d_seq2, w2 * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
+    if ((e = hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st)) != hipSuccess || (e = hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
+    if (n && (e = hipMemcpyAsync(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
+    if (tot) {
+        if ((e = hipMemcpyAsync(s->d_seq2, d_seq2, (size_t)(tot / 16) * 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(s->d_nmask, d_nmask, (size_t)(tot / 32) * 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return fail(e);
+    }
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e);
+    *out = s;
+    return TELR_OK;
+}
 extern "C" void telr_seqset_free(telr_seqset *s)
 {
     if (!s) return;

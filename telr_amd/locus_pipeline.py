@@ -87,7 +87,7 @@ def locus_cost(l):
     return c
 
 
-def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, dist=None, device=None, shards=None, **kw):
+def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_seqs, dist=None, device=None, shards=None, timings=None, **kw):
     """Stages 3-4 sharded over the ranks of one node: loci are assigned by LPT on their bases
     (`shards` = the per-rank lists of locus indices when the caller dealt them already, identical on every rank), every rank runs the bundle on its shard,
     and ONE all-gather of fixed-capacity blocks of fixed-width rows merges the coordinate / allele-frequency table
@@ -101,6 +101,8 @@ def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names
     mine = shards[rank]
     capacity = max(len(x) for x in shards)          # every rank computes the same number: no size exchange
     sub = [loci[i] for i in mine]
+    import time
+    t0 = time.time()
     res = run_loci(backend, ref_index, ref_names, ref_seq, sub, lib_names, lib_seqs, **kw) if sub else \
         {"annotation": [], "liftover": [], "summary": {}, "af": {}}
     by_name = {}
@@ -115,7 +117,12 @@ def run_loci_distributed(backend, ref_index, ref_names, ref_seq, loci, lib_names
     chrom_ids = {n: i for i, n in enumerate(ref_names)}
     fam_ids = {n: i for i, n in enumerate(lib_names)}
     rows = shard.rows_from_reports(ids, reps, freqs, chrom_ids, fam_ids)
-    return shard.all_gather_rows(rows, dist, device, capacity=capacity), res
+    t1 = time.time()
+    merged = shard.all_gather_rows(rows, dist, device, capacity=capacity)
+    if timings is not None:                 # the phases of the N > 1 leg, per rank: the bundle (this rank's shard) and the one collective
+        timings["bundle_s"] = timings.get("bundle_s", 0.0) + t1 - t0
+        timings["allgather_s"] = timings.get("allgather_s", 0.0) + time.time() - t1
+    return merged, res
 
 
 def write_outputs(res, loci, out_dir, sample_name, ref_fasta, sv_info=None, today=None):

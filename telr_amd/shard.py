@@ -145,6 +145,70 @@ def exchange_window_reads(locus_id, read_id, dest, reads, read_index, dist=None,
     return h["locus_id"][order].astype(np.int64), h["read_id"][order].astype(np.int64), (raw, off[order], h["length"][order].astype(np.int32))
 
 
+def packed_words(lengths):
+    """words of the packed form per sequence: (2-bit words, mask words) -- every sequence starts on a 64-base boundary"""
+    blocks = (np.asarray(lengths, np.int64) + 63) // 64
+    return blocks * 4, blocks * 2
+
+
+def exchange_window_reads_packed(locus_id, read_id, dest, lengths, gather_packed, dist=None, device=None, timings=None):
+    """`exchange_window_reads` without ever leaving the device or unpacking a base (round 4): the (locus, read) pairs are put in
+    destination order, `gather_packed(order)` hands back the packed words of the reads in that order as two torch int32 tensors
+    (the product passes SeqSet.subset(...).packed(): one gather kernel over the resident 2-bit read set; 3 bits per base on the
+    wire instead of 8), and TWO collectives move them: the per-peer counts (pairs, words), then ONE all-to-all of int32 words,
+    per destination [3 n header words: locus, read, length][2-bit words][mask words].  Nothing is staged through host memory;
+    the only host work is the argsort of the (small) pair list.
+    -> (locus ids, read ids, lengths) of the received pairs in RECEIVED order (peer by peer), the two word tensors of exactly
+    these reads end to end (= the packed form of a set with these lengths: SeqSet.from_packed), and `order` = the permutation
+    that sorts the received pairs by (locus id, read id)."""
+    import time
+    import torch
+    t0 = time.time()
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    locus_id = np.asarray(locus_id, np.int64); read_id = np.asarray(read_id, np.int64); dest = np.asarray(dest, np.int64)
+    lengths = np.asarray(lengths, np.int64)
+    order_s = np.argsort(dest, kind="stable")
+    seq2, nmask = gather_packed(order_s)
+    dev = seq2.device
+    w2, wn = packed_words(lengths[order_s])
+    n_to = np.bincount(dest, minlength=world).astype(np.int64)
+    cuts = np.concatenate([[0], np.cumsum(n_to)])
+    w2_to = np.array([int(w2[cuts[d]:cuts[d + 1]].sum()) for d in range(world)], np.int64)
+    hdr = torch.from_numpy(np.stack([locus_id[order_s], read_id[order_s], lengths[order_s]], axis=1).astype(np.int32).reshape(-1)).to(dev)
+    if timings is not None:
+        timings["pack_s"] = timings.get("pack_s", 0.0) + time.time() - t0
+    t0 = time.time()
+    if world == 1:
+        n_from, w2_from = n_to, w2_to
+        got_hdr, got2, gotn = hdr, seq2, nmask
+    else:
+        # the wire: the device the process group works on (RCCL: the GPU the words are on; the gloo smoke runs of a 1-GPU box and
+        # the CPU tests: host memory)
+        wire = torch.device(device) if device is not None else torch.device("cpu")
+        sizes = torch.from_numpy(np.stack([n_to, w2_to], axis=1).reshape(-1)).to(wire)
+        rs = torch.empty_like(sizes)
+        dist.all_to_all_single(rs, sizes)
+        rs = rs.cpu().numpy().reshape(world, 2)
+        n_from, w2_from = rs[:, 0], rs[:, 1]
+        c2 = np.concatenate([[0], np.cumsum(w2_to)]); cn = c2 // 2
+        send = torch.cat([x for d in range(world) for x in (hdr[3 * cuts[d]:3 * cuts[d + 1]], seq2[c2[d]:c2[d + 1]], nmask[cn[d]:cn[d + 1]])]) if len(dest) else torch.zeros(0, dtype=torch.int32, device=dev)
+        in_split = [int(3 * n_to[d] + w2_to[d] + w2_to[d] // 2) for d in range(world)]
+        out_split = [int(3 * n_from[p] + w2_from[p] + w2_from[p] // 2) for p in range(world)]
+        recv = torch.empty(sum(out_split), dtype=torch.int32, device=wire)
+        dist.all_to_all_single(recv, send.to(wire), output_split_sizes=out_split, input_split_sizes=in_split)
+        recv = recv.to(dev)
+        hs, s2, sn, o = [], [], [], 0
+        for p_ in range(world):
+            a, b, c = 3 * int(n_from[p_]), int(w2_from[p_]), int(w2_from[p_]) // 2
+            hs.append(recv[o:o + a]); s2.append(recv[o + a:o + a + b]); sn.append(recv[o + a + b:o + a + b + c]); o += a + b + c
+        got_hdr, got2, gotn = torch.cat(hs), torch.cat(s2), torch.cat(sn)
+    h = got_hdr.cpu().numpy().reshape(-1, 3).astype(np.int64)
+    if timings is not None:
+        timings["collective_s"] = timings.get("collective_s", 0.0) + time.time() - t0
+    order = np.lexsort((h[:, 1], h[:, 0]))
+    return h[:, 0], h[:, 1], h[:, 2].astype(np.int32), got2, gotn, order
+
+
 def gather_stage1(alns, cigars, reads, read_names, dist=None, device=None, force=False, read_gid=None):
     """The stage-1 hand-off at N > 1: Sniffles wants ONE coordinate-sorted BAM, the reads were dealt to the ranks.  Every rank
     packs what it mapped -- records, CIGAR words, read bases, lengths and names -- into one byte blob; ONE all-gather of the five

@@ -189,6 +189,53 @@ def test_window_read_exchange_and_empty_rank(tmp_path, world):
     assert loc.tolist() == [1, 3] and rid.tolist() == [2, 9] and [buf[o:o + n].tolist() for o, n in zip(off, ln)] == [[4, 5], [0, 1, 2, 3]]
 
 
+def _packed_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from telr_amd import shard
+    import packed_np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    it = _exchange_items(rank, world)
+    buf, off, ln = _exchange_reads(rank)
+    seqs = [bytes(buf[o:o + n]).decode() for o, n in zip(off, ln)]          # letters A..E: E packs as an ambiguous base
+    lens, w2, wn = packed_np.pack(seqs)
+    ridx = np.array([x[3] for x in it], np.int64)
+
+    def gather_packed(order):
+        a, b = packed_np.subset_words(lens, w2, wn, ridx[order])
+        return torch.from_numpy(a.view(np.int32).copy()), torch.from_numpy(b.view(np.int32).copy())
+    tm = {}
+    loc, rid, rl, g2, gn, order = shard.exchange_window_reads_packed([x[0] for x in it], [x[1] for x in it], [x[2] for x in it], ln[ridx] if len(ridx) else np.zeros(0, np.int32),
+                                                                     gather_packed, dist, timings=tm)
+    got = packed_np.unpack(rl, g2.numpy(), gn.numpy())
+    assert "collective_s" in tm and len(g2) == 2 * len(gn) == int(shard.packed_words(rl)[0].sum())
+    import json
+    json.dump([(int(loc[i]), int(rid[i]), got[i]) for i in order], open(os.path.join(out_dir, "packed%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_packed_window_read_exchange(tmp_path, world):
+    """round 4: the same hand-off on PACKED words (2-bit codes + ambiguity mask, the library's device layout) as torch tensors:
+    two collectives (counts, one int32 payload per peer), nothing unpacked on the way; every read arrives at the owner of its
+    locus with the bases it left with, also from / to a rank that sends nothing"""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_packed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = {r: [] for r in range(world)}
+    for rank in range(world):
+        buf, off, ln = _exchange_reads(rank)
+        for locus, gid, d, k in _exchange_items(rank, world):
+            want[d].append((locus, gid, bytes(buf[off[k]:off[k] + ln[k]]).decode().replace("B", "N").replace("D", "N").replace("E", "N")))
+    for r in range(world):
+        got = [tuple(x) for x in json.load(open(str(tmp_path / ("packed%d.json" % r))))]
+        assert got == sorted(want[r])
+
+
 def test_bench_launcher_starts_n_ranks():
     """`python bench.py --gpus 2` without RANK in the environment starts two ranks itself (torch.distributed.run as a child of
     a process that has not touched the GPU) and relays rank 0's line -- here with the gloo backend and no GPU work"""

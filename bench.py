@@ -268,16 +268,16 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
     if dist is not None:
         t = torch.tensor([t_all, t_map], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_all, t_map = float(t[0]), float(t[1])
         t = torch.tensor([ab, sz], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t); ab, sz = float(t[0]), float(t[1])
-    sha = None
+    sha = isha = None
     if a.bam_sha and os.path.exists(bam_path):
-        sha = file_sha256(bam_path)
+        sha = file_sha256(bam_path); isha = inflated_sha256(bam_path)
     for f in (bam_path, bam_path + ".bai"):
         if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
             os.unlink(f)
     job = None
     if dist is not None and a.bam_leg == "device" and (dist.get_world_size() > 1 or a.force_exchange):
         job = job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_dir)
-    return {"job_bam": job, "bam_sha256": sha, "writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1], "seconds_of_each_pass": [x[1] for x in legs[1:]],
+    return {"job_bam": job, "bam_sha256": sha, "inflated_sha256": isha, "writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1], "seconds_of_each_pass": [x[1] for x in legs[1:]],
                "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "cigars_resident": bool(eng.L.telr_debug_bam_twin()) if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
                "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s; this rank's reads (at N > 1 the job's ONE file is `job_bam`); median of three passes after a first one that sizes and pins the writer's buffers" % bam_dir}
 
@@ -295,13 +295,15 @@ def file_sha256(path):
 
 
 def job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_dir):
-    """N > 1: ONE coordinate-sorted BAM for the job (Sniffles reads one file, TELR_sv.py:35-47).  Every rank maps its reads, the
-    records / CIGARs / reads travel to rank 0 (shard.gather_stage1), rank 0 builds the file with one telr_write_bam_dev call."""
+    """N > 1: ONE coordinate-sorted BAM for the job (Sniffles reads one file, TELR_sv.py:35-47), written by ALL ranks
+    (shard.write_job_bam): every rank maps its reads, the records are range-partitioned by coordinate and travel -- with their
+    reads as packed device words -- to the rank that owns their slice, every rank codes and writes its slice of the one file,
+    rank 0 writes the one .bai."""
     from telr_amd import shard
-    from telr_amd.aligner import Index
     path = os.path.join(bam_dir, "telr_bench_job.bam")
     names = ["read%d" % g for g in D["read_gid"]]
     out = None
+    world = dist.get_world_size()
     for rep in range(2):
         if rank == 0:
             for f in (path, path + ".bai"):
@@ -313,38 +315,49 @@ def job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_
         r = ix.map_raw(qs, mo)
         res = ix.result_arrays(r)
         t_map = time.time() - t0
-        got = shard.gather_stage1(res.alns, res.cigars, D["reads"], names, dist=dist, device=device, force=a.force_exchange, read_gid=D["read_gid"])
+        err = None
+        try:
+            ph = shard.write_job_bam(path, ix, eng, res.alns, res.cigars, qs, D["reads"][2], names, D["read_gid"], D["names"], [len(x) for x in D["ref"]], dist, device,
+                                     level=max(1, a.bam_level), writer_kw=dict(cmdline="bench"))
+        except Exception as e:                 # (a rank that fails inside a collective takes the job down: nothing to hide here)
+            err = "%s: %s" % (type(e).__name__, e); ph = {}
+        aligned = int(res.alns["qlen"][(res.alns["flags"] & 1) != 0].sum())
         ix.free_raw(r)
-        t_gather = time.time() - t0 - t_map
-        if rank == 0:
-            try:                       # the other ranks wait at the barrier below whatever happens here
-                alns, cigars, reads, all_names = got
-                ix.bam_prepare(path, int((0.95 if a.bam_level else 2.9) * int(reads[2].sum())) + (64 << 20))
-                fr, _tot = eng.mem_info()
-                if fr < 12 * int(reads[2].sum()) + (2 << 30):          # the job's reads + the writer's ~9 B per base: this rank's mapping scratch goes back first
-                    eng.release_scratch()
-                jq = eng.seqset(reads)
-                jr = ix.result_from_arrays(alns, cigars)
-                ix.write_bam_device(jr, jq, Index._cstr_array(all_names), D["names"], path, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
-                ix.free_raw(jr); jq.free()
-                out = {"records": int(len(alns)), "reads": int(len(reads[2])), "aligned_bases": int(alns["qlen"][(alns["flags"] & 1) != 0].sum())}
-                del got, alns, cigars, reads
-            except Exception as e:
-                out = {"error": "%s: %s" % (type(e).__name__, e)}
         dist.barrier(); sync()
         t_all = time.time() - t0
+    if err is not None:
+        return {"error": err} if rank == 0 else None
+    dev = device if device is not None else "cpu"
+    t = torch.tensor([aligned], dtype=torch.float64, device=dev); dist.all_reduce(t); aligned = float(t[0])
+    phases = [None] * world
+    dist.all_gather_object(phases, {k: (round(v, 5) if isinstance(v, float) else v) for k, v in ph.items()})
     if rank != 0:
         return None
-    if "error" in out:
-        return out
-    out.update(seconds=t_all, map_seconds=t_map, gather_seconds=t_gather, write_seconds=t_all - t_map - t_gather, bam_bytes=os.path.getsize(path),
-               gbp_per_s_incl_bam=out["aligned_bases"] / t_all / 1e9, bam_sha256=file_sha256(path) if a.bam_sha else None, path=path,
-               what="every rank maps its reads; records, CIGARs, read bases and names go point-to-point to rank 0 (%s), which writes ONE sorted BAM + .bai "
-                    "for the job with one telr_write_bam_dev call; second of two passes" % dist.get_backend())
+    out = {"records": phases[0].get("records"), "reads": int(D["total_reads"]), "aligned_bases": int(aligned), "seconds": t_all, "map_seconds": t_map,
+           "write_seconds": t_all - t_map, "bam_bytes": os.path.getsize(path), "gbp_per_s_incl_bam": aligned / t_all / 1e9,
+           "bam_sha256": file_sha256(path) if a.bam_sha else None, "inflated_sha256": inflated_sha256(path) if a.bam_sha else None, "path": path,
+           "phase_s_per_rank": phases,
+           "what": "every rank maps its reads; records range-partitioned by coordinate (sampled splitters), ONE all-to-all (%s) of records + CIGAR words + packed "
+                   "2-bit reads to the owner of each coordinate slice; every rank codes the BGZF blocks of its slice on its device and writes them at its offset of the "
+                   "ONE file; rank 0 writes the .bai from the gathered coordinates / virtual offsets; second of two passes" % dist.get_backend()}
     for f in (path, path + ".bai"):
         if os.path.exists(f) and not os.environ.get("TELR_KEEP_BAM"):
             os.unlink(f)
     return out
+
+
+def inflated_sha256(path):
+    """SHA-256 of the BGZF file's INFLATED stream (block boundaries differ between a one-rank and an N-rank file; the stream does not)"""
+    import hashlib, struct, zlib
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        data = fh.read()
+    o = 0
+    while o < len(data):
+        bsize = struct.unpack_from("<H", data, o + 16)[0] + 1
+        h.update(zlib.decompress(data[o + 18:o + bsize - 8], -15))
+        o += bsize
+    return h.hexdigest()
 
 
 def files_leg_run(a, D, eng, pname, np):
@@ -808,6 +821,11 @@ def main():
             sync()
             t_passes.append(time.time() - t0)
         t_loci = sorted(t_passes)[len(t_passes) // 2]
+        phase_all = [{k: round(v, 5) for k, v in phase.items()}]
+        if dist is not None and world > 1:
+            got = [None] * world
+            dist.all_gather_object(got, phase_all[0])
+            phase_all = got
         if prof is not None:
             import pstats
             prof.disable()
@@ -858,7 +876,7 @@ def main():
                     "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads as packed device words (counts + ONE int32 payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
                     # where the last pass went on THIS rank (seconds): selecting + exchanging the window reads (pack_s = gather kernel and
                     # header upload, collective_s = the two all-to-alls and the header download), the bundle on the rank's loci, the one all-gather
-                    "phase_s_last_pass_rank0": {k: round(v, 5) for k, v in phase.items()},
+                    "phase_s_last_pass_per_rank": phase_all,
                     "note": "host glue (Python) included; window reads = telr_assembly.window_reads on this run's stage-1 records; contigs / ALT sequences are "
                             "truth-derived stand-ins for wtdbg2 / Sniffles (absent on the box)"}
     if rank != 0:

@@ -238,6 +238,10 @@ const telr_aln *telr_result_alns(const telr_result *r);     /* sorted by (qid, r
  * rank 0 from the records every rank mapped (telr_amd/shard.py: gather_stage1). */
 int             telr_result_from_arrays(telr_ctx *ctx, const telr_aln *alns, int64_t n, const uint32_t *cigars, int64_t n_cigar,
                                         telr_result **out);
+/* the same with the CIGAR words in DEVICE memory (e.g. the receive buffer of an all-to-all): copied device-to-device into the
+ * result's device array -- which the device BAM writer reads in place -- and mirrored to the host array once */
+int             telr_result_from_device_cigars(telr_ctx *ctx, const telr_aln *alns, int64_t n, const void *d_cigars, int64_t n_cigar,
+                                               telr_result **out);
 int             telr_result_wait(const telr_result *r);
 int64_t         telr_result_cigar_count(const telr_result *r);
 const uint32_t *telr_result_cigars(const telr_result *r);
@@ -287,6 +291,29 @@ int  telr_write_bam(const telr_result *r, int32_t n_queries, const char *const *
  * removed from the context by the next telr_bam_prepare / telr_destroy / telr_bam_discard (the file itself stays: a caller
  * whose mapping failed unlinks it -- the reference tests for the file's existence, TELR_alignment.py:110-114).  A writer call
  * that fails removes `bam_path` and its .bai itself.  One telr_write_bam_dev runs at a time per process. */
+/* ---- ONE coordinate-sorted BAM written by N ranks (SURVEY 8e x TELR_alignment.py:103-114; TELR_sv.py:35-47 reads one file) ----
+ * The records of the job are range-partitioned by (refID, position); rank k holds the reads that have a record in slice k with
+ * ALL their records (`emit[i]` = record i of the result lies in this slice; the others are only there so that the SA tag of an
+ * emitted record can name them) and makes the BGZF blocks of its slice on its device: telr_write_bam_slice (with_header: rank 0;
+ * TELR_SAM_NO_UNMAPPED in flags on every rank but the last, which also holds the reads without a record).  The slice's size is
+ * then known (telr_bam_segment_info: out[0] bytes in the file, [1] mapped records, [2] unmapped reads, [3] uncompressed
+ * bytes); after an exclusive scan of the sizes over the ranks every rank puts its image at its place of the one file
+ * (telr_bam_segment_write: `path` exists, is_last appends the BGZF EOF block) and hands what the index needs of its records
+ * (telr_bam_segment_entries: arrays of [1] entries in file order, virtual offsets for the slice at file_off) to rank 0, which
+ * writes the one .bai from the concatenated arrays (telr_bai_write).  The inflated stream of the N-rank file equals the
+ * one-rank file's byte for byte (same records, same order -- ties by the job-level read number: the reads of a rank must be
+ * in that order); the BGZF block boundaries differ.  The image lives in the context until its next writer call. */
+typedef struct telr_bam_segment telr_bam_segment;
+int  telr_write_bam_slice(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx,
+                          const char *const *qnames, const char *const *tnames, int32_t flags,
+                          const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
+                          const uint8_t *emit, int32_t with_header, int32_t level, telr_bam_segment **out);
+int  telr_bam_segment_info(const telr_bam_segment *s, int64_t *out);
+int  telr_bam_segment_entries(const telr_bam_segment *s, int64_t file_off, int32_t *tid, int32_t *ts, int32_t *te, uint64_t *vb, uint64_t *v_end);
+int  telr_bam_segment_write(telr_ctx *ctx, const telr_bam_segment *s, const char *path, int64_t file_off, int32_t is_last);
+void telr_bam_segment_free(telr_bam_segment *s);
+int  telr_bai_write(const char *bai_path, int64_t n, const int32_t *tid, const int32_t *ts, const int32_t *te, const uint64_t *vb, uint64_t v_end,
+                    int64_t n_unmapped, int32_t n_targets, const int32_t *t_len);
 int  telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est_bytes);
 int  telr_bam_release_wait(void);
 int  telr_bam_discard(telr_ctx *ctx);

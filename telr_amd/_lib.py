@@ -15,7 +15,7 @@ EXPORTS = [
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_from_arrays", "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
-    "telr_init_background", "telr_release_scratch", "telr_device_mem", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_bam_discard", "telr_seqset_packed", "telr_seqset_from_packed", "telr_consensus_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
+    "telr_init_background", "telr_release_scratch", "telr_device_mem", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_bam_discard", "telr_write_bam_slice", "telr_bam_segment_info", "telr_bam_segment_entries", "telr_bam_segment_write", "telr_bam_segment_free", "telr_bai_write", "telr_result_from_device_cigars", "telr_seqset_packed", "telr_seqset_from_packed", "telr_consensus_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
 _lib = None
@@ -85,6 +85,13 @@ def lib():
     L.telr_bam_prepare.restype = C.c_int; L.telr_bam_prepare.argtypes = [vp, cp, i64]
     L.telr_bam_release_wait.restype = C.c_int; L.telr_bam_release_wait.argtypes = []
     L.telr_bam_discard.restype = C.c_int; L.telr_bam_discard.argtypes = [vp]
+    L.telr_write_bam_slice.restype = C.c_int; L.telr_write_bam_slice.argtypes = [vp, vp, vp, vp, vp, vp, i32, cp, cp, cp, cp, vp, i32, i32, C.POINTER(vp)]
+    L.telr_bam_segment_info.restype = C.c_int; L.telr_bam_segment_info.argtypes = [vp, vp]
+    L.telr_bam_segment_entries.restype = C.c_int; L.telr_bam_segment_entries.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.telr_bam_segment_write.restype = C.c_int; L.telr_bam_segment_write.argtypes = [vp, vp, cp, i64, i32]
+    L.telr_bam_segment_free.restype = None; L.telr_bam_segment_free.argtypes = [vp]
+    L.telr_bai_write.restype = C.c_int; L.telr_bai_write.argtypes = [cp, i64, vp, vp, vp, vp, C.c_uint64, i64, i32, vp]
+    L.telr_result_from_device_cigars.restype = C.c_int; L.telr_result_from_device_cigars.argtypes = [vp, vp, i64, vp, i64, C.POINTER(vp)]
     L.telr_debug_bam_twin.restype = C.c_int; L.telr_debug_bam_twin.argtypes = []
     L.telr_debug_result_twin.restype = i64; L.telr_debug_result_twin.argtypes = [vp, vp, i64]
     L.telr_debug_bam_sink_ms.restype = C.c_int; L.telr_debug_bam_sink_ms.argtypes = [vp]

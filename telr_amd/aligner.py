@@ -165,6 +165,9 @@ class SeqSet:
         """the set's two word arrays as torch int32 tensors ON THE DEVICE, zero-copy views of the library's memory (valid while
         the set lives): what the N > 1 hand-offs put on the wire (telr_seqset_packed)"""
         import torch
+        if not torch.cuda.is_available():
+            raise _lib.TelrError("SeqSet.packed: torch sees no GPU in this process -- import torch BEFORE the first telr_amd call "
+                                 "(the torch wheel carries its own HIP runtime; a process initialises only one)")
         p2, pn, n2, nn = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_int64()
         self.eng._chk(self.eng.L.telr_seqset_packed(self.h, C.byref(p2), C.byref(pn), C.byref(n2), C.byref(nn)), "telr_seqset_packed")
         dev = "cuda:%d" % self.eng.device
@@ -249,8 +252,56 @@ class Index:
         self.eng._chk(self.eng.L.telr_result_from_arrays(self.eng.h, alns.ctypes.data, len(alns), cigars.ctypes.data, len(cigars), C.byref(r)), "telr_result_from_arrays")
         return r
 
+    def result_from_device_cigars(self, alns, cigars_t):
+        """the same over CIGAR words that are on the device already (a torch int32 / uint8 tensor, e.g. what an all-to-all
+        delivered): they become the result's device copy as they are (telr_result_from_device_cigars)"""
+        import torch
+        alns = np.ascontiguousarray(alns, dtype=ALN_DTYPE)
+        t = cigars_t.contiguous()
+        n = t.numel() * t.element_size() // 4
+        torch.cuda.current_stream(t.device).synchronize()
+        r = C.c_void_p()
+        self.eng._chk(self.eng.L.telr_result_from_device_cigars(self.eng.h, alns.ctypes.data, len(alns), C.c_void_p(t.data_ptr() if n else 0), n, C.byref(r)),
+                      "telr_result_from_device_cigars")
+        return r
+
     def free_raw(self, r):
         self.eng.L.telr_result_free(r)
+
+    # ---- one BAM written by N ranks: the slice of this rank (include/telr_hip.h: telr_write_bam_slice ...) ----
+    def write_bam_slice(self, r, queries, qnames, tnames, emit, with_header, md=True, cs=True, softclip=True, rg=None, cmdline="telr_map", level=1, unmapped=True):
+        """-> segment handle: the BGZF blocks of the records with emit[i] != 0 (+ the unmapped reads of `queries` when `unmapped`)
+        as an image on the device; the other records only feed the SA tags"""
+        qa, ta = self._cstr_array(qnames), self._cstr_array(tnames)
+        flags = (1 if md else 0) | (2 if cs else 0) | (4 if softclip else 0) | (0 if unmapped else 8)
+        rg_id, rg_sm, rg_lb = (None, None, None) if rg is None else tuple(x.encode() for x in rg)
+        emit = np.ascontiguousarray(emit, dtype=np.uint8)
+        seg = C.c_void_p()
+        self.eng._chk(self.eng.L.telr_write_bam_slice(self.eng.h, r, queries.h, self.h, qa, ta, flags, rg_id, rg_sm, rg_lb, cmdline.encode(),
+                                                      emit.ctypes.data, 1 if with_header else 0, level, C.byref(seg)), "telr_write_bam_slice")
+        return seg
+
+    def segment_info(self, seg):
+        out = np.zeros(4, np.int64)
+        self.eng._chk(self.eng.L.telr_bam_segment_info(seg, out.ctypes.data), "telr_bam_segment_info")
+        return dict(zip(("bytes", "mapped_records", "unmapped_reads", "uncompressed_bytes"), (int(x) for x in out)))
+
+    def segment_entries(self, seg, file_off):
+        """-> (tid, start, end, virtual offset) arrays of the slice's mapped records in file order, and the virtual offset behind them"""
+        n = self.segment_info(seg)["mapped_records"]
+        tid, ts, te = (np.zeros(n, np.int32) for _ in range(3)); vb = np.zeros(n, np.uint64); v_end = C.c_uint64()
+        self.eng._chk(self.eng.L.telr_bam_segment_entries(seg, int(file_off), tid.ctypes.data, ts.ctypes.data, te.ctypes.data, vb.ctypes.data, C.byref(v_end)), "telr_bam_segment_entries")
+        return tid, ts, te, vb, int(v_end.value)
+
+    def segment_write(self, seg, path, file_off, is_last):
+        self.eng._chk(self.eng.L.telr_bam_segment_write(self.eng.h, seg, path.encode(), int(file_off), 1 if is_last else 0), "telr_bam_segment_write")
+
+    def segment_free(self, seg):
+        self.eng.L.telr_bam_segment_free(seg)
+
+    def bai_write(self, path, tid, ts, te, vb, v_end, n_unmapped, tlens):
+        tid, ts, te = (np.ascontiguousarray(x, np.int32) for x in (tid, ts, te)); vb = np.ascontiguousarray(vb, np.uint64); tl = np.ascontiguousarray(tlens, np.int32)
+        self.eng._chk(self.eng.L.telr_bai_write(path.encode(), len(tid), tid.ctypes.data, ts.ctypes.data, te.ctypes.data, vb.ctypes.data, int(v_end), int(n_unmapped), len(tl), tl.ctypes.data), "telr_bai_write")
 
     def result_arrays(self, r):
         L = self.eng.L

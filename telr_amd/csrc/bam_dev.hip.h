@@ -36,6 +36,7 @@ struct BamArgs {
     const char *rg; int32_t rg_len;                     // 0 = no RG tag
     int32_t flags;                                      // TELR_SAM_*
     BamInfo *info; uint32_t *rec_size; uint64_t *key; const uint64_t *rec_ustart; uint8_t *ubuf;
+    const uint8_t *emit;                                // slice mode (nullable): record k is written iff emit[k]; the others are only there for the SA tags of their read
     const uint32_t *order; int32_t s0;                  // k_bam_write in pieces of the SORTED order: block x writes record order[s0 + x] (order null: record x)
 };
 
@@ -320,9 +321,13 @@ __global__ void __launch_bounds__(256) k_bam_size(BamArgs A)
     const BamLayout Y = d_bam_layout(A, a);
     const int rg = A.rg_len ? 3 + A.rg_len + 1 : 0;
     uint32_t size;
+    if (A.emit && !A.emit[k]) {          // another rank writes this record: no bytes here, sorted behind everything
+        A.rec_size[k] = 0; A.key[k] = ~0ULL;
+        return;
+    }
     if (a.tid < 0) {
         size = 36u + Y.l_name + (uint32_t)(Y.l_seq + 1) / 2 + Y.l_seq + rg;
-        A.key[k] = ~0ULL;
+        A.key[k] = ~0ULL - 1;
     } else {
         const BamInfo I = A.info[k];
         const int sa = Y.sec ? 0 : d_bam_sa(A, k, nullptr);
@@ -355,8 +360,9 @@ __global__ void __launch_bounds__(64) k_bam_write(BamArgs A)
     const int k = A.order ? (int)A.order[blockIdx.x + A.s0] : (int)blockIdx.x;
     const telr_aln a = A.alns[k];
     const BamLayout Y = d_bam_layout(A, a);
-    uint8_t *const rec = A.ubuf + A.rec_ustart[k];
     const uint32_t size = A.rec_size[k];
+    if (size == 0) return;               // slice mode: not this rank's record
+    uint8_t *const rec = A.ubuf + A.rec_ustart[k];
     const bool un = a.tid < 0;
     const int n_cig_field = un ? 0 : (Y.long_cigar ? 2 : Y.n_cig);
     uint8_t *const p_name = rec + 36, *const p_cig = p_name + Y.l_name, *const p_seq = p_cig + 4 * n_cig_field,
@@ -1153,7 +1159,8 @@ static void progress_set(StreamProgress *p, uint64_t ready, int state, uint64_t 
     p->cv.notify_all();
 }
 static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, StreamProgress *prog, const void *tail, size_t tail_bytes, const char *path,
-                          int fd_open = -1, uint8_t *map_dst = nullptr, size_t map_bytes = 0, uint64_t *total_out = nullptr, BamSink *sink = nullptr, float *sink_wait_ms = nullptr)
+                          int fd_open = -1, uint8_t *map_dst = nullptr, size_t map_bytes = 0, uint64_t *total_out = nullptr, BamSink *sink = nullptr, float *sink_wait_ms = nullptr,
+                          uint64_t file_off = 0, bool keep_size = false)      // file_off: the image goes to this offset of the file (map_dst = the mapping of that place); keep_size: do not cut the file
 {
     const size_t CH = 32u << 20; const int R = 8;
     uint8_t *ring; TRY(ctx_hbuf_t(ctx, "bam_ring", CH * R, &ring));
@@ -1193,7 +1200,7 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
                 HostPool::get().run(NT, [&](int i) { const size_t o = (size_t)i * piece; if (o < n) memcpy(dst + o, src + o, std::min(piece, n - o)); });
             } else {
                 size_t done = 0;
-                while (done < n) { ssize_t w = pwrite(fd, src + done, n - done, (off_t)((uint64_t)c * CH + done)); if (w <= 0) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); return; } done += (size_t)w; }
+                while (done < n) { ssize_t w = pwrite(fd, src + done, n - done, (off_t)(file_off + (uint64_t)c * CH + done)); if (w <= 0) { std::lock_guard<std::mutex> lk(mu); fail = true; cv.notify_all(); return; } done += (size_t)w; }
             }
             { std::lock_guard<std::mutex> lk(mu); written = c + 1; }
             cv.notify_all();
@@ -1241,9 +1248,9 @@ static int stream_to_file(telr_ctx *ctx, const uint8_t *d_img, uint64_t bytes, S
     if (rc == TELR_OK && tail_bytes) {
         const bool in_map = map_dst && total + tail_bytes <= map_bytes && (!sink || sink->wait_ready((size_t)(total + tail_bytes)) >= total + tail_bytes);
         if (in_map) memcpy(map_dst + total, tail, tail_bytes);
-        else if (pwrite(fd, tail, tail_bytes, (off_t)total) != (ssize_t)tail_bytes) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
+        else if (pwrite(fd, tail, tail_bytes, (off_t)(file_off + total)) != (ssize_t)tail_bytes) { ctx->err = std::string("write to ") + path + " failed"; rc = TELR_E_ARG; }
     }
-    if (rc == TELR_OK && fd_open >= 0 && !sink && ftruncate(fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;      // with a sink: cut by the caller, once its threads have stopped
+    if (rc == TELR_OK && fd_open >= 0 && !sink && !keep_size && ftruncate(fd, (off_t)(total + tail_bytes)) != 0) rc = TELR_E_ARG;      // with a sink: cut by the caller, once its threads have stopped
     if (fd_open < 0) close(fd);
     if (total_out) *total_out = total;
     return rc;
@@ -1316,9 +1323,21 @@ extern "C" int telr_device_mem(telr_ctx *ctx, int64_t *free_bytes, int64_t *tota
     if (total_bytes) *total_bytes = (int64_t)tot;
     return TELR_OK;
 }
+// ---- one coordinate slice of a BAM (N > 1 ranks: every rank writes the slice of the job's file it holds the records of) ----
+// The BGZF blocks of the slice as an image in the context's device memory (valid until the context's next writer call), the
+// blocks' offsets inside it, and what the index needs of every record written: rank 0 merges those into the one .bai.
+struct telr_bam_segment {
+    telr_ctx *ctx = nullptr;
+    const uint8_t *d_img = nullptr; uint64_t cbytes = 0, ubytes = 0;
+    std::vector<uint64_t> coff;                       // [nblk + 1] offsets of the BGZF blocks inside the image
+    std::vector<int32_t> tid, ts, te;                 // mapped records of the slice in file order
+    std::vector<uint64_t> ustart;                     // [n + 1] their offsets in the slice's uncompressed stream (header included)
+    int64_t n_unmapped = 0;
+};
+struct BamSliceOpt { const uint8_t *emit; int32_t with_header; telr_bam_segment *seg; };
 static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                         const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
-                        const char *bam_path, int32_t write_index, int32_t level);
+                        const char *bam_path, int32_t write_index, int32_t level, const BamSliceOpt *so = nullptr);
 extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                                   const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                                   const char *bam_path, int32_t write_index, int32_t level)
@@ -1344,9 +1363,9 @@ extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const tel
 }
 static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                         const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
-                        const char *bam_path, int32_t write_index, int32_t level)
+                        const char *bam_path, int32_t write_index, int32_t level, const BamSliceOpt *so)
 {
-    if (!ctx || !r || !queries || !idx || !idx->targets || !qnames || !tnames || !bam_path) return TELR_E_ARG;
+    if (!ctx || !r || !queries || !idx || !idx->targets || !qnames || !tnames || (!bam_path && !so)) return TELR_E_ARG;
     if (level < 0) return TELR_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1387,7 +1406,7 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
       parallel_ranges(host_threads(), nq, [&](int, int a0, int a1) { for (int q = a0; q < a1; ++q) memcpy(&qn_buf[(size_t)qn_off[q]], qnames[q], (size_t)(qn_off[q + 1] - qn_off[q])); }); }
     std::vector<int32_t> tn_off((size_t)nt + 1); std::string tn_buf;
     { int32_t o = 0; for (int t = 0; t < nt; ++t) { tn_off[t] = o; o += (int32_t)strlen(tnames[t]) + 1; } tn_off[nt] = o; tn_buf.resize((size_t)o); for (int t = 0; t < nt; ++t) memcpy(&tn_buf[tn_off[t]], tnames[t], (size_t)(tn_off[t + 1] - tn_off[t])); }
-    const std::string head = bam_header(nt, tnames, tg->len.data(), rg_id, rg_sm, rg_lb, pg_line);
+    const std::string head = (so && !so->with_header) ? std::string() : bam_header(nt, tnames, tg->len.data(), rg_id, rg_sm, rg_lb, pg_line);
     const int rg_len = rg_id ? (int)strlen(rg_id) : 0;
     // ---- 2. upload
     telr_aln *d_alns; char *d_qn, *d_tn, *d_rg; int64_t *d_qnoff; int32_t *d_tnoff; BamInfo *d_info; uint32_t *d_size, *d_ord0, *d_ord; uint64_t *d_key, *d_key2, *d_szs, *d_ust, *d_rust;
@@ -1412,6 +1431,15 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     A.q2 = queries->d_seq2; A.qn = queries->d_nmask; A.qboff = queries->d_boff; A.t2 = tg->d_seq2; A.tn = tg->d_nmask; A.tboff = tg->d_boff;
     A.qnames = d_qn; A.qname_off = d_qnoff; A.tnames = d_tn; A.tname_off = d_tnoff; A.rg = d_rg; A.rg_len = rg_len; A.flags = flags;
     A.info = d_info; A.rec_size = d_size; A.key = d_key; A.rec_ustart = d_rust; A.ubuf = nullptr;
+    size_t n_ghost = 0;
+    if (so && so->emit) {
+        uint8_t *d_emit; TRY(ctx_buf_t(ctx, "bam_emit", nrec + 1, &d_emit));
+        std::vector<uint8_t> h_emit(nrec, 1);             // (the pseudo records of the unmapped reads are always this rank's)
+        for (size_t k = 0; k < n_mapped; ++k) { h_emit[k] = so->emit[k] ? 1 : 0; n_ghost += h_emit[k] ? 0 : 1; }
+        if (nrec) HIPCHK(hipMemcpyAsync(d_emit, h_emit.data(), nrec, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        A.emit = d_emit;
+    }
     uint64_t utotal = head.size();
     std::vector<uint32_t> h_order(nrec); std::vector<uint64_t> h_ustart(nrec + 1, head.size());
     if (nrec) {
@@ -1533,7 +1561,7 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
         }
         prog = new StreamProgress();
         StreamProgress *pg = prog; uint64_t *coff_p = coff.data(); hipStream_t st2 = ctx->side[0]; const int device = ctx->device;
-        BamSink *sk = ctx->bam_sink && ctx->bam_sink->path == bam_path ? ctx->bam_sink : nullptr;
+        BamSink *sk = bam_path && ctx->bam_sink && ctx->bam_sink->path == bam_path ? ctx->bam_sink : nullptr;
         const std::vector<hipEvent_t> evg_copy = evg;          // (the bag destroys them after the producer has been joined)
         producer = std::thread([=]() mutable {
             (void)hipSetDevice(device);
@@ -1560,10 +1588,26 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     float bai_ms = 0;
     // the index is laid out with stream offsets while the blocks are still being coded; their file offsets go in at the end
     std::vector<size_t> bai_fix;
-    if (write_index) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), nt, tg->len.data(), bai, bai_fix); bai_ms = ms_since(tb0); });
+    if (write_index && !so) bai_th = std::thread([&] { auto tb0 = now(); bai_build(recs, h_order.data(), nrec, n_unmapped, h_ustart.data(), nt, tg->len.data(), bai, bai_fix); bai_ms = ms_since(tb0); });
     std::thread bai_starter;
     if (prog) bai_starter = std::thread([&] { if (producer.joinable()) producer.join(); });        // the block offsets are complete when the producer is
     static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (so) {
+        // slice mode: the image stays on the device (telr_bam_segment_write puts it at its place in the job's file once the
+        // sizes of the slices before it are known); the records' coordinates and stream offsets go with it for the one index
+        if (bai_starter.joinable()) bai_starter.join();
+        if (producer.joinable()) producer.join();
+        int rc = TELR_OK;
+        if (prog) { if (prog->state < 0) rc = TELR_E_HIP; cbytes = prog->total; delete prog; }
+        HIPCHK(hipDeviceSynchronize());
+        telr_bam_segment *S = so->seg;
+        S->ctx = ctx; S->d_img = d_c; S->cbytes = cbytes; S->ubytes = utotal; S->coff = coff; S->n_unmapped = (int64_t)n_unmapped;
+        const size_t nw = nrec - n_ghost - n_unmapped;                       // mapped records of the slice, first in the sorted order
+        S->tid.resize(nw); S->ts.resize(nw); S->te.resize(nw); S->ustart.assign(h_ustart.begin(), h_ustart.begin() + nw + 1);
+        for (size_t i = 0; i < nw; ++i) { const telr_aln &a = recs[h_order[i]]; S->tid[i] = a.tid; S->ts[i] = a.ts; S->te[i] = a.te > a.ts ? a.te : a.ts + 1; }
+        g_bam_times.ms[7] = ms_since(t_all);
+        return rc;
+    }
     int rc = sink_to_file(ctx, d_c, cbytes, prog, eof_blk, 28, bam_path);
     g_bam_times.ms[5] = ms_since(t0);
     if (bai_starter.joinable()) bai_starter.join();
@@ -1579,4 +1623,134 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     }
     g_bam_times.ms[7] = ms_since(t_all);
     return rc;
+}
+
+// ---- the slice entry points (include/telr_hip.h) ---------------------------------------------------------------------
+extern "C" int telr_write_bam_slice(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
+                                    const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
+                                    const uint8_t *emit, int32_t with_header, int32_t level, telr_bam_segment **out)
+{
+    if (!out || level < 1) return TELR_E_ARG;
+    static std::mutex mu;                                   // (the writer's process-wide records, as in telr_write_bam_dev)
+    std::lock_guard<std::mutex> lk(mu);
+    (void)hipGetLastError();
+    telr_bam_segment *S = new telr_bam_segment();
+    BamSliceOpt so{ emit, with_header, S };
+    int rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, nullptr, 0, level, &so);
+    if (rc == TELR_E_NOMEM) {
+        (void)hipGetLastError();
+        ctx_release_map_scratch(ctx, g_bam_need);
+        rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, nullptr, 0, level, &so);
+    }
+    if (rc != TELR_OK) { delete S; return rc; }
+    *out = S;
+    return TELR_OK;
+}
+extern "C" void telr_bam_segment_free(telr_bam_segment *s) { delete s; }
+// out[0] bytes of the slice in the file, [1] mapped records, [2] unmapped reads, [3] bytes of its uncompressed stream
+extern "C" int telr_bam_segment_info(const telr_bam_segment *s, int64_t *out)
+{
+    if (!s || !out) return TELR_E_ARG;
+    out[0] = (int64_t)s->cbytes; out[1] = (int64_t)s->tid.size(); out[2] = s->n_unmapped; out[3] = (int64_t)s->ubytes;
+    return TELR_OK;
+}
+static uint64_t segment_voff(const telr_bam_segment *s, uint64_t file_off, uint64_t u)
+{
+    const size_t nblk = s->coff.size() - 1, b = (size_t)(u / BAM_BLK);
+    if (b >= nblk) return (file_off + s->cbytes) << 16;
+    return (file_off + s->coff[b]) << 16 | (u - (uint64_t)b * BAM_BLK);
+}
+// what the job's index needs of the slice, with the slice at `file_off` of the file: per mapped record (file order) the
+// reference, start, end and the virtual offset of its first byte; v_end = the virtual offset behind the last mapped record
+extern "C" int telr_bam_segment_entries(const telr_bam_segment *s, int64_t file_off, int32_t *tid, int32_t *ts, int32_t *te, uint64_t *vb, uint64_t *v_end)
+{
+    if (!s || file_off < 0 || !v_end || s->coff.empty()) return TELR_E_ARG;
+    const size_t n = s->tid.size();
+    if (n && (!tid || !ts || !te || !vb)) return TELR_E_ARG;
+    for (size_t i = 0; i < n; ++i) { tid[i] = s->tid[i]; ts[i] = s->ts[i]; te[i] = s->te[i]; vb[i] = segment_voff(s, (uint64_t)file_off, s->ustart[i]); }
+    *v_end = segment_voff(s, (uint64_t)file_off, s->ustart[n]);
+    return TELR_OK;
+}
+// the slice's image -> bytes [file_off, file_off + size) of `path` (an existing file: rank 0 creates it, every rank writes its
+// own range); is_last: the BGZF end-of-file block behind it.  The range is allocated first (ENOSPC is an error code here, never
+// a SIGBUS), mapped and pre-faulted, and filled through the pinned ring by the host pool.
+extern "C" int telr_bam_segment_write(telr_ctx *ctx, const telr_bam_segment *s, const char *path, int64_t file_off, int32_t is_last)
+{
+    if (!ctx || !s || !path || file_off < 0 || s->ctx != ctx) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    static const uint8_t eof_blk[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const size_t tail = is_last ? 28 : 0, len = (size_t)s->cbytes + tail;
+    int fd = open(path, O_RDWR);
+    if (fd < 0) { ctx->err = std::string("cannot open ") + path; return TELR_E_ARG; }
+    int rc = TELR_OK;
+    uint8_t *map = nullptr; size_t map_len = 0; const uint64_t al = (uint64_t)file_off & ~(uint64_t)4095;
+    if (len) {
+        if (posix_fallocate(fd, (off_t)file_off, (off_t)len) != 0) { ctx->err = std::string("no space for ") + path; close(fd); return TELR_E_ARG; }
+        map_len = (size_t)((uint64_t)file_off + len - al);
+        void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)al);
+        if (m != MAP_FAILED) { map = (uint8_t*)m; (void)madvise(map, map_len, 23 /* MADV_POPULATE_WRITE */); }
+    }
+    uint64_t total = 0;
+    rc = stream_to_file(ctx, s->d_img, s->cbytes, nullptr, eof_blk, tail, path, fd, map ? map + ((uint64_t)file_off - al) : nullptr, map ? len : 0, &total, nullptr, nullptr,
+                        (uint64_t)file_off, true);
+    if (map) munmap(map, map_len);
+    close(fd);
+    if (rc == TELR_OK && total != s->cbytes) rc = TELR_E_HIP;
+    return rc;
+}
+// The .bai of a file whose records are described by arrays in FILE order (n mapped records: reference, start, end, virtual
+// offset of the first byte; v_end: the virtual offset behind the last of them; n_unmapped reads follow): what rank 0 writes
+// from the entries of all slices.  Same bins, chunk merging, linear index and metadata pseudo-bin as the one-rank writer.
+extern "C" int telr_bai_write(const char *bai_path, int64_t n, const int32_t *tid, const int32_t *ts, const int32_t *te, const uint64_t *vb, uint64_t v_end,
+                              int64_t n_unmapped, int32_t n_targets, const int32_t *t_len)
+{
+    if (!bai_path || n < 0 || n_targets < 0 || (n && (!tid || !ts || !te || !vb)) || (n_targets && !t_len)) return TELR_E_ARG;
+    std::string bai;
+    auto put32 = [&](uint32_t v) { bai.append((const char*)&v, 4); };
+    auto put64 = [&](std::string &d, uint64_t v) { d.append((const char*)&v, 8); };
+    bai = "BAI\1"; put32((uint32_t)n_targets);
+    int64_t i = 0;
+    struct Ch { uint32_t bin; uint64_t vb, ve; };
+    std::vector<Ch> chs;
+    for (int t = 0; t < n_targets; ++t) {
+        chs.clear();
+        const int n_lin = (t_len[t] >> 14) + 1;
+        std::vector<uint64_t> lin(n_lin, 0);
+        int max_lin = 0; uint64_t ref_beg = 0, ref_end = 0, n_map = 0; bool any = false;
+        while (i < n && tid[i] == t) {
+            const uint64_t b = vb[i], e_ = i + 1 < n ? vb[i + 1] : v_end;
+            const int e = te[i] > ts[i] ? te[i] : ts[i] + 1;
+            chs.push_back(Ch{ (uint32_t)reg2bin(ts[i], e), b, e_ });
+            const int w0 = ts[i] >> 14, w1 = (e - 1) >> 14;
+            for (int wv = w0; wv <= w1 && wv < n_lin; ++wv) { if (lin[wv] == 0 || b < lin[wv]) lin[wv] = b; if (wv + 1 > max_lin) max_lin = wv + 1; }
+            if (!any) { ref_beg = b; any = true; }
+            ref_end = e_; ++n_map; ++i;
+        }
+        if (i < n && tid[i] < t) return TELR_E_ARG;                 // not in file order
+        std::stable_sort(chs.begin(), chs.end(), [](const Ch &x, const Ch &y) { return x.bin < y.bin; });
+        std::string body; uint32_t nbin = 0;
+        for (size_t c0 = 0; c0 < chs.size(); ) {
+            size_t c1 = c0; std::vector<std::pair<uint64_t, uint64_t>> ch;
+            while (c1 < chs.size() && chs[c1].bin == chs[c0].bin) {
+                if (!ch.empty() && (ch.back().second >> 16) == (chs[c1].vb >> 16)) ch.back().second = chs[c1].ve; else ch.push_back(std::make_pair(chs[c1].vb, chs[c1].ve));
+                ++c1;
+            }
+            uint32_t bin = chs[c0].bin, nc = (uint32_t)ch.size();
+            body.append((const char*)&bin, 4); body.append((const char*)&nc, 4);
+            for (auto &c : ch) { put64(body, c.first); put64(body, c.second); }
+            ++nbin; c0 = c1;
+        }
+        put32(nbin + (any ? 1 : 0));
+        bai += body;
+        if (any) { put32(37450u); put32(2u); put64(bai, ref_beg); put64(bai, ref_end); put64(bai, n_map); put64(bai, 0); }
+        for (int wv = 1; wv < max_lin; ++wv) if (lin[wv] == 0) lin[wv] = lin[wv - 1];
+        put32((uint32_t)max_lin);
+        for (int wv = 0; wv < max_lin; ++wv) put64(bai, lin[wv]);
+    }
+    if (i != n) return TELR_E_ARG;
+    put64(bai, (uint64_t)n_unmapped);
+    FILE *f = fopen(bai_path, "wb");
+    if (!f) return TELR_E_ARG;
+    const bool ok = fwrite(bai.data(), 1, bai.size(), f) == bai.size();
+    return (fclose(f) == 0 && ok) ? TELR_OK : TELR_E_ARG;
 }

@@ -1134,6 +1134,30 @@ extern "C" int telr_result_from_arrays(telr_ctx *ctx, const telr_aln *alns, int6
     *out = R;
     return TELR_OK;
 }
+// the same with the CIGAR words on the DEVICE (what an all-to-all delivered): they become the result's device copy as they are
+// (the device BAM writer reads them in place) and are mirrored to the host array once
+extern "C" int telr_result_from_device_cigars(telr_ctx *ctx, const telr_aln *alns, int64_t n, const void *d_cigars, int64_t n_cigar, telr_result **out)
+{
+    if (!ctx || !out || n < 0 || n_cigar < 0 || (n > 0 && !alns) || (n_cigar > 0 && !d_cigars)) return TELR_E_ARG;
+    for (int64_t i = 0; i < n; ++i) if (alns[i].n_cigar < 0 || alns[i].cigar_off < 0 || alns[i].cigar_off + alns[i].n_cigar > n_cigar) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    telr_result *R = new telr_result();
+    R->ctx = ctx;
+    R->alns.assign(alns, alns + n);
+    R->cig = cig_alloc((size_t)n_cigar + 1);
+    if (!R->cig) { delete R; return TELR_E_NOMEM; }
+    R->cap = (size_t)n_cigar + 1; R->ncig = (size_t)n_cigar;
+    if (hipMalloc(&R->d_cig, ((size_t)n_cigar + 1) * 4) != hipSuccess) { (void)hipGetLastError(); delete R; return TELR_E_NOMEM; }
+    R->d_cap = (size_t)n_cigar + 1;
+    if (n_cigar) {
+        hipError_t e = hipMemcpy(R->d_cig, d_cigars, (size_t)n_cigar * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(R->cig, R->d_cig, (size_t)n_cigar * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); delete R; return TELR_E_HIP; }
+    }
+    R->twin_n = R->ncig; R->twin_off = false;
+    *out = R;
+    return TELR_OK;
+}
 extern "C" int64_t telr_result_count(const telr_result *r) { return r ? (int64_t)r->alns.size() : 0; }
 extern "C" const telr_aln *telr_result_alns(const telr_result *r) { return r ? r->alns.data() : nullptr; }
 // test tap: the device copy of the CIGAR array kept under TELR_MF_KEEP_CIGARS -> `out` (n words); returns the number of words

@@ -209,72 +209,233 @@ def exchange_window_reads_packed(locus_id, read_id, dest, lengths, gather_packed
     return h[:, 0], h[:, 1], h[:, 2].astype(np.int32), got2, gotn, order
 
 
-def gather_stage1(alns, cigars, reads, read_names, dist=None, device=None, force=False, read_gid=None):
-    """The stage-1 hand-off at N > 1: Sniffles wants ONE coordinate-sorted BAM, the reads were dealt to the ranks.  Every rank
-    packs what it mapped -- records, CIGAR words, read bases, lengths and names -- into one byte blob; ONE all-gather of the five
-    sizes and ONE all-to-all whose only non-empty destination is rank 0 (RCCL over xGMI on device tensors, gloo in the tests: the
-    same two collectives the loci leg uses) bring them to rank 0, which re-bases the query ids and CIGAR offsets and holds the job's
-    records in rank order: the input of ONE telr_write_bam_dev call ("each rank writes its own shard, host merges" --
-    the merge is the device writer's sort; writing is bound by the host's page cache, so a second writer would not help).
-    force: run the collectives at world size 1 too.  read_gid: the job-level number of every read of this rank (its place in the
-    input file); with it rank 0 puts reads and records back into file order, so the job's arrays -- and the BAM written from them,
-    ties in the coordinate sort included -- do not depend on how the reads were dealt.
-    -> on rank 0: (alns, cigars, (buf, off, len), names) of the whole job (with read_gid the offsets are not ascending: read i of the job
-    is buf[off[i] : off[i] + len[i]]); on the other ranks None."""
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
-    buf, off, ln = reads
-    alns = np.ascontiguousarray(alns); cigars = np.ascontiguousarray(cigars, dtype=np.uint32)
-    ln = np.ascontiguousarray(ln, np.int32); off = np.asarray(off, np.int64)
-    if world == 1 and not (force and dist is not None and dist.is_initialized()):
-        return alns, cigars, (buf, off, ln), list(read_names)
+# ---- stage 1 -> ONE coordinate-sorted BAM written by all ranks (round 4) ---------------------------------------------------
+# Sniffles reads one file (TELR_sv.py:35-47); the reads were dealt to the ranks.  Instead of bringing everything to rank 0
+# (gather_stage1: one writer behind N mappers), the job's records are RANGE-PARTITIONED by coordinate: sampled splitters (one
+# small all-gather), every record goes to the rank that owns its coordinate slice together with its read -- as packed 2-bit
+# words, device tensors, never ASCII -- and with the OTHER records of that read (marked "not yours": the SA tag of a record
+# names its read's other alignments), ONE all-to-all of a byte payload per peer; every rank then codes the BGZF blocks of its
+# slice on its own device (telr_write_bam_slice), the slice sizes are scanned over the ranks (one tiny all-gather), every rank
+# puts its image at its place of the one file, and rank 0 writes the one .bai from the records' coordinates and virtual offsets.
+
+
+def _pad8(n):
+    return (int(n) + 7) & ~7
+
+
+def stage1_splitters(keys, world, dist, wire, per_rank=64):
+    """coordinate keys (int64, this rank's records) -> world - 1 ascending splitters, the same on every rank: the quantiles of
+    per_rank * world samples of every rank's sorted keys (ONE all-gather of fixed-size blocks)"""
     import torch
-    dev = device if device is not None else "cpu"
-    names_blob = np.frombuffer(("\n".join(read_names)).encode(), np.uint8)
-    # the reads of this rank end to end (they usually are already)
-    if len(ln) and not (off == np.cumsum(ln.astype(np.int64)) - ln).all():
-        buf = np.concatenate([buf[o:o + l] for o, l in zip(off, ln)])
-    gid = np.zeros(0, np.int64) if read_gid is None else np.ascontiguousarray(read_gid, np.int64)
-    mine = [alns.view(np.uint8).reshape(-1), cigars.view(np.uint8).reshape(-1), np.ascontiguousarray(buf, np.uint8)[:int(ln.sum())], ln.view(np.uint8).reshape(-1), names_blob,
-            gid.view(np.uint8).reshape(-1)]
-    sizes = torch.tensor([len(x) for x in mine], dtype=torch.int64, device=dev)
-    all_sizes = [torch.empty(6, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
-    all_sizes = [[int(v) for v in t.cpu().tolist()] for t in all_sizes]
-    blob = torch.from_numpy(np.concatenate(mine)).to(dev)
-    recv_n = [sum(x) for x in all_sizes] if rank == 0 else [0] * world
-    got = torch.empty(sum(recv_n), dtype=torch.uint8, device=dev)
-    dist.all_to_all_single(got, blob, output_split_sizes=recv_n, input_split_sizes=[len(blob)] + [0] * (world - 1))
-    if rank != 0:
-        return None
-    got = got.cpu().numpy()
-    out_alns, out_cig, out_buf, out_len, out_names, out_gid = [], [], [], [], [], []
-    q0 = 0; c0 = 0; p0 = 0
-    for r in range(world):
-        p = []
-        for k in range(6):
-            p.append(got[p0:p0 + all_sizes[r][k]]); p0 += all_sizes[r][k]
-        a = np.frombuffer(p[0].tobytes(), dtype=alns.dtype).copy()
+    n = per_rank * world
+    ks = np.sort(np.asarray(keys, np.int64))
+    samp = ks[(np.arange(n) * len(ks)) // n] if len(ks) else np.full(n, np.iinfo(np.int64).max, np.int64)
+    mine = torch.from_numpy(np.ascontiguousarray(samp)).to(wire)
+    got = torch.empty(world * n, dtype=torch.int64, device=wire)
+    dist.all_gather_into_tensor(got, mine)
+    allk = np.sort(got.cpu().numpy())
+    allk = allk[allk != np.iinfo(np.int64).max]
+    if len(allk) == 0:
+        return np.zeros(world - 1, np.int64)
+    return allk[(np.arange(1, world) * len(allk)) // world]
+
+
+def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, world, dist, wire, timings=None):
+    """Every record (with its read and the read's other records) to the rank `rec_dest` says; reads without a record to the last
+    rank.  alns: this rank's records, query-major, qid = index into this rank's reads (lengths / names / gid, ascending gid);
+    cig_t: the CIGAR words as a torch int32 tensor (device); gather_packed(read indices) -> the packed words of those reads.
+    -> dict(alns, emit, cig (torch int32), lengths, names, gid, seq2, nmask) of what this rank now holds: reads in ascending gid
+    order, records query-major with qid / cigar_off re-based, emit[i] = record i lies in this rank's slice."""
+    import time
+    import torch
+    t0 = time.time()
+    rank = dist.get_rank()
+    alns = np.ascontiguousarray(alns)
+    nq = len(lengths)
+    lengths = np.asarray(lengths, np.int32); gid = np.asarray(gid, np.int64)
+    qid = alns["qid"].astype(np.int64)
+    rec_dest = np.asarray(rec_dest, np.int64)
+    rstart = np.searchsorted(qid, np.arange(nq)); rcount = np.searchsorted(qid, np.arange(nq), side="right") - rstart
+    # (destination, read) pairs: every slice one of the read's records lies in; reads without records -> the last rank
+    pair = np.unique(np.concatenate([rec_dest * nq + qid, (world - 1) * nq + np.nonzero(rcount == 0)[0]]))       # sorted by (dest, read) = (dest, gid)
+    p_dest = pair // nq; p_read = pair % nq
+    n_to = np.bincount(p_dest, minlength=world).astype(np.int64)
+    cuts = np.concatenate([[0], np.cumsum(n_to)])
+    # the records that travel with every pair
+    p_nrec = rcount[p_read]
+    tot_rec = int(p_nrec.sum())
+    pr_off = np.cumsum(p_nrec) - p_nrec
+    ridx = np.repeat(rstart[p_read] - pr_off, p_nrec) + np.arange(tot_rec, dtype=np.int64)          # record index per sent record
+    r_pair = np.repeat(np.arange(len(pair)), p_nrec)
+    s_alns = alns[ridx].copy()
+    s_emit = (rec_dest[ridx] == p_dest[r_pair]).astype(np.uint8)
+    s_alns["qid"] = (r_pair - cuts[p_dest[r_pair]]).astype(np.int32)                                # index of the read inside its destination block
+    rec_cuts = np.concatenate([[0], np.cumsum(np.bincount(p_dest[r_pair], minlength=world))]).astype(np.int64)
+    ncig = s_alns["n_cigar"].astype(np.int64)
+    c_off_all = np.cumsum(ncig) - ncig
+    cig_cuts = np.concatenate([[0], np.cumsum(np.bincount(p_dest[r_pair], weights=ncig, minlength=world))]).astype(np.int64)       # CIGAR words per destination block
+    old_off = alns["cigar_off"].astype(np.int64)[ridx]
+    s_alns["cigar_off"] = (c_off_all - cig_cuts[p_dest[r_pair]]).astype(s_alns["cigar_off"].dtype) if tot_rec else s_alns["cigar_off"]
+    dev = cig_t.device
+    # the CIGAR words of the sent records, gathered on the device
+    tot_cig = int(ncig.sum())
+    if tot_cig:
+        src = torch.from_numpy(np.ascontiguousarray(old_off - c_off_all)).to(dev)
+        widx = torch.repeat_interleave(src, torch.from_numpy(ncig).to(dev)) + torch.arange(tot_cig, device=dev, dtype=torch.int64)
+        s_cig = cig_t.view(torch.int32)[widx]
+    else:
+        s_cig = torch.zeros(0, dtype=torch.int32, device=dev)
+    seq2, nmask = gather_packed(p_read)
+    w2, _ = packed_words(lengths[p_read])
+    w2_cuts = np.concatenate([[0], np.cumsum(w2)])[cuts]
+    if timings is not None:
+        timings["pack_s"] = timings.get("pack_s", 0.0) + time.time() - t0
+    t0 = time.time()
+    # per destination: [records][emit][gid][length][names][CIGAR words][2-bit words][mask words], every section padded to 8 bytes
+    sec = np.zeros((world, 8), np.int64)
+    parts = []
+    for d in range(world):
+        a = s_alns[rec_cuts[d]:rec_cuts[d + 1]]; e = s_emit[rec_cuts[d]:rec_cuts[d + 1]]
+        rd = p_read[cuts[d]:cuts[d + 1]]
+        nb = "\n".join(names[i] for i in rd).encode()
+        host = [a.view(np.uint8).reshape(-1), e, gid[rd].view(np.uint8).reshape(-1), lengths[rd].view(np.uint8).reshape(-1), np.frombuffer(nb, np.uint8)]
+        devp = [s_cig[cig_cuts[d]:cig_cuts[d + 1]], seq2[w2_cuts[d]:w2_cuts[d + 1]], nmask[w2_cuts[d] // 2:w2_cuts[d + 1] // 2]]
+        sec[d, :5] = [len(x) for x in host]; sec[d, 5:] = [int(x.numel()) * 4 for x in devp]
+        hb = np.zeros(sum(_pad8(len(x)) for x in host), np.uint8); o = 0
+        for x in host:
+            hb[o:o + len(x)] = x; o += _pad8(len(x))
+        parts.append(torch.from_numpy(hb).to(dev))
+        for x in devp:
+            parts.append(x.contiguous().view(torch.uint8))
+            if (x.numel() * 4) % 8:
+                parts.append(torch.zeros(4, dtype=torch.uint8, device=dev))
+    send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+    in_split = [int(sum(_pad8(v) for v in sec[d])) for d in range(world)]
+    st = torch.from_numpy(sec.reshape(-1).copy()).to(wire); rs = torch.empty_like(st)
+    dist.all_to_all_single(rs, st)
+    rsec = rs.cpu().numpy().reshape(world, 8)
+    out_split = [int(sum(_pad8(v) for v in rsec[p_])) for p_ in range(world)]
+    recv = torch.empty(sum(out_split), dtype=torch.uint8, device=wire)
+    dist.all_to_all_single(recv, send.to(wire), output_split_sizes=out_split, input_split_sizes=in_split)
+    recv = recv.to(dev)
+    if timings is not None:
+        timings["collective_s"] = timings.get("collective_s", 0.0) + time.time() - t0
+        timings["bytes_sent"] = int(sum(in_split)) - in_split[rank]
+    t0 = time.time()
+    g_alns, g_emit, g_gid, g_len, g_names, g_cig, g_s2, g_sn = [], [], [], [], [], [], [], []
+    o = 0; q0 = 0; c0 = 0
+    for p_ in range(world):
+        v = rsec[p_]; pos = [o]
+        for x in v:
+            pos.append(pos[-1] + _pad8(x))
+        host = recv[pos[0]:pos[5]].cpu().numpy()
+        h0 = pos[0]
+        a = np.frombuffer(host[pos[0] - h0:pos[0] - h0 + v[0]].tobytes(), dtype=alns.dtype).copy()
         a["qid"] += q0; a["cigar_off"] += c0
-        lens = np.frombuffer(p[3].tobytes(), np.int32)
-        out_alns.append(a); out_cig.append(np.frombuffer(p[1].tobytes(), np.uint32)); out_buf.append(p[2]); out_len.append(lens)
-        out_names += p[4].tobytes().decode().split("\n") if len(lens) else []
-        out_gid.append(np.frombuffer(p[5].tobytes(), np.int64))
-        q0 += len(lens); c0 += len(p[1]) // 4
-    ln_all = np.concatenate(out_len); a_all = np.concatenate(out_alns); buf_all = np.concatenate(out_buf); gid_all = np.concatenate(out_gid)
-    off_all = np.cumsum(ln_all.astype(np.int64)) - ln_all
-    if read_gid is not None:
-        if len(gid_all) != len(ln_all):
-            raise ValueError("gather_stage1: read_gid must be given by every rank or by none")
-        order = np.argsort(gid_all, kind="stable")                  # new place -> gathered place
+        ln = np.frombuffer(host[pos[3] - h0:pos[3] - h0 + v[3]].tobytes(), np.int32)
+        g_alns.append(a); g_emit.append(host[pos[1] - h0:pos[1] - h0 + v[1]].copy())
+        g_gid.append(np.frombuffer(host[pos[2] - h0:pos[2] - h0 + v[2]].tobytes(), np.int64)); g_len.append(ln)
+        g_names += host[pos[4] - h0:pos[4] - h0 + v[4]].tobytes().decode().split("\n") if len(ln) else []
+        g_cig.append(recv[pos[5]:pos[5] + v[5]].view(torch.int32)); g_s2.append(recv[pos[6]:pos[6] + v[6]].view(torch.int32)); g_sn.append(recv[pos[7]:pos[7] + v[7]].view(torch.int32))
+        q0 += len(ln); c0 += int(v[5]) // 4
+        o = pos[8]
+    a_all = np.concatenate(g_alns); e_all = np.concatenate(g_emit); gid_all = np.concatenate(g_gid); len_all = np.concatenate(g_len)
+    cig_all = torch.cat(g_cig); s2 = torch.cat(g_s2); sn = torch.cat(g_sn)
+    # reads into ascending job order (ties of the coordinate sort are broken by it): a permutation of the packed pieces on the device
+    order = np.argsort(gid_all, kind="stable")
+    if len(order) and not (order == np.arange(len(order))).all():
+        w2a, _ = packed_words(len_all)
+        st2 = np.cumsum(w2a) - w2a
+        src = torch.from_numpy(np.ascontiguousarray(st2[order] - (np.cumsum(w2a[order]) - w2a[order]))).to(dev)
+        cnt = torch.from_numpy(np.ascontiguousarray(w2a[order])).to(dev)
+        tot2 = int(w2a.sum())
+        i2 = torch.repeat_interleave(src, cnt) + torch.arange(tot2, device=dev, dtype=torch.int64)
+        s2 = s2[i2]
+        half = torch.repeat_interleave(src // 2, cnt // 2) + torch.arange(tot2 // 2, device=dev, dtype=torch.int64)
+        sn = sn[half]
         place = np.empty(len(order), np.int64); place[order] = np.arange(len(order))
         a_all["qid"] = place[a_all["qid"]]
-        a_all = a_all[np.argsort(a_all["qid"], kind="stable")]      # the records of a read stay in the order the engine gave them
-        # the bases stay where the gather put them: a sequence set is (buffer, offsets, lengths), so putting the reads into file
-        # order is a permutation of the two small arrays (moving 4 GB of bases through a gather index would cost 60 GB of host memory)
-        ln_all = ln_all[order]; off_all = off_all[order]
-        out_names = [out_names[i] for i in order]
-    return a_all, np.concatenate(out_cig), (buf_all, off_all, ln_all), out_names
+        ro = np.argsort(a_all["qid"], kind="stable")
+        a_all = a_all[ro]; e_all = e_all[ro]
+        len_all = len_all[order]; gid_all = gid_all[order]; g_names = [g_names[i] for i in order]
+    if timings is not None:
+        timings["unpack_s"] = timings.get("unpack_s", 0.0) + time.time() - t0
+    return dict(alns=a_all, emit=e_all, cig=cig_all, lengths=len_all, names=g_names, gid=gid_all, seq2=s2, nmask=sn)
+
+
+def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tnames, tlens, dist, device=None, level=1, writer_kw=None, timings=None):
+    """ONE coordinate-sorted BAM + .bai for the job, written by all ranks (see the block comment above).  Collective: every rank
+    calls it with its own stage-1 result (alns, cigars: host arrays of this rank's telr_map), its resident read set (SeqSet) and
+    the reads' lengths / names / job-level numbers (ascending).  tnames / tlens: the reference.  -> on every rank a dict of
+    phase seconds and sizes (rank 0: the job's totals as well)."""
+    import time
+    import torch
+    from .aligner import SeqSet
+    tm = {} if timings is None else timings
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = torch.device("cuda", eng.device)
+    wire = torch.device(device) if device is not None else torch.device("cpu")
+    kw = dict(md=True, cs=True, softclip=True, cmdline="telr_map"); kw.update(writer_kw or {})
+    t0 = time.time()
+    alns = np.ascontiguousarray(alns)
+    keys = alns["tid"].astype(np.int64) << 32 | alns["ts"].astype(np.int64)
+    split = stage1_splitters(keys, world, dist, wire)
+    dest = np.searchsorted(split, keys, side="right")
+    cig_t = torch.from_numpy(np.ascontiguousarray(cigars, dtype=np.uint32).view(np.int32)).to(dev)
+    held = []
+
+    def gather_packed(idx):
+        sub = read_set.subset(np.asarray(idx, np.int32)); held.append(sub)
+        return sub.packed()
+    tm["partition_s"] = time.time() - t0
+    got = exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, dest, world, dist, wire, timings=tm)
+    for sub in held:
+        sub.free()
+    del cig_t
+    t0 = time.time()
+    jq = SeqSet.from_packed(eng, got["lengths"], got["seq2"], got["nmask"])
+    jr = ix.result_from_device_cigars(got["alns"], got["cig"])
+    seg = ix.write_bam_slice(jr, jq, ix._cstr_array(got["names"]), tnames, got["emit"], with_header=rank == 0, unmapped=rank == world - 1, level=level, **kw)
+    info = ix.segment_info(seg)
+    tm["code_slice_s"] = time.time() - t0
+    t0 = time.time()
+    sizes = torch.zeros(world, dtype=torch.int64, device=wire); mine = torch.tensor([info["bytes"]], dtype=torch.int64, device=wire)
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = sizes.cpu().numpy()
+    base = int(sizes[:rank].sum()); total = int(sizes.sum()) + 28
+    if rank == 0:                                   # the file exists at its final length before anybody writes into it
+        with open(path, "wb") as fh:
+            fh.truncate(total)
+    dist.barrier()
+    tm["scan_sizes_s"] = time.time() - t0
+    t0 = time.time()
+    ix.segment_write(seg, path, base, rank == world - 1)
+    tm["write_slice_s"] = time.time() - t0
+    t0 = time.time()
+    tid, ts, te, vb, v_end = ix.segment_entries(seg, base)
+    ent = np.concatenate([tid.astype(np.int64), ts.astype(np.int64), te.astype(np.int64), vb.view(np.int64), np.array([v_end, info["unmapped_reads"]], np.uint64).view(np.int64)])
+    n_ent = torch.zeros(world, dtype=torch.int64, device=wire)
+    dist.all_gather_into_tensor(n_ent, torch.tensor([len(ent)], dtype=torch.int64, device=wire))
+    n_ent = [int(x) for x in n_ent.cpu().numpy()]
+    recv = torch.empty(sum(n_ent) if rank == 0 else 0, dtype=torch.int64, device=wire)
+    dist.all_to_all_single(recv, torch.from_numpy(ent).to(wire), output_split_sizes=n_ent if rank == 0 else [0] * world, input_split_sizes=[len(ent)] + [0] * (world - 1))
+    out = dict(tm, slice_bytes=info["bytes"], slice_records=info["mapped_records"], slice_unmapped_reads=info["unmapped_reads"], reads_held=int(len(got["lengths"])),
+               records_held=int(len(got["alns"])))
+    if rank == 0:
+        raw = recv.cpu().numpy(); o = 0
+        T, S, E, V = [], [], [], []
+        v_last, n_un = 0, 0
+        for r_ in range(world):
+            n = (n_ent[r_] - 2) // 4
+            b = raw[o:o + n_ent[r_]]; o += n_ent[r_]
+            T.append(b[:n]); S.append(b[n:2 * n]); E.append(b[2 * n:3 * n]); V.append(b[3 * n:4 * n].view(np.uint64))
+            v_last = int(b[4 * n:].view(np.uint64)[0]); n_un += int(b[4 * n + 1])
+        ix.bai_write(path + ".bai", np.concatenate(T), np.concatenate(S), np.concatenate(E), np.concatenate(V), v_last, n_un, tlens)
+        out.update(bam_bytes=total, records=int(sum(len(x) for x in T)), unmapped_reads=n_un)
+    out["index_s"] = time.time() - t0
+    dist.barrier()
+    ix.segment_free(seg); ix.free_raw(jr); jq.free()
+    return out
 
 
 def rows_from_reports(locus_ids, reports, freqs, chrom_ids, family_ids):

@@ -22,5 +22,8 @@ def data_dir():
 def engine():
     """The HIP engine on cuda:0.  No fallback: a missing library or device is an error."""
     os.environ["TELR_DEBUG"] = "1"      # keep stage-level captures for the parity tests
+    # torch first: its wheel carries its own HIP runtime, and a process can initialise only one -- loaded first, libtelrhip.so
+    # binds to the same one, and tensors (SeqSet.packed, torch.distributed) and the engine share the device
+    import torch  # noqa: F401
     from telr_amd.aligner import Engine
     return Engine(0)

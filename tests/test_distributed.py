@@ -236,6 +236,94 @@ def test_packed_window_read_exchange(tmp_path, world):
         assert got == sorted(want[r])
 
 
+def _stage1_fake(rank, world):
+    """this rank's share of a fabricated job: 40 reads dealt round-robin; read g has 0-3 records at pseudo-random coordinates"""
+    sys.path.insert(0, ROOT)
+    from telr_amd._abi import ALN_DTYPE
+    gids = np.arange(rank, 40, world)
+    seqs, names, recs, cig = [], [], [], []
+    for k, g in enumerate(gids):
+        r = np.random.default_rng(1000 + g)
+        L = int(r.integers(5, 150))
+        seqs.append("".join(r.choice(list("ACGTN"), L))); names.append("read%d" % g)
+        for j in range(int(r.integers(0, 4))):
+            a = np.zeros(1, ALN_DTYPE)[0]
+            a["qid"] = k; a["tid"] = int(r.integers(0, 3)); a["ts"] = int(r.integers(0, 1000)); a["te"] = a["ts"] + 10; a["qlen"] = L
+            a["flags"] = 1 if j == 0 else 2; a["n_cigar"] = int(r.integers(1, 6)); a["cigar_off"] = len(cig); a["mapq"] = g
+            cig += [int(x) for x in r.integers(1, 1 << 20, size=a["n_cigar"])]
+            recs.append(a)
+    alns = np.array(recs, ALN_DTYPE) if recs else np.zeros(0, ALN_DTYPE)
+    return gids, seqs, names, alns, np.array(cig, np.uint32)
+
+
+def _stage1_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import json
+    import torch
+    import torch.distributed as dist
+    from telr_amd import shard
+    import packed_np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gids, seqs, names, alns, cig = _stage1_fake(rank, world)
+    lens, w2, wn = packed_np.pack(seqs)
+    keys = alns["tid"].astype(np.int64) << 32 | alns["ts"].astype(np.int64)
+    split = shard.stage1_splitters(keys, world, dist, torch.device("cpu"))
+    dest = np.searchsorted(split, keys, side="right")
+
+    def gather_packed(idx):
+        a, b = packed_np.subset_words(lens, w2, wn, idx)
+        return torch.from_numpy(a.view(np.int32).copy()), torch.from_numpy(b.view(np.int32).copy())
+    got = shard.exchange_stage1(alns, torch.from_numpy(cig.view(np.int32).copy()), lens, names, gids, gather_packed, dest, world, dist, torch.device("cpu"))
+    rs = packed_np.unpack(got["lengths"], got["seq2"].numpy(), got["nmask"].numpy())
+    cg = got["cig"].numpy().view(np.uint32)
+    out = {"split": [int(x) for x in split], "gid": [int(x) for x in got["gid"]], "names": got["names"], "reads": rs,
+           "recs": [(int(got["gid"][a["qid"]]), int(a["tid"]), int(a["ts"]), int(a["flags"]), int(e), [int(x) for x in cg[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]]]) for a, e in zip(got["alns"], got["emit"])]}
+    json.dump(out, open(os.path.join(out_dir, "s1_%d.json" % rank), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_stage1_range_partition_and_exchange(tmp_path, world):
+    """round 4, the N-rank BAM: records are range-partitioned by coordinate with sampled splitters (identical on every rank); every
+    record arrives exactly once as "emit" on the rank that owns its slice, with its read (packed words intact) and with ALL the
+    other records of that read as non-emit copies; reads without a record go to the last rank; reads arrive in ascending job
+    order, records query-major, CIGAR words intact"""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_stage1_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [json.load(open(str(tmp_path / ("s1_%d.json" % r)))) for r in range(world)]
+    assert all(o["split"] == outs[0]["split"] for o in outs) and outs[0]["split"] == sorted(outs[0]["split"])
+    want_reads, want_recs = {}, {}
+    for rank in range(world):
+        gids, seqs, names, alns, cig = _stage1_fake(rank, world)
+        for g, s_ in zip(gids, seqs):
+            want_reads[int(g)] = s_
+        for a in alns:
+            want_recs.setdefault(int(gids[a["qid"]]), []).append((int(a["tid"]), int(a["ts"]), int(a["flags"]), [int(x) for x in cig[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]]]))
+    emitted = {}
+    for r, o in enumerate(outs):
+        assert o["gid"] == sorted(o["gid"]) and o["names"] == ["read%d" % g for g in o["gid"]]
+        assert o["reads"] == [want_reads[g] for g in o["gid"]]
+        per = {}
+        last = -1
+        for g, tid, ts, fl, e, cg in o["recs"]:
+            assert g >= last; last = g                                  # query-major in job order
+            per.setdefault(g, []).append((tid, ts, fl, cg))
+            if e:
+                key = (tid << 32) | ts
+                assert (r == 0 or key >= o["split"][r - 1]) and (r == world - 1 or key < o["split"][r])      # inside this rank's slice
+                emitted.setdefault(g, []).append((tid, ts, fl, cg))
+        for g, lst in per.items():
+            assert lst == want_recs[g]                                  # every record of the read, in the engine's order
+        for g in o["gid"]:                                             # a read is here because a record of it is, or (last rank) it has none
+            assert g in per or (r == world - 1 and g not in want_recs)
+    assert {g: sorted(v) for g, v in emitted.items()} == {g: sorted(v) for g, v in want_recs.items()}      # every record emitted exactly once
+    assert sorted(set(g for o in outs for g in o["gid"]) ) == sorted(want_reads)                            # no read lost (unmapped ones included)
+
+
 def test_bench_launcher_starts_n_ranks():
     """`python bench.py --gpus 2` without RANK in the environment starts two ranks itself (torch.distributed.run as a child of
     a process that has not touched the GPU) and relays rank 0's line -- here with the gloo backend and no GPU work"""
@@ -255,90 +343,3 @@ def test_locus_names_with_underscores():
     assert locus_pipeline.locus_of_report({"ID": "chrUn_CP007071v1_100_101_4000_4900"}) == "chrUn_CP007071v1_100_101"
     assert locus_pipeline.locus_of_report({"ID": "chr2L_33000_33020_12_4711"}) == "chr2L_33000_33020"
     assert locus_pipeline.locus_cost({"contig": "ACGT" * 5, "alt": "AC", "read_bases": 100}) == 122
-
-
-def _stage1_piece(rank, world):
-    """what rank `rank` mapped: records with LOCAL query ids and CIGAR offsets, its reads and their names (rank 1 of 3 holds nothing)"""
-    from telr_amd._abi import ALN_DTYPE
-    rng = np.random.default_rng(50 + rank)
-    n_reads = 0 if (world == 3 and rank == 1) else 4 + rank
-    ln = rng.integers(5, 40, size=n_reads).astype(np.int32)
-    buf = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(ln.sum())) if n_reads else np.zeros(0, np.uint8)
-    off = np.cumsum(ln.astype(np.int64)) - ln
-    names = ["r%d_%d" % (rank, i) for i in range(n_reads)]
-    recs, cig = [], []
-    for q in range(n_reads):
-        for _ in range(int(rng.integers(0, 3))):
-            a = np.zeros(1, ALN_DTYPE)
-            a["qid"] = q; a["tid"] = 0; a["qlen"] = ln[q]; a["ts"] = int(rng.integers(0, 1000)); a["flags"] = 1
-            ops = [int(rng.integers(1, 9)) << 4 | int(rng.integers(0, 3)) for _ in range(int(rng.integers(1, 5)))]
-            a["cigar_off"] = len(cig); a["n_cigar"] = len(ops); cig += ops
-            recs.append(a)
-    alns = np.concatenate(recs) if recs else np.zeros(0, ALN_DTYPE)
-    return alns, np.array(cig, np.uint32), (buf, off, ln), names
-
-
-def _gather_worker(rank, world, port, out_path):
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    from telr_amd import shard
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    alns, cig, reads, names = _stage1_piece(rank, world)
-    got = shard.gather_stage1(alns, cig, reads, names, dist=dist)
-    # the same with file-order numbers: read q of rank r is read q * world + r of the job
-    got2 = shard.gather_stage1(alns, cig, reads, names, dist=dist, read_gid=np.arange(len(names), dtype=np.int64) * world + rank)
-    if rank == 0:
-        a, c, (buf, off, ln), nm = got
-        a2, c2, (buf2, off2, ln2), nm2 = got2
-        np.savez(out_path, alns=a, cig=c, buf=buf, off=off, ln=ln, names=np.array(nm), alns2=a2, cig2=c2, buf2=buf2, off2=off2, ln2=ln2, names2=np.array(nm2))
-    else:
-        assert got is None and got2 is None
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_stage1_rebases_query_ids_and_cigar_offsets(tmp_path, world):
-    """the job's records on rank 0 = the ranks' records in rank order, query ids and CIGAR offsets re-based, reads and names
-    concatenated (world 3: the middle rank holds no reads at all)"""
-    import torch.multiprocessing as mp
-    out = str(tmp_path / "g.npz")
-    mp.spawn(_gather_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    z = np.load(out)
-    q0 = 0; c0 = 0; k0 = 0; b0 = 0
-    for r in range(world):
-        alns, cig, (buf, off, ln), names = _stage1_piece(r, world)
-        n = len(alns)
-        got = z["alns"][k0:k0 + n]
-        np.testing.assert_array_equal(got["qid"], alns["qid"] + q0)
-        np.testing.assert_array_equal(got["cigar_off"], alns["cigar_off"] + c0)
-        for f in ("ts", "n_cigar", "qlen", "flags"):
-            np.testing.assert_array_equal(got[f], alns[f])
-        np.testing.assert_array_equal(z["cig"][c0:c0 + len(cig)], cig)
-        np.testing.assert_array_equal(z["ln"][q0:q0 + len(ln)], ln)
-        np.testing.assert_array_equal(z["buf"][b0:b0 + len(buf)], buf)
-        assert list(z["names"][q0:q0 + len(ln)]) == names
-        q0 += len(ln); c0 += len(cig); k0 += n; b0 += len(buf)
-    assert k0 == len(z["alns"]) and q0 == len(z["ln"]) and (z["off"] == np.cumsum(z["ln"].astype(np.int64)) - z["ln"]).all()
-    # every record's CIGAR is where its offset says
-    for a in z["alns"]:
-        assert a["cigar_off"] + a["n_cigar"] <= len(z["cig"])
-    # with read_gid: reads in file order, the records of a read together and in the engine's order, CIGARs still where the offsets say
-    pieces = [_stage1_piece(r, world) for r in range(world)]
-    gids = sorted((q * world + r, r, q) for r in range(world) for q in range(len(pieces[r][3])))
-    assert list(z["names2"]) == [pieces[r][3][q] for _, r, q in gids]
-    np.testing.assert_array_equal(z["ln2"], [pieces[r][2][2][q] for _, r, q in gids])
-    # (the bases are not moved: the offsets are permuted with the lengths)
-    for k, (_, r, q) in enumerate(gids):
-        want = pieces[r][2][0][pieces[r][2][1][q]:pieces[r][2][1][q] + pieces[r][2][2][q]]
-        np.testing.assert_array_equal(z["buf2"][z["off2"][k]:z["off2"][k] + z["ln2"][k]], want)
-    k = 0
-    for new_q, (_, r, q) in enumerate(gids):
-        alns, cig = pieces[r][0], pieces[r][1]
-        for a in alns[alns["qid"] == q]:
-            g = z["alns2"][k]; k += 1
-            assert g["qid"] == new_q and g["ts"] == a["ts"] and g["n_cigar"] == a["n_cigar"]
-            np.testing.assert_array_equal(z["cig2"][g["cigar_off"]:g["cigar_off"] + g["n_cigar"]], cig[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]])
-    assert k == len(z["alns2"]) == len(z["alns"])

@@ -52,7 +52,10 @@ def test_two_ranks_merge_to_the_one_rank_locus_table():
             "--read-bases", "60000000", "--insertions", "30", "--no-cpu-baseline", "--no-stream-leg", "--bam-sha"]
     out = []
     for extra in (["--gpus", "1"], ["--gpus", "2", "--one-gpu", "--backend", "gloo"]):
-        p = subprocess.run(base + extra, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        env = dict(os.environ)
+        if "2" in extra:
+            env["TELR_KEEP_BAM"] = "1"                 # the job's file is validated below
+        p = subprocess.run(base + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         assert p.returncode == 0, p.stderr.decode()[-3000:]
         lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
         assert len(lines) == 1, lines[:5]
@@ -66,12 +69,26 @@ def test_two_ranks_merge_to_the_one_rank_locus_table():
     assert two["te_loci"]["rows_in_merged_table"] == one["te_loci"]["rows_in_merged_table"] > 0
     assert two["te_loci"]["merged_table_sha256"] == one["te_loci"]["merged_table_sha256"]
     assert two["te_loci"]["recovered_exact_chrom_family_strand_pos20"] == one["te_loci"]["recovered_exact_chrom_family_strand_pos20"] >= 25
-    # stage 1 hands Sniffles ONE sorted BAM: the job's BAM built on rank 0 from both ranks' records is, byte for byte, the file one rank writes alone
+    # stage 1 hands Sniffles ONE sorted BAM: both ranks write their coordinate slice of the one file (shard.write_job_bam); its INFLATED
+    # stream is, byte for byte, the stream of the file one rank writes alone (the BGZF block boundaries differ: two coders)
     jb = two["stage1_to_sorted_bam"]["job_bam"]
     assert "error" not in jb, jb
     assert one["stage1_to_sorted_bam"]["job_bam"] is None
-    assert jb["bam_sha256"] == one["stage1_to_sorted_bam"]["bam_sha256"] and jb["bam_bytes"] == one["stage1_to_sorted_bam"]["bam_bytes"]
+    assert jb["inflated_sha256"] == one["stage1_to_sorted_bam"]["inflated_sha256"] is not None
     assert jb["reads"] == one["config"]["reads_this_rank"] > two["config"]["reads_this_rank"] and jb["records"] > 0
+    ph = jb["phase_s_per_rank"]
+    assert len(ph) == 2 and all(k in ph[r] for r in (0, 1) for k in ("partition_s", "collective_s", "code_slice_s", "write_slice_s", "index_s", "slice_bytes"))
+    assert ph[0]["slice_bytes"] > 0 and ph[1]["slice_bytes"] > 0 and ph[0]["slice_bytes"] + ph[1]["slice_bytes"] + 28 == jb["bam_bytes"]
+    assert ph[0]["slice_unmapped_reads"] == 0                                 # reads without a record belong to the last slice
+    # the merged index: every chunk and every linear-index entry of the .bai points at a record start of the two-coder file
+    v = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "validate_bam.py"), jb["path"], str(jb["records"] + ph[1]["slice_unmapped_reads"])],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    for f in (jb["path"], jb["path"] + ".bai"):
+        if os.path.exists(f):
+            os.unlink(f)
+    assert v.returncode == 0, v.stderr.decode()[-2000:]
+    vj = json.loads(v.stdout.decode().strip().splitlines()[-1])
+    assert vj["records"] == jb["records"] + ph[1]["slice_unmapped_reads"] and vj["bai_chunks"] > 0 and vj["bai_linear_entries"] > 0
 
 
 @pytest.mark.gpu
@@ -94,4 +111,4 @@ def test_collectives_of_the_n_rank_path_run_through_rccl_on_device_tensors():
     assert forced["te_loci"]["merged_table_sha256"] == plain["te_loci"]["merged_table_sha256"]
     jb = forced["stage1_to_sorted_bam"]["job_bam"]
     assert "error" not in jb and "nccl" in jb["what"], jb
-    assert jb["bam_sha256"] == plain["stage1_to_sorted_bam"]["bam_sha256"] == forced["stage1_to_sorted_bam"]["bam_sha256"]
+    assert jb["inflated_sha256"] == plain["stage1_to_sorted_bam"]["inflated_sha256"] == forced["stage1_to_sorted_bam"]["inflated_sha256"] is not None

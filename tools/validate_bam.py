@@ -44,11 +44,18 @@ try:
     bai = open(path + ".bai", "rb").read()
     assert bai[:4] == b"BAI\x01" and struct.unpack_from("<i", bai, 4)[0] == n_ref
     import bisect
-    b = 8; n_lin = 0
+    b = 8; n_lin = 0; n_chunks = 0
     for _ in range(n_ref):
         n_bin = struct.unpack_from("<i", bai, b)[0]; b += 4
         for _ in range(n_bin):
-            _, nch = struct.unpack_from("<Ii", bai, b); b += 8 + 16 * nch
+            bin_id, nch = struct.unpack_from("<Ii", bai, b)
+            if bin_id != 37450:                      # every chunk of a real bin begins at a record start (the pseudo-bin holds offsets and counts)
+                for c in range(nch):
+                    v = struct.unpack_from("<Q", bai, b + 8 + 16 * c)[0]
+                    k = bisect.bisect_right(blk_off, v >> 16) - 1
+                    assert blk_off[k] == v >> 16 and (u_off[k] + (v & 0xffff)) in rec_starts, "chunk does not begin at a record start"
+                n_chunks += nch
+            b += 8 + 16 * nch
         n_intv = struct.unpack_from("<i", bai, b)[0]; b += 4
         lin = struct.unpack_from("<%dQ" % n_intv, bai, b); b += 8 * n_intv
         prev = 0
@@ -58,7 +65,7 @@ try:
                 k = bisect.bisect_right(blk_off, v >> 16) - 1
                 assert blk_off[k] == v >> 16 and (u_off[k] + (v & 0xffff)) in rec_starts, "linear index entry is not a record start"
         n_lin += n_intv
-    out["bai_linear_entries"] = n_lin
+    out["bai_linear_entries"] = n_lin; out["bai_chunks"] = n_chunks
 except FileNotFoundError:
     out["bai_linear_entries"] = None
 if len(sys.argv) > 2:

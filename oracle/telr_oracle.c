@@ -59,6 +59,7 @@
 #define MFX_RMQ      0x8000
 #define MFX_ZSPLIT   0x10000
 #define MFX_MAPQ     0x20000
+#define MFX_CONVEX   0x80000      /* ngmlr-* presets: NGMLR's convex gap cost exactly (length-tracking cells, scores in 1/20 units) instead of the two-piece envelope */
 #define DP_DMAX    4096           /* widest band (diagonals) the DP accepts; wider -> diagonal fallback */
 #define DEPTH_CAP  8000           /* samtools depth default -d */
 
@@ -649,8 +650,30 @@ typedef struct { int score, bi, bj, touched; int64_t cells; } dp_res_t;
 /* ext=0: global alignment of (m,n), returns H(m,n), traceback from (m,n).
  * ext=1: extension from (0,0): best cell with z-drop, traceback from it.
  * The CIGAR is appended to rev_cig in REVERSE order of ops (end -> start). */
+/* (experiment 0x80000, below: the ngmlr-* presets' convex gap cost in exact form) */
+typedef struct convex_s { int S, a, b, amb, open, emax, emin, dec, flat; } convex_t;
+static int convex_of(const telr_map_opt *mo, convex_t *c)
+{
+    if (mo->a == 2 && mo->b == 5 && mo->q == 6 && mo->e == 4 && mo->q2 == 60 && mo->e2 == 1) {          /* ngmlr-pacbio */
+        c->S = 20; c->a = 40; c->b = 100; c->amb = 20 * mo->sc_ambi; c->open = 100; c->emax = 100; c->emin = 20; c->dec = 3; c->flat = 27; return 1;
+    }
+    if (mo->a == 2 && mo->b == 2 && mo->q == 2 && mo->e == 2 && mo->q2 == 4 && mo->e2 == 1) {           /* ngmlr-ont (the preset's units are already doubled) */
+        c->S = 10; c->a = 20; c->b = 20; c->amb = 10 * mo->sc_ambi; c->open = 20; c->emax = 20; c->emin = 10; c->dec = 3; c->flat = 4; return 1;
+    }
+    return 0;
+}
+static inline int cx_ext(const convex_t *c, int len) { int v = c->emax - c->dec * len; return v > c->emin ? v : c->emin; }
+static inline int64_t cx_cost(const convex_t *c, int L)       /* a whole gap of L bases */
+{
+    int64_t t = c->open;
+    for (int i = 0; i < L && i < c->flat; ++i) t += cx_ext(c, i);
+    if (L > c->flat) t += (int64_t)(L - c->flat) * c->emin;
+    return t;
+}
+static dp_res_t band_dp_convex(const dp_seq_t *s, int dlo, int dhi, int ext, const telr_map_opt *mo, const struct convex_s *C, u32v_t *rev_cig);
 static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr_map_opt *mo, u32v_t *rev_cig)
 {
+    if (mo->flags & MFX_CONVEX) { struct convex_s C; if (convex_of(mo, &C)) return band_dp_convex(s, dlo, dhi, ext, mo, &C, rev_cig); }
     const int m = s->m, n = s->n, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const int q1 = mo->q, e1 = mo->e, q2 = mo->q2, e2 = mo->e2;
     dp_res_t res = { 0, 0, 0, 0, 0 };
@@ -724,6 +747,87 @@ static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr
         else if (state == 2) { cig_push(rev_cig, 1, 1); if (!(t & 16)) state = 0; --i; }
         else if (state == 3) { cig_push(rev_cig, 2, 1); if (!(t & 32)) state = 0; --j; }
         else                 { cig_push(rev_cig, 1, 1); if (!(t & 64)) state = 0; --i; }
+    }
+    if (i > 0) cig_push(rev_cig, 1, i);
+    if (j > 0) cig_push(rev_cig, 2, j);
+#undef IX
+    free(H); free(tb);
+    return res;
+}
+
+/* ---- experiment 0x80000: NGMLR's convex gap cost, exactly (Sedlazeck 2018, Methods; ngmlr 0.2.7 defaults, envs/telr.yml:48) ----
+ * NGMLR charges a gap `open` once and every gap base an extension that DECAYS with the length the gap already has:
+ * ext(i) = max(ext_min, ext_max - decay * i) for the base that makes a gap of length i one longer; pacbio: match 2, mismatch 5,
+ * open 5, ext 5 -> 1, decay 0.15; ont: 1, 1, 1, 1 -> 0.5, 0.15.  NGMLR keeps the current gap length with every gap cell, so the
+ * recurrence is the affine one with a length-dependent extension -- restated here in integers by scaling every score with
+ * 20 (0.15 = 3/20): pacbio ext(i) = max(20, 100 - 3 i), ont ext(i) = max(10, 20 - 3 i).  The presets of the spec replace this
+ * by the lower envelope of two affine pieces (exact at L = 1 and from L = 27 / 5 on); this variant measures what
+ * that costs (tests/test_faithful_gate.py, tools/faithful_table.py).  Cells: H, E (gap in the query: target base consumed),
+ * F, and the lengths LE, LF of the gaps E / F end with; ties as in band_dp (diagonal > E > F; "opened" before "extended"). */
+static dp_res_t band_dp_convex(const dp_seq_t *s, int dlo, int dhi, int ext, const telr_map_opt *mo, const convex_t *C, u32v_t *rev_cig)
+{
+    const int m = s->m, n = s->n, D = dhi - dlo + 1, stride = (D + 2) / 2;
+    dp_res_t res = { 0, 0, 0, 0, 0 };
+    const int NEGX = -(1 << 29);
+    int32_t *H = (int32_t*)malloc(4 * (size_t)(D + 2) * 5), *E = H + (D + 2), *F = E + (D + 2), *LE = F + (D + 2), *LF = LE + (D + 2);
+    for (int x = 0; x < (D + 2) * 3; ++x) H[x] = NEGX;
+    for (int x = 0; x < (D + 2) * 2; ++x) LE[x] = 0;
+    uint8_t *tb = (uint8_t*)calloc((size_t)(m + n + 1) * stride, 1);
+#define IX(d) ((d) - dlo + 1)
+    int best = 0, bi = 0, bj = 0, prev_cur = NEGX;
+    if (0 >= dlo && 0 <= dhi) H[IX(0)] = 0;
+    for (int a = 1; a <= m + n; ++a) {
+        int d0 = -a > dlo ? -a : dlo; if (a - 2 * m > d0) d0 = a - 2 * m;
+        int d1 = a < dhi ? a : dhi;   if (2 * n - a < d1) d1 = 2 * n - a;
+        if (((d0 - a) & 1) != 0) ++d0;
+        int cur = NEGX, cur_d = 0;
+        for (int d = d0; d <= d1; d += 2) {
+            int i = (a - d) >> 1, j = (a + d) >> 1, x = IX(d);
+            int32_t h, ve, vf, le = 0, lf = 0; uint8_t t = 0;
+            if (i == 0) { ve = (int32_t)-cx_cost(C, j); le = j; vf = NEGX; h = ve; }
+            else if (j == 0) { vf = (int32_t)-cx_cost(C, i); lf = i; ve = NEGX; h = vf; }
+            else {
+                int32_t hl = H[x - 1], hu = H[x + 1], hd = H[x], o, g;
+                o = hl - C->open - cx_ext(C, 0); g = E[x - 1] - cx_ext(C, LE[x - 1]);
+                if (g > o) { ve = g; le = LE[x - 1] + 1; t |= 8; } else { ve = o; le = 1; }
+                o = hu - C->open - cx_ext(C, 0); g = F[x + 1] - cx_ext(C, LF[x + 1]);
+                if (g > o) { vf = g; lf = LF[x + 1] + 1; t |= 16; } else { vf = o; lf = 1; }
+                int qb = qbase(s, i - 1), tbv = tbase(s, j - 1);
+                int sc = (qb > 3 || tbv > 3) ? -C->amb : (qb == tbv ? C->a : -C->b);
+                h = hd + sc; int src = 0;
+                if (ve > h) h = ve, src = 1;
+                if (vf > h) h = vf, src = 2;
+                t |= (uint8_t)src;
+                tb[(size_t)a * stride + ((d - dlo) >> 1)] = t;
+                ++res.cells;
+            }
+            if (h < NEGX) h = NEGX;
+            if (ve < NEGX) ve = NEGX;
+            if (vf < NEGX) vf = NEGX;
+            if (le > C->flat) le = C->flat;          /* beyond it the extension is flat: the length need not grow */
+            if (lf > C->flat) lf = C->flat;
+            H[x] = h; E[x] = ve; F[x] = vf; LE[x] = le; LF[x] = lf;
+            if (h > cur) cur = h, cur_d = d;
+        }
+        if (ext) {
+            if (cur > best) best = cur, bi = (a - cur_d) >> 1, bj = (a + cur_d) >> 1;
+            int c2 = cur > prev_cur ? cur : prev_cur;
+            if (best - c2 > mo->zdrop * C->S) break;
+            prev_cur = cur;
+        }
+    }
+    int i, j;
+    if (ext) { res.score = best; i = bi; j = bj; }
+    else { res.score = H[IX(n - m)]; i = m; j = n; }
+    res.bi = i; res.bj = j;
+    int state = 0;
+    while (i > 0 && j > 0) {
+        uint8_t t = tb[(size_t)(i + j) * stride + ((j - i - dlo) >> 1)];
+        if (j - i - dlo <= mo->fill_margin || dhi - (j - i) <= mo->fill_margin) res.touched = 1;
+        if (state == 0) state = t & 7;
+        if (state == 0) { cig_push(rev_cig, 0, 1); --i; --j; }
+        else if (state == 1) { cig_push(rev_cig, 2, 1); if (!(t & 8))  state = 0; --j; }
+        else                 { cig_push(rev_cig, 1, 1); if (!(t & 16)) state = 0; --i; }
     }
     if (i > 0) cig_push(rev_cig, 1, i);
     if (j > 0) cig_push(rev_cig, 2, j);
@@ -952,6 +1056,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
      * the tuned presets against this mode is gated by tests/test_faithful_gate.py. */
     const int faithful = (mo->flags & (TELR_MF_FAITHFUL | 0x200)) != 0, faithful_ext = (mo->flags & (TELR_MF_FAITHFUL | 0x400)) != 0;
     const int ext_max = faithful_ext ? (1 << 30) : mo->ext_max, ext_band = faithful_ext ? mo->bw : mo->ext_band;
+    convex_t CX; const int cx = (mo->flags & MFX_CONVEX) && convex_of(mo, &CX);       /* experiment: segment scores come back in 1/S units */
     /* query accessor on the chain's strand */
     dp_seq_t s; s.q = q; s.t = t; s.qcomp = c->rev;
     /* breakpoints */
@@ -994,6 +1099,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         if (faithful) { if (lo < -s.m) lo = even_lo(-s.m); if (hi > s.n) hi = s.n; }      /* no wider than the matrix */
         const int longgap = mo->bw_long > mo->bw && (dl > mo->bw || -dl > mo->bw);
         dp_res_t r = longgap ? longgap_fill(&s, mo, &rc) : (!faithful && hi - lo + 1 > DP_DMAX) ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
+        if (cx && (longgap || (!faithful && hi - lo + 1 > DP_DMAX))) r.score *= CX.S;             /* (these two rare paths keep the envelope) */
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
         if (r.touched && !is_long && !faithful && !longgap) {            /* second pass with the wide band */
             int W2 = fill_band_wide(s.m, s.n, mo);
@@ -1055,6 +1161,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     }
     al->ts = rs; al->te = re;
     if (c->rev) { al->qs = qlen - qe; al->qe = qlen - qs; } else { al->qs = qs; al->qe = qe; }
+    if (cx) dp = dp >= 0 ? (dp + CX.S / 2) / CX.S : -((-dp + CX.S / 2) / CX.S);                    /* back to the preset's units */
     al->mlen = mlen; al->blen = blen; al->n_ambi = n_zdrop; al->dp_score = dp; (void)nambi;      /* n_ambi: 0 unless the 0x10000 experiment counts z-dropped fills */
     al->n_cigar = (int32_t)cig.n; al->cigar_off = cigars->n;
     for (int64_t z = 0; z < cig.n; ++z) vpush(uint32_t, *cigars, cig.a[z]);

@@ -27,10 +27,19 @@ N_SAMPLE = 300
 
 def _records(res):
     out = {}
-    for a in res["alns"]:
+    for k, a in enumerate(res["alns"]):
         if a["flags"] & 2:
             continue
         out.setdefault(int(a["qid"]), []).append(a)
+    return out
+
+
+def _cigar_digests(res):
+    """{(qid, tid, ts, te, qs, qe): hash of the record's CIGAR words} of the non-secondary records"""
+    out = {}
+    for a, h in zip(res["alns"], res.get("cigar_hash", [])):
+        if not a["flags"] & 2:
+            out[(int(a["qid"]), int(a["tid"]), int(a["ts"]), int(a["te"]), int(a["qs"]), int(a["qe"]))] = int(h)
     return out
 
 
@@ -39,11 +48,15 @@ def _map_threads(oix, reads, mo, T=8):
     from concurrent.futures import ThreadPoolExecutor
 
     def work(k):
-        al = oix.map(reads[k::T], mo)["alns"].copy()
+        r = oix.map(reads[k::T], mo)
+        al = r["alns"].copy()
         al["qid"] = al["qid"] * T + k
-        return al
+        cg = r["cigars"]
+        hs = np.array([hash(cg[a["cigar_off"]:a["cigar_off"] + a["n_cigar"]].tobytes()) for a in al], np.int64)
+        return al, hs
     with ThreadPoolExecutor(T) as ex:
-        return {"alns": np.concatenate(list(ex.map(work, range(T))))}
+        parts = list(ex.map(work, range(T)))
+    return {"alns": np.concatenate([p[0] for p in parts]), "cigar_hash": np.concatenate([p[1] for p in parts])}
 
 
 def drift(oix, reads, mo, parts=4, other=None, forgive_zdrop=False):
@@ -53,7 +66,10 @@ def drift(oix, reads, mo, parts=4, other=None, forgive_zdrop=False):
     mf = mo.copy(); mf.flags |= parts
     if other is not None:
         mf = other
-    a, b = _records(_map_threads(oix, reads, mo)), _records(_map_threads(oix, reads, mf))
+    ra_, rb_ = _map_threads(oix, reads, mo), _map_threads(oix, reads, mf)
+    a, b = _records(ra_), _records(rb_)
+    ca, cb = _cigar_digests(ra_), _cigar_digests(rb_)
+    cigar = sum(1 for k, v in ca.items() if k in cb and cb[k] != v)          # same read, same coordinates, another CIGAR
     n = coord = core = score = 0
     for q in sorted(set(a) | set(b)):
         ra, rb = a.get(q, []), b.get(q, [])
@@ -76,7 +92,7 @@ def drift(oix, reads, mo, parts=4, other=None, forgive_zdrop=False):
                 coord += 1
             if int(x["dp_score"]) != int(best["dp_score"]):
                 score += 1
-    return dict(n=n, coord=coord / max(1, n), core=core / max(1, n), score=score / max(1, n))
+    return dict(n=n, coord=coord / max(1, n), core=core / max(1, n), score=score / max(1, n), cigar=cigar / max(1, n))
 
 
 @pytest.mark.parametrize("name", ["map-ont", "map-pb", "ngmlr-ont", "ngmlr-pacbio"])
@@ -174,14 +190,14 @@ def workload(kind, n):
         io, mo = preset("asm10"); mo.best_n = 10
         return io, mo, [bytes(ref).decode()], reads
     if kind in ("clr-map-pb", "clr-ngmlr-pacbio"):
-        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=4000, total_bases=36_000_000, err=(0.013, 0.065, 0.052), read_seed=20261002 + 77)
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, err=(0.013, 0.065, 0.052), read_seed=20261002 + 77)
         io, mo = preset("map-pb" if kind == "clr-map-pb" else "ngmlr-pacbio")
     elif kind == "ont-ngmlr-ont":
-        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=4000, total_bases=36_000_000, read_seed=20261002 + 78)
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, read_seed=20261002 + 78)
         io, mo = preset("ngmlr-ont")
     elif kind == "c4-density":
         # the repeat density of configs[4]: a 1,300-family library, 45 % of the sequence TE-derived
-        d = synth.make_stage1_dataset(seed=20261002 + 4, genome_len=12_000_000, n_reads=3000, total_bases=27_000_000, n_ins=100, n_fam=1300, te_frac=0.45, gc=0.47, read_seed=20261002 + 79)
+        d = synth.make_stage1_dataset(seed=20261002 + 4, genome_len=12_000_000, n_reads=6000, total_bases=54_000_000, n_ins=100, n_fam=1300, te_frac=0.45, gc=0.47, read_seed=20261002 + 79)
         io, mo = preset("map-ont")
     else:
         raise ValueError(kind)
@@ -203,6 +219,10 @@ def bit_table(kind, n, bits=None):
         mf = mo.copy(); mf.flags |= b
         r = drift(oix, reads, mo, other=mf)
         rows.append((name, r))
+    if kind in ("clr-ngmlr-pacbio", "ont-ngmlr-ont") and bits is None:
+        # a13: NGMLR's convex gap cost in exact form (length-tracking cells, scores in 1/20 units) against the two-piece envelope of the spec
+        mf = mo.copy(); mf.flags |= 0x80000
+        rows.append((CONVEX, drift(oix, reads, mo, other=mf)))
     if mo.bw < 20000:
         mf = mo.copy(); mf.flags |= 0x4000 | 0x10000
         rows.append(("long join, not counting reads whose joined record z-drops in a fill (minimap2 splits it again)", drift(oix, reads, mo, other=mf, forgive_zdrop=True)))
@@ -221,6 +241,7 @@ def bit_table(kind, n, bits=None):
     return rows
 
 
+CONVEX = "NGMLR's convex gap cost exactly (extension 5 -> 1 / 1 -> 0.5, decay 0.15 per gap base) instead of the two-piece envelope"
 LONG_JOIN = ("long join (re-chain with bw_long 20,000)", "long join, not counting reads whose joined record z-drops in a fill (minimap2 splits it again)")
 
 

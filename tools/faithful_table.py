@@ -8,8 +8,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_faithful_gate as g
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-print("| workload | omission | records | records changed | coordinates changed | DP score changed |")
-print("|---|---|---|---|---|---|")
+print("| workload | omission | records | records changed | coordinates changed | DP score changed | CIGAR changed (same coordinates) |")
+print("|---|---|---|---|---|---|---|")
 for kind, k in (("flanks-asm10", 2 * n), ("clr-map-pb", n), ("clr-ngmlr-pacbio", n), ("ont-ngmlr-ont", n), ("c4-density", n)):
     for name, r in g.bit_table(kind, k):
-        print("| %s | %s | %d | %.2f %% | %.2f %% | %.2f %% |" % (kind, name, r["n"], 100 * r["core"], 100 * r["coord"], 100 * r["score"]), flush=True)
+        print("| %s | %s | %d | %.2f %% | %.2f %% | %.2f %% | %s |" % (kind, name, r["n"], 100 * r["core"], 100 * r["coord"], 100 * r["score"], ("%.2f %%" % (100 * r["cigar"])) if "cigar" in r else "-"), flush=True)

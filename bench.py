@@ -832,23 +832,42 @@ def main():
             st = pstats.Stats(prof, stream=sys.stderr); st.sort_stats("cumulative").print_stats(40); st.sort_stats("tottime").print_stats(25)
         if dist is not None:
             t = torch.tensor([t_loci], dtype=torch.float64, device=device if device is not None else "cpu"); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_loci = float(t[0])
-        good = 0; af_ok = 0; n_rows = len(rows)
         fam_of = {i: n for i, n in enumerate(lib_names)}
-        why = {"no row (no TE annotated on the contig)": n_loci - n_rows, "annotation merged with a neighbouring reference TE copy (several families)": 0,
-               "unlifted (flanks not placed next to each other)": 0, "other": 0}
-        for r in rows:
-            l = loci[int(r["locus_id"])]; tr = l["truth"]
-            if r["type"] == 1 and r["chrom_id"] == chrom_ids[tr["chrom"]] and abs(int(r["start"]) - tr["pos"]) <= 20 and \
-                    (1 if tr["strand"] == "+" else -1) == r["strand"] and r["n_family"] >= 1 and fam_of[int(r["family_id"][0])] == tr["family"]:
-                good += 1
-                if not np.isnan(r["af"]) and abs(float(r["af"]) - tr["af"]) <= 0.15:
-                    af_ok += 1
-            elif r["n_family"] > 1:
-                why["annotation merged with a neighbouring reference TE copy (several families)"] += 1
-            elif r["type"] == 0:
-                why["unlifted (flanks not placed next to each other)"] += 1
-            else:
-                why["other"] += 1
+
+        def tally(rows):
+            good = 0; af_ok = 0
+            why = {"no row (no TE annotated on the contig)": n_loci - len(rows), "annotation merged with a neighbouring reference TE copy (several families)": 0,
+                   "unlifted (flanks not placed next to each other)": 0, "other": 0}
+            for r in rows:
+                l = loci[int(r["locus_id"])]; tr = l["truth"]
+                if r["type"] == 1 and r["chrom_id"] == chrom_ids[tr["chrom"]] and abs(int(r["start"]) - tr["pos"]) <= 20 and \
+                        (1 if tr["strand"] == "+" else -1) == r["strand"] and r["n_family"] >= 1 and fam_of[int(r["family_id"][0])] == tr["family"]:
+                    good += 1
+                    if not np.isnan(r["af"]) and abs(float(r["af"]) - tr["af"]) <= 0.15:
+                        af_ok += 1
+                elif r["n_family"] > 1:
+                    why["annotation merged with a neighbouring reference TE copy (several families)"] += 1
+                elif r["type"] == 0:
+                    why["unlifted (flanks not placed next to each other)"] += 1
+                else:
+                    why["other"] += 1
+            return good, af_ok, why
+        n_rows = len(rows)
+        good, af_ok, why = tally(rows)
+        # The OTHER call set, in every line: the per-locus calls S4-S6 run minimap2's `-x map-ont|map-pb`, whose 2.22 defaults
+        # carry the long join (-r500,20000) -- [recall]-grade, there is no minimap2 here to settle it.  With the long join a library hit
+        # chains ACROSS an insertion nested in a reference TE copy and the reference's own merge / decision tree calls the locus
+        # "reference" (DESIGN 3.11); without it the hit breaks at the insertion.  Same loci, same reads, bw_long = 0 in every per-locus preset:
+        alt_set = None
+        try:
+            from telr_amd import presets as _presets
+            with _presets.override(bw_long=0):
+                rows0, _ = loci_pass()
+            g0, a0, w0 = tally(rows0)
+            alt_set = {"recovered_exact_chrom_family_strand_pos20": g0, "of_those_af_within_0.15": a0, "rows_in_merged_table": len(rows0), "not_recovered": w0,
+                       "what": "the same pass with bw_long = 0 in the map-ont / map-pb presets of S4-S6 (the round-2 records: a library hit ends at a nested insertion)"}
+        except Exception as e:
+            alt_set = {"error": "%s: %s" % (type(e).__name__, e)}
         # the polishing hand-off (H3) with the consensus made on the device (telr_consensus_build: pile-up majority vote, NOT
         # wtpoa-cns's POA -- an extra behind a flag of the pipeline, timed here once, outside the loci/s figure)
         polish = None
@@ -872,6 +891,7 @@ def main():
                                        int(r["gap"]), int(r["tsd_len"]), [int(x) for x in r["family_id"]], [None if np.isnan(x) else float(x) for x in r["medians"]],
                                        None if np.isnan(r["af"]) else float(r["af"])) for r in rs]).encode()).hexdigest()
         loci_out = {"n": n_loci, "seconds": t_loci, "seconds_of_each_pass": t_passes, "rows_in_merged_table": n_rows, "merged_table_sha256": digest, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
+                    "recovered_with_bw_long_0_at_S4_S6": alt_set,
                     "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0, "polish_pileup": polish,
                     "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads as packed device words (counts + ONE int32 payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,
                     # where the last pass went on THIS rank (seconds): selecting + exchanging the window reads (pack_s = gather kernel and

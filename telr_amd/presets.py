@@ -14,6 +14,24 @@ def _gap_q8(k, scale=0.8):
     return int(0.01 * scale * k * 256 + 0.5)
 
 
+_OVERRIDES = {}          # field -> value laid over every preset while `override(...)` is active (experiments, A/B legs of bench.py)
+
+
+class override:
+    """`with presets.override(bw_long=0): ...` -- every preset() call inside (any thread) gets these map-option fields on top of
+    the table's.  For experiments only: e.g. bench.py reports the per-locus call set with and without the long join at S4-S6."""
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.saved = dict(_OVERRIDES); _OVERRIDES.update(self.fields)
+        return self
+
+    def __exit__(self, *exc):
+        _OVERRIDES.clear(); _OVERRIDES.update(self.saved)
+        return False
+
+
 def preset(name):
     io = IdxOpt(k=15, w=10, is_hpc=0, bucket_bits=0)
     mo = MapOpt(
@@ -53,4 +71,6 @@ def preset(name):
     else:
         raise ValueError("unknown preset %r" % (name,))
     mo.chain_gap_q8 = _gap_q8(io.k)
+    for f, v in _OVERRIDES.items():
+        setattr(mo, f, v)
     return io, mo

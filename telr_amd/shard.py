@@ -378,6 +378,13 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
     kw = dict(md=True, cs=True, softclip=True, cmdline="telr_map"); kw.update(writer_kw or {})
     t0 = time.time()
     alns = np.ascontiguousarray(alns)
+    # room for the wire buffers (torch allocates them next to the engine): CIGAR words and packed reads exist up to ~6 times on
+    # their way (source, gathered, payload, received, re-ordered, the writer's copies); the context's grow-only mapping scratch
+    # (150+ GB after a 30x stage 1) goes back first when the device is that full -- the next telr_map sizes it again
+    payload = 4 * len(cigars) + int(np.asarray(lengths, np.int64).sum()) * 3 // 8 + alns.nbytes
+    fr, _tot = eng.mem_info()
+    if fr < 8 * payload + (2 << 30):
+        eng.release_scratch()
     keys = alns["tid"].astype(np.int64) << 32 | alns["ts"].astype(np.int64)
     split = stage1_splitters(keys, world, dist, wire)
     dest = np.searchsorted(split, keys, side="right")
@@ -395,6 +402,9 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
     t0 = time.time()
     jq = SeqSet.from_packed(eng, got["lengths"], got["seq2"], got["nmask"])
     jr = ix.result_from_device_cigars(got["alns"], got["cig"])
+    got["seq2"] = got["nmask"] = got["cig"] = None          # the library holds its own copies now: torch's cache goes back to the device for the writer
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
     seg = ix.write_bam_slice(jr, jq, ix._cstr_array(got["names"]), tnames, got["emit"], with_header=rank == 0, unmapped=rank == world - 1, level=level, **kw)
     info = ix.segment_info(seg)
     tm["code_slice_s"] = time.time() - t0

@@ -316,6 +316,8 @@ def job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_
         res = ix.result_arrays(r)
         t_map = time.time() - t0
         err = None
+        if a.one_gpu:                  # the smoke mode puts every rank on ONE device: N grow-only mapping scratches next to the wire buffers do not fit
+            eng.release_scratch()
         try:
             ph = shard.write_job_bam(path, ix, eng, res.alns, res.cigars, qs, D["reads"][2], names, D["read_gid"], D["names"], [len(x) for x in D["ref"]], dist, device,
                                      level=max(1, a.bam_level), writer_kw=dict(cmdline="bench"))

@@ -622,11 +622,13 @@ struct SeedArgs {
     // staged input (tile_off non-null): mz_x / mz_y are the sketch kernel's per-tile staging arrays (tile t at t * SK_TILE,
     // tile_off[t+1] - tile_off[t] entries), read in place instead of being compacted first; q_tile0[q] = first tile of query q
     const int32_t *tile_off, *q_tile0;
+    // MODE 1 inside the LDS sort (segsort.hip.h: SeedProducer): the keys of the query go to lds_keys[w - lds_base] instead of keys[w]
+    uint64_t *lds_keys; int32_t lds_base;
 };
 
 __device__ __forceinline__ void d_put_key(const SeedArgs &A, int64_t w, uint64_t key)
 {
-    A.keys[w] = key;
+    if (A.lds_keys) A.lds_keys[w - A.lds_base] = key; else A.keys[w] = key;
 }
 // target holding global position g (goff ascending, goff[n] = end)
 __device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n, uint32_t g)
@@ -640,10 +642,10 @@ __device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n
 // aligner against every contig (TELR_te.py:68-78,119-132,504-506; TELR_assembly.py:199-212): a minimizer's occurrences are
 // counted inside the target and compared with THAT target's cut-off (tmid), so a TE k-mer shared by hundreds of contigs
 // is not masked as repetitive.
+// the minimizers of query q, taken in turn by `nthr` threads (this one is `tid`)
 template <int MODE>
-__global__ void __launch_bounds__(256) k_seed(SeedArgs A)
+__device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, const int tid, const int nthr)
 {
-    const int q = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
     const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
     const int tf = A.qtarget ? A.qtarget[q] : -1;
     const bool pt = tf < 0 && A.per_target && A.tmid;
@@ -654,7 +656,7 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
     // staged input: minimizer g of the query lives in tile t at slot g - tile_off[t]; g only grows, so t is advanced, not searched
     int t = A.tile_off ? A.q_tile0[q] : 0, t_lo = 0, t_hi = 0;
     if (A.tile_off) { t_lo = A.tile_off[t]; t_hi = A.tile_off[t + 1]; }
-    for (int g = m0 + threadIdx.x; g < m1; g += blockDim.x) {
+    for (int g = m0 + tid; g < m1; g += nthr) {
         int64_t gi = g;
         if (A.tile_off) {
             while (g >= t_hi) { ++t; t_lo = t_hi; t_hi = A.tile_off[t + 1]; }
@@ -722,6 +724,11 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
     }
 }
 #undef SEED_POS
+template <int MODE>
+__global__ void __launch_bounds__(256) k_seed(SeedArgs A)
+{
+    d_seed_query<MODE>(A, A.q_order ? A.q_order[blockIdx.x] : blockIdx.x, threadIdx.x, blockDim.x);
+}
 
 // ---- seeding with sub-read voting (spec 3.10: NGMLR's candidate search) ------------------------------------------------
 // All-vs-all calls with mo.vote_len > 0, plain (compacted) minimizer arrays.

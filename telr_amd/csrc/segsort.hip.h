@@ -86,8 +86,31 @@ template <int N> __device__ __forceinline__ void d_regsort(uint64_t (&k)[N])
     }
 }
 
-template <int T, int E>
-__global__ void __launch_bounds__(T) k_segsort(SegSortArgs A, int tier)
+// where a segment's keys come from: copied from an array (coalesced) ...
+struct LoadKeys {
+    __device__ __forceinline__ void fill(const SegSortArgs &A, int s, uint64_t *lds, int n, int npad, int tid, int nthr) const
+    {
+        const uint64_t *src = A.in + (A.src_beg ? A.src_beg[s] : (int64_t)A.seg_beg[s]);
+        for (int i = tid; i < npad; i += nthr) lds[i] = i < n ? src[i] : SEGSORT_PAD;
+    }
+};
+// ... or made on the spot: the anchor keys of query s written straight into LDS by the seeding routine (kernels.hip.h:
+// d_seed_query<1>), so that unsorted keys never exist in HBM (8 B written + 8 B read per anchor less, and the gather latency of
+// the occurrence lists hides behind the other workgroups' sorting)
+#ifdef TELR_HAVE_SEED_ARGS
+struct SeedProducer {
+    SeedArgs S;
+    __device__ __forceinline__ void fill(const SegSortArgs &A, int s, uint64_t *lds, int n, int npad, int tid, int nthr) const
+    {
+        SeedArgs B = S; B.lds_keys = lds; B.lds_base = A.seg_beg[s];
+        for (int i = n + tid; i < npad; i += nthr) lds[i] = SEGSORT_PAD;
+        d_seed_query<1>(B, s, tid, nthr);
+    }
+};
+#endif
+
+template <int T, int E, class P>
+__global__ void __launch_bounds__(T) k_segsort(SegSortArgs A, int tier, P prod)
 {
     extern __shared__ uint64_t seg_lds[];
     const int tid = threadIdx.x;
@@ -97,15 +120,10 @@ __global__ void __launch_bounds__(T) k_segsort(SegSortArgs A, int tier)
         const int s = list[it];
         const int32_t d0 = A.seg_beg[s];
         const int n = A.seg_end[s] - d0;
-        const uint64_t *src = A.in + (A.src_beg ? A.src_beg[s] : (int64_t)d0);
         uint64_t *dst = A.out + d0;
-        // coalesced load, pads behind the segment
+        // the keys into LDS, pads behind the segment
         const int npad = ((n + E - 1) / E) * E;        // the threads that own a real key own E slots
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = tid + e * T;
-            if (i < npad) seg_lds[i] = i < n ? src[i] : SEGSORT_PAD;
-        }
+        prod.fill(A, s, seg_lds, n, npad, tid, T);
         __syncthreads();
         uint64_t k[E];
         const bool live = tid * E < n;                // this thread owns at least one real key

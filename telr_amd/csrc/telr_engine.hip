@@ -27,6 +27,7 @@
 #include <vector>
 #include "../../include/telr_hip.h"
 #include "kernels.hip.h"
+#define TELR_HAVE_SEED_ARGS 1
 #include "segsort.hip.h"
 
 // ---------------------------------------------------------------------------------------
@@ -139,8 +140,9 @@ template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size
 // LDS; `any_over` (known to the caller from the anchor counts) sends the larger ones through rocPRIM afterwards.
 // TELR_SORT64=1 keeps the library sort for every segment (A/B).  out[beg[s] .. end[s]) <- sorted in[...]; src_beg (nullable)
 // gives the segments' places in `in` when they differ from their places in `out`.
+template <class P = LoadKeys>
 static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint64_t *out, const int32_t *beg, const int32_t *end, const int64_t *src_beg,
-                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st)
+                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st, P prod = P())
 {
     static const bool lib_sort = getenv("TELR_SORT64") != nullptr;
     if (nseg <= 0 || nkeys == 0) return TELR_OK;
@@ -154,10 +156,10 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
         return TELR_OK;
     }
     if (src_beg && any_over) return TELR_E_ARG;
-    static bool attr_set = false;
+    static bool attr_set = false;            // (one flag per producer type: a function-local static of the template instance)
     if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 8 * 8));
-        HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 20 * 8));
+        HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 8, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 8 * 8));
+        HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 20, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 20 * 8));
         attr_set = true;
     }
     SegSortArgs A; A.in = in; A.out = out; A.seg_beg = beg; A.seg_end = end; A.src_beg = src_beg; A.order = order; A.nseg = nseg;
@@ -171,13 +173,13 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
     const int ncu = 256;
     auto grid = [&](int resident) { return dim3((unsigned)std::min<int64_t>(nseg, (int64_t)ncu * resident * 8)); };
     // largest tiers first: their few long-running workgroups start while the device is otherwise idle
-    hipLaunchKernelGGL((k_segsort<1024, 20>), grid(1), dim3(1024), 1024 * 20 * 8, st, A, 6);
-    hipLaunchKernelGGL((k_segsort<1024, 8>), grid(2), dim3(1024), 1024 * 8 * 8, st, A, 5);
-    hipLaunchKernelGGL((k_segsort<512, 8>), grid(4), dim3(512), 512 * 8 * 8, st, A, 4);
-    hipLaunchKernelGGL((k_segsort<256, 8>), grid(8), dim3(256), 256 * 8 * 8, st, A, 3);
-    hipLaunchKernelGGL((k_segsort<128, 8>), grid(16), dim3(128), 128 * 8 * 8, st, A, 2);
-    hipLaunchKernelGGL((k_segsort<64, 8>), grid(32), dim3(64), 64 * 8 * 8, st, A, 1);
-    hipLaunchKernelGGL((k_segsort<64, 2>), grid(32), dim3(64), 64 * 2 * 8, st, A, 0);
+    hipLaunchKernelGGL((k_segsort<1024, 20, P>), grid(1), dim3(1024), 1024 * 20 * 8, st, A, 6, prod);
+    hipLaunchKernelGGL((k_segsort<1024, 8, P>), grid(2), dim3(1024), 1024 * 8 * 8, st, A, 5, prod);
+    hipLaunchKernelGGL((k_segsort<512, 8, P>), grid(4), dim3(512), 512 * 8 * 8, st, A, 4, prod);
+    hipLaunchKernelGGL((k_segsort<256, 8, P>), grid(8), dim3(256), 256 * 8 * 8, st, A, 3, prod);
+    hipLaunchKernelGGL((k_segsort<128, 8, P>), grid(16), dim3(128), 128 * 8 * 8, st, A, 2, prod);
+    hipLaunchKernelGGL((k_segsort<64, 8, P>), grid(32), dim3(64), 64 * 8 * 8, st, A, 1, prod);
+    hipLaunchKernelGGL((k_segsort<64, 2, P>), grid(32), dim3(64), 64 * 2 * 8, st, A, 0, prod);
     HIPCHK(hipGetLastError());
     if (any_over) {
         size_t tb = 0;
@@ -1655,20 +1657,28 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     static const bool lib_sort = getenv("TELR_SORT64") != nullptr;      // A/B: rocPRIM's segmented radix sort for every query
     const bool any_over = n_over > 0;
     uint64_t *d_keys, *d_skeys;
-    TRY(ctx_buf_t(ctx, "keys", (vote && !lib_sort && !any_over) ? (size_t)1 : (size_t)na, &d_keys));
+    static const bool seed_unfused_env = getenv("TELR_SEED_UNFUSED") != nullptr;
+    TRY(ctx_buf_t(ctx, "keys", (!lib_sort && !any_over && (vote || !seed_unfused_env)) ? (size_t)1 : (size_t)na, &d_keys));       // only the two-step forms need the unsorted keys in memory
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
     S.mz_aoff = d_maoff; S.keys = d_keys;
     // sub-read voting: the LDS sort reads the survivors from the staging pieces in place; only the library sort needs them dense
     const bool vote_in_place = vote && !lib_sort && !any_over;
+    // The anchor keys are MADE inside the sort (SeedProducer: the seeding routine writes a query's keys straight into the sorting
+    // workgroup's LDS), so unsorted keys never exist in HBM; TELR_SEED_UNFUSED=1 keeps the two-step form for A/B, and a range with a
+    // query above the LDS limit takes it too (its library sort reads the keys from memory)
+    static const bool seed_unfused = getenv("TELR_SEED_UNFUSED") != nullptr;
+    const bool seed_fused = !vote && !lib_sort && !any_over && !seed_unfused;
+    S.lds_keys = nullptr; S.lds_base = 0;
     if (vote) { if (!vote_in_place) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, d_keys); }
-    else hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
+    else if (!seed_fused) hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
     t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
 
     // ---- per-query sort of the anchor keys --------------------------------------------------
     StageTimer t_so(ctx, ST_SORT, true);
-    if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st));
+    if (na > 0 && seed_fused) { SeedProducer sp; sp.S = S; TRY((seg_sort_u64<SeedProducer>(ctx, "so_a", nullptr, d_skeys, d_qaoff, d_qaoff + 1, nullptr, d_qorder, nq, (size_t)na, false, st, sp))); }
+    else if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st));
     t_so.stop();
 
     // ---- chaining ---------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """Every build-time alternative the engine still carries behind an environment switch (A/B paths of earlier rounds: the
-walker back-tracking, host-side chain selection, the byte-wide trace-back spill, the 64-bit anchor sort, compacted
+walker back-tracking, host-side chain selection, the byte-wide trace-back spill, the library's anchor sort, seeding and sorting as two kernels, compacted
 minimizers, untagged two-piece cells, the 64-bit sketch, the int32 wide classes, serial class launches, chunked packed
 launches, trace-back lane limits, synchronous result DMA, the table filter in the vote presets' lookups, which queries vote with 16-bit counters) must produce the SAME bits as the default path: each switch runs
 the randomised HIP-vs-oracle parity (tests/fuzz_parity.py: every stage compared) in a process of its own, because the
@@ -17,7 +17,7 @@ SWITCHES = [
     {"TELR_BT_WALKER": "1"}, {"TELR_HOST_SELECT": "1"}, {"TELR_TB8": "1"}, {"TELR_SORT64": "1"}, {"TELR_MZ_COMPACT": "1"},
     {"TELR_NO_TAG8": "1"}, {"TELR_SKETCH64": "1"}, {"TELR_NO_PKW": "1"}, {"TELR_SERIAL": "1"}, {"TELR_PK_CHUNKS": "3"},
     {"TELR_TB_SPLIT": "0"}, {"TELR_TBW_MAX": "0"}, {"TELR_SYNC_RESULT": "1"}, {"TELR_NO_AVX2": "1"}, {"TELR_PACK_THREADS": "1"},
-    {"TELR_TRACE_HOST": "1"}, {"TELR_VOTE_FILTER": "1"}, {"TELR_VOTE_T16_LIMIT": "0"}, {"TELR_VOTE_T16_LIMIT": "400"},
+    {"TELR_TRACE_HOST": "1"}, {"TELR_SEED_UNFUSED": "1"}, {"TELR_VOTE_FILTER": "1"}, {"TELR_VOTE_T16_LIMIT": "0"}, {"TELR_VOTE_T16_LIMIT": "400"},
 ]
 
 

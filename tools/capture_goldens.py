@@ -712,6 +712,136 @@ def capture_repeatmask(T):
         shutil.rmtree(d)
 
 
+# ---------------------------------------------------------------------------------------
+def nested_locus():
+    """ONE nested insertion, built from seeds: the reference carries a copy of family famA between two unique flanks; the
+    assembled contig carries famB inserted INSIDE that copy (TSD of 6 bases).  -> ref, contig, ALT sequence, library"""
+    fl, fr = rnd_seq(3000, 101), rnd_seq(3000, 102)
+    fam_a, fam_b = rnd_seq(2400, 103), rnd_seq(1500, 104)
+    ref = rnd_seq(20000, 105) + fl + fam_a + fr + rnd_seq(20000, 106)
+    cut = 1100
+    tsd = fam_a[cut - 6:cut]
+    contig = fl + fam_a[:cut] + fam_b + tsd + fam_a[cut:] + fr
+    alt = fam_b + tsd                                 # Sniffles' ALT of an insertion: the inserted bases (breakpoint to breakpoint)
+    pos = 20000 + len(fl) + cut                      # where famB sits on the reference
+    return ref, contig, alt, ["famA", "famB"], [fam_a, fam_b], pos
+
+
+class FakeAnnot(FakeSubprocess):
+    """the tool calls of TELR_te.annotate_contig (minimap2_family=True): samtools faidx, the two minimap2 runs (canned PAF made by
+    the CPU oracle from the same sequences), bedtools intersect -wao / sort / merge -d / getfasta (telr_amd.intervals)"""
+    def __init__(self, seqs, s4_paf, s5_paf):
+        FakeSubprocess.__init__(self, seqs, {})
+        self.s4, self.s5 = s4_paf, s5_paf
+
+    def check_output(self, cmd, **kw):                    # TELR_utility.get_cmd_output: the S4 run
+        assert os.path.basename(cmd[0]) == "minimap2" and "--secondary=no" in cmd
+        return "".join(l + "\n" for l in self.s4).encode()
+
+    def call(self, cmd, stdout=None, shell=False, **kw):
+        c = cmd.replace('"', "").split() if shell else list(cmd)
+        tool = os.path.basename(c[0])
+        if tool == "minimap2":                             # the S5 run: the library against one contig
+            stdout.write("".join(l + "\n" for l in self.s5)); return 0
+        if tool == "bedtools" and c[1] == "intersect":
+            a = self._rows(c[c.index("-a") + 1]); b = self._rows(c[c.index("-b") + 1])
+            stdout.write("".join("\t".join(r) + "\n" for r in iv.intersect_wao(a, b))); return 0
+        if tool == "bedtools" and c[1] == "merge" and "-d" in c:
+            rows = self._rows(c[c.index("-i") + 1])
+            cols = [int(x) - 1 for x in c[c.index("-c") + 1].split(",")]
+            stdout.write("".join("\t".join(r) + "\n" for r in iv.merge_distinct(rows, int(c[c.index("-d") + 1]), cols, c[c.index("-delim") + 1]))); return 0
+        return FakeSubprocess.call(self, cmd, stdout=stdout, shell=shell, **kw)
+
+
+def capture_nested(T, L, U):
+    """The reference's OWN annotate_contig (merge -d 10000 of the library hits that overlap the ALT hit) and its OWN liftover
+    on one nested insertion, fed with the aligner output of the CPU oracle (= the engine's, bit for bit) for S4, S5 and S7 --
+    run once with the long join in the per-locus presets (bw_long 20000: minimap2 2.22's -r500,20000) and once without.  The
+    verdicts are the golden: what the REFERENCE's glue makes of each aligner behaviour."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_backend import OracleBackend
+    from telr_amd import presets as P, telr_te, telr_liftover
+    ref, contig, alt, lib_names, lib, pos = nested_locus()
+    name = "chr2L_%d_%d" % (pos, pos + 1)
+    be = OracleBackend()
+    out = {"ref_seeds": "tools/capture_goldens.py: nested_locus()", "locus": name, "truth_pos": pos, "cases": {}}
+    for label, bwl in (("long_join", 20000), ("no_long_join", 0)):
+        with P.override(bw_long=bwl):
+            ann, s4rows, s5rows = telr_te.annotate_contig(be, [name], [contig], [alt], lib_names, lib, "ont")
+        # PAF text of the two runs (the 12 columns the reference reads: names, lengths, intervals, strand, matches, block, mapq)
+        def paf_of(rows, qnames, qlens):
+            return [paf(q, ql, 0, ql, r[5], r[0], len(contig), int(r[1]), int(r[2]), int(r[2]) - int(r[1]), int(r[2]) - int(r[1]), int(r[4])) for r, q, ql in zip(rows, qnames, qlens)]
+        s4 = paf_of(s4rows, [name] * len(s4rows), [len(alt)] * len(s4rows))
+        s5 = paf_of(s5rows, [r[3] for r in s5rows], [len(lib[lib_names.index(r[3])]) for r in s5rows])
+        tmp = tempfile.mkdtemp(prefix="gold_")
+        try:
+            fa1, fa2, lib_fa = os.path.join(tmp, "contigs.fa"), os.path.join(tmp, "ref.fa"), os.path.join(tmp, "lib.fa")
+            write_fasta_with_fai(fa1, {name: contig}); write_fasta_with_fai(fa2, {"chr2L": ref}); write_fasta_with_fai(lib_fa, dict(zip(lib_names, lib)))
+            vcf = os.path.join(tmp, "vcf.tsv")
+            with open(vcf, "w") as f:
+                f.write("\t".join(["chr2L", str(pos), str(pos + 1), str(len(alt)), "20", "0.5", "1", alt, "r1,r2", "PASS", "0/1", "10", "10"]) + "\n")
+            odir = os.path.join(tmp, "out"); os.mkdir(odir)
+            fake = FakeAnnot({fa1: {name: contig}, fa2: {"chr2L": ref}}, s4, s5)
+            T.subprocess = fake; U.subprocess = fake
+            saved = sys.stdout; sys.stdout = io.StringIO()
+            try:
+                bed_path, _te_fa = T.annotate_contig(fa1, {name}, lib_fa, vcf, odir, "s", 1, "ont", True, os.path.join(tmp, "eval.tsv"))
+            finally:
+                sys.stdout = saved
+            with open(bed_path) as f:
+                ref_ann = [l.rstrip("\n").split("\t") for l in f if l.strip()]
+            # S7 for the reference's flanks of that annotation: the oracle maps them (asm10 -N 10), the reference's liftover decides
+            io10, mo10 = P.preset("asm10"); mo10.best_n = 10
+            rix = be.index([ref], io10)
+            pafs = {}
+            for r in ref_ann:
+                s_, e_ = int(r[1]), int(r[2])
+                prefix = "_".join([r[0], r[1], r[2]])
+                for side, (a0, a1) in (("5p", (s_ - 499, s_)), ("3p", (e_, e_ + 500))):
+                    if a0 < 0 or a1 > len(contig):
+                        continue
+                    q = contig[a0:a1]
+                    res = rix.map([q], mo10)
+                    pafs[(prefix, side)] = [paf("%s:%d-%d" % (r[0], a0, a1), len(q), int(a["qs"]), int(a["qe"]), "-" if a["flags"] & 8 else "+", "chr2L", len(ref),
+                                                int(a["ts"]), int(a["te"]), int(a["mlen"]), int(a["blen"]), int(a["mapq"])) for a in res.alns]
+            b1 = os.path.join(tmp, "te.bed")
+            with open(b1, "w") as f:
+                for r in ref_ann:
+                    f.write("\t".join(r) + "\n")
+            # the reference genome's own TE annotation (what RepeatMasker would give): the famA copy
+            b2 = os.path.join(tmp, "ref_te.bed")
+            with open(b2, "w") as f:
+                f.write("\t".join(["chr2L", str(20000 + 3000), str(20000 + 3000 + 2400), "famA", ".", "+"]) + "\n")
+            L.subprocess = FakeSubprocess({fa1: {name: contig}, fa2: {"chr2L": ref}}, pafs)
+
+            class FakePool(object):
+                def __init__(self, processes=None):
+                    pass
+
+                def map(self, fn, items):
+                    return [fn(i) for i in items]
+
+                def close(self):
+                    pass
+
+                def join(self):
+                    pass
+            L.Pool = FakePool
+            ldir = os.path.join(tmp, "lift"); os.mkdir(ldir)
+            saved = sys.stdout; sys.stdout = io.StringIO()
+            try:
+                rep = L.liftover(fa1, fa2, b1, b2, "asm10", 500, 20, 20, ldir, 1, False, False, True)
+            finally:
+                sys.stdout = saved
+            with open(rep) as f:
+                report = json.load(f)
+        finally:
+            shutil.rmtree(tmp)
+        out["cases"][label] = {"bw_long": bwl, "s4_paf": s4, "s5_paf": s5, "reference_annotation": ref_ann, "flank_paf": {"|".join(k): v for k, v in pafs.items()},
+                               "reference_liftover_report": report}
+    return out
+
+
 def main():
     L, T, S, U = import_reference()
     if "--only-repeatmask" in sys.argv:
@@ -720,6 +850,11 @@ def main():
         print("wrote repeatmask.json")
         return
     os.makedirs(GOLD, exist_ok=True)
+    if "--only-nested" in sys.argv:
+        with open(os.path.join(GOLD, "nested_locus.json"), "w") as f:
+            json.dump(capture_nested(T, L, U), f, indent=1, sort_keys=True)
+        print("wrote nested_locus.json")
+        return
     import telr.TELR_output as O
     if "--only-assembly" in sys.argv:
         with open(os.path.join(GOLD, "prep_assembly.json"), "w") as f:
@@ -727,7 +862,7 @@ def main():
         print("wrote prep_assembly.json")
         return
     for name, obj in (("prep_assembly.json", capture_prep_assembly()), ("liftover_single.json", capture_liftover(L)), ("liftover_driver.json", capture_liftover_driver(L)),
-                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O)), ("sv.json", capture_sv(S, U)), ("repeatmask.json", capture_repeatmask(T))):
+                      ("af.json", capture_af(T)), ("helpers.json", capture_helpers(L, T, S, U)), ("output.json", capture_output(O)), ("sv.json", capture_sv(S, U)), ("repeatmask.json", capture_repeatmask(T)), ("nested_locus.json", capture_nested(T, L, U))):
         with open(os.path.join(GOLD, name), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)
         print("wrote", name)

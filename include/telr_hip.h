@@ -98,6 +98,16 @@ typedef struct telr_map_opt {
      * differ by more than `bw` is aligned as two banded halves joined by one long gap at its best position.
      * 0 = off (asm10, ngmlr-*: NGMLR splits reads at SV breakpoints). */
     int32_t bw_long;
+    /* convex gap cost (NGMLR, Sedlazeck 2018 Methods; `ngmlr -x ont`, TELR_alignment.py:28-51): cx_scale > 0 replaces the
+     * two-piece affine cost (q, e, q2, e2 are then unused by the base-level DP) by: a gap pays cx_open once, and the gap base that
+     * makes a gap of length i one longer pays ext(i) = max(cx_ext_min, cx_ext_max - cx_decay * i) -- NGMLR keeps the current
+     * length with every gap cell, so this is the affine recurrence with a length-dependent extension.  All four numbers, and
+     * every score inside the DP (a, b, sc_ambi, zdrop times cx_scale), are in 1/cx_scale of the unit of a / b / dp_score; a
+     * record's dp_score is the sum of its segments' scores divided by cx_scale, rounded half up.  ngmlr-ont (NGMLR: match 1,
+     * mismatch 1, open 1, extension 1 -> 0.5, decay 0.15; the preset's unit is half of NGMLR's): cx_scale 10, open 20,
+     * ext 20 -> 10, decay 3.  ngmlr-pacbio keeps the two-piece envelope: at its scale (20) a 220-base fill leaves int16; the
+     * oracle's experiment bit 0x80000 measures what that costs (0.18 % of the records' coordinates). */
+    int32_t cx_scale, cx_open, cx_ext_max, cx_ext_min, cx_decay;
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */

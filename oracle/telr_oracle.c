@@ -654,6 +654,13 @@ typedef struct { int score, bi, bj, touched; int64_t cells; } dp_res_t;
 typedef struct convex_s { int S, a, b, amb, open, emax, emin, dec, flat; } convex_t;
 static int convex_of(const telr_map_opt *mo, convex_t *c)
 {
+    if (mo->cx_scale > 0) {                  /* the spec (telr_map_opt.cx_*): ngmlr-ont since round 4 */
+        c->S = mo->cx_scale; c->a = mo->a * c->S; c->b = mo->b * c->S; c->amb = mo->sc_ambi * c->S;
+        c->open = mo->cx_open; c->emax = mo->cx_ext_max; c->emin = mo->cx_ext_min; c->dec = mo->cx_decay;
+        c->flat = c->dec > 0 && c->emax > c->emin ? (c->emax - c->emin + c->dec - 1) / c->dec : 0;
+        return 1;
+    }
+    if (!(mo->flags & MFX_CONVEX)) return 0;
     if (mo->a == 2 && mo->b == 5 && mo->q == 6 && mo->e == 4 && mo->q2 == 60 && mo->e2 == 1) {          /* ngmlr-pacbio */
         c->S = 20; c->a = 40; c->b = 100; c->amb = 20 * mo->sc_ambi; c->open = 100; c->emax = 100; c->emin = 20; c->dec = 3; c->flat = 27; return 1;
     }
@@ -673,7 +680,7 @@ static inline int64_t cx_cost(const convex_t *c, int L)       /* a whole gap of 
 static dp_res_t band_dp_convex(const dp_seq_t *s, int dlo, int dhi, int ext, const telr_map_opt *mo, const struct convex_s *C, u32v_t *rev_cig);
 static dp_res_t band_dp(const dp_seq_t *s, int dlo, int dhi, int ext, const telr_map_opt *mo, u32v_t *rev_cig)
 {
-    if (mo->flags & MFX_CONVEX) { struct convex_s C; if (convex_of(mo, &C)) return band_dp_convex(s, dlo, dhi, ext, mo, &C, rev_cig); }
+    if (mo->cx_scale > 0 || (mo->flags & MFX_CONVEX)) { struct convex_s C; if (convex_of(mo, &C)) return band_dp_convex(s, dlo, dhi, ext, mo, &C, rev_cig); }
     const int m = s->m, n = s->n, D = dhi - dlo + 1, stride = (D + 2) / 2;
     const int q1 = mo->q, e1 = mo->e, q2 = mo->q2, e2 = mo->e2;
     dp_res_t res = { 0, 0, 0, 0, 0 };
@@ -1056,7 +1063,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
      * the tuned presets against this mode is gated by tests/test_faithful_gate.py. */
     const int faithful = (mo->flags & (TELR_MF_FAITHFUL | 0x200)) != 0, faithful_ext = (mo->flags & (TELR_MF_FAITHFUL | 0x400)) != 0;
     const int ext_max = faithful_ext ? (1 << 30) : mo->ext_max, ext_band = faithful_ext ? mo->bw : mo->ext_band;
-    convex_t CX; const int cx = (mo->flags & MFX_CONVEX) && convex_of(mo, &CX);       /* experiment: segment scores come back in 1/S units */
+    convex_t CX; const int cx = (mo->cx_scale > 0 || (mo->flags & MFX_CONVEX)) && convex_of(mo, &CX);       /* segment scores come back in 1/S units */
     /* query accessor on the chain's strand */
     dp_seq_t s; s.q = q; s.t = t; s.qcomp = c->rev;
     /* breakpoints */
@@ -1099,7 +1106,11 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         if (faithful) { if (lo < -s.m) lo = even_lo(-s.m); if (hi > s.n) hi = s.n; }      /* no wider than the matrix */
         const int longgap = mo->bw_long > mo->bw && (dl > mo->bw || -dl > mo->bw);
         dp_res_t r = longgap ? longgap_fill(&s, mo, &rc) : (!faithful && hi - lo + 1 > DP_DMAX) ? band_dp_fallback(&s, mo, &rc, &fb_mlen) : band_dp(&s, lo, hi, 0, mo, &rc);
-        if (cx && (longgap || (!faithful && hi - lo + 1 > DP_DMAX))) r.score *= CX.S;             /* (these two rare paths keep the envelope) */
+        if (cx && (longgap || (!faithful && hi - lo + 1 > DP_DMAX))) {
+            /* the diagonal fall-back closes with ONE gap: its convex cost; (a long-gap fill keeps the envelope: telr_map refuses cx_scale with bw_long) */
+            if (!longgap) { int g = s.m > s.n ? s.m - s.n : s.n - s.m, c1 = mo->q + g * mo->e, c2 = mo->q2 + g * mo->e2; r.score = (r.score + (g ? (c1 < c2 ? c1 : c2) : 0)) * CX.S - (g ? (int)cx_cost(&CX, g) : 0); }
+            else r.score *= CX.S;
+        }
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += s.n;
         if (r.touched && !is_long && !faithful && !longgap) {            /* second pass with the wide band */
             int W2 = fill_band_wide(s.m, s.n, mo);
@@ -1161,7 +1172,7 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
     }
     al->ts = rs; al->te = re;
     if (c->rev) { al->qs = qlen - qe; al->qe = qlen - qs; } else { al->qs = qs; al->qe = qe; }
-    if (cx) dp = dp >= 0 ? (dp + CX.S / 2) / CX.S : -((-dp + CX.S / 2) / CX.S);                    /* back to the preset's units */
+    if (cx) { int32_t v = dp + CX.S / 2; dp = v >= 0 ? v / CX.S : -((-v + CX.S - 1) / CX.S); }      /* back to the preset's units: floor((sum + S/2) / S) */
     al->mlen = mlen; al->blen = blen; al->n_ambi = n_zdrop; al->dp_score = dp; (void)nambi;      /* n_ambi: 0 unless the 0x10000 experiment counts z-dropped fills */
     al->n_cigar = (int32_t)cig.n; al->cigar_off = cigars->n;
     for (int64_t z = 0; z < cig.n; ++z) vpush(uint32_t, *cigars, cig.a[z]);

@@ -16,6 +16,7 @@ class MapOpt(C.Structure):
         ("sc_ambi", C.c_int32), ("zdrop", C.c_int32), ("min_dp_max", C.c_int32), ("min_ksw_len", C.c_int32),
         ("ext_max", C.c_int32), ("ext_band", C.c_int32), ("flags", C.c_int32), ("fill_band_q4", C.c_int32), ("fill_margin", C.c_int32),
         ("vote_len", C.c_int32), ("vote_bin_shift", C.c_int32), ("vote_min", C.c_int32), ("vote_frac_q8", C.c_int32), ("bw_long", C.c_int32),
+        ("cx_scale", C.c_int32), ("cx_open", C.c_int32), ("cx_ext_max", C.c_int32), ("cx_ext_min", C.c_int32), ("cx_decay", C.c_int32),
     ]
 
     def copy(self):

@@ -33,7 +33,19 @@ struct ChainOpt {            // subset of telr_map_opt the device needs
 };
 struct DpOpt {
     int32_t a, b, q, e, q2, e2, sc_ambi, zdrop;
+    // convex gap cost (telr_map_opt.cx_*; cx_scale > 0): a, b, sc_ambi, zdrop above are then already multiplied by cx_scale, q / e / q2 / e2
+    // are unused, and the E2 / F2 slots of every kernel carry the LENGTH of the gap its E / F state ends with (capped at cx_flat, from
+    // where the extension is flat): ext(len) = max(cx_emin, cx_emax - cx_dec * len)
+    int32_t cx_scale, cx_open, cx_emax, cx_emin, cx_dec, cx_flat;
 };
+__host__ __device__ __forceinline__ int d_cx_ext(const DpOpt &o, int len) { int v = o.cx_emax - o.cx_dec * len; return v > o.cx_emin ? v : o.cx_emin; }
+__host__ __device__ __forceinline__ int d_cx_cost(const DpOpt &o, int L)          // a whole gap of L bases
+{
+    int t = o.cx_open;
+    for (int i = 0; i < L && i < o.cx_flat; ++i) t += d_cx_ext(o, i);
+    if (L > o.cx_flat) t += (L - o.cx_flat) * o.cx_emin;
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------
 // small device helpers
@@ -1926,6 +1938,19 @@ __device__ __forceinline__ uint32_t d_cell(const DpOpt &o, int32_t hd, int32_t h
                                            int qb, int tbv, int32_t &h, int32_t &ve1, int32_t &vf1, int32_t &ve2, int32_t &vf2)
 {
     uint32_t t = 0; int32_t op, g;
+    if (o.cx_scale) {        // convex cost: e2l / f2u are the lengths of the gaps E(left) / F(up) end with; ve2 / vf2 the new lengths
+        const int le = e2l < 0 ? 0 : e2l > o.cx_flat ? o.cx_flat : e2l, lf = f2u < 0 ? 0 : f2u > o.cx_flat ? o.cx_flat : f2u;
+        op = hl - o.cx_open - d_cx_ext(o, 0); g = e1l - d_cx_ext(o, le); if (g > op) { ve1 = g; t |= 8; ve2 = le + 1; } else { ve1 = op; ve2 = 1; }
+        op = hu - o.cx_open - d_cx_ext(o, 0); g = f1u - d_cx_ext(o, lf); if (g > op) { vf1 = g; t |= 16; vf2 = lf + 1; } else { vf1 = op; vf2 = 1; }
+        if (ve2 > o.cx_flat) ve2 = o.cx_flat;
+        if (vf2 > o.cx_flat) vf2 = o.cx_flat;
+        int scx;
+        if (qb > 3 || tbv > 3) scx = -o.sc_ambi; else if (qb == tbv) { scx = o.a; t |= 128; } else scx = -o.b;
+        h = hd + scx; uint32_t srcx = 0;
+        if (ve1 > h) { h = ve1; srcx = 1; }
+        if (vf1 > h) { h = vf1; srcx = 2; }
+        return t | srcx;
+    }
     op = hl - o.q - o.e;   g = e1l - o.e;  if (g > op) { ve1 = g; t |= 8; }  else ve1 = op;
     op = hu - o.q - o.e;   g = f1u - o.e;  if (g > op) { vf1 = g; t |= 16; } else vf1 = op;
     op = hl - o.q2 - o.e2; g = e2l - o.e2; if (g > op) { ve2 = g; t |= 32; } else ve2 = op;
@@ -2104,7 +2129,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) { sc += __shfl_xor(sc, s); ml += __shfl_xor(ml, s); }
         int g = m > n ? m - n : n - m;
-        if (g) { int c1 = o.q + g * o.e, c2 = o.q2 + g * o.e2; sc -= c1 < c2 ? c1 : c2; }
+        if (g) { if (o.cx_scale) sc -= d_cx_cost(o, g); else { int c1 = o.q + g * o.e, c2 = o.q2 + g * o.e2; sc -= c1 < c2 ? c1 : c2; } }
         if (lane == 0) {
             int no = 0;
             if (g) A.cig[P.cig_off + no++] = (uint32_t)g << 4 | (m > n ? 1u : 2u);
@@ -2130,7 +2155,9 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
         for (int d = d0 + 2 * lane; d <= d1; d += 128) {
             const int i = (a - d) >> 1, j = (a + d) >> 1, x = d - dlo + 1;
             int32_t h, ve1, vf1, ve2, vf2;
-            if (i == 0) {
+            if (i == 0 && o.cx_scale) { ve1 = -d_cx_cost(o, j); ve2 = j < o.cx_flat ? j : o.cx_flat; vf1 = TELR_NEG; vf2 = 0; h = ve1; }
+            else if (j == 0 && o.cx_scale) { vf1 = -d_cx_cost(o, i); vf2 = i < o.cx_flat ? i : o.cx_flat; ve1 = TELR_NEG; ve2 = 0; h = vf1; }
+            else if (i == 0) {
                 ve1 = -(o.q + j * o.e); ve2 = -(o.q2 + j * o.e2); vf1 = vf2 = TELR_NEG;
                 h = ve1 > ve2 ? ve1 : ve2;
             } else if (j == 0) {
@@ -2243,6 +2270,10 @@ __device__ __forceinline__ void d_init_diag(const DpOpt &o, int d, int dhi, int 
     H = E1 = E2 = F1 = F2 = TELR_NEG; alo = 0x40000000; span = 0;
     if (!have || d > dhi) return;
     if (d == 0) H = 0;
+    else if (o.cx_scale) {
+        if (d > 0) { E1 = -d_cx_cost(o, d); E2 = d < o.cx_flat ? d : o.cx_flat; H = E1; }
+        else { F1 = -d_cx_cost(o, -d); F2 = -d < o.cx_flat ? -d : o.cx_flat; H = F1; }
+    }
     else if (d > 0) { E1 = -(o.q + d * o.e); E2 = -(o.q2 + d * o.e2); H = E1 > E2 ? E1 : E2; }
     else { F1 = -(o.q - d * o.e); F2 = -(o.q2 - d * o.e2); H = F1 > F2 ? F1 : F2; }
     const int lo = (d < 0 ? -d : d) + 2, hi1 = 2 * m + d, hi2 = 2 * n - d, hi = hi1 < hi2 ? hi1 : hi2;
@@ -2253,6 +2284,7 @@ __device__ __forceinline__ uint32_t d_cell_nc(const DpOpt &o, int32_t hd, int32_
                                               int qb, int tbv, int32_t &h, int32_t &ve1, int32_t &vf1, int32_t &ve2, int32_t &vf2)
 {
     uint32_t t = 0; int32_t op, g;
+    if (o.cx_scale) return d_cell(o, hd, hl, e1l, e2l, hu, f1u, f2u, qb, tbv, h, ve1, vf1, ve2, vf2);      // convex cost: the one scalar cell
     op = hl - (o.q + o.e);   g = e1l - o.e;  ve1 = g > op ? g : op; t |= g > op ? 8u : 0u;
     op = hu - (o.q + o.e);   g = f1u - o.e;  vf1 = g > op ? g : op; t |= g > op ? 16u : 0u;
     op = hl - (o.q2 + o.e2); g = e2l - o.e2; ve2 = g > op ? g : op; t |= g > op ? 32u : 0u;
@@ -2409,6 +2441,8 @@ __device__ __forceinline__ uint32_t PKU(pk_s2 v) { return __builtin_bit_cast(uin
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return PKU(PKS(a) + PKS(b)); }
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return PKU(PKS(a) - PKS(b)); }
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return PKU(__builtin_elementwise_max(PKS(a), PKS(b))); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return PKU(__builtin_elementwise_min(PKS(a), PKS(b))); }
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return PKU(PKS(a) * PKS(b)); }
 // 0xffff where the half is negative.  Inline asm keeps the packed form: written in C the compiler turns the
 // mask-and-select idiom into per-half SDWA compares + v_cndmask + v_perm (about twice the instructions).
 __device__ __forceinline__ uint32_t pk_sign(uint32_t a)
@@ -2427,7 +2461,8 @@ __device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
 
-struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF, q2e2F; };      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
+struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF, q2e2F;      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
+                 uint32_t cx_oe0, cx_emax, cx_emin, cx_dec, cx_flat; };        // convex cost (d_cell_pk_cx): open + ext(0), the extension's range, its decay, the length cap
 
 // ONEP (one-piece): in a band of D diagonals no gap run is longer than D - 1, and while (D - 1)(e - e2) < q2 - q the second
 // affine piece q2 + L e2 is STRICTLY dearer than q + L e for every possible run length, so E2 / F2 are strictly below
@@ -2457,6 +2492,32 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
         m = pk_sign(pk_sub(h, ve2)); h = pk_max(h, ve2); src = pk_sel(m, 0x00030003u, src);
         m = pk_sign(pk_sub(h, vf2)); h = pk_max(h, vf2); src = pk_sel(m, 0x00040004u, src);
     }
+    return t | src;
+}
+
+// The cell of the CONVEX gap cost (DpOpt.cx_*; ngmlr-ont): one E and one F state, and in the registers that hold E2 / F2 elsewhere
+// the LENGTH of the gap the state ends with (it travels exactly like its state: same neighbour shifts, same lane exchange).
+//   ext(len) = clamp(emax - dec * len, emin, emax)      (the upper clamp only tames the garbage lengths of cells that are -inf)
+//   E = max(H_left - open - ext(0)  [opened, length 1],  E_left - ext(LE_left)  [extended, length LE_left + 1, capped at `flat`])
+// Flags as in d_cell_pk (bit 3 / 4: E / F extended, bit 7: bases equal, bits 0-2: source 0 diagonal, 1 E, 2 F): the walks need nothing new.
+__device__ __forceinline__ uint32_t d_cell_pk_cx(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t el, uint32_t lel, uint32_t hu, uint32_t fu, uint32_t lfu,
+                                                 uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve, uint32_t &vf, uint32_t &nle, uint32_t &nlf)
+{
+    const uint32_t one = 0x00010001u;
+    const uint32_t ce = pk_min(c.cx_emax, pk_max(c.cx_emin, pk_sub(c.cx_emax, pk_mul(lel, c.cx_dec))));
+    const uint32_t cf = pk_min(c.cx_emax, pk_max(c.cx_emin, pk_sub(c.cx_emax, pk_mul(lfu, c.cx_dec))));
+    uint32_t op, g, m, t;
+    op = pk_sub(hl, c.cx_oe0); g = pk_sub(el, ce); ve = pk_max(op, g); m = pk_sign(pk_sub(op, g)); t  = m & 0x00080008u;
+    nle = pk_sel(m, pk_min(pk_add(lel, one), c.cx_flat), one);
+    op = pk_sub(hu, c.cx_oe0); g = pk_sub(fu, cf); vf = pk_max(op, g); m = pk_sign(pk_sub(op, g)); t |= m & 0x00100010u;
+    nlf = pk_sel(m, pk_min(pk_add(lfu, one), c.cx_flat), one);
+    const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
+    const uint32_t sc = pk_sub(eq & c.ab, c.b);
+    t |= eq & 0x00800080u;
+    h = pk_add(hd, sc);
+    uint32_t src;
+    m = pk_sign(pk_sub(h, ve)); h = pk_max(h, ve); src = m & 0x00010001u;
+    m = pk_sign(pk_sub(h, vf)); h = pk_max(h, vf); src = pk_sel(m, 0x00020002u, src);
     return t | src;
 }
 
@@ -2585,12 +2646,13 @@ __device__ __forceinline__ int d_step_cells(int a, int m, int n, int dlo, int dh
 // through `xch` (LDS, [2][NW][3]) with one barrier per step, everything else is unchanged.
 // FULL: the first FULL registers of a lane are inside the band for every problem of the class (classes are cut so that
 // only the last register can straddle dhi), so they need no out-of-band masks.
-template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false, bool TB4 = false, bool TAG8 = false>
+template <int LPP, int R, bool EXT, int NW = 1, int FULL = 0, bool ONEP = false, bool TB4 = false, bool TAG8 = false, bool CX = false>
 __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restrict__ list, int nlist, int first_prob, uint32_t *xch = nullptr)
 {
     static_assert(NW == 1 || LPP == 64 * NW, "multi-wave problems use whole waves");
     static_assert(!TB4 || (ONEP && LPP == 1 && !EXT), "nibble spill: one-piece cell, one problem per lane");
     static_assert(!TAG8 || (!ONEP && !TB4 && !EXT && NW == 1), "tagged two-piece cell: fills of the one-launch classes");
+    static_assert(!CX || (!ONEP && !TB4 && !TAG8), "convex cell: plain flags, byte spill");
     constexpr int RW = LPP * R;
     const int lane = threadIdx.x, sub = lane / LPP, l = lane % LPP;
     const int wv = NW > 1 ? lane >> 6 : 0, wl = lane & 63;
@@ -2602,6 +2664,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
     c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.a = pk_dup(o.a); c.nab = pk_dup(-(o.a + o.b)); c.qeF = c.qe;
     c.q2e2F = c.q2e2;
+    c.cx_oe0 = pk_dup(o.cx_open + d_cx_ext(o, 0)); c.cx_emax = pk_dup(o.cx_emax); c.cx_emin = pk_dup(o.cx_emin); c.cx_dec = pk_dup(o.cx_dec); c.cx_flat = pk_dup(o.cx_flat);
     if constexpr (TB4) {           // scores times four, provenance tags in the two low bits (d_cell_pk4)
         c.qe = pk_dup(4 * (o.q + o.e) - 2); c.qeF = pk_dup(4 * (o.q + o.e) - 1); c.e = pk_dup(4 * o.e);
         c.a = pk_dup(4 * o.a + 2); c.nab = pk_dup(-4 * (o.a + o.b));
@@ -2683,6 +2746,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 const uint32_t hl = __builtin_amdgcn_alignbit(Ho[r], lh, 16), e1l = __builtin_amdgcn_alignbit(E1o[r], le1, 16), e2l = __builtin_amdgcn_alignbit(E2o[r], le2, 16);
                 if constexpr (TB4) { te[r] = d_cell_pk4<0>(c, He[r], hl, e1l, Ho[r], F1o[r], qb[r], tbv[r], h, ve1, vf1); ve2 = PK_NEG; vf2 = PK_NEG; }
                 else if constexpr (TAG8) te[r] = d_cell_pk8(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                else if constexpr (CX) te[r] = d_cell_pk_cx(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 else te[r] = d_cell_pk<ONEP>(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { He[r] = h; F1e[r] = vf1; F2e[r] = vf2; }
                 else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]); }
@@ -2728,6 +2792,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 uint32_t t;
                 if constexpr (TB4) { t = d_cell_pk4<4>(c, Ho[r], He[r], E1e[r], hu, f1u, qb[r], tbv[r], h, ve1, vf1); ve2 = PK_NEG; vf2 = PK_NEG; }
                 else if constexpr (TAG8) t = d_cell_pk8(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
+                else if constexpr (CX) t = d_cell_pk_cx(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 else t = d_cell_pk<ONEP>(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { Ho[r] = h; F1o[r] = vf1; F2o[r] = vf2; }
                 else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]); }
@@ -2879,6 +2944,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
     const int32_t *list = cls_list + off.off[cls];
     const int n = off.off[cls + 1] - off.off[cls];
     // widest band in which the second affine piece can never pay (see d_cell_pk): (D - 1)(e - e2) < q2 - q
+    if (A.o.cx_scale) {          // convex gap cost: its own cell (plain flags, byte spill) in every class
+        switch (cls) {
+        case 10: d_dp_pkr<1, 5, false, 1, 4, false, false, false, true>(A, list, n, first); break;
+        case 11: d_dp_pkr<1, 6, false, 1, 5, false, false, false, true>(A, list, n, first); break;
+        case 12: d_dp_pkr<1, 7, false, 1, 6, false, false, false, true>(A, list, n, first); break;
+        case 13: d_dp_pkr<1, 8, false, 1, 7, false, false, false, true>(A, list, n, first); break;
+        case 17: d_dp_pkr<1, 4, false, 1, 0, false, false, false, true>(A, list, n, first); break;
+        case 14: d_dp_pkr<2, 5, false, 1, 0, false, false, false, true>(A, list, n, first); break;
+        case 15: d_dp_pkr<2, 6, false, 1, 0, false, false, false, true>(A, list, n, first); break;
+        case 22: d_dp_pkr<4, 8, false, 1, 0, false, false, false, true>(A, list, n, first); break;
+        default: d_dp_pkr<2, 8, false, 1, 0, false, false, false, true>(A, list, n, first); break;
+        }
+        return;
+    }
     const int onep_d = d_onep_d(A.o.q, A.o.e, A.o.q2, A.o.e2);
     if (cls == 17 && onep_d >= 16) { if (A.tb4 & 1) d_dp_pkr<1, 4, false, 1, 0, true, true>(A, list, n, first); else d_dp_pkr<1, 4, false, 1, 0, true>(A, list, n, first); return; }
     if (cls == 10 && onep_d >= 20) { if (A.tb4 & 2) d_dp_pkr<1, 5, false, 1, 4, true, true>(A, list, n, first); else d_dp_pkr<1, 5, false, 1, 4, true>(A, list, n, first); return; }
@@ -2918,7 +2997,8 @@ __global__ void __launch_bounds__(64 * NW) k_dp_pkw(DpArgs A)
 {
     __shared__ uint32_t xch[2 * NW * 3];
     __builtin_amdgcn_s_setprio(3);
-    d_dp_pkr<64 * NW, 1, false, NW>(A, A.list, A.nlist, blockIdx.x, xch);
+    if (A.o.cx_scale) d_dp_pkr<64 * NW, 1, false, NW, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x, xch);
+    else d_dp_pkr<64 * NW, 1, false, NW>(A, A.list, A.nlist, blockIdx.x, xch);
 }
 // z-drop extensions (class 18): their own launch on a side stream; four lanes per problem keep the single-wave
 // latency of the long windows down
@@ -2927,14 +3007,16 @@ __global__ void __launch_bounds__(64 * NW) k_dp_pkw(DpArgs A)
 __global__ void __launch_bounds__(64) k_dp_pkx(DpArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
-    d_dp_pkr<PKX_LPP, PKX_R, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX_LPP));
+    if (A.o.cx_scale) d_dp_pkr<PKX_LPP, PKX_R, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX_LPP));
+    else d_dp_pkr<PKX_LPP, PKX_R, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX_LPP));
 }
 // the same class with sixteen lanes per problem (same trace-back layout): a quarter of the work per lane and step, for
 // calls with few extensions, where the longest window is what the caller waits for
 __global__ void __launch_bounds__(64) k_dp_pkx16(DpArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
-    d_dp_pkr<16, 1, true>(A, A.list, A.nlist, blockIdx.x * 4);
+    if (A.o.cx_scale) d_dp_pkr<16, 1, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * 4);
+    else d_dp_pkr<16, 1, true>(A, A.list, A.nlist, blockIdx.x * 4);
 }
 
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the
@@ -3252,7 +3334,7 @@ __global__ void __launch_bounds__(256) k_seq_gather(const uint32_t *__restrict__
 // bases, block length) and keeps the reach of the two end extensions; the per-problem records stay on the device.
 struct StitchRec { int32_t p0, p1, has_left, pad; };     // problems [p0, p1) of a kept chain
 struct ChainStat { int32_t dp, mlen, blen, l_bi, l_bj, r_bi, r_bj, pad; };     // 32 B
-__global__ void __launch_bounds__(64) k_chain_stats(const StitchRec *__restrict__ sv, int32_t nk, const DpRes *__restrict__ res, ChainStat *__restrict__ out)
+__global__ void __launch_bounds__(64) k_chain_stats(const StitchRec *__restrict__ sv, int32_t nk, const DpRes *__restrict__ res, ChainStat *__restrict__ out, int32_t cx_scale)
 {
     const int x = blockIdx.x, lane = threadIdx.x;
     if (x >= nk) return;
@@ -3262,6 +3344,7 @@ __global__ void __launch_bounds__(64) k_chain_stats(const StitchRec *__restrict_
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) { dp += __shfl_xor(dp, s); ml += __shfl_xor(ml, s); bl += __shfl_xor(bl, s); }
     if (lane == 0) {
+        if (cx_scale) { const int v = dp + cx_scale / 2; dp = v >= 0 ? v / cx_scale : -((-v + cx_scale - 1) / cx_scale); }      // convex cost: segment scores are in 1/cx_scale units
         ChainStat c; c.dp = dp; c.mlen = ml; c.blen = bl; c.pad = 0;
         const DpRes a = res[S.p0], b = res[S.p1 - 1];
         c.l_bi = a.bi; c.l_bj = a.bj; c.r_bi = b.bi; c.r_bj = b.bj;

@@ -327,7 +327,10 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
         // (exact at L = 1 and L >= 27, within 6 in between);  ont (1, -1, open 1, extend 1 -> 0.5), doubled to integers:
         // C(L) = 2 + sum_{i<L} max(1, 2 - 0.3 i) ~ min(2 + 2L, 4 + L).  AS is in these integer units (ont: twice NGMLR's).
         io->k = 13; io->w = 5;
-        if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; }
+        // round 4: for `ont` the convex cost is the spec in EXACT form (cx_*: scores in 1/10 of this preset's unit, the gap length rides
+        // with every gap cell): against the envelope it moved 3.2 % of the records' coordinates (faithful gate); pacbio keeps the envelope
+        // (0.18 %; at its scale of 20 a 220-base fill leaves int16)
+        if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; mo->cx_scale = 10; mo->cx_open = 20; mo->cx_ext_max = 20; mo->cx_ext_min = 10; mo->cx_decay = 3; }
         else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; }
         mo->fill_band_q4 = 12; mo->fill_margin = 2;
         mo->vote_len = 256; mo->vote_bin_shift = 5; mo->vote_min = 3; mo->vote_frac_q8 = 128;      // NGMLR's sub-read voting
@@ -1298,8 +1301,18 @@ struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int6
 // sharing a wave are alike and the long ones start first), forward kernels, trace-back.
 // longest gap fill (m+n) the packed int16 kernels take: |H| <= b*(m+n)/2 + q2 + 128*e2 and a*(m+n)/2 must stay inside
 // +-16000 (bands of these classes have at most 128 diagonals); 0 disables the packed classes
+// convex gap cost (cx_scale > 0): the same bounds on the scaled scores -- |H| <= b S (m+n)/2 + open + D ext_max
+static inline int pk_cx_limit(const telr_map_opt *mo, int D)
+{
+    const int S = mo->cx_scale, bS = mo->b * S, aS = mo->a * S;
+    if (getenv("TELR_NO_PK") || bS > 400 || aS > 400 || mo->sc_ambi * S > 400 || mo->cx_ext_max > 400 || mo->cx_open > 400 || mo->cx_ext_max < mo->cx_ext_min || mo->cx_ext_min < 0 || mo->cx_decay < 0) return 0;
+    const int by_b = 2 * (15800 - mo->cx_open - D * mo->cx_ext_max) / (bS > 0 ? bS : 1) - 2, by_a = 32000 / (aS > 0 ? aS : 1) - 2;
+    const int lim = by_b < by_a ? by_b : by_a;
+    return lim > 0 ? lim : 0;
+}
 static inline int pk_steps_limit(const telr_map_opt *mo)
 {
+    if (mo->cx_scale > 0) return pk_cx_limit(mo, 128);
     if (!(mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9) || getenv("TELR_NO_PK")) return 0;
     const int by_b = 2 * (15800 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
@@ -1309,6 +1322,7 @@ static inline int pk_steps_limit(const telr_map_opt *mo)
 static inline int pk_wide_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || getenv("TELR_NO_PKW")) return 0;
+    if (mo->cx_scale > 0) return pk_cx_limit(mo, 1024);
     const int by_b = 2 * (15800 - mo->q2 - 1024 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
@@ -1319,7 +1333,7 @@ static inline int pk_wide_limit(const telr_map_opt *mo)
 static inline int tb4_mask(const telr_map_opt *mo)
 {
     static const bool off = (getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0) || getenv("TELR_TB8") != nullptr;
-    if (off || !pk_steps_limit(mo)) return 0;
+    if (off || !pk_steps_limit(mo) || mo->cx_scale > 0) return 0;          // (the convex cell spills plain bytes)
     const int d = d_onep_d(mo->q, mo->e, mo->q2, mo->e2);
     return (d >= 16 ? 1 : 0) | (d >= 20 ? 2 : 0);
 }
@@ -1334,14 +1348,15 @@ static inline int tb4_steps(const telr_map_opt *mo)
 static inline int tag8_steps(const telr_map_opt *mo)
 {
     static const bool off = (getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0) || getenv("TELR_NO_TAG8") != nullptr;
-    if (off || !pk_steps_limit(mo)) return 0;
+    if (off || !pk_steps_limit(mo) || mo->cx_scale > 0) return 0;
     const int by_b = 2 * (1975 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 4000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
 }
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
-    if (!pk_steps_limit(mo) || mo->zdrop > 4000 || getenv("TELR_NO_PKEXT")) return 0;
+    if (!pk_steps_limit(mo) || mo->zdrop * (mo->cx_scale > 0 ? mo->cx_scale : 1) > 4000 || getenv("TELR_NO_PKEXT")) return 0;
+    if (mo->cx_scale > 0) return pk_cx_limit(mo, 64);
     const int by_b = 2 * (15800 - mo->q2 - 64 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
@@ -1401,6 +1416,13 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     DpArgs D; D.qseq2 = qs->d_seq2; D.qnmask = qs->d_nmask; D.tseq2 = tg->d_seq2; D.tnmask = tg->d_nmask; D.probs = d_probs;
     D.qtot = qs->padded_bases; D.ttot = tg->padded_bases;
     D.o.a = mo->a; D.o.b = mo->b; D.o.q = mo->q; D.o.e = mo->e; D.o.q2 = mo->q2; D.o.e2 = mo->e2; D.o.sc_ambi = mo->sc_ambi; D.o.zdrop = mo->zdrop;
+    D.o.cx_scale = D.o.cx_open = D.o.cx_emax = D.o.cx_emin = D.o.cx_dec = D.o.cx_flat = 0;
+    if (mo->cx_scale > 0) {          // convex gap cost: every score of the DP in 1/cx_scale units (k_chain_stats scales the records' sums back)
+        const int S = mo->cx_scale;
+        D.o.a *= S; D.o.b *= S; D.o.sc_ambi *= S; D.o.zdrop *= S;
+        D.o.cx_scale = S; D.o.cx_open = mo->cx_open; D.o.cx_emax = mo->cx_ext_max; D.o.cx_emin = mo->cx_ext_min; D.o.cx_dec = mo->cx_decay;
+        D.o.cx_flat = mo->cx_decay > 0 && mo->cx_ext_max > mo->cx_ext_min ? (mo->cx_ext_max - mo->cx_ext_min + mo->cx_decay - 1) / mo->cx_decay : 0;
+    }
     D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
     D.retry = d_retry; D.tb4 = tb4_mask(mo); D.tag8_steps = tag8_steps(mo);
     static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
@@ -2033,7 +2055,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             TRY(ctx_hbuf_t(ctx, "h_chain_stat", (size_t)nk, &h_cs));
             TRY(ctx_hbuf_t(ctx, "h_dp_acc", (size_t)TELR_N_DPCLS * 4 + 1, &h_acc));
             HIPCHK(hipMemsetAsync(d_acc, 0, ((size_t)TELR_N_DPCLS * 4 + 1) * 8, st));
-            hipLaunchKernelGGL(k_chain_stats, dim3(nk), dim3(64), 0, st, d_sv, nk, d_res, d_cs);
+            hipLaunchKernelGGL(k_chain_stats, dim3(nk), dim3(64), 0, st, d_sv, nk, d_res, d_cs, mo->cx_scale > 0 ? mo->cx_scale : 0);
             hipLaunchKernelGGL(k_dp_account, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, d_res, np, d_acc);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_cs, d_cs, (size_t)nk * sizeof(ChainStat), hipMemcpyDeviceToHost, st));
@@ -2350,6 +2372,9 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     if (mo->chain_lookback != 64 && mo->chain_lookback != 128 && mo->chain_lookback != 256) { ctx->err = "chain_lookback must be 64, 128 or 256"; return TELR_E_ARG; }
     if (mo->e < mo->e2 || mo->q > mo->q2) { ctx->err = "two-piece gap cost needs e >= e2 and q <= q2"; return TELR_E_ARG; }
     if (mo->fill_margin < 0 || mo->fill_margin > 64) { ctx->err = "fill_margin must be 0..64"; return TELR_E_ARG; }
+    if (mo->cx_scale < 0 || (mo->cx_scale > 0 && (mo->bw_long > 0 || mo->cx_scale > 64 || mo->cx_open < 0 || mo->cx_ext_min < 0 || mo->cx_ext_max < mo->cx_ext_min || mo->cx_decay < 0))) {
+        ctx->err = "convex gap cost: cx_scale 1..64, 0 <= cx_ext_min <= cx_ext_max, cx_open >= 0, cx_decay >= 0, and no long join (bw_long) with it"; return TELR_E_ARG;
+    }
     if (mo->vote_len != 0 && (mo->vote_len < 16 || mo->vote_len > 65536 || mo->vote_bin_shift < 0 || mo->vote_bin_shift > 20 || mo->vote_min < 1 || mo->vote_frac_q8 < 0 || mo->vote_frac_q8 > 256)) {
         ctx->err = "sub-read voting needs vote_len 16..65536, vote_bin_shift 0..20, vote_min >= 1, vote_frac_q8 0..256"; return TELR_E_ARG; }
     if (mo->flags & TELR_MF_FAITHFUL) { ctx->err = "TELR_MF_FAITHFUL is a mode of the CPU oracle (test infrastructure), not of the engine"; return TELR_E_ARG; }

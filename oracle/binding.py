@@ -57,6 +57,7 @@ def lib():
                               C.POINTER(i32), C.POINTER(i32)]
         L.tor_depth_medians.argtypes = [vp, i64, vp, i32, vp, i32, vp, vp, vp, vp]
         L.tor_consensus.restype = i64; L.tor_consensus.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, i32, vp, i64, vp, vp]
+        L.tor_poa.restype = i64; L.tor_poa.argtypes = [vp, i64, vp, vp, vp, i32, vp, vp, vp, i32, vp, i64, vp, vp]
         _lib = L
     return _lib
 
@@ -160,8 +161,9 @@ for _i, _c in enumerate("ACGT"):
 _NT4[ord("U")] = 3; _NT4[ord("u")] = 3
 
 
-def consensus(alns, cigars, queries, targets, min_depth=3):
-    """pile-up consensus of the targets from the primary records (spec 3.12) -> list of str"""
+def consensus(alns, cigars, queries, targets, min_depth=3, poa=False):
+    """pile-up consensus of the targets from the primary records (spec 3.12), or -- poa=True -- the window partial-order
+    consensus (spec 3.13) -> list of str"""
     from telr_amd.fasta import concat
     alns = np.ascontiguousarray(alns); cigars = np.ascontiguousarray(cigars, dtype=np.uint32)
     qb, qo, ql = queries if isinstance(queries, tuple) else concat(queries)
@@ -170,7 +172,7 @@ def consensus(alns, cigars, queries, targets, min_depth=3):
     tb = np.ascontiguousarray(tb, np.uint8); to = np.ascontiguousarray(to, np.int64); tl = np.ascontiguousarray(tl, np.int32)
     cap = int(tl.sum()) * (1 + 8) + 16
     out = np.zeros(cap, np.uint8); ooff = np.zeros(len(tl), np.int64); olen = np.zeros(len(tl), np.int32)
-    n = lib().tor_consensus(alns.ctypes.data, len(alns), cigars.ctypes.data, q4.ctypes.data, qo.ctypes.data, len(tl), tb.ctypes.data, to.ctypes.data, tl.ctypes.data,
+    n = (lib().tor_poa if poa else lib().tor_consensus)(alns.ctypes.data, len(alns), cigars.ctypes.data, q4.ctypes.data, qo.ctypes.data, len(tl), tb.ctypes.data, to.ctypes.data, tl.ctypes.data,
                             int(min_depth), out.ctypes.data, cap, ooff.ctypes.data, olen.ctypes.data)
     assert n <= cap
     return [bytes(out[ooff[i]:ooff[i] + olen[i]]).decode() for i in range(len(tl))]

@@ -1455,3 +1455,223 @@ int64_t tor_consensus(const telr_aln *alns, int64_t n_aln, const uint32_t *cigar
     free(cell); free(base);
     return w;
 }
+
+/* ------------------------------------------------------------------------- */
+/* 9. window partial-order consensus (spec 3.13; SURVEY 8(f) rank 4: the polishing hand-off H3, TELR_assembly.py:226-247 pipes
+ *    `samtools view -F0x900` of the reads->contig alignments into wtpoa-cns).  wtpoa-cns's source is absent, so this restates the
+ *    PUBLISHED scheme of window POA polishing (Lee 2002 Bioinformatics 18:452 partial-order alignment; Vaser 2017 Genome Res
+ *    27:737 window consensus): the draft is cut into windows of POA_W bases; every primary record that covers a window whole gives
+ *    the piece of its read that its CIGAR aligns to the window; the pieces are aligned one after the other to a graph that starts
+ *    as the draft's window (global sequence-to-graph alignment, linear gap) and are merged into it; the consensus of the window
+ *    is the heaviest-bundle path.  Every cap and tie-break below is part of the spec (the HIP kernel follows it bit for bit). */
+#define POA_W       200     /* window (draft bases) */
+#define POA_SEGMAX  400     /* a piece longer than 2 W or shorter than W / 2 is a structural difference, not an error of the draft */
+#define POA_MAXSEG  64      /* pieces per window (the first ones in record order) */
+#define POA_MAXNODE 2048
+#define POA_MAXIN   8       /* in-edges per node; an edge beyond that is not recorded */
+#define POA_M       3
+#define POA_X       (-5)
+#define POA_G       (-4)
+typedef struct {
+    int n;                                   /* nodes */
+    uint8_t base[POA_MAXNODE];
+    int16_t nin[POA_MAXNODE], nout[POA_MAXNODE];
+    int16_t in[POA_MAXNODE][POA_MAXIN]; int16_t inw[POA_MAXNODE][POA_MAXIN];
+    int16_t ring[POA_MAXNODE];               /* next node aligned to the same column (circular; itself when alone) */
+    int16_t order[POA_MAXNODE];              /* topological order */
+    int16_t startc[POA_MAXNODE], endc[POA_MAXNODE];      /* sequences (the draft's window included) that begin / end at the node */
+} poa_t;
+static void poa_add_edge(poa_t *g, int u, int v)
+{
+    for (int k = 0; k < g->nin[v]; ++k) if (g->in[v][k] == u) { ++g->inw[v][k]; return; }
+    if (g->nin[v] >= POA_MAXIN) return;
+    g->in[v][g->nin[v]] = (int16_t)u; g->inw[v][g->nin[v]] = 1; ++g->nin[v]; ++g->nout[u];
+}
+/* align seq[0..n) to the graph and merge it in; H is scratch of (nodes + 1) x (n + 1) */
+static void poa_add_seq(poa_t *g, const uint8_t *seq, int n, int16_t *H, int16_t *rank)
+{
+    const int stride = n + 1;
+    /* row 0 = the virtual start */
+    for (int j = 0; j <= n; ++j) H[j] = (int16_t)(j * POA_G);
+    for (int r = 0; r < g->n; ++r) rank[g->order[r]] = (int16_t)(r + 1);
+    for (int r = 0; r < g->n; ++r) {
+        const int v = g->order[r];
+        int16_t *row = H + (size_t)(r + 1) * stride;
+        for (int j = 0; j <= n; ++j) {
+            int best = -32000;
+            const int npred = g->nin[v] ? g->nin[v] : 1;
+            for (int k = 0; k < npred; ++k) {
+                const int16_t *pr = H + (size_t)(g->nin[v] ? rank[g->in[v][k]] : 0) * stride;
+                int c = pr[j] + POA_G;                                                   /* the node is skipped */
+                if (c > best) best = c;
+                if (j > 0) { c = pr[j - 1] + (seq[j - 1] == g->base[v] && seq[j - 1] < 4 ? POA_M : POA_X); if (c > best) best = c; }
+            }
+            if (j > 0) { const int c = row[j - 1] + POA_G; if (c > best) best = c; }      /* the base is inserted */
+            row[j] = (int16_t)best;
+        }
+    }
+    /* the end: the sink with the best score, smallest id on ties */
+    int endv = -1, endsc = -32768;
+    for (int v = 0; v < g->n; ++v) if (!g->nout[v]) { const int sc = H[(size_t)rank[v] * stride + n]; if (sc > endsc) endsc = sc, endv = v; }
+    /* walk back: diagonal from the first pred that explains the cell, else skip-node from the first pred, else inserted base */
+    static __thread int16_t pn[POA_MAXNODE + POA_SEGMAX + 2], pj[POA_MAXNODE + POA_SEGMAX + 2];
+    int np = 0, v = endv, j = n;
+    while (v >= 0 || j > 0) {
+        if (v < 0) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; continue; }          /* bases before the graph's start */
+        const int16_t *row = H + (size_t)rank[v] * stride;
+        const int cur = row[j], npred = g->nin[v] ? g->nin[v] : 1;
+        int moved = 0;
+        if (j > 0) {
+            const int sc = seq[j - 1] == g->base[v] && seq[j - 1] < 4 ? POA_M : POA_X;
+            for (int k = 0; k < npred && !moved; ++k) {
+                const int p = g->nin[v] ? g->in[v][k] : -1;
+                if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j - 1] + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = 1; }
+            }
+        }
+        for (int k = 0; k < npred && !moved; ++k) {
+            const int p = g->nin[v] ? g->in[v][k] : -1;
+            if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j] + POA_G == cur) { v = p; moved = 1; }      /* node skipped: nothing to merge */
+        }
+        if (!moved) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; }
+    }
+    /* merge, start -> end, keeping `order` topological WITHOUT re-sorting.  Invariant: the nodes of one column (a ring) are
+     * contiguous in `order`, the column's first node in front.  A new node aligned to column x (another base there) goes right
+     * behind x; a new node that stands for an inserted base goes behind the LAST node of the column before it (or keeps the place
+     * of the new node before it; a new first node goes in front of everything).  anchor[k] = the old rank the k-th new node is
+     * put behind (-1: the front); anchors do not decrease along the path, nodes with one anchor keep their path order. */
+    static __thread int16_t newv[POA_SEGMAX + 2], anchor[POA_SEGMAX + 2];
+    const int n_old = g->n;
+    int prev = -1, nnew = 0, behind = -1;                                  /* behind: where an inserted base would go now */
+    for (int z = np - 1; z >= 0; --z) {
+        const uint8_t b = seq[pj[z]];
+        int u = -1;
+        const int x = pn[z];
+        if (x >= 0) {
+            if (g->base[x] == b) u = x;
+            else for (int s_ = g->ring[x]; s_ != x; s_ = g->ring[s_]) if (g->base[s_] == b) { u = s_; break; }
+        }
+        if (u < 0) {
+            u = g->n++;
+            g->base[u] = b; g->nin[u] = g->nout[u] = 0; g->ring[u] = (int16_t)u; g->startc[u] = g->endc[u] = 0;
+            newv[nnew] = (int16_t)u; anchor[nnew] = (int16_t)(x >= 0 ? rank[x] - 1 : behind); ++nnew;      /* rank[] is 1-based */
+            if (x >= 0) { g->ring[u] = g->ring[x]; g->ring[x] = (int16_t)u; }
+        }
+        if (x >= 0) {                                                      /* behind the whole column of x (its old members) */
+            int m = rank[x] - 1;
+            for (int s_ = g->ring[x]; s_ != x; s_ = g->ring[s_]) if (s_ < n_old && rank[s_] - 1 > m) m = rank[s_] - 1;
+            behind = m;
+        }
+        if (prev >= 0) poa_add_edge(g, prev, u); else ++g->startc[u];
+        prev = u;
+    }
+    if (prev >= 0) ++g->endc[prev];
+    if (nnew) {
+        static __thread int16_t no[POA_MAXNODE];
+        const int nold = g->n - nnew;
+        int k = 0, o = 0;
+        while (k < nnew && anchor[k] < 0) no[o++] = newv[k++];
+        for (int i = 0; i < nold; ++i) { no[o++] = g->order[i]; while (k < nnew && anchor[k] == i) no[o++] = newv[k++]; }
+        memcpy(g->order, no, sizeof(int16_t) * (size_t)g->n);
+    }
+    /* the checker checks itself: every edge must point forward in `order` (the sweep of the next piece relies on it) */
+    for (int r = 0; r < g->n; ++r) rank[g->order[r]] = (int16_t)(r + 1);
+    for (int v = 0; v < g->n; ++v) for (int k = 0; k < g->nin[v]; ++k) if (rank[g->in[v][k]] >= rank[v]) { fprintf(stderr, "tor_poa: edge %d -> %d against the order\n", g->in[v][k], v); abort(); }
+}
+/* heaviest bundle: every node takes its heaviest in-edge (the better-scored source, then the first, on ties).  The consensus
+ * ENDS at the node most sequences end at and BEGINS at the node most sequences begin at (better score / smaller id on ties; the
+ * walk back stops there, or at a node without in-edges): a piece whose cut at the window border is one base off must not
+ * lengthen the window's consensus by that base -> bases in out[], returns the length */
+static int poa_consensus(const poa_t *g, char *out)
+{
+    static __thread int32_t score[POA_MAXNODE]; static __thread int16_t bp[POA_MAXNODE];
+    for (int r = 0; r < g->n; ++r) {
+        const int v = g->order[r];
+        int bw = -1, bs = -1, b = -1;
+        for (int k = 0; k < g->nin[v]; ++k) {
+            const int u = g->in[v][k], w = g->inw[v][k];
+            if (w > bw || (w == bw && score[u] > bs)) { bw = w; bs = score[u]; b = u; }
+        }
+        bp[v] = (int16_t)b; score[v] = b >= 0 ? bs + bw : 0;
+    }
+    int endv = -1, startv = -1;
+    for (int v = 0; v < g->n; ++v) {
+        if (endv < 0 || g->endc[v] > g->endc[endv] || (g->endc[v] == g->endc[endv] && score[v] > score[endv])) endv = v;
+        if (startv < 0 || g->startc[v] > g->startc[startv]) startv = v;
+    }
+    static __thread char tmp[POA_MAXNODE];
+    int n = 0;
+    for (int v = endv; v >= 0; v = bp[v]) { tmp[n++] = "ACGTN"[g->base[v]]; if (v == startv) break; }
+    for (int i = 0; i < n; ++i) out[i] = tmp[n - 1 - i];
+    return n;
+}
+/* same interface as tor_consensus */
+int64_t tor_poa(const telr_aln *alns, int64_t n_aln, const uint32_t *cigars, const uint8_t *q_nt4, const int64_t *qoff,
+                int32_t n_targets, const char *t_ascii, const int64_t *toff, const int32_t *tlen, int32_t min_depth,
+                char *out, int64_t cap, int64_t *out_off, int32_t *out_len)
+{
+    poa_t *g = (poa_t*)malloc(sizeof(poa_t));
+    int16_t *H = (int16_t*)malloc(sizeof(int16_t) * (size_t)(POA_MAXNODE + 1) * (POA_SEGMAX + 1)), *rank = (int16_t*)malloc(2 * POA_MAXNODE);
+    uint8_t *seg = (uint8_t*)malloc((size_t)POA_MAXSEG * POA_SEGMAX); int seglen[POA_MAXSEG];
+    char *wout = (char*)malloc(POA_MAXNODE);
+    /* records by target, in record order */
+    int64_t *first = (int64_t*)calloc(n_targets + 1, 8), *idx = (int64_t*)malloc(8 * (n_aln ? n_aln : 1));
+    for (int64_t i = 0; i < n_aln; ++i) if (!(alns[i].flags & (TELR_F_SECONDARY | TELR_F_SUPPL))) ++first[alns[i].tid + 1];
+    for (int32_t t = 0; t < n_targets; ++t) first[t + 1] += first[t];
+    { int64_t *fill = (int64_t*)malloc(8 * (n_targets + 1)); memcpy(fill, first, 8 * (n_targets + 1));
+      for (int64_t i = 0; i < n_aln; ++i) if (!(alns[i].flags & (TELR_F_SECONDARY | TELR_F_SUPPL))) idx[fill[alns[i].tid]++] = i;
+      free(fill); }
+    int64_t w = 0;
+    for (int32_t t = 0; t < n_targets; ++t) {
+        out_off[t] = w;
+        const char *ts = t_ascii + toff[t];
+        for (int32_t w0 = 0; w0 < tlen[t]; w0 += POA_W) {
+            const int32_t w1 = w0 + POA_W < tlen[t] ? w0 + POA_W : tlen[t];
+            int nseg = 0;
+            for (int64_t z = first[t]; z < first[t + 1] && nseg < POA_MAXSEG; ++z) {
+                const telr_aln *r = &alns[idx[z]];
+                if (r->ts > w0 || r->te < w1) continue;                     /* the record must cover the window whole */
+                const int rev = (r->flags & TELR_F_REV) != 0;
+                const uint8_t *q = q_nt4 + qoff[r->qid];
+                int32_t qi = rev ? r->qlen - r->qe : r->qs, ti = r->ts, qa = -1, qb = -1;
+                for (int32_t c = 0; c < r->n_cigar && qb < 0; ++c) {
+                    const uint32_t cg = cigars[r->cigar_off + c]; const int op = cg & 0xf, l = cg >> 4;
+                    if (op == 1) { qi += l; continue; }
+                    /* an op that consumes target bases [ti, ti + l): the query offset where the target reaches w0 / w1 */
+                    if (qa < 0 && w0 < ti + l) qa = op == 0 ? qi + (w0 - ti) : qi;
+                    if (w1 <= ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
+                    if (op == 0) qi += l;
+                    ti += l;
+                }
+                if (qb < 0) qb = qi;                                         /* the window ends with the record's last target base */
+                const int len = qb - qa;
+                if (qa < 0 || len < (w1 - w0) / 2 || len > POA_SEGMAX) continue;     /* (a piece shorter than half the window: the read lacks what the draft has here) */
+                int ok = 1;
+                for (int x = 0; x < len; ++x) {
+                    int b = rev ? q[r->qlen - 1 - (qa + x)] : q[qa + x];
+                    if (rev && b < 4) b = 3 - b;
+                    if (b > 3) { ok = 0; break; }                             /* a piece with an ambiguous base does not vote */
+                    seg[(size_t)nseg * POA_SEGMAX + x] = (uint8_t)b;
+                }
+                if (!ok) continue;
+                seglen[nseg++] = len;
+            }
+            if (nseg < min_depth) { for (int32_t p = w0; p < w1; ++p) { if (w < cap) out[w] = "ACGTN"[NT4[(uint8_t)ts[p]]]; ++w; } continue; }
+            /* the graph starts as the draft's window */
+            g->n = w1 - w0;
+            for (int v = 0; v < g->n; ++v) {
+                g->base[v] = NT4[(uint8_t)ts[w0 + v]]; g->nin[v] = g->nout[v] = 0; g->ring[v] = (int16_t)v; g->order[v] = (int16_t)v;
+                g->startc[v] = v == 0; g->endc[v] = v == g->n - 1;
+                if (v) { g->in[v][0] = (int16_t)(v - 1); g->inw[v][0] = 1; g->nin[v] = 1; g->nout[v - 1] = 1; }
+            }
+            for (int s = 0; s < nseg; ++s) {
+                if (g->n + seglen[s] > POA_MAXNODE) continue;                 /* the graph could outgrow its arrays: the piece is left out */
+                poa_add_seq(g, seg + (size_t)s * POA_SEGMAX, seglen[s], H, rank);
+            }
+            const int cl = poa_consensus(g, wout);
+            for (int x = 0; x < cl; ++x) { if (w < cap) out[w] = wout[x]; ++w; }
+        }
+        out_len[t] = (int32_t)(w - out_off[t]);
+    }
+    free(g); free(H); free(rank); free(seg); free(wout); free(first); free(idx);
+    return w;
+}

@@ -52,13 +52,13 @@ int main(int argc, char **argv)
         CK(hipEventRecord(ev[0]));
         hipLaunchKernelGGL(k_segsort_classify, dim3((nseg + 255) / 256), dim3(256), 0, 0, A);
         CK(hipEventRecord(ev[1]));
-        hipLaunchKernelGGL((k_segsort<1024, 20, LoadKeys>), grid(1), dim3(1024), 1024 * 20 * 8, 0, A, 6); CK(hipEventRecord(ev[2]));
-        hipLaunchKernelGGL((k_segsort<1024, 8, LoadKeys>), grid(2), dim3(1024), 1024 * 8 * 8, 0, A, 5); CK(hipEventRecord(ev[3]));
-        hipLaunchKernelGGL((k_segsort<512, 8, LoadKeys>), grid(4), dim3(512), 512 * 8 * 8, 0, A, 4); CK(hipEventRecord(ev[4]));
-        hipLaunchKernelGGL((k_segsort<256, 8, LoadKeys>), grid(8), dim3(256), 256 * 8 * 8, 0, A, 3); CK(hipEventRecord(ev[5]));
-        hipLaunchKernelGGL((k_segsort<128, 8, LoadKeys>), grid(16), dim3(128), 128 * 8 * 8, 0, A, 2); CK(hipEventRecord(ev[6]));
-        hipLaunchKernelGGL((k_segsort<64, 8, LoadKeys>), grid(32), dim3(64), 64 * 8 * 8, 0, A, 1); CK(hipEventRecord(ev[7]));
-        hipLaunchKernelGGL((k_segsort<64, 2, LoadKeys>), grid(32), dim3(64), 64 * 2 * 8, 0, A, 0); CK(hipEventRecord(ev[8]));
+        hipLaunchKernelGGL((k_segsort<1024, 20, LoadKeys>), grid(1), dim3(1024), 1024 * 20 * 8, 0, A, 6, LoadKeys()); CK(hipEventRecord(ev[2]));
+        hipLaunchKernelGGL((k_segsort<1024, 8, LoadKeys>), grid(2), dim3(1024), 1024 * 8 * 8, 0, A, 5, LoadKeys()); CK(hipEventRecord(ev[3]));
+        hipLaunchKernelGGL((k_segsort<512, 8, LoadKeys>), grid(4), dim3(512), 512 * 8 * 8, 0, A, 4, LoadKeys()); CK(hipEventRecord(ev[4]));
+        hipLaunchKernelGGL((k_segsort<256, 8, LoadKeys>), grid(8), dim3(256), 256 * 8 * 8, 0, A, 3, LoadKeys()); CK(hipEventRecord(ev[5]));
+        hipLaunchKernelGGL((k_segsort<128, 8, LoadKeys>), grid(16), dim3(128), 128 * 8 * 8, 0, A, 2, LoadKeys()); CK(hipEventRecord(ev[6]));
+        hipLaunchKernelGGL((k_segsort<64, 8, LoadKeys>), grid(32), dim3(64), 64 * 8 * 8, 0, A, 1, LoadKeys()); CK(hipEventRecord(ev[7]));
+        hipLaunchKernelGGL((k_segsort<64, 2, LoadKeys>), grid(32), dim3(64), 64 * 2 * 8, 0, A, 0, LoadKeys()); CK(hipEventRecord(ev[8]));
         CK(hipDeviceSynchronize());
         float tot = 0;
         for (int t = 0; t <= SEGSORT_TIERS; ++t) { float ms; CK(hipEventElapsedTime(&ms, ev[t], ev[t + 1])); best[t] = std::min(best[t], ms); tot += ms; }

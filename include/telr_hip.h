@@ -339,6 +339,13 @@ int  telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *
 typedef struct telr_consensus telr_consensus;
 int  telr_consensus_build(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth,
                           telr_consensus **out);
+/* The same hand-off with a WINDOW PARTIAL-ORDER consensus (opt-in like the pile-up: wtpoa-cns's own source is
+ * absent, this is the published scheme of window POA polishing): the draft is cut into 200-base windows, every primary record
+ * that covers a window whole gives the piece of its read its CIGAR aligns there, the pieces are re-aligned one by one to a graph
+ * that starts as the draft's window (sequence-to-graph DP, one wave per window) and merged into it, the window's consensus is
+ * the heaviest-bundle path.  Unlike the pile-up vote it re-phases columns: it does not trust the pairwise CIGARs inside a window. */
+int  telr_poa_build(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth,
+                    telr_consensus **out);
 int32_t telr_consensus_count(const telr_consensus *c);              /* = number of targets */
 const char *telr_consensus_seq(const telr_consensus *c);             /* concatenated consensus sequences (A C G T N) */
 const int64_t *telr_consensus_off(const telr_consensus *c);

@@ -15,7 +15,7 @@ EXPORTS = [
     "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_from_arrays", "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
-    "telr_init_background", "telr_release_scratch", "telr_device_mem", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_bam_discard", "telr_write_bam_slice", "telr_bam_segment_info", "telr_bam_segment_entries", "telr_bam_segment_write", "telr_bam_segment_free", "telr_bai_write", "telr_result_from_device_cigars", "telr_seqset_packed", "telr_seqset_from_packed", "telr_consensus_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
+    "telr_init_background", "telr_release_scratch", "telr_device_mem", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_bam_discard", "telr_write_bam_slice", "telr_bam_segment_info", "telr_bam_segment_entries", "telr_bam_segment_write", "telr_bam_segment_free", "telr_bai_write", "telr_result_from_device_cigars", "telr_seqset_packed", "telr_seqset_from_packed", "telr_consensus_build", "telr_poa_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
 ]
 
 _lib = None
@@ -78,6 +78,7 @@ def lib():
         getattr(L, fn).restype = vp; getattr(L, fn).argtypes = [vp]
     L.telr_fasta_free.restype = None; L.telr_fasta_free.argtypes = [vp]
     L.telr_consensus_build.restype = C.c_int; L.telr_consensus_build.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp)]
+    L.telr_poa_build.restype = C.c_int; L.telr_poa_build.argtypes = [vp, vp, vp, vp, i32, C.POINTER(vp)]
     L.telr_consensus_count.restype = i32; L.telr_consensus_count.argtypes = [vp]
     for fn in ("telr_consensus_seq", "telr_consensus_off", "telr_consensus_len"):
         getattr(L, fn).restype = vp; getattr(L, fn).argtypes = [vp]

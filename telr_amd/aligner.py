@@ -393,10 +393,12 @@ class Index:
         d.update(zip(("sink_allocate_bg", "sink_map_bg", "sink_wait", "sink_mapping_used", "stream_wait_coder", "stream_wait_dma", "stream_host_copy", "stream_wait_slot", "stream_loop", "sink_stop", "sink_truncate"), (float(x) for x in b)))
         return d
 
-    def consensus(self, r, queries, min_depth=3):
-        """pile-up consensus of this index's targets from the primary records of raw result r (telr_consensus_build) -> list of str"""
+    def consensus(self, r, queries, min_depth=3, poa=False):
+        """consensus of this index's targets from the primary records of raw result r -> list of str: the pile-up vote
+        (telr_consensus_build) or, poa=True, the window partial-order consensus (telr_poa_build)"""
         h = C.c_void_p()
-        self.eng._chk(self.eng.L.telr_consensus_build(self.eng.h, r, queries.h, self.h, int(min_depth), C.byref(h)), "telr_consensus_build")
+        fn, what = (self.eng.L.telr_poa_build, "telr_poa_build") if poa else (self.eng.L.telr_consensus_build, "telr_consensus_build")
+        self.eng._chk(fn(self.eng.h, r, queries.h, self.h, int(min_depth), C.byref(h)), what)
         try:
             L = self.eng.L
             n = int(L.telr_consensus_count(h))

@@ -1,0 +1,347 @@
+// telr_amd/csrc/poa.hip.h -- window partial-order consensus on the device (spec 3.13; oracle/telr_oracle.c: tor_poa).
+//
+// the polishing hand-off H3 (TELR_assembly.py:226-247 pipes `samtools view -F0x900` of the reads->contig
+// alignments into wtpoa-cns).  wtpoa-cns is absent, so this is the published scheme of window POA polishing (Lee 2002; Vaser
+// 2017), not its code: the draft is cut into windows of POA_W bases; every primary record that covers a window whole gives the
+// piece of its read that its CIGAR aligns to the window; the pieces are aligned one after the other to a graph that starts as
+// the draft's window (global sequence-to-graph alignment, linear gap) and merged into it; the window's consensus is the
+// heaviest-bundle path between the nodes most sequences begin / end at.  Opt-in (`polish="poa"`): another consensus can change
+// call sets.  Caps and tie-breaks are the oracle's, bit for bit (tests/test_gpu_consensus.py).
+//
+//   host            the pieces of every window from the records' CIGARs (record order), CSR by window
+//   k_poa_window    ONE WAVE per window (persistent over the window list): the graph and the score matrix live in a slot of
+//                   global scratch (L2-resident for the common window: ~800 nodes x ~220 columns of int16); a node's row is
+//                   computed by all lanes (columns strided over the lanes, the in-row gap chain as a max-plus prefix scan);
+//                   the walk back, the merge and the heaviest-bundle pass are short serial stretches on lane 0.
+// Integer work bounded by instruction issue and L2 latency: no MFMA.
+#pragma once
+
+#define POA_W       200
+#define POA_SEGMAX  400
+#define POA_MAXSEG  64
+#define POA_MAXNODE 2048
+#define POA_MAXIN   8
+#define POA_M       3
+#define POA_X       (-5)
+#define POA_G       (-4)
+
+struct PoaPiece { int32_t qid, qa, len, rev; };           // query bases [qa, qa + len) on the alignment strand
+struct PoaArgs {
+    const PoaPiece *pieces; const int32_t *wptr;          // pieces of window w: [wptr[w], wptr[w + 1]) in record order
+    const int32_t *w_tid, *w_w0, *w_w1; int32_t nwin, min_depth;
+    const uint32_t *q2, *qn; const int64_t *qboff; const int32_t *qlen;
+    const uint32_t *t2, *tn; const int64_t *tboff;
+    uint8_t *scratch; size_t slot_bytes;                  // one slot per resident wave
+    uint8_t *wout; int32_t *wlen;                         // consensus of window w: wout[w * POA_MAXNODE ...], wlen[w]
+};
+// slot layout (bytes)
+#define POA_O_BASE   0                                    /* u8  [MAXNODE] */
+#define POA_O_NIN    (POA_O_BASE + POA_MAXNODE)           /* u8  [MAXNODE] */
+#define POA_O_NOUT   (POA_O_NIN + POA_MAXNODE)            /* i16 [MAXNODE] */
+#define POA_O_IN     (POA_O_NOUT + 2 * POA_MAXNODE)       /* i16 [MAXNODE][MAXIN] */
+#define POA_O_INW    (POA_O_IN + 2 * POA_MAXNODE * POA_MAXIN)
+#define POA_O_RING   (POA_O_INW + 2 * POA_MAXNODE * POA_MAXIN)
+#define POA_O_ORDER  (POA_O_RING + 2 * POA_MAXNODE)
+#define POA_O_RANK   (POA_O_ORDER + 2 * POA_MAXNODE)
+#define POA_O_STARTC (POA_O_RANK + 2 * POA_MAXNODE)
+#define POA_O_ENDC   (POA_O_STARTC + 2 * POA_MAXNODE)
+#define POA_O_BP     (POA_O_ENDC + 2 * POA_MAXNODE)
+#define POA_O_NO     (POA_O_BP + 2 * POA_MAXNODE)
+#define POA_O_SCORE  (POA_O_NO + 2 * POA_MAXNODE)         /* i32 [MAXNODE] */
+#define POA_O_PN     (POA_O_SCORE + 4 * POA_MAXNODE)      /* i16 [MAXNODE + SEGMAX + 2] */
+#define POA_NPATH    (POA_MAXNODE + POA_SEGMAX + 8)
+#define POA_O_PJ     (POA_O_PN + 2 * POA_NPATH)
+#define POA_O_NEWV   (POA_O_PJ + 2 * POA_NPATH)           /* i16 [SEGMAX + 8] */
+#define POA_O_ANCH   (POA_O_NEWV + 2 * (POA_SEGMAX + 8))
+#define POA_O_H      ((POA_O_ANCH + 2 * (POA_SEGMAX + 8) + 255) & ~255)      /* i16 [(MAXNODE + 1)][SEGMAX + 1] */
+#define POA_SLOT_BYTES ((size_t)POA_O_H + 2 * (size_t)(POA_MAXNODE + 1) * (POA_SEGMAX + 1))
+
+__device__ __forceinline__ int d_poa_qbase(const PoaArgs &A, const PoaPiece &P, int x)
+{
+    // base x of the piece on the alignment strand (a reverse record reads its query mirrored and complemented)
+    const int64_t b0 = A.qboff[P.qid]; const int ql = A.qlen[P.qid];
+    const int pos = P.rev ? ql - 1 - (P.qa + x) : P.qa + x;
+    int b = d_base(A.q2, A.qn, b0 + pos);
+    if (P.rev && b < 4) b = 3 - b;
+    return b;
+}
+
+__global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
+{
+    __shared__ uint8_t seq[POA_SEGMAX + 8];
+    __shared__ int32_t sel[POA_MAXSEG];
+    __shared__ int32_t sh[8];
+    const int lane = threadIdx.x;
+    uint8_t *S = A.scratch + (size_t)blockIdx.x * A.slot_bytes;
+    uint8_t *base = S + POA_O_BASE, *nin = S + POA_O_NIN;
+    int16_t *nout = (int16_t*)(S + POA_O_NOUT), *in = (int16_t*)(S + POA_O_IN), *inw = (int16_t*)(S + POA_O_INW), *ring = (int16_t*)(S + POA_O_RING);
+    int16_t *order = (int16_t*)(S + POA_O_ORDER), *rank = (int16_t*)(S + POA_O_RANK), *startc = (int16_t*)(S + POA_O_STARTC), *endc = (int16_t*)(S + POA_O_ENDC);
+    int16_t *bp = (int16_t*)(S + POA_O_BP), *no = (int16_t*)(S + POA_O_NO), *pn = (int16_t*)(S + POA_O_PN), *pj = (int16_t*)(S + POA_O_PJ);
+    int16_t *newv = (int16_t*)(S + POA_O_NEWV), *anchor = (int16_t*)(S + POA_O_ANCH), *H = (int16_t*)(S + POA_O_H);
+    int32_t *score = (int32_t*)(S + POA_O_SCORE);
+    for (int w = blockIdx.x; w < A.nwin; w += gridDim.x) {
+        const int tid = A.w_tid[w], w0 = A.w_w0[w], w1 = A.w_w1[w], L = w1 - w0;
+        const int64_t tb0 = A.tboff[tid];
+        uint8_t *out = A.wout + (size_t)w * POA_MAXNODE;
+        // ---- the pieces that vote: the first POA_MAXSEG without an ambiguous base, in record order
+        int nsel = 0;
+        for (int c = A.wptr[w]; c < A.wptr[w + 1] && nsel < POA_MAXSEG; ++c) {
+            const PoaPiece P = A.pieces[c];
+            bool bad = false;
+            for (int x = lane; x < P.len; x += 64) bad |= d_poa_qbase(A, P, x) > 3;
+            if (!__any(bad)) { if (lane == 0) sel[nsel] = c; ++nsel; }
+        }
+        __syncthreads();
+        if (nsel < A.min_depth) {
+            for (int x = lane; x < L; x += 64) out[x] = "ACGTN"[d_base(A.t2, A.tn, tb0 + w0 + x)];
+            if (lane == 0) A.wlen[w] = L;
+            __syncthreads();
+            continue;
+        }
+        // ---- the graph starts as the draft's window
+        int n = L;
+        for (int v = lane; v < L; v += 64) {
+            base[v] = (uint8_t)d_base(A.t2, A.tn, tb0 + w0 + v); nin[v] = v ? 1 : 0; nout[v] = v < L - 1 ? 1 : 0; ring[v] = (int16_t)v; order[v] = (int16_t)v;
+            startc[v] = v == 0; endc[v] = v == L - 1;
+            if (v) { in[v * POA_MAXIN] = (int16_t)(v - 1); inw[v * POA_MAXIN] = 1; }
+        }
+        __syncthreads();
+        for (int si = 0; si < nsel; ++si) {
+            const PoaPiece P = A.pieces[sel[si]];
+            const int m = P.len, stride = m + 1;
+            if (n + m > POA_MAXNODE) continue;
+            for (int x = lane; x < m; x += 64) seq[x] = (uint8_t)d_poa_qbase(A, P, x);
+            for (int r = lane; r < n; r += 64) rank[order[r]] = (int16_t)(r + 1);
+            for (int j = lane; j <= m; j += 64) H[j] = (int16_t)(j * POA_G);
+            __syncthreads();
+            // ---- sweep: one row per node, in topological order
+            for (int r = 0; r < n; ++r) {
+                const int v = order[r];
+                const int np_ = nin[v] ? nin[v] : 1;
+                int16_t *row = H + (size_t)(r + 1) * stride;
+                int carry = -1000000;                      // max over the columns before this chunk of (T[k] - k G)
+                for (int j0 = 0; j0 <= m; j0 += 64) {
+                    const int j = j0 + lane;
+                    int t = -32000;
+                    if (j <= m) {
+                        const int sb = j > 0 ? seq[j - 1] : 4;
+                        const int sc = sb == base[v] && sb < 4 ? POA_M : POA_X;
+                        for (int k = 0; k < np_; ++k) {
+                            const int16_t *pr = H + (size_t)(nin[v] ? rank[in[v * POA_MAXIN + k]] : 0) * stride;
+                            int c = pr[j] + POA_G; t = c > t ? c : t;
+                            if (j > 0) { c = pr[j - 1] + sc; t = c > t ? c : t; }
+                        }
+                    }
+                    // row[j] = max over k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
+                    int u = j <= m ? t - j * POA_G : -1000000;
+#pragma unroll
+                    for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(u, s); if (lane >= s) u = o > u ? o : u; }
+                    u = carry > u ? carry : u;
+                    if (j <= m) row[j] = (int16_t)(u + j * POA_G);
+                    carry = __shfl(u, 63);
+                }
+                __syncthreads();                            // the next node's predecessors may be this row
+            }
+            // ---- the end: the node without out-edges whose last column scores best, smallest id on ties
+            {
+                int bs = -32768, bv = 0x7fffffff;
+                for (int v = lane; v < n; v += 64) if (!nout[v]) { const int sc = H[(size_t)rank[v] * stride + m]; if (sc > bs) { bs = sc; bv = v; } }
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) { const int os = __shfl_xor(bs, s), ov = __shfl_xor(bv, s); if (os > bs || (os == bs && ov < bv)) { bs = os; bv = ov; } }
+                if (lane == 0) sh[0] = bv == 0x7fffffff ? -1 : bv;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                // ---- walk back: diagonal from the first predecessor that explains the cell, else node skipped, else base inserted
+                int np = 0, v = sh[0], j = m;
+                while (v >= 0 || j > 0) {
+                    if (v < 0) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; continue; }
+                    const int16_t *row = H + (size_t)rank[v] * stride;
+                    const int cur = row[j], npred = nin[v] ? nin[v] : 1;
+                    bool moved = false;
+                    if (j > 0) {
+                        const int sc = seq[j - 1] == base[v] && seq[j - 1] < 4 ? POA_M : POA_X;
+                        for (int k = 0; k < npred && !moved; ++k) {
+                            const int p = nin[v] ? in[v * POA_MAXIN + k] : -1;
+                            if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j - 1] + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = true; }
+                        }
+                    }
+                    for (int k = 0; k < npred && !moved; ++k) {
+                        const int p = nin[v] ? in[v * POA_MAXIN + k] : -1;
+                        if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j] + POA_G == cur) { v = p; moved = true; }
+                    }
+                    if (!moved) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; }
+                }
+                // ---- merge, start -> end (placement rules: see the oracle)
+                const int n_old = n;
+                int prev = -1, nnew = 0, behind = -1;
+                for (int z = np - 1; z >= 0; --z) {
+                    const uint8_t b = seq[pj[z]];
+                    const int x = pn[z];
+                    int u = -1;
+                    if (x >= 0) {
+                        if (base[x] == b) u = x;
+                        else for (int s_ = ring[x]; s_ != x; s_ = ring[s_]) if (base[s_] == b) { u = s_; break; }
+                    }
+                    if (u < 0) {
+                        u = n++;
+                        base[u] = b; nin[u] = 0; nout[u] = 0; ring[u] = (int16_t)u; startc[u] = 0; endc[u] = 0;
+                        newv[nnew] = (int16_t)u; anchor[nnew] = (int16_t)(x >= 0 ? rank[x] - 1 : behind); ++nnew;
+                        if (x >= 0) { ring[u] = ring[x]; ring[x] = (int16_t)u; }
+                    }
+                    if (x >= 0) {
+                        int mm = rank[x] - 1;
+                        for (int s_ = ring[x]; s_ != x; s_ = ring[s_]) if (s_ < n_old && rank[s_] - 1 > mm) mm = rank[s_] - 1;
+                        behind = mm;
+                    }
+                    if (prev >= 0) {
+                        bool found = false;
+                        for (int k = 0; k < nin[u]; ++k) if (in[u * POA_MAXIN + k] == prev) { ++inw[u * POA_MAXIN + k]; found = true; break; }
+                        if (!found && nin[u] < POA_MAXIN) { in[u * POA_MAXIN + nin[u]] = (int16_t)prev; inw[u * POA_MAXIN + nin[u]] = 1; ++nin[u]; ++nout[prev]; }
+                    } else ++startc[u];
+                    prev = u;
+                }
+                if (prev >= 0) ++endc[prev];
+                if (nnew) {
+                    const int nold = n - nnew;
+                    int k = 0, o = 0;
+                    while (k < nnew && anchor[k] < 0) no[o++] = newv[k++];
+                    for (int i = 0; i < nold; ++i) { no[o++] = order[i]; while (k < nnew && anchor[k] == i) no[o++] = newv[k++]; }
+                }
+                sh[1] = n; sh[2] = nnew;
+            }
+            __syncthreads();
+            n = sh[1];
+            if (sh[2]) { for (int i = lane; i < n; i += 64) order[i] = no[i]; }
+            __syncthreads();
+        }
+        // ---- heaviest bundle between the most common start / end nodes
+        if (lane == 0) {
+            for (int r = 0; r < n; ++r) {
+                const int v = order[r];
+                int bw = -1, bs = -1, b = -1;
+                for (int k = 0; k < nin[v]; ++k) {
+                    const int u = in[v * POA_MAXIN + k], wgt = inw[v * POA_MAXIN + k];
+                    if (wgt > bw || (wgt == bw && score[u] > bs)) { bw = wgt; bs = score[u]; b = u; }
+                }
+                bp[v] = (int16_t)b; score[v] = b >= 0 ? bs + bw : 0;
+            }
+            int endv = -1, startv = -1;
+            for (int v = 0; v < n; ++v) {
+                if (endv < 0 || endc[v] > endc[endv] || (endc[v] == endc[endv] && score[v] > score[endv])) endv = v;
+                if (startv < 0 || startc[v] > startc[startv]) startv = v;
+            }
+            int cl = 0;
+            for (int v = endv; v >= 0; v = bp[v]) { no[cl++] = (int16_t)v; if (v == startv) break; }
+            for (int i = 0; i < cl; ++i) out[i] = "ACGTN"[base[no[cl - 1 - i]]];
+            A.wlen[w] = cl;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------------
+static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth, telr_consensus **out)
+{
+    if (!ctx || !r || !queries || !idx || !idx->targets || !out || min_depth < 0) return TELR_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    result_wait(r);
+    hipStream_t st = ctx->stream;
+    const telr_seqset *tg = idx->targets;
+    const int32_t nt = tg->n;
+    for (const telr_aln &a : r->alns) if (a.qid < 0 || a.qid >= queries->n || a.tid < 0 || a.tid >= nt) return TELR_E_ARG;
+    // windows
+    std::vector<int64_t> wbase((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) wbase[t + 1] = wbase[t] + (tg->len[t] + POA_W - 1) / POA_W;
+    const int64_t nwin = wbase[nt];
+    telr_consensus *C = new telr_consensus();
+    C->off.assign((size_t)nt, 0); C->len.assign((size_t)nt, 0);
+    if (nwin == 0) { *out = C; return TELR_OK; }
+    if (nwin >= (1LL << 31) / POA_MAXNODE * 64) { delete C; return TELR_E_RANGE; }
+    std::vector<int32_t> w_tid((size_t)nwin), w_w0((size_t)nwin), w_w1((size_t)nwin);
+    for (int t = 0; t < nt; ++t) for (int64_t k = wbase[t]; k < wbase[t + 1]; ++k) {
+        w_tid[k] = t; w_w0[k] = (int32_t)((k - wbase[t]) * POA_W); w_w1[k] = std::min(w_w0[k] + POA_W, tg->len[t]);
+    }
+    // the pieces, record by record (the walk of oracle/telr_oracle.c: tor_poa), then grouped by window keeping the record order
+    struct Cand { int64_t win; PoaPiece p; };
+    std::vector<Cand> cand;
+    for (const telr_aln &a : r->alns) {
+        if (a.flags & (TELR_F_SECONDARY | TELR_F_SUPPL)) continue;
+        const bool rev = (a.flags & TELR_F_REV) != 0;
+        const int32_t tl = tg->len[a.tid];
+        for (int32_t w0 = (a.ts + POA_W - 1) / POA_W * POA_W; w0 < tl; w0 += POA_W) {
+            const int32_t w1 = std::min(w0 + POA_W, tl);
+            if (a.te < w1) break;
+            int32_t qi = rev ? a.qlen - a.qe : a.qs, ti = a.ts, qa = -1, qb = -1;
+            for (int32_t c = 0; c < a.n_cigar && qb < 0; ++c) {
+                const uint32_t cg = r->cig[a.cigar_off + c]; const int op = cg & 0xf, l = (int)(cg >> 4);
+                if (op == 1) { qi += l; continue; }
+                if (qa < 0 && w0 < ti + l) qa = op == 0 ? qi + (w0 - ti) : qi;
+                if (w1 <= ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
+                if (op == 0) qi += l;
+                ti += l;
+            }
+            if (qb < 0) qb = qi;
+            const int len = qb - qa;
+            if (qa < 0 || len < (w1 - w0) / 2 || len > POA_SEGMAX) continue;
+            Cand cd; cd.win = wbase[a.tid] + w0 / POA_W; cd.p.qid = a.qid; cd.p.qa = qa; cd.p.len = len; cd.p.rev = rev ? 1 : 0;
+            cand.push_back(cd);
+        }
+    }
+    std::vector<int32_t> wptr((size_t)nwin + 1, 0);
+    for (const Cand &c : cand) ++wptr[c.win + 1];
+    for (int64_t k = 0; k < nwin; ++k) wptr[k + 1] += wptr[k];
+    std::vector<PoaPiece> pieces(cand.size());
+    { std::vector<int32_t> fill(wptr.begin(), wptr.end() - 1); for (const Cand &c : cand) pieces[fill[c.win]++] = c.p; }
+    const int nslot = (int)std::min<int64_t>(nwin, 256 * 8 * 4);
+    PoaArgs A; memset(&A, 0, sizeof(A));
+    PoaPiece *d_p; int32_t *d_wptr, *d_wt, *d_w0, *d_w1, *d_wlen; uint8_t *d_scr, *d_wout;
+    int rc;
+    auto fail = [&](int code) { delete C; return code; };
+    if ((rc = ctx_buf_t(ctx, "poa_pieces", pieces.size() + 1, &d_p)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_wptr", (size_t)nwin + 1, &d_wptr)) != TELR_OK ||
+        (rc = ctx_buf_t(ctx, "poa_wt", (size_t)nwin, &d_wt)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_w0", (size_t)nwin, &d_w0)) != TELR_OK ||
+        (rc = ctx_buf_t(ctx, "poa_w1", (size_t)nwin, &d_w1)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_wlen", (size_t)nwin, &d_wlen)) != TELR_OK ||
+        (rc = ctx_buf_t(ctx, "poa_scratch", (size_t)nslot * POA_SLOT_BYTES, &d_scr)) != TELR_OK ||
+        (rc = ctx_buf_t(ctx, "poa_wout", (size_t)nwin * POA_MAXNODE, &d_wout)) != TELR_OK) return fail(rc);
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx->err = std::string(#x) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP); } } while (0)
+    if (!pieces.empty()) CK(hipMemcpyAsync(d_p, pieces.data(), pieces.size() * sizeof(PoaPiece), hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_wptr, wptr.data(), ((size_t)nwin + 1) * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_wt, w_tid.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_w0, w_w0.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(d_w1, w_w1.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
+    A.pieces = d_p; A.wptr = d_wptr; A.w_tid = d_wt; A.w_w0 = d_w0; A.w_w1 = d_w1; A.nwin = (int32_t)nwin; A.min_depth = min_depth;
+    A.q2 = queries->d_seq2; A.qn = queries->d_nmask; A.qboff = queries->d_boff; A.qlen = queries->d_len;
+    A.t2 = tg->d_seq2; A.tn = tg->d_nmask; A.tboff = tg->d_boff;
+    A.scratch = d_scr; A.slot_bytes = POA_SLOT_BYTES; A.wout = d_wout; A.wlen = d_wlen;
+    hipLaunchKernelGGL(k_poa_window, dim3((unsigned)nslot), dim3(64), 0, st, A);
+    CK(hipGetLastError());
+    std::vector<int32_t> wlen((size_t)nwin);
+    std::vector<uint8_t> wout((size_t)nwin * POA_MAXNODE);
+    CK(hipMemcpyAsync(wlen.data(), d_wlen, (size_t)nwin * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(wout.data(), d_wout, wout.size(), hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+#undef CK
+    int64_t tot = 0;
+    for (int64_t k = 0; k < nwin; ++k) tot += wlen[k];
+    C->seq.resize((size_t)tot);
+    int64_t o = 0;
+    for (int t = 0; t < nt; ++t) {
+        C->off[t] = o;
+        for (int64_t k = wbase[t]; k < wbase[t + 1]; ++k) { memcpy(&C->seq[(size_t)o], &wout[(size_t)k * POA_MAXNODE], (size_t)wlen[k]); o += wlen[k]; }
+        C->len[t] = (int32_t)(o - C->off[t]);
+    }
+    *out = C;
+    return TELR_OK;
+}
+extern "C" int telr_poa_build(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth, telr_consensus **out)
+{
+    (void)hipGetLastError();
+    int rc = poa_impl(ctx, r, queries, idx, min_depth, out);
+    if (rc == TELR_E_NOMEM) {
+        (void)hipGetLastError();
+        mem_note(ctx, "telr_poa_build: out of memory");
+        ctx_release_map_scratch(ctx, (uint64_t)256 * 8 * 4 * POA_SLOT_BYTES + ((uint64_t)1 << 30));
+        rc = poa_impl(ctx, r, queries, idx, min_depth, out);
+    }
+    return rc;
+}

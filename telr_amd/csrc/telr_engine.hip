@@ -3181,3 +3181,4 @@ extern "C" int telr_write_bam(const telr_result *r, int32_t n_queries, const cha
 #include "bam_dev.hip.h"
 #include "fasta_io.hip.h"
 #include "pileup.hip.h"
+#include "poa.hip.h"

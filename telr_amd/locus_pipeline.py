@@ -19,16 +19,17 @@ def run_loci_impl(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_s
     """loci: list of dicts(name, contig, alt, reads).  With `read_set` (the stage-1 read SeqSet resident on the
     device) a locus gives `read_idx` (indices into it) instead of `reads`.  polish="pileup": the draft contigs are first
     polished on the device with the locus' reads (telr_assembly.polish_consensus: the polishing loop of
-    TELR_assembly.py:185-262 with a pile-up consensus in the place of wtpoa-cns -- a different algorithm, hence opt-in).
+    TELR_assembly.py:185-262 with a pile-up consensus in the place of wtpoa-cns -- a different algorithm, hence opt-in);
+    polish="poa": the same with the window partial-order consensus (spec 3.13).
     -> dict(annotation, liftover, summary, af[, contigs])"""
-    if polish == "pileup" and loci:
+    if polish in ("pileup", "poa") and loci:
         from . import telr_assembly
         rs = [l["read_idx"] if read_set is not None else l["reads"] for l in loci]
         pol = telr_assembly.polish_consensus(backend, [l["name"] for l in loci], [l["contig"] for l in loci], rs, presets=presets,
-                                             iterations=polish_iterations, read_set=read_set)
+                                             iterations=polish_iterations, read_set=read_set, method=polish)
         loci = [dict(l, contig=c) for l, c in zip(loci, pol)]
     elif polish not in (None, "", "none"):
-        raise ValueError("polish must be None or 'pileup'")
+        raise ValueError("polish must be None, 'pileup' or 'poa'")
     names = [l["name"] for l in loci]
     contigs = {l["name"]: l["contig"] for l in loci}
     reads_by_locus = {l["name"]: (l["read_idx"] if read_set is not None else l["reads"]) for l in loci}

@@ -118,14 +118,18 @@ def polish_alignments(engine, contig_names, contig_seqs, reads_by_locus, read_na
     return ["".join(mapped[k]) + "".join(unmapped[k]) for k in range(len(contig_names))], res.alns, res.cigars
 
 
-def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets="ont", iterations=1, min_depth=3, read_set=None):
+def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets="ont", iterations=1, min_depth=3, read_set=None, method="pileup"):
     """The polishing loop of `run_wtdbg2_polishing` (TELR_assembly.py:185-262) with the consensus made on the device: per
     iteration ONE engine call maps the reads of every locus to its draft contig (`-ax P -r2k`, as S3) and ONE pile-up pass over
     the primary records (`-F0x900`) rewrites all contigs (`telr_consensus_build`: majority vote per position, spec 3.12).
     This is NOT wtpoa-cns's partial-order alignment -- a different consensus algorithm can change call sets, which is why the
     locus pipeline only uses it on request (`polish="pileup"`).  reads_by_locus[k]: read sequences, or -- with `read_set`, the
     stage-1 SeqSet resident on the device -- read indices (gathered on the device, as in telr_af.get_af).
+    method="poa": the window partial-order consensus instead (`telr_poa_build`, spec 3.13: the reads are re-aligned to a graph of
+    each 200-base window; closer to what wtpoa-cns does, still not its code).
     -> list of polished contig sequences (a contig no read maps to stays as it is)."""
+    if method not in ("pileup", "poa"):
+        raise ValueError("method must be 'pileup' or 'poa'")
     from .presets import preset
     io, mo = preset("map-pb" if presets == "pacbio" else "map-ont")
     mo.bw = 2000
@@ -142,7 +146,7 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
         ix = engine.index(contigs, io)
         r = ix.map_raw(qset, mo, qtarget=qt)
         try:
-            contigs = ix.consensus(r, qset, min_depth=min_depth)
+            contigs = ix.consensus(r, qset, min_depth=min_depth, poa=method == "poa")
         finally:
             ix.free_raw(r)
             ix.free()

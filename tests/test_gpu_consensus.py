@@ -68,3 +68,48 @@ def test_polish_consensus_moves_the_drafts_to_the_truth(engine):
     d0, d1 = diffs(drafts), diffs(out)
     assert d0 >= 400 and d1 <= d0 // 5, (d0, d1)
     assert out[5] == drafts[5]
+
+
+@pytest.mark.parametrize("seed,pname", [(1, "map-ont"), (2, "map-pb")])
+def test_hip_poa_equals_oracle(engine, seed, pname):
+    """the window partial-order consensus (telr_poa_build: k_poa_window, one wave per window) against the oracle's tor_poa,
+    string for string: the same pieces, the same graphs, the same heaviest-bundle paths"""
+    truths, drafts, reads = _loci(seed, n_loci=6, depth=24)
+    io, mo = preset(pname); mo.bw = 2000
+    qt = np.array([k for k, rs in enumerate(reads) for _ in rs], np.int32)
+    flat = [r for rs in reads for r in rs]
+    ix = engine.index(drafts, io)
+    qset = engine.seqset(flat)
+    r = ix.map_raw(qset, mo, qtarget=qt)
+    try:
+        res = ix.result_arrays(r)
+        for md in (3, 1, 12):
+            got = ix.consensus(r, qset, min_depth=md, poa=True)
+            want = ob.consensus(res.alns, res.cigars, flat, drafts, min_depth=md, poa=True)
+            assert got == want, [(i, len(got[i]), len(want[i])) for i in range(len(got)) if got[i] != want[i]]
+    finally:
+        ix.free_raw(r)
+    assert got[5] == drafts[5].upper().replace("R", "N") or got[5] == drafts[5]        # nothing mapped: the draft stays
+    assert got[3].upper() == got[3]
+
+
+def test_polish_poa_against_the_pile_up(engine):
+    truths, drafts, reads = _loci(7, n_loci=8, depth=40)
+    names = ["c%d" % i for i in range(8)]
+    pile = telr_assembly.polish_consensus(engine, names, drafts, reads, presets="ont", iterations=1)
+    poa = telr_assembly.polish_consensus(engine, names, drafts, reads, presets="ont", iterations=1, method="poa")
+    io2, mo2 = preset("asm10")
+
+    def diffs(seqs):
+        tot = 0
+        for k, s in enumerate(seqs):
+            if k == 5:
+                continue
+            a = engine.index([s], io2).map([truths[k]], mo2).alns
+            a = a[(a["flags"] & 1) != 0][0]
+            tot += int(a["blen"] - a["mlen"])
+        return tot
+    d0, d1, d2 = diffs(drafts), diffs(pile), diffs(poa)
+    print("differences to the truth over 7 contigs: drafts %d, pile-up %d, POA %d" % (d0, d1, d2))
+    assert d0 >= 400 and d2 <= d0 // 5 and d2 <= d1 + 10, (d0, d1, d2)
+    assert poa[5] == drafts[5]

@@ -884,6 +884,16 @@ def main():
                 polish = {"seconds": tp, "loci_per_s": len(loci) / tp, "contigs_changed": int(sum(1 for x, y in zip(pol, ctg) if x != y)),
                           "bases_before": int(sum(len(x) for x in ctg)), "bases_after": int(sum(len(x) for x in pol)),
                           "what": "one telr_map (-ax P -r2k, window reads of every locus against its draft contig) + one pile-up consensus pass over all contigs"}
+                # the same hand-off with the window partial-order consensus (telr_poa_build)
+                try:
+                    sync(); t0p = time.time()
+                    pol2 = telr_assembly.polish_consensus(eng, names_p, ctg, [w.astype(np.int32) for w in wr_p], presets=presets_arg, read_set=qs, method="poa")
+                    sync(); tp2 = time.time() - t0p
+                    polish["poa"] = {"seconds": tp2, "loci_per_s": len(loci) / tp2, "contigs_changed": int(sum(1 for x, y in zip(pol2, ctg) if x != y)),
+                                     "bases_after": int(sum(len(x) for x in pol2)), "differs_from_pileup": int(sum(1 for x, y in zip(pol2, pol) if x != y)),
+                                     "what": "one telr_map + one window partial-order consensus pass (200-base windows, one wave per window)"}
+                except Exception as e:
+                    polish["poa"] = {"error": "%s: %s" % (type(e).__name__, e)}
             except Exception as e:
                 polish = {"error": "%s: %s" % (type(e).__name__, e)}
         wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]

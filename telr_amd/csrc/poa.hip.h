@@ -53,7 +53,9 @@ struct PoaArgs {
 #define POA_O_PJ     (POA_O_PN + 2 * POA_NPATH)
 #define POA_O_NEWV   (POA_O_PJ + 2 * POA_NPATH)           /* i16 [SEGMAX + 8] */
 #define POA_O_ANCH   (POA_O_NEWV + 2 * (POA_SEGMAX + 8))
-#define POA_O_H      ((POA_O_ANCH + 2 * (POA_SEGMAX + 8) + 255) & ~255)      /* i16 [(MAXNODE + 1)][SEGMAX + 1] */
+#define POA_O_PROW   ((POA_O_ANCH + 2 * (POA_SEGMAX + 8) + 15) & ~15)       /* i16 [MAXNODE][MAXIN]: rows of the predecessors of the node at rank r */
+#define POA_O_PCB    (POA_O_PROW + 2 * POA_MAXNODE * POA_MAXIN)             /* i16 [MAXNODE]: predecessors << 8 | base of the node at rank r */
+#define POA_O_H      ((POA_O_PCB + 2 * POA_MAXNODE + 255) & ~255)           /* i16 [(MAXNODE + 1)][SEGMAX + 1] */
 #define POA_SLOT_BYTES ((size_t)POA_O_H + 2 * (size_t)(POA_MAXNODE + 1) * (POA_SEGMAX + 1))
 
 __device__ __forceinline__ int d_poa_qbase(const PoaArgs &A, const PoaPiece &P, int x)
@@ -79,6 +81,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
     int16_t *bp = (int16_t*)(S + POA_O_BP), *no = (int16_t*)(S + POA_O_NO), *pn = (int16_t*)(S + POA_O_PN), *pj = (int16_t*)(S + POA_O_PJ);
     int16_t *newv = (int16_t*)(S + POA_O_NEWV), *anchor = (int16_t*)(S + POA_O_ANCH), *H = (int16_t*)(S + POA_O_H);
     int32_t *score = (int32_t*)(S + POA_O_SCORE);
+    int16_t *prow = (int16_t*)(S + POA_O_PROW), *pcb = (int16_t*)(S + POA_O_PCB);
     for (int w = blockIdx.x; w < A.nwin; w += gridDim.x) {
         const int tid = A.w_tid[w], w0 = A.w_w0[w], w1 = A.w_w1[w], L = w1 - w0;
         const int64_t tb0 = A.tboff[tid];
@@ -114,10 +117,20 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             for (int r = lane; r < n; r += 64) rank[order[r]] = (int16_t)(r + 1);
             for (int j = lane; j <= m; j += 64) H[j] = (int16_t)(j * POA_G);
             __syncthreads();
+            // per RANK: the rows of the node's predecessors and (count << 8 | base) -- the sweep then reads two sequential tables, one
+            // node ahead, instead of chasing order -> in-list -> rank inside every step (a single wave waits out every dependent load)
+            for (int r = lane; r < n; r += 64) {
+                const int v = order[r], c = nin[v];
+                pcb[r] = (int16_t)((c ? c : 1) << 8 | base[v]);
+                for (int k = 0; k < (c ? c : 1); ++k) prow[r * POA_MAXIN + k] = c ? rank[in[v * POA_MAXIN + k]] : 0;
+            }
+            __syncthreads();
             // ---- sweep: one row per node, in topological order
+            int nx_cb = pcb[0]; uint32_t nx_p01 = *(const uint32_t*)&prow[0];
             for (int r = 0; r < n; ++r) {
-                const int v = order[r];
-                const int np_ = nin[v] ? nin[v] : 1;
+                const int cb = nx_cb, np_ = cb >> 8, vb = cb & 0xff;
+                const uint32_t p01 = nx_p01;
+                if (r + 1 < n) { nx_cb = pcb[r + 1]; nx_p01 = *(const uint32_t*)&prow[(r + 1) * POA_MAXIN]; }
                 int16_t *row = H + (size_t)(r + 1) * stride;
                 int carry = -1000000;                      // max over the columns before this chunk of (T[k] - k G)
                 for (int j0 = 0; j0 <= m; j0 += 64) {
@@ -125,9 +138,10 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                     int t = -32000;
                     if (j <= m) {
                         const int sb = j > 0 ? seq[j - 1] : 4;
-                        const int sc = sb == base[v] && sb < 4 ? POA_M : POA_X;
+                        const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
                         for (int k = 0; k < np_; ++k) {
-                            const int16_t *pr = H + (size_t)(nin[v] ? rank[in[v * POA_MAXIN + k]] : 0) * stride;
+                            const int pr_row = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : (int)prow[r * POA_MAXIN + k];
+                            const int16_t *pr = H + (size_t)pr_row * stride;
                             int c = pr[j] + POA_G; t = c > t ? c : t;
                             if (j > 0) { c = pr[j - 1] + sc; t = c > t ? c : t; }
                         }

@@ -127,7 +127,7 @@ def test_locus_bundle_equals_oracle_other_seeds(engine, seed, n_ins, reads_per_l
 
 
 def test_bundle_with_device_polishing_recovers_the_same_loci(engine):
-    """polish="pileup" (telr_consensus_build in the place of wtpoa-cns, opt-in): the drafts carry 0.5 % residual error; polished
+    """polish="pileup" / polish="poa" (telr_consensus_build / telr_poa_build in the place of wtpoa-cns, opt-in): the drafts carry 0.5 % residual error; polished
     with their reads (both alleles: reads of the reference allele cross the element with one long D, which does not vote) they
     give the same insertion calls, and the contigs did change"""
     from locus_data import make_loci
@@ -152,5 +152,16 @@ def test_bundle_with_device_polishing_recovers_the_same_loci(engine):
     # every contig keeps its element: the length changes by small-indel corrections only
     for l in loci:
         assert abs(len(b["contigs"][l["name"]]) - len(l["contig"])) <= 0.004 * len(l["contig"]) + 10
+    # the window partial-order consensus in the same place (round 4, polish="poa"): the same calls again, the element kept
+    c = locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, presets="ont", polish="poa")
+    kc = key(c)
+    assert len(kc) == len(ka)
+    for x, y in zip(ka, kc):
+        assert x[:3] == y[:3] and x[4:] == y[4:] and abs(x[3] - y[3]) <= 20, (x, y)
+    check_truth(c, loci, truth)
+    print("sum of |call - truth| with the POA consensus:", err(kc))
+    assert err(kc) <= err(ka)
+    for l in loci:
+        assert abs(len(c["contigs"][l["name"]]) - len(l["contig"])) <= 0.004 * len(l["contig"]) + 10
     with pytest.raises(ValueError):
-        locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, polish="poa")
+        locus_pipeline.run_loci(engine, ref_ix, ["chr2L"], lambda ch: ref, loci, lib_names, lib, polish="racon")

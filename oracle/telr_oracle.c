@@ -1469,6 +1469,7 @@ int64_t tor_consensus(const telr_aln *alns, int64_t n_aln, const uint32_t *cigar
 #define POA_MAXSEG  64      /* pieces per window (the first ones in record order) */
 #define POA_MAXNODE 2048
 #define POA_MAXIN   8       /* in-edges per node; an edge beyond that is not recorded */
+#define POA_MAXINDEL 30     /* a longer D / I run is a structural difference: its piece does not vote (CONS_MAXDEL of the pile-up) */
 #define POA_M       3
 #define POA_X       (-5)
 #define POA_G       (-4)
@@ -1632,17 +1633,22 @@ int64_t tor_poa(const telr_aln *alns, int64_t n_aln, const uint32_t *cigars, con
                 if (r->ts > w0 || r->te < w1) continue;                     /* the record must cover the window whole */
                 const int rev = (r->flags & TELR_F_REV) != 0;
                 const uint8_t *q = q_nt4 + qoff[r->qid];
-                int32_t qi = rev ? r->qlen - r->qe : r->qs, ti = r->ts, qa = -1, qb = -1;
+                /* the piece = query bases [qa, qb): qa / qb = the query offset where the target first reaches w0 / w1 (at the first op
+                 * that consumes a target base beyond it), so that a read's pieces tile it and an insertion at a window border belongs to
+                 * the window before it.  A D or I run longer than POA_MAXINDEL that touches the window is a structural difference (a read
+                 * of the other allele), not an error of the draft: the piece does not vote (the pile-up's rule, spec 3.12). */
+                int32_t qi = rev ? r->qlen - r->qe : r->qs, ti = r->ts, qa = -1, qb = -1, big = 0;
                 for (int32_t c = 0; c < r->n_cigar && qb < 0; ++c) {
                     const uint32_t cg = cigars[r->cigar_off + c]; const int op = cg & 0xf, l = cg >> 4;
-                    if (op == 1) { qi += l; continue; }
-                    /* an op that consumes target bases [ti, ti + l): the query offset where the target reaches w0 / w1 */
+                    if (op == 1) { if (l > POA_MAXINDEL && ti > w0 && ti <= w1) big = 1; qi += l; continue; }
                     if (qa < 0 && w0 < ti + l) qa = op == 0 ? qi + (w0 - ti) : qi;
-                    if (w1 <= ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
+                    if (w1 < ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
+                    if (op == 2 && l > POA_MAXINDEL && ti < w1 && ti + l > w0) big = 1;
                     if (op == 0) qi += l;
                     ti += l;
                 }
-                if (qb < 0) qb = qi;                                         /* the window ends with the record's last target base */
+                if (qb < 0) qb = qi;                                         /* the record ends with the window */
+                if (big) continue;
                 const int len = qb - qa;
                 if (qa < 0 || len < (w1 - w0) / 2 || len > POA_SEGMAX) continue;     /* (a piece shorter than half the window: the read lacks what the draft has here) */
                 int ok = 1;

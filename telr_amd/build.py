@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libtelrhip.so")
 SOURCES = ["telr_engine.hip"]
-DEPS = SOURCES + ["kernels.hip.h", "bam_dev.hip.h", "fasta_io.hip.h", "pileup.hip.h", "../../include/telr_hip.h"]
+DEPS = sorted(f for f in os.listdir(SRC) if f.endswith((".hip", ".h"))) + ["../../include/telr_hip.h"]          # every source and header under csrc/
 
 
 def needs_build():

@@ -21,6 +21,7 @@
 #define POA_MAXSEG  64
 #define POA_MAXNODE 2048
 #define POA_MAXIN   8
+#define POA_MAXINDEL 30
 #define POA_M       3
 #define POA_X       (-5)
 #define POA_G       (-4)
@@ -286,16 +287,18 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
         for (int32_t w0 = (a.ts + POA_W - 1) / POA_W * POA_W; w0 < tl; w0 += POA_W) {
             const int32_t w1 = std::min(w0 + POA_W, tl);
             if (a.te < w1) break;
-            int32_t qi = rev ? a.qlen - a.qe : a.qs, ti = a.ts, qa = -1, qb = -1;
+            int32_t qi = rev ? a.qlen - a.qe : a.qs, ti = a.ts, qa = -1, qb = -1; bool big = false;
             for (int32_t c = 0; c < a.n_cigar && qb < 0; ++c) {
                 const uint32_t cg = r->cig[a.cigar_off + c]; const int op = cg & 0xf, l = (int)(cg >> 4);
-                if (op == 1) { qi += l; continue; }
+                if (op == 1) { if (l > POA_MAXINDEL && ti > w0 && ti <= w1) big = true; qi += l; continue; }
                 if (qa < 0 && w0 < ti + l) qa = op == 0 ? qi + (w0 - ti) : qi;
-                if (w1 <= ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
+                if (w1 < ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
+                if (op == 2 && l > POA_MAXINDEL && ti < w1 && ti + l > w0) big = true;
                 if (op == 0) qi += l;
                 ti += l;
             }
             if (qb < 0) qb = qi;
+            if (big) continue;
             const int len = qb - qa;
             if (qa < 0 || len < (w1 - w0) / 2 || len > POA_SEGMAX) continue;
             Cand cd; cd.win = wbase[a.tid] + w0 / POA_W; cd.p.qid = a.qid; cd.p.qa = qa; cd.p.len = len; cd.p.rev = rev ? 1 : 0;

@@ -67,7 +67,7 @@ def run_loci_impl(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_s
         if job is not None:
             job.release()
     out = {"annotation": ann, "liftover": reports, "summary": summary, "af": freqs}
-    if polish == "pileup":
+    if polish in ("pileup", "poa"):
         out["contigs"] = contigs
     return out
 

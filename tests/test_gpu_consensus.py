@@ -113,3 +113,25 @@ def test_polish_poa_against_the_pile_up(engine):
     print("differences to the truth over 7 contigs: drafts %d, pile-up %d, POA %d" % (d0, d1, d2))
     assert d0 >= 400 and d2 <= d0 // 5 and d2 <= d1 + 10, (d0, d1, d2)
     assert poa[5] == drafts[5]
+
+
+def test_hip_poa_equals_oracle_on_two_allele_loci(engine):
+    """the same comparison where the reads come from TWO alleles (tests/locus_data.py: half of the reads lack the element the
+    contig carries and cross it with one long D): pieces under the long-indel rule, windows at the junctions"""
+    from locus_data import make_loci
+    ref, lib_names, lib, loci, truth = make_loci()
+    io, mo = preset("map-ont"); mo.bw = 2000
+    drafts = [l["contig"] for l in loci]
+    qt = np.array([k for k, l in enumerate(loci) for _ in l["reads"]], np.int32)
+    flat = [r for l in loci for r in l["reads"]]
+    ix = engine.index(drafts, io)
+    qset = engine.seqset(flat)
+    r = ix.map_raw(qset, mo, qtarget=qt)
+    try:
+        res = ix.result_arrays(r)
+        got = ix.consensus(r, qset, min_depth=3, poa=True)
+        want = ob.consensus(res.alns, res.cigars, flat, drafts, min_depth=3, poa=True)
+        bad = [(i, len(got[i]), len(want[i]), next((p for p in range(min(len(got[i]), len(want[i]))) if got[i][p] != want[i][p]), -1)) for i in range(len(got)) if got[i] != want[i]]
+        assert not bad, bad
+    finally:
+        ix.free_raw(r)

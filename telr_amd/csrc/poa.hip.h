@@ -310,7 +310,14 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     for (int64_t k = 0; k < nwin; ++k) wptr[k + 1] += wptr[k];
     std::vector<PoaPiece> pieces(cand.size());
     { std::vector<int32_t> fill(wptr.begin(), wptr.end() - 1); for (const Cand &c : cand) pieces[fill[c.win]++] = c.p; }
-    const int nslot = (int)std::min<int64_t>(nwin, 256 * 8 * 4);
+    // one slot per RESIDENT wave (a wave beyond that would start when the others have done all their windows: twice the time)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_poa_window, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+    hipDeviceProp_t prop; int ncu = 256;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    int64_t want = (int64_t)per_cu * ncu;
+    if (const char *e = getenv("TELR_POA_SLOTS")) { const long v = atol(e); if (v > 0) want = v; }          // experiments
+    const int nslot = (int)std::min<int64_t>(nwin, want);
     PoaArgs A; memset(&A, 0, sizeof(A));
     PoaPiece *d_p; int32_t *d_wptr, *d_wt, *d_w0, *d_w1, *d_wlen; uint8_t *d_scr, *d_wout;
     int rc;
@@ -357,7 +364,7 @@ extern "C" int telr_poa_build(telr_ctx *ctx, const telr_result *r, const telr_se
     if (rc == TELR_E_NOMEM) {
         (void)hipGetLastError();
         mem_note(ctx, "telr_poa_build: out of memory");
-        ctx_release_map_scratch(ctx, (uint64_t)256 * 8 * 4 * POA_SLOT_BYTES + ((uint64_t)1 << 30));
+        ctx_release_map_scratch(ctx, (uint64_t)256 * 32 * POA_SLOT_BYTES + ((uint64_t)1 << 30));
         rc = poa_impl(ctx, r, queries, idx, min_depth, out);
     }
     return rc;

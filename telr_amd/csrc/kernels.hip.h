@@ -1214,120 +1214,6 @@ __global__ void k_peaks(const int32_t *__restrict__ q_aoff, const int32_t *__res
 
 struct ChainRec { int32_t score, cnt, a_off, pad; uint64_t a0, a1; };   // 32 B
 
-// back-tracking, one wave per query: predecessor deltas (1..256, 0 = none) and visited marks are staged in
-// LDS, lane 0 walks the sorted peaks at LDS latency and records the anchor indices of the chain, then all
-// lanes copy the chain's anchors (coalesced gather/scatter).
-#define BT_CAP 8192
-// The back-tracking state of one query lives in LDS (one uint16 per anchor: the number of resident queries per CU is what
-// bounds this stage, so the list of walked anchors goes to a global scratch).  Two launches share this body: the bulk
-// launch gives every query 16 KB (BT_CAP anchors) and leaves the longer ones to a second, concurrent launch whose blocks
-// own the whole 160 KB of a CU (BT_CAP_BIG anchors); only beyond that does a single lane chase pointers in global memory.
-#define BT_CAP_BIG 65000
-// PT = uint8_t when the look-back is at most 128 anchors (deltas fit a byte: twice the resident queries again), else uint16_t
-template <typename PT>
-__device__ __forceinline__ void d_backtrack_query(int q, int cap, bool defer_big, PT *pdel, uint16_t *gidx, int32_t *sh,
-                                                  const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff,
-                                                  const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
-                                                  const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
-                                                  uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains)
-{
-    constexpr int VISITED = (PT)~(PT)0;
-    const int lane = threadIdx.x;
-    const int64_t base = q_aoff[q];
-    const int n = q_aoff[q + 1] - q_aoff[q], np = n_peaks[q];
-    ChainRec *out = rec + ch_off[q];
-    uint16_t *idx = gidx + base;          // anchor indices of the chain being walked: written by lane 0, read back by all lanes
-    if (n > cap) {
-        if (defer_big) return;
-        if (lane == 0) {
-            int nch = 0, wr = 0;
-            for (int t = 0; t < np; ++t) {
-                int i = (int)(uint32_t)(pk[base + t] & 0xffffffffu);
-                if (vis[base + i]) continue;
-                int cnt = 0, j = i;
-                while (j >= 0 && !vis[base + j]) { vis[base + j] = 1; ++cnt; j = p[base + j]; }
-                int sc = f[base + i] - (j >= 0 ? f[base + j] : 0);
-                if (sc < min_sc || cnt < min_cnt) continue;
-                j = i;
-                for (int z = cnt - 1; z >= 0; --z) { canch[base + wr + z] = keys[base + j]; j = p[base + j]; }
-                ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr; r.pad = 0;
-                r.a0 = canch[base + wr]; r.a1 = canch[base + wr + cnt - 1];
-                out[nch++] = r; wr += cnt;
-            }
-            n_chains[q] = nch;
-        }
-        return;
-    }
-    for (int i = lane; i < n; i += 64) { int pj = p[base + i]; pdel[i] = (PT)(pj < 0 ? 0 : i - pj); }
-    __syncthreads();
-    int nch = 0, wr = 0;
-    for (int tb = 0; tb < np; tb += 64) {
-        // 64 sorted peaks per round, one coalesced load; the peak's f is encoded in its sort key
-        const uint64_t mykey = tb + lane < np ? pk[base + tb + lane] : 0;
-        const int nt = np - tb < 64 ? np - tb : 64;
-        for (int u = 0; u < nt; ++u) {
-            const uint64_t key = d_readlane64(mykey, u);
-            const int i = (int)(uint32_t)(key & 0xffffffffu), fi = 0x7fffffff - (int)(uint32_t)(key >> 32);
-            if (pdel[i] == VISITED) continue;                       // uniform: already on a chain
-            if (lane == 0) {
-                int cnt = 0, j = i;
-                while (j >= 0) {
-                    const int d = pdel[j];
-                    if (d == VISITED) break;                          // reached a visited anchor
-                    pdel[j] = (PT)VISITED;
-                    idx[cnt++] = (uint16_t)j;
-                    j = d ? j - d : -1;
-                }
-                sh[0] = cnt; sh[1] = j;
-                __threadfence_block();
-            }
-            __syncthreads();
-            const int cnt = sh[0], j = sh[1];
-            const int sc = fi - (j >= 0 ? f[base + j] : 0);
-            if (sc >= min_sc && cnt >= min_cnt) {
-                for (int z = lane; z < cnt; z += 64) canch[base + wr + cnt - 1 - z] = keys[base + idx[z]];
-                if (lane == 0) {
-                    ChainRec r; r.score = sc; r.cnt = cnt; r.a_off = wr; r.pad = 0;
-                    r.a0 = keys[base + idx[cnt - 1]]; r.a1 = keys[base + i];
-                    out[nch] = r;
-                }
-                ++nch; wr += cnt;
-            }
-            __syncthreads();
-        }
-    }
-    if (lane == 0) n_chains[q] = nch;
-}
-template <typename PT>
-__global__ void __launch_bounds__(64) k_backtrack_w(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                                    const int32_t *__restrict__ f, const int32_t *__restrict__ p, const uint64_t *__restrict__ pk,
-                                                    const int32_t *__restrict__ n_peaks, const int32_t *__restrict__ ch_off, int32_t min_sc, int32_t min_cnt,
-                                                    uint8_t *__restrict__ vis, uint64_t *__restrict__ canch, ChainRec *__restrict__ rec, int32_t *__restrict__ n_chains,
-                                                    const int32_t *__restrict__ q_order, int32_t cap, const int32_t *__restrict__ big_list, const int32_t *__restrict__ big_cnt,
-                                                    uint16_t *__restrict__ idx)
-{
-    extern __shared__ uint16_t bt_lds[];
-    __shared__ int32_t sh[2];
-    PT *pdel = (PT*)bt_lds;
-    if (big_list) {      // second launch: the queries the bulk launch leaves out, a few blocks looping over the list
-        const int nb = *big_cnt;
-        for (int e = blockIdx.x; e < nb; e += gridDim.x) {
-            d_backtrack_query<PT>(big_list[e], cap, false, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
-            __syncthreads();
-        }
-        return;
-    }
-    if ((int)blockIdx.x >= nq) return;
-    d_backtrack_query<PT>(q_order ? q_order[blockIdx.x] : blockIdx.x, cap, true, pdel, idx, sh, keys, q_aoff, f, p, pk, n_peaks, ch_off, min_sc, min_cnt, vis, canch, rec, n_chains);
-}
-// queries with lo < anchors <= hi (one list per LDS tier of the list launches)
-__global__ void k_bt_big(const int32_t *__restrict__ q_aoff, int32_t nq, int32_t lo, int32_t hi, int32_t *__restrict__ big_list, int32_t *__restrict__ big_cnt)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    const int n = q_aoff[q + 1] - q_aoff[q];
-    if (n > lo && n <= hi) big_list[atomicAdd(big_cnt, 1)] = q;
-}
 
 // ---- back-tracking without a walker (round 2).  The predecessor links form a forest (p[i] < i, i - p[i] <= look-back).
 // Visiting the peaks in rank order (f descending, index ascending) and walking up until a visited anchor is the same as:

@@ -1725,8 +1725,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     // ---- peaks + back-tracking ----------------------------------------------------------------
     StageTimer t_bt(ctx, ST_BACKTRACK, true);
     uint8_t *d_flags; uint64_t *d_pk, *d_pk2, *d_canch; int32_t *d_npk, *d_pkend, *d_choff, *d_nch;
-    TRY(ctx_buf_t(ctx, "flags", (size_t)na * 2 + 16, &d_flags));   // nonpeak | vis
-    uint8_t *d_nonpeak = d_flags, *d_vis = d_flags + na;
+    TRY(ctx_buf_t(ctx, "flags", (size_t)na + 16, &d_flags));
+    uint8_t *d_nonpeak = d_flags;
     TRY(ctx_buf_t(ctx, "pk", (size_t)na, &d_pk));
     TRY(ctx_buf_t(ctx, "pk2", (size_t)na, &d_pk2));
     TRY(ctx_buf_t(ctx, "canch", (size_t)na, &d_canch));
@@ -1734,7 +1734,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "pk_end", (size_t)nq + 1, &d_pkend));
     TRY(ctx_buf_t(ctx, "ch_off", (size_t)nq + 1, &d_choff));
     TRY(ctx_buf_t(ctx, "n_chains", (size_t)nq + 1, &d_nch));
-    HIPCHK(hipMemsetAsync(d_flags, 0, getenv("TELR_BT_WALKER") ? (size_t)na * 2 + 16 : (size_t)na + 16, st));      // the visited marks only serve the round-1 walker
+    HIPCHK(hipMemsetAsync(d_flags, 0, (size_t)na + 16, st));
     hipLaunchKernelGGL(k_nonpeak, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_p, d_nonpeak);
     hipLaunchKernelGGL(k_peaks, dim3(nq), dim3(256), 0, st, d_qaoff, d_f, d_nonpeak, mo->min_chain_score, d_pk, d_npk, d_pkend);
     HIPCHK(hipGetLastError());
@@ -1746,8 +1746,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipStreamSynchronize(st));
     ChainRec *d_rec;
     TRY(ctx_buf_t(ctx, "chain_rec", (size_t)npk_tot, &d_rec));
-    static const bool bt_walker = getenv("TELR_BT_WALKER") != nullptr;      // the round-1 kernel (lane 0 walks), kept for A/B runs
-    if (!bt_walker) {
+    {
         // owner / depth sweeps (kernels.hip.h, "back-tracking without a walker"): five launches over all queries, longest first
         uint32_t *d_owner; int32_t *d_depth, *d_chtop, *d_chaoff;
         TRY(ctx_buf_t(ctx, "bt_owner", (size_t)na + 1, &d_owner));
@@ -1762,48 +1761,6 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                            d_owner, d_depth, d_chtop, d_chaoff, d_rec, d_nch, d_qorder);
         hipLaunchKernelGGL(k_bt_scatter, dim3(nq), dim3(256), 0, st, d_skeys, d_qaoff, d_owner, d_depth, d_chaoff, d_canch, d_qorder);
         HIPCHK(hipGetLastError());
-    } else
-    {
-        // queries with more than BT_CAP anchors run from lists, in two LDS tiers on side streams under the bulk launch
-        // (repeat-rich genomes put a third of the reads there): the stage is bound by resident queries per CU, so a query
-        // should not hold more LDS than its tier needs
-        static const int BT_CAP_MID = 24576;
-        int32_t *d_big; TRY(ctx_buf_t(ctx, "bt_big", 2 * ((size_t)nq + 1), &d_big));      // per tier: [0] count, then the list
-        int32_t *d_mid = d_big, *d_far = d_big + nq + 1;
-        uint16_t *d_btidx; TRY(ctx_buf_t(ctx, "bt_idx", (size_t)na + 1, &d_btidx));
-        HIPCHK(hipMemsetAsync(d_mid, 0, 4, st)); HIPCHK(hipMemsetAsync(d_far, 0, 4, st));
-        hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP, BT_CAP_MID, d_mid + 1, d_mid);
-        hipLaunchKernelGGL(k_bt_big, dim3((nq + 255) / 256), dim3(256), 0, st, d_qaoff, nq, BT_CAP_MID, 0x7fffffff, d_far + 1, d_far);
-        HIPCHK(hipGetLastError());
-        // one byte of LDS per anchor when the look-back fits a byte (the bulk launch then keeps 20 queries per CU resident)
-        const bool pt8 = mo->chain_lookback <= 128;
-        const size_t psz = pt8 ? 1 : 2;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG));
-            HIPCHK(hipFuncSetAttribute((const void*)k_backtrack_w<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_CAP_BIG * 2));
-            attr_set = true;
-        }
-        HIPCHK(hipEventRecord(ctx->ev_fork, st));
-        for (int tier = 1; tier >= 0; --tier) {      // the largest queries first
-            hipStream_t s2 = ctx->side[tier];
-            const int cap = tier ? BT_CAP_BIG : BT_CAP_MID, grid = tier ? 512 : 1536;
-            const int32_t *lst = tier ? d_far : d_mid;
-            HIPCHK(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-            if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(grid), dim3(64), (size_t)cap * psz, s2, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                                        mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap, lst + 1, lst, d_btidx);
-            else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(grid), dim3(64), (size_t)cap * psz, s2, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                                    mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, cap, lst + 1, lst, d_btidx);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(ctx->ev_side[tier], s2));
-        }
-        if (pt8) hipLaunchKernelGGL(k_backtrack_w<uint8_t>, dim3(nq), dim3(64), (size_t)BT_CAP * psz, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                                    mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
-        else hipLaunchKernelGGL(k_backtrack_w<uint16_t>, dim3(nq), dim3(64), (size_t)BT_CAP * psz, st, d_skeys, d_qaoff, nq, d_f, d_p, d_pk2, d_npk, d_choff,
-                                mo->min_chain_score, mo->min_cnt, d_vis, d_canch, d_rec, d_nch, d_qorder, BT_CAP, (const int32_t*)nullptr, (const int32_t*)nullptr, d_btidx);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[0], 0));
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[1], 0));
     }
     HIPCHK(hipGetLastError());
     // Pass-1 chain selection runs on the device (k_select1); TELR_HOST_SELECT=1 keeps the round-1 host version for A/B runs.

@@ -1469,6 +1469,7 @@ int64_t tor_consensus(const telr_aln *alns, int64_t n_aln, const uint32_t *cigar
 #define POA_MAXSEG  64      /* pieces per window (the first ones in record order) */
 #define POA_MAXNODE 2048
 #define POA_MAXIN   8       /* in-edges per node; an edge beyond that is not recorded */
+#define POA_BAND    64      /* cells per node row: the piece's positions within ~32 of where the node's column falls on the piece */
 #define POA_MAXINDEL 30     /* a longer D / I run is a structural difference: its piece does not vote (CONS_MAXDEL of the pile-up) */
 #define POA_M       3
 #define POA_X       (-5)
@@ -1481,6 +1482,8 @@ typedef struct {
     int16_t ring[POA_MAXNODE];               /* next node aligned to the same column (circular; itself when alone) */
     int16_t order[POA_MAXNODE];              /* topological order */
     int16_t startc[POA_MAXNODE], endc[POA_MAXNODE];      /* sequences (the draft's window included) that begin / end at the node */
+    int16_t col[POA_MAXNODE];                /* the window column the node belongs to (a new node: that of the node it is aligned to / put behind) */
+    int L;                                   /* columns of the window */
 } poa_t;
 static void poa_add_edge(poa_t *g, int u, int v)
 {
@@ -1489,49 +1492,58 @@ static void poa_add_edge(poa_t *g, int u, int v)
     g->in[v][g->nin[v]] = (int16_t)u; g->inw[v][g->nin[v]] = 1; ++g->nin[v]; ++g->nout[u];
 }
 /* align seq[0..n) to the graph and merge it in; H is scratch of (nodes + 1) x (n + 1) */
+/* The score matrix is BANDED: the row of a node holds POA_BAND cells, the piece's positions [lo, lo + POA_BAND) with
+ * lo = clamp((col + 1) * n / L - POA_BAND / 2, 0, max(0, n + 1 - POA_BAND)) -- around where the node's column falls on the piece
+ * when piece and window are stretched onto each other (a 200-base window of a 10 %-error read drifts by a few bases, never 32);
+ * every cell outside a row's band counts as -32000.  Row 0 (the virtual start) is j * gap and not stored. */
+static inline int poa_lo(int col, int n, int L) { int lo = (col + 1) * n / L - POA_BAND / 2, hi = n + 1 - POA_BAND; if (lo > hi) lo = hi; return lo < 0 ? 0 : lo; }
+static inline int poa_cell(const int16_t *H, const int16_t *lo, int row, int j, int n)
+{
+    if (row == 0) return j * POA_G;
+    const int jj = j - lo[row - 1];
+    return (jj < 0 || jj >= POA_BAND || j > n) ? -32000 : H[(size_t)(row - 1) * POA_BAND + jj];
+}
 static void poa_add_seq(poa_t *g, const uint8_t *seq, int n, int16_t *H, int16_t *rank)
 {
-    const int stride = n + 1;
-    /* row 0 = the virtual start */
-    for (int j = 0; j <= n; ++j) H[j] = (int16_t)(j * POA_G);
-    for (int r = 0; r < g->n; ++r) rank[g->order[r]] = (int16_t)(r + 1);
+    static __thread int16_t lo[POA_MAXNODE];
+    for (int r = 0; r < g->n; ++r) { rank[g->order[r]] = (int16_t)(r + 1); lo[r] = (int16_t)poa_lo(g->col[g->order[r]], n, g->L); }
     for (int r = 0; r < g->n; ++r) {
         const int v = g->order[r];
-        int16_t *row = H + (size_t)(r + 1) * stride;
-        for (int j = 0; j <= n; ++j) {
+        int16_t *row = H + (size_t)r * POA_BAND;
+        const int j0 = lo[r], j1 = j0 + POA_BAND - 1 < n ? j0 + POA_BAND - 1 : n;
+        for (int j = j0; j <= j1; ++j) {
             int best = -32000;
             const int npred = g->nin[v] ? g->nin[v] : 1;
             for (int k = 0; k < npred; ++k) {
-                const int16_t *pr = H + (size_t)(g->nin[v] ? rank[g->in[v][k]] : 0) * stride;
-                int c = pr[j] + POA_G;                                                   /* the node is skipped */
+                const int pr = g->nin[v] ? rank[g->in[v][k]] : 0;
+                int c = poa_cell(H, lo, pr, j, n) + POA_G;                                  /* the node is skipped */
                 if (c > best) best = c;
-                if (j > 0) { c = pr[j - 1] + (seq[j - 1] == g->base[v] && seq[j - 1] < 4 ? POA_M : POA_X); if (c > best) best = c; }
+                if (j > 0) { c = poa_cell(H, lo, pr, j - 1, n) + (seq[j - 1] == g->base[v] && seq[j - 1] < 4 ? POA_M : POA_X); if (c > best) best = c; }
             }
-            if (j > 0) { const int c = row[j - 1] + POA_G; if (c > best) best = c; }      /* the base is inserted */
-            row[j] = (int16_t)best;
+            if (j > j0) { const int c = row[j - 1 - j0] + POA_G; if (c > best) best = c; }  /* the base is inserted */
+            row[j - j0] = (int16_t)best;
         }
     }
     /* the end: the sink with the best score, smallest id on ties */
     int endv = -1, endsc = -32768;
-    for (int v = 0; v < g->n; ++v) if (!g->nout[v]) { const int sc = H[(size_t)rank[v] * stride + n]; if (sc > endsc) endsc = sc, endv = v; }
+    for (int v = 0; v < g->n; ++v) if (!g->nout[v]) { const int sc = poa_cell(H, lo, rank[v], n, n); if (sc > endsc) endsc = sc, endv = v; }
     /* walk back: diagonal from the first pred that explains the cell, else skip-node from the first pred, else inserted base */
     static __thread int16_t pn[POA_MAXNODE + POA_SEGMAX + 2], pj[POA_MAXNODE + POA_SEGMAX + 2];
     int np = 0, v = endv, j = n;
     while (v >= 0 || j > 0) {
         if (v < 0) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; continue; }          /* bases before the graph's start */
-        const int16_t *row = H + (size_t)rank[v] * stride;
-        const int cur = row[j], npred = g->nin[v] ? g->nin[v] : 1;
+        const int cur = poa_cell(H, lo, rank[v], j, n), npred = g->nin[v] ? g->nin[v] : 1;
         int moved = 0;
         if (j > 0) {
             const int sc = seq[j - 1] == g->base[v] && seq[j - 1] < 4 ? POA_M : POA_X;
             for (int k = 0; k < npred && !moved; ++k) {
                 const int p = g->nin[v] ? g->in[v][k] : -1;
-                if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j - 1] + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = 1; }
+                if (poa_cell(H, lo, p >= 0 ? rank[p] : 0, j - 1, n) + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = 1; }
             }
         }
         for (int k = 0; k < npred && !moved; ++k) {
             const int p = g->nin[v] ? g->in[v][k] : -1;
-            if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j] + POA_G == cur) { v = p; moved = 1; }      /* node skipped: nothing to merge */
+            if (poa_cell(H, lo, p >= 0 ? rank[p] : 0, j, n) + POA_G == cur) { v = p; moved = 1; }      /* node skipped: nothing to merge */
         }
         if (!moved) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; }
     }
@@ -1554,6 +1566,7 @@ static void poa_add_seq(poa_t *g, const uint8_t *seq, int n, int16_t *H, int16_t
         if (u < 0) {
             u = g->n++;
             g->base[u] = b; g->nin[u] = g->nout[u] = 0; g->ring[u] = (int16_t)u; g->startc[u] = g->endc[u] = 0;
+            g->col[u] = x >= 0 ? g->col[x] : prev >= 0 ? g->col[prev] : 0;
             newv[nnew] = (int16_t)u; anchor[nnew] = (int16_t)(x >= 0 ? rank[x] - 1 : behind); ++nnew;      /* rank[] is 1-based */
             if (x >= 0) { g->ring[u] = g->ring[x]; g->ring[x] = (int16_t)u; }
         }
@@ -1611,7 +1624,7 @@ int64_t tor_poa(const telr_aln *alns, int64_t n_aln, const uint32_t *cigars, con
                 char *out, int64_t cap, int64_t *out_off, int32_t *out_len)
 {
     poa_t *g = (poa_t*)malloc(sizeof(poa_t));
-    int16_t *H = (int16_t*)malloc(sizeof(int16_t) * (size_t)(POA_MAXNODE + 1) * (POA_SEGMAX + 1)), *rank = (int16_t*)malloc(2 * POA_MAXNODE);
+    int16_t *H = (int16_t*)malloc(sizeof(int16_t) * (size_t)POA_MAXNODE * POA_BAND), *rank = (int16_t*)malloc(2 * POA_MAXNODE);
     uint8_t *seg = (uint8_t*)malloc((size_t)POA_MAXSEG * POA_SEGMAX); int seglen[POA_MAXSEG];
     char *wout = (char*)malloc(POA_MAXNODE);
     /* records by target, in record order */
@@ -1663,10 +1676,10 @@ int64_t tor_poa(const telr_aln *alns, int64_t n_aln, const uint32_t *cigars, con
             }
             if (nseg < min_depth) { for (int32_t p = w0; p < w1; ++p) { if (w < cap) out[w] = "ACGTN"[NT4[(uint8_t)ts[p]]]; ++w; } continue; }
             /* the graph starts as the draft's window */
-            g->n = w1 - w0;
+            g->n = g->L = w1 - w0;
             for (int v = 0; v < g->n; ++v) {
                 g->base[v] = NT4[(uint8_t)ts[w0 + v]]; g->nin[v] = g->nout[v] = 0; g->ring[v] = (int16_t)v; g->order[v] = (int16_t)v;
-                g->startc[v] = v == 0; g->endc[v] = v == g->n - 1;
+                g->startc[v] = v == 0; g->endc[v] = v == g->n - 1; g->col[v] = (int16_t)v;
                 if (v) { g->in[v][0] = (int16_t)(v - 1); g->inw[v][0] = 1; g->nin[v] = 1; g->nout[v - 1] = 1; }
             }
             for (int s = 0; s < nseg; ++s) {

@@ -10,9 +10,11 @@
 //
 //   host            the pieces of every window from the records' CIGARs (record order), CSR by window
 //   k_poa_window    ONE WAVE per window (persistent over the window list): the graph and the score matrix live in a slot of
-//                   global scratch (L2-resident for the common window: ~800 nodes x ~220 columns of int16); a node's row is
-//                   computed by all lanes (columns strided over the lanes, the in-row gap chain as a max-plus prefix scan);
-//                   the walk back, the merge and the heaviest-bundle pass are short serial stretches on lane 0.
+//                   global scratch.  The matrix is BANDED: a node's row holds the POA_BAND = 64 columns around the diagonal
+//                   of the node's window column (d_poa_lo; a piece is at most 30 bases off the diagonal by the POA_MAXINDEL
+//                   rule), i.e. exactly one cell per lane, 128 B per node instead of 2 (m + 1): ~100 KB per window instead
+//                   of ~350 KB.  The in-row gap chain is a max-plus prefix scan over the wave; the walk back, the merge and
+//                   the heaviest-bundle pass are short serial stretches on lane 0.
 // Integer work bounded by instruction issue and L2 latency: no MFMA.
 #pragma once
 
@@ -22,6 +24,7 @@
 #define POA_MAXNODE 2048
 #define POA_MAXIN   8
 #define POA_MAXINDEL 30
+#define POA_BAND    64      /* cells per node row (oracle: poa_lo / poa_cell) */
 #define POA_M       3
 #define POA_X       (-5)
 #define POA_G       (-4)
@@ -55,9 +58,21 @@ struct PoaArgs {
 #define POA_O_NEWV   (POA_O_PJ + 2 * POA_NPATH)           /* i16 [SEGMAX + 8] */
 #define POA_O_ANCH   (POA_O_NEWV + 2 * (POA_SEGMAX + 8))
 #define POA_O_PROW   ((POA_O_ANCH + 2 * (POA_SEGMAX + 8) + 15) & ~15)       /* i16 [MAXNODE][MAXIN]: rows of the predecessors of the node at rank r */
-#define POA_O_PCB    (POA_O_PROW + 2 * POA_MAXNODE * POA_MAXIN)             /* i16 [MAXNODE]: predecessors << 8 | base of the node at rank r */
-#define POA_O_H      ((POA_O_PCB + 2 * POA_MAXNODE + 255) & ~255)           /* i16 [(MAXNODE + 1)][SEGMAX + 1] */
-#define POA_SLOT_BYTES ((size_t)POA_O_H + 2 * (size_t)(POA_MAXNODE + 1) * (POA_SEGMAX + 1))
+#define POA_O_PPLO   (POA_O_PROW + 2 * POA_MAXNODE * POA_MAXIN)             /* i16 [MAXNODE][MAXIN]: first column of those rows' bands */
+#define POA_O_PCB    (POA_O_PPLO + 2 * POA_MAXNODE * POA_MAXIN)             /* i16 [MAXNODE]: predecessors << 8 | base of the node at rank r */
+#define POA_O_COL    (POA_O_PCB + 2 * POA_MAXNODE)                          /* i16 [MAXNODE]: window column of the node */
+#define POA_O_LO     (POA_O_COL + 2 * POA_MAXNODE)                          /* i16 [MAXNODE]: first column of the band of the node at rank r */
+#define POA_O_H      ((POA_O_LO + 2 * POA_MAXNODE + 255) & ~255)            /* i16 [MAXNODE][POA_BAND]: the banded score matrix (row r = the node at rank r) */
+#define POA_SLOT_BYTES ((size_t)POA_O_H + 2 * (size_t)POA_MAXNODE * POA_BAND)
+
+__host__ __device__ __forceinline__ int d_poa_lo(int col, int n, int L) { int lo = (col + 1) * n / L - POA_BAND / 2, hi = n + 1 - POA_BAND; if (lo > hi) lo = hi; return lo < 0 ? 0 : lo; }
+// cell (row, j) of the banded matrix: row 0 = the virtual start, outside a row's band -32000
+__device__ __forceinline__ int d_poa_cell(const int16_t *H, const int16_t *lo, int row, int j, int n)
+{
+    if (row == 0) return j * POA_G;
+    const int jj = j - lo[row - 1];
+    return (jj < 0 || jj >= POA_BAND || j > n) ? -32000 : H[(size_t)(row - 1) * POA_BAND + jj];
+}
 
 __device__ __forceinline__ int d_poa_qbase(const PoaArgs &A, const PoaPiece &P, int x)
 {
@@ -82,7 +97,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
     int16_t *bp = (int16_t*)(S + POA_O_BP), *no = (int16_t*)(S + POA_O_NO), *pn = (int16_t*)(S + POA_O_PN), *pj = (int16_t*)(S + POA_O_PJ);
     int16_t *newv = (int16_t*)(S + POA_O_NEWV), *anchor = (int16_t*)(S + POA_O_ANCH), *H = (int16_t*)(S + POA_O_H);
     int32_t *score = (int32_t*)(S + POA_O_SCORE);
-    int16_t *prow = (int16_t*)(S + POA_O_PROW), *pcb = (int16_t*)(S + POA_O_PCB);
+    int16_t *prow = (int16_t*)(S + POA_O_PROW), *pplo = (int16_t*)(S + POA_O_PPLO), *pcb = (int16_t*)(S + POA_O_PCB), *col = (int16_t*)(S + POA_O_COL), *lo_r = (int16_t*)(S + POA_O_LO);
     for (int w = blockIdx.x; w < A.nwin; w += gridDim.x) {
         const int tid = A.w_tid[w], w0 = A.w_w0[w], w1 = A.w_w1[w], L = w1 - w0;
         const int64_t tb0 = A.tboff[tid];
@@ -106,61 +121,64 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
         int n = L;
         for (int v = lane; v < L; v += 64) {
             base[v] = (uint8_t)d_base(A.t2, A.tn, tb0 + w0 + v); nin[v] = v ? 1 : 0; nout[v] = v < L - 1 ? 1 : 0; ring[v] = (int16_t)v; order[v] = (int16_t)v;
-            startc[v] = v == 0; endc[v] = v == L - 1;
+            startc[v] = v == 0; endc[v] = v == L - 1; col[v] = (int16_t)v;
             if (v) { in[v * POA_MAXIN] = (int16_t)(v - 1); inw[v * POA_MAXIN] = 1; }
         }
         __syncthreads();
         for (int si = 0; si < nsel; ++si) {
             const PoaPiece P = A.pieces[sel[si]];
-            const int m = P.len, stride = m + 1;
+            const int m = P.len;
             if (n + m > POA_MAXNODE) continue;
             for (int x = lane; x < m; x += 64) seq[x] = (uint8_t)d_poa_qbase(A, P, x);
-            for (int r = lane; r < n; r += 64) rank[order[r]] = (int16_t)(r + 1);
-            for (int j = lane; j <= m; j += 64) H[j] = (int16_t)(j * POA_G);
+            for (int r = lane; r < n; r += 64) { const int v = order[r]; rank[v] = (int16_t)(r + 1); lo_r[r] = (int16_t)d_poa_lo(col[v], m, L); }
             __syncthreads();
-            // per RANK: the rows of the node's predecessors and (count << 8 | base) -- the sweep then reads two sequential tables, one
-            // node ahead, instead of chasing order -> in-list -> rank inside every step (a single wave waits out every dependent load)
+            // per RANK: the rows of the node's predecessors, the first columns of their bands and (count << 8 | base) -- the sweep reads
+            // sequential tables, one node ahead, instead of chasing order -> in-list -> rank inside every step
             for (int r = lane; r < n; r += 64) {
                 const int v = order[r], c = nin[v];
                 pcb[r] = (int16_t)((c ? c : 1) << 8 | base[v]);
-                for (int k = 0; k < (c ? c : 1); ++k) prow[r * POA_MAXIN + k] = c ? rank[in[v * POA_MAXIN + k]] : 0;
+                for (int k = 0; k < (c ? c : 1); ++k) {
+                    const int pr = c ? rank[in[v * POA_MAXIN + k]] : 0;
+                    prow[r * POA_MAXIN + k] = (int16_t)pr; pplo[r * POA_MAXIN + k] = pr ? lo_r[pr - 1] : 0;
+                }
             }
             __syncthreads();
-            // ---- sweep: one row per node, in topological order
-            int nx_cb = pcb[0]; uint32_t nx_p01 = *(const uint32_t*)&prow[0];
+            // ---- sweep: one row of POA_BAND cells per node, in topological order: lane l computes column lo + l
+            int nx_cb = pcb[0], nx_lo = lo_r[0]; uint32_t nx_p01 = *(const uint32_t*)&prow[0], nx_l01 = *(const uint32_t*)&pplo[0];
             for (int r = 0; r < n; ++r) {
-                const int cb = nx_cb, np_ = cb >> 8, vb = cb & 0xff;
-                const uint32_t p01 = nx_p01;
-                if (r + 1 < n) { nx_cb = pcb[r + 1]; nx_p01 = *(const uint32_t*)&prow[(r + 1) * POA_MAXIN]; }
-                int16_t *row = H + (size_t)(r + 1) * stride;
-                int carry = -1000000;                      // max over the columns before this chunk of (T[k] - k G)
-                for (int j0 = 0; j0 <= m; j0 += 64) {
-                    const int j = j0 + lane;
-                    int t = -32000;
-                    if (j <= m) {
-                        const int sb = j > 0 ? seq[j - 1] : 4;
-                        const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
-                        for (int k = 0; k < np_; ++k) {
-                            const int pr_row = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : (int)prow[r * POA_MAXIN + k];
-                            const int16_t *pr = H + (size_t)pr_row * stride;
-                            int c = pr[j] + POA_G; t = c > t ? c : t;
-                            if (j > 0) { c = pr[j - 1] + sc; t = c > t ? c : t; }
+                const int cb = nx_cb, np_ = cb >> 8, vb = cb & 0xff, j = nx_lo + lane;
+                const uint32_t p01 = nx_p01, l01 = nx_l01;
+                if (r + 1 < n) { nx_cb = pcb[r + 1]; nx_lo = lo_r[r + 1]; nx_p01 = *(const uint32_t*)&prow[(r + 1) * POA_MAXIN]; nx_l01 = *(const uint32_t*)&pplo[(r + 1) * POA_MAXIN]; }
+                int t = -32000;
+                if (j <= m) {
+                    const int sb = j > 0 ? seq[j - 1] : 4;
+                    const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
+                    for (int k = 0; k < np_; ++k) {
+                        const int pr = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : (int)prow[r * POA_MAXIN + k];
+                        const int pl = k == 0 ? (int)(l01 & 0xffffu) : k == 1 ? (int)(l01 >> 16) : (int)pplo[r * POA_MAXIN + k];
+                        int vj, vj1;
+                        if (pr == 0) { vj = j * POA_G; vj1 = (j - 1) * POA_G; }
+                        else {
+                            const int jj = j - pl;                     // (j <= m here)
+                            const int16_t *prw = H + (size_t)(pr - 1) * POA_BAND;
+                            vj = (jj >= 0 && jj < POA_BAND) ? prw[jj] : -32000;
+                            vj1 = (jj >= 1 && jj <= POA_BAND) ? prw[jj - 1] : -32000;
                         }
+                        int c = vj + POA_G; t = c > t ? c : t;
+                        if (j > 0) { c = vj1 + sc; t = c > t ? c : t; }
                     }
-                    // row[j] = max over k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
-                    int u = j <= m ? t - j * POA_G : -1000000;
-#pragma unroll
-                    for (int s = 1; s < 64; s <<= 1) { const int o = __shfl_up(u, s); if (lane >= s) u = o > u ? o : u; }
-                    u = carry > u ? carry : u;
-                    if (j <= m) row[j] = (int16_t)(u + j * POA_G);
-                    carry = __shfl(u, 63);
                 }
+                // row[j] = max over the band's k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
+                int u = j <= m ? t - j * POA_G : -1000000;
+#pragma unroll
+                for (int s_ = 1; s_ < 64; s_ <<= 1) { const int o = __shfl_up(u, s_); if (lane >= s_) u = o > u ? o : u; }
+                if (j <= m) H[(size_t)r * POA_BAND + lane] = (int16_t)(u + j * POA_G);
                 __syncthreads();                            // the next node's predecessors may be this row
             }
             // ---- the end: the node without out-edges whose last column scores best, smallest id on ties
             {
                 int bs = -32768, bv = 0x7fffffff;
-                for (int v = lane; v < n; v += 64) if (!nout[v]) { const int sc = H[(size_t)rank[v] * stride + m]; if (sc > bs) { bs = sc; bv = v; } }
+                for (int v = lane; v < n; v += 64) if (!nout[v]) { const int sc = d_poa_cell(H, lo_r, rank[v], m, m); if (sc > bs) { bs = sc; bv = v; } }
 #pragma unroll
                 for (int s = 32; s >= 1; s >>= 1) { const int os = __shfl_xor(bs, s), ov = __shfl_xor(bv, s); if (os > bs || (os == bs && ov < bv)) { bs = os; bv = ov; } }
                 if (lane == 0) sh[0] = bv == 0x7fffffff ? -1 : bv;
@@ -171,19 +189,18 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 int np = 0, v = sh[0], j = m;
                 while (v >= 0 || j > 0) {
                     if (v < 0) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; continue; }
-                    const int16_t *row = H + (size_t)rank[v] * stride;
-                    const int cur = row[j], npred = nin[v] ? nin[v] : 1;
+                    const int cur = d_poa_cell(H, lo_r, rank[v], j, m), npred = nin[v] ? nin[v] : 1;
                     bool moved = false;
                     if (j > 0) {
                         const int sc = seq[j - 1] == base[v] && seq[j - 1] < 4 ? POA_M : POA_X;
                         for (int k = 0; k < npred && !moved; ++k) {
                             const int p = nin[v] ? in[v * POA_MAXIN + k] : -1;
-                            if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j - 1] + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = true; }
+                            if (d_poa_cell(H, lo_r, p >= 0 ? rank[p] : 0, j - 1, m) + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = true; }
                         }
                     }
                     for (int k = 0; k < npred && !moved; ++k) {
                         const int p = nin[v] ? in[v * POA_MAXIN + k] : -1;
-                        if (H[(size_t)(p >= 0 ? rank[p] : 0) * stride + j] + POA_G == cur) { v = p; moved = true; }
+                        if (d_poa_cell(H, lo_r, p >= 0 ? rank[p] : 0, j, m) + POA_G == cur) { v = p; moved = true; }
                     }
                     if (!moved) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; }
                 }
@@ -201,6 +218,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                     if (u < 0) {
                         u = n++;
                         base[u] = b; nin[u] = 0; nout[u] = 0; ring[u] = (int16_t)u; startc[u] = 0; endc[u] = 0;
+                        col[u] = x >= 0 ? col[x] : prev >= 0 ? col[prev] : 0;
                         newv[nnew] = (int16_t)u; anchor[nnew] = (int16_t)(x >= 0 ? rank[x] - 1 : behind); ++nnew;
                         if (x >= 0) { ring[u] = ring[x]; ring[x] = (int16_t)u; }
                     }

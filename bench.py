@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preset", default="", help="override the configuration's preset")
     ap.add_argument("--fill-band-q4", type=int, default=0, help="experiment: override the preset's first-pass band factor (0 = preset)")
+    ap.add_argument("--map-opt", default="", help="experiment: map-option fields laid over the preset of the timed map and of the CPU oracle, e.g. cx_scale=20,cx_open=100 (the loci leg keeps its presets)")
     ap.add_argument("--loci", type=int, default=-1, help="candidate loci for the TE-loci/s leg (-1 = all spiked insertions, 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU smoke test of the launcher)")
     ap.add_argument("--data-cache", default="", help="directory: the rank's generated data set is stored there / loaded from there (profiling runs: no forked generator)")
@@ -529,6 +530,9 @@ def main():
     io, mo = preset(pname)
     if a.fill_band_q4:
         mo.fill_band_q4 = a.fill_band_q4
+    for kv in filter(None, a.map_opt.split(",")):
+        k_, v_ = kv.split("=")
+        setattr(mo, k_, type(getattr(mo, k_))(float(v_)))
     ref_strs = [bytes(r).decode() for r in D["ref"]]
     eng = Engine(local)
     t0 = time.time()
@@ -954,7 +958,7 @@ def main():
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
         "dtype": "int16", "data": "synthetic",
         "value_incl_h2d": value_h2d, "value_streaming_incl_h2d": value_stream, "h2d_pack_upload_s": t_upload_max, "h2d_pack_upload_first_call_s": t_upload_first,
-        "config": {"workload": "BASELINE %s: %s, preset %s, stage-1 reads->reference" % (cfg["label"], D["text"], pname),
+        "config": {"workload": "BASELINE %s: %s, preset %s, stage-1 reads->reference" % (cfg["label"], D["text"], pname + (" + experiment " + a.map_opt if a.map_opt else "")),
                    "reads_this_rank": int(len(D["reads"][2])), "read_bases_this_rank": n_bases, "read_bases_job": job_bases,
                    "parallelism": ("one fixed read set dealt to %d ranks in blocks by cumulative bases" % world if a.scaling == "strong" else "every rank maps its own read set (x%d)" % world)
                                   + "; index replicated (built by every rank, no broadcast); no collective on the stage-1 data path",

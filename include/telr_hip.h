@@ -105,8 +105,8 @@ typedef struct telr_map_opt {
      * every score inside the DP (a, b, sc_ambi, zdrop times cx_scale), are in 1/cx_scale of the unit of a / b / dp_score; a
      * record's dp_score is the sum of its segments' scores divided by cx_scale, rounded half up.  ngmlr-ont (NGMLR: match 1,
      * mismatch 1, open 1, extension 1 -> 0.5, decay 0.15; the preset's unit is half of NGMLR's): cx_scale 10, open 20,
-     * ext 20 -> 10, decay 3.  ngmlr-pacbio keeps the two-piece envelope: at its scale (20) a 220-base fill leaves int16; the
-     * oracle's experiment bit 0x80000 measures what that costs (0.18 % of the records' coordinates). */
+     * ext 20 -> 10, decay 3.  ngmlr-pacbio (match 2, mismatch 5, open 5, extension 5 -> 1): cx_scale 20, open 100, ext 100 -> 20,
+     * decay 3.  cx_scale = 0 over either preset gives the two-piece envelope q / e / q2 / e2 of round 3. */
     int32_t cx_scale, cx_open, cx_ext_max, cx_ext_min, cx_decay;
 } telr_map_opt;
 
@@ -171,7 +171,7 @@ int  telr_device_name(const telr_ctx *ctx, char *buf, int buflen);
 /* ---- presets: the -x values the reference passes -------------------------- */
 /* name in {"map-ont","map-pb","asm10","ngmlr-ont","ngmlr-pacbio"}; returns TELR_E_ARG otherwise.
  * ngmlr-*: the stage-1 default of the reference (`ngmlr -x ont|pacbio`, TELR_alignment.py:28-51): (w,k) = (5,13)
- * minimizers (NGMLR's 13-mers at every third position) and NGMLR's convex gap cost as its two-piece affine envelope. */
+ * minimizers (NGMLR's 13-mers at every third position), sub-read voting, NGMLR's convex gap cost in exact form (cx_*). */
 int  telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo);
 
 /* ---- sequence sets --------------------------------------------------------- */

@@ -654,7 +654,7 @@ typedef struct { int score, bi, bj, touched; int64_t cells; } dp_res_t;
 typedef struct convex_s { int S, a, b, amb, open, emax, emin, dec, flat; } convex_t;
 static int convex_of(const telr_map_opt *mo, convex_t *c)
 {
-    if (mo->cx_scale > 0) {                  /* the spec (telr_map_opt.cx_*): ngmlr-ont since round 4 */
+    if (mo->cx_scale > 0) {                  /* the spec (telr_map_opt.cx_*): both ngmlr-* presets since round 4 */
         c->S = mo->cx_scale; c->a = mo->a * c->S; c->b = mo->b * c->S; c->amb = mo->sc_ambi * c->S;
         c->open = mo->cx_open; c->emax = mo->cx_ext_max; c->emin = mo->cx_ext_min; c->dec = mo->cx_decay;
         c->flat = c->dec > 0 && c->emax > c->emin ? (c->emax - c->emin + c->dec - 1) / c->dec : 0;

@@ -2350,7 +2350,7 @@ __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffff
 #define PK_NEG 0xC000C000u
 
 struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF, q2e2F;      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
-                 uint32_t cx_oe0, cx_emax, cx_emin, cx_dec, cx_flat; };        // convex cost (d_cell_pk_cx): open + ext(0), the extension's range, its decay, the length cap
+                 uint32_t cx_oe0, cx_e1, cx_emin, cx_dec; };        // convex cost (d_cell_pk_cx): open + ext(0), ext(1), the extension's floor, its decay
 
 // ONEP (one-piece): in a band of D diagonals no gap run is longer than D - 1, and while (D - 1)(e - e2) < q2 - q the second
 // affine piece q2 + L e2 is STRICTLY dearer than q + L e for every possible run length, so E2 / F2 are strictly below
@@ -2383,22 +2383,22 @@ __device__ __forceinline__ uint32_t d_cell_pk(const PkConst &c, uint32_t hd, uin
     return t | src;
 }
 
-// The cell of the CONVEX gap cost (DpOpt.cx_*; ngmlr-ont): one E and one F state, and in the registers that hold E2 / F2 elsewhere
-// the LENGTH of the gap the state ends with (it travels exactly like its state: same neighbour shifts, same lane exchange).
-//   ext(len) = clamp(emax - dec * len, emin, emax)      (the upper clamp only tames the garbage lengths of cells that are -inf)
-//   E = max(H_left - open - ext(0)  [opened, length 1],  E_left - ext(LE_left)  [extended, length LE_left + 1, capped at `flat`])
+// The cell of the CONVEX gap cost (DpOpt.cx_*; ngmlr-*): one E and one F state, and in the registers that hold E2 / F2 elsewhere
+// what the NEXT base of the gap the state ends with costs, x = ext(length) (it travels exactly like its state: same neighbour
+// shifts, same lane exchange).  The oracle and the scalar cell keep the length itself; ext(len + 1) = max(emin, ext(len) - dec), so
+// carrying the cost is the same function without the multiplication and the clamps:
+//   E = max(H_left - open - ext(0)  [opened: x = ext(1)],  E_left - x_left  [extended: x = max(emin, x_left - dec)])
+// Every value that enters an x register from outside the recurrence (initial state, band edge, first / last lane) is emin, never
+// PK_NEG: x stays inside [emin, emax] and `-inf - x` cannot wrap.
 // Flags as in d_cell_pk (bit 3 / 4: E / F extended, bit 7: bases equal, bits 0-2: source 0 diagonal, 1 E, 2 F): the walks need nothing new.
-__device__ __forceinline__ uint32_t d_cell_pk_cx(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t el, uint32_t lel, uint32_t hu, uint32_t fu, uint32_t lfu,
-                                                 uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve, uint32_t &vf, uint32_t &nle, uint32_t &nlf)
+__device__ __forceinline__ uint32_t d_cell_pk_cx(const PkConst &c, uint32_t hd, uint32_t hl, uint32_t el, uint32_t xel, uint32_t hu, uint32_t fu, uint32_t xfu,
+                                                 uint32_t qb, uint32_t tbv, uint32_t &h, uint32_t &ve, uint32_t &vf, uint32_t &nxe, uint32_t &nxf)
 {
-    const uint32_t one = 0x00010001u;
-    const uint32_t ce = pk_min(c.cx_emax, pk_max(c.cx_emin, pk_sub(c.cx_emax, pk_mul(lel, c.cx_dec))));
-    const uint32_t cf = pk_min(c.cx_emax, pk_max(c.cx_emin, pk_sub(c.cx_emax, pk_mul(lfu, c.cx_dec))));
     uint32_t op, g, m, t;
-    op = pk_sub(hl, c.cx_oe0); g = pk_sub(el, ce); ve = pk_max(op, g); m = pk_sign(pk_sub(op, g)); t  = m & 0x00080008u;
-    nle = pk_sel(m, pk_min(pk_add(lel, one), c.cx_flat), one);
-    op = pk_sub(hu, c.cx_oe0); g = pk_sub(fu, cf); vf = pk_max(op, g); m = pk_sign(pk_sub(op, g)); t |= m & 0x00100010u;
-    nlf = pk_sel(m, pk_min(pk_add(lfu, one), c.cx_flat), one);
+    op = pk_sub(hl, c.cx_oe0); g = pk_sub(el, xel); ve = pk_max(op, g); m = pk_sign(pk_sub(op, g)); t  = m & 0x00080008u;
+    nxe = pk_sel(m, pk_max(pk_sub(xel, c.cx_dec), c.cx_emin), c.cx_e1);
+    op = pk_sub(hu, c.cx_oe0); g = pk_sub(fu, xfu); vf = pk_max(op, g); m = pk_sign(pk_sub(op, g)); t |= m & 0x00100010u;
+    nxf = pk_sel(m, pk_max(pk_sub(xfu, c.cx_dec), c.cx_emin), c.cx_e1);
     const uint32_t eq = pk_sign(pk_sub(qb ^ tbv, 0x00010001u));          // bases equal
     const uint32_t sc = pk_sub(eq & c.ab, c.b);
     t |= eq & 0x00800080u;
@@ -2552,7 +2552,8 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     PkConst c; c.qe = pk_dup(o.q + o.e); c.e = pk_dup(o.e); c.q2e2 = pk_dup(o.q2 + o.e2); c.e2 = pk_dup(o.e2);
     c.ab = pk_dup(o.a + o.b); c.b = pk_dup(o.b); c.a = pk_dup(o.a); c.nab = pk_dup(-(o.a + o.b)); c.qeF = c.qe;
     c.q2e2F = c.q2e2;
-    c.cx_oe0 = pk_dup(o.cx_open + d_cx_ext(o, 0)); c.cx_emax = pk_dup(o.cx_emax); c.cx_emin = pk_dup(o.cx_emin); c.cx_dec = pk_dup(o.cx_dec); c.cx_flat = pk_dup(o.cx_flat);
+    c.cx_oe0 = pk_dup(o.cx_open + d_cx_ext(o, 0)); c.cx_e1 = pk_dup(d_cx_ext(o, 1)); c.cx_emin = pk_dup(o.cx_emin); c.cx_dec = pk_dup(o.cx_dec);
+    const uint32_t XN = CX ? c.cx_emin : PK_NEG;        // what an E2 / F2 register holds outside the recurrence (convex cost: see d_cell_pk_cx)
     if constexpr (TB4) {           // scores times four, provenance tags in the two low bits (d_cell_pk4)
         c.qe = pk_dup(4 * (o.q + o.e) - 2); c.qeF = pk_dup(4 * (o.q + o.e) - 1); c.e = pk_dup(4 * o.e);
         c.a = pk_dup(4 * o.a + 2); c.nab = pk_dup(-4 * (o.a + o.b));
@@ -2568,7 +2569,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     uint32_t He[R], E1e[R], E2e[R], F1e[R], F2e[R], Ho[R], E1o[R], E2o[R], F1o[R], F2o[R], inE[R], inO[R], qb[R], tbv[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        He[r] = E1e[r] = E2e[r] = F1e[r] = F2e[r] = Ho[r] = E1o[r] = E2o[r] = F1o[r] = F2o[r] = PK_NEG;
+        He[r] = E1e[r] = F1e[r] = Ho[r] = E1o[r] = F1o[r] = PK_NEG; E2e[r] = F2e[r] = E2o[r] = F2o[r] = XN;
         if constexpr (TB4) { E1e[r] |= 0x00010001u; E1o[r] |= 0x00010001u; }        // E states carry tag 1
         if constexpr (TAG8) { E1e[r] |= 0x00030003u; E1o[r] |= 0x00030003u; F1e[r] |= 0x00020002u; F1o[r] |= 0x00020002u; E2e[r] |= 0x00010001u; E2o[r] |= 0x00010001u; }
         const int d0 = de0 + 4 * r;
@@ -2603,10 +2604,12 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     int best = 0, bi = 0, bj = 0, prev_cur = -16384, done = have ? 0 : 1, ncell = 0;
     const int zdrop = o.zdrop;
     // RE-BIASING (convex cost: its scores are in 1/cx_scale units, ten to twenty times the affine presets', and a 2,000-base window
-    // would leave int16): every 32 trips the problem's row maximum is brought back to within +-4,096 of zero by moving all its H / E /
-    // F values by 4,096 and keeping the sum of the moves (`off`).  Cells more than ~12,000 below the row maximum become -inf: a path
-    // through such a cell can be replaced by one through the row's best cell plus at most two gaps across the band (< 3,000 for 128
-    // diagonals), so it is never the optimum -- scores and paths stay those of the oracle's int32 cells.  Not for multi-wave problems.
+    // would leave int16): every 32 trips the problem's row maximum is brought back to zero by moving all its H / E / F values by it and
+    // keeping the sum of the moves (`off`); in between the maximum drifts by at most 32 (a + b) S / 2 < 4,000.  Cells more than 12,000
+    // below the row maximum become -inf: a path through such a cell can be replaced by one through the row's best cell that joins it
+    // later -- one gap across the band and the matches skipped meanwhile, < 5,500 for 128 diagonals at scale 20 -- so it is never the
+    // optimum: scores and paths stay those of the oracle's int32 cells.  (A live cell sinks by at most 2 (open + ext) <= 400 a trip:
+    // -12,000 - 32 x 400 stays inside int16 until the next round marks it.)  Not for multi-wave problems.
     constexpr bool REB = CX && NW == 1;
     int off = 0, fin_off = 0;
     const bool first = l == 0, last = l == LPP - 1;
@@ -2628,11 +2631,11 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             const int a = 2 * k;
             if (qleft == 0) { d_stream_fill_acgt(QS, A.qseq2, P.qi0, qs_, ((a - de0) >> 1) - 1, P.qcomp, A.qtot); qleft = 32; }
             { uint32_t qv = (uint32_t)d_stream_next_acgt(QS); if (EXT && ((a - de0) >> 1) - 1 >= m) qv |= 8u; d_push_q<R>(qb, qv); } --qleft;
-            uint32_t ph = PK_NEG, pe1 = PK_NEG, pe2 = PK_NEG;
+            uint32_t ph = PK_NEG, pe1 = PK_NEG, pe2 = XN;
             if (LPP > 1) {
-                ph = DPP_SHR1((int)PK_NEG, (int)Ho[R - 1]); pe1 = DPP_SHR1((int)PK_NEG, (int)E1o[R - 1]); pe2 = DPP_SHR1((int)PK_NEG, (int)E2o[R - 1]);
+                ph = DPP_SHR1((int)PK_NEG, (int)Ho[R - 1]); pe1 = DPP_SHR1((int)PK_NEG, (int)E1o[R - 1]); pe2 = DPP_SHR1((int)XN, (int)E2o[R - 1]);
                 if (NW > 1 && wl == 0 && wv > 0) { const uint32_t *x = xch + (1 * NW + wv - 1) * 3; ph = x[0]; pe1 = x[1]; pe2 = x[2]; }
-                if (first) { ph = PK_NEG; pe1 = PK_NEG; pe2 = PK_NEG; }
+                if (first) { ph = PK_NEG; pe1 = PK_NEG; pe2 = XN; }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -2644,7 +2647,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 else if constexpr (CX) te[r] = d_cell_pk_cx(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 else te[r] = d_cell_pk<ONEP>(c, He[r], hl, e1l, e2l, Ho[r], F1o[r], F2o[r], qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { He[r] = h; F1e[r] = vf1; F2e[r] = vf2; }
-                else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (PK_NEG & ~inE[r]); }
+                else { He[r] = (h & inE[r]) | (PK_NEG & ~inE[r]); F1e[r] = (vf1 & inE[r]) | (PK_NEG & ~inE[r]); F2e[r] = (vf2 & inE[r]) | (XN & ~inE[r]); }
                 E1e[r] = ve1; E2e[r] = ve2;
             }
             if (!EXT && a >= amin) {      // only the last steps of a wave can be some problem's last step (lists are sorted by steps)
@@ -2672,11 +2675,11 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
             const int a = 2 * k + 1;
             if (tleft == 0) { d_stream_fill_acgt(TS, A.tseq2, P.ti0, ts_, ((a + de0 + 1) >> 1) + 2 * R - 2, 0, A.ttot); tleft = 32; }
             { uint32_t tv = (uint32_t)d_stream_next_acgt(TS); if (EXT && ((a + de0 + 1) >> 1) + 2 * R - 2 >= n) tv |= 8u; d_push_t<R>(tbv, tv); } --tleft;
-            uint32_t nh = PK_NEG, nf1 = PK_NEG, nf2 = PK_NEG;
+            uint32_t nh = PK_NEG, nf1 = PK_NEG, nf2 = XN;
             if (LPP > 1) {
-                nh = DPP_SHL1((int)PK_NEG, (int)He[0]); nf1 = DPP_SHL1((int)PK_NEG, (int)F1e[0]); nf2 = DPP_SHL1((int)PK_NEG, (int)F2e[0]);
+                nh = DPP_SHL1((int)PK_NEG, (int)He[0]); nf1 = DPP_SHL1((int)PK_NEG, (int)F1e[0]); nf2 = DPP_SHL1((int)XN, (int)F2e[0]);
                 if (NW > 1 && wl == 63 && wv < NW - 1) { const uint32_t *x = xch + (0 * NW + wv + 1) * 3; nh = x[0]; nf1 = x[1]; nf2 = x[2]; }
-                if (last) { nh = PK_NEG; nf1 = PK_NEG; nf2 = PK_NEG; }
+                if (last) { nh = PK_NEG; nf1 = PK_NEG; nf2 = XN; }
             }
             uint32_t row[R];
 #pragma unroll
@@ -2690,7 +2693,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 else if constexpr (CX) t = d_cell_pk_cx(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 else t = d_cell_pk<ONEP>(c, Ho[r], He[r], E1e[r], E2e[r], hu, f1u, f2u, qb[r], tbv[r], h, ve1, vf1, ve2, vf2);
                 if (r < FULL) { Ho[r] = h; F1o[r] = vf1; F2o[r] = vf2; }
-                else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (PK_NEG & ~inO[r]); }
+                else { Ho[r] = (h & inO[r]) | (PK_NEG & ~inO[r]); F1o[r] = (vf1 & inO[r]) | (PK_NEG & ~inO[r]); F2o[r] = (vf2 & inO[r]) | (XN & ~inO[r]); }
                 E1o[r] = ve1; E2o[r] = ve2;
                 row[r] = TB4 ? (te[r] | t) : __builtin_amdgcn_perm(t, te[r], 0x06040200u);
             }
@@ -2795,15 +2798,13 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
 #pragma unroll
                 for (int r = 0; r < R; ++r) hv[r] = pk_max(He[r], Ho[r]);
                 const int mx = d_pk_rowmax<LPP, R>(hv);
-                const int delta = mx > 4096 ? 4096 : mx < -4096 ? -4096 : 0;
-                if (__any(delta != 0)) {
-                    const uint32_t dd = pk_dup(delta), thr = pk_dup(-12000);
+                const int delta = mx < -8192 ? 0 : mx;            // (a row of -inf: no problem in these lanes, or one past its end)
+                const uint32_t dd = pk_dup(delta), thr = pk_dup(delta - 12000);
 #define REB_ONE(x) { const uint32_t dead = pk_sign(pk_sub((x), thr)); (x) = pk_sel(dead, PK_NEG, pk_max(pk_sub((x), dd), PK_NEG)); }
 #pragma unroll
-                    for (int r = 0; r < R; ++r) { REB_ONE(He[r]) REB_ONE(Ho[r]) REB_ONE(E1e[r]) REB_ONE(E1o[r]) REB_ONE(F1e[r]) REB_ONE(F1o[r]) }
+                for (int r = 0; r < R; ++r) { REB_ONE(He[r]) REB_ONE(Ho[r]) REB_ONE(E1e[r]) REB_ONE(E1o[r]) REB_ONE(F1e[r]) REB_ONE(F1o[r]) }
 #undef REB_ONE
-                    off += delta;
-                }
+                off += delta;
             }
         }
         if (EXT && __all(done)) break;

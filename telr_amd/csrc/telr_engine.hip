@@ -327,11 +327,11 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
         // (exact at L = 1 and L >= 27, within 6 in between);  ont (1, -1, open 1, extend 1 -> 0.5), doubled to integers:
         // C(L) = 2 + sum_{i<L} max(1, 2 - 0.3 i) ~ min(2 + 2L, 4 + L).  AS is in these integer units (ont: twice NGMLR's).
         io->k = 13; io->w = 5;
-        // round 4: for `ont` the convex cost is the spec in EXACT form (cx_*: scores in 1/10 of this preset's unit, the gap length rides
-        // with every gap cell): against the envelope it moved 3.2 % of the records' coordinates (faithful gate); pacbio keeps the envelope
-        // (0.18 %; at its scale of 20 a 220-base fill leaves int16)
+        // round 4: the convex cost is the spec in EXACT form (cx_*: scores in 1/10 (ont) or 1/20 (pacbio) of the preset's unit; what the
+        // next base of a gap costs rides with every gap cell): against the envelope it moved 3.2 % (ont) / 0.18 % (pacbio) of the
+        // records' coordinates (faithful gate).  q / e / q2 / e2 stay the envelope's: `cx_scale = 0` over the preset is that A/B.
         if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; mo->cx_scale = 10; mo->cx_open = 20; mo->cx_ext_max = 20; mo->cx_ext_min = 10; mo->cx_decay = 3; }
-        else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; }
+        else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; mo->cx_scale = 20; mo->cx_open = 100; mo->cx_ext_max = 100; mo->cx_ext_min = 20; mo->cx_decay = 3; }
         mo->fill_band_q4 = 12; mo->fill_margin = 2;
         mo->vote_len = 256; mo->vote_bin_shift = 5; mo->vote_min = 3; mo->vote_frac_q8 = 128;      // NGMLR's sub-read voting
     }
@@ -1356,8 +1356,10 @@ static inline int tag8_steps(const telr_map_opt *mo)
 }
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
-    if (!pk_steps_limit(mo) || mo->zdrop * (mo->cx_scale > 0 ? mo->cx_scale : 1) > 4000 || getenv("TELR_NO_PKEXT")) return 0;
-    if (mo->cx_scale > 0) return pk_cx_limit(mo, 64) ? 7900 : 0;
+    if (!pk_steps_limit(mo) || getenv("TELR_NO_PKEXT")) return 0;
+    // (convex cost: the z-drop test runs on the re-biased row maximum + the sum of the moves, in int32 -- kernels.hip.h, REB)
+    if (mo->cx_scale > 0) return mo->zdrop * mo->cx_scale <= 30000 && pk_cx_limit(mo, 64) ? 7900 : 0;
+    if (mo->zdrop > 4000) return 0;
     const int by_b = 2 * (15800 - mo->q2 - 64 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;

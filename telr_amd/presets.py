@@ -62,6 +62,8 @@ def preset(name):
             mo.cx_scale, mo.cx_open, mo.cx_ext_max, mo.cx_ext_min, mo.cx_decay = 10, 20, 20, 10, 3
         else:
             mo.a, mo.b, mo.q, mo.e, mo.q2, mo.e2 = 2, 5, 6, 4, 60, 1
+            # exact as well (scores in 1/20: ext(i) = max(20, 100 - 3 i)); the envelope moved 0.18 % of the coordinates
+            mo.cx_scale, mo.cx_open, mo.cx_ext_max, mo.cx_ext_min, mo.cx_decay = 20, 100, 100, 20, 3
         # NGMLR's candidate search: 256-base sub-reads vote for reference regions (diagonal bins of 32 bases, a window of three
         # bins = its corridor), regions with at least half the votes of the sub-read's best one stay
         mo.vote_len, mo.vote_bin_shift, mo.vote_min, mo.vote_frac_q8 = 256, 5, 3, 128

@@ -851,8 +851,18 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
         }
         __syncthreads();
         const int send = nsub < sb + VOTE_SUBCAP ? nsub : sb + VOTE_SUBCAP;
+        // (the first chunk of the wave's NEXT sub-read is loaded while the current one is voted: its round trip is off the wave's path)
+        uint32_t pf_off[2] = {0, 0}, pf_n[2] = {0, 0}, pf_y[2] = {0, 0}, pf_sp[2] = {0, 0}; int pf_s = -1;
+#define VOTE_LOAD_CHUNK(o_, n_, y_, sp_, gc_, g1_) { _Pragma("unroll") for (int u = 0; u < 2; ++u) { const int g = (gc_) + 2 * lane + u; o_[u] = 0; n_[u] = 0; y_[u] = 0; sp_[u] = 0; \
+            if (g < (g1_)) { o_[u] = (uint32_t)A.mz_ent[g]; n_[u] = (uint32_t)A.mz_n[g]; y_[u] = A.mz_y[g]; sp_[u] = ((const uint32_t*)A.mz_x)[2 * (size_t)g] & 0xffu; } } }
         for (int s = sb + wv; s < send; s += VOTE_WAVES) {
             const int g0 = sub_first[s - sb], g1 = sub_first[s - sb + 1];
+            uint32_t c0_off[2], c0_n[2], c0_y[2], c0_sp[2];
+            if (pf_s == s) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { c0_off[u] = pf_off[u]; c0_n[u] = pf_n[u]; c0_y[u] = pf_y[u]; c0_sp[u] = pf_sp[u]; }
+            } else VOTE_LOAD_CHUNK(c0_off, c0_n, c0_y, c0_sp, g0, g1)
+            if (s + VOTE_WAVES < send) { pf_s = s + VOTE_WAVES; VOTE_LOAD_CHUNK(pf_off, pf_n, pf_y, pf_sp, sub_first[pf_s - sb], sub_first[pf_s - sb + 1]) }
             if (g0 >= g1) continue;
             // ---- votes (all chunks of the sub-read), hits remembered
             uint32_t vmax = 0, nhit = 0;
@@ -866,17 +876,13 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                     // the chunk: two minimizers per lane
                     uint32_t n2[2];
                     __builtin_amdgcn_wave_barrier();
+                    uint32_t c_off[2], c_y[2], c_sp[2];
+                    if (gc == g0) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int g = gc + 2 * lane + u;
-                        uint32_t off = 0, n = 0, qpos = 0, zs = 0;
-                        if (g < g1) {
-                            off = (uint32_t)A.mz_ent[g]; n = (uint32_t)A.mz_n[g];
-                            const uint32_t y = A.mz_y[g];
-                            qpos = y >> 1; zs = (y & 1u) << 8 | (uint32_t)(A.mz_x[g] & 0xff);
-                        }
-                        C.off[2 * lane + u] = off; C.qpos[2 * lane + u] = qpos; C.zs[2 * lane + u] = (uint16_t)zs; n2[u] = n;
-                    }
+                        for (int u = 0; u < 2; ++u) { c_off[u] = c0_off[u]; n2[u] = c0_n[u]; c_y[u] = c0_y[u]; c_sp[u] = c0_sp[u]; }
+                    } else VOTE_LOAD_CHUNK(c_off, n2, c_y, c_sp, gc, g1)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { C.off[2 * lane + u] = c_off[u]; C.qpos[2 * lane + u] = c_y[u] >> 1; C.zs[2 * lane + u] = (uint16_t)((c_y[u] & 1u) << 8 | c_sp[u]); }
                     uint32_t inc = n2[0] + n2[1];
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
@@ -951,6 +957,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            const bool one_chunk = g1 - g0 <= VOTE_MZ;
             if (nhit <= VOTE_HCAP) {
                 // ---- survivors from the remembered hits.  The minimizer data of a remembered hit is read from the mz arrays again
                 // (the LDS chunk holds only the last 128 minimizers): qpos / span / strand by minimizer index g0 + chunk * 128 + m
@@ -969,8 +976,13 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                     if (lane == 0 && bm) base = atomicAdd(&blk_cnt, (uint32_t)__popcll(bm));
                     base = (uint32_t)__shfl((int)base, 0);
                     if (pass_hit) {
-                        const int g = g0 + (int)(x.sm >> 18) * VOTE_MZ + (int)((x.sm >> 11) & (VOTE_MZ - 1));
-                        const uint32_t y = A.mz_y[g], span = (uint32_t)(A.mz_x[g] & 0xff), qpos = y >> 1, rev = x.sm & 1u;
+                        // qpos / span of the hit's minimizer: still in the LDS chunk when the sub-read is ONE chunk (nearly always:
+                        // 256 bases hold ~85 (w,k) = (5,13) minimizers), else from the arrays again
+                        const uint32_t mi = (x.sm >> 11) & (VOTE_MZ - 1);
+                        uint32_t span, qpos;
+                        if (one_chunk) { span = C.zs[mi] & 0xffu; qpos = C.qpos[mi]; }
+                        else { const int g = g0 + (int)(x.sm >> 18) * VOTE_MZ + (int)mi; span = (uint32_t)(A.mz_x[g] & 0xff); qpos = A.mz_y[g] >> 1; }
+                        const uint32_t rev = x.sm & 1u;
                         const uint64_t key = (rev ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)x.gp << 32;
                         out[base + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = key;
                     }
@@ -984,6 +996,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
     __syncthreads();
     if (tid == 0) VA.q_cnt[q] = (int32_t)blk_cnt;
 }
+#undef VOTE_LOAD_CHUNK
 // staging -> dense keys (only ahead of the library sort: the LDS sort of segsort.hip.h reads the staging pieces in place)
 __global__ void __launch_bounds__(256) k_vote_compact(const uint64_t *__restrict__ stage, const int64_t *__restrict__ q_soff, const int32_t *__restrict__ q_aoff, int32_t nq,
                                                       uint64_t *__restrict__ keys)

@@ -853,12 +853,19 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
         const int send = nsub < sb + VOTE_SUBCAP ? nsub : sb + VOTE_SUBCAP;
         // (the first chunk of the wave's NEXT sub-read is loaded while the current one is voted: its round trip is off the wave's path)
         uint32_t pf_off[2] = {0, 0}, pf_n[2] = {0, 0}, pf_y[2] = {0, 0}, pf_sp[2] = {0, 0}; int pf_s = -1;
+        // VOTE_LOAD_CHUNK only ISSUES the loads (masked loads into zeroed registers: nothing depends on them here); VOTE_PIN, at the
+        // place of use, keeps the compiler from carrying derived values instead -- it would compute them, and wait, right behind the loads
 #define VOTE_LOAD_CHUNK(o_, n_, y_, sp_, gc_, g1_) { _Pragma("unroll") for (int u = 0; u < 2; ++u) { const int g = (gc_) + 2 * lane + u; o_[u] = 0; n_[u] = 0; y_[u] = 0; sp_[u] = 0; \
-            if (g < (g1_)) { o_[u] = (uint32_t)A.mz_ent[g]; n_[u] = (uint32_t)A.mz_n[g]; y_[u] = A.mz_y[g]; sp_[u] = ((const uint32_t*)A.mz_x)[2 * (size_t)g] & 0xffu; } } }
+            if (g < (g1_)) { o_[u] = (uint32_t)A.mz_ent[g]; n_[u] = (uint32_t)A.mz_n[g]; y_[u] = A.mz_y[g]; sp_[u] = ((const uint32_t*)A.mz_x)[2 * (size_t)g]; } } }
+#define VOTE_PIN(o_, n_, y_, sp_) { _Pragma("unroll") for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(o_[u]), "+v"(n_[u]), "+v"(y_[u]), "+v"(sp_[u])); }
         for (int s = sb + wv; s < send; s += VOTE_WAVES) {
+#ifdef VOTE_EXP_PREAMBLE
+            continue;
+#endif
             const int g0 = sub_first[s - sb], g1 = sub_first[s - sb + 1];
             uint32_t c0_off[2], c0_n[2], c0_y[2], c0_sp[2];
             if (pf_s == s) {
+                VOTE_PIN(pf_off, pf_n, pf_y, pf_sp)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { c0_off[u] = pf_off[u]; c0_n[u] = pf_n[u]; c0_y[u] = pf_y[u]; c0_sp[u] = pf_sp[u]; }
             } else VOTE_LOAD_CHUNK(c0_off, c0_n, c0_y, c0_sp, g0, g1)
@@ -882,7 +889,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                         for (int u = 0; u < 2; ++u) { c_off[u] = c0_off[u]; n2[u] = c0_n[u]; c_y[u] = c0_y[u]; c_sp[u] = c0_sp[u]; }
                     } else VOTE_LOAD_CHUNK(c_off, n2, c_y, c_sp, gc, g1)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { C.off[2 * lane + u] = c_off[u]; C.qpos[2 * lane + u] = c_y[u] >> 1; C.zs[2 * lane + u] = (uint16_t)((c_y[u] & 1u) << 8 | c_sp[u]); }
+                    for (int u = 0; u < 2; ++u) { C.off[2 * lane + u] = c_off[u]; C.qpos[2 * lane + u] = c_y[u] >> 1; C.zs[2 * lane + u] = (uint16_t)((c_y[u] & 1u) << 8 | (c_sp[u] & 0xffu)); }
                     uint32_t inc = n2[0] + n2[1];
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
@@ -918,7 +925,11 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 const uint32_t m = C.rid[cb + upto - 1u];
                                 const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
                                 m_[u] = m;
+#ifdef VOTE_EXP_NOGATHER          /* timing experiment only (wrong results): what the occurrence gather costs */
+                                py_[u] = (uint32_t)(((uint64_t)(C.off[m] + (h - pm)) * 2654435761ull) >> 4) % 260000000u;
+#else
                                 py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
+#endif
                             }
                             cb += (uint32_t)__popcll(wmask);
                         }
@@ -932,7 +943,12 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 const uint32_t qadj = rv_[u] ? (uint32_t)qlen - (qpos + 1 - span) - 1 : qpos;
                                 sl_[u] = d_vote_slot(gp_[u], qadj, rv_[u], V.shift);
                                 if (pass == 0) {
-                                    const uint32_t c = d_vt_add<T16>(T, sl_[u]); vmax = c > vmax ? c : vmax;
+#ifdef VOTE_EXP_NOATOMIC
+                                    const uint32_t c = 3; T[T16 ? sl_[u] >> 1 : sl_[u]] = 0x00030003u;
+#else
+                                    const uint32_t c = d_vt_add<T16>(T, sl_[u]);
+#endif
+                                    vmax = c > vmax ? c : vmax;
                                     if (hbase + h < VOTE_HCAP) { VoteHit x; x.gp = gp_[u]; x.sm = sl_[u] | m << 11 | (uint32_t)(gc - g0) / VOTE_MZ << 18; HS[hbase + h] = x; }
                                 } else pass_hit = d_vt_get<T16>(T, (sl_[u] - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl_[u]) + d_vt_get<T16>(T, (sl_[u] + 2u) & (VOTE_SLOTS - 1)) >= thr1;
                             }
@@ -997,6 +1013,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
     if (tid == 0) VA.q_cnt[q] = (int32_t)blk_cnt;
 }
 #undef VOTE_LOAD_CHUNK
+#undef VOTE_PIN
 // staging -> dense keys (only ahead of the library sort: the LDS sort of segsort.hip.h reads the staging pieces in place)
 __global__ void __launch_bounds__(256) k_vote_compact(const uint64_t *__restrict__ stage, const int64_t *__restrict__ q_soff, const int32_t *__restrict__ q_aoff, int32_t nq,
                                                       uint64_t *__restrict__ keys)

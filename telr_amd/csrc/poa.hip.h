@@ -8,13 +8,15 @@
 // heaviest-bundle path between the nodes most sequences begin / end at.  Opt-in (`polish="poa"`): another consensus can change
 // call sets.  Caps and tie-breaks are the oracle's, bit for bit (tests/test_gpu_consensus.py).
 //
-//   host            the pieces of every window from the records' CIGARs (record order), CSR by window
+//   host            the pieces of every window from the records' CIGARs -- ONE walk per record gives the query offsets at all the
+//                   window borders it crosses -- in record order, CSR by window
 //   k_poa_window    ONE WAVE per window (persistent over the window list): the graph and the score matrix live in a slot of
 //                   global scratch.  The matrix is BANDED: a node's row holds the POA_BAND = 64 columns around the diagonal
 //                   of the node's window column (d_poa_lo; a piece is at most 30 bases off the diagonal by the POA_MAXINDEL
-//                   rule), i.e. exactly one cell per lane, 128 B per node instead of 2 (m + 1): ~100 KB per window instead
-//                   of ~350 KB.  The in-row gap chain is a max-plus prefix scan over the wave; the walk back, the merge and
-//                   the heaviest-bundle pass are short serial stretches on lane 0.
+//                   rule), i.e. exactly one cell per lane.  The row of the node before is read from registers (lane shuffle),
+//                   the in-row gap chain is a max-plus prefix scan over the wave, every cell notes where its value came from;
+//                   the walk back (one byte per step), the merge and the heaviest-bundle pass are serial stretches on lane 0.
+//   k_poa_pack      the windows' strings, packed, for the copy back
 // Integer work bounded by instruction issue and L2 latency: no MFMA.
 #pragma once
 
@@ -63,7 +65,8 @@ struct PoaArgs {
 #define POA_O_COL    (POA_O_PCB + 2 * POA_MAXNODE)                          /* i16 [MAXNODE]: window column of the node */
 #define POA_O_LO     (POA_O_COL + 2 * POA_MAXNODE)                          /* i16 [MAXNODE]: first column of the band of the node at rank r */
 #define POA_O_H      ((POA_O_LO + 2 * POA_MAXNODE + 255) & ~255)            /* i16 [MAXNODE][POA_BAND]: the banded score matrix (row r = the node at rank r) */
-#define POA_SLOT_BYTES ((size_t)POA_O_H + 2 * (size_t)POA_MAXNODE * POA_BAND)
+#define POA_O_TB     (POA_O_H + 2 * POA_MAXNODE * POA_BAND)                 /* u8  [MAXNODE][POA_BAND]: where a cell's value came from (0-7: diagonal from predecessor k, 8-15: skipped the node, from predecessor k, 16: base inserted) */
+#define POA_SLOT_BYTES ((size_t)POA_O_TB + (size_t)POA_MAXNODE * POA_BAND)
 
 __host__ __device__ __forceinline__ int d_poa_lo(int col, int n, int L) { int lo = (col + 1) * n / L - POA_BAND / 2, hi = n + 1 - POA_BAND; if (lo > hi) lo = hi; return lo < 0 ? 0 : lo; }
 // cell (row, j) of the banded matrix: row 0 = the virtual start, outside a row's band -32000
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
     int16_t *bp = (int16_t*)(S + POA_O_BP), *no = (int16_t*)(S + POA_O_NO), *pn = (int16_t*)(S + POA_O_PN), *pj = (int16_t*)(S + POA_O_PJ);
     int16_t *newv = (int16_t*)(S + POA_O_NEWV), *anchor = (int16_t*)(S + POA_O_ANCH), *H = (int16_t*)(S + POA_O_H);
     int32_t *score = (int32_t*)(S + POA_O_SCORE);
+    uint8_t *TB = S + POA_O_TB;
     int16_t *prow = (int16_t*)(S + POA_O_PROW), *pplo = (int16_t*)(S + POA_O_PPLO), *pcb = (int16_t*)(S + POA_O_PCB), *col = (int16_t*)(S + POA_O_COL), *lo_r = (int16_t*)(S + POA_O_LO);
     for (int w = blockIdx.x; w < A.nwin; w += gridDim.x) {
         const int tid = A.w_tid[w], w0 = A.w_w0[w], w1 = A.w_w1[w], L = w1 - w0;
@@ -143,38 +147,54 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 }
             }
             __syncthreads();
-            // ---- sweep: one row of POA_BAND cells per node, in topological order: lane l computes column lo + l
+            // ---- sweep: one row of POA_BAND cells per node, in topological order: lane l computes column lo + l.  The row of the
+            // node before (nearly every node's only predecessor) stays in registers and is read with a lane shuffle -- waiting for the
+            // row just stored to come back from L2 was most of a step; rows further back are read from the slot.  Every cell also
+            // notes where its value came from, by the walk's own preference (diagonal before skipped node before inserted base, the
+            // first predecessor that explains it): the walk back then reads one byte per step instead of all candidates again.
             int nx_cb = pcb[0], nx_lo = lo_r[0]; uint32_t nx_p01 = *(const uint32_t*)&prow[0], nx_l01 = *(const uint32_t*)&pplo[0];
+            int prev_val = -32000, prev_lo = 0;
             for (int r = 0; r < n; ++r) {
-                const int cb = nx_cb, np_ = cb >> 8, vb = cb & 0xff, j = nx_lo + lane;
-                const uint32_t p01 = nx_p01, l01 = nx_l01;
+                const int cb = __builtin_amdgcn_readfirstlane(nx_cb), np_ = cb >> 8, vb = cb & 0xff, lo = __builtin_amdgcn_readfirstlane(nx_lo), j = lo + lane;
+                const uint32_t p01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_p01), l01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_l01);
                 if (r + 1 < n) { nx_cb = pcb[r + 1]; nx_lo = lo_r[r + 1]; nx_p01 = *(const uint32_t*)&prow[(r + 1) * POA_MAXIN]; nx_l01 = *(const uint32_t*)&pplo[(r + 1) * POA_MAXIN]; }
-                int t = -32000;
-                if (j <= m) {
-                    const int sb = j > 0 ? seq[j - 1] : 4;
-                    const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
-                    for (int k = 0; k < np_; ++k) {
-                        const int pr = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : (int)prow[r * POA_MAXIN + k];
-                        const int pl = k == 0 ? (int)(l01 & 0xffffu) : k == 1 ? (int)(l01 >> 16) : (int)pplo[r * POA_MAXIN + k];
-                        int vj, vj1;
-                        if (pr == 0) { vj = j * POA_G; vj1 = (j - 1) * POA_G; }
-                        else {
-                            const int jj = j - pl;                     // (j <= m here)
-                            const int16_t *prw = H + (size_t)(pr - 1) * POA_BAND;
-                            vj = (jj >= 0 && jj < POA_BAND) ? prw[jj] : -32000;
-                            vj1 = (jj >= 1 && jj <= POA_BAND) ? prw[jj - 1] : -32000;
-                        }
-                        int c = vj + POA_G; t = c > t ? c : t;
-                        if (j > 0) { c = vj1 + sc; t = c > t ? c : t; }
+                const int sb = j > 0 && j <= m ? seq[j - 1] : 4;
+                const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
+                int vmax = -1000000, vk = 0, dmax = -1000000, dk = 0;
+                bool synced = false;
+                for (int k = 0; k < np_; ++k) {
+                    const int pr = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : __builtin_amdgcn_readfirstlane((int)prow[r * POA_MAXIN + k]);
+                    const int pl = k == 0 ? (int)(l01 & 0xffffu) : k == 1 ? (int)(l01 >> 16) : __builtin_amdgcn_readfirstlane((int)pplo[r * POA_MAXIN + k]);
+                    int vj, vj1;
+                    if (pr == 0) { vj = j * POA_G; vj1 = (j - 1) * POA_G; }
+                    else if (pr == r) {                          // the row before: registers
+                        const int jj = j - prev_lo;
+                        const int a = __shfl(prev_val, jj & 63), b = __shfl(prev_val, (jj - 1) & 63);
+                        vj = (jj >= 0 && jj < POA_BAND) ? a : -32000;
+                        vj1 = (jj >= 1 && jj <= POA_BAND) ? b : -32000;
+                    } else {
+                        if (!synced) { __syncthreads(); synced = true; }        // (rows stored by other lanes of this wave)
+                        const int jj = j - pl;
+                        const int16_t *prw = H + (size_t)(pr - 1) * POA_BAND;
+                        vj = (jj >= 0 && jj < POA_BAND && j <= m) ? prw[jj] : -32000;
+                        vj1 = (jj >= 1 && jj <= POA_BAND && j <= m) ? prw[jj - 1] : -32000;
                     }
+                    int c = vj + POA_G; if (c > vmax) { vmax = c; vk = k; }
+                    c = vj1 + sc; if (j > 0 && c > dmax) { dmax = c; dk = k; }
                 }
+                int t = vmax > dmax ? vmax : dmax; t = t > -32000 ? t : -32000;
                 // row[j] = max over the band's k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
                 int u = j <= m ? t - j * POA_G : -1000000;
 #pragma unroll
                 for (int s_ = 1; s_ < 64; s_ <<= 1) { const int o = __shfl_up(u, s_); if (lane >= s_) u = o > u ? o : u; }
-                if (j <= m) H[(size_t)r * POA_BAND + lane] = (int16_t)(u + j * POA_G);
-                __syncthreads();                            // the next node's predecessors may be this row
+                const int cur = (int)(int16_t)(u + j * POA_G);
+                if (j <= m) {
+                    H[(size_t)r * POA_BAND + lane] = (int16_t)cur;
+                    TB[(size_t)r * POA_BAND + lane] = (uint8_t)(j > 0 && dmax == cur ? dk : vmax == cur ? 8 | vk : 16);
+                }
+                prev_val = j <= m ? cur : -32000; prev_lo = lo;
             }
+            __syncthreads();
             // ---- the end: the node without out-edges whose last column scores best, smallest id on ties
             {
                 int bs = -32768, bv = 0x7fffffff;
@@ -185,25 +205,25 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             }
             __syncthreads();
             if (lane == 0) {
-                // ---- walk back: diagonal from the first predecessor that explains the cell, else node skipped, else base inserted
-                int np = 0, v = sh[0], j = m;
-                while (v >= 0 || j > 0) {
-                    if (v < 0) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; continue; }
-                    const int cur = d_poa_cell(H, lo_r, rank[v], j, m), npred = nin[v] ? nin[v] : 1;
-                    bool moved = false;
-                    if (j > 0) {
-                        const int sc = seq[j - 1] == base[v] && seq[j - 1] < 4 ? POA_M : POA_X;
-                        for (int k = 0; k < npred && !moved; ++k) {
-                            const int p = nin[v] ? in[v * POA_MAXIN + k] : -1;
-                            if (d_poa_cell(H, lo_r, p >= 0 ? rank[p] : 0, j - 1, m) + sc == cur) { pn[np] = (int16_t)v; pj[np] = (int16_t)(j - 1); ++np; v = p; --j; moved = true; }
-                        }
-                    }
-                    for (int k = 0; k < npred && !moved; ++k) {
-                        const int p = nin[v] ? in[v * POA_MAXIN + k] : -1;
-                        if (d_poa_cell(H, lo_r, p >= 0 ? rank[p] : 0, j, m) + POA_G == cur) { v = p; moved = true; }
-                    }
-                    if (!moved) { pn[np] = -1; pj[np] = (int16_t)(j - 1); ++np; --j; }
+                // ---- walk back along the notes of the sweep (pn holds ROW numbers here, 0 = no node; turned into nodes below)
+                int np = 0, j = m;
+                int r = sh[0] >= 0 ? rank[sh[0]] : 0, lo = r ? lo_r[r - 1] : 0;
+                for (int it = 0; (r > 0 || j > 0) && j >= 0 && it < 2 * POA_NPATH; ++it) {        // (the bounds only keep a broken slot from hanging the device)
+                    const int jj = j - lo;
+                    const int tb = r > 0 && jj >= 0 && jj < POA_BAND ? TB[(size_t)(r - 1) * POA_BAND + jj] : 16;
+                    if (tb < 16) {
+                        const int k = tb & 7, nr = prow[(r - 1) * POA_MAXIN + k], nlo = pplo[(r - 1) * POA_MAXIN + k];
+                        if (tb < 8) { pn[np] = (int16_t)r; pj[np] = (int16_t)(j - 1); ++np; --j; }
+                        r = nr; lo = nlo;
+                    } else { pn[np] = 0; pj[np] = (int16_t)(j - 1); ++np; --j; }
                 }
+                sh[3] = np;
+            }
+            __syncthreads();
+            for (int z = lane; z < sh[3]; z += 64) { const int r = pn[z]; pn[z] = r ? order[r - 1] : (int16_t)-1; }
+            __syncthreads();
+            if (lane == 0) {
+                const int np = sh[3];
                 // ---- merge, start -> end (placement rules: see the oracle)
                 const int n_old = n;
                 int prev = -1, nnew = 0, behind = -1;
@@ -273,6 +293,12 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
     }
 }
 
+__global__ void __launch_bounds__(64) k_poa_pack(const uint8_t *__restrict__ wout, const int64_t *__restrict__ woff, uint8_t *__restrict__ pack)
+{
+    const int64_t w = blockIdx.x, o = woff[w]; const int n = (int)(woff[w + 1] - o);
+    for (int i = threadIdx.x; i < n; i += 64) pack[o + i] = wout[(size_t)w * POA_MAXNODE + i];
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------
 static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, int32_t min_depth, telr_consensus **out)
 {
@@ -298,28 +324,43 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     // the pieces, record by record (the walk of oracle/telr_oracle.c: tor_poa), then grouped by window keeping the record order
     struct Cand { int64_t win; PoaPiece p; };
     std::vector<Cand> cand;
+    // ONE walk over a record's CIGAR serves all its windows (the oracle scans it once per window; same values): the query offset
+    // at a window border P is that of the M / D op that contains P -- qi + (P - ti) inside an M, qi at a D -- or, when the record
+    // ends exactly at P, the query offset behind its last op; an insertion longer than POA_MAXINDEL at ti spoils the window with
+    // w0 < ti <= w1, such a deletion every window it overlaps.
+    std::vector<int32_t> bval; std::vector<uint8_t> bbig;
     for (const telr_aln &a : r->alns) {
         if (a.flags & (TELR_F_SECONDARY | TELR_F_SUPPL)) continue;
         const bool rev = (a.flags & TELR_F_REV) != 0;
         const int32_t tl = tg->len[a.tid];
-        for (int32_t w0 = (a.ts + POA_W - 1) / POA_W * POA_W; w0 < tl; w0 += POA_W) {
-            const int32_t w1 = std::min(w0 + POA_W, tl);
-            if (a.te < w1) break;
-            int32_t qi = rev ? a.qlen - a.qe : a.qs, ti = a.ts, qa = -1, qb = -1; bool big = false;
-            for (int32_t c = 0; c < a.n_cigar && qb < 0; ++c) {
-                const uint32_t cg = r->cig[a.cigar_off + c]; const int op = cg & 0xf, l = (int)(cg >> 4);
-                if (op == 1) { if (l > POA_MAXINDEL && ti > w0 && ti <= w1) big = true; qi += l; continue; }
-                if (qa < 0 && w0 < ti + l) qa = op == 0 ? qi + (w0 - ti) : qi;
-                if (w1 < ti + l) qb = op == 0 ? qi + (w1 - ti) : qi;
-                if (op == 2 && l > POA_MAXINDEL && ti < w1 && ti + l > w0) big = true;
-                if (op == 0) qi += l;
-                ti += l;
+        const int32_t kf = (a.ts + POA_W - 1) / POA_W;                      // first window that starts inside the record
+        int32_t cnt = 0;
+        for (int32_t w0 = kf * POA_W; w0 < tl && a.te >= std::min(w0 + POA_W, tl); w0 += POA_W) ++cnt;
+        if (cnt == 0) continue;
+        // borders b = 0 .. cnt: positions (kf + b) W, the last one cut at the target's end
+        bval.assign((size_t)cnt + 1, -1); bbig.assign((size_t)cnt, 0);
+        auto border = [&](int32_t b) { return std::min((kf + b) * POA_W, tl); };
+        int32_t qi = rev ? a.qlen - a.qe : a.qs, ti = a.ts, nb = 0;
+        for (int32_t c = 0; c < a.n_cigar; ++c) {
+            const uint32_t cg = r->cig[a.cigar_off + c]; const int op = cg & 0xf, l = (int)(cg >> 4);
+            if (op == 1) {
+                if (l > POA_MAXINDEL && ti > 0) { const int32_t k = (ti - 1) / POA_W - kf; if (k >= 0 && k < cnt && ti <= border(k + 1)) bbig[k] = 1; }
+                qi += l; continue;
             }
-            if (qb < 0) qb = qi;
-            if (big) continue;
+            while (nb <= cnt && border(nb) < ti + l) { bval[nb] = op == 0 ? qi + (border(nb) - ti) : qi; ++nb; }
+            if (op == 2 && l > POA_MAXINDEL) {
+                for (int32_t k = std::max(0, ti / POA_W - kf); k < cnt && (kf + k) * POA_W < ti + l; ++k) if (ti < border(k + 1)) bbig[k] = 1;
+            }
+            if (op == 0) qi += l;
+            ti += l;
+        }
+        for (int32_t k = 0; k < cnt; ++k) {
+            const int32_t w0 = (kf + k) * POA_W, w1 = border(k + 1);
+            const int32_t qa = bval[k], qb = bval[k + 1] >= 0 ? bval[k + 1] : qi;
+            if (bbig[k]) continue;
             const int len = qb - qa;
             if (qa < 0 || len < (w1 - w0) / 2 || len > POA_SEGMAX) continue;
-            Cand cd; cd.win = wbase[a.tid] + w0 / POA_W; cd.p.qid = a.qid; cd.p.qa = qa; cd.p.len = len; cd.p.rev = rev ? 1 : 0;
+            Cand cd; cd.win = wbase[a.tid] + kf + k; cd.p.qid = a.qid; cd.p.qa = qa; cd.p.len = len; cd.p.rev = rev ? 1 : 0;
             cand.push_back(cd);
         }
     }
@@ -357,21 +398,23 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     A.scratch = d_scr; A.slot_bytes = POA_SLOT_BYTES; A.wout = d_wout; A.wlen = d_wlen;
     hipLaunchKernelGGL(k_poa_window, dim3((unsigned)nslot), dim3(64), 0, st, A);
     CK(hipGetLastError());
+    // the windows' strings leave the device packed (the slots of wout are POA_MAXNODE bytes each: 2 KB for ~200 bases)
     std::vector<int32_t> wlen((size_t)nwin);
-    std::vector<uint8_t> wout((size_t)nwin * POA_MAXNODE);
     CK(hipMemcpyAsync(wlen.data(), d_wlen, (size_t)nwin * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(wout.data(), d_wout, wout.size(), hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<int64_t> woff((size_t)nwin + 1, 0);
+    for (int64_t k = 0; k < nwin; ++k) woff[k + 1] = woff[k] + wlen[k];
+    const int64_t tot = woff[nwin];
+    int64_t *d_woff; uint8_t *d_pack;
+    if ((rc = ctx_buf_t(ctx, "poa_woff", (size_t)nwin + 1, &d_woff)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_pack", (size_t)tot + 1, &d_pack)) != TELR_OK) return fail(rc);
+    CK(hipMemcpyAsync(d_woff, woff.data(), ((size_t)nwin + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_poa_pack, dim3((unsigned)nwin), dim3(64), 0, st, d_wout, d_woff, d_pack);
+    CK(hipGetLastError());
+    C->seq.resize((size_t)tot);
+    if (tot) CK(hipMemcpyAsync(&C->seq[0], d_pack, (size_t)tot, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
 #undef CK
-    int64_t tot = 0;
-    for (int64_t k = 0; k < nwin; ++k) tot += wlen[k];
-    C->seq.resize((size_t)tot);
-    int64_t o = 0;
-    for (int t = 0; t < nt; ++t) {
-        C->off[t] = o;
-        for (int64_t k = wbase[t]; k < wbase[t + 1]; ++k) { memcpy(&C->seq[(size_t)o], &wout[(size_t)k * POA_MAXNODE], (size_t)wlen[k]); o += wlen[k]; }
-        C->len[t] = (int32_t)(o - C->off[t]);
-    }
+    for (int t = 0; t < nt; ++t) { C->off[t] = woff[wbase[t]]; C->len[t] = (int32_t)(woff[wbase[t + 1]] - woff[wbase[t]]); }
     *out = C;
     return TELR_OK;
 }

@@ -256,10 +256,39 @@ __device__ __forceinline__ uint32_t d_mz_sel4_w10(const uint32_t *p, int ua0, in
     return sel;
 }
 
+// The same for w = 5 (the ngmlr-* presets): p = the 12 LDS words from 4 slots before the first own slot, window a (0..7) starts at
+// slot ua0 + a.  (The neighbour scans of the general path read LDS with a stride of four words per lane: 73 % of its LDS cycles
+// were bank conflicts -- profiles/r04: SQ_LDS_BANK_CONFLICT of k_sketch32<2, 0>.)
+__device__ __forceinline__ uint32_t d_mz_sel4_w5(const uint32_t *p, int ua0, int ns, bool edge)
+{
+    uint32_t v[12];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const uint4 t = ((const uint4*)p)[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+    uint32_t t2[11], m[8];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) t2[i] = v[i] < v[i + 1] ? v[i] : v[i + 1];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { uint32_t x = t2[a] < t2[a + 2] ? t2[a] : t2[a + 2]; m[a] = x < v[a + 4] ? x : v[a + 4]; }
+    if (edge) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) if ((uint32_t)(ua0 + a) > (uint32_t)(ns - 5)) m[a] = 0;
+    }
+    uint32_t T2[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) T2[i] = m[i] > m[i + 1] ? m[i] : m[i + 1];
+    uint32_t sel = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t M = T2[c] > T2[c + 2] ? T2[c] : T2[c + 2]; M = M > m[c + 4] ? M : m[c + 4];
+        if (v[4 + c] != SK_NONE && M == v[4 + c]) sel |= 1u << c;
+    }
+    return sel;
+}
+
 // Thread t of a tile owns the 4 consecutive slots u0 + 4t .. +3: it hashes them from one 64-bit window of the packed bases
 // (strand bits stay in registers), the first 2*halo threads also hash one halo slot each, and after the barrier every thread
 // tests its own 4 slots.  The selected slots are ranked with ballots (no shuffles).
-template <int MODE, int HALO>        // HALO = 9: w = 10, the register formulation above; 0 = any w, neighbour scans in LDS
+template <int MODE, int HALO>        // HALO = 9 / 4: w = 10 / 5, the register formulations above; 0 = any w, neighbour scans in LDS
 __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
 {
     static_assert(SK_TILE == 4 * SK_THREADS, "4 slots per thread");
@@ -305,6 +334,9 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch32(SketchArgs A)
     if (HALO == 9 && ns >= 10) {
         const bool edge = u0 - 9 < 0 || u0 + SK_TILE + 9 > ns;
         sel = d_mz_sel4_w10(xs + tid * 4, uo - 9, ns, edge);
+    } else if (HALO == 4 && ns >= 5) {
+        const bool edge = u0 - 4 < 0 || u0 + SK_TILE + 4 > ns;
+        sel = d_mz_sel4_w5(xs + tid * 4, uo - 4, ns, edge);
     } else {
         const int need = A.w < ns ? A.w : ns;
 #pragma unroll

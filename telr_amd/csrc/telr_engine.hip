@@ -685,6 +685,7 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     else {
         A.out_x = d_sx; A.out_y = d_sy;
         if (k <= 15 && w == 10 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 9>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        else if (k <= 15 && w == 5 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 4>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
         else if (k <= 15 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 0>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
         else hipLaunchKernelGGL(k_sketch<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
     }
@@ -755,8 +756,8 @@ struct telr_index {
     uint32_t *d_ht_home = nullptr;                                            // its home-slot bitmap
     std::vector<uint32_t> sorted_counts; // ascending, for the mid_occ quantile
     // per-target occurrence statistics (built on first use): runs = (minimizer, target) pairs, keys = target<<32 | count sorted
-    mutable uint64_t *d_pt_keys = nullptr; mutable int32_t *d_pt_off = nullptr, *d_pt_mid = nullptr; mutable int32_t pt_runs = -1;
-    mutable float pt_frac = -1.f; mutable int32_t pt_lo = -1, pt_hi = -1;
+    mutable uint64_t *d_pt_keys = nullptr; mutable int32_t *d_pt_off = nullptr; mutable int32_t pt_runs = -1;
+    mutable std::mutex pt_mu;                 // the lazily built per-target runs above: contexts may share an index (include/telr_hip.h)
     mutable double anchors_per_base = 0;  // seen by the last telr_map call on this index (0 = none yet): sizes the first range of the next call
     mutable double dens_bound = -1; mutable int32_t dens_mid = -1;     // index_density_bound() and the cut-off it was computed for
 };
@@ -765,7 +766,7 @@ extern "C" void telr_index_free(telr_index *ix)
 {
     if (!ix) return;
     (void)hipFree(ix->d_ent_hash); (void)hipFree(ix->d_ent_off); (void)hipFree(ix->d_pos); (void)hipFree(ix->d_bstart); (void)hipFree(ix->d_goff); (void)hipFree(ix->d_ht); (void)hipFree(ix->d_ht_home);
-    (void)hipFree(ix->d_pt_keys); (void)hipFree(ix->d_pt_off); (void)hipFree(ix->d_pt_mid);
+    (void)hipFree(ix->d_pt_keys); (void)hipFree(ix->d_pt_off);
     delete ix;
 }
 extern "C" int telr_index_stats(const telr_index *ix, int64_t *n_mz, int64_t *n_distinct)
@@ -913,6 +914,7 @@ static int index_per_target_occ(telr_ctx *ctx, const telr_index *ix, const telr_
 {
     const int n = ix->targets->n; const int64_t nmz = ix->n_mz;
     hipStream_t st = ctx->stream;
+    std::unique_lock<std::mutex> pt_lock(ix->pt_mu);
     if (ix->pt_runs < 0) {
         int32_t *d_head, *d_rank, *d_tid, *d_start; int32_t n_runs = 0;
         TRY(ctx_buf_t(ctx, "pt_head", (size_t)nmz + 1, &d_head));
@@ -932,7 +934,6 @@ static int index_per_target_occ(telr_ctx *ctx, const telr_index *ix, const telr_
         TRY(ctx_buf_t(ctx, "pt_key0", (size_t)n_runs + 1, &d_k0));
         HIPCHK(hipMalloc(&ix->d_pt_keys, ((size_t)n_runs + 1) * 8));
         HIPCHK(hipMalloc(&ix->d_pt_off, ((size_t)n + 2) * 4));
-        HIPCHK(hipMalloc(&ix->d_pt_mid, ((size_t)n + 1) * 4));
         if (n_runs > 0) {
             hipLaunchKernelGGL(k_pt_run_starts, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, d_head, d_rank, nmz, d_start, n_runs);
             hipLaunchKernelGGL(k_pt_run_keys, dim3((n_runs + 255) / 256), dim3(256), 0, st, d_start, d_tid, n_runs, d_k0);
@@ -945,15 +946,16 @@ static int index_per_target_occ(telr_ctx *ctx, const telr_index *ix, const telr_
         hipLaunchKernelGGL(k_pt_target_off, dim3((n + 1 + 255) / 256), dim3(256), 0, st, ix->d_pt_keys, n_runs, n, ix->d_pt_off);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
-        ix->pt_runs = n_runs; ix->pt_frac = -1.f;
+        ix->pt_runs = n_runs;
     }
-    if (ix->pt_frac != mo->mid_occ_frac || ix->pt_lo != mo->min_mid_occ || ix->pt_hi != mo->max_mid_occ) {
-        hipLaunchKernelGGL(k_pt_mid_occ, dim3((n + 255) / 256), dim3(256), 0, st, ix->d_pt_keys, ix->d_pt_off, n, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ, ix->d_pt_mid);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));       // worker contexts read it from their own streams
-        ix->pt_frac = mo->mid_occ_frac; ix->pt_lo = mo->min_mid_occ; ix->pt_hi = mo->max_mid_occ;
-    }
-    *d_tmid = ix->d_pt_mid;
+    pt_lock.unlock();
+    // the cut-offs themselves depend on the call's options: the context's own buffer (two contexts may map against one index at once)
+    int32_t *d_mid;
+    TRY(ctx_buf_t(ctx, "pt_mid", (size_t)n + 1, &d_mid));
+    hipLaunchKernelGGL(k_pt_mid_occ, dim3((n + 255) / 256), dim3(256), 0, st, ix->d_pt_keys, ix->d_pt_off, n, mo->mid_occ_frac, mo->min_mid_occ, mo->max_mid_occ, d_mid);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));       // worker contexts read it from their own streams
+    *d_tmid = d_mid;
     return TELR_OK;
 }
 

@@ -1680,7 +1680,7 @@ __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__
 // 19-21: wide fills in int16 while the scores fit (steps <= pk_wide_steps): D <= 256 / 512 / 1024, 1 / 2 / 4 waves per problem
 // 22: 65..128 diagonals, four lanes x R = 8 (16 problems per wave): the class of the retried fills (wide band of a ~200-base
 //     segment = 100-130 diagonals), which the margin rule of the band spec makes ~1 % of all fills
-__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps)
+__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps, int pk_wide_maxd = 1024)
 {
     if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
     if (kind == 0 && steps <= pk_max_steps) {
@@ -1694,7 +1694,7 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
         if (D <= 64) return 16;
         if (D <= 128) return 22;
     }
-    if (kind == 0 && steps <= pk_wide_steps && D > 64) {
+    if (kind == 0 && steps <= pk_wide_steps && D > 64 && D <= pk_wide_maxd) {
         if (D <= 256) return 19;
         if (D <= 512) return 20;
         if (D <= 1024) return 21;
@@ -1740,13 +1740,13 @@ __device__ __forceinline__ bool d_any_n(const uint32_t *__restrict__ nmask, int6
 }
 __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_margin, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
                              const uint32_t *__restrict__ qnmask, const uint32_t *__restrict__ tnmask,
-                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4, int32_t tb4_steps)
+                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4, int32_t tb4_steps, int32_t pk_wide_maxd)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
-    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps, pk_wide_steps);
+    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps, pk_wide_steps, pk_wide_maxd);
     if (cls >= 10 && P.kind < 3) {
         // the packed kernels have no ambiguity case: a problem with an N inside either window takes an int32 class
         const bool hasn = d_any_n(qnmask, P.qstep > 0 ? P.qi0 : P.qi0 - P.m + 1, P.m) || d_any_n(tnmask, P.tstep > 0 ? P.ti0 : P.ti0 - P.n + 1, P.n);
@@ -2671,8 +2671,9 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
     // below the row maximum become -inf: a path through such a cell can be replaced by one through the row's best cell that joins it
     // later -- one gap across the band and the matches skipped meanwhile, < 5,500 for 128 diagonals at scale 20 -- so it is never the
     // optimum: scores and paths stay those of the oracle's int32 cells.  (A live cell sinks by at most 2 (open + ext) <= 400 a trip:
-    // -12,000 - 32 x 400 stays inside int16 until the next round marks it.)  Not for multi-wave problems.
-    constexpr bool REB = CX && NW == 1;
+    // -12,000 - 32 x 400 stays inside int16 until the next round marks it.)  Multi-wave problems take the maximum over their waves
+    // through LDS; which band widths the window holds at a preset's scale is the host's decision (telr_engine.hip: pk_cx_ok).
+    constexpr bool REB = CX;
     int off = 0, fin_off = 0;
     const bool first = l == 0, last = l == LPP - 1;
     // which register / half holds the final diagonal n-m (its parity is the parity of m+n)
@@ -2850,16 +2851,19 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                 }
             }
         }
-        if (NW > 1) {
-            if (wl == 63) { uint32_t *x = xch + (1 * NW + wv) * 3; x[0] = Ho[R - 1]; x[1] = E1o[R - 1]; x[2] = E2o[R - 1]; }
-            __syncthreads();
-        }
         if constexpr (REB) {
             if ((k & 31) == 31) {
                 uint32_t hv[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) hv[r] = pk_max(He[r], Ho[r]);
-                const int mx = d_pk_rowmax<LPP, R>(hv);
+                int mx = d_pk_rowmax<(LPP > 64 ? 64 : LPP), R>(hv);
+                if (NW > 1) {             // one problem over NW waves: the maximum of the waves' maxima
+                    int32_t *xm = (int32_t*)(xch + 2 * NW * 3);
+                    if (wl == 0) xm[wv] = mx;
+                    __syncthreads();
+#pragma unroll
+                    for (int w_ = 0; w_ < NW; ++w_) mx = xm[w_] > mx ? xm[w_] : mx;
+                }
                 const int delta = mx < -8192 ? 0 : mx;            // (a row of -inf: no problem in these lanes, or one past its end)
                 const uint32_t dd = pk_dup(delta), thr = pk_dup(delta - 12000);
 #define REB_ONE(x) { const uint32_t dead = pk_sign(pk_sub((x), thr)); (x) = pk_sel(dead, PK_NEG, pk_max(pk_sub((x), dd), PK_NEG)); }
@@ -2868,6 +2872,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
 #undef REB_ONE
                 off += delta;
             }
+        }
+        if (NW > 1) {
+            if (wl == 63) { uint32_t *x = xch + (1 * NW + wv) * 3; x[0] = Ho[R - 1]; x[1] = E1o[R - 1]; x[2] = E2o[R - 1]; }
+            __syncthreads();
         }
         if (EXT && __all(done)) break;
     }
@@ -2970,7 +2978,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PK_WPE)
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) k_dp_pkw(DpArgs A)
 {
-    __shared__ uint32_t xch[2 * NW * 3];
+    __shared__ uint32_t xch[2 * NW * 3 + NW];          // values that cross a wave boundary; the waves' row maxima (re-biasing)
     __builtin_amdgcn_s_setprio(3);
     if (A.o.cx_scale) d_dp_pkr<64 * NW, 1, false, NW, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x, xch);
     else d_dp_pkr<64 * NW, 1, false, NW>(A, A.list, A.nlist, blockIdx.x, xch);

@@ -1303,19 +1303,26 @@ struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int6
 // sharing a wave are alike and the long ones start first), forward kernels, trace-back.
 // longest gap fill (m+n) the packed int16 kernels take: |H| <= b*(m+n)/2 + q2 + 128*e2 and a*(m+n)/2 must stay inside
 // +-16000 (bands of these classes have at most 128 diagonals); 0 disables the packed classes
-// convex gap cost (cx_scale > 0): the same bounds on the scaled scores -- |H| <= b S (m+n)/2 + open + D ext_max
-static inline int pk_cx_limit(const telr_map_opt *mo, int D)
+// convex gap cost (cx_scale > 0): the packed int16 classes re-bias their scores as they go (kernels.hip.h, REB), so the length of
+// a fill does not matter; what must hold is (1) the packed constants fit, (2) a live cell cannot sink out of int16 between two
+// rounds (2 (open + ext_max) a trip, 32 trips), (3) the 12,000-wide window holds every cell an optimal path can use in a band
+// of D diagonals: one gap across the band + the matches skipped meanwhile, gap(D) + a S D / 2 (derivation: kernels.hip.h, REB).
+static inline int cx_gap(const telr_map_opt *mo, int L)
+{
+    int t = mo->cx_open;
+    for (int i = 0; i < L; ++i) { const int e = mo->cx_ext_max - mo->cx_decay * i; t += e > mo->cx_ext_min ? e : mo->cx_ext_min; }
+    return t;
+}
+static inline bool pk_cx_ok(const telr_map_opt *mo, int D)
 {
     const int S = mo->cx_scale, bS = mo->b * S, aS = mo->a * S;
-    if (getenv("TELR_NO_PK") || bS > 400 || aS > 400 || mo->sc_ambi * S > 400 || mo->cx_ext_max > 400 || mo->cx_open > 400 || mo->cx_ext_max < mo->cx_ext_min || mo->cx_ext_min < 0 || mo->cx_decay < 0) return 0;
-    const int by_b = 2 * (15800 - mo->cx_open - D * mo->cx_ext_max) / (bS > 0 ? bS : 1) - 2, by_a = 32000 / (aS > 0 ? aS : 1) - 2;
-    const int lim = by_b < by_a ? by_b : by_a;
-    return lim > 0 ? lim : 0;
+    if (getenv("TELR_NO_PK") || bS > 400 || aS > 400 || mo->sc_ambi * S > 400 || mo->cx_open + mo->cx_ext_max > 320 || mo->cx_ext_max < mo->cx_ext_min || mo->cx_ext_min < 0 || mo->cx_decay < 0) return false;
+    return cx_gap(mo, D) + aS * D / 2 <= 11900;
 }
 static inline int pk_steps_limit(const telr_map_opt *mo)
 {
     // (convex cost: the single-wave packed classes re-bias their scores as they go -- kernels.hip.h, REB -- so only the constants have to fit)
-    if (mo->cx_scale > 0) return pk_cx_limit(mo, 128) ? 7900 : 0;
+    if (mo->cx_scale > 0) return pk_cx_ok(mo, 128) ? 7900 : 0;
     if (!(mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9) || getenv("TELR_NO_PK")) return 0;
     const int by_b = 2 * (15800 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
@@ -1325,10 +1332,16 @@ static inline int pk_steps_limit(const telr_map_opt *mo)
 static inline int pk_wide_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || getenv("TELR_NO_PKW")) return 0;
-    if (mo->cx_scale > 0) return pk_cx_limit(mo, 1024);
+    if (mo->cx_scale > 0) return pk_cx_ok(mo, 256) ? 7900 : 0;          // (which of the three wide classes: pk_wide_maxd)
     const int by_b = 2 * (15800 - mo->q2 - 1024 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
+}
+// the widest band the wide int16 classes take (19: 256, 20: 512, 21: 1,024 diagonals)
+static inline int pk_wide_maxd(const telr_map_opt *mo)
+{
+    if (mo->cx_scale <= 0) return 1024;
+    return pk_cx_ok(mo, 1024) ? 1024 : pk_cx_ok(mo, 512) ? 512 : pk_cx_ok(mo, 256) ? 256 : 0;
 }
 // longest z-drop extension window (m+n) the packed int16 kernel takes: scores stay inside +-16000
 // classes that spill four bits per cell (kernels.hip.h: d_tb4): the one-piece classes of the preset, when every class has its
@@ -1360,7 +1373,7 @@ static inline int pk_ext_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || getenv("TELR_NO_PKEXT")) return 0;
     // (convex cost: the z-drop test runs on the re-biased row maximum + the sum of the moves, in int32 -- kernels.hip.h, REB)
-    if (mo->cx_scale > 0) return mo->zdrop * mo->cx_scale <= 30000 && pk_cx_limit(mo, 64) ? 7900 : 0;
+    if (mo->cx_scale > 0) return mo->zdrop * mo->cx_scale <= 30000 && pk_cx_ok(mo, 64) ? 7900 : 0;
     if (mo->zdrop > 4000) return 0;
     const int by_b = 2 * (15800 - mo->q2 - 64 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
@@ -1381,7 +1394,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo), tb4_steps(mo));
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo), tb4_steps(mo), pk_wide_maxd(mo));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));

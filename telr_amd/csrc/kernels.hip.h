@@ -891,9 +891,6 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
             if (g < (g1_)) { o_[u] = (uint32_t)A.mz_ent[g]; n_[u] = (uint32_t)A.mz_n[g]; y_[u] = A.mz_y[g]; sp_[u] = ((const uint32_t*)A.mz_x)[2 * (size_t)g]; } } }
 #define VOTE_PIN(o_, n_, y_, sp_) { _Pragma("unroll") for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(o_[u]), "+v"(n_[u]), "+v"(y_[u]), "+v"(sp_[u])); }
         for (int s = sb + wv; s < send; s += VOTE_WAVES) {
-#ifdef VOTE_EXP_PREAMBLE
-            continue;
-#endif
             const int g0 = sub_first[s - sb], g1 = sub_first[s - sb + 1];
             uint32_t c0_off[2], c0_n[2], c0_y[2], c0_sp[2];
             if (pf_s == s) {
@@ -957,11 +954,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 const uint32_t m = C.rid[cb + upto - 1u];
                                 const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
                                 m_[u] = m;
-#ifdef VOTE_EXP_NOGATHER          /* timing experiment only (wrong results): what the occurrence gather costs */
-                                py_[u] = (uint32_t)(((uint64_t)(C.off[m] + (h - pm)) * 2654435761ull) >> 4) % 260000000u;
-#else
                                 py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
-#endif
                             }
                             cb += (uint32_t)__popcll(wmask);
                         }
@@ -975,12 +968,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 const uint32_t qadj = rv_[u] ? (uint32_t)qlen - (qpos + 1 - span) - 1 : qpos;
                                 sl_[u] = d_vote_slot(gp_[u], qadj, rv_[u], V.shift);
                                 if (pass == 0) {
-#ifdef VOTE_EXP_NOATOMIC
-                                    const uint32_t c = 3; T[T16 ? sl_[u] >> 1 : sl_[u]] = 0x00030003u;
-#else
-                                    const uint32_t c = d_vt_add<T16>(T, sl_[u]);
-#endif
-                                    vmax = c > vmax ? c : vmax;
+                                    const uint32_t c = d_vt_add<T16>(T, sl_[u]); vmax = c > vmax ? c : vmax;
                                     if (hbase + h < VOTE_HCAP) { VoteHit x; x.gp = gp_[u]; x.sm = sl_[u] | m << 11 | (uint32_t)(gc - g0) / VOTE_MZ << 18; HS[hbase + h] = x; }
                                 } else pass_hit = d_vt_get<T16>(T, (sl_[u] - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl_[u]) + d_vt_get<T16>(T, (sl_[u] + 2u) & (VOTE_SLOTS - 1)) >= thr1;
                             }

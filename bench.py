@@ -125,7 +125,7 @@ def launch_ranks(a):
     return pr.wait()
 
 
-PMC_PROFILE = "r03_pmc_k_dp_pk.json"       # per-launch counters of the dominant kernel, collected by tools/collect_profiles.sh
+PMC_PROFILE = "r04_pmc_k_dp_pk.json"       # per-launch counters of the dominant kernel, collected by tools/collect_profiles.sh
 PARITY_FIELDS = ("tid", "qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "score", "subsc", "dp_score", "cnt", "n_sub", "parent", "n_cigar", "flags", "mapq")
 
 

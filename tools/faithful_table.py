@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The drift table of the oracle's experiment bits (oracle/telr_oracle.c: MFX_*) for DESIGN.md section 2: every omission of the
 engine's spec against minimap2 2.22's published behaviour, on every gate workload.  CPU only; ~10 minutes on 8 cores.
-usage: python tools/faithful_table.py [reads per workload, default 300]"""
+usage: python tools/faithful_table.py [reads per workload, default 300] [workload, ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +10,9 @@ import test_faithful_gate as g
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 print("| workload | omission | records | records changed | coordinates changed | DP score changed | CIGAR changed (same coordinates) |")
 print("|---|---|---|---|---|---|---|")
+only = sys.argv[2:]
 for kind, k in (("flanks-asm10", 2 * n), ("clr-map-pb", n), ("clr-ngmlr-pacbio", n), ("ont-ngmlr-ont", n), ("c4-density", n)):
+    if only and kind not in only:
+        continue
     for name, r in g.bit_table(kind, k):
         print("| %s | %s | %d | %.2f %% | %.2f %% | %.2f %% | %s |" % (kind, name, r["n"], 100 * r["core"], 100 * r["coord"], 100 * r["score"], ("%.2f %%" % (100 * r["cigar"])) if "cigar" in r else "-"), flush=True)

@@ -11,10 +11,14 @@ from telr_amd.presets import preset
 
 
 
-def draw_case(seed, big=False):
-    """one random configuration -> (preset name, io, mo, genome, reads, qtarget, edge_repeats)"""
+def draw_case(seed, big=False, sv=False, presets=None):
+    """one random configuration -> (preset name, io, mo, genome, reads, qtarget, edge_repeats).
+    sv: half of the reads carry one to three large insertions / deletions (30-600 bases): wide bands, long gap runs -- the
+    convex cost's re-biased int16 classes, their multi-wave form and the int32 fall-back (FUZZ_SV=1; FUZZ_PRESETS=a,b restricts
+    the presets drawn)"""
     rng = np.random.default_rng(seed)
-    pname = ["map-ont", "map-ont", "map-pb", "asm10", "ngmlr-ont", "ngmlr-pacbio"][int(rng.integers(0, 6))]
+    names = presets or ["map-ont", "map-ont", "map-pb", "asm10", "ngmlr-ont", "ngmlr-pacbio"]
+    pname = names[int(rng.integers(0, len(names)))]
     io, mo = preset(pname)
     ntg = int(rng.integers(1, 4))
     genome = [synth.random_seq(rng, int(rng.integers(300000, 1500000) if big else rng.integers(20000, 120000))) for _ in range(ntg)]
@@ -41,6 +45,14 @@ def draw_case(seed, big=False):
     err = float(rng.uniform(0.0, 0.07))
     reads, truth = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(8000, 40000) if big else rng.integers(400, 9000)), err=(err, err / 2, err))
     truth = [int(t[0]) for t in truth]
+    if sv:
+        for ri in range(len(reads)):
+            if rng.random() < 0.5 and len(reads[ri]) > 1500:
+                r = reads[ri]
+                for _ in range(int(rng.integers(1, 4))):
+                    L = int(rng.integers(30, 600)); p = int(rng.integers(300, max(301, len(r) - 300 - L)))
+                    r = np.concatenate([r[:p], r[p + L:]]) if rng.random() < 0.5 else np.concatenate([r[:p], synth.random_seq(rng, L), r[p:]])
+                reads[ri] = r
     if edge_repeats:                                  # reads that start exactly at base 0 / end at the last base of a target
         for _ in range(int(rng.integers(1, 6))):
             gi = int(rng.integers(0, ntg)); g = genome[gi]
@@ -80,10 +92,10 @@ def draw_case(seed, big=False):
     return pname, io, mo, genome, reads, qtarget, edge_repeats
 
 
-def run(eng, n_iter, seed0, big=False):
+def run(eng, n_iter, seed0, big=False, sv=False, presets=None):
     from test_gpu_parity import compare_all
     for it in range(n_iter):
-        pname, io, mo, genome, reads, qtarget, edge_repeats = draw_case(seed0 * 1000 + it, big)
+        pname, io, mo, genome, reads, qtarget, edge_repeats = draw_case(seed0 * 1000 + it, big, sv, presets)
         try:
             compare_all(eng, genome, reads, io, mo, qtarget=qtarget)
         except Exception as e:
@@ -96,5 +108,6 @@ if __name__ == "__main__":
     n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
-    run(Engine(0), n_iter, seed0, big=os.environ.get("FUZZ_BIG") is not None)
+    run(Engine(0), n_iter, seed0, big=os.environ.get("FUZZ_BIG") is not None, sv=os.environ.get("FUZZ_SV") is not None,
+        presets=os.environ["FUZZ_PRESETS"].split(",") if os.environ.get("FUZZ_PRESETS") else None)
     print("fuzz ok:", n_iter, "iterations in %.1f s" % (time.time() - t0))

@@ -15,3 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def test_random_configurations(engine, seed):
     import fuzz_parity
     fuzz_parity.run(engine, 40, seed)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_configurations_with_large_indels_under_the_convex_cost(engine, seed):
+    """reads with 30-600-base insertions / deletions on the `ngmlr-*` presets: fills in bands of 128-1,024 diagonals and long gap
+    runs, i.e. the re-biased int16 classes of the convex cost (one wave, several waves) and the int32 classes behind them"""
+    import fuzz_parity
+    fuzz_parity.run(engine, 12, seed, sv=True, presets=["ngmlr-ont", "ngmlr-pacbio"])

@@ -185,6 +185,11 @@ void telr_seqset_free(telr_seqset *s);
  * form: no host packing, no upload.  Replaces `seqtk subseq` of window reads out of the read file
  * (TELR_assembly.py:419-456) when the reads are already resident for stage 1. */
 int  telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out);
+/* the same with an orientation per copy: sequence i of the new set is the REVERSE COMPLEMENT of parent[idx[i]] when rc[i] != 0
+ * (rc NULL = telr_seqset_subset).  Replaces the reverse-complemented contig FASTA of the per-locus realignment
+ * (`realignment()` maps the window reads to the contig and to its reverse complement, TELR_te.py:495-515, 644-646): the
+ * contigs are turned on the device, from the packed form they already have there. */
+int  telr_seqset_subset_rc(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, const uint8_t *rc, telr_seqset **out);
 int64_t telr_seqset_bases(const telr_seqset *s);
 int32_t telr_seqset_count(const telr_seqset *s);
 /* The packed form itself, for moving sequences between the GPUs of a node without ever unpacking them (the N > 1 hand-offs of

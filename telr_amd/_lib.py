@@ -12,7 +12,7 @@ SO_PATH = os.environ.get("TELR_LIB") or os.path.join(_HERE, "libtelrhip.so")    
 
 EXPORTS = [
     "telr_init", "telr_destroy", "telr_strerror", "telr_last_error", "telr_device_name", "telr_preset",
-    "telr_seqset_create", "telr_seqset_subset", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
+    "telr_seqset_create", "telr_seqset_subset", "telr_seqset_subset_rc", "telr_seqset_free", "telr_seqset_bases", "telr_seqset_count",
     "telr_index_build", "telr_index_free", "telr_index_stats", "telr_map",
     "telr_result_from_arrays", "telr_result_count", "telr_result_alns", "telr_result_cigar_count", "telr_result_cigars", "telr_result_wait", "telr_result_free",
     "telr_init_background", "telr_release_scratch", "telr_device_mem", "telr_write_paf", "telr_write_sam", "telr_write_bam", "telr_write_bam_dev", "telr_bam_prepare", "telr_bam_release_wait", "telr_bam_discard", "telr_write_bam_slice", "telr_bam_segment_info", "telr_bam_segment_entries", "telr_bam_segment_write", "telr_bam_segment_free", "telr_bai_write", "telr_result_from_device_cigars", "telr_seqset_packed", "telr_seqset_from_packed", "telr_consensus_build", "telr_poa_build", "telr_consensus_count", "telr_consensus_seq", "telr_consensus_off", "telr_consensus_len", "telr_consensus_free", "telr_fasta_load", "telr_fasta_count", "telr_fasta_bases", "telr_fasta_extent", "telr_fasta_seq", "telr_fasta_off", "telr_fasta_len", "telr_fasta_names", "telr_fasta_free", "telr_depth_medians", "telr_window_reads", "telr_stage_ms", "telr_stage_name", "telr_last_counters", "telr_last_dp_classes",
@@ -44,6 +44,7 @@ def lib():
     L.telr_preset.restype = C.c_int; L.telr_preset.argtypes = [cp, C.POINTER(IdxOpt), C.POINTER(MapOpt)]
     L.telr_seqset_create.restype = C.c_int; L.telr_seqset_create.argtypes = [vp, i32, vp, vp, vp, C.POINTER(vp)]
     L.telr_seqset_subset.restype = C.c_int; L.telr_seqset_subset.argtypes = [vp, vp, i32, vp, C.POINTER(vp)]
+    L.telr_seqset_subset_rc.restype = C.c_int; L.telr_seqset_subset_rc.argtypes = [vp, vp, i32, vp, vp, C.POINTER(vp)]
     L.telr_seqset_packed.restype = C.c_int; L.telr_seqset_packed.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.telr_seqset_from_packed.restype = C.c_int; L.telr_seqset_from_packed.argtypes = [vp, i32, vp, vp, i64, vp, i64, C.POINTER(vp)]
     L.telr_seqset_free.restype = None; L.telr_seqset_free.argtypes = [vp]

@@ -149,15 +149,22 @@ class SeqSet:
     def bases(self):
         return int(self.eng.L.telr_seqset_bases(self.h))
 
-    def subset(self, idx, eng=None):
+    def subset(self, idx, eng=None, rc=None):
         """new set = copies of sequences idx (repeats allowed), gathered on the device from the packed form
-        (eng: the context whose stream does the gather; default the one the set was made on)"""
+        (eng: the context whose stream does the gather; default the one the set was made on); rc: one flag per copy, set = the copy
+        is the reverse complement of its source (telr_seqset_subset_rc)"""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         eng = self.eng if eng is None else eng
         sub = SeqSet.__new__(SeqSet)
         sub.eng = eng
         h = C.c_void_p()
-        eng._chk(eng.L.telr_seqset_subset(eng.h, self.h, len(idx), idx.ctypes.data, C.byref(h)), "telr_seqset_subset")
+        if rc is None:
+            eng._chk(eng.L.telr_seqset_subset(eng.h, self.h, len(idx), idx.ctypes.data, C.byref(h)), "telr_seqset_subset")
+        else:
+            rc = np.ascontiguousarray(rc, dtype=np.uint8)
+            if len(rc) != len(idx):
+                raise ValueError("subset: one rc flag per index")
+            eng._chk(eng.L.telr_seqset_subset_rc(eng.h, self.h, len(idx), idx.ctypes.data, rc.ctypes.data, C.byref(h)), "telr_seqset_subset_rc")
         sub.h = h; sub.len = self.len[idx].copy(); sub.n = len(idx)
         return sub
 

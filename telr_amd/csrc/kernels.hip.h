@@ -3287,16 +3287,38 @@ __global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ p
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
 
-// ---- sequence-set subset: copy the packed words of the chosen sequences (64-base padded, so whole words) into a new set
+// ---- sequence-set subset: copy the packed words of the chosen sequences (64-base padded, so whole words) into a new set;
+// with `rc` (nullable) sequence i of the new set is the REVERSE COMPLEMENT of its source when rc[i] is set: the contigs of the
+// per-locus realignment (S6 maps every window read to the forward and the reverse-complement contig, TELR_te.py:644-646) are
+// turned on the device instead of on the host.  Base j of the result = 3 - base (L - 1 - j), an N stays an N (code 0 + mask bit,
+// as the packers write it), the padding behind the sequence is zero.
 __global__ void __launch_bounds__(256) k_seq_gather(const uint32_t *__restrict__ src2, const uint32_t *__restrict__ srcn,
                                                     const int64_t *__restrict__ src_boff, const int32_t *__restrict__ idx,
-                                                    const int64_t *__restrict__ dst_boff, int32_t n, uint32_t *__restrict__ dst2, uint32_t *__restrict__ dstn)
+                                                    const int64_t *__restrict__ dst_boff, int32_t n, uint32_t *__restrict__ dst2, uint32_t *__restrict__ dstn,
+                                                    const uint8_t *__restrict__ rc = nullptr, const int32_t *__restrict__ dst_len = nullptr)
 {
     const int i = blockIdx.x;
     if (i >= n) return;
     const int64_t sb = src_boff[idx[i]], db = dst_boff[i], nb = dst_boff[i + 1] - db;      // padded bases, multiples of 64
     const uint32_t *s2 = src2 + sb / 16, *sn = srcn + sb / 32;
     uint32_t *d2 = dst2 + db / 16, *dn = dstn + db / 32;
+    if (rc && rc[i]) {
+        const int L = dst_len[i];
+        for (int64_t w = threadIdx.x; w < nb / 32; w += blockDim.x) {            // 32 bases: two code words, one mask word
+            uint32_t c0 = 0, c1 = 0, m = 0;
+            for (int x = 0; x < 32; ++x) {
+                const int64_t j = w * 32 + x;
+                if (j >= L) break;
+                const int64_t p = L - 1 - j;
+                const uint32_t isn = (sn[p >> 5] >> (int)(p & 31)) & 1u;
+                const uint32_t code = isn ? 0u : 3u - ((s2[p >> 4] >> ((int)(p & 15) * 2)) & 3u);
+                if (x < 16) c0 |= code << (2 * x); else c1 |= code << (2 * (x - 16));
+                m |= isn << x;
+            }
+            d2[2 * w] = c0; d2[2 * w + 1] = c1; dn[w] = m;
+        }
+        return;
+    }
     for (int64_t w = threadIdx.x; w < nb / 16; w += blockDim.x) d2[w] = s2[w];
     for (int64_t w = threadIdx.x; w < nb / 32; w += blockDim.x) dn[w] = sn[w];
 }

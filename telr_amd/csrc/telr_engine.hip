@@ -520,7 +520,7 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     *out = s;
     return TELR_OK;
 }
-extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out)
+static int seqset_subset_impl(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, const uint8_t *rc, telr_seqset **out)
 {
     (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     if (!ctx || !parent || n < 0 || !out || (n > 0 && !idx)) return TELR_E_ARG;
@@ -537,26 +537,36 @@ extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int3
     s->boff[n] = tot; s->padded_bases = tot;
     const size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
     auto fail = [&](hipError_t e) { ctx->err = std::string("seqset subset: ") + hipGetErrorString(e); telr_seqset_free(s); return e == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP; };
-    hipError_t e; int32_t *d_idx = nullptr;
+    hipError_t e; int32_t *d_idx = nullptr; uint8_t *d_rc = nullptr;
     if ((e = hipMalloc(&s->d_seq2, w2 * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_nmask, wn * 4)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_boff, (n + 1) * 8)) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&s->d_len, (n ? n : 1) * 4)) != hipSuccess) return fail(e);
     // the index list lives in the context's scratch: a hipMalloc / hipFree pair per call would make the call wait for the whole device
-    { void *p = nullptr; const int rc = ctx_buf(ctx, "subset_idx", (size_t)(n ? n : 1) * 4, &p); if (rc != TELR_OK) { telr_seqset_free(s); return rc; } d_idx = (int32_t*)p; }
+    { void *p = nullptr; const int rc_ = ctx_buf(ctx, "subset_idx", (size_t)(n ? n : 1) * 4, &p); if (rc_ != TELR_OK) { telr_seqset_free(s); return rc_; } d_idx = (int32_t*)p; }
+    if (rc) { void *p = nullptr; const int rc_ = ctx_buf(ctx, "subset_rc", (size_t)(n ? n : 1), &p); if (rc_ != TELR_OK) { telr_seqset_free(s); return rc_; } d_rc = (uint8_t*)p; }
     hipStream_t st = ctx->stream;
     // the 8 slack words behind the last sequence are read by window loads: keep them defined
     if ((e = hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st)) != hipSuccess || (e = hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st)) != hipSuccess) return fail(e);
     if ((e = hipMemcpyAsync(s->d_boff, s->boff.data(), (n + 1) * 8, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
     if (n) {
         if ((e = hipMemcpyAsync(s->d_len, s->len.data(), n * 4, hipMemcpyHostToDevice, st)) != hipSuccess || (e = hipMemcpyAsync(d_idx, idx, n * 4, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
-        hipLaunchKernelGGL(k_seq_gather, dim3(n), dim3(256), 0, st, parent->d_seq2, parent->d_nmask, parent->d_boff, d_idx, s->d_boff, n, s->d_seq2, s->d_nmask);
+        if (d_rc && (e = hipMemcpyAsync(d_rc, rc, n, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(k_seq_gather, dim3(n), dim3(256), 0, st, parent->d_seq2, parent->d_nmask, parent->d_boff, d_idx, s->d_boff, n, s->d_seq2, s->d_nmask, (const uint8_t*)d_rc, (const int32_t*)s->d_len);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e);
     }
     e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(e);
     *out = s;
     return TELR_OK;
+}
+extern "C" int telr_seqset_subset(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, telr_seqset **out)
+{
+    return seqset_subset_impl(ctx, parent, n, idx, nullptr, out);
+}
+extern "C" int telr_seqset_subset_rc(telr_ctx *ctx, const telr_seqset *parent, int32_t n, const int32_t *idx, const uint8_t *rc, telr_seqset **out)
+{
+    return seqset_subset_impl(ctx, parent, n, idx, rc, out);
 }
 extern "C" int telr_seqset_packed(const telr_seqset *s, const void **d_seq2, const void **d_nmask, int64_t *nwords2, int64_t *nwordsn)
 {

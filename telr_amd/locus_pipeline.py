@@ -36,14 +36,21 @@ def run_loci_impl(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_s
     # S6 (window reads -> forward / reverse-complement contig) needs the contigs only: on an engine with a second context it
     # runs in a host thread of its own while S4, S5, S7 and the liftover tree run here; the annotation meets it at the depth step
     job = None
+    # on the engine the contigs are packed and uploaded ONCE: S4 / S5 index that set as it is, S6 takes its forward + reverse-complement
+    # target set from it on the device
+    cset = backend.seqset([l["contig"] for l in loci]) if loci and hasattr(backend, "worker") else None
+    cwhere = {l["name"]: k for k, l in enumerate(loci)} if cset is not None else None
+    if cwhere is not None and len(cwhere) != len(loci):
+        cset = cwhere = None                    # (duplicate locus names: contigs[name] is the last one, the set's order would not say so)
     if overlap_af and loci and hasattr(backend, "worker"):
         # a second context brings its own scratch: only where the device has room for it next to what stage 1 left behind
         fr, tot = backend.mem_info()
         if fr >= 0.3 * tot and not getattr(backend.worker(), "crowded", False):
-            job = telr_af.af_start(backend.worker(), contigs, reads_by_locus, presets, read_set, threaded=True)
+            job = telr_af.af_start(backend.worker(), contigs, reads_by_locus, presets, read_set, threaded=True,
+                                   contig_set=(cset, cwhere) if cset is not None else None)
     try:
         ann, s2c, t2c = telr_te.annotate_contig(backend, names, [l["contig"] for l in loci], [l["alt"] for l in loci],
-                                                lib_names, lib_seqs, presets)
+                                                lib_names, lib_seqs, presets, contig_set=cset)
         mapper = telr_liftover.engine_flank_mapper(ref_index, ref_names)
         reports, summary = telr_liftover.liftover(mapper, contigs, ann, ref_seq, ref_te_rows, flank_len, gap, overlap)
         contig_te = {}

@@ -205,11 +205,13 @@ def _af_map(job, engine, targets, reads_by_locus, presets, read_set):
                          ", ".join("%s %.1f" % kv for kv in engine.stage_ms().items() if kv[1] > 0.5) + "\n")
 
 
-def af_start(engine, contigs, reads_by_locus, presets="ont", read_set=None, names=None, threaded=False):
+def af_start(engine, contigs, reads_by_locus, presets="ont", read_set=None, names=None, threaded=False, contig_set=None):
     """Start the S6 realignment (window reads -> forward and reverse-complement contig of their locus) of the loci `names`
     (default: every locus that has a contig and reads).  It needs no annotation: with threaded=True it runs in a host thread
     on `engine` (which must then be a context nothing else uses meanwhile: Engine.worker()) while the caller annotates and
-    lifts the same loci.  -> AfJob for af_finish."""
+    lifts the same loci.  contig_set = (SeqSet of contigs resident on the device, {locus name: its index there}): the forward /
+    reverse-complement target set is then made on the device (SeqSet.subset(rc=...)) instead of being packed here and uploaded.
+    -> AfJob for af_finish."""
     job = AfJob()
     job.engine = engine; job.threaded = threaded
     job.names = [n for n in (names if names is not None else contigs) if n in contigs and n in reads_by_locus]
@@ -217,7 +219,12 @@ def af_start(engine, contigs, reads_by_locus, presets="ont", read_set=None, name
     job.lens = {n: len(contigs[n]) for n in job.names}
     if not job.names:
         return job
-    targets = _af_pack(job, contigs)          # in the caller's thread: Python-bound work gains nothing from a second thread
+    if contig_set is not None:
+        cset, where = contig_set
+        order = np.array([where[n] for n in job.names], np.int32)
+        targets = cset.subset(np.repeat(order, 2), eng=engine, rc=np.tile(np.array([0, 1], np.uint8), len(order)))
+    else:
+        targets = _af_pack(job, contigs)          # in the caller's thread: Python-bound work gains nothing from a second thread
     if not threaded:
         _af_map(job, engine, targets, reads_by_locus, presets, read_set)
         return job

@@ -22,13 +22,14 @@ def _strand(a):
     return "-" if a["flags"] & 8 else "+"
 
 
-def annotate_contig(backend, contig_names, contig_seqs, alt_seqs, lib_names, lib_seqs, presets="ont"):
+def annotate_contig(backend, contig_names, contig_seqs, alt_seqs, lib_names, lib_seqs, presets="ont", contig_set=None):
     """-> (annotation BED rows [contig, start, end, families, ".", strand], seq2contig rows, te2contig rows)
 
     backend: telr_amd.aligner.Engine (or a test double with the same index()/map() surface).
-    alt_seqs[i] is the Sniffles ALT sequence of locus i (None = locus skipped)."""
+    alt_seqs[i] is the Sniffles ALT sequence of locus i (None = locus skipped).
+    contig_set: the contigs as a sequence set already on the device (same order as contig_seqs), indexed as it is."""
     io, mo = preset("map-ont" if presets == "ont" else "map-pb")
-    ix = backend.index(list(contig_seqs), io)
+    ix = backend.index(contig_set if contig_set is not None else list(contig_seqs), io)
     # S4: --secondary=no, query i restricted to contig i
     mo4 = mo.copy(); mo4.secondary = 0
     q_idx = [i for i, s in enumerate(alt_seqs) if s]

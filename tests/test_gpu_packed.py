@@ -47,3 +47,25 @@ def test_packed_words_are_the_documented_layout_and_round_trip(engine, data_dir)
     ix.free_raw(raw); back.free(); s.free()
     with pytest.raises(Exception):                                     # word counts that do not fit the lengths are refused
         SeqSet.from_packed(engine, [100], moved2[:4], movedn[:2])
+
+
+def test_reverse_complement_subset_equals_the_packed_reverse_complement(engine):
+    """telr_seqset_subset_rc: the copies flagged rc are the reverse complements of their sources, word for word what the packer
+    makes of the reverse-complemented strings (N stays N, lengths 0 / 1 / 63 / 64 / 65 / several words, repeats)"""
+    import packed_np
+    from telr_amd.fasta import revcomp
+    rng = np.random.default_rng(5)
+    seqs = ["", "A", "ACGTN", "".join(rng.choice(list("ACGT"), 63)), "".join(rng.choice(list("ACGT"), 64)), "".join(rng.choice(list("ACGTN"), 65)),
+            "".join(rng.choice(list("ACGT"), 1000)), "N" * 40 + "".join(rng.choice(list("ACGT"), 333)) + "NN"]
+    s = engine.seqset(seqs)
+    idx = np.array([7, 0, 1, 2, 3, 3, 4, 5, 6, 6, 7], np.int32)
+    rc = np.array([1, 1, 1, 1, 0, 1, 1, 1, 0, 1, 0], np.uint8)
+    sub = s.subset(idx, rc=rc)
+    w2, wn = sub.packed()
+    want = [revcomp(seqs[i]) if f else seqs[i] for i, f in zip(idx, rc)]
+    lens, e2, en = packed_np.pack(want)
+    assert list(sub.len) == [len(x) for x in want]
+    np.testing.assert_array_equal(w2.cpu().numpy().view(np.uint32), e2)
+    np.testing.assert_array_equal(wn.cpu().numpy().view(np.uint32), en)
+    with pytest.raises(ValueError):
+        s.subset(idx, rc=rc[:3])

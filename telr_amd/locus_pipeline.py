@@ -42,7 +42,8 @@ def run_loci_impl(backend, ref_index, ref_names, ref_seq, loci, lib_names, lib_s
     cwhere = {l["name"]: k for k, l in enumerate(loci)} if cset is not None else None
     if cwhere is not None and len(cwhere) != len(loci):
         cset = cwhere = None                    # (duplicate locus names: contigs[name] is the last one, the set's order would not say so)
-    if overlap_af and loci and hasattr(backend, "worker"):
+    import os
+    if overlap_af and loci and hasattr(backend, "worker") and not os.environ.get("TELR_LOCI_NO_OVERLAP"):          # (the switch: A/B runs)
         # a second context brings its own scratch: only where the device has room for it next to what stage 1 left behind
         fr, tot = backend.mem_info()
         if fr >= 0.3 * tot and not getattr(backend.worker(), "crowded", False):

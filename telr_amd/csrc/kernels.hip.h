@@ -1172,15 +1172,13 @@ __device__ __forceinline__ void d_chain_push(uint32_t gi, uint32_t qi, uint32_t 
     if (ok && v2 >= B) { B = v2; bp = j; }
 }
 
+// one run of anchors [base, base + n): a query's whole list, or one ISLAND of it (below); pdelta = where the run starts inside its
+// query's list (predecessor indices are stored relative to the query)
 template <int R, bool SKIP>
-__global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
+__device__ __forceinline__ void d_chain_run(const uint64_t *__restrict__ keys, const int64_t base, const int n, const int pdelta,
+                                            const ChainOpt &o, int32_t *__restrict__ f, int32_t *__restrict__ p)
 {
-    if ((int)blockIdx.x >= nq) return;
-    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;    // longest reads first: the kernel ends with the short ones
     const int lane = threadIdx.x;
-    const int64_t base = q_aoff[q];
-    const int n = q_aoff[q + 1] - q_aoff[q];
     const uint64_t *a = keys + base;
     const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
     const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
@@ -1229,9 +1227,50 @@ __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys,
                 for (int s = 0; s < R; ++s)     // anchors currently owned: index > j and <= j + 64R by construction
                     d_chain_push<SKIP>(gi[s], qi[s], sp1[s], gj1, qj1, fj2p2, j, max_gap, ddc, gap_q8, skip_q8, B[s], bp[s]);
             }
-            if (lane < jn) { f[base + j0 + lane] = myB >> 1; p[base + j0 + lane] = (myB & 1) ? -1 : myp; }
+            if (lane < jn) { f[base + j0 + lane] = myB >> 1; p[base + j0 + lane] = (myB & 1) ? -1 : myp + pdelta; }
         }
     }
+}
+
+template <int R, bool SKIP>
+__global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
+                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
+{
+    if ((int)blockIdx.x >= nq) return;
+    const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;    // longest reads first: the kernel ends with the short ones
+    d_chain_run<R, SKIP>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p);
+}
+// ISLANDS.  Anchors are sorted by (strand, reference position) and a link needs 0 < dr <= max_gap, so wherever two consecutive
+// anchors of a query lie more than max_gap apart (or on different strands: bit 31) no link crosses: the list falls into islands
+// that chain independently -- same f, same p, the look-back window being a window of indices inside the island anyway.  One wave
+// per query is the right grain for stage 1 (458,550 reads); a call with FEW queries and long lists -- the TE library against a
+// thousand contigs (S5: 127 queries, ~100 k anchors each), the ALT sequences, the flanks -- left the device to 127 waves, each
+// walking its list serially.  Such calls (nq <= CHAIN_ISL_NQ) chain island by island: k_isl_heads marks the island heads,
+// a scan numbers them, k_isl_fill writes their offsets, and k_chain_isl is a grid-stride loop over the count the device holds.
+#define CHAIN_ISL_NQ 4096
+__global__ void __launch_bounds__(256) k_isl_heads(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq, uint32_t max_gap, int32_t *__restrict__ head)
+{
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        head[base + i] = i == 0 || (uint32_t)(keys[base + i] >> 32) - (uint32_t)(keys[base + i - 1] >> 32) > max_gap;
+}
+__global__ void __launch_bounds__(256) k_isl_fill(const int32_t *__restrict__ q_aoff, int32_t nq, const int32_t *__restrict__ head, const int32_t *__restrict__ rank, int32_t na,
+                                                  int32_t *__restrict__ isl_off, int32_t *__restrict__ isl_pd)
+{
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) if (head[base + i]) { const int id = rank[base + i]; isl_off[id] = (int32_t)base + i; isl_pd[id] = i; }
+    if (q == 0 && threadIdx.x == 0) isl_off[rank[na]] = na;
+}
+template <int R, bool SKIP>
+__global__ void __launch_bounds__(64) k_chain_isl(const uint64_t *__restrict__ keys, const int32_t *__restrict__ isl_off, const int32_t *__restrict__ isl_pd, const int32_t *__restrict__ nisl,
+                                                  ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p)
+{
+    const int n_isl = *nisl;
+    for (int s = blockIdx.x; s < n_isl; s += gridDim.x) d_chain_run<R, SKIP>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p);
 }
 
 // peaks: anchors with no successor of larger f

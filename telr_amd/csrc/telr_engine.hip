@@ -1742,7 +1742,27 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     const int Rr = mo->chain_lookback / 64;
 #define CHAIN_LAUNCH(RR, SK) hipLaunchKernelGGL((k_chain<RR, SK>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder)
     const bool skip = co.chain_skip_q8 != 0;
-    if (Rr == 1) { if (skip) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(1, false); }
+    static const bool no_islands = getenv("TELR_CHAIN_NO_ISLANDS") != nullptr;       // A/B: one wave per query whatever the call's shape
+    if (nq <= CHAIN_ISL_NQ && na > 0 && !no_islands) {
+        // few queries: chain island by island (kernels.hip.h: ISLANDS) -- same f and p, thousands of waves instead of nq
+        int32_t *d_head, *d_rank, *d_ioff, *d_ipd;
+        TRY(ctx_buf_t(ctx, "isl_head", (size_t)na + 1, &d_head));
+        TRY(ctx_buf_t(ctx, "isl_rank", (size_t)na + 1, &d_rank));
+        TRY(ctx_buf_t(ctx, "isl_off", (size_t)na + 2, &d_ioff));
+        TRY(ctx_buf_t(ctx, "isl_pd", (size_t)na + 1, &d_ipd));
+        HIPCHK(hipMemsetAsync(d_head + na, 0, 4, st));
+        hipLaunchKernelGGL(k_isl_heads, dim3(nq), dim3(256), 0, st, d_skeys, d_qaoff, nq, (uint32_t)co.max_gap, d_head);
+        HIPCHK(hipGetLastError());
+        TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_head, d_rank, (size_t)na + 1)));
+        hipLaunchKernelGGL(k_isl_fill, dim3(nq), dim3(256), 0, st, d_qaoff, nq, d_head, d_rank, (int32_t)na, d_ioff, d_ipd);
+        const unsigned grid = (unsigned)std::min<int64_t>((int64_t)na, 256 * 32);
+#define CHAIN_ISL(RR, SK) hipLaunchKernelGGL((k_chain_isl<RR, SK>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p)
+        if (Rr == 1) { if (skip) CHAIN_ISL(1, true); else CHAIN_ISL(1, false); }
+        else if (Rr == 2) { if (skip) CHAIN_ISL(2, true); else CHAIN_ISL(2, false); }
+        else { if (skip) CHAIN_ISL(4, true); else CHAIN_ISL(4, false); }
+#undef CHAIN_ISL
+    }
+    else if (Rr == 1) { if (skip) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(1, false); }
     else if (Rr == 2) { if (skip) CHAIN_LAUNCH(2, true); else CHAIN_LAUNCH(2, false); }
     else { if (skip) CHAIN_LAUNCH(4, true); else CHAIN_LAUNCH(4, false); }
 #undef CHAIN_LAUNCH

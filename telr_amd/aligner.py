@@ -99,7 +99,7 @@ class Engine:
     def worker(self):
         """A second context on the same device (created on first use, closed with this one): a host thread can run an engine
         call on it while this context runs another -- contexts are not re-entrant, different contexts are independent
-        (the library's sub-batch workers are such contexts).  Sequence sets and indexes are plain device data and may be
+        (the second range slot of a large call is such a context).  Sequence sets and indexes are plain device data and may be
         used from either."""
         w = getattr(self, "_worker", None)
         if w is None:

@@ -1286,7 +1286,6 @@ static uint64_t g_bam_need = 0;          // device bytes the writer was about to
 static void ctx_collect_scratch(telr_ctx *ctx, std::vector<DBuf*> &v)
 {
     for (auto &kv : ctx->bufs) if (kv.first.compare(0, 4, "bam_") != 0 && kv.second.p) v.push_back(&kv.second);
-    for (int k = 0; k < 4; ++k) if (ctx->child[k]) ctx_collect_scratch(ctx->child[k], v);
     if (ctx->slot1) ctx_collect_scratch(ctx->slot1, v);
 }
 // largest buffers first, until `need` bytes are free (the next telr_map call allocates what it misses again: ~25 ms per GB)

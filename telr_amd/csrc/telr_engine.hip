@@ -56,7 +56,7 @@ struct telr_ctx {
     std::vector<std::pair<uint32_t*, size_t>> cig_pool;   // recycled result CIGAR buffers
     std::vector<std::vector<telr_aln>> aln_pool;          // recycled result record arrays (a fresh 50-MB vector is page-faulted on every call)
     // grow-only host scratch of map_batch / map_range (same reason: no allocation, no first-touch faults in the steady state)
-    std::vector<telr_aln> h_kal, h_stage, h_merge;
+    std::vector<telr_aln> h_kal, h_stage;
     std::vector<int32_t> h_nsurv, h_poffv;
     TileList tiles;                                       // a batch of 1 Gbp has ~1 M tiles
     int debug = 0;                        // keep stage-level captures for the parity tests
@@ -67,16 +67,13 @@ struct telr_ctx {
     hipEvent_t evk[6] = {nullptr};        // un-synchronised markers around single kernels
     int64_t dpcls[TELR_N_DPCLS * 4] = {0};
     int64_t dp_retries = 0;
-    int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (ranges x lanes)
+    int64_t pk_launches = 0;              // k_dp_pk launches of first DP passes in the last telr_map call (one per range)
     bool background = false;              // streams at the lowest priority (telr_init_background)
     telr_ctx *twin_owner = nullptr; int64_t twin_bases = 0;       // set for the duration of a telr_map call on the contexts that append to its result
     uint32_t *twin_pool = nullptr; size_t twin_pool_cap = 0;      // device CIGAR array of a freed result (TELR_MF_KEEP_CIGARS), for the next call
     struct BamSink *bam_sink = nullptr;   // an output file being prepared for telr_write_bam_dev (bam_dev.hip.h)
-    telr_ctx *child[4] = {nullptr};       // worker contexts (own streams / scratch) for concurrent sub-batches
-    telr_ctx *slot1 = nullptr;            // the second range slot (a parent context with lane workers of its own)
+    telr_ctx *slot1 = nullptr;            // the second range slot (a context of the same kind: own streams and scratch)
     bool pipe_nomem = false;              // two ranges in flight once ran out of device memory: later calls run one at a time
-    int n_child = 0;
-    bool is_child = false;
     char devname[256] = {0};
     // debug captures of the last batch (device pointers stay valid until the next call)
     int64_t dbg_na = 0; int32_t dbg_nq = 0;
@@ -230,7 +227,7 @@ extern "C" int telr_stage_ms(const telr_ctx *ctx, float *ms) { if (!ctx || !ms) 
 extern "C" int telr_last_counters(const telr_ctx *ctx, telr_counters *out) { if (!ctx || !out) return TELR_E_ARG; *out = ctx->ctr; return TELR_OK; }
 extern "C" int telr_last_dp_classes(const telr_ctx *ctx, int64_t *out) { if (!ctx || !out) return TELR_E_ARG; memcpy(out, ctx->dpcls, sizeof(ctx->dpcls)); return TELR_OK; }
 
-// background = true: every stream of the context (and of its sub-batch contexts) is created at the device's lowest priority, so
+// background = true: every stream of the context (and of its second range slot) is created at the device's lowest priority, so
 // that the kernels of another context of the process are dispatched ahead of this one's (telr_init_background)
 static int ctx_init(int device, bool background, telr_ctx **out)
 {
@@ -259,24 +256,12 @@ static int ctx_init(int device, bool background, telr_ctx **out)
 }
 extern "C" int telr_init(int device, telr_ctx **out) { return ctx_init(device, false, out); }
 extern "C" int telr_init_background(int device, telr_ctx **out) { return ctx_init(device, true, out); }
-static int ctx_make_child(telr_ctx *ctx, int k)
-{
-    if (ctx->child[k]) return TELR_OK;
-    telr_ctx *c = nullptr;
-    int r = ctx_init(ctx->device, ctx->background, &c);
-    if (r != TELR_OK) return r;
-    c->is_child = true; c->debug = ctx->debug;
-    ctx->child[k] = c;
-    if (k + 1 > ctx->n_child) ctx->n_child = k + 1;
-    return TELR_OK;
-}
 static void bam_sink_drop(telr_ctx *ctx);
 extern "C" void telr_destroy(telr_ctx *ctx)
 {
     if (!ctx) return;
     bam_sink_drop(ctx);
     if (ctx->twin_pool) { (void)hipFree(ctx->twin_pool); ctx->twin_pool = nullptr; }
-    for (int k = 0; k < 4; ++k) if (ctx->child[k]) { telr_destroy(ctx->child[k]); ctx->child[k] = nullptr; }
     if (ctx->slot1) { telr_destroy(ctx->slot1); ctx->slot1 = nullptr; }
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
@@ -1033,17 +1018,16 @@ struct telr_result {
     size_t ncig = 0, cap = 0;      // cap in ops
     mutable hipEvent_t dma_done = nullptr;   // non-null while the CIGAR DMA has not been waited for
     // TELR_MF_KEEP_CIGARS: the same array on the device (same offsets), for telr_write_bam_dev.  Mirrored piece by piece as the
-    // host array grows: the stitched scratch of a range by a device copy, the pieces merged in on the host (long-read lane) by an
-    // upload behind the remaining ranges.  Complete iff twin_n == ncig and !twin_off.
-    uint32_t *d_cig = nullptr; size_t d_cap = 0, twin_n = 0; bool twin_off = false, is_part = false;
+    // host array grows: the stitched scratch of a range by a device copy.  Complete iff twin_n == ncig and !twin_off.
+    uint32_t *d_cig = nullptr; size_t d_cap = 0, twin_n = 0; bool twin_off = false;
     mutable std::vector<hipEvent_t> up_events;   // uploads into d_cig that read `cig`: waited for before `cig` moves
     // Ranges of one telr_map call may be in flight on two slots (telr_map: range pipelining).  They append to this result in
-    // range order: a range waits here for its turn before it first touches alns / cig, and keeps the turn until its lanes
-    // are merged.  turn < 0: a range failed, everybody leaves.
+    // range order: a range waits here for its turn before it first touches alns / cig, and keeps the turn until it is in.
+    // turn < 0: a range failed, everybody leaves.
     std::mutex gate_m; std::condition_variable gate_cv; int turn = 0;
     ~telr_result();
 };
-// what a batch saw when it got its turn (map_range merges the lanes from there)
+// what a batch saw when it got its turn
 struct RangeTurn { int turn = -1; bool entered = false; size_t a0 = 0, c0 = 0; };
 static bool gate_enter(telr_result *R, RangeTurn *g)
 {
@@ -1096,7 +1080,7 @@ static void pool_put(telr_ctx *ctx, uint32_t *p, size_t cap)
 // owner: the top-level context of the call (its pool supplies / takes the device array); bases: query bases of the whole call.
 static void twin_put(telr_ctx *owner, telr_result *R, const telr_map_opt *mo, size_t base, size_t n, const uint32_t *src_dev, int64_t bases, hipStream_t st)
 {
-    if (!(mo->flags & TELR_MF_KEEP_CIGARS) || R->is_part || R->twin_off) return;
+    if (!(mo->flags & TELR_MF_KEEP_CIGARS) || R->twin_off) return;
     if (base != R->twin_n) { R->twin_off = true; return; }           // a piece went by unmirrored
     if (!R->d_cig) {
         const size_t want = std::max<size_t>((size_t)((double)bases * 0.3) + ((size_t)1 << 20), base + n + 1);
@@ -1131,9 +1115,9 @@ static void pool_get(telr_ctx *ctx, uint32_t **p, size_t *cap)
 telr_result::~telr_result()
 {
     result_wait(this); pool_put(ctx, cig, cap);
-    if (d_cig) { if (ctx && !ctx->is_child && !ctx->twin_pool) { ctx->twin_pool = d_cig; ctx->twin_pool_cap = d_cap; } else (void)hipFree(d_cig); d_cig = nullptr; }
+    if (d_cig) { if (ctx && !ctx->twin_pool) { ctx->twin_pool = d_cig; ctx->twin_pool_cap = d_cap; } else (void)hipFree(d_cig); d_cig = nullptr; }
     // (a worker context never takes from its pool -- its results are created without one -- so it does not keep vectors either)
-    if (ctx && !ctx->is_child && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
+    if (ctx && alns.capacity() && ctx->aln_pool.size() < 2) { alns.clear(); ctx->aln_pool.emplace_back(std::move(alns)); }
 }
 // a result made of caller-supplied records and CIGAR words (copied): one rank writes the BAM of reads other ranks mapped
 extern "C" int telr_result_from_arrays(telr_ctx *ctx, const telr_aln *alns, int64_t n, const uint32_t *cigars, int64_t n_cigar, telr_result **out)
@@ -1237,7 +1221,7 @@ public:
     void run(int ntask, const std::function<void(int)> &f)
     {
         if (ntask <= 0) return;
-        std::unique_lock<std::mutex> job(job_mu_);          // serialise callers (sub-batch contexts share the pool)
+        std::unique_lock<std::mutex> job(job_mu_);          // serialise callers (the two range slots share the pool)
         ensure(ntask - 1);
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -1593,7 +1577,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     const int nq = q1 - q0, k = ix->io.k, w = ix->io.w;
     const telr_seqset *tg = ix->targets;
     hipStream_t st = ctx->stream;
-    HostTrace ht(ctx->is_child ? "batch/worker" : "batch");
+    HostTrace ht("batch");
 
     // ---- sketch -------------------------------------------------------------------------
     // queries in descending length order for the one-block-per-query kernels (their tail is the longest read): sorted by
@@ -2194,171 +2178,20 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     return TELR_OK;
 }
 
-// A non-owning sequence set made of sequences idx[] of `parent`, gathered on c's stream into c's grow-only scratch
-// (no allocation in the steady state); valid until the next call with the same tag.
-static int seqset_subset_into(telr_ctx *ctx, const telr_seqset *parent, const std::vector<int32_t> &idx, const std::string &tag, telr_seqset *s)
-{
-    telr_ctx *c = ctx;
-    const int n = (int)idx.size();
-    s->ctx = c; s->n = n; s->boff.resize(n + 1); s->len.resize(n); s->total_bases = 0; s->max_len = 0;
-    int64_t tot = 0;
-    for (int i = 0; i < n; ++i) {
-        const int32_t L = parent->len[idx[i]];
-        s->len[i] = L; s->boff[i] = tot; tot += ((int64_t)L + 63) & ~63LL; s->total_bases += L;
-        if (L > s->max_len) s->max_len = L;
-    }
-    s->boff[n] = tot; s->padded_bases = tot;
-    const size_t w2 = (size_t)(tot / 16) + 8, wn = (size_t)(tot / 32) + 8;
-    int32_t *d_idx;
-    TRY(ctx_buf_t(c, (tag + "seq2").c_str(), w2, &s->d_seq2));
-    TRY(ctx_buf_t(c, (tag + "nmask").c_str(), wn, &s->d_nmask));
-    TRY(ctx_buf_t(c, (tag + "boff").c_str(), (size_t)n + 1, &s->d_boff));
-    TRY(ctx_buf_t(c, (tag + "len").c_str(), (size_t)n + 1, &s->d_len));
-    TRY(ctx_buf_t(c, (tag + "idx").c_str(), (size_t)n + 1, &d_idx));
-    hipStream_t st = c->stream;
-    HIPCHK(hipMemsetAsync(s->d_seq2 + (w2 - 8), 0, 32, st));
-    HIPCHK(hipMemsetAsync(s->d_nmask + (wn - 8), 0, 32, st));
-    HIPCHK(hipMemcpyAsync(s->d_boff, s->boff.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-    if (n) {
-        HIPCHK(hipMemcpyAsync(s->d_len, s->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_idx, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_seq_gather, dim3(n), dim3(256), 0, st, parent->d_seq2, parent->d_nmask, parent->d_boff, d_idx, s->d_boff, n, s->d_seq2, s->d_nmask);
-        HIPCHK(hipGetLastError());
-    }
-    return TELR_OK;
-}
-
 // One range [q0,q1) of the query set (at most one batch worth of bases); its records and CIGARs are appended to R.
-//
-// Long-read lane (opt-in, TELR_LONGSPLIT).  Seeding, chaining, back-tracking and the problem builder give one wave to a
-// read, so a batch waits for its longest read in each of these stages.  The longest reads can be mapped as their own small
-// batch on a worker context, concurrently with the rest (the bulk worker writes straight into R).  This paid while the
-// back-tracking walked with one lane; it no longer does (see below), so a range is one batch by default.
-//
 // A range whose anchors do not fit int32 offsets (map_batch: TELR_SPLIT_RANGE) is halved and retried.
+// (Rounds 1-3 could also map the longest reads of a range as a batch of their own on a worker context, and whole sub-batches on
+// several: both lost to the walker-free back-tracking + two ranges in flight and were removed in round 4 -- docs/DESIGN_r1_r3.md.)
 static int map_range(telr_ctx *ctx, const telr_index *ix, const telr_seqset *queries, const int32_t *qtarget, const int32_t *d_qt,
                      int32_t q0, int32_t q1, const telr_map_opt *mo, OccCut mid_occ, telr_result *R, int turn = -1)
 {
     const int nq = q1 - q0;
     if (nq <= 0) return TELR_OK;
-    int64_t total_bases = 0; int32_t max_len = 0;
-    for (int i = q0; i < q1; ++i) { total_bases += queries->len[i]; if (queries->len[i] > max_len) max_len = queries->len[i]; }
-    bool lane = false;
-    std::vector<int32_t> lane_idx[2];         // 0: the bulk, 1: the long reads (query ids, ascending)
-    {
-        // Off by default since the end of round 2: with the walker-free back-tracking, the tail classes on side streams and
-        // 2-Gbp ranges the lane no longer pays (configs[2] ranges of 0.5 / 1 / 2 Gbp: 13.8 / 15.1 / 15.8 Gbp/s with it, 14.6 /
-        // 15.4 / 16.0 without; configs[4] 15.1 / 15.5; configs[3] 3.93 / 3.88).  TELR_LONGSPLIT=auto applies the rule below,
-        // =<bases> sets the length threshold, =force splits any input (tests of the merge).
-        const char *e = getenv("TELR_LONGSPLIT");
-        const bool force = e && !strcmp(e, "force"), off = !e || !strcmp(e, "0");
-        if (!off && !ctx->is_child && nq >= 2 && (force || (!ctx->debug && nq >= 2000 && total_bases >= 100000000LL))) {
-            // Which reads go to the lane.  A range with far more reads than the device holds waves (>= 64 k reads): the longest
-            // reads holding ~10 % of the bases (configs[2], lengths log-normal around 9 kb, 230 k reads per range: reads above
-            // 50 / 40 / 25 / 20 / 15 kb in the lane -> 14.9 / 15.2 / 15.5 / 15.4 / 15.2 Gbp/s; 25 kb = 8 % of the bases), when
-            // they stand out (twice the mean length: uniform lengths have no tail to hide).  Fewer reads (configs[1]: 10 k
-            // reads of 47 kb, barely one wave per SIMD slot): only the very longest, a third of the maximum and up (a 10 % lane
-            // there costs 15 %: two half-empty pipelines).
-            int32_t thr = std::max(max_len / 3, force ? 0 : 30000);
-            if (!force && nq >= 65536) {
-                const int nb = (max_len >> 8) + 1;
-                std::vector<int64_t> hist((size_t)nb, 0);
-                for (int i = q0; i < q1; ++i) hist[queries->len[i] >> 8] += queries->len[i];
-                int64_t acc = 0; int b = nb - 1;
-                for (; b > 0; --b) { acc += hist[b]; if (acc * 10 >= total_bases) break; }
-                const int64_t mean = total_bases / nq;
-                if ((int64_t)b << 8 >= 2 * mean && (b << 8) < thr) thr = b << 8;
-            }
-            if (e && atoi(e) >= 1000) thr = atoi(e);          // experiments: the length above which a read goes to the long-read lane
-            int64_t long_bases = 0;
-            for (int i = q0; i < q1; ++i) { const int k = queries->len[i] > thr ? 1 : 0; lane_idx[k].push_back(i); if (k) long_bases += queries->len[i]; }
-            lane = !lane_idx[0].empty() && !lane_idx[1].empty() && (force || long_bases * 100 <= total_bases * 35);
-        }
-    }
-    int rr = TELR_OK;
+    int64_t total_bases = 0;
+    for (int i = q0; i < q1; ++i) total_bases += queries->len[i];
     RangeTurn gate; gate.turn = turn;         // (pipelined ranges: R is only touched once the earlier ranges are in)
-    HostTrace hr("range");
-    if (!lane) {
-        rr = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R, &gate);
-        if (rr == TELR_OK) ctx->ctr.query_bases += total_bases;
-    } else {
-        for (int k = 0; k < 2; ++k) TRY(ctx_make_child(ctx, k));
-        for (int k = 0; k < 2; ++k) { ctx->child[k]->twin_owner = ctx->twin_owner ? ctx->twin_owner : ctx; ctx->child[k]->twin_bases = ctx->twin_bases; }
-        // the recycled (large) result buffers go to the bulk worker, which fills R
-        for (auto &pc : ctx->cig_pool) ctx->child[0]->cig_pool.push_back(pc);
-        ctx->cig_pool.clear();
-        telr_seqset sub[2]; telr_result *P1 = new telr_result(); P1->ctx = nullptr; P1->is_part = true; int rc[2] = { TELR_OK, TELR_OK };
-        auto work = [&](int k) {
-            telr_ctx *c = ctx->child[k];
-            (void)hipSetDevice(c->device);
-            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0;
-            const int n = (int)lane_idx[k].size();
-            if ((rc[k] = seqset_subset_into(c, queries, lane_idx[k], "lane_", &sub[k])) != TELR_OK) return;
-            int32_t *d_q = nullptr;
-            if (qtarget) {
-                std::vector<int32_t> qt(n);
-                for (int i = 0; i < n; ++i) qt[i] = qtarget[lane_idx[k][i]];
-                if ((rc[k] = ctx_buf_t(c, "lane_qt", (size_t)n + 1, &d_q)) != TELR_OK) return;
-                if (hipMemcpyAsync(d_q, qt.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rc[k] = TELR_E_HIP; return; }
-            }
-            rc[k] = map_batch(c, ix, &sub[k], d_q, 0, n, mo, mid_occ, k == 0 ? R : P1, k == 0 ? &gate : nullptr);
-            if (rc[k] == TELR_OK) c->ctr.query_bases += sub[k].total_bases;
-        };
-        hr.mark("lane lists");
-        std::thread tl(work, 1);
-        work(0);
-        hr.mark("bulk worker done");
-        tl.join();
-        hr.mark("long-read worker joined");
-        sub[0].d_seq2 = sub[0].d_nmask = nullptr; sub[1].d_seq2 = sub[1].d_nmask = nullptr;       // scratch of the workers, not owned
-        sub[0].d_boff = sub[1].d_boff = nullptr; sub[0].d_len = sub[1].d_len = nullptr;
-        for (int k = 0; k < 2 && rr == TELR_OK; ++k) if (rc[k] != TELR_OK) { if (rc[k] != TELR_SPLIT_RANGE) ctx->err = ctx->child[k]->err; rr = rc[k]; }
-        if (rr == TELR_OK && !gate_enter(R, &gate)) { ctx->err = "an earlier range of the call failed"; rr = TELR_E_HIP; }
-        const size_t a_start = gate.a0;
-        if (rr != TELR_OK) {                  // roll back what the bulk worker appended
-            if (gate.entered) { result_wait(R); R->alns.resize(gate.a0); R->ncig = gate.c0; }
-        } else {
-            // the long reads' ops go behind the bulk's; records are merged by query id (both lists are sorted by it)
-            result_wait(P1);
-            const size_t base1 = R->ncig;
-            if (P1->ncig) {
-                if (base1 + P1->ncig + 1 > R->cap) {
-                    result_wait(R);
-                    if (!cig_grow(&R->cig, &R->cap, base1, base1 + P1->ncig + 1 + P1->ncig / 8)) { P1->ctx = ctx->child[1]; delete P1; return TELR_E_NOMEM; }
-                }
-                const int NT = host_threads();
-                const size_t nw = P1->ncig; const int chunks = 64;          // (parallel_ranges runs fewer than 64 items on the calling thread)
-                parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
-                    for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + base1 + lo, P1->cig + lo, (hi - lo) * 4); }
-                });
-                R->ncig = base1 + P1->ncig;
-                if (R->twin_n > base1) R->twin_n = base1;
-                twin_put(ctx->twin_owner ? ctx->twin_owner : ctx, R, mo, base1, nw, nullptr, ctx->twin_bases, ctx->copy_stream);      // the long-read lane's ops: uploaded behind the ranges still to come
-            }
-            std::vector<telr_aln> &merged = ctx->h_merge;
-            merged.resize(R->alns.size() - a_start + P1->alns.size());
-            { size_t a = a_start, b = 0, o = 0;
-              const size_t na = R->alns.size(), nb = P1->alns.size();
-              while (a < na || b < nb) {
-                  const int32_t qa = a < na ? lane_idx[0][R->alns[a].qid] : INT32_MAX, qb = b < nb ? lane_idx[1][P1->alns[b].qid] : INT32_MAX;
-                  if (qa < qb) { telr_aln r = R->alns[a++]; r.qid = qa; merged[o++] = r; }
-                  else { telr_aln r = P1->alns[b++]; r.qid = qb; r.cigar_off += (int64_t)base1; merged[o++] = r; }
-              } }
-            R->alns.resize(a_start + merged.size());
-            std::copy(merged.begin(), merged.end(), R->alns.begin() + a_start);
-            for (int k = 0; k < 2; ++k) {
-                telr_ctx *c = ctx->child[k];
-                for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
-                const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
-                for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
-                for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
-                ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches;
-            }
-        }
-        P1->ctx = ctx->child[1];              // its buffer goes back to that worker's pool
-        delete P1;
-        hr.mark("merge");
-    }
+    int rr = map_batch(ctx, ix, queries, d_qt, q0, q1, mo, mid_occ, R, &gate);
+    if (rr == TELR_OK) ctx->ctr.query_bases += total_bases;
     if (rr == TELR_SPLIT_RANGE) {
         if (nq < 2) { ctx->err = "one read seeds 2^31 anchors or more"; return TELR_E_RANGE; }
         int32_t mid = q0; int64_t acc = 0;
@@ -2411,10 +2244,7 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
     int64_t total_bases = 0;
     for (int i = 0; i < nq; ++i) total_bases += queries->len[i];
     ctx->twin_owner = ctx; ctx->twin_bases = total_bases;
-    int nsub = 1;      // concurrent sub-batches on worker contexts: measured on the MI355X box, only pays when host cores are plentiful; opt-in via TELR_SUBBATCH
-    if (const char *e = getenv("TELR_SUBBATCH")) { int v = atoi(e); if (v >= 1 && v <= 4) nsub = v; }
-    if (nsub > nq) nsub = nq > 0 ? nq : 1;
-    if (nsub == 1) {
+    {
         // Ranges bounded by bases: a read set of any size streams through as consecutive ranges.  HBM is 288 GB and a range
         // needs ~75 B of scratch per read base at 0.25 anchors per base: a read set of up to 1.6 Gbp is ONE range (configs[2]
         // reads alone in ranges of 0.5 / 1 / 1.4 / 2.1 Gbp: 13.7 / 14.9 / 15.3 / 15.5 Gbp/s -- fewer synchronisation points and
@@ -2430,13 +2260,12 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // Range pipelining: a read set that needs more than one range runs TWO ranges at a time on two slots (the context and
         // a second one of the same kind), so the host work between the stages of a range -- synchronisations, the second
         // selection pass, the record assembly -- and its latency-bound stretches are covered by the other range's kernels;
-        // results are appended in range order through the turn gate of the result.  With the long-read lane (two batches per
-        // range already) this gained nothing; without it configs[2] goes from 15.7 to 16.5-17.4 Gbp/s (ranges of 0.7-1.6 Gbp:
-        // flat).  A read set that fits ONE range is halved when it holds 0.67 Gbp or more (below that the halves lose: 5-17 % at
+        // results are appended in range order through the turn gate of the result (round 2: configs[2] from 15.7 to 16.5-17.4 Gbp/s,
+        // ranges of 0.7-1.6 Gbp: flat).  A read set that fits ONE range is halved when it holds 0.67 Gbp or more (below that the halves lose: 5-17 % at
         // 0.4-0.5 Gbp).  TELR_PIPELINE=1 switches it off; =force pipelines any multi-range call (tests).
         int pipe = 2; bool force = false;
         if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }
-        if (ctx->is_child || ctx->pipe_nomem || (!force && (ctx->debug || nq < 4000))) pipe = 1;
+        if (ctx->pipe_nomem || (!force && (ctx->debug || nq < 4000))) pipe = 1;
         if (pipe == 2 && !fixed) {
             // ranges of at most 1.4 Gbp (two in flight: ~200 GB of scratch at configs[2]'s anchor density) and at most 1.6 G
             // anchors at the density seen by the last call on this index; a read set within one such range is not split
@@ -2536,60 +2365,6 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
                 }
                 q0 = q1;
             }
-        }
-    } else {
-        // split by bases into nsub contiguous ranges
-        std::vector<int32_t> cut(nsub + 1, nq);
-        { int64_t acc = 0; int k = 1; cut[0] = 0;
-          for (int i = 0; i < nq && k < nsub; ++i) { acc += queries->len[i]; if (acc >= total_bases * k / nsub) cut[k++] = i + 1; } }
-        for (int k = 0; k < nsub; ++k) { int r = ctx_make_child(ctx, k); if (r != TELR_OK) { delete R; return r; } }
-        std::vector<telr_result*> part(nsub, nullptr);
-        std::vector<int> rc(nsub, TELR_OK);
-        std::vector<std::thread> th;
-        for (int k = 0; k < nsub; ++k) th.emplace_back([&, k]() {
-            telr_ctx *c = ctx->child[k];
-            (void)hipSetDevice(c->device);
-            memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(&c->ctr, 0, sizeof(c->ctr)); memset(c->dpcls, 0, sizeof(c->dpcls)); c->dp_retries = 0; c->pk_launches = 0; c->st_pending = 0;
-            part[k] = new telr_result(); part[k]->ctx = nullptr; part[k]->is_part = true;
-            if (cut[k + 1] > cut[k]) {
-                for (int i = cut[k]; i < cut[k + 1]; ++i) c->ctr.query_bases += queries->len[i];
-                rc[k] = map_batch(c, ix, queries, d_qt, cut[k], cut[k + 1], mo, mid_occ, part[k]);
-            }
-        });
-        for (auto &t : th) t.join();
-        for (int k = 0; k < nsub; ++k) if (rc[k] != TELR_OK) { ctx->err = ctx->child[k]->err; for (auto *p : part) delete p; delete R; return rc[k] == TELR_SPLIT_RANGE ? TELR_E_RANGE : rc[k]; }
-        // merge: records in query order, CIGAR arrays concatenated (parallel copy into a pooled buffer)
-        size_t tot_a = 0, tot_c = 0;
-        std::vector<size_t> a0(nsub + 1, 0), c0(nsub + 1, 0);
-        for (int k = 0; k < nsub; ++k) { a0[k] = tot_a; c0[k] = tot_c; tot_a += part[k]->alns.size(); tot_c += part[k]->ncig; }
-        a0[nsub] = tot_a; c0[nsub] = tot_c;
-        pool_get(ctx, &R->cig, &R->cap);
-        if (!cig_grow(&R->cig, &R->cap, 0, tot_c + 1 + tot_c / 8)) { for (auto *p : part) delete p; delete R; return TELR_E_NOMEM; }
-        R->ncig = tot_c; R->twin_off = true;          // sub-batch results are merged on the host only
-        R->alns.resize(tot_a);
-        const int NT = host_threads();
-        for (int k = 0; k < nsub; ++k) {
-            telr_result *P = part[k];
-            result_wait(P);
-            parallel_ranges(NT, (int)P->alns.size(), [&](int, int x0, int x1) {
-                for (int x = x0; x < x1; ++x) { telr_aln r = P->alns[x]; r.cigar_off += (int64_t)c0[k]; R->alns[a0[k] + x] = r; }
-            });
-            const size_t nw = P->ncig; const int chunks = 64;
-            parallel_ranges(NT, chunks, [&](int, int x0, int x1) {
-                for (int x = x0; x < x1; ++x) { size_t lo = nw * x / chunks, hi = nw * (x + 1) / chunks; if (hi > lo) memcpy(R->cig + c0[k] + lo, P->cig + lo, (hi - lo) * 4); }
-            });
-        }
-        // counters / timings: sums over the workers (stage times are GPU/host time spent, not wall)
-        for (int k = 0; k < nsub; ++k) {
-            telr_ctx *c = ctx->child[k];
-            for (int z = 0; z < TELR_N_STAGES; ++z) ctx->stage_ms[z] += c->stage_ms[z];
-            const int64_t *src = (const int64_t*)&c->ctr; int64_t *dst = (int64_t*)&ctx->ctr;
-            for (size_t z = 0; z < sizeof(telr_counters) / 8; ++z) dst[z] += src[z];
-            for (int z = 0; z < TELR_N_DPCLS * 4; ++z) ctx->dpcls[z] += c->dpcls[z];
-            ctx->dp_retries += c->dp_retries; ctx->pk_launches += c->pk_launches;
-            // the workers' result buffers go back to their own pools for the next call
-            part[k]->ctx = c;
-            delete part[k];
         }
     }
     ctx->stage_ms[ST_MAP_WALL] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_wall0).count();

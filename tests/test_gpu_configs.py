@@ -58,19 +58,19 @@ def test_c2_shape_many_chromosomes_ranges_and_lane(engine):
     ok, n = _truth_ok(g, plan, ids, res.alns)
     assert n >= 0.99 * len(ln) and ok >= 0.97 * n, (ok, n, len(ln))
     whole = _digest_of_digests(_per_read_digest(res.alns, res.cigars))
-    os.environ["TELR_BATCH_MBP"] = "20"; os.environ["TELR_LONGSPLIT"] = "force"
+    os.environ["TELR_BATCH_MBP"] = "20"; os.environ["TELR_PIPELINE"] = "1"          # several ranges, one at a time
     try:
         res2 = ix.map(qs, mo)
     finally:
-        del os.environ["TELR_BATCH_MBP"], os.environ["TELR_LONGSPLIT"]
+        del os.environ["TELR_BATCH_MBP"], os.environ["TELR_PIPELINE"]
     assert _digest_of_digests(_per_read_digest(res2.alns, res2.cigars)) == whole
     assert (np.diff(res2.alns["qid"]) >= 0).all()
     # the same with two ranges in flight (range pipelining; default on calls of 200 Mbp and more)
-    os.environ["TELR_BATCH_MBP"] = "12"; os.environ["TELR_LONGSPLIT"] = "force"; os.environ["TELR_PIPELINE"] = "force"
+    os.environ["TELR_BATCH_MBP"] = "12"; os.environ["TELR_PIPELINE"] = "force"
     try:
         res3 = ix.map(qs, mo)
     finally:
-        del os.environ["TELR_BATCH_MBP"], os.environ["TELR_LONGSPLIT"], os.environ["TELR_PIPELINE"]
+        del os.environ["TELR_BATCH_MBP"], os.environ["TELR_PIPELINE"]
     assert _digest_of_digests(_per_read_digest(res3.alns, res3.cigars)) == whole
     assert (np.diff(res3.alns["qid"]) >= 0).all()
     # oracle parity on a few reads against the same 137.6-Mb index would need ~1 min of CPU index build: the full-size

@@ -401,89 +401,10 @@ def test_sorted_bam_and_bai(engine, data_dir, tmp_path):
     assert 37450 in bins and bins[37450][1][0] == len(mapped)
 
 
-def test_concurrent_subbatches(engine):
-    """Large calls are cut into sub-batches that run concurrently on worker contexts; the merged result must be
-    identical to the single-batch result (forced here on a small input through TELR_SUBBATCH)."""
-    import os
-    rng = np.random.default_rng(2024)
-    genome = [synth.random_seq(rng, 120000)]
-    reads, _ = synth.simulate_reads(rng, genome, 45, 5000)
-    reads.insert(7, np.zeros(0, np.uint8))
-    io, mo = preset("map-ont")
-    os.environ["TELR_SUBBATCH"] = "3"
-    try:
-        res3, oref = compare_all(engine, genome, reads, io, mo, stages=False)
-        os.environ["TELR_SUBBATCH"] = "4"
-        compare_all(engine, genome, reads, io, mo, stages=False)
-    finally:
-        del os.environ["TELR_SUBBATCH"]
-    assert len(res3.alns) >= 44
-
-
-def test_int32_and_lds_fallback_kernels(engine):
-    """The packed int16 kernels take a problem only while its scores provably fit and its windows hold no N; everything
-    else runs on the int32 register kernels and the LDS kernel.  Force that path for all problems (TELR_NO_PK /
-    TELR_NO_PKEXT) and, separately, put Ns into extension and fill windows: results must not change."""
-    import os
-    rng = np.random.default_rng(4242)
-    genome = [synth.random_seq(rng, 140000)]
-    reads, _ = synth.simulate_reads(rng, genome, 36, 4000)
-    for i in (2, 9, 17):                                 # Ns inside the end windows and in the middle of some reads
-        reads[i][8:14] = ord("N"); reads[i][-15:-9] = ord("N"); reads[i][len(reads[i]) // 2:len(reads[i]) // 2 + 3] = ord("N")
-    genome[0][50000:50010] = ord("N")
-    io, mo = preset("map-ont")
-    base, _ = compare_all(engine, genome, reads, io, mo, stages=False)
-    os.environ["TELR_NO_PK"] = "1"; os.environ["TELR_NO_PKEXT"] = "1"
-    try:
-        alt, _ = compare_all(engine, genome, reads, io, mo, stages=False)
-    finally:
-        del os.environ["TELR_NO_PK"]; del os.environ["TELR_NO_PKEXT"]
-    assert len(base.alns) == len(alt.alns) >= 30
-    for f in ALN_FIELDS:
-        np.testing.assert_array_equal(base.alns[f], alt.alns[f], err_msg=f)
-
-
-def test_several_batches_per_call(engine):
-    """A call with more read bases than one batch holds (1 Gbp by default; forced small here) runs batch after batch and
-    appends to one result: records and CIGARs must equal the single-batch result."""
-    import os
-    rng = np.random.default_rng(31337)
-    genome = [synth.random_seq(rng, 110000)]
-    reads, _ = synth.simulate_reads(rng, genome, 48, 4000)
-    io, mo = preset("map-ont")
-    os.environ["TELR_BATCH_KBP"] = "40"          # about five batches
-    try:
-        res, _ = compare_all(engine, genome, reads, io, mo, stages=False)
-    finally:
-        del os.environ["TELR_BATCH_KBP"]
-    assert len(res.alns) >= 45
-
-
-def test_long_read_lane(engine):
-    """Large calls map their few longest reads as a separate small batch on a worker context, concurrently with the
-    rest; the merged result must be identical to the single-batch result (forced here on a small input), with and
-    without per-query target filters."""
-    import os
-    rng = np.random.default_rng(99)
-    genome = [synth.random_seq(rng, 150000), synth.random_seq(rng, 60000)]
-    reads, _ = synth.simulate_reads(rng, genome, 40, 3000)
-    long_reads, _ = synth.simulate_reads(rng, genome, 4, 30000)
-    reads[3:3] = long_reads[:2]; reads.extend(long_reads[2:]); reads.insert(9, np.zeros(0, np.uint8))
-    io, mo = preset("map-ont")
-    os.environ["TELR_LONGSPLIT"] = "force"
-    try:
-        res, oref = compare_all(engine, genome, reads, io, mo, stages=False)
-        qt = np.array([i % 3 - 1 for i in range(len(reads))], np.int32)      # -1 / 0 / 1
-        compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
-    finally:
-        del os.environ["TELR_LONGSPLIT"]
-    assert len(res.alns) >= 40
-
-
 def test_pipelined_ranges(engine):
-    """Two ranges of a call are in flight at a time (second slot: its own parent context and lane workers) and append to
-    the one result in range order.  Forced here on a small input, with and without the long-read lanes and with an odd
-    and an even number of ranges: records and CIGARs must equal the oracle's single-batch result."""
+    """Two ranges of a call are in flight at a time (second slot: a context of its own) and append to the one result in range
+    order.  Forced here on a small input, with an odd and an even number of ranges and with one range only: records and CIGARs
+    must equal the oracle's single-batch result."""
     import os
     rng = np.random.default_rng(4242)
     genome = [synth.random_seq(rng, 120000), synth.random_seq(rng, 50000)]
@@ -492,16 +413,13 @@ def test_pipelined_ranges(engine):
     reads[7:7] = long_reads[:3]; reads.extend(long_reads[3:]); reads.insert(20, np.zeros(0, np.uint8))
     io, mo = preset("map-ont")
     qt = np.array([i % 3 - 1 for i in range(len(reads))], np.int32)
-    for kbp, lanes in (("60", True), ("45", False), ("1000", True)):
+    for kbp in ("60", "45", "1000"):
         os.environ["TELR_PIPELINE"] = "force"; os.environ["TELR_BATCH_KBP"] = kbp
-        if lanes:
-            os.environ["TELR_LONGSPLIT"] = "force"
         try:
             res, _ = compare_all(engine, genome, reads, io, mo, stages=False)
             compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
         finally:
             del os.environ["TELR_PIPELINE"], os.environ["TELR_BATCH_KBP"]
-            os.environ.pop("TELR_LONGSPLIT", None)
         assert len(res.alns) >= 60 and (np.diff(res.alns["qid"]) >= 0).all()
     # the fall-back when two ranges in flight do not fit the device: the second slot is released and the call runs again one
     # range at a time (forced here after a successful pipelined attempt)
@@ -542,8 +460,8 @@ def test_cigars_kept_on_the_device_equal_the_host_array(engine):
         finally:
             ix.free_raw(r0); ix.free_raw(r1)
     check(); check(qt)
-    for env in ({"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "60", "TELR_LONGSPLIT": "force"}, {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "45"},
-                {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "1000", "TELR_LONGSPLIT": "force"}, {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "60", "TELR_TEST_PIPE_NOMEM": "1"}):
+    for env in ({"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "60"}, {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "45"},
+                {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "1000"}, {"TELR_PIPELINE": "force", "TELR_BATCH_KBP": "60", "TELR_TEST_PIPE_NOMEM": "1"}):
         os.environ.update(env)
         try:
             check(); check(qt)

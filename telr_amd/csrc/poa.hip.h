@@ -374,8 +374,7 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_poa_window, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
     hipDeviceProp_t prop; int ncu = 256;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-    int64_t want = (int64_t)per_cu * ncu;
-    if (const char *e = getenv("TELR_POA_SLOTS")) { const long v = atol(e); if (v > 0) want = v; }          // experiments
+    const int64_t want = (int64_t)per_cu * ncu;
     const int nslot = (int)std::min<int64_t>(nwin, want);
     PoaArgs A; memset(&A, 0, sizeof(A));
     PoaPiece *d_p; int32_t *d_wptr, *d_wt, *d_w0, *d_w1, *d_wlen; uint8_t *d_scr, *d_wout;

@@ -1290,7 +1290,6 @@ template <typename F> static void parallel_ranges(int nt, int n, F f)
     });
 }
 
-struct HostChain { int32_t qid, score, cnt, rev, tid, rs, re, qs, qe, disc; int64_t a_glob; };
 
 // ---------------------------------------------------------------------------------------
 // One DP pass over a problem array: scratch sizing, class lists (sorted by length so that the problems
@@ -1794,10 +1793,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipGetLastError());
-    // Pass-1 chain selection runs on the device (k_select1); TELR_HOST_SELECT=1 keeps the round-1 host version for A/B runs.
-    // The host version, and the debug taps of the parity tests, need every chain record on the host.
-    static const bool host_select = getenv("TELR_HOST_SELECT") != nullptr;
-    const bool need_recs = host_select || ctx->debug;
+    // Pass-1 chain selection runs on the device (k_select1).  The debug taps of the parity tests need every chain record on the host.
+    const bool need_recs = ctx->debug != 0;
     int32_t *h_nch, *h_choff, *h_qaoff; ChainRec *h_rec;
     TRY(ctx_hbuf_t(ctx, "h_nch", (size_t)nq + 1, &h_nch));
     TRY(ctx_hbuf_t(ctx, "h_choff", (size_t)nq + 1, &h_choff));
@@ -1820,7 +1817,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     KeptChain *d_kc = nullptr;               // their descriptors for the problem builder (device)
     int nk = 0;
     int64_t n_chain_tot = 0;
-    if (!host_select) {
+    {
         StageTimer t_sel(ctx, ST_SELECT, true);
         uint64_t *d_sk, *d_sk2; int32_t *d_segend, *d_pfs, *d_pfe, *d_ptid, *d_pkey, *d_tct, *d_tcn, *d_nkept, *d_koff; uint8_t *d_keep;
         TRY(ctx_buf_t(ctx, "sel_key", (size_t)npk_tot + 1, &d_sk));
@@ -1872,73 +1869,6 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
                 ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9);
             }
         }
-    } else {
-    StageTimer t_sel(ctx, ST_SELECT, false);
-    std::vector<int32_t> q_ch0(nq + 1, 0);
-    for (int q = 0; q < nq; ++q) q_ch0[q + 1] = q_ch0[q] + h_nch[q];
-    n_chain_tot = q_ch0[nq];
-    HostChain *chains;                                            // all chains of the batch, query-major (grow-only pinned
-    TRY(ctx_hbuf_t(ctx, "h_chains", (size_t)n_chain_tot + 1, &chains));   // scratch: a fresh vector would be zero-filled and page-faulted every call)
-    std::vector<int32_t> kept;                                    // indices into chains, query-major, pass-1 rank order
-    {
-        std::vector<std::vector<int32_t>> tkept(NT);
-        std::vector<int32_t> q_nk(nq, 0);
-        parallel_ranges(NT, nq, [&](int t, int qa, int qb) {
-            std::vector<Sel> s; std::vector<int32_t> cscore;
-            for (int q = qa; q < qb; ++q) {
-                const int c0 = q_ch0[q], n = h_nch[q], qlen = qs->len[q0 + q];
-                for (int c = 0; c < n; ++c) {
-                    const ChainRec &r = h_rec[h_choff[q] + c];
-                    HostChain &hc = chains[c0 + c];
-                    hc.qid = q0 + q; hc.score = r.score; hc.cnt = r.cnt; hc.rev = (int)(r.a0 >> 63); hc.disc = c;
-                    uint32_t g0 = (uint32_t)A_G(r.a0);
-                    int tid = (int)(std::upper_bound(ix->goff.begin(), ix->goff.begin() + tg->n, g0) - ix->goff.begin()) - 1;
-                    hc.tid = tid;
-                    int go = (int)ix->goff[tid];
-                    hc.rs = A_G(r.a0) - go - A_SPAN(r.a0) + 1; hc.re = A_G(r.a1) - go + 1;
-                    if (hc.rs < 0) hc.rs = 0;
-                    hc.qs = A_Q(r.a0) - A_SPAN(r.a0) + 1;      hc.qe = A_Q(r.a1) + 1;
-                    hc.a_glob = (int64_t)h_qaoff[q] + r.a_off;
-                }
-                s.resize(n); cscore.resize(n);
-                for (int i = 0; i < n; ++i) {
-                    const HostChain &c = chains[c0 + i];
-                    s[i].ci = i; s[i].key = c.score; s[i].ord = c.disc; s[i].tid = c.tid;
-                    if (c.rev) { s[i].fs = qlen - c.qe; s[i].fe = qlen - c.qs; } else { s[i].fs = c.qs; s[i].fe = c.qe; }
-                    cscore[i] = c.score;
-                }
-                std::sort(s.begin(), s.end(), sel_less);
-                select_chains(s, mo, cscore);
-                int nkq = 0;
-                for (int i = 0; i < n; ++i) if (s[i].keep) { tkept[t].push_back(c0 + s[i].ci); ++nkq; }
-                q_nk[q] = nkq;
-            }
-        });
-        for (int q = 0; q < nq; ++q) q_k0[q + 1] = q_k0[q] + q_nk[q];
-        kept.reserve(q_k0[nq]);
-        for (int t = 0; t < NT; ++t) kept.insert(kept.end(), tkept[t].begin(), tkept[t].end());   // ranges are contiguous and ordered
-    }
-    if (ctx->debug) {
-        ctx->dbg_chain.clear();
-        for (int ci = 0; ci < n_chain_tot; ++ci) { const HostChain &c = chains[ci]; int32_t v[9] = { c.qid, c.score, c.cnt, c.rev, c.tid, c.rs, c.re, c.qs, c.qe }; ctx->dbg_chain.insert(ctx->dbg_chain.end(), v, v + 9); }
-    }
-    nk = (int)kept.size();
-    // the kept chains in the two forms the rest of the batch uses
-    KeptChain *hk;
-    TRY(ctx_hbuf_t(ctx, "h_kept", (size_t)nk, &hk));
-    TRY(ctx_hbuf_t(ctx, "h_kept_lite", (size_t)nk, &hl));
-    parallel_ranges(NT, nk, [&](int, int xa, int xb) {
-        for (int x = xa; x < xb; ++x) {
-            const HostChain &c = chains[kept[x]]; KeptChain &K = hk[x];
-            K.qid = c.qid; K.tid = c.tid; K.rev = c.rev; K.cnt = c.cnt; K.a_glob = c.a_glob; K.rs = c.rs; K.qs = c.qs; K.re = c.re; K.qe = c.qe;
-            K.qlen = qs->len[c.qid]; K.tlen = tg->len[c.tid]; K.qbase = qs->boff[c.qid]; K.tbase = tg->boff[c.tid]; K.goff = ix->goff[c.tid]; K.pad = 0;
-            KeptLite &L = hl[x];
-            L.qid = c.qid; L.score = c.score; L.cnt = c.cnt; L.rev = c.rev; L.tid = c.tid; L.rs = c.rs; L.re = c.re; L.qs = c.qs; L.qe = c.qe; L.pad = 0;
-        }
-    });
-    TRY(ctx_buf_t(ctx, "kept", (size_t)nk, &d_kc));
-    if (nk) HIPCHK(hipMemcpyAsync(d_kc, hk, (size_t)nk * sizeof(KeptChain), hipMemcpyHostToDevice, st));
-    t_sel.stop();
     }
     ctx->ctr.chains += n_chain_tot; ht.mark("selection (sync: kept chains)");
 
@@ -2169,7 +2099,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     t_as2.stop();
     if (do_dp) {
         for (int t = 0; t < NT; ++t) ctx->ctr.cigar_ops += tops[t];
-        if (getenv("TELR_SYNC_RESULT")) { StageTimer t_g2(ctx, ST_GATHER, false); result_wait(R); t_g2.stop(); }   // else: waited for by whoever reads the CIGARs
+        // (the CIGAR DMA is waited for by whoever reads the CIGARs: result_wait)
     }
     ctx->ctr.records += ns;
     ht.mark("host assembly");

@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCHES = [
-    {"TELR_HOST_SELECT": "1"}, {"TELR_TB8": "1"}, {"TELR_SORT64": "1"}, {"TELR_MZ_COMPACT": "1"},
+    {"TELR_TB8": "1"}, {"TELR_SORT64": "1"}, {"TELR_MZ_COMPACT": "1"},
     {"TELR_NO_TAG8": "1"}, {"TELR_SKETCH64": "1"}, {"TELR_NO_PKW": "1"}, {"TELR_SERIAL": "1"}, {"TELR_PK_CHUNKS": "3"},
-    {"TELR_TB_SPLIT": "0"}, {"TELR_TBW_MAX": "0"}, {"TELR_SYNC_RESULT": "1"}, {"TELR_NO_AVX2": "1"}, {"TELR_PACK_THREADS": "1"},
+    {"TELR_TB_SPLIT": "0"}, {"TELR_TBW_MAX": "0"}, {"TELR_NO_AVX2": "1"}, {"TELR_PACK_THREADS": "1"},
     {"TELR_TRACE_HOST": "1"}, {"TELR_SEED_UNFUSED": "1"}, {"TELR_CHAIN_NO_ISLANDS": "1"}, {"TELR_VOTE_FILTER": "1"}, {"TELR_VOTE_T16_LIMIT": "0"}, {"TELR_VOTE_T16_LIMIT": "400"},
 ]
 

@@ -15,7 +15,8 @@
 //                   of the node's window column (d_poa_lo; a piece is at most 30 bases off the diagonal by the POA_MAXINDEL
 //                   rule), i.e. exactly one cell per lane.  The row of the node before is read from registers (lane shuffle),
 //                   the in-row gap chain is a max-plus prefix scan over the wave, every cell notes where its value came from;
-//                   the walk back (one byte per step), the merge and the heaviest-bundle pass are serial stretches on lane 0.
+//                   the walk back (one byte per step) and the heaviest-bundle pass are serial stretches on lane 0, the merge of
+//                   a piece into the graph and the new topological order are parallel passes over the path.
 //   k_poa_pack      the windows' strings, packed, for the copy back
 // Integer work bounded by instruction issue and L2 latency: no MFMA.
 #pragma once
@@ -222,50 +223,68 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             __syncthreads();
             for (int z = lane; z < sh[3]; z += 64) { const int r = pn[z]; pn[z] = r ? order[r - 1] : (int16_t)-1; }
             __syncthreads();
-            if (lane == 0) {
-                const int np = sh[3];
-                // ---- merge, start -> end (placement rules: see the oracle)
-                const int n_old = n;
-                int prev = -1, nnew = 0, behind = -1;
-                for (int z = np - 1; z >= 0; --z) {
-                    const uint8_t b = seq[pj[z]];
-                    const int x = pn[z];
-                    int u = -1;
+            // ---- merge, start -> end (placement rules: see the oracle), as a PARALLEL pass over the path: step t (lane t of a chunk of
+            // 64) touches only its own node -- a path visits a column once, so the rings searched / extended by two steps are
+            // disjoint, every step's target node u_t and source node u_(t-1) are distinct from every other step's -- and what the serial
+            // loop carries from step to step are three "last value so far" scans: the id of the next new node (a count), and for
+            // inserted bases the rank bound `behind` and the column of the last aligned step before them.
+            {
+                const int np = sh[3], n_old = n;
+                int c_new = 0, c_behind = -1, c_col = 0, c_prevu = -1;
+                const uint64_t below = (1ULL << lane) - 1ULL;
+                for (int t0 = 0; t0 < np; t0 += 64) {
+                    const int t = t0 + lane, z = np - 1 - t; const bool on = t < np;
+                    int x = -1, u = -1, mm = -1, cx = 0; uint8_t b = 4;
+                    if (on) { x = pn[z]; b = seq[pj[z]]; }
                     if (x >= 0) {
                         if (base[x] == b) u = x;
                         else for (int s_ = ring[x]; s_ != x; s_ = ring[s_]) if (base[s_] == b) { u = s_; break; }
-                    }
-                    if (u < 0) {
-                        u = n++;
-                        base[u] = b; nin[u] = 0; nout[u] = 0; ring[u] = (int16_t)u; startc[u] = 0; endc[u] = 0;
-                        col[u] = x >= 0 ? col[x] : prev >= 0 ? col[prev] : 0;
-                        newv[nnew] = (int16_t)u; anchor[nnew] = (int16_t)(x >= 0 ? rank[x] - 1 : behind); ++nnew;
-                        if (x >= 0) { ring[u] = ring[x]; ring[x] = (int16_t)u; }
-                    }
-                    if (x >= 0) {
-                        int mm = rank[x] - 1;
+                        mm = rank[x] - 1;
                         for (int s_ = ring[x]; s_ != x; s_ = ring[s_]) if (s_ < n_old && rank[s_] - 1 > mm) mm = rank[s_] - 1;
-                        behind = mm;
+                        cx = col[x];
                     }
-                    if (prev >= 0) {
-                        bool found = false;
-                        for (int k = 0; k < nin[u]; ++k) if (in[u * POA_MAXIN + k] == prev) { ++inw[u * POA_MAXIN + k]; found = true; break; }
-                        if (!found && nin[u] < POA_MAXIN) { in[u * POA_MAXIN + nin[u]] = (int16_t)prev; inw[u * POA_MAXIN + nin[u]] = 1; ++nin[u]; ++nout[prev]; }
-                    } else ++startc[u];
-                    prev = u;
+                    const bool isnew = on && u < 0;
+                    const uint64_t al = __ballot(x >= 0), nw = __ballot(isnew), alb = al & below;
+                    const int src = alb ? 63 - __builtin_clzll(alb) : 0;
+                    const int mm_b = __shfl(mm, src), cx_b = __shfl(cx, src);
+                    const int behind_before = alb ? mm_b : c_behind, col_ins = alb ? cx_b : c_col;
+                    const int k = c_new + (int)__popcll(nw & below);
+                    if (isnew) {
+                        u = n_old + k;
+                        base[u] = b; nin[u] = 0; nout[u] = 0; startc[u] = 0; endc[u] = 0;
+                        col[u] = (int16_t)(x >= 0 ? cx : col_ins);
+                        newv[k] = (int16_t)u; anchor[k] = (int16_t)(x >= 0 ? rank[x] - 1 : behind_before);
+                        if (x >= 0) { ring[u] = ring[x]; ring[x] = (int16_t)u; } else ring[u] = (int16_t)u;
+                    }
+                    int pu = __shfl_up(u, 1); if (lane == 0) pu = c_prevu;
+                    __syncthreads();                                    // the new nodes' fields, before their neighbours' edges
+                    if (on) {
+                        if (pu >= 0) {
+                            bool found = false;
+                            for (int q_ = 0; q_ < nin[u]; ++q_) if (in[u * POA_MAXIN + q_] == pu) { ++inw[u * POA_MAXIN + q_]; found = true; break; }
+                            if (!found && nin[u] < POA_MAXIN) { in[u * POA_MAXIN + nin[u]] = (int16_t)pu; inw[u * POA_MAXIN + nin[u]] = 1; ++nin[u]; ++nout[pu]; }
+                        } else ++startc[u];
+                        if (t == np - 1) ++endc[u];
+                    }
+                    c_new += (int)__popcll(nw);
+                    if (al) { const int last = 63 - __builtin_clzll(al); c_behind = __shfl(mm, last); c_col = __shfl(cx, last); }
+                    { const int lastl = np - 1 - t0 < 63 ? np - 1 - t0 : 63; c_prevu = __shfl(u, lastl); }
+                    __syncthreads();
                 }
-                if (prev >= 0) ++endc[prev];
+                const int nnew = c_new;
+                n = n_old + nnew;
                 if (nnew) {
-                    const int nold = n - nnew;
-                    int k = 0, o = 0;
-                    while (k < nnew && anchor[k] < 0) no[o++] = newv[k++];
-                    for (int i = 0; i < nold; ++i) { no[o++] = order[i]; while (k < nnew && anchor[k] == i) no[o++] = newv[k++]; }
+                    // the order: new node k goes behind old rank anchor[k] (anchors do not decrease along the path), after the k new nodes before it
+                    for (int k = lane; k < nnew; k += 64) no[anchor[k] + 1 + k] = newv[k];
+                    for (int i_ = lane; i_ < n_old; i_ += 64) {
+                        int lo_ = 0, hi_ = nnew;                        // anchors < i_
+                        while (lo_ < hi_) { const int mid = (lo_ + hi_) >> 1; if (anchor[mid] < i_) lo_ = mid + 1; else hi_ = mid; }
+                        no[i_ + lo_] = order[i_];
+                    }
+                    __syncthreads();
+                    for (int i_ = lane; i_ < n; i_ += 64) order[i_] = no[i_];
                 }
-                sh[1] = n; sh[2] = nnew;
             }
-            __syncthreads();
-            n = sh[1];
-            if (sh[2]) { for (int i = lane; i < n; i += 64) order[i] = no[i]; }
             __syncthreads();
         }
         // ---- heaviest bundle between the most common start / end nodes

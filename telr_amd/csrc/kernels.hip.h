@@ -792,7 +792,9 @@ __global__ void __launch_bounds__(256) k_seed(SeedArgs A)
 //   k_vote_compact  staging -> the dense key arrays at the scanned per-query offsets
 #define VOTE_SLOTS   2048
 #define VOTE_SUBCAP  512
+#ifndef VOTE_WAVES
 #define VOTE_WAVES   3
+#endif
 #ifndef VOTE_HCAP
 #define VOTE_HCAP    768            /* hits of a sub-read remembered in LDS */
 #endif

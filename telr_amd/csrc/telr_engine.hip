@@ -2412,7 +2412,10 @@ extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n
     TRY(ctx_buf_t(ctx, "dm_tlen", (size_t)n_targets, &d_tlen));
     TRY(ctx_buf_t(ctx, "dm_recs", recs.size(), &d_recs));
     result_wait(r);
-    TRY(ctx_buf_t(ctx, "dm_cig", r->ncig, &d_cig));
+    // the CIGAR array: the result's own device copy when it kept one (TELR_MF_KEEP_CIGARS), else uploaded
+    const bool twin = r->d_cig && !r->twin_off && r->twin_n == r->ncig;
+    if (twin) { d_cig = r->d_cig; HIPCHK(hipDeviceSynchronize()); }      // (its last pieces were copied on other streams, as in telr_write_bam_dev)
+    else TRY(ctx_buf_t(ctx, "dm_cig", r->ncig, &d_cig));
     TRY(ctx_buf_t(ctx, "dm_ivt", (size_t)n_iv, &d_ivt));
     TRY(ctx_buf_t(ctx, "dm_ivs", (size_t)n_iv, &d_ivs));
     TRY(ctx_buf_t(ctx, "dm_ive", (size_t)n_iv, &d_ive));
@@ -2421,7 +2424,7 @@ extern "C" int telr_depth_medians(telr_ctx *ctx, const telr_result *r, int32_t n
     HIPCHK(hipMemcpyAsync(d_toff, toff.data(), (size_t)(n_targets + 1) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_tlen, target_len, (size_t)n_targets * 4, hipMemcpyHostToDevice, st));
     if (!recs.empty()) HIPCHK(hipMemcpyAsync(d_recs, recs.data(), recs.size() * sizeof(DepthRec), hipMemcpyHostToDevice, st));
-    if (r->ncig) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
+    if (r->ncig && !twin) HIPCHK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
     if (n_iv) {
         HIPCHK(hipMemcpyAsync(d_ivt, iv_tid, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_ivs, iv_start, (size_t)n_iv * 4, hipMemcpyHostToDevice, st));

@@ -197,6 +197,9 @@ def _af_map(job, engine, targets, reads_by_locus, presets, read_set):
         job.qs = engine.seqset(queries + queries)
     qtarget_all = np.concatenate([qtarget_fw, qtarget_fw + 1])
     marks.append(("subset", time.time() - t0))
+    if hasattr(engine, "worker"):                    # the engine: the depth step reads the CIGARs where they are made (TELR_MF_KEEP_CIGARS)
+        from ._abi import MF_KEEP_CIGARS
+        mo = mo.copy(); mo.flags |= MF_KEEP_CIGARS
     job.r = job.ix.map_raw(job.qs, mo, qtarget=qtarget_all)
     marks.append(("map", time.time() - t0))
     if trace:

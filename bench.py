@@ -818,6 +818,7 @@ def main():
         # three timed passes, the median reported: one pass is 120-160 ms of four small engine calls and Python, and a single
         # sample of it swings by 25 % from run to run (every pass gives the same table)
         t_passes = []
+        free_first = eng.mem_info()[0]
         for _ in range(1 if prof is not None else int(os.environ.get("TELR_LOCI_PASSES", "3"))):
             if dist is not None:
                 dist.barrier()
@@ -827,6 +828,7 @@ def main():
             sync()
             t_passes.append(time.time() - t0)
         t_loci = sorted(t_passes)[len(t_passes) // 2]
+        free_last = eng.mem_info()[0]
         phase_all = [{k: round(v, 5) for k, v in phase.items()}]
         if dist is not None and world > 1:
             got = [None] * world
@@ -906,7 +908,7 @@ def main():
         digest = hashlib.sha256(repr([(int(r["locus_id"]), int(r["status"]), int(r["chrom_id"]), int(r["start"]), int(r["end"]), int(r["strand"]), int(r["type"]), int(r["n_family"]),
                                        int(r["gap"]), int(r["tsd_len"]), [int(x) for x in r["family_id"]], [None if np.isnan(x) else float(x) for x in r["medians"]],
                                        None if np.isnan(r["af"]) else float(r["af"])) for r in rs]).encode()).hexdigest()
-        loci_out = {"n": n_loci, "seconds": t_loci, "seconds_of_each_pass": t_passes, "rows_in_merged_table": n_rows, "merged_table_sha256": digest, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
+        loci_out = {"n": n_loci, "seconds": t_loci, "seconds_of_each_pass": t_passes, "device_free_GB_before_first_and_after_last_pass": [round(free_first / 1e9, 3), round(free_last / 1e9, 3)], "rows_in_merged_table": n_rows, "merged_table_sha256": digest, "recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "not_recovered": why,
                     "recovered_with_bw_long_0_at_S4_S6": alt_set,
                     "window_reads_per_locus_mean_this_rank": float(np.mean(wr_counts)) if wr_counts else 0.0, "polish_pileup": polish,
                     "collectives": "none" if world == 1 and not (a.force_exchange and dist is not None) else "all-to-all of the window reads as packed device words (counts + ONE int32 payload), ONE all-gather of the %d-byte locus rows" % shard.LOCUS_ROW.itemsize,

@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--cpu-sample-seed", type=int, default=20261002, help="seed of the random read sample the CPU oracle maps (cpu_baseline, parity)")
     ap.add_argument("--require-cache", action="store_true", help="with --data-cache: fail instead of generating (profiled runs must not fork the generator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-default-aligner-leg", action="store_true", help="skip value_reference_default_aligner (the same timed steps with the reference's default aligner, ngmlr -x ont|pacbio)")
+    ap.add_argument("--default-aligner-parity-reads", type=int, default=12000, help="reads of the oracle parity sample of that leg (0 = none)")
+    ap.add_argument("--no-upstream-check", action="store_true", help="skip reference_cpu_path (the upstream tools on PATH, tools/crosscheck_upstream.py)")
+    ap.add_argument("--upstream-sample-reads", type=int, default=2000, help="reads of the sample the upstream tools map when they are on PATH")
     ap.add_argument("--preset", default="", help="override the configuration's preset")
     ap.add_argument("--fill-band-q4", type=int, default=0, help="experiment: override the preset's first-pass band factor (0 = preset)")
     ap.add_argument("--map-opt", default="", help="experiment: map-option fields laid over the preset of the timed map and of the CPU oracle, e.g. cx_scale=20,cx_open=100 (the loci leg keeps its presets)")
@@ -550,61 +554,117 @@ def main():
     # Steps are streamed the way a stage-1 run over many read batches would be: telr_map returns when the alignment
     # records are complete, the DMA of the last range's CIGARs finishes in the background, and a result is released only
     # after the next call has been issued.  Everything, the last DMA included, is complete before the closing synchronisation.
-    held = []
-
-    def step():
-        r = ix.map_raw(qs, mo)
-        L = eng.L
-        n = L.telr_result_count(r)
-        # a VIEW of the library-owned record array (valid until the result is freed: after the next step): counting the
-        # aligned bases must not copy 50 MB of records per step inside the timed region
-        al = np.frombuffer((ctypes.c_char * (n * ALN_DTYPE.itemsize)).from_address(L.telr_result_alns(r)), dtype=ALN_DTYPE, count=n) if n else np.zeros(0, ALN_DTYPE)
-        while held:
-            ix.free_raw(held.pop())
-        held.append(r)
-        return int(al["qlen"][(al["flags"] & 1) != 0].sum()), al
-
     def sync():
         torch.cuda.synchronize(local)
         if dist is not None:
             dist.barrier()
 
-    step(); step()      # set-up, not warm-up steps: the first calls size the engine's grow-only scratch and pin the TWO
-                        # result buffers that are alive at any time when steps are streamed
-    for _ in range(a.warmup):
-        step()
-    stage_tot = {}
-    cls_tot = None; ctr_tot = {}; launches = 0; retries = 0
-    sync()
-    t0 = time.time()
-    aligned = 0
-    for _ in range(a.steps):
-        b, al = step()
-        aligned += b
-        for k, v in eng.stage_ms().items():
-            stage_tot[k] = stage_tot.get(k, 0.0) + v
-        c = eng.dp_classes(); cls_tot = c if cls_tot is None else cls_tot + c
-        for k, v in eng.counters().items():
-            ctr_tot[k] = ctr_tot.get(k, 0) + v
-        launches += int(eng.L.telr_debug_pk_launches(eng.h)); retries += int(eng.L.telr_debug_dp_retries(eng.h))
-    if held:
-        eng.L.telr_result_wait(held[-1])      # the last step's CIGAR array is home as well
-    sync()
-    dt = time.time() - t0
-    dt_local = dt
-    al = al.copy()                            # the last step's records outlive the result handle (window reads of the loci leg)
-    while held:
-        ix.free_raw(held.pop())
+    def timed_map(ix_, mo_):
+        """2 set-up calls + a.warmup untimed + EXACTLY a.steps timed steps of ix_.map_raw(qs, mo_), bracketed by sync(); max over ranks"""
+        held = []
+
+        def step():
+            r = ix_.map_raw(qs, mo_)
+            L = eng.L
+            n = L.telr_result_count(r)
+            # a VIEW of the library-owned record array (valid until the result is freed: after the next step): counting the
+            # aligned bases must not copy 50 MB of records per step inside the timed region
+            al = np.frombuffer((ctypes.c_char * (n * ALN_DTYPE.itemsize)).from_address(L.telr_result_alns(r)), dtype=ALN_DTYPE, count=n) if n else np.zeros(0, ALN_DTYPE)
+            while held:
+                ix_.free_raw(held.pop())
+            held.append(r)
+            return int(al["qlen"][(al["flags"] & 1) != 0].sum()), al
+
+        step(); step()      # set-up, not warm-up steps: the first calls size the engine's grow-only scratch and pin the TWO
+                            # result buffers that are alive at any time when steps are streamed
+        for _ in range(a.warmup):
+            step()
+        T = dict(stage_tot={}, cls_tot=None, ctr_tot={}, launches=0, retries=0)
+        sync()
+        t0 = time.time()
+        aligned = 0
+        for _ in range(a.steps):
+            b, al = step()
+            aligned += b
+            for k, v in eng.stage_ms().items():
+                T["stage_tot"][k] = T["stage_tot"].get(k, 0.0) + v
+            c = eng.dp_classes(); T["cls_tot"] = c if T["cls_tot"] is None else T["cls_tot"] + c
+            for k, v in eng.counters().items():
+                T["ctr_tot"][k] = T["ctr_tot"].get(k, 0) + v
+            T["launches"] += int(eng.L.telr_debug_pk_launches(eng.h)); T["retries"] += int(eng.L.telr_debug_dp_retries(eng.h))
+        if held:
+            eng.L.telr_result_wait(held[-1])      # the last step's CIGAR array is home as well
+        sync()
+        dt = time.time() - t0
+        T["dt_local"] = dt
+        T["al"] = al.copy()                       # the last step's records outlive the result handle (window reads of the loci leg)
+        while held:
+            ix_.free_raw(held.pop())
+        if dist is not None:
+            dev = device if device is not None else "cpu"
+            t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t[0])
+            s_ = torch.tensor([aligned], dtype=torch.float64, device=dev); dist.all_reduce(s_, op=dist.ReduceOp.SUM); aligned = float(s_[0])
+        T["dt"] = dt; T["aligned"] = aligned; T["value"] = aligned / dt / 1e9
+        return T
+
+    PK = list(range(10, 18)) + [22]
+
+    def pk_roofline(T):
+        """the contract's roofline object of k_dp_pk for one timed leg: live HIP-event launch time (telr_stage_ms "k_dp_pk") and the
+        algorithmic bytes the library counted per problem (2-bit query + target bases once, 4 B per CIGAR run, 32 B result)"""
+        cls = T["cls_tot"]
+        launches = max(1, T["launches"])
+        k_ms_tot = T["stage_tot"].get("k_dp_pk", 0.0)
+        k_bytes_tot = float(cls[PK, 3].sum())
+        achieved = k_bytes_tot / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else 0.0
+        return {"bound": "hbm", "kernel": "k_dp_pk", "dp_classes": PK, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "launch_ms": k_ms_tot / launches, "launches_per_step": launches / a.steps, "algorithmic_bytes_per_launch": k_bytes_tot / launches,
+                "problems_per_launch": float(cls[PK, 0].sum()) / launches, "cells_per_launch": float(cls[PK, 1].sum()) / launches,
+                "gcups": float(cls[PK, 1].sum()) / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else None}
+
+    T0 = timed_map(ix, mo)
+    stage_tot, cls_tot, ctr_tot, launches, retries = T0["stage_tot"], T0["cls_tot"], T0["ctr_tot"], T0["launches"], T0["retries"]
+    dt, dt_local, aligned, al, value = T0["dt"], T0["dt_local"], T0["aligned"], T0["al"], T0["value"]
     per_rank_ms = [dt_local / a.steps * 1e3]
     if dist is not None:
         dev = device if device is not None else "cpu"
-        t = torch.tensor([dt, t_upload], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt, t_upload_max = float(t[0]), float(t[1])
-        s = torch.tensor([aligned, n_bases], dtype=torch.float64, device=dev); dist.all_reduce(s, op=dist.ReduceOp.SUM); aligned, job_bases = float(s[0]), float(s[1])
+        t = torch.tensor([t_upload], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); t_upload_max = float(t[0])
+        s = torch.tensor([n_bases], dtype=torch.float64, device=dev); dist.all_reduce(s, op=dist.ReduceOp.SUM); job_bases = float(s[0])
         pr = torch.zeros(world, dtype=torch.float64, device=dev); pr[rank] = dt_local / a.steps * 1e3; dist.all_reduce(pr); per_rank_ms = [float(x) for x in pr.cpu()]
     else:
         t_upload_max, job_bases = t_upload, float(n_bases)
-    value = aligned / dt / 1e9
     value_h2d = aligned / (dt + a.steps * t_upload_max) / 1e9
+
+    # ---- the reference's DEFAULT stage-1 aligner on the same reads (TELR_input.py:176-177 `--aligner nglmr`, TELR_alignment.py:28-51):
+    # the same measurement -- same read set resident, same warm-up, same a.steps timed steps, same synchronisation -- with the
+    # `ngmlr-ont` / `ngmlr-pacbio` preset on its own (w,k) = (5,13) index.  Skipped when the headline preset already is that one.
+    default_aligner = None
+    pname_ng = "ngmlr-ont" if cfg["err"][1] < 0.05 else "ngmlr-pacbio"
+    ix_ng = None
+    if not a.no_default_aligner_leg and pname != pname_ng and not a.map_opt:
+        try:
+            eng.release_scratch()
+            io_ng, mo_ng = preset(pname_ng)
+            t0 = time.time()
+            ix_ng = eng.index(ref_strs, io_ng)
+            t_index_ng = time.time() - t0
+            T1 = timed_map(ix_ng, mo_ng)
+            al1 = T1["al"]
+            rf = pk_roofline(T1)
+            dp_ms1 = T1["stage_tot"].get("dp", 0.0) / a.steps
+            rf["note"] = "same definition as `roofline`; all DP kernels together: %.1f ms per step" % dp_ms1
+            default_aligner = {"preset": pname_ng, "value": T1["value"], "unit": "Gbp/s", "ms_per_step": T1["dt"] / a.steps * 1e3, "steps": a.steps, "warmup": a.warmup,
+                               "index_build_s": t_index_ng, "roofline": rf,
+                               "stage_ms_per_step": {k: v / a.steps for k, v in T1["stage_tot"].items()},
+                               "dp_classes": {str(c): [int(x) // a.steps for x in T1["cls_tot"][c]] for c in range(T1["cls_tot"].shape[0]) if T1["cls_tot"][c, 0]},
+                               "counters": {k: v / a.steps for k, v in T1["ctr_tot"].items()}, "dp_retries": T1["retries"] // a.steps,
+                               "frac_reads_mapped": len(np.unique(al1["qid"][(al1["flags"] & 1) != 0])) / max(1, len(D["reads"][2])),
+                               "what": "the reference's default stage-1 aligner (`--aligner nglmr` -> `ngmlr -x %s`, TELR_input.py:176-177, TELR_alignment.py:28-51) on the SAME resident read set: "
+                                       "preset %s (13-mers at every third position, sub-read voting, NGMLR's convex gap cost exactly), timed exactly like `value`" % (pname_ng.split("-")[1], pname_ng)}
+            del T1, al1
+            eng.release_scratch()
+        except Exception as e:
+            default_aligner = {"preset": pname_ng, "error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- host-inclusive rate of a run that STREAMS its read batches: while step k maps, a second context packs and uploads
     # the reads of step k+1 (the same read set again, from the caller's ASCII buffer).  Timed from before the first upload to
@@ -929,13 +989,12 @@ def main():
     # over the launches); its algorithmic bytes are counted per problem by the library: 2-bit query+target bases read once, 4 B per CIGAR run,
     # 32 B result.
     cls = cls_tot
-    PK = list(range(10, 18)) + [22]
     k_name = "k_dp_pk"
+    rf0 = pk_roofline(T0)
     launches = max(1, launches)
+    achieved, k_ms = rf0["achieved"], rf0["launch_ms"]
     k_ms_tot = stage_tot.get("k_dp_pk", 0.0)
     k_bytes_tot = float(cls[PK, 3].sum())
-    achieved = k_bytes_tot / (k_ms_tot * 1e-3) / 1e9 if k_ms_tot > 0 else 0.0
-    k_ms = k_ms_tot / launches
     # What this run did NOT measure itself -- HBM bytes and VALU issue of the kernel from the committed PMC passes of the same
     # command (rocprofv3 --pmc cannot run inside this process) -- is attached under `from_profile` with its provenance and only
     # when the profile was taken on this workload; everything else in `roofline` is measured live in this run.
@@ -997,6 +1056,40 @@ def main():
     if loci_out is not None:
         out["te_loci_per_s"] = loci_out["n"] / loci_out["seconds"]
         out["te_loci"] = loci_out
+    # ---- the reference's own CPU path (ngmlr / minimap2 / samtools / bedtools), when this box has it on PATH: timed with the
+    # reference's argv shapes S1 / S2 / S7 and cross-checked record by record against this engine (tools/crosscheck_upstream.py;
+    # SURVEY 8(d)).  Absent tools are reported as absent.
+    if not a.no_upstream_check:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import crosscheck_upstream as xc
+
+            def xc_sample():
+                rng = np.random.default_rng(a.cpu_sample_seed)
+                rb, ro, rl = D["reads"]
+                pick = np.sort(rng.choice(len(rl), size=min(len(rl), a.upstream_sample_reads), replace=False))
+                fl_n, fl_s = [], []
+                for l in D["loci"][:100]:
+                    c = l["contig"] if isinstance(l["contig"], (bytes, bytearray)) else l["contig"].encode()
+                    fl_n += [l["name"] + "_5p", l["name"] + "_3p"]; fl_s += [c[:500], c[-500:]]
+                return dict(ref_names=D["names"], ref_seqs=ref_strs, read_names=["read%d" % D["read_gid"][i] for i in pick],
+                            read_seqs=[bytes(rb[ro[i]:ro[i] + rl[i]]) for i in pick], read_bases=int(rl[pick].sum()), flank_names=fl_n, flank_seqs=fl_s,
+                            text="%d reads drawn at random (seed %d) from this run's read set + the first and last 500 bases of the first 100 locus contigs, against the full reference" % (len(pick), a.cpu_sample_seed))
+
+            def xc_bam(ref_fa, reads_fa, bam_path):
+                from telr_amd import telr_alignment
+                telr_alignment.alignment(bam_path, reads_fa, ref_fa, os.path.dirname(bam_path), "xcheck", 1, "minimap2", "ont", engine=eng)
+                return None
+            out["reference_cpu_path"] = xc.reference_cpu_path(ours=xc.default_ours(eng), sample=xc_sample, presets="ont" if cfg["err"][1] < 0.05 else "pacbio", bam_writer=xc_bam)
+        except Exception as e:
+            out["reference_cpu_path"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if default_aligner is not None:
+        out["value_reference_default_aligner"] = default_aligner
+        if "error" not in default_aligner and a.default_aligner_parity_reads > 0 and not a.no_cpu_baseline:
+            # the same leg's parity evidence and CPU figure: the oracle with the same preset on a random sample of the same reads
+            cb = cpu_baseline(ref_strs, D["reads"], io_ng, mo_ng, a.default_aligner_parity_reads, gpu_index=ix_ng, seed=a.cpu_sample_seed + 1)
+            default_aligner["parity"] = cb.pop("parity", None)
+            default_aligner["cpu_baseline"] = cb
     if not a.no_cpu_baseline:
         ns = a.cpu_sample_reads or max(8, int(3.0e7 * usable_cpus() / max(1.0, n_bases / len(D["reads"][2]))))   # ~15-20 s of CPU work
         out["cpu_baseline"] = cpu_baseline(ref_strs, D["reads"], io, mo, ns, gpu_index=ix, seed=a.cpu_sample_seed)

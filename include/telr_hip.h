@@ -79,7 +79,7 @@ typedef struct telr_map_opt {
     int32_t min_dp_max;       /* -s                                                    */
     int32_t min_ksw_len;      /* min gap-fill segment length                           */
     int32_t ext_max;          /* max bases an end extension may consume on the query   */
-    int32_t ext_band;         /* half band width of end extensions                     */
+    int32_t ext_band;         /* half band width of end extensions (<= 31 with bw_long; presets: 31, ngmlr-ont 63) */
     int32_t flags;            /* TELR_MF_*                                             */
     int32_t fill_band_q4;     /* first-pass half band of a gap fill: 2 + q4*floor(sqrt(min(m,n)))/16;
                                  0 = 8.  Paths that come close to a band edge are re-aligned with the wide band. */
@@ -108,6 +108,14 @@ typedef struct telr_map_opt {
      * ext 20 -> 10, decay 3.  ngmlr-pacbio (match 2, mismatch 5, open 5, extension 5 -> 1): cx_scale 20, open 100, ext 100 -> 20,
      * decay 3.  cx_scale = 0 over either preset gives the two-piece envelope q / e / q2 / e2 of round 3. */
     int32_t cx_scale, cx_open, cx_ext_max, cx_ext_min, cx_decay;
+    /* second pass of an end extension (round 5).  An extension that ENDS BEFORE THE END OF THE READ -- its best cell lies short of
+     * the min(remaining query, ext_max) bases it was given: the read is clipped there, i.e. the window runs into sequence that is
+     * not homologous (an insertion, a chimeric junction) -- is aligned once more in a band of +-ext_band_wide (same ext_max, same
+     * z-drop; the wide result replaces the first).  Under the cheap convex gaps of ngmlr-ont a path through such sequence keeps
+     * gaining a little and wanders off the +-31 band without ever touching its edge, so the edge rule of the gap fills does not
+     * see it; extensions that reach the read's end (19 in 20) keep the narrow band.  0 or <= ext_band = off (every preset but
+     * ngmlr-ont).  tests/test_faithful_gate.py, DESIGN.md section 2. */
+    int32_t ext_band_wide;
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */
@@ -393,7 +401,7 @@ int  telr_last_counters(const telr_ctx *ctx, telr_counters *out);
 /* per DP class (TELR_N_DPCLS classes) of the last telr_map call:
  * out[c*4+0] problems, [c*4+1] DP cells, [c*4+2] anti-diagonal steps (sum of m+n),
  * [c*4+3] algorithmic bytes (2-bit bases read once + 4 B per CIGAR run + 32 B result) */
-#define TELR_N_DPCLS 23
+#define TELR_N_DPCLS 25
 int  telr_last_dp_classes(const telr_ctx *ctx, int64_t *out /* [TELR_N_DPCLS*4] */);
 
 #ifdef __cplusplus

@@ -17,6 +17,7 @@ class MapOpt(C.Structure):
         ("ext_max", C.c_int32), ("ext_band", C.c_int32), ("flags", C.c_int32), ("fill_band_q4", C.c_int32), ("fill_margin", C.c_int32),
         ("vote_len", C.c_int32), ("vote_bin_shift", C.c_int32), ("vote_min", C.c_int32), ("vote_frac_q8", C.c_int32), ("bw_long", C.c_int32),
         ("cx_scale", C.c_int32), ("cx_open", C.c_int32), ("cx_ext_max", C.c_int32), ("cx_ext_min", C.c_int32), ("cx_decay", C.c_int32),
+        ("ext_band_wide", C.c_int32),
     ]
 
     def copy(self):
@@ -44,7 +45,7 @@ class Counters(C.Structure):
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8
 MF_CIGAR, MF_PER_TARGET, MF_FAITHFUL, MF_KEEP_CIGARS = 1, 2, 4, 8
 N_STAGES = 16
-N_DPCLS = 23
+N_DPCLS = 25
 
 import numpy as _np
 

@@ -101,8 +101,9 @@ def parse_argv(argv):
     return o
 
 
-def main(argv=None):
-    o = parse_argv(sys.argv[1:] if argv is None else argv)
+def run(argv, out_path="/dev/stdout", engine=None):
+    """answer one argv shape (argv[0] = minimap2 | ngmlr) with the engine; SAM / PAF goes to `out_path`.  -> number of records"""
+    o = parse_argv(argv)
     from .aligner import Engine
     from .presets import preset
     from .fasta import read_fasta
@@ -117,20 +118,27 @@ def main(argv=None):
         mo.flags &= ~1
     tn, ts = read_fasta(o["target"])
     qn, qs = read_fasta(o["query"])
-    eng = Engine(0)
+    eng = engine if engine is not None else Engine(0)
     ix = eng.index(ts, io)
     # S5 shape (library against ONE contig file) and every other shape are all-vs-all here; the batched
     # per-locus forms are in telr_amd.telr_te / telr_af / telr_liftover
     r = ix.map_raw(qs, mo)
     try:
-        sys.stdout.flush()
+        n = int(eng.L.telr_result_count(r))
         if o["sam"]:
-            ix.write_sam(r, qn, qs, tn, ts, "/dev/stdout", md=o["md"], cs=o["cs"], softclip=o["softclip"], rg=o["rg"],
-                         cmdline=" ".join([o["tool"]] + (sys.argv[2:] if argv is None else argv[1:])))
+            ix.write_sam(r, qn, qs, tn, ts, out_path, md=o["md"], cs=o["cs"], softclip=o["softclip"], rg=o["rg"],
+                         cmdline=" ".join([o["tool"]] + list(argv[1:])))
         else:
-            ix.write_paf(r, qn, tn, "/dev/stdout", with_cigar=o["cigar"])
+            ix.write_paf(r, qn, tn, out_path, with_cigar=o["cigar"])
     finally:
         ix.free_raw(r)
+        ix.free()
+    return n
+
+
+def main(argv=None):
+    sys.stdout.flush()
+    run(sys.argv[1:] if argv is None else argv)
     return 0
 
 

@@ -1701,7 +1701,7 @@ __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__
 // DP classes.  0-4: LDS-state kernel (z-drop extensions, very wide fills), by band width;
 // 5-9: register kernel for gap-fill problems: (lanes per problem, diagonal pairs per lane) =
 // (32,1) (64,1) (64,2) (64,4) (64,8)  ->  bands up to 64 / 128 / 256 / 512 / 1024 diagonals.
-#define DP_NCLS 23
+#define DP_NCLS 25
 // 10-17: packed-int16 register kernel d_dp_pkr<LPP, R> for short gap fills, by band width.  One lane per problem:
 // class 17 D <= 16 (R = 4), classes 10..13 D = 17-20 / 21-24 / 25-28 / 29-32 (R = 5 / 6 / 7 / 8: exact ranges, so that only
 // the last register of a lane can straddle the upper band edge); two lanes: classes 14..16 D <= 40 / 48 / 64 (R = 5 / 6 / 8).
@@ -1709,9 +1709,14 @@ __global__ void __launch_bounds__(64) k_segments_w(const KeptChain *__restrict__
 // 19-21: wide fills in int16 while the scores fit (steps <= pk_wide_steps): D <= 256 / 512 / 1024, 1 / 2 / 4 waves per problem
 // 22: 65..128 diagonals, four lanes x R = 8 (16 problems per wave): the class of the retried fills (wide band of a ~200-base
 //     segment = 100-130 diagonals), which the margin rule of the band spec makes ~1 % of all fills
-__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps, int pk_wide_maxd = 1024)
+// 23, 24: z-drop extensions with D <= 128 / 256 (eight / sixteen lanes, R = 4): presets with ext_band > 31 (ngmlr-ont, round 5)
+__device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max_steps, int pk_ext_steps, int pk_wide_steps, int pk_wide_maxd = 1024, int pk_ext_maxd = 64)
 {
-    if ((kind == 1 || kind == 2) && D <= 64 && steps <= pk_ext_steps) return 18;
+    if ((kind == 1 || kind == 2) && steps <= pk_ext_steps) {
+        if (D <= 64) return 18;
+        if (D <= 128 && pk_ext_maxd >= 128) return 23;
+        if (D <= 256 && pk_ext_maxd >= 256) return 24;
+    }
     if (kind == 0 && steps <= pk_max_steps) {
         if (D <= 16) return 17;
         if (D <= 20) return 10;
@@ -1749,7 +1754,8 @@ __host__ __device__ __forceinline__ int d_tb4_rowb(int cls) { return cls == 17 ?
 // dwords per packed trace-back row
 __device__ __forceinline__ int d_cls_slots(int cls)
 {
-    if (cls == 22) return 32;
+    if (cls == 22 || cls == 23) return 32;
+    if (cls == 24) return 64;
     if (cls >= 19) return 64 << (cls - 19);
     if (cls >= 10) return cls <= 13 ? cls - 5 : cls == 14 ? 10 : cls == 15 ? 12 : cls == 17 ? 4 : 16;
     return cls == 5 ? 32 : 64 << (cls - 6);
@@ -1769,13 +1775,13 @@ __device__ __forceinline__ bool d_any_n(const uint32_t *__restrict__ nmask, int6
 }
 __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_margin, int32_t pk_max_steps, int32_t pk_ext_steps, int32_t pk_wide_steps,
                              const uint32_t *__restrict__ qnmask, const uint32_t *__restrict__ tnmask,
-                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4, int32_t tb4_steps, int32_t pk_wide_maxd)
+                             int64_t *__restrict__ tb_bytes, int64_t *__restrict__ cig_ops, int32_t tb4, int32_t tb4_steps, int32_t pk_wide_maxd, int32_t pk_ext_maxd)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= np) return;
     const DpProb P = probs[i];
     int D = P.dhi - P.dlo + 1, stride = (D + 2) / 2;
-    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps, pk_wide_steps, pk_wide_maxd);
+    int cls = d_dp_class(P.kind, D, P.m + P.n, pk_max_steps, pk_ext_steps, pk_wide_steps, pk_wide_maxd, pk_ext_maxd);
     if (cls >= 10 && P.kind < 3) {
         // the packed kernels have no ambiguity case: a problem with an N inside either window takes an int32 class
         const bool hasn = d_any_n(qnmask, P.qstep > 0 ? P.qi0 : P.qi0 - P.m + 1, P.m) || d_any_n(tnmask, P.tstep > 0 ? P.ti0 : P.ti0 - P.n + 1, P.n);
@@ -1793,7 +1799,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
     int cells = 0;
-    if (cls >= 10 && cls != 18) for (int d = P.dlo; d <= P.dhi; ++d) {
+    if (cls >= 10 && cls != 18 && cls < 23) for (int d = P.dlo; d <= P.dhi; ++d) {
         int ilo = d < 0 ? 1 - d : 1, ihi = P.n - d < P.m ? P.n - d : P.m;
         if (ihi >= ilo) cells += ihi - ilo + 1;
     }
@@ -3029,6 +3035,20 @@ __global__ void __launch_bounds__(64) k_dp_pkx16(DpArgs A)
     __builtin_amdgcn_s_setprio(3);
     if (A.o.cx_scale) d_dp_pkr<16, 1, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * 4);
     else d_dp_pkr<16, 1, true>(A, A.list, A.nlist, blockIdx.x * 4);
+}
+
+// the wider extension bands (classes 23 / 24: D <= 128 / 256), eight / sixteen lanes per problem, same cell, same spill layout rule
+__global__ void __launch_bounds__(64) k_dp_pkx_w8(DpArgs A)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if (A.o.cx_scale) d_dp_pkr<8, 4, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * 8);
+    else d_dp_pkr<8, 4, true>(A, A.list, A.nlist, blockIdx.x * 8);
+}
+__global__ void __launch_bounds__(64) k_dp_pkx_w16(DpArgs A)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if (A.o.cx_scale) d_dp_pkr<16, 4, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * 4);
+    else d_dp_pkr<16, 4, true>(A, A.list, A.nlist, blockIdx.x * 4);
 }
 
 // ---- trace-back: one thread per problem walks its trace-back bytes and writes the

@@ -1362,16 +1362,21 @@ static inline int tag8_steps(const telr_map_opt *mo)
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
 }
+// diagonals of the preset's extension band (-ext_band rounded to even .. ext_band), as the packed extension classes cut them: 64 / 128 / 256
+static inline int pk_ext_d(const telr_map_opt *mo) { const int D = 2 * mo->ext_band + 2; return D <= 64 ? 64 : D <= 128 ? 128 : 256; }
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
     if (!pk_steps_limit(mo) || getenv("TELR_NO_PKEXT")) return 0;
+    const int D = pk_ext_d(mo);
     // (convex cost: the z-drop test runs on the re-biased row maximum + the sum of the moves, in int32 -- kernels.hip.h, REB)
-    if (mo->cx_scale > 0) return mo->zdrop * mo->cx_scale <= 30000 && pk_cx_ok(mo, 64) ? 7900 : 0;
+    if (mo->cx_scale > 0) return mo->zdrop * mo->cx_scale <= 30000 && pk_cx_ok(mo, D) ? 7900 : 0;
     if (mo->zdrop > 4000) return 0;
-    const int by_b = 2 * (15800 - mo->q2 - 64 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
+    const int by_b = 2 * (15800 - mo->q2 - D * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
 }
+// the widest band the packed extension classes take (18: 64, 23: 128, 24: 256 diagonals)
+static inline int pk_ext_maxd(const telr_map_opt *mo) { return pk_ext_limit(mo) ? pk_ext_d(mo) : 64; }
 static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, const telr_map_opt *mo, DpProb *d_probs, int np, DpRes *d_res,
                    uint32_t **d_rawcig_io, int32_t *d_retry, const std::string &sfx, bool primary)
 {
@@ -1387,7 +1392,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     TRY(ctx_buf_t(ctx, ("cls_key" + sfx).c_str(), (size_t)np, &d_clskey));
     TRY(ctx_buf_t(ctx, ("cls_keytmp" + sfx).c_str(), (size_t)np, &d_keytmp));
     TRY(ctx_buf_t(ctx, ("cls_listtmp" + sfx).c_str(), (size_t)np, &d_listtmp));
-    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo), tb4_steps(mo), pk_wide_maxd(mo));
+    hipLaunchKernelGGL(k_prob_sizes, dim3((np + 255) / 256), dim3(256), 0, st, d_probs, np, primary ? mo->fill_margin : 0, pk_steps_limit(mo), pk_ext_limit(mo), pk_wide_limit(mo), qs->d_nmask, tg->d_nmask, d_tbb, d_cgo, tb4_mask(mo), tb4_steps(mo), pk_wide_maxd(mo), pk_ext_maxd(mo));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(d_tbb + np, 0, 8, st));
     HIPCHK(hipMemsetAsync(d_cgo + np, 0, 8, st));
@@ -1471,7 +1476,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     auto side_stream = [&]() { if (serial) return st; hipStream_t s2 = ctx->side[side % TELR_NSIDE]; ++side; used.push_back(s2); return s2; };
     // launch order = expected single-problem latency, longest first (the device offers only a few hardware queues,
     // so streams beyond that share one and run in submission order)
-    static const int SIDE_ORDER[] = { 9, 4, 3, 21, 8, 20, 18, 2, 7, 19, 1, 0 };
+    static const int SIDE_ORDER[] = { 9, 4, 3, 21, 8, 20, 24, 23, 18, 2, 7, 19, 1, 0 };
     for (int c : SIDE_ORDER) {
         if (h_cls[c] == 0) continue;
         hipStream_t s2 = side_stream();
@@ -1490,6 +1495,8 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         else if (c == 21) hipLaunchKernelGGL((k_dp_pkw<4>), dim3(nl), dim3(256), 0, s2, D);
         else if (c == 20) hipLaunchKernelGGL((k_dp_pkw<2>), dim3(nl), dim3(128), 0, s2, D);
         else if (c == 19) hipLaunchKernelGGL((k_dp_pkw<1>), dim3(nl), dim3(64), 0, s2, D);
+        else if (c == 23) hipLaunchKernelGGL(k_dp_pkx_w8, dim3((nl + 7) / 8), dim3(64), 0, s2, D);
+        else if (c == 24) hipLaunchKernelGGL(k_dp_pkx_w16, dim3((nl + 3) / 4), dim3(64), 0, s2, D);
         else if (nl < 8192) hipLaunchKernelGGL(k_dp_pkx16, dim3((nl + 3) / 4), dim3(64), 0, s2, D);       // few problems: latency counts
         else { const int ppw = 64 / PKX_LPP; hipLaunchKernelGGL(k_dp_pkx, dim3((nl + ppw - 1) / ppw), dim3(64), 0, s2, D); }
         HIPCHK(hipGetLastError());
@@ -1497,7 +1504,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             // few long problems: one wave walks one problem (latency); many (extensions, or a tail class with thousands of problems
             // on a repeat-rich genome): one lane per problem (throughput)
             static const int tbw_max = [] { const char *e = getenv("TELR_TBW_MAX"); return e ? atoi(e) : 2048; }();
-            if (c == 18 || c == 0 || nl > tbw_max) hipLaunchKernelGGL(k_traceback, dim3((nl + 63) / 64), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
+            if (c == 18 || c == 23 || c == 24 || c == 0 || nl > tbw_max) hipLaunchKernelGGL(k_traceback, dim3((nl + 63) / 64), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
             else hipLaunchKernelGGL(k_traceback_w, dim3(nl), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
             HIPCHK(hipGetLastError());
         }
@@ -2147,6 +2154,8 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         ctx->err = "sub-read voting needs vote_len 16..65536, vote_bin_shift 0..20, vote_min >= 1, vote_frac_q8 0..256"; return TELR_E_ARG; }
     if (mo->flags & TELR_MF_FAITHFUL) { ctx->err = "TELR_MF_FAITHFUL is a mode of the CPU oracle (test infrastructure), not of the engine"; return TELR_E_ARG; }
     if (mo->max_gap >= TELR_TPAD || mo->ext_band * 2 + 1 > DP_DMAX || mo->ext_band < 1 || mo->ext_max < 1) return TELR_E_ARG;
+    if (mo->bw_long > mo->bw && mo->ext_band > 31) {       // the two halves of a long-gap fill (spec 3.11) are bands of the extension width, held in 64 diagonals of LDS
+        ctx->err = "long join (bw_long) needs ext_band <= 31"; return TELR_E_ARG; }
     if (queries->max_len >= (1 << 24)) return TELR_E_RANGE;
     HIPCHK(hipSetDevice(ctx->device));
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));

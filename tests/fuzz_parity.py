@@ -73,7 +73,7 @@ def draw_case(seed, big=False, sv=False, presets=None):
         from telr_amd.presets import _gap_q8
         mo.chain_gap_q8 = _gap_q8(io.k)
     mo.chain_lookback = int(rng.choice([64, 128, 256]))
-    mo.fill_band_q4 = int(rng.integers(1, 17)); mo.fill_margin = int(rng.integers(0, 4))
+    mo.fill_band_q4 = int(rng.integers(1, 17)); mo.fill_margin = int(rng.integers(0, 6))
     if rng.random() < 0.25:                             # gap costs on both sides of the one-piece rule of the packed cell ((D-1)(e-e2) < q2-q)
         mo.q2 = int(mo.q + rng.integers(0, 30)); mo.e2 = int(rng.integers(1, mo.e + 1))
     per_target = ntg > 1 and rng.random() < 0.2          # ranked per target, per-target occurrence cut-offs
@@ -89,6 +89,9 @@ def draw_case(seed, big=False, sv=False, presets=None):
     mo.best_n = int(rng.integers(1, 8)); mo.secondary = int(rng.integers(0, 2))
     mo.chain_skip_q8 = int(rng.choice([0, 0, 0, 3]))
     mo.ext_max = int(rng.choice([256, 2048])); mo.zdrop = int(rng.choice([100, 400]))
+    mo.ext_band = int(rng.choice([31, 31, 31, 63, 63, 127, 20, 45, 95]))      # round 5: the extension band is a preset parameter (classes 18 / 23 / 24)
+    if mo.bw_long > mo.bw and mo.ext_band > 31:
+        mo.ext_band = 31                                 # (the long join's two-band fills are cut to the 64-diagonal extension band: telr_map refuses wider)
     return pname, io, mo, genome, reads, qtarget, edge_repeats
 
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "c1", "--genome-len", "3000000",
-           "--reads", "1500", "--read-bases", "60000000", "--insertions", "30", "--cpu-sample-reads", "40"]
+           "--reads", "1500", "--read-bases", "60000000", "--insertions", "30", "--cpu-sample-reads", "40", "--default-aligner-parity-reads", "40"]
     p = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
@@ -29,12 +29,22 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["peak"] in (8000.0, 2500.0) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert (r["bound"], r["peak"]) in {("hbm", 8000.0), ("mfma", 2500.0)} and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
     assert c["parity"]["identical"] is True and c["parity"]["reads"] == 40 and c["parity"]["records_engine"] == c["parity"]["records_oracle"] > 0
+    # the reference's DEFAULT aligner (`--aligner nglmr`) under the same clock: same steps, own roofline, own parity sample
+    g = d["value_reference_default_aligner"]
+    assert "error" not in g, g
+    assert g["preset"] == "ngmlr-ont" and g["steps"] == 2 and g["warmup"] == 1 and 0 < g["value"] and g["unit"] == "Gbp/s"
+    assert abs(g["roofline"]["frac"] - g["roofline"]["achieved"] / 8000.0) < 1e-9 and g["roofline"]["bound"] == "hbm"
+    assert g["parity"]["identical"] is True and g["parity"]["reads"] == 40 and g["parity"]["records_engine"] == g["parity"]["records_oracle"] > 0
+    assert g["cpu_baseline"]["kind"] == "port" and 0 < g["cpu_baseline"]["value"] < g["value"]
+    # the upstream tools are not on this box: the cross-check leg says so instead of skipping silently
+    x = d["reference_cpu_path"]
+    assert x["looked_for"] == ["minimap2", "ngmlr", "samtools", "bedtools"] and (x["available"] is False or "shapes" in x)
     b = d["stage1_to_sorted_bam"]                                        # the default run carries the stage-1 hand-off leg
     assert "error" not in b and b["writer"] == "device" and 0 < b["gbp_per_s_incl_bam"] < d["value"] and b["bam_bytes"] > 1000000
     assert d["value_incl_h2d"] <= d["value"] and d["te_loci"]["n"] == 30

@@ -108,14 +108,6 @@ typedef struct telr_map_opt {
      * ext 20 -> 10, decay 3.  ngmlr-pacbio (match 2, mismatch 5, open 5, extension 5 -> 1): cx_scale 20, open 100, ext 100 -> 20,
      * decay 3.  cx_scale = 0 over either preset gives the two-piece envelope q / e / q2 / e2 of round 3. */
     int32_t cx_scale, cx_open, cx_ext_max, cx_ext_min, cx_decay;
-    /* second pass of an end extension (round 5).  An extension that ENDS BEFORE THE END OF THE READ -- its best cell lies short of
-     * the min(remaining query, ext_max) bases it was given: the read is clipped there, i.e. the window runs into sequence that is
-     * not homologous (an insertion, a chimeric junction) -- is aligned once more in a band of +-ext_band_wide (same ext_max, same
-     * z-drop; the wide result replaces the first).  Under the cheap convex gaps of ngmlr-ont a path through such sequence keeps
-     * gaining a little and wanders off the +-31 band without ever touching its edge, so the edge rule of the gap fills does not
-     * see it; extensions that reach the read's end (19 in 20) keep the narrow band.  0 or <= ext_band = off (every preset but
-     * ngmlr-ont).  tests/test_faithful_gate.py, DESIGN.md section 2. */
-    int32_t ext_band_wide;
 } telr_map_opt;
 
 #define TELR_MF_CIGAR      0x1   /* -c / -a : run base-level alignment               */

@@ -1063,7 +1063,6 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
      * the tuned presets against this mode is gated by tests/test_faithful_gate.py. */
     const int faithful = (mo->flags & (TELR_MF_FAITHFUL | 0x200)) != 0, faithful_ext = (mo->flags & (TELR_MF_FAITHFUL | 0x400)) != 0;
     const int ext_max = faithful_ext ? (1 << 30) : mo->ext_max, ext_band = faithful_ext ? mo->bw : mo->ext_band;
-    const int ext_wide = faithful_ext ? 0 : mo->ext_band_wide;          /* second pass of clipped extensions (0 = off) */
     convex_t CX; const int cx = (mo->cx_scale > 0 || (mo->flags & MFX_CONVEX)) && convex_of(mo, &CX);       /* segment scores come back in 1/S units */
     /* query accessor on the chain's strand */
     dp_seq_t s; s.q = q; s.t = t; s.qcomp = c->rev;
@@ -1090,10 +1089,6 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         rc.n = 0;
         dp_res_t r = band_dp(&s, even_lo(-ext_band), ext_band, 1, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
-        if (r.bi < mq && ext_wide > ext_band) {          /* spec 3.7: the read is clipped here -- second pass in the wide extension band */
-            ctr->window_bases -= mt; mt = r0 < mq + ext_wide ? r0 : mq + ext_wide; s.n = mt; ctr->window_bases += mt;
-            rc.n = 0; int64_t c0 = r.cells; r = band_dp(&s, even_lo(-ext_wide), ext_wide, 1, mo, &rc); ctr->dp_cells += r.cells; r.cells += c0;
-        }
         dp += r.score; qs = q0 - r.bi; rs = r0 - r.bj;
         /* rev_cig is end->start of the reversed problem == left-to-right on the forward sequences */
         for (int64_t z = 0; z < rc.n; ++z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
@@ -1157,10 +1152,6 @@ static void align_chain(const tor_index *ix, const uint8_t *q, int qlen, const c
         rc.n = 0;
         dp_res_t r = band_dp(&s, even_lo(-ext_band), ext_band, 1, mo, &rc);
         ++ctr->dp_problems; ctr->dp_cells += r.cells; ctr->window_bases += mt;
-        if (r.bi < mq && ext_wide > ext_band) {
-            ctr->window_bases -= mt; mt = rt < mq + ext_wide ? rt : mq + ext_wide; s.n = mt; ctr->window_bases += mt;
-            rc.n = 0; int64_t c0 = r.cells; r = band_dp(&s, even_lo(-ext_wide), ext_wide, 1, mo, &rc); ctr->dp_cells += r.cells; r.cells += c0;
-        }
         dp += r.score; qe += r.bi; re += r.bj;
         for (int64_t z = rc.n - 1; z >= 0; --z) cig_push(&cig, rc.a[z] & 0xf, rc.a[z] >> 4);
     }

@@ -17,7 +17,6 @@ class MapOpt(C.Structure):
         ("ext_max", C.c_int32), ("ext_band", C.c_int32), ("flags", C.c_int32), ("fill_band_q4", C.c_int32), ("fill_margin", C.c_int32),
         ("vote_len", C.c_int32), ("vote_bin_shift", C.c_int32), ("vote_min", C.c_int32), ("vote_frac_q8", C.c_int32), ("bw_long", C.c_int32),
         ("cx_scale", C.c_int32), ("cx_open", C.c_int32), ("cx_ext_max", C.c_int32), ("cx_ext_min", C.c_int32), ("cx_decay", C.c_int32),
-        ("ext_band_wide", C.c_int32),
     ]
 
     def copy(self):

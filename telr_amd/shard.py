@@ -277,6 +277,7 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
     old_off = alns["cigar_off"].astype(np.int64)[ridx]
     s_alns["cigar_off"] = (c_off_all - cig_cuts[p_dest[r_pair]]).astype(s_alns["cigar_off"].dtype) if tot_rec else s_alns["cigar_off"]
     dev = cig_t.device
+    _sub(timings, "pack_host_index_s", t0, dev); t1 = time.time()
     # the CIGAR words of the sent records, gathered on the device
     tot_cig = int(ncig.sum())
     if tot_cig:
@@ -285,11 +286,12 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
         s_cig = cig_t.view(torch.int32)[widx]
     else:
         s_cig = torch.zeros(0, dtype=torch.int32, device=dev)
+    _sub(timings, "pack_cigar_gather_s", t1, dev); t1 = time.time()
     seq2, nmask = gather_packed(p_read)
+    _sub(timings, "pack_read_subset_s", t1, dev)
     w2, _ = packed_words(lengths[p_read])
     w2_cuts = np.concatenate([[0], np.cumsum(w2)])[cuts]
-    if timings is not None:
-        timings["pack_s"] = timings.get("pack_s", 0.0) + time.time() - t0
+    _sub(timings, "pack_s", t0, dev)
     t0 = time.time()
     # per destination: [records][emit][gid][length][names][CIGAR words][2-bit words][mask words], every section padded to 8 bytes
     sec = np.zeros((world, 8), np.int64)
@@ -310,6 +312,7 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
             if (x.numel() * 4) % 8:
                 parts.append(torch.zeros(4, dtype=torch.uint8, device=dev))
     send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+    _sub(timings, "payload_build_s", t0, dev)
     in_split = [int(sum(_pad8(v) for v in sec[d])) for d in range(world)]
     st = torch.from_numpy(sec.reshape(-1).copy()).to(wire); rs = torch.empty_like(st)
     dist.all_to_all_single(rs, st)
@@ -341,6 +344,8 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
         o = pos[8]
     a_all = np.concatenate(g_alns); e_all = np.concatenate(g_emit); gid_all = np.concatenate(g_gid); len_all = np.concatenate(g_len)
     cig_all = torch.cat(g_cig); s2 = torch.cat(g_s2); sn = torch.cat(g_sn)
+    _sub(timings, "unpack_parse_s", t0, dev)
+    t1 = time.time()
     # reads into ascending job order (ties of the coordinate sort are broken by it): a permutation of the packed pieces on the device
     order = np.argsort(gid_all, kind="stable")
     if len(order) and not (order == np.arange(len(order))).all():
@@ -358,9 +363,22 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
         ro = np.argsort(a_all["qid"], kind="stable")
         a_all = a_all[ro]; e_all = e_all[ro]
         len_all = len_all[order]; gid_all = gid_all[order]; g_names = [g_names[i] for i in order]
+    _sub(timings, "unpack_reorder_s", t1, dev)
     if timings is not None:
         timings["unpack_s"] = timings.get("unpack_s", 0.0) + time.time() - t0
     return dict(alns=a_all, emit=e_all, cig=cig_all, lengths=len_all, names=g_names, gid=gid_all, seq2=s2, nmask=sn)
+
+
+def _sub(timings, key, t0, dev=None):
+    """sub-phase timer; with TELR_PHASE_SYNC=1 the device is drained first, so that a phase is charged with its own kernels and
+    copies instead of whatever was still queued when its first blocking call came"""
+    import os, time
+    if timings is None:
+        return
+    if os.environ.get("TELR_PHASE_SYNC") and dev is not None and getattr(dev, "type", "") == "cuda":
+        import torch
+        torch.cuda.synchronize(dev)
+    timings[key] = timings.get(key, 0.0) + time.time() - t0
 
 
 def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tnames, tlens, dist, device=None, level=1, writer_kw=None, timings=None):
@@ -384,11 +402,16 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
     payload = 4 * len(cigars) + int(np.asarray(lengths, np.int64).sum()) * 3 // 8 + alns.nbytes
     fr, _tot = eng.mem_info()
     if fr < 8 * payload + (2 << 30):
+        t1 = time.time()
         eng.release_scratch()
+        _sub(tm, "partition_release_scratch_s", t1, dev)
+    t1 = time.time()
     keys = alns["tid"].astype(np.int64) << 32 | alns["ts"].astype(np.int64)
     split = stage1_splitters(keys, world, dist, wire)
     dest = np.searchsorted(split, keys, side="right")
+    _sub(tm, "partition_splitters_s", t1, dev); t1 = time.time()
     cig_t = torch.from_numpy(np.ascontiguousarray(cigars, dtype=np.uint32).view(np.int32)).to(dev)
+    _sub(tm, "partition_cigar_upload_s", t1, dev)
     held = []
 
     def gather_packed(idx):
@@ -401,12 +424,15 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
     del cig_t
     t0 = time.time()
     jq = SeqSet.from_packed(eng, got["lengths"], got["seq2"], got["nmask"])
+    _sub(tm, "slice_from_packed_s", t0, dev); t1 = time.time()
     jr = ix.result_from_device_cigars(got["alns"], got["cig"])
+    _sub(tm, "slice_result_s", t1, dev); t1 = time.time()
     got["seq2"] = got["nmask"] = got["cig"] = None          # the library holds its own copies now: torch's cache goes back to the device for the writer
     if dev.type == "cuda":
         torch.cuda.empty_cache()
     seg = ix.write_bam_slice(jr, jq, ix._cstr_array(got["names"]), tnames, got["emit"], with_header=rank == 0, unmapped=rank == world - 1, level=level, **kw)
     info = ix.segment_info(seg)
+    _sub(tm, "slice_code_s", t1, dev)
     tm["code_slice_s"] = time.time() - t0
     t0 = time.time()
     sizes = torch.zeros(world, dtype=torch.int64, device=wire); mine = torch.tensor([info["bytes"]], dtype=torch.int64, device=wire)

@@ -22,7 +22,10 @@ _lib = None
 
 
 class TelrError(RuntimeError):
-    pass
+    """`code` = the library's TELR_E_* return code when the error came from a C-ABI call (None otherwise)"""
+    def __init__(self, msg, code=None):
+        RuntimeError.__init__(self, msg)
+        self.code = code
 
 
 def lib():

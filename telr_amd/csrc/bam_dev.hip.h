@@ -1117,7 +1117,7 @@ extern "C" int telr_bam_prepare(telr_ctx *ctx, const char *bam_path, int64_t est
     }
     k->ms_map = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (k->fd < 0 || !k->map) { k->over = true; ctx->bam_sink = k; return TELR_OK; }      // the writer falls back to plain streaming
-    static const bool no_populate = getenv("TELR_BAM_NO_POPULATE") != nullptr;
+    static const bool no_populate = ab_on("bam_no_populate");
     k->th = std::thread([k] {
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t i = 0; i < k->n_slices; ++i) {
@@ -1337,12 +1337,13 @@ struct BamSliceOpt { const uint8_t *emit; int32_t with_header; telr_bam_segment 
 static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                         const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                         const char *bam_path, int32_t write_index, int32_t level, const BamSliceOpt *so = nullptr);
+// one writer at a time per process, whole-file and slice calls alike: the call's timing / size records (g_bam_*), the NOMEM retry size and
+// the code tables are process-wide
+static std::mutex g_bam_mu;
 extern "C" int telr_write_bam_dev(telr_ctx *ctx, const telr_result *r, const telr_seqset *queries, const telr_index *idx, const char *const *qnames,
                                   const char *const *tnames, int32_t flags, const char *rg_id, const char *rg_sm, const char *rg_lb, const char *pg_line,
                                   const char *bam_path, int32_t write_index, int32_t level)
 {
-    // one writer at a time per process: the call's timing / size records (g_bam_*) and the code tables are process-wide
-    static std::mutex g_bam_mu;
     std::lock_guard<std::mutex> writer_lock(g_bam_mu);
     (void)hipGetLastError();          // a failed allocation of an EARLIER call leaves its error with the thread: not this call's
     int rc = bam_dev_impl(ctx, r, queries, idx, qnames, tnames, flags, rg_id, rg_sm, rg_lb, pg_line, bam_path, write_index, level);
@@ -1382,7 +1383,7 @@ static int bam_dev_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *
     auto t0 = now();
     // ... unless the result kept them there (TELR_MF_KEEP_CIGARS): the mirrored array is used in place
     uint32_t *d_cig;
-    static const bool no_twin = getenv("TELR_BAM_NO_TWIN") != nullptr;
+    static const bool no_twin = ab_on("bam_no_twin");
     const bool twin = r->d_cig && !r->twin_off && r->twin_n == r->ncig && !no_twin;
     g_bam_twin = twin ? 1 : 0;
     if (twin) { d_cig = r->d_cig; HIPCHK(hipDeviceSynchronize()); }      // its last pieces were copied on other streams
@@ -1630,8 +1631,7 @@ extern "C" int telr_write_bam_slice(telr_ctx *ctx, const telr_result *r, const t
                                     const uint8_t *emit, int32_t with_header, int32_t level, telr_bam_segment **out)
 {
     if (!out || level < 1) return TELR_E_ARG;
-    static std::mutex mu;                                   // (the writer's process-wide records, as in telr_write_bam_dev)
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(g_bam_mu);               // (the same lock as telr_write_bam_dev: the writer's records are process-wide)
     (void)hipGetLastError();
     telr_bam_segment *S = new telr_bam_segment();
     BamSliceOpt so{ emit, with_header, S };

@@ -38,7 +38,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     const char *p = (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
     if (p == MAP_FAILED) { delete F; return TELR_E_ARG; }
-    static const bool trace = getenv("TELR_TRACE_FASTA") != nullptr;
+    static const bool trace = trace_on("fasta");
     auto tt0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!trace) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[fasta %s] %-22s %8.2f ms\n", path, what, std::chrono::duration<double, std::milli>(t1 - tt0).count()); tt0 = t1; };
     struct Rec { size_t hdr, body, end; };       // header line start (after '>' / '@'), first byte after the header line, end of the sequence text
@@ -105,7 +105,7 @@ extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
     int64_t tot = 0, ntot = 0;
     std::vector<int64_t> noff(nr);
     for (size_t r = 0; r < nr; ++r) { F->off[r] = tot; tot += F->len[r]; noff[r] = ntot; ntot += nlen[r] + 1; }
-    static const bool no_zero_copy = getenv("TELR_FASTA_COPY") != nullptr;
+    static const bool no_zero_copy = ab_on("fasta_copy");
     const bool in_place = folded.load() == 0 && !no_zero_copy;
     F->seq_bytes = (size_t)tot;
     if (in_place) {

@@ -3085,7 +3085,7 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
         const int64_t off = (LAYOUT == 2 || cls >= 10) ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
                           : packed ? ((((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)) : ((int64_t)a * stride + sl);
         // lines are taken relative to the 64-byte grid of the whole scratch buffer; the wave-interleaved classes keep their
-        // bytes in 8-byte units 512 bytes apart (k_tb_gather) -- this generic walk reaches them only in the TELR_TB_SPLIT=0 mode
+        // bytes in 8-byte units 512 bytes apart (k_tb_gather) -- this generic walk reaches them only in the TELR_AB=tb_one_launch mode
         const int64_t abs_off = P.tb_off + (d_tb_interleaved(cls) ? ((off >> 3) << 9) + (off & 7) : off), line = abs_off >> 6;
         const int slot = TB_SLOTS > 1 ? (int)(line & 1) : 0;
         if ((slot ? tag1 : tag0) != line) {

@@ -75,6 +75,7 @@ struct telr_ctx {
     telr_ctx *slot1 = nullptr;            // the second range slot (a context of the same kind: own streams and scratch)
     bool pipe_nomem = false;              // two ranges in flight once ran out of device memory: later calls run one at a time
     char devname[256] = {0};
+    int n_cu = 0;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     // debug captures of the last batch (device pointers stay valid until the next call)
     int64_t dbg_na = 0; int32_t dbg_nq = 0;
     std::vector<int32_t> dbg_chain;       // 9 ints per chain
@@ -86,10 +87,40 @@ struct telr_ctx {
 #define TRY(expr) do { int _r = (expr); if (_r != TELR_OK) return _r; } while (0)
 #define TELR_SPLIT_RANGE (-100)      // internal: a batch with >= 2^31 anchors; map_range() halves it
 
-// TELR_TRACE_MEM=1: device memory at the points where the engine runs out of it or gives it back (stderr)
+// ---- environment: TWO switches carry every alternative form and every trace the engine still has (read once per process) ----------
+//   TELR_AB=tok[,tok...]     A/B forms of earlier rounds, kept because tests/test_gpu_switches.py holds each of them to the same bits:
+//                            sort64 (rocPRIM's segmented sort for every query), seed_unfused (seeding and sorting as two kernels),
+//                            sketch64 (the 64-bit sketch kernel for k <= 15 too), mz_compact (compacted minimizer arrays), no_islands
+//                            (one wave per query in every chaining call), vote_filter (table filter in the vote presets' lookups),
+//                            no_pk / no_pkw / no_pkext (int32 classes instead of the packed fills / wide fills / extensions), tb8 (byte
+//                            spill in the one-piece classes), no_tag8 (untagged two-piece cell), tb_one_launch (ONE trace-back launch
+//                            after all forward kernels), no_avx2 (scalar host packer), fasta_copy (no in-place use of the mapped file),
+//                            bam_no_populate, bam_no_twin (BAM writer: no pre-faulted mapping / CIGARs uploaded again)
+//   TELR_TRACE=tok[,tok...]  stderr traces: host (wall-clock marks of every batch's host side), mem (device memory at the points
+//                            where the engine runs out of it or gives it back), fasta (phases of telr_fasta_load)
+// The others are operational: TELR_DEBUG, TELR_HOST_THREADS, TELR_PACK_THREADS, TELR_BATCH_MBP / TELR_BATCH_KBP (range size),
+// TELR_PIPELINE (ranges in flight), TELR_SERIAL (profiling: every DP class on the main stream), TELR_TEST_PIPE_NOMEM (test hook).
+static bool env_token(const char *var, const char *tok)
+{
+    const char *e = getenv(var);
+    if (!e) return false;
+    const size_t n = strlen(tok);
+    for (const char *p = e; *p; ) {
+        const char *q = strchr(p, ',');
+        const size_t len = q ? (size_t)(q - p) : strlen(p);
+        if (len == n && !strncmp(p, tok, n)) return true;
+        if (!q) break;
+        p = q + 1;
+    }
+    return false;
+}
+static inline bool ab_on(const char *tok) { return env_token("TELR_AB", tok); }
+static inline bool trace_on(const char *tok) { return env_token("TELR_TRACE", tok); }
+
+// TELR_TRACE=mem: device memory at the points where the engine runs out of it or gives it back (stderr)
 static void mem_note(telr_ctx *ctx, const char *tag)
 {
-    static const bool on = getenv("TELR_TRACE_MEM") != nullptr;
+    static const bool on = trace_on("mem");
     if (!on) return;
     size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
     size_t own = 0, bam = 0;
@@ -135,13 +166,13 @@ template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size
 // ---------------------------------------------------------------------------------------
 // Segmented sort of 64-bit keys (segsort.hip.h): every segment of at most SEGSORT_CAP keys is sorted by ONE workgroup in
 // LDS; `any_over` (known to the caller from the anchor counts) sends the larger ones through rocPRIM afterwards.
-// TELR_SORT64=1 keeps the library sort for every segment (A/B).  out[beg[s] .. end[s]) <- sorted in[...]; src_beg (nullable)
+// TELR_AB=sort64 keeps the library sort for every segment (A/B).  out[beg[s] .. end[s]) <- sorted in[...]; src_beg (nullable)
 // gives the segments' places in `in` when they differ from their places in `out`.
 template <class P = LoadKeys>
 static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint64_t *out, const int32_t *beg, const int32_t *end, const int64_t *src_beg,
                         const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st, P prod = P())
 {
-    static const bool lib_sort = getenv("TELR_SORT64") != nullptr;
+    static const bool lib_sort = ab_on("sort64");
     if (nseg <= 0 || nkeys == 0) return TELR_OK;
     if (lib_sort) {
         if (src_beg) return TELR_E_ARG;              // the caller compacts first
@@ -153,11 +184,14 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
         return TELR_OK;
     }
     if (src_beg && any_over) return TELR_E_ARG;
-    static bool attr_set = false;            // (one flag per producer type: a function-local static of the template instance)
-    if (!attr_set) {
+    // the opt-in to more than 64 KiB of dynamic LDS belongs to the DEVICE's function object: one bit per device (and per producer
+    // type: a function-local static of the template instance); setting it twice from two host threads is harmless
+    static std::atomic<uint64_t> attr_dev{0};
+    const uint64_t dev_bit = 1ULL << (ctx->device & 63);
+    if (!(attr_dev.load(std::memory_order_acquire) & dev_bit)) {
         HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 8, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 8 * 8));
         HIPCHK(hipFuncSetAttribute((const void*)k_segsort<1024, 20, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 20 * 8));
-        attr_set = true;
+        attr_dev.fetch_or(dev_bit, std::memory_order_release);
     }
     SegSortArgs A; A.in = in; A.out = out; A.seg_beg = beg; A.seg_end = end; A.src_beg = src_beg; A.order = order; A.nseg = nseg;
     const std::string T(tag);
@@ -167,7 +201,7 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
     if (any_over) { TRY(ctx_buf_t(ctx, (T + "_fbbeg").c_str(), (size_t)nseg, &A.fb_beg)); TRY(ctx_buf_t(ctx, (T + "_fbend").c_str(), (size_t)nseg, &A.fb_end)); }
     HIPCHK(hipMemsetAsync(A.tier_cnt, 0, (SEGSORT_TIERS + 1) * 4, st));
     hipLaunchKernelGGL(k_segsort_classify, dim3((nseg + 255) / 256), dim3(256), 0, st, A);
-    const int ncu = 256;
+    const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     auto grid = [&](int resident) { return dim3((unsigned)std::min<int64_t>(nseg, (int64_t)ncu * resident * 8)); };
     // largest tiers first: their few long-running workgroups start while the device is otherwise idle
     hipLaunchKernelGGL((k_segsort<1024, 20, P>), grid(1), dim3(1024), 1024 * 20 * 8, st, A, 6, prod);
@@ -242,7 +276,7 @@ static int ctx_init(int device, bool background, telr_ctx **out)
     auto hipStreamCreate = [&](hipStream_t *st) { return background ? hipStreamCreateWithPriority(st, hipStreamDefault, prio_least) : ::hipStreamCreate(st); };
     if (const char *e = getenv("TELR_DEBUG")) ctx->debug = atoi(e);
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) { snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount); ctx->n_cu = prop.multiProcessorCount; }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < 6; ++i) if (hipEventCreate(&ctx->evk[i]) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
     for (int i = 0; i < TELR_N_STAGES; ++i) for (int j = 0; j < 2; ++j) if (hipEventCreate(&ctx->ev_st[i][j]) != hipSuccess) { delete ctx; return TELR_E_NODEVICE; }
@@ -467,7 +501,7 @@ extern "C" int telr_seqset_create(telr_ctx *ctx, int32_t n, const char *ascii, c
     std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[nchunk > 0 ? nchunk : 1]);
     for (int c = 0; c < nchunk; ++c) done[c].store(0, std::memory_order_relaxed);
     std::atomic<int> next(0);
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !getenv("TELR_NO_AVX2");
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !ab_on("no_avx2");
     int nth = (int)std::min<int64_t>(std::max(1u, std::thread::hardware_concurrency()), 16);
     if (const char *e = getenv("TELR_PACK_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) nth = v; }      // a caller that packs the next batch while the current one maps leaves cores to the mapper
     if (s->total_bases < (1 << 20)) nth = 1;
@@ -680,9 +714,9 @@ static int run_sketch(telr_ctx *ctx, const telr_seqset *s, const TileList &T, in
     if (hpc) { H.out_x = d_sx; H.out_y = d_sy; hipLaunchKernelGGL(k_sketch_hpc<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, H); }
     else {
         A.out_x = d_sx; A.out_y = d_sy;
-        if (k <= 15 && w == 10 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 9>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
-        else if (k <= 15 && w == 5 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 4>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
-        else if (k <= 15 && !getenv("TELR_SKETCH64")) hipLaunchKernelGGL((k_sketch32<2, 0>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        if (k <= 15 && w == 10 && !ab_on("sketch64")) hipLaunchKernelGGL((k_sketch32<2, 9>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        else if (k <= 15 && w == 5 && !ab_on("sketch64")) hipLaunchKernelGGL((k_sketch32<2, 4>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
+        else if (k <= 15 && !ab_on("sketch64")) hipLaunchKernelGGL((k_sketch32<2, 0>), dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
         else hipLaunchKernelGGL(k_sketch<2>, dim3(T.n), dim3(SK_THREADS), lds, ctx->stream, A);
     }
     HIPCHK(hipGetLastError());
@@ -1310,14 +1344,14 @@ static inline int cx_gap(const telr_map_opt *mo, int L)
 static inline bool pk_cx_ok(const telr_map_opt *mo, int D)
 {
     const int S = mo->cx_scale, bS = mo->b * S, aS = mo->a * S;
-    if (getenv("TELR_NO_PK") || bS > 400 || aS > 400 || mo->sc_ambi * S > 400 || mo->cx_open + mo->cx_ext_max > 320 || mo->cx_ext_max < mo->cx_ext_min || mo->cx_ext_min < 0 || mo->cx_decay < 0) return false;
+    if (ab_on("no_pk") || bS > 400 || aS > 400 || mo->sc_ambi * S > 400 || mo->cx_open + mo->cx_ext_max > 320 || mo->cx_ext_max < mo->cx_ext_min || mo->cx_ext_min < 0 || mo->cx_decay < 0) return false;
     return cx_gap(mo, D) + aS * D / 2 <= 11900;
 }
 static inline int pk_steps_limit(const telr_map_opt *mo)
 {
     // (convex cost: the single-wave packed classes re-bias their scores as they go -- kernels.hip.h, REB -- so only the constants have to fit)
     if (mo->cx_scale > 0) return pk_cx_ok(mo, 128) ? 7900 : 0;
-    if (!(mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9) || getenv("TELR_NO_PK")) return 0;
+    if (!(mo->b <= 9 && mo->a <= 4 && mo->q2 + mo->e2 <= 64 && mo->sc_ambi <= 9) || ab_on("no_pk")) return 0;
     const int by_b = 2 * (15800 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
@@ -1325,7 +1359,7 @@ static inline int pk_steps_limit(const telr_map_opt *mo)
 // same bound for the wide int16 classes (bands up to 1024 diagonals)
 static inline int pk_wide_limit(const telr_map_opt *mo)
 {
-    if (!pk_steps_limit(mo) || getenv("TELR_NO_PKW")) return 0;
+    if (!pk_steps_limit(mo) || ab_on("no_pkw")) return 0;
     if (mo->cx_scale > 0) return pk_cx_ok(mo, 256) ? 7900 : 0;          // (which of the three wide classes: pk_wide_maxd)
     const int by_b = 2 * (15800 - mo->q2 - 1024 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 32000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
@@ -1339,10 +1373,10 @@ static inline int pk_wide_maxd(const telr_map_opt *mo)
 }
 // longest z-drop extension window (m+n) the packed int16 kernel takes: scores stay inside +-16000
 // classes that spill four bits per cell (kernels.hip.h: d_tb4): the one-piece classes of the preset, when every class has its
-// own trace-back launch (the one-launch walk of TELR_TB_SPLIT=0 reads bytes); TELR_TB8=1 keeps the byte spill for A/B
+// own trace-back launch (the one-launch walk of TELR_AB=tb_one_launch reads bytes); TELR_AB=tb8 keeps the byte spill for A/B
 static inline int tb4_mask(const telr_map_opt *mo)
 {
-    static const bool off = (getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0) || getenv("TELR_TB8") != nullptr;
+    static const bool off = ab_on("tb_one_launch") || ab_on("tb8");
     if (off || !pk_steps_limit(mo) || mo->cx_scale > 0) return 0;          // (the convex cell spills plain bytes)
     const int d = d_onep_d(mo->q, mo->e, mo->q2, mo->e2);
     return (d >= 16 ? 1 : 0) | (d >= 20 ? 2 : 0);
@@ -1354,10 +1388,10 @@ static inline int tb4_steps(const telr_map_opt *mo)
     const int lim = by_b < by_a ? by_b : by_a;
     return lim > 0 ? lim : 0;
 }
-// the same for the two-piece tagged cell (scores times eight); off with the one-launch trace-back (it reads plain flags) or TELR_NO_TAG8=1
+// the same for the two-piece tagged cell (scores times eight); off with the one-launch trace-back (it reads plain flags) or TELR_AB=no_tag8
 static inline int tag8_steps(const telr_map_opt *mo)
 {
-    static const bool off = (getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0) || getenv("TELR_NO_TAG8") != nullptr;
+    static const bool off = ab_on("tb_one_launch") || ab_on("no_tag8");
     if (off || !pk_steps_limit(mo) || mo->cx_scale > 0) return 0;
     const int by_b = 2 * (1975 - mo->q2 - 128 * mo->e2) / (mo->b > 0 ? mo->b : 1) - 2, by_a = 4000 / (mo->a > 0 ? mo->a : 1) - 2;
     const int lim = by_b < by_a ? by_b : by_a;
@@ -1367,7 +1401,7 @@ static inline int tag8_steps(const telr_map_opt *mo)
 static inline int pk_ext_d(const telr_map_opt *mo) { const int D = 2 * mo->ext_band + 2; return D <= 64 ? 64 : D <= 128 ? 128 : 256; }
 static inline int pk_ext_limit(const telr_map_opt *mo)
 {
-    if (!pk_steps_limit(mo) || getenv("TELR_NO_PKEXT")) return 0;
+    if (!pk_steps_limit(mo) || ab_on("no_pkext")) return 0;
     const int D = pk_ext_d(mo);
     // (convex cost: the z-drop test runs on the re-biased row maximum + the sum of the moves, in int32 -- kernels.hip.h, REB)
     if (mo->cx_scale > 0) return mo->zdrop * mo->cx_scale <= 30000 && pk_cx_ok(mo, D) ? 7900 : 0;
@@ -1443,9 +1477,9 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     D.tb = d_tb; D.cig = *d_rawcig_io; D.res = d_res; D.dcap = 0;
     D.retry = d_retry; D.tb4 = tb4_mask(mo); D.tag8_steps = tag8_steps(mo);
     static const int CAP[5] = { 64, 128, 256, 1024, DP_DMAX };
-    // trace-back per class list, right behind the class's forward kernel on the same stream (TELR_TB_SPLIT=0: one
+    // trace-back per class list, right behind the class's forward kernel on the same stream (TELR_AB=tb_one_launch: one
     // trace-back launch over all problems after every forward kernel has finished)
-    static const bool tb_split = !(getenv("TELR_TB_SPLIT") && atoi(getenv("TELR_TB_SPLIT")) == 0);
+    static const bool tb_split = !ab_on("tb_one_launch");
     // wave table of the packed launch (all packed classes in one launch, waves ordered by decreasing cost); built
     // before the tail classes are started so that these two small launches do not queue behind them
     int nw = 0; uint32_t *d_wv2 = nullptr;
@@ -1504,7 +1538,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         if (tb_split) {
             // few long problems: one wave walks one problem (latency); many (extensions, or a tail class with thousands of problems
             // on a repeat-rich genome): one lane per problem (throughput)
-            static const int tbw_max = [] { const char *e = getenv("TELR_TBW_MAX"); return e ? atoi(e) : 2048; }();
+            const int tbw_max = 2048;
             if (c == 18 || c == 23 || c == 24 || c == 0 || nl > tbw_max) hipLaunchKernelGGL(k_traceback, dim3((nl + 63) / 64), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
             else hipLaunchKernelGGL(k_traceback_w, dim3(nl), dim3(64), 0, s2, d_probs, d_res, nl, d_tb, *d_rawcig_io, d_retry, D.list);
             HIPCHK(hipGetLastError());
@@ -1513,7 +1547,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     D.dcap = 0;
     // packed classes: the wave table is cut into chunks; the trace-back of a chunk (memory bound) runs on its own
     // stream underneath the forward pass (issue bound) of the next chunk
-    static const int pk_chunks = [] { const char *e = getenv("TELR_PK_CHUNKS"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+    const int pk_chunks = 1;
     const bool tb_over = tb_split && !serial && nw > 0;
     if (primary) HIPCHK(hipEventRecord(ctx->evk[5], st));
     if (primary && nw > 0) ++ctx->pk_launches;
@@ -1562,10 +1596,10 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     return TELR_OK;
 }
 
-// TELR_TRACE_HOST=1: wall-clock marks of the host side of every batch on stderr (where does a range wait for the host?)
+// TELR_TRACE=host: wall-clock marks of the host side of every batch on stderr (where does a range wait for the host?)
 struct HostTrace {
     bool on; const char *tag; std::chrono::steady_clock::time_point t0, last;
-    HostTrace(const char *t) : tag(t) { static const bool e = getenv("TELR_TRACE_HOST") != nullptr; on = e; t0 = last = std::chrono::steady_clock::now(); }
+    HostTrace(const char *t) : tag(t) { static const bool e = trace_on("host"); on = e; t0 = last = std::chrono::steady_clock::now(); }
     void mark(const char *what) {
         if (!on) return;
         auto now = std::chrono::steady_clock::now();
@@ -1600,8 +1634,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     StageTimer t_sk(ctx, ST_SKETCH, true);
     TileList &T = ctx_tiles(ctx);
     uint64_t *d_mx; uint32_t *d_my; int32_t *d_toff; int32_t nmz = 0;
-    // the seeding kernels read the sketch kernel's staging arrays in place (no compaction copy); TELR_MZ_COMPACT=1 for A/B
-    static const bool mz_compact_env = getenv("TELR_MZ_COMPACT") != nullptr;
+    // the seeding kernels read the sketch kernel's staging arrays in place (no compaction copy); TELR_AB=mz_compact for A/B
+    static const bool mz_compact_env = ab_on("mz_compact");
     // sub-read voting (spec 3.10) applies to all-vs-all calls only; its kernel reads the compacted minimizer arrays
     const bool vote = mo->vote_len > 0 && !d_qtarget && !(mo->flags & TELR_MF_PER_TARGET);
     const bool mz_staged = !ix->io.is_hpc && !mz_compact_env && !vote;
@@ -1652,7 +1686,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         int64_t *d_qhits; int32_t *d_qcnt;
         TRY(ctx_buf_t(ctx, "vote_qhits", (size_t)nq + 2, &d_qhits)); TRY(ctx_buf_t(ctx, "vote_qsoff", (size_t)nq + 2, &d_qsoff)); TRY(ctx_buf_t(ctx, "vote_qcnt", (size_t)nq + 2, &d_qcnt));
         if (nmz) {
-            static const bool always_filter = getenv("TELR_VOTE_FILTER") != nullptr;
+            static const bool always_filter = ab_on("vote_filter");
             if (k <= 13 && !always_filter) hipLaunchKernelGGL(k_vote_lookup<false>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
             else hipLaunchKernelGGL(k_vote_lookup<true>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
         }
@@ -1665,7 +1699,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY(ctx_buf_t(ctx, "vote_stage", (size_t)nhits + 1, &d_stage));
         VA.q_soff = d_qsoff; VA.stage = d_stage; VA.q_cnt = d_qcnt;
         // queries whose hits fit 16-bit vote counters (nearly all) with the half-size table, the others with 32-bit counters
-        static const int64_t lim16 = getenv("TELR_VOTE_T16_LIMIT") ? atoll(getenv("TELR_VOTE_T16_LIMIT")) : 65535;
+        const int64_t lim16 = 65535;
         hipLaunchKernelGGL(k_seed_vote<true>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
         hipLaunchKernelGGL(k_seed_vote<false>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
         d_cnt = d_qcnt; d_aoff = d_qaoff; ncnt = (size_t)nq; d_qcnt_v = d_qcnt;
@@ -1695,19 +1729,19 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipStreamSynchronize(st));
     if (na64 >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
     ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
-    static const bool lib_sort = getenv("TELR_SORT64") != nullptr;      // A/B: rocPRIM's segmented radix sort for every query
+    static const bool lib_sort = ab_on("sort64");      // A/B: rocPRIM's segmented radix sort for every query
     const bool any_over = n_over > 0;
     uint64_t *d_keys, *d_skeys;
-    static const bool seed_unfused_env = getenv("TELR_SEED_UNFUSED") != nullptr;
+    static const bool seed_unfused_env = ab_on("seed_unfused");
     TRY(ctx_buf_t(ctx, "keys", (!lib_sort && !any_over && (vote || !seed_unfused_env)) ? (size_t)1 : (size_t)na, &d_keys));       // only the two-step forms need the unsorted keys in memory
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
     S.mz_aoff = d_maoff; S.keys = d_keys;
     // sub-read voting: the LDS sort reads the survivors from the staging pieces in place; only the library sort needs them dense
     const bool vote_in_place = vote && !lib_sort && !any_over;
     // The anchor keys are MADE inside the sort (SeedProducer: the seeding routine writes a query's keys straight into the sorting
-    // workgroup's LDS), so unsorted keys never exist in HBM; TELR_SEED_UNFUSED=1 keeps the two-step form for A/B, and a range with a
+    // workgroup's LDS), so unsorted keys never exist in HBM; TELR_AB=seed_unfused keeps the two-step form for A/B, and a range with a
     // query above the LDS limit takes it too (its library sort reads the keys from memory)
-    static const bool seed_unfused = getenv("TELR_SEED_UNFUSED") != nullptr;
+    static const bool seed_unfused = ab_on("seed_unfused");
     const bool seed_fused = !vote && !lib_sort && !any_over && !seed_unfused;
     S.lds_keys = nullptr; S.lds_base = 0;
     if (vote) { if (!vote_in_place) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, d_keys); }
@@ -1733,7 +1767,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     const int Rr = mo->chain_lookback / 64;
 #define CHAIN_LAUNCH(RR, SK) hipLaunchKernelGGL((k_chain<RR, SK>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder)
     const bool skip = co.chain_skip_q8 != 0;
-    static const bool no_islands = getenv("TELR_CHAIN_NO_ISLANDS") != nullptr;       // A/B: one wave per query whatever the call's shape
+    static const bool no_islands = ab_on("no_islands");       // A/B: one wave per query whatever the call's shape
     if (nq <= CHAIN_ISL_NQ && na > 0 && !no_islands) {
         // few queries: chain island by island (kernels.hip.h: ISLANDS) -- same f and p, thousands of waves instead of nq
         int32_t *d_head, *d_rank, *d_ioff, *d_ipd;

@@ -72,7 +72,7 @@ class FastaFile:
         h = C.c_void_p()
         rc = self.L.telr_fasta_load(str(path).encode(), C.byref(h))
         if rc != 0:
-            raise _lib.TelrError("telr_fasta_load(%s): %s" % (path, self.L.telr_strerror(rc).decode()))
+            raise _lib.TelrError("telr_fasta_load(%s): %s" % (path, self.L.telr_strerror(rc).decode()), code=rc)
         self.h = h
         self.n = int(self.L.telr_fasta_count(h))
         nb = int(self.L.telr_fasta_extent(h))        # the packed bases, or the whole mapped file when its sequences are used in place
@@ -115,6 +115,10 @@ def load(path):
     from . import _lib
     try:
         return FastaFile(path)
-    except _lib.TelrError:
-        # a layout the C parser refuses (multi-line FASTQ, a record that does not start with '>' / '@'): the Python reader decides
+    except _lib.TelrError as e:
+        # a layout the C parser refuses (multi-line FASTQ, a record that does not start with '>' / '@': TELR_E_ARG = -3): the Python
+        # reader decides.  Anything else -- a record too long for the engine (TELR_E_RANGE), an I/O failure, no memory -- is the caller's
+        # to see: the slow path would only fail later with an unrelated message.
+        if getattr(e, "code", None) != -3:
+            raise
         return None

@@ -6,6 +6,8 @@ TELR_te.py:899 -> TELR_liftover.py:254-264.  Parameter values follow the minimap
 manual as recorded in SURVEY.md 8(a) [recall]; `telr_preset()` in the C library returns
 the same numbers (tests/test_abi.py keeps them in lock-step).
 """
+import threading
+
 from ._abi import IdxOpt, MapOpt, MF_CIGAR
 
 
@@ -15,6 +17,7 @@ def _gap_q8(k, scale=0.8):
 
 
 _OVERRIDES = {}          # field -> value laid over every preset while `override(...)` is active (experiments, A/B legs of bench.py)
+_OV_LOCK = threading.Lock()      # preset() is called from the S6 worker thread too: the table is swapped, never edited in place
 
 
 class override:
@@ -24,11 +27,16 @@ class override:
         self.fields = fields
 
     def __enter__(self):
-        self.saved = dict(_OVERRIDES); _OVERRIDES.update(self.fields)
+        global _OVERRIDES
+        with _OV_LOCK:
+            self.saved = _OVERRIDES
+            _OVERRIDES = dict(self.saved, **self.fields)         # a NEW dict: a reader holds either the old table or the new one
         return self
 
     def __exit__(self, *exc):
-        _OVERRIDES.clear(); _OVERRIDES.update(self.saved)
+        global _OVERRIDES
+        with _OV_LOCK:
+            _OVERRIDES = self.saved
         return False
 
 
@@ -86,6 +94,6 @@ def preset(name):
     else:
         raise ValueError("unknown preset %r" % (name,))
     mo.chain_gap_q8 = _gap_q8(io.k)
-    for f, v in _OVERRIDES.items():
+    for f, v in _OVERRIDES.items():          # (one reference read: see override)
         setattr(mo, f, v)
     return io, mo

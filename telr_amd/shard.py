@@ -7,7 +7,7 @@
   fixed-capacity blocks merges them (RCCL over xGMI on GPUs, `backend="nccl"`; gloo in the CPU tests).
   Variable-length payloads (sequences, CIGARs) stay on the owning rank;
 * between the two (only when the reads themselves are sharded): the window reads of a locus sit on whichever
-  ranks mapped them and travel to the locus' owner in one all-to-all (`exchange_window_reads`).
+  ranks mapped them and travel to the locus' owner in one all-to-all (`exchange_window_reads_packed`).
 The reference's only parallelism on this path is `multiprocessing.Pool(processes=thread)` over loci
 (src/telr/TELR_assembly.py:70-71, TELR_te.py:644-646, TELR_liftover.py:1049-1052).
 """
@@ -79,72 +79,6 @@ def all_gather_rows(rows, dist=None, device=None, capacity=None):
     return np.sort(allrows, order="locus_id")
 
 
-READ_HDR = np.dtype([("locus_id", np.int32), ("read_id", np.int32), ("length", np.int32), ("pad", np.int32)])
-
-
-def exchange_window_reads(locus_id, read_id, dest, reads, read_index, dist=None, device=None):
-    """The stage-1 -> per-locus hand-off when reads are sharded over ranks: every rank holds the window reads of ALL loci
-    that fall in ITS read shard and sends each to the rank that owns the locus.  (The reference does this through the
-    shared file system: pysam.fetch on the stage-1 BAM + seqtk over the read file, TELR_assembly.py:384-462.)
-
-    One entry per (locus, read) pair to send: locus_id[i], read_id[i] (global read id), dest[i] (owner rank of the locus),
-    read_index[i] = index of the read in `reads` = (buf, off, len), this rank's read set on the host.
-    -> (locus ids, read ids, (buf, off, len)) of the pairs this rank received, sorted by (locus id, read id).
-    Two all-to-all collectives: the byte counts, then one buffer per peer [n][n x READ_HDR][bases]."""
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    locus_id = np.asarray(locus_id, np.int64); read_id = np.asarray(read_id, np.int64); dest = np.asarray(dest, np.int64)
-    read_index = np.asarray(read_index, np.int64)
-    rbuf, roff, rln = reads
-    roff = np.asarray(roff, np.int64); rln = np.asarray(rln, np.int64)
-
-    def pack(sel):
-        """[n][headers][bases] of the entries `sel`"""
-        hdr = np.zeros(len(sel), READ_HDR)
-        hdr["locus_id"] = locus_id[sel]; hdr["read_id"] = read_id[sel]; hdr["length"] = rln[read_index[sel]]
-        # the bases of all selected reads in one gather: flat index = start of the read, repeated, + position inside it
-        ri = read_index[sel]; ln = rln[ri]
-        tot = int(ln.sum())
-        if tot:
-            ends = np.cumsum(ln)
-            flat = np.repeat(roff[ri] - (ends - ln), ln) + np.arange(tot, dtype=np.int64)
-            bases = np.asarray(rbuf)[flat]
-        else:
-            bases = np.zeros(0, np.uint8)
-        return np.concatenate([np.frombuffer(np.int64(len(sel)).tobytes(), np.uint8), hdr.view(np.uint8).reshape(-1), bases])
-
-    def unpack(raw, sizes):
-        """-> header array and base offsets (into raw) of all reads of the concatenated per-peer buffers"""
-        hdrs, offs, o = [], [], 0
-        for sz in sizes:
-            b = raw[o:o + sz]
-            n = int(np.frombuffer(b[:8].tobytes(), np.int64)[0]) if sz >= 8 else 0
-            h = np.frombuffer(b[8:8 + n * READ_HDR.itemsize].tobytes(), READ_HDR)
-            start = o + 8 + n * READ_HDR.itemsize
-            ln = h["length"].astype(np.int64)
-            hdrs.append(h); offs.append(start + np.cumsum(ln) - ln)
-            o += sz
-        h = np.concatenate(hdrs) if hdrs else np.zeros(0, READ_HDR)
-        return h, (np.concatenate(offs) if offs else np.zeros(0, np.int64))
-
-    if world == 1:
-        raw = pack(np.arange(len(dest))); sizes = [len(raw)]
-    else:
-        import torch
-        bufs = [pack(np.nonzero(dest == d)[0]) for d in range(world)]
-        dev = device if device is not None else "cpu"
-        n_send = torch.tensor([len(b) for b in bufs], dtype=torch.int64, device=dev)
-        n_recv = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_to_all_single(n_recv, n_send)
-        sizes = [int(x) for x in n_recv.cpu().tolist()]
-        send = torch.from_numpy(np.concatenate(bufs)).to(dev)
-        recv = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
-        dist.all_to_all_single(recv, send, output_split_sizes=sizes, input_split_sizes=[len(b) for b in bufs])
-        raw = recv.cpu().numpy()
-    h, off = unpack(raw, sizes)
-    order = np.lexsort((h["read_id"], h["locus_id"]))
-    return h["locus_id"][order].astype(np.int64), h["read_id"][order].astype(np.int64), (raw, off[order], h["length"][order].astype(np.int32))
-
-
 def packed_words(lengths):
     """words of the packed form per sequence: (2-bit words, mask words) -- every sequence starts on a 64-base boundary"""
     blocks = (np.asarray(lengths, np.int64) + 63) // 64
@@ -152,7 +86,9 @@ def packed_words(lengths):
 
 
 def exchange_window_reads_packed(locus_id, read_id, dest, lengths, gather_packed, dist=None, device=None, timings=None):
-    """`exchange_window_reads` without ever leaving the device or unpacking a base (round 4): the (locus, read) pairs are put in
+    """The stage-1 -> per-locus hand-off when reads are sharded over ranks, without ever leaving the device or unpacking a base (round 4;
+    the ASCII form of rounds 1-3 was deleted in round 5; the reference does this through the shared file system: pysam.fetch on the
+    stage-1 BAM + seqtk over the read file, TELR_assembly.py:384-462): the (locus, read) pairs are put in
     destination order, `gather_packed(order)` hands back the packed words of the reads in that order as two torch int32 tensors
     (the product passes SeqSet.subset(...).packed(): one gather kernel over the resident 2-bit read set; 3 bits per base on the
     wire instead of 8), and TWO collectives move them: the per-peer counts (pairs, words), then ONE all-to-all of int32 words,
@@ -249,70 +185,75 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
     import time
     import torch
     t0 = time.time()
-    rank = dist.get_rank()
-    alns = np.ascontiguousarray(alns)
-    nq = len(lengths)
-    lengths = np.asarray(lengths, np.int32); gid = np.asarray(gid, np.int64)
-    qid = alns["qid"].astype(np.int64)
-    rec_dest = np.asarray(rec_dest, np.int64)
-    rstart = np.searchsorted(qid, np.arange(nq)); rcount = np.searchsorted(qid, np.arange(nq), side="right") - rstart
-    # (destination, read) pairs: every slice one of the read's records lies in; reads without records -> the last rank
-    pair = np.unique(np.concatenate([rec_dest * nq + qid, (world - 1) * nq + np.nonzero(rcount == 0)[0]]))       # sorted by (dest, read) = (dest, gid)
-    p_dest = pair // nq; p_read = pair % nq
-    n_to = np.bincount(p_dest, minlength=world).astype(np.int64)
-    cuts = np.concatenate([[0], np.cumsum(n_to)])
-    # the records that travel with every pair
-    p_nrec = rcount[p_read]
-    tot_rec = int(p_nrec.sum())
-    pr_off = np.cumsum(p_nrec) - p_nrec
-    ridx = np.repeat(rstart[p_read] - pr_off, p_nrec) + np.arange(tot_rec, dtype=np.int64)          # record index per sent record
-    r_pair = np.repeat(np.arange(len(pair)), p_nrec)
-    s_alns = alns[ridx].copy()
-    s_emit = (rec_dest[ridx] == p_dest[r_pair]).astype(np.uint8)
-    s_alns["qid"] = (r_pair - cuts[p_dest[r_pair]]).astype(np.int32)                                # index of the read inside its destination block
-    rec_cuts = np.concatenate([[0], np.cumsum(np.bincount(p_dest[r_pair], minlength=world))]).astype(np.int64)
-    ncig = s_alns["n_cigar"].astype(np.int64)
-    c_off_all = np.cumsum(ncig) - ncig
-    cig_cuts = np.concatenate([[0], np.cumsum(np.bincount(p_dest[r_pair], weights=ncig, minlength=world))]).astype(np.int64)       # CIGAR words per destination block
-    old_off = alns["cigar_off"].astype(np.int64)[ridx]
-    s_alns["cigar_off"] = (c_off_all - cig_cuts[p_dest[r_pair]]).astype(s_alns["cigar_off"].dtype) if tot_rec else s_alns["cigar_off"]
-    dev = cig_t.device
-    _sub(timings, "pack_host_index_s", t0, dev); t1 = time.time()
-    # the CIGAR words of the sent records, gathered on the device
-    tot_cig = int(ncig.sum())
-    if tot_cig:
-        src = torch.from_numpy(np.ascontiguousarray(old_off - c_off_all)).to(dev)
-        widx = torch.repeat_interleave(src, torch.from_numpy(ncig).to(dev)) + torch.arange(tot_cig, device=dev, dtype=torch.int64)
-        s_cig = cig_t.view(torch.int32)[widx]
-    else:
-        s_cig = torch.zeros(0, dtype=torch.int32, device=dev)
-    _sub(timings, "pack_cigar_gather_s", t1, dev); t1 = time.time()
-    seq2, nmask = gather_packed(p_read)
-    _sub(timings, "pack_read_subset_s", t1, dev)
-    w2, _ = packed_words(lengths[p_read])
-    w2_cuts = np.concatenate([[0], np.cumsum(w2)])[cuts]
-    _sub(timings, "pack_s", t0, dev)
-    t0 = time.time()
-    # per destination: [records][emit][gid][length][names][CIGAR words][2-bit words][mask words], every section padded to 8 bytes
-    sec = np.zeros((world, 8), np.int64)
-    parts = []
-    for d in range(world):
-        a = s_alns[rec_cuts[d]:rec_cuts[d + 1]]; e = s_emit[rec_cuts[d]:rec_cuts[d + 1]]
-        rd = p_read[cuts[d]:cuts[d + 1]]
-        nb = "\n".join(names[i] for i in rd).encode()
-        host = [a.view(np.uint8).reshape(-1), e, gid[rd].view(np.uint8).reshape(-1), lengths[rd].view(np.uint8).reshape(-1), np.frombuffer(nb, np.uint8)]
-        devp = [s_cig[cig_cuts[d]:cig_cuts[d + 1]], seq2[w2_cuts[d]:w2_cuts[d + 1]], nmask[w2_cuts[d] // 2:w2_cuts[d + 1] // 2]]
-        sec[d, :5] = [len(x) for x in host]; sec[d, 5:] = [int(x.numel()) * 4 for x in devp]
-        hb = np.zeros(sum(_pad8(len(x)) for x in host), np.uint8); o = 0
-        for x in host:
-            hb[o:o + len(x)] = x; o += _pad8(len(x))
-        parts.append(torch.from_numpy(hb).to(dev))
-        for x in devp:
-            parts.append(x.contiguous().view(torch.uint8))
-            if (x.numel() * 4) % 8:
-                parts.append(torch.zeros(4, dtype=torch.uint8, device=dev))
-    send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
-    _sub(timings, "payload_build_s", t0, dev)
+    err = None
+    try:
+        rank = dist.get_rank()
+        alns = np.ascontiguousarray(alns)
+        nq = len(lengths)
+        lengths = np.asarray(lengths, np.int32); gid = np.asarray(gid, np.int64)
+        qid = alns["qid"].astype(np.int64)
+        rec_dest = np.asarray(rec_dest, np.int64)
+        rstart = np.searchsorted(qid, np.arange(nq)); rcount = np.searchsorted(qid, np.arange(nq), side="right") - rstart
+        # (destination, read) pairs: every slice one of the read's records lies in; reads without records -> the last rank
+        pair = np.unique(np.concatenate([rec_dest * nq + qid, (world - 1) * nq + np.nonzero(rcount == 0)[0]]))       # sorted by (dest, read) = (dest, gid)
+        p_dest = pair // nq; p_read = pair % nq
+        n_to = np.bincount(p_dest, minlength=world).astype(np.int64)
+        cuts = np.concatenate([[0], np.cumsum(n_to)])
+        # the records that travel with every pair
+        p_nrec = rcount[p_read]
+        tot_rec = int(p_nrec.sum())
+        pr_off = np.cumsum(p_nrec) - p_nrec
+        ridx = np.repeat(rstart[p_read] - pr_off, p_nrec) + np.arange(tot_rec, dtype=np.int64)          # record index per sent record
+        r_pair = np.repeat(np.arange(len(pair)), p_nrec)
+        s_alns = alns[ridx].copy()
+        s_emit = (rec_dest[ridx] == p_dest[r_pair]).astype(np.uint8)
+        s_alns["qid"] = (r_pair - cuts[p_dest[r_pair]]).astype(np.int32)                                # index of the read inside its destination block
+        rec_cuts = np.concatenate([[0], np.cumsum(np.bincount(p_dest[r_pair], minlength=world))]).astype(np.int64)
+        ncig = s_alns["n_cigar"].astype(np.int64)
+        c_off_all = np.cumsum(ncig) - ncig
+        cig_cuts = np.concatenate([[0], np.cumsum(np.bincount(p_dest[r_pair], weights=ncig, minlength=world))]).astype(np.int64)       # CIGAR words per destination block
+        old_off = alns["cigar_off"].astype(np.int64)[ridx]
+        s_alns["cigar_off"] = (c_off_all - cig_cuts[p_dest[r_pair]]).astype(s_alns["cigar_off"].dtype) if tot_rec else s_alns["cigar_off"]
+        dev = cig_t.device
+        _sub(timings, "pack_host_index_s", t0, dev); t1 = time.time()
+        # the CIGAR words of the sent records, gathered on the device
+        tot_cig = int(ncig.sum())
+        if tot_cig:
+            src = torch.from_numpy(np.ascontiguousarray(old_off - c_off_all)).to(dev)
+            widx = torch.repeat_interleave(src, torch.from_numpy(ncig).to(dev)) + torch.arange(tot_cig, device=dev, dtype=torch.int64)
+            s_cig = cig_t.view(torch.int32)[widx]
+        else:
+            s_cig = torch.zeros(0, dtype=torch.int32, device=dev)
+        _sub(timings, "pack_cigar_gather_s", t1, dev); t1 = time.time()
+        seq2, nmask = gather_packed(p_read)
+        _sub(timings, "pack_read_subset_s", t1, dev)
+        w2, _ = packed_words(lengths[p_read])
+        w2_cuts = np.concatenate([[0], np.cumsum(w2)])[cuts]
+        _sub(timings, "pack_s", t0, dev)
+        t0 = time.time()
+        # per destination: [records][emit][gid][length][names][CIGAR words][2-bit words][mask words], every section padded to 8 bytes
+        sec = np.zeros((world, 8), np.int64)
+        parts = []
+        for d in range(world):
+            a = s_alns[rec_cuts[d]:rec_cuts[d + 1]]; e = s_emit[rec_cuts[d]:rec_cuts[d + 1]]
+            rd = p_read[cuts[d]:cuts[d + 1]]
+            nb = "\n".join(names[i] for i in rd).encode()
+            host = [a.view(np.uint8).reshape(-1), e, gid[rd].view(np.uint8).reshape(-1), lengths[rd].view(np.uint8).reshape(-1), np.frombuffer(nb, np.uint8)]
+            devp = [s_cig[cig_cuts[d]:cig_cuts[d + 1]], seq2[w2_cuts[d]:w2_cuts[d + 1]], nmask[w2_cuts[d] // 2:w2_cuts[d + 1] // 2]]
+            sec[d, :5] = [len(x) for x in host]; sec[d, 5:] = [int(x.numel()) * 4 for x in devp]
+            hb = np.zeros(sum(_pad8(len(x)) for x in host), np.uint8); o = 0
+            for x in host:
+                hb[o:o + len(x)] = x; o += _pad8(len(x))
+            parts.append(torch.from_numpy(hb).to(dev))
+            for x in devp:
+                parts.append(x.contiguous().view(torch.uint8))
+                if (x.numel() * 4) % 8:
+                    parts.append(torch.zeros(4, dtype=torch.uint8, device=dev))
+        send = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+        _sub(timings, "payload_build_s", t0, dev)
+    except Exception as e:          # (out of memory while packing, a bad index ...): the peers must hear of it before they enter the all-to-all
+        err = e
+    _agree(dist, wire, err, "packing the records and reads")
     in_split = [int(sum(_pad8(v) for v in sec[d])) for d in range(world)]
     st = torch.from_numpy(sec.reshape(-1).copy()).to(wire); rs = torch.empty_like(st)
     dist.all_to_all_single(rs, st)
@@ -325,48 +266,67 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
         timings["collective_s"] = timings.get("collective_s", 0.0) + time.time() - t0
         timings["bytes_sent"] = int(sum(in_split)) - in_split[rank]
     t0 = time.time()
-    g_alns, g_emit, g_gid, g_len, g_names, g_cig, g_s2, g_sn = [], [], [], [], [], [], [], []
-    o = 0; q0 = 0; c0 = 0
-    for p_ in range(world):
-        v = rsec[p_]; pos = [o]
-        for x in v:
-            pos.append(pos[-1] + _pad8(x))
-        host = recv[pos[0]:pos[5]].cpu().numpy()
-        h0 = pos[0]
-        a = np.frombuffer(host[pos[0] - h0:pos[0] - h0 + v[0]].tobytes(), dtype=alns.dtype).copy()
-        a["qid"] += q0; a["cigar_off"] += c0
-        ln = np.frombuffer(host[pos[3] - h0:pos[3] - h0 + v[3]].tobytes(), np.int32)
-        g_alns.append(a); g_emit.append(host[pos[1] - h0:pos[1] - h0 + v[1]].copy())
-        g_gid.append(np.frombuffer(host[pos[2] - h0:pos[2] - h0 + v[2]].tobytes(), np.int64)); g_len.append(ln)
-        g_names += host[pos[4] - h0:pos[4] - h0 + v[4]].tobytes().decode().split("\n") if len(ln) else []
-        g_cig.append(recv[pos[5]:pos[5] + v[5]].view(torch.int32)); g_s2.append(recv[pos[6]:pos[6] + v[6]].view(torch.int32)); g_sn.append(recv[pos[7]:pos[7] + v[7]].view(torch.int32))
-        q0 += len(ln); c0 += int(v[5]) // 4
-        o = pos[8]
-    a_all = np.concatenate(g_alns); e_all = np.concatenate(g_emit); gid_all = np.concatenate(g_gid); len_all = np.concatenate(g_len)
-    cig_all = torch.cat(g_cig); s2 = torch.cat(g_s2); sn = torch.cat(g_sn)
-    _sub(timings, "unpack_parse_s", t0, dev)
-    t1 = time.time()
-    # reads into ascending job order (ties of the coordinate sort are broken by it): a permutation of the packed pieces on the device
-    order = np.argsort(gid_all, kind="stable")
-    if len(order) and not (order == np.arange(len(order))).all():
-        w2a, _ = packed_words(len_all)
-        st2 = np.cumsum(w2a) - w2a
-        src = torch.from_numpy(np.ascontiguousarray(st2[order] - (np.cumsum(w2a[order]) - w2a[order]))).to(dev)
-        cnt = torch.from_numpy(np.ascontiguousarray(w2a[order])).to(dev)
-        tot2 = int(w2a.sum())
-        i2 = torch.repeat_interleave(src, cnt) + torch.arange(tot2, device=dev, dtype=torch.int64)
-        s2 = s2[i2]
-        half = torch.repeat_interleave(src // 2, cnt // 2) + torch.arange(tot2 // 2, device=dev, dtype=torch.int64)
-        sn = sn[half]
-        place = np.empty(len(order), np.int64); place[order] = np.arange(len(order))
-        a_all["qid"] = place[a_all["qid"]]
-        ro = np.argsort(a_all["qid"], kind="stable")
-        a_all = a_all[ro]; e_all = e_all[ro]
-        len_all = len_all[order]; gid_all = gid_all[order]; g_names = [g_names[i] for i in order]
-    _sub(timings, "unpack_reorder_s", t1, dev)
-    if timings is not None:
-        timings["unpack_s"] = timings.get("unpack_s", 0.0) + time.time() - t0
+    err = None
+    try:
+        g_alns, g_emit, g_gid, g_len, g_names, g_cig, g_s2, g_sn = [], [], [], [], [], [], [], []
+        o = 0; q0 = 0; c0 = 0
+        for p_ in range(world):
+            v = rsec[p_]; pos = [o]
+            for x in v:
+                pos.append(pos[-1] + _pad8(x))
+            host = recv[pos[0]:pos[5]].cpu().numpy()
+            h0 = pos[0]
+            a = np.frombuffer(host[pos[0] - h0:pos[0] - h0 + v[0]].tobytes(), dtype=alns.dtype).copy()
+            a["qid"] += q0; a["cigar_off"] += c0
+            ln = np.frombuffer(host[pos[3] - h0:pos[3] - h0 + v[3]].tobytes(), np.int32)
+            g_alns.append(a); g_emit.append(host[pos[1] - h0:pos[1] - h0 + v[1]].copy())
+            g_gid.append(np.frombuffer(host[pos[2] - h0:pos[2] - h0 + v[2]].tobytes(), np.int64)); g_len.append(ln)
+            g_names += host[pos[4] - h0:pos[4] - h0 + v[4]].tobytes().decode().split("\n") if len(ln) else []
+            g_cig.append(recv[pos[5]:pos[5] + v[5]].view(torch.int32)); g_s2.append(recv[pos[6]:pos[6] + v[6]].view(torch.int32)); g_sn.append(recv[pos[7]:pos[7] + v[7]].view(torch.int32))
+            q0 += len(ln); c0 += int(v[5]) // 4
+            o = pos[8]
+        a_all = np.concatenate(g_alns); e_all = np.concatenate(g_emit); gid_all = np.concatenate(g_gid); len_all = np.concatenate(g_len)
+        cig_all = torch.cat(g_cig); s2 = torch.cat(g_s2); sn = torch.cat(g_sn)
+        _sub(timings, "unpack_parse_s", t0, dev)
+        t1 = time.time()
+        # reads into ascending job order (ties of the coordinate sort are broken by it): a permutation of the packed pieces on the device
+        order = np.argsort(gid_all, kind="stable")
+        if len(order) and not (order == np.arange(len(order))).all():
+            w2a, _ = packed_words(len_all)
+            st2 = np.cumsum(w2a) - w2a
+            src = torch.from_numpy(np.ascontiguousarray(st2[order] - (np.cumsum(w2a[order]) - w2a[order]))).to(dev)
+            cnt = torch.from_numpy(np.ascontiguousarray(w2a[order])).to(dev)
+            tot2 = int(w2a.sum())
+            i2 = torch.repeat_interleave(src, cnt) + torch.arange(tot2, device=dev, dtype=torch.int64)
+            s2 = s2[i2]
+            half = torch.repeat_interleave(src // 2, cnt // 2) + torch.arange(tot2 // 2, device=dev, dtype=torch.int64)
+            sn = sn[half]
+            place = np.empty(len(order), np.int64); place[order] = np.arange(len(order))
+            a_all["qid"] = place[a_all["qid"]]
+            ro = np.argsort(a_all["qid"], kind="stable")
+            a_all = a_all[ro]; e_all = e_all[ro]
+            len_all = len_all[order]; gid_all = gid_all[order]; g_names = [g_names[i] for i in order]
+        _sub(timings, "unpack_reorder_s", t1, dev)
+        if timings is not None:
+            timings["unpack_s"] = timings.get("unpack_s", 0.0) + time.time() - t0
+    except Exception as e:          # (no room for the re-ordered copies, ...)
+        err = e
+    _agree(dist, wire, err, "unpacking the received records and reads")
     return dict(alns=a_all, emit=e_all, cig=cig_all, lengths=len_all, names=g_names, gid=gid_all, seq2=s2, nmask=sn)
+
+
+class JobBamError(RuntimeError):
+    """raised on EVERY rank when any rank failed inside a collective section of write_job_bam"""
+
+
+def _agree(dist, wire, err, what):
+    """One all-reduce(MAX) of an ok / failed flag: every rank leaves here the same way.  A rank that fails between two collectives
+    must not simply unwind -- its peers would block in the next all-gather / all-to-all for ever."""
+    import torch
+    f = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=wire)
+    dist.all_reduce(f, op=dist.ReduceOp.MAX)
+    if int(f.item()):
+        raise JobBamError("write_job_bam: %s failed on %s" % (what, "this rank: %s: %s" % (type(err).__name__, err) if err is not None else "another rank"))
 
 
 def _sub(timings, key, t0, dev=None):
@@ -410,68 +370,115 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
     split = stage1_splitters(keys, world, dist, wire)
     dest = np.searchsorted(split, keys, side="right")
     _sub(tm, "partition_splitters_s", t1, dev); t1 = time.time()
-    cig_t = torch.from_numpy(np.ascontiguousarray(cigars, dtype=np.uint32).view(np.int32)).to(dev)
-    _sub(tm, "partition_cigar_upload_s", t1, dev)
     held = []
+    seg = jr = jq = None
+    ok = False
+    try:
+        err = None; cig_t = None
+        try:
+            cig_t = torch.from_numpy(np.ascontiguousarray(cigars, dtype=np.uint32).view(np.int32)).to(dev)
+        except Exception as e:
+            err = e
+        _agree(dist, wire, err, "uploading the CIGAR words")
+        _sub(tm, "partition_cigar_upload_s", t1, dev)
 
-    def gather_packed(idx):
-        sub = read_set.subset(np.asarray(idx, np.int32)); held.append(sub)
-        return sub.packed()
-    tm["partition_s"] = time.time() - t0
-    got = exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, dest, world, dist, wire, timings=tm)
-    for sub in held:
-        sub.free()
-    del cig_t
-    t0 = time.time()
-    jq = SeqSet.from_packed(eng, got["lengths"], got["seq2"], got["nmask"])
-    _sub(tm, "slice_from_packed_s", t0, dev); t1 = time.time()
-    jr = ix.result_from_device_cigars(got["alns"], got["cig"])
-    _sub(tm, "slice_result_s", t1, dev); t1 = time.time()
-    got["seq2"] = got["nmask"] = got["cig"] = None          # the library holds its own copies now: torch's cache goes back to the device for the writer
-    if dev.type == "cuda":
-        torch.cuda.empty_cache()
-    seg = ix.write_bam_slice(jr, jq, ix._cstr_array(got["names"]), tnames, got["emit"], with_header=rank == 0, unmapped=rank == world - 1, level=level, **kw)
-    info = ix.segment_info(seg)
-    _sub(tm, "slice_code_s", t1, dev)
-    tm["code_slice_s"] = time.time() - t0
-    t0 = time.time()
-    sizes = torch.zeros(world, dtype=torch.int64, device=wire); mine = torch.tensor([info["bytes"]], dtype=torch.int64, device=wire)
-    dist.all_gather_into_tensor(sizes, mine)
-    sizes = sizes.cpu().numpy()
-    base = int(sizes[:rank].sum()); total = int(sizes.sum()) + 28
-    if rank == 0:                                   # the file exists at its final length before anybody writes into it
-        with open(path, "wb") as fh:
-            fh.truncate(total)
-    dist.barrier()
-    tm["scan_sizes_s"] = time.time() - t0
-    t0 = time.time()
-    ix.segment_write(seg, path, base, rank == world - 1)
-    tm["write_slice_s"] = time.time() - t0
-    t0 = time.time()
-    tid, ts, te, vb, v_end = ix.segment_entries(seg, base)
-    ent = np.concatenate([tid.astype(np.int64), ts.astype(np.int64), te.astype(np.int64), vb.view(np.int64), np.array([v_end, info["unmapped_reads"]], np.uint64).view(np.int64)])
-    n_ent = torch.zeros(world, dtype=torch.int64, device=wire)
-    dist.all_gather_into_tensor(n_ent, torch.tensor([len(ent)], dtype=torch.int64, device=wire))
-    n_ent = [int(x) for x in n_ent.cpu().numpy()]
-    recv = torch.empty(sum(n_ent) if rank == 0 else 0, dtype=torch.int64, device=wire)
-    dist.all_to_all_single(recv, torch.from_numpy(ent).to(wire), output_split_sizes=n_ent if rank == 0 else [0] * world, input_split_sizes=[len(ent)] + [0] * (world - 1))
-    out = dict(tm, slice_bytes=info["bytes"], slice_records=info["mapped_records"], slice_unmapped_reads=info["unmapped_reads"], reads_held=int(len(got["lengths"])),
-               records_held=int(len(got["alns"])))
-    if rank == 0:
-        raw = recv.cpu().numpy(); o = 0
-        T, S, E, V = [], [], [], []
-        v_last, n_un = 0, 0
-        for r_ in range(world):
-            n = (n_ent[r_] - 2) // 4
-            b = raw[o:o + n_ent[r_]]; o += n_ent[r_]
-            T.append(b[:n]); S.append(b[n:2 * n]); E.append(b[2 * n:3 * n]); V.append(b[3 * n:4 * n].view(np.uint64))
-            v_last = int(b[4 * n:].view(np.uint64)[0]); n_un += int(b[4 * n + 1])
-        ix.bai_write(path + ".bai", np.concatenate(T), np.concatenate(S), np.concatenate(E), np.concatenate(V), v_last, n_un, tlens)
-        out.update(bam_bytes=total, records=int(sum(len(x) for x in T)), unmapped_reads=n_un)
-    out["index_s"] = time.time() - t0
-    dist.barrier()
-    ix.segment_free(seg); ix.free_raw(jr); jq.free()
-    return out
+        def gather_packed(idx):
+            sub = read_set.subset(np.asarray(idx, np.int32)); held.append(sub)
+            return sub.packed()
+        tm["partition_s"] = time.time() - t0
+        got = exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, dest, world, dist, wire, timings=tm)
+        while held:
+            held.pop().free()
+        del cig_t
+        t0 = time.time()
+        err = None; info = None
+        try:
+            jq = SeqSet.from_packed(eng, got["lengths"], got["seq2"], got["nmask"])
+            _sub(tm, "slice_from_packed_s", t0, dev); t1 = time.time()
+            jr = ix.result_from_device_cigars(got["alns"], got["cig"])
+            _sub(tm, "slice_result_s", t1, dev); t1 = time.time()
+            got["seq2"] = got["nmask"] = got["cig"] = None          # the library holds its own copies now: torch's cache goes back to the device for the writer
+            if dev.type == "cuda":
+                torch.cuda.empty_cache()
+            seg = ix.write_bam_slice(jr, jq, ix._cstr_array(got["names"]), tnames, got["emit"], with_header=rank == 0, unmapped=rank == world - 1, level=level, **kw)
+            info = ix.segment_info(seg)
+            _sub(tm, "slice_code_s", t1, dev)
+        except Exception as e:              # out of device memory in the coder, ...
+            err = e
+        _agree(dist, wire, err, "coding the BGZF blocks of a slice")
+        tm["code_slice_s"] = time.time() - t0
+        t0 = time.time()
+        sizes = torch.zeros(world, dtype=torch.int64, device=wire); mine = torch.tensor([info["bytes"]], dtype=torch.int64, device=wire)
+        dist.all_gather_into_tensor(sizes, mine)
+        sizes = sizes.cpu().numpy()
+        base = int(sizes[:rank].sum()); total = int(sizes.sum()) + 28
+        err = None
+        if rank == 0:                                   # the file exists at its final length before anybody writes into it
+            try:
+                with open(path, "wb") as fh:
+                    fh.truncate(total)
+            except Exception as e:
+                err = e
+        _agree(dist, wire, err, "creating the job's file")          # (also the barrier: nobody writes before the file exists)
+        tm["scan_sizes_s"] = time.time() - t0
+        t0 = time.time()
+        err = None
+        try:
+            ix.segment_write(seg, path, base, rank == world - 1)
+        except Exception as e:              # ENOSPC, a vanished directory, ...
+            err = e
+        _agree(dist, wire, err, "writing a slice into the job's file")
+        tm["write_slice_s"] = time.time() - t0
+        t0 = time.time()
+        tid, ts, te, vb, v_end = ix.segment_entries(seg, base)
+        ent = np.concatenate([tid.astype(np.int64), ts.astype(np.int64), te.astype(np.int64), vb.view(np.int64), np.array([v_end, info["unmapped_reads"]], np.uint64).view(np.int64)])
+        n_ent = torch.zeros(world, dtype=torch.int64, device=wire)
+        dist.all_gather_into_tensor(n_ent, torch.tensor([len(ent)], dtype=torch.int64, device=wire))
+        n_ent = [int(x) for x in n_ent.cpu().numpy()]
+        recv = torch.empty(sum(n_ent) if rank == 0 else 0, dtype=torch.int64, device=wire)
+        dist.all_to_all_single(recv, torch.from_numpy(ent).to(wire), output_split_sizes=n_ent if rank == 0 else [0] * world, input_split_sizes=[len(ent)] + [0] * (world - 1))
+        out = dict(tm, slice_bytes=info["bytes"], slice_records=info["mapped_records"], slice_unmapped_reads=info["unmapped_reads"], reads_held=int(len(got["lengths"])),
+                   records_held=int(len(got["alns"])))
+        err = None
+        if rank == 0:
+            try:
+                raw = recv.cpu().numpy(); o = 0
+                T, S, E, V = [], [], [], []
+                v_last, n_un = 0, 0
+                for r_ in range(world):
+                    n = (n_ent[r_] - 2) // 4
+                    b = raw[o:o + n_ent[r_]]; o += n_ent[r_]
+                    T.append(b[:n]); S.append(b[n:2 * n]); E.append(b[2 * n:3 * n]); V.append(b[3 * n:4 * n].view(np.uint64))
+                    v_last = int(b[4 * n:].view(np.uint64)[0]); n_un += int(b[4 * n + 1])
+                ix.bai_write(path + ".bai", np.concatenate(T), np.concatenate(S), np.concatenate(E), np.concatenate(V), v_last, n_un, tlens)
+                out.update(bam_bytes=total, records=int(sum(len(x) for x in T)), unmapped_reads=n_un)
+            except Exception as e:
+                err = e
+        out["index_s"] = time.time() - t0
+        _agree(dist, wire, err, "writing the index")                 # (the closing barrier of the call)
+        ok = True
+        return out
+    finally:
+        # whatever happened: the slice, the result, the received read set and the gathered subsets go back to the device, and a
+        # failed call leaves no file behind (rank 0 created it)
+        for sub in held:
+            try:
+                sub.free()
+            except Exception:
+                pass
+        if seg is not None:
+            ix.segment_free(seg)
+        if jr is not None:
+            ix.free_raw(jr)
+        if jq is not None:
+            jq.free()
+        if not ok and rank == 0:
+            import os
+            for f in (path, path + ".bai"):
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
 
 
 def rows_from_reports(locus_ids, reports, freqs, chrom_ids, family_ids):

@@ -54,7 +54,7 @@ def test_awkward_fasta(tmp_path):
 
 def test_single_line_records_are_used_in_place(tmp_path, monkeypatch):
     """every sequence on one line: the base buffer is the mapped file (nothing copied); one folded or CR LF record: a packed copy;
-    both give the same names and sequences as the Python reader, and the same as the copying path (TELR_FASTA_COPY)"""
+    both give the same names and sequences as the Python reader, and the same as the copying path (TELR_AB=fasta_copy)"""
     rng = np.random.default_rng(5)
     seqs = ["".join(rng.choice(list("ACGTN"), int(rng.integers(0, 300)))) for _ in range(3000)]
     p = tmp_path / "one.fa"
@@ -107,12 +107,12 @@ def test_errors(tmp_path):
 
 
 def test_copying_path_behind_its_switch(tmp_path):
-    """TELR_FASTA_COPY=1 (read once per process): single-line records are copied into a packed buffer as folded ones are; same names and sequences"""
+    """TELR_AB=fasta_copy (read once per process): single-line records are copied into a packed buffer as folded ones are; same names and sequences"""
     import subprocess, sys
     p = tmp_path / "one.fa"
     p.write_text("".join(">s%d\n%s\n" % (i, "ACGT" * (i % 7 + 1)) for i in range(200)))
     code = "import sys; sys.path.insert(0, %r)\nfrom telr_amd.fasta import FastaFile\nf = FastaFile(sys.argv[1])\nprint(len(f.triple[0]) == f.bases, f.seqs() == ['ACGT' * (i %% 7 + 1) for i in range(200)])" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env, want in (({}, b"False True"), ({"TELR_FASTA_COPY": "1"}, b"True True")):
+    for env, want in (({}, b"False True"), ({"TELR_AB": "fasta_copy"}, b"True True")):
         r = subprocess.run([sys.executable, "-c", code, str(p)], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert r.returncode == 0 and r.stdout.strip() == want, (env, r.stdout, r.stderr.decode()[-1000:])
 

@@ -236,10 +236,10 @@ def test_prepared_output_file_gives_the_same_bam(engine, tmp_path):
         ix.free_raw(r)
 
 
-@pytest.mark.parametrize("switch", ["TELR_BAM_NO_POPULATE", "TELR_BAM_NO_TWIN"])
+@pytest.mark.parametrize("switch", ["bam_no_populate", "bam_no_twin"])
 def test_writer_switches_in_a_process_of_their_own(tmp_path, switch):
-    """TELR_BAM_NO_POPULATE=1 (the prepared file's blocks allocated, not pre-faulted: the round's earlier sink) and
-    TELR_BAM_NO_TWIN=1 (the writer uploads the CIGARs although the result kept them on the device): read once per process,
+    """TELR_AB=bam_no_populate (the prepared file's blocks allocated, not pre-faulted: the round's earlier sink) and
+    TELR_AB=bam_no_twin (the writer uploads the CIGARs although the result kept them on the device): read once per process,
     so each runs in its own; the file must be the one the default path writes"""
     import os, subprocess, sys
     code = r"""
@@ -256,10 +256,10 @@ a, b = sys.argv[1] + "/a.bam", sys.argv[1] + "/b.bam"
 ix.write_bam_device(r, qset, names, tn, a, cmdline="t", level=1)
 ix.bam_prepare(b, 40 << 20)
 ix.write_bam_device(rk, qset, names, tn, b, cmdline="t", level=1)
-assert eng.L.telr_debug_bam_twin() == (0 if os.environ.get("TELR_BAM_NO_TWIN") else 1)
+assert eng.L.telr_debug_bam_twin() == (0 if "bam_no_twin" in os.environ.get("TELR_AB", "") else 1)
 assert open(a, "rb").read() == open(b, "rb").read() and open(a + ".bai", "rb").read() == open(b + ".bai", "rb").read()
 assert eng.L.telr_bam_release_wait() == 0
 print("same")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=dict(os.environ, **{switch: "1"}), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    p = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=dict(os.environ, TELR_AB=switch), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0 and b"same" in p.stdout, p.stderr.decode()[-2000:]

@@ -1,7 +1,6 @@
 """Every build-time alternative the engine still carries behind an environment switch (A/B paths of earlier rounds: the
 host-side chain selection, the byte-wide trace-back spill, the library's anchor sort, seeding and sorting as two kernels, compacted
-minimizers, untagged two-piece cells, the 64-bit sketch, the int32 wide classes, serial class launches, chunked packed
-launches, trace-back lane limits, synchronous result DMA, the table filter in the vote presets' lookups, which queries vote with 16-bit counters) must produce the SAME bits as the default path: each switch runs
+minimizers, untagged two-piece cells, the 64-bit sketch, the int32 wide classes, serial class launches, the table filter in the vote presets' lookups) must produce the SAME bits as the default path: each switch runs
 the randomised HIP-vs-oracle parity (tests/fuzz_parity.py: every stage compared) in a process of its own, because the
 switches are read once per process."""
 import os
@@ -13,11 +12,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# (round 5: the alternative forms are tokens of ONE variable, TELR_AB; TELR_PK_CHUNKS, TELR_TBW_MAX and TELR_VOTE_T16_LIMIT are gone with their code)
 SWITCHES = [
-    {"TELR_TB8": "1"}, {"TELR_SORT64": "1"}, {"TELR_MZ_COMPACT": "1"},
-    {"TELR_NO_TAG8": "1"}, {"TELR_SKETCH64": "1"}, {"TELR_NO_PKW": "1"}, {"TELR_SERIAL": "1"}, {"TELR_PK_CHUNKS": "3"},
-    {"TELR_TB_SPLIT": "0"}, {"TELR_TBW_MAX": "0"}, {"TELR_NO_AVX2": "1"}, {"TELR_PACK_THREADS": "1"},
-    {"TELR_TRACE_HOST": "1"}, {"TELR_SEED_UNFUSED": "1"}, {"TELR_CHAIN_NO_ISLANDS": "1"}, {"TELR_VOTE_FILTER": "1"}, {"TELR_VOTE_T16_LIMIT": "0"}, {"TELR_VOTE_T16_LIMIT": "400"},
+    {"TELR_AB": "tb8"}, {"TELR_AB": "sort64"}, {"TELR_AB": "mz_compact"},
+    {"TELR_AB": "no_tag8"}, {"TELR_AB": "sketch64"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "no_pk"}, {"TELR_SERIAL": "1"},
+    {"TELR_AB": "tb_one_launch"}, {"TELR_AB": "no_avx2"}, {"TELR_PACK_THREADS": "1"},
+    {"TELR_TRACE": "host"}, {"TELR_AB": "seed_unfused"}, {"TELR_AB": "no_islands"}, {"TELR_AB": "vote_filter"}, {"TELR_AB": "tb8,no_tag8,sort64"},
 ]
 
 
@@ -31,7 +31,7 @@ def test_switch_keeps_parity(env):
 
 def test_switch_keeps_parity_big_inputs():
     """the same on Mb-size genomes and 8-40-kb reads (wide classes, long fills) for the switches that touch the DP classes"""
-    for env in ({"TELR_TB8": "1"}, {"TELR_NO_TAG8": "1"}, {"TELR_NO_PKW": "1"}, {"TELR_PK_CHUNKS": "2"}):
+    for env in ({"TELR_AB": "tb8"}, {"TELR_AB": "no_tag8"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}):
         e = dict(os.environ); e.update(env); e["FUZZ_BIG"] = "1"
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "3", "5"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
         assert p.returncode == 0 and "fuzz ok: 3 iterations" in p.stdout.decode(), (env, p.stdout.decode()[-3000:])

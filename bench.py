@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--bam-dir", default="/dev/shm")
     ap.add_argument("--bam-level", type=int, default=1)
     ap.add_argument("--files-leg", action="store_true", help="stage 1 as the reference runs it, from FILES: the read set and the reference are written as FASTA under --bam-dir, then telr_alignment.alignment(bam, reads.fa, ref.fa, ...) is timed end to end (parse, pack, upload, index, map, sorted BAM + .bai)")
+    ap.add_argument("--poa-parity", type=int, default=0, help="polish leg: the device consensus (window POA and pile-up) of the first N loci against the CPU oracle, contig for contig")
     ap.add_argument("--no-polish-leg", action="store_true", help="skip the (untimed-for-the-metric) device polishing pass over the loci")
     ap.add_argument("--no-bam-prepare", action="store_true", help="do not create / allocate / map the BAM file in the background while the reads are mapped")
     ap.add_argument("--dry-launch", action="store_true", help="launcher smoke test: ranks initialise torch.distributed, report and exit (no GPU work)")
@@ -772,7 +773,7 @@ def main():
 
         phase = {}                                 # seconds per phase of the LAST pass (exchange, bundle, all-gather)
 
-        def loci_pass():
+        def loci_pass(polish=None):
             phase.clear()
             # a12: every read with ANY stage-1 record overlapping [bp-1000, bp+1000) (TELR_assembly.py:384-415), from the
             # records of the last step (this rank's reads)
@@ -781,7 +782,7 @@ def main():
                 for l, idx in zip(loci, wr):
                     l["read_idx"] = idx.astype(np.int32)
                 return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, shards=shards,
-                                                           presets=presets_arg, read_set=qs, timings=phase)
+                                                           presets=presets_arg, read_set=qs, timings=phase, polish=polish)
             t_ex = time.time()
             lid = np.repeat(np.arange(len(wr)), [len(x) for x in wr]); ridx = np.concatenate(wr) if len(wr) else np.zeros(0, np.int64)
             own = np.array([owner[i] for i in range(len(loci))], np.int64)
@@ -803,7 +804,7 @@ def main():
                 l.pop("reads", None)
             phase["exchange_s"] = phase.get("exchange_s", 0.0) + time.time() - t_ex
             return locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], loci, lib_names, lib, dist=dist, device=device,
-                                                       shards=shards, presets=presets_arg, read_set=pool_set, timings=phase)
+                                                       shards=shards, presets=presets_arg, read_set=pool_set, timings=phase, polish=polish)
         flank_parity = None
         if a.flank_parity and rank == 0:
             from telr_amd.fasta import concat
@@ -962,6 +963,51 @@ def main():
                     polish["poa"] = {"error": "%s: %s" % (type(e).__name__, e)}
             except Exception as e:
                 polish = {"error": "%s: %s" % (type(e).__name__, e)}
+            # the A/B DESIGN section 8 listed first: the call set of the SAME loci pass with the contigs polished on the device first
+            # (TELR_assembly.py:185-262 runs wtpoa-cns there), pile-up against window POA against no polishing
+            if isinstance(polish, dict) and "error" not in polish:
+                ab = {}
+                for mode in ("pileup", "poa"):
+                    try:
+                        sync(); t0p = time.time()
+                        rows_m, _ = loci_pass(polish=mode)
+                        sync(); tm_ = time.time() - t0p
+                        g_, a_, w_ = tally(rows_m)
+                        same = int(sum(1 for x, y in zip(np.sort(rows_m, order="locus_id"), np.sort(rows, order="locus_id"))
+                                       if (int(x["locus_id"]), int(x["chrom_id"]), int(x["start"]), int(x["end"]), int(x["strand"]), int(x["type"]), [int(v) for v in x["family_id"]]) ==
+                                          (int(y["locus_id"]), int(y["chrom_id"]), int(y["start"]), int(y["end"]), int(y["strand"]), int(y["type"]), [int(v) for v in y["family_id"]]))) if len(rows_m) == len(rows) else None
+                        ab[mode] = {"recovered_exact_chrom_family_strand_pos20": g_, "of_those_af_within_0.15": a_, "rows_in_merged_table": len(rows_m), "not_recovered": w_,
+                                    "rows_with_the_unpolished_call": same, "seconds_incl_polish": tm_}
+                    except Exception as e:
+                        ab[mode] = {"error": "%s: %s" % (type(e).__name__, e)}
+                polish["call_set_ab"] = dict(ab, none={"recovered_exact_chrom_family_strand_pos20": good, "of_those_af_within_0.15": af_ok, "rows_in_merged_table": n_rows},
+                                             what="the whole loci pass (S4-S7, depth, AF, liftover) on contigs polished first by the device consensus; `rows_with_the_unpolished_call` = rows whose "
+                                                  "chromosome, coordinates, strand, type and families equal the unpolished pass's")
+            # full-size parity of the two consensus kernels: the first --poa-parity loci, engine vs CPU oracle, contig string for contig string
+            if a.poa_parity > 0 and isinstance(polish, dict) and "error" not in polish:
+                try:
+                    from oracle import binding as ob
+                    npar = min(a.poa_parity, len(loci))
+                    io_p, mo_p = preset("map-pb" if presets_arg == "pacbio" else "map-ont"); mo_p.bw = 2000
+                    drafts = [c if isinstance(c, str) else bytes(c).decode() for c in ctg[:npar]]
+                    qt_p = np.array([k for k in range(npar) for _ in wr_p[k]], np.int32)
+                    ridx_p = np.concatenate([wr_p[k] for k in range(npar)]).astype(np.int32)
+                    flat_p = [bytes(rbuf[roff[i]:roff[i] + rln[i]]).decode() for i in ridx_p]
+                    ixp = eng.index(drafts, io_p); qsp = qs.subset(ridx_p)
+                    rp = ixp.map_raw(qsp, mo_p, qtarget=qt_p)
+                    resp = ixp.result_arrays(rp)
+                    par = {"loci": npar, "reads": int(len(ridx_p)), "records": int(len(resp.alns)), "windows_of_200_bases": int(sum((len(d_) + 199) // 200 for d_ in drafts))}
+                    for key, is_poa in (("poa", True), ("pileup", False)):
+                        got = ixp.consensus(rp, qsp, min_depth=3, poa=is_poa)
+                        t0o = time.time()
+                        want = ob.consensus(resp.alns, resp.cigars, flat_p, drafts, min_depth=3, poa=is_poa)
+                        par[key] = {"identical": got == want, "contigs_differing": int(sum(1 for x, y in zip(got, want) if x != y)), "contigs_changed_by_the_consensus": int(sum(1 for x, y in zip(got, drafts) if x != y)),
+                                    "oracle_seconds": time.time() - t0o}
+                    ixp.free_raw(rp); ixp.free(); qsp.free()
+                    par["what"] = "telr_poa_build / telr_consensus_build on the polish alignments (-ax P -r2k, per-query targets) of the first loci with their real window reads, against the CPU oracle's tor_poa / pile-up on the same records: every contig string equal = every window equal"
+                    polish["parity"] = par
+                except Exception as e:
+                    polish["parity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         wr_counts = [len(x) for x in telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])]
         import hashlib
         rs = np.sort(rows, order="locus_id")

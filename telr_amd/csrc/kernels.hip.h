@@ -1234,13 +1234,128 @@ __device__ __forceinline__ void d_chain_run(const uint64_t *__restrict__ keys, c
     }
 }
 
+// LAZY FAR LOOK-BACK (round 5; look-backs of 128 / 256 anchors).  The push loop above spends 19 instructions on every one of the H
+// links of an anchor, and on a true chain -- anchors every few bases, f growing with every one of them -- the far ones never matter: the
+// best predecessor is among the nearest.  Here an anchor takes pushes from its 64 NEAREST predecessors only (one slot, the R = 1 loop),
+// and the H - 64 far ones are looked at only when they could still win:  a link scores at most span_i + f_j, so with
+//   M_i = max f over the far predecessors of i     (lane l of chunk c: lanes >= l of chunk c-R, all of the chunks between, lanes < l of
+//                                                   chunk c-1: one suffix maximum, the chunks' maxima, one prefix maximum -- two scans
+//                                                   per finished chunk, kept in registers)
+// the far ones are out as soon as span_i + M_i <= best so far (ties go to the LARGER index, i.e. to the near ones).  The order of the
+// look-back does not matter for the result: f(i) = the maximum, p(i) = the largest index attaining it provided it beats span_i -- what
+// the ascending loop with ">=" yields (d_chain_push).  When the bound does not decide (anchors without a near predecessor: chain starts,
+// repeats) a scalar test on the nearest far predecessor's position (index i - 65: everything further back lies even further away) sorts
+// out the isolated ones, and what is left evaluates its far links on the spot, one per lane and chunk, from the last R chunks'
+// (reference word, query position, f) kept in registers, with a wave reduction (maximum, then the largest index among its holders).
+// Same f, same p as d_chain_run (tests/test_gpu_parity.py compares both with the oracle; TELR_AB=chain_push keeps the full push loop).
 template <int R, bool SKIP>
+__device__ __forceinline__ void d_chain_run_lazy(const uint64_t *__restrict__ keys, const int64_t base, const int n, const int pdelta,
+                                                 const ChainOpt &o, int32_t *__restrict__ f, int32_t *__restrict__ p)
+{
+    static_assert(R >= 2, "a look-back of 64 has no far part");
+    constexpr int32_t NEG = -(1 << 29);
+    const int lane = threadIdx.x;
+    const uint64_t *a = keys + base;
+    const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
+    const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
+    uint32_t gi, qi, sp1; int32_t B, bp;
+    { const uint64_t k = lane < n ? a[lane] : 0; gi = (uint32_t)(k >> 32); qi = (uint32_t)A_Q(k); sp1 = (uint32_t)A_SPAN(k) - 1u; B = 2 * A_SPAN(k) + 1; bp = -1; }
+    // the last R finished chunks, newest first: reference word, query position (0x7fffffff: no such anchor -- fails every range test), 2 f + 2;
+    // their suffix maxima of f by lane, the newest one's prefix maximum, every chunk's maximum
+    uint32_t hg[R], hq[R]; int32_t hf[R], hsuf[R], hfull[R], pre0 = NEG;
+#pragma unroll
+    for (int h = 0; h < R; ++h) { hg[h] = 0; hq[h] = 0x7fffffffu; hf[h] = 0; hsuf[h] = NEG; hfull[h] = NEG; }
+    uint32_t gcur = (uint32_t)__builtin_amdgcn_readlane((int)gi, 0);
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        // the far bound of this chunk's anchors (every lane holds its anchor of THIS chunk now)
+        int32_t Ms = hsuf[R - 1] > pre0 ? hsuf[R - 1] : pre0;
+#pragma unroll
+        for (int h = 1; h < R - 1; ++h) Ms = hfull[h] > Ms ? hfull[h] : Ms;
+        Ms += (int32_t)sp1 + 1;
+        const int inext = j0 + 64 + lane;
+        const uint64_t knext = inext < n ? a[inext] : 0;
+        const uint32_t ng = (uint32_t)(knext >> 32), nqp = (uint32_t)A_Q(knext), nsp1 = (uint32_t)A_SPAN(knext) - 1u;
+        const int32_t nB = 2 * A_SPAN(knext) + 1;
+        int32_t myB = 0, myp = -1;
+        const int jn = n - j0 < 64 ? n - j0 : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const int j = j0 + jj;
+            const uint32_t gj = gcur, gj1 = gj + 1u;
+            const uint32_t gnext = jj < 63 ? (uint32_t)__builtin_amdgcn_readlane((int)gi, jj + 1) : (uint32_t)__builtin_amdgcn_readlane((int)ng, 0);
+            gcur = gnext;
+            int32_t sB = __builtin_amdgcn_readlane(B, jj);
+            const int32_t sMs = __builtin_amdgcn_readlane(Ms, jj);
+            const bool me = lane == jj;
+            if (sMs > (sB >> 1)) {
+                // the nearest far predecessor, index j - 65: lane jj - 1 of the newest chunk, or lane 63 of the one before
+                const uint32_t gfar = jj ? (uint32_t)__builtin_amdgcn_readlane((int)hg[0], jj - 1) : (uint32_t)__builtin_amdgcn_readlane((int)hg[1], 63);
+                if (gj - gfar <= max_gap) {
+                    const uint32_t qS = (uint32_t)__builtin_amdgcn_readlane((int)qi, jj), spS = (uint32_t)__builtin_amdgcn_readlane((int)sp1, jj);
+                    int32_t Bl = NEG * 2, bl = -1;
+#pragma unroll
+                    for (int h = R - 1; h >= 0; --h) {          // oldest chunk first: ascending predecessor index, ">=" keeps the largest
+                        const bool in_set = h == 0 ? lane < jj : h == R - 1 ? lane >= jj : true;
+                        int32_t Bt = Bl, bt = bl;
+                        d_chain_push<SKIP>(gj, qS, spS, hg[h] + 1u, hq[h] + 1u, hf[h], j0 - 64 * (h + 1) + lane, max_gap, ddc, gap_q8, skip_q8, Bt, bt);
+                        Bl = in_set ? Bt : Bl; bl = in_set ? bt : bl;
+                    }
+                    int32_t m = Bl;
+#pragma unroll
+                    for (int s = 32; s >= 1; s >>= 1) { const int32_t v = __shfl_xor(m, s); m = v > m ? v : m; }
+                    if (m > sB) {           // strictly better than every near link (and than the span alone): the far link it is
+                        int32_t w = Bl == m ? bl : -1;
+#pragma unroll
+                        for (int s = 32; s >= 1; s >>= 1) { const int32_t v = __shfl_xor(w, s); w = v > w ? v : w; }
+                        B = me ? m : B; bp = me ? w : bp; sB = __builtin_amdgcn_readfirstlane(m);
+                    }
+                }
+            }
+            const uint32_t qj1 = (uint32_t)__builtin_amdgcn_readlane((int)qi, jj) + 1u;
+            // lane jj hands over: its anchor's final state goes to (myB, myp), its slot takes the anchor 64 further on.  Six moves of ONE
+            // lane under an execution mask of that lane (full-rate v_mov) instead of six v_cndmask_b32 with a 64-bit mask operand (VOP3,
+            // half rate): the loop's bookkeeping, not its arithmetic, was a third of its issue cycles.  (The wave is whole here.)
+            {
+                const uint64_t one = 1ULL << jj; uint64_t sv;
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\t"
+                             "v_mov_b32 %[myB], %[B]\n\tv_mov_b32 %[myp], %[bp]\n\tv_mov_b32 %[gi], %[ng]\n\tv_mov_b32 %[sp1], %[nsp1]\n\t"
+                             "v_mov_b32 %[qi], %[nqp]\n\tv_mov_b32 %[B], %[nB]\n\ts_mov_b64 exec, %[sv]"
+                             : [myB] "+v"(myB), [myp] "+v"(myp), [gi] "+v"(gi), [sp1] "+v"(sp1), [qi] "+v"(qi), [B] "+v"(B), [sv] "=&s"(sv)
+                             : [bp] "v"(bp), [ng] "v"(ng), [nsp1] "v"(nsp1), [nqp] "v"(nqp), [nB] "v"(nB), [m] "s"(one));
+            }
+            if (gnext - gj <= max_gap) {
+                const int32_t fj2p2 = (sB & ~1) + 2;
+                d_chain_push<SKIP>(gi, qi, sp1, gj1, qj1, fj2p2, j, max_gap, ddc, gap_q8, skip_q8, B, bp);
+            }
+        }
+        if (lane < jn) { f[base + j0 + lane] = myB >> 1; p[base + j0 + lane] = (myB & 1) ? -1 : myp + pdelta; }
+        if (j0 + 64 < n) {
+            // this chunk becomes history (its anchors' words come back from memory: the slot holds the next chunk's by now)
+#pragma unroll
+            for (int h = R - 1; h >= 1; --h) { hg[h] = hg[h - 1]; hq[h] = hq[h - 1]; hf[h] = hf[h - 1]; hsuf[h] = hsuf[h - 1]; hfull[h] = hfull[h - 1]; }
+            const uint64_t k = a[j0 + lane];
+            hg[0] = (uint32_t)(k >> 32); hq[0] = (uint32_t)A_Q(k); hf[0] = (myB & ~1) + 2;
+            const int32_t fv = myB >> 1;
+            int32_t inc = fv, suf = fv;
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int32_t u = __shfl_up(inc, s), d = __shfl_down(suf, s);
+                if (lane >= s) inc = u > inc ? u : inc;
+                if (lane + s < 64) suf = d > suf ? d : suf;
+            }
+            const int32_t ex = __shfl_up(inc, 1);
+            pre0 = lane ? ex : NEG; hsuf[0] = suf; hfull[0] = __builtin_amdgcn_readlane(suf, 0);
+        }
+    }
+}
+
+template <int R, bool SKIP, bool LAZY = true>
 __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
                                               ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
 {
     if ((int)blockIdx.x >= nq) return;
     const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;    // longest reads first: the kernel ends with the short ones
-    d_chain_run<R, SKIP>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p);
+    if constexpr (LAZY && R >= 2) d_chain_run_lazy<R, SKIP>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p);
+    else d_chain_run<R, SKIP>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p);
 }
 // ISLANDS.  Anchors are sorted by (strand, reference position) and a link needs 0 < dr <= max_gap, so wherever two consecutive
 // anchors of a query lie more than max_gap apart (or on different strands: bit 31) no link crosses: the list falls into islands
@@ -1267,12 +1382,15 @@ __global__ void __launch_bounds__(256) k_isl_fill(const int32_t *__restrict__ q_
     for (int i = threadIdx.x; i < n; i += blockDim.x) if (head[base + i]) { const int id = rank[base + i]; isl_off[id] = (int32_t)base + i; isl_pd[id] = i; }
     if (q == 0 && threadIdx.x == 0) isl_off[rank[na]] = na;
 }
-template <int R, bool SKIP>
+template <int R, bool SKIP, bool LAZY = true>
 __global__ void __launch_bounds__(64) k_chain_isl(const uint64_t *__restrict__ keys, const int32_t *__restrict__ isl_off, const int32_t *__restrict__ isl_pd, const int32_t *__restrict__ nisl,
                                                   ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p)
 {
     const int n_isl = *nisl;
-    for (int s = blockIdx.x; s < n_isl; s += gridDim.x) d_chain_run<R, SKIP>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p);
+    for (int s = blockIdx.x; s < n_isl; s += gridDim.x) {
+        if constexpr (LAZY && R >= 2) d_chain_run_lazy<R, SKIP>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p);
+        else d_chain_run<R, SKIP>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p);
+    }
 }
 
 // peaks: anchors with no successor of larger f

@@ -90,7 +90,7 @@ struct telr_ctx {
 // ---- environment: TWO switches carry every alternative form and every trace the engine still has (read once per process) ----------
 //   TELR_AB=tok[,tok...]     A/B forms of earlier rounds, kept because tests/test_gpu_switches.py holds each of them to the same bits:
 //                            sort64 (rocPRIM's segmented sort for every query), seed_unfused (seeding and sorting as two kernels),
-//                            sketch64 (the 64-bit sketch kernel for k <= 15 too), mz_compact (compacted minimizer arrays), no_islands
+//                            chain_push (every link of the look-back scored), sketch64 (the 64-bit sketch kernel for k <= 15 too), mz_compact (compacted minimizer arrays), no_islands
 //                            (one wave per query in every chaining call), vote_filter (table filter in the vote presets' lookups),
 //                            no_pk / no_pkw / no_pkext (int32 classes instead of the packed fills / wide fills / extensions), tb8 (byte
 //                            spill in the one-piece classes), no_tag8 (untagged two-piece cell), tb_one_launch (ONE trace-back launch
@@ -1765,7 +1765,9 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw_long > mo->bw ? mo->bw_long : mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
     co.chain_gap_q8 = mo->chain_gap_q8; co.chain_skip_q8 = mo->chain_skip_q8;
     const int Rr = mo->chain_lookback / 64;
-#define CHAIN_LAUNCH(RR, SK) hipLaunchKernelGGL((k_chain<RR, SK>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder)
+    static const bool chain_push = ab_on("chain_push");       // A/B: the full push loop (every one of the H links scored) instead of the lazy far look-back
+#define CHAIN_LAUNCH(RR, SK) do { if (chain_push) hipLaunchKernelGGL((k_chain<RR, SK, false>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder); \
+                                  else hipLaunchKernelGGL((k_chain<RR, SK, true>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder); } while (0)
     const bool skip = co.chain_skip_q8 != 0;
     static const bool no_islands = ab_on("no_islands");       // A/B: one wave per query whatever the call's shape
     if (nq <= CHAIN_ISL_NQ && na > 0 && !no_islands) {
@@ -1781,7 +1783,8 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_head, d_rank, (size_t)na + 1)));
         hipLaunchKernelGGL(k_isl_fill, dim3(nq), dim3(256), 0, st, d_qaoff, nq, d_head, d_rank, (int32_t)na, d_ioff, d_ipd);
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)na, 256 * 32);
-#define CHAIN_ISL(RR, SK) hipLaunchKernelGGL((k_chain_isl<RR, SK>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p)
+#define CHAIN_ISL(RR, SK) do { if (chain_push) hipLaunchKernelGGL((k_chain_isl<RR, SK, false>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); \
+                               else hipLaunchKernelGGL((k_chain_isl<RR, SK, true>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); } while (0)
         if (Rr == 1) { if (skip) CHAIN_ISL(1, true); else CHAIN_ISL(1, false); }
         else if (Rr == 2) { if (skip) CHAIN_ISL(2, true); else CHAIN_ISL(2, false); }
         else { if (skip) CHAIN_ISL(4, true); else CHAIN_ISL(4, false); }

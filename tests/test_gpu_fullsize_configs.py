@@ -40,3 +40,20 @@ def test_call_sites_s6_s7_and_the_bundle_at_configs2_size():
     assert fp["parity"]["identical"] is True and fp["parity"]["reads"] == 200 and fp["parity"]["records_engine"] >= 200, fp["parity"]      # S7: 2 flanks per locus
     assert fp["s6"]["identical"] is True and fp["s6"]["loci"] == 100 and fp["s6"]["records_engine"] == fp["s6"]["records_oracle"] > 5000, fp["s6"]
     assert fp["bundle"]["identical"] is True and fp["bundle"]["loci"] == 60 and fp["bundle"]["liftover_reports"] == 60, fp["bundle"]
+
+
+def test_polish_hand_off_at_configs2_size_poa_and_pile_up_equal_the_oracle():
+    """H3 (TELR_assembly.py:226-247) at full size: the polish alignments of 100 configs[2] loci with their real window reads (~4,000
+    reads, ~12,600 windows of 200 bases); telr_poa_build == tor_poa and telr_consensus_build == the oracle's pile-up for every contig,
+    i.e. for every window; and the call-set A/B of the three polish modes is in the line"""
+    d = _bench("--config", "c2", "--loci", "100", "--poa-parity", "100", "--no-cpu-baseline", "--no-default-aligner-leg")
+    pol = d["te_loci"]["polish_pileup"]
+    assert "error" not in pol, pol
+    par = pol["parity"]
+    assert "error" not in par, par
+    assert par["loci"] == 100 and par["reads"] > 2000 and par["records"] > 2000 and par["windows_of_200_bases"] > 10000, par
+    for k in ("poa", "pileup"):
+        assert par[k]["identical"] is True and par[k]["contigs_differing"] == 0 and par[k]["contigs_changed_by_the_consensus"] > 50, (k, par[k])
+    ab = pol["call_set_ab"]
+    for k in ("pileup", "poa"):
+        assert "error" not in ab[k] and ab[k]["rows_in_merged_table"] == ab["none"]["rows_in_merged_table"] == 100, ab

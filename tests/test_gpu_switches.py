@@ -17,7 +17,7 @@ SWITCHES = [
     {"TELR_AB": "tb8"}, {"TELR_AB": "sort64"}, {"TELR_AB": "mz_compact"},
     {"TELR_AB": "no_tag8"}, {"TELR_AB": "sketch64"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "no_pk"}, {"TELR_SERIAL": "1"},
     {"TELR_AB": "tb_one_launch"}, {"TELR_AB": "no_avx2"}, {"TELR_PACK_THREADS": "1"},
-    {"TELR_TRACE": "host"}, {"TELR_AB": "seed_unfused"}, {"TELR_AB": "no_islands"}, {"TELR_AB": "vote_filter"}, {"TELR_AB": "tb8,no_tag8,sort64"},
+    {"TELR_TRACE": "host"}, {"TELR_AB": "seed_unfused"}, {"TELR_AB": "no_islands"}, {"TELR_AB": "vote_filter"}, {"TELR_AB": "tb8,no_tag8,sort64"}, {"TELR_AB": "chain_push"},
 ]
 
 

@@ -11,7 +11,7 @@ cache=$(mktemp -d /tmp/telr_cache.XXXXXX)
 hipcc -O3 --offload-arch=gfx950 -o tools/ubench/valu_rate tools/ubench/valu_rate.hip || { echo "ubench build failed"; exit 1; }
 timeout 1200 python3 bench.py --config $cfg --data-cache $cache --bam-leg device --files-leg > $out/${tag}_bench_default.json 2>$out/${tag}_bench_default.err || { echo "plain bench run failed"; tail -5 $out/${tag}_bench_default.err; exit 1; }
 ls $cache/*.npz > /dev/null || { echo "no data cache"; exit 1; }
-B="python3 bench.py --config $cfg --data-cache $cache --require-cache --no-cpu-baseline --loci 0 --no-stream-leg --no-shard-leg --bam-leg none"
+B="python3 bench.py --config $cfg --data-cache $cache --require-cache --no-cpu-baseline --loci 0 --no-stream-leg --no-default-aligner-leg --no-shard-leg --bam-leg none"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- $B --steps 3 --warmup 1 > $out/${tag}_bench_under_rocprof.json 2>/dev/null
 python3 tools/prof_summary.py gpurun_out/kt > $out/${tag}_kernel_trace_summary.txt
 python3 tools/step_timeline.py gpurun_out/kt > $out/${tag}_step_timeline.txt

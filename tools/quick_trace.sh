@@ -6,8 +6,8 @@ tag=${1:-qt}; cfg=${2:-c2}; shift; shift
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof; mkdir -p $out
 cache=$(mktemp -d /tmp/telr_cache.XXXXXX)
-timeout 900 python3 bench.py --config $cfg --data-cache $cache --bam-leg none --loci 0 --no-stream-leg --no-shard-leg --steps 4 --warmup 1 "$@" > $out/${tag}_bench_plain.json 2>$out/${tag}_bench_plain.err || { echo "plain run failed"; tail -5 $out/${tag}_bench_plain.err; exit 1; }
-B="python3 bench.py --config $cfg --data-cache $cache --require-cache --no-cpu-baseline --loci 0 --no-stream-leg --no-shard-leg --bam-leg none"
+timeout 900 python3 bench.py --config $cfg --data-cache $cache --bam-leg none --loci 0 --no-stream-leg --no-default-aligner-leg --no-shard-leg --steps 4 --warmup 1 "$@" > $out/${tag}_bench_plain.json 2>$out/${tag}_bench_plain.err || { echo "plain run failed"; tail -5 $out/${tag}_bench_plain.err; exit 1; }
+B="python3 bench.py --config $cfg --data-cache $cache --require-cache --no-cpu-baseline --loci 0 --no-stream-leg --no-default-aligner-leg --no-shard-leg --bam-leg none"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -- $B --steps 3 --warmup 1 "$@" > $out/${tag}_bench_under_rocprof.json 2>/dev/null
 python3 tools/prof_summary.py gpurun_out/kt > $out/${tag}_kernel_trace_summary.txt
 rm -rf gpurun_out/kt $cache

@@ -130,7 +130,8 @@ def launch_ranks(a):
     return pr.wait()
 
 
-PMC_PROFILE = "r04_pmc_k_dp_pk.json"       # per-launch counters of the dominant kernel, collected by tools/collect_profiles.sh
+PMC_PROFILE = "r05_pmc_k_dp_pk.json"       # per-launch counters of the dominant kernel, collected by tools/collect_profiles.sh
+PMC_PROFILE_NG = "r05_ngmlr_ont_c2_pmc_k_dp_pk.json"      # the same for the default-aligner leg (tools/collect_ngmlr_profiles.sh + tools/pmc_to_json.py)
 PARITY_FIELDS = ("tid", "qlen", "qs", "qe", "tlen", "ts", "te", "mlen", "blen", "score", "subsc", "dp_score", "cnt", "n_sub", "parent", "n_cigar", "flags", "mapq")
 
 
@@ -654,6 +655,14 @@ def main():
             rf = pk_roofline(T1)
             dp_ms1 = T1["stage_tot"].get("dp", 0.0) / a.steps
             rf["note"] = "same definition as `roofline`; all DP kernels together: %.1f ms per step" % dp_ms1
+            rf["traffic"] = None
+            try:            # HBM bytes per launch from the committed PMC passes of the same preset on this workload (rocprofv3 --pmc cannot run inside this process)
+                pmn = json.load(open(os.path.join(ROOT, "profiles", PMC_PROFILE_NG)))
+                if pmn.get("config") == a.config and pname_ng == "ngmlr-ont" and not a.coverage and a.genome_scale == 1.0 and world == 1:
+                    rf["traffic"] = pmn["traffic_bytes_per_launch"]
+                    rf["from_profile"] = {"file": "profiles/" + PMC_PROFILE_NG, "collected_at_commit": pmn.get("head_sha"), "traffic_over_algorithmic": pmn.get("traffic_over_algorithmic"), "valu_issue": pmn.get("valu_issue")}
+            except Exception:
+                pass
             default_aligner = {"preset": pname_ng, "value": T1["value"], "unit": "Gbp/s", "ms_per_step": T1["dt"] / a.steps * 1e3, "steps": a.steps, "warmup": a.warmup,
                                "index_build_s": t_index_ng, "roofline": rf,
                                "stage_ms_per_step": {k: v / a.steps for k, v in T1["stage_tot"].items()},
@@ -764,12 +773,20 @@ def main():
         chrom_ids = {n: i for i, n in enumerate(D["names"])}
         ref_of = dict(zip(D["names"], ref_strs))
         presets_arg = "ont" if cfg["err"][1] < 0.05 else "pacbio"
-        shards = shard.shard_loci([locus_pipeline.locus_cost(l) for l in loci], world)
+        rbuf, roff, rln = D["reads"]
+        # LPT cost of a locus = what its bundle maps: the contig and ALT bases plus the bases of its window reads TWICE (S6 maps every window
+        # read against the forward and the reverse-complement contig) -- the window reads are most of it and differ five-fold between loci.
+        # At N > 1 a rank sees the window reads of its own share of the reads: one all-reduce of n_loci counters (metadata, not on the data path).
+        wr0 = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])
+        rb_loc = np.array([int(rln[w].sum()) for w in wr0], np.int64)
+        if dist is not None and world > 1:
+            t_ = torch.from_numpy(rb_loc).to(device if device is not None else "cpu"); dist.all_reduce(t_); rb_loc = t_.cpu().numpy()
+        shards = shard.shard_loci([locus_pipeline.locus_cost(l) + 2 * int(b) for l, b in zip(loci, rb_loc)], world)
+        del wr0
         owner = {}
         for r_, lst in enumerate(shards):
             for i in lst:
                 owner[i] = r_
-        rbuf, roff, rln = D["reads"]
 
         phase = {}                                 # seconds per phase of the LAST pass (exchange, bundle, all-gather)
 
@@ -945,6 +962,7 @@ def main():
                 wr_p = telr_assembly.window_reads(al, chrom_ids, [(l["chrom"], l["start"], l["end"]) for l in loci])
                 names_p = [l["name"] for l in loci]; ctg = [l["contig"] for l in loci]
                 telr_assembly.polish_consensus(eng, names_p[:8], ctg[:8], [w.astype(np.int32) for w in wr_p[:8]], presets=presets_arg, read_set=qs)      # sizes the scratch
+                telr_assembly.polish_consensus(eng, names_p[:8], ctg[:8], [w.astype(np.int32) for w in wr_p[:8]], presets=presets_arg, read_set=qs, method="poa")      # (and the POA kernel's first launch: 4 s in one run of round 5)
                 sync(); t0p = time.time()
                 pol = telr_assembly.polish_consensus(eng, names_p, ctg, [w.astype(np.int32) for w in wr_p], presets=presets_arg, read_set=qs)
                 sync(); tp = time.time() - t0p

@@ -3155,12 +3155,15 @@ __global__ void __launch_bounds__(64) k_dp_pkx16(DpArgs A)
     else d_dp_pkr<16, 1, true>(A, A.list, A.nlist, blockIdx.x * 4);
 }
 
-// the wider extension bands (classes 23 / 24: D <= 128 / 256), eight / sixteen lanes per problem, same cell, same spill layout rule
+// the wider extension bands (classes 23 / 24: D <= 128 / 256), same cell, same spill layout rule (32 / 64 dwords per row)
+#ifndef PKX8_LPP
+#define PKX8_LPP 8           /* lanes per problem of class 23: 8 lanes x 4 registers; 4 x 8 (16 problems per wave, 132 VGPRs) measured slower: 15.1 vs 11.7 ms per range */
+#endif
 __global__ void __launch_bounds__(64) k_dp_pkx_w8(DpArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
-    if (A.o.cx_scale) d_dp_pkr<8, 4, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * 8);
-    else d_dp_pkr<8, 4, true>(A, A.list, A.nlist, blockIdx.x * 8);
+    if (A.o.cx_scale) d_dp_pkr<PKX8_LPP, 32 / PKX8_LPP, true, 1, 0, false, false, false, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX8_LPP));
+    else d_dp_pkr<PKX8_LPP, 32 / PKX8_LPP, true>(A, A.list, A.nlist, blockIdx.x * (64 / PKX8_LPP));
 }
 __global__ void __launch_bounds__(64) k_dp_pkx_w16(DpArgs A)
 {

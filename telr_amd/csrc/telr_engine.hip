@@ -1530,7 +1530,7 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         else if (c == 21) hipLaunchKernelGGL((k_dp_pkw<4>), dim3(nl), dim3(256), 0, s2, D);
         else if (c == 20) hipLaunchKernelGGL((k_dp_pkw<2>), dim3(nl), dim3(128), 0, s2, D);
         else if (c == 19) hipLaunchKernelGGL((k_dp_pkw<1>), dim3(nl), dim3(64), 0, s2, D);
-        else if (c == 23) hipLaunchKernelGGL(k_dp_pkx_w8, dim3((nl + 7) / 8), dim3(64), 0, s2, D);
+        else if (c == 23) { const int ppw = 64 / PKX8_LPP; hipLaunchKernelGGL(k_dp_pkx_w8, dim3((nl + ppw - 1) / ppw), dim3(64), 0, s2, D); }
         else if (c == 24) hipLaunchKernelGGL(k_dp_pkx_w16, dim3((nl + 3) / 4), dim3(64), 0, s2, D);
         else if (nl < 8192) hipLaunchKernelGGL(k_dp_pkx16, dim3((nl + 3) / 4), dim3(64), 0, s2, D);       // few problems: latency counts
         else { const int ppw = 64 / PKX_LPP; hipLaunchKernelGGL(k_dp_pkx, dim3((nl + ppw - 1) / ppw), dim3(64), 0, s2, D); }

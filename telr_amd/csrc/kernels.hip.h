@@ -831,7 +831,10 @@ __global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q
     for (int o = 32; o >= 1; o >>= 1) s += (int64_t)((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)s, o) | (uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)((uint64_t)s >> 32), o) << 32);
     if (lane == 0) q_hits[q] = s;
 }
-struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[4]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
+#ifndef VOTE_WIN
+#define VOTE_WIN 8                 /* windows of 64 hits whose occurrence loads are in flight together */
+#endif
+struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[2 * VOTE_WIN]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
 struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
 // The vote table of a wave: 2,048 counters.  T16: two 16-bit counters per word -- half the LDS, 12 instead of 9 waves per CU -- for
 // queries whose hits cannot overflow one (the kernel is launched twice: queries with at most `lim16` hits here, the others with
@@ -840,6 +843,11 @@ template <bool T16> __device__ __forceinline__ uint32_t d_vt_add(uint32_t *T, ui
 {
     if (T16) { const uint32_t sh = (s & 1u) << 4; return ((atomicAdd(&T[s >> 1], 1u << sh) >> sh) & 0xffffu) + 1u; }
     return atomicAdd(&T[s], 1u) + 1u;
+}
+template <bool T16> __device__ __forceinline__ void d_vt_vote(uint32_t *T, uint32_t s)
+{
+    if (T16) (void)__hip_atomic_fetch_add(&T[s >> 1], 1u << ((s & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else (void)__hip_atomic_fetch_add(&T[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <bool T16> __device__ __forceinline__ uint32_t d_vt_get(const uint32_t *T, uint32_t s)
 {
@@ -936,43 +944,49 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                     uint32_t cb = 0;              // lists that start before the current window
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t H = (uint32_t)__shfl((int)inc, 63);
-                    // the walk: two windows of 64 hits per trip
-                    for (uint32_t h0 = 0; h0 < H; h0 += 128) {
-                        uint32_t m_[2], gp_[2], sl_[2], rv_[2]; bool in_[2]; uint32_t py_[2];
-                        // list starts inside the two windows
-                        if (lane < 4) C.wm[lane] = 0;
+                    // the walk: VOTE_WIN windows of 64 hits per trip.  Round 5: EIGHT windows (four before): with in-kernel clocks a trip of two
+                    // windows took 3,700 cycles -- one scattered-load latency of the loaded part: a trip decodes its hits' lists, ASKS for their
+                    // occurrences and waits -- and a sub-read (430 hits on average) made four of them in a row; now a sub-read's occurrence
+                    // loads go out together (SQ_WAIT_ANY was 60 % of the kernel's wave cycles) and are consumed window by window as they arrive.
+                    for (uint32_t h0 = 0; h0 < H; h0 += 64 * VOTE_WIN) {
+                        uint32_t m_[VOTE_WIN], py_[VOTE_WIN]; bool in_[VOTE_WIN];
+                        // list starts inside the windows of this trip
+                        if (lane < 2 * VOTE_WIN) C.wm[lane] = 0;
                         __builtin_amdgcn_wave_barrier();
                         { const uint32_t d0 = st0 - h0, d1 = st1 - h0;
-                          if (n2[0] && d0 < 128u) atomicOr(&C.wm[d0 >> 5], 1u << (d0 & 31));
-                          if (n2[1] && d1 < 128u) atomicOr(&C.wm[d1 >> 5], 1u << (d1 & 31)); }
+                          if (n2[0] && d0 < 64u * VOTE_WIN) atomicOr(&C.wm[d0 >> 5], 1u << (d0 & 31));
+                          if (n2[1] && d1 < 64u * VOTE_WIN) atomicOr(&C.wm[d1 >> 5], 1u << (d1 & 31)); }
                         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < VOTE_WIN; ++u) {
                             const uint32_t h = h0 + 64 * u + lane;
                             in_[u] = h < H; m_[u] = 0; py_[u] = 0;
-                            const uint64_t wmask = (uint64_t)C.wm[2 * u + 1] << 32 | C.wm[2 * u];
-                            const uint32_t upto = (uint32_t)__popcll(wmask & ((2ULL << lane) - 1ULL));
-                            if (in_[u]) {
-                                const uint32_t m = C.rid[cb + upto - 1u];
-                                const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
-                                m_[u] = m;
-                                py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
+                            if (h0 + 64 * u < H) {          // (wave-uniform: a window past the last hit asks for nothing)
+                                const uint64_t wmask = (uint64_t)C.wm[2 * u + 1] << 32 | C.wm[2 * u];
+                                const uint32_t upto = (uint32_t)__popcll(wmask & ((2ULL << lane) - 1ULL));
+                                if (in_[u]) {
+                                    const uint32_t m = C.rid[cb + upto - 1u];
+                                    const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
+                                    m_[u] = m;
+                                    py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
+                                }
+                                cb += (uint32_t)__popcll(wmask);
                             }
-                            cb += (uint32_t)__popcll(wmask);
                         }
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
+                        for (int u = 0; u < VOTE_WIN; ++u) {
+                            if (h0 + 64 * u >= H) break;
                             const uint32_t h = h0 + 64 * u + lane;
-                            bool pass_hit = false;
+                            bool pass_hit = false; uint32_t gp_ = 0, rv_ = 0;
                             if (in_[u]) {
                                 const uint32_t m = m_[u], zs = C.zs[m], span = zs & 0xffu, qpos = C.qpos[m];
-                                rv_[u] = (py_[u] & 1u) ^ (zs >> 8); gp_[u] = py_[u] >> 1;
-                                const uint32_t qadj = rv_[u] ? (uint32_t)qlen - (qpos + 1 - span) - 1 : qpos;
-                                sl_[u] = d_vote_slot(gp_[u], qadj, rv_[u], V.shift);
+                                rv_ = (py_[u] & 1u) ^ (zs >> 8); gp_ = py_[u] >> 1;
+                                const uint32_t qadj = rv_ ? (uint32_t)qlen - (qpos + 1 - span) - 1 : qpos;
+                                const uint32_t sl_ = d_vote_slot(gp_, qadj, rv_, V.shift);
                                 if (pass == 0) {
-                                    const uint32_t c = d_vt_add<T16>(T, sl_[u]); vmax = c > vmax ? c : vmax;
-                                    if (hbase + h < VOTE_HCAP) { VoteHit x; x.gp = gp_[u]; x.sm = sl_[u] | m << 11 | (uint32_t)(gc - g0) / VOTE_MZ << 18; HS[hbase + h] = x; }
-                                } else pass_hit = d_vt_get<T16>(T, (sl_[u] - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl_[u]) + d_vt_get<T16>(T, (sl_[u] + 2u) & (VOTE_SLOTS - 1)) >= thr1;
+                                    d_vt_vote<T16>(T, sl_);          // (no return value: the fullest bin is read off the table afterwards)
+                                    if (hbase + h < VOTE_HCAP) { VoteHit x; x.gp = gp_; x.sm = sl_ | m << 11 | (uint32_t)(gc - g0) / VOTE_MZ << 18; HS[hbase + h] = x; }
+                                } else pass_hit = d_vt_get<T16>(T, (sl_ - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl_) + d_vt_get<T16>(T, (sl_ + 2u) & (VOTE_SLOTS - 1)) >= thr1;
                             }
                             if (pass == 1) {
                                 const uint64_t bm = __ballot(pass_hit);
@@ -981,7 +995,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 base = (uint32_t)__shfl((int)base, 0);
                                 if (pass_hit) {
                                     const uint32_t m = m_[u], zs = C.zs[m], span = zs & 0xffu, qpos = C.qpos[m];
-                                    const uint64_t key = (rv_[u] ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)gp_[u] << 32;
+                                    const uint64_t key = (rv_ ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)gp_ << 32;
                                     out[base + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = key;
                                 }
                             }
@@ -991,7 +1005,11 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                 }
                 if (pass == 0) {
                     nhit = hbase;
-                    for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)vmax, o); vmax = v > vmax ? v : vmax; }
+                    if (nhit > VOTE_HCAP) {          // (rare: the second walk needs the fullest bin first -- one sweep over the table)
+                        __builtin_amdgcn_wave_barrier();
+                        for (int i = lane; i < TW; i += 64) { const uint32_t w_ = T[i]; const uint32_t a_ = T16 ? (w_ & 0xffffu) : w_, b_ = T16 ? (w_ >> 16) : 0u; vmax = a_ > vmax ? a_ : vmax; vmax = b_ > vmax ? b_ : vmax; }
+                        for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)vmax, o); vmax = v > vmax ? v : vmax; }
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -999,30 +1017,55 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
             if (nhit <= VOTE_HCAP) {
                 // ---- survivors from the remembered hits.  The minimizer data of a remembered hit is read from the mz arrays again
                 // (the LDS chunk holds only the last 128 minimizers): qpos / span / strand by minimizer index g0 + chunk * 128 + m
+                // Round 5: the votes are fire-and-forget additions (no returned count to wait for in the walk); here the groups of 64 remembered
+                // hits are read TOGETHER -- the hit, its bin and the two neighbours: independent LDS reads, back to back -- the fullest bin
+                // is the largest centre count any hit sees (every voted bin is some hit's bin), the survivors of the whole sub-read take
+                // their place in the query's piece with ONE addition to the block's cursor, then the keys are written.
+                constexpr int NG = VOTE_HCAP / 64;
+                VoteHit xs[NG]; uint32_t s3[NG]; uint32_t cmax = 0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    xs[g].gp = 0; xs[g].sm = 0; s3[g] = 0;
+                    if ((uint32_t)(g * 64) < nhit) {
+                        const uint32_t h = (uint32_t)(g * 64) + lane;
+                        if (h < nhit) {
+                            xs[g] = HS[h];
+                            const uint32_t sl = xs[g].sm & (VOTE_SLOTS - 1);
+                            const uint32_t c_ = d_vt_get<T16>(T, sl);
+                            s3[g] = d_vt_get<T16>(T, (sl - 2u) & (VOTE_SLOTS - 1)) + c_ + d_vt_get<T16>(T, (sl + 2u) & (VOTE_SLOTS - 1));
+                            cmax = c_ > cmax ? c_ : cmax;
+                        }
+                    }
+                }
+                for (int o = 32; o >= 1; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)cmax, o); cmax = v > cmax ? v : cmax; }
+                vmax = cmax;
                 uint32_t thr = (vmax * (uint32_t)V.frac_q8 + 255u) >> 8;
                 if (thr < (uint32_t)V.vmin) thr = (uint32_t)V.vmin;
-                for (uint32_t h0 = 0; h0 < nhit; h0 += 64) {
-                    const uint32_t h = h0 + lane;
-                    bool pass_hit = false; VoteHit x; x.gp = 0; x.sm = 0;
-                    if (h < nhit) {
-                        x = HS[h];
-                        const uint32_t sl = x.sm & (VOTE_SLOTS - 1);
-                        pass_hit = d_vt_get<T16>(T, (sl - 2u) & (VOTE_SLOTS - 1)) + d_vt_get<T16>(T, sl) + d_vt_get<T16>(T, (sl + 2u) & (VOTE_SLOTS - 1)) >= thr;
-                    }
-                    const uint64_t bm = __ballot(pass_hit);
-                    uint32_t base = 0;
-                    if (lane == 0 && bm) base = atomicAdd(&blk_cnt, (uint32_t)__popcll(bm));
-                    base = (uint32_t)__shfl((int)base, 0);
-                    if (pass_hit) {
-                        // qpos / span of the hit's minimizer: still in the LDS chunk when the sub-read is ONE chunk (nearly always:
-                        // 256 bases hold ~85 (w,k) = (5,13) minimizers), else from the arrays again
-                        const uint32_t mi = (x.sm >> 11) & (VOTE_MZ - 1);
-                        uint32_t span, qpos;
-                        if (one_chunk) { span = C.zs[mi] & 0xffu; qpos = C.qpos[mi]; }
-                        else { const int g = g0 + (int)(x.sm >> 18) * VOTE_MZ + (int)mi; span = (uint32_t)(A.mz_x[g] & 0xff); qpos = A.mz_y[g] >> 1; }
-                        const uint32_t rev = x.sm & 1u;
-                        const uint64_t key = (rev ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)x.gp << 32;
-                        out[base + (uint32_t)__popcll(bm & ((1ULL << lane) - 1ULL))] = key;
+                uint64_t bm[NG]; uint32_t tot = 0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    bm[g] = 0;
+                    if ((uint32_t)(g * 64) < nhit) { bm[g] = __ballot((uint32_t)(g * 64) + lane < nhit && s3[g] >= thr); tot += (uint32_t)__popcll(bm[g]); }
+                }
+                uint32_t base = 0;
+                if (lane == 0 && tot) base = atomicAdd(&blk_cnt, tot);
+                base = (uint32_t)__shfl((int)base, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if ((uint32_t)(g * 64) < nhit) {
+                        if ((bm[g] >> lane) & 1ULL) {
+                            // qpos / span of the hit's minimizer: still in the LDS chunk when the sub-read is ONE chunk (nearly always:
+                            // 256 bases hold ~85 (w,k) = (5,13) minimizers), else from the arrays again
+                            const VoteHit x = xs[g];
+                            const uint32_t mi = (x.sm >> 11) & (VOTE_MZ - 1);
+                            uint32_t span, qpos;
+                            if (one_chunk) { span = C.zs[mi] & 0xffu; qpos = C.qpos[mi]; }
+                            else { const int gq = g0 + (int)(x.sm >> 18) * VOTE_MZ + (int)mi; span = (uint32_t)(A.mz_x[gq] & 0xff); qpos = A.mz_y[gq] >> 1; }
+                            const uint32_t rev = x.sm & 1u;
+                            const uint64_t key = (rev ? (1ULL << 63) | (uint64_t)((uint32_t)qlen - (qpos + 1 - span) - 1) << 8 : (uint64_t)qpos << 8) | (uint64_t)span | (uint64_t)x.gp << 32;
+                            out[base + (uint32_t)__popcll(bm[g] & ((1ULL << lane) - 1ULL))] = key;
+                        }
+                        base += (uint32_t)__popcll(bm[g]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();

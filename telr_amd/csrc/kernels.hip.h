@@ -834,6 +834,18 @@ __global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q
 #ifndef VOTE_WIN
 #define VOTE_WIN 8                 /* windows of 64 hits whose occurrence loads are in flight together */
 #endif
+// inclusive prefix sum over the 64 lanes of a wave with DPP moves only (gfx9 pattern: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast:15
+// into rows 1 and 3 and row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ uint32_t d_wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
+    return v;
+}
 struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[2 * VOTE_WIN]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
 struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
 // The vote table of a wave: 2,048 counters.  T16: two 16-bit counters per word -- half the LDS, 12 instead of 9 waves per CU -- for
@@ -930,8 +942,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
 #pragma unroll
                     for (int u = 0; u < 2; ++u) { C.off[2 * lane + u] = c_off[u]; C.qpos[2 * lane + u] = c_y[u] >> 1; C.zs[2 * lane + u] = (uint16_t)((c_y[u] & 1u) << 8 | (c_sp[u] & 0xffu)); }
                     uint32_t inc = n2[0] + n2[1];
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += v; }
+                    inc = d_wave_scan_add(inc);          // (DPP row shifts + the two row broadcasts: no LDS round trips; six ds_bpermute before)
                     C.P[2 * lane] = inc - n2[1]; C.P[2 * lane + 1] = inc;
                     // the minimizers that have hits, in order (rid), and where this lane's two lists start: a hit's list is then found
                     // by counting list starts up to it -- bits of one 64-bit word per window -- instead of bisecting the prefix sums
@@ -943,7 +954,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                     const uint32_t st0 = inc - n2[0] - n2[1], st1 = inc - n2[1];
                     uint32_t cb = 0;              // lists that start before the current window
                     __builtin_amdgcn_wave_barrier();
-                    const uint32_t H = (uint32_t)__shfl((int)inc, 63);
+                    const uint32_t H = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                     // the walk: VOTE_WIN windows of 64 hits per trip.  Round 5: EIGHT windows (four before): with in-kernel clocks a trip of two
                     // windows took 3,700 cycles -- one scattered-load latency of the loaded part: a trip decodes its hits' lists, ASKS for their
                     // occurrences and waits -- and a sub-read (430 hits on average) made four of them in a row; now a sub-read's occurrence

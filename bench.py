@@ -286,7 +286,7 @@ def bam_leg_run(a, rank, D, ix, qs, mo, eng, n_bases, sync, dist, device, torch,
         job = job_bam_run(a, rank, D, ix, qs, mo, eng, sync, dist, device, torch, np, bam_dir)
     return {"job_bam": job, "bam_sha256": sha, "inflated_sha256": isha, "writer": a.bam_leg, "level": a.bam_level, "seconds": t_all, "map_seconds": t_map, "bam_seconds": t_all - t_map, "first_pass_seconds": legs[0][1], "seconds_of_each_pass": [x[1] for x in legs[1:]],
                "stage_ms": ix.bam_stage_ms() if a.bam_leg == "device" else None, "cigars_resident": bool(eng.L.telr_debug_bam_twin()) if a.bam_leg == "device" else None, "bam_bytes": sz, "gbp_per_s_incl_bam": ab / t_all / 1e9, "path": bam_path,
-               "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s; this rank's reads (at N > 1 the job's ONE file is `job_bam`); median of three passes after a first one that sizes and pins the writer's buffers" % bam_dir}
+               "what": "reads resident in HBM -> telr_map -> coordinate-sorted BAM (--cs --MD -Y, SEQ + QUAL 0xff) + .bai under %s (tmpfs when that is /dev/shm: no disk in the figure); this rank's reads (at N > 1 the job's ONE file is `job_bam`); median of three passes after a first one that sizes and pins the writer's buffers" % bam_dir}
 
 
 def file_sha256(path):

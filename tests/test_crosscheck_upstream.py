@@ -130,3 +130,25 @@ def test_leg_with_fake_tools_on_path(monkeypatch, tmp_path):
     assert any(l.split()[1:7] == ["-cx", "asm10", "-v", "0", "-N", "10"] for l in seen)
     bt = out["bedtools"]
     assert bt["cases"] == 21 and bt["bedtools_equals_intervals_py"] == 21 and bt["bedtools_equals_hand_derived"] == 21 and not bt["differing"]
+
+
+def test_samtools_leg_with_a_fake_binary(monkeypatch, tmp_path):
+    """`samtools quickcheck / view -c / idxstats` on a BAM the library wrote (here: a stand-in file and a fake samtools that answers like one)"""
+    bindir = tmp_path / "bin"; bindir.mkdir()
+    _fake(str(bindir), "samtools", "import sys\na = sys.argv[1:]\n"
+          "if a[0] == 'quickcheck': sys.exit(0)\n"
+          "if a[0] == 'view' and a[1] == '-c': print(19); sys.exit(0)\n"
+          "if a[0] == 'idxstats': print('ref\\t38000\\t19\\t0'); print('*\\t0\\t0\\t6'); sys.exit(0)\n"
+          "sys.exit(2)\n")
+    monkeypatch.setenv("PATH", str(bindir))
+    work = tmp_path / "work"; work.mkdir()
+
+    def bam_writer(ref_fa, reads_fa, bam_path):
+        assert ref_fa.endswith("ref_38kb.fasta") and reads_fa.endswith("reads.fasta")
+        open(bam_path, "wb").write(b"BAM\1"); open(bam_path + ".bai", "wb").write(b"BAI\1")
+        return 19
+    out = xc.reference_cpu_path(ours=None, threads=2, workdir=str(work), bam_writer=bam_writer)
+    json.dumps(out)
+    assert out["available"] and list(out["found"]) == ["samtools"] and out["shapes"] == []
+    st = out["samtools"]
+    assert st["quickcheck_exit_code"] == 0 and st["view_c"] == 19 and st["count_matches"] is True and st["idxstats_mapped"] == 19

@@ -352,7 +352,7 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
         if (s == "ngmlr-ont") { mo->a = 2; mo->b = 2; mo->q = 2; mo->e = 2; mo->q2 = 4; mo->e2 = 1; mo->cx_scale = 10; mo->cx_open = 20; mo->cx_ext_max = 20; mo->cx_ext_min = 10; mo->cx_decay = 3; }
         else { mo->a = 2; mo->b = 5; mo->q = 6; mo->e = 4; mo->q2 = 60; mo->e2 = 1; mo->cx_scale = 20; mo->cx_open = 100; mo->cx_ext_max = 100; mo->cx_ext_min = 20; mo->cx_decay = 3; }
         mo->fill_band_q4 = 12; mo->fill_margin = 2;
-        if (s == "ngmlr-ont") { mo->fill_band_q4 = 7; mo->fill_margin = 4; mo->ext_band = 63; }      // round 5: see telr_amd/presets.py (fills: same results, 18 % fewer cells; extensions: the 0.5 % rule)
+        if (s == "ngmlr-ont") { mo->fill_band_q4 = 7; mo->fill_margin = 4; mo->ext_band = 63; mo->zdrop = 100; }      // round 5: see telr_amd/presets.py (fills: same results, 18 % fewer cells; extensions: the 0.5 % rule)
         mo->vote_len = 256; mo->vote_bin_shift = 5; mo->vote_min = 3; mo->vote_frac_q8 = 128;      // NGMLR's sub-read voting
     }
     else if (s == "asm10") {

@@ -260,7 +260,7 @@ def test_faithful_v2_bits(kind, n):
         the spec since round 3 -- section 3.11 -- and the row reads 0.00 %: the one-pass chaining within bw_long equals minimap2's
         two rounds with look-back 5000 on every record of the samples.);
     (Round 5: the row "full-band fills + uncapped extensions" of ngmlr-ont is no longer exempt -- its extension band is +-63 and its
-    fill band (7, 4) since then: 0.46 % of the records' coordinates on the 1,080-record sample, profiles/r05_faithful_table.md.)
+    fill band (7, 4) and its z-drop 100 since then: 0.20 % of the records' coordinates on 4,881 records, profiles/r05_faithful_table.md.)
     The row "the two-piece envelope instead of NGMLR's convex gap cost" (a13): the exact form IS the spec of both presets since
     round 4; the row states what the round-3 envelope moved (ngmlr-pacbio 0.18 % of 4,940 records' coordinates, ngmlr-ont 3.2 %:
     listed in EXPLAINED for `ont`)."""

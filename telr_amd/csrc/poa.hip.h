@@ -31,6 +31,8 @@
 #define POA_M       3
 #define POA_X       (-5)
 #define POA_G       (-4)
+#define POA_RING    16      /* rows of the sweep kept in LDS: a predecessor at most that many ranks back is read from there */
+#define POA_SPEC    16      /* steps the walk back guesses per trip */
 
 struct PoaPiece { int32_t qid, qa, len, rev; };           // query bases [qa, qa + len) on the alignment strand
 struct PoaArgs {
@@ -78,6 +80,22 @@ __device__ __forceinline__ int d_poa_cell(const int16_t *H, const int16_t *lo, i
     return (jj < 0 || jj >= POA_BAND || j > n) ? -32000 : H[(size_t)(row - 1) * POA_BAND + jj];
 }
 
+// inclusive prefix maximum over the wave (DPP row shifts + the two row broadcasts; a lane without a source takes the identity: the compiler folds move and maximum into one v_max_i32_dpp)
+__device__ __forceinline__ int d_wave_scan_max(int v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp((int)0x80000000, v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+    return v;
+}
+// lane i reads lane i + 1 / lane i - 1 of the whole wave (a lane without a source gets `fill`)
+__device__ __forceinline__ int d_wave_shl1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int d_wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+
 __device__ __forceinline__ int d_poa_qbase(const PoaArgs &A, const PoaPiece &P, int x)
 {
     // base x of the piece on the alignment strand (a reverse record reads its query mirrored and complemented)
@@ -88,11 +106,21 @@ __device__ __forceinline__ int d_poa_qbase(const PoaArgs &A, const PoaPiece &P, 
     return b;
 }
 
+#ifdef POA_PROF
+__device__ unsigned long long g_poa_prof[16];
+#define POA_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); pf[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define POA_T(i) do { } while (0)
+#endif
 __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
 {
+#ifdef POA_PROF
+    unsigned long long pf[10] = {0,0,0,0,0,0,0,0,0,0}, t_last = __builtin_readcyclecounter();
+#endif
     __shared__ uint8_t seq[POA_SEGMAX + 8];
     __shared__ int32_t sel[POA_MAXSEG];
     __shared__ int32_t sh[8];
+    __shared__ int16_t hring[POA_RING * POA_BAND];
     const int lane = threadIdx.x;
     uint8_t *S = A.scratch + (size_t)blockIdx.x * A.slot_bytes;
     uint8_t *base = S + POA_O_BASE, *nin = S + POA_O_NIN;
@@ -122,6 +150,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             __syncthreads();
             continue;
         }
+        POA_T(0);
         // ---- the graph starts as the draft's window
         int n = L;
         for (int v = lane; v < L; v += 64) {
@@ -130,6 +159,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             if (v) { in[v * POA_MAXIN] = (int16_t)(v - 1); inw[v * POA_MAXIN] = 1; }
         }
         __syncthreads();
+        POA_T(1);
         for (int si = 0; si < nsel; ++si) {
             const PoaPiece P = A.pieces[sel[si]];
             const int m = P.len;
@@ -153,26 +183,56 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             // row just stored to come back from L2 was most of a step; rows further back are read from the slot.  Every cell also
             // notes where its value came from, by the walk's own preference (diagonal before skipped node before inserted base, the
             // first predecessor that explains it): the walk back then reads one byte per step instead of all candidates again.
-            int nx_cb = pcb[0], nx_lo = lo_r[0]; uint32_t nx_p01 = *(const uint32_t*)&prow[0], nx_l01 = *(const uint32_t*)&pplo[0];
+            POA_T(2);
+            // Round 5: the four per-rank tables reach the sweep 64 ranks at a time (lane i holds rank rb + i; a row reads them with
+            // v_readlane), the batch after the running one already asked for: one load latency per 64 rows instead of one per row.
+            // The in-row gap chain is a DPP prefix maximum, the row before is shifted by 0 / 1 / 2 lanes with DPP moves (no LDS
+            // round trips), and the last POA_RING rows also stay in LDS: a predecessor a few ranks back -- the other arm of a
+            // bubble -- is read from there; only a predecessor further back waits for the row stored in the slot.
+            int c_cb = 0, c_lo = 0, n_cb = 0, n_lo = 0; uint32_t c_p01 = 0, c_l01 = 0, n_p01 = 0, n_l01 = 0;
+            if (lane < n) { n_cb = pcb[lane]; n_lo = lo_r[lane]; n_p01 = *(const uint32_t*)&prow[lane * POA_MAXIN]; n_l01 = *(const uint32_t*)&pplo[lane * POA_MAXIN]; }
             int prev_val = -32000, prev_lo = 0;
-            for (int r = 0; r < n; ++r) {
-                const int cb = __builtin_amdgcn_readfirstlane(nx_cb), np_ = cb >> 8, vb = cb & 0xff, lo = __builtin_amdgcn_readfirstlane(nx_lo), j = lo + lane;
-                const uint32_t p01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_p01), l01 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx_l01);
-                if (r + 1 < n) { nx_cb = pcb[r + 1]; nx_lo = lo_r[r + 1]; nx_p01 = *(const uint32_t*)&prow[(r + 1) * POA_MAXIN]; nx_l01 = *(const uint32_t*)&pplo[(r + 1) * POA_MAXIN]; }
+            // (two loops: the batch in flight must not be a value the ROW loop carries -- the compiler then copies it every row behind
+            // an s_waitcnt vmcnt(0), which also waits for the row's stores: one store latency per row, 4,500 cycles measured)
+            for (int rb = 0; rb < n; rb += 64) {
+                c_cb = n_cb; c_lo = n_lo; c_p01 = n_p01; c_l01 = n_l01;
+                { const int rr = rb + 64 + lane;
+                  if (rr < n) { n_cb = pcb[rr]; n_lo = lo_r[rr]; n_p01 = *(const uint32_t*)&prow[rr * POA_MAXIN]; n_l01 = *(const uint32_t*)&pplo[rr * POA_MAXIN]; } }
+                const int rcnt = n - rb < 64 ? n - rb : 64;
+            for (int ri = 0; ri < rcnt; ++ri) {
+                const int r = rb + ri;
+                const int cb = __builtin_amdgcn_readlane(c_cb, ri), np_ = cb >> 8, vb = cb & 0xff, lo = __builtin_amdgcn_readlane(c_lo, ri), j = lo + lane;
+                const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)c_p01, ri), l01 = (uint32_t)__builtin_amdgcn_readlane((int)c_l01, ri);
                 const int sb = j > 0 && j <= m ? seq[j - 1] : 4;
                 const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
                 int vmax = -1000000, vk = 0, dmax = -1000000, dk = 0;
                 bool synced = false;
+                const int dl0 = lo - prev_lo;
+                if (r > 0 && np_ == 1 && (int)(p01 & 0xffffu) == r && (unsigned)dl0 <= 1u) {
+                    // the common row, straight-line: one predecessor, the row before, its band 0 or 1 columns to the left
+                    const int s_r = d_wave_shr1(prev_val, -32000), s_l = d_wave_shl1(prev_val, -32000);
+                    vmax = (dl0 ? s_l : prev_val) + POA_G;
+                    if (j > 0) dmax = (dl0 ? prev_val : s_r) + sc;
+                } else
                 for (int k = 0; k < np_; ++k) {
                     const int pr = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : __builtin_amdgcn_readfirstlane((int)prow[r * POA_MAXIN + k]);
                     const int pl = k == 0 ? (int)(l01 & 0xffffu) : k == 1 ? (int)(l01 >> 16) : __builtin_amdgcn_readfirstlane((int)pplo[r * POA_MAXIN + k]);
                     int vj, vj1;
                     if (pr == 0) { vj = j * POA_G; vj1 = (j - 1) * POA_G; }
                     else if (pr == r) {                          // the row before: registers
-                        const int jj = j - prev_lo;
-                        const int a = __shfl(prev_val, jj & 63), b = __shfl(prev_val, (jj - 1) & 63);
+                        const int dl = lo - prev_lo, jj = lane + dl;
+                        int a, b;
+                        if (dl == 0) { a = prev_val; b = d_wave_shr1(prev_val, -32000); }
+                        else if (dl == 1) { a = d_wave_shl1(prev_val, -32000); b = prev_val; }
+                        else if (dl == 2) { b = d_wave_shl1(prev_val, -32000); a = d_wave_shl1(b, -32000); }
+                        else { a = __shfl(prev_val, jj & 63); b = __shfl(prev_val, (jj - 1) & 63); }
                         vj = (jj >= 0 && jj < POA_BAND) ? a : -32000;
                         vj1 = (jj >= 1 && jj <= POA_BAND) ? b : -32000;
+                    } else if (r - (pr - 1) <= POA_RING) {       // a few ranks back: the ring in LDS
+                        const int jj = j - pl;
+                        const int16_t *rw = hring + ((pr - 1) & (POA_RING - 1)) * POA_BAND;
+                        vj = (jj >= 0 && jj < POA_BAND) ? rw[jj] : -32000;
+                        vj1 = (jj >= 1 && jj <= POA_BAND) ? rw[jj - 1] : -32000;
                     } else {
                         if (!synced) { __syncthreads(); synced = true; }        // (rows stored by other lanes of this wave)
                         const int jj = j - pl;
@@ -185,17 +245,18 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 }
                 int t = vmax > dmax ? vmax : dmax; t = t > -32000 ? t : -32000;
                 // row[j] = max over the band's k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
-                int u = j <= m ? t - j * POA_G : -1000000;
-#pragma unroll
-                for (int s_ = 1; s_ < 64; s_ <<= 1) { const int o = __shfl_up(u, s_); if (lane >= s_) u = o > u ? o : u; }
+                const int u = d_wave_scan_max(j <= m ? t - j * POA_G : -1000000);
                 const int cur = (int)(int16_t)(u + j * POA_G);
                 if (j <= m) {
                     H[(size_t)r * POA_BAND + lane] = (int16_t)cur;
-                    TB[(size_t)r * POA_BAND + lane] = (uint8_t)(j > 0 && dmax == cur ? dk : vmax == cur ? 8 | vk : 16);
+                    TB[(size_t)r * POA_BAND + (j & (POA_BAND - 1))] = (uint8_t)(j > 0 && dmax == cur ? dk : vmax == cur ? 8 | vk : 16);      // (the walk back finds a column's note without the row's band)
                 }
                 prev_val = j <= m ? cur : -32000; prev_lo = lo;
+                hring[(r & (POA_RING - 1)) * POA_BAND + lane] = (int16_t)prev_val;
+            }
             }
             __syncthreads();
+            POA_T(3);
             // ---- the end: the node without out-edges whose last column scores best, smallest id on ties
             {
                 int bs = -32768, bv = 0x7fffffff;
@@ -205,24 +266,58 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 if (lane == 0) sh[0] = bv == 0x7fffffff ? -1 : bv;
             }
             __syncthreads();
-            if (lane == 0) {
-                // ---- walk back along the notes of the sweep (pn holds ROW numbers here, 0 = no node; turned into nodes below)
+            POA_T(4);
+            {
+                // ---- walk back along the notes of the sweep (pn holds ROW numbers here, 0 = no node; turned into nodes below).
+                // Round 5: the whole wave walks.  One step at a time from lane 0 was two dependent loads from the slot per step (the
+                // note, then the predecessor's row): ~800 round trips to memory per piece, most of the kernel.  Now a trip GUESSES the
+                // next POA_SPEC steps -- diagonal moves along first predecessors, the common run between two differences -- lane l
+                // taking step l: the rows come from a window of the first-predecessor table held in registers (64 ranks, followed with
+                // v_readlane), the notes of all guessed cells are loaded at once, and the steps up to the first note that is not
+                // "diagonal from the first predecessor" are emitted together; that one step is then taken as noted.
                 int np = 0, j = m;
-                int r = sh[0] >= 0 ? rank[sh[0]] : 0, lo = r ? lo_r[r - 1] : 0;
+                int r = __builtin_amdgcn_readfirstlane(sh[0] >= 0 ? (int)rank[sh[0]] : 0);
+                int wbase = -1; uint32_t pp = 0;                  // lane i: rows of the first two predecessors of row wbase - i
                 for (int it = 0; (r > 0 || j > 0) && j >= 0 && it < 2 * POA_NPATH; ++it) {        // (the bounds only keep a broken slot from hanging the device)
-                    const int jj = j - lo;
-                    const int tb = r > 0 && jj >= 0 && jj < POA_BAND ? TB[(size_t)(r - 1) * POA_BAND + jj] : 16;
-                    if (tb < 16) {
-                        const int k = tb & 7, nr = prow[(r - 1) * POA_MAXIN + k], nlo = pplo[(r - 1) * POA_MAXIN + k];
-                        if (tb < 8) { pn[np] = (int16_t)r; pj[np] = (int16_t)(j - 1); ++np; --j; }
-                        r = nr; lo = nlo;
-                    } else { pn[np] = 0; pj[np] = (int16_t)(j - 1); ++np; --j; }
+                    if (r == 0) {                                  // bases before the graph's start
+                        for (int x = lane; x < j; x += 64) { pn[np + x] = 0; pj[np + x] = (int16_t)(j - 1 - x); }
+                        np += j; j = 0; break;
+                    }
+                    if (wbase < 0 || wbase - r > 63) { wbase = r; const int rr = r - lane; pp = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }
+                    int mine = 0, c = r, len = 0;
+                    for (int l = 0; l < POA_SPEC; ++l) {
+                        if (c == 0 || wbase - c > 63 || l > j) break;
+                        if (lane == l) mine = c;
+                        ++len;
+                        c = (int)((uint32_t)__builtin_amdgcn_readlane((int)pp, wbase - c) & 0xffffu);
+                    }
+                    const int jl = j - lane;
+                    int tb = 16;
+                    if (lane < len) {
+                        const int lo_l = lo_r[mine - 1], jj = jl - lo_l;
+                        const int t = TB[(size_t)(mine - 1) * POA_BAND + (jl & (POA_BAND - 1))];
+                        tb = jj >= 0 && jj < POA_BAND ? t : 16;
+                    }
+                    const uint64_t okm = __ballot(lane < len && tb == 0);
+                    const int s_ = (int)__builtin_ctzll(~okm);      // diagonal steps along first predecessors (<= len <= POA_SPEC)
+                    if (lane < s_) { pn[np + lane] = (int16_t)mine; pj[np + lane] = (int16_t)(jl - 1); }
+                    np += s_; j -= s_;
+                    if (s_ == len) { r = c; continue; }
+                    r = __builtin_amdgcn_readlane(mine, s_);
+                    const int tbs = __builtin_amdgcn_readlane(tb, s_);
+                    if (tbs < 16) {
+                        const int k = tbs & 7;
+                        if (tbs < 8) { if (lane == 0) { pn[np] = (int16_t)r; pj[np] = (int16_t)(j - 1); } ++np; --j; }
+                        const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)pp, wbase - r);
+                        r = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : __builtin_amdgcn_readfirstlane((int)prow[(r - 1) * POA_MAXIN + k]);
+                    } else { if (lane == 0) { pn[np] = 0; pj[np] = (int16_t)(j - 1); } ++np; --j; }
                 }
-                sh[3] = np;
+                if (lane == 0) sh[3] = np;
             }
             __syncthreads();
             for (int z = lane; z < sh[3]; z += 64) { const int r = pn[z]; pn[z] = r ? order[r - 1] : (int16_t)-1; }
             __syncthreads();
+            POA_T(5);
             // ---- merge, start -> end (placement rules: see the oracle), as a PARALLEL pass over the path: step t (lane t of a chunk of
             // 64) touches only its own node -- a path visits a column once, so the rings searched / extended by two steps are
             // disjoint, every step's target node u_t and source node u_(t-1) are distinct from every other step's -- and what the serial
@@ -271,6 +366,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                     { const int lastl = np - 1 - t0 < 63 ? np - 1 - t0 : 63; c_prevu = __shfl(u, lastl); }
                     __syncthreads();
                 }
+                POA_T(6);
                 const int nnew = c_new;
                 n = n_old + nnew;
                 if (nnew) {
@@ -286,30 +382,86 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 }
             }
             __syncthreads();
+            POA_T(7);
         }
-        // ---- heaviest bundle between the most common start / end nodes
-        if (lane == 0) {
-            for (int r = 0; r < n; ++r) {
-                const int v = order[r];
-                int bw = -1, bs = -1, b = -1;
-                for (int k = 0; k < nin[v]; ++k) {
-                    const int u = in[v * POA_MAXIN + k], wgt = inw[v * POA_MAXIN + k];
-                    if (wgt > bw || (wgt == bw && score[u] > bs)) { bw = wgt; bs = score[u]; b = u; }
+        POA_T(7);
+        // ---- heaviest bundle between the most common start / end nodes.  Round 5: one step at a time from lane 0 this was four
+        // dependent loads per node and one per step of the way back (2 ms of a window's 10).  Now 64 ranks at a time: every lane
+        // loads its node's in-edges and the ranks / scores of their sources at once; the scores are then settled in rank order
+        // with v_readlane -- a source in the same 64 ranks is read from its lane's register, an earlier one came with
+        // the loads -- and stored by all lanes together; bp[] holds the RANK of the chosen source, so the way back is followed in a
+        // register window as well.
+        for (int r = lane; r < n; r += 64) rank[order[r]] = (int16_t)(r + 1);
+        __syncthreads();
+        for (int r0 = 0; r0 < n; r0 += 64) {
+            const int rr = r0 + lane, cnt = n - r0 < 64 ? n - r0 : 64;
+            int v = 0, c = 0; uint32_t i01 = 0, i23 = 0, w01 = 0, w23 = 0, r01 = 0, r23 = 0; int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if (rr < n) {
+                v = order[rr]; c = nin[v];
+                const uint2 iv = *(const uint2*)&in[v * POA_MAXIN], wv = *(const uint2*)&inw[v * POA_MAXIN];
+                i01 = iv.x; i23 = iv.y; w01 = wv.x; w23 = wv.y;
+                if (c > 0) { const int u = (int)(i01 & 0xffffu); r01 = (uint32_t)(uint16_t)rank[u]; s0 = score[u]; }
+                if (c > 1) { const int u = (int)(i01 >> 16); r01 |= (uint32_t)(uint16_t)rank[u] << 16; s1 = score[u]; }
+                if (c > 2) { const int u = (int)(i23 & 0xffffu); r23 = (uint32_t)(uint16_t)rank[u]; s2 = score[u]; }
+                if (c > 3) { const int u = (int)(i23 >> 16); r23 |= (uint32_t)(uint16_t)rank[u] << 16; s3 = score[u]; }
+            }
+            int sc = 0, bpr = 0;
+            for (int l = 0; l < cnt; ++l) {
+                const int cl_ = __builtin_amdgcn_readlane(c, l);
+                int bw = -1, bs = -1, br = 0;
+                for (int k = 0; k < cl_; ++k) {
+                    int wgt, ru, su;
+                    if (k < 4) {
+                        const uint32_t wp = (uint32_t)__builtin_amdgcn_readlane((int)(k < 2 ? w01 : w23), l), rp = (uint32_t)__builtin_amdgcn_readlane((int)(k < 2 ? r01 : r23), l);
+                        wgt = (int)(int16_t)((k & 1) ? wp >> 16 : wp & 0xffffu); ru = (int)((k & 1) ? rp >> 16 : rp & 0xffffu);
+                        su = __builtin_amdgcn_readlane(k == 0 ? s0 : k == 1 ? s1 : k == 2 ? s2 : s3, l);
+                    } else {
+                        const int vv = __builtin_amdgcn_readlane(v, l);
+                        const int u = __builtin_amdgcn_readfirstlane((int)in[vv * POA_MAXIN + k]);
+                        wgt = __builtin_amdgcn_readfirstlane((int)inw[vv * POA_MAXIN + k]); ru = __builtin_amdgcn_readfirstlane((int)rank[u]); su = __builtin_amdgcn_readfirstlane(score[u]);
+                    }
+                    if (ru - 1 >= r0) su = __builtin_amdgcn_readlane(sc, ru - 1 - r0);      // settled in this pass: not in memory yet
+                    if (wgt > bw || (wgt == bw && su > bs)) { bw = wgt; bs = su; br = ru; }
                 }
-                bp[v] = (int16_t)b; score[v] = b >= 0 ? bs + bw : 0;
+                if (lane == l) { sc = cl_ > 0 ? bs + bw : 0; bpr = br; }
             }
-            int endv = -1, startv = -1;
-            for (int v = 0; v < n; ++v) {
-                if (endv < 0 || endc[v] > endc[endv] || (endc[v] == endc[endv] && score[v] > score[endv])) endv = v;
-                if (startv < 0 || startc[v] > startc[startv]) startv = v;
+            if (rr < n) { score[v] = sc; bp[rr] = (int16_t)bpr; }
+            __syncthreads();
+        }
+        {
+            // the end: most sequences end there, better score, smaller id; the start: most sequences begin there, smaller id
+            int ec = -1, es = -1, ev = 0x7fffffff, stc = -1, stv = 0x7fffffff;
+            for (int v = lane; v < n; v += 64) {
+                const int e = endc[v], sc_ = score[v], st = startc[v];
+                if (e > ec || (e == ec && sc_ > es)) { ec = e; es = sc_; ev = v; }
+                if (st > stc) { stc = st; stv = v; }
             }
-            int cl = 0;
-            for (int v = endv; v >= 0; v = bp[v]) { no[cl++] = (int16_t)v; if (v == startv) break; }
-            for (int i = 0; i < cl; ++i) out[i] = "ACGTN"[base[no[cl - 1 - i]]];
-            A.wlen[w] = cl;
+#pragma unroll
+            for (int x = 32; x >= 1; x >>= 1) {
+                const int oc = __shfl_xor(ec, x), os = __shfl_xor(es, x), ov = __shfl_xor(ev, x), otc = __shfl_xor(stc, x), otv = __shfl_xor(stv, x);
+                if (oc > ec || (oc == ec && (os > es || (os == es && ov < ev)))) { ec = oc; es = os; ev = ov; }
+                if (otc > stc || (otc == stc && otv < stv)) { stc = otc; stv = otv; }
+            }
+            // the way back over ranks (1-based; bp[rank - 1] = rank of the chosen source, 0 = none)
+            int cur = __builtin_amdgcn_readfirstlane((int)rank[ev]); const int rs = __builtin_amdgcn_readfirstlane((int)rank[stv]);
+            int cl = 0, wb = -1, bw_ = 0;                          // lane i: bp of rank wb - i
+            for (int it = 0; cur > 0 && it < POA_MAXNODE; ++it) {
+                if (wb < 0 || wb - cur > 63) { wb = cur; const int q_ = cur - lane; bw_ = q_ >= 1 ? (int)bp[q_ - 1] : 0; }
+                if (lane == 0) no[cl] = (int16_t)cur;
+                ++cl;
+                if (cur == rs) break;
+                cur = __builtin_amdgcn_readlane(bw_, wb - cur);
+            }
+            __syncthreads();
+            for (int i = lane; i < cl; i += 64) out[i] = "ACGTN"[base[order[no[cl - 1 - i] - 1]]];
+            if (lane == 0) A.wlen[w] = cl;
         }
         __syncthreads();
+        POA_T(8);
     }
+#ifdef POA_PROF
+    if (lane == 0) for (int i = 0; i < 10; ++i) atomicAdd(&g_poa_prof[i], pf[i]);
+#endif
 }
 
 __global__ void __launch_bounds__(64) k_poa_pack(const uint8_t *__restrict__ wout, const int64_t *__restrict__ woff, uint8_t *__restrict__ pack)
@@ -428,6 +580,12 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     CK(hipMemcpyAsync(d_woff, woff.data(), ((size_t)nwin + 1) * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_poa_pack, dim3((unsigned)nwin), dim3(64), 0, st, d_wout, d_woff, d_pack);
     CK(hipGetLastError());
+#ifdef POA_PROF
+    { unsigned long long h[16]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_poa_prof), sizeof(h))); unsigned long long z[16] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_poa_prof), z, sizeof(z)));
+      double tot_ = 0; for (int i = 0; i < 9; ++i) tot_ += (double)h[i];
+      static const char *nm[9] = {"select", "init", "setup", "sweep", "end", "walk", "merge", "order", "bundle"};
+      fprintf(stderr, "[poa prof] windows %lld pieces %zu:", (long long)nwin, pieces.size()); for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h[i] / (tot_ > 0 ? tot_ : 1)); fprintf(stderr, "\n"); }
+#endif
     C->seq.resize((size_t)tot);
     if (tot) CK(hipMemcpyAsync(&C->seq[0], d_pack, (size_t)tot, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));

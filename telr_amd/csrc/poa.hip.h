@@ -32,7 +32,7 @@
 #define POA_X       (-5)
 #define POA_G       (-4)
 #define POA_RING    16      /* rows of the sweep kept in LDS: a predecessor at most that many ranks back is read from there */
-#define POA_SPEC    16      /* steps the walk back guesses per trip */
+#define POA_SPEC    64      /* steps the walk back guesses per trip */
 
 struct PoaPiece { int32_t qid, qa, len, rev; };           // query bases [qa, qa + len) on the alignment strand
 struct PoaArgs {
@@ -67,19 +67,12 @@ struct PoaArgs {
 #define POA_O_PCB    (POA_O_PPLO + 2 * POA_MAXNODE * POA_MAXIN)             /* i16 [MAXNODE]: predecessors << 8 | base of the node at rank r */
 #define POA_O_COL    (POA_O_PCB + 2 * POA_MAXNODE)                          /* i16 [MAXNODE]: window column of the node */
 #define POA_O_LO     (POA_O_COL + 2 * POA_MAXNODE)                          /* i16 [MAXNODE]: first column of the band of the node at rank r */
-#define POA_O_H      ((POA_O_LO + 2 * POA_MAXNODE + 255) & ~255)            /* i16 [MAXNODE][POA_BAND]: the banded score matrix (row r = the node at rank r) */
+#define POA_O_HLAST  (POA_O_LO + 2 * POA_MAXNODE)                            /* i16 [MAXNODE]: the last column of the row of rank r (-32000 outside its band) */
+#define POA_O_H      ((POA_O_HLAST + 2 * POA_MAXNODE + 255) & ~255)            /* i16 [MAXNODE][POA_BAND]: the banded score matrix (row r = the node at rank r) */
 #define POA_O_TB     (POA_O_H + 2 * POA_MAXNODE * POA_BAND)                 /* u8  [MAXNODE][POA_BAND]: where a cell's value came from (0-7: diagonal from predecessor k, 8-15: skipped the node, from predecessor k, 16: base inserted) */
 #define POA_SLOT_BYTES ((size_t)POA_O_TB + (size_t)POA_MAXNODE * POA_BAND)
 
 __host__ __device__ __forceinline__ int d_poa_lo(int col, int n, int L) { int lo = (col + 1) * n / L - POA_BAND / 2, hi = n + 1 - POA_BAND; if (lo > hi) lo = hi; return lo < 0 ? 0 : lo; }
-// cell (row, j) of the banded matrix: row 0 = the virtual start, outside a row's band -32000
-__device__ __forceinline__ int d_poa_cell(const int16_t *H, const int16_t *lo, int row, int j, int n)
-{
-    if (row == 0) return j * POA_G;
-    const int jj = j - lo[row - 1];
-    return (jj < 0 || jj >= POA_BAND || j > n) ? -32000 : H[(size_t)(row - 1) * POA_BAND + jj];
-}
-
 // inclusive prefix maximum over the wave (DPP row shifts + the two row broadcasts; a lane without a source takes the identity: the compiler folds move and maximum into one v_max_i32_dpp)
 __device__ __forceinline__ int d_wave_scan_max(int v)
 {
@@ -115,9 +108,12 @@ __device__ unsigned long long g_poa_prof[16];
 __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
 {
 #ifdef POA_PROF
-    unsigned long long pf[10] = {0,0,0,0,0,0,0,0,0,0}, t_last = __builtin_readcyclecounter();
+    unsigned long long pf[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, t_last = __builtin_readcyclecounter();
+#define POA_C(i, x) pf[i] += (x)
+#else
+#define POA_C(i, x) do { } while (0)
 #endif
-    __shared__ uint8_t seq[POA_SEGMAX + 8];
+    __shared__ uint8_t seq[POA_SEGMAX + 72];          // seq[x + 1] = base x of the piece; 7 (equal to no base) in front and for 64 entries behind
     __shared__ int32_t sel[POA_MAXSEG];
     __shared__ int32_t sh[8];
     __shared__ int16_t hring[POA_RING * POA_BAND];
@@ -130,6 +126,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
     int16_t *newv = (int16_t*)(S + POA_O_NEWV), *anchor = (int16_t*)(S + POA_O_ANCH), *H = (int16_t*)(S + POA_O_H);
     int32_t *score = (int32_t*)(S + POA_O_SCORE);
     uint8_t *TB = S + POA_O_TB;
+    int16_t *hlast = (int16_t*)(S + POA_O_HLAST);
     int16_t *prow = (int16_t*)(S + POA_O_PROW), *pplo = (int16_t*)(S + POA_O_PPLO), *pcb = (int16_t*)(S + POA_O_PCB), *col = (int16_t*)(S + POA_O_COL), *lo_r = (int16_t*)(S + POA_O_LO);
     for (int w = blockIdx.x; w < A.nwin; w += gridDim.x) {
         const int tid = A.w_tid[w], w0 = A.w_w0[w], w1 = A.w_w1[w], L = w1 - w0;
@@ -164,19 +161,30 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             const PoaPiece P = A.pieces[sel[si]];
             const int m = P.len;
             if (n + m > POA_MAXNODE) continue;
-            for (int x = lane; x < m; x += 64) seq[x] = (uint8_t)d_poa_qbase(A, P, x);
+            for (int x = lane; x < m; x += 64) seq[x + 1] = (uint8_t)d_poa_qbase(A, P, x);
+            seq[m + 1 + lane] = 7; if (lane == 0) seq[0] = 7;
             for (int r = lane; r < n; r += 64) { const int v = order[r]; rank[v] = (int16_t)(r + 1); lo_r[r] = (int16_t)d_poa_lo(col[v], m, L); }
             __syncthreads();
             // per RANK: the rows of the node's predecessors, the first columns of their bands and (count << 8 | base) -- the sweep reads
             // sequential tables, one node ahead, instead of chasing order -> in-list -> rank inside every step
+            bool far_ = false;                           // a predecessor further back than the LDS ring: the rows go to the slot as well
             for (int r = lane; r < n; r += 64) {
-                const int v = order[r], c = nin[v];
-                pcb[r] = (int16_t)((c ? c : 1) << 8 | base[v]);
-                for (int k = 0; k < (c ? c : 1); ++k) {
+                const int v = order[r], c = nin[v], np = c ? c : 1;
+                bool ring_ = true; int pr0 = 0;
+                for (int k = 0; k < np; ++k) {
                     const int pr = c ? rank[in[v * POA_MAXIN + k]] : 0;
                     prow[r * POA_MAXIN + k] = (int16_t)pr; pplo[r * POA_MAXIN + k] = pr ? lo_r[pr - 1] : 0;
+                    far_ |= pr && r - (pr - 1) > POA_RING;
+                    ring_ &= pr && r - (pr - 1) <= POA_RING;
+                    if (k == 0) pr0 = pr;
                 }
+                // the kind of row the sweep meets: 0 / 1 = one predecessor, the row before, its band 0 / 1 columns to the left;
+                // 2 = one or two predecessors within the ring; 3 = anything else
+                const int dl = r ? lo_r[r] - lo_r[r - 1] : 9;
+                const int kind = np == 1 && pr0 == r && (unsigned)dl <= 1u ? dl : np <= 2 && ring_ ? 2 : 3;
+                pcb[r] = (int16_t)(kind << 12 | np << 8 | base[v]);
             }
+            const bool need_h = __any(far_);
             __syncthreads();
             // ---- sweep: one row of POA_BAND cells per node, in topological order: lane l computes column lo + l.  The row of the
             // node before (nearly every node's only predecessor) stays in registers and is read with a lane shuffle -- waiting for the
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             // bubble -- is read from there; only a predecessor further back waits for the row stored in the slot.
             int c_cb = 0, c_lo = 0, n_cb = 0, n_lo = 0; uint32_t c_p01 = 0, c_l01 = 0, n_p01 = 0, n_l01 = 0;
             if (lane < n) { n_cb = pcb[lane]; n_lo = lo_r[lane]; n_p01 = *(const uint32_t*)&prow[lane * POA_MAXIN]; n_l01 = *(const uint32_t*)&pplo[lane * POA_MAXIN]; }
-            int prev_val = -32000, prev_lo = 0;
+            int prev_val = -32000;
             // (two loops: the batch in flight must not be a value the ROW loop carries -- the compiler then copies it every row behind
             // an s_waitcnt vmcnt(0), which also waits for the row's stores: one store latency per row, 4,500 cycles measured)
             for (int rb = 0; rb < n; rb += 64) {
@@ -201,40 +209,49 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 const int rcnt = n - rb < 64 ? n - rb : 64;
             for (int ri = 0; ri < rcnt; ++ri) {
                 const int r = rb + ri;
-                const int cb = __builtin_amdgcn_readlane(c_cb, ri), np_ = cb >> 8, vb = cb & 0xff, lo = __builtin_amdgcn_readlane(c_lo, ri), j = lo + lane;
-                const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)c_p01, ri), l01 = (uint32_t)__builtin_amdgcn_readlane((int)c_l01, ri);
-                const int sb = j > 0 && j <= m ? seq[j - 1] : 4;
-                const int sc = sb == vb && sb < 4 ? POA_M : POA_X;
+                POA_C(9, 1);
+                const int cb = __builtin_amdgcn_readlane(c_cb, ri), kind = cb >> 12, np_ = (cb >> 8) & 15, vb = cb & 0xff, lo = __builtin_amdgcn_readlane(c_lo, ri), j = lo + lane;
+                const int sc = seq[j] == vb ? POA_M : POA_X;
                 int vmax = -1000000, vk = 0, dmax = -1000000, dk = 0;
-                bool synced = false;
-                const int dl0 = lo - prev_lo;
-                if (r > 0 && np_ == 1 && (int)(p01 & 0xffffu) == r && (unsigned)dl0 <= 1u) {
+                // Cells right of the piece's end (j > m) are computed like the others and never read by a cell left of them: a row reads
+                // columns j and j - 1 of its predecessors, the gap chain runs left to right -- no lane masks in the row.
+                if (kind < 2) {
                     // the common row, straight-line: one predecessor, the row before, its band 0 or 1 columns to the left
+                    POA_C(10, 1);
                     const int s_r = d_wave_shr1(prev_val, -32000), s_l = d_wave_shl1(prev_val, -32000);
-                    vmax = (dl0 ? s_l : prev_val) + POA_G;
-                    if (j > 0) dmax = (dl0 ? prev_val : s_r) + sc;
-                } else
+                    vmax = (kind ? s_l : prev_val) + POA_G;
+                    dmax = (kind ? prev_val : s_r) + sc;
+                } else {
+                const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)c_p01, ri), l01 = (uint32_t)__builtin_amdgcn_readlane((int)c_l01, ri);
+                if (kind == 2) {
+                    // one or two predecessors a few ranks back (the arms of a bubble): both from the ring in LDS, straight-line
+                    POA_C(12, 1);
+                    const bool two = np_ == 2;
+                    const int pr0 = (int)(p01 & 0xffffu), pr1 = two ? (int)(p01 >> 16) : pr0, j0 = j - (int)(l01 & 0xffffu), j1 = j - (two ? (int)(l01 >> 16) : 20000);
+                    const int16_t *rw0 = hring + ((pr0 - 1) & (POA_RING - 1)) * POA_BAND, *rw1 = hring + ((pr1 - 1) & (POA_RING - 1)) * POA_BAND;
+                    const int a0 = rw0[j0 & (POA_BAND - 1)], b0 = rw0[(j0 - 1) & (POA_BAND - 1)], a1 = rw1[j1 & (POA_BAND - 1)], b1 = rw1[(j1 - 1) & (POA_BAND - 1)];
+                    const int off1 = two ? -32000 : -1000000;
+                    vmax = ((unsigned)j0 < (unsigned)POA_BAND ? a0 : -32000) + POA_G;
+                    dmax = ((unsigned)(j0 - 1) < (unsigned)POA_BAND ? b0 : -32000) + sc;
+                    const int c1 = ((unsigned)j1 < (unsigned)POA_BAND ? a1 : off1) + POA_G, d1 = ((unsigned)(j1 - 1) < (unsigned)POA_BAND ? b1 : off1) + sc;
+                    if (c1 > vmax) { vmax = c1; vk = 1; }
+                    if (d1 > dmax) { dmax = d1; dk = 1; }
+                } else {
+                bool synced = false;
                 for (int k = 0; k < np_; ++k) {
                     const int pr = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : __builtin_amdgcn_readfirstlane((int)prow[r * POA_MAXIN + k]);
                     const int pl = k == 0 ? (int)(l01 & 0xffffu) : k == 1 ? (int)(l01 >> 16) : __builtin_amdgcn_readfirstlane((int)pplo[r * POA_MAXIN + k]);
                     int vj, vj1;
                     if (pr == 0) { vj = j * POA_G; vj1 = (j - 1) * POA_G; }
-                    else if (pr == r) {                          // the row before: registers
-                        const int dl = lo - prev_lo, jj = lane + dl;
-                        int a, b;
-                        if (dl == 0) { a = prev_val; b = d_wave_shr1(prev_val, -32000); }
-                        else if (dl == 1) { a = d_wave_shl1(prev_val, -32000); b = prev_val; }
-                        else if (dl == 2) { b = d_wave_shl1(prev_val, -32000); a = d_wave_shl1(b, -32000); }
-                        else { a = __shfl(prev_val, jj & 63); b = __shfl(prev_val, (jj - 1) & 63); }
-                        vj = (jj >= 0 && jj < POA_BAND) ? a : -32000;
-                        vj1 = (jj >= 1 && jj <= POA_BAND) ? b : -32000;
-                    } else if (r - (pr - 1) <= POA_RING) {       // a few ranks back: the ring in LDS
+                    else if (r - (pr - 1) <= POA_RING) {         // the row before or a few ranks back (the other arm of a bubble): the ring in LDS
                         const int jj = j - pl;
                         const int16_t *rw = hring + ((pr - 1) & (POA_RING - 1)) * POA_BAND;
-                        vj = (jj >= 0 && jj < POA_BAND) ? rw[jj] : -32000;
-                        vj1 = (jj >= 1 && jj <= POA_BAND) ? rw[jj - 1] : -32000;
+                        const int a = rw[jj & (POA_BAND - 1)], b = rw[(jj - 1) & (POA_BAND - 1)];
+                        vj = (jj >= 0 && jj < POA_BAND) ? a : -32000;
+                        vj1 = (jj >= 1 && jj <= POA_BAND) ? b : -32000;
                     } else {
                         if (!synced) { __syncthreads(); synced = true; }        // (rows stored by other lanes of this wave)
+                        POA_C(11, 1);
                         const int jj = j - pl;
                         const int16_t *prw = H + (size_t)(pr - 1) * POA_BAND;
                         vj = (jj >= 0 && jj < POA_BAND && j <= m) ? prw[jj] : -32000;
@@ -243,16 +260,18 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                     int c = vj + POA_G; if (c > vmax) { vmax = c; vk = k; }
                     c = vj1 + sc; if (j > 0 && c > dmax) { dmax = c; dk = k; }
                 }
+                }
+                }
+                if (lo == 0 && lane == 0) dmax = -1000000;          // column 0 has no diagonal
                 int t = vmax > dmax ? vmax : dmax; t = t > -32000 ? t : -32000;
                 // row[j] = max over the band's k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
-                const int u = d_wave_scan_max(j <= m ? t - j * POA_G : -1000000);
-                const int cur = (int)(int16_t)(u + j * POA_G);
-                if (j <= m) {
-                    H[(size_t)r * POA_BAND + lane] = (int16_t)cur;
-                    TB[(size_t)r * POA_BAND + (j & (POA_BAND - 1))] = (uint8_t)(j > 0 && dmax == cur ? dk : vmax == cur ? 8 | vk : 16);      // (the walk back finds a column's note without the row's band)
-                }
-                prev_val = j <= m ? cur : -32000; prev_lo = lo;
-                hring[(r & (POA_RING - 1)) * POA_BAND + lane] = (int16_t)prev_val;
+                const int jg = j * -POA_G;
+                const int cur = (int)(int16_t)(d_wave_scan_max(t + jg) - jg);
+                if (need_h) H[(size_t)r * POA_BAND + lane] = (int16_t)cur;
+                TB[(size_t)r * POA_BAND + (j & (POA_BAND - 1))] = (uint8_t)(dmax == cur ? dk : vmax == cur ? 8 | vk : 16);      // (the walk back finds a column's note without the row's band)
+                prev_val = cur;
+                if (lane == (m - lo < POA_BAND - 1 ? m - lo : POA_BAND - 1)) hlast[r] = (int16_t)(j == m ? cur : -32000);      // (the end is chosen among last columns)
+                hring[(r & (POA_RING - 1)) * POA_BAND + lane] = (int16_t)cur;
             }
             }
             __syncthreads();
@@ -260,7 +279,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             // ---- the end: the node without out-edges whose last column scores best, smallest id on ties
             {
                 int bs = -32768, bv = 0x7fffffff;
-                for (int v = lane; v < n; v += 64) if (!nout[v]) { const int sc = d_poa_cell(H, lo_r, rank[v], m, m); if (sc > bs) { bs = sc; bv = v; } }
+                for (int v = lane; v < n; v += 64) if (!nout[v]) { const int sc = hlast[rank[v] - 1]; if (sc > bs) { bs = sc; bv = v; } }
 #pragma unroll
                 for (int s = 32; s >= 1; s >>= 1) { const int os = __shfl_xor(bs, s), ov = __shfl_xor(bv, s); if (os > bs || (os == bs && ov < bv)) { bs = os; bv = ov; } }
                 if (lane == 0) sh[0] = bv == 0x7fffffff ? -1 : bv;
@@ -277,13 +296,17 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 // "diagonal from the first predecessor" are emitted together; that one step is then taken as noted.
                 int np = 0, j = m;
                 int r = __builtin_amdgcn_readfirstlane(sh[0] >= 0 ? (int)rank[sh[0]] : 0);
-                int wbase = -1; uint32_t pp = 0;                  // lane i: rows of the first two predecessors of row wbase - i
+                int wbase = -1, nbase = -1; uint32_t pp = 0, pnx = 0;     // lane i: rows of the first two predecessors of row wbase - i; the window asked for ahead
                 for (int it = 0; (r > 0 || j > 0) && j >= 0 && it < 2 * POA_NPATH; ++it) {        // (the bounds only keep a broken slot from hanging the device)
                     if (r == 0) {                                  // bases before the graph's start
                         for (int x = lane; x < j; x += 64) { pn[np + x] = 0; pj[np + x] = (int16_t)(j - 1 - x); }
                         np += j; j = 0; break;
                     }
-                    if (wbase < 0 || wbase - r > 63) { wbase = r; const int rr = r - lane; pp = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }
+                    POA_C(13, 1);
+                    if (wbase < r || wbase - r > 63) {
+                        if (nbase >= r && nbase - r <= 63) { pp = pnx; wbase = nbase; nbase = -1; }
+                        else { POA_C(14, 1); wbase = r; const int rr = r - lane; pp = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }
+                    }
                     int mine = 0, c = r, len = 0;
                     for (int l = 0; l < POA_SPEC; ++l) {
                         if (c == 0 || wbase - c > 63 || l > j) break;
@@ -291,6 +314,8 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                         ++len;
                         c = (int)((uint32_t)__builtin_amdgcn_readlane((int)pp, wbase - c) & 0xffffu);
                     }
+                    // the guess left the window: the window it ends in is asked for together with the notes (one round trip for both)
+                    if (c > 0 && wbase - c > 63) { nbase = c; const int rr = c - lane; pnx = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }
                     const int jl = j - lane;
                     int tb = 16;
                     if (lane < len) {
@@ -299,7 +324,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                         tb = jj >= 0 && jj < POA_BAND ? t : 16;
                     }
                     const uint64_t okm = __ballot(lane < len && tb == 0);
-                    const int s_ = (int)__builtin_ctzll(~okm);      // diagonal steps along first predecessors (<= len <= POA_SPEC)
+                    const int s_ = ~okm ? (int)__builtin_ctzll(~okm) : 64;      // diagonal steps along first predecessors (<= len <= POA_SPEC)
                     if (lane < s_) { pn[np + lane] = (int16_t)mine; pj[np + lane] = (int16_t)(jl - 1); }
                     np += s_; j -= s_;
                     if (s_ == len) { r = c; continue; }
@@ -330,7 +355,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 for (int t0 = 0; t0 < np; t0 += 64) {
                     const int t = t0 + lane, z = np - 1 - t; const bool on = t < np;
                     int x = -1, u = -1, mm = -1, cx = 0; uint8_t b = 4;
-                    if (on) { x = pn[z]; b = seq[pj[z]]; }
+                    if (on) { x = pn[z]; b = seq[pj[z] + 1]; }
                     if (x >= 0) {
                         if (base[x] == b) u = x;
                         else for (int s_ = ring[x]; s_ != x; s_ = ring[s_]) if (base[s_] == b) { u = s_; break; }
@@ -460,7 +485,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
         POA_T(8);
     }
 #ifdef POA_PROF
-    if (lane == 0) for (int i = 0; i < 10; ++i) atomicAdd(&g_poa_prof[i], pf[i]);
+    if (lane == 0) for (int i = 0; i < 16; ++i) atomicAdd(&g_poa_prof[i], pf[i]);
 #endif
 }
 
@@ -584,7 +609,8 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     { unsigned long long h[16]; CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_poa_prof), sizeof(h))); unsigned long long z[16] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_poa_prof), z, sizeof(z)));
       double tot_ = 0; for (int i = 0; i < 9; ++i) tot_ += (double)h[i];
       static const char *nm[9] = {"select", "init", "setup", "sweep", "end", "walk", "merge", "order", "bundle"};
-      fprintf(stderr, "[poa prof] windows %lld pieces %zu:", (long long)nwin, pieces.size()); for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h[i] / (tot_ > 0 ? tot_ : 1)); fprintf(stderr, "\n"); }
+      fprintf(stderr, "[poa prof] windows %lld pieces %zu:", (long long)nwin, pieces.size()); for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * (double)h[i] / (tot_ > 0 ? tot_ : 1)); fprintf(stderr, "\n");
+      fprintf(stderr, "[poa prof] rows %llu fast %.1f%% ring reads %.1f%% slot reads %.2f%% of rows; walk trips %.1f per piece, window loads %.1f per piece\n", h[9], 100.0 * h[10] / (h[9] ? h[9] : 1), 100.0 * h[12] / (h[9] ? h[9] : 1), 100.0 * h[11] / (h[9] ? h[9] : 1), (double)h[13] / (pieces.size() ? pieces.size() : 1), (double)h[14] / (pieces.size() ? pieces.size() : 1)); }
 #endif
     C->seq.resize((size_t)tot);
     if (tot) CK(hipMemcpyAsync(&C->seq[0], d_pack, (size_t)tot, hipMemcpyDeviceToHost, st));

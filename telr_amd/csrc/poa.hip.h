@@ -316,26 +316,57 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                     }
                     // the guess left the window: the window it ends in is asked for together with the notes (one round trip for both)
                     if (c > 0 && wbase - c > 63) { nbase = c; const int rr = c - lane; pnx = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }
+                    // the notes of the guessed cells AND of the cells up to two columns left / right of them: an inserted base moves the
+                    // way one column left of the guess, a skipped node one column right -- the trip goes on through such steps as long as
+                    // the way stays within two columns of the guess (five 5-bit notes per lane in one register)
                     const int jl = j - lane;
-                    int tb = 16;
+                    uint32_t pk = 0x1084210u;                     // 16 (no note: an inserted base) five times
                     if (lane < len) {
-                        const int lo_l = lo_r[mine - 1], jj = jl - lo_l;
-                        const int t = TB[(size_t)(mine - 1) * POA_BAND + (jl & (POA_BAND - 1))];
-                        tb = jj >= 0 && jj < POA_BAND ? t : 16;
+                        const int lo_l = lo_r[mine - 1];
+                        const uint8_t *tr = TB + (size_t)(mine - 1) * POA_BAND;
+                        uint32_t q = 0;
+#pragma unroll
+                        for (int d = -2; d <= 2; ++d) {
+                            const int col = jl + d, jj = col - lo_l;
+                            const uint32_t t = tr[col & (POA_BAND - 1)];
+                            q |= (col >= 0 && jj >= 0 && jj < POA_BAND ? t : 16u) << (5 * (d + 2));
+                        }
+                        pk = q;
                     }
-                    const uint64_t okm = __ballot(lane < len && tb == 0);
-                    const int s_ = ~okm ? (int)__builtin_ctzll(~okm) : 64;      // diagonal steps along first predecessors (<= len <= POA_SPEC)
-                    if (lane < s_) { pn[np + lane] = (int16_t)mine; pj[np + lane] = (int16_t)(jl - 1); }
-                    np += s_; j -= s_;
-                    if (s_ == len) { r = c; continue; }
-                    r = __builtin_amdgcn_readlane(mine, s_);
-                    const int tbs = __builtin_amdgcn_readlane(tb, s_);
-                    if (tbs < 16) {
-                        const int k = tbs & 7;
-                        if (tbs < 8) { if (lane == 0) { pn[np] = (int16_t)r; pj[np] = (int16_t)(j - 1); } ++np; --j; }
-                        const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)pp, wbase - r);
-                        r = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : __builtin_amdgcn_readfirstlane((int)prow[(r - 1) * POA_MAXIN + k]);
-                    } else { if (lane == 0) { pn[np] = 0; pj[np] = (int16_t)(j - 1); } ++np; --j; }
+                    uint64_t okm[5];
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) okm[d] = __ballot(lane < len && ((pk >> (5 * d)) & 31u) == 0u);
+                    int l = 0, d = 0;                              // the way is at the chain's step l, d columns right of the guess
+                    int nr = -1, nj = 0;                           // the state the next trip starts from
+                    for (int ev = 0; ev < 2 * POA_SPEC + 8; ++ev) {
+                        // plain diagonal steps from here
+                        const uint64_t om = d == -2 ? okm[0] : d == -1 ? okm[1] : d == 0 ? okm[2] : d == 1 ? okm[3] : okm[4];
+                        const uint64_t rest = ~(om >> l);
+                        int run = rest ? (int)__builtin_ctzll(rest) : 64; if (run > len - l) run = len - l;
+                        if (lane >= l && lane < l + run) { pn[np + lane - l] = (int16_t)mine; pj[np + lane - l] = (int16_t)(jl + d - 1); }
+                        np += run; l += run;
+                        if (l >= len) { nr = c; nj = j - l + d; break; }
+                        const int col = j - l + d;
+                        const int tbs = (int)(((uint32_t)__builtin_amdgcn_readlane((int)pk, l) >> (5 * (d + 2))) & 31u);
+                        if (tbs == 8) {                            // the node is skipped (first predecessor): the chain's next row, the same column
+                            ++l; ++d;
+                            if (l >= len) { nr = c; nj = col; break; }
+                            if (d > 2) { nr = __builtin_amdgcn_readlane(mine, l); nj = col; break; }
+                        } else if (tbs == 16) {                    // an inserted base: the same row, one column left
+                            if (lane == 0) { pn[np] = 0; pj[np] = (int16_t)(col - 1); }
+                            ++np; --d;
+                            if (d < -2 || col - 1 < 0) { nr = __builtin_amdgcn_readlane(mine, l); nj = col - 1; break; }
+                        } else {                                   // another predecessor: the trip ends with that step
+                            const int rr = __builtin_amdgcn_readlane(mine, l), k = tbs & 7;
+                            if (tbs < 8) { if (lane == 0) { pn[np] = (int16_t)rr; pj[np] = (int16_t)(col - 1); } ++np; }
+                            const uint32_t p01 = (uint32_t)__builtin_amdgcn_readlane((int)pp, wbase - rr);
+                            nr = k == 0 ? (int)(p01 & 0xffffu) : k == 1 ? (int)(p01 >> 16) : __builtin_amdgcn_readfirstlane((int)prow[(rr - 1) * POA_MAXIN + k]);
+                            nj = tbs < 8 ? col - 1 : col;
+                            break;
+                        }
+                    }
+                    if (nr < 0) { nr = __builtin_amdgcn_readlane(mine, l); nj = j - l + d; }      // (the bound of the loop above: not reached)
+                    r = nr; j = nj;
                 }
                 if (lane == 0) sh[3] = np;
             }

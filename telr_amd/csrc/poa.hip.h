@@ -38,6 +38,7 @@ struct PoaPiece { int32_t qid, qa, len, rev; };           // query bases [qa, qa
 struct PoaArgs {
     const PoaPiece *pieces; const int32_t *wptr;          // pieces of window w: [wptr[w], wptr[w + 1]) in record order
     const int32_t *w_tid, *w_w0, *w_w1; int32_t nwin, min_depth;
+    const int32_t *wperm; int32_t *next;                  // the windows by falling number of pieces; the next one to hand out
     const uint32_t *q2, *qn; const int64_t *qboff; const int32_t *qlen;
     const uint32_t *t2, *tn; const int64_t *tboff;
     uint8_t *scratch; size_t slot_bytes;                  // one slot per resident wave
@@ -128,7 +129,14 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
     uint8_t *TB = S + POA_O_TB;
     int16_t *hlast = (int16_t*)(S + POA_O_HLAST);
     int16_t *prow = (int16_t*)(S + POA_O_PROW), *pplo = (int16_t*)(S + POA_O_PPLO), *pcb = (int16_t*)(S + POA_O_PCB), *col = (int16_t*)(S + POA_O_COL), *lo_r = (int16_t*)(S + POA_O_LO);
-    for (int w = blockIdx.x; w < A.nwin; w += gridDim.x) {
+    // the windows are handed out one by one, the ones with most pieces first: a wave that drew short windows takes more of them
+    // (dealt round-robin the busiest wave of 6,144 finished long after the average one)
+    for (;;) {
+        int wi = 0;
+        if (lane == 0) wi = atomicAdd(A.next, 1);
+        wi = __builtin_amdgcn_readfirstlane(wi);
+        if (wi >= A.nwin) break;
+        const int w = A.wperm[wi];
         const int tid = A.w_tid[w], w0 = A.w_w0[w], w1 = A.w_w1[w], L = w1 - w0;
         const int64_t tb0 = A.tboff[tid];
         uint8_t *out = A.wout + (size_t)w * POA_MAXNODE;
@@ -596,6 +604,14 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     for (int64_t k = 0; k < nwin; ++k) wptr[k + 1] += wptr[k];
     std::vector<PoaPiece> pieces(cand.size());
     { std::vector<int32_t> fill(wptr.begin(), wptr.end() - 1); for (const Cand &c : cand) pieces[fill[c.win]++] = c.p; }
+    std::vector<int32_t> wperm((size_t)nwin);
+    {   // counting sort by the number of pieces, most first (ties: window order)
+        int32_t mx = 0; for (int64_t k = 0; k < nwin; ++k) mx = std::max(mx, wptr[k + 1] - wptr[k]);
+        std::vector<int64_t> cnt((size_t)mx + 2, 0);
+        for (int64_t k = 0; k < nwin; ++k) ++cnt[(size_t)(mx - (wptr[k + 1] - wptr[k])) + 1];
+        for (int32_t c = 0; c <= mx; ++c) cnt[(size_t)c + 1] += cnt[c];
+        for (int64_t k = 0; k < nwin; ++k) wperm[(size_t)cnt[(size_t)(mx - (wptr[k + 1] - wptr[k]))]++] = (int32_t)k;
+    }
     // one slot per RESIDENT wave (a wave beyond that would start when the others have done all their windows: twice the time)
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_poa_window, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
@@ -604,12 +620,13 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     const int64_t want = (int64_t)per_cu * ncu;
     const int nslot = (int)std::min<int64_t>(nwin, want);
     PoaArgs A; memset(&A, 0, sizeof(A));
-    PoaPiece *d_p; int32_t *d_wptr, *d_wt, *d_w0, *d_w1, *d_wlen; uint8_t *d_scr, *d_wout;
+    PoaPiece *d_p; int32_t *d_wptr, *d_wt, *d_w0, *d_w1, *d_wlen, *d_wperm, *d_next; uint8_t *d_scr, *d_wout;
     int rc;
     auto fail = [&](int code) { delete C; return code; };
     if ((rc = ctx_buf_t(ctx, "poa_pieces", pieces.size() + 1, &d_p)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_wptr", (size_t)nwin + 1, &d_wptr)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "poa_wt", (size_t)nwin, &d_wt)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_w0", (size_t)nwin, &d_w0)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "poa_w1", (size_t)nwin, &d_w1)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_wlen", (size_t)nwin, &d_wlen)) != TELR_OK ||
+        (rc = ctx_buf_t(ctx, "poa_wperm", (size_t)nwin, &d_wperm)) != TELR_OK || (rc = ctx_buf_t(ctx, "poa_next", (size_t)4, &d_next)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "poa_scratch", (size_t)nslot * POA_SLOT_BYTES, &d_scr)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "poa_wout", (size_t)nwin * POA_MAXNODE, &d_wout)) != TELR_OK) return fail(rc);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx->err = std::string(#x) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP); } } while (0)
@@ -618,7 +635,9 @@ static int poa_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset *quer
     CK(hipMemcpyAsync(d_wt, w_tid.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
     CK(hipMemcpyAsync(d_w0, w_w0.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
     CK(hipMemcpyAsync(d_w1, w_w1.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
-    A.pieces = d_p; A.wptr = d_wptr; A.w_tid = d_wt; A.w_w0 = d_w0; A.w_w1 = d_w1; A.nwin = (int32_t)nwin; A.min_depth = min_depth;
+    CK(hipMemcpyAsync(d_wperm, wperm.data(), (size_t)nwin * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemsetAsync(d_next, 0, 4, st));
+    A.pieces = d_p; A.wptr = d_wptr; A.w_tid = d_wt; A.w_w0 = d_w0; A.w_w1 = d_w1; A.nwin = (int32_t)nwin; A.min_depth = min_depth; A.wperm = d_wperm; A.next = d_next;
     A.q2 = queries->d_seq2; A.qn = queries->d_nmask; A.qboff = queries->d_boff; A.qlen = queries->d_len;
     A.t2 = tg->d_seq2; A.tn = tg->d_nmask; A.tboff = tg->d_boff;
     A.scratch = d_scr; A.slot_bytes = POA_SLOT_BYTES; A.wout = d_wout; A.wlen = d_wlen;

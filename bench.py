@@ -978,9 +978,10 @@ def main():
                 # the same hand-off with the window partial-order consensus (telr_poa_build)
                 try:
                     sync(); t0p = time.time()
-                    pol2 = telr_assembly.polish_consensus(eng, names_p, ctg, [w.astype(np.int32) for w in wr_p], presets=presets_arg, read_set=qs, method="poa")
+                    ph2 = {}
+                    pol2 = telr_assembly.polish_consensus(eng, names_p, ctg, [w.astype(np.int32) for w in wr_p], presets=presets_arg, read_set=qs, method="poa", timings=ph2)
                     sync(); tp2 = time.time() - t0p
-                    polish["poa"] = {"seconds": tp2, "loci_per_s": len(loci) / tp2, "contigs_changed": int(sum(1 for x, y in zip(pol2, ctg) if x != y)),
+                    polish["poa"] = {"seconds": tp2, "loci_per_s": len(loci) / tp2, "phases_s": {k: round(v, 4) for k, v in ph2.items()}, "contigs_changed": int(sum(1 for x, y in zip(pol2, ctg) if x != y)),
                                      "bases_after": int(sum(len(x) for x in pol2)), "differs_from_pileup": int(sum(1 for x, y in zip(pol2, pol) if x != y)),
                                      "what": "one telr_map + one window partial-order consensus pass (200-base windows, one wave per window)"}
                 except Exception as e:

@@ -118,7 +118,7 @@ def polish_alignments(engine, contig_names, contig_seqs, reads_by_locus, read_na
     return ["".join(mapped[k]) + "".join(unmapped[k]) for k in range(len(contig_names))], res.alns, res.cigars
 
 
-def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets="ont", iterations=1, min_depth=3, read_set=None, method="pileup"):
+def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets="ont", iterations=1, min_depth=3, read_set=None, method="pileup", timings=None):
     """The polishing loop of `run_wtdbg2_polishing` (TELR_assembly.py:185-262) with the consensus made on the device: per
     iteration ONE engine call maps the reads of every locus to its draft contig (`-ax P -r2k`, as S3) and ONE pile-up pass over
     the primary records (`-F0x900`) rewrites all contigs (`telr_consensus_build`: majority vote per position, spec 3.12).
@@ -127,12 +127,19 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
     stage-1 SeqSet resident on the device -- read indices (gathered on the device, as in telr_af.get_af).
     method="poa": the window partial-order consensus instead (`telr_poa_build`, spec 3.13: the reads are re-aligned to a graph of
     each 200-base window; closer to what wtpoa-cns does, still not its code).
+    timings: a dict that receives the wall-clock seconds of the pass's phases (read set, index, map, consensus).
     -> list of polished contig sequences (a contig no read maps to stays as it is)."""
+    import time
+    def _t(key, t0):
+        if timings is not None:
+            timings[key] = timings.get(key, 0.0) + time.time() - t0
+        return time.time()
     if method not in ("pileup", "poa"):
         raise ValueError("method must be 'pileup' or 'poa'")
     from .presets import preset
     io, mo = preset("map-pb" if presets == "pacbio" else "map-ont")
     mo.bw = 2000
+    t0 = time.time()
     contigs = [c if isinstance(c, str) else bytes(c).decode() for c in contig_seqs]
     qt, flat = [], []
     for k, rs in enumerate(reads_by_locus):
@@ -142,13 +149,18 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
         return contigs
     qset = read_set.subset(np.asarray(flat, np.int32)) if read_set is not None else engine.seqset(flat)
     qt = np.asarray(qt, np.int32)
+    t0 = _t("read_set_s", t0)
     for _ in range(max(1, int(iterations))):
         ix = engine.index(contigs, io)
+        t0 = _t("index_s", t0)
         r = ix.map_raw(qset, mo, qtarget=qt)
+        t0 = _t("map_s", t0)
         try:
             contigs = ix.consensus(r, qset, min_depth=min_depth, poa=method == "poa")
+            t0 = _t("consensus_s", t0)
         finally:
             ix.free_raw(r)
             ix.free()
     qset.free()
+    _t("free_s", t0)
     return contigs

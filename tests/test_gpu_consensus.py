@@ -135,3 +135,53 @@ def test_hip_poa_equals_oracle_on_two_allele_loci(engine):
         assert not bad, bad
     finally:
         ix.free_raw(r)
+
+
+def test_hip_poa_equals_oracle_with_long_indels_inside_the_windows(engine):
+    """reads that carry 18-28-base deletions and insertions against the draft (under the 30-base rule their pieces vote): edges
+    of the window graphs that span more ranks than the kernel's LDS ring of rows holds (POA_RING = 16) -- the sweep then writes
+    its rows to the slot and reads such a predecessor from there -- and chains of inserted nodes behind one column"""
+    rng = np.random.default_rng(20261003)
+    drafts, reads = [], []
+    for k in range(5):
+        L = int(rng.integers(5000, 9000))
+        truth = synth.random_seq(rng, L)
+        drafts.append(bytes(synth.mutate(rng, truth, 0.004, 0.002, 0.002)).decode())
+        # the SAME long differences in a third of the reads each (alleles), so that they are heavy enough to stay in the graphs
+        events = sorted(int(x) for x in rng.integers(300, L - 300, 6))
+        kinds = [(int(rng.integers(0, 2)), int(rng.integers(18, 29)), synth.random_seq(rng, 28)) for _ in events]
+        rs = []
+        for i in range(36):
+            t = truth
+            if i % 3:
+                parts, last = [], 0
+                for (pos, (ins, ln, filler)) in zip(events, kinds):
+                    if (i + pos) % 2:
+                        continue
+                    parts.append(t[last:pos])
+                    if ins:
+                        parts.append(filler[:ln]); last = pos
+                    else:
+                        last = pos + ln
+                parts.append(t[last:])
+                t = np.concatenate(parts)
+            s = int(rng.integers(0, max(1, len(t) - 3500))); r = synth.mutate(rng, t[s:s + int(rng.integers(2500, 5000))], 0.03, 0.015, 0.02)
+            rs.append(bytes(synth.revcomp_arr(r) if rng.integers(0, 2) else r).decode())
+        reads.append(rs)
+    io, mo = preset("map-ont"); mo.bw = 2000
+    qt = np.array([k for k, rs in enumerate(reads) for _ in rs], np.int32)
+    flat = [r for rs in reads for r in rs]
+    ix = engine.index(drafts, io)
+    qset = engine.seqset(flat)
+    r = ix.map_raw(qset, mo, qtarget=qt)
+    try:
+        res = ix.result_arrays(r)
+        # the long differences are in the records (else this test tests nothing)
+        ops = res.cigars & 0xf; lens = res.cigars >> 4
+        assert int(((ops == 2) & (lens >= 18) & (lens <= 30)).sum()) >= 20 and int(((ops == 1) & (lens >= 18) & (lens <= 30)).sum()) >= 20
+        for md in (3, 1):
+            got = ix.consensus(r, qset, min_depth=md, poa=True)
+            want = ob.consensus(res.alns, res.cigars, flat, drafts, min_depth=md, poa=True)
+            assert got == want, [(i, len(got[i]), len(want[i])) for i in range(len(got)) if got[i] != want[i]]
+    finally:
+        ix.free_raw(r)

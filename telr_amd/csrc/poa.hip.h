@@ -9,16 +9,28 @@
 // call sets.  Caps and tie-breaks are the oracle's, bit for bit (tests/test_gpu_consensus.py).
 //
 //   host            the pieces of every window from the records' CIGARs -- ONE walk per record gives the query offsets at all the
-//                   window borders it crosses -- in record order, CSR by window
-//   k_poa_window    ONE WAVE per window (persistent over the window list): the graph and the score matrix live in a slot of
-//                   global scratch.  The matrix is BANDED: a node's row holds the POA_BAND = 64 columns around the diagonal
-//                   of the node's window column (d_poa_lo; a piece is at most 30 bases off the diagonal by the POA_MAXINDEL
-//                   rule), i.e. exactly one cell per lane.  The row of the node before is read from registers (lane shuffle),
-//                   the in-row gap chain is a max-plus prefix scan over the wave, every cell notes where its value came from;
-//                   the walk back (one byte per step) and the heaviest-bundle pass are serial stretches on lane 0, the merge of
-//                   a piece into the graph and the new topological order are parallel passes over the path.
+//                   window borders it crosses -- in record order, CSR by window; the records are walked by the worker threads
+//   k_poa_window    ONE WAVE per window, the windows handed out one by one (most pieces first) to as many waves as are resident:
+//                   the graph lives in a slot of global scratch.  The score matrix is BANDED: a node's row holds the POA_BAND = 64
+//                   columns around the diagonal of the node's window column (d_poa_lo; a piece is at most 30 bases off the diagonal
+//                   by the POA_MAXINDEL rule), i.e. exactly one cell per lane.  Round 5 -- the kernel was a chain of dependent
+//                   loads (SQ_WAIT_ANY 76 % of its wave cycles), 335 ms per 1,000 configs[2] loci; now 104 ms:
+//                   * sweep: the per-rank tables (kind of row, base, band, first two predecessors) reach it 64 ranks at a time in
+//                     registers (v_readlane); the set-up pass sorts the rows into kinds -- one predecessor = the row before (DPP
+//                     lane shifts of the row held in registers), one or two predecessors within the last POA_RING rows (an LDS ring),
+//                     anything else (the general loop; a predecessor further back than the ring comes from the slot, and only then
+//                     are the rows written there); the in-row gap chain is a DPP prefix maximum; no lane masks (cells right of the
+//                     piece's end are never read by cells left of them); a cell notes where its value came from (one byte)
+//                   * walk back: by the whole wave -- a trip guesses up to 64 diagonal steps along first predecessors (the chain of
+//                     rows followed in a register window of the predecessor table), loads the notes of the guessed cells and of the
+//                     two columns either side at once, and follows the way through inserted bases / skipped nodes as long as it
+//                     stays within them: 13 round trips to memory per piece instead of 800
+//                   * merge of the piece into the graph and the new topological order: parallel passes over the path
+//                   * heaviest bundle: 64 ranks at a time, the scores settled in rank order with v_readlane, the way back in a
+//                     register window of the chosen-source table
 //   k_poa_pack      the windows' strings, packed, for the copy back
-// Integer work bounded by instruction issue and L2 latency: no MFMA.
+// Integer work bounded by instruction issue (VALU and SALU alike) and L2 / MALL latency: no MFMA.  -DPOA_PROF: wave clocks per
+// phase and row / trip counters on stderr (tools/poa_iter.sh).
 #pragma once
 
 #define POA_W       200
@@ -194,9 +206,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             }
             const bool need_h = __any(far_);
             __syncthreads();
-            // ---- sweep: one row of POA_BAND cells per node, in topological order: lane l computes column lo + l.  The row of the
-            // node before (nearly every node's only predecessor) stays in registers and is read with a lane shuffle -- waiting for the
-            // row just stored to come back from L2 was most of a step; rows further back are read from the slot.  Every cell also
+            // ---- sweep: one row of POA_BAND cells per node, in topological order: lane l computes column lo + l.  Every cell also
             // notes where its value came from, by the walk's own preference (diagonal before skipped node before inserted base, the
             // first predecessor that explains it): the walk back then reads one byte per step instead of all candidates again.
             POA_T(2);

@@ -206,6 +206,11 @@ def _af_map(job, engine, targets, reads_by_locus, presets, read_set):
         import sys
         sys.stderr.write("af_map: " + ", ".join("%s %.1f ms" % (k, v * 1e3) for k, v in marks) + " | engine stages " +
                          ", ".join("%s %.1f" % kv for kv in engine.stage_ms().items() if kv[1] > 0.5) + "\n")
+        try:
+            dc = engine.dp_classes()
+            sys.stderr.write("af_map dp classes (problems, Mcells): " + ", ".join("%s: %d %.0f" % (c, v[0], v[1] / 1e6) for c, v in enumerate(np.asarray(dc).reshape(-1, 4).tolist()) if v[0]) + " | counters " + str({k: v for k, v in engine.counters().items() if v}) + "\n")
+        except Exception as e:
+            sys.stderr.write("af_map: no class counters (%s)\n" % e)
 
 
 def af_start(engine, contigs, reads_by_locus, presets="ont", read_set=None, names=None, threaded=False, contig_set=None):

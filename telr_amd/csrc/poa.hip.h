@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 // 2 = one or two predecessors within the ring; 3 = anything else
                 const int dl = r ? lo_r[r] - lo_r[r - 1] : 9;
                 const int kind = np == 1 && pr0 == r && (unsigned)dl <= 1u ? dl : np <= 2 && ring_ ? 2 : 3;
-                pcb[r] = (int16_t)(kind << 12 | np << 8 | base[v]);
+                pcb[r] = (int16_t)((nout[v] ? 0 : 1) << 14 | kind << 12 | np << 8 | base[v]);      // bit 14: no out-edge -- a candidate for the end, its last column is noted
             }
             const bool need_h = __any(far_);
             __syncthreads();
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
             for (int ri = 0; ri < rcnt; ++ri) {
                 const int r = rb + ri;
                 POA_C(9, 1);
-                const int cb = __builtin_amdgcn_readlane(c_cb, ri), kind = cb >> 12, np_ = (cb >> 8) & 15, vb = cb & 0xff, lo = __builtin_amdgcn_readlane(c_lo, ri), j = lo + lane;
+                const int cb = __builtin_amdgcn_readlane(c_cb, ri), kind = (cb >> 12) & 3, np_ = (cb >> 8) & 15, vb = cb & 0xff, lo = __builtin_amdgcn_readlane(c_lo, ri), j = lo + lane;
                 const int sc = seq[j] == vb ? POA_M : POA_X;
                 int vmax = -1000000, vk = 0, dmax = -1000000, dk = 0;
                 // Cells right of the piece's end (j > m) are computed like the others and never read by a cell left of them: a row reads
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 }
                 }
                 }
-                if (lo == 0 && lane == 0) dmax = -1000000;          // column 0 has no diagonal
+                if (lo == 0) { if (lane == 0) dmax = -1000000; }      // column 0 has no diagonal (a uniform branch: most rows have none)
                 int t = vmax > dmax ? vmax : dmax; t = t > -32000 ? t : -32000;
                 // row[j] = max over the band's k <= j of T[k] + (j - k) G  =  (prefix max of T[k] - k G) + j G
                 const int jg = j * -POA_G;
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 if (need_h) H[(size_t)r * POA_BAND + lane] = (int16_t)cur;
                 TB[(size_t)r * POA_BAND + (j & (POA_BAND - 1))] = (uint8_t)(dmax == cur ? dk : vmax == cur ? 8 | vk : 16);      // (the walk back finds a column's note without the row's band)
                 prev_val = cur;
-                if (lane == (m - lo < POA_BAND - 1 ? m - lo : POA_BAND - 1)) hlast[r] = (int16_t)(j == m ? cur : -32000);      // (the end is chosen among last columns)
+                if (cb >> 14) { if (lane == (m - lo < POA_BAND - 1 ? m - lo : POA_BAND - 1)) hlast[r] = (int16_t)(j == m ? cur : -32000); }      // (the end is chosen among the last columns of the nodes without out-edges)
                 hring[(r & (POA_RING - 1)) * POA_BAND + lane] = (int16_t)cur;
             }
             }
@@ -325,12 +325,23 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                         if (nbase >= r && nbase - r <= 63) { pp = pnx; wbase = nbase; nbase = -1; }
                         else { POA_C(14, 1); wbase = r; const int rr = r - lane; pp = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }
                     }
+                    // the chain of first predecessors from r, step l on lane l: rows whose first predecessor is the row before them are
+                    // taken a run at a time (a ballot over the window), the others one v_readlane each
+                    const uint64_t consec = __ballot(wbase - lane >= 1 && (int)(pp & 0xffffu) == wbase - lane - 1);
                     int mine = 0, c = r, len = 0;
-                    for (int l = 0; l < POA_SPEC; ++l) {
-                        if (c == 0 || wbase - c > 63 || l > j) break;
-                        if (lane == l) mine = c;
-                        ++len;
-                        c = (int)((uint32_t)__builtin_amdgcn_readlane((int)pp, wbase - c) & 0xffffu);
+                    while (len < POA_SPEC && c != 0 && wbase - c <= 63 && len <= j) {
+                        const int ci = wbase - c;
+                        const uint64_t rest = ~(consec >> ci);
+                        const int full = (rest ? (int)__builtin_ctzll(rest) : 64) + 1;    // the run and the row that ends it
+                        int take = full;
+                        if (take > 64 - ci) take = 64 - ci;                               // (the window's end, the rows above the virtual start,
+                        if (take > c) take = c;                                           //  the lanes, the columns left)
+                        if (take > POA_SPEC - len) take = POA_SPEC - len;
+                        if (take > j - len + 1) take = j - len + 1;
+                        const bool whole = take == full;
+                        if (lane >= len && lane < len + take) mine = c - (lane - len);
+                        c = whole ? (int)((uint32_t)__builtin_amdgcn_readlane((int)pp, ci + take - 1) & 0xffffu) : c - take;
+                        len += take;
                     }
                     // the guess left the window: the window it ends in is asked for together with the notes (one round trip for both)
                     if (c > 0 && wbase - c > 63) { nbase = c; const int rr = c - lane; pnx = rr >= 1 ? *(const uint32_t*)&prow[(rr - 1) * POA_MAXIN] : 0u; }

@@ -185,3 +185,14 @@ def test_hip_poa_equals_oracle_with_long_indels_inside_the_windows(engine):
             assert got == want, [(i, len(got[i]), len(want[i])) for i in range(len(got)) if got[i] != want[i]]
     finally:
         ix.free_raw(r)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_hip_poa_equals_oracle_on_random_shapes(engine, seed):
+    """tests/fuzz_poa.py: contigs shorter than a window / a base past a border, depths 0 to 80 (beyond the 64-piece cap), clean to
+    noisy reads, N runs, 12-45-base indels either side of the 30-base rule, both presets, min_depth 3 and 1"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fuzz_poa
+    fuzz_poa.run(engine, 12, seed)

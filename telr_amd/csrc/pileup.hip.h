@@ -103,6 +103,12 @@ __global__ void __launch_bounds__(256) k_widen_i32(const int32_t *__restrict__ i
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = in[i];
 }
+// the scan at the first position of every target (and at the end): the targets' offsets in the output, for ONE copy back
+__global__ void __launch_bounds__(256) k_pick_i64(const int64_t *__restrict__ in, const int64_t *__restrict__ at, int32_t n, int64_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[at[i]];
+}
 
 struct telr_consensus { std::string seq; std::vector<int64_t> off; std::vector<int32_t> len; };
 extern "C" void telr_consensus_free(telr_consensus *c) { delete c; }
@@ -144,16 +150,21 @@ static int consensus_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset
     telr_consensus *C = new telr_consensus();
     C->off.assign((size_t)nt, 0); C->len.assign((size_t)nt, 0);
     if (total == 0) { *out = C; return TELR_OK; }
-    telr_aln *d_alns; uint32_t *d_cig, *d_cell; int64_t *d_tbase, *d_e64, *d_woff; int32_t *d_emit; uint8_t *d_out;
+    telr_aln *d_alns; uint32_t *d_cig = nullptr, *d_cell; int64_t *d_tbase, *d_e64, *d_woff, *d_hw; int32_t *d_emit; uint8_t *d_out;
     int rc;
     auto fail = [&](int code) { delete C; return code; };
-    if ((rc = ctx_buf_t(ctx, "cons_alns", n + 1, &d_alns)) != TELR_OK || (rc = ctx_buf_t(ctx, "cons_cig", r->ncig + 1, &d_cig)) != TELR_OK ||
+    // the CIGAR array: the result's own device copy when it kept one (TELR_MF_KEEP_CIGARS; round 5: polish_consensus asks for it --
+    // the upload was 250 MB of pageable memory per 1,000 configs[2] loci), else uploaded
+    const bool twin = r->d_cig && !r->twin_off && r->twin_n == r->ncig;
+    if (twin) { d_cig = r->d_cig; if (hipDeviceSynchronize() != hipSuccess) return fail(TELR_E_HIP); }      // (its last pieces were copied on other streams, as in telr_depth_medians)
+    if ((rc = ctx_buf_t(ctx, "cons_alns", n + 1, &d_alns)) != TELR_OK || (!twin && (rc = ctx_buf_t(ctx, "cons_cig", r->ncig + 1, &d_cig)) != TELR_OK) ||
+        (rc = ctx_buf_t(ctx, "cons_hw", (size_t)nt + 1, &d_hw)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "cons_cell", (size_t)total * CONS_CELL, &d_cell)) != TELR_OK || (rc = ctx_buf_t(ctx, "cons_tbase", (size_t)nt + 1, &d_tbase)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "cons_emit", (size_t)total + 1, &d_emit)) != TELR_OK || (rc = ctx_buf_t(ctx, "cons_e64", (size_t)total + 1, &d_e64)) != TELR_OK ||
         (rc = ctx_buf_t(ctx, "cons_woff", (size_t)total + 1, &d_woff)) != TELR_OK) return fail(rc);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx->err = std::string(#x) + ": " + hipGetErrorString(e_); return fail(e_ == hipErrorOutOfMemory ? TELR_E_NOMEM : TELR_E_HIP); } } while (0)
     if (n) CK(hipMemcpyAsync(d_alns, r->alns.data(), n * sizeof(telr_aln), hipMemcpyHostToDevice, st));
-    if (r->ncig) CK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
+    if (r->ncig && !twin) CK(hipMemcpyAsync(d_cig, r->cig, r->ncig * 4, hipMemcpyHostToDevice, st));
     CK(hipMemcpyAsync(d_tbase, tbase.data(), ((size_t)nt + 1) * 8, hipMemcpyHostToDevice, st));
     CK(hipMemsetAsync(d_cell, 0, (size_t)total * CONS_CELL * 4, st));
     if (n) hipLaunchKernelGGL(k_pile_count, dim3((unsigned)n), dim3(64), 0, st, d_alns, (int32_t)n, d_cig, queries->d_seq2, queries->d_nmask, queries->d_boff, d_tbase, d_cell);
@@ -164,7 +175,9 @@ static int consensus_impl(telr_ctx *ctx, const telr_result *r, const telr_seqset
     if ((rc = dev_exclusive_scan<int64_t, int64_t>(ctx, d_e64, d_woff, (size_t)total + 1)) != TELR_OK) return fail(rc);
     // offsets of the targets in the output = the scan at their first position
     std::vector<int64_t> h_w((size_t)nt + 1);
-    for (int t = 0; t <= nt; ++t) CK(hipMemcpyAsync(&h_w[t], d_woff + tbase[t], 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_pick_i64, dim3((unsigned)((nt + 256) / 256)), dim3(256), 0, st, d_woff, d_tbase, nt + 1, d_hw);      // (one copy, not one per target)
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(h_w.data(), d_hw, ((size_t)nt + 1) * 8, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
     const int64_t wtot = h_w[nt];
     if ((rc = ctx_buf_t(ctx, "cons_out", (size_t)wtot + 1, &d_out)) != TELR_OK) return fail(rc);

@@ -139,6 +139,9 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
     from .presets import preset
     io, mo = preset("map-pb" if presets == "pacbio" else "map-ont")
     mo.bw = 2000
+    if hasattr(engine, "worker"):                    # the engine: the pile-up reads the CIGARs where they are made (TELR_MF_KEEP_CIGARS)
+        from ._abi import MF_KEEP_CIGARS
+        mo = mo.copy(); mo.flags |= MF_KEEP_CIGARS
     t0 = time.time()
     contigs = [c if isinstance(c, str) else bytes(c).decode() for c in contig_seqs]
     counts = np.fromiter((len(rs) for rs in reads_by_locus), np.int64, len(reads_by_locus))

@@ -2258,7 +2258,11 @@ __device__ void d_longgap(const DpArgs &A, const DpProb &P, int prob, int lane, 
 // One wave per problem; DP state per diagonal in LDS, updated in place (cells of one
 // anti-diagonal touch only the other parity's diagonals).  Trace-back bytes go to
 // tb[a][slot]; the walk itself is done by k_traceback.
-__global__ void __launch_bounds__(64) k_dp(DpArgs A)
+// NT = 64: one wave per problem (every class).  NT = 256 (round 5, classes 3 and 4: bands of up to DP_DMAX diagonals): four waves sweep an
+// anti-diagonal together -- the polishing map's `-r2k` fills (a few thousand problems of up to 4,000 diagonals, 760 Mcells per 1,000 loci) were
+// single waves of 30 ms; only fills go there (z-drop extensions are at most 255 diagonals wide: classes 0-2), the long-gap and fallback
+// kinds are done by the block's first wave.
+template <int NT> __device__ __forceinline__ void d_dp_lds(const DpArgs &A)
 {
     extern __shared__ __align__(16) int32_t lds[];
     const int pi = blockIdx.x;
@@ -2274,6 +2278,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.cells = 0; R.tbases = n; R.mcols = 0;
     int ncell = 0;
 
+    if (NT > 64 && (P.kind == 5 || P.kind == 3) && lane >= 64) return;      // (single-wave code below; a barrier counts the waves still running)
     if (P.kind == 5) { d_longgap(A, P, prob, lane, lds); return; }
     if (P.kind == 3) {
         // band wider than the engine accepts: diagonal + one closing gap (oracle band_dp_fallback)
@@ -2298,7 +2303,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     }
 
     int32_t *H = lds, *E1 = H + (A.dcap + 2), *F1 = E1 + (A.dcap + 2), *E2 = F1 + (A.dcap + 2), *F2 = E2 + (A.dcap + 2);
-    for (int x = lane; x < D + 2; x += 64) { H[x] = TELR_NEG; E1[x] = TELR_NEG; F1[x] = TELR_NEG; E2[x] = TELR_NEG; F2[x] = TELR_NEG; }
+    for (int x = lane; x < D + 2; x += NT) { H[x] = TELR_NEG; E1[x] = TELR_NEG; F1[x] = TELR_NEG; E2[x] = TELR_NEG; F2[x] = TELR_NEG; }
     __syncthreads();
     if (lane == 0 && 0 >= dlo && 0 <= dhi) H[0 - dlo + 1] = 0;
     __syncthreads();
@@ -2309,7 +2314,7 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
         int d1 = a < dhi ? a : dhi;   if (2 * n - a < d1) d1 = 2 * n - a;
         if (((d0 - a) & 1) != 0) ++d0;
         int64_t curk = INT64_MIN;
-        for (int d = d0 + 2 * lane; d <= d1; d += 128) {
+        for (int d = d0 + 2 * lane; d <= d1; d += 2 * NT) {
             const int i = (a - d) >> 1, j = (a + d) >> 1, x = d - dlo + 1;
             int32_t h, ve1, vf1, ve2, vf2;
             if (i == 0 && o.cx_scale) { ve1 = -d_cx_cost(o, j); ve2 = j < o.cx_flat ? j : o.cx_flat; vf1 = TELR_NEG; vf2 = 0; h = ve1; }
@@ -2337,9 +2342,16 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
             int64_t kk = (int64_t)h * 4294967296LL + (int64_t)(0x7fffffff - (d - dlo));   // max h, smallest d among ties
             curk = kk > curk ? kk : curk;
         }
-        __syncthreads();   // single wave: orders this step's LDS writes before the next step's reads
+        __syncthreads();   // orders this step's LDS writes before the next step's reads
         if (ext) {
             curk = d_wave_max64(curk);
+            if (NT > 64) {                   // (no extension is this wide today -- ext_band <= 127 -- but the step's maximum is the block's)
+                __shared__ long long wk[NT / 64];
+                if ((lane & 63) == 0) wk[lane >> 6] = curk;
+                __syncthreads();
+                for (int w = 0; w < NT / 64; ++w) curk = wk[w] > curk ? wk[w] : curk;
+                __syncthreads();
+            }
             int cur = TELR_NEG, cur_d = 0;
             if (curk != INT64_MIN) { cur = (int)(curk >> 32); cur_d = 0x7fffffff - (int)(curk & 0xffffffffLL) + dlo; }
             if (cur > best) { best = cur; bi = (a - cur_d) >> 1; bj = (a + cur_d) >> 1; }
@@ -2351,6 +2363,13 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
     __syncthreads();
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) ncell += __shfl_xor(ncell, s);
+    if (NT > 64) {                       // the waves' cell counts through LDS (the DP state is done with)
+        __shared__ int32_t wcells[NT / 64];
+        if ((lane & 63) == 0) wcells[lane >> 6] = ncell;
+        __syncthreads();
+        ncell = 0;
+        for (int w = 0; w < NT / 64; ++w) ncell += wcells[w];
+    }
     if (lane == 0) {
         if (ext) { R.score = best; R.bi = bi; R.bj = bj; }
         else { R.score = H[(n - m) - dlo + 1]; R.bi = m; R.bj = n; }
@@ -2358,6 +2377,8 @@ __global__ void __launch_bounds__(64) k_dp(DpArgs A)
         A.res[prob] = R;
     }
 }
+__global__ void __launch_bounds__(64) k_dp(DpArgs A) { d_dp_lds<64>(A); }
+__global__ void __launch_bounds__(256) k_dp_w4(DpArgs A) { d_dp_lds<256>(A); }
 
 // ---- register forward kernel for gap-fill problems (global alignment, D <= 2*R*LPP).
 // LPP lanes per problem (64/LPP problems per wave); lane l owns the 2R consecutive

@@ -90,7 +90,7 @@ struct telr_ctx {
 // ---- environment: TWO switches carry every alternative form and every trace the engine still has (read once per process) ----------
 //   TELR_AB=tok[,tok...]     A/B forms of earlier rounds, kept because tests/test_gpu_switches.py holds each of them to the same bits:
 //                            sort64 (rocPRIM's segmented sort for every query), seed_unfused (seeding and sorting as two kernels),
-//                            chain_push (every link of the look-back scored), sketch64 (the 64-bit sketch kernel for k <= 15 too), mz_compact (compacted minimizer arrays), no_islands
+//                            chain_push (every link of the look-back scored), sketch64 (the 64-bit sketch kernel for k <= 15 too), mz_compact (compacted minimizer arrays), dp_one_wave (the widest LDS classes with one wave per problem), no_islands
 //                            (one wave per query in every chaining call), vote_filter (table filter in the vote presets' lookups),
 //                            no_pk / no_pkw / no_pkext (int32 classes instead of the packed fills / wide fills / extensions), tb8 (byte
 //                            spill in the one-piece classes), no_tag8 (untagged two-piece cell), tb_one_launch (ONE trace-back launch
@@ -1521,8 +1521,15 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         if (c <= 4) {
             D.dcap = CAP[c];
             size_t lds = (size_t)(CAP[c] + 2) * 5 * 4;
-            if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(k_dp, dim3(nl), dim3(64), lds, s2, D);
+            // classes 3 and 4 (bands of 257 .. DP_DMAX diagonals: fills only) with four waves per problem (TELR_AB=dp_one_wave: one, as classes 0-2)
+            static const bool one_wave = ab_on("dp_one_wave");
+            if (c >= 3 && !one_wave) {
+                if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp_w4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_dp_w4, dim3(nl), dim3(256), lds, s2, D);
+            } else {
+                if (lds > 48 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_dp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_dp, dim3(nl), dim3(64), lds, s2, D);
+            }
         }
         else if (c == 9) hipLaunchKernelGGL((k_dp_reg<256, 2, 4>), dim3(nl), dim3(256), 0, s2, D);
         else if (c == 8) hipLaunchKernelGGL((k_dp_reg<128, 2, 2>), dim3(nl), dim3(128), 0, s2, D);

@@ -15,6 +15,8 @@ read ORDER depends on PYTHONHASHSEED; here reads come out in input order (the co
 sort` followed by `samtools view -F0x900 BAM | wtpoa-cns -d CNS -i -` (:199-236).  wtpoa-cns itself is a hand-off point and
 is not built here; what it reads on stdin is.
 """
+import os
+
 import numpy as np
 
 
@@ -159,6 +161,10 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
         t0 = _t("index_s", t0)
         r = ix.map_raw(qset, mo, qtarget=qt)
         t0 = _t("map_s", t0)
+        if os.environ.get("TELR_AF_TRACE") and hasattr(engine, "dp_classes"):
+            import sys
+            sys.stderr.write("polish map: stages " + ", ".join("%s %.1f" % kv for kv in engine.stage_ms().items() if kv[1] > 0.5) + " | dp classes (problems, Mcells): " +
+                             ", ".join("%d: %d %.0f" % (c, v[0], v[1] / 1e6) for c, v in enumerate(np.asarray(engine.dp_classes()).reshape(-1, 4).tolist()) if v[0]) + "\n")
         try:
             contigs = ix.consensus(r, qset, min_depth=min_depth, poa=method == "poa")
             t0 = _t("consensus_s", t0)

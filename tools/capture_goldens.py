@@ -3,7 +3,7 @@
 
 The reference (/root/reference) is imported with in-memory stubs for Bio / pysam and with
 `subprocess` replaced by a fake that answers the bedtools / minimap2 / samtools calls of the
-liftover and AF paths (canned PAF for minimap2; telr_amd.intervals for bedtools).  Only inputs
+liftover and AF paths (canned PAF for minimap2; tools/bedtools_bruteforce.py for bedtools).  Only inputs
 and outputs are written (JSON under tests/golden/); no reference source is copied.
 
   python tools/capture_goldens.py          # rewrites tests/golden/*.json
@@ -15,14 +15,18 @@ import shutil
 import sys
 import tempfile
 import types
+import zlib
 
+if os.environ.get("PYTHONHASHSEED") != "0":            # the reference builds read-id lists from sets: one fixed string hash, so that a re-run rewrites the same files
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 REF = "/root/reference/src"
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-from telr_amd import intervals as iv  # noqa: E402
+import bedtools_bruteforce as bt  # noqa: E402   (tools/: written from the bedtools manual, NOT telr_amd.intervals -- that is the thing under test)
 
 
 def import_reference():
@@ -60,10 +64,10 @@ class FakeSubprocess(object):
                 s = self.seqs[fa][r[0]][int(r[1]):int(r[2])]
                 out += ">%s:%s-%s\n%s\n" % (r[0], r[1], r[2], s)
         elif tool == "bedtools" and cmd[1] == "sort":
-            out = "".join("\t".join(r) + "\n" for r in iv.bed_sort(self._rows(cmd[cmd.index("-i") + 1])))
+            out = "".join("\t".join(r) + "\n" for r in bt.sort_bed(self._rows(cmd[cmd.index("-i") + 1])))
         elif tool == "bedtools" and cmd[1] == "closest":
             a = self._rows(cmd[cmd.index("-a") + 1]); b = self._rows(cmd[cmd.index("-b") + 1])
-            rows = iv.closest_same_strand(a, b) if "-s" in cmd else iv.closest_signed_k(a, b, k=int(cmd[cmd.index("-k") + 1]))
+            rows = bt.closest_s_d_tall(a, b) if "-s" in cmd else bt.closest_d_Dref_k(a, b, int(cmd[cmd.index("-k") + 1]))
             out = "".join("\t".join(r) + "\n" for r in rows)
         elif tool == "bedtools" and cmd[1] == "merge":
             rows = self._rows(cmd[cmd.index("-i") + 1])
@@ -200,7 +204,7 @@ def capture_liftover_driver(L):
             ("chr2L_20003_20013", 5000, 6000, "jockey", "+", 20003), ("chr2L_40000_40010", 5000, 7000, "copia", "-", 40000),
             ("chr2L_60000_60010", 300, 900, "roo", "+", 60000)]
     for name, s, e, fam, strand, pos in spec:
-        contigs[name] = rnd_seq(12000, hash(name) % 1000)
+        contigs[name] = rnd_seq(12000, zlib.crc32(name.encode()) % 1000)
         bed1.append([name, str(s), str(e), fam, ".", strand])
         prefix = "_".join([name, str(s), str(e)])
         q5 = "%s:%d-%d" % (name, s - 499, s); q3 = "%s:%d-%d" % (name, e, e + 500)
@@ -244,7 +248,7 @@ def capture_liftover_driver(L):
             summ = json.load(f)
     finally:
         shutil.rmtree(tmp)
-    return {"ref_seed": {"chr2L": [120000, 7]}, "contig_seeds": {n: [12000, hash(n) % 1000] for n in contigs},
+    return {"ref_seed": {"chr2L": [120000, 7]}, "contig_seeds": {n: [12000, zlib.crc32(n.encode()) % 1000] for n in contigs},
             "contig_seqs": contigs, "bed1": bed1, "paf": {"|".join(k): v for k, v in pafs.items()},
             "expected_report": report, "expected_nonref_bed": nonref, "expected_summary": summ}
 
@@ -384,7 +388,7 @@ def capture_sv(S, U):
 
 def capture_sv_table(S, U):
     """swap_coordinate (TELR_sv.py:183-190), rm_vcf_redundancy (:193-228, pandas groupby) and the table side of filter_vcf
-    (:231-324): RepeatMasker is replaced by a canned GFF, `bedtools sort` / `bedtools merge` on that GFF by telr_amd.intervals
+    (:231-324): RepeatMasker is replaced by a canned GFF, `bedtools sort` / `bedtools merge` on that GFF by inline stand-ins
     semantics (GFF is 1-based inclusive; merge prints 0-based starts and joins book-ended features)."""
     parsed = [   # 13 columns, as `bcftools query` prints them (leading blanks in the per-sample fields)
         ["chr2L", "1200", "1100", "310", "9", "0.45", "3", "ACGTACGTAAACGTACGTAA", "r1,r2", "PASS", " 0/1", " 11", " 9"],
@@ -678,7 +682,7 @@ def capture_prep_assembly():
 def capture_repeatmask(T):
     """parse_rm_out and gff3tobed of the reference on a RepeatMasker .out.gff written here (RepeatMasker's GFF2 lines:
     seq, RepeatMasker, similarity, start, end, score, strand, ., Target "Motif:<family>" start end); `bedtools sort` answered by
-    telr_amd.intervals.bed_sort"""
+    tools/bedtools_bruteforce.sort_bed"""
     import random
     rnd = random.Random(4)
     lines = ["##gff-version 2", "##date 2026-10-02", "##sequence-region ref_38kb.fasta"]
@@ -700,7 +704,7 @@ def capture_repeatmask(T):
             toks = cmd.split() if shell else cmd
             assert toks[0] == "bedtools" and toks[1] == "sort"
             rows = fake._rows(toks[toks.index("-i") + 1])
-            stdout.write("".join("\t".join(r) + "\n" for r in iv.bed_sort(rows)))
+            stdout.write("".join("\t".join(r) + "\n" for r in bt.sort_bed(rows)))
             return 0
         T.subprocess.call = call
         try:
@@ -729,7 +733,7 @@ def nested_locus():
 
 class FakeAnnot(FakeSubprocess):
     """the tool calls of TELR_te.annotate_contig (minimap2_family=True): samtools faidx, the two minimap2 runs (canned PAF made by
-    the CPU oracle from the same sequences), bedtools intersect -wao / sort / merge -d / getfasta (telr_amd.intervals)"""
+    the CPU oracle from the same sequences), bedtools intersect -wao / sort / merge -d / getfasta (tools/bedtools_bruteforce.py)"""
     def __init__(self, seqs, s4_paf, s5_paf):
         FakeSubprocess.__init__(self, seqs, {})
         self.s4, self.s5 = s4_paf, s5_paf
@@ -745,11 +749,11 @@ class FakeAnnot(FakeSubprocess):
             stdout.write("".join(l + "\n" for l in self.s5)); return 0
         if tool == "bedtools" and c[1] == "intersect":
             a = self._rows(c[c.index("-a") + 1]); b = self._rows(c[c.index("-b") + 1])
-            stdout.write("".join("\t".join(r) + "\n" for r in iv.intersect_wao(a, b))); return 0
+            stdout.write("".join("\t".join(r) + "\n" for r in bt.intersect_wao(a, b))); return 0
         if tool == "bedtools" and c[1] == "merge" and "-d" in c:
             rows = self._rows(c[c.index("-i") + 1])
             cols = [int(x) - 1 for x in c[c.index("-c") + 1].split(",")]
-            stdout.write("".join("\t".join(r) + "\n" for r in iv.merge_distinct(rows, int(c[c.index("-d") + 1]), cols, c[c.index("-delim") + 1]))); return 0
+            stdout.write("".join("\t".join(r) + "\n" for r in bt.merge(rows, int(c[c.index("-d") + 1]), cols, ["distinct"] * len(cols), c[c.index("-delim") + 1]))); return 0
         return FakeSubprocess.call(self, cmd, stdout=stdout, shell=shell, **kw)
 
 

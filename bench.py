@@ -52,6 +52,10 @@ CONFIGS = {
     # name: (BASELINE.json config, chromosomes, coverage, read errors (sub, ins, del), preset, insertions, families, lead N)
     "c1": dict(label="configs[1]", preset="map-ont", err=(0.04, 0.02, 0.04)),
     "c2": dict(label="configs[2]", genome="dm6", coverage=30.0, preset="map-ont", err=(0.04, 0.02, 0.04), n_ins=1000, n_fam=127, lead_n=0),
+    # configs[2] on the HARD genome (round 6; telr_amd/synth.py HARD: tandem arrays, microsatellites, low-complexity stretches, segmental duplications,
+    # a satellite block next to 15 % of the insertions; reads with error bursts) -- not a BASELINE configuration: the same workload where the
+    # aligner heuristics this engine leaves out (seed rescue, max_chain_skip, RMQ chaining) and the over-size sort path would bite
+    "c2r": dict(label="configs[2] on the hard genome", genome="dm6", coverage=30.0, preset="map-ont", err=(0.04, 0.02, 0.04), n_ins=1000, n_fam=127, lead_n=0, hard=True),
     "c3": dict(label="configs[3]", genome="dm6", coverage=30.0, preset="ngmlr-pacbio", err=(0.013, 0.065, 0.052), n_ins=1000, n_fam=127, lead_n=0),
     "c4": dict(label="configs[4]", genome="chr22", coverage=50.0, preset="map-ont", err=(0.04, 0.02, 0.04), n_ins=3000, n_fam=1300, lead_n=11_000_000),
 }
@@ -218,19 +222,28 @@ def build_dataset(a, cfg, rank, world, lws):
     if a.genome_scale != 1.0:
         chroms = [(n, max(30000, int(L * a.genome_scale))) for n, L in chroms]
     lead_n = int(cfg["lead_n"] * a.genome_scale)
-    g = synth.make_genome(20261002, chroms, n_fam=cfg["n_fam"], n_ins=a.insertions or cfg["n_ins"], lead_n=lead_n, threads=min(procs, 8))
+    hard = synth.HARD if cfg.get("hard") else None
+    g = synth.make_genome(20261002, chroms, n_fam=cfg["n_fam"], n_ins=a.insertions or cfg["n_ins"], lead_n=lead_n, threads=min(procs, 8), hard=hard)
     cov = a.coverage or cfg["coverage"]
     plan = synth.plan_reads(g, cov, read_seed=(20261002 + 1000 * (rank + 1)) if a.scaling == "weak" else None)
     if a.scaling == "strong" and world > 1:
         blocks = np.array(shard.shard_reads(synth.block_bases(plan), world)[rank], np.int64)
     else:
         blocks = np.arange(plan["n_blocks"])
-    buf, off, ln, gid = synth.materialize_reads(g, plan, blocks, err=cfg["err"], procs=procs)
+    buf, off, ln, gid = synth.materialize_reads(g, plan, blocks, err=cfg["err"], procs=procs, burst=hard["burst"] if hard else None)
     loci = synth.make_loci(g)
     nb = int(sum(len(r) for r in g["ref"]))
     text = "synthetic %s-size genome (%d sequences, %d bp%s, %d-family TE library, 15%% TE-derived) + %.0fx %s-like reads (%d reads, %.2f Gbp planned, errors sub:ins:del %.3f:%.3f:%.3f) + %d spiked TE insertions (AF 0.25/0.5/1.0)" % (
         cfg["genome"], len(chroms), nb, (", %d-bp leading N block" % lead_n) if lead_n else "", cfg["n_fam"], cov,
         "ONT" if cfg["err"][1] < 0.05 else "PacBio-CLR", plan["n"], float(plan["length"].sum()) / 1e9, cfg["err"][0], cfg["err"][1], cfg["err"][2], len(g["insertions"]))
+    if hard:
+        import collections
+        nb_k = collections.Counter(); n_k = collections.Counter()
+        for f in g["hard_features"]:
+            n_k[f[3]] += 1; nb_k[f[3]] += f[2] - f[1]
+        text += "; HARD genome: " + ", ".join("%d %s (%.2f %% of the bases)" % (n_k[k], k, 100.0 * nb_k[k] / nb) for k in ("tandem", "micro", "lowcx", "segdup", "satellite")) + \
+                ", satellites next to %d of the insertions; reads with error bursts (one per ~%d bases, %d-%d bases at %.1f x the error rates)" % (
+                    n_k["satellite"], int(1 / hard["burst"][0]), hard["burst"][1], hard["burst"][2], hard["burst"][3])
     return dict(names=g["names"], ref=g["ref"], library=g["library"], reads=(buf, off, ln), read_gid=gid, loci=loci, text=text,
                 total_reads=plan["n"], total_bases=int(plan["length"].sum()))
 

@@ -388,6 +388,10 @@ const char *telr_stage_name(int i);
 typedef struct telr_counters {
     int64_t query_bases, minimizers, probes, anchors, chains, dp_problems, dp_cells,
             window_bases, cigar_ops, records;
+    /* engine-only (the oracle leaves them 0): queries with more anchors than one workgroup sorts in LDS (a read in a tandem
+     * array / satellite), and the ranges that held at least one such query and therefore took the two-step seeding + the
+     * library's segmented sort for it */
+    int64_t over_queries, over_ranges;
 } telr_counters;
 int  telr_last_counters(const telr_ctx *ctx, telr_counters *out);
 /* per DP class (TELR_N_DPCLS classes) of the last telr_map call:

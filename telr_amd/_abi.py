@@ -38,7 +38,7 @@ class Aln(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "query_bases", "minimizers", "probes", "anchors", "chains", "dp_problems", "dp_cells",
-        "window_bases", "cigar_ops", "records")]
+        "window_bases", "cigar_ops", "records", "over_queries", "over_ranges")]
 
 
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8

@@ -1923,6 +1923,8 @@ __device__ __forceinline__ int d_dp_class(int kind, int D, int steps, int pk_max
 __host__ __device__ __forceinline__ int d_onep_d(int q, int e, int q2, int e2) { return e > e2 ? (q2 - q + (e - e2) - 1) / (e - e2) : 1 << 20; }
 __host__ __device__ __forceinline__ bool d_tb4(int cls, int tb4) { return (cls == 17 && (tb4 & 1)) || (cls == 10 && (tb4 & 2)); }
 __host__ __device__ __forceinline__ int d_tb4_rowb(int cls) { return cls == 17 ? 8 : 12; }       // bytes per row: 4 * ceil(R / 2)
+// the z-drop extension classes spill in tiles of four rows (d_dp_pkx): a 64-byte line = four consecutive rows of 16 bytes
+__host__ __device__ __forceinline__ bool d_tb_tiled(int cls) { return cls == 18 || cls == 23 || cls == 24; }
 // dwords per packed trace-back row
 __device__ __forceinline__ int d_cls_slots(int cls)
 {
@@ -1967,6 +1969,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
     }
     else if (P.kind >= 3) tb = 0;
     else if (d_tb4(cls, tb4)) tb = ((int64_t)(((P.m + P.n) / 2 + 2) / 2) * (2 * d_tb4_rowb(cls)) + 63) & ~63LL;     // row pairs of nibbles
+    else if (d_tb_tiled(cls)) tb = (int64_t)(((P.m + P.n) / 2 + 4) / 4) * d_cls_slots(cls) * 16;     // tiles of four rows (d_dp_pkx)
     else if (cls >= 10) tb = ((int64_t)((P.m + P.n) / 2 + 1) * d_cls_slots(cls) * 4 + 63) & ~63LL;     // whole 64-byte lines (d_traceback_rows)
     else if (cls >= 5) tb = (int64_t)((P.m + P.n) / 4 + 1) * d_cls_slots(cls) * 4;
     else tb = ((int64_t)(P.m + P.n + 1) * stride + 127) & ~127LL;
@@ -2876,7 +2879,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
         for (int s = 32; s >= 1; s >>= 1) { int v = __shfl_xor(amax, s); amax = v > amax ? v : amax; v = __shfl_xor(amin, s); amin = v < amin ? v : amin; }
     }
     amin = __builtin_amdgcn_readfirstlane(amin);
-    uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off) + l * R;
+    uint32_t *tb32 = (uint32_t*)(A.tb + P.tb_off) + (EXT ? ((l * R) >> 2) * 16 + ((l * R) & 3) : l * R);      // (EXT: the tiled layout below)
     const int last_row = have ? mn >> 1 : -1;
     // base streams: the newest query base enters register 0 (low half) and ages towards register R-1, the newest
     // target base enters register R-1 (high half) and ages towards register 0
@@ -3065,6 +3068,17 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                         for (int u = 0; u < (R + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
                     }
                 }
+            } else if constexpr (EXT) {
+                // TILED spill of the extension classes (round 6): four consecutive rows of a lane's 16 bytes (R = 4: the lane's own four
+                // registers; R = 1: four neighbouring lanes) share one 64-byte line -- row k of dword x at dword
+                // (k >> 2) * 4 RW + (x >> 2) * 16 + (k & 3) * 4 + (x & 3).  The walk (d_traceback_lane) moves up a diagonal, i.e. up the
+                // rows in one byte column: one line per FOUR steps instead of one (64-diagonal band) or two (128) per step.
+                static_assert(!EXT || R == 4 || R == 1, "tiled spill: a lane owns a whole 16-byte group (R = 4) or one dword of it (R = 1)");
+                if (k <= last_row) {
+                    uint32_t *dst = tb32 + (int64_t)(k >> 2) * (4 * RW) + (k & 3) * 4;
+                    if constexpr (R == 4) *(uint4*)dst = make_uint4(row[0], row[1], row[2], row[3]);
+                    else dst[0] = row[0];
+                }
             } else if (k <= last_row) {
                 uint32_t *dst = tb32 + (int64_t)k * RW;
                 if constexpr (R % 4 == 0) {
@@ -3231,9 +3245,7 @@ __global__ void __launch_bounds__(64) k_dp_pkx16(DpArgs A)
 }
 
 // the wider extension bands (classes 23 / 24: D <= 128 / 256), same cell, same spill layout rule (32 / 64 dwords per row)
-#ifndef PKX8_LPP
-#define PKX8_LPP 8           /* lanes per problem of class 23: 8 lanes x 4 registers; 4 x 8 (16 problems per wave, 132 VGPRs) measured slower: 15.1 vs 11.7 ms per range */
-#endif
+#define PKX8_LPP 8           /* lanes per problem of class 23: 8 lanes x 4 registers; 4 x 8 (16 problems per wave, 132 VGPRs) measured slower in round 5: 15.1 vs 11.7 ms per range */
 __global__ void __launch_bounds__(64) k_dp_pkx_w8(DpArgs A)
 {
     __builtin_amdgcn_s_setprio(3);
@@ -3269,16 +3281,18 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
     const int cls = P.pad[0] & 0xff, dlo = P.dlo, mg = P.pad[0] >> 8;
     const int D = P.dhi - dlo + 1, stride = (D + 2) / 2;
     const int lpp = cls >= 5 ? d_cls_slots(cls) : 0;
-    const bool packed = cls >= 5;
+    const bool packed = cls >= 5, tiled = d_tb_tiled(cls);
     int i = res[pi].bi, j = res[pi].bj;
     uint32_t *cg = cig + P.cig_off;
     int no = 0, ml = 0, mc = 0, state = 0, cur_op = -1, cur_len = 0;
-    const int rowb = packed ? lpp * 4 : stride;      // bytes between consecutive rows of the trace-back matrix
+    const int rowb = tiled ? lpp * 16 : packed ? lpp * 4 : stride;      // bytes between consecutive rows of the trace-back matrix (tiled: between tiles of four rows)
     int64_t tag0 = -1, tag1 = -1, pfb = -2;           // lines in the two LDS slots; 128-byte block held in registers
     uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0, v4 = v0, v5 = v0, v6 = v0, v7 = v0;
     while (i > 0 && j > 0) {
         const int a = i + j, sl = (j - i - dlo) >> 1;
-        const int64_t off = (LAYOUT == 2 || cls >= 10) ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
+        // tiled (the extension classes, d_dp_pkx): row k = a >> 1 of dword x = sl >> 1 at dword (k >> 2) 4 lpp + (x >> 2) 16 + (k & 3) 4 + (x & 3)
+        const int64_t off = tiled ? ((((int64_t)(a >> 3) * (4 * lpp) + ((sl >> 3) << 4) + (((a >> 1) & 3) << 2) + ((sl >> 1) & 3)) << 2) + ((a & 1) << 1) + (sl & 1))
+                          : (LAYOUT == 2 || cls >= 10) ? ((((int64_t)(a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1))
                           : packed ? ((((int64_t)(a >> 2) * lpp + sl) << 2) + (a & 3)) : ((int64_t)a * stride + sl);
         // lines are taken relative to the 64-byte grid of the whole scratch buffer; the wave-interleaved classes keep their
         // bytes in 8-byte units 512 bytes apart (k_tb_gather) -- this generic walk reaches them only in the TELR_AB=tb_one_launch mode
@@ -3317,18 +3331,27 @@ __device__ __forceinline__ void d_traceback_lane(const DpProb *__restrict__ prob
             }
         }
         const int w = (int)(abs_off & 63);
-        const uint32_t t = (stage[slot * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
+        const uint8_t *st8 = (const uint8_t*)stage + ((slot * 1024 + lane) << 2);       // byte x of this lane's line at st8[(x >> 2) * 256 + (x & 3)]
+        const uint32_t t = st8[(w >> 2) * 256 + (w & 3)];
+        // tiled: the cells one to three steps up the diagonal are the same byte column of the rows above, 16 bytes apart in this
+        // very line while the row is not the tile's first -- read with the current cell, a run of diagonal moves is one trip
+        const int mij = i < j ? i : j, kr = tiled ? (a >> 1) & 3 : 0;
+        const bool v1 = kr >= 1 && mij > 1, v2 = kr >= 2 && mij > 2, v3 = kr >= 3 && mij > 3;
+        const uint32_t t1 = v1 ? st8[((w - 16) >> 2) * 256 + (w & 3)] : 0xffu, t2 = v2 ? st8[((w - 32) >> 2) * 256 + (w & 3)] : 0xffu, t3 = v3 ? st8[((w - 48) >> 2) * 256 + (w & 3)] : 0xffu;
+        const uint32_t nd = (uint32_t)((t1 & 7u) != 0u) << 1 | (uint32_t)((t2 & 7u) != 0u) << 2 | (uint32_t)((t3 & 7u) != 0u) << 3;
+        const uint32_t mb = (t >> 7) | ((t1 >> 7) & 1u) << 1 | ((t2 >> 7) & 1u) << 2 | ((t3 >> 7) & 1u) << 3;
         touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
         // one step of the walk without branches: the 64 lanes are in 64 different states
         const int s0 = state ? state : (int)(t & 7);                 // 0 = diagonal, 1/3 = deletion (E1/E2), 2/4 = insertion (F1/F2)
         const int isM = s0 == 0, isD = s0 & 1;
         const int op = isM ? 0 : (isD ? 2 : 1);
+        const int nn = isM ? __builtin_ctz(nd | 16u) : 1;            // cells of this trip: a run of 1 .. 4 diagonal moves, or one step of a gap (nd bit 0 is clear)
         state = (isM || !((t >> (2 + s0)) & 1)) ? 0 : s0;            // a gap state continues while its extension flag is set
-        ml += isM & (int)(t >> 7); mc += isM;
-        i -= isD ^ 1; j -= isM | isD;
+        ml += isM ? __builtin_popcount(mb & ((1u << nn) - 1u)) : 0; mc += isM ? nn : 0;
+        i -= isM ? nn : (isD ^ 1); j -= isM ? nn : isD;
         const bool same = op == cur_op;
         if (!same && cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
-        cur_len = same ? cur_len + 1 : 1; cur_op = op;
+        cur_len = same ? cur_len + nn : nn; cur_op = op;
     }
     if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
@@ -3406,28 +3429,50 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                                   : (((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1);
                 const bool act = i > 0 && j > 0 && o >= lim;
                 if (!__any(act)) break;
-                const int oo = act ? o : 0, w = oo & 63;
-                uint32_t t = (stage[((oo >> 6) & 1) * 1024 + (w >> 2) * 64 + lane] >> ((w & 3) * 8)) & 0xffu;
+                const int oo = act ? o : 0;
+                // byte of the cell at byte offset x of the problem's trace-back matrix (lines L + 1 and L are in the two LDS slots)
+#define TBR_BYTE(x) ((uint32_t)stage8[((((x) >> 6) & 1) * 1024 + (((x) & 63) >> 2) * 64 + lane) * 4 + ((x) & 3)])
+                const uint8_t *stage8 = (const uint8_t*)stage;
+                uint32_t t = TBR_BYTE(oo);
+                // UP TO FOUR DIAGONAL MOVES IN ONE TRIP (round 6): nine path steps in ten are diagonal moves, and the cell one step up
+                // the diagonal is the same byte column one row (rowb bytes) up -- for most classes inside the two lines this wave
+                // holds in LDS anyway.  The three cells above are read with the current one (independent LDS reads instead of a
+                // chain of four round trips), and a run of "H came from the diagonal" cells is ONE trip of the loop.
+                const int mij = i < j ? i : j, room = o - lim;
+                const bool v1 = act && mij > 1 && room >= rowb, v2 = act && mij > 2 && room >= 2 * rowb, v3 = act && mij > 3 && room >= 3 * rowb;
+                const uint32_t t1 = TBR_BYTE(v1 ? oo - rowb : 0), t2 = TBR_BYTE(v2 ? oo - 2 * rowb : 0), t3 = TBR_BYTE(v3 ? oo - 3 * rowb : 0);
+#undef TBR_BYTE
+                uint32_t nd, mb;                    // bit r: cell r of the diagonal is NOT a diagonal move (or not there); bases equal
                 if (rb4) {                                                         // even step: low nibble, odd step: high nibble
-                    const uint32_t nb = (t >> ((a & 1) << 2)) & 0xfu;               // raw: tag of H (2 diagonal, 1 E, 0 F), E extended, F opened
+                    const int sh = (a & 1) << 2;
+                    nd = (uint32_t)(!v1 || ((t1 >> sh) & 3u) != 2u) << 1 | (uint32_t)(!v2 || ((t2 >> sh) & 3u) != 2u) << 2 | (uint32_t)(!v3 || ((t3 >> sh) & 3u) != 2u) << 3;
+                    mb = 0;
+                    const uint32_t nb = (t >> sh) & 0xfu;                           // raw: tag of H (2 diagonal, 1 E, 0 F), E extended, F opened
                     t = (2u - (nb & 3u)) | (nb & 4u) | ((nb & 8u) ^ 8u);
                 } else if (tag8) {                                                  // raw: tag of H (4 - source), E1 / E2 extended, F1 / F2 opened
+                    nd = (uint32_t)(!v1 || (t1 & 7u) != 4u) << 1 | (uint32_t)(!v2 || (t2 & 7u) != 4u) << 2 | (uint32_t)(!v3 || (t3 & 7u) != 4u) << 3;
+                    mb = 0;
                     t = (4u - (t & 7u)) | (t & 0x28u) | ((t & 0x50u) ^ 0x50u);
+                } else {
+                    nd = (uint32_t)(!v1 || (t1 & 7u) != 0u) << 1 | (uint32_t)(!v2 || (t2 & 7u) != 0u) << 2 | (uint32_t)(!v3 || (t3 & 7u) != 0u) << 3;
+                    mb = (t >> 7) | (t1 >> 7) << 1 | (t2 >> 7) << 2 | (t3 >> 7) << 3;
                 }
                 if (act) {
                     touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
                     const int s0 = state ? state : (int)(t & (rb4 ? 3 : 7));
                     const int isM = s0 == 0, isD = s0 & 1;
                     const int op = isM ? 0 : (isD ? 2 : 1);
+                    // cells of this trip: the run of diagonal moves from the current cell on (1 .. 4), or one step of a gap
+                    const int nn = isM ? __builtin_ctz(nd | 16u) : 1;         // (nd bit 0 is clear: the current cell is a diagonal move here)
                     // a step inside a gap run costs its piece's extension, the step that enters the run (walking backwards: the
                     // run's LAST cell) its opening as well
                     if (!isM) gc += (s0 <= 2 ? o_.e : o_.e2) + (state ? 0 : (s0 <= 2 ? o_.q : o_.q2));
                     state = (isM || !((t >> ((rb4 ? 1 : 2) + s0)) & 1)) ? 0 : s0;
-                    ml += isM & (int)(t >> 7); mc += isM;
-                    i -= isD ^ 1; j -= isM | isD;
+                    ml += isM ? __builtin_popcount(mb & ((1u << nn) - 1u)) : 0; mc += isM ? nn : 0;
+                    i -= isM ? nn : (isD ^ 1); j -= isM ? nn : isD;
                     const bool same = op == cur_op;
                     if (!same && cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
-                    cur_len = same ? cur_len + 1 : 1; cur_op = op;
+                    cur_len = same ? cur_len + nn : nn; cur_op = op;
                 }
             }
             if (!__any(i > 0 && j > 0)) break;
@@ -3449,6 +3494,9 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
 }
 // trace-back of the packed fill classes, driven by the same cost-ordered wave table as the forward launch (one block
 // per table entry, one lane per problem of that entry): the long problems start first and no class waits for another
+#ifdef TB_PROF        /* debug tap (-DTB_PROF): per launch, the waves' own durations against the launch's span -- is the launch its longest wave? */
+__device__ unsigned long long g_tb_prof[8];      // [0] sum of wave ticks (100 MHz), [1] max (ticks << 16 | lines), [2] waves, [3] sum of lines, [4] first start, [5] last end
+#endif
 __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ probs, DpRes *__restrict__ res,
                                                      const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                      const uint32_t *__restrict__ waves, const int32_t *__restrict__ cls_list, ClsOff off, int32_t tb4, DpOpt o, int32_t tag8_steps)
@@ -3461,8 +3509,20 @@ __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ 
     const int rb4 = d_tb4(cls, tb4) ? d_tb4_rowb(cls) : 0;
     const DpProb P0 = probs[cls_list[off.off[cls] + first]];                   // the wave's longest problem: k_dp_pk chose the cell by it
     const bool tag8 = !rb4 && !(cls == 17 && d_onep_d(o.q, o.e, o.q2, o.e2) >= 16) && !(cls == 10 && d_onep_d(o.q, o.e, o.q2, o.e2) >= 20) && P0.m + P0.n <= tag8_steps;
+#ifdef TB_PROF
+    const unsigned long long t0_ = wall_clock64();
+#endif
     d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)], d_tb_interleaved(cls),
                      rb4, tag8, o, tb_all, cig, retry, stage);
+#ifdef TB_PROF
+    if (threadIdx.x == 0) {
+        const unsigned long long t1_ = wall_clock64(), dt = t1_ - t0_;
+        const int rowb_ = rb4 ? rb4 : PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)] * 4;
+        unsigned long long lines = (unsigned long long)(((P0.m + P0.n) / 2 + 1) * rowb_ + 63) >> 6; if (lines > 65535) lines = 65535;
+        atomicAdd(&g_tb_prof[0], dt); atomicMax(&g_tb_prof[1], dt << 16 | lines); atomicAdd(&g_tb_prof[2], 1ULL); atomicAdd(&g_tb_prof[3], lines);
+        atomicMin(&g_tb_prof[4], t0_); atomicMax(&g_tb_prof[5], t1_);
+    }
+#endif
 }
 
 // Trace-back of the few long / wide problems: one WAVE per problem.  Every lane runs the same walk (uniform control
@@ -3524,8 +3584,31 @@ __global__ void __launch_bounds__(64) k_traceback_w(const DpProb *__restrict__ p
             __syncthreads();
         }
         const int w = (int)(col - c0);
-        const uint32_t t = (win[(r0 - row) * 16 + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
         touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
+        if (state == 0) {
+            // A DIAGONAL RUN IN ONE TRIP (round 6): nine path steps in ten are diagonal moves and the walk took them one LDS round
+            // trip at a time on every lane alike.  Lane k now looks at the cell k steps up the diagonal (i - k, j - k) -- the same
+            // diagonal slot, so in every layout a byte of the window that is already in LDS -- and a ballot gives the length of
+            // the run of "H came from the diagonal" cells from the current cell on: the whole run is one step of the loop.
+            const int ik = i - lane, jk = j - lane, ak = a - 2 * lane;
+            int rowk; int64_t colk;
+            if (cls >= 10) { rowk = ak >> 1; colk = ((int64_t)(sl >> 1) << 2) + ((ak & 1) << 1) + (sl & 1); }
+            else if (packed) { rowk = ak >> 2; colk = ((int64_t)sl << 2) + (ak & 3); }
+            else { rowk = ak; colk = sl; }
+            const int kk = r0 - rowk, wk = (int)(colk - c0);
+            const bool inw = ik > 0 && jk > 0 && kk < 64 && wk >= 0 && wk < 64;
+            const uint32_t tk = inw ? (win[kk * 16 + (wk >> 2)] >> ((wk & 3) * 8)) & 0xffu : 0xffu;
+            const uint64_t stop = ~__ballot(inw && (tk & 7u) == 0u);
+            const int run = stop ? __builtin_ctzll(stop) : 64;
+            if (run > 0) {
+                const uint64_t low = run >= 64 ? ~0ULL : (1ULL << run) - 1;
+                ml += __builtin_popcountll(__ballot(inw && (tk >> 7)) & low); mc += run; i -= run; j -= run;
+                if (cur_op == 0) cur_len += run;
+                else { if (cur_len && lane == 0) cg[no] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; if (cur_len) ++no; cur_op = 0; cur_len = run; }
+                continue;
+            }
+        }
+        const uint32_t t = (win[(r0 - row) * 16 + (w >> 2)] >> ((w & 3) * 8)) & 0xffu;
         if (state == 0) state = t & 7;
         int op;
         if (state == 0) { op = 0; ml += (t >> 7) & 1; ++mc; --i; --j; }

@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(64) k_poa_window(PoaArgs A)
                 // 2 = one or two predecessors within the ring; 3 = anything else
                 const int dl = r ? lo_r[r] - lo_r[r - 1] : 9;
                 const int kind = np == 1 && pr0 == r && (unsigned)dl <= 1u ? dl : np <= 2 && ring_ ? 2 : 3;
-                pcb[r] = (int16_t)((nout[v] ? 0 : 1) << 14 | kind << 12 | np << 8 | base[v]);      // bit 14: no out-edge -- a candidate for the end, its last column is noted
+                // (the sweep's copy of the node's base: an ambiguous node -- an N of the draft -- is 6, which equals neither a piece's N (4) nor the pad (7):
+                // the oracle scores N against N as a mismatch, tor_poa `seq[j-1] == base && seq[j-1] < 4`; the merge reads base[] itself)
+                pcb[r] = (int16_t)((nout[v] ? 0 : 1) << 14 | kind << 12 | np << 8 | (base[v] < 4 ? base[v] : 6));      // bit 14: no out-edge -- a candidate for the end, its last column is noted
             }
             const bool need_h = __any(far_);
             __syncthreads();

@@ -1594,6 +1594,15 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
         HIPCHK(hipEventRecord(ctx->ev_side[u % TELR_NSIDE], used[u]));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[u % TELR_NSIDE], 0));
     }
+#ifdef TB_PROF
+    if (nw > 0) {
+        HIPCHK(hipDeviceSynchronize());
+        unsigned long long h[8]; HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tb_prof), sizeof(h)));
+        unsigned long long z[8] = {0, 0, 0, 0, ~0ULL, 0, 0, 0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tb_prof), z, sizeof(z)));
+        if (h[2]) fprintf(stderr, "[tb prof] k_traceback_pk: %llu waves, span %.3f ms, longest wave %.3f ms (%llu lines), mean wave %.3f ms, %.1f lines per wave, wave-ms / span = %.1f waves on the device on average\n",
+                          h[2], (double)(h[5] - h[4]) / 1e5, (double)(h[1] >> 16) / 1e5, h[1] & 0xffffULL, (double)h[0] / (double)h[2] / 1e5, (double)h[3] / (double)h[2], (double)h[0] / (double)(h[5] - h[4] ? h[5] - h[4] : 1));
+    }
+#endif
     if (!tb_split) {
         if (primary) HIPCHK(hipEventRecord(ctx->evk[3], st));
         hipLaunchKernelGGL(k_traceback, dim3((np + 63) / 64), dim3(64), 0, st, d_probs, d_res, np, d_tb, *d_rawcig_io, d_retry, (const int32_t*)nullptr);
@@ -1736,6 +1745,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     HIPCHK(hipStreamSynchronize(st));
     if (na64 >= (1LL << 31) - 256) { stage_collect(ctx); return TELR_SPLIT_RANGE; }
     ctx->ctr.minimizers += nmz; ctx->ctr.probes += nmz;
+    ctx->ctr.over_queries += n_over; ctx->ctr.over_ranges += n_over > 0;
     static const bool lib_sort = ab_on("sort64");      // A/B: rocPRIM's segmented radix sort for every query
     const bool any_over = n_over > 0;
     uint64_t *d_keys, *d_skeys;

@@ -60,9 +60,24 @@ def simulate_reads(rng, genome_seqs, n_reads, mean_len, sigma=0.5, min_len=500, 
 
 # ---------------------------------------------------------------------------------------
 # bulk generators used by bench.py (vectorised over whole read sets)
-def mutate_bulk(rng, seq, seg_len, sub, ins, dele):
-    """mutate() over a concatenation of segments; returns (new array, new per-segment lengths)."""
+def burst_mask(rng, n, burst):
+    """bases inside an error burst: bursts start at a rate of burst[0] per base and last burst[1] .. burst[2] bases"""
+    st = np.nonzero(rng.random(n, dtype=np.float32) < burst[0])[0]
+    d = np.zeros(n + 1, np.int32)
+    if len(st):
+        ln = rng.integers(burst[1], burst[2] + 1, size=len(st))
+        np.add.at(d, st, 1); np.add.at(d, np.minimum(st + ln, n), -1)
+    return np.cumsum(d[:n]) > 0
+
+
+def mutate_bulk(rng, seq, seg_len, sub, ins, dele, burst=None):
+    """mutate() over a concatenation of segments; returns (new array, new per-segment lengths).
+    burst = (starts per base, shortest, longest, factor): inside a burst every error rate is `factor` times the read's (the
+    hard data sets: a stretch of a read where the basecaller lost the signal)."""
     n = len(seq)
+    if burst is not None:
+        f = np.where(burst_mask(rng, n, burst), np.float32(burst[3]), np.float32(1.0))
+        sub, ins, dele = sub * f, ins * f, dele * f
     r = rng.random(n, dtype=np.float32)
     keep = r >= dele
     is_sub = keep & (r < dele + sub)
@@ -89,7 +104,7 @@ def mutate_bulk(rng, seq, seg_len, sub, ins, dele):
     return res, new_len.astype(np.int64)
 
 
-def sample_reads_bulk(rng, hap, n_reads, mean_len, sigma, min_len, max_len, err, chunk=512):
+def sample_reads_bulk(rng, hap, n_reads, mean_len, sigma, min_len, max_len, err, chunk=512, burst=None):
     """Reads from one haplotype (uint8 array). -> (buf, off, len, truth[n,3]=(start,end,strand))"""
     G = len(hap)
     mu = np.log(mean_len) - sigma * sigma / 2
@@ -108,7 +123,7 @@ def sample_reads_bulk(rng, hap, n_reads, mean_len, sigma, min_len, max_len, err,
         idx = np.where(st == 1, starts[c0:c1][rid] + L[rid] - 1 - within, starts[c0:c1][rid] + within)
         frag = hap[idx]
         frag = np.where(st == 1, _COMP[frag], frag)
-        res, nl = mutate_bulk(rng, frag, L, *err)
+        res, nl = mutate_bulk(rng, frag, L, *err, burst=burst)
         bufs.append(res); out_len[c0:c1] = nl
     buf = np.concatenate(bufs) if bufs else np.zeros(0, np.uint8)
     off = np.cumsum(out_len) - out_len
@@ -121,8 +136,106 @@ def make_te_library(rng, n_fam, lo=300, hi=8000):
     return [random_seq(rng, int(L), gc=0.45) for L in lens]
 
 
+# ---------------------------------------------------------------------------------------
+# The HARD genome (round 6).  The i.i.d.-plus-dispersed-TE-copies genome above has none of the sequence classes a long-read
+# aligner's heuristics exist for (minimap2's occurrence filter, seed rescue, max_chain_skip; NGMLR's candidate voting) and in
+# which dm6's own TEs sit: tandem arrays, microsatellites, low-complexity stretches, satellite blocks, segmental duplications.
+# `hard` adds them, seeded, and the reads get error bursts.  Defaults: ~4 % of the sequence in tandem arrays (unit 2-500 bp,
+# array 0.1-50 kb, copies 0-5 % diverged), ~150 microsatellites per Mb (unit 1-6 bp, 20-300 bp), ~1 % AT-rich / homopolymer-rich
+# low-complexity stretches (100-3,000 bp), one segmental duplication per ~6 Mb (10-100 kb, 1-5 % diverged, either orientation),
+# a satellite block (unit 5-400 bp, 1-10 kb) within 50-400 bp of 15 % of the spiked insertions, and in the reads one error burst
+# per ~20 kb (50-300 bases at 3.5 times the read's error rates).
+HARD = dict(tandem_frac=0.04, micro_per_mb=150, lowcx_frac=0.01, segdup_every=6_000_000, sat_ins_frac=0.15, burst=(1.0 / 20000, 50, 300, 3.5))
+
+
+def _tandem_array(r, unit_len, arr_len, gc, div):
+    unit = random_seq_fast(r, unit_len, gc)
+    arr = np.tile(unit, arr_len // unit_len + 2)[:arr_len]
+    if div > 0:
+        arr = mutate(r, arr, div, div / 4, div / 4)
+    return arr
+
+
+def _put(ref, p, seq, lo=0):
+    """overwrite ref[p : p + len(seq)] (clipped to the sequence, never into the leading N block) -> (start, end) written"""
+    p = max(lo, p); e = min(len(ref), p + len(seq))
+    if e <= p:
+        return p, p
+    ref[p:e] = seq[:e - p]
+    return p, e
+
+
+def harden_sequence(r, ref, lo=0, gc=0.42, hard=None):
+    """tandem arrays, microsatellites, low-complexity stretches and segmental duplications written over `ref` (in place) from
+    generator `r`; -> [(start, end, kind)]"""
+    hard = HARD if hard is None or hard is True else hard
+    L = len(ref)
+    feats = []
+    if L - lo < 50000:
+        return feats
+    covered = 0
+    while covered < hard["tandem_frac"] * (L - lo):
+        unit_len = int(np.exp(r.uniform(np.log(2), np.log(500))))
+        arr_len = int(np.exp(r.uniform(np.log(100), np.log(50000))))
+        arr = _tandem_array(r, unit_len, max(arr_len, 2 * unit_len), gc, float(r.uniform(0, 0.05)))
+        s, e = _put(ref, int(r.integers(lo, L - len(arr))), arr, lo)
+        feats.append((s, e, "tandem")); covered += e - s
+    for _ in range(int(hard["micro_per_mb"] * (L - lo) / 1e6)):
+        arr = _tandem_array(r, int(r.integers(1, 7)), int(r.integers(20, 301)), 0.5, float(r.uniform(0, 0.03)))
+        s, e = _put(ref, int(r.integers(lo, L - len(arr))), arr, lo)
+        feats.append((s, e, "micro"))
+    covered = 0
+    while covered < hard["lowcx_frac"] * (L - lo):
+        n = int(np.exp(r.uniform(np.log(100), np.log(3000))))
+        if r.random() < 0.5:
+            seq = random_seq_fast(r, n, float(r.uniform(0.03, 0.2)))                     # AT-rich
+        else:                                                                           # runs of homopolymers, 3-25 bases each
+            runs = r.integers(3, 26, size=n // 3 + 1)
+            seq = np.repeat(BASES[r.integers(0, 4, size=len(runs))], runs)[:n]
+        s, e = _put(ref, int(r.integers(lo, L - n)), seq, lo)
+        feats.append((s, e, "lowcx")); covered += e - s
+    for _ in range(max(1 if L - lo >= 1_000_000 else 0, int((L - lo) // hard["segdup_every"]))):
+        n = int(np.exp(r.uniform(np.log(10000), np.log(100000))))
+        src = int(r.integers(lo, L - n)); dst = int(r.integers(lo, L - n - n // 20))
+        if abs(src - dst) < 2 * n:
+            continue
+        d = float(r.uniform(0.01, 0.05))
+        cp = mutate(r, ref[src:src + n], d * 0.8, d * 0.1, d * 0.1)
+        if r.integers(0, 2):
+            cp = revcomp_arr(cp)
+        s, e = _put(ref, dst, cp, lo)
+        feats.append((src, src + n, "segdup_src")); feats.append((s, e, "segdup"))
+    return feats
+
+
+def satellites_at_sites(r, ref, sites, tsd_max=8, gc=0.42, hard=None, keep_clear=300):
+    """a satellite block next to a fraction of the insertion sites (`sites`: sorted positions on this sequence): unit 5-400 bp,
+    1-10 kb, 0-3 % diverged copies, starting 50-400 bp after the site's duplication or ending 50-400 bp before the site; never
+    over a site itself nor within `keep_clear` bases of a neighbouring one.  -> [(start, end, 'satellite', site)]"""
+    hard = HARD if hard is None or hard is True else hard
+    feats = []
+    sites = [int(x) for x in sites]
+    for k, p in enumerate(sites):
+        if r.random() >= hard["sat_ins_frac"]:
+            continue
+        gap = int(r.integers(50, 401))
+        arr = _tandem_array(r, int(np.exp(r.uniform(np.log(5), np.log(400)))), int(np.exp(r.uniform(np.log(1000), np.log(10000)))), gc, float(r.uniform(0, 0.03)))
+        if r.integers(0, 2):          # downstream of the site
+            s = p + tsd_max + gap
+            room = (sites[k + 1] - keep_clear if k + 1 < len(sites) else len(ref)) - s
+        else:                          # upstream
+            room = p - gap - (sites[k - 1] + tsd_max + keep_clear if k > 0 else 0)
+            s = p - gap - min(len(arr), max(0, room))
+        n = min(len(arr), room)
+        if n < 200 or s < 0:
+            continue
+        ref[s:s + n] = arr[:n]
+        feats.append((s, s + n, "satellite", p))
+    return feats
+
+
 def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total_bases=470_000_000, n_ins=200,
-                        n_fam=127, te_frac=0.15, gc=0.42, err=(0.04, 0.02, 0.04), sigma=0.6, read_seed=None):
+                        n_fam=127, te_frac=0.15, gc=0.42, err=(0.04, 0.02, 0.04), sigma=0.6, read_seed=None, hard=None):
     """BASELINE.json configs[1]: synthetic chr2L-sized genome + ONT-like reads + spiked TE insertions.
 
     Returns dict(ref=uint8 array, library=[arrays], reads=(buf, off, len), insertions=[(pos, fam, strand, tsd, af)],
@@ -143,8 +256,13 @@ def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total
         ref[p:p + len(cp)] = cp
         covered += len(cp)
         te_copies.append((p, p + len(cp)))
+    hard_feats = []
+    if hard:
+        hard_feats = harden_sequence(np.random.default_rng([seed, 7]), ref, 0, gc, hard)
     # spiked non-reference insertions, >= 5 kb apart
     sites = np.sort(rng.choice(np.arange(5000, genome_len - 5000, 5000), size=n_ins, replace=False)) + rng.integers(0, 2000, size=n_ins)
+    if hard:
+        hard_feats += satellites_at_sites(np.random.default_rng([seed, 8]), ref, sites, gc=gc, hard=hard)
     ins = []
     for p in sites:
         ins.append((int(p), int(rng.integers(0, n_fam)), int(rng.integers(0, 2)), int(rng.integers(4, 9)), float(rng.choice([0.5, 1.0]))))
@@ -165,13 +283,14 @@ def make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10000, total
         rng = np.random.default_rng(read_seed)
     mean_len = total_bases / n_reads
     nA = n_reads // 2
-    rA = sample_reads_bulk(rng, haps[0], nA, mean_len, sigma, 500, 150000, err)
-    rB = sample_reads_bulk(rng, haps[1], n_reads - nA, mean_len, sigma, 500, 150000, err)
+    burst = (HARD if hard is True else hard)["burst"] if hard else None
+    rA = sample_reads_bulk(rng, haps[0], nA, mean_len, sigma, 500, 150000, err, burst=burst)
+    rB = sample_reads_bulk(rng, haps[1], n_reads - nA, mean_len, sigma, 500, 150000, err, burst=burst)
     buf = np.concatenate([rA[0], rB[0]])
     ln = np.concatenate([rA[2], rB[2]])
     off = np.cumsum(ln.astype(np.int64)) - ln
     truth = np.concatenate([np.c_[np.zeros(nA, np.int64), rA[3]], np.c_[np.ones(n_reads - nA, np.int64), rB[3]]])
-    return dict(ref=ref, library=lib, reads=(buf, off.astype(np.int64), ln.astype(np.int32)), insertions=ins, truth=truth, haps=haps, te_copies=te_copies)
+    return dict(ref=ref, library=lib, reads=(buf, off.astype(np.int64), ln.astype(np.int32)), insertions=ins, truth=truth, haps=haps, te_copies=te_copies, hard_features=hard_feats)
 
 
 def make_loci_from_dataset(d, n_loci, seed=7, flank=(8000, 15000), reads_cap=60, window=1000):
@@ -245,7 +364,7 @@ def _pool_map(fn, items, threads):
         return list(ex.map(fn, items))
 
 
-def make_genome(seed, chroms, n_fam=127, te_frac=0.15, gc=0.42, n_ins=1000, lead_n=0, afs=(0.25, 0.5, 1.0), threads=1):
+def make_genome(seed, chroms, n_fam=127, te_frac=0.15, gc=0.42, n_ins=1000, lead_n=0, afs=(0.25, 0.5, 1.0), threads=1, hard=None):
     """-> dict(names, ref=[uint8 arrays], library, insertions=[(chrom id, pos, fam, strand, tsd, af)] sorted,
     haps[h][c] = uint8 arrays, hap_ins[h][c] = (ref positions, cumulative shift after each insertion present on h)).
     lead_n: length of a leading N block of every chromosome (chr22's 11 Mb)."""
@@ -270,11 +389,14 @@ def make_genome(seed, chroms, n_fam=127, te_frac=0.15, gc=0.42, n_ins=1000, lead
             p = int(r.integers(lo, L - len(cp)))
             ref[p:p + len(cp)] = cp
             covered += len(cp)
+        feats = harden_sequence(np.random.default_rng([seed, 7, ci]), ref, lo, gc, hard) if hard else []
         if lo:
             ref[:lo] = ord("N")
-        return ref
+        return ref, feats
 
-    refs = _pool_map(one_chrom, list(range(len(chroms))), threads)
+    made = _pool_map(one_chrom, list(range(len(chroms))), threads)
+    refs = [m[0] for m in made]
+    hard_feats = [[(ci,) + f for f in m[1]] for ci, m in enumerate(made)]
     # insertion sites: slots of a 5-kb grid over all chromosomes (>= 3 kb apart after the jitter), outside the N block
     slots_c, slots_p = [], []
     for ci, (_, L) in enumerate(chroms):
@@ -288,6 +410,10 @@ def make_genome(seed, chroms, n_fam=127, te_frac=0.15, gc=0.42, n_ins=1000, lead
         ins.append((int(slots_c[k]), int(slots_p[k] + rng.integers(0, 2000)), int(rng.integers(0, n_fam)), int(rng.integers(0, 2)),
                     int(rng.integers(4, 9)), float(rng.choice(afs))))
     ins.sort()
+    if hard:          # satellite blocks next to a share of the insertion sites (before the haplotypes are cut from the reference)
+        for ci in range(len(chroms)):
+            sites = [p for (c, p, *_rest) in ins if c == ci]
+            hard_feats[ci] += [(ci,) + f for f in satellites_at_sites(np.random.default_rng([seed, 8, ci]), refs[ci], sites, gc=gc, hard=hard)]
 
     def build(hc):
         h, ci = hc
@@ -307,7 +433,7 @@ def make_genome(seed, chroms, n_fam=127, te_frac=0.15, gc=0.42, n_ins=1000, lead
     built = _pool_map(build, [(h, ci) for h in range(N_HAP) for ci in range(len(chroms))], threads)
     haps = [[built[h * len(chroms) + ci][0] for ci in range(len(chroms))] for h in range(N_HAP)]
     hap_ins = [[built[h * len(chroms) + ci][1] for ci in range(len(chroms))] for h in range(N_HAP)]
-    return dict(names=names, ref=refs, library=lib, insertions=ins, haps=haps, hap_ins=hap_ins, seed=seed)
+    return dict(names=names, ref=refs, library=lib, insertions=ins, haps=haps, hap_ins=hap_ins, seed=seed, hard_features=[f for fs in hard_feats for f in fs])
 
 
 def hap_to_ref(g, h, ci, x):
@@ -367,15 +493,15 @@ def _mat_block(b):
         s = int(plan["start"][i]); f = g_haps[plan["hap"][i]][plan["chrom"][i]][s:s + int(plan["length"][i])]
         frags.append(_COMP[f[::-1]] if plan["strand"][i] else f)
     frag = np.concatenate(frags) if frags else np.zeros(0, np.uint8)
-    return mutate_bulk(rng, frag, L, *err)
+    return mutate_bulk(rng, frag, L, *err, burst=_MAT.get("burst"))
 
 
-def materialize_reads(g, plan, blocks=None, err=(0.04, 0.02, 0.04), procs=1):
+def materialize_reads(g, plan, blocks=None, err=(0.04, 0.02, 0.04), procs=1, burst=None):
     """Bases of the reads of `blocks` (default all), block by block with generator (seed, 3, block) -- the same
     bases whatever the world size or the worker count.  procs > 1: forked worker processes (call before the
     process touches the GPU).  -> (buf, off, len, read_ids): read_ids[i] = index of sequence i in the plan."""
     blocks = np.arange(plan["n_blocks"]) if blocks is None else np.asarray(blocks)
-    _MAT.update(haps=g["haps"], plan=plan, err=err)
+    _MAT.update(haps=g["haps"], plan=plan, err=err, burst=burst)
     items = [int(b) for b in blocks]
     if procs > 1 and len(items) > 1:
         import multiprocessing as mp

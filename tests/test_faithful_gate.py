@@ -177,12 +177,15 @@ BITS = [("look-back 5000", 0x100), ("full-band fills + uncapped extensions", 0x2
         ("high-occurrence seed rescue", 0x2000), ("long join (re-chain with bw_long 20,000)", 0x4000), ("RMQ-style chaining (-r100k, unbounded look-back)", 0x8000)]
 
 
-def workload(kind, n):
-    """(index options, map options, reference strings, read strings) of a gate workload"""
+def workload(kind, n, hard=False):
+    """(index options, map options, reference strings, read strings) of a gate workload; hard: the same workload on the HARD
+    genome of telr_amd/synth.py (tandem arrays, microsatellites, low-complexity stretches, segmental duplications, satellite
+    blocks next to insertions, reads with error bursts)"""
+    hard = True if hard else None
     if kind == "flanks-asm10":
         # 500-base flanks as the liftover cuts them (TELR_liftover.py:167-266), from TE-free and TE-derived reference sequence
         # alike, 0.5 % substitutions (a polished contig), asm10 -N 10
-        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10, total_bases=100000)
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=10, total_bases=100000, hard=hard)
         rng = np.random.default_rng(21)
         ref = d["ref"]
         reads = []
@@ -193,14 +196,18 @@ def workload(kind, n):
         io, mo = preset("asm10"); mo.best_n = 10
         return io, mo, [bytes(ref).decode()], reads
     if kind in ("clr-map-pb", "clr-ngmlr-pacbio"):
-        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, err=(0.013, 0.065, 0.052), read_seed=20261002 + 77)
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, err=(0.013, 0.065, 0.052), read_seed=20261002 + 77, hard=hard)
         io, mo = preset("map-pb" if kind == "clr-map-pb" else "ngmlr-pacbio")
     elif kind == "ont-ngmlr-ont":
-        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, read_seed=20261002 + 78)
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, read_seed=20261002 + 78, hard=hard)
         io, mo = preset("ngmlr-ont")
     elif kind == "c4-density":
         # the repeat density of configs[4]: a 1,300-family library, 45 % of the sequence TE-derived
-        d = synth.make_stage1_dataset(seed=20261002 + 4, genome_len=12_000_000, n_reads=6000, total_bases=54_000_000, n_ins=100, n_fam=1300, te_frac=0.45, gc=0.47, read_seed=20261002 + 79)
+        d = synth.make_stage1_dataset(seed=20261002 + 4, genome_len=12_000_000, n_reads=6000, total_bases=54_000_000, n_ins=100, n_fam=1300, te_frac=0.45, gc=0.47, read_seed=20261002 + 79, hard=hard)
+        io, mo = preset("map-ont")
+    elif kind == "ont-map-ont":
+        # the configs[2] default (`--aligner minimap2`, TELR_alignment.py:56-86): round 6, with the hard genome
+        d = synth.make_stage1_dataset(seed=20261002, genome_len=23513712, n_reads=6000, total_bases=54_000_000, read_seed=20261002 + 78, hard=hard)
         io, mo = preset("map-ont")
     else:
         raise ValueError(kind)
@@ -209,8 +216,11 @@ def workload(kind, n):
     return io, mo, [bytes(d["ref"]).decode()], [bytes(buf[off[i]:off[i] + ln[i]]).decode() for i in pick]
 
 
-def bit_table(kind, n, bits=None):
-    io, mo, ref, reads = workload(kind, n)
+ZDROP_ROWS = ("z-drop 400 (minimap2's value) instead of the preset's", "no z-drop at all (NGMLR has none) instead of the preset's")
+
+
+def bit_table(kind, n, bits=None, hard=False):
+    io, mo, ref, reads = workload(kind, n, hard)
     oix = ob.OracleIndex(ref, io)
     rows = []
     base = _map_threads(oix, reads, mo)
@@ -227,6 +237,11 @@ def bit_table(kind, n, bits=None):
         # (the preset's q / e / q2 / e2, which apply once cx_scale is 0)
         mf = mo.copy(); mf.cx_scale = 0
         rows.append((CONVEX, drift(oix, reads, mo, other=mf)))
+    if mo.zdrop < 400 and bits is None:
+        # round 5 set `ngmlr-ont`'s z-drop to 100 (a speed change on the reference's DEFAULT aligner, telr_amd/presets.py): its own rows
+        for name, zd in zip(ZDROP_ROWS, (400, 1 << 24)):
+            mf = mo.copy(); mf.zdrop = zd
+            rows.append((name, drift(oix, reads, mo, other=mf)))
     if mo.bw < 20000:
         mf = mo.copy(); mf.flags |= 0x4000 | 0x10000
         rows.append(("long join, not counting reads whose joined record z-drops in a fill (minimap2 splits it again)", drift(oix, reads, mo, other=mf, forgive_zdrop=True)))

@@ -757,6 +757,31 @@ def main():
                 rate = ab / dts_ / 1e9
                 shard_out["ranks"][str(nrk)] = {"shard_gbp": float(ln_all[idx].sum()) / 1e9, "ms_per_step": dts_ / n_sh * 1e3, "gbp_per_s": rate, "efficiency_vs_one_gpu": rate / value,
                                                 "stage_ms_last_call": {k: round(v, 2) for k, v in eng.stage_ms().items() if v >= 0.3}}
+                # round 6: what the shard's BAM costs its rank locally -- records, sort, BGZF on the device and the write of the rank's
+                # share of the file (tmpfs) -- so that the estimate below is end to end, not map-only.  (Not in it: the record exchange, 0.8 GB per
+                # rank over xGMI at 8 ranks, and rank skew: no second device on this pool.)
+                if a.bam_leg == "device":
+                    try:
+                        from telr_amd._abi import MF_KEEP_CIGARS
+                        from telr_amd.aligner import Index
+                        import tempfile
+                        mo_k = type(mo).from_buffer_copy(mo); mo_k.flags |= MF_KEEP_CIGARS
+                        bdir = a.bam_dir if os.path.isdir(a.bam_dir) and os.access(a.bam_dir, os.W_OK) else tempfile.gettempdir()
+                        bpath = os.path.join(bdir, "telr_bench_shard%d.bam" % nrk)
+                        qn_sub = Index._cstr_array(["read%d" % D["read_gid"][i] for i in idx])
+                        tb_s = []
+                        for rep in range(3):
+                            ix.bam_release_wait(); sync(); t0b = time.time()
+                            rk = ix.map_raw(sub, mo_k); t_m = time.time() - t0b
+                            ix.write_bam_device(rk, sub, qn_sub, D["names"], bpath, md=True, cs=True, softclip=True, cmdline="bench", index=True, level=a.bam_level)
+                            sync(); tb_s.append(time.time() - t0b - t_m)
+                            ix.free_raw(rk)
+                        for f in (bpath, bpath + ".bai"):
+                            if os.path.exists(f):
+                                os.unlink(f)
+                        shard_out["ranks"][str(nrk)]["bam_seconds_local"] = sorted(tb_s[1:])[0]
+                    except Exception as e:
+                        shard_out["ranks"][str(nrk)]["bam_seconds_local"] = None; shard_out["ranks"][str(nrk)]["bam_error"] = "%s: %s" % (type(e).__name__, e)
                 sub.free()
         except Exception as e:
             shard_out = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -959,6 +984,22 @@ def main():
             return good, af_ok, why
         n_rows = len(rows)
         good, af_ok, why = tally(rows)
+        # round 6: the loci leg at 1 / N of the load -- the loci rank 0 of an N-rank run is dealt (LPT), run alone on this GPU
+        loci_shard_s = {}
+        if world == 1 and shard_out is not None and "ranks" in shard_out:
+            try:
+                costs = [locus_pipeline.locus_cost(l) + 2 * int(b) for l, b in zip(loci, rb_loc)]
+                for nrk in (2, 4, 8):
+                    mine = shard.shard_loci(costs, nrk)[0]
+                    lsub = [loci[i] for i in mine]
+                    ts_ = []
+                    for rep in range(3):
+                        sync(); t0 = time.time()
+                        locus_pipeline.run_loci_distributed(eng, ix10, D["names"], lambda ch: ref_of[ch], lsub, lib_names, lib, shards=[list(range(len(lsub)))], presets=presets_arg, read_set=qs)
+                        sync(); ts_.append(time.time() - t0)
+                    loci_shard_s[str(nrk)] = {"loci": len(lsub), "seconds": sorted(ts_)[1]}
+            except Exception as e:
+                loci_shard_s = {"error": "%s: %s" % (type(e).__name__, e)}
         # The OTHER call set, in every line: the per-locus calls S4-S6 run minimap2's `-x map-ont|map-pb`, whose 2.22 defaults
         # carry the long join (-r500,20000) -- [recall]-grade, there is no minimap2 here to settle it.  With the long join a library hit
         # chains ACROSS an insertion nested in a reference TE copy and the reference's own merge / decision tree calls the locus
@@ -1141,6 +1182,24 @@ def main():
     if bam_out is not None:
         out["stage1_to_sorted_bam"] = bam_out
     if shard_out is not None:
+        # end to end (round 6): map step + the rank's local BAM phases + the loci leg, rank 0's share of an N-rank run against the one-GPU run of the
+        # same three -- still an estimate from ONE device (no exchange over xGMI, no skew between ranks)
+        try:
+            ls = locals().get("loci_shard_s") or {}
+            if "ranks" in shard_out and bam_out is not None and bam_out.get("bam_seconds") is not None and loci_out is not None and "error" not in ls:
+                ms_step = dt / a.steps * 1e3
+                t1 = ms_step / 1e3 + bam_out["bam_seconds"] + loci_out["seconds"]
+                e2e = {"one_gpu_seconds": {"map_step": ms_step / 1e3, "bam_local": bam_out["bam_seconds"], "loci_pass": loci_out["seconds"], "sum": t1}, "ranks": {}}
+                for nrk, rv in shard_out["ranks"].items():
+                    if rv.get("bam_seconds_local") is None or nrk not in ls:
+                        continue
+                    tn = rv["ms_per_step"] / 1e3 + rv["bam_seconds_local"] + ls[nrk]["seconds"]
+                    e2e["ranks"][nrk] = {"map_step": rv["ms_per_step"] / 1e3, "bam_local": rv["bam_seconds_local"], "loci_pass": ls[nrk]["seconds"], "loci": ls[nrk]["loci"], "sum": tn,
+                                         "speedup_vs_one_gpu": t1 / tn, "efficiency": t1 / tn / int(nrk)}
+                e2e["what"] = "rank 0's share of an N-rank run (reads by cumulative bases, loci by LPT) through the map step, the device BAM writer and the loci pass, alone on this GPU, against the one-GPU run of the same three: what the local work allows, before the exchanges (records + packed reads of the job BAM, window reads, ONE all-gather of 104-byte rows) and rank skew"
+                shard_out["end_to_end"] = e2e
+        except Exception as e:
+            shard_out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["expected_strong_scaling"] = shard_out
     if a.loci and locals().get("flank_parity") is not None:
         out["flank_parity_asm10"] = flank_parity

@@ -37,6 +37,7 @@ extern "C" {
 #define TELR_E_ARG        -3   /* invalid argument                           */
 #define TELR_E_RANGE      -4   /* input exceeds the engine's coordinate bits */
 #define TELR_E_NOMEM      -5
+#define TELR_E_IO         -6   /* a file could not be opened / mapped / written (telr_fasta_load: errno is the caller's to read) */
 
 /* ---- alignment record flags -------------------------------------------- */
 #define TELR_F_PRIMARY     0x1   /* parent == self                                  */

@@ -41,6 +41,8 @@ class Counters(C.Structure):
         "window_bases", "cigar_ops", "records", "over_queries", "over_ranges")]
 
 
+# return codes (include/telr_hip.h)
+TELR_OK, TELR_E_NODEVICE, TELR_E_HIP, TELR_E_ARG, TELR_E_RANGE, TELR_E_NOMEM, TELR_E_IO = 0, -1, -2, -3, -4, -5, -6
 F_PRIMARY, F_SECONDARY, F_SUPPL, F_REV = 1, 2, 4, 8
 MF_CIGAR, MF_PER_TARGET, MF_FAITHFUL, MF_KEEP_CIGARS = 1, 2, 4, 8
 N_STAGES = 16

@@ -28,16 +28,17 @@ extern "C" int64_t telr_fasta_bases(const telr_fasta *f) { return f ? (int64_t)f
 extern "C" int telr_fasta_load(const char *path, telr_fasta **out)
 {
     if (!path || !out) return TELR_E_ARG;
+    // (I/O failures have their own code since round 6: TELR_E_ARG is left for a layout this parser refuses, which the Python reader may still take)
     int fd = open(path, O_RDONLY);
-    if (fd < 0) return TELR_E_ARG;
+    if (fd < 0) return TELR_E_IO;
     struct stat sb;
-    if (fstat(fd, &sb) != 0) { close(fd); return TELR_E_ARG; }
+    if (fstat(fd, &sb) != 0) { close(fd); return TELR_E_IO; }
     const size_t n = (size_t)sb.st_size;
     telr_fasta *F = new telr_fasta();
     if (n == 0) { close(fd); *out = F; return TELR_OK; }
     const char *p = (const char*)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if (p == MAP_FAILED) { delete F; return TELR_E_ARG; }
+    if (p == MAP_FAILED) { delete F; return TELR_E_IO; }
     static const bool trace = trace_on("fasta");
     auto tt0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { if (!trace) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[fasta %s] %-22s %8.2f ms\n", path, what, std::chrono::duration<double, std::milli>(t1 - tt0).count()); tt0 = t1; };

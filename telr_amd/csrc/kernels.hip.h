@@ -573,6 +573,14 @@ __global__ void __launch_bounds__(SK_THREADS) k_sketch_hpc(SketchHpcArgs A)
 
 // ---------------------------------------------------------------------------------------
 // 2. index build helpers
+// index build: the sort keys (hash = x >> 8) and their values (y) into the arrays the radix sort starts from
+__global__ void __launch_bounds__(256) k_ix_hash_keys(const uint64_t *__restrict__ x, const uint32_t *__restrict__ y, int64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = x[i] >> 8;
+    if (val != y) val[i] = y[i];
+}
 __global__ void k_head_flags(const uint64_t *__restrict__ h, int64_t n, int32_t *__restrict__ flag)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -645,8 +653,24 @@ __device__ __forceinline__ bool d_ht_lookup(const IndexView &I, uint64_t h, uint
     }
 }
 
+// inclusive prefix sum over the 64 lanes of a wave with DPP moves only (gfx9 pattern: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast:15
+// into rows 1 and 3 and row_bcast:31 into rows 2 and 3)
+__device__ __forceinline__ uint32_t d_wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------
 // 3. seeding: one block per query.  MODE 0 counts anchors per minimizer, MODE 1 writes keys.
+// Round 6: MODE 0 also turns the counts into offsets RELATIVE TO THE QUERY'S FIRST ANCHOR (a block-level scan over the query's
+// minimizers, 256 at a time) and leaves the query's total in q_cnt: what follows is one small scan over the queries (k_qscan)
+// instead of the library's scan + 64-bit reduction over all ~24 M minimizers of a range (2.1 ms per range on the stage's critical path).
 struct SeedArgs {
     IndexView I;
     const uint64_t *mz_x; const uint32_t *mz_y;
@@ -658,21 +682,23 @@ struct SeedArgs {
     const int32_t *tmid;         // per-target occurrence cut-offs [n_targets] (nullable: the pooled cut-off mid_occ applies)
     int32_t per_target;          // qtarget < 0: filter and count a minimizer's occurrences separately inside every target
     int32_t n_targets;
-    int32_t *mz_cnt;             // MODE 0 out
+    int32_t *mz_cnt;             // MODE 0 out / MODE 1 in: anchors of the minimizer
     int32_t *mz_ent;             // MODE 0 out / MODE 1 in: first occurrence of the minimizer in `pos` (saves the second probe)
     int32_t *mz_n;               // MODE 0 out / MODE 1 in: its occurrence count (0 = absent)
-    const int32_t *mz_aoff;      // MODE 1 in
+    int32_t *mz_aoff;            // MODE 0 out / MODE 1 in: its first anchor, counted from the query's first anchor
+    int32_t *q_cnt;              // MODE 0 out: anchors of the query
+    const int32_t *q_aoff;       // MODE 1 in (keys in memory): first anchor of every query
     uint64_t *keys;              // MODE 1 out
     // staged input (tile_off non-null): mz_x / mz_y are the sketch kernel's per-tile staging arrays (tile t at t * SK_TILE,
     // tile_off[t+1] - tile_off[t] entries), read in place instead of being compacted first; q_tile0[q] = first tile of query q
     const int32_t *tile_off, *q_tile0;
-    // MODE 1 inside the LDS sort (segsort.hip.h: SeedProducer): the keys of the query go to lds_keys[w - lds_base] instead of keys[w]
-    uint64_t *lds_keys; int32_t lds_base;
+    // MODE 1 inside the LDS sort (segsort.hip.h: SeedProducer): anchor w of the query goes to lds_keys[w] instead of keys[q_aoff[q] + w]
+    uint64_t *lds_keys;
 };
 
 __device__ __forceinline__ void d_put_key(const SeedArgs &A, int64_t w, uint64_t key)
 {
-    if (A.lds_keys) A.lds_keys[w - A.lds_base] = key; else A.keys[w] = key;
+    if (A.lds_keys) A.lds_keys[w] = key; else A.keys[w] = key;
 }
 // target holding global position g (goff ascending, goff[n] = end)
 __device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n, uint32_t g)
@@ -700,7 +726,13 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
     // staged input: minimizer g of the query lives in tile t at slot g - tile_off[t]; g only grows, so t is advanced, not searched
     int t = A.tile_off ? A.q_tile0[q] : 0, t_lo = 0, t_hi = 0;
     if (A.tile_off) { t_lo = A.tile_off[t]; t_hi = A.tile_off[t + 1]; }
-    for (int g = m0 + tid; g < m1; g += nthr) {
+    const int64_t wbase = MODE == 1 && !A.lds_keys ? A.q_aoff[q] : 0;       // where the query's anchors start in the key array
+    __shared__ int32_t s_wtot[16];                                           // MODE 0 (one block of at most 1,024 threads per query): the waves' totals
+    int32_t carry = 0;                                                       // MODE 0: anchors of the minimizers before this round's
+    for (int gb = m0; gb < m1; gb += nthr) {
+      int32_t cnt_out = 0;
+      const int g = gb + tid;
+      if (g < m1) do {
         int64_t gi = g;
         if (A.tile_off) {
             while (g >= t_hi) { ++t; t_lo = t_hi; t_hi = A.tile_off[t + 1]; }
@@ -714,7 +746,7 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
             A.mz_ent[g] = (int32_t)off; A.mz_n[g] = (int32_t)n;
             o0 = off; o1 = off + n;
         } else {
-            if (A.mz_aoff[g + 1] == A.mz_aoff[g]) continue;
+            if (A.mz_cnt[g] == 0) break;
             o0 = (uint32_t)A.mz_ent[g]; o1 = o0 + (uint32_t)A.mz_n[g];
         }
         // one occurrence: o0 IS the occurrence (k_ht_build), not an index into `pos`
@@ -723,7 +755,7 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
 #define SEED_POS(i_) (single ? pos1 : A.I.pos[i_])
         if (pt) {
             // occurrences are sorted by global position, i.e. grouped by target: one run per target
-            int32_t total = 0, w = MODE == 1 ? A.mz_aoff[g] : 0;
+            int32_t total = 0; int64_t w = MODE == 1 ? wbase + A.mz_aoff[g] : 0;
             uint64_t kf = 0, kr = 0; int32_t qz = 0;
             if (MODE == 1) {
                 const uint32_t y = A.mz_y[gi];
@@ -743,8 +775,8 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
                 }
                 o = e;
             }
-            if (MODE == 0) A.mz_cnt[g] = total;
-            continue;
+            cnt_out = total;
+            break;
         }
         int32_t cnt = 0;
         if (o1 > o0) {
@@ -752,19 +784,41 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
             else cnt = (int32_t)(o1 - o0);
             if (cnt > occ) cnt = 0;
         }
-        if (MODE == 0) A.mz_cnt[g] = cnt;
-        else if (cnt > 0) {
+        cnt_out = cnt;
+        if (MODE == 1 && cnt > 0) {
             uint32_t y = A.mz_y[gi];
             int32_t span = (int32_t)(x & 0xff), qpos = (int32_t)(y >> 1), qz = (int32_t)(y & 1);
             uint64_t kf = (uint64_t)qpos << 8 | (uint64_t)span;
             uint64_t kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
-            int32_t w = A.mz_aoff[g];
+            int64_t w = wbase + A.mz_aoff[g];
             for (uint32_t o = o0; o < o1; ++o) {
                 uint32_t py = SEED_POS(o), gp = py >> 1;
                 if (tf >= 0 && (gp < g0 || gp >= g1)) continue;
                 d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)gp << 32);
             }
         }
+      } while (0);
+      if (MODE == 0 && g < m1) A.mz_cnt[g] = cnt_out;
+    }
+    if (MODE == 0) {
+        // the counts -> offsets from the query's first anchor, in a pass of its own behind the probes (with the scan inside the probing
+        // rounds every round ended in a barrier and the block's waves could no longer hide each other's table misses: 8.1 -> 9.9 ms
+        // per range): 256 counts a round, wave scan (DPP), the waves' totals through LDS
+        __syncthreads();
+        const int wv = tid >> 6, nwv = (nthr + 63) >> 6;
+        for (int gb = m0; gb < m1; gb += nthr) {
+            const int g = gb + tid;
+            const int32_t c = g < m1 ? A.mz_cnt[g] : 0;
+            const uint32_t inc = d_wave_scan_add((uint32_t)c);
+            if ((tid & 63) == 63) s_wtot[wv] = (int32_t)inc;
+            __syncthreads();
+            int32_t before = 0, all = 0;
+            for (int z = 0; z < nwv; ++z) { const int32_t v = s_wtot[z]; if (z < wv) before += v; all += v; }
+            if (g < m1) A.mz_aoff[g] = carry + before + (int32_t)inc - c;
+            carry += all;
+            __syncthreads();
+        }
+        if (tid == 0) A.q_cnt[q] = carry;
     }
 }
 #undef SEED_POS
@@ -834,18 +888,6 @@ __global__ void __launch_bounds__(64) k_vote_qhits(const int32_t *__restrict__ q
 #ifndef VOTE_WIN
 #define VOTE_WIN 8                 /* windows of 64 hits whose occurrence loads are in flight together */
 #endif
-// inclusive prefix sum over the 64 lanes of a wave with DPP moves only (gfx9 pattern: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast:15
-// into rows 1 and 3 and row_bcast:31 into rows 2 and 3)
-__device__ __forceinline__ uint32_t d_wave_scan_add(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
-    return v;
-}
 struct VoteChunk { uint32_t P[VOTE_MZ], off[VOTE_MZ], qpos[VOTE_MZ]; uint16_t zs[VOTE_MZ]; uint8_t rid[VOTE_MZ]; uint32_t wm[2 * VOTE_WIN]; };      // rid[r] = r-th minimizer WITH hits; wm: list-start bits of the two hit windows in flight
 struct VoteHit { uint32_t gp; uint32_t sm; };      // sm = slot | minimizer << 11
 // The vote table of a wave: 2,048 counters.  T16: two 16-bit counters per word -- half the LDS, 12 instead of 9 waves per CU -- for
@@ -1092,10 +1134,10 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
 #undef VOTE_PIN
 // staging -> dense keys (only ahead of the library sort: the LDS sort of segsort.hip.h reads the staging pieces in place)
 __global__ void __launch_bounds__(256) k_vote_compact(const uint64_t *__restrict__ stage, const int64_t *__restrict__ q_soff, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                                      uint64_t *__restrict__ keys)
+                                                      uint64_t *__restrict__ keys, const int32_t *__restrict__ list)
 {
-    const int q = blockIdx.x;
-    if (q >= nq) return;
+    if ((int)blockIdx.x >= nq) return;
+    const int q = list ? list[blockIdx.x] : (int)blockIdx.x;        // list: only these queries (the over-size ones ahead of the library sort)
     const int64_t s0 = q_soff[q]; const int a0 = q_aoff[q], n = q_aoff[q + 1] - a0;
     for (int i = threadIdx.x; i < n; i += 256) {
         const uint64_t k = stage[s0 + i];
@@ -1164,20 +1206,36 @@ __global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__r
     if (i == n) dst[n] = tail;
 }
 
-// per-query anchor offsets = the minimizer-level scan read at the query's first minimizer (idx[nq] = the minimizer total, so
-// dst[nq] = the anchor total), and the number of queries whose anchors exceed `cap` (they take the library sort)
-__global__ void k_qaoff_over(const int32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t nq, int32_t cap, int32_t *__restrict__ dst, int32_t *__restrict__ n_over)
+// ---- exclusive scan of per-query counts by ONE workgroup (round 6: the per-query offsets of a range -- 10^5 queries -- do not need the
+// library's device-wide scan, its state initialisation and a 64-bit reduction beside it): out[0 .. n] (out[n] = the total, as Tout),
+// tot64 = the total in 64 bits (an int32 scan wraps silently: the caller halves a batch of 2^31 anchors or more), n_over = counts
+// above `cap` (queries whose anchors one workgroup cannot sort in LDS).  Thread t owns the contiguous chunk t of the counts.
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(1024) k_qscan(const Tin *__restrict__ cnt, int32_t n, int64_t cap, Tout *__restrict__ out, int64_t *__restrict__ tot64, int32_t *__restrict__ n_over,
+                                                int32_t *__restrict__ over_list = nullptr)
 {
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > nq) return;
-    const int32_t a = src[idx[i]];
-    dst[i] = a;
-    if (i < nq && src[idx[i + 1]] - a > cap) atomicAdd(n_over, 1);
-}
-__global__ void k_count_over(const int32_t *__restrict__ cnt, int32_t nq, int32_t cap, int32_t *__restrict__ n_over)
-{
-    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq && cnt[i] > cap) atomicAdd(n_over, 1);
+    __shared__ int64_t s_sum[1024];
+    __shared__ int32_t s_nover;
+    const int tid = threadIdx.x, per = (n + 1023) / 1024;
+    const int lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+    if (tid == 0) s_nover = 0;
+    __syncthreads();
+    int64_t sum = 0;
+    // (over_list: the indices of the counts above `cap`, in no particular order; the caller provides n entries)
+    for (int i = lo; i < hi; ++i) { const int64_t v = (int64_t)cnt[i]; sum += v; if (n_over && v > cap) { const int z = atomicAdd(&s_nover, 1); if (over_list) over_list[z] = i; } }
+    s_sum[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele over the 1,024 chunk sums
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int64_t v = tid >= d ? s_sum[tid - d] : 0;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    int64_t run = s_sum[tid] - sum;
+    for (int i = lo; i < hi; ++i) { out[i] = (Tout)run; run += (int64_t)cnt[i]; }
+    if (tid == 1023) { out[n] = (Tout)s_sum[1023]; if (tot64) *tot64 = s_sum[1023]; }
+    if (tid == 0 && n_over) *n_over = s_nover;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2130,6 +2188,10 @@ __device__ __forceinline__ uint32_t d_cell(const DpOpt &o, int32_t hd, int32_t h
 // end on the reversed sequences; H of every band cell and its trace-back byte go to the problem's scratch; the junction is the
 // short-axis coordinate that maximises  max_k [HL + e2 k] + max_k [HR + e2 k]  (smallest coordinate, then smallest k on ties);
 // lane 0 walks both halves and writes the run-merged ops end -> start: RIGHT reversed, the gap, LEFT.
+// d_longgap is single-wave code: its steps are ordered by a WAVE-level barrier (LDS operations of one wave are executed in order; the
+// fence keeps the compiler from moving them across).  Until round 5 it called __syncthreads(), also from k_dp_w4, whose waves 1-3 had
+// returned by then -- a barrier that not every thread of the block reaches is undefined in the HIP model.
+__device__ __forceinline__ void d_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }      // (workgroup scope: the halves' H / trace-back bytes go through global memory)
 __device__ __forceinline__ void d_longgap_half(const DpArgs &A, const DpProb &P, int side, int lm, int ln, int m, int n, int lane, int32_t *lds,
                                                int32_t *Hg, uint8_t *tbg, int &ncell)
 {
@@ -2138,11 +2200,11 @@ __device__ __forceinline__ void d_longgap_half(const DpArgs &A, const DpProb &P,
     const int qstep = side ? -P.qstep : P.qstep, tstep = side ? -P.tstep : P.tstep;
     const int64_t qi0 = side ? P.qi0 + (int64_t)P.qstep * (m - 1) : P.qi0, ti0 = side ? P.ti0 + (int64_t)P.tstep * (n - 1) : P.ti0;
     int32_t *H = lds, *E1 = H + (A.dcap + 2), *F1 = E1 + (A.dcap + 2), *E2 = F1 + (A.dcap + 2), *F2 = E2 + (A.dcap + 2);
-    __syncthreads();
+    d_wave_sync();
     for (int x = lane; x < D + 2; x += 64) { H[x] = TELR_NEG; E1[x] = TELR_NEG; F1[x] = TELR_NEG; E2[x] = TELR_NEG; F2[x] = TELR_NEG; }
-    __syncthreads();
+    d_wave_sync();
     if (lane == 0) { H[0 - dlo + 1] = 0; Hg[0 - dlo] = 0; }
-    __syncthreads();
+    d_wave_sync();
     for (int a = 1; a <= lm + ln; ++a) {
         int d0 = -a > dlo ? -a : dlo; if (a - 2 * lm > d0) d0 = a - 2 * lm;
         int d1 = a < dhi ? a : dhi;   if (2 * ln - a < d1) d1 = 2 * ln - a;
@@ -2168,7 +2230,7 @@ __device__ __forceinline__ void d_longgap_half(const DpArgs &A, const DpProb &P,
             H[x] = h; E1[x] = ve1; F1[x] = vf1; E2[x] = ve2; F2[x] = vf2;
             Hg[(int64_t)a * D + (d - dlo)] = h;
         }
-        __syncthreads();
+        d_wave_sync();
     }
 }
 // walk from (i, j) to (0, 0) through a half's trace-back bytes: run-merged ops (end -> start) appended at out[no...]; counts M columns and equal bases
@@ -2201,7 +2263,7 @@ __device__ void d_longgap(const DpArgs &A, const DpProb &P, int prob, int lane, 
     d_longgap_half(A, P, 0, lm, ln, m, n, lane, lds, HL, tbL, ncell);
     d_longgap_half(A, P, 1, lm, ln, m, n, lane, lds, HR, tbR, ncell);
     __threadfence_block();
-    __syncthreads();
+    d_wave_sync();
     // ---- the junction
     const int lim = ins ? lm : ln;
     int64_t bestk = INT64_MIN; int b_al = 0, b_ar = 0;
@@ -2281,7 +2343,7 @@ template <int NT> __device__ __forceinline__ void d_dp_lds(const DpArgs &A)
     DpRes R; R.score = 0; R.bi = 0; R.bj = 0; R.nops = 0; R.mlen = 0; R.cells = 0; R.tbases = n; R.mcols = 0;
     int ncell = 0;
 
-    if (NT > 64 && (P.kind == 5 || P.kind == 3) && lane >= 64) return;      // (single-wave code below; a barrier counts the waves still running)
+    if (NT > 64 && (P.kind == 5 || P.kind == 3) && lane >= 64) return;      // (single-wave code below, without workgroup barriers: d_wave_sync)
     if (P.kind == 5) { d_longgap(A, P, prob, lane, lds); return; }
     if (P.kind == 3) {
         // band wider than the engine accepts: diagonal + one closing gap (oracle band_dp_fallback)

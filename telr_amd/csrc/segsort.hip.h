@@ -102,7 +102,7 @@ struct SeedProducer {
     SeedArgs S;
     __device__ __forceinline__ void fill(const SegSortArgs &A, int s, uint64_t *lds, int n, int npad, int tid, int nthr) const
     {
-        SeedArgs B = S; B.lds_keys = lds; B.lds_base = A.seg_beg[s];
+        SeedArgs B = S; B.lds_keys = lds;
         for (int i = n + tid; i < npad; i += nthr) lds[i] = SEGSORT_PAD;
         d_seed_query<1>(B, s, tid, nthr);
     }

@@ -29,6 +29,7 @@
 #include "kernels.hip.h"
 #define TELR_HAVE_SEED_ARGS 1
 #include "segsort.hip.h"
+#include "radix.hip.h"
 
 // ---------------------------------------------------------------------------------------
 static const char *STAGE_NAMES[TELR_N_STAGES] = {
@@ -167,10 +168,12 @@ template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size
 // Segmented sort of 64-bit keys (segsort.hip.h): every segment of at most SEGSORT_CAP keys is sorted by ONE workgroup in
 // LDS; `any_over` (known to the caller from the anchor counts) sends the larger ones through rocPRIM afterwards.
 // TELR_AB=sort64 keeps the library sort for every segment (A/B).  out[beg[s] .. end[s]) <- sorted in[...]; src_beg (nullable)
-// gives the segments' places in `in` when they differ from their places in `out`.
+// gives the segments' places in `in` when they differ from their places in `out`.  fb_in (round 6): where the OVER-SIZE segments' keys lie
+// (at their places in `out`) when the producer makes the others on the spot or reads them through src_beg -- only those queries take the
+// two-step form then, not the whole range.
 template <class P = LoadKeys>
 static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint64_t *out, const int32_t *beg, const int32_t *end, const int64_t *src_beg,
-                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st, P prod = P())
+                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st, P prod = P(), const uint64_t *fb_in = nullptr)
 {
     static const bool lib_sort = ab_on("sort64");
     if (nseg <= 0 || nkeys == 0) return TELR_OK;
@@ -183,7 +186,7 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
         HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, in, out, (unsigned)nkeys, (unsigned)nseg, beg, end, 0, 64, st));
         return TELR_OK;
     }
-    if (src_beg && any_over) return TELR_E_ARG;
+    if (src_beg && any_over && !fb_in) return TELR_E_ARG;
     // the opt-in to more than 64 KiB of dynamic LDS belongs to the DEVICE's function object: one bit per device (and per producer
     // type: a function-local static of the template instance); setting it twice from two host threads is harmless
     static std::atomic<uint64_t> attr_dev{0};
@@ -213,10 +216,11 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
     hipLaunchKernelGGL((k_segsort<64, 2, P>), grid(32), dim3(64), 64 * 2 * 8, st, A, 0, prod);
     HIPCHK(hipGetLastError());
     if (any_over) {
+        const uint64_t *fin = fb_in ? fb_in : in;
         size_t tb = 0;
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, in, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, fin, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, in, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, fin, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
     }
     return TELR_OK;
 }
@@ -252,6 +256,7 @@ extern "C" const char *telr_strerror(int code)
     case TELR_E_ARG: return "invalid argument";
     case TELR_E_RANGE: return "input exceeds the engine's coordinate range (targets < 2^31 bases, queries < 2^24 bases)";
     case TELR_E_NOMEM: return "out of device memory";
+    case TELR_E_IO: return "file could not be opened, mapped or written";
     default: return "unknown error";
     }
 }
@@ -337,7 +342,7 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
     mo->a = 2; mo->b = 4; mo->q = 4; mo->e = 2; mo->q2 = 24; mo->e2 = 1; mo->sc_ambi = 1; mo->zdrop = 400;
     mo->min_dp_max = 80; mo->min_ksw_len = 200; mo->ext_max = 2048; mo->ext_band = 31; mo->flags = TELR_MF_CIGAR; mo->fill_band_q4 = 6; mo->fill_margin = 1;
     if (s == "map-ont") { mo->fill_band_q4 = 4; mo->bw_long = 20000; }                 // -r500,20000: long join
-    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 12; mo->bw_long = 20000; }
+    else if (s == "map-pb") { io->k = 19; io->is_hpc = 1; mo->fill_band_q4 = 12; mo->bw_long = 20000; mo->ext_max = 3900; }      // (ext_max: round 6, the hard genome -- telr_amd/presets.py)
     else if (s == "ngmlr-ont" || s == "ngmlr-pacbio") {
         // `ngmlr -x ont|pacbio` (TELR_alignment.py:28-51, the reference's default aligner).  NGMLR 0.2.7 indexes 13-mers at
         // every third reference position: (w,k) = (5,13) minimizers have that density.  Its convex gap cost (open, then an
@@ -354,6 +359,7 @@ extern "C" int telr_preset(const char *name, telr_idx_opt *io, telr_map_opt *mo)
         mo->fill_band_q4 = 12; mo->fill_margin = 2;
         if (s == "ngmlr-ont") { mo->fill_band_q4 = 7; mo->fill_margin = 4; mo->ext_band = 63; mo->zdrop = 100; }      // round 5: see telr_amd/presets.py (fills: same results, 18 % fewer cells; extensions: the 0.5 % rule)
         mo->vote_len = 256; mo->vote_bin_shift = 5; mo->vote_min = 3; mo->vote_frac_q8 = 128;      // NGMLR's sub-read voting
+        mo->chain_lookback = 256;              // round 6: the 0.5 % rule on the hard genome (telr_amd/presets.py)
     }
     else if (s == "asm10") {
         io->k = 19; io->w = 19; mo->min_mid_occ = 50; mo->max_mid_occ = 500; mo->bw = 10000; mo->max_gap = 10000;
@@ -838,7 +844,21 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
     TRY(ctx_buf_t(ctx, "ix_h2", (size_t)nmz, &d_h2));
     HIPCHK(hipMalloc(&ix->d_pos, ((size_t)nmz + 1) * 4));
     d_y2 = ix->d_pos;
-    if (nmz > 0) {
+    // (the hand-written LSD radix sort of radix.hip.h; TELR_AB=index_sort_lib: rocPRIM's, the cross-check of tests/test_gpu_switches.py)
+    static const bool sort_lib = ab_on("index_sort_lib");
+    uint32_t *d_rshist = nullptr;
+    if (nmz > 0 && !sort_lib) {
+        const int passes = (2 * k + 7) / 8;
+        uint64_t *d_tk; TRY(ctx_buf_t(ctx, "ix_rs_keys", (size_t)nmz, &d_tk));
+        TRY(ctx_buf_t(ctx, "ix_rs_hist", (size_t)RS_BINS * ((nmz + RS_TILE - 1) / RS_TILE) + RS_BINS, &d_rshist));
+        // an even number of passes ends where it began: the hashes start in the final arrays (d_h2, pos) then, else in the temporaries (d_tk, d_y)
+        uint64_t *k0 = passes % 2 == 0 ? d_h2 : d_tk; uint32_t *v0 = passes % 2 == 0 ? d_y2 : d_y;
+        hipLaunchKernelGGL(k_ix_hash_keys, dim3((nmz + 255) / 256), dim3(256), 0, ctx->stream, d_x, d_y, (int64_t)nmz, k0, v0);
+        HIPCHK(hipGetLastError());
+        if (passes % 2 == 0) (void)radix_sort_passes<uint64_t, true>(d_h2, d_y2, d_tk, d_y, (int64_t)nmz, 2 * k, d_rshist, ctx->stream);
+        else (void)radix_sort_passes<uint64_t, true>(d_tk, d_y, d_h2, d_y2, (int64_t)nmz, 2 * k, d_rshist, ctx->stream);
+        HIPCHK(hipGetLastError());
+    } else if (nmz > 0) {
         auto hin = rocprim::make_transform_iterator(d_x, [] __device__(uint64_t v) { return v >> 8; });
         size_t tb = 0;
         HIPCHK(rocprim::radix_sort_pairs(nullptr, tb, hin, d_h2, d_y, d_y2, (size_t)nmz, 0, 2 * k, ctx->stream));
@@ -883,10 +903,19 @@ static int index_build_impl(telr_ctx *ctx, const telr_seqset *tg, const telr_idx
         TRY(ctx_buf_t(ctx, "ix_cnt", (size_t)n_ent, &d_c));
         TRY(ctx_buf_t(ctx, "ix_cnt2", (size_t)n_ent, &d_c2));
         hipLaunchKernelGGL(k_ent_counts, dim3((n_ent + 255) / 256), dim3(256), 0, ctx->stream, ix->d_ent_off, n_ent, d_c);
-        size_t tb = 0;
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tb, d_c, d_c2, (size_t)n_ent, 0, 32, ctx->stream));
-        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::radix_sort_keys(tmp, tb, d_c, d_c2, (size_t)n_ent, 0, 32, ctx->stream));
+        if (!sort_lib) {
+            // a count is at most nmz: as many 8-bit passes as its bits need, an even number of them (the result then lies in d_c again)
+            int nb = 8; while (nb < 32 && ((int64_t)1 << nb) <= (int64_t)nmz) nb += 8;
+            if ((nb / 8) % 2) nb += 8;
+            (void)radix_sort_passes<uint32_t, false>(d_c, nullptr, d_c2, nullptr, (int64_t)n_ent, nb, d_rshist, ctx->stream);
+            HIPCHK(hipGetLastError());
+            d_c2 = d_c;
+        } else {
+            size_t tb = 0;
+            HIPCHK(rocprim::radix_sort_keys(nullptr, tb, d_c, d_c2, (size_t)n_ent, 0, 32, ctx->stream));
+            void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
+            HIPCHK(rocprim::radix_sort_keys(tmp, tb, d_c, d_c2, (size_t)n_ent, 0, 32, ctx->stream));
+        }
         HIPCHK(hipMemcpyAsync(ix->sorted_counts.data(), d_c2, (size_t)n_ent * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1567,7 +1596,8 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             if (w1 <= w0) continue;
             hipLaunchKernelGGL(k_dp_pk, dim3(w1 - w0), dim3(64), 0, st, D, d_wv2 + w0, d_clslist, coff);
             HIPCHK(hipGetLastError());
-            if (tb_over) {
+            static const bool dbg_tb_skip = ab_on("dbg_tb_skip");        // EXPERIMENT ONLY (wrong records): what would the step be without the packed classes' trace-back?
+            if (tb_over && !dbg_tb_skip) {
                 HIPCHK(hipEventRecord(ctx->ev_chunk[g], st));
                 HIPCHK(hipStreamWaitEvent(ctx->tb_stream, ctx->ev_chunk[g], 0));
                 hipLaunchKernelGGL(k_traceback_pk, dim3(w1 - w0), dim3(64), 0, ctx->tb_stream, d_probs, d_res, d_tb, *d_rawcig_io, d_retry, d_wv2 + w0, d_clslist, coff, D.tb4, D.o, D.tag8_steps);
@@ -1690,25 +1720,30 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "mz_aoff", (size_t)nmz + 1, &d_maoff));
     TRY(ctx_buf_t(ctx, "q_aoff", (size_t)nq + 1, &d_qaoff));
     SeedArgs S; S.I = I; S.mz_x = d_mx; S.mz_y = d_my; S.q_mzoff = d_qmz; S.qlen = qs->d_len + q0; S.qtarget = d_qtarget ? d_qtarget + q0 : nullptr;
-    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.keys = nullptr; S.q_order = d_qorder;
+    S.mid_occ = mid_occ; S.tmid = occ.d_tmid; S.per_target = (mo->flags & TELR_MF_PER_TARGET) ? 1 : 0; S.n_targets = tg->n; S.mz_cnt = d_mcnt; S.mz_ent = d_ment; S.mz_n = d_mn; S.mz_aoff = nullptr; S.q_cnt = nullptr; S.q_aoff = nullptr; S.lds_keys = nullptr; S.keys = nullptr; S.q_order = d_qorder;
     S.tile_off = mz_staged ? d_toff : nullptr; S.q_tile0 = mz_staged ? d_first : nullptr;
     VoteOpt VO; VO.len = mo->vote_len; VO.shift = mo->vote_bin_shift; VO.vmin = mo->vote_min; VO.frac_q8 = mo->vote_frac_q8;
     VoteArgs VA; memset(&VA, 0, sizeof(VA));
-    // the counts that become anchor offsets: per minimizer, or per query when the sub-reads vote (the vote kernel appends a
-    // query's survivors to its piece of a staging array; k_vote_compact moves them to the scanned offsets)
-    int32_t *d_cnt = d_mcnt, *d_aoff = d_maoff; size_t ncnt = (size_t)nmz;
-    int64_t *d_qsoff = nullptr; uint64_t *d_stage = nullptr; int32_t *d_qcnt_v = nullptr;
+    // the per-query anchor counts: from the seeding kernel (which also leaves every minimizer's offset inside its query), or from the
+    // vote kernel when the sub-reads vote (it appends a query's survivors to its piece of a staging array; k_vote_compact moves them to
+    // the scanned offsets)
+    int32_t *d_qcnt;
+    TRY(ctx_buf_t(ctx, "q_cnt", (size_t)nq + 2, &d_qcnt));
+    S.q_cnt = d_qcnt; S.mz_aoff = d_maoff; S.q_aoff = d_qaoff;
+    int64_t *d_qsoff = nullptr; uint64_t *d_stage = nullptr;
+    int64_t *d_na64; TRY(ctx_buf_t(ctx, "seed_na64", 2, &d_na64));
+    int32_t *d_nover = (int32_t*)(d_na64 + 1);
     if (vote) {
-        int64_t *d_qhits; int32_t *d_qcnt;
-        TRY(ctx_buf_t(ctx, "vote_qhits", (size_t)nq + 2, &d_qhits)); TRY(ctx_buf_t(ctx, "vote_qsoff", (size_t)nq + 2, &d_qsoff)); TRY(ctx_buf_t(ctx, "vote_qcnt", (size_t)nq + 2, &d_qcnt));
+        int64_t *d_qhits;
+        TRY(ctx_buf_t(ctx, "vote_qhits", (size_t)nq + 2, &d_qhits)); TRY(ctx_buf_t(ctx, "vote_qsoff", (size_t)nq + 2, &d_qsoff));
         if (nmz) {
             static const bool always_filter = ab_on("vote_filter");
             if (k <= 13 && !always_filter) hipLaunchKernelGGL(k_vote_lookup<false>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
             else hipLaunchKernelGGL(k_vote_lookup<true>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
         }
         hipLaunchKernelGGL(k_vote_qhits, dim3(nq + 1), dim3(64), 0, st, d_qmz, d_mn, nq, d_qhits);
+        hipLaunchKernelGGL((k_qscan<int64_t, int64_t>), dim3(1), dim3(1024), 0, st, d_qhits, nq, (int64_t)0, d_qsoff, (int64_t*)nullptr, (int32_t*)nullptr);
         HIPCHK(hipGetLastError());
-        TRY((dev_exclusive_scan<int64_t, int64_t>(ctx, d_qhits, d_qsoff, (size_t)nq + 1)));
         int64_t nhits = 0;
         HIPCHK(hipMemcpyAsync(&nhits, d_qsoff + nq, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1718,28 +1753,16 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         const int64_t lim16 = 65535;
         hipLaunchKernelGGL(k_seed_vote<true>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
         hipLaunchKernelGGL(k_seed_vote<false>, dim3(nq), dim3(64 * VOTE_WAVES), 0, st, S, VO, VA, std::min<int64_t>(lim16, 65535));
-        d_cnt = d_qcnt; d_aoff = d_qaoff; ncnt = (size_t)nq; d_qcnt_v = d_qcnt;
     } else hipLaunchKernelGGL(k_seed<0>, dim3(nq), dim3(256), 0, st, S);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(d_cnt + ncnt, 0, 4, st));
-    // the anchors of a batch are addressed with int32 offsets: their number is first summed in 64 bits (the int32 scan
-    // below would wrap silently); a batch with 2^31 anchors or more is handed back to the caller, which halves it
-    int64_t *d_na64; TRY(ctx_buf_t(ctx, "seed_na64", 2, &d_na64));
-    {
-        auto it64 = rocprim::make_transform_iterator(d_cnt, [] __device__(int32_t v) { return (int64_t)v; });
-        size_t tb = 0;
-        HIPCHK(rocprim::reduce(nullptr, tb, it64, d_na64, (int64_t)0, ncnt + 1, rocprim::plus<int64_t>(), st));
-        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::reduce(tmp, tb, it64, d_na64, (int64_t)0, ncnt + 1, rocprim::plus<int64_t>(), st));
-    }
-    TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_cnt, d_aoff, ncnt + 1)));
-    // per-query anchor offsets, and how many queries hold more anchors than one workgroup sorts in LDS (segsort.hip.h)
-    int32_t *d_nover = (int32_t*)(d_na64 + 1);
-    HIPCHK(hipMemsetAsync(d_nover, 0, 8, st));
-    if (vote) hipLaunchKernelGGL(k_count_over, dim3((nq + 255) / 256), dim3(256), 0, st, d_qcnt_v, nq, SEGSORT_CAP, d_nover);
-    else hipLaunchKernelGGL(k_qaoff_over, dim3((nq + 256) / 256), dim3(256), 0, st, d_maoff, d_qmz, nq, SEGSORT_CAP, d_qaoff, d_nover);
+    // per-query anchor offsets (ONE workgroup: k_qscan), the anchor total in 64 bits -- the anchors of a batch are addressed with int32
+    // offsets, a batch with 2^31 anchors or more is handed back to the caller, which halves it -- and how many queries hold more anchors
+    // than one workgroup sorts in LDS (segsort.hip.h)
+    int32_t *d_overlist; TRY(ctx_buf_t(ctx, "q_overlist", (size_t)nq + 1, &d_overlist));
+    hipLaunchKernelGGL((k_qscan<int32_t, int32_t>), dim3(1), dim3(1024), 0, st, d_qcnt, nq, (int64_t)SEGSORT_CAP, d_qaoff, d_na64, d_nover, d_overlist);
+    HIPCHK(hipGetLastError());
     int32_t na = 0; int64_t na64 = 0; int32_t n_over = 0;
-    HIPCHK(hipMemcpyAsync(&na, d_aoff + ncnt, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&na, d_qaoff + nq, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&na64, d_na64, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&n_over, d_nover, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1752,25 +1775,31 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     static const bool seed_unfused_env = ab_on("seed_unfused");
     TRY(ctx_buf_t(ctx, "keys", (!lib_sort && !any_over && (vote || !seed_unfused_env)) ? (size_t)1 : (size_t)na, &d_keys));       // only the two-step forms need the unsorted keys in memory
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
-    S.mz_aoff = d_maoff; S.keys = d_keys;
+    S.keys = d_keys;
     // sub-read voting: the LDS sort reads the survivors from the staging pieces in place; only the library sort needs them dense
-    const bool vote_in_place = vote && !lib_sort && !any_over;
+    // (round 6: a query above the LDS limit -- a read inside a tandem array or a satellite -- no longer takes its whole range out of the
+    // fused / in-place form: only the over-size queries get their keys written to memory for the library's segmented sort)
+    const bool vote_in_place = vote && !lib_sort;
     // The anchor keys are MADE inside the sort (SeedProducer: the seeding routine writes a query's keys straight into the sorting
     // workgroup's LDS), so unsorted keys never exist in HBM; TELR_AB=seed_unfused keeps the two-step form for A/B, and a range with a
     // query above the LDS limit takes it too (its library sort reads the keys from memory)
     static const bool seed_unfused = ab_on("seed_unfused");
-    const bool seed_fused = !vote && !lib_sort && !any_over && !seed_unfused;
-    S.lds_keys = nullptr; S.lds_base = 0;
-    if (vote) { if (!vote_in_place) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, d_keys); }
+    const bool seed_fused = !vote && !lib_sort && !seed_unfused;
+    S.lds_keys = nullptr;
+    if (vote) {
+        if (!vote_in_place) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, d_keys, (const int32_t*)nullptr);
+        else if (any_over) hipLaunchKernelGGL(k_vote_compact, dim3(n_over), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, n_over, d_keys, (const int32_t*)d_overlist);
+    }
     else if (!seed_fused) hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
+    else if (any_over) { SeedArgs So = S; So.q_order = d_overlist; hipLaunchKernelGGL(k_seed<1>, dim3(n_over), dim3(256), 0, st, So); }
     HIPCHK(hipGetLastError());
     t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
 
     // ---- per-query sort of the anchor keys --------------------------------------------------
     StageTimer t_so(ctx, ST_SORT, true);
-    if (na > 0 && seed_fused) { SeedProducer sp; sp.S = S; TRY((seg_sort_u64<SeedProducer>(ctx, "so_a", nullptr, d_skeys, d_qaoff, d_qaoff + 1, nullptr, d_qorder, nq, (size_t)na, false, st, sp))); }
-    else if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st));
+    if (na > 0 && seed_fused) { SeedProducer sp; sp.S = S; TRY((seg_sort_u64<SeedProducer>(ctx, "so_a", nullptr, d_skeys, d_qaoff, d_qaoff + 1, nullptr, d_qorder, nq, (size_t)na, any_over, st, sp, d_keys))); }
+    else if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st, LoadKeys(), d_keys));
     t_so.stop();
 
     // ---- chaining ---------------------------------------------------------------------------

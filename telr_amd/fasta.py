@@ -116,9 +116,10 @@ def load(path):
     try:
         return FastaFile(path)
     except _lib.TelrError as e:
-        # a layout the C parser refuses (multi-line FASTQ, a record that does not start with '>' / '@': TELR_E_ARG = -3): the Python
-        # reader decides.  Anything else -- a record too long for the engine (TELR_E_RANGE), an I/O failure, no memory -- is the caller's
-        # to see: the slow path would only fail later with an unrelated message.
-        if getattr(e, "code", None) != -3:
+        # a layout the C parser refuses (multi-line FASTQ, a record that does not start with '>' / '@': TELR_E_ARG): the Python
+        # reader decides.  Anything else -- a record too long for the engine (TELR_E_RANGE), an I/O failure (TELR_E_IO: open / stat /
+        # mmap), no memory -- is the caller's to see: the slow path would only fail later with an unrelated message.
+        from ._abi import TELR_E_ARG
+        if getattr(e, "code", None) != TELR_E_ARG:
             raise
         return None

@@ -58,6 +58,10 @@ def preset(name):
     elif name == "map-pb":
         io.k, io.is_hpc = 19, 1
         mo.fill_band_q4 = 12        # real CLR reads (the bundled fixture) have bursty indels: 8 still loses two of its 25 records to the full band
+        # round 6, the HARD genome (profiles/r06_faithful_table_hard.md): the 2,048-base cap of the end extensions moved 0.70 % of 4,701 records'
+        # coordinates (a read whose last kilobases lie in a tandem array has no anchors there: the extension has to cross them); 3,900 bases
+        # -- still inside the packed int16 extension class, m + n <= 7,854 -- leaves what the +-31 band moves
+        mo.ext_max = 3900
     elif name in ("ngmlr-ont", "ngmlr-pacbio"):
         # `ngmlr -x ont|pacbio`, the reference's default stage-1 aligner (TELR_alignment.py:28-51, TELR_input.py:176-177):
         # 13-mers at every third reference position = (w,k) = (5,13) minimizers; NGMLR's convex gap cost as the lower
@@ -75,6 +79,12 @@ def preset(name):
         # NGMLR's candidate search: 256-base sub-reads vote for reference regions (diagonal bins of 32 bases, a window of three
         # bins = its corridor), regions with at least half the votes of the sub-read's best one stay
         mo.vote_len, mo.vote_bin_shift, mo.vote_min, mo.vote_frac_q8 = 256, 5, 3, 128
+        # round 6, the HARD genome (tandem arrays, satellites, segmental duplications, reads with error bursts; profiles/r06_faithful_table_hard.md):
+        # with 13-mers a sub-read brings hundreds of repeat hits, they sort between the true anchors, and a look-back of 128 anchors no longer
+        # reaches across them: against look-back 5,000 it moved 1.1 % of ~4,900 records (1.0-1.4 % of the coordinates) on both presets -- over
+        # the 0.5 % rule -- and broke chains whose pieces then ran into the extension cap (0.9 % of the coordinates).  256: 0.29 % / 0.37 % (ont),
+        # 0.26 % / 0.11 % (pacbio), and the extension rows fall to 0.22 % / 0.37 % and 0.00 % / 0.15 % with it.
+        mo.chain_lookback = 256
         mo.fill_band_q4, mo.fill_margin = 12, 2         # cheap gaps let paths wander: the band the faithful-mode gate needs on the fixture
         if name == "ngmlr-ont":
             # round 5, both measured on the oracle (tests/test_faithful_gate.py, profiles/r05_faithful_table.md):

@@ -259,12 +259,30 @@ def exchange_stage1(alns, cig_t, lengths, names, gid, gather_packed, rec_dest, w
     dist.all_to_all_single(rs, st)
     rsec = rs.cpu().numpy().reshape(world, 8)
     out_split = [int(sum(_pad8(v) for v in rsec[p_])) for p_ in range(world)]
-    recv = torch.empty(sum(out_split), dtype=torch.uint8, device=wire)
-    dist.all_to_all_single(recv, send.to(wire), output_split_sizes=out_split, input_split_sizes=in_split)
-    recv = recv.to(dev)
+    # the largest allocation of the exchange (the receive buffer) and the host / device staging of the payload: a rank that runs out of
+    # memory HERE must take every rank out before the payload all-to-all, not leave its peers waiting in it
+    err = None; recv = send_w = None
+    try:
+        recv = torch.empty(sum(out_split), dtype=torch.uint8, device=wire)
+        send_w = send.to(wire)
+    except Exception as e:
+        err = e
+    _agree(dist, wire, err, "allocating the receive buffer of the record exchange")
+    dist.all_to_all_single(recv, send_w, output_split_sizes=out_split, input_split_sizes=in_split)
+    del send_w
+    err = None
+    try:
+        recv = recv.to(dev)
+    except Exception as e:
+        err = e
+    _agree(dist, wire, err, "moving the received records to the device")
     if timings is not None:
         timings["collective_s"] = timings.get("collective_s", 0.0) + time.time() - t0
         timings["bytes_sent"] = int(sum(in_split)) - in_split[rank]
+        # what the payload travelled on (round 6): under RCCL the wire is the device the words already lie on -- no host
+        # staging on either side -- and at world size 1 the rank's whole payload goes through the all-to-all to itself
+        timings["wire"] = str(wire); timings["payload_sent_from"] = str(send.device); timings["payload_received_on"] = str(recv.device)
+        timings["bytes_to_self"] = int(in_split[rank])
     t0 = time.time()
     err = None
     try:
@@ -372,7 +390,7 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
     _sub(tm, "partition_splitters_s", t1, dev); t1 = time.time()
     held = []
     seg = jr = jq = None
-    ok = False
+    ok = False; created = False
     try:
         err = None; cig_t = None
         try:
@@ -420,6 +438,7 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
             except Exception as e:
                 err = e
         _agree(dist, wire, err, "creating the job's file")          # (also the barrier: nobody writes before the file exists)
+        created = True                                              # from here on a failed call removes the file; before, `path` may hold an earlier run's BAM
         tm["scan_sizes_s"] = time.time() - t0
         t0 = time.time()
         err = None
@@ -430,13 +449,24 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
         _agree(dist, wire, err, "writing a slice into the job's file")
         tm["write_slice_s"] = time.time() - t0
         t0 = time.time()
-        tid, ts, te, vb, v_end = ix.segment_entries(seg, base)
-        ent = np.concatenate([tid.astype(np.int64), ts.astype(np.int64), te.astype(np.int64), vb.view(np.int64), np.array([v_end, info["unmapped_reads"]], np.uint64).view(np.int64)])
+        err = None; ent = np.zeros(0, np.int64)
+        try:
+            tid, ts, te, vb, v_end = ix.segment_entries(seg, base)
+            ent = np.concatenate([tid.astype(np.int64), ts.astype(np.int64), te.astype(np.int64), vb.view(np.int64), np.array([v_end, info["unmapped_reads"]], np.uint64).view(np.int64)])
+        except Exception as e:
+            err = e
+        _agree(dist, wire, err, "collecting a slice's index entries")
         n_ent = torch.zeros(world, dtype=torch.int64, device=wire)
         dist.all_gather_into_tensor(n_ent, torch.tensor([len(ent)], dtype=torch.int64, device=wire))
         n_ent = [int(x) for x in n_ent.cpu().numpy()]
-        recv = torch.empty(sum(n_ent) if rank == 0 else 0, dtype=torch.int64, device=wire)
-        dist.all_to_all_single(recv, torch.from_numpy(ent).to(wire), output_split_sizes=n_ent if rank == 0 else [0] * world, input_split_sizes=[len(ent)] + [0] * (world - 1))
+        err = None; recv = ent_w = None
+        try:
+            recv = torch.empty(sum(n_ent) if rank == 0 else 0, dtype=torch.int64, device=wire)
+            ent_w = torch.from_numpy(ent).to(wire)
+        except Exception as e:
+            err = e
+        _agree(dist, wire, err, "allocating the index entries' exchange")
+        dist.all_to_all_single(recv, ent_w, output_split_sizes=n_ent if rank == 0 else [0] * world, input_split_sizes=[len(ent)] + [0] * (world - 1))
         out = dict(tm, slice_bytes=info["bytes"], slice_records=info["mapped_records"], slice_unmapped_reads=info["unmapped_reads"], reads_held=int(len(got["lengths"])),
                    records_held=int(len(got["alns"])))
         err = None
@@ -472,7 +502,7 @@ def write_job_bam(path, ix, eng, alns, cigars, read_set, lengths, names, gid, tn
             ix.free_raw(jr)
         if jq is not None:
             jq.free()
-        if not ok and rank == 0:
+        if not ok and created and rank == 0:
             import os
             for f in (path, path + ".bai"):
                 try:

@@ -96,10 +96,17 @@ def test_errors(tmp_path):
     from telr_amd._lib import TelrError
     p = tmp_path / "x.txt"
     p.write_text("hello\n")
-    with pytest.raises(TelrError):
+    from telr_amd._abi import TELR_E_ARG, TELR_E_IO
+    from telr_amd.fasta import load
+    with pytest.raises(TelrError) as ei:
         FastaFile(str(p))
-    with pytest.raises(TelrError):
+    assert ei.value.code == TELR_E_ARG                  # a layout the parser refuses: fasta.load() hands the file to the Python reader
+    assert load(str(p)) is None
+    with pytest.raises(TelrError) as ei:
         FastaFile(str(tmp_path / "missing.fa"))
+    assert ei.value.code == TELR_E_IO                   # an I/O failure has its own code (round 6) ...
+    with pytest.raises(TelrError):
+        load(str(tmp_path / "missing.fa"))              # ... and is NOT retried on the slow path
     e = tmp_path / "e.fa"
     e.write_text("")
     f = FastaFile(str(e))

@@ -122,3 +122,8 @@ def test_collectives_of_the_n_rank_path_run_through_rccl_on_device_tensors():
     jb = forced["stage1_to_sorted_bam"]["job_bam"]
     assert "error" not in jb and "nccl" in jb["what"], jb
     assert jb["inflated_sha256"] == plain["stage1_to_sorted_bam"]["inflated_sha256"] == forced["stage1_to_sorted_bam"]["inflated_sha256"] is not None
+    # round 6: the record exchange's payload never leaves the device under RCCL -- packed on it, sent from it, received on it --
+    # and the all-to-all really carried bytes (at world size 1: all of them, to the rank itself)
+    ph = jb["phase_s_per_rank"][0]
+    assert ph["wire"].startswith("cuda") and ph["payload_sent_from"].startswith("cuda") and ph["payload_received_on"].startswith("cuda"), ph
+    assert ph["bytes_to_self"] > 1000000 and ph["bytes_sent"] == 0, ph

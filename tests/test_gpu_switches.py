@@ -18,6 +18,7 @@ SWITCHES = [
     {"TELR_AB": "no_tag8"}, {"TELR_AB": "sketch64"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "no_pk"}, {"TELR_SERIAL": "1"},
     {"TELR_AB": "tb_one_launch"}, {"TELR_AB": "no_avx2"}, {"TELR_PACK_THREADS": "1"},
     {"TELR_TRACE": "host"}, {"TELR_AB": "seed_unfused"}, {"TELR_AB": "no_islands"}, {"TELR_AB": "vote_filter"}, {"TELR_AB": "tb8,no_tag8,sort64"}, {"TELR_AB": "chain_push"}, {"TELR_AB": "dp_one_wave"},
+    {"TELR_AB": "index_sort_lib"},          # round 6: rocPRIM's sorts in the index build instead of radix.hip.h (the cross-check SURVEY 7 step 5 asks for)
 ]
 
 
@@ -31,7 +32,7 @@ def test_switch_keeps_parity(env):
 
 def test_switch_keeps_parity_big_inputs():
     """the same on Mb-size genomes and 8-40-kb reads (wide classes, long fills) for the switches that touch the DP classes"""
-    for env in ({"TELR_AB": "tb8"}, {"TELR_AB": "no_tag8"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "dp_one_wave"}):
+    for env in ({"TELR_AB": "tb8"}, {"TELR_AB": "no_tag8"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "dp_one_wave"}, {"TELR_AB": "index_sort_lib"}):
         e = dict(os.environ); e.update(env); e["FUZZ_BIG"] = "1"
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "3", "5"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
         assert p.returncode == 0 and "fuzz ok: 3 iterations" in p.stdout.decode(), (env, p.stdout.decode()[-3000:])

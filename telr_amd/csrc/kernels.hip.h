@@ -1206,36 +1206,67 @@ __global__ void k_gather_i32(const int32_t *__restrict__ src, const int32_t *__r
     if (i == n) dst[n] = tail;
 }
 
-// ---- exclusive scan of per-query counts by ONE workgroup (round 6: the per-query offsets of a range -- 10^5 queries -- do not need the
-// library's device-wide scan, its state initialisation and a 64-bit reduction beside it): out[0 .. n] (out[n] = the total, as Tout),
-// tot64 = the total in 64 bits (an int32 scan wraps silently: the caller halves a batch of 2^31 anchors or more), n_over = counts
-// above `cap` (queries whose anchors one workgroup cannot sort in LDS).  Thread t owns the contiguous chunk t of the counts.
-template <typename Tin, typename Tout>
-__global__ void __launch_bounds__(1024) k_qscan(const Tin *__restrict__ cnt, int32_t n, int64_t cap, Tout *__restrict__ out, int64_t *__restrict__ tot64, int32_t *__restrict__ n_over,
-                                                int32_t *__restrict__ over_list = nullptr)
+// ---- exclusive scan of per-query counts (round 6: the per-query offsets of a range -- 10^5 queries -- do not need the library's
+// device-wide scan, its state initialisation and a 64-bit reduction beside it).  Two launches of 256-thread workgroups over tiles of
+// 4,096 counts: k_qscan_sums (every tile's total, 64-bit; counts above `cap` appended to over_list), k_qscan_write (a tile's base =
+// the totals of the tiles before it, then its counts in place).  out[0 .. n] (out[n] = the total, as Tout), tot64 = the total in 64
+// bits (an int32 scan wraps silently: the caller halves a batch of 2^31 anchors or more), n_over = counts above `cap` (queries whose
+// anchors one workgroup cannot sort in LDS; the tiles add to it: the caller clears it), over_list = their indices in no particular order.
+// (A first form, ONE workgroup of 1,024 threads, cost the configs[2] step 11 ms: while the other range's k_dp_pk holds 452 of a SIMD's
+// 512 registers no CU has room for sixteen more waves at once, and the little kernel waited milliseconds for a CU to drain.)
+#define QSCAN_TILE 4096
+template <typename Tin>
+__global__ void __launch_bounds__(256) k_qscan_sums(const Tin *__restrict__ cnt, int32_t n, int64_t cap, int64_t *__restrict__ tile_sum, int32_t *__restrict__ n_over, int32_t *__restrict__ over_list)
 {
-    __shared__ int64_t s_sum[1024];
-    __shared__ int32_t s_nover;
-    const int tid = threadIdx.x, per = (n + 1023) / 1024;
-    const int lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
-    if (tid == 0) s_nover = 0;
-    __syncthreads();
+    __shared__ int64_t s[4];
+    const int tid = threadIdx.x, base = blockIdx.x * QSCAN_TILE;
     int64_t sum = 0;
-    // (over_list: the indices of the counts above `cap`, in no particular order; the caller provides n entries)
-    for (int i = lo; i < hi; ++i) { const int64_t v = (int64_t)cnt[i]; sum += v; if (n_over && v > cap) { const int z = atomicAdd(&s_nover, 1); if (over_list) over_list[z] = i; } }
-    s_sum[tid] = sum;
+#pragma unroll 4
+    for (int j = 0; j < QSCAN_TILE / 256; ++j) {
+        const int i = base + j * 256 + tid;
+        if (i < n) { const int64_t v = (int64_t)cnt[i]; sum += v; if (n_over && v > cap) { const int z = atomicAdd(n_over, 1); if (over_list) over_list[z] = i; } }
+    }
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((tid & 63) == 0) s[tid >> 6] = sum;
     __syncthreads();
-    // Hillis-Steele over the 1,024 chunk sums
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int64_t v = tid >= d ? s_sum[tid - d] : 0;
+    if (tid == 0) tile_sum[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(256) k_qscan_write(const Tin *__restrict__ cnt, int32_t n, const int64_t *__restrict__ tile_sum, Tout *__restrict__ out, int64_t *__restrict__ tot64)
+{
+    __shared__ int64_t s[256];
+    const int tid = threadIdx.x, base = blockIdx.x * QSCAN_TILE, ntile = gridDim.x;
+    // the tiles before this one (and, for the last tile, all of them: the total)
+    int64_t bsum = 0, all = 0;
+    for (int t = tid; t < ntile; t += 256) { const int64_t v = tile_sum[t]; all += v; if (t < (int)blockIdx.x) bsum += v; }
+    s[tid] = bsum;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) s[tid] += s[tid + o]; __syncthreads(); }
+    const int64_t tile_base = s[0];
+    __syncthreads();
+    if ((int)blockIdx.x == ntile - 1) {
+        s[tid] = all;
         __syncthreads();
-        s_sum[tid] += v;
+        for (int o = 128; o >= 1; o >>= 1) { if (tid < o) s[tid] += s[tid + o]; __syncthreads(); }
+        if (tid == 0) { out[n] = (Tout)s[0]; if (tot64) *tot64 = s[0]; }
         __syncthreads();
     }
-    int64_t run = s_sum[tid] - sum;
-    for (int i = lo; i < hi; ++i) { out[i] = (Tout)run; run += (int64_t)cnt[i]; }
-    if (tid == 1023) { out[n] = (Tout)s_sum[1023]; if (tot64) *tot64 = s_sum[1023]; }
-    if (tid == 0 && n_over) *n_over = s_nover;
+    // thread t owns 16 consecutive counts of the tile
+    const int lo = base + tid * (QSCAN_TILE / 256);
+    int64_t v[QSCAN_TILE / 256], sum = 0;
+#pragma unroll
+    for (int j = 0; j < QSCAN_TILE / 256; ++j) { v[j] = lo + j < n ? (int64_t)cnt[lo + j] : 0; sum += v[j]; }
+    s[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int64_t x = tid >= d ? s[tid - d] : 0;
+        __syncthreads();
+        s[tid] += x;
+        __syncthreads();
+    }
+    int64_t run = tile_base + s[tid] - sum;
+#pragma unroll
+    for (int j = 0; j < QSCAN_TILE / 256; ++j) { if (lo + j < n) out[lo + j] = (Tout)run; run += v[j]; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2703,6 +2734,16 @@ __device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ uint32_t pk_dup(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 #define PK_NEG 0xC000C000u
+// The trace-back spill is written once and read once, milliseconds later, by another kernel: with -DTB_NT the stores and the walk's loads
+// are NON-TEMPORAL (streaming through the caches instead of displacing the other range's table lines and filter bitmap from L2 / MALL)
+#ifdef TB_NT
+typedef uint32_t tb_u2 __attribute__((ext_vector_type(2)));
+#define TB_ST2(p, a, b) __builtin_nontemporal_store(tb_u2{(a), (b)}, (tb_u2*)(p))
+#define TB_LD2(p) ({ const tb_u2 v_ = __builtin_nontemporal_load((const tb_u2*)(p)); make_uint2(v_.x, v_.y); })
+#else
+#define TB_ST2(p, a, b) (*(uint2*)(p) = make_uint2((a), (b)))
+#define TB_LD2(p) (*(const uint2*)(p))
+#endif
 
 struct PkConst { uint32_t qe, e, q2e2, e2, ab, b, a, nab, qeF, q2e2F;      // nab = -(a + b); the nibble cell (TB4) holds them times four, with tags
                  uint32_t cx_oe0, cx_e1, cx_emin, cx_dec; };        // convex cost (d_cell_pk_cx): open + ext(0), ext(1), the extension's floor, its decay
@@ -3084,10 +3125,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                     uint32_t *dst = tb32 + (int64_t)((k - 1) / 2 * RW4) * 128;
                     if (k <= last_row) {
 #pragma unroll
-                        for (int u = 0; u < RW4; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                        for (int u = 0; u < RW4; ++u) TB_ST2(dst + u * 128, sq[2 * u], sq[2 * u + 1]);
                     } else if (k - 1 <= last_row) {
 #pragma unroll
-                        for (int u = 0; u < (RW4 + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                        for (int u = 0; u < (RW4 + 1) / 2; ++u) TB_ST2(dst + u * 128, sq[2 * u], sq[2 * u + 1]);
                     }
                 } else {
 #pragma unroll
@@ -3098,7 +3139,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                         sq[RW4] = 0;
                         uint32_t *dst = tb32 + (int64_t)(k / 2 * RW4) * 128;
 #pragma unroll
-                        for (int u = 0; u < (RW4 + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                        for (int u = 0; u < (RW4 + 1) / 2; ++u) TB_ST2(dst + u * 128, sq[2 * u], sq[2 * u + 1]);
                     }
                 }
             } else if constexpr (LPP == 1 && !EXT) {
@@ -3113,10 +3154,10 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                     uint32_t *dst = tb32 + (int64_t)((k - 1) / 2 * R) * 128;
                     if (k <= last_row) {
 #pragma unroll
-                        for (int u = 0; u < R; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                        for (int u = 0; u < R; ++u) TB_ST2(dst + u * 128, sq[2 * u], sq[2 * u + 1]);
                     } else if (k - 1 <= last_row) {
 #pragma unroll
-                        for (int u = 0; u < (R + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                        for (int u = 0; u < (R + 1) / 2; ++u) TB_ST2(dst + u * 128, sq[2 * u], sq[2 * u + 1]);
                     }
                 } else {
 #pragma unroll
@@ -3127,7 +3168,7 @@ __device__ __forceinline__ void d_dp_pkr(const DpArgs &A, const int32_t *__restr
                         sq[R] = 0;
                         uint32_t *dst = tb32 + (int64_t)(k / 2 * R) * 128;
 #pragma unroll
-                        for (int u = 0; u < (R + 1) / 2; ++u) *(uint2*)(dst + u * 128) = make_uint2(sq[2 * u], sq[2 * u + 1]);
+                        for (int u = 0; u < (R + 1) / 2; ++u) TB_ST2(dst + u * 128, sq[2 * u], sq[2 * u + 1]);
                     }
                 }
             } else if constexpr (EXT) {
@@ -3467,7 +3508,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
         // 512 bytes apart, and each of the eight load instructions reads 512 contiguous bytes for the wave
 #define TBR_FETCH(L_, x0, x1, x2, x3) do { const int L__ = (L_); if (L__ >= 0 && L__ <= mytopline) { \
             if (il) { const uint2 *src = (const uint2*)tb + (int64_t)L__ * 512; \
-                const uint2 u0 = src[0], u1 = src[64], u2 = src[128], u3 = src[192], u4 = src[256], u5 = src[320], u6 = src[384], u7 = src[448]; \
+                const uint2 u0 = TB_LD2(src), u1 = TB_LD2(src + 64), u2 = TB_LD2(src + 128), u3 = TB_LD2(src + 192), u4 = TB_LD2(src + 256), u5 = TB_LD2(src + 320), u6 = TB_LD2(src + 384), u7 = TB_LD2(src + 448); \
                 x0 = make_uint4(u0.x, u0.y, u1.x, u1.y); x1 = make_uint4(u2.x, u2.y, u3.x, u3.y); x2 = make_uint4(u4.x, u4.y, u5.x, u5.y); x3 = make_uint4(u6.x, u6.y, u7.x, u7.y); } \
             else { const uint4 *src = (const uint4*)(tb + ((int64_t)L__ << 6)); x0 = src[0]; x1 = src[1]; x2 = src[2]; x3 = src[3]; } } } while (0)
 #define TBR_PUT(dst_, x0, x1, x2, x3) do { uint32_t *dst = (dst_); \

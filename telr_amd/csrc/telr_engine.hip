@@ -173,7 +173,7 @@ template <typename T> static int ctx_buf_t(telr_ctx *ctx, const char *name, size
 // two-step form then, not the whole range.
 template <class P = LoadKeys>
 static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint64_t *out, const int32_t *beg, const int32_t *end, const int64_t *src_beg,
-                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st, P prod = P(), const uint64_t *fb_in = nullptr)
+                        const int32_t *order, int nseg, size_t nkeys, bool any_over, hipStream_t st, P prod = P(), const uint64_t *fb_in = nullptr, hipEvent_t fb_ready = nullptr)
 {
     static const bool lib_sort = ab_on("sort64");
     if (nseg <= 0 || nkeys == 0) return TELR_OK;
@@ -204,6 +204,19 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
     if (any_over) { TRY(ctx_buf_t(ctx, (T + "_fbbeg").c_str(), (size_t)nseg, &A.fb_beg)); TRY(ctx_buf_t(ctx, (T + "_fbend").c_str(), (size_t)nseg, &A.fb_end)); }
     HIPCHK(hipMemsetAsync(A.tier_cnt, 0, (SEGSORT_TIERS + 1) * 4, st));
     hipLaunchKernelGGL(k_segsort_classify, dim3((nseg + 255) / 256), dim3(256), 0, st, A);
+    // the library's sort of the over-size segments runs on a side stream UNDER the tiers (a few segments of 10^5 keys: long, narrow
+    // launches that the main stream's work would otherwise queue behind); the main stream joins at the end
+    hipStream_t fbs = any_over ? ctx->side[1] : nullptr;
+    if (any_over) {
+        HIPCHK(hipEventRecord(ctx->ev_side[1], st)); HIPCHK(hipStreamWaitEvent(fbs, ctx->ev_side[1], 0));
+        if (fb_ready) HIPCHK(hipStreamWaitEvent(fbs, fb_ready, 0));        // the over-size queries' keys are written on another side stream
+        const uint64_t *fin = fb_in ? fb_in : in;
+        size_t tb = 0;
+        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, fin, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, fbs));
+        void *tmp; TRY(ctx_buf(ctx, "rp_tmp_fb", tb, &tmp));
+        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, fin, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, fbs));
+        HIPCHK(hipEventRecord(ctx->ev_side[1], fbs));
+    }
     const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     auto grid = [&](int resident) { return dim3((unsigned)std::min<int64_t>(nseg, (int64_t)ncu * resident * 8)); };
     // largest tiers first: their few long-running workgroups start while the device is otherwise idle
@@ -215,13 +228,7 @@ static int seg_sort_u64(telr_ctx *ctx, const char *tag, const uint64_t *in, uint
     hipLaunchKernelGGL((k_segsort<64, 8, P>), grid(32), dim3(64), 64 * 8 * 8, st, A, 1, prod);
     hipLaunchKernelGGL((k_segsort<64, 2, P>), grid(32), dim3(64), 64 * 2 * 8, st, A, 0, prod);
     HIPCHK(hipGetLastError());
-    if (any_over) {
-        const uint64_t *fin = fb_in ? fb_in : in;
-        size_t tb = 0;
-        HIPCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, fin, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
-        void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tb, &tmp));
-        HIPCHK(rocprim::segmented_radix_sort_keys(tmp, tb, fin, out, (unsigned)nkeys, (unsigned)nseg, A.fb_beg, A.fb_end, 0, 64, st));
-    }
+    if (any_over) HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[1], 0));
     return TELR_OK;
 }
 
@@ -645,10 +652,27 @@ extern "C" int32_t telr_seqset_count(const telr_seqset *s) { return s ? s->n : 0
 
 // ---------------------------------------------------------------------------------------
 // rocPRIM plumbing (scans and sorts are library calls; the hot kernels are in kernels.hip.h)
+// out[0 .. n] = exclusive scan of cnt[0 .. n) (kernels.hip.h: k_qscan_sums / k_qscan_write -- hand-written, two small launches, no state to
+// initialise); tot64 / n_over / over_list are optional
+template <typename Tin, typename Tout>
+static int dev_qscan(telr_ctx *ctx, const Tin *cnt, int32_t n, Tout *out, int64_t *tot64, int64_t cap, int32_t *n_over, int32_t *over_list)
+{
+    const int ntile = n > 0 ? (n + QSCAN_TILE - 1) / QSCAN_TILE : 1;
+    int64_t *d_ts; TRY(ctx_buf_t(ctx, "qscan_tiles", (size_t)ntile, &d_ts));
+    if (n_over) HIPCHK(hipMemsetAsync(n_over, 0, 4, ctx->stream));
+    hipLaunchKernelGGL((k_qscan_sums<Tin>), dim3(ntile), dim3(256), 0, ctx->stream, cnt, n, cap, d_ts, n_over, over_list);
+    hipLaunchKernelGGL((k_qscan_write<Tin, Tout>), dim3(ntile), dim3(256), 0, ctx->stream, cnt, n, d_ts, out, tot64);
+    HIPCHK(hipGetLastError());
+    return TELR_OK;
+}
 template <typename Tin, typename Tout>
 static int dev_exclusive_scan(telr_ctx *ctx, const Tin *in, Tout *out, size_t n)
 {
     if (n == 0) return TELR_OK;
+    // round 6: every scan of the map path is the hand-written one (in[n - 1] is the callers' trailing zero: out[n - 1] = the total);
+    // TELR_AB=scan_lib keeps rocPRIM's as the cross-check (tests/test_gpu_switches.py).  Up to 2^31 - 1 elements.
+    static const bool scan_lib = ab_on("scan_lib");
+    if (!scan_lib && n - 1 <= 0x7fffffff) return dev_qscan<Tin, Tout>(ctx, in, (int32_t)(n - 1), out, nullptr, 0, nullptr, nullptr);
     size_t tb = 0;
     auto it = rocprim::make_transform_iterator(in, [] __device__(Tin v) { return (Tout)v; });
     HIPCHK(rocprim::exclusive_scan(nullptr, tb, it, out, (Tout)0, n, rocprim::plus<Tout>(), ctx->stream));
@@ -1742,7 +1766,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
             else hipLaunchKernelGGL(k_vote_lookup<true>, dim3((unsigned)((nmz + 255) / 256)), dim3(256), 0, st, I, d_mx, nmz, mid_occ, d_ment, d_mn);
         }
         hipLaunchKernelGGL(k_vote_qhits, dim3(nq + 1), dim3(64), 0, st, d_qmz, d_mn, nq, d_qhits);
-        hipLaunchKernelGGL((k_qscan<int64_t, int64_t>), dim3(1), dim3(1024), 0, st, d_qhits, nq, (int64_t)0, d_qsoff, (int64_t*)nullptr, (int32_t*)nullptr);
+        TRY((dev_qscan<int64_t, int64_t>(ctx, d_qhits, nq, d_qsoff, nullptr, 0, nullptr, nullptr)));
         HIPCHK(hipGetLastError());
         int64_t nhits = 0;
         HIPCHK(hipMemcpyAsync(&nhits, d_qsoff + nq, 8, hipMemcpyDeviceToHost, st));
@@ -1759,7 +1783,7 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     // offsets, a batch with 2^31 anchors or more is handed back to the caller, which halves it -- and how many queries hold more anchors
     // than one workgroup sorts in LDS (segsort.hip.h)
     int32_t *d_overlist; TRY(ctx_buf_t(ctx, "q_overlist", (size_t)nq + 1, &d_overlist));
-    hipLaunchKernelGGL((k_qscan<int32_t, int32_t>), dim3(1), dim3(1024), 0, st, d_qcnt, nq, (int64_t)SEGSORT_CAP, d_qaoff, d_na64, d_nover, d_overlist);
+    TRY((dev_qscan<int32_t, int32_t>(ctx, d_qcnt, nq, d_qaoff, d_na64, (int64_t)SEGSORT_CAP, d_nover, d_overlist)));
     HIPCHK(hipGetLastError());
     int32_t na = 0; int64_t na64 = 0; int32_t n_over = 0;
     HIPCHK(hipMemcpyAsync(&na, d_qaoff + nq, 4, hipMemcpyDeviceToHost, st));
@@ -1777,29 +1801,44 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     TRY(ctx_buf_t(ctx, "skeys", (size_t)na, &d_skeys));
     S.keys = d_keys;
     // sub-read voting: the LDS sort reads the survivors from the staging pieces in place; only the library sort needs them dense
-    // (round 6: a query above the LDS limit -- a read inside a tandem array or a satellite -- no longer takes its whole range out of the
-    // fused / in-place form: only the over-size queries get their keys written to memory for the library's segmented sort)
-    const bool vote_in_place = vote && !lib_sort;
+    // A range that holds an over-size query takes the two-step form as a whole (the round-5 rule).  TELR_AB=over_routed: only the over-size
+    // queries do (their keys written on a side stream under the LDS sort of the others) -- built in round 6 for the hard genome, where EVERY
+    // range holds such a read, and measured SLOWER on configs[2] (196.7 against 185.0 ms per step, same box, three alternating runs each:
+    // profiles/r06_oversize_routing_ab.txt) and no faster on the hard genome; kept behind the switch, tests/test_gpu_switches.py.
+    static const bool over_routed = ab_on("over_routed");
+    const bool over_whole = any_over && !over_routed;
+    const bool vote_in_place = vote && !lib_sort && !over_whole;
     // The anchor keys are MADE inside the sort (SeedProducer: the seeding routine writes a query's keys straight into the sorting
     // workgroup's LDS), so unsorted keys never exist in HBM; TELR_AB=seed_unfused keeps the two-step form for A/B, and a range with a
     // query above the LDS limit takes it too (its library sort reads the keys from memory)
     static const bool seed_unfused = ab_on("seed_unfused");
-    const bool seed_fused = !vote && !lib_sort && !seed_unfused;
+    const bool seed_fused = !vote && !lib_sort && !seed_unfused && !over_whole;
     S.lds_keys = nullptr;
+    // (TELR_AB=over_routed: the over-size queries' keys go to memory on a SIDE stream, under the LDS sort of everybody else; the library's sort waits for it)
+    hipEvent_t over_ready = nullptr;
     if (vote) {
         if (!vote_in_place) hipLaunchKernelGGL(k_vote_compact, dim3(nq), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, nq, d_keys, (const int32_t*)nullptr);
-        else if (any_over) hipLaunchKernelGGL(k_vote_compact, dim3(n_over), dim3(256), 0, st, d_stage, d_qsoff, d_qaoff, n_over, d_keys, (const int32_t*)d_overlist);
+        else if (any_over) {
+            HIPCHK(hipEventRecord(ctx->ev_fork, st)); HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+            hipLaunchKernelGGL(k_vote_compact, dim3(n_over), dim3(256), 0, ctx->side[0], d_stage, d_qsoff, d_qaoff, n_over, d_keys, (const int32_t*)d_overlist);
+            HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0])); over_ready = ctx->ev_side[0];
+        }
     }
     else if (!seed_fused) hipLaunchKernelGGL(k_seed<1>, dim3(nq), dim3(256), 0, st, S);
-    else if (any_over) { SeedArgs So = S; So.q_order = d_overlist; hipLaunchKernelGGL(k_seed<1>, dim3(n_over), dim3(256), 0, st, So); }
+    else if (any_over) {
+        SeedArgs So = S; So.q_order = d_overlist;
+        HIPCHK(hipEventRecord(ctx->ev_fork, st)); HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_seed<1>, dim3(n_over), dim3(256), 0, ctx->side[0], So);
+        HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0])); over_ready = ctx->ev_side[0];
+    }
     HIPCHK(hipGetLastError());
     t_sd.stop(); ht.mark("seed (sync: anchor total)");
     ctx->ctr.anchors += na;
 
     // ---- per-query sort of the anchor keys --------------------------------------------------
     StageTimer t_so(ctx, ST_SORT, true);
-    if (na > 0 && seed_fused) { SeedProducer sp; sp.S = S; TRY((seg_sort_u64<SeedProducer>(ctx, "so_a", nullptr, d_skeys, d_qaoff, d_qaoff + 1, nullptr, d_qorder, nq, (size_t)na, any_over, st, sp, d_keys))); }
-    else if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st, LoadKeys(), d_keys));
+    if (na > 0 && seed_fused) { SeedProducer sp; sp.S = S; TRY((seg_sort_u64<SeedProducer>(ctx, "so_a", nullptr, d_skeys, d_qaoff, d_qaoff + 1, nullptr, d_qorder, nq, (size_t)na, any_over, st, sp, d_keys, over_ready))); }
+    else if (na > 0) TRY(seg_sort_u64(ctx, "so_a", vote_in_place ? d_stage : d_keys, d_skeys, d_qaoff, d_qaoff + 1, vote_in_place ? d_qsoff : nullptr, d_qorder, nq, (size_t)na, any_over, st, LoadKeys(), d_keys, over_ready));
     t_so.stop();
 
     // ---- chaining ---------------------------------------------------------------------------

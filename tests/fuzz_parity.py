@@ -1,5 +1,5 @@
 """Randomised HIP-vs-oracle parity: random genomes, read sets and option mixes, every stage compared bit for bit
-(tests/test_gpu_parity.py: compare_all).  usage: [FUZZ_BIG=1] python tests/fuzz_parity.py [iterations] [seed]   (FUZZ_BIG: Mb-size genomes, reads of 8-40 kb)"""
+(tests/test_gpu_parity.py: compare_all).  usage: [FUZZ_BIG=1] [FUZZ_HARD=1] python tests/fuzz_parity.py [iterations] [seed]   (FUZZ_BIG: Mb-size genomes, reads of 8-40 kb; FUZZ_HARD: repeat-rich targets, reads with error bursts)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # test infrastructure: the oracle is the checker
@@ -11,8 +11,37 @@ from telr_amd.presets import preset
 
 
 
-def draw_case(seed, big=False, sv=False, presets=None):
+def harden(rng, genome, reads):
+    """round 6: the HARD sequence classes of telr_amd/synth.py in fuzz size -- tandem arrays, microsatellites, low-complexity stretches,
+    (on Mb-size targets) a segmental duplication -- written over the targets, and error bursts in a third of the reads"""
+    for g in genome:
+        if len(g) >= 300000:
+            synth.harden_sequence(rng, g, 0, 0.42, dict(synth.HARD, tandem_frac=0.08, micro_per_mb=600, lowcx_frac=0.03, segdup_every=400_000))
+        else:
+            for _ in range(int(rng.integers(1, 5))):
+                arr = synth._tandem_array(rng, int(np.exp(rng.uniform(np.log(2), np.log(200)))), int(rng.integers(100, 3000)), 0.42, float(rng.uniform(0, 0.05)))
+                synth._put(g, int(rng.integers(0, max(1, len(g) - len(arr)))), arr)
+            for _ in range(int(rng.integers(2, 12))):
+                arr = synth._tandem_array(rng, int(rng.integers(1, 7)), int(rng.integers(20, 300)), 0.5, 0.0)
+                synth._put(g, int(rng.integers(0, max(1, len(g) - len(arr)))), arr)
+            n = int(rng.integers(100, 800))
+            synth._put(g, int(rng.integers(0, max(1, len(g) - n))), synth.random_seq_fast(rng, n, 0.08))
+    return genome
+
+
+def burst(rng, reads):
+    for ri in range(len(reads)):
+        r = reads[ri]
+        if len(r) > 600 and rng.random() < 0.33:
+            L = int(rng.integers(50, 300)); p = int(rng.integers(100, len(r) - L - 100))
+            reads[ri] = np.concatenate([r[:p], synth.mutate(rng, r[p:p + L], 0.12, 0.06, 0.12), r[p + L:]])
+    return reads
+
+
+def draw_case(seed, big=False, sv=False, presets=None, hard=False):
     """one random configuration -> (preset name, io, mo, genome, reads, qtarget, edge_repeats).
+    hard: tandem arrays / microsatellites / low-complexity stretches / segmental duplications in the targets, error bursts in the reads
+    (FUZZ_HARD=1): reads that sit in repeats -- many equal-score chains, anchors past the LDS sort's limit, extensions through arrays.
     sv: half of the reads carry one to three large insertions / deletions (30-600 bases): wide bands, long gap runs -- the
     convex cost's re-biased int16 classes, their multi-wave form and the int32 fall-back (FUZZ_SV=1; FUZZ_PRESETS=a,b restricts
     the presets drawn)"""
@@ -27,6 +56,8 @@ def draw_case(seed, big=False, sv=False, presets=None):
         for _ in range(int(rng.integers(0, 8))):
             p = int(rng.integers(0, len(g) - len(te)))
             g[p:p + len(te)] = synth.mutate(rng, te, float(rng.uniform(0, 0.08)), 0.0, 0.0)[:len(te)]
+    if hard:
+        harden(rng, genome, None)
     if rng.random() < 0.3:
         g = genome[0]; p = int(rng.integers(0, len(g) - 300)); g[p:p + int(rng.integers(1, 300))] = ord("N")
     # round 4: targets that BEGIN (or end) inside a repeat copy, with homopolymer runs at the very start -- the class of the
@@ -45,6 +76,8 @@ def draw_case(seed, big=False, sv=False, presets=None):
     err = float(rng.uniform(0.0, 0.07))
     reads, truth = synth.simulate_reads(rng, genome, int(rng.integers(5, 70)), int(rng.integers(8000, 40000) if big else rng.integers(400, 9000)), err=(err, err / 2, err))
     truth = [int(t[0]) for t in truth]
+    if hard:
+        reads = burst(rng, reads)
     if sv:
         for ri in range(len(reads)):
             if rng.random() < 0.5 and len(reads[ri]) > 1500:
@@ -95,10 +128,10 @@ def draw_case(seed, big=False, sv=False, presets=None):
     return pname, io, mo, genome, reads, qtarget, edge_repeats
 
 
-def run(eng, n_iter, seed0, big=False, sv=False, presets=None):
+def run(eng, n_iter, seed0, big=False, sv=False, presets=None, hard=False):
     from test_gpu_parity import compare_all
     for it in range(n_iter):
-        pname, io, mo, genome, reads, qtarget, edge_repeats = draw_case(seed0 * 1000 + it, big, sv, presets)
+        pname, io, mo, genome, reads, qtarget, edge_repeats = draw_case(seed0 * 1000 + it, big, sv, presets, hard)
         try:
             compare_all(eng, genome, reads, io, mo, qtarget=qtarget)
         except Exception as e:
@@ -112,5 +145,5 @@ if __name__ == "__main__":
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t0 = time.time()
     run(Engine(0), n_iter, seed0, big=os.environ.get("FUZZ_BIG") is not None, sv=os.environ.get("FUZZ_SV") is not None,
-        presets=os.environ["FUZZ_PRESETS"].split(",") if os.environ.get("FUZZ_PRESETS") else None)
+        presets=os.environ["FUZZ_PRESETS"].split(",") if os.environ.get("FUZZ_PRESETS") else None, hard=os.environ.get("FUZZ_HARD") is not None)
     print("fuzz ok:", n_iter, "iterations in %.1f s" % (time.time() - t0))

@@ -34,6 +34,19 @@ def test_full_size_configuration_equals_the_oracle_on_a_random_sample(cfg, prese
     assert d["frac_reads_mapped"] > 0.75 and d["value"] > 1.0
 
 
+@pytest.mark.parametrize("preset", ["map-ont", "ngmlr-ont"])
+def test_hard_genome_at_configs2_size_equals_the_oracle_on_a_random_sample(preset):
+    """round 6: `--config c2r` = configs[2] on the HARD genome (4 % tandem arrays, microsatellites, low-complexity
+    stretches, segmental duplications, satellite blocks next to 15 % of the insertions; reads with error bursts), both stage-1
+    aligners: one step on the whole read set, 3,000 sampled reads record for record against the oracle on the same full-size index;
+    the over-size path is in use (reads inside arrays hold more anchors than one workgroup sorts in LDS)"""
+    d = _bench("--config", "c2r", "--loci", "0", "--cpu-sample-reads", "3000", "--no-default-aligner-leg", "--preset", preset)
+    assert "hard genome" in d["config"]["workload"] and ("preset " + preset) in d["config"]["workload"] and d["config"]["read_bases_this_rank"] >= 3.5e9, d["config"]
+    par = d["cpu_baseline"]["parity"]
+    assert par["reads"] == 3000 and par["identical"] is True and par["reads_differing"] == 0 and par["records_engine"] == par["records_oracle"] >= 2500, par
+    assert d["counters"]["over_queries"] > 0 and d["frac_reads_mapped"] > 0.75
+
+
 def test_call_sites_s6_s7_and_the_bundle_at_configs2_size():
     d = _bench("--config", "c2", "--loci", "100", "--flank-parity", "--no-cpu-baseline", "--no-polish-leg")
     fp = d["flank_parity_asm10"]

@@ -23,3 +23,12 @@ def test_random_configurations_with_large_indels_under_the_convex_cost(engine, s
     runs, i.e. the re-biased int16 classes of the convex cost (one wave, several waves) and the int32 classes behind them"""
     import fuzz_parity
     fuzz_parity.run(engine, 12, seed, sv=True, presets=["ngmlr-ont", "ngmlr-pacbio"])
+
+
+@pytest.mark.parametrize("seed,big", [(31, False), (32, False), (33, True)])
+def test_random_configurations_on_hard_sequence(engine, seed, big):
+    """round 6: targets with tandem arrays, microsatellites, low-complexity stretches and (Mb-size targets) segmental duplications,
+    reads with error bursts -- the sequence classes of `bench.py --config c2r`: queries past the LDS sort's limit (the library's
+    segmented sort for those only), hundreds of equal chains, extensions through arrays; every stage against the oracle"""
+    import fuzz_parity
+    fuzz_parity.run(engine, 4 if big else 30, seed, big=big, hard=True)

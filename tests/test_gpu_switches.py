@@ -18,6 +18,8 @@ SWITCHES = [
     {"TELR_AB": "no_tag8"}, {"TELR_AB": "sketch64"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "no_pk"}, {"TELR_SERIAL": "1"},
     {"TELR_AB": "tb_one_launch"}, {"TELR_AB": "no_avx2"}, {"TELR_PACK_THREADS": "1"},
     {"TELR_TRACE": "host"}, {"TELR_AB": "seed_unfused"}, {"TELR_AB": "no_islands"}, {"TELR_AB": "vote_filter"}, {"TELR_AB": "tb8,no_tag8,sort64"}, {"TELR_AB": "chain_push"}, {"TELR_AB": "dp_one_wave"},
+    {"TELR_AB": "over_routed"},             # round 6: only the over-size queries of a range take the two-step seeding (measured, not the default)
+    {"TELR_AB": "scan_lib"},                # round 6: rocPRIM's device-wide scans instead of k_qscan_sums / k_qscan_write
     {"TELR_AB": "index_sort_lib"},          # round 6: rocPRIM's sorts in the index build instead of radix.hip.h (the cross-check SURVEY 7 step 5 asks for)
 ]
 

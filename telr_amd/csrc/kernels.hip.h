@@ -3479,14 +3479,20 @@ __global__ void __launch_bounds__(64) k_traceback(const DpProb *__restrict__ pro
 // two register sets hold the next two lines in flight: one memory wait per line for the whole wave instead of one per step.
 // rb4 != 0: the class spills nibbles (d_tb4), rb4 = bytes per row; the matching columns then come from the score (o = gap costs)
 // tag8: the wave's bytes are the raw tags of d_cell_pk8 (no "bases equal" bit either)
-__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, bool il, int rb4, bool tag8, const DpOpt o_,
+// ENC (round 6): the encoding of the wave's bytes as a COMPILE-TIME choice -- 0 plain flags, 1 raw tags of d_cell_pk8, 2 nibbles: the walk is a chain of
+// dependent steps whose issue slots set the wave's time (profiles/r06_traceback_experiments.txt); with the three encodings behind run-time branches its loop
+// was 150 instructions and 12 branches.  IL: the wave-interleaved layout of the one-lane classes.
+template <int ENC, bool IL>
+__device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ probs, DpRes *__restrict__ res, int pi, bool have, int lpp, int rb4_, const DpOpt o_,
                                                  const uint8_t *__restrict__ tb_all, uint32_t *__restrict__ cig, int32_t *__restrict__ retry,
                                                  uint32_t *stage)
 {
+    constexpr bool il = IL, tag8 = ENC == 1, nib = ENC == 2;
+    const int rb4 = ENC == 2 ? rb4_ : 0;
     const int lane = threadIdx.x;
     DpProb P = probs[pi];
     if (P.kind >= 3) have = false;
-    const int rowb = rb4 ? rb4 : lpp * 4, dlo = P.dlo, dhi_ = P.dhi, mg = P.pad[0] >> 8;
+    const int rowb = nib ? rb4 : lpp * 4, dlo = P.dlo, dhi_ = P.dhi, mg = P.pad[0] >> 8;
     int gc = 0;                                                    // tagged spills: cost of the gap runs of the path (piece by piece, as the DP counted them)
     int i = 0, j = 0;
     if (have) { i = res[pi].bi; j = res[pi].bj; }
@@ -3528,7 +3534,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
             const int lim = L << 6;
             for (;;) {
                 const int a = i + j, sl = (j - i - dlo) >> 1;
-                const int o = rb4 ? (a >> 1) * rb4 + ((sl >> 2) << 2) + (((sl >> 1) & 1) << 1) + (sl & 1)
+                const int o = nib ? (a >> 1) * rb4 + ((sl >> 2) << 2) + (((sl >> 1) & 1) << 1) + (sl & 1)
                                   : (((a >> 1) * lpp + (sl >> 1)) << 2) + ((a & 1) << 1) + (sl & 1);
                 const bool act = i > 0 && j > 0 && o >= lim;
                 if (!__any(act)) break;
@@ -3546,13 +3552,13 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                 const uint32_t t1 = TBR_BYTE(v1 ? oo - rowb : 0), t2 = TBR_BYTE(v2 ? oo - 2 * rowb : 0), t3 = TBR_BYTE(v3 ? oo - 3 * rowb : 0);
 #undef TBR_BYTE
                 uint32_t nd, mb;                    // bit r: cell r of the diagonal is NOT a diagonal move (or not there); bases equal
-                if (rb4) {                                                         // even step: low nibble, odd step: high nibble
+                if constexpr (ENC == 2) {                                          // even step: low nibble, odd step: high nibble
                     const int sh = (a & 1) << 2;
                     nd = (uint32_t)(!v1 || ((t1 >> sh) & 3u) != 2u) << 1 | (uint32_t)(!v2 || ((t2 >> sh) & 3u) != 2u) << 2 | (uint32_t)(!v3 || ((t3 >> sh) & 3u) != 2u) << 3;
                     mb = 0;
                     const uint32_t nb = (t >> sh) & 0xfu;                           // raw: tag of H (2 diagonal, 1 E, 0 F), E extended, F opened
                     t = (2u - (nb & 3u)) | (nb & 4u) | ((nb & 8u) ^ 8u);
-                } else if (tag8) {                                                  // raw: tag of H (4 - source), E1 / E2 extended, F1 / F2 opened
+                } else if constexpr (ENC == 1) {                                    // raw: tag of H (4 - source), E1 / E2 extended, F1 / F2 opened
                     nd = (uint32_t)(!v1 || (t1 & 7u) != 4u) << 1 | (uint32_t)(!v2 || (t2 & 7u) != 4u) << 2 | (uint32_t)(!v3 || (t3 & 7u) != 4u) << 3;
                     mb = 0;
                     t = (4u - (t & 7u)) | (t & 0x28u) | ((t & 0x50u) ^ 0x50u);
@@ -3562,7 +3568,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                 }
                 if (act) {
                     touched |= (j - i - dlo <= mg) | (dhi_ - (j - i) <= mg);       // within mg diagonals of a band edge
-                    const int s0 = state ? state : (int)(t & (rb4 ? 3 : 7));
+                    const int s0 = state ? state : (int)(t & (nib ? 3 : 7));
                     const int isM = s0 == 0, isD = s0 & 1;
                     const int op = isM ? 0 : (isD ? 2 : 1);
                     // cells of this trip: the run of diagonal moves from the current cell on (1 .. 4), or one step of a gap
@@ -3570,7 +3576,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
                     // a step inside a gap run costs its piece's extension, the step that enters the run (walking backwards: the
                     // run's LAST cell) its opening as well
                     if (!isM) gc += (s0 <= 2 ? o_.e : o_.e2) + (state ? 0 : (s0 <= 2 ? o_.q : o_.q2));
-                    state = (isM || !((t >> ((rb4 ? 1 : 2) + s0)) & 1)) ? 0 : s0;
+                    state = (isM || !((t >> ((nib ? 1 : 2) + s0)) & 1)) ? 0 : s0;
                     ml += isM ? __builtin_popcount(mb & ((1u << nn) - 1u)) : 0; mc += isM ? nn : 0;
                     i -= isM ? nn : (isD ^ 1); j -= isM ? nn : isD;
                     const bool same = op == cur_op;
@@ -3591,7 +3597,7 @@ __device__ __forceinline__ void d_traceback_rows(const DpProb *__restrict__ prob
     if (i > 0) { if (cur_op == 1) cur_len += i; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 1; cur_len = i; } }
     if (j > 0) { if (cur_op == 2) cur_len += j; else { if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op; cur_op = 2; cur_len = j; } }
     if (cur_len) cg[no++] = (uint32_t)cur_len << 4 | (uint32_t)cur_op;
-    if (rb4 || tag8) ml = (res[pi].score + o_.b * mc + gc) / (o_.a + o_.b);      // a ml - b (mc - ml) - gc = score
+    if (nib || tag8) ml = (res[pi].score + o_.b * mc + gc) / (o_.a + o_.b);      // a ml - b (mc - ml) - gc = score
     res[pi].nops = no; res[pi].mlen = ml; res[pi].mcols = mc;
     if (retry && P.kind == 0 && touched && P.m + P.n <= ADAPT_MAX_STEPS) retry[pi] = 1;
 }
@@ -3615,8 +3621,13 @@ __global__ void __launch_bounds__(64) k_traceback_pk(const DpProb *__restrict__ 
 #ifdef TB_PROF
     const unsigned long long t0_ = wall_clock64();
 #endif
-    d_traceback_rows(probs, res, cls_list[off.off[cls] + (have ? first + t : first)], have, PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)], d_tb_interleaved(cls),
-                     rb4, tag8, o, tb_all, cig, retry, stage);
+    const int pi_ = cls_list[off.off[cls] + (have ? first + t : first)], lpp_ = PK_LPP[PK_IDX(cls)] * PK_R[PK_IDX(cls)];
+    if (d_tb_interleaved(cls)) {
+        if (rb4) d_traceback_rows<2, true>(probs, res, pi_, have, lpp_, rb4, o, tb_all, cig, retry, stage);
+        else if (tag8) d_traceback_rows<1, true>(probs, res, pi_, have, lpp_, 0, o, tb_all, cig, retry, stage);
+        else d_traceback_rows<0, true>(probs, res, pi_, have, lpp_, 0, o, tb_all, cig, retry, stage);
+    } else if (tag8) d_traceback_rows<1, false>(probs, res, pi_, have, lpp_, 0, o, tb_all, cig, retry, stage);
+    else d_traceback_rows<0, false>(probs, res, pi_, have, lpp_, 0, o, tb_all, cig, retry, stage);
 #ifdef TB_PROF
     if (threadIdx.x == 0) {
         const unsigned long long t1_ = wall_clock64(), dt = t1_ - t0_;

@@ -2073,7 +2073,7 @@ __global__ void k_prob_sizes(DpProb *__restrict__ probs, int32_t np, int fill_ma
     else cig_ops[i] = P.kind == 3 ? 2 : (int64_t)P.m + P.n;
 }
 // scratch offsets of every problem, class histogram, and the (key, problem) pairs whose ONE radix sort yields all class
-// lists at once: key = class << 20 | (0xFFFFF - steps), so a class is a contiguous range ordered by decreasing steps
+// lists at once: key = class << 19 | (0x7FFFF - steps), so a class is a contiguous range ordered by decreasing steps
 struct ClsOff { int32_t off[DP_NCLS + 1]; };
 // Trace-back offsets in CLASS-LIST order: the 64 problems of a wave (neighbours in their class list) get adjacent pieces of
 // the trace-back buffer.  With offsets in problem order every lane of a wave worked in a different page of a 10-GB buffer and
@@ -2116,8 +2116,8 @@ __global__ void __launch_bounds__(256) k_prob_assign(DpProb *__restrict__ probs,
         if (cig_off) probs[i].cig_off = cig_off[i];       // a retry keeps the CIGAR slot of the original problem
         const int c = probs[i].kind >= 3 ? 0 : (probs[i].pad[0] & 0xff);
         atomicAdd(&lcnt[c], 1);
-        int steps = probs[i].m + probs[i].n; if (steps > 0xFFFFF) steps = 0xFFFFF;
-        sort_key[i] = (uint32_t)c << 20 | (uint32_t)(0xFFFFF - steps);
+        int steps = probs[i].m + probs[i].n; if (steps > 0x7FFFF) steps = 0x7FFFF;
+        sort_key[i] = (uint32_t)c << 19 | (uint32_t)(0x7FFFF - steps);          // 24 bits: three radix passes instead of four
         sort_val[i] = i;
     }
     __syncthreads();
@@ -3258,7 +3258,8 @@ __global__ void k_pk_waves(const DpProb *__restrict__ probs, const int32_t *__re
     while (i >= plan.woff[c + 1]) ++c;
     const int first = (i - plan.woff[c]) * (64 / PK_LPP[c]);
     const DpProb P = probs[cls_list[off.off[PK_CLS(c)] + first]];     // lists are sorted by decreasing steps
-    keys[i] = (uint32_t)((P.m + P.n) * PK_R[c]);
+    const uint32_t cost = (uint32_t)((P.m + P.n) * PK_R[c]);          // < 2^16 (packed fills: m + n <= 7,900, at most 8 registers): two radix passes
+    keys[i] = cost > 0xFFFFu ? 0xFFFFu : cost;
     vals[i] = (uint32_t)PK_CLS(c) << 26 | (uint32_t)first;
 }
 #ifndef PK_WPE

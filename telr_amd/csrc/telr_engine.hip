@@ -1500,9 +1500,9 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
     for (int c = 0; c < DP_NCLS; ++c) coff.off[c + 1] = coff.off[c] + h_cls[c];
     {
         size_t tbytes = 0;
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 25, st));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 24, st));
         void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
-        HIPCHK(rocprim::radix_sort_pairs(tmp, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 25, st));
+        HIPCHK(rocprim::radix_sort_pairs(tmp, tbytes, d_clskey, d_keytmp, d_listtmp, d_clslist, (size_t)np, 0, 24, st));
     }
     if (np > 0) {       // trace-back pieces laid out in class-list order (page locality of the spill and of the walk)
         int64_t *d_tbs;
@@ -1550,9 +1550,9 @@ static int dp_pass(telr_ctx *ctx, const telr_seqset *qs, const telr_seqset *tg, 
             hipLaunchKernelGGL(k_pk_waves, dim3((nw + 255) / 256), dim3(256), 0, st, d_probs, d_clslist, coff, plan, d_wk, d_wv);
             HIPCHK(hipGetLastError());
             size_t tbytes = 0;
-            HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 18, st));
+            HIPCHK(rocprim::radix_sort_pairs_desc(nullptr, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 16, st));
             void *tmp; TRY(ctx_buf(ctx, "rp_tmp", tbytes, &tmp));
-            HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 18, st));
+            HIPCHK(rocprim::radix_sort_pairs_desc(tmp, tbytes, d_wk, d_wk2, d_wv, d_wv2, (size_t)nw, 0, 16, st));
         }
     }
     // The few long/wide problems are latency-bound single waves: start each tail class on its own side

@@ -30,6 +30,7 @@
 
 struct ChainOpt {            // subset of telr_map_opt the device needs
     int32_t max_gap, bw, min_cnt, min_chain_score, chain_gap_q8, chain_skip_q8;
+    int32_t dense_n, dense_span, mw_n;    // k_chain's choice of loop per run (a speed matter only: every loop yields the same f and p), see d_chain_dense
 };
 struct DpOpt {
     int32_t a, b, q, e, q2, e2, sc_ambi, zdrop;
@@ -1323,7 +1324,7 @@ template <int R, bool SKIP>
 __device__ __forceinline__ void d_chain_run(const uint64_t *__restrict__ keys, const int64_t base, const int n, const int pdelta,
                                             const ChainOpt &o, int32_t *__restrict__ f, int32_t *__restrict__ p)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t *a = keys + base;
     const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
     const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
@@ -1397,7 +1398,7 @@ __device__ __forceinline__ void d_chain_run_lazy(const uint64_t *__restrict__ ke
 {
     static_assert(R >= 2, "a look-back of 64 has no far part");
     constexpr int32_t NEG = -(1 << 29);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t *a = keys + base;
     const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
     const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
@@ -1491,14 +1492,128 @@ __device__ __forceinline__ void d_chain_run_lazy(const uint64_t *__restrict__ ke
     }
 }
 
-template <int R, bool SKIP, bool LAZY = true>
+// WHICH LOOP (round 6).  The lazy look-back wins on true chains (the far links are never scored) and loses badly inside satellites and
+// tandem arrays: there an anchor's collinear predecessor lies (copies in the read) x (a few bases) anchors back, past the 64 nearest,
+// the bound never decides and EVERY anchor pays the far evaluation -- R gathered links plus two wave reductions, ~3 times the price
+// of the plain push loop's R links -- and such a query is one wave of 10^5-10^6 anchors that the whole range waits for.  A run of
+// at least `dense_n` anchors is sampled at 64 places: where 64 consecutive anchors sit within `dense_span` reference bases (several
+// anchors per base: a lattice of repeat copies, not a chain) in a third of the samples, the run takes the push loop.  Same f, same p
+// either way; TELR_AB=chain_lazy / chain_push pin one loop.
+__device__ __forceinline__ bool d_chain_dense(const uint64_t *__restrict__ a, const int n, const ChainOpt &o)
+{
+    if (o.dense_n <= 0 || n < o.dense_n || n < 128) return false;
+    const int i = (int)(((int64_t)(threadIdx.x & 63) * (n - 65)) / 63);
+    const uint32_t g0 = (uint32_t)(a[i] >> 32), g1 = (uint32_t)(a[i + 64] >> 32);      // (another strand: bit 31 makes the difference huge)
+    return __popcll(__ballot(g1 - g0 <= (uint32_t)o.dense_span)) >= 21;
+}
+// R WAVES ON ONE RUN (round 6).  The push loop's R links per anchor are independent: wave w of a workgroup of R owns the chunks
+// c = w (mod R) of 64 anchors, one anchor per lane.  An anchor's look-back of 64 R predecessors is then
+//   * lanes >= l of chunk c - R: the wave's OWN previous chunk -- a lane takes its next anchor the moment its own is final, as in the
+//     push loop, and keeps receiving the rest of that chunk's pushes;
+//   * chunks c - R + 1 .. c - 1: the other waves' -- read from a ring of the last 64 R final anchors in LDS (reference word + 1,
+//     query position + 1, 2 f + 2), 64 entries at a time into registers, pushed with v_readlane, as far as the counter `done` says
+//     they are published (a wave polls it with s_sleep: all R waves of a workgroup are resident, the wave that finalises the lowest
+//     unfinished chunk never waits);
+//   * lanes < l of chunk c: the wave's own 64-step loop, publishing eight anchors at a time.
+// Pushes reach an anchor in ascending order of j, so ">=" keeps the largest index among ties: same f, same p as the other loops.
+// An entry of the ring is overwritten by the anchor 64 R further on, which is published only after every chunk that reads the old
+// one has finished absorbing.  The critical path per anchor is one link (~45 instructions) instead of R links.  Only for runs that a
+// whole call would wait for (o.mw_n anchors: a window read across a satellite against its contig brings 10^6): thousands of dense
+// runs keep the device busy by themselves, and workgroups of R waves for EVERY query cost the easy genome 5 % of its step (measured).
+template <int R, bool SKIP>
+__device__ __forceinline__ void d_chain_run_mw(const uint64_t *__restrict__ keys, const int64_t base, const int n, const int pdelta,
+                                               const ChainOpt &o, int32_t *__restrict__ f, int32_t *__restrict__ p, uint4 *ring, int32_t *done_s)
+{
+    static_assert(R >= 2, "one wave is the push loop");
+    constexpr int RING = 64 * R;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t *a = keys + base;
+    const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
+    const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
+    if (threadIdx.x == 0) *done_s = 0;
+    __syncthreads();
+    const int nchunk = (n + 63) >> 6;
+    uint32_t gi, qi, sp1; int32_t B, bp = -1;
+    { const int i = wv * 64 + lane; const uint64_t k = i < n ? a[i] : 0; gi = (uint32_t)(k >> 32); qi = (uint32_t)A_Q(k); sp1 = (uint32_t)A_SPAN(k) - 1u; B = 2 * A_SPAN(k) + 1; }
+    for (int c = wv; c < nchunk; c += R) {
+        const int j0 = c * 64;
+        // the anchor that takes this lane's place in chunk c + R
+        const int inext = j0 + RING + lane;
+        const uint64_t knext = inext < n ? a[inext] : 0;
+        const uint32_t ng = (uint32_t)(knext >> 32), nqp = (uint32_t)A_Q(knext), nsp1 = (uint32_t)A_SPAN(knext) - 1u;
+        const int32_t nB = 2 * A_SPAN(knext) + 1;
+        // ---- the other waves' chunks
+        int j = j0 - 64 * (R - 1); if (j < 0) j = 0;
+        int polls = 0;
+        while (j < j0) {
+            const int avail = __builtin_amdgcn_readfirstlane(__hip_atomic_load(done_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (avail <= j) { if (++polls > (1 << 24)) break; __builtin_amdgcn_s_sleep(2); continue; }       // (the bound only keeps a broken build from hanging the device: ~1 s)
+            int lim = avail < j0 ? avail : j0; if (lim > j + 64) lim = j + 64;
+            const int cnt = lim - j;
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < cnt) e = ring[(j + lane) & (RING - 1)];
+            for (int t = 0; t < cnt; ++t) {
+                const uint32_t gj1 = (uint32_t)__builtin_amdgcn_readlane((int)e.x, t), qj1 = (uint32_t)__builtin_amdgcn_readlane((int)e.y, t);
+                const int32_t fj2p2 = __builtin_amdgcn_readlane((int)e.z, t);
+                d_chain_push<SKIP>(gi, qi, sp1, gj1, qj1, fj2p2, j + t, max_gap, ddc, gap_q8, skip_q8, B, bp);
+            }
+            j = lim;
+        }
+        // ---- the wave's own chunk
+        const int jn = n - j0 < 64 ? n - j0 : 64;
+        int32_t myB = 0, myp = -1; uint32_t myg = 0, myq = 0;
+        for (int jj = 0; jj < jn; ++jj) {
+            const uint32_t gj1 = (uint32_t)__builtin_amdgcn_readlane((int)gi, jj) + 1u, qj1 = (uint32_t)__builtin_amdgcn_readlane((int)qi, jj) + 1u;
+            const int32_t fj2p2 = (__builtin_amdgcn_readlane(B, jj) & ~1) + 2;
+            const bool me = lane == jj;
+            myB = me ? B : myB; myp = me ? bp : myp; myg = me ? gi : myg; myq = me ? qi : myq;
+            gi = me ? ng : gi; qi = me ? nqp : qi; sp1 = me ? nsp1 : sp1; B = me ? nB : B;
+            d_chain_push<SKIP>(gi, qi, sp1, gj1, qj1, fj2p2, j0 + jj, max_gap, ddc, gap_q8, skip_q8, B, bp);
+            if ((jj & 7) == 7 || jj == jn - 1) {
+                if (lane >= (jj & ~7) && lane <= jj) ring[(j0 + lane) & (RING - 1)] = make_uint4(myg + 1u, myq + 1u, (uint32_t)((myB & ~1) + 2), 0u);
+                __hip_atomic_store(done_s, j0 + jj + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (lane < jn) { f[base + j0 + lane] = myB >> 1; p[base + j0 + lane] = (myB & 1) ? -1 : myp + pdelta; }
+    }
+}
+// MODE 0: the push loop, 1: the lazy far look-back, 2: chosen per run.  `skip_mw`: runs that k_chain_mw takes (dense and at least
+// o.mw_n anchors) are left to it.
+__device__ __forceinline__ bool d_chain_is_mw(const bool dense, const int n, const ChainOpt &o) { return dense && o.mw_n > 0 && n >= o.mw_n; }
+template <int R, bool SKIP, int MODE>
+__device__ __forceinline__ void d_chain_any(const uint64_t *__restrict__ keys, const int64_t base, const int n, const int pdelta,
+                                            const ChainOpt &o, int32_t *__restrict__ f, int32_t *__restrict__ p, const bool skip_mw)
+{
+    if constexpr (MODE == 0 || R < 2) d_chain_run<R, SKIP>(keys, base, n, pdelta, o, f, p);
+    else if constexpr (MODE == 1) d_chain_run_lazy<R, SKIP>(keys, base, n, pdelta, o, f, p);
+    else {
+        const bool dense = d_chain_dense(keys + base, n, o);
+        if (skip_mw && d_chain_is_mw(dense, n, o)) return;
+        if (dense) d_chain_run<R, SKIP>(keys, base, n, pdelta, o, f, p);
+        else d_chain_run_lazy<R, SKIP>(keys, base, n, pdelta, o, f, p);
+    }
+}
+template <int R, bool SKIP, int MODE = 2>
 __global__ void __launch_bounds__(64) k_chain(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq,
-                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order)
+                                              ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p, const int32_t *__restrict__ q_order, int32_t skip_mw)
 {
     if ((int)blockIdx.x >= nq) return;
     const int q = q_order ? q_order[blockIdx.x] : blockIdx.x;    // longest reads first: the kernel ends with the short ones
-    if constexpr (LAZY && R >= 2) d_chain_run_lazy<R, SKIP>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p);
-    else d_chain_run<R, SKIP>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p);
+    d_chain_any<R, SKIP, MODE>(keys, q_aoff[q], q_aoff[q + 1] - q_aoff[q], 0, o, f, p, skip_mw != 0);
+}
+// the long dense runs of a call, R waves each (beside k_chain, on a stream of its own): `list` = the range's over-size queries
+// (every run of o.mw_n > SEGSORT_CAP anchors is one of them), or every query when list == nullptr (tests with small thresholds)
+template <int R, bool SKIP>
+__global__ void __launch_bounds__(64 * R) k_chain_mw(const uint64_t *__restrict__ keys, const int32_t *__restrict__ q_aoff, int32_t nq, const int32_t *__restrict__ list,
+                                                     ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p)
+{
+    __shared__ uint4 ring[64 * R];
+    __shared__ int32_t done_s;
+    if ((int)blockIdx.x >= nq) return;
+    const int q = list ? list[blockIdx.x] : (int)blockIdx.x;
+    const int64_t base = q_aoff[q]; const int n = q_aoff[q + 1] - q_aoff[q];
+    if (!d_chain_is_mw(d_chain_dense(keys + base, n, o), n, o)) return;      // (the same test in every wave of the workgroup)
+    d_chain_run_mw<R, SKIP>(keys, base, n, 0, o, f, p, ring, &done_s);
 }
 // ISLANDS.  Anchors are sorted by (strand, reference position) and a link needs 0 < dr <= max_gap, so wherever two consecutive
 // anchors of a query lie more than max_gap apart (or on different strands: bit 31) no link crosses: the list falls into islands
@@ -1525,15 +1640,13 @@ __global__ void __launch_bounds__(256) k_isl_fill(const int32_t *__restrict__ q_
     for (int i = threadIdx.x; i < n; i += blockDim.x) if (head[base + i]) { const int id = rank[base + i]; isl_off[id] = (int32_t)base + i; isl_pd[id] = i; }
     if (q == 0 && threadIdx.x == 0) isl_off[rank[na]] = na;
 }
-template <int R, bool SKIP, bool LAZY = true>
+template <int R, bool SKIP, int MODE = 2>
 __global__ void __launch_bounds__(64) k_chain_isl(const uint64_t *__restrict__ keys, const int32_t *__restrict__ isl_off, const int32_t *__restrict__ isl_pd, const int32_t *__restrict__ nisl,
                                                   ChainOpt o, int32_t *__restrict__ f, int32_t *__restrict__ p)
 {
     const int n_isl = *nisl;
-    for (int s = blockIdx.x; s < n_isl; s += gridDim.x) {
-        if constexpr (LAZY && R >= 2) d_chain_run_lazy<R, SKIP>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p);
-        else d_chain_run<R, SKIP>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p);
-    }
+    for (int s = blockIdx.x; s < n_isl; s += gridDim.x)
+        d_chain_any<R, SKIP, MODE>(keys, isl_off[s], isl_off[s + 1] - isl_off[s], isl_pd[s], o, f, p, false);
 }
 
 // peaks: anchors with no successor of larger f

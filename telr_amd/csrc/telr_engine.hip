@@ -1849,13 +1849,25 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
     // long join: anchors are chained within max(bw, bw_long) diagonals
     ChainOpt co; co.max_gap = mo->max_gap; co.bw = mo->bw_long > mo->bw ? mo->bw_long : mo->bw; co.min_cnt = mo->min_cnt; co.min_chain_score = mo->min_chain_score;
     co.chain_gap_q8 = mo->chain_gap_q8; co.chain_skip_q8 = mo->chain_skip_q8;
+    // which loop: chosen per run of anchors (kernels.hip.h: WHICH LOOP); A/B: chain_push = the full push loop (every one of the H links scored)
+    // everywhere, chain_lazy = the lazy far look-back everywhere, chain_no_mw = no second kernel for the long dense runs.
+    // TELR_CHAIN_DENSE=n,span,mw_n moves the choices (tests, experiments).
+    static const bool chain_push = ab_on("chain_push"), chain_lazy = ab_on("chain_lazy"), chain_no_mw = ab_on("chain_no_mw");
+    static int dense_v[3] = {2048, 48, 1 << 19};
+    static const bool dense_env = [] { if (const char *e = getenv("TELR_CHAIN_DENSE")) sscanf(e, "%d%*[,:]%d%*[,:]%d", &dense_v[0], &dense_v[1], &dense_v[2]); return true; }();
+    (void)dense_env;
     const int Rr = mo->chain_lookback / 64;
-    static const bool chain_push = ab_on("chain_push");       // A/B: the full push loop (every one of the H links scored) instead of the lazy far look-back
-#define CHAIN_LAUNCH(RR, SK) do { if (chain_push) hipLaunchKernelGGL((k_chain<RR, SK, false>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder); \
-                                  else hipLaunchKernelGGL((k_chain<RR, SK, true>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder); } while (0)
-    const bool skip = co.chain_skip_q8 != 0;
+    const bool mw_all = dense_v[2] <= SEGSORT_CAP;            // (small thresholds: every query is looked at, not only the over-size list)
     static const bool no_islands = ab_on("no_islands");       // A/B: one wave per query whatever the call's shape
-    if (nq <= CHAIN_ISL_NQ && na > 0 && !no_islands) {
+    const bool islands = nq <= CHAIN_ISL_NQ && na > 0 && !no_islands;
+    const bool mw = !chain_push && !chain_lazy && !chain_no_mw && Rr >= 2 && na > 0 && !islands && dense_v[2] > 0 && (mw_all || n_over > 0);
+    co.dense_n = dense_v[0]; co.dense_span = dense_v[1]; co.mw_n = mw ? dense_v[2] : 0;
+#define CHAIN_LAUNCH(RR, SK) do { if (chain_push) hipLaunchKernelGGL((k_chain<RR, SK, 0>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder, 0); \
+                                  else if (chain_lazy) hipLaunchKernelGGL((k_chain<RR, SK, 1>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder, 0); \
+                                  else hipLaunchKernelGGL((k_chain<RR, SK, 2>), dim3(nq), dim3(64), 0, st, d_skeys, d_qaoff, nq, co, d_f, d_p, d_qorder, mw ? 1 : 0); } while (0)
+#define CHAIN_MW(RR, SK) hipLaunchKernelGGL((k_chain_mw<RR, SK>), dim3(mw_all ? nq : n_over), dim3(64 * RR), 0, ctx->side[0], d_skeys, d_qaoff, mw_all ? nq : n_over, mw_all ? (const int32_t*)nullptr : (const int32_t*)d_overlist, co, d_f, d_p)
+    const bool skip = co.chain_skip_q8 != 0;
+    if (islands) {
         // few queries: chain island by island (kernels.hip.h: ISLANDS) -- same f and p, thousands of waves instead of nq
         int32_t *d_head, *d_rank, *d_ioff, *d_ipd;
         TRY(ctx_buf_t(ctx, "isl_head", (size_t)na + 1, &d_head));
@@ -1868,17 +1880,30 @@ static int map_batch(telr_ctx *ctx, const telr_index *ix, const telr_seqset *qs,
         TRY((dev_exclusive_scan<int32_t, int32_t>(ctx, d_head, d_rank, (size_t)na + 1)));
         hipLaunchKernelGGL(k_isl_fill, dim3(nq), dim3(256), 0, st, d_qaoff, nq, d_head, d_rank, (int32_t)na, d_ioff, d_ipd);
         const unsigned grid = (unsigned)std::min<int64_t>((int64_t)na, 256 * 32);
-#define CHAIN_ISL(RR, SK) do { if (chain_push) hipLaunchKernelGGL((k_chain_isl<RR, SK, false>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); \
-                               else hipLaunchKernelGGL((k_chain_isl<RR, SK, true>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); } while (0)
+#define CHAIN_ISL(RR, SK) do { if (chain_push) hipLaunchKernelGGL((k_chain_isl<RR, SK, 0>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); \
+                               else if (chain_lazy) hipLaunchKernelGGL((k_chain_isl<RR, SK, 1>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); \
+                               else hipLaunchKernelGGL((k_chain_isl<RR, SK, 2>), dim3(grid), dim3(64), 0, st, d_skeys, d_ioff, d_ipd, d_rank + na, co, d_f, d_p); } while (0)
         if (Rr == 1) { if (skip) CHAIN_ISL(1, true); else CHAIN_ISL(1, false); }
         else if (Rr == 2) { if (skip) CHAIN_ISL(2, true); else CHAIN_ISL(2, false); }
         else { if (skip) CHAIN_ISL(4, true); else CHAIN_ISL(4, false); }
 #undef CHAIN_ISL
     }
-    else if (Rr == 1) { if (skip) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(1, false); }
-    else if (Rr == 2) { if (skip) CHAIN_LAUNCH(2, true); else CHAIN_LAUNCH(2, false); }
-    else { if (skip) CHAIN_LAUNCH(4, true); else CHAIN_LAUNCH(4, false); }
+    else {
+        if (mw) {
+            // the long dense runs beside the others: forked here, joined behind k_chain
+            HIPCHK(hipEventRecord(ctx->ev_side[0], st));
+            HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_side[0], 0));
+            if (Rr == 2) { if (skip) CHAIN_MW(2, true); else CHAIN_MW(2, false); }
+            else { if (skip) CHAIN_MW(4, true); else CHAIN_MW(4, false); }
+            HIPCHK(hipEventRecord(ctx->ev_side[0], ctx->side[0]));
+        }
+        if (Rr == 1) { if (skip) CHAIN_LAUNCH(1, true); else CHAIN_LAUNCH(1, false); }
+        else if (Rr == 2) { if (skip) CHAIN_LAUNCH(2, true); else CHAIN_LAUNCH(2, false); }
+        else { if (skip) CHAIN_LAUNCH(4, true); else CHAIN_LAUNCH(4, false); }
+        if (mw) HIPCHK(hipStreamWaitEvent(st, ctx->ev_side[0], 0));
+    }
 #undef CHAIN_LAUNCH
+#undef CHAIN_MW
     HIPCHK(hipGetLastError());
     t_ch.stop();
 

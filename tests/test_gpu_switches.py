@@ -21,6 +21,12 @@ SWITCHES = [
     {"TELR_AB": "over_routed"},             # round 6: only the over-size queries of a range take the two-step seeding (measured, not the default)
     {"TELR_AB": "scan_lib"},                # round 6: rocPRIM's device-wide scans instead of k_qscan_sums / k_qscan_write
     {"TELR_AB": "index_sort_lib"},          # round 6: rocPRIM's sorts in the index build instead of radix.hip.h (the cross-check SURVEY 7 step 5 asks for)
+    {"TELR_AB": "chain_lazy"},              # round 6: the lazy far look-back for every run of anchors (the default chooses per run: kernels.hip.h WHICH LOOP)
+    {"TELR_CHAIN_DENSE": "128,300"},        # ... and the choice moved so that small inputs see both outcomes (default: runs of >= 2,048 anchors, 64 within 48 bases)
+    {"TELR_CHAIN_DENSE": "128,1000000"},    # ... and every run of >= 128 anchors through the push loop
+    {"TELR_AB": "no_islands", "TELR_CHAIN_DENSE": "128,300,128"},      # round 6: R waves on a long dense run (k_chain_mw, kernels.hip.h: R WAVES ON ONE RUN; default: runs of >= 524,288 anchors)
+    {"TELR_AB": "no_islands", "TELR_CHAIN_DENSE": "128,1000000,1000"},
+    {"TELR_AB": "chain_no_mw"},
 ]
 
 
@@ -34,7 +40,7 @@ def test_switch_keeps_parity(env):
 
 def test_switch_keeps_parity_big_inputs():
     """the same on Mb-size genomes and 8-40-kb reads (wide classes, long fills) for the switches that touch the DP classes"""
-    for env in ({"TELR_AB": "tb8"}, {"TELR_AB": "no_tag8"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "dp_one_wave"}, {"TELR_AB": "index_sort_lib"}):
+    for env in ({"TELR_AB": "tb8"}, {"TELR_AB": "no_tag8"}, {"TELR_AB": "no_pkw"}, {"TELR_AB": "no_pkext"}, {"TELR_AB": "dp_one_wave"}, {"TELR_AB": "index_sort_lib"}, {"TELR_CHAIN_DENSE": "128,300", "FUZZ_HARD": "1"}, {"TELR_AB": "no_islands", "TELR_CHAIN_DENSE": "128,300,128", "FUZZ_HARD": "1"}, {"TELR_AB": "no_islands", "TELR_CHAIN_DENSE": "128,1000000,20481", "FUZZ_HARD": "1"}):
         e = dict(os.environ); e.update(env); e["FUZZ_BIG"] = "1"
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "3", "5"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
         assert p.returncode == 0 and "fuzz ok: 3 iterations" in p.stdout.decode(), (env, p.stdout.decode()[-3000:])

@@ -709,6 +709,12 @@ __device__ __forceinline__ int d_tid_of(const uint32_t *__restrict__ goff, int n
     return lo;
 }
 
+// first index in [lo, hi) of an occurrence list whose global position is >= g (a list is sorted by position: the index sort is stable)
+__device__ __forceinline__ uint32_t d_occ_lower(const uint32_t *__restrict__ pos, uint32_t lo, uint32_t hi, uint32_t g)
+{
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if ((pos[mid] >> 1) < g) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 // A query restricted to one target (qtarget >= 0) and the per-target mode stand for the reference's separate runs of the
 // aligner against every contig (TELR_te.py:68-78,119-132,504-506; TELR_assembly.py:199-212): a minimizer's occurrences are
 // counted inside the target and compared with THAT target's cut-off (tmid), so a TE k-mer shared by hundreds of contigs
@@ -769,7 +775,8 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
                 const int t = d_tid_of(A.I.goff, A.n_targets, SEED_POS(o) >> 1);
                 const uint32_t gend = A.I.goff[t + 1];
                 uint32_t e = o + 1;
-                while (e < o1 && (SEED_POS(e) >> 1) < gend) ++e;
+                // (a run is one to three occurrences as a rule; a satellite's thousands inside one contig are stepped over by bisection)
+                for (int lin = 0; e < o1 && (SEED_POS(e) >> 1) < gend; ) { ++e; if (++lin == 8) { e = d_occ_lower(A.I.pos, e, o1, gend); break; } }
                 if ((int32_t)(e - o) <= A.tmid[t]) {
                     total += (int32_t)(e - o);
                     if (MODE == 1) for (uint32_t z = o; z < e; ++z) { const uint32_t py = SEED_POS(z); d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32); }
@@ -780,9 +787,15 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
             break;
         }
         int32_t cnt = 0;
+        uint32_t a0 = o0, a1 = o1;           // the occurrences that count: all, or those inside the query's target
         if (o1 > o0) {
-            if (tf >= 0) { for (uint32_t o = o0; o < o1; ++o) { uint32_t gp = SEED_POS(o) >> 1; cnt += (gp >= g0 && gp < g1) ? 1 : 0; } }
-            else cnt = (int32_t)(o1 - o0);
+            if (tf >= 0) {
+                // Round 6: the target's piece of the list by bisection (the list is sorted by position).  A linear sweep met lists of
+                // 10^5-10^6 entries on the hard genome -- a satellite shared by the contigs of 150 loci, S6 -- once per query minimizer.
+                if (single) { const uint32_t gp = pos1 >> 1; if (gp < g0 || gp >= g1) a1 = a0; }
+                else { a0 = d_occ_lower(A.I.pos, o0, o1, g0); a1 = d_occ_lower(A.I.pos, a0, o1, g1); }
+            }
+            cnt = (int32_t)(a1 - a0);
             if (cnt > occ) cnt = 0;
         }
         cnt_out = cnt;
@@ -792,10 +805,9 @@ __device__ __forceinline__ void d_seed_query(const SeedArgs &A, const int q, con
             uint64_t kf = (uint64_t)qpos << 8 | (uint64_t)span;
             uint64_t kr = (1ULL << 63) | (uint64_t)(qlen - (qpos + 1 - span) - 1) << 8 | (uint64_t)span;
             int64_t w = wbase + A.mz_aoff[g];
-            for (uint32_t o = o0; o < o1; ++o) {
-                uint32_t py = SEED_POS(o), gp = py >> 1;
-                if (tf >= 0 && (gp < g0 || gp >= g1)) continue;
-                d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)gp << 32);
+            for (uint32_t o = a0; o < a1; ++o) {
+                const uint32_t py = SEED_POS(o);
+                d_put_key(A, w++, ((int)(py & 1) == qz ? kf : kr) | (uint64_t)(py >> 1) << 32);
             }
         }
       } while (0);

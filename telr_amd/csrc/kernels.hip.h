@@ -1538,7 +1538,7 @@ __device__ __forceinline__ void d_chain_run_mw(const uint64_t *__restrict__ keys
 {
     static_assert(R >= 2, "one wave is the push loop");
     constexpr int RING = 64 * R;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (the wave's number as a SCALAR: chunk bounds, loop control and ring offsets stay on the scalar side)
     const uint64_t *a = keys + base;
     const uint32_t max_gap = (uint32_t)o.max_gap, ddc = o.bw < o.max_gap ? (uint32_t)(o.max_gap - 1 - o.bw) : 0u;
     const uint32_t gap_q8 = (uint32_t)o.chain_gap_q8, skip_q8 = (uint32_t)o.chain_skip_q8;
@@ -1577,9 +1577,15 @@ __device__ __forceinline__ void d_chain_run_mw(const uint64_t *__restrict__ keys
         for (int jj = 0; jj < jn; ++jj) {
             const uint32_t gj1 = (uint32_t)__builtin_amdgcn_readlane((int)gi, jj) + 1u, qj1 = (uint32_t)__builtin_amdgcn_readlane((int)qi, jj) + 1u;
             const int32_t fj2p2 = (__builtin_amdgcn_readlane(B, jj) & ~1) + 2;
-            const bool me = lane == jj;
-            myB = me ? B : myB; myp = me ? bp : myp; myg = me ? gi : myg; myq = me ? qi : myq;
-            gi = me ? ng : gi; qi = me ? nqp : qi; sp1 = me ? nsp1 : sp1; B = me ? nB : B;
+            // lane jj hands over (eight moves of ONE lane under an execution mask of that lane, as in the lazy loop; the wave is whole here)
+            {
+                const uint64_t one = 1ULL << jj; uint64_t sv;
+                asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\t"
+                             "v_mov_b32 %[myB], %[B]\n\tv_mov_b32 %[myp], %[bp]\n\tv_mov_b32 %[myg], %[gi]\n\tv_mov_b32 %[myq], %[qi]\n\t"
+                             "v_mov_b32 %[gi], %[ng]\n\tv_mov_b32 %[qi], %[nqp]\n\tv_mov_b32 %[sp1], %[nsp1]\n\tv_mov_b32 %[B], %[nB]\n\ts_mov_b64 exec, %[sv]"
+                             : [myB] "+v"(myB), [myp] "+v"(myp), [myg] "+v"(myg), [myq] "+v"(myq), [gi] "+v"(gi), [qi] "+v"(qi), [sp1] "+v"(sp1), [B] "+v"(B), [sv] "=&s"(sv)
+                             : [bp] "v"(bp), [ng] "v"(ng), [nqp] "v"(nqp), [nsp1] "v"(nsp1), [nB] "v"(nB), [m] "s"(one));
+            }
             d_chain_push<SKIP>(gi, qi, sp1, gj1, qj1, fj2p2, j0 + jj, max_gap, ddc, gap_q8, skip_q8, B, bp);
             if ((jj & 7) == 7 || jj == jn - 1) {
                 if (lane >= (jj & ~7) && lane <= jj) ring[(j0 + lane) & (RING - 1)] = make_uint4(myg + 1u, myq + 1u, (uint32_t)((myB & ~1) + 2), 0u);

@@ -231,3 +231,30 @@ def test_alignment_called_again_writes_the_same_file(engine, data_dir, tmp_path)
         h = (hashlib.sha256(open(bam, "rb").read()).hexdigest(), hashlib.sha256(open(bam + ".bai", "rb").read()).hexdigest())
         assert seen.setdefault(method, h) == h, (i, method)
     assert len(seen) == 2 and seen["minimap2"] != seen["nglmr"]
+
+
+def test_shared_satellite_with_per_query_targets(engine):
+    """round 6: a satellite shared by MANY contigs (the hard genome's loci, `bench.py --config c2r`): a satellite k-mer's pooled
+    occurrence list runs to tens of thousands of entries, of which a query with its own target (S6, the polishing map) wants its
+    target's piece -- found by bisection (`d_occ_lower`), as are the per-target runs of more than eight occurrences in the pooled
+    per-target mode (S5).  Every stage against the oracle, per-query targets and MF_PER_TARGET; the reads chain lattices of
+    (copies in the read) x (copies in the contig) anchors: runs that take the push loop (kernels.hip.h: WHICH LOOP)."""
+    from telr_amd._abi import MF_PER_TARGET
+    rng = np.random.default_rng(20261004)
+    unit = synth.random_seq(rng, 23)
+    contigs = []
+    for c in range(12):
+        g = synth.random_seq(rng, 9000)
+        arr = synth.mutate(rng, np.tile(unit, 130)[:2800], 0.01 * (c % 3), 0.0, 0.0)[:2800]
+        p = 2500 + 150 * c
+        g[p:p + len(arr)] = arr
+        contigs.append(g)
+    reads, truth = synth.simulate_reads(rng, contigs, 36, 3500, err=(0.03, 0.015, 0.03))
+    qt = np.array([t[0] for t in truth], dtype=np.int32)
+    io, mo = preset("map-ont")
+    res, oref = compare_all(engine, contigs, reads, io, mo, qtarget=qt)
+    assert len(res.alns) >= len(reads) and int(np.diff(oref["anchor_off"]).max()) > 10000      # lattices, not chains
+    assert (res.alns["tid"] == qt[res.alns["qid"]]).all()
+    mo5 = mo.copy(); mo5.flags |= MF_PER_TARGET
+    res5, _ = compare_all(engine, contigs, reads, io, mo5)
+    assert len(res5.alns) >= len(res.alns)

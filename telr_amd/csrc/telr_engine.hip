@@ -2352,7 +2352,12 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
         // 0.4-0.5 Gbp).  TELR_PIPELINE=1 switches it off; =force pipelines any multi-range call (tests).
         int pipe = 2; bool force = false;
         if (const char *e = getenv("TELR_PIPELINE")) { force = !strcmp(e, "force"); pipe = force || atoi(e) >= 2 ? 2 : 1; }
+        // Round 6: a call with per-query targets (S6: every window read against the forward and the reverse-complement contig of its locus,
+        // 0.75-0.9 Gbp; the polishing map) runs its ranges one at a time: it shares the device with the other calls of the loci pass already,
+        // and on the hard genome its ranges are a few long chaining / sorting kernels on reads that bring 10^6 anchors each -- two in flight took
+        // 0.96 or 1.45 s per 1,000 c2r loci from pass to pass, one at a time 0.89; configs[2]: 96 -> 90 ms (profiles/r06_chain_loop_choice_ab.txt, part 8).
         if (ctx->pipe_nomem || (!force && (ctx->debug || nq < 4000))) pipe = 1;
+        const bool in_turn = pipe == 2 && qtarget && !force;          // one range, or the ranges of the plan below in turn (no more scratch per range than two in flight took)
         if (pipe == 2 && !fixed) {
             // ranges of at most 1.4 Gbp (two in flight: ~200 GB of scratch at configs[2]'s anchor density) and at most 1.6 G
             // anchors at the density seen by the last call on this index; a read set within one such range is not split
@@ -2377,7 +2382,28 @@ extern "C" int telr_map(telr_ctx *ctx, const telr_index *ix, const telr_seqset *
             ranges.push_back(std::make_pair(q0, q1));
             q0 = q1;
         }
-        if (pipe == 2 && ranges.size() >= 2) {
+        { static const bool tr = trace_on("host");
+          if (tr) fprintf(stderr, "[host plan] %d queries, %.1f Mbp, %zu range(s) of <= %.1f Mbp, %s, anchors per base seen %.3f%s\n", nq, total_bases / 1048576.0, ranges.size(), batch_bases / 1048576.0,
+                          pipe == 2 && ranges.size() >= 2 && !in_turn ? "two in flight" : "one at a time", ix->anchors_per_base, qtarget ? ", per-query targets" : ""); }
+        if (in_turn && ranges.size() >= 2) {
+            // ONE range when the device has room for it (what such a call waits for is its longest chaining run, once per range: two ranges
+            // in turn took 1.57 s per 1,000 c2r loci, one range 0.88), the ranges of the plan above in turn when it has not
+            int r = total_bases <= (1600LL << 20) ? map_range(ctx, ix, queries, qtarget, d_qt, 0, nq, mo, mid_occ, R) : TELR_E_NOMEM;
+            if (r == TELR_OK && getenv("TELR_TEST_PIPE_NOMEM")) r = TELR_E_NOMEM;      // tests: exercise the fall-back
+            if (r == TELR_E_NOMEM) {
+                (void)hipGetLastError();          // (the failed allocation's error is sticky for this thread)
+                mem_note(ctx, "telr_map: one range with per-query targets ran out");
+                (void)hipDeviceSynchronize();
+                result_wait(R); R->alns.clear(); R->ncig = 0; R->twin_n = 0;
+                { std::lock_guard<std::mutex> lk(R->gate_m); R->turn = 0; }
+                memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms)); memset(&ctx->ctr, 0, sizeof(ctx->ctr)); memset(ctx->dpcls, 0, sizeof(ctx->dpcls));
+                ctx->dp_retries = 0; ctx->pk_launches = 0; ctx->st_pending = 0; ctx->err.clear();
+                r = TELR_OK;
+                for (size_t i = 0; i < ranges.size() && r == TELR_OK; ++i) r = map_range(ctx, ix, queries, qtarget, d_qt, ranges[i].first, ranges[i].second, mo, mid_occ, R);
+            }
+            if (r != TELR_OK) { delete R; return r; }
+            if (ctx->ctr.anchors > 0 && ctx->ctr.query_bases > (64LL << 20)) ix->anchors_per_base = (double)ctx->ctr.anchors / (double)ctx->ctr.query_bases;
+        } else if (pipe == 2 && ranges.size() >= 2) {
             if (!ctx->slot1) {
                 int r = ctx_init(ctx->device, ctx->background, &ctx->slot1);
                 if (r != TELR_OK) { delete R; return r; }

@@ -432,6 +432,26 @@ def test_pipelined_ranges(engine):
     assert len(res.alns) >= 60 and (np.diff(res.alns["qid"]) >= 0).all()
 
 
+def test_per_query_target_call_runs_one_range_and_falls_back_to_ranges_in_turn(engine):
+    """round 6: a call with per-query targets (S6, the polishing map) that the range plan would cut runs as ONE range (what it waits
+    for is its longest chaining run, once per range), and as the plan's ranges in turn when the device has no room for that (forced
+    here after a successful attempt): the oracle's records either way.  4,200 short queries: the plan applies from 4,000 on."""
+    import os
+    rng = np.random.default_rng(4343)
+    genome = [synth.random_seq(rng, 60000), synth.random_seq(rng, 40000), synth.random_seq(rng, 30000)]
+    reads, truth = synth.simulate_reads(rng, genome, 4200, 400)
+    qt = np.array([t[0] for t in truth], np.int32)
+    io, mo = preset("map-ont")
+    os.environ["TELR_BATCH_KBP"] = "500"
+    try:
+        res, _ = compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
+        os.environ["TELR_TEST_PIPE_NOMEM"] = "1"
+        res2, _ = compare_all(engine, genome, reads, io, mo, qtarget=qt, stages=False)
+    finally:
+        del os.environ["TELR_BATCH_KBP"]; os.environ.pop("TELR_TEST_PIPE_NOMEM", None)
+    assert len(res.alns) >= 3000 and (np.diff(res.alns["qid"]) >= 0).all() and len(res2.alns) == len(res.alns)
+
+
 def test_cigars_kept_on_the_device_equal_the_host_array(engine):
     """TELR_MF_KEEP_CIGARS: the device copy of a result's CIGAR array (for telr_write_bam_dev) is the host array, word for word --
     one range, pipelined ranges with and without the long-read lanes (whose pieces are merged in on the host and uploaded),

@@ -995,17 +995,19 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                         for (int u = 0; u < 2; ++u) { c_off[u] = c0_off[u]; n2[u] = c0_n[u]; c_y[u] = c0_y[u]; c_sp[u] = c0_sp[u]; }
                     } else VOTE_LOAD_CHUNK(c_off, n2, c_y, c_sp, gc, g1)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { C.off[2 * lane + u] = c_off[u]; C.qpos[2 * lane + u] = c_y[u] >> 1; C.zs[2 * lane + u] = (uint16_t)((c_y[u] & 1u) << 8 | (c_sp[u] & 0xffu)); }
+                    for (int u = 0; u < 2; ++u) { C.qpos[2 * lane + u] = c_y[u] >> 1; C.zs[2 * lane + u] = (uint16_t)((c_y[u] & 1u) << 8 | (c_sp[u] & 0xffu)); }
                     uint32_t inc = n2[0] + n2[1];
                     inc = d_wave_scan_add(inc);          // (DPP row shifts + the two row broadcasts: no LDS round trips; six ds_bpermute before)
-                    C.P[2 * lane] = inc - n2[1]; C.P[2 * lane + 1] = inc;
                     // the minimizers that have hits, in order (rid), and where this lane's two lists start: a hit's list is then found
-                    // by counting list starts up to it -- bits of one 64-bit word per window -- instead of bisecting the prefix sums
+                    // by counting list starts up to it -- bits of one 64-bit word per window -- instead of bisecting the prefix sums.
+                    // Round 6: the list records are indexed by that RANK (P[r] = the hits up to and including list r, off[r] = its first
+                    // occurrence), so a hit reads its list's bounds, its occurrence offset and its minimizer side by side -- ONE level of LDS
+                    // reads in front of the occurrence load, where the minimizer's number stood between them (round 5's list, item 2)
                     const uint64_t nz0 = __ballot(n2[0] > 0), nz1 = __ballot(n2[1] > 0);
                     const uint64_t below = (1ULL << lane) - 1ULL;
                     const uint32_t rk0 = (uint32_t)__popcll(nz0 & below) + (uint32_t)__popcll(nz1 & below);
-                    if (n2[0]) C.rid[rk0] = (uint8_t)(2 * lane);
-                    if (n2[1]) C.rid[rk0 + (n2[0] ? 1u : 0u)] = (uint8_t)(2 * lane + 1);
+                    if (n2[0]) { C.rid[rk0] = (uint8_t)(2 * lane); C.P[rk0] = inc - n2[1]; C.off[rk0] = c_off[0]; }
+                    if (n2[1]) { const uint32_t rk1 = rk0 + (n2[0] ? 1u : 0u); C.rid[rk1] = (uint8_t)(2 * lane + 1); C.P[rk1] = inc; C.off[rk1] = c_off[1]; }
                     const uint32_t st0 = inc - n2[0] - n2[1], st1 = inc - n2[1];
                     uint32_t cb = 0;              // lists that start before the current window
                     __builtin_amdgcn_wave_barrier();
@@ -1031,10 +1033,10 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
                                 const uint64_t wmask = (uint64_t)C.wm[2 * u + 1] << 32 | C.wm[2 * u];
                                 const uint32_t upto = (uint32_t)__popcll(wmask & ((2ULL << lane) - 1ULL));
                                 if (in_[u]) {
-                                    const uint32_t m = C.rid[cb + upto - 1u];
-                                    const uint32_t pm = m ? C.P[m - 1] : 0u, nm = C.P[m] - pm;
-                                    m_[u] = m;
-                                    py_[u] = nm == 1 ? C.off[m] : A.I.pos[C.off[m] + (h - pm)];
+                                    const uint32_t r = cb + upto - 1u;
+                                    const uint32_t pm = r ? C.P[r - 1] : 0u, nm = C.P[r] - pm, of = C.off[r];
+                                    m_[u] = C.rid[r];
+                                    py_[u] = nm == 1 ? of : A.I.pos[of + (h - pm)];
                                 }
                                 cb += (uint32_t)__popcll(wmask);
                             }

@@ -937,7 +937,7 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
     const int q = A.q_order ? A.q_order[blockIdx.x] : blockIdx.x;
     const int m0 = A.q_mzoff[q], m1 = A.q_mzoff[q + 1];
     const int qlen = A.qlen[q];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar: the sub-read loop, its chunk bounds and the wave's LDS bases stay on the scalar side)
     uint32_t *T = tab[wv];
     VoteHit *HS = stash[wv];
     VoteChunk &C = chunk[wv];
@@ -968,14 +968,14 @@ __global__ void __launch_bounds__(64 * VOTE_WAVES) k_seed_vote(SeedArgs A, VoteO
             if (g < (g1_)) { o_[u] = (uint32_t)A.mz_ent[g]; n_[u] = (uint32_t)A.mz_n[g]; y_[u] = A.mz_y[g]; sp_[u] = ((const uint32_t*)A.mz_x)[2 * (size_t)g]; } } }
 #define VOTE_PIN(o_, n_, y_, sp_) { _Pragma("unroll") for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(o_[u]), "+v"(n_[u]), "+v"(y_[u]), "+v"(sp_[u])); }
         for (int s = sb + wv; s < send; s += VOTE_WAVES) {
-            const int g0 = sub_first[s - sb], g1 = sub_first[s - sb + 1];
+            const int g0 = __builtin_amdgcn_readfirstlane(sub_first[s - sb]), g1 = __builtin_amdgcn_readfirstlane(sub_first[s - sb + 1]);
             uint32_t c0_off[2], c0_n[2], c0_y[2], c0_sp[2];
             if (pf_s == s) {
                 VOTE_PIN(pf_off, pf_n, pf_y, pf_sp)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { c0_off[u] = pf_off[u]; c0_n[u] = pf_n[u]; c0_y[u] = pf_y[u]; c0_sp[u] = pf_sp[u]; }
             } else VOTE_LOAD_CHUNK(c0_off, c0_n, c0_y, c0_sp, g0, g1)
-            if (s + VOTE_WAVES < send) { pf_s = s + VOTE_WAVES; VOTE_LOAD_CHUNK(pf_off, pf_n, pf_y, pf_sp, sub_first[pf_s - sb], sub_first[pf_s - sb + 1]) }
+            if (s + VOTE_WAVES < send) { pf_s = s + VOTE_WAVES; const int pg0 = __builtin_amdgcn_readfirstlane(sub_first[pf_s - sb]), pg1 = __builtin_amdgcn_readfirstlane(sub_first[pf_s - sb + 1]); VOTE_LOAD_CHUNK(pf_off, pf_n, pf_y, pf_sp, pg0, pg1) }
             if (g0 >= g1) continue;
             // ---- votes (all chunks of the sub-read), hits remembered
             uint32_t vmax = 0, nhit = 0;

@@ -131,6 +131,47 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
     each 200-base window; closer to what wtpoa-cns does, still not its code).
     timings: a dict that receives the wall-clock seconds of the pass's phases (read set, index, map, consensus).
     -> list of polished contig sequences (a contig no read maps to stays as it is)."""
+    if method not in ("pileup", "poa"):
+        raise ValueError("method must be 'pileup' or 'poa'")
+    counts_all = np.fromiter((len(rs) for rs in reads_by_locus), np.int64, len(reads_by_locus))
+    # Round 6: on the engine the loci are polished as TWO halves at a time, the second one on the engine's second context in a host thread of its
+    # own (per-locus results do not depend on what else is in the call: per-query targets, windows per contig): the host work of a half -- packing,
+    # the range plan, the pieces of the window consensus from the CIGARs, grouping, uploads, Python -- runs under the other half's kernels
+    # (configs[2], window consensus: 164-184 -> see DESIGN section 6).  TELR_POLISH_HALVES=1 keeps one call (A/B; tests hold both to the same strings).
+    two = hasattr(engine, "worker") and len(reads_by_locus) >= 64 and int(counts_all.sum()) > 0 and os.environ.get("TELR_POLISH_HALVES", "2") != "1"
+    if two:
+        fr, tot = engine.mem_info()
+        two = fr >= 0.3 * tot and not getattr(engine.worker(), "crowded", False)
+    if two:
+        import threading
+        cum = np.cumsum(counts_all)
+        cut = int(np.searchsorted(cum, cum[-1] // 2)) + 1
+        cut = min(max(cut, 1), len(reads_by_locus) - 1)
+        out = [None, None]; err = [None]
+        t_b = {} if timings is not None else None
+        def second():
+            try:
+                out[1] = _polish_part(engine.worker(), contig_seqs[cut:], reads_by_locus[cut:], presets, iterations, min_depth, read_set, method, t_b)
+            except Exception as e:            # no room beside the first half (or any other failure of the second context): that half in turn, below
+                err[0] = e
+        th = threading.Thread(target=second); th.start()
+        try:
+            out[0] = _polish_part(engine, contig_seqs[:cut], reads_by_locus[:cut], presets, iterations, min_depth, read_set, method, timings)
+        finally:
+            th.join()
+        if err[0] is not None:
+            if "out of device memory" not in str(err[0]) and "out of memory" not in str(err[0]):
+                raise err[0]
+            engine.worker().release_scratch()
+            out[1] = _polish_part(engine, contig_seqs[cut:], reads_by_locus[cut:], presets, iterations, min_depth, read_set, method, timings)
+        elif timings is not None:
+            timings["second_half_s"] = sum(t_b.values())
+        return out[0] + out[1]
+    return _polish_part(engine, contig_seqs, reads_by_locus, presets, iterations, min_depth, read_set, method, timings)
+
+
+def _polish_part(engine, contig_seqs, reads_by_locus, presets, iterations, min_depth, read_set, method, timings):
+    """polish_consensus for the loci given, one engine call per iteration on `engine`"""
     import time
     def _t(key, t0):
         if timings is not None:
@@ -152,7 +193,7 @@ def polish_consensus(engine, contig_names, contig_seqs, reads_by_locus, presets=
     qt = np.repeat(np.arange(len(reads_by_locus), dtype=np.int32), counts)           # the locus of every read, in locus order
     if read_set is not None:                                                         # read indices: no Python loop over 40 k reads
         flat = np.concatenate([np.asarray(rs, np.int32).reshape(-1) for rs in reads_by_locus])
-        qset = read_set.subset(flat)
+        qset = read_set.subset(flat, eng=engine) if hasattr(read_set, "eng") else read_set.subset(flat)      # (the gather on THIS context's stream: contexts are not re-entrant)
     else:
         qset = engine.seqset([r for rs in reads_by_locus for r in rs])
     t0 = _t("read_set_s", t0)

@@ -232,3 +232,23 @@ def test_hip_poa_equals_oracle_where_reads_and_draft_carry_n_in_the_same_columns
             assert got == want, [(i, len(got[i]), len(want[i])) for i in range(len(got)) if got[i] != want[i]]
     finally:
         ix.free_raw(r); ix.free(); qset.free()
+
+
+@pytest.mark.parametrize("method", ["pileup", "poa"])
+def test_polish_in_two_halves_equals_one_call(engine, method, monkeypatch):
+    """round 6: from 64 loci on `polish_consensus` runs the loci as two halves at a time, the second on the engine's second context in a host
+    thread (the host work of one half under the other's kernels): per-locus results do not depend on what else is in the call, so the strings
+    equal those of ONE call (TELR_POLISH_HALVES=1), two iterations included; a locus without reads and one with N / lower-case draft bases in both halves"""
+    truths, drafts, reads = _loci(11, n_loci=72, depth=12)
+    reads[40] = []; d = np.frombuffer(drafts[50].encode(), np.uint8).copy(); d[200:230] |= 32; d[700:702] = ord("N"); drafts[50] = bytes(d).decode()
+    names = ["c%d" % i for i in range(len(drafts))]
+    monkeypatch.setenv("TELR_POLISH_HALVES", "1")
+    one = telr_assembly.polish_consensus(engine, names, drafts, reads, presets="ont", iterations=2, method=method)
+    monkeypatch.delenv("TELR_POLISH_HALVES")
+    t = {}
+    two = telr_assembly.polish_consensus(engine, names, drafts, reads, presets="ont", iterations=2, method=method, timings=t)
+    assert "second_half_s" in t                      # the two-halves path ran
+    assert len(one) == len(two) == 72
+    for k in range(72):
+        assert one[k] == two[k], "locus %d" % k
+    assert sum(a != b for a, b in zip(one, drafts)) >= 60        # and polishing did something
